@@ -1,0 +1,283 @@
+"""ctypes binding of include/sph_ffi.h.
+
+The product library is ``adaptive_sph_amd/csrc/libsph_hip.so`` (symbol prefix ``sph_``).  The binding
+is prefix-parametrised only so that the test-suite can drive the CPU oracle (``oracle_`` prefix,
+same signatures) through the identical harness; nothing in this package loads anything under
+``oracle/`` -- `load_product()` fails loudly when the HIP library is missing.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+import numpy as np
+
+PKG_DIR = Path(__file__).resolve().parent
+PRODUCT_LIB = PKG_DIR / "csrc" / "libsph_hip.so"
+
+# ---- enums (include/sph_ffi.h; names follow simulation_parameters.rs) ---------------------------
+VISCOSITY_TYPE = {"WCSPH": 0, "ApproxLaplace": 1, "XSPH": 2}
+LEVEL_ESTIMATION_METHOD = {"None": 0, "CenterDiff": 1, "EmptyAngle": 2}
+SUPPORT_LENGTH_ESTIMATION = {
+    "FromDistribution": 0, "FromDistributionClamped1": 1, "FromDistributionClamped2": 2,
+    "FromDistribution2": 3, "FromMass": 4,
+}
+PRESSURE_SOLVER_METHOD = {"IISPH": 0, "IISPH2": 1, "HybridDFSPH": 2, "OnlyDivergence": 3}
+HYBRID_DFSPH_DENSITY_SOURCE_TERM = {"DensityAndDivergence": 0, "OnlyDensity": 1}
+BOUNDARY_PENALTY_TERM = {"None": 0, "Linear": 1, "Quadratic1": 2, "Quadratic2": 3}
+OPERATOR_DISCRETIZATION = {"ConsistentSimpleGradient": 0, "ConsistentSymmetricGradient": 1, "Winchenbach2020": 2}
+FILL_STASH_WITH = {None: 0, "SurfaceDistanceFirstIteration": 1, "SurfaceDistanceMiddle": 2}
+SIZING_FUNCTION = {"Radius2": 0, "Radius": 1, "Mass": 2}
+
+# field id -> (numpy dtype, components)
+FIELDS = {
+    "mass": (0, np.float32, 1), "position": (1, np.float32, 2), "velocity": (2, np.float32, 2),
+    "pressure_accel": (3, np.float32, 2), "density": (4, np.float32, 1), "ppe_source_term": (5, np.float32, 1),
+    "pressure": (6, np.float32, 1), "aii": (7, np.float32, 1), "density_error": (8, np.float32, 1),
+    "h2": (9, np.float32, 1), "h2_next": (10, np.float32, 1), "constant_field": (11, np.float32, 1),
+    "neighbor_count": (12, np.uint32, 1), "level_estimation": (13, np.float32, 1), "level_old": (14, np.float32, 1),
+    "stash": (15, np.float32, 1), "flag_is_fluid_surface": (16, np.uint8, 1),
+    "flag_insufficient_neighs": (17, np.uint8, 1), "particle_size_class": (18, np.uint8, 1),
+    "lambda_sum": (19, np.float32, 1), "lambda_grad_sum": (20, np.float32, 2), "cell_index": (21, np.uint32, 1),
+}
+
+STATUS_NAMES = {
+    0: "SPH_OK", 1: "SPH_ERR_INVALID_ARGUMENT", 2: "SPH_ERR_DEVICE", 3: "SPH_ERR_CAPACITY", 4: "SPH_ERR_NO_BOUNDARY",
+    10: "SPH_ERR_DENSITY_NOT_FINITE", 11: "SPH_ERR_DENSITY_TOO_SMALL", 12: "SPH_ERR_AII_NOT_FINITE",
+    13: "SPH_ERR_AII_NEGATIVE", 14: "SPH_ERR_AP_NOT_FINITE", 15: "SPH_ERR_PRESSURE_NOT_FINITE",
+    16: "SPH_ERR_TOO_MANY_NEIGHBORS", 17: "SPH_ERR_VELOCITY_NOT_FINITE", 18: "SPH_ERR_POSITION_NOT_FINITE",
+    19: "SPH_ERR_VISCOSITY_NOT_FINITE", 20: "SPH_ERR_XSPH_TODO", 21: "SPH_ERR_CHECK_NEIGHBORHOOD",
+    22: "SPH_ERR_CHECK_AII", 23: "SPH_ERR_LEVEL_WEIGHT", 30: "SPH_ERR_UNSUPPORTED",
+}
+
+
+class SphParams(C.Structure):
+    _fields_ = [
+        ("rest_density", C.c_float), ("cfl_factor", C.c_float), ("max_dt", C.c_float), ("viscosity", C.c_float),
+        ("viscosity_type", C.c_int32), ("gravity", C.c_float), ("jacobi_omega", C.c_float),
+        ("level_estimation_method", C.c_int32), ("maximum_range", C.c_float),
+        ("support_length_estimation", C.c_int32), ("sdf_gradient_eps", C.c_float),
+        ("has_pull_fluid_to", C.c_int32), ("pull_fluid_to", C.c_float * 3),
+        ("maximum_surface_distance", C.c_float), ("boundary_is_fluid_surface", C.c_int32),
+        ("use_extended_range_for_level_estimation", C.c_int32), ("level_estimation_after_advection", C.c_int32),
+        ("level_estimation_range", C.c_float), ("pressure_solver_method", C.c_int32),
+        ("iisph_max_avg_density_error", C.c_float), ("hybrid_dfsph_factor", C.c_float),
+        ("hybrid_dfsph_max_avg_density_error", C.c_float), ("hybrid_dfsph_max_avg_divergence_error", C.c_float),
+        ("hybrid_dfsph_density_source_term", C.c_int32),
+        ("hybrid_dfsph_non_pressure_accel_before_divergence_free", C.c_int32),
+        ("boundary_penalty_term", C.c_int32), ("operator_discretization", C.c_int32), ("max_iters", C.c_uint32),
+        ("check_neighborhood", C.c_int32), ("check_aii", C.c_int32), ("constrain_neighborhood_count", C.c_int32),
+        ("fill_stash_with", C.c_int32), ("sizing_function", C.c_int32), ("particle_radius_fine", C.c_float),
+        ("particle_radius_base", C.c_float),
+    ]
+
+
+class SphPlane(C.Structure):
+    _fields_ = [("dir_x", C.c_float), ("dir_y", C.c_float), ("delta", C.c_float)]
+
+
+class SphSolverStats(C.Structure):
+    _fields_ = [
+        ("iters", C.c_uint32), ("converged", C.c_int32), ("normal_count", C.c_uint32), ("singular_count", C.c_uint32),
+        ("negative_count", C.c_uint32), ("avg_error", C.c_float), ("max_error", C.c_float),
+    ]
+
+
+class SphStepStats(C.Structure):
+    _fields_ = [
+        ("dt", C.c_float), ("time", C.c_float), ("step_number", C.c_uint64), ("n_particles", C.c_uint64),
+        ("div_solver", SphSolverStats), ("density_solver", SphSolverStats),
+        ("ms_simulation_step", C.c_double), ("ms_neighborhood", C.c_double), ("ms_level_estimation", C.c_double),
+        ("ms_div_solver", C.c_double), ("ms_density_solver", C.c_double),
+    ]
+
+
+class SphGridInfo(C.Structure):
+    _fields_ = [("cell_size", C.c_float), ("cells_min_x", C.c_int32), ("cells_min_y", C.c_int32),
+                ("size_x", C.c_int32), ("size_y", C.c_int32)]
+
+
+class SphKernelTime(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("launches", C.c_uint64), ("total_ms", C.c_double)]
+
+
+class SphError(RuntimeError):
+    """Non-zero status from the library == a panic!/assert! of the reference step."""
+
+    def __init__(self, status: int, message: str):
+        self.status = status
+        super().__init__(f"{STATUS_NAMES.get(status, status)}: {message}")
+
+
+# every symbol include/sph_ffi.h declares (checked by tests/test_abi.py)
+ABI_SYMBOLS = [
+    "create", "destroy", "upload", "upload_field", "download", "download_neighbors", "num_particles", "time",
+    "set_time", "step", "last_error", "grid", "profile_enable", "profile_reset", "profile_get",
+    "comm_unique_id", "comm_init",
+]
+
+
+class SphLibrary:
+    """A loaded implementation of include/sph_ffi.h."""
+
+    def __init__(self, path: os.PathLike, prefix: str = "sph_"):
+        path = Path(path)
+        if not path.exists():
+            raise FileNotFoundError(
+                f"{path} is missing: the HIP library must be built first "
+                f"(python -c 'import __graft_entry__ as g; g.build()' or adaptive_sph_amd.build.build_hip())")
+        self.path = path
+        self.prefix = prefix
+        self.lib = C.CDLL(str(path), mode=C.RTLD_GLOBAL if prefix == "sph_" else C.RTLD_LOCAL)
+        L, P = self.lib, prefix
+        vp, u64, i32 = C.c_void_p, C.c_uint64, C.c_int
+
+        def sig(name, res, args, required=True):
+            try:
+                fn = getattr(L, P + name)
+            except AttributeError:
+                if required:
+                    raise
+                return None
+            fn.restype, fn.argtypes = res, args
+            return fn
+
+        self.create = sig("create", i32, [u64, i32, C.POINTER(SphPlane), i32, C.POINTER(vp)])
+        self.destroy = sig("destroy", None, [vp])
+        self.upload = sig("upload", i32, [vp, u64, vp, vp, vp])
+        self.upload_field = sig("upload_field", i32, [vp, i32, vp, u64])
+        self.download = sig("download", i32, [vp, i32, vp, u64])
+        self.download_neighbors = sig("download_neighbors", i32, [vp, vp, vp, u64, C.POINTER(u64)])
+        self.num_particles = sig("num_particles", u64, [vp])
+        self.time = sig("time", C.c_float, [vp])
+        self.set_time = sig("set_time", i32, [vp, C.c_float, u64])
+        self.step = sig("step", i32, [vp, C.POINTER(SphParams), C.POINTER(SphStepStats)])
+        self.last_error = sig("last_error", C.c_char_p, [vp])
+        self.grid = sig("grid", i32, [vp, C.POINTER(SphGridInfo)])
+        # product-only entry points (the oracle has no device, profiler or communicator)
+        self.profile_enable = sig("profile_enable", i32, [vp, i32], required=False)
+        self.profile_reset = sig("profile_reset", i32, [vp], required=False)
+        self.profile_get = sig("profile_get", i32, [vp, C.POINTER(SphKernelTime), i32, C.POINTER(i32)], required=False)
+        self.comm_unique_id = sig("comm_unique_id", i32, [C.POINTER(C.c_uint8)], required=False)
+        self.comm_init = sig("comm_init", i32, [vp, C.POINTER(C.c_uint8), i32, i32], required=False)
+
+
+_PRODUCT = None
+
+
+def load_product() -> SphLibrary:
+    """The HIP library.  No fallback: a missing/unbuildable extension is an error."""
+    global _PRODUCT
+    if _PRODUCT is None:
+        _PRODUCT = SphLibrary(PRODUCT_LIB, "sph_")
+    return _PRODUCT
+
+
+def _as_f32(a, shape=None) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if shape is not None:
+        a = a.reshape(shape)
+    return a
+
+
+class Context:
+    """One simulation context (``FluidSimulation`` state container on the library side)."""
+
+    def __init__(self, lib: SphLibrary, n_capacity: int, planes, device_id: int = 0):
+        self.lib = lib
+        planes = list(planes)
+        arr = (SphPlane * max(1, len(planes)))()
+        for k, (dx, dy, delta) in enumerate(planes):
+            arr[k] = SphPlane(dx, dy, delta)
+        h = C.c_void_p()
+        rc = lib.create(int(n_capacity), int(device_id), arr, len(planes), C.byref(h))
+        if rc != 0:
+            raise SphError(rc, "create failed")
+        self.handle = h
+        self.capacity = int(n_capacity)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int):
+        if rc != 0:
+            msg = self.lib.last_error(self.handle)
+            raise SphError(rc, msg.decode(errors="replace") if msg else "")
+
+    @property
+    def n(self) -> int:
+        return int(self.lib.num_particles(self.handle))
+
+    @property
+    def time(self) -> float:
+        return float(self.lib.time(self.handle))
+
+    def set_time(self, t: float, step_number: int = 0):
+        self._check(self.lib.set_time(self.handle, float(t), int(step_number)))
+
+    def upload(self, mass, position, velocity):
+        mass = _as_f32(mass)
+        n = mass.shape[0]
+        position = _as_f32(position, (n, 2))
+        velocity = _as_f32(velocity, (n, 2))
+        self._check(self.lib.upload(self.handle, n, mass.ctypes.data, position.ctypes.data, velocity.ctypes.data))
+
+    def upload_field(self, name: str, values):
+        fid, dt, w = FIELDS[name]
+        a = np.ascontiguousarray(values, dtype=dt)
+        self._check(self.lib.upload_field(self.handle, fid, a.ctypes.data, a.nbytes))
+
+    def download(self, name: str) -> np.ndarray:
+        fid, dt, w = FIELDS[name]
+        n = self.n
+        out = np.empty((n, w) if w > 1 else (n,), dtype=dt)
+        self._check(self.lib.download(self.handle, fid, out.ctypes.data, out.nbytes))
+        return out
+
+    def download_neighbors(self):
+        """CSR (offsets[n+1], indices) of the current neighbour lists, host particle order."""
+        n = self.n
+        total = C.c_uint64(0)
+        offsets = np.empty(n + 1, dtype=np.uint32)
+        self._check(self.lib.download_neighbors(self.handle, offsets.ctypes.data, None, 0, C.byref(total)))
+        indices = np.empty(int(total.value), dtype=np.uint32)
+        self._check(self.lib.download_neighbors(self.handle, offsets.ctypes.data, indices.ctypes.data,
+                                                indices.size, C.byref(total)))
+        return offsets, indices
+
+    def step(self, params: SphParams) -> SphStepStats:
+        st = SphStepStats()
+        self._check(self.lib.step(self.handle, C.byref(params), C.byref(st)))
+        return st
+
+    def grid(self) -> SphGridInfo:
+        g = SphGridInfo()
+        self._check(self.lib.grid(self.handle, C.byref(g)))
+        return g
+
+    # ---- measurement hooks (product only) ----
+    def profile_enable(self, on: bool = True):
+        self._check(self.lib.profile_enable(self.handle, 1 if on else 0))
+
+    def profile_reset(self):
+        self._check(self.lib.profile_reset(self.handle))
+
+    def profile_get(self) -> dict:
+        cap = 64
+        arr = (SphKernelTime * cap)()
+        n = C.c_int(0)
+        self._check(self.lib.profile_get(self.handle, arr, cap, C.byref(n)))
+        return {arr[i].name.decode(): (int(arr[i].launches), float(arr[i].total_ms)) for i in range(n.value)}
+
+    def comm_init(self, unique_id: bytes, rank: int, n_ranks: int):
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        self._check(self.lib.comm_init(self.handle, buf, int(rank), int(n_ranks)))

@@ -1,0 +1,145 @@
+"""Host-side mirror of the scene format and initialiser.
+
+Reference: ``SceneConfig`` / ``SceneBoundary`` / ``SceneFluidBlock`` (src/simulation/simulation.rs:3052-3072),
+``add_fluid_block`` (:2915-2983), ``init_fluid_sim`` (:3074-3231), ``SdfPlane::new_boundary_box``
+(src/simulation/sdf/sdf_plane.rs:13-20).
+
+All arithmetic is float32 exactly as in the reference: ``floor(size / spacing)`` particles per axis,
+positions ``idx * spacing + min`` (x outer loop, y inner loop), mass ``spacing^2 * volume_fill_ratio * 1``.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import List, Sequence, Tuple
+
+import numpy as np
+import yaml
+
+f32 = np.float32
+
+
+@dataclass
+class SceneBoundary:
+    type: str
+    width: float
+    height: float
+
+
+@dataclass
+class SceneFluidBlock:
+    pos: Sequence[float]
+    size: Sequence[float]
+    spacing: float
+    volume_fill_ratio: float
+    velocity: Sequence[float]
+
+
+@dataclass
+class SceneConfig:
+    boundary: SceneBoundary
+    blocks: List[SceneFluidBlock] = field(default_factory=list)
+
+    @classmethod
+    def from_mapping(cls, m) -> "SceneConfig":
+        b = m["boundary"]
+        return cls(SceneBoundary(str(b["type"]), float(b["width"]), float(b["height"])),
+                   [SceneFluidBlock(list(x["pos"]), list(x["size"]), float(x["spacing"]),
+                                    float(x["volume_fill_ratio"]), list(x["velocity"])) for x in m["blocks"]])
+
+    @classmethod
+    def from_yaml(cls, text_or_path) -> "SceneConfig":
+        s = str(text_or_path)
+        if "\n" not in s and (s.endswith(".yaml") or s.endswith(".yml")):
+            with open(s, "r") as fh:
+                s = fh.read()
+        return cls.from_mapping(yaml.safe_load(s))
+
+
+def block_dims(block: SceneFluidBlock) -> Tuple[int, int]:
+    """num_particles_x / _y of add_fluid_block (simulation.rs:2968-2971), float32 floor."""
+    min_x, min_y = f32(block.pos[0]), f32(block.pos[1])
+    max_x, max_y = min_x + f32(block.size[0]), min_y + f32(block.size[1])  # init_fluid_sim :3090-3091
+    s = f32(block.spacing)
+    nx = int(np.floor((max_x - min_x) / s))
+    ny = int(np.floor((max_y - min_y) / s))
+    return max(nx, 0), max(ny, 0)
+
+
+def add_fluid_block(block: SceneFluidBlock):
+    """-> (position[n,2], mass[n], velocity[n,2]) float32, particle order x-outer / y-inner."""
+    nx, ny = block_dims(block)
+    s = f32(block.spacing)
+    min_x, min_y = f32(block.pos[0]), f32(block.pos[1])
+    xs = np.arange(nx, dtype=np.float32) * s + min_x
+    ys = np.arange(ny, dtype=np.float32) * s + min_y
+    pos = np.empty((nx, ny, 2), dtype=np.float32)
+    pos[:, :, 0] = xs[:, None]
+    pos[:, :, 1] = ys[None, :]
+    particle_volume = s * s * f32(block.volume_fill_ratio)
+    particle_mass = particle_volume * f32(1.0)  # INIT_REST_DENSITY (simulation.rs:344)
+    n = nx * ny
+    mass = np.full(n, particle_mass, dtype=np.float32)
+    vel = np.empty((n, 2), dtype=np.float32)
+    vel[:, 0] = f32(block.velocity[0])
+    vel[:, 1] = f32(block.velocity[1])
+    return pos.reshape(n, 2), mass, vel
+
+
+def boundary_planes(boundary: SceneBoundary, init_boundary_handler: str = "AnalyticOverestimate"):
+    """Planes (dir_x, dir_y, delta) of the boundary handler built by init_fluid_sim (:3137-3213)."""
+    if init_boundary_handler == "NoBoundary":
+        return []
+    if init_boundary_handler != "AnalyticOverestimate":
+        # AnalyticUnderestimate = Sdf2D polygon, Particles = Akinci particles: SURVEY.md section 8f "next"
+        raise NotImplementedError(f"init_boundary_handler={init_boundary_handler} is outside the covered path "
+                                  f"(only the SdfPlane box of AnalyticOverestimate is)")
+    if boundary.type != "box":
+        raise NotImplementedError(f"boundary type {boundary.type!r}")
+    w, h = f32(boundary.width), f32(boundary.height)
+    min_x, min_y = f32(0.0) - w / f32(2.0), f32(0.0) - h / f32(2.0)
+    max_x, max_y = f32(0.0) + w / f32(2.0), f32(0.0) + h / f32(2.0)
+    return [(1.0, 0.0, float(-min_x)), (-1.0, 0.0, float(max_x)), (0.0, 1.0, float(-min_y)), (0.0, -1.0, float(max_y))]
+
+
+def init_particles(scene: SceneConfig):
+    """Concatenated blocks in scene order (init_fluid_sim :3088-3099)."""
+    ps, ms, vs = [], [], []
+    for b in scene.blocks:
+        p, m, v = add_fluid_block(b)
+        ps.append(p)
+        ms.append(m)
+        vs.append(v)
+    if not ps:
+        return (np.zeros((0, 2), np.float32), np.zeros(0, np.float32), np.zeros((0, 2), np.float32))
+    return np.concatenate(ps), np.concatenate(ms), np.concatenate(vs)
+
+
+# ---- the BASELINE.json workloads as SceneConfig ---------------------------
+
+def dam_break_1m() -> SceneConfig:
+    """configs[1]: 1024 x 1024 = 1 048 576 uniform particles, box 4 x 2."""
+    return SceneConfig(SceneBoundary("box", 4.0, 2.0),
+                       [SceneFluidBlock([-1.999, -0.999], [1.0005, 1.0005], 0.0009765625, 0.93, [0.0, 0.0])])
+
+
+def dam_break_1m_adaptive() -> SceneConfig:
+    """configs[2]: 942 080 fine + 58 880 coarse particles, radius ratio 4:1."""
+    return SceneConfig(SceneBoundary("box", 4.0, 2.0),
+                       [SceneFluidBlock([-1.999, -0.999], [1.0005, 0.8989], 0.0009765625, 0.93, [0.0, 0.0]),
+                        SceneFluidBlock([1.0, -0.996], [0.9, 1.0005], 0.00390625, 0.93, [0.0, 0.0])])
+
+
+def dam_break_8m() -> SceneConfig:
+    """configs[3]: 2896 x 2896 = 8 386 816 particles."""
+    return SceneConfig(SceneBoundary("box", 4.0, 2.0),
+                       [SceneFluidBlock([-1.9995, -0.9995], [1.4143, 1.4143], 0.00048828125, 0.93, [0.0, 0.0])])
+
+
+def dam_break_small(nx: int = 64, ny: int = 64, spacing: float = 1.0 / 64.0) -> SceneConfig:
+    """A small dam break with the proportions of configs[1] (column one spacing off the left/bottom wall),
+    for parity tests."""
+    off = spacing * 1.024   # configs[1]: 0.001 / (1/1024)
+    eps = spacing * 0.5
+    return SceneConfig(SceneBoundary("box", 4.0, 2.0),
+                       [SceneFluidBlock([-2.0 + off, -1.0 + off], [nx * spacing + eps, ny * spacing + eps], spacing, 0.93,
+                                        [0.0, 0.0])])

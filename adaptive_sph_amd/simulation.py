@@ -1,0 +1,167 @@
+"""Host-side mirror of the reference's simulation API for the hot path.
+
+Reference (src/simulation/simulation.rs):
+  ``FluidSimulation``                       :471-533   (particles, neighs, boundary_handler, time)
+  ``init_fluid_sim`` / ``init_simulation_params``   :3074-3256
+  ``single_step_without_adaptivity``        :1980-2730  -> dt     <== the call that crosses the C ABI
+  ``single_step``                           :1973-1978
+  ``write_statistics``                      :3279-3359
+
+Same names, same argument meaning, same error behaviour (the reference panics; here `ffi.SphError`
+carries the status code of the guard that fired).  All arithmetic of the step lives in the HIP library;
+this file only moves arrays across the boundary and keeps the reference's counters.
+"""
+from __future__ import annotations
+
+import time as _time
+from typing import Dict, List, Optional
+
+import numpy as np
+
+from . import ffi
+from .scene import SceneConfig, boundary_planes, init_particles
+from .simulation_parameters import SimulationParams
+
+
+class _ParticleView:
+    """``fluid_simulation.particles.<field>`` -> numpy array downloaded in host particle order
+    (ParticleVec, simulation.rs:284-334)."""
+
+    def __init__(self, ctx: ffi.Context):
+        object.__setattr__(self, "_ctx", ctx)
+
+    def __getattr__(self, name: str) -> np.ndarray:
+        if name in ffi.FIELDS:
+            return self._ctx.download(name)
+        raise AttributeError(name)
+
+    def __setattr__(self, name: str, value):
+        if name in ffi.FIELDS:
+            self._ctx.upload_field(name, value)
+        else:
+            raise AttributeError(name)
+
+
+class _Counter:
+    def __init__(self):
+        self.values: List[float] = []
+
+    def add_value(self, v: float):
+        self.values.append(float(v))
+
+    def avg(self):
+        return sum(self.values) / len(self.values) if self.values else float("nan")
+
+
+class FluidSimulation:
+    """Drop-in for ``FluidSimulation<DimensionUtils2d, 2>`` on the step path."""
+
+    def __init__(self, position, velocity, mass, planes, counters_enabled: bool = False,
+                 lib: Optional[ffi.SphLibrary] = None, device_id: int = 0, n_capacity: Optional[int] = None):
+        self.lib = lib if lib is not None else ffi.load_product()
+        mass = np.ascontiguousarray(mass, dtype=np.float32)
+        n = mass.shape[0]
+        self.ctx = ffi.Context(self.lib, n_capacity if n_capacity is not None else max(n, 1), planes, device_id)
+        self.ctx.upload(mass, position, velocity)
+        self.particles = _ParticleView(self.ctx)
+        self.counters_enabled = counters_enabled
+        self.pcounters: Dict[str, _Counter] = {}
+        self.vcounters: Dict[str, _Counter] = {}
+        self.step_number = 0
+        self.last_stats: Optional[ffi.SphStepStats] = None
+
+    # ---- reference surface ---------------------------------------------------------------------
+    @property
+    def time(self) -> float:
+        return self.ctx.time
+
+    def num_fluid_particles(self) -> int:
+        return self.ctx.n
+
+    def single_step_without_adaptivity(self, simulation_params: SimulationParams) -> float:
+        """simulation.rs:1980-2730; returns dt (:2729)."""
+        p = simulation_params.to_ffi() if isinstance(simulation_params, SimulationParams) else simulation_params
+        t0 = _time.perf_counter()
+        st = self.ctx.step(p)
+        wall_ms = (_time.perf_counter() - t0) * 1e3
+        self.last_stats = st
+        self.step_number = int(st.step_number)
+        if self.counters_enabled:
+            self._v("particle-count", st.n_particles)               # :1990-1991
+            self._v("dt", st.dt)                                    # :2202
+            if st.div_solver.iters > 0:
+                self._v("div-iterations", st.div_solver.iters)      # :2542-2544
+            if st.density_solver.iters > 0:
+                self._v("density-iterations", st.density_solver.iters)  # :2617-2619
+            self._p("simulation-step", wall_ms)
+            self._p("neighborhood", st.ms_neighborhood)
+            self._p("level-estimation", st.ms_level_estimation)
+            self._p("div-solver", st.ms_div_solver)
+            self._p("density-solver", st.ms_density_solver)
+        return float(st.dt)
+
+    def single_step(self, simulation_params: SimulationParams) -> None:
+        """simulation.rs:1973-1978.  The adaptive half (single_step_adaptivity, :2732-2796) is host
+        bookkeeping that stays on the Rust side (out of scope); with
+        merging/sharing/splitting all off it is a no-op apart from classification."""
+        if simulation_params.merging or simulation_params.sharing or simulation_params.splitting:
+            raise NotImplementedError("single_step_adaptivity (split/merge/share) stays on the reference host; "
+                                      "call single_step_without_adaptivity and run adaptivity there")
+        self.single_step_without_adaptivity(simulation_params)
+
+    def neighbors(self):
+        """NeighborhoodCache as CSR (offsets, indices), host particle order."""
+        return self.ctx.download_neighbors()
+
+    # ---- counters / statistics (simulation.rs:137-189, 3279-3359) -------------------------------
+    def _v(self, key, v):
+        self.vcounters.setdefault(key, _Counter()).add_value(v)
+
+    def _p(self, key, ms):
+        self.pcounters.setdefault(key, _Counter()).add_value(ms)
+
+    def write_statistics(self) -> str:
+        pc, vc = self.pcounters, self.vcounters
+        sim_ms = sum(pc["simulation-step"].values)
+        lines = []
+        lines.append("${:.2f}\\si{{\\second}}$ & {} & {:.02f} & {:.02f} & - \\\\".format(
+            sim_ms / 1e3, int(round(vc["particle-count"].avg())),
+            vc["div-iterations"].avg() if "div-iterations" in vc else float("nan"),
+            vc["density-iterations"].avg() if "density-iterations" in vc else float("nan")))
+        lines.append("")
+        lines.append(f"simulation-time: {sim_ms}ms")
+        lines.append("")
+        for label in sorted(pc):
+            lines.append(f"{label}: avg:{pc[label].avg()}ms")
+        lines.append("")
+        for label in sorted(vc):
+            c = vc[label]
+            lines.append(f"{label}: min:{min(c.values)} max:{max(c.values)} avg:{c.avg()}")
+        return "\n".join(lines) + "\n"
+
+    def close(self):
+        self.ctx.close()
+
+
+def init_simulation_params(simulation_params: SimulationParams, scene_config: SceneConfig) -> SimulationParams:
+    """simulation.rs:3233-3256 (adaptive build: h is unused and set to 0)."""
+    return simulation_params.replace(h=0.0)
+
+
+def init_fluid_sim(simulation_params: SimulationParams, scene_config: SceneConfig, counters_enabled: bool = False,
+                   lib: Optional[ffi.SphLibrary] = None, device_id: int = 0) -> FluidSimulation:
+    """simulation.rs:3074-3231."""
+    pos, mass, vel = init_particles(scene_config)
+    planes = boundary_planes(scene_config.boundary, simulation_params.init_boundary_handler)
+    return FluidSimulation(pos, vel, mass, planes, counters_enabled, lib=lib, device_id=device_id)
+
+
+def run_until(fluid_simulation: FluidSimulation, simulation_params: SimulationParams, max_seconds: float,
+              max_steps: Optional[int] = None) -> int:
+    """The GUI-free loop of the image harness (platform/desktop/animation/mod.rs:138-272) /
+    `run --max-seconds` (main_loop.rs:346-350): step until simulated time >= max_seconds."""
+    steps = 0
+    while fluid_simulation.time < max_seconds and (max_steps is None or steps < max_steps):
+        fluid_simulation.single_step_without_adaptivity(simulation_params)
+        steps += 1
+    return steps

@@ -1,0 +1,260 @@
+/*
+ * sph_ffi.h -- C-ABI boundary of the MI355X-native SPH particle loop.
+ *
+ * This is the drop-in seam for ONE method of the reference (kaegi/adaptive-sph):
+ *
+ *     FluidSimulation::<DimensionUtils2d,2>::single_step_without_adaptivity(&mut self, SimulationParams) -> FT
+ *         src/simulation/simulation.rs:1980-2730
+ *
+ * plus the state it reads/mutates (`FluidSimulation.particles`, `.neighs`, `.boundary_handler`,
+ * `.time`; simulation.rs:471-477).  The reference has no FFI of its own (it is one Rust crate), so
+ * every entry point below cites the Rust item it replaces.  INTEGRATION.md shows the Rust
+ * `extern "C"` block and the ~40-line patch a maintainer would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; the library never retains a host pointer after the call returns;
+ *   - `Vec<VF<2>>` (nalgebra SVector<f32,2>, 8 contiguous bytes x,y) is passed as `const float*` of
+ *     length 2*n (`as_ptr() as *const f32`);
+ *   - every function returns an `int` status (0 = SPH_OK); the reference signals the same
+ *     conditions by panic!/assert! (caught by catch_unwind at platform/desktop/main_loop.rs:300-311);
+ *     unwinding across `extern "C"` is UB, so the Rust shim turns non-zero into `panic!`;
+ *   - one host thread per context at a time (the reference's `fluid` thread, main_loop.rs:152-181).
+ *
+ * Two libraries implement this header with different symbol prefixes:
+ *   libsph_hip.so      sph_*      the product: hand-written HIP kernels for gfx950 (adaptive_sph_amd/csrc)
+ *   liboracle.so       oracle_*   TEST INFRASTRUCTURE ONLY: scalar CPU restatement (oracle/)
+ */
+#ifndef SPH_FFI_H
+#define SPH_FFI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- enums: 1:1 with src/simulation/simulation_parameters.rs ------------------------------- */
+enum { SPH_VISC_WCSPH = 0, SPH_VISC_APPROX_LAPLACE = 1, SPH_VISC_XSPH = 2 };          /* :148-153 */
+enum { SPH_LEVEL_NONE = 0, SPH_LEVEL_CENTER_DIFF = 1, SPH_LEVEL_EMPTY_ANGLE = 2 };    /* :183-194 */
+enum {                                                                                 /* :170-181 */
+    SPH_H_FROM_DISTRIBUTION = 0, SPH_H_FROM_DISTRIBUTION_CLAMPED1 = 1, SPH_H_FROM_DISTRIBUTION_CLAMPED2 = 2,
+    SPH_H_FROM_DISTRIBUTION2 = 3, SPH_H_FROM_MASS = 4
+};
+enum { SPH_SOLVER_IISPH = 0, SPH_SOLVER_IISPH2 = 1, SPH_SOLVER_HYBRID_DFSPH = 2, SPH_SOLVER_ONLY_DIVERGENCE = 3 }; /* :196-206 */
+enum { SPH_DENSITY_AND_DIVERGENCE = 0, SPH_ONLY_DENSITY = 1 };                         /* :208-212 */
+enum { SPH_PENALTY_NONE = 0, SPH_PENALTY_LINEAR = 1, SPH_PENALTY_QUADRATIC1 = 2, SPH_PENALTY_QUADRATIC2 = 3 }; /* :17-23 */
+enum { SPH_OP_SIMPLE_GRADIENT = 0, SPH_OP_SYMMETRIC_GRADIENT = 1, SPH_OP_WINCHENBACH2020 = 2 };               /* :110-122 */
+enum { SPH_STASH_NONE = 0, SPH_STASH_SURFACE_DISTANCE_FIRST = 1, SPH_STASH_SURFACE_DISTANCE_MIDDLE = 2 };     /* :4-8 */
+enum { SPH_SIZING_RADIUS2 = 0, SPH_SIZING_RADIUS = 1, SPH_SIZING_MASS = 2 };            /* :10-15 */
+
+/* ---- per-step parameters: POD mirror of every SimulationParams field the path reads --------
+ * (simulation_parameters.rs:26-108).  Passed BY VALUE EVERY STEP because the GUI thread may edit
+ * any of them between steps (main_loop.rs:280).  Fields the path never reads (use_iisph,
+ * eos_*, merge/share knobs, ...) stay on the Rust side. */
+typedef struct sph_params {
+    float    rest_density;
+    float    cfl_factor;
+    float    max_dt;
+    float    viscosity;
+    int32_t  viscosity_type;
+    float    gravity;
+    float    jacobi_omega;
+    int32_t  level_estimation_method;
+    float    maximum_range;
+    int32_t  support_length_estimation;
+    float    sdf_gradient_eps;
+    int32_t  has_pull_fluid_to;          /* Option<VF<3>>: 0 = None */
+    float    pull_fluid_to[3];
+    float    maximum_surface_distance;
+    int32_t  boundary_is_fluid_surface;
+    int32_t  use_extended_range_for_level_estimation;
+    int32_t  level_estimation_after_advection;
+    float    level_estimation_range;
+    int32_t  pressure_solver_method;
+    float    iisph_max_avg_density_error;
+    float    hybrid_dfsph_factor;
+    float    hybrid_dfsph_max_avg_density_error;
+    float    hybrid_dfsph_max_avg_divergence_error;
+    int32_t  hybrid_dfsph_density_source_term;
+    int32_t  hybrid_dfsph_non_pressure_accel_before_divergence_free;
+    int32_t  boundary_penalty_term;
+    int32_t  operator_discretization;
+    uint32_t max_iters;
+    int32_t  check_neighborhood;
+    int32_t  check_aii;
+    int32_t  constrain_neighborhood_count;
+    int32_t  fill_stash_with;
+    /* read by LevelEstimationState::target_mass / classify_particle (simulation.rs:213-237,
+     * adaptivity/mod.rs:32-59) -- the first host-side consumer of the step's output */
+    int32_t  sizing_function;
+    float    particle_radius_fine;
+    float    particle_radius_base;
+} sph_params;
+
+/* ---- boundary description: SdfPlane{dir,delta} (sdf/sdf_plane.rs:4-7); a box is the 4 inward
+ * planes of SdfPlane::new_boundary_box (sdf_plane.rs:13-20).  n_planes = 0 is NoBoundaryHandler,
+ * which cannot step in the reference either (compute_aii hits unimplemented!(),
+ * boundary_handler/mod.rs:35-46) -> sph_step returns SPH_ERR_NO_BOUNDARY. */
+typedef struct sph_plane {
+    float dir_x, dir_y, delta;
+} sph_plane;
+
+/* ---- pressure-solver statistics of the LAST Jacobi iteration (simulation.rs:397-469) -------- */
+typedef struct sph_solver_stats {
+    uint32_t iters;              /* value returned by iisph_pressure_iterations: index of last iteration */
+    int32_t  converged;
+    uint32_t normal_count;
+    uint32_t singular_count;
+    uint32_t negative_count;
+    float    avg_error;          /* avg_error_times_normal_particle_count / normal_particle_count */
+    float    max_error;
+} sph_solver_stats;
+
+/* ---- what one step reports back; feeds vcounters "dt", "div-iterations",
+ * "density-iterations", "particle-count" (simulation.rs:1990-1991, 2202, 2542-2544, 2617-2619)
+ * and pcounters (ids as in the reference: simulation.rs:1993, 2023-2058, 2517-2545, 2578-2620) */
+typedef struct sph_step_stats {
+    float    dt;                 /* return value of single_step_without_adaptivity (sim.rs:2729) */
+    float    time;               /* FluidSimulation.time after the step (sim.rs:2724) */
+    uint64_t step_number;
+    uint64_t n_particles;
+    sph_solver_stats div_solver;      /* HybridDFSPH / OnlyDivergence */
+    sph_solver_stats density_solver;  /* IISPH / HybridDFSPH */
+    double   ms_simulation_step;
+    double   ms_neighborhood;
+    double   ms_level_estimation;
+    double   ms_div_solver;
+    double   ms_density_solver;
+} sph_step_stats;
+
+/* ---- field ids for sph_upload_field / sph_download (ParticleVec, simulation.rs:284-334) ----- */
+enum {
+    SPH_F_MASS = 0,            /* f32[n]   */
+    SPH_F_POSITION = 1,        /* f32[2n]  */
+    SPH_F_VELOCITY = 2,        /* f32[2n]  */
+    SPH_F_PRESSURE_ACCEL = 3,  /* f32[2n]  */
+    SPH_F_DENSITY = 4,         /* f32[n]   */
+    SPH_F_PPE_SOURCE_TERM = 5, /* f32[n]   */
+    SPH_F_PRESSURE = 6,        /* f32[n]   */
+    SPH_F_AII = 7,             /* f32[n]   */
+    SPH_F_DENSITY_ERROR = 8,   /* f32[n]   */
+    SPH_F_H2 = 9,              /* f32[n]   */
+    SPH_F_H2_NEXT = 10,        /* f32[n]   */
+    SPH_F_CONSTANT_FIELD = 11, /* f32[n]   */
+    SPH_F_NEIGHBOR_COUNT = 12, /* u32[n]   (usize in the reference) */
+    SPH_F_LEVEL_ESTIMATION = 13, /* f32[n]: FluidSurface(x) -> x, FluidInterior -> NaN (sim.rs:197-201) */
+    SPH_F_LEVEL_OLD = 14,      /* f32[n]   */
+    SPH_F_STASH = 15,          /* f32[n]   */
+    SPH_F_FLAG_IS_FLUID_SURFACE = 16,     /* u8[n] */
+    SPH_F_FLAG_INSUFFICIENT_NEIGHS = 17,  /* u8[n] */
+    SPH_F_PARTICLE_SIZE_CLASS = 18,       /* u8[n]: adaptivity/mod.rs:12-23 order */
+    /* BoundaryWinchenbach2020.lambda folded per particle (boundary_winchenbach2020.rs:27):
+     * sum of lambda and sum of grad-lambda over the planes -- all downstream uses are linear */
+    SPH_F_LAMBDA_SUM = 19,     /* f32[n]   */
+    SPH_F_LAMBDA_GRAD_SUM = 20,/* f32[2n]  */
+    /* spatial-hash cell of each particle in the reference's CellGrid convention
+     * (neighborhood_search.rs:253-255, 273-274, 383-395): linear index, x fastest */
+    SPH_F_CELL_INDEX = 21,     /* u32[n]   */
+    SPH_F_COUNT_ = 22
+};
+
+/* ---- status codes: one per reference guard ------------------------------------------------- */
+enum {
+    SPH_OK = 0,
+    SPH_ERR_INVALID_ARGUMENT = 1,
+    SPH_ERR_DEVICE = 2,                 /* HIP / RCCL runtime failure */
+    SPH_ERR_CAPACITY = 3,               /* n > n_capacity */
+    SPH_ERR_NO_BOUNDARY = 4,            /* boundary_handler/mod.rs:35-46 unimplemented!() */
+    SPH_ERR_DENSITY_NOT_FINITE = 10,    /* sim.rs:1046 */
+    SPH_ERR_DENSITY_TOO_SMALL = 11,     /* sim.rs:1047  density > 0.0001 */
+    SPH_ERR_AII_NOT_FINITE = 12,        /* sim.rs:1106 */
+    SPH_ERR_AII_NEGATIVE = 13,          /* sim.rs:1391-1400 */
+    SPH_ERR_AP_NOT_FINITE = 14,         /* sim.rs:1269-1271 */
+    SPH_ERR_PRESSURE_NOT_FINITE = 15,   /* sim.rs:1279-1281 */
+    SPH_ERR_TOO_MANY_NEIGHBORS = 16,    /* neighborhood_search.rs:149-151 (20000) */
+    SPH_ERR_VELOCITY_NOT_FINITE = 17,   /* sim.rs:2443, 2558 */
+    SPH_ERR_POSITION_NOT_FINITE = 18,   /* sim.rs:2667 */
+    SPH_ERR_VISCOSITY_NOT_FINITE = 19,  /* sim.rs:987, 995 */
+    SPH_ERR_XSPH_TODO = 20,             /* sim.rs:2673-2676 todo!() */
+    SPH_ERR_CHECK_NEIGHBORHOOD = 21,    /* sim.rs:1810-1863 */
+    SPH_ERR_CHECK_AII = 22,             /* sim.rs:1347-1375 */
+    SPH_ERR_LEVEL_WEIGHT = 23,          /* sim.rs:843-845 */
+    SPH_ERR_UNSUPPORTED = 30            /* a SimulationParams combination this build does not cover */
+};
+
+typedef struct sph_ctx sph_ctx;
+
+/* ---- lifecycle ------------------------------------------------------------------------------
+ * sph_create  <->  FluidSimulation::new (sim.rs:487-533) + BoundaryWinchenbach2020::new
+ *                  (boundary_winchenbach2020.rs:33-46: builds the two 10001-entry lambda LUTs).
+ * `device_id` is the HIP device ordinal this context owns (one process per GPU).
+ * "Restart" in the GUI = destroy + create (main_loop.rs:269-278). */
+int  sph_create(uint64_t n_capacity, int device_id, const sph_plane* planes, int n_planes, sph_ctx** out);
+void sph_destroy(sph_ctx* ctx);
+
+/* Replace the whole particle set (FluidSimulation::new arguments, and what the host must do
+ * whenever single_step_adaptivity (sim.rs:2732-2796) changed N or permuted indices).
+ * h2_next is initialised from mass as in sim.rs:505-520; all other fields zero/default;
+ * time and step_number are NOT reset (use sph_set_time). */
+int  sph_upload(sph_ctx* ctx, uint64_t n, const float* mass, const float* position_xy, const float* velocity_xy);
+
+/* Overwrite one host-written field (mass, position, velocity, h2, h2_next, level_estimation,
+ * level_old -- the fields adaptivity writes: splitting.rs:60-79, particle_merging.rs:319-368,
+ * particle_sharing.rs:202-237) without changing N. */
+int  sph_upload_field(sph_ctx* ctx, int field, const void* src, uint64_t src_bytes);
+
+/* Read one field back in HOST particle order. */
+int  sph_download(sph_ctx* ctx, int field, void* dst, uint64_t dst_bytes);
+
+/* Current neighbour lists (NeighborhoodCache.neighs, neighborhood_search.rs:13-15) as CSR in
+ * host particle order: offsets[n+1], indices[offsets[n]].  Call with indices == NULL to get the
+ * total in *n_indices first.  Set: { j : |x_ij|^2 < ((h_i+h_j)/2 * 2)^2 }, self included
+ * (neighborhood_search.rs:143-146, 187-238).  Order within a list is unspecified (the reference's
+ * is R*-tree traversal order). */
+int  sph_download_neighbors(sph_ctx* ctx, uint32_t* offsets, uint32_t* indices, uint64_t indices_capacity,
+                            uint64_t* n_indices);
+
+uint64_t sph_num_particles(const sph_ctx* ctx);
+float    sph_time(const sph_ctx* ctx);
+int      sph_set_time(sph_ctx* ctx, float time, uint64_t step_number);
+
+/* ---- THE hot path ---------------------------------------------------------------------------
+ * sph_step  <->  single_step_without_adaptivity (sim.rs:1980-2730).  Synchronous: returns after
+ * dt and the statistics are on the host.  `out` may be NULL. */
+int  sph_step(sph_ctx* ctx, const sph_params* params, sph_step_stats* out);
+
+/* Message for the last non-zero status of this context (what the Rust shim puts in panic!). */
+const char* sph_last_error(const sph_ctx* ctx);
+
+/* ---- grid info (CellGrid of neighborhood_search.rs:355-410 as built by the last step) ------- */
+typedef struct sph_grid_info {
+    float   cell_size;           /* support radius of the largest particle */
+    int32_t cells_min_x, cells_min_y;
+    int32_t size_x, size_y;
+} sph_grid_info;
+int  sph_grid(const sph_ctx* ctx, sph_grid_info* out);
+
+/* ---- measurement hooks (bench.py / rocprof cross-check; not part of the reference surface) -- */
+typedef struct sph_kernel_time {
+    char     name[48];
+    uint64_t launches;
+    double   total_ms;           /* HIP-event time on the context's stream */
+} sph_kernel_time;
+int  sph_profile_enable(sph_ctx* ctx, int enable);
+int  sph_profile_reset(sph_ctx* ctx);
+int  sph_profile_get(sph_ctx* ctx, sph_kernel_time* out, int capacity, int* n_out);
+
+/* ---- multi-GPU: 1-D slab decomposition along x, one process (= one context) per GPU --------
+ * The 128-byte RCCL unique id is created on rank 0 (sph_comm_unique_id) and broadcast by the
+ * launcher (torch.distributed / MPI / a socket); every rank then calls sph_comm_init.
+ * After that sph_upload takes this rank's particles only and sph_step exchanges ghost columns
+ * with the x-neighbours over RCCL point-to-point and all-reduces the CFL minimum and the Jacobi
+ * residual statistics. */
+int  sph_comm_unique_id(uint8_t id_out[128]);
+int  sph_comm_init(sph_ctx* ctx, const uint8_t id[128], int rank, int n_ranks);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* SPH_FFI_H */

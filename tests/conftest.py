@@ -1,0 +1,35 @@
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+REPO = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(REPO))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle_lib():
+    """The CPU oracle (TEST INFRASTRUCTURE): built on demand with gcc, loaded through the same
+    ctypes binding as the product, symbol prefix oracle_."""
+    from tests.oracle_harness import load_oracle
+    return load_oracle()
+
+
+@pytest.fixture(scope="session")
+def product_lib():
+    """The HIP library through its C ABI; built on demand with hipcc (cross-compiles without a GPU)."""
+    from adaptive_sph_amd import build, ffi
+    build.build_hip()
+    return ffi.load_product()
+
+
+@pytest.fixture(scope="session")
+def gpu_available():
+    import torch
+    return torch.cuda.is_available()

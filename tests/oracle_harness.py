@@ -1,0 +1,100 @@
+"""TEST-ONLY helpers around the CPU oracle (oracle/).  Nothing in the product package imports this."""
+from __future__ import annotations
+
+import ctypes as C
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+from adaptive_sph_amd import ffi
+
+REPO = Path(__file__).resolve().parent.parent
+ORACLE_DIR = REPO / "oracle"
+ORACLE_LIB = ORACLE_DIR / "liboracle.so"
+
+_ORACLE = None
+
+
+def build_oracle():
+    r = subprocess.run(["make", "-C", str(ORACLE_DIR)], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("oracle build failed:\n" + r.stdout + r.stderr)
+    return ORACLE_LIB
+
+
+def load_oracle() -> ffi.SphLibrary:
+    global _ORACLE
+    if _ORACLE is None:
+        build_oracle()
+        lib = ffi.SphLibrary(ORACLE_LIB, "oracle_")
+        L = lib.lib
+        L.oracle_cubic_kernel_2d.restype = C.c_float
+        L.oracle_cubic_kernel_2d.argtypes = [C.c_float, C.c_float]
+        L.oracle_cubic_kernel_2d_deriv.restype = None
+        L.oracle_cubic_kernel_2d_deriv.argtypes = [C.c_float, C.c_float, C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        for nm in ("oracle_sphere_volume_to_radius", "oracle_radius_to_sphere_volume"):
+            getattr(L, nm).restype = C.c_float
+            getattr(L, nm).argtypes = [C.c_float]
+        L.oracle_h_from_mass.restype = C.c_float
+        L.oracle_h_from_mass.argtypes = [C.c_float, C.c_float]
+        for nm in ("oracle_lambda2", "oracle_dlambda2"):
+            getattr(L, nm).restype = C.c_double
+            getattr(L, nm).argtypes = [C.c_double]
+        L.oracle_lambda_luts.restype = None
+        L.oracle_lambda_luts.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.oracle_lut_get.restype = C.c_float
+        L.oracle_lut_get.argtypes = [C.c_void_p, C.c_int, C.c_float]
+        L.oracle_add_fluid_block.restype = C.c_uint64
+        L.oracle_add_fluid_block.argtypes = [C.c_float] * 8 + [C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.oracle_boundary_box.restype = None
+        L.oracle_boundary_box.argtypes = [C.c_float, C.c_float, C.POINTER(ffi.SphPlane)]
+        L.oracle_build_neighbors.restype = C.c_int
+        L.oracle_build_neighbors.argtypes = [C.c_void_p, C.c_float]
+        L.oracle_check_neighborhood.restype = C.c_int
+        L.oracle_check_neighborhood.argtypes = [C.c_void_p]
+        L.oracle_num_threads.restype = C.c_int
+        L.oracle_set_num_threads.argtypes = [C.c_int]
+        _ORACLE = lib
+    return _ORACLE
+
+
+def oracle_kernel_deriv(lib, dx, dy, h):
+    gx, gy = C.c_float(), C.c_float()
+    lib.lib.oracle_cubic_kernel_2d_deriv(dx, dy, h, C.byref(gx), C.byref(gy))
+    return gx.value, gy.value
+
+
+def oracle_scene_block(lib, block):
+    """add_fluid_block through the oracle's own C restatement."""
+    args = [block.pos[0], block.pos[1], block.size[0], block.size[1], block.spacing, block.volume_fill_ratio,
+            block.velocity[0], block.velocity[1]]
+    n = int(lib.lib.oracle_add_fluid_block(*args, 0, None, None, None))
+    pos = np.empty((n, 2), np.float32)
+    mass = np.empty(n, np.float32)
+    vel = np.empty((n, 2), np.float32)
+    lib.lib.oracle_add_fluid_block(*args, n, pos.ctypes.data, mass.ctypes.data, vel.ctypes.data)
+    return pos, mass, vel
+
+
+def oracle_box(lib, width, height):
+    arr = (ffi.SphPlane * 4)()
+    lib.lib.oracle_boundary_box(width, height, arr)
+    return [(p.dir_x, p.dir_y, p.delta) for p in arr]
+
+
+def csr_sets(offsets, indices):
+    """list of sorted index arrays per particle"""
+    return [np.sort(indices[offsets[i]:offsets[i + 1]]) for i in range(len(offsets) - 1)]
+
+
+def uniform_params(**kw):
+    """default-config.yaml with the uniform dam-break overrides of SURVEY.md section 8d config 2
+    (media/motivation-video.yaml:42-57)."""
+    from adaptive_sph_amd.simulation_parameters import SimulationParams
+    base = SimulationParams.from_yaml(str(REPO / "tests" / "golden" / "default-config.yaml"))
+    over = dict(merging=False, sharing=False, splitting=False, level_estimation_method="None",
+                support_length_estimation="FromMass", pressure_solver_method="HybridDFSPH",
+                hybrid_dfsph_factor=20000000.0, max_dt=0.002, viscosity=0.001, max_iters=200)
+    over.update(kw)
+    return base.replace(**over)
