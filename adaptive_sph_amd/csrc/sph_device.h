@@ -1,0 +1,167 @@
+// Device-side numerical primitives of the SPH particle loop for gfx950 (wave64).
+//
+// What they compute is fixed by the reference:
+//   cubic spline W / dW/dx            src/simulation/sph_kernels.rs:23-71
+//   h_ij = (h_i + h_j) * 0.5          src/simulation/sph_kernels.rs:273-278
+//   neighbour predicate               src/simulation/neighborhood_search.rs:143-146
+//   LookupTable1D::get                src/simulation/boundary_handler/sdf_boundary_handler/lookup_table.rs:32-48
+//
+// The library is compiled with -ffp-contract=off, so `a*b + c` is two roundings like Rust;
+// FMAs appear only where written as fmaf().  The neighbour predicate and the cell index use
+// exactly the reference's operations (bit-exact index sets).  Pair VALUES use the hardware
+// reciprocal / square root (v_rcp_f32, v_sqrt_f32, v_rsq_f32: 1 ulp) in FAST mode; the reference's
+// own summation order is not reproducible (R*-tree traversal order + rayon reduce), so values
+// are comparable to ~1e-6 relative per sweep either way.  EXACT mode (SPH_HIP_EXACT=1) keeps
+// IEEE division and sqrt in the reference's operation order, for diagnosing parity.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define SPH_PI_F 3.14159274101257324219f          // std::f32::consts::PI
+#define SPH_FRAC_1_PI_F 0.318309873342514038086f  // std::f32::consts::FRAC_1_PI
+#define SPH_ETA 1.9f                              // simulation.rs:369
+#define SPH_SEVEN_PI (7.f * SPH_PI_F)
+
+struct GridP {
+    float cs;            // cell size = support radius of the largest particle
+    int minx, miny;      // cells_min  (neighborhood_search.rs:273)
+    int sx, sy;          // grid size  (cells_max - cells_min)
+    int ntx, nty;        // tiles per axis
+    uint32_t ncells;
+};
+
+// per-step scalars the kernels read (subset of sph_params + dt)
+struct StepP {
+    float rest_density, viscosity, gravity, jacobi_omega, dt, sdf_eps;
+    float pull_x, pull_y;
+    float hyb_vfactor;  // min(dt * hybrid_dfsph_factor, 1)
+    int viscosity_type, penalty, opdisc, has_pull, n_planes;
+};
+
+struct PlaneP {
+    float dx, dy, delta;
+};
+#define SPH_MAX_PLANES 8
+
+struct SolverPartial {
+    uint32_t normal, singular, negative;
+    float sum_err, max_err;
+};
+
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ float fast_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
+
+// sph_kernels.rs:23-32
+__device__ __forceinline__ float cubic_unnorm(float q)
+{
+    if (q < 0.5f) return 6.f * (q * q * q - q * q) + 1.f;
+    if (q < 1.f) {
+        float v = 1.f - q;
+        return 2.f * (v * v * v);
+    }
+    return 0.f;
+}
+// sph_kernels.rs:34-43
+__device__ __forceinline__ float cubic_unnorm_deriv(float q)
+{
+    if (q < 0.5f) return 18.f * q * q - 12.f * q;
+    if (q < 1.f) {
+        float v = 1.f - q;
+        return -6.f * v * v;
+    }
+    return 0.f;
+}
+
+// W(|x_ij|, h) given r^2 (sph_kernels.rs:49-52)
+template <bool EXACT>
+__device__ __forceinline__ float kernel_w(float r2, float h)
+{
+    if (EXACT) {
+        float r = sqrtf(r2);
+        float nf = 10.f / (SPH_SEVEN_PI * (h * h));
+        return nf * cubic_unnorm(r / (2.f * h));
+    } else {
+        float r = fast_sqrt(r2);
+        float nf = 10.f * fast_rcp(SPH_SEVEN_PI * (h * h));
+        return nf * cubic_unnorm(r * fast_rcp(2.f * h));
+    }
+}
+
+// dW/dx (sph_kernels.rs:61-71); (dx,dy) = x_i - x_j, r2 = |x_ij|^2
+template <bool EXACT>
+__device__ __forceinline__ void kernel_grad(float dx, float dy, float r2, float h, float& gx, float& gy)
+{
+    if (EXACT) {
+        float r = sqrtf(r2);
+        float q = r / (2.f * h);
+        if (q <= 1.0e-5f) {
+            gx = 0.f;
+            gy = 0.f;
+            return;
+        }
+        float ux = dx / r, uy = dy / r;
+        float nf = 10.f / (SPH_SEVEN_PI * (h * h));
+        float s = nf * cubic_unnorm_deriv(q) / (2.f * h);
+        gx = s * ux;
+        gy = s * uy;
+    } else {
+        float rinv = fast_rsq(r2);
+        float r = r2 * rinv;
+        float inv2h = fast_rcp(2.f * h);
+        float q = r * inv2h;
+        float nf = 10.f * fast_rcp(SPH_SEVEN_PI * (h * h));
+        float s = nf * cubic_unnorm_deriv(q) * inv2h * rinv;
+        if (!(q > 1.0e-5f)) s = 0.f;   // also covers r2 == 0 (rinv = inf, r = nan)
+        gx = s * dx;
+        gy = s * dy;
+    }
+}
+
+// uniform-h specialisation helpers: every h_ij equals h, so nf and 1/(2h) are per-launch constants
+struct UniformH {
+    float h, nf, inv2h;
+};
+
+// DimensionUtils2d::sphere_volume_to_radius, local_smoothing_length_from_mass
+// (sph_kernels.rs:203-206, simulation.rs:371-380): IEEE ops (bit-exact h => bit-exact neighbour sets)
+__device__ __forceinline__ float h_from_mass(float mass, float rest_density)
+{
+    float volume = mass / rest_density;
+    return SPH_ETA * sqrtf(volume * SPH_FRAC_1_PI_F);
+}
+
+// LookupTable1D::get with (min,max,steps) = (-1,1,10000); caller guarantees -1 <= x < 1
+__device__ __forceinline__ float lut_get(const float* __restrict__ data, float x)
+{
+    float fidx = (x - (-1.f)) * 0.5f * 10000.f;
+    float fl = floorf(fidx);
+    float interp = fidx - fl;
+    int idx = (int)fl;
+    if (idx + 1 >= 10001) return data[idx];
+    return data[idx] * (1.f - interp) + data[idx + 1] * interp;
+}
+
+// wave64 / block reductions (fixed order => deterministic)
+__device__ __forceinline__ float wave_sum(float v)
+{
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v)
+{
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_down(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_min(float v)
+{
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_down(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
+{
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}

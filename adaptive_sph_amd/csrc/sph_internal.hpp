@@ -1,0 +1,144 @@
+// Internal host-side interface between the translation units of libsph_hip.so.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "sph_device.h"
+#include "sph_ffi.h"
+
+// ---- HIP-event profiler (measurement hook; sph_profile_* in the C ABI) ------------------------
+struct Profiler {
+    int mode = 0;  // 0 off, 1 every kernel, 2 only names starting with "density"
+    struct Rec {
+        std::string name;
+        uint64_t launches = 0;
+        double total_ms = 0;
+    };
+    struct Pending {
+        int rec;
+        hipEvent_t a, b;
+    };
+    std::vector<Rec> recs;
+    std::vector<Pending> pending;
+    std::vector<hipEvent_t> pool;
+
+    int find(const char* name);
+    bool wants(const char* name) const;
+    hipEvent_t get_event();
+    void begin(const char* name, hipStream_t s);
+    void end(hipStream_t s);
+    void collect();  // after a stream sync: fold pending event pairs into recs
+    void reset();
+    ~Profiler();
+    int cur = -1;
+    hipEvent_t cur_a = nullptr;
+};
+
+struct ProfScope {
+    Profiler* p;
+    hipStream_t s;
+    bool on;
+    ProfScope(Profiler* p_, const char* name, hipStream_t s_) : p(p_), s(s_), on(p_ && p_->mode && p_->wants(name))
+    {
+        if (on) p->begin(name, s);
+    }
+    ~ProfScope()
+    {
+        if (on) p->end(s);
+    }
+};
+
+// ---- step header: per-step scalars reduced on the device, read once by the host ---------------
+struct HeaderOut {
+    float min_x, min_y, max_x, max_y, h_max, h_min, min_cfl;
+    uint32_t pad;
+};
+
+// ---- Jacobi control block (device resident; copied to the host at sync points) ----------------
+struct SolverCtrl {
+    uint32_t done;    // stop decision taken (iisph_pressure_iterations break)
+    uint32_t iters;   // num_pressure_iters at the break
+    uint32_t cur;     // index of the pressure buffer holding the current iterate
+    uint32_t ticket;  // reduce-kernel arrival counter
+    uint32_t normal, singular, negative;
+    float sum_err, max_err;
+    uint32_t pad[3];
+};
+
+// error word layout: first failing guard wins (atomicCAS from 0)
+struct DeviceStatus {
+    uint32_t error;  // SPH_ERR_* or 0
+    uint32_t info;   // particle index (host order) or auxiliary value
+};
+
+// ---- sph_sort.hip ------------------------------------------------------------------------------
+// Stable LSD radix sort of (key,val) pairs on `bits` key bits.  Returns 0 if the result is in
+// (keyA,valA), 1 if in (keyB,valB).
+int radix_sort_pairs(hipStream_t s, Profiler* prof, uint32_t* keyA, uint32_t* valA, uint32_t* keyB, uint32_t* valB,
+                     uint32_t n, int bits, uint32_t* hist_scratch /* >= 256 * nblocks + 256 */);
+size_t radix_sort_scratch_elems(uint32_t n);
+
+void launch_cell_keys(hipStream_t s, Profiler* prof, const float4* pm, uint32_t n, GridP g, uint32_t* key, uint32_t* val);
+void launch_reorder(hipStream_t s, Profiler* prof, uint32_t n, GridP g, const uint32_t* sorted_key, const uint32_t* perm,
+                    const float4* pm_in, const float2* vel_in, const uint32_t* orig_in, const float* lvl_in,
+                    const float* lvlold_in, float4* pm_out, float2* vel_out, uint32_t* orig_out, float* lvl_out,
+                    float* lvlold_out, uint32_t* cxy);
+void launch_cell_start(hipStream_t s, Profiler* prof, const uint32_t* sorted_key, uint32_t n, uint32_t ncells,
+                       uint32_t* cell_start /* [ncells+1] */);
+void launch_build_tiles(hipStream_t s, Profiler* prof, GridP g, int TX, int TY, const uint32_t* cell_start,
+                        uint32_t* tiles, uint32_t* n_tiles /* device counter, zeroed here */);
+
+// ---- sph_sweeps.hip ----------------------------------------------------------------------------
+struct SweepArgs {
+    GridP g;
+    StepP sp;
+    uint32_t n;
+    int exact;       // EXACT math mode
+    int uniform_h;   // all h bit-identical
+    int grid_blocks;
+    // grid structure
+    const uint32_t* cell_start;
+    const uint32_t* tiles;
+    const uint32_t* n_tiles;
+    const uint32_t* cxy;
+    const uint32_t* orig;
+    // particle state (sorted order)
+    const float4* pm;
+    float2* vel;
+    float2* vel_tmp;
+    float* rho;
+    float* lam_sum;
+    float2* lam_grad;
+    float* constf;
+    float* aii;
+    float* src;
+    float* p0;
+    float* p1;
+    float2* pacc;
+    float* dens_err;
+    float* stat;
+    uint32_t* ncount;
+    // boundary
+    const PlaneP* planes;
+    const float* lam_lut;
+    const float* dlam_lut;
+    // control
+    SolverCtrl* ctrl;
+    DeviceStatus* status;
+};
+
+void sweep_tile_dims(int* tx, int* ty);
+void launch_density(hipStream_t s, Profiler* prof, const SweepArgs& a);
+void launch_aii_const(hipStream_t s, Profiler* prof, const SweepArgs& a);
+void launch_non_pressure(hipStream_t s, Profiler* prof, const SweepArgs& a);                // vel -> vel_tmp
+void launch_source_term(hipStream_t s, Profiler* prof, const SweepArgs& a, int kind);      // 0 div, 1 full, 2 only-density
+void launch_pressure_accel(hipStream_t s, Profiler* prof, const SweepArgs& a, int iter);   // iter < 0: final sweep, uses ctrl->cur
+void launch_jacobi_update(hipStream_t s, Profiler* prof, const SweepArgs& a, int iter, int residual_density);
+void launch_solver_reduce(hipStream_t s, Profiler* prof, const SweepArgs& a, int iter, int residual_density, float max_avg_error,
+                          uint32_t max_iters, float* block_partials);
+void launch_vel_add_pacc(hipStream_t s, Profiler* prof, const SweepArgs& a);               // v += dt a^p
+void launch_integrate(hipStream_t s, Profiler* prof, const SweepArgs& a, float4* pm_out, int mode);  // 0: v+=dt a; x+=dt v   1: hybrid

@@ -1,0 +1,276 @@
+// Spatial-hash neighbour build for gfx950: cell index -> stable LSD radix sort of (cell, particle)
+// pairs -> cell-range table -> list of occupied tiles.
+//
+// What is computed follows the reference's own uniform-grid scheme
+// (/root/reference/src/simulation/neighborhood_search.rs:243-321 and CellGrid :355-410):
+//   cell      = floor(x / cell_size) per axis as i32                     (:253-255)
+//   cells_min = floor(min / cell_size) - 1, cells_max = floor(max / cell_size) + 2   (:273-274)
+//   linear    = (cx - minx) + (cy - miny) * size_x, x fastest            (:383-395)
+// How it is computed is MI355X-native: one-wave (64-lane) workgroups rank keys with ballot-based
+// match-any, digit histograms are scanned row-wise, and the cell-range table is written by the
+// threads that sit on a key boundary of the sorted sequence (no atomics, deterministic).
+#include "sph_internal.hpp"
+
+#define RS_ITEMS 16
+#define RS_TILE (64 * RS_ITEMS)
+
+// ------------------------------------------------------------------------------------------------
+// radix sort
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_rs_hist(const uint32_t* __restrict__ key, uint32_t n, int shift, uint32_t nblocks,
+                                                 uint32_t* __restrict__ hist)
+{
+    __shared__ uint32_t h[256];
+    const int lane = threadIdx.x;
+    for (int d = lane; d < 256; d += 64) h[d] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * RS_TILE;
+#pragma unroll
+    for (int i = 0; i < RS_ITEMS; i++) {
+        uint32_t idx = base + i * 64 + lane;
+        if (idx < n) atomicAdd(&h[(key[idx] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    for (int d = lane; d < 256; d += 64) hist[(size_t)d * nblocks + blockIdx.x] = h[d];
+}
+
+// one workgroup per digit: exclusive scan of that digit's per-block counts, total -> totals[d]
+__global__ __launch_bounds__(256) void k_rs_rowscan(uint32_t* __restrict__ hist, uint32_t nblocks, uint32_t* __restrict__ totals)
+{
+    __shared__ uint32_t wsum[4];
+    __shared__ uint32_t carry_s;
+    uint32_t* row = hist + (size_t)blockIdx.x * nblocks;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (uint32_t b = 0; b < nblocks; b += 256) {
+        uint32_t i = b + tid;
+        uint32_t v = i < nblocks ? row[i] : 0u;
+        uint32_t x = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            uint32_t y = __shfl_up(x, o, 64);
+            if (lane >= o) x += y;
+        }
+        if (lane == 63) wsum[w] = x;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (int k = 0; k < w; k++) woff += wsum[k];
+        uint32_t carry = carry_s;
+        if (i < nblocks) row[i] = carry + woff + x - v;
+        __syncthreads();
+        if (tid == 255) carry_s = carry + woff + x;
+        __syncthreads();
+    }
+    if (tid == 0) totals[blockIdx.x] = carry_s;
+}
+
+__global__ __launch_bounds__(64) void k_rs_scatter(const uint32_t* __restrict__ key_in, const uint32_t* __restrict__ val_in,
+                                                    uint32_t* __restrict__ key_out, uint32_t* __restrict__ val_out, uint32_t n,
+                                                    int shift, uint32_t nblocks, const uint32_t* __restrict__ hist,
+                                                    const uint32_t* __restrict__ totals)
+{
+    __shared__ uint32_t running[256];
+    const int lane = threadIdx.x;
+    // exclusive scan of the 256 digit totals (4 per lane) + this block's row-scanned offsets
+    {
+        uint32_t t0 = totals[4 * lane], t1 = totals[4 * lane + 1], t2 = totals[4 * lane + 2], t3 = totals[4 * lane + 3];
+        uint32_t s = t0 + t1 + t2 + t3;
+        uint32_t x = s;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            uint32_t y = __shfl_up(x, o, 64);
+            if (lane >= o) x += y;
+        }
+        uint32_t ex = x - s;
+        const uint32_t* hb = hist + blockIdx.x;
+        running[4 * lane] = ex + hb[(size_t)(4 * lane) * nblocks];
+        running[4 * lane + 1] = ex + t0 + hb[(size_t)(4 * lane + 1) * nblocks];
+        running[4 * lane + 2] = ex + t0 + t1 + hb[(size_t)(4 * lane + 2) * nblocks];
+        running[4 * lane + 3] = ex + t0 + t1 + t2 + hb[(size_t)(4 * lane + 3) * nblocks];
+    }
+    __syncthreads();
+    const uint32_t base = blockIdx.x * RS_TILE;
+    const uint64_t lt = (1ull << lane) - 1ull;
+    for (int i = 0; i < RS_ITEMS; i++) {
+        uint32_t idx = base + i * 64 + lane;
+        bool valid = idx < n;
+        uint32_t k = valid ? key_in[idx] : 0u;
+        uint32_t v = valid ? val_in[idx] : 0u;
+        uint32_t d = (k >> shift) & 255u;
+        uint64_t peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            bool bit = (d >> b) & 1u;
+            uint64_t m = __ballot(bit);
+            peers &= bit ? m : ~m;
+        }
+        uint32_t rank = __popcll(peers & lt);
+        uint32_t cnt = __popcll(peers);
+        uint32_t off = running[d];
+        __syncthreads();
+        if (valid && rank == 0) running[d] = off + cnt;
+        __syncthreads();
+        if (valid) {
+            key_out[off + rank] = k;
+            val_out[off + rank] = v;
+        }
+    }
+}
+
+size_t radix_sort_scratch_elems(uint32_t n)
+{
+    size_t nblocks = ((size_t)n + RS_TILE - 1) / RS_TILE;
+    return 256 * (nblocks ? nblocks : 1) + 256;
+}
+
+int radix_sort_pairs(hipStream_t s, Profiler* prof, uint32_t* keyA, uint32_t* valA, uint32_t* keyB, uint32_t* valB, uint32_t n,
+                     int bits, uint32_t* scratch)
+{
+    if (n == 0) return 0;
+    uint32_t nblocks = (n + RS_TILE - 1) / RS_TILE;
+    uint32_t* hist = scratch;
+    uint32_t* totals = scratch + (size_t)256 * nblocks;
+    int passes = (bits + 7) / 8;
+    if (passes < 1) passes = 1;
+    int cur = 0;
+    for (int p = 0; p < passes; p++) {
+        uint32_t *ki = cur ? keyB : keyA, *vi = cur ? valB : valA, *ko = cur ? keyA : keyB, *vo = cur ? valA : valB;
+        {
+            ProfScope ps(prof, "sort_hist", s);
+            hipLaunchKernelGGL(k_rs_hist, dim3(nblocks), dim3(64), 0, s, ki, n, p * 8, nblocks, hist);
+        }
+        {
+            ProfScope ps(prof, "sort_rowscan", s);
+            hipLaunchKernelGGL(k_rs_rowscan, dim3(256), dim3(256), 0, s, hist, nblocks, totals);
+        }
+        {
+            ProfScope ps(prof, "sort_scatter", s);
+            hipLaunchKernelGGL(k_rs_scatter, dim3(nblocks), dim3(64), 0, s, ki, vi, ko, vo, n, p * 8, nblocks, hist, totals);
+        }
+        cur ^= 1;
+    }
+    return cur;
+}
+
+// ------------------------------------------------------------------------------------------------
+// cell keys / reorder / cell-range table / tiles
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_cell_keys(const float4* __restrict__ pm, uint32_t n, GridP g, uint32_t* __restrict__ key,
+                                                    uint32_t* __restrict__ val)
+{
+    uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float4 p = pm[i];
+    // IEEE division, like `(particle_pos / kernel_support_radius).map(|x| x.floor() as i32)`
+    int cx = (int)floorf(p.x / g.cs) - g.minx;
+    int cy = (int)floorf(p.y / g.cs) - g.miny;
+    key[i] = (uint32_t)cx + (uint32_t)cy * (uint32_t)g.sx;
+    val[i] = i;
+}
+
+void launch_cell_keys(hipStream_t s, Profiler* prof, const float4* pm, uint32_t n, GridP g, uint32_t* key, uint32_t* val)
+{
+    ProfScope ps(prof, "cell_keys", s);
+    hipLaunchKernelGGL(k_cell_keys, dim3((n + 255) / 256), dim3(256), 0, s, pm, n, g, key, val);
+}
+
+__global__ __launch_bounds__(256) void k_reorder(uint32_t n, GridP g, const uint32_t* __restrict__ sorted_key,
+                                                  const uint32_t* __restrict__ perm, const float4* __restrict__ pm_in,
+                                                  const float2* __restrict__ vel_in, const uint32_t* __restrict__ orig_in,
+                                                  const float* __restrict__ lvl_in, const float* __restrict__ lvlold_in,
+                                                  float4* __restrict__ pm_out, float2* __restrict__ vel_out,
+                                                  uint32_t* __restrict__ orig_out, float* __restrict__ lvl_out,
+                                                  float* __restrict__ lvlold_out, uint32_t* __restrict__ cxy)
+{
+    uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    uint32_t src = perm[i];
+    pm_out[i] = pm_in[src];
+    vel_out[i] = vel_in[src];
+    orig_out[i] = orig_in[src];
+    lvl_out[i] = lvl_in[src];
+    lvlold_out[i] = lvlold_in[src];
+    uint32_t k = sorted_key[i];
+    uint32_t cy = k / (uint32_t)g.sx;
+    uint32_t cx = k - cy * (uint32_t)g.sx;
+    cxy[i] = cx | (cy << 16);
+}
+
+void launch_reorder(hipStream_t s, Profiler* prof, uint32_t n, GridP g, const uint32_t* sorted_key, const uint32_t* perm,
+                    const float4* pm_in, const float2* vel_in, const uint32_t* orig_in, const float* lvl_in,
+                    const float* lvlold_in, float4* pm_out, float2* vel_out, uint32_t* orig_out, float* lvl_out,
+                    float* lvlold_out, uint32_t* cxy)
+{
+    ProfScope ps(prof, "reorder", s);
+    hipLaunchKernelGGL(k_reorder, dim3((n + 255) / 256), dim3(256), 0, s, n, g, sorted_key, perm, pm_in, vel_in, orig_in, lvl_in,
+                       lvlold_in, pm_out, vel_out, orig_out, lvl_out, lvlold_out, cxy);
+}
+
+// cell_start[c] = index of the first sorted particle whose cell is >= c; cell_start[ncells] = n.
+// Thread i (0..n) owns the boundary between sorted particles i-1 and i and fills the cells in
+// (key[i-1], key[i]].
+__global__ __launch_bounds__(256) void k_cell_start(const uint32_t* __restrict__ key, uint32_t n, uint32_t ncells,
+                                                     uint32_t* __restrict__ cell_start)
+{
+    uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i > n) return;
+    uint32_t lo, hi;  // fill cells lo..hi inclusive with i
+    if (i == 0) {
+        lo = 0;
+        hi = n ? key[0] : ncells;
+    } else if (i == n) {
+        lo = key[n - 1] + 1;
+        hi = ncells;
+    } else {
+        uint32_t a = key[i - 1], b = key[i];
+        if (a == b) return;
+        lo = a + 1;
+        hi = b;
+    }
+    for (uint32_t c = lo; c <= hi; c++) cell_start[c] = i;
+}
+
+void launch_cell_start(hipStream_t s, Profiler* prof, const uint32_t* sorted_key, uint32_t n, uint32_t ncells, uint32_t* cell_start)
+{
+    ProfScope ps(prof, "cell_start", s);
+    hipLaunchKernelGGL(k_cell_start, dim3((n + 1 + 255) / 256), dim3(256), 0, s, sorted_key, n, ncells, cell_start);
+}
+
+// list of tiles (TX x TY cells) that own at least one particle; wave-aggregated append keeps
+// runs of 64 consecutive tiles in order (the order only affects scheduling, never results)
+__global__ __launch_bounds__(256) void k_build_tiles(GridP g, int TX, int TY, const uint32_t* __restrict__ cell_start,
+                                                      uint32_t* __restrict__ tiles, uint32_t* __restrict__ n_tiles)
+{
+    uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    uint32_t ntiles = (uint32_t)g.ntx * (uint32_t)g.nty;
+    uint32_t cnt = 0;
+    if (t < ntiles) {
+        int tx = t % g.ntx, ty = t / g.ntx;
+        int cx0 = tx * TX, cy0 = ty * TY;
+        int cxe = min(cx0 + TX, g.sx);
+        for (int r = 0; r < TY; r++) {
+            int cy = cy0 + r;
+            if (cy >= g.sy) break;
+            cnt += cell_start[(uint32_t)cy * g.sx + cxe] - cell_start[(uint32_t)cy * g.sx + cx0];
+        }
+    }
+    bool has = cnt > 0;
+    uint64_t m = __ballot(has);
+    if (m == 0) return;
+    int lane = threadIdx.x & 63;
+    uint32_t base = 0;
+    int leader = __ffsll((unsigned long long)m) - 1;
+    if (lane == leader) base = atomicAdd(n_tiles, (uint32_t)__popcll(m));
+    base = __shfl(base, leader, 64);
+    if (has) tiles[base + __popcll(m & ((1ull << lane) - 1ull))] = t;
+}
+
+void launch_build_tiles(hipStream_t s, Profiler* prof, GridP g, int TX, int TY, const uint32_t* cell_start, uint32_t* tiles,
+                        uint32_t* n_tiles)
+{
+    ProfScope ps(prof, "build_tiles", s);
+    hipMemsetAsync(n_tiles, 0, sizeof(uint32_t), s);
+    uint32_t ntiles = (uint32_t)g.ntx * (uint32_t)g.nty;
+    hipLaunchKernelGGL(k_build_tiles, dim3((ntiles + 255) / 256), dim3(256), 0, s, g, TX, TY, cell_start, tiles, n_tiles);
+}
