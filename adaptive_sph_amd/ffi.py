@@ -170,6 +170,13 @@ def load_product() -> SphLibrary:
     """The HIP library.  No fallback: a missing/unbuildable extension is an error."""
     global _PRODUCT
     if _PRODUCT is None:
+        # torch bundles its own libamdhip64 / libhsa-runtime64 / librccl with the SAME sonames as
+        # /opt/rocm's.  Whichever set is loaded first serves the whole process, and a mixed set aborts at
+        # exit -- so pin the order: torch's runtime first, then this library binds to it.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         _PRODUCT = SphLibrary(PRODUCT_LIB, "sph_")
     return _PRODUCT
 

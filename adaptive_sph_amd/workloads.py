@@ -1,0 +1,57 @@
+"""BASELINE.json workloads: parameter sets and scenes.
+
+`DEFAULT_CONFIG` is the content of the reference's default-config.yaml as a mapping (tests check it
+against tests/golden/default-config.yaml); the dam-break configs apply the reference's own uniform
+recipe on top (media/motivation-video.yaml:42-57 + section 8d overrides).
+"""
+from __future__ import annotations
+
+from . import scene as sc
+from .simulation_parameters import SimulationParams, apply_overrides
+
+DEFAULT_CONFIG = dict(
+    rest_density=1, cfl_factor=0.4, max_dt=0.006, h=0.0, use_iisph=True, eos_power=7, eos_stiffness=80,
+    viscosity_type="ApproxLaplace", viscosity=0.003, jacobi_omega=0.5, gravity=-9.81, check_neighborhood=False,
+    maximum_range=5.0, level_estimation_method="EmptyAngle", neighborhood_search_algorithm="RStar",
+    init_boundary_handler="AnalyticOverestimate", support_length_estimation="FromMass",
+    constrain_neighborhood_count=False, maximum_surface_distance=8.0, particle_radius_base=0.7,
+    particle_radius_fine=0.005, merging=True, sharing=True, splitting=True, minimum_share_partners=0,
+    minimum_merge_partners=0, max_mass_transfer_sharing=400000, max_mass_transfer_merging=100,
+    allow_share_with_optimal_particle=False, allow_share_with_too_small_particle=False,
+    allow_merge_with_optimal_particle=False, allow_merge_on_size_difference=False, boundary_is_fluid_surface=False,
+    max_merge_distance=1.6, max_share_distance=1.6, hybrid_dfsph_factor=0.0, hybrid_dfsph_max_avg_density_error=0.01,
+    hybrid_dfsph_max_avg_divergence_error=0.001, hybrid_dfsph_density_source_term="DensityAndDivergence",
+    hybrid_dfsph_non_pressure_accel_before_divergence_free=True, iisph_max_avg_density_error=0.002,
+    sdf_gradient_eps=0.00001, fail_on_missing_split_pattern=False, use_extended_range_for_level_estimation=True,
+    boundary_penalty_term="Quadratic1", sizing_function="Radius", level_estimation_after_advection=False,
+    level_estimation_range=5.5, max_iters=1000, operator_discretization="ConsistentSimpleGradient", check_aii=False,
+    pressure_solver_method="HybridDFSPH",
+)
+
+DAM_BREAK_OVERRIDES = dict(
+    merging=False, sharing=False, splitting=False, level_estimation_method="None",
+    support_length_estimation="FromMass", pressure_solver_method="HybridDFSPH", hybrid_dfsph_factor=20000000.0,
+    max_dt=0.002, viscosity=0.001, max_iters=200,
+)
+
+
+def default_params(**overrides) -> SimulationParams:
+    m = dict(DEFAULT_CONFIG)
+    apply_overrides(m, overrides)
+    return SimulationParams.from_mapping(m)
+
+
+def dam_break_params(**overrides) -> SimulationParams:
+    m = dict(DEFAULT_CONFIG)
+    apply_overrides(m, DAM_BREAK_OVERRIDES)
+    apply_overrides(m, overrides)
+    return SimulationParams.from_mapping(m)
+
+
+WORKLOADS = {
+    # name: (scene factory, params factory, description)
+    "dam_break_1m": (sc.dam_break_1m, dam_break_params, "2D dam-break, 1024x1024 = 1 048 576 uniform-h particles, HybridDFSPH"),
+    "dam_break_1m_adaptive": (sc.dam_break_1m_adaptive, dam_break_params, "2D dam-break, 1 000 960 particles, 4:1 radius ratio"),
+    "dam_break_8m": (sc.dam_break_8m, dam_break_params, "2D dam-break, 2896x2896 = 8 386 816 particles"),
+    "dam_break_64k": (lambda: sc.dam_break_small(256, 256, 1.0 / 256), dam_break_params, "2D dam-break, 256x256 particles (smoke)"),
+}

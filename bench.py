@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""bench.py -- particle-steps/sec of the MI355X-native SPH step (BASELINE.json metric).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload dam_break_1m]
+
+A "step" is one `sph_step` (= single_step_without_adaptivity, simulation.rs:1980-2730) over the whole
+particle set, inputs resident in HBM.  N=1 runs BASELINE.json configs[1] (2D dam-break, 1 048 576
+uniform-h particles, HybridDFSPH).  For N>1 the driver launches one rank per GPU through
+torch.distributed.run; the particle set is split into x-slabs (one per rank, RCCL halo exchange).
+
+Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  roofline      dominant neighbour sweep by time share: algorithmic bytes / HIP-event launch time vs 8 TB/s HBM
+  roofline_density  the same for the density kernel (north_star's named target kernel)
+  kernels       per-kernel HIP-event breakdown of a profiled pass over the same workload
+  cpu_baseline  the CPU oracle ("port" of the reference algorithm, OpenMP on the host cores) timed on a
+                bounded sample of the same workload -- a reported baseline, never the measured path.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+REPO = Path(__file__).resolve().parent
+sys.path.insert(0, str(REPO))
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
+
+# algorithmic HBM bytes per particle per launch (DESIGN.md "Kernels")
+ALGO_BYTES = {
+    "density": 20, "aii_constfield": 40, "non_pressure_accel": 36, "source_term": 44,
+    "pressure_accel": 40, "jacobi_update": 60, "integrate": 40, "vel_add_pacc": 24,
+}
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--profile-steps", type=int, default=20)
+    return ap.parse_args()
+
+
+def cpu_baseline(scene, params, budget_s: float):
+    """The oracle (kind "port") on the host cores, bounded sample of the SAME workload."""
+    from adaptive_sph_amd import ffi, scene as sc
+    from tests.oracle_harness import load_oracle
+    olib = load_oracle()
+    pos, mass, vel = sc.init_particles(scene)
+    planes = sc.boundary_planes(scene.boundary)
+    ctx = ffi.Context(olib, len(mass), planes)
+    ctx.upload(mass, pos, vel)
+    p = params.to_ffi()
+    cores = int(olib.lib.oracle_num_threads())
+    ctx.step(p)  # untimed first step (page faults, list allocation)
+    t0 = time.perf_counter()
+    steps = 0
+    while steps < 50:
+        ctx.step(p)
+        steps += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    n = len(mass)
+    ctx.close()
+    return {"value": n * steps / dt, "unit": "particle-steps/s", "cores": cores, "kind": "port",
+            "sample": f"steps 1..{steps} of the same {n}-particle scene from rest ({dt:.1f} s of CPU time, OpenMP oracle)"}
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    import torch
+    import torch.distributed as dist
+    from adaptive_sph_amd import build, ffi, scene as sc
+    from adaptive_sph_amd.workloads import WORKLOADS
+
+    if rank == 0:
+        build.build_hip()
+    distributed = world > 1
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.barrier()
+    plib = ffi.load_product()
+
+    wl = args.workload or ("dam_break_1m" if world == 1 else "dam_break_8m")
+    scene_f, params_f, desc = WORKLOADS[wl]
+    scene, params = scene_f(), params_f()
+    pos, mass, vel = sc.init_particles(scene)
+    planes = sc.boundary_planes(scene.boundary)
+    n_total = len(mass)
+
+    if distributed:
+        from adaptive_sph_amd.distributed import make_slab_context
+        ctx = make_slab_context(plib, pos, mass, vel, planes, rank, world, local_rank)
+    else:
+        ctx = ffi.Context(plib, n_total, planes, device_id=local_rank)
+        ctx.upload(mass, pos, vel)
+    p = params.to_ffi()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        ctx.step(p)
+
+    # ---- timed region: exactly K steps; density kernel timed live with HIP events on the library's stream
+    ctx.profile_reset()
+    ctx.profile_enable(2)
+    div_iters, dens_iters = [], []
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        st = ctx.step(p)
+        div_iters.append(int(st.div_solver.iters) + 1)
+        dens_iters.append(int(st.density_solver.iters) + 1)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof_density = ctx.profile_get()
+    ctx.profile_enable(0)
+    if distributed:
+        tt = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    n_local = ctx.n
+
+    # ---- per-kernel breakdown: a second, fully profiled pass (not part of `value`)
+    ctx.profile_reset()
+    ctx.profile_enable(1)
+    for _ in range(args.profile_steps):
+        ctx.step(p)
+    prof_all = ctx.profile_get()
+    ctx.profile_enable(0)
+
+    if rank != 0:
+        if distributed:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    def roof(name, launches, total_ms):
+        if not launches or name not in ALGO_BYTES:
+            return None
+        avg_s = total_ms * 1e-3 / launches
+        achieved = ALGO_BYTES[name] * n_local / avg_s / 1e9
+        return {"kernel": name, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_us": avg_s * 1e6,
+                "algorithmic_bytes_per_particle": ALGO_BYTES[name]}
+
+    total_prof_ms = sum(v[1] for v in prof_all.values()) or 1.0
+    kernels = []
+    for name, (launches, total_ms) in sorted(prof_all.items(), key=lambda kv: -kv[1][1]):
+        k = {"name": name, "launches_per_step": launches / max(args.profile_steps, 1), "avg_us": total_ms * 1e3 / max(launches, 1),
+             "time_share": total_ms / total_prof_ms}
+        r = roof(name, launches, total_ms)
+        if r:
+            k["achieved_GBs"] = r["achieved"]
+            k["frac_hbm_peak"] = r["frac"]
+        kernels.append(k)
+    dominant = next((k["name"] for k in kernels if k["name"] in ALGO_BYTES), None)
+    roofline = roof(dominant, *prof_all[dominant]) if dominant else None
+    dl, dm = prof_density.get("density", (0, 0.0))
+    roofline_density = roof("density", dl, dm)
+
+    out = {
+        "metric": "particle-steps/sec (whole node), 2D dam-break N=1M DFSPH; 1/2/4/8 GPUs",
+        "value": n_total * args.steps / elapsed,
+        "unit": "particle-steps/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed * 1e3 / args.steps,
+        "higher_is_better": True,
+        "scaling": "strong" if distributed else "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"{wl}: {desc}", "particles": n_total, "solver": params.pressure_solver_method,
+                   "mean_div_iterations": float(np.mean(div_iters)), "mean_density_iterations": float(np.mean(dens_iters)),
+                   "parallelism": f"x-slabs x{world}" if distributed else "single GPU"},
+        "roofline": roofline,
+        "roofline_density": roofline_density,
+        "kernels": kernels,
+    }
+    if not args.no_cpu_baseline and not distributed:
+        out["cpu_baseline"] = cpu_baseline(scene, params, args.cpu_seconds)
+    print(json.dumps(out))
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -24,6 +24,7 @@ def oracle_lib():
 @pytest.fixture(scope="session")
 def product_lib():
     """The HIP library through its C ABI; built on demand with hipcc (cross-compiles without a GPU)."""
+    import torch  # noqa: F401  (runtime load order, see ffi.load_product)
     from adaptive_sph_amd import build, ffi
     build.build_hip()
     return ffi.load_product()

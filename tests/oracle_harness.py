@@ -91,10 +91,5 @@ def csr_sets(offsets, indices):
 def uniform_params(**kw):
     """default-config.yaml with the uniform dam-break overrides of SURVEY.md section 8d config 2
     (media/motivation-video.yaml:42-57)."""
-    from adaptive_sph_amd.simulation_parameters import SimulationParams
-    base = SimulationParams.from_yaml(str(REPO / "tests" / "golden" / "default-config.yaml"))
-    over = dict(merging=False, sharing=False, splitting=False, level_estimation_method="None",
-                support_length_estimation="FromMass", pressure_solver_method="HybridDFSPH",
-                hybrid_dfsph_factor=20000000.0, max_dt=0.002, viscosity=0.001, max_iters=200)
-    over.update(kw)
-    return base.replace(**over)
+    from adaptive_sph_amd.workloads import dam_break_params
+    return dam_break_params(**kw)

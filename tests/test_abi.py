@@ -1,0 +1,56 @@
+"""The C-ABI library loads and exports every symbol include/sph_ffi.h declares (no GPU, no compute)."""
+import ctypes as C
+import re
+from pathlib import Path
+
+from adaptive_sph_amd import ffi
+
+REPO = Path(__file__).resolve().parent.parent
+
+
+def _declared_functions():
+    text = (REPO / "include" / "sph_ffi.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(sph_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_symbols_exported(product_lib):
+    names = _declared_functions()
+    assert len(names) >= 17
+    for nm in names:
+        assert hasattr(product_lib.lib, nm), f"libsph_hip.so does not export {nm}"
+    assert sorted("sph_" + s for s in ffi.ABI_SYMBOLS) == names
+
+
+def test_oracle_exports_same_surface(oracle_lib):
+    for s in ffi.ABI_SYMBOLS:
+        if s.startswith(("profile_", "comm_")):
+            continue
+        assert hasattr(oracle_lib.lib, "oracle_" + s)
+
+
+def test_struct_layouts_match_header():
+    # sizes implied by the header (natural alignment): guards the ctypes mirror against drift
+    assert C.sizeof(ffi.SphParams) == 37 * 4
+    assert C.sizeof(ffi.SphPlane) == 12
+    assert C.sizeof(ffi.SphSolverStats) == 28
+    assert C.sizeof(ffi.SphStepStats) == 8 + 8 + 8 + 28 + 28 + 5 * 8
+    assert C.sizeof(ffi.SphGridInfo) == 20
+    assert C.sizeof(ffi.SphKernelTime) == 64
+
+
+def test_no_gpu_create_fails_loudly(product_lib, gpu_available):
+    """Without a device the product must report an error, never fall back to a CPU path."""
+    if gpu_available:
+        return
+    h = C.c_void_p()
+    arr = (ffi.SphPlane * 1)(ffi.SphPlane(1.0, 0.0, 1.0))
+    rc = product_lib.create(16, 0, arr, 1, C.byref(h))
+    assert rc == 2  # SPH_ERR_DEVICE
+
+
+def test_product_package_does_not_reference_oracle():
+    for f in (REPO / "adaptive_sph_amd").rglob("*"):
+        if f.suffix in (".py", ".hip", ".h", ".hpp") and f.is_file():
+            txt = f.read_text()
+            assert "liboracle" not in txt and "oracle_harness" not in txt, f

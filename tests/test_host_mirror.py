@@ -1,0 +1,72 @@
+"""Host-side mirror of the reference's config/scene interface (no GPU)."""
+import numpy as np
+import pytest
+import yaml
+
+from adaptive_sph_amd import scene as sc
+from adaptive_sph_amd.simulation_parameters import SimulationParams, apply_overrides, load_yaml_mapping
+from adaptive_sph_amd.workloads import DEFAULT_CONFIG, dam_break_params, default_params
+from tests.oracle_harness import REPO
+
+CFG = str(REPO / "tests" / "golden" / "default-config.yaml")
+
+
+def test_default_config_yaml_roundtrip():
+    p = SimulationParams.from_yaml(CFG)
+    assert p.pressure_solver_method == "HybridDFSPH" and p.level_estimation_method == "EmptyAngle"
+    assert p.pull_fluid_to is None and p.fill_stash_with is None
+    assert p == default_params()
+    assert load_yaml_mapping(CFG) == {k: v for k, v in DEFAULT_CONFIG.items()}
+
+
+def test_override_must_hit_existing_key():
+    m = load_yaml_mapping(CFG)
+    apply_overrides(m, {"max_dt": 0.002})
+    assert m["max_dt"] == 0.002
+    with pytest.raises(KeyError, match="not able to find attribute"):
+        apply_overrides(m, {"no_such_key": 1})
+
+
+def test_missing_mandatory_field_is_an_error():
+    m = load_yaml_mapping(CFG)
+    del m["jacobi_omega"]
+    with pytest.raises(KeyError, match="jacobi_omega"):
+        SimulationParams.from_mapping(m)
+    m = load_yaml_mapping(CFG)
+    m["viscosity_type"] = "Nope"
+    with pytest.raises(ValueError):
+        SimulationParams.from_mapping(m)
+
+
+def test_level_estimation_none_spelling():
+    # `level_estimation_method: None` in the media recipes is the enum variant None, not a YAML null
+    p = SimulationParams.from_yaml(CFG, {"level_estimation_method": "None"})
+    assert p.to_ffi().level_estimation_method == 0
+
+
+def test_to_ffi_values():
+    f = dam_break_params().to_ffi()
+    assert f.pressure_solver_method == 2 and f.viscosity_type == 1 and f.boundary_penalty_term == 2
+    assert f.max_iters == 200 and abs(f.max_dt - 0.002) < 1e-9 and f.hybrid_dfsph_factor == 20000000.0
+    assert f.has_pull_fluid_to == 0 and f.operator_discretization == 0 and f.support_length_estimation == 4
+
+
+def test_add_fluid_block_layout():
+    b = sc.SceneFluidBlock([0.4, -0.5], [0.55, 1.4], 0.03, 0.93, [0.5, -1.0])
+    pos, mass, vel = sc.add_fluid_block(b)
+    assert pos.shape == (18 * 46, 2)
+    f32 = np.float32
+    # x outer, y inner; idx * spacing + min in f32
+    assert pos[0, 0] == f32(0.4) and pos[0, 1] == f32(-0.5)
+    assert pos[1, 0] == f32(0.4) and pos[1, 1] == f32(1) * f32(0.03) + f32(-0.5)
+    assert pos[46, 0] == f32(1) * f32(0.03) + f32(0.4)
+    assert np.all(mass == f32(0.03) * f32(0.03) * f32(0.93) * f32(1.0))
+    assert np.all(vel == np.array([0.5, -1.0], np.float32))
+
+
+def test_scene_yaml():
+    scn = sc.SceneConfig.from_yaml(str(REPO / "tests" / "golden" / "default-scene.yaml"))
+    assert scn.boundary.type == "box" and scn.boundary.width == 2 and len(scn.blocks) == 2
+    with pytest.raises(NotImplementedError):
+        sc.boundary_planes(scn.boundary, "AnalyticUnderestimate")
+    assert sc.boundary_planes(scn.boundary, "NoBoundary") == []
