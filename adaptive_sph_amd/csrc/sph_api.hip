@@ -9,6 +9,7 @@
 // (/root/reference/src/simulation/simulation.rs:1980-2730); the citations sit next to each call.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -301,7 +302,9 @@ struct sph_ctx {
     int pcur = 0;  // which pm buffer is live; the other one holds the sorted PRE-step positions after a step
     DevBuf vel_tmp;
     // per-step
-    DevBuf key[2], val[2], sort_scratch, cxy, cell_start, tiles;
+    DevBuf key[2], val[2], sort_scratch, cxy, cell_start, nl, nl_ok, mrho, pt0, pt1;
+    bool uniform_h = false;
+    float h_uniform = 0.f;
     DevBuf rho, lam_sum, lam_grad, constf, aii, src, p0, p1, pacc, dens_err, stat, ncount;
     DevBuf planes_d, lam_lut, dlam_lut, hdr_partials, hdr_out, ctrl, status, n_tiles, red_partials, scratch;
     HeaderOut* hdr_host = nullptr;      // pinned
@@ -347,11 +350,15 @@ static int alloc_particle_buffers(sph_ctx* c)
     HIPCHK(c, c->vel_tmp.ensure(n * sizeof(float2)));
     HIPCHK(c, c->sort_scratch.ensure(radix_sort_scratch_elems((uint32_t)n) * sizeof(uint32_t)));
     HIPCHK(c, c->cxy.ensure(n * sizeof(uint32_t)));
-    DevBuf* f1[] = {&c->rho, &c->lam_sum, &c->constf, &c->aii, &c->src, &c->p0, &c->p1, &c->dens_err, &c->stat, &c->ncount};
+    DevBuf* f1[] = {&c->rho, &c->lam_sum, &c->constf, &c->aii, &c->src, &c->p0, &c->p1, &c->dens_err, &c->stat, &c->ncount,
+                    &c->mrho, &c->pt0, &c->pt1};
     for (auto b : f1) HIPCHK(c, b->ensure(n * sizeof(float)));
     HIPCHK(c, c->lam_grad.ensure(n * sizeof(float2)));
     HIPCHK(c, c->pacc.ensure(n * sizeof(float2)));
     HIPCHK(c, c->scratch.ensure(n * sizeof(float4)));
+    HIPCHK(c, c->nl.ensure(sweep_list_bytes((uint32_t)n)));
+    HIPCHK(c, c->nl_ok.ensure(n));
+    HIPCHK(c, c->red_partials.ensure(sizeof(SolverPartial) * (size_t)solver_reduce_blocks((uint32_t)n)));
     return SPH_OK;
 }
 
@@ -380,8 +387,7 @@ extern "C" int sph_create(uint64_t n_capacity, int device_id, const sph_plane* p
     bool ok = c->planes_d.ensure(sizeof(PlaneP) * SPH_MAX_PLANES) == hipSuccess && c->lam_lut.ensure(10001 * 4) == hipSuccess &&
               c->dlam_lut.ensure(10001 * 4) == hipSuccess && c->hdr_partials.ensure(sizeof(HeaderOut) * HDR_BLOCKS) == hipSuccess &&
               c->hdr_out.ensure(sizeof(HeaderOut)) == hipSuccess && c->ctrl.ensure(sizeof(SolverCtrl)) == hipSuccess &&
-              c->status.ensure(sizeof(DeviceStatus)) == hipSuccess && c->n_tiles.ensure(16) == hipSuccess &&
-              c->red_partials.ensure(sizeof(SolverPartial) * 1024) == hipSuccess;
+              c->status.ensure(sizeof(DeviceStatus)) == hipSuccess && c->n_tiles.ensure(16) == hipSuccess;
     if (!ok) return bail(SPH_ERR_DEVICE);
     if (hipHostMalloc((void**)&c->hdr_host, sizeof(HeaderOut)) != hipSuccess) return bail(SPH_ERR_DEVICE);
     if (hipHostMalloc((void**)&c->ctrl_host, sizeof(SolverCtrl)) != hipSuccess) return bail(SPH_ERR_DEVICE);
@@ -406,7 +412,7 @@ extern "C" void sph_destroy(sph_ctx* c)
     if (c->stream) hipStreamSynchronize(c->stream);
     DevBuf* all[] = {&c->pm[0], &c->pm[1], &c->vel[0], &c->vel[1], &c->orig[0], &c->orig[1], &c->lvl[0], &c->lvl[1], &c->lvlold[0],
                      &c->lvlold[1], &c->vel_tmp, &c->key[0], &c->key[1], &c->val[0], &c->val[1], &c->sort_scratch, &c->cxy, &c->cell_start,
-                     &c->tiles, &c->rho, &c->lam_sum, &c->lam_grad, &c->constf, &c->aii, &c->src, &c->p0, &c->p1, &c->pacc, &c->dens_err,
+                     &c->nl, &c->nl_ok, &c->mrho, &c->pt0, &c->pt1, &c->rho, &c->lam_sum, &c->lam_grad, &c->constf, &c->aii, &c->src, &c->p0, &c->p1, &c->pacc, &c->dens_err,
                      &c->stat, &c->ncount, &c->planes_d, &c->lam_lut, &c->dlam_lut, &c->hdr_partials, &c->hdr_out, &c->ctrl, &c->status,
                      &c->n_tiles, &c->red_partials, &c->scratch};
     for (auto b : all) b->release();
@@ -599,9 +605,6 @@ static SweepArgs make_args(sph_ctx* c, const StepP& sp)
     a.n = (uint32_t)c->n;
     a.exact = c->exact;
     a.cell_start = c->cell_start.as<uint32_t>();
-    a.tiles = c->tiles.as<uint32_t>();
-    a.n_tiles = c->n_tiles.as<uint32_t>();
-    a.cxy = c->cxy.as<uint32_t>();
     a.orig = c->orig[k].as<uint32_t>();
     a.pm = c->pm[c->pcur].as<float4>();
     a.vel = c->vel[k].as<float2>();
@@ -618,14 +621,18 @@ static SweepArgs make_args(sph_ctx* c, const StepP& sp)
     a.dens_err = c->dens_err.as<float>();
     a.stat = c->stat.as<float>();
     a.ncount = c->ncount.as<uint32_t>();
+    a.nl = c->nl.as<uint4>();
+    a.partials = c->red_partials.as<float>();
+    a.mrho = c->mrho.as<float>();
+    a.pt0 = c->pt0.as<float>();
+    a.pt1 = c->pt1.as<float>();
+    a.uniform_h = c->uniform_h ? 1 : 0;
+    a.h_uniform = c->h_uniform;
     a.planes = c->planes_d.as<PlaneP>();
     a.lam_lut = c->lam_lut.as<float>();
     a.dlam_lut = c->dlam_lut.as<float>();
     a.ctrl = c->ctrl.as<SolverCtrl>();
     a.status = c->status.as<DeviceStatus>();
-    uint32_t ntiles = (uint32_t)c->grid.ntx * (uint32_t)c->grid.nty;
-    uint32_t gb = ntiles < a.n ? ntiles : a.n;
-    a.grid_blocks = (int)(gb < 4096u ? (gb ? gb : 1u) : 4096u);
     return a;
 }
 
@@ -662,29 +669,34 @@ static int sync_ctrl(sph_ctx* c)
     return SPH_OK;
 }
 
-// iisph_pressure_iterations (simulation.rs:1377-1516).  Iterations are enqueued speculatively in
-// chunks; every kernel of an iteration checks the device-side `done` flag first, so iterations
-// queued past the stop decision cost a launch and nothing else.
+// iisph_pressure_iterations (simulation.rs:1377-1516).  Iteration 0 was folded into the source-term
+// sweep (closed form, see OpSource); its statistics are reduced here.  Iterations are enqueued
+// speculatively up to the predicted count, followed by the FINAL pressure-acceleration sweep with its
+// fused tail (v += dt a^p / integrate); every kernel checks the device-side `done` flag first, so
+// iterations queued past the stop decision cost a launch and nothing else, and the final sweep only
+// runs once the decision is taken.  One host sync per chunk.
 static int pressure_iterations(sph_ctx* c, SweepArgs& a, float max_avg_error, int residual_density, uint32_t max_iters,
-                               uint32_t predicted_iters, sph_solver_stats* st)
+                               uint32_t predicted_iters, int tail, float4* pm_out, sph_solver_stats* st)
 {
     hipStream_t s = c->stream;
-    HIPCHK(c, hipMemsetAsync(c->ctrl.p, 0, sizeof(SolverCtrl), s));
-    uint32_t k = 0;
-    uint32_t chunk = predicted_iters + 2 > 3 ? predicted_iters + 2 : 3;
+    Profiler* prof = &c->prof;
+    // ctrl was zeroed before the source sweep; iteration 0's stop decision:
+    launch_solver_reduce(s, prof, a, 0, residual_density, max_avg_error, max_iters, c->red_partials.as<float>());
+    uint32_t k = 1;
+    uint32_t upto = predicted_iters > 2 ? predicted_iters : 2;  // iterations 0..upto (iters is the index of the last one)
     for (;;) {
-        for (uint32_t q = 0; q < chunk && k <= max_iters; q++, k++) {
-            launch_pressure_accel(s, &c->prof, a, (int)k);
-            launch_jacobi_update(s, &c->prof, a, (int)k, residual_density);
-            launch_solver_reduce(s, &c->prof, a, (int)k, residual_density, max_avg_error, max_iters, c->red_partials.as<float>());
+        for (; k <= upto && k <= max_iters; k++) {
+            launch_pressure_accel(s, prof, a, (int)k, 0, nullptr);
+            launch_jacobi_update(s, prof, a, (int)k, residual_density);
+            launch_solver_reduce(s, prof, a, (int)k, residual_density, max_avg_error, max_iters, c->red_partials.as<float>());
         }
+        launch_pressure_accel(s, prof, a, -1, tail, pm_out);
         int rc = sync_ctrl(c);
         if (rc) return rc;
         if (c->ctrl_host->done) break;
         if (k > max_iters) break;  // cannot happen: iteration max_iters always sets done
-        chunk = 4;
+        upto = k + 1;
     }
-    launch_pressure_accel(s, &c->prof, a, -1);
     const SolverCtrl& h = *c->ctrl_host;
     c->pressure_cur = h.cur;
     st->iters = h.iters;
@@ -704,9 +716,36 @@ static int ilog2_ceil(uint32_t v)
     return b;
 }
 
+// host-side timeline of one step (SPH_HIP_TRACE=1): where the CPU thread spends its time
+struct HostTrace {
+    bool on;
+    std::chrono::steady_clock::time_point t0;
+    double acc[8] = {0};
+    int steps = 0;
+    HostTrace() { const char* e = getenv("SPH_HIP_TRACE"); on = e && e[0] == '1'; }
+    void start() { if (on) t0 = std::chrono::steady_clock::now(); }
+    void mark(int k)
+    {
+        if (!on) return;
+        auto t1 = std::chrono::steady_clock::now();
+        acc[k] += std::chrono::duration<double, std::micro>(t1 - t0).count();
+        t0 = t1;
+    }
+    void end_step()
+    {
+        if (!on) return;
+        if (++steps % 20 == 0) {
+            fprintf(stderr, "[sph trace] per step us: header+sync %.1f | sort+grid launches %.1f | sweeps launches %.1f | div solve %.1f | mid %.1f | dens solve %.1f | tail+sync %.1f\n",
+                    acc[0] / steps, acc[1] / steps, acc[2] / steps, acc[3] / steps, acc[4] / steps, acc[5] / steps, acc[6] / steps);
+        }
+    }
+};
+static HostTrace g_trace;
+
 extern "C" int sph_step(sph_ctx* c, const sph_params* p, sph_step_stats* out)
 {
     if (!c || !p) return SPH_ERR_INVALID_ARGUMENT;
+    g_trace.start();
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
     Profiler* prof = &c->prof;
@@ -739,6 +778,7 @@ extern "C" int sph_step(sph_ctx* c, const sph_params* p, sph_step_stats* out)
     HIPCHK(c, hipMemcpyAsync(c->hdr_host, c->hdr_out.p, sizeof(HeaderOut), hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
     const HeaderOut hdr = *c->hdr_host;
+    g_trace.mark(0);
     if (!std::isfinite(hdr.min_x) || !std::isfinite(hdr.max_x) || !std::isfinite(hdr.min_y) || !std::isfinite(hdr.max_y) ||
         !(hdr.h_max > 0.f))
         return c->fail(SPH_ERR_POSITION_NOT_FINITE, "particle positions or smoothing lengths are not finite");
@@ -755,14 +795,12 @@ extern "C" int sph_step(sph_ctx* c, const sph_params* p, sph_step_stats* out)
     g.sx = (int)sx;
     g.sy = (int)sy;
     g.ncells = (uint32_t)(sx * sy);
-    int TX, TY;
-    sweep_tile_dims(&TX, &TY);
-    g.ntx = (g.sx + TX - 1) / TX;
-    g.nty = (g.sy + TY - 1) / TY;
+    g.ntx = g.nty = 0;
     c->grid = g;
     c->grid_valid = true;
     HIPCHK(c, c->cell_start.ensure(((size_t)g.ncells + 1) * sizeof(uint32_t)));
-    HIPCHK(c, c->tiles.ensure((size_t)g.ntx * g.nty * sizeof(uint32_t)));
+    c->uniform_h = (hdr.h_min == hdr.h_max);
+    c->h_uniform = hdr.h_max;
 
     // CFL (simulation.rs:2190-2191)
     const float cfl_dt = p->cfl_factor * sqrtf(hdr.min_cfl);
@@ -802,8 +840,8 @@ extern "C" int sph_step(sph_ctx* c, const sph_params* p, sph_step_stats* out)
     c->pcur ^= 1;
     k = c->cur;
     launch_cell_start(s, prof, c->key[0].as<uint32_t>(), n, g.ncells, c->cell_start.as<uint32_t>());
-    launch_build_tiles(s, prof, g, TX, TY, c->cell_start.as<uint32_t>(), c->tiles.as<uint32_t>(), c->n_tiles.as<uint32_t>());
     hipEventRecord(c->ev[1], s);
+    g_trace.mark(1);
 
     SweepArgs a = make_args(c, sp);
     sph_step_stats st;
@@ -828,47 +866,52 @@ extern "C" int sph_step(sph_ctx* c, const sph_params* p, sph_step_stats* out)
         a.vel_tmp = c->vel_tmp.as<float2>();
     };
 
+    auto begin_solve = [&](int kind, int residual_density) {
+        hipMemsetAsync(c->ctrl.p, 0, sizeof(SolverCtrl), s);
+        launch_source_term(s, prof, a, kind, residual_density);  // + Jacobi iteration 0
+    };
+    float4* pm_next = c->pm[c->pcur ^ 1].as<float4>();
+    enum { T_NONE = 0, T_VEL = 1, T_VX = 2, T_HYBRID = 3 };  // TAIL_* of sph_sweeps.hip
+
     switch (p->pressure_solver_method) {
     case SPH_SOLVER_IISPH:  // simulation.rs:2389-2446
         non_pressure();
         hipEventRecord(c->ev[4], s);
-        launch_source_term(s, prof, a, 1);
-        rc = pressure_iterations(c, a, p->iisph_max_avg_density_error, 1, p->max_iters, c->last_dens_iters, &st.density_solver);
+        begin_solve(1, 1);
+        rc = pressure_iterations(c, a, p->iisph_max_avg_density_error, 1, p->max_iters, c->last_dens_iters, T_VX, pm_next, &st.density_solver);
         if (rc) return rc;
         hipEventRecord(c->ev[5], s);
-        launch_integrate(s, prof, a, c->pm[c->pcur ^ 1].as<float4>(), 0);
         break;
     case SPH_SOLVER_ONLY_DIVERGENCE:  // simulation.rs:2448-2500
         non_pressure();
         hipEventRecord(c->ev[2], s);
-        launch_source_term(s, prof, a, 0);
-        rc = pressure_iterations(c, a, p->hybrid_dfsph_max_avg_divergence_error, 0, p->max_iters, c->last_div_iters, &st.div_solver);
+        begin_solve(0, 0);
+        rc = pressure_iterations(c, a, p->hybrid_dfsph_max_avg_divergence_error, 0, p->max_iters, c->last_div_iters, T_VX, pm_next, &st.div_solver);
         if (rc) return rc;
         hipEventRecord(c->ev[3], s);
-        launch_integrate(s, prof, a, c->pm[c->pcur ^ 1].as<float4>(), 0);
         break;
     default:  // HybridDFSPH, simulation.rs:2502-2670
         if (p->hybrid_dfsph_non_pressure_accel_before_divergence_free) non_pressure();
         hipEventRecord(c->ev[2], s);
-        launch_source_term(s, prof, a, 0);
-        rc = pressure_iterations(c, a, p->hybrid_dfsph_max_avg_divergence_error, 0, p->max_iters, c->last_div_iters, &st.div_solver);
+        begin_solve(0, 0);
+        g_trace.mark(2);
+        rc = pressure_iterations(c, a, p->hybrid_dfsph_max_avg_divergence_error, 0, p->max_iters, c->last_div_iters, T_VEL, nullptr, &st.div_solver);
         if (rc) return rc;
+        g_trace.mark(3);
         hipEventRecord(c->ev[3], s);
-        launch_vel_add_pacc(s, prof, a);
         if (!p->hybrid_dfsph_non_pressure_accel_before_divergence_free) non_pressure();
         hipEventRecord(c->ev[4], s);
-        launch_source_term(s, prof, a, p->hybrid_dfsph_density_source_term == SPH_ONLY_DENSITY ? 2 : 1);
-        rc = pressure_iterations(c, a, p->hybrid_dfsph_max_avg_density_error, 1, p->max_iters, c->last_dens_iters, &st.density_solver);
+        begin_solve(p->hybrid_dfsph_density_source_term == SPH_ONLY_DENSITY ? 2 : 1, 1);
+        g_trace.mark(4);
+        rc = pressure_iterations(c, a, p->hybrid_dfsph_max_avg_density_error, 1, p->max_iters, c->last_dens_iters, T_HYBRID, pm_next, &st.density_solver);
         if (rc) return rc;
+        g_trace.mark(5);
         hipEventRecord(c->ev[5], s);
-        launch_integrate(s, prof, a, c->pm[c->pcur ^ 1].as<float4>(), 1);
         break;
     }
     hipEventRecord(c->ev[6], s);
     c->pcur ^= 1;  // integrated positions live in the other pm buffer; the old one keeps the pre-step snapshot
-
-    rc = sync_ctrl(c);
-    if (rc) return rc;
+    HIPCHK(c, hipEventSynchronize(c->ev[6]));
     if (p->viscosity_type == SPH_VISC_XSPH)  // simulation.rs:2673-2676
         return c->fail(SPH_ERR_XSPH_TODO, "not yet implemented (XSPH velocity smoothing)");
 
@@ -887,6 +930,8 @@ extern "C" int sph_step(sph_ctx* c, const sph_params* p, sph_step_stats* out)
     if (has_dens && hipEventElapsedTime(&ms, c->ev[4], c->ev[5]) == hipSuccess) st.ms_density_solver = ms;
     if (prof->mode) prof->collect();
     if (out) *out = st;
+    g_trace.mark(6);
+    g_trace.end_step();
     return SPH_OK;
 }
 

@@ -54,75 +54,83 @@ __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcp
 __device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 __device__ __forceinline__ float fast_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
 
-// sph_kernels.rs:23-32
+// sph_kernels.rs:23-32, written select-style (both branches are a handful of VALU ops; a divergent
+// branch costs more than evaluating both)
 __device__ __forceinline__ float cubic_unnorm(float q)
 {
-    if (q < 0.5f) return 6.f * (q * q * q - q * q) + 1.f;
-    if (q < 1.f) {
-        float v = 1.f - q;
-        return 2.f * (v * v * v);
-    }
-    return 0.f;
+    const float a = 6.f * (q * q * q - q * q) + 1.f;
+    const float v = 1.f - q;
+    const float b = 2.f * (v * v * v);
+    return q < 0.5f ? a : (q < 1.f ? b : 0.f);
 }
 // sph_kernels.rs:34-43
 __device__ __forceinline__ float cubic_unnorm_deriv(float q)
 {
-    if (q < 0.5f) return 18.f * q * q - 12.f * q;
-    if (q < 1.f) {
-        float v = 1.f - q;
-        return -6.f * v * v;
-    }
-    return 0.f;
+    const float a = 18.f * q * q - 12.f * q;
+    const float v = 1.f - q;
+    const float b = -6.f * v * v;
+    return q < 0.5f ? a : (q < 1.f ? b : 0.f);
 }
 
-// W(|x_ij|, h) given r^2 (sph_kernels.rs:49-52)
-template <bool EXACT>
-__device__ __forceinline__ float kernel_w(float r2, float h)
-{
-    if (EXACT) {
+// Math policies.  EXACT: IEEE division / sqrt in the reference's operation order.  FAST: hardware
+// v_rcp_f32 / v_rsq_f32 / v_sqrt_f32 (1 ulp).  UNIFORM: FAST with every h_ij == h (all particles
+// carry the bit-identical smoothing length), so the normalisation and 1/(2h) are launch constants.
+struct MathExact {
+    static constexpr bool EXACT = true, UNIFORM = false;
+    float h;  // unused
+    __device__ __forceinline__ float w(float r2, float hij) const
+    {
         float r = sqrtf(r2);
-        float nf = 10.f / (SPH_SEVEN_PI * (h * h));
-        return nf * cubic_unnorm(r / (2.f * h));
-    } else {
-        float r = fast_sqrt(r2);
-        float nf = 10.f * fast_rcp(SPH_SEVEN_PI * (h * h));
-        return nf * cubic_unnorm(r * fast_rcp(2.f * h));
+        float nf = 10.f / (SPH_SEVEN_PI * (hij * hij));
+        return nf * cubic_unnorm(r / (2.f * hij));
     }
-}
-
-// dW/dx (sph_kernels.rs:61-71); (dx,dy) = x_i - x_j, r2 = |x_ij|^2
-template <bool EXACT>
-__device__ __forceinline__ void kernel_grad(float dx, float dy, float r2, float h, float& gx, float& gy)
-{
-    if (EXACT) {
+    __device__ __forceinline__ void grad(float dx, float dy, float r2, float hij, float& gx, float& gy) const
+    {
         float r = sqrtf(r2);
-        float q = r / (2.f * h);
-        if (q <= 1.0e-5f) {
-            gx = 0.f;
-            gy = 0.f;
-            return;
-        }
+        float q = r / (2.f * hij);
         float ux = dx / r, uy = dy / r;
-        float nf = 10.f / (SPH_SEVEN_PI * (h * h));
-        float s = nf * cubic_unnorm_deriv(q) / (2.f * h);
-        gx = s * ux;
-        gy = s * uy;
-    } else {
+        float nf = 10.f / (SPH_SEVEN_PI * (hij * hij));
+        float s = nf * cubic_unnorm_deriv(q) / (2.f * hij);
+        bool z = q <= 1.0e-5f;
+        gx = z ? 0.f : s * ux;
+        gy = z ? 0.f : s * uy;
+    }
+};
+struct MathFast {
+    static constexpr bool EXACT = false, UNIFORM = false;
+    float h;  // unused
+    __device__ __forceinline__ float w(float r2, float hij) const
+    {
+        float r = fast_sqrt(r2);
+        float nf = 10.f * fast_rcp(SPH_SEVEN_PI * (hij * hij));
+        return nf * cubic_unnorm(r * fast_rcp(2.f * hij));
+    }
+    __device__ __forceinline__ void grad(float dx, float dy, float r2, float hij, float& gx, float& gy) const
+    {
         float rinv = fast_rsq(r2);
         float r = r2 * rinv;
-        float inv2h = fast_rcp(2.f * h);
+        float inv2h = fast_rcp(2.f * hij);
         float q = r * inv2h;
-        float nf = 10.f * fast_rcp(SPH_SEVEN_PI * (h * h));
+        float nf = 10.f * fast_rcp(SPH_SEVEN_PI * (hij * hij));
         float s = nf * cubic_unnorm_deriv(q) * inv2h * rinv;
-        if (!(q > 1.0e-5f)) s = 0.f;   // also covers r2 == 0 (rinv = inf, r = nan)
+        s = (q > 1.0e-5f) ? s : 0.f;  // also covers r2 == 0 (rinv = inf, r = nan)
         gx = s * dx;
         gy = s * dy;
     }
-}
-
-// uniform-h specialisation helpers: every h_ij equals h, so nf and 1/(2h) are per-launch constants
-struct UniformH {
+};
+struct MathUniform {
+    static constexpr bool EXACT = false, UNIFORM = true;
     float h, nf, inv2h;
+    __device__ __forceinline__ float w(float r2, float) const { return nf * cubic_unnorm(fast_sqrt(r2) * inv2h); }
+    __device__ __forceinline__ void grad(float dx, float dy, float r2, float, float& gx, float& gy) const
+    {
+        float rinv = fast_rsq(r2);
+        float q = (r2 * rinv) * inv2h;
+        float s = nf * cubic_unnorm_deriv(q) * inv2h * rinv;
+        s = (q > 1.0e-5f) ? s : 0.f;
+        gx = s * dx;
+        gy = s * dy;
+    }
 };
 
 // DimensionUtils2d::sphere_volume_to_radius, local_smoothing_length_from_mass

@@ -99,12 +99,9 @@ struct SweepArgs {
     uint32_t n;
     int exact;       // EXACT math mode
     int uniform_h;   // all h bit-identical
-    int grid_blocks;
+    float h_uniform;
     // grid structure
     const uint32_t* cell_start;
-    const uint32_t* tiles;
-    const uint32_t* n_tiles;
-    const uint32_t* cxy;
     const uint32_t* orig;
     // particle state (sorted order)
     const float4* pm;
@@ -122,6 +119,11 @@ struct SweepArgs {
     float* dens_err;
     float* stat;
     uint32_t* ncount;
+    uint4* nl;          // neighbour list words (sph_sweeps.hip)
+    float* partials;    // per-block solver statistics
+    float* mrho;        // m / rho
+    float* pt0;         // p / rho^2 for pressure buffer 0 / 1
+    float* pt1;
     // boundary
     const PlaneP* planes;
     const float* lam_lut;
@@ -131,12 +133,13 @@ struct SweepArgs {
     DeviceStatus* status;
 };
 
-void sweep_tile_dims(int* tx, int* ty);
+size_t sweep_list_bytes(uint32_t n);
+uint32_t solver_reduce_blocks(uint32_t n);
 void launch_density(hipStream_t s, Profiler* prof, const SweepArgs& a);
 void launch_aii_const(hipStream_t s, Profiler* prof, const SweepArgs& a);
 void launch_non_pressure(hipStream_t s, Profiler* prof, const SweepArgs& a);                // vel -> vel_tmp
-void launch_source_term(hipStream_t s, Profiler* prof, const SweepArgs& a, int kind);      // 0 div, 1 full, 2 only-density
-void launch_pressure_accel(hipStream_t s, Profiler* prof, const SweepArgs& a, int iter);   // iter < 0: final sweep, uses ctrl->cur
+void launch_source_term(hipStream_t s, Profiler* prof, const SweepArgs& a, int kind, int residual_density);  // kind: 0 div, 1 full, 2 only-density; includes Jacobi iteration 0
+void launch_pressure_accel(hipStream_t s, Profiler* prof, const SweepArgs& a, int iter, int tail, float4* pm_out);  // iter < 0: final sweep (runs once ctrl->done), tail = TAIL_*
 void launch_jacobi_update(hipStream_t s, Profiler* prof, const SweepArgs& a, int iter, int residual_density);
 void launch_solver_reduce(hipStream_t s, Profiler* prof, const SweepArgs& a, int iter, int residual_density, float max_avg_error,
                           uint32_t max_iters, float* block_partials);

@@ -2,37 +2,52 @@
 //
 // Execution model (MI355X-first, not a translation of the reference's rayon loops over
 // Vec<Vec<u32>> neighbour lists):
-//   * particles live in a cell-sorted SoA (x,y,m,h packed as one float4 => one 16-B load per
-//     particle, coalesced);
-//   * a 256-thread workgroup owns one TILE of TX x TY cells.  It stages the tile plus a one-cell
-//     halo -- TY+2 contiguous runs of the sorted arrays, because cells are ordered x-fastest --
-//     into LDS once, together with the sweep's per-neighbour payload (so p_j/rho_j^2, m_j/rho_j ...
-//     are computed once per particle, not once per pair);
-//   * each thread then owns one particle of the tile and walks the 3 rows x 3 cells of its
-//     neighbourhood as three contiguous LDS ranges (ds_read_b128 per candidate, lanes of one cell
-//     read the same address => LDS broadcast), applying the reference's neighbour predicate
+//   * particles live in a cell-sorted SoA (x,y,m,h packed as one float4 => one 16-B access per
+//     particle); thread i of a launch owns sorted particle i, so every per-particle read and
+//     write is coalesced and every wave is 64 consecutive, spatially adjacent particles;
+//   * the DENSITY sweep (first of the step) walks the 3 rows x 3 cells around each particle --
+//     three contiguous index ranges, because cells are ordered x-fastest -- and applies the
+//     reference's neighbour predicate
 //         |x_ij|^2 < ((h_i + h_j) * 0.5 * 2)^2        (neighborhood_search.rs:143-146)
-//     with exactly the reference's operations, so the visited set IS the reference's list;
-//   * every particle writes only its own outputs (gather-only, no atomics, deterministic order:
-//     rows bottom-to-top, sorted index ascending).
-// Tiles whose halo does not fit the LDS budget (extreme size ratios) fall back to reading the
-// payload straight from L2/HBM with the same code path.
+//     with exactly the reference's operations, so the accepted set IS the reference's list.  It
+//     records the accepted candidates as 16-bit index deltas (j - i), 4 per 8-byte word,
+//     transposed per wave (word g of lane l at [wave][g][l]) so that every later access to the
+//     list is one coalesced 512-B wave load;
+//   * all later sweeps of the step (positions do not change until the final integrate) replay
+//     that list: per group of 4 neighbours one 8-B list load (prefetched one group ahead), four
+//     independent gathers of the neighbour payload and four pair evaluations -- 13 instead of
+//     ~38 candidate evaluations per particle, 4-way ILP, no barriers, no LDS, full occupancy.
+//     Neighbours of neighbouring lanes are adjacent in memory (cell-sorted order), so the gathers
+//     hit the same few cache lines per wave; per-neighbour derived quantities (p_j/rho_j^2,
+//     m_j/rho_j) are produced once per particle by the sweep that owns them, not once per pair;
+//   * every particle writes only its own outputs (gather-only, no atomics); the visiting order
+//     (rows bottom-to-top, sorted index ascending) is identical on both paths, so results do not
+//     depend on which path ran.
+// Particles with more than NL_MAXN neighbours or with a neighbour further than +-32767 slots away
+// (extreme size ratios, enormous rows) fall back to the candidate walk in every sweep.
 //
 // Each Op below cites the reference sweep it implements (src/simulation/simulation.rs and
 // src/simulation/boundary_handler/sdf_boundary_handler/boundary_winchenbach2020.rs).
 #include "sph_internal.hpp"
 
-#define TILE_THREADS 256
-#define TILE_TX 8
-#define TILE_TY 7
-#define TILE_CAP 1024
+#define SWEEP_THREADS 256
+
+// Neighbour list word (one uint4 = 16 B per particle, coalesced 1 KB per wave):
+//   x, y, z : accepted-candidate bit masks of the three cell rows cy-1, cy, cy+1.  Bit b of row r
+//             is sorted particle  cell_start[(cy+r-1)*sx + cx-1] + b  (the row's candidate range
+//             is contiguous because cells are ordered x-fastest); the bases are re-read from the
+//             L2-resident cell table, which costs no HBM traffic;
+//   w       : neighbour count (bits 0..15) | NL_OK (list complete: every row has <= 32 candidates)
+//                                          | NL_WALL (particle has boundary terms: lambda != 0)
+#define NL_OK 0x80000000u
+#define NL_WALL 0x40000000u
 
 struct SweepCommon {
     GridP g;
+    uint32_t n;
+    uint32_t nblocks;
     const uint32_t* __restrict__ cell_start;
-    const uint32_t* __restrict__ tiles;
-    const uint32_t* __restrict__ n_tiles;
-    const uint32_t* __restrict__ cxy;
+    uint4* __restrict__ nl;   // neighbour list words
 };
 
 __device__ __forceinline__ void raise_error(DeviceStatus* st, uint32_t code, uint32_t info)
@@ -41,128 +56,152 @@ __device__ __forceinline__ void raise_error(DeviceStatus* st, uint32_t code, uin
 }
 
 // ------------------------------------------------------------------------------------------------
-// generic tile sweep
+// generic sweep.  BUILD = true: candidate walk + list recording (density sweep).
+//
+// Op interface:
+//   typedef Math;  Math m;                      math policy (sph_device.h)
+//   bool   skip()                               launch-uniform early exit (speculative Jacobi iterations)
+//   float4 loadA(j)                             (x, y, m, h) of particle j
+//   NB     nb(acc, j, Aj)                       per-neighbour payload of particle j
+//   void   begin(acc, i, Ai)                    load own data, zero accumulators
+//   void   pair(acc, Aj, NBj, dx, dy, r2, hij)  one accepted pair
+//   void   finish(acc, i, Ai, wall)             boundary terms (only if `wall`), outputs, guards
+//   void   epilogue(acc, active, blk)           optional block-level tail (HAS_EPILOGUE)
 // ------------------------------------------------------------------------------------------------
-template <class Op, int TX, int TY, int CAP>
-__global__ __launch_bounds__(TILE_THREADS) void k_sweep(Op op, SweepCommon c)
+template <class Op, bool BUILD>
+__global__ __launch_bounds__(SWEEP_THREADS) void k_sweep(Op op, SweepCommon c)
 {
-    __shared__ uint32_t s_cs[TY + 2][TX + 3];
-    __shared__ uint32_t s_off[TY + 3];
-    __shared__ uint32_t s_ioff[TY + 1];
-    __shared__ float4 s_A[CAP];
-    __shared__ float4 s_B[Op::HAS_B ? CAP : 1];
-
     if (op.skip()) return;
-
-    const int tid = threadIdx.x;
-    const uint32_t n_tiles = *c.n_tiles;
+    // XCD-aware block order: the dispatcher places block b on XCD b % 8; give every XCD a contiguous
+    // band of the cell-sorted array so that vertically adjacent waves (which share neighbour rows)
+    // hit the same L2.
+    const uint32_t per_xcd = (c.nblocks + 7) >> 3;
+    const uint32_t blk = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    if (blk >= c.nblocks) return;
+    const uint32_t i = blk * SWEEP_THREADS + threadIdx.x;
+    const bool active = i < c.n;
+    typedef typename Op::Math Math;
+    typedef typename Op::NB NB;
     const GridP g = c.g;
+    typename Op::Acc acc;
 
-    for (uint32_t slot = blockIdx.x; slot < n_tiles; slot += gridDim.x) {
-        const uint32_t t = c.tiles[slot];
-        const int tx = t % g.ntx, ty = t / g.ntx;
-        const int cx0 = tx * TX, cy0 = ty * TY;
-        const int cA = max(cx0 - 1, 0);
-        const int cE = min(cx0 + TX + 1, g.sx);
-        const int ncol = cE - cA + 1;  // cell_start entries per row
-        const int cxi_end = min(cx0 + TX, g.sx);
+    if (active) {
+        const float4 Ai = op.loadA(i);
+        uint4 lw = make_uint4(0, 0, 0, 0);
+        if (!BUILD) lw = c.nl[i];
+        op.begin(acc, i, Ai);
 
-        for (int idx = tid; idx < (TY + 2) * (TX + 3); idx += TILE_THREADS) {
-            int r = idx / (TX + 3), q = idx - r * (TX + 3);
-            int cy = cy0 - 1 + r;
-            uint32_t v = 0;
-            if (cy >= 0 && cy < g.sy) v = c.cell_start[(uint32_t)cy * g.sx + cA + min(q, ncol - 1)];
-            s_cs[r][q] = v;
-        }
-        __syncthreads();
-        if (tid == 0) {
-            uint32_t o = 0;
-            for (int r = 0; r < TY + 2; r++) {
-                s_off[r] = o;
-                o += s_cs[r][ncol - 1] - s_cs[r][0];
-            }
-            s_off[TY + 2] = o;
-            uint32_t io = 0;
-            s_ioff[0] = 0;
-            for (int r = 1; r <= TY; r++) {
-                io += s_cs[r][cxi_end - cA] - s_cs[r][cx0 - cA];
-                s_ioff[r] = io;
-            }
-        }
-        __syncthreads();
-        const uint32_t total = s_off[TY + 2];
-        const uint32_t n_int = s_ioff[TY];
-        const bool lds_mode = total <= (uint32_t)CAP;
-
-        if (lds_mode) {
-            for (uint32_t k = tid; k < total; k += TILE_THREADS) {
-                int r = 0;
+        // own cell (the same IEEE expression the sort key was computed from) and the three row bases
+        const int cx = (int)floorf(Ai.x / g.cs) - g.minx;
+        const int cy = (int)floorf(Ai.y / g.cs) - g.miny;
+        uint32_t rb[3], re[3];
+        const bool walk = BUILD || !(lw.w & NL_OK);
 #pragma unroll
-                for (int q = 1; q < TY + 2; q++) r += (k >= s_off[q]) ? 1 : 0;
-                uint32_t gidx = s_cs[r][0] + (k - s_off[r]);
-                s_A[k] = op.loadA(gidx);
-                if (Op::HAS_B) s_B[k] = op.loadB(gidx);
-            }
+        for (int dr = 0; dr < 3; dr++) {
+            const int yy = cy + dr - 1;
+            const bool ok = yy >= 0 && yy < g.sy;
+            const uint32_t base = (uint32_t)(ok ? yy : 0) * (uint32_t)g.sx;
+            rb[dr] = ok ? c.cell_start[base + (uint32_t)max(cx - 1, 0)] : 0u;
+            re[dr] = (ok && walk) ? c.cell_start[base + (uint32_t)min(cx + 2, g.sx)] : rb[dr];
         }
-        __syncthreads();
-
-        for (uint32_t k = tid; k < n_int; k += TILE_THREADS) {
-            int r = 1;
+#define SPH_PAIR(AJ, NJ, ON)                                                              \
+    {                                                                                     \
+        const float dx = Ai.x - AJ.x, dy = Ai.y - AJ.y;                                   \
+        const float r2 = dx * dx + dy * dy;                                               \
+        const float hij = Math::UNIFORM ? op.m.h : (Ai.w + AJ.w) * 0.5f;                  \
+        if (ON) op.pair(acc, AJ, NJ, dx, dy, r2, hij);                                    \
+    }
+        if (!walk) {
+            // ---- list replay: per row, up to 4 set bits per trip (4 independent gathers in flight) ------
+            const uint32_t masks[3] = {lw.x, lw.y, lw.z};
 #pragma unroll
-            for (int q = 1; q < TY; q++) r += (k >= s_ioff[q]) ? 1 : 0;
-            const uint32_t gi = s_cs[r][cx0 - cA] + (k - s_ioff[r - 1]);
-            const int lc = (int)(c.cxy[gi] & 0xffffu) - cA;
-            float4 Ai, Bi = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (lds_mode) {
-                uint32_t li = s_off[r] + (gi - s_cs[r][0]);
-                Ai = s_A[li];
-                if (Op::HAS_B) Bi = s_B[li];
-            } else {
-                Ai = op.loadA(gi);
-                if (Op::HAS_B) Bi = op.loadB(gi);
-            }
-            typename Op::Acc acc;
-            op.begin(acc, gi, Ai, Bi);
-#pragma unroll
-            for (int dr = -1; dr <= 1; dr++) {
-                const int rr = r + dr;
-                const uint32_t b = s_cs[rr][lc - 1], e = s_cs[rr][lc + 2];
-                const uint32_t lbase = s_off[rr] - s_cs[rr][0];
-                for (uint32_t j = b; j < e; j++) {
-                    float4 Aj, Bj = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (lds_mode) {
-                        Aj = s_A[lbase + j];
-                        if (Op::HAS_B) Bj = s_B[lbase + j];
-                    } else {
-                        Aj = op.loadA(j);
-                        if (Op::HAS_B) Bj = op.loadB(j);
-                    }
-                    // neighbour predicate, exactly the reference's operations (no FMA, strict <)
-                    const float dx = Ai.x - Aj.x, dy = Ai.y - Aj.y;
-                    const float r2 = dx * dx + dy * dy;
-                    const float hij = (Ai.w + Aj.w) * 0.5f;
-                    const float s = hij * 2.f;
-                    if (r2 < s * s) op.pair(acc, Aj, Bj, dx, dy, r2, hij);
+            for (int dr = 0; dr < 3; dr++) {
+                uint32_t mk = masks[dr];
+                const uint32_t base = rb[dr];
+                while (mk) {
+                    const uint32_t b0 = __ffs(mk) - 1;
+                    mk &= mk - 1;
+                    const bool v1 = mk != 0;
+                    const uint32_t b1 = v1 ? __ffs(mk) - 1 : b0;
+                    mk &= mk - 1;
+                    const bool v2 = mk != 0;
+                    const uint32_t b2 = v2 ? __ffs(mk) - 1 : b0;
+                    mk &= mk - 1;
+                    const bool v3 = mk != 0;
+                    const uint32_t b3 = v3 ? __ffs(mk) - 1 : b0;
+                    mk &= mk - 1;
+                    const uint32_t j0 = base + b0, j1 = base + b1, j2 = base + b2, j3 = base + b3;
+                    const float4 A0 = op.loadA(j0), A1 = op.loadA(j1), A2 = op.loadA(j2), A3 = op.loadA(j3);
+                    const NB N0 = op.nb(acc, j0, A0), N1 = op.nb(acc, j1, A1), N2 = op.nb(acc, j2, A2), N3 = op.nb(acc, j3, A3);
+                    SPH_PAIR(A0, N0, true)
+                    SPH_PAIR(A1, N1, v1)
+                    SPH_PAIR(A2, N2, v2)
+                    SPH_PAIR(A3, N3, v3)
                 }
             }
-            op.finish(acc, gi, Ai, Bi);
-        }
-        __syncthreads();
+        } else {
+            // ---- candidate walk: 3 rows x 3 cells, exact reference predicate, 4 candidates per trip ------
+            uint32_t mk[3] = {0u, 0u, 0u};
+            uint32_t nacc = 0;
+            bool ok_list = true;
+#pragma unroll
+            for (int dr = 0; dr < 3; dr++) {
+                const uint32_t b = rb[dr], e = re[dr];
+                ok_list = ok_list && (e - b) <= 32u;
+                for (uint32_t j = b; j < e; j += 4) {
+                    const bool v1 = j + 1 < e, v2 = j + 2 < e, v3 = j + 3 < e;
+                    const uint32_t j1 = v1 ? j + 1 : j, j2 = v2 ? j + 2 : j, j3 = v3 ? j + 3 : j;
+                    const float4 A0 = op.loadA(j), A1 = op.loadA(j1), A2 = op.loadA(j2), A3 = op.loadA(j3);
+#define SPH_CAND(JJ, AJ, VALID, K)                                                        \
+    {                                                                                     \
+        /* neighbour predicate, exactly the reference's operations (no FMA, strict <) */  \
+        const float dx = Ai.x - AJ.x, dy = Ai.y - AJ.y;                                   \
+        const float r2 = dx * dx + dy * dy;                                               \
+        const float hij = Math::UNIFORM ? op.m.h : (Ai.w + AJ.w) * 0.5f;                  \
+        const float s = hij * 2.f;                                                        \
+        if ((VALID) && r2 < s * s) {                                                      \
+            const NB Nj = op.nb(acc, JJ, AJ);                                             \
+            op.pair(acc, AJ, Nj, dx, dy, r2, hij);                                        \
+            const uint32_t bit = (JJ) - b;                                                \
+            if (bit < 32u) mk[dr] |= 1u << bit;                                           \
+            nacc++;                                                                       \
+        }                                                                                 \
     }
+                    SPH_CAND(j, A0, true, 0)
+                    SPH_CAND(j1, A1, v1, 1)
+                    SPH_CAND(j2, A2, v2, 2)
+                    SPH_CAND(j3, A3, v3, 3)
+                }
+            }
+            if (BUILD) lw = make_uint4(mk[0], mk[1], mk[2], (nacc & 0xffffu) | (ok_list ? NL_OK : 0u));
+        }
+        const bool wall = op.finish(acc, i, Ai, BUILD ? true : (lw.w & NL_WALL) != 0u);
+        if (BUILD) {
+            if (wall) lw.w |= NL_WALL;
+            c.nl[i] = lw;
+        }
+    }
+    if (Op::HAS_EPILOGUE) op.epilogue(acc, active, blk);
 }
 
 // ------------------------------------------------------------------------------------------------
-// Op: density  (+ boundary lambda terms, + neighbour count)
+// Op: density  (+ boundary lambda terms, + neighbour count, + m/rho)
 //   calculate_particle_density               simulation.rs:1007-1028, asserts :1046-1047
 //   BoundaryWinchenbach2020::update_after_advect   boundary_winchenbach2020.rs:58-152
 //   neighbor_count                           simulation.rs:2072-2074
 // ------------------------------------------------------------------------------------------------
-template <bool EXACT>
+struct NBNone {};
+
+template <class MathT>
 struct OpDensity {
-    static constexpr bool HAS_B = false;
+    typedef MathT Math;
+    static constexpr bool HAS_EPILOGUE = false;
+    typedef NBNone NB;
+    MathT m;
     const float4* __restrict__ pm;
     const uint32_t* __restrict__ orig;
     float* __restrict__ rho;
+    float* __restrict__ mrho;
     float* __restrict__ lam_sum;
     float2* __restrict__ lam_grad;
     uint32_t* __restrict__ ncount;
@@ -174,14 +213,16 @@ struct OpDensity {
     struct Acc {
         float sum, lam;
         uint32_t cnt;
+        bool wall;
     };
     __device__ bool skip() const { return false; }
-    __device__ float4 loadA(uint32_t g) const { return pm[g]; }
-    __device__ float4 loadB(uint32_t) const { return make_float4(0.f, 0.f, 0.f, 0.f); }
+    __device__ void epilogue(Acc&, bool, uint32_t) const {}
+    __device__ float4 loadA(uint32_t j) const { return pm[j]; }
+    __device__ NB nb(const Acc&, uint32_t, float4) const { return NB{}; }
 
     __device__ static float probe(const PlaneP& pl, float x, float y) { return (pl.dx * x + pl.dy * y) + pl.delta; }
 
-    __device__ void begin(Acc& a, uint32_t gi, float4 Ai, float4) const
+    __device__ void begin(Acc& a, uint32_t i, float4 Ai) const
     {
         a.sum = 0.f;
         a.cnt = 0;
@@ -226,22 +267,25 @@ struct OpDensity {
             gys += gy / sr_i * s;
         }
         a.lam = ls;
-        lam_sum[gi] = ls;
-        lam_grad[gi] = make_float2(gxs, gys);
+        a.wall = ls != 0.f || gxs != 0.f || gys != 0.f;
+        lam_sum[i] = ls;
+        lam_grad[i] = make_float2(gxs, gys);
     }
-    __device__ void pair(Acc& a, float4 Aj, float4, float, float, float r2, float hij) const
+    __device__ void pair(Acc& a, float4 Aj, NB, float, float, float r2, float hij) const
     {
-        a.sum += Aj.z * kernel_w<EXACT>(r2, hij);
+        a.sum += Aj.z * m.w(r2, hij);
         a.cnt++;
     }
-    __device__ void finish(Acc& a, uint32_t gi, float4, float4) const
+    __device__ bool finish(Acc& a, uint32_t i, float4 Ai, bool) const
     {
         float d = a.sum + a.lam;
-        rho[gi] = d;
-        ncount[gi] = a.cnt;
-        if (!isfinite(d)) raise_error(status, SPH_ERR_DENSITY_NOT_FINITE, orig[gi]);
-        else if (!(d > 0.0001f)) raise_error(status, SPH_ERR_DENSITY_TOO_SMALL, orig[gi]);
-        if (a.cnt > 20000u) raise_error(status, SPH_ERR_TOO_MANY_NEIGHBORS, orig[gi]);
+        rho[i] = d;
+        mrho[i] = Ai.z / d;
+        ncount[i] = a.cnt;
+        if (!isfinite(d)) raise_error(status, SPH_ERR_DENSITY_NOT_FINITE, orig[i]);
+        else if (!(d > 0.0001f)) raise_error(status, SPH_ERR_DENSITY_TOO_SMALL, orig[i]);
+        if (a.cnt > 20000u) raise_error(status, SPH_ERR_TOO_MANY_NEIGHBORS, orig[i]);
+        return a.wall;
     }
 };
 
@@ -250,12 +294,16 @@ struct OpDensity {
 //   compute_aii -> BoundaryWinchenbach2020::iisph_aii   simulation.rs:1080-1125, boundary_winchenbach2020.rs:225-306
 //   constant_field                                       simulation.rs:2235-2248
 // ------------------------------------------------------------------------------------------------
-template <bool EXACT>
+template <class MathT>
 struct OpAiiConst {
-    static constexpr bool HAS_B = true;
+    typedef MathT Math;
+    static constexpr bool HAS_EPILOGUE = false;
+    typedef float NB;  // m_j / rho_j
+    MathT m;
     const float4* __restrict__ pm;
     const uint32_t* __restrict__ orig;
     const float* __restrict__ rho;
+    const float* __restrict__ mrho;
     const float* __restrict__ lam_sum;
     const float2* __restrict__ lam_grad;
     float* __restrict__ aii;
@@ -266,34 +314,36 @@ struct OpAiiConst {
         float cf, ax, ay, a2, bx, by;
     };
     __device__ bool skip() const { return false; }
-    __device__ float4 loadA(uint32_t g) const { return pm[g]; }
-    __device__ float4 loadB(uint32_t g) const
+    __device__ void epilogue(Acc&, bool, uint32_t) const {}
+    __device__ float4 loadA(uint32_t j) const { return pm[j]; }
+    __device__ NB nb(const Acc&, uint32_t j, float4) const { return mrho[j]; }
+    __device__ void begin(Acc& a, uint32_t, float4) const { a.cf = a.ax = a.ay = a.a2 = a.bx = a.by = 0.f; }
+    __device__ void pair(Acc& a, float4 Aj, NB mr, float dx, float dy, float r2, float hij) const
     {
-        float r = rho[g];
-        return make_float4(r, pm[g].z / r, 0.f, 0.f);  // rho_j, m_j / rho_j
-    }
-    __device__ void begin(Acc& a, uint32_t, float4, float4) const { a.cf = a.ax = a.ay = a.a2 = a.bx = a.by = 0.f; }
-    __device__ void pair(Acc& a, float4 Aj, float4 Bj, float dx, float dy, float r2, float hij) const
-    {
-        a.cf += Bj.y * kernel_w<EXACT>(r2, hij);
+        a.cf += mr * m.w(r2, hij);
         float gx, gy;
-        kernel_grad<EXACT>(dx, dy, r2, hij, gx, gy);
+        m.grad(dx, dy, r2, hij, gx, gy);
         a.ax += Aj.z * gx;
         a.ay += Aj.z * gy;
         if (sp.opdisc == SPH_OP_WINCHENBACH2020) {
-            a.bx += Bj.y * gx;
-            a.by += Bj.y * gy;
-            a.a2 += Bj.y * (gx * gx + gy * gy);
+            a.bx += mr * gx;
+            a.by += mr * gy;
+            a.a2 += mr * (gx * gx + gy * gy);
         } else {
             a.a2 += Aj.z * (gx * gx + gy * gy);
         }
     }
-    __device__ void finish(Acc& a, uint32_t gi, float4 Ai, float4 Bi) const
+    __device__ bool finish(Acc& a, uint32_t i, float4 Ai, bool wall) const
     {
-        constf[gi] = a.cf + lam_sum[gi] / sp.rest_density;
-        const float mi = Ai.z, rho_i = Bi.x, rho_b = sp.rest_density;
+        float ls = 0.f;
+        float2 gl = make_float2(0.f, 0.f);
+        if (wall) {
+            ls = lam_sum[i];
+            gl = lam_grad[i];
+        }
+        constf[i] = a.cf + ls / sp.rest_density;
+        const float mi = Ai.z, rho_i = rho[i], rho_b = sp.rest_density;
         const float rho_i_sq = rho_i * rho_i;
-        const float2 gl = lam_grad[gi];
         float v;
         if (sp.opdisc == SPH_OP_WINCHENBACH2020) {
             float f = rho_b * (1.f / (rho_i * rho_i) + 0.f / (rho_b * rho_b));
@@ -308,8 +358,9 @@ struct OpAiiConst {
             float rx = a.ax / rho_i + rgx / rho_i, ry = a.ay / rho_i + rgy / rho_i;
             v = (lx * rx + ly * ry) + (mi * a.a2) / (rho_i * rho_i * rho_i);
         }
-        aii[gi] = v;
-        if (!isfinite(v)) raise_error(status, SPH_ERR_AII_NOT_FINITE, orig[gi]);
+        aii[i] = v;
+        if (!isfinite(v)) raise_error(status, SPH_ERR_AII_NOT_FINITE, orig[i]);
+        return wall;
     }
 };
 
@@ -318,11 +369,16 @@ struct OpAiiConst {
 //   update_velocity_with_non_pressure_accel / calculate_particle_non_pressure_accel
 //   simulation.rs:1051-1077, 931-1005
 // ------------------------------------------------------------------------------------------------
-// pair() needs the particle's own (rho_i, v_i): the skeleton passes only the neighbour payload, so
-// the op keeps a copy of Bi in its accumulator.
-template <bool EXACT>
+struct NBRhoVel {
+    float rho, vx, vy;
+};
+
+template <class MathT>
 struct OpNonPressure {
-    static constexpr bool HAS_B = true;
+    typedef MathT Math;
+    static constexpr bool HAS_EPILOGUE = false;
+    typedef NBRhoVel NB;
+    MathT m;
     const float4* __restrict__ pm;
     const uint32_t* __restrict__ orig;
     const float* __restrict__ rho;
@@ -334,31 +390,33 @@ struct OpNonPressure {
         float vx, vy, rho_i, vix, viy;
     };
     __device__ bool skip() const { return false; }
-    __device__ float4 loadA(uint32_t g) const { return pm[g]; }
-    __device__ float4 loadB(uint32_t g) const
+    __device__ void epilogue(Acc&, bool, uint32_t) const {}
+    __device__ float4 loadA(uint32_t j) const { return pm[j]; }
+    __device__ NB nb(const Acc&, uint32_t j, float4) const
     {
-        float2 v = vel[g];
-        return make_float4(rho[g], v.x, v.y, 0.f);
+        float2 v = vel[j];
+        return NB{rho[j], v.x, v.y};
     }
-    __device__ void begin(Acc& a, uint32_t, float4, float4 Bi) const
+    __device__ void begin(Acc& a, uint32_t i, float4) const
     {
         a.vx = a.vy = 0.f;
-        a.rho_i = Bi.x;
-        a.vix = Bi.y;
-        a.viy = Bi.z;
+        a.rho_i = rho[i];
+        float2 v = vel[i];
+        a.vix = v.x;
+        a.viy = v.y;
     }
-    __device__ void pair(Acc& a, float4 Aj, float4 Bj, float dx, float dy, float r2, float hij) const
+    __device__ void pair(Acc& a, float4 Aj, NB Bj, float dx, float dy, float r2, float hij) const
     {
-        const float ux = a.vix - Bj.y, uy = a.viy - Bj.z;
+        const float ux = a.vix - Bj.vx, uy = a.viy - Bj.vy;
         if (sp.viscosity_type == SPH_VISC_APPROX_LAPLACE) {
             const float xv = dx * ux + dy * uy;
             if (xv >= 0.f) return;
             float gx, gy;
-            kernel_grad<EXACT>(dx, dy, r2, hij, gx, gy);
-            const float rho_ij = (a.rho_i + Bj.x) * 0.5f;
+            m.grad(dx, dy, r2, hij, gx, gy);
+            const float rho_ij = (a.rho_i + Bj.rho) * 0.5f;
             const float den = r2 + 0.01f * hij * hij;
             float coeff;
-            if (EXACT) coeff = 2.f * 4.f * (Aj.z / rho_ij) * xv / den;
+            if (MathT::EXACT) coeff = 2.f * 4.f * (Aj.z / rho_ij) * xv / den;
             else coeff = 8.f * (Aj.z * fast_rcp(rho_ij)) * xv * fast_rcp(den);
             const float f = sp.viscosity * coeff;
             a.vx += f * gx;
@@ -367,14 +425,14 @@ struct OpNonPressure {
             const float est = ux * dx + uy * dy;
             if (est < 0.f) {
                 float gx, gy;
-                kernel_grad<EXACT>(dx, dy, r2, hij, gx, gy);
+                m.grad(dx, dy, r2, hij, gx, gy);
                 const float den = r2 + 0.001f * hij * hij;
                 float viscous_term, pi_ab;
-                if (EXACT) {
-                    viscous_term = 2.f * sp.viscosity * hij * 88.f / (a.rho_i + Bj.x);
+                if (MathT::EXACT) {
+                    viscous_term = 2.f * sp.viscosity * hij * 88.f / (a.rho_i + Bj.rho);
                     pi_ab = -viscous_term * est / den;
                 } else {
-                    viscous_term = 2.f * sp.viscosity * hij * 88.f * fast_rcp(a.rho_i + Bj.x);
+                    viscous_term = 2.f * sp.viscosity * hij * 88.f * fast_rcp(a.rho_i + Bj.rho);
                     pi_ab = -viscous_term * est * fast_rcp(den);
                 }
                 const float f = -Aj.z * pi_ab;
@@ -383,7 +441,7 @@ struct OpNonPressure {
             }
         }
     }
-    __device__ void finish(Acc& a, uint32_t gi, float4 Ai, float4) const
+    __device__ bool finish(Acc& a, uint32_t i, float4 Ai, bool wall) const
     {
         float px = 0.f, py = 0.f;
         if (sp.has_pull) {
@@ -394,58 +452,106 @@ struct OpNonPressure {
         }
         const float ax = (a.vx + 0.f) + px;
         const float ay = (a.vy + sp.gravity) + py;
-        if (!isfinite(a.vx) || !isfinite(a.vy)) raise_error(status, SPH_ERR_VISCOSITY_NOT_FINITE, orig[gi]);
-        vel_out[gi] = make_float2(a.vix + sp.dt * ax, a.viy + sp.dt * ay);
+        if (!isfinite(a.vx) || !isfinite(a.vy)) raise_error(status, SPH_ERR_VISCOSITY_NOT_FINITE, orig[i]);
+        vel_out[i] = make_float2(a.vix + sp.dt * ax, a.viy + sp.dt * ay);
+        return wall;
     }
 };
 
 // ------------------------------------------------------------------------------------------------
-// Op: PPE source term (+ pressure := 0)
+// Op: PPE source term (+ pressure := 0, p/rho^2 := 0)
 //   prepare_ppe_divergence / prepare_full_ppe / prepare_only_density_part_ppe   simulation.rs:1127-1204
 //   calculate_source_term_divergence/_full/_only_density_part                   simulation.rs:1633-1676, 1712-1748
 //   calculate_divergence_iisph (+ boundary part)    simulation.rs:1552-1592, boundary_winchenbach2020.rs:196-223
 // ------------------------------------------------------------------------------------------------
-template <bool EXACT>
+struct NBVecMr {
+    float qx, qy, mr;  // vector quantity Q_j, m_j / rho_j
+};
+
+// block partial of PressureSolverStatistics in fixed lane order (deterministic); k_solver_final adds the
+// block partials in block (= particle) order.  cls: 0 normal, 1 singular, 2 negative, 3 none.
+__device__ __forceinline__ void solver_block_partial(SolverPartial* __restrict__ partials, uint32_t cls, float err, uint32_t blk)
+{
+    __shared__ SolverPartial s_w[SWEEP_THREADS / 64];
+    uint32_t normal = wave_sum_u32(cls == 0u ? 1u : 0u);
+    uint32_t singular = wave_sum_u32(cls == 1u ? 1u : 0u);
+    uint32_t negative = wave_sum_u32(cls == 2u ? 1u : 0u);
+    float sum = wave_sum(cls == 0u ? err : 0.f);
+    float mx = wave_max(cls == 0u ? fabsf(err) : 0.f);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) s_w[w] = SolverPartial{normal, singular, negative, sum, mx};
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        SolverPartial t = s_w[0];
+        for (int k = 1; k < SWEEP_THREADS / 64; k++) {
+            t.normal += s_w[k].normal;
+            t.singular += s_w[k].singular;
+            t.negative += s_w[k].negative;
+            t.sum_err += s_w[k].sum_err;
+            t.max_err = fmaxf(t.max_err, s_w[k].max_err);
+        }
+        partials[blk] = t;
+    }
+}
+
+template <class MathT>
 struct OpSource {
-    static constexpr bool HAS_B = true;
+    typedef MathT Math;
+    static constexpr bool HAS_EPILOGUE = true;
+    typedef NBVecMr NB;
+    MathT m;
     const float4* __restrict__ pm;
+    const uint32_t* __restrict__ orig;
     const float* __restrict__ rho;
+    const float* __restrict__ mrho;
     const float2* __restrict__ vel;
     const float2* __restrict__ lam_grad;
+    const float* __restrict__ aii;
     float* __restrict__ src;
-    float* __restrict__ p_zero;
+    float* __restrict__ p_out;       // pressure after iteration 0 (buffer 1)
+    float* __restrict__ pterm_out;
+    float* __restrict__ dens_err;
+    SolverPartial* __restrict__ partials;
+    DeviceStatus* status;
     StepP sp;
     int kind;  // 0 divergence, 1 full, 2 only density
+    int residual_density;
     struct Acc {
         float sum, rho_i, inv_rho_i, qx, qy;
+        float err;
+        uint32_t cls;
     };
     __device__ bool skip() const { return false; }
-    __device__ float4 loadA(uint32_t g) const { return pm[g]; }
-    __device__ float4 loadB(uint32_t g) const
+    __device__ float4 loadA(uint32_t j) const { return pm[j]; }
+    __device__ NB nb(const Acc&, uint32_t j, float4) const
     {
-        float2 v = vel[g];
-        float r = rho[g];
-        return make_float4(v.x, v.y, pm[g].z / r, r);  // v_j, m_j/rho_j, rho_j
+        float2 v = vel[j];
+        float mr = 0.f;
+        if (sp.opdisc == SPH_OP_WINCHENBACH2020) mr = mrho[j];
+        return NB{v.x, v.y, mr};
     }
-    __device__ void begin(Acc& a, uint32_t, float4, float4 Bi) const
+    __device__ void begin(Acc& a, uint32_t i, float4) const
     {
         a.sum = 0.f;
-        a.rho_i = Bi.w;
-        a.inv_rho_i = fast_rcp(Bi.w);
-        a.qx = Bi.x;
-        a.qy = Bi.y;
+        a.rho_i = rho[i];
+        a.inv_rho_i = fast_rcp(a.rho_i);
+        float2 v = vel[i];
+        a.qx = v.x;
+        a.qy = v.y;
+        a.err = 0.f;
+        a.cls = 3u;
     }
-    __device__ void pair(Acc& a, float4 Aj, float4 Bj, float dx, float dy, float r2, float hij) const
+    __device__ void pair(Acc& a, float4 Aj, NB Bj, float dx, float dy, float r2, float hij) const
     {
         if (kind == 2) return;
         float gx, gy;
-        kernel_grad<EXACT>(dx, dy, r2, hij, gx, gy);
-        const float dot = (Bj.x - a.qx) * gx + (Bj.y - a.qy) * gy;
-        if (sp.opdisc == SPH_OP_WINCHENBACH2020) a.sum += Bj.z * dot;
-        else if (EXACT) a.sum += Aj.z / a.rho_i * dot;
+        m.grad(dx, dy, r2, hij, gx, gy);
+        const float dot = (Bj.qx - a.qx) * gx + (Bj.qy - a.qy) * gy;
+        if (sp.opdisc == SPH_OP_WINCHENBACH2020) a.sum += Bj.mr * dot;
+        else if (MathT::EXACT) a.sum += Aj.z / a.rho_i * dot;
         else a.sum += Aj.z * a.inv_rho_i * dot;
     }
-    __device__ void finish(Acc& a, uint32_t gi, float4, float4) const
+    __device__ bool finish(Acc& a, uint32_t i, float4, bool wall) const
     {
         const float rho_i = a.rho_i, rho_b = sp.rest_density, dt = sp.dt;
         float s;
@@ -453,75 +559,154 @@ struct OpSource {
         if (kind == 2) {
             s = -(sp.rest_density - rho_i) / (nde * dt * dt);
         } else {
-            const float2 gl = lam_grad[gi];
+            float2 gl = make_float2(0.f, 0.f);
+            if (wall) gl = lam_grad[i];
             const float bdot = (0.f - a.qx) * gl.x + (0.f - a.qy) * gl.y;
             const float bdiv = sp.opdisc == SPH_OP_WINCHENBACH2020 ? bdot : rho_b / rho_i * bdot;
             const float vdiv = a.sum + (sp.n_planes ? bdiv : 0.f);
             if (kind == 0) s = -vdiv / dt;
             else s = -(sp.rest_density - rho_i) / (nde * dt * dt) - vdiv / dt;
         }
-        src[gi] = s;
-        p_zero[gi] = 0.f;
+        src[i] = s;
+        // ---- Jacobi iteration 0 (iisph_single_pressure_iteration, simulation.rs:1207-1322) in closed form:
+        // the iteration starts from p = 0, so a^p = 0 and (Ap)_i = 0 for every particle, and
+        //   p' = 0 + w * (s - 0) / a_ii,  err = rho_i dt^2 (s - 0)  or  dt (s - 0)
+        // -- the values the generic sweeps A and B would produce, without their two neighbour passes.
+        const float aii_i = aii[i];
+        if (aii_i < 0.f) raise_error(status, SPH_ERR_AII_NEGATIVE, orig[i]);  // simulation.rs:1390-1403
+        if (fabsf(aii_i) < 10e-4f) {
+            p_out[i] = 0.f;
+            pterm_out[i] = 0.f;
+            a.cls = 1u;
+            return wall;
+        }
+        const float a_p = 0.f;
+        float pn = 0.f + sp.jacobi_omega * (s - a_p) / aii_i;
+        if (!isfinite(pn)) raise_error(status, SPH_ERR_PRESSURE_NOT_FINITE, orig[i]);
+        float err;
+        if (residual_density) {
+            err = rho_i * dt * dt * (s - a_p);
+            dens_err[i] = err;
+        } else {
+            err = dt * (s - a_p);
+        }
+        if (pn <= 0.f) {
+            p_out[i] = 0.f;
+            pterm_out[i] = 0.f;
+            a.cls = 2u;
+        } else {
+            p_out[i] = pn;
+            pterm_out[i] = pn / (rho_i * rho_i);
+            a.cls = 0u;
+            a.err = err;
+        }
+        return wall;
     }
+    __device__ void epilogue(Acc& a, bool active, uint32_t blk) const { solver_block_partial(partials, active ? a.cls : 3u, a.err, blk); }
 };
 
 // ------------------------------------------------------------------------------------------------
 // Op: pressure acceleration (Jacobi sweep A)
 //   calculate_particle_pressure_accel(s) / calculate_fluid_fluid_pressure_accel   simulation.rs:1518-1543, 1750-1808
 //   iisph_boundary_pressure_accel                                  boundary_winchenbach2020.rs:164-194
+// The neighbour payload p_j / rho_j^2 is written once per particle by the sweep that produced p.
 // ------------------------------------------------------------------------------------------------
-template <bool EXACT>
+// tail modes of the FINAL sweep (the one after the stop decision, simulation.rs:1499-1509):
+//   TAIL_NONE                 just a^p
+//   TAIL_VEL      HybridDFSPH after the divergence solve: v += dt a^p                    (simulation.rs:2547-2560)
+//   TAIL_VX       IISPH / OnlyDivergence: v += dt a^p ; x += dt v                         (simulation.rs:2433-2445, 2486-2499)
+//   TAIL_HYBRID   HybridDFSPH: x += dt v + dt^2 a^p ; v += dt a^p * min(dt*factor, 1)   (simulation.rs:2644-2646)
+// The final sweep is queued speculatively behind the predicted last iteration and runs only once the
+// device-side stop decision has been taken (ctrl->done).
+enum { TAIL_NONE = 0, TAIL_VEL = 1, TAIL_VX = 2, TAIL_HYBRID = 3 };
+
+template <class MathT>
 struct OpPressureAccel {
-    static constexpr bool HAS_B = true;
+    typedef MathT Math;
+    static constexpr bool HAS_EPILOGUE = false;
+    typedef float NB;  // p_j / (rho_j * rho_j)
+    MathT m;
     const float4* __restrict__ pm;
+    const uint32_t* __restrict__ orig;
     const float* __restrict__ rho;
     const float* __restrict__ p0;
     const float* __restrict__ p1;
+    const float* __restrict__ pt0;
+    const float* __restrict__ pt1;
     const float2* __restrict__ lam_grad;
     float2* __restrict__ pacc;
+    float2* __restrict__ vel;
+    float4* __restrict__ pm_out;
     const SolverCtrl* __restrict__ ctrl;
+    DeviceStatus* status;
     StepP sp;
     int iter;  // >= 0: Jacobi iteration `iter` (reads buffer iter&1, skipped when the solve is done); < 0: final sweep
+    int tail;
     struct Acc {
         float ax, ay, p1t;
+        const float* pt;
+        const float* p;
     };
-    __device__ bool skip() const { return iter >= 0 && ctrl->done != 0u; }
-    __device__ const float* pbuf() const
+    __device__ bool skip() const { return iter >= 0 ? ctrl->done != 0u : ctrl->done == 0u; }
+    __device__ void epilogue(Acc&, bool, uint32_t) const {}
+    __device__ float4 loadA(uint32_t j) const { return pm[j]; }
+    __device__ NB nb(const Acc& a, uint32_t j, float4) const { return a.pt[j]; }
+    __device__ void begin(Acc& a, uint32_t i, float4) const
     {
-        uint32_t cur = iter >= 0 ? (uint32_t)(iter & 1) : ctrl->cur;
-        return cur ? p1 : p0;
-    }
-    __device__ float4 loadA(uint32_t g) const { return pm[g]; }
-    __device__ float4 loadB(uint32_t g) const
-    {
-        float r = rho[g], p = pbuf()[g];
-        return make_float4(p / (r * r), p, r, 0.f);  // p_j / rho_j^2, p_j, rho_j
-    }
-    __device__ void begin(Acc& a, uint32_t, float4, float4 Bi) const
-    {
+        const uint32_t cur = iter >= 0 ? (uint32_t)(iter & 1) : ctrl->cur;
+        a.pt = cur ? pt1 : pt0;
+        a.p = cur ? p1 : p0;
         a.ax = a.ay = 0.f;
-        a.p1t = Bi.x;
+        a.p1t = a.pt[i];
     }
-    __device__ void pair(Acc& a, float4 Aj, float4 Bj, float dx, float dy, float r2, float hij) const
+    __device__ void pair(Acc& a, float4 Aj, NB ptj, float dx, float dy, float r2, float hij) const
     {
         float gx, gy;
-        kernel_grad<EXACT>(dx, dy, r2, hij, gx, gy);
-        const float f = -Aj.z * (a.p1t + Bj.x);
+        m.grad(dx, dy, r2, hij, gx, gy);
+        const float f = -Aj.z * (a.p1t + ptj);
         a.ax += f * gx;
         a.ay += f * gy;
     }
-    __device__ void finish(Acc& a, uint32_t gi, float4, float4 Bi) const
+    __device__ bool finish(Acc& a, uint32_t i, float4 Ai, bool wall) const
     {
         float bx = 0.f, by = 0.f;
-        if (sp.n_planes) {
-            const float p_i = Bi.y, rho_i = Bi.z, rho_b = sp.rest_density;
+        if (sp.n_planes && wall) {
+            const float p_i = a.p[i], rho_i = rho[i], rho_b = sp.rest_density;
             const float p_ib = sp.opdisc == SPH_OP_SYMMETRIC_GRADIENT ? p_i : 0.f;
             const float f = -rho_b * (p_i / (rho_i * rho_i) + p_ib / (rho_b * rho_b));
-            const float2 gl = lam_grad[gi];
+            const float2 gl = lam_grad[i];
             bx = f * gl.x;
             by = f * gl.y;
         }
-        pacc[gi] = make_float2(a.ax + bx, a.ay + by);
+        const float2 ap = make_float2(a.ax + bx, a.ay + by);
+        pacc[i] = ap;
+        if (tail != TAIL_NONE) {
+            const float dt = sp.dt;
+            float2 v = vel[i];
+            if (tail == TAIL_VEL) {
+                v.x += dt * ap.x;
+                v.y += dt * ap.y;
+                if (!isfinite(v.x) || !isfinite(v.y)) raise_error(status, SPH_ERR_VELOCITY_NOT_FINITE, orig[i]);
+            } else if (tail == TAIL_VX) {
+                float4 p = Ai;
+                v.x += dt * ap.x;
+                v.y += dt * ap.y;
+                p.x += dt * v.x;
+                p.y += dt * v.y;
+                if (!isfinite(v.x) || !isfinite(v.y)) raise_error(status, SPH_ERR_VELOCITY_NOT_FINITE, orig[i]);
+                pm_out[i] = p;
+            } else {
+                float4 p = Ai;
+                p.x += dt * v.x + dt * dt * ap.x;
+                p.y += dt * v.y + dt * dt * ap.y;
+                v.x += dt * ap.x * sp.hyb_vfactor;
+                v.y += dt * ap.y * sp.hyb_vfactor;
+                if (!isfinite(p.x) || !isfinite(p.y)) raise_error(status, SPH_ERR_POSITION_NOT_FINITE, orig[i]);
+                pm_out[i] = p;
+            }
+            vel[i] = v;
+        }
+        return wall;
     }
 };
 
@@ -532,23 +717,25 @@ struct OpPressureAccel {
 // Per-particle residual class goes to stat[] (normal: the error; singular / negative: tagged NaNs),
 // reduced in fixed particle order by k_solver_reduce.
 // ------------------------------------------------------------------------------------------------
-#define STAT_SINGULAR 0x7fc00001u
-#define STAT_NEGATIVE 0x7fc00002u
-
-template <bool EXACT>
+template <class MathT>
 struct OpJacobi {
-    static constexpr bool HAS_B = true;
+    typedef MathT Math;
+    static constexpr bool HAS_EPILOGUE = true;
+    typedef NBVecMr NB;
+    MathT m;
     const float4* __restrict__ pm;
     const uint32_t* __restrict__ orig;
     const float* __restrict__ rho;
+    const float* __restrict__ mrho;
     const float2* __restrict__ pacc;
     const float2* __restrict__ lam_grad;
     const float* __restrict__ aii;
     const float* __restrict__ src;
     const float* __restrict__ p_in;
     float* __restrict__ p_out;
+    float* __restrict__ pterm_out;
     float* __restrict__ dens_err;
-    float* __restrict__ stat;
+    SolverPartial* __restrict__ partials;
     const SolverCtrl* __restrict__ ctrl;
     DeviceStatus* status;
     StepP sp;
@@ -556,134 +743,118 @@ struct OpJacobi {
     int residual_density;
     struct Acc {
         float sum, rho_i, inv_rho_i, qx, qy;
+        float err;       // residual of a "normal" particle
+        uint32_t cls;    // 0 normal, 1 singular, 2 negative (PressureSolverStatistics, simulation.rs:397-445)
     };
     __device__ bool skip() const { return ctrl->done != 0u; }
-    __device__ float4 loadA(uint32_t g) const { return pm[g]; }
-    __device__ float4 loadB(uint32_t g) const
+    __device__ float4 loadA(uint32_t j) const { return pm[j]; }
+    __device__ NB nb(const Acc&, uint32_t j, float4) const
     {
-        float2 a = pacc[g];
-        float r = rho[g];
-        return make_float4(a.x, a.y, pm[g].z / r, r);
+        float2 a = pacc[j];
+        float mr = 0.f;
+        if (sp.opdisc == SPH_OP_WINCHENBACH2020) mr = mrho[j];
+        return NB{a.x, a.y, mr};
     }
-    __device__ void begin(Acc& a, uint32_t, float4, float4 Bi) const
+    __device__ void begin(Acc& a, uint32_t i, float4) const
     {
         a.sum = 0.f;
-        a.rho_i = Bi.w;
-        a.inv_rho_i = fast_rcp(Bi.w);
-        a.qx = Bi.x;
-        a.qy = Bi.y;
+        a.rho_i = rho[i];
+        a.inv_rho_i = fast_rcp(a.rho_i);
+        float2 q = pacc[i];
+        a.qx = q.x;
+        a.qy = q.y;
+        a.err = 0.f;
+        a.cls = 3u;
     }
-    __device__ void pair(Acc& a, float4 Aj, float4 Bj, float dx, float dy, float r2, float hij) const
+    __device__ void pair(Acc& a, float4 Aj, NB Bj, float dx, float dy, float r2, float hij) const
     {
         float gx, gy;
-        kernel_grad<EXACT>(dx, dy, r2, hij, gx, gy);
-        const float dot = (Bj.x - a.qx) * gx + (Bj.y - a.qy) * gy;
-        if (sp.opdisc == SPH_OP_WINCHENBACH2020) a.sum += Bj.z * dot;
-        else if (EXACT) a.sum += Aj.z / a.rho_i * dot;
+        m.grad(dx, dy, r2, hij, gx, gy);
+        const float dot = (Bj.qx - a.qx) * gx + (Bj.qy - a.qy) * gy;
+        if (sp.opdisc == SPH_OP_WINCHENBACH2020) a.sum += Bj.mr * dot;
+        else if (MathT::EXACT) a.sum += Aj.z / a.rho_i * dot;
         else a.sum += Aj.z * a.inv_rho_i * dot;
     }
-    __device__ void finish(Acc& a, uint32_t gi, float4, float4) const
+    __device__ bool finish(Acc& a, uint32_t i, float4, bool wall) const
     {
-        const float aii_i = aii[gi];
-        if (iter == 0 && aii_i < 0.f) raise_error(status, SPH_ERR_AII_NEGATIVE, orig[gi]);
+        const float aii_i = aii[i];
         if (fabsf(aii_i) < 10e-4f) {
-            p_out[gi] = 0.f;
-            stat[gi] = __uint_as_float(STAT_SINGULAR);
-            return;
+            p_out[i] = 0.f;
+            pterm_out[i] = 0.f;
+            a.cls = 1u;
+            return wall;
         }
         const float rho_i = a.rho_i, rho_b = sp.rest_density, dt = sp.dt;
         float bdiv = 0.f;
-        if (sp.n_planes) {
-            const float2 gl = lam_grad[gi];
+        if (sp.n_planes && wall) {
+            const float2 gl = lam_grad[i];
             const float bdot = (0.f - a.qx) * gl.x + (0.f - a.qy) * gl.y;
             bdiv = sp.opdisc == SPH_OP_WINCHENBACH2020 ? bdot : rho_b / rho_i * bdot;
         }
         const float a_p = a.sum + bdiv;
-        const float s = src[gi];
-        if (!isfinite(a_p)) raise_error(status, SPH_ERR_AP_NOT_FINITE, orig[gi]);
-        float pn = p_in[gi] + sp.jacobi_omega * (s - a_p) / aii_i;
-        if (!isfinite(pn)) raise_error(status, SPH_ERR_PRESSURE_NOT_FINITE, orig[gi]);
+        const float s = src[i];
+        if (!isfinite(a_p)) raise_error(status, SPH_ERR_AP_NOT_FINITE, orig[i]);
+        float pn = p_in[i] + sp.jacobi_omega * (s - a_p) / aii_i;
+        if (!isfinite(pn)) raise_error(status, SPH_ERR_PRESSURE_NOT_FINITE, orig[i]);
         float err;
         if (residual_density) {
             err = rho_i * dt * dt * (s - a_p);
-            dens_err[gi] = err;
+            dens_err[i] = err;
         } else {
             err = dt * (s - a_p);
         }
         if (pn <= 0.f) {  // clamp_negative_pressures is true at every call site
-            p_out[gi] = 0.f;
-            stat[gi] = __uint_as_float(STAT_NEGATIVE);
+            p_out[i] = 0.f;
+            pterm_out[i] = 0.f;
+            a.cls = 2u;
         } else {
-            p_out[gi] = pn;
-            stat[gi] = err;
+            p_out[i] = pn;
+            pterm_out[i] = pn / (rho_i * rho_i);  // p_j / (rho_j * rho_j) of calculate_fluid_fluid_pressure_accel
+            a.cls = 0u;
+            a.err = err;
         }
+        return wall;
     }
+    __device__ void epilogue(Acc& a, bool active, uint32_t blk) const { solver_block_partial(partials, active ? a.cls : 3u, a.err, blk); }
 };
 
 // ------------------------------------------------------------------------------------------------
 // residual reduction + stop decision    (PressureSolverStatistics simulation.rs:397-469,
 // stopping rule of iisph_pressure_iterations simulation.rs:1453-1479)
-// Fixed particle-order chunks -> block partials -> the last block to arrive (agent-scope
-// release/acquire around the ticket) adds them in index order: deterministic.
+// One 1024-thread block adds the Jacobi kernel's per-block partials in a fixed order (deterministic;
+// the reference's rayon tree order is not) and takes the stop decision on the device.
 // ------------------------------------------------------------------------------------------------
-#define REDUCE_BLOCKS 128
-
-__global__ __launch_bounds__(256) void k_solver_reduce(const float* __restrict__ stat, uint32_t n, SolverCtrl* ctrl,
-                                                        SolverPartial* partials, int iter, int residual_density, float max_avg_error,
-                                                        uint32_t max_iters, float rest_density, float dt)
+__global__ __launch_bounds__(1024) void k_solver_final(const SolverPartial* __restrict__ partials, uint32_t nparts, SolverCtrl* ctrl, int iter,
+                                                        int residual_density, float max_avg_error, uint32_t max_iters, float rest_density,
+                                                        float dt)
 {
     if (ctrl->done) return;
-    __shared__ SolverPartial s_w[4];
-    __shared__ bool s_last;
+    __shared__ SolverPartial s_w[16];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const uint32_t chunk = (n + REDUCE_BLOCKS - 1) / REDUCE_BLOCKS;
-    const uint32_t b0 = blockIdx.x * chunk, b1 = min(b0 + chunk, n);
-    uint32_t normal = 0, singular = 0, negative = 0;
-    float sum = 0.f, mx = 0.f;
-    for (uint32_t i = b0 + tid; i < b1; i += 256) {
-        float v = stat[i];
-        uint32_t bits = __float_as_uint(v);
-        if (bits == STAT_SINGULAR) singular++;
-        else if (bits == STAT_NEGATIVE) negative++;
-        else {
-            normal++;
-            sum += v;
-            mx = fmaxf(mx, fabsf(v));
-        }
+    SolverPartial t{0, 0, 0, 0.f, 0.f};
+    for (uint32_t k = tid; k < nparts; k += 1024) {
+        const SolverPartial q = partials[k];
+        t.normal += q.normal;
+        t.singular += q.singular;
+        t.negative += q.negative;
+        t.sum_err += q.sum_err;
+        t.max_err = fmaxf(t.max_err, q.max_err);
     }
-    normal = wave_sum_u32(normal);
-    singular = wave_sum_u32(singular);
-    negative = wave_sum_u32(negative);
-    sum = wave_sum(sum);
-    mx = wave_max(mx);
-    if (lane == 0) s_w[w] = SolverPartial{normal, singular, negative, sum, mx};
+    t.normal = wave_sum_u32(t.normal);
+    t.singular = wave_sum_u32(t.singular);
+    t.negative = wave_sum_u32(t.negative);
+    t.sum_err = wave_sum(t.sum_err);
+    t.max_err = wave_max(t.max_err);
+    if (lane == 0) s_w[w] = t;
     __syncthreads();
     if (tid == 0) {
-        SolverPartial t = s_w[0];
-        for (int k = 1; k < 4; k++) {
+        t = s_w[0];
+        for (int k = 1; k < 16; k++) {
             t.normal += s_w[k].normal;
             t.singular += s_w[k].singular;
             t.negative += s_w[k].negative;
             t.sum_err += s_w[k].sum_err;
             t.max_err = fmaxf(t.max_err, s_w[k].max_err);
-        }
-        partials[blockIdx.x] = t;
-        __threadfence();  // agent-scope release of the partial before the ticket
-        uint32_t prev = atomicAdd(&ctrl->ticket, 1u);
-        s_last = (prev == gridDim.x - 1);
-    }
-    __syncthreads();
-    if (!s_last) return;
-    if (tid == 0) {
-        __threadfence();  // agent-scope acquire: drop stale L1 lines before reading the other blocks' partials
-        SolverPartial t{0, 0, 0, 0.f, 0.f};
-        for (uint32_t k = 0; k < gridDim.x; k++) {
-            const volatile uint32_t* q = (const volatile uint32_t*)&partials[k];
-            t.normal += q[0];
-            t.singular += q[1];
-            t.negative += q[2];
-            t.sum_err += __uint_as_float(q[3]);
-            t.max_err = fmaxf(t.max_err, __uint_as_float(q[4]));
         }
         const float avg = t.normal > 0 ? t.sum_err / (float)t.normal : __uint_as_float(0x7fc00000u);
         bool stop;
@@ -697,7 +868,6 @@ __global__ __launch_bounds__(256) void k_solver_reduce(const float* __restrict__
         ctrl->max_err = t.max_err;
         ctrl->iters = (uint32_t)iter;
         ctrl->cur = (uint32_t)((iter + 1) & 1);  // mem::swap(pressure, pressure_next_iter)
-        ctrl->ticket = 0;
         if (stop) ctrl->done = 1u;
     }
 }
@@ -748,78 +918,74 @@ __global__ __launch_bounds__(256) void k_integrate(uint32_t n, float dt, float v
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
-static SweepCommon common_of(const SweepArgs& a) { return SweepCommon{a.g, a.cell_start, a.tiles, a.n_tiles, a.cxy}; }
+static SweepCommon common_of(const SweepArgs& a)
+{
+    return SweepCommon{a.g, a.n, (a.n + SWEEP_THREADS - 1) / SWEEP_THREADS, a.cell_start, a.nl};
+}
 
-template <class Op>
+template <class Op, bool BUILD>
 static void launch_sweep(hipStream_t s, const SweepArgs& a, const Op& op)
 {
-    hipLaunchKernelGGL((k_sweep<Op, TILE_TX, TILE_TY, TILE_CAP>), dim3(a.grid_blocks), dim3(TILE_THREADS), 0, s, op, common_of(a));
+    const uint32_t nblocks = (a.n + SWEEP_THREADS - 1) / SWEEP_THREADS;
+    const uint32_t grid = ((nblocks + 7) / 8) * 8;  // XCD remap needs a multiple of 8
+    hipLaunchKernelGGL((k_sweep<Op, BUILD>), dim3(grid), dim3(SWEEP_THREADS), 0, s, op, common_of(a));
 }
 
-void sweep_tile_dims(int* tx, int* ty)
+size_t sweep_list_bytes(uint32_t n) { return (size_t)n * sizeof(uint4); }
+uint32_t solver_reduce_blocks(uint32_t n) { return (n + SWEEP_THREADS - 1) / SWEEP_THREADS; }
+
+static MathUniform uniform_math(float h)
 {
-    *tx = TILE_TX;
-    *ty = TILE_TY;
+    MathUniform m;
+    m.h = h;
+    m.nf = 10.f / (SPH_SEVEN_PI * (h * h));
+    m.inv2h = 1.f / (2.f * h);
+    return m;
 }
+
+// math mode dispatch: EXACT (diagnostic) / UNIFORM (all h identical) / FAST
+#define SPH_DISPATCH(OPNAME, BUILD, ...)                                                   \
+    if (a.exact) {                                                                         \
+        OPNAME<MathExact> op{MathExact{0.f}, __VA_ARGS__};                                 \
+        launch_sweep<OPNAME<MathExact>, BUILD>(s, a, op);                                  \
+    } else if (a.uniform_h) {                                                              \
+        OPNAME<MathUniform> op{uniform_math(a.h_uniform), __VA_ARGS__};                    \
+        launch_sweep<OPNAME<MathUniform>, BUILD>(s, a, op);                                \
+    } else {                                                                               \
+        OPNAME<MathFast> op{MathFast{0.f}, __VA_ARGS__};                                   \
+        launch_sweep<OPNAME<MathFast>, BUILD>(s, a, op);                                   \
+    }
 
 void launch_density(hipStream_t s, Profiler* prof, const SweepArgs& a)
 {
     ProfScope ps(prof, "density", s);
-    if (a.exact) {
-        OpDensity<true> op{a.pm, a.orig, a.rho, a.lam_sum, a.lam_grad, a.ncount, a.planes, a.lam_lut, a.dlam_lut, a.status, a.sp};
-        launch_sweep(s, a, op);
-    } else {
-        OpDensity<false> op{a.pm, a.orig, a.rho, a.lam_sum, a.lam_grad, a.ncount, a.planes, a.lam_lut, a.dlam_lut, a.status, a.sp};
-        launch_sweep(s, a, op);
-    }
+    SPH_DISPATCH(OpDensity, true, a.pm, a.orig, a.rho, a.mrho, a.lam_sum, a.lam_grad, a.ncount, a.planes, a.lam_lut, a.dlam_lut, a.status, a.sp)
 }
 
 void launch_aii_const(hipStream_t s, Profiler* prof, const SweepArgs& a)
 {
     ProfScope ps(prof, "aii_constfield", s);
-    if (a.exact) {
-        OpAiiConst<true> op{a.pm, a.orig, a.rho, a.lam_sum, a.lam_grad, a.aii, a.constf, a.status, a.sp};
-        launch_sweep(s, a, op);
-    } else {
-        OpAiiConst<false> op{a.pm, a.orig, a.rho, a.lam_sum, a.lam_grad, a.aii, a.constf, a.status, a.sp};
-        launch_sweep(s, a, op);
-    }
+    SPH_DISPATCH(OpAiiConst, false, a.pm, a.orig, a.rho, a.mrho, a.lam_sum, a.lam_grad, a.aii, a.constf, a.status, a.sp)
 }
 
 void launch_non_pressure(hipStream_t s, Profiler* prof, const SweepArgs& a)
 {
     ProfScope ps(prof, "non_pressure_accel", s);
-    if (a.exact) {
-        OpNonPressure<true> op{a.pm, a.orig, a.rho, a.vel, a.vel_tmp, a.status, a.sp};
-        launch_sweep(s, a, op);
-    } else {
-        OpNonPressure<false> op{a.pm, a.orig, a.rho, a.vel, a.vel_tmp, a.status, a.sp};
-        launch_sweep(s, a, op);
-    }
+    SPH_DISPATCH(OpNonPressure, false, a.pm, a.orig, a.rho, a.vel, a.vel_tmp, a.status, a.sp)
 }
 
-void launch_source_term(hipStream_t s, Profiler* prof, const SweepArgs& a, int kind)
+void launch_source_term(hipStream_t s, Profiler* prof, const SweepArgs& a, int kind, int residual_density)
 {
     ProfScope ps(prof, "source_term", s);
-    if (a.exact) {
-        OpSource<true> op{a.pm, a.rho, a.vel, a.lam_grad, a.src, a.p0, a.sp, kind};
-        launch_sweep(s, a, op);
-    } else {
-        OpSource<false> op{a.pm, a.rho, a.vel, a.lam_grad, a.src, a.p0, a.sp, kind};
-        launch_sweep(s, a, op);
-    }
+    SPH_DISPATCH(OpSource, false, a.pm, a.orig, a.rho, a.mrho, a.vel, a.lam_grad, a.aii, a.src, a.p1, a.pt1, a.dens_err,
+                 (SolverPartial*)a.partials, a.status, a.sp, kind, residual_density)
 }
 
-void launch_pressure_accel(hipStream_t s, Profiler* prof, const SweepArgs& a, int iter)
+void launch_pressure_accel(hipStream_t s, Profiler* prof, const SweepArgs& a, int iter, int tail, float4* pm_out)
 {
-    ProfScope ps(prof, "pressure_accel", s);
-    if (a.exact) {
-        OpPressureAccel<true> op{a.pm, a.rho, a.p0, a.p1, a.lam_grad, a.pacc, a.ctrl, a.sp, iter};
-        launch_sweep(s, a, op);
-    } else {
-        OpPressureAccel<false> op{a.pm, a.rho, a.p0, a.p1, a.lam_grad, a.pacc, a.ctrl, a.sp, iter};
-        launch_sweep(s, a, op);
-    }
+    ProfScope ps(prof, iter >= 0 ? "pressure_accel" : "pressure_accel_final", s);
+    SPH_DISPATCH(OpPressureAccel, false, a.pm, a.orig, a.rho, a.p0, a.p1, a.pt0, a.pt1, a.lam_grad, a.pacc, a.vel, pm_out, a.ctrl, a.status, a.sp,
+                 iter, tail)
 }
 
 void launch_jacobi_update(hipStream_t s, Profiler* prof, const SweepArgs& a, int iter, int residual_density)
@@ -827,20 +993,16 @@ void launch_jacobi_update(hipStream_t s, Profiler* prof, const SweepArgs& a, int
     ProfScope ps(prof, "jacobi_update", s);
     const float* pin = (iter & 1) ? a.p1 : a.p0;
     float* pout = (iter & 1) ? a.p0 : a.p1;
-    if (a.exact) {
-        OpJacobi<true> op{a.pm, a.orig, a.rho, a.pacc, a.lam_grad, a.aii, a.src, pin, pout, a.dens_err, a.stat, a.ctrl, a.status, a.sp, iter, residual_density};
-        launch_sweep(s, a, op);
-    } else {
-        OpJacobi<false> op{a.pm, a.orig, a.rho, a.pacc, a.lam_grad, a.aii, a.src, pin, pout, a.dens_err, a.stat, a.ctrl, a.status, a.sp, iter, residual_density};
-        launch_sweep(s, a, op);
-    }
+    float* ptout = (iter & 1) ? a.pt0 : a.pt1;
+    SPH_DISPATCH(OpJacobi, false, a.pm, a.orig, a.rho, a.mrho, a.pacc, a.lam_grad, a.aii, a.src, pin, pout, ptout, a.dens_err, (SolverPartial*)a.partials, a.ctrl,
+                 a.status, a.sp, iter, residual_density)
 }
 
 void launch_solver_reduce(hipStream_t s, Profiler* prof, const SweepArgs& a, int iter, int residual_density, float max_avg_error,
                           uint32_t max_iters, float* block_partials)
 {
     ProfScope ps(prof, "solver_reduce", s);
-    hipLaunchKernelGGL(k_solver_reduce, dim3(REDUCE_BLOCKS), dim3(256), 0, s, a.stat, a.n, a.ctrl, (SolverPartial*)block_partials, iter,
+    hipLaunchKernelGGL(k_solver_final, dim3(1), dim3(1024), 0, s, (const SolverPartial*)block_partials, solver_reduce_blocks(a.n), a.ctrl, iter,
                        residual_density, max_avg_error, max_iters, a.sp.rest_density, a.sp.dt);
 }
 
@@ -850,9 +1012,9 @@ void launch_vel_add_pacc(hipStream_t s, Profiler* prof, const SweepArgs& a)
     hipLaunchKernelGGL(k_vel_add_pacc, dim3((a.n + 255) / 256), dim3(256), 0, s, a.n, a.sp.dt, a.vel, a.pacc, a.orig, a.status);
 }
 
-void launch_integrate(hipStream_t s, Profiler* prof, const SweepArgs& a, float4* pm_rw, int mode)
+void launch_integrate(hipStream_t s, Profiler* prof, const SweepArgs& a, float4* pm_out, int mode)
 {
     ProfScope ps(prof, "integrate", s);
-    hipLaunchKernelGGL(k_integrate, dim3((a.n + 255) / 256), dim3(256), 0, s, a.n, a.sp.dt, a.sp.hyb_vfactor, mode, a.pm, pm_rw, a.vel, a.pacc,
+    hipLaunchKernelGGL(k_integrate, dim3((a.n + 255) / 256), dim3(256), 0, s, a.n, a.sp.dt, a.sp.hyb_vfactor, mode, a.pm, pm_out, a.vel, a.pacc,
                        a.orig, a.status);
 }
