@@ -34,7 +34,7 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s;
 # algorithmic HBM bytes per particle per launch (DESIGN.md "Kernels")
 ALGO_BYTES = {
     "density": 20, "aii_constfield": 40, "non_pressure_accel": 36, "source_term": 44,
-    "pressure_accel": 40, "jacobi_update": 60, "integrate": 40, "vel_add_pacc": 24,
+    "pressure_accel": 40, "pressure_accel_final": 40, "jacobi_update": 60,
 }
 
 
