@@ -31,7 +31,12 @@ int Profiler::find(const char* name)
     recs.push_back(Rec{name, 0, 0});
     return (int)recs.size() - 1;
 }
-bool Profiler::wants(const char* name) const { return mode == 1 || (mode == 2 && strncmp(name, "density", 7) == 0); }
+bool Profiler::wants(const char* name) const
+{
+    // mode 2: the density kernel only, on every 8th step (a timing-enabled event record forces a command
+    // flush; sampling keeps the perturbation of the timed region below 1 %)
+    return mode == 1 || (mode == 2 && (step_index & 7u) == 0u && strncmp(name, "density", 7) == 0);
+}
 hipEvent_t Profiler::get_event()
 {
     if (!pool.empty()) {
@@ -163,6 +168,17 @@ __global__ __launch_bounds__(256) void k_pack_upload(uint32_t n, const float* __
     orig[i] = i;
     lvl[i] = __uint_as_float(0x7fc00000u);  // LevelEstimationState::FluidInterior
     lvlold[i] = 0.f;
+}
+
+// copy the Jacobi control block and the error word into mapped pinned host memory (one lane); the host
+// busy-polls an event recorded right behind this kernel
+__global__ void k_publish(const SolverCtrl* __restrict__ ctrl, const DeviceStatus* __restrict__ status, SolverCtrl* __restrict__ h_ctrl,
+                          DeviceStatus* __restrict__ h_status)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        *h_ctrl = *ctrl;
+        *h_status = *status;
+    }
 }
 
 enum { G_F32 = 0, G_F32X2 = 1, G_PM_X = 2, G_PM_M = 3, G_PM_H = 4, G_U32 = 5, G_H2NEXT = 6 };
@@ -307,9 +323,14 @@ struct sph_ctx {
     float h_uniform = 0.f;
     DevBuf rho, lam_sum, lam_grad, constf, aii, src, p0, p1, pacc, dens_err, stat, ncount;
     DevBuf planes_d, lam_lut, dlam_lut, hdr_partials, hdr_out, ctrl, status, n_tiles, red_partials, scratch;
-    HeaderOut* hdr_host = nullptr;      // pinned
-    SolverCtrl* ctrl_host = nullptr;    // pinned
-    DeviceStatus* status_host = nullptr;  // pinned
+    // mapped pinned host memory: written by kernels directly (no D2H copy launches)
+    HeaderOut* hdr_host = nullptr;
+    SolverCtrl* ctrl_host = nullptr;
+    DeviceStatus* status_host = nullptr;
+    HeaderOut* hdr_host_dev = nullptr;
+    SolverCtrl* ctrl_host_dev = nullptr;
+    DeviceStatus* status_host_dev = nullptr;
+    hipEvent_t ev_sync = nullptr;
 
     GridP grid{};
     bool grid_valid = false;
@@ -389,9 +410,14 @@ extern "C" int sph_create(uint64_t n_capacity, int device_id, const sph_plane* p
               c->hdr_out.ensure(sizeof(HeaderOut)) == hipSuccess && c->ctrl.ensure(sizeof(SolverCtrl)) == hipSuccess &&
               c->status.ensure(sizeof(DeviceStatus)) == hipSuccess && c->n_tiles.ensure(16) == hipSuccess;
     if (!ok) return bail(SPH_ERR_DEVICE);
-    if (hipHostMalloc((void**)&c->hdr_host, sizeof(HeaderOut)) != hipSuccess) return bail(SPH_ERR_DEVICE);
-    if (hipHostMalloc((void**)&c->ctrl_host, sizeof(SolverCtrl)) != hipSuccess) return bail(SPH_ERR_DEVICE);
-    if (hipHostMalloc((void**)&c->status_host, sizeof(DeviceStatus)) != hipSuccess) return bail(SPH_ERR_DEVICE);
+    if (hipHostMalloc((void**)&c->hdr_host, sizeof(HeaderOut), hipHostMallocMapped) != hipSuccess) return bail(SPH_ERR_DEVICE);
+    if (hipHostMalloc((void**)&c->ctrl_host, sizeof(SolverCtrl), hipHostMallocMapped) != hipSuccess) return bail(SPH_ERR_DEVICE);
+    if (hipHostMalloc((void**)&c->status_host, sizeof(DeviceStatus), hipHostMallocMapped) != hipSuccess) return bail(SPH_ERR_DEVICE);
+    if (hipHostGetDevicePointer((void**)&c->hdr_host_dev, c->hdr_host, 0) != hipSuccess) return bail(SPH_ERR_DEVICE);
+    if (hipHostGetDevicePointer((void**)&c->ctrl_host_dev, c->ctrl_host, 0) != hipSuccess) return bail(SPH_ERR_DEVICE);
+    if (hipHostGetDevicePointer((void**)&c->status_host_dev, c->status_host, 0) != hipSuccess) return bail(SPH_ERR_DEVICE);
+    if (hipEventCreateWithFlags(&c->ev_sync, hipEventDisableTiming) != hipSuccess) return bail(SPH_ERR_DEVICE);
+    memset(c->status_host, 0, sizeof(DeviceStatus));
     // BoundaryWinchenbach2020::new (boundary_winchenbach2020.rs:33-36)
     std::vector<float> lam, dlam;
     sph_lambda::build_luts(lam, dlam);
@@ -421,6 +447,7 @@ extern "C" void sph_destroy(sph_ctx* c)
     if (c->status_host) hipHostFree(c->status_host);
     for (auto& e : c->ev)
         if (e) hipEventDestroy(e);
+    if (c->ev_sync) hipEventDestroy(c->ev_sync);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -654,16 +681,36 @@ static const char* status_message(uint32_t code)
     }
 }
 
-// copy ctrl + status to the host and wait; returns the device error code (0 if none)
+// Wait for everything queued on the context's stream.  Busy-polls an event instead of
+// hipStreamSynchronize: the blocking wait's wake-up latency (tens of microseconds, more once another
+// runtime user in the process has switched the device to blocking-sync scheduling) would otherwise be
+// paid three times per step.
+static int wait_stream(sph_ctx* c)
+{
+    HIPCHK(c, hipEventRecord(c->ev_sync, c->stream));
+    auto t0 = std::chrono::steady_clock::now();
+    for (uint64_t spins = 0;; spins++) {
+        hipError_t e = hipEventQuery(c->ev_sync);
+        if (e == hipSuccess) return SPH_OK;
+        if (e != hipErrorNotReady) return c->fail(SPH_ERR_DEVICE, "hipEventQuery failed: %s", hipGetErrorString(e));
+        if ((spins & 0xfffu) == 0xfffu &&
+            std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 60.0)
+            return c->fail(SPH_ERR_DEVICE, "device did not finish the queued work within 60 s");
+    }
+}
+
+// publish ctrl + status to the host and wait; returns the device error code (0 if none)
 static int sync_ctrl(sph_ctx* c)
 {
     hipStream_t s = c->stream;
-    HIPCHK(c, hipMemcpyAsync(c->ctrl_host, c->ctrl.p, sizeof(SolverCtrl), hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipMemcpyAsync(c->status_host, c->status.p, sizeof(DeviceStatus), hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipStreamSynchronize(s));
+    hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, s, c->ctrl.as<SolverCtrl>(), c->status.as<DeviceStatus>(), c->ctrl_host_dev,
+                       c->status_host_dev);
+    int rc = wait_stream(c);
+    if (rc) return rc;
     if (c->status_host->error) {
         uint32_t code = c->status_host->error, info = c->status_host->info;
-        hipMemsetAsync(c->status.p, 0, sizeof(DeviceStatus), s);
+        (void)hipMemsetAsync(c->status.p, 0, sizeof(DeviceStatus), s);
+        c->status_host->error = 0;
         return c->fail((int)code, "%s (particle i=%u)", status_message(code), info);
     }
     return SPH_OK;
@@ -763,7 +810,11 @@ extern "C" int sph_step(sph_ctx* c, const sph_params* p, sph_step_stats* out)
         return c->fail(SPH_ERR_INVALID_ARGUMENT, "assertion failed: simulation_params.use_extended_range_for_level_estimation");
     if (n == 0) return c->fail(SPH_ERR_INVALID_ARGUMENT, "called `Option::unwrap()` on a `None` value (no particles)");
 
-    hipEventRecord(c->ev[0], s);
+    // phase timing with HIP events only while profiling: a timing-enabled hipEventRecord forces a command
+    // flush, and seven of them cost ~0.3 ms per step; otherwise the host wall clock fills ms_simulation_step
+    const bool tev = c->prof.mode == 1;
+    const auto wall0 = std::chrono::steady_clock::now();
+    if (tev) hipEventRecord(c->ev[0], s);
     int k = c->cur;
 
     // ---- step header: h from mass (simulation.rs:1998-2003), bounding box, CFL term -------------
@@ -773,10 +824,12 @@ extern "C" int sph_step(sph_ctx* c, const sph_params* p, sph_step_stats* out)
         if (nb > HDR_BLOCKS) nb = HDR_BLOCKS;
         hipLaunchKernelGGL(k_header, dim3(nb), dim3(256), 0, s, c->pm[c->pcur].as<float4>(), c->vel[k].as<float2>(), n, p->rest_density, 1,
                            c->hdr_partials.as<HeaderOut>());
-        hipLaunchKernelGGL(k_header_final, dim3(1), dim3(256), 0, s, c->hdr_partials.as<HeaderOut>(), nb, c->hdr_out.as<HeaderOut>());
+        hipLaunchKernelGGL(k_header_final, dim3(1), dim3(256), 0, s, c->hdr_partials.as<HeaderOut>(), nb, c->hdr_host_dev);
     }
-    HIPCHK(c, hipMemcpyAsync(c->hdr_host, c->hdr_out.p, sizeof(HeaderOut), hipMemcpyDeviceToHost, s));
-    HIPCHK(c, hipStreamSynchronize(s));
+    {
+        int rcw = wait_stream(c);
+        if (rcw) return rcw;
+    }
     const HeaderOut hdr = *c->hdr_host;
     g_trace.mark(0);
     if (!std::isfinite(hdr.min_x) || !std::isfinite(hdr.max_x) || !std::isfinite(hdr.min_y) || !std::isfinite(hdr.max_y) ||
@@ -840,7 +893,7 @@ extern "C" int sph_step(sph_ctx* c, const sph_params* p, sph_step_stats* out)
     c->pcur ^= 1;
     k = c->cur;
     launch_cell_start(s, prof, c->key[0].as<uint32_t>(), n, g.ncells, c->cell_start.as<uint32_t>());
-    hipEventRecord(c->ev[1], s);
+    if (tev) hipEventRecord(c->ev[1], s);
     g_trace.mark(1);
 
     SweepArgs a = make_args(c, sp);
@@ -876,42 +929,41 @@ extern "C" int sph_step(sph_ctx* c, const sph_params* p, sph_step_stats* out)
     switch (p->pressure_solver_method) {
     case SPH_SOLVER_IISPH:  // simulation.rs:2389-2446
         non_pressure();
-        hipEventRecord(c->ev[4], s);
+        if (tev) hipEventRecord(c->ev[4], s);
         begin_solve(1, 1);
         rc = pressure_iterations(c, a, p->iisph_max_avg_density_error, 1, p->max_iters, c->last_dens_iters, T_VX, pm_next, &st.density_solver);
         if (rc) return rc;
-        hipEventRecord(c->ev[5], s);
+        if (tev) hipEventRecord(c->ev[5], s);
         break;
     case SPH_SOLVER_ONLY_DIVERGENCE:  // simulation.rs:2448-2500
         non_pressure();
-        hipEventRecord(c->ev[2], s);
+        if (tev) hipEventRecord(c->ev[2], s);
         begin_solve(0, 0);
         rc = pressure_iterations(c, a, p->hybrid_dfsph_max_avg_divergence_error, 0, p->max_iters, c->last_div_iters, T_VX, pm_next, &st.div_solver);
         if (rc) return rc;
-        hipEventRecord(c->ev[3], s);
+        if (tev) hipEventRecord(c->ev[3], s);
         break;
     default:  // HybridDFSPH, simulation.rs:2502-2670
         if (p->hybrid_dfsph_non_pressure_accel_before_divergence_free) non_pressure();
-        hipEventRecord(c->ev[2], s);
+        if (tev) hipEventRecord(c->ev[2], s);
         begin_solve(0, 0);
         g_trace.mark(2);
         rc = pressure_iterations(c, a, p->hybrid_dfsph_max_avg_divergence_error, 0, p->max_iters, c->last_div_iters, T_VEL, nullptr, &st.div_solver);
         if (rc) return rc;
         g_trace.mark(3);
-        hipEventRecord(c->ev[3], s);
+        if (tev) hipEventRecord(c->ev[3], s);
         if (!p->hybrid_dfsph_non_pressure_accel_before_divergence_free) non_pressure();
-        hipEventRecord(c->ev[4], s);
+        if (tev) hipEventRecord(c->ev[4], s);
         begin_solve(p->hybrid_dfsph_density_source_term == SPH_ONLY_DENSITY ? 2 : 1, 1);
         g_trace.mark(4);
         rc = pressure_iterations(c, a, p->hybrid_dfsph_max_avg_density_error, 1, p->max_iters, c->last_dens_iters, T_HYBRID, pm_next, &st.density_solver);
         if (rc) return rc;
         g_trace.mark(5);
-        hipEventRecord(c->ev[5], s);
+        if (tev) hipEventRecord(c->ev[5], s);
         break;
     }
-    hipEventRecord(c->ev[6], s);
+    if (tev) hipEventRecord(c->ev[6], s);
     c->pcur ^= 1;  // integrated positions live in the other pm buffer; the old one keeps the pre-step snapshot
-    HIPCHK(c, hipEventSynchronize(c->ev[6]));
     if (p->viscosity_type == SPH_VISC_XSPH)  // simulation.rs:2673-2676
         return c->fail(SPH_ERR_XSPH_TODO, "not yet implemented (XSPH velocity smoothing)");
 
@@ -921,14 +973,19 @@ extern "C" int sph_step(sph_ctx* c, const sph_params* p, sph_step_stats* out)
     c->step_number += 1;
     st.time = c->time;
     st.step_number = c->step_number;
-    float ms = 0.f;
-    if (hipEventElapsedTime(&ms, c->ev[0], c->ev[6]) == hipSuccess) st.ms_simulation_step = ms;
-    if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) st.ms_neighborhood = ms;
-    const bool has_div = p->pressure_solver_method == SPH_SOLVER_ONLY_DIVERGENCE || p->pressure_solver_method == SPH_SOLVER_HYBRID_DFSPH;
-    const bool has_dens = p->pressure_solver_method != SPH_SOLVER_ONLY_DIVERGENCE;
-    if (has_div && hipEventElapsedTime(&ms, c->ev[2], c->ev[3]) == hipSuccess) st.ms_div_solver = ms;
-    if (has_dens && hipEventElapsedTime(&ms, c->ev[4], c->ev[5]) == hipSuccess) st.ms_density_solver = ms;
+    st.ms_simulation_step = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+    if (tev) {
+        float ms = 0.f;
+        (void)hipEventSynchronize(c->ev[6]);
+        if (hipEventElapsedTime(&ms, c->ev[0], c->ev[6]) == hipSuccess) st.ms_simulation_step = ms;
+        if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) st.ms_neighborhood = ms;
+        const bool has_div = p->pressure_solver_method == SPH_SOLVER_ONLY_DIVERGENCE || p->pressure_solver_method == SPH_SOLVER_HYBRID_DFSPH;
+        const bool has_dens = p->pressure_solver_method != SPH_SOLVER_ONLY_DIVERGENCE;
+        if (has_div && hipEventElapsedTime(&ms, c->ev[2], c->ev[3]) == hipSuccess) st.ms_div_solver = ms;
+        if (has_dens && hipEventElapsedTime(&ms, c->ev[4], c->ev[5]) == hipSuccess) st.ms_density_solver = ms;
+    }
     if (prof->mode) prof->collect();
+    prof->step_index++;
     if (out) *out = st;
     g_trace.mark(6);
     g_trace.end_step();

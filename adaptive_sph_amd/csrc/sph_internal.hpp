@@ -12,7 +12,8 @@
 
 // ---- HIP-event profiler (measurement hook; sph_profile_* in the C ABI) ------------------------
 struct Profiler {
-    int mode = 0;  // 0 off, 1 every kernel, 2 only names starting with "density"
+    int mode = 0;  // 0 off, 1 every kernel, 2 only names starting with "density" (sampled: every 8th step)
+    uint64_t step_index = 0;
     struct Rec {
         std::string name;
         uint64_t launches = 0;
