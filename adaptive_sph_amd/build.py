@@ -34,7 +34,7 @@ def build_hip(force: bool = False, verbose: bool = False) -> Path:
         return out
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
            "-ffp-contract=off", "-fno-fast-math", "-fgpu-rdc=0" if False else "-Wall",
-           "-I", str(REPO / "include"), "-o", str(out)] + [str(s) for s in srcs] + ["-L/opt/rocm/lib", "-lrccl"]
+           "-I", str(REPO / "include"), "-o", str(out)] + os.environ.get("SPH_EXTRA_HIPCC_FLAGS", "").split() + [str(s) for s in srcs] + ["-L/opt/rocm/lib", "-lrccl"]
     cmd = [c for c in cmd if c]
     if verbose:
         print(" ".join(cmd))

@@ -63,14 +63,136 @@ __device__ __forceinline__ void raise_error(DeviceStatus* st, uint32_t code, uin
 //   bool   skip()                               launch-uniform early exit (speculative Jacobi iterations)
 //   float4 loadA(j)                             (x, y, m, h) of particle j
 //   NB     nb(acc, j, Aj)                       per-neighbour payload of particle j
+//   void   init(acc)                            lane-independent state (e.g. which pressure buffer is current)
 //   void   begin(acc, i, Ai)                    load own data, zero accumulators
 //   void   pair(acc, Aj, NBj, dx, dy, r2, hij)  one accepted pair
 //   void   finish(acc, i, Ai, wall)             boundary terms (only if `wall`), outputs, guards
 //   void   epilogue(acc, active, blk)           optional block-level tail (HAS_EPILOGUE)
 // ------------------------------------------------------------------------------------------------
+// LDS slot type of the per-neighbour payload: 12-byte payloads are padded to 16 B (ds_read_b128)
+template <class NB, int SZ = sizeof(NB)>
+struct NBSlot {
+    NB v;
+};
+template <class NB>
+struct NBSlot<NB, 12> {
+    NB v;
+    float pad;
+};
+
+#define STAGE_CAP 256   // staged particles per wave: 3 rows x (64 particles + 2 cells) of the rest lattice ~ 220
+
+// pair loops of one particle, against LDS (STAGED) or against global memory / L2
+template <class Op, bool BUILD, bool STAGED>
+__device__ __forceinline__ void run_pairs(const Op& op, typename Op::Acc& acc, const float4 Ai, const uint32_t (&rb)[3],
+                                          const uint32_t (&re)[3], const bool walk, uint4& lw, const float4* __restrict__ sA,
+                                          const NBSlot<typename Op::NB>* __restrict__ sN, const int (&soff)[3])
+{
+    typedef typename Op::Math Math;
+    typedef typename Op::NB NB;
+#define SPH_FETCH(J, DR, AOUT, NOUT)                                                      \
+    float4 AOUT;                                                                          \
+    NB NOUT;                                                                              \
+    if (STAGED) {                                                                         \
+        const int sl = soff[DR] + (int)(J);                                               \
+        AOUT = sA[sl];                                                                    \
+        NOUT = sN[sl].v;                                                                  \
+    } else {                                                                              \
+        AOUT = op.loadA(J);                                                               \
+        NOUT = op.nb(acc, J, AOUT);                                                       \
+    }
+#define SPH_PAIR(AJ, NJ, ON)                                                              \
+    {                                                                                     \
+        const float dx = Ai.x - AJ.x, dy = Ai.y - AJ.y;                                   \
+        const float r2 = dx * dx + dy * dy;                                               \
+        const float hij = Math::UNIFORM ? op.m.h : (Ai.w + AJ.w) * 0.5f;                  \
+        if (ON) op.pair(acc, AJ, NJ, dx, dy, r2, hij);                                    \
+    }
+    if (!walk) {
+        // ---- list replay: per row, up to 4 set bits per trip (4 independent fetches in flight) ----------
+        const uint32_t masks[3] = {lw.x, lw.y, lw.z};
+#pragma unroll
+        for (int dr = 0; dr < 3; dr++) {
+            uint32_t mk = masks[dr];
+            const uint32_t base = rb[dr];
+            while (mk) {
+                const uint32_t b0 = __ffs(mk) - 1;
+                mk &= mk - 1;
+                const bool v1 = mk != 0;
+                const uint32_t b1 = v1 ? __ffs(mk) - 1 : b0;
+                mk &= mk - 1;
+                const bool v2 = mk != 0;
+                const uint32_t b2 = v2 ? __ffs(mk) - 1 : b0;
+                mk &= mk - 1;
+                const bool v3 = mk != 0;
+                const uint32_t b3 = v3 ? __ffs(mk) - 1 : b0;
+                mk &= mk - 1;
+                const uint32_t j0 = base + b0, j1 = base + b1, j2 = base + b2, j3 = base + b3;
+                SPH_FETCH(j0, dr, A0, N0)
+                SPH_FETCH(j1, dr, A1, N1)
+                SPH_FETCH(j2, dr, A2, N2)
+                SPH_FETCH(j3, dr, A3, N3)
+                SPH_PAIR(A0, N0, true)
+                SPH_PAIR(A1, N1, v1)
+                SPH_PAIR(A2, N2, v2)
+                SPH_PAIR(A3, N3, v3)
+            }
+        }
+    } else {
+        // ---- candidate walk: 3 rows x 3 cells, exact reference predicate, 4 candidates per trip ----------
+        uint32_t mk[3] = {0u, 0u, 0u};
+        uint32_t nacc = 0;
+        bool ok_list = true;
+#pragma unroll
+        for (int dr = 0; dr < 3; dr++) {
+            const uint32_t b = rb[dr], e = re[dr];
+            ok_list = ok_list && (e - b) <= 32u;
+            for (uint32_t j = b; j < e; j += 4) {
+                const bool v1 = j + 1 < e, v2 = j + 2 < e, v3 = j + 3 < e;
+                const uint32_t j1 = v1 ? j + 1 : j, j2 = v2 ? j + 2 : j, j3 = v3 ? j + 3 : j;
+                SPH_FETCH(j, dr, A0, N0)
+                SPH_FETCH(j1, dr, A1, N1)
+                SPH_FETCH(j2, dr, A2, N2)
+                SPH_FETCH(j3, dr, A3, N3)
+#define SPH_CAND(JJ, AJ, NJ, VALID)                                                       \
+    {                                                                                     \
+        /* neighbour predicate, exactly the reference's operations (no FMA, strict <) */  \
+        const float dx = Ai.x - AJ.x, dy = Ai.y - AJ.y;                                   \
+        const float r2 = dx * dx + dy * dy;                                               \
+        const float hij = Math::UNIFORM ? op.m.h : (Ai.w + AJ.w) * 0.5f;                  \
+        const float s = hij * 2.f;                                                        \
+        if ((VALID) && r2 < s * s) {                                                      \
+            op.pair(acc, AJ, NJ, dx, dy, r2, hij);                                        \
+            const uint32_t bit = (JJ) - b;                                                \
+            if (bit < 32u) mk[dr] |= 1u << bit;                                           \
+            nacc++;                                                                       \
+        }                                                                                 \
+    }
+                SPH_CAND(j, A0, N0, true)
+                SPH_CAND(j1, A1, N1, v1)
+                SPH_CAND(j2, A2, N2, v2)
+                SPH_CAND(j3, A3, N3, v3)
+            }
+        }
+        if (BUILD) lw = make_uint4(mk[0], mk[1], mk[2], (nacc & 0xffffu) | (ok_list ? NL_OK : 0u));
+    }
+#undef SPH_FETCH
+#undef SPH_PAIR
+#undef SPH_CAND
+}
+
 template <class Op, bool BUILD>
 __global__ __launch_bounds__(SWEEP_THREADS) void k_sweep(Op op, SweepCommon c)
 {
+    typedef typename Op::NB NB;
+#ifdef SPH_USE_STAGING
+    __shared__ float4 s_A[SWEEP_THREADS / 64][STAGE_CAP];
+    __shared__ NBSlot<NB> s_N[SWEEP_THREADS / 64][STAGE_CAP];
+#else
+    __shared__ float4 s_A[1][1];
+    __shared__ NBSlot<NB> s_N[1][1];
+#endif
+
     if (op.skip()) return;
     // XCD-aware block order: the dispatcher places block b on XCD b % 8; give every XCD a contiguous
     // band of the cell-sorted array so that vertically adjacent waves (which share neighbour rows)
@@ -80,101 +202,88 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_sweep(Op op, SweepCommon c)
     if (blk >= c.nblocks) return;
     const uint32_t i = blk * SWEEP_THREADS + threadIdx.x;
     const bool active = i < c.n;
-    typedef typename Op::Math Math;
-    typedef typename Op::NB NB;
     const GridP g = c.g;
     typename Op::Acc acc;
+    op.init(acc);  // lane-independent state (valid on lanes past the end too: they help staging)
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
 
+    float4 Ai = make_float4(0.f, 0.f, 0.f, 0.f);
+    uint4 lw = make_uint4(0, 0, 0, 0);
+    uint32_t rb[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, re[3] = {0u, 0u, 0u};
+    bool walk = false;
+    int cy = -1;
     if (active) {
-        const float4 Ai = op.loadA(i);
-        uint4 lw = make_uint4(0, 0, 0, 0);
+        Ai = op.loadA(i);
         if (!BUILD) lw = c.nl[i];
         op.begin(acc, i, Ai);
-
         // own cell (the same IEEE expression the sort key was computed from) and the three row bases
         const int cx = (int)floorf(Ai.x / g.cs) - g.minx;
-        const int cy = (int)floorf(Ai.y / g.cs) - g.miny;
-        uint32_t rb[3], re[3];
-        const bool walk = BUILD || !(lw.w & NL_OK);
+        cy = (int)floorf(Ai.y / g.cs) - g.miny;
+        walk = BUILD || !(lw.w & NL_OK);
+        const uint32_t mk[3] = {lw.x, lw.y, lw.z};
 #pragma unroll
         for (int dr = 0; dr < 3; dr++) {
             const int yy = cy + dr - 1;
             const bool ok = yy >= 0 && yy < g.sy;
             const uint32_t base = (uint32_t)(ok ? yy : 0) * (uint32_t)g.sx;
             rb[dr] = ok ? c.cell_start[base + (uint32_t)max(cx - 1, 0)] : 0u;
-            re[dr] = (ok && walk) ? c.cell_start[base + (uint32_t)min(cx + 2, g.sx)] : rb[dr];
+            // end of what this lane will touch in the row: the candidate range end (walk) or the highest set bit
+            if (walk) re[dr] = ok ? c.cell_start[base + (uint32_t)min(cx + 2, g.sx)] : rb[dr];
+            else re[dr] = rb[dr] + (mk[dr] ? 32u - (uint32_t)__clz(mk[dr]) : 0u);
         }
-#define SPH_PAIR(AJ, NJ, ON)                                                              \
-    {                                                                                     \
-        const float dx = Ai.x - AJ.x, dy = Ai.y - AJ.y;                                   \
-        const float r2 = dx * dx + dy * dy;                                               \
-        const float hij = Math::UNIFORM ? op.m.h : (Ai.w + AJ.w) * 0.5f;                  \
-        if (ON) op.pair(acc, AJ, NJ, dx, dy, r2, hij);                                    \
     }
-        if (!walk) {
-            // ---- list replay: per row, up to 4 set bits per trip (4 independent gathers in flight) ------
-            const uint32_t masks[3] = {lw.x, lw.y, lw.z};
+
+    // ---- stage the wave's three row ranges into LDS (coalesced), if the wave sits in one cell row ---------
+    int soff[3] = {0, 0, 0};
+    bool staged = false;
+    {
+        const int cy0 = __shfl(cy, 0, 64);
+        const bool same_row = __all(!active || cy == cy0) && cy0 >= 0;
+        uint32_t lo[3], hi[3], T = 0;
 #pragma unroll
-            for (int dr = 0; dr < 3; dr++) {
-                uint32_t mk = masks[dr];
-                const uint32_t base = rb[dr];
-                while (mk) {
-                    const uint32_t b0 = __ffs(mk) - 1;
-                    mk &= mk - 1;
-                    const bool v1 = mk != 0;
-                    const uint32_t b1 = v1 ? __ffs(mk) - 1 : b0;
-                    mk &= mk - 1;
-                    const bool v2 = mk != 0;
-                    const uint32_t b2 = v2 ? __ffs(mk) - 1 : b0;
-                    mk &= mk - 1;
-                    const bool v3 = mk != 0;
-                    const uint32_t b3 = v3 ? __ffs(mk) - 1 : b0;
-                    mk &= mk - 1;
-                    const uint32_t j0 = base + b0, j1 = base + b1, j2 = base + b2, j3 = base + b3;
-                    const float4 A0 = op.loadA(j0), A1 = op.loadA(j1), A2 = op.loadA(j2), A3 = op.loadA(j3);
-                    const NB N0 = op.nb(acc, j0, A0), N1 = op.nb(acc, j1, A1), N2 = op.nb(acc, j2, A2), N3 = op.nb(acc, j3, A3);
-                    SPH_PAIR(A0, N0, true)
-                    SPH_PAIR(A1, N1, v1)
-                    SPH_PAIR(A2, N2, v2)
-                    SPH_PAIR(A3, N3, v3)
-                }
+        for (int dr = 0; dr < 3; dr++) {
+            uint32_t l = rb[dr], h = active ? re[dr] : 0u;
+            for (int o = 32; o > 0; o >>= 1) {
+                l = min(l, (uint32_t)__shfl_xor((int)l, o, 64));
+                h = max(h, (uint32_t)__shfl_xor((int)h, o, 64));
             }
-        } else {
-            // ---- candidate walk: 3 rows x 3 cells, exact reference predicate, 4 candidates per trip ------
-            uint32_t mk[3] = {0u, 0u, 0u};
-            uint32_t nacc = 0;
-            bool ok_list = true;
-#pragma unroll
-            for (int dr = 0; dr < 3; dr++) {
-                const uint32_t b = rb[dr], e = re[dr];
-                ok_list = ok_list && (e - b) <= 32u;
-                for (uint32_t j = b; j < e; j += 4) {
-                    const bool v1 = j + 1 < e, v2 = j + 2 < e, v3 = j + 3 < e;
-                    const uint32_t j1 = v1 ? j + 1 : j, j2 = v2 ? j + 2 : j, j3 = v3 ? j + 3 : j;
-                    const float4 A0 = op.loadA(j), A1 = op.loadA(j1), A2 = op.loadA(j2), A3 = op.loadA(j3);
-#define SPH_CAND(JJ, AJ, VALID, K)                                                        \
-    {                                                                                     \
-        /* neighbour predicate, exactly the reference's operations (no FMA, strict <) */  \
-        const float dx = Ai.x - AJ.x, dy = Ai.y - AJ.y;                                   \
-        const float r2 = dx * dx + dy * dy;                                               \
-        const float hij = Math::UNIFORM ? op.m.h : (Ai.w + AJ.w) * 0.5f;                  \
-        const float s = hij * 2.f;                                                        \
-        if ((VALID) && r2 < s * s) {                                                      \
-            const NB Nj = op.nb(acc, JJ, AJ);                                             \
-            op.pair(acc, AJ, Nj, dx, dy, r2, hij);                                        \
-            const uint32_t bit = (JJ) - b;                                                \
-            if (bit < 32u) mk[dr] |= 1u << bit;                                           \
-            nacc++;                                                                       \
-        }                                                                                 \
-    }
-                    SPH_CAND(j, A0, true, 0)
-                    SPH_CAND(j1, A1, v1, 1)
-                    SPH_CAND(j2, A2, v2, 2)
-                    SPH_CAND(j3, A3, v3, 3)
-                }
-            }
-            if (BUILD) lw = make_uint4(mk[0], mk[1], mk[2], (nacc & 0xffffu) | (ok_list ? NL_OK : 0u));
+            lo[dr] = l;
+            hi[dr] = h > l ? h : l;
+            soff[dr] = (int)T - (int)l;  // slot of global index j in row dr = soff[dr] + j
+            T += hi[dr] - lo[dr];
         }
+        staged = same_row && T <= STAGE_CAP;
+#ifndef SPH_USE_STAGING
+        // measured on MI355X at N = 1M: staging is SLOWER than gathering through L1/L2 (Jacobi 38.9 vs 28.5 us,
+        // source 40 vs 27 us): random ds_read_b128 costs as much as the L1 gathers it replaces and the 16-32 KB
+        // of LDS per block cut occupancy.  Kept as a compile-time option (-DSPH_USE_STAGING).
+        staged = false;
+#endif
+#ifdef SPH_USE_STAGING
+        if (staged) {
+            for (uint32_t t = lane; t < T; t += 64) {
+                const uint32_t t1 = hi[0] - lo[0], t2 = t1 + (hi[1] - lo[1]);
+                const int dr = t < t1 ? 0 : (t < t2 ? 1 : 2);
+                const uint32_t j = (dr == 0 ? lo[0] + t : (dr == 1 ? lo[1] + (t - t1) : lo[2] + (t - t2)));
+                const float4 Aj = op.loadA(j);
+                s_A[wv][t] = Aj;
+                s_N[wv][t].v = op.nb(acc, j, Aj);
+            }
+            // the wave's own LDS writes are read back by other lanes of the same wave only: LDS operations of
+            // one wave execute in order, so a compiler barrier + counter wait is all that is needed
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+#endif
+    }
+
+    if (active) {
+#ifdef SPH_USE_STAGING
+        if (staged) run_pairs<Op, BUILD, true>(op, acc, Ai, rb, re, walk, lw, s_A[wv], s_N[wv], soff);
+        else
+#endif
+            run_pairs<Op, BUILD, false>(op, acc, Ai, rb, re, walk, lw, s_A[0], s_N[0], soff);
         const bool wall = op.finish(acc, i, Ai, BUILD ? true : (lw.w & NL_WALL) != 0u);
         if (BUILD) {
             if (wall) lw.w |= NL_WALL;
@@ -216,6 +325,7 @@ struct OpDensity {
         bool wall;
     };
     __device__ bool skip() const { return false; }
+    __device__ void init(Acc&) const {}
     __device__ void epilogue(Acc&, bool, uint32_t) const {}
     __device__ float4 loadA(uint32_t j) const { return pm[j]; }
     __device__ NB nb(const Acc&, uint32_t, float4) const { return NB{}; }
@@ -314,6 +424,7 @@ struct OpAiiConst {
         float cf, ax, ay, a2, bx, by;
     };
     __device__ bool skip() const { return false; }
+    __device__ void init(Acc&) const {}
     __device__ void epilogue(Acc&, bool, uint32_t) const {}
     __device__ float4 loadA(uint32_t j) const { return pm[j]; }
     __device__ NB nb(const Acc&, uint32_t j, float4) const { return mrho[j]; }
@@ -390,6 +501,7 @@ struct OpNonPressure {
         float vx, vy, rho_i, vix, viy;
     };
     __device__ bool skip() const { return false; }
+    __device__ void init(Acc&) const {}
     __device__ void epilogue(Acc&, bool, uint32_t) const {}
     __device__ float4 loadA(uint32_t j) const { return pm[j]; }
     __device__ NB nb(const Acc&, uint32_t j, float4) const
@@ -522,6 +634,7 @@ struct OpSource {
         uint32_t cls;
     };
     __device__ bool skip() const { return false; }
+    __device__ void init(Acc&) const {}
     __device__ float4 loadA(uint32_t j) const { return pm[j]; }
     __device__ NB nb(const Acc&, uint32_t j, float4) const
     {
@@ -651,11 +764,14 @@ struct OpPressureAccel {
     __device__ void epilogue(Acc&, bool, uint32_t) const {}
     __device__ float4 loadA(uint32_t j) const { return pm[j]; }
     __device__ NB nb(const Acc& a, uint32_t j, float4) const { return a.pt[j]; }
-    __device__ void begin(Acc& a, uint32_t i, float4) const
+    __device__ void init(Acc& a) const
     {
         const uint32_t cur = iter >= 0 ? (uint32_t)(iter & 1) : ctrl->cur;
         a.pt = cur ? pt1 : pt0;
         a.p = cur ? p1 : p0;
+    }
+    __device__ void begin(Acc& a, uint32_t i, float4) const
+    {
         a.ax = a.ay = 0.f;
         a.p1t = a.pt[i];
     }
@@ -747,6 +863,7 @@ struct OpJacobi {
         uint32_t cls;    // 0 normal, 1 singular, 2 negative (PressureSolverStatistics, simulation.rs:397-445)
     };
     __device__ bool skip() const { return ctrl->done != 0u; }
+    __device__ void init(Acc&) const {}
     __device__ float4 loadA(uint32_t j) const { return pm[j]; }
     __device__ NB nb(const Acc&, uint32_t j, float4) const
     {
