@@ -1,0 +1,122 @@
+// Context of one simulation on one GPU + helpers shared by sph_api.hip and sph_step.hip.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "sph_internal.hpp"
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    hipError_t ensure(size_t need)
+    {
+        if (need <= bytes) return hipSuccess;
+        if (p) hipFree(p);
+        p = nullptr;
+        bytes = 0;
+        size_t grow = need + need / 4 + 256;
+        hipError_t e = hipMalloc(&p, grow);
+        if (e == hipSuccess) bytes = grow;
+        return e;
+    }
+    void release()
+    {
+        if (p) hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    template <class T>
+    T* as() const { return (T*)p; }
+};
+
+struct sph_ctx {
+    int device = 0;
+    uint64_t cap = 0, n = 0;
+    hipStream_t stream = nullptr;
+    int n_planes = 0;
+    PlaneP planes_h[SPH_MAX_PLANES];
+    float time = 0.f;
+    uint64_t step_number = 0;
+    std::string err;
+    Profiler prof;
+    int exact = 0;
+
+    // persistent SoA (ping-pong across the per-step reorder)
+    DevBuf pm[2], vel[2], orig[2], lvl[2], lvlold[2];
+    int cur = 0;   // which of the (vel, orig, lvl, lvlold) ping-pong set is live
+    int pcur = 0;  // which pm buffer is live; the other one holds the sorted PRE-step positions after a step
+    DevBuf vel_tmp;
+    // per-step
+    DevBuf key[2], val[2], sort_scratch, cxy, cell_start, nl, nl_ok, mrho, pt0, pt1;
+    bool uniform_h = false;
+    float h_uniform = 0.f;
+    DevBuf rho, lam_sum, lam_grad, constf, aii, src, p0, p1, pacc, dens_err, stat, ncount;
+    DevBuf planes_d, lam_lut, dlam_lut, hdr_partials, hdr_out, ctrl, status, n_tiles, red_partials, scratch;
+    // mapped pinned host memory: written by kernels directly (no D2H copy launches)
+    HeaderOut* hdr_host = nullptr;
+    SolverCtrl* ctrl_host = nullptr;
+    DeviceStatus* status_host = nullptr;
+    HeaderOut* hdr_host_dev = nullptr;
+    SolverCtrl* ctrl_host_dev = nullptr;
+    DeviceStatus* status_host_dev = nullptr;
+    hipEvent_t ev_sync = nullptr;
+
+    // ---- slab decomposition (multi-GPU): this context owns x in [cut_lo, cut_hi) -------------------
+    struct Dist {
+        bool on = false;
+        int rank = 0, nranks = 1;
+        float cut_lo = 0.f, cut_hi = 0.f;
+        uint32_t n_tot = 0;          // particles in the arrays incl. ghosts (== n when not distributed)
+        bool have_flags = false;     // `owned` describes the current arrays (after a step)
+        uint32_t n_halo[2] = {0, 0}, n_ghost[2] = {0, 0};   // [left, right]
+        DevBuf owned;                // u8 per slot: 1 owned, 0 ghost
+        DevBuf halo_idx, halo_pos, halo_src, ghost_dst;      // index lists / maps (u32)
+        DevBuf send[2], recv[2];     // staging, [left, right]
+        DevBuf counts;               // device counters
+        DevBuf solver_tot;           // 4 doubles: normal, singular, negative, sum_err (all-reduced)
+        uint32_t* counts_host = nullptr;       // mapped pinned
+        uint32_t* counts_host_dev = nullptr;
+        void* nccl = nullptr;        // ncclComm_t
+    } dist;
+
+    GridP grid{};
+    bool grid_valid = false;
+    uint32_t pressure_cur = 0;
+    uint32_t last_div_iters = 2, last_dens_iters = 2;
+    hipEvent_t ev[8];
+
+    int fail(int code, const char* fmt, ...)
+    {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        err = buf;
+        return code;
+    }
+};
+
+#define HIPCHK(ctx, call)                                                                                  \
+    do {                                                                                                   \
+        hipError_t e_ = (call);                                                                            \
+        if (e_ != hipSuccess) return (ctx)->fail(SPH_ERR_DEVICE, "%s failed: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+
+// ---- shared helpers (sph_step.hip) -------------------------------------------------------------
+int wait_stream(sph_ctx* c);
+const char* status_message(uint32_t code);
+SweepArgs make_args(sph_ctx* c, const StepP& sp);
+
+// ---- small launch wrappers owned by sph_api.hip -----------------------------------------------
+void launch_header(sph_ctx* c, uint32_t n, float rest_density, int from_mass, HeaderOut* out_dev);
+void launch_publish(sph_ctx* c);
+void launch_check_neighborhood(sph_ctx* c, const SweepArgs& a);
+void dist_release(sph_ctx* c);  // sph_step.hip

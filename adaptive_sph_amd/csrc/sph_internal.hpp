@@ -122,6 +122,8 @@ struct SweepArgs {
     uint32_t* ncount;
     uint4* nl;          // neighbour list words (sph_sweeps.hip)
     float* partials;    // per-block solver statistics
+    const uint8_t* owned;  // slab decomposition: 1 owned, 0 ghost (nullptr: everything is owned)
+    double* solver_tot; // multi-rank: all-reduced solver totals
     float* mrho;        // m / rho
     float* pt0;         // p / rho^2 for pressure buffer 0 / 1
     float* pt1;
@@ -142,6 +144,9 @@ void launch_non_pressure(hipStream_t s, Profiler* prof, const SweepArgs& a);    
 void launch_source_term(hipStream_t s, Profiler* prof, const SweepArgs& a, int kind, int residual_density);  // kind: 0 div, 1 full, 2 only-density; includes Jacobi iteration 0
 void launch_pressure_accel(hipStream_t s, Profiler* prof, const SweepArgs& a, int iter, int tail, float4* pm_out);  // iter < 0: final sweep (runs once ctrl->done), tail = TAIL_*
 void launch_jacobi_update(hipStream_t s, Profiler* prof, const SweepArgs& a, int iter, int residual_density);
+void launch_solver_local(hipStream_t s, Profiler* prof, const SweepArgs& a, float* block_partials);
+void launch_solver_decide(hipStream_t s, Profiler* prof, const SweepArgs& a, int iter, int residual_density, float max_avg_error,
+                          uint32_t max_iters);
 void launch_solver_reduce(hipStream_t s, Profiler* prof, const SweepArgs& a, int iter, int residual_density, float max_avg_error,
                           uint32_t max_iters, float* block_partials);
 void launch_vel_add_pacc(hipStream_t s, Profiler* prof, const SweepArgs& a);               // v += dt a^p

@@ -1,0 +1,1190 @@
+// The step driver: sequences the sweeps exactly like single_step_without_adaptivity
+// (/root/reference/src/simulation/simulation.rs:1980-2730) -- the citations sit next to each call --
+// for a GROUP of contexts (ranks) and a transport between them:
+//
+//   single GPU            group of one context, no transport                      (sph_step)
+//   one process per GPU   group of one context, RCCL transport over xGMI          (sph_step after sph_comm_init)
+//   loopback              group of k contexts in one process, copies as transport (sph_group_step; used to
+//                         verify the slab algorithm against the single-context result on one GPU)
+//
+// Multi-rank decomposition: 1-D slabs along x, rank r owns x in [cut_r, cut_r+1).
+// Per step: owned particles that left the slab migrate to the x-neighbour; owned particles within one
+// support radius (2 h_max, all-reduced) of a cut are sent to that neighbour as ghosts; every sweep whose
+// output is read through neighbour gathers (rho, m/rho, v, p/rho^2, a^p) is followed by a ghost refresh
+// of exactly that field; CFL dt and the Jacobi residual statistics are all-reduced so that every rank
+// takes the same stop decision.  Ghost lanes are idle in the sweeps (their values come from their owner).
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <array>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "sph_context.hpp"
+
+// ------------------------------------------------------------------------------------------------
+// helpers shared with sph_api.hip
+// ------------------------------------------------------------------------------------------------
+SweepArgs make_args(sph_ctx* c, const StepP& sp)
+{
+    SweepArgs a{};
+    const int k = c->cur;
+    a.g = c->grid;
+    a.sp = sp;
+    a.n = c->dist.on ? c->dist.n_tot : (uint32_t)c->n;
+    a.exact = c->exact;
+    a.cell_start = c->cell_start.as<uint32_t>();
+    a.orig = c->orig[k].as<uint32_t>();
+    a.pm = c->pm[c->pcur].as<float4>();
+    a.vel = c->vel[k].as<float2>();
+    a.vel_tmp = c->vel_tmp.as<float2>();
+    a.rho = c->rho.as<float>();
+    a.lam_sum = c->lam_sum.as<float>();
+    a.lam_grad = c->lam_grad.as<float2>();
+    a.constf = c->constf.as<float>();
+    a.aii = c->aii.as<float>();
+    a.src = c->src.as<float>();
+    a.p0 = c->p0.as<float>();
+    a.p1 = c->p1.as<float>();
+    a.pacc = c->pacc.as<float2>();
+    a.dens_err = c->dens_err.as<float>();
+    a.stat = c->stat.as<float>();
+    a.ncount = c->ncount.as<uint32_t>();
+    a.nl = c->nl.as<uint4>();
+    a.partials = c->red_partials.as<float>();
+    a.mrho = c->mrho.as<float>();
+    a.pt0 = c->pt0.as<float>();
+    a.pt1 = c->pt1.as<float>();
+    a.uniform_h = c->uniform_h ? 1 : 0;
+    a.h_uniform = c->h_uniform;
+    a.planes = c->planes_d.as<PlaneP>();
+    a.lam_lut = c->lam_lut.as<float>();
+    a.dlam_lut = c->dlam_lut.as<float>();
+    a.ctrl = c->ctrl.as<SolverCtrl>();
+    a.status = c->status.as<DeviceStatus>();
+    a.owned = c->dist.on ? c->dist.owned.as<uint8_t>() : nullptr;
+    a.solver_tot = c->dist.solver_tot.as<double>();
+    return a;
+}
+
+const char* status_message(uint32_t code)
+{
+    switch (code) {
+    case SPH_ERR_DENSITY_NOT_FINITE: return "assertion failed: p_density.is_finite()";
+    case SPH_ERR_DENSITY_TOO_SMALL: return "assertion failed: *p_density > 0.0001";
+    case SPH_ERR_AII_NOT_FINITE: return "assertion failed: (*p_aii).is_finite()";
+    case SPH_ERR_AII_NEGATIVE: return "AII should not be negative!";
+    case SPH_ERR_AP_NOT_FINITE: return "'!a_p.is_finite()' failed. Pressure values probably have exploded!";
+    case SPH_ERR_PRESSURE_NOT_FINITE: return "'!p_pressure_next_iter.is_finite()' failed.";
+    case SPH_ERR_TOO_MANY_NEIGHBORS: return "exceeded maximum allowed number of 20000 neighbors";
+    case SPH_ERR_VELOCITY_NOT_FINITE: return "Assertion 'p_velocity[d].is_finite()' failed!";
+    case SPH_ERR_POSITION_NOT_FINITE: return "Assertion 'p_position[d].is_finite()' failed!";
+    case SPH_ERR_VISCOSITY_NOT_FINITE: return "Assertion 'viscosity_accel[d].is_finite()' failed!";
+    case SPH_ERR_CHECK_NEIGHBORHOOD: return "neighbour list differs from the brute-force definition";
+    default: return "device-side guard failed";
+    }
+}
+
+// Wait for everything queued on the context's stream.  Busy-polls an event instead of
+// hipStreamSynchronize: the blocking wait's wake-up latency would otherwise be paid at every wait point.
+int wait_stream(sph_ctx* c)
+{
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipEventRecord(c->ev_sync, c->stream));
+    auto t0 = std::chrono::steady_clock::now();
+    for (uint64_t spins = 0;; spins++) {
+        hipError_t e = hipEventQuery(c->ev_sync);
+        if (e == hipSuccess) return SPH_OK;
+        if (e != hipErrorNotReady) return c->fail(SPH_ERR_DEVICE, "hipEventQuery failed: %s", hipGetErrorString(e));
+        if ((spins & 0xfffu) == 0xfffu && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 120.0)
+            return c->fail(SPH_ERR_DEVICE, "device did not finish the queued work within 120 s");
+    }
+}
+
+static int ilog2_ceil(uint32_t v)
+{
+    int b = 0;
+    while ((1ull << b) < (uint64_t)v) b++;
+    return b;
+}
+
+// host-side timeline of one step (SPH_HIP_TRACE=1): where the CPU thread spends its time
+struct HostTrace {
+    bool on;
+    std::chrono::steady_clock::time_point t0;
+    double acc[8] = {0};
+    int steps = 0;
+    HostTrace()
+    {
+        const char* e = getenv("SPH_HIP_TRACE");
+        on = e && e[0] == '1';
+    }
+    void start()
+    {
+        if (on) t0 = std::chrono::steady_clock::now();
+    }
+    void mark(int k)
+    {
+        if (!on) return;
+        auto t1 = std::chrono::steady_clock::now();
+        acc[k] += std::chrono::duration<double, std::micro>(t1 - t0).count();
+        t0 = t1;
+    }
+    void end_step()
+    {
+        if (!on) return;
+        if (++steps % 20 == 0)
+            fprintf(stderr, "[sph trace] per step us: decomposition %.1f | header %.1f | neighbourhood launches %.1f | first sweeps %.1f | div solve %.1f | dens solve %.1f\n",
+                    acc[0] / steps, acc[1] / steps, acc[2] / steps, acc[3] / steps, acc[4] / steps, acc[5] / steps);
+    }
+};
+static HostTrace g_trace;
+
+// ------------------------------------------------------------------------------------------------
+// kernels of the slab decomposition
+// ------------------------------------------------------------------------------------------------
+// class of every slot of the previous step's arrays: 0 stay, 1 migrate left, 2 migrate right, 3 drop (ghost)
+__global__ __launch_bounds__(256) void k_classify_migrate(uint32_t n, const float4* __restrict__ pm, const uint8_t* __restrict__ owned,
+                                                           float cut_lo, float cut_hi, int has_left, int has_right, uint32_t* __restrict__ key,
+                                                           uint32_t* __restrict__ val, uint32_t* __restrict__ counts)
+{
+    uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    uint32_t cls = 4;
+    if (i < n) {
+        const float x = pm[i].x;
+        if (owned && !owned[i]) cls = 3;
+        else if (has_left && x < cut_lo) cls = 1;
+        else if (has_right && !(x < cut_hi)) cls = 2;
+        else cls = 0;
+        key[i] = cls;
+        val[i] = i;
+    }
+    for (uint32_t k = 0; k < 4; k++) {
+        uint64_t m = __ballot(cls == k);
+        if (m && (threadIdx.x & 63) == (uint32_t)(__ffsll((unsigned long long)m) - 1)) atomicAdd(&counts[k], (uint32_t)__popcll(m));
+    }
+}
+
+// owned particles within `w` of a cut are ghosts of that neighbour: 1 left halo, 2 right halo, 0 none
+__global__ __launch_bounds__(256) void k_classify_halo(uint32_t n, const float4* __restrict__ pm, float lo_edge, float hi_edge, int has_left,
+                                                        int has_right, uint32_t* __restrict__ key, uint32_t* __restrict__ val,
+                                                        uint32_t* __restrict__ counts)
+{
+    uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    uint32_t cls = 4;
+    if (i < n) {
+        const float x = pm[i].x;
+        const bool l = has_left && x < lo_edge, r = has_right && !(x < hi_edge);
+        cls = (l && r) ? 3u : (l ? 1u : (r ? 2u : 0u));
+        key[i] = cls;
+        val[i] = i;
+    }
+    for (uint32_t k = 0; k < 4; k++) {
+        uint64_t m = __ballot(cls == k);
+        if (m && (threadIdx.x & 63) == (uint32_t)(__ffsll((unsigned long long)m) - 1)) atomicAdd(&counts[4 + k], (uint32_t)__popcll(m));
+    }
+}
+
+// migrant record: x, y, m, h, vx, vy, id, level, level_old
+#define MIG_WORDS 9
+__global__ __launch_bounds__(256) void k_pack_migrants(uint32_t base, uint32_t cnt, const float4* __restrict__ pm, const float2* __restrict__ vel,
+                                                        const uint32_t* __restrict__ orig, const float* __restrict__ lvl,
+                                                        const float* __restrict__ lvlold, float* __restrict__ rec)
+{
+    uint32_t k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= cnt) return;
+    const uint32_t i = base + k;
+    const float4 p = pm[i];
+    const float2 v = vel[i];
+    float* r = rec + (size_t)k * MIG_WORDS;
+    r[0] = p.x; r[1] = p.y; r[2] = p.z; r[3] = p.w; r[4] = v.x; r[5] = v.y;
+    r[6] = __uint_as_float(orig[i]);
+    r[7] = lvl[i];
+    r[8] = lvlold[i];
+}
+__global__ __launch_bounds__(256) void k_unpack_migrants(uint32_t base, uint32_t cnt, const float* __restrict__ rec, float4* __restrict__ pm,
+                                                          float2* __restrict__ vel, uint32_t* __restrict__ orig, float* __restrict__ lvl,
+                                                          float* __restrict__ lvlold)
+{
+    uint32_t k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= cnt) return;
+    const uint32_t i = base + k;
+    const float* r = rec + (size_t)k * MIG_WORDS;
+    pm[i] = make_float4(r[0], r[1], r[2], r[3]);
+    vel[i] = make_float2(r[4], r[5]);
+    orig[i] = __float_as_uint(r[6]);
+    lvl[i] = r[7];
+    lvlold[i] = r[8];
+}
+
+// ghost record (static per step): x, y, m, h, vx, vy
+#define GHOST_WORDS 6
+__global__ __launch_bounds__(256) void k_pack_ghosts(const uint32_t* __restrict__ idx, uint32_t cnt, const float4* __restrict__ pm,
+                                                      const float2* __restrict__ vel, float* __restrict__ rec)
+{
+    uint32_t k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= cnt) return;
+    const uint32_t i = idx[k];
+    const float4 p = pm[i];
+    const float2 v = vel[i];
+    float* r = rec + (size_t)k * GHOST_WORDS;
+    r[0] = p.x; r[1] = p.y; r[2] = p.z; r[3] = p.w; r[4] = v.x; r[5] = v.y;
+}
+__global__ __launch_bounds__(256) void k_unpack_ghosts(uint32_t base, uint32_t cnt, const float* __restrict__ rec, float4* __restrict__ pm,
+                                                        float2* __restrict__ vel, uint32_t* __restrict__ orig, float* __restrict__ lvl,
+                                                        float* __restrict__ lvlold)
+{
+    uint32_t k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= cnt) return;
+    const uint32_t i = base + k;
+    const float* r = rec + (size_t)k * GHOST_WORDS;
+    pm[i] = make_float4(r[0], r[1], r[2], r[3]);
+    vel[i] = make_float2(r[4], r[5]);
+    orig[i] = 0xffffffffu;
+    lvl[i] = __uint_as_float(0x7fc00000u);
+    lvlold[i] = 0.f;
+}
+
+__global__ __launch_bounds__(256) void k_halo_pos(const uint32_t* __restrict__ halo_idx, uint32_t cnt, uint32_t* __restrict__ halo_pos)
+{
+    uint32_t k = blockIdx.x * 256 + threadIdx.x;
+    if (k < cnt) halo_pos[halo_idx[k]] = k;
+}
+
+// after the cell sort: where did my halo particles and my ghosts end up?  perm[s] = pre-sort index of slot s
+__global__ __launch_bounds__(256) void k_build_maps(uint32_t n_tot, uint32_t n_own, const uint32_t* __restrict__ perm,
+                                                     const uint32_t* __restrict__ halo_pos, uint32_t* __restrict__ halo_src,
+                                                     uint32_t* __restrict__ ghost_dst, uint8_t* __restrict__ owned)
+{
+    uint32_t s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= n_tot) return;
+    const uint32_t old = perm[s];
+    const bool own = old < n_own;
+    owned[s] = own ? 1 : 0;
+    if (own) {
+        const uint32_t k = halo_pos[old];
+        if (k != 0xffffffffu) halo_src[k] = s;
+    } else {
+        ghost_dst[old - n_own] = s;
+    }
+}
+
+// refresh one field of the ghosts: gather my halo particles' values / scatter the received ones
+__global__ __launch_bounds__(256) void k_pack_field(const uint32_t* __restrict__ src_idx, uint32_t cnt, int words, const float* __restrict__ field,
+                                                     float* __restrict__ out)
+{
+    uint32_t k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= cnt) return;
+    const uint32_t i = src_idx[k];
+    for (int w = 0; w < words; w++) out[(size_t)k * words + w] = field[(size_t)i * words + w];
+}
+__global__ __launch_bounds__(256) void k_unpack_field(const uint32_t* __restrict__ dst_idx, uint32_t cnt, int words, const float* __restrict__ in,
+                                                       float* __restrict__ field)
+{
+    uint32_t k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= cnt) return;
+    const uint32_t i = dst_idx[k];
+    for (int w = 0; w < words; w++) field[(size_t)i * words + w] = in[(size_t)k * words + w];
+}
+
+__global__ void k_fill_u8(uint8_t* p, uint32_t n, uint8_t v)
+{
+    uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// transports
+// ------------------------------------------------------------------------------------------------
+struct Group;
+struct Xfer {
+    const void* send[2];  // to left, to right
+    size_t send_bytes[2];
+    void* recv[2];        // from left, from right
+    size_t recv_bytes[2];
+};
+
+struct Comm {
+    virtual ~Comm() {}
+    // reduce k host values per member element-wise over ALL ranks; every member's row receives the result
+    virtual int allreduce_min_f32(Group& G, std::vector<std::vector<float>>& rows) = 0;
+    virtual int allreduce_max_i32(Group& G, std::vector<int>& vals) = 0;
+    // every member learns the (to-left, to-right) counts its x-neighbours are about to send it
+    virtual int neighbour_counts(Group& G, const std::vector<uint32_t>& to_left, const std::vector<uint32_t>& to_right,
+                                 std::vector<uint32_t>& from_left, std::vector<uint32_t>& from_right) = 0;
+    // device buffers; ordered after everything queued on the members' streams
+    virtual int exchange(Group& G, std::vector<Xfer>& x) = 0;
+    // element-wise sum of the members' 4 device doubles (solver totals), result in every member's buffer
+    virtual int allreduce_solver(Group& G) = 0;
+};
+
+struct Group {
+    std::vector<sph_ctx*> m;
+    Comm* comm = nullptr;  // nullptr: one rank, nothing to exchange
+    bool multi() const { return comm != nullptr; }
+};
+
+static int wait_all(Group& G)
+{
+    for (auto c : G.m) {
+        int rc = wait_stream(c);
+        if (rc) return rc;
+    }
+    return SPH_OK;
+}
+
+// ---- loopback: all ranks are contexts of this process ---------------------------------------------
+struct LocalComm : Comm {
+    int allreduce_min_f32(Group& G, std::vector<std::vector<float>>& rows) override
+    {
+        for (size_t k = 0; k < rows[0].size(); k++) {
+            float v = rows[0][k];
+            for (auto& r : rows) v = fminf(v, r[k]);
+            for (auto& r : rows) r[k] = v;
+        }
+        return SPH_OK;
+    }
+    int allreduce_max_i32(Group& G, std::vector<int>& vals) override
+    {
+        int v = 0;
+        for (int x : vals) v = x > v ? x : v;
+        for (int& x : vals) x = v;
+        return SPH_OK;
+    }
+    int neighbour_counts(Group& G, const std::vector<uint32_t>& tl, const std::vector<uint32_t>& tr, std::vector<uint32_t>& fl,
+                         std::vector<uint32_t>& fr) override
+    {
+        const size_t n = G.m.size();
+        for (size_t i = 0; i < n; i++) {
+            fl[i] = i > 0 ? tr[i - 1] : 0;
+            fr[i] = i + 1 < n ? tl[i + 1] : 0;
+        }
+        return SPH_OK;
+    }
+    int exchange(Group& G, std::vector<Xfer>& x) override
+    {
+        int rc = wait_all(G);
+        if (rc) return rc;
+        const size_t n = G.m.size();
+        for (size_t i = 0; i < n; i++) {
+            sph_ctx* c = G.m[i];
+            HIPCHK(c, hipSetDevice(c->device));
+            if (i > 0 && x[i].recv_bytes[0]) HIPCHK(c, hipMemcpyAsync(x[i].recv[0], x[i - 1].send[1], x[i].recv_bytes[0], hipMemcpyDefault, c->stream));
+            if (i + 1 < n && x[i].recv_bytes[1]) HIPCHK(c, hipMemcpyAsync(x[i].recv[1], x[i + 1].send[0], x[i].recv_bytes[1], hipMemcpyDefault, c->stream));
+        }
+        return wait_all(G);  // senders may reuse their staging buffers afterwards
+    }
+    int allreduce_solver(Group& G) override
+    {
+        int rc = wait_all(G);
+        if (rc) return rc;
+        double tot[4] = {0, 0, 0, 0};
+        std::vector<std::array<double, 4>> rows(G.m.size());
+        for (size_t i = 0; i < G.m.size(); i++) {
+            HIPCHK(G.m[i], hipMemcpy(rows[i].data(), G.m[i]->dist.solver_tot.p, 32, hipMemcpyDeviceToHost));
+            for (int k = 0; k < 4; k++) tot[k] += rows[i][k];
+        }
+        for (auto c : G.m) HIPCHK(c, hipMemcpy(c->dist.solver_tot.p, tot, 32, hipMemcpyHostToDevice));
+        return SPH_OK;
+    }
+};
+
+// ---- RCCL over xGMI: one rank per process ------------------------------------------------------------
+#define NCCLCHK(ctx, call)                                                                               \
+    do {                                                                                                 \
+        ncclResult_t r_ = (call);                                                                        \
+        if (r_ != ncclSuccess) return (ctx)->fail(SPH_ERR_DEVICE, "%s failed: %s", #call, ncclGetErrorString(r_)); \
+    } while (0)
+
+struct RcclComm : Comm {
+    // small device scratch for host-value collectives
+    static int host_allreduce(sph_ctx* c, void* host, size_t bytes, size_t count, ncclDataType_t dt, ncclRedOp_t op)
+    {
+        ncclComm_t nc = (ncclComm_t)c->dist.nccl;
+        void* d = c->dist.counts.as<uint32_t>() + 16;  // scratch area behind the counters
+        HIPCHK(c, hipMemcpyAsync(d, host, bytes, hipMemcpyHostToDevice, c->stream));
+        NCCLCHK(c, ncclAllReduce(d, d, count, dt, op, nc, c->stream));
+        HIPCHK(c, hipMemcpyAsync(host, d, bytes, hipMemcpyDeviceToHost, c->stream));
+        return wait_stream(c);
+    }
+    int allreduce_min_f32(Group& G, std::vector<std::vector<float>>& rows) override
+    {
+        return host_allreduce(G.m[0], rows[0].data(), rows[0].size() * 4, rows[0].size(), ncclFloat32, ncclMin);
+    }
+    int allreduce_max_i32(Group& G, std::vector<int>& vals) override
+    {
+        return host_allreduce(G.m[0], vals.data(), vals.size() * 4, vals.size(), ncclInt32, ncclMax);
+    }
+    int neighbour_counts(Group& G, const std::vector<uint32_t>& tl, const std::vector<uint32_t>& tr, std::vector<uint32_t>& fl,
+                         std::vector<uint32_t>& fr) override
+    {
+        sph_ctx* c = G.m[0];
+        ncclComm_t nc = (ncclComm_t)c->dist.nccl;
+        const int r = c->dist.rank, nr = c->dist.nranks;
+        uint32_t* d = c->dist.counts.as<uint32_t>() + 16;  // [0]=to_left [1]=to_right [2]=from_left [3]=from_right
+        uint32_t h[4] = {tl[0], tr[0], 0, 0};
+        HIPCHK(c, hipMemcpyAsync(d, h, 16, hipMemcpyHostToDevice, c->stream));
+        NCCLCHK(c, ncclGroupStart());
+        if (r > 0) {
+            NCCLCHK(c, ncclSend(d + 0, 1, ncclUint32, r - 1, nc, c->stream));
+            NCCLCHK(c, ncclRecv(d + 2, 1, ncclUint32, r - 1, nc, c->stream));
+        }
+        if (r + 1 < nr) {
+            NCCLCHK(c, ncclSend(d + 1, 1, ncclUint32, r + 1, nc, c->stream));
+            NCCLCHK(c, ncclRecv(d + 3, 1, ncclUint32, r + 1, nc, c->stream));
+        }
+        NCCLCHK(c, ncclGroupEnd());
+        HIPCHK(c, hipMemcpyAsync(h, d, 16, hipMemcpyDeviceToHost, c->stream));
+        int rc = wait_stream(c);
+        if (rc) return rc;
+        fl[0] = r > 0 ? h[2] : 0;
+        fr[0] = r + 1 < nr ? h[3] : 0;
+        return SPH_OK;
+    }
+    int exchange(Group& G, std::vector<Xfer>& x) override
+    {
+        sph_ctx* c = G.m[0];
+        ncclComm_t nc = (ncclComm_t)c->dist.nccl;
+        const int r = c->dist.rank, nr = c->dist.nranks;
+        NCCLCHK(c, ncclGroupStart());
+        if (r > 0) {
+            if (x[0].send_bytes[0]) NCCLCHK(c, ncclSend(x[0].send[0], x[0].send_bytes[0], ncclChar, r - 1, nc, c->stream));
+            if (x[0].recv_bytes[0]) NCCLCHK(c, ncclRecv(x[0].recv[0], x[0].recv_bytes[0], ncclChar, r - 1, nc, c->stream));
+        }
+        if (r + 1 < nr) {
+            if (x[0].send_bytes[1]) NCCLCHK(c, ncclSend(x[0].send[1], x[0].send_bytes[1], ncclChar, r + 1, nc, c->stream));
+            if (x[0].recv_bytes[1]) NCCLCHK(c, ncclRecv(x[0].recv[1], x[0].recv_bytes[1], ncclChar, r + 1, nc, c->stream));
+        }
+        NCCLCHK(c, ncclGroupEnd());
+        return SPH_OK;
+    }
+    int allreduce_solver(Group& G) override
+    {
+        sph_ctx* c = G.m[0];
+        NCCLCHK(c, ncclAllReduce(c->dist.solver_tot.p, c->dist.solver_tot.p, 4, ncclFloat64, ncclSum, (ncclComm_t)c->dist.nccl, c->stream));
+        return SPH_OK;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// the group step
+// ------------------------------------------------------------------------------------------------
+struct Member {
+    sph_ctx* c;
+    uint32_t n;  // particles in the arrays (owned + ghosts)
+    StepP sp;
+    SweepArgs a;
+    sph_step_stats st;
+    std::chrono::steady_clock::time_point wall0;
+};
+
+// collective error check at a wait point: returns the first error of this process, or (multi-rank) a generic
+// failure if another rank failed -- every rank must leave the step together or the next collective hangs
+static int agree(Group& G, int local_rc)
+{
+    if (!G.multi()) return local_rc;
+    std::vector<int> v(G.m.size(), local_rc);
+    int rc = G.comm->allreduce_max_i32(G, v);
+    if (rc) return rc;
+    if (local_rc) return local_rc;
+    if (v[0]) return G.m[0]->fail(v[0], "another rank of the slab decomposition reported status %d", v[0]);
+    return SPH_OK;
+}
+
+// publish ctrl + status of every member to the host and wait; device-side guards -> status code
+static int sync_ctrl(Group& G)
+{
+    int rc = SPH_OK;
+    for (auto c : G.m) {
+        (void)hipSetDevice(c->device);
+        launch_publish(c);
+    }
+    for (auto c : G.m) {
+        int r = wait_stream(c);
+        if (r && !rc) rc = r;
+        if (!r && c->status_host->error) {
+            uint32_t code = c->status_host->error, info = c->status_host->info;
+            (void)hipMemsetAsync(c->status.p, 0, sizeof(DeviceStatus), c->stream);
+            c->status_host->error = 0;
+            r = c->fail((int)code, "%s (particle i=%u)", status_message(code), info);
+            if (!rc) rc = r;
+        }
+    }
+    return agree(G, rc);
+}
+
+// refresh `field` (words floats per particle) of every member's ghosts from their owners
+static int refresh_ghosts(Group& G, std::vector<Member>& M, float* (*sel)(Member&), int words, const char* what)
+{
+    if (!G.multi()) return SPH_OK;
+    std::vector<Xfer> x(M.size());
+    for (size_t i = 0; i < M.size(); i++) {
+        sph_ctx* c = M[i].c;
+        (void)hipSetDevice(c->device);
+        ProfScope ps(&c->prof, "ghost_pack", c->stream);
+        float* field = sel(M[i]);
+        for (int side = 0; side < 2; side++) {
+            const uint32_t cnt = c->dist.n_halo[side];
+            const uint32_t off = side == 0 ? 0 : c->dist.n_halo[0];
+            if (cnt)
+                hipLaunchKernelGGL(k_pack_field, dim3((cnt + 255) / 256), dim3(256), 0, c->stream, c->dist.halo_src.as<uint32_t>() + off, cnt, words,
+                                   field, c->dist.send[side].as<float>());
+            x[i].send[side] = c->dist.send[side].p;
+            x[i].send_bytes[side] = (size_t)cnt * words * 4;
+            x[i].recv[side] = c->dist.recv[side].p;
+            x[i].recv_bytes[side] = (size_t)c->dist.n_ghost[side] * words * 4;
+        }
+    }
+    int rc = G.comm->exchange(G, x);
+    if (rc) return rc;
+    for (size_t i = 0; i < M.size(); i++) {
+        sph_ctx* c = M[i].c;
+        (void)hipSetDevice(c->device);
+        ProfScope ps(&c->prof, "ghost_unpack", c->stream);
+        float* field = sel(M[i]);
+        for (int side = 0; side < 2; side++) {
+            const uint32_t cnt = c->dist.n_ghost[side];
+            const uint32_t off = side == 0 ? 0 : c->dist.n_ghost[0];
+            if (cnt)
+                hipLaunchKernelGGL(k_unpack_field, dim3((cnt + 255) / 256), dim3(256), 0, c->stream, c->dist.ghost_dst.as<uint32_t>() + off, cnt,
+                                   words, c->dist.recv[side].as<float>(), field);
+        }
+    }
+    (void)what;
+    return SPH_OK;
+}
+
+static float* sel_rho(Member& m) { return m.a.rho; }
+static float* sel_mrho(Member& m) { return m.a.mrho; }
+static float* sel_vel(Member& m) { return (float*)m.a.vel; }
+static float* sel_pacc(Member& m) { return (float*)m.a.pacc; }
+static float* sel_pt0(Member& m) { return m.a.pt0; }
+static float* sel_pt1(Member& m) { return m.a.pt1; }
+
+static int ensure_dist_buffers(sph_ctx* c, uint32_t n)
+{
+    auto& d = c->dist;
+    const size_t cap = c->cap ? c->cap : 1;
+    (void)n;
+    HIPCHK(c, d.owned.ensure(cap));
+    HIPCHK(c, d.halo_idx.ensure(cap * 4));
+    HIPCHK(c, d.halo_pos.ensure(cap * 4));
+    HIPCHK(c, d.halo_src.ensure(cap * 4));
+    HIPCHK(c, d.ghost_dst.ensure(cap * 4));
+    for (int s = 0; s < 2; s++) {
+        HIPCHK(c, d.send[s].ensure(cap * MIG_WORDS * 4 / 2 + 1024));
+        HIPCHK(c, d.recv[s].ensure(cap * MIG_WORDS * 4 / 2 + 1024));
+    }
+    HIPCHK(c, d.counts.ensure(256));
+    HIPCHK(c, d.solver_tot.ensure(64));
+    if (!d.counts_host) {
+        HIPCHK(c, hipHostMalloc((void**)&d.counts_host, 64, hipHostMallocMapped));
+        HIPCHK(c, hipHostGetDevicePointer((void**)&d.counts_host_dev, d.counts_host, 0));
+    }
+    return SPH_OK;
+}
+
+__global__ void k_copy_counts(const uint32_t* __restrict__ src, uint32_t* __restrict__ host_dst)
+{
+    if (threadIdx.x < 8) host_dst[threadIdx.x] = src[threadIdx.x];
+}
+
+// ---- slab maintenance (multi-rank only) ---------------------------------------------------------------
+// part 1: drop last step's ghosts, hand over particles that left the slab
+static int partition_and_migrate(Group& G, std::vector<Member>& M)
+{
+    const size_t nm = M.size();
+    int rc = SPH_OK;
+    // (1) classify the previous arrays: stay / migrate left / migrate right / drop (ghost); stable partition by a
+    //     1-pass radix sort on the 2-bit class (reuses the neighbour-build sort: deterministic order)
+    for (auto& m : M) {
+        sph_ctx* c = m.c;
+        auto& d = c->dist;
+        (void)hipSetDevice(c->device);
+        if ((rc = ensure_dist_buffers(c, m.n))) return rc;
+        const uint32_t n_prev = d.have_flags ? d.n_tot : (uint32_t)c->n;
+        (void)hipMemsetAsync(d.counts.p, 0, 64, c->stream);
+        if (n_prev) {
+            ProfScope ps(&c->prof, "slab_partition", c->stream);
+            hipLaunchKernelGGL(k_classify_migrate, dim3((n_prev + 255) / 256), dim3(256), 0, c->stream, n_prev, c->pm[c->pcur].as<float4>(),
+                               d.have_flags ? d.owned.as<uint8_t>() : (const uint8_t*)nullptr, d.cut_lo, d.cut_hi, d.rank > 0 ? 1 : 0,
+                               d.rank + 1 < d.nranks ? 1 : 0, c->key[0].as<uint32_t>(), c->val[0].as<uint32_t>(), d.counts.as<uint32_t>());
+            int res = radix_sort_pairs(c->stream, &c->prof, c->key[0].as<uint32_t>(), c->val[0].as<uint32_t>(), c->key[1].as<uint32_t>(),
+                                       c->val[1].as<uint32_t>(), n_prev, 2, c->sort_scratch.as<uint32_t>());
+            if (res == 1) {
+                std::swap(c->key[0], c->key[1]);
+                std::swap(c->val[0], c->val[1]);
+            }
+            GridP g1{};
+            g1.sx = 1;
+            const int k = c->cur;
+            launch_reorder(c->stream, &c->prof, n_prev, g1, c->key[0].as<uint32_t>(), c->val[0].as<uint32_t>(), c->pm[c->pcur].as<float4>(),
+                           c->vel[k].as<float2>(), c->orig[k].as<uint32_t>(), c->lvl[k].as<float>(), c->lvlold[k].as<float>(),
+                           c->pm[c->pcur ^ 1].as<float4>(), c->vel[k ^ 1].as<float2>(), c->orig[k ^ 1].as<uint32_t>(), c->lvl[k ^ 1].as<float>(),
+                           c->lvlold[k ^ 1].as<float>(), c->cxy.as<uint32_t>());
+            c->cur = k ^ 1;
+            c->pcur ^= 1;
+        }
+        hipLaunchKernelGGL(k_copy_counts, dim3(1), dim3(64), 0, c->stream, d.counts.as<uint32_t>(), d.counts_host_dev);
+    }
+    if ((rc = agree(G, wait_all(G)))) return rc;
+    // (2) migrants: counts -> neighbours, then the records
+    std::vector<uint32_t> tl(nm), tr(nm), fl(nm), fr(nm);
+    for (size_t i = 0; i < nm; i++) {
+        tl[i] = M[i].c->dist.counts_host[1];
+        tr[i] = M[i].c->dist.counts_host[2];
+    }
+    if ((rc = G.comm->neighbour_counts(G, tl, tr, fl, fr))) return rc;
+    std::vector<Xfer> x(nm);
+    for (size_t i = 0; i < nm; i++) {
+        sph_ctx* c = M[i].c;
+        auto& d = c->dist;
+        (void)hipSetDevice(c->device);
+        const uint32_t n_stay = d.counts_host[0];
+        if ((uint64_t)n_stay + fl[i] + fr[i] > c->cap)
+            return agree(G, c->fail(SPH_ERR_CAPACITY, "slab of rank %d needs %llu particles, capacity %llu", d.rank,
+                                    (unsigned long long)n_stay + fl[i] + fr[i], (unsigned long long)c->cap));
+        const int k = c->cur;
+        const uint32_t base[2] = {n_stay, n_stay + tl[i]};
+        const uint32_t cnt[2] = {tl[i], tr[i]};
+        for (int side = 0; side < 2; side++) {
+            if (cnt[side])
+                hipLaunchKernelGGL(k_pack_migrants, dim3((cnt[side] + 255) / 256), dim3(256), 0, c->stream, base[side], cnt[side],
+                                   c->pm[c->pcur].as<float4>(), c->vel[k].as<float2>(), c->orig[k].as<uint32_t>(), c->lvl[k].as<float>(),
+                                   c->lvlold[k].as<float>(), d.send[side].as<float>());
+            x[i].send[side] = d.send[side].p;
+            x[i].send_bytes[side] = (size_t)cnt[side] * MIG_WORDS * 4;
+            x[i].recv[side] = d.recv[side].p;
+        }
+        x[i].recv_bytes[0] = (size_t)fl[i] * MIG_WORDS * 4;
+        x[i].recv_bytes[1] = (size_t)fr[i] * MIG_WORDS * 4;
+    }
+    if ((rc = G.comm->exchange(G, x))) return rc;
+    for (size_t i = 0; i < nm; i++) {
+        sph_ctx* c = M[i].c;
+        auto& d = c->dist;
+        (void)hipSetDevice(c->device);
+        const int k = c->cur;
+        const uint32_t n_stay = d.counts_host[0];
+        const uint32_t cnt[2] = {fl[i], fr[i]};
+        const uint32_t base[2] = {n_stay, n_stay + fl[i]};
+        for (int side = 0; side < 2; side++)
+            if (cnt[side])
+                hipLaunchKernelGGL(k_unpack_migrants, dim3((cnt[side] + 255) / 256), dim3(256), 0, c->stream, base[side], cnt[side],
+                                   d.recv[side].as<float>(), c->pm[c->pcur].as<float4>(), c->vel[k].as<float2>(), c->orig[k].as<uint32_t>(),
+                                   c->lvl[k].as<float>(), c->lvlold[k].as<float>());
+        c->n = n_stay + fl[i] + fr[i];
+        d.have_flags = false;
+        d.n_tot = (uint32_t)c->n;
+        M[i].n = (uint32_t)c->n;
+    }
+    return SPH_OK;
+}
+
+// part 2: ghost layer -- owned particles within halo_width of a cut are copied to that neighbour, in array
+// order (stable partition again)
+static int build_ghost_layer(Group& G, std::vector<Member>& M, float halo_width)
+{
+    const size_t nm = M.size();
+    int rc = SPH_OK;
+    std::vector<uint32_t> tl(nm), tr(nm), fl(nm), fr(nm);
+    std::vector<Xfer> x(nm);
+    for (auto& m : M) {
+        sph_ctx* c = m.c;
+        auto& d = c->dist;
+        (void)hipSetDevice(c->device);
+        const uint32_t n = (uint32_t)c->n;
+        (void)hipMemsetAsync(d.counts.p, 0, 64, c->stream);
+        if (n) {
+            ProfScope ps(&c->prof, "slab_halo_select", c->stream);
+            hipLaunchKernelGGL(k_classify_halo, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, c->pm[c->pcur].as<float4>(), d.cut_lo + halo_width,
+                               d.cut_hi - halo_width, d.rank > 0 ? 1 : 0, d.rank + 1 < d.nranks ? 1 : 0, c->key[0].as<uint32_t>(),
+                               c->val[0].as<uint32_t>(), d.counts.as<uint32_t>());
+            int res = radix_sort_pairs(c->stream, &c->prof, c->key[0].as<uint32_t>(), c->val[0].as<uint32_t>(), c->key[1].as<uint32_t>(),
+                                       c->val[1].as<uint32_t>(), n, 2, c->sort_scratch.as<uint32_t>());
+            if (res == 1) {
+                std::swap(c->key[0], c->key[1]);
+                std::swap(c->val[0], c->val[1]);
+            }
+        }
+        hipLaunchKernelGGL(k_copy_counts, dim3(1), dim3(64), 0, c->stream, d.counts.as<uint32_t>(), d.counts_host_dev);
+    }
+    if ((rc = agree(G, wait_all(G)))) return rc;
+    for (size_t i = 0; i < nm; i++) {
+        auto& d = M[i].c->dist;
+        if (d.counts_host[4 + 3])
+            return agree(G, M[i].c->fail(SPH_ERR_UNSUPPORTED, "slab of rank %d is narrower than two support radii", d.rank));
+        tl[i] = d.counts_host[4 + 1];
+        tr[i] = d.counts_host[4 + 2];
+    }
+    if ((rc = agree(G, SPH_OK))) return rc;
+    if ((rc = G.comm->neighbour_counts(G, tl, tr, fl, fr))) return rc;
+    for (size_t i = 0; i < nm; i++) {
+        sph_ctx* c = M[i].c;
+        auto& d = c->dist;
+        (void)hipSetDevice(c->device);
+        const uint32_t n = (uint32_t)c->n;
+        if ((uint64_t)n + fl[i] + fr[i] > c->cap)
+            return agree(G, c->fail(SPH_ERR_CAPACITY, "slab of rank %d + ghosts needs %llu particles, capacity %llu", d.rank,
+                                    (unsigned long long)n + fl[i] + fr[i], (unsigned long long)c->cap));
+        const uint32_t n_none = d.counts_host[4 + 0];
+        d.n_halo[0] = tl[i];
+        d.n_halo[1] = tr[i];
+        d.n_ghost[0] = fl[i];
+        d.n_ghost[1] = fr[i];
+        const uint32_t nh = tl[i] + tr[i];
+        // halo index list = sorted values behind the `none` class: [left..., right...]
+        if (nh) HIPCHK(c, hipMemcpyAsync(d.halo_idx.p, c->val[0].as<uint32_t>() + n_none, (size_t)nh * 4, hipMemcpyDeviceToDevice, c->stream));
+        const int k = c->cur;
+        for (int side = 0; side < 2; side++) {
+            const uint32_t cnt = d.n_halo[side], off = side == 0 ? 0 : d.n_halo[0];
+            if (cnt)
+                hipLaunchKernelGGL(k_pack_ghosts, dim3((cnt + 255) / 256), dim3(256), 0, c->stream, d.halo_idx.as<uint32_t>() + off, cnt,
+                                   c->pm[c->pcur].as<float4>(), c->vel[k].as<float2>(), d.send[side].as<float>());
+            x[i].send[side] = d.send[side].p;
+            x[i].send_bytes[side] = (size_t)cnt * GHOST_WORDS * 4;
+            x[i].recv[side] = d.recv[side].p;
+            x[i].recv_bytes[side] = (size_t)d.n_ghost[side] * GHOST_WORDS * 4;
+        }
+    }
+    if ((rc = G.comm->exchange(G, x))) return rc;
+    for (size_t i = 0; i < nm; i++) {
+        sph_ctx* c = M[i].c;
+        auto& d = c->dist;
+        (void)hipSetDevice(c->device);
+        const int k = c->cur;
+        const uint32_t n = (uint32_t)c->n;
+        const uint32_t base[2] = {n, n + d.n_ghost[0]};
+        for (int side = 0; side < 2; side++)
+            if (d.n_ghost[side])
+                hipLaunchKernelGGL(k_unpack_ghosts, dim3((d.n_ghost[side] + 255) / 256), dim3(256), 0, c->stream, base[side], d.n_ghost[side],
+                                   d.recv[side].as<float>(), c->pm[c->pcur].as<float4>(), c->vel[k].as<float2>(), c->orig[k].as<uint32_t>(),
+                                   c->lvl[k].as<float>(), c->lvlold[k].as<float>());
+        d.n_tot = n + d.n_ghost[0] + d.n_ghost[1];
+        M[i].n = d.n_tot;
+        // pre-sort index -> position in my halo list
+        if (d.n_tot) (void)hipMemsetAsync(d.halo_pos.p, 0xff, (size_t)d.n_tot * 4, c->stream);
+        const uint32_t nh = d.n_halo[0] + d.n_halo[1];
+        if (nh) hipLaunchKernelGGL(k_halo_pos, dim3((nh + 255) / 256), dim3(256), 0, c->stream, d.halo_idx.as<uint32_t>(), nh, d.halo_pos.as<uint32_t>());
+    }
+    return SPH_OK;
+}
+
+// iisph_pressure_iterations (simulation.rs:1377-1516).  Iteration 0 was folded into the source-term sweep
+// (closed form, see OpSource); its statistics are reduced here.  Iterations are enqueued speculatively up to
+// the predicted count, followed by the FINAL pressure-acceleration sweep with its fused tail; every kernel
+// checks the device-side `done` flag first, so iterations queued past the stop decision cost a launch and
+// nothing else, and the final sweep only runs once the decision is taken.  One host wait per chunk.
+static int pressure_iterations(Group& G, std::vector<Member>& M, float max_avg_error, int residual_density, uint32_t max_iters,
+                               uint32_t predicted_iters, int tail, bool density_solver)
+{
+    int rc;
+    auto reduce_and_decide = [&](int iter) -> int {
+        for (auto& m : M) {
+            (void)hipSetDevice(m.c->device);
+            if (!G.multi()) launch_solver_reduce(m.c->stream, &m.c->prof, m.a, iter, residual_density, max_avg_error, max_iters, m.a.partials);
+            else launch_solver_local(m.c->stream, &m.c->prof, m.a, m.a.partials);
+        }
+        if (G.multi()) {
+            int r = G.comm->allreduce_solver(G);
+            if (r) return r;
+            for (auto& m : M) {
+                (void)hipSetDevice(m.c->device);
+                launch_solver_decide(m.c->stream, &m.c->prof, m.a, iter, residual_density, max_avg_error, max_iters);
+            }
+        }
+        return SPH_OK;
+    };
+    auto pt_of = [&](int cur) { return cur ? sel_pt1 : sel_pt0; };
+    // iteration 0 wrote pressure buffer 1
+    if ((rc = refresh_ghosts(G, M, sel_pt1, 1, "pt"))) return rc;
+    if ((rc = reduce_and_decide(0))) return rc;
+    uint32_t k = 1;
+    uint32_t upto = predicted_iters > 2 ? predicted_iters : 2;
+    for (;;) {
+        for (; k <= upto && k <= max_iters; k++) {
+            for (auto& m : M) {
+                (void)hipSetDevice(m.c->device);
+                if (m.n) launch_pressure_accel(m.c->stream, &m.c->prof, m.a, (int)k, 0, nullptr);
+            }
+            if ((rc = refresh_ghosts(G, M, sel_pacc, 2, "pacc"))) return rc;
+            for (auto& m : M) {
+                (void)hipSetDevice(m.c->device);
+                if (m.n) launch_jacobi_update(m.c->stream, &m.c->prof, m.a, (int)k, residual_density);
+            }
+            if ((rc = refresh_ghosts(G, M, pt_of((k + 1) & 1), 1, "pt"))) return rc;
+            if ((rc = reduce_and_decide((int)k))) return rc;
+        }
+        for (auto& m : M) {
+            (void)hipSetDevice(m.c->device);
+            if (m.n) launch_pressure_accel(m.c->stream, &m.c->prof, m.a, -1, tail, m.c->pm[m.c->pcur ^ 1].as<float4>());
+        }
+        if ((rc = sync_ctrl(G))) return rc;
+        if (M[0].c->ctrl_host->done) break;
+        if (k > max_iters) break;  // cannot happen: iteration max_iters always sets done
+        upto = k + 1;
+    }
+    for (auto& m : M) {
+        const SolverCtrl& h = *m.c->ctrl_host;
+        m.c->pressure_cur = h.cur;
+        sph_solver_stats* st = density_solver ? &m.st.density_solver : &m.st.div_solver;
+        st->iters = h.iters;
+        st->converged = 1;
+        st->normal_count = h.normal;
+        st->singular_count = h.singular;
+        st->negative_count = h.negative;
+        st->avg_error = h.normal > 0 ? h.sum_err / (float)h.normal : NAN;
+        st->max_error = h.max_err;
+    }
+    return SPH_OK;
+}
+
+static int group_step(Group& G, const sph_params* p, sph_step_stats* outs)
+{
+    int rc = SPH_OK;
+    g_trace.start();
+    std::vector<Member> M(G.m.size());
+    for (size_t i = 0; i < G.m.size(); i++) {
+        M[i].c = G.m[i];
+        M[i].n = (uint32_t)G.m[i]->n;
+        memset(&M[i].st, 0, sizeof(sph_step_stats));
+        M[i].wall0 = std::chrono::steady_clock::now();
+    }
+    sph_ctx* c0 = G.m[0];
+    // ---- parameter combinations this build does not cover are refused, never approximated ---------------
+    if (c0->n_planes == 0) return c0->fail(SPH_ERR_NO_BOUNDARY, "not implemented: NoBoundaryHandler::iisph_aii");
+    if (p->support_length_estimation != SPH_H_FROM_MASS)
+        return c0->fail(SPH_ERR_UNSUPPORTED, "support_length_estimation other than FromMass is not covered yet");
+    if (p->constrain_neighborhood_count) return c0->fail(SPH_ERR_UNSUPPORTED, "constrain_neighborhood_count is not covered yet");
+    if (p->pressure_solver_method == SPH_SOLVER_IISPH2) return c0->fail(SPH_ERR_UNSUPPORTED, "IISPH2 is not covered yet");
+    if (p->level_estimation_method != SPH_LEVEL_NONE)
+        return c0->fail(SPH_ERR_UNSUPPORTED, "level estimation on the device is not covered yet (SURVEY.md 8f rank 1)");
+    if (p->check_aii) return c0->fail(SPH_ERR_UNSUPPORTED, "check_aii is not covered yet");
+    if (!p->level_estimation_after_advection && !p->use_extended_range_for_level_estimation)
+        return c0->fail(SPH_ERR_INVALID_ARGUMENT, "assertion failed: simulation_params.use_extended_range_for_level_estimation");
+    if (!G.multi() && c0->n == 0) return c0->fail(SPH_ERR_INVALID_ARGUMENT, "called `Option::unwrap()` on a `None` value (no particles)");
+
+    // ---- slab maintenance part 1 needs no global scalar: partition + migrate (multi-rank) -----------------
+    // (the ghost layer needs the all-reduced h_max, so the header of the owned particles comes first)
+    const bool tev = c0->prof.mode == 1;
+    for (auto& m : M) {
+        (void)hipSetDevice(m.c->device);
+        if (tev) (void)hipEventRecord(m.c->ev[0], m.c->stream);
+    }
+
+    // ---- step header over the OWNED particles: h from mass (simulation.rs:1998-2003), CFL term, h_max ------
+    // (multi-rank: ghosts of the previous step are still interleaved -> partition first, inside decompose();
+    //  for that the header has to run on the partitioned arrays, so decompose() is split around it)
+    std::vector<std::vector<float>> red(M.size(), std::vector<float>(3));
+    if (G.multi()) {
+        if ((rc = partition_and_migrate(G, M))) return rc;  // only needs the cuts
+    }
+    g_trace.mark(0);
+    for (auto& m : M) {
+        (void)hipSetDevice(m.c->device);
+        launch_header(m.c, (uint32_t)m.c->n, p->rest_density, 1, m.c->hdr_host_dev);
+    }
+    if ((rc = agree(G, wait_all(G)))) return rc;
+    for (size_t i = 0; i < M.size(); i++) {
+        const HeaderOut h = *M[i].c->hdr_host;
+        red[i][0] = M[i].c->n ? -h.h_max : 0.f;
+        red[i][1] = M[i].c->n ? h.h_min : INFINITY;
+        red[i][2] = M[i].c->n ? h.min_cfl : INFINITY;
+    }
+    if (G.multi() && (rc = G.comm->allreduce_min_f32(G, red))) return rc;
+    const float h_max_g = -red[0][0], h_min_g = red[0][1], min_cfl_g = red[0][2];
+    if (!(h_max_g > 0.f) || !std::isfinite(h_max_g))
+        return agree(G, c0->fail(SPH_ERR_POSITION_NOT_FINITE, "particle positions or smoothing lengths are not finite"));
+    // CFL (simulation.rs:2190-2191)
+    const float cfl_dt = p->cfl_factor * sqrtf(min_cfl_g);
+    const float dt = fminf(p->max_dt, cfl_dt);
+
+    if (G.multi()) {
+        // ghost layer with the real width: one support radius of the largest particle anywhere
+        if ((rc = build_ghost_layer(G, M, h_max_g * 2.f))) return rc;
+        // bounding box of owned + ghosts
+        for (auto& m : M) {
+            (void)hipSetDevice(m.c->device);
+            launch_header(m.c, m.n, p->rest_density, 1, m.c->hdr_host_dev);
+        }
+        if ((rc = agree(G, wait_all(G)))) return rc;
+    }
+    g_trace.mark(1);
+
+    for (auto& m : M) {
+        sph_ctx* c = m.c;
+        (void)hipSetDevice(c->device);
+        const HeaderOut hdr = *c->hdr_host;
+        const uint32_t n = m.n;
+        // CellGrid (neighborhood_search.rs:261-275) with cell = support radius of the largest particle
+        GridP g{};
+        g.cs = h_max_g * 2.f;
+        if (n) {
+            if (!std::isfinite(hdr.min_x) || !std::isfinite(hdr.max_x) || !std::isfinite(hdr.min_y) || !std::isfinite(hdr.max_y))
+                return agree(G, c->fail(SPH_ERR_POSITION_NOT_FINITE, "particle positions are not finite"));
+            g.minx = (int)floorf(hdr.min_x / g.cs) - 1;
+            g.miny = (int)floorf(hdr.min_y / g.cs) - 1;
+            const long long sx = (long long)((int)floorf(hdr.max_x / g.cs) + 2) - g.minx;
+            const long long sy = (long long)((int)floorf(hdr.max_y / g.cs) + 2) - g.miny;
+            if (sx <= 0 || sy <= 0 || sx >= 65536 || sy >= 65536 || sx * sy >= (1ll << 31))
+                return agree(G, c->fail(SPH_ERR_UNSUPPORTED, "cell grid %lld x %lld is too large for this build", sx, sy));
+            g.sx = (int)sx;
+            g.sy = (int)sy;
+        } else {
+            g.sx = g.sy = 1;
+        }
+        g.ncells = (uint32_t)g.sx * (uint32_t)g.sy;
+        g.ntx = g.nty = 0;
+        c->grid = g;
+        c->grid_valid = true;
+        HIPCHK(c, c->cell_start.ensure(((size_t)g.ncells + 1) * sizeof(uint32_t)));
+        c->uniform_h = (h_min_g == h_max_g);
+        c->h_uniform = h_max_g;
+
+        StepP sp{};
+        sp.rest_density = p->rest_density;
+        sp.viscosity = p->viscosity;
+        sp.gravity = p->gravity;
+        sp.jacobi_omega = p->jacobi_omega;
+        sp.dt = dt;
+        sp.sdf_eps = p->sdf_gradient_eps;
+        sp.pull_x = p->pull_fluid_to[0];
+        sp.pull_y = p->pull_fluid_to[1];
+        sp.hyb_vfactor = fminf(dt * p->hybrid_dfsph_factor, 1.f);
+        sp.viscosity_type = p->viscosity_type;
+        sp.penalty = p->boundary_penalty_term;
+        sp.opdisc = p->operator_discretization;
+        sp.has_pull = p->has_pull_fluid_to;
+        sp.n_planes = c->n_planes;
+        m.sp = sp;
+
+        // ---- neighbourhood: cell index -> radix sort -> reorder -> cell ranges ---------------------------
+        // (replaces build_neighborhood_list + filter_down, simulation.rs:2018-2070; same neighbour set)
+        hipStream_t s = c->stream;
+        Profiler* prof = &c->prof;
+        int k = c->cur;
+        if (n) {
+            launch_cell_keys(s, prof, c->pm[c->pcur].as<float4>(), n, g, c->key[0].as<uint32_t>(), c->val[0].as<uint32_t>());
+            int res = radix_sort_pairs(s, prof, c->key[0].as<uint32_t>(), c->val[0].as<uint32_t>(), c->key[1].as<uint32_t>(),
+                                       c->val[1].as<uint32_t>(), n, ilog2_ceil(g.ncells), c->sort_scratch.as<uint32_t>());
+            if (res == 1) {  // keep the sorted keys in key[0] / val[0]
+                std::swap(c->key[0], c->key[1]);
+                std::swap(c->val[0], c->val[1]);
+            }
+            launch_reorder(s, prof, n, g, c->key[0].as<uint32_t>(), c->val[0].as<uint32_t>(), c->pm[c->pcur].as<float4>(), c->vel[k].as<float2>(),
+                           c->orig[k].as<uint32_t>(), c->lvl[k].as<float>(), c->lvlold[k].as<float>(), c->pm[c->pcur ^ 1].as<float4>(),
+                           c->vel[k ^ 1].as<float2>(), c->orig[k ^ 1].as<uint32_t>(), c->lvl[k ^ 1].as<float>(), c->lvlold[k ^ 1].as<float>(),
+                           c->cxy.as<uint32_t>());
+            c->cur = k ^ 1;
+            c->pcur ^= 1;
+        }
+        launch_cell_start(s, prof, c->key[0].as<uint32_t>(), n, g.ncells, c->cell_start.as<uint32_t>());
+        if (c->dist.on) {
+            auto& d = c->dist;
+            if (n)
+                hipLaunchKernelGGL(k_build_maps, dim3((n + 255) / 256), dim3(256), 0, s, n, (uint32_t)c->n, c->val[0].as<uint32_t>(),
+                                   d.halo_pos.as<uint32_t>(), d.halo_src.as<uint32_t>(), d.ghost_dst.as<uint32_t>(), d.owned.as<uint8_t>());
+            d.have_flags = true;
+        }
+        if (tev) (void)hipEventRecord(c->ev[1], s);
+        m.a = make_args(c, sp);
+        m.st.n_particles = c->n;
+        m.st.dt = dt;
+    }
+    g_trace.mark(2);
+
+    // ---- density + boundary lambda + neighbour count (simulation.rs:2072-2074, 2179-2180, 2204) -----------
+    for (auto& m : M) {
+        (void)hipSetDevice(m.c->device);
+        if (m.n) launch_density(m.c->stream, &m.c->prof, m.a);
+        if (p->check_neighborhood && !G.multi()) launch_check_neighborhood(m.c, m.a);
+    }
+    if ((rc = refresh_ghosts(G, M, sel_rho, 1, "rho"))) return rc;
+    if ((rc = refresh_ghosts(G, M, sel_mrho, 1, "mrho"))) return rc;
+    // ---- constant_field + a_ii (simulation.rs:2235-2259) ---------------------------------------------------
+    for (auto& m : M) {
+        (void)hipSetDevice(m.c->device);
+        if (m.n) launch_aii_const(m.c->stream, &m.c->prof, m.a);
+    }
+    auto non_pressure = [&]() -> int {  // update_velocity_with_non_pressure_accel: velocity_temp, then mem::swap
+        for (auto& m : M) {
+            sph_ctx* c = m.c;
+            (void)hipSetDevice(c->device);
+            if (m.n) launch_non_pressure(c->stream, &c->prof, m.a);
+            std::swap(c->vel[c->cur], c->vel_tmp);
+            m.a.vel = c->vel[c->cur].as<float2>();
+            m.a.vel_tmp = c->vel_tmp.as<float2>();
+        }
+        return refresh_ghosts(G, M, sel_vel, 2, "vel");
+    };
+    auto begin_solve = [&](int kind, int residual_density) {
+        for (auto& m : M) {
+            (void)hipSetDevice(m.c->device);
+            (void)hipMemsetAsync(m.c->ctrl.p, 0, sizeof(SolverCtrl), m.c->stream);
+            if (m.n) launch_source_term(m.c->stream, &m.c->prof, m.a, kind, residual_density);  // + Jacobi iteration 0
+        }
+    };
+    auto rec = [&](int e) {
+        if (tev)
+            for (auto& m : M) {
+                (void)hipSetDevice(m.c->device);
+                (void)hipEventRecord(m.c->ev[e], m.c->stream);
+            }
+    };
+    enum { T_NONE = 0, T_VEL = 1, T_VX = 2, T_HYBRID = 3 };  // TAIL_* of sph_sweeps.hip
+    g_trace.mark(3);
+
+    switch (p->pressure_solver_method) {
+    case SPH_SOLVER_IISPH:  // simulation.rs:2389-2446
+        if ((rc = non_pressure())) return rc;
+        rec(4);
+        begin_solve(1, 1);
+        if ((rc = pressure_iterations(G, M, p->iisph_max_avg_density_error, 1, p->max_iters, c0->last_dens_iters, T_VX, true))) return rc;
+        rec(5);
+        break;
+    case SPH_SOLVER_ONLY_DIVERGENCE:  // simulation.rs:2448-2500
+        if ((rc = non_pressure())) return rc;
+        rec(2);
+        begin_solve(0, 0);
+        if ((rc = pressure_iterations(G, M, p->hybrid_dfsph_max_avg_divergence_error, 0, p->max_iters, c0->last_div_iters, T_VX, false))) return rc;
+        rec(3);
+        break;
+    default:  // HybridDFSPH, simulation.rs:2502-2670
+        if (p->hybrid_dfsph_non_pressure_accel_before_divergence_free)
+            if ((rc = non_pressure())) return rc;
+        rec(2);
+        begin_solve(0, 0);
+        if ((rc = pressure_iterations(G, M, p->hybrid_dfsph_max_avg_divergence_error, 0, p->max_iters, c0->last_div_iters, T_VEL, false))) return rc;
+        g_trace.mark(4);
+        rec(3);
+        if ((rc = refresh_ghosts(G, M, sel_vel, 2, "vel"))) return rc;  // v += dt a^p happened in the final sweep
+        if (!p->hybrid_dfsph_non_pressure_accel_before_divergence_free)
+            if ((rc = non_pressure())) return rc;
+        rec(4);
+        begin_solve(p->hybrid_dfsph_density_source_term == SPH_ONLY_DENSITY ? 2 : 1, 1);
+        if ((rc = pressure_iterations(G, M, p->hybrid_dfsph_max_avg_density_error, 1, p->max_iters, c0->last_dens_iters, T_HYBRID, true))) return rc;
+        g_trace.mark(5);
+        rec(5);
+        break;
+    }
+    rec(6);
+    if (p->viscosity_type == SPH_VISC_XSPH)  // simulation.rs:2673-2676
+        return c0->fail(SPH_ERR_XSPH_TODO, "not yet implemented (XSPH velocity smoothing)");
+
+    for (size_t i = 0; i < M.size(); i++) {
+        Member& m = M[i];
+        sph_ctx* c = m.c;
+        c->pcur ^= 1;  // integrated positions live in the other pm buffer; the old one keeps the pre-step snapshot
+        c->last_div_iters = m.st.div_solver.iters;
+        c->last_dens_iters = m.st.density_solver.iters;
+        c->time += dt;  // simulation.rs:2724-2725
+        c->step_number += 1;
+        m.st.time = c->time;
+        m.st.step_number = c->step_number;
+        m.st.ms_simulation_step = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - m.wall0).count();
+        if (tev) {
+            (void)hipSetDevice(c->device);
+            float ms = 0.f;
+            (void)hipEventSynchronize(c->ev[6]);
+            if (hipEventElapsedTime(&ms, c->ev[0], c->ev[6]) == hipSuccess) m.st.ms_simulation_step = ms;
+            if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) m.st.ms_neighborhood = ms;
+            const bool has_div = p->pressure_solver_method == SPH_SOLVER_ONLY_DIVERGENCE || p->pressure_solver_method == SPH_SOLVER_HYBRID_DFSPH;
+            const bool has_dens = p->pressure_solver_method != SPH_SOLVER_ONLY_DIVERGENCE;
+            if (has_div && hipEventElapsedTime(&ms, c->ev[2], c->ev[3]) == hipSuccess) m.st.ms_div_solver = ms;
+            if (has_dens && hipEventElapsedTime(&ms, c->ev[4], c->ev[5]) == hipSuccess) m.st.ms_density_solver = ms;
+        }
+        if (c->prof.mode) c->prof.collect();
+        c->prof.step_index++;
+        if (outs) outs[i] = m.st;
+    }
+    g_trace.end_step();
+    return SPH_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+static RcclComm g_rccl;
+static LocalComm g_local;
+
+extern "C" int sph_step(sph_ctx* c, const sph_params* p, sph_step_stats* out)
+{
+    if (!c || !p) return SPH_ERR_INVALID_ARGUMENT;
+    HIPCHK(c, hipSetDevice(c->device));
+    Group G;
+    G.m.push_back(c);
+    if (c->dist.on) {
+        if (!c->dist.nccl) return c->fail(SPH_ERR_INVALID_ARGUMENT, "slab context without a communicator: call sph_comm_init or use sph_group_step");
+        G.comm = &g_rccl;
+    }
+    return group_step(G, p, out);
+}
+
+extern "C" int sph_group_step(sph_ctx** ctxs, int n, const sph_params* p, sph_step_stats* outs)
+{
+    if (!ctxs || n <= 0 || !p) return SPH_ERR_INVALID_ARGUMENT;
+    Group G;
+    for (int i = 0; i < n; i++) {
+        if (!ctxs[i]) return SPH_ERR_INVALID_ARGUMENT;
+        if (n > 1 && (!ctxs[i]->dist.on || ctxs[i]->dist.rank != i || ctxs[i]->dist.nranks != n))
+            return ctxs[i]->fail(SPH_ERR_INVALID_ARGUMENT, "context %d is not configured as rank %d of %d (sph_dist_configure)", i, i, n);
+        G.m.push_back(ctxs[i]);
+    }
+    if (n > 1) G.comm = &g_local;
+    return group_step(G, p, outs);
+}
+
+extern "C" int sph_dist_configure(sph_ctx* c, int rank, int n_ranks, float cut_lo, float cut_hi)
+{
+    if (!c || rank < 0 || n_ranks < 1 || rank >= n_ranks) return SPH_ERR_INVALID_ARGUMENT;
+    c->dist.on = n_ranks > 1;
+    c->dist.rank = rank;
+    c->dist.nranks = n_ranks;
+    c->dist.cut_lo = cut_lo;
+    c->dist.cut_hi = cut_hi;
+    c->dist.have_flags = false;
+    c->dist.n_tot = (uint32_t)c->n;
+    if (c->dist.on) {
+        HIPCHK(c, hipSetDevice(c->device));
+        return ensure_dist_buffers(c, (uint32_t)c->n);
+    }
+    return SPH_OK;
+}
+
+extern "C" int sph_comm_unique_id(uint8_t id_out[128])
+{
+    if (!id_out) return SPH_ERR_INVALID_ARGUMENT;
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+    ncclUniqueId id;
+    if (ncclGetUniqueId(&id) != ncclSuccess) return SPH_ERR_DEVICE;
+    memcpy(id_out, &id, 128);
+    return SPH_OK;
+}
+
+extern "C" int sph_comm_init(sph_ctx* c, const uint8_t id[128], int rank, int n_ranks)
+{
+    if (!c || !id || rank < 0 || n_ranks < 1 || rank >= n_ranks) return SPH_ERR_INVALID_ARGUMENT;
+    if (n_ranks == 1) return SPH_OK;
+    if (!c->dist.on || c->dist.rank != rank || c->dist.nranks != n_ranks)
+        return c->fail(SPH_ERR_INVALID_ARGUMENT, "call sph_dist_configure(rank, n_ranks, cuts) before sph_comm_init");
+    HIPCHK(c, hipSetDevice(c->device));
+    ncclUniqueId uid;
+    memcpy(&uid, id, 128);
+    ncclComm_t nc;
+    NCCLCHK(c, ncclCommInitRank(&nc, n_ranks, uid, rank));
+    c->dist.nccl = nc;
+    return SPH_OK;
+}
+
+void dist_release(sph_ctx* c)
+{
+    auto& d = c->dist;
+    if (d.nccl) ncclCommDestroy((ncclComm_t)d.nccl);
+    d.nccl = nullptr;
+    DevBuf* all[] = {&d.owned, &d.halo_idx, &d.halo_pos, &d.halo_src, &d.ghost_dst, &d.send[0], &d.send[1], &d.recv[0], &d.recv[1], &d.counts, &d.solver_tot};
+    for (auto b : all) b->release();
+    if (d.counts_host) (void)hipHostFree(d.counts_host);
+    d.counts_host = nullptr;
+}

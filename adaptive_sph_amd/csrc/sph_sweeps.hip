@@ -48,6 +48,7 @@ struct SweepCommon {
     uint32_t nblocks;
     const uint32_t* __restrict__ cell_start;
     uint4* __restrict__ nl;   // neighbour list words
+    const uint8_t* __restrict__ owned;  // slab decomposition: ghost lanes idle (their values come from their owner)
 };
 
 __device__ __forceinline__ void raise_error(DeviceStatus* st, uint32_t code, uint32_t info)
@@ -201,7 +202,7 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_sweep(Op op, SweepCommon c)
     const uint32_t blk = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
     if (blk >= c.nblocks) return;
     const uint32_t i = blk * SWEEP_THREADS + threadIdx.x;
-    const bool active = i < c.n;
+    const bool active = i < c.n && (!c.owned || c.owned[i < c.n ? i : 0]);
     const GridP g = c.g;
     typename Op::Acc acc;
     op.init(acc);  // lane-independent state (valid on lanes past the end too: they help staging)
@@ -989,6 +990,68 @@ __global__ __launch_bounds__(1024) void k_solver_final(const SolverPartial* __re
     }
 }
 
+// multi-rank variant: local totals (doubles, exact for the counts) -> all-reduce(sum) over the ranks (RCCL, in
+// stream) -> the same stop decision on every rank
+__global__ __launch_bounds__(1024) void k_solver_local(const SolverPartial* __restrict__ partials, uint32_t nparts, const SolverCtrl* ctrl,
+                                                        double* __restrict__ tot)
+{
+    if (ctrl->done) return;
+    __shared__ SolverPartial s_w[16];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    SolverPartial t{0, 0, 0, 0.f, 0.f};
+    for (uint32_t k = tid; k < nparts; k += 1024) {
+        const SolverPartial q = partials[k];
+        t.normal += q.normal;
+        t.singular += q.singular;
+        t.negative += q.negative;
+        t.sum_err += q.sum_err;
+        t.max_err = fmaxf(t.max_err, q.max_err);
+    }
+    t.normal = wave_sum_u32(t.normal);
+    t.singular = wave_sum_u32(t.singular);
+    t.negative = wave_sum_u32(t.negative);
+    t.sum_err = wave_sum(t.sum_err);
+    t.max_err = wave_max(t.max_err);
+    if (lane == 0) s_w[w] = t;
+    __syncthreads();
+    if (tid == 0) {
+        t = s_w[0];
+        for (int k = 1; k < 16; k++) {
+            t.normal += s_w[k].normal;
+            t.singular += s_w[k].singular;
+            t.negative += s_w[k].negative;
+            t.sum_err += s_w[k].sum_err;
+            t.max_err = fmaxf(t.max_err, s_w[k].max_err);
+        }
+        tot[0] = (double)t.normal;
+        tot[1] = (double)t.singular;
+        tot[2] = (double)t.negative;
+        tot[3] = (double)t.sum_err;
+        tot[4] = (double)t.max_err;  // not all-reduced: local maximum, informational
+    }
+}
+
+__global__ void k_solver_decide(const double* __restrict__ tot, SolverCtrl* ctrl, int iter, int residual_density, float max_avg_error,
+                                uint32_t max_iters, float rest_density, float dt)
+{
+    if (threadIdx.x != 0 || ctrl->done) return;
+    const uint32_t normal = (uint32_t)tot[0];
+    const float sum_err = (float)tot[3];
+    const float avg = normal > 0 ? sum_err / (float)normal : __uint_as_float(0x7fc00000u);
+    bool stop;
+    if (residual_density) stop = normal == 0 || (fabsf(avg / rest_density) < max_avg_error && iter > 1);
+    else stop = normal == 0 || (fabsf(avg) < max_avg_error / dt && iter > 1);
+    if (!stop && (uint32_t)iter == max_iters) stop = true;
+    ctrl->normal = normal;
+    ctrl->singular = (uint32_t)tot[1];
+    ctrl->negative = (uint32_t)tot[2];
+    ctrl->sum_err = sum_err;
+    ctrl->max_err = (float)tot[4];
+    ctrl->iters = (uint32_t)iter;
+    ctrl->cur = (uint32_t)((iter + 1) & 1);
+    if (stop) ctrl->done = 1u;
+}
+
 // ------------------------------------------------------------------------------------------------
 // per-particle maps
 // ------------------------------------------------------------------------------------------------
@@ -1037,12 +1100,13 @@ __global__ __launch_bounds__(256) void k_integrate(uint32_t n, float dt, float v
 // ------------------------------------------------------------------------------------------------
 static SweepCommon common_of(const SweepArgs& a)
 {
-    return SweepCommon{a.g, a.n, (a.n + SWEEP_THREADS - 1) / SWEEP_THREADS, a.cell_start, a.nl};
+    return SweepCommon{a.g, a.n, (a.n + SWEEP_THREADS - 1) / SWEEP_THREADS, a.cell_start, a.nl, a.owned};
 }
 
 template <class Op, bool BUILD>
 static void launch_sweep(hipStream_t s, const SweepArgs& a, const Op& op)
 {
+    if (a.n == 0) return;
     const uint32_t nblocks = (a.n + SWEEP_THREADS - 1) / SWEEP_THREADS;
     const uint32_t grid = ((nblocks + 7) / 8) * 8;  // XCD remap needs a multiple of 8
     hipLaunchKernelGGL((k_sweep<Op, BUILD>), dim3(grid), dim3(SWEEP_THREADS), 0, s, op, common_of(a));
@@ -1121,6 +1185,21 @@ void launch_solver_reduce(hipStream_t s, Profiler* prof, const SweepArgs& a, int
     ProfScope ps(prof, "solver_reduce", s);
     hipLaunchKernelGGL(k_solver_final, dim3(1), dim3(1024), 0, s, (const SolverPartial*)block_partials, solver_reduce_blocks(a.n), a.ctrl, iter,
                        residual_density, max_avg_error, max_iters, a.sp.rest_density, a.sp.dt);
+}
+
+void launch_solver_local(hipStream_t s, Profiler* prof, const SweepArgs& a, float* block_partials)
+{
+    ProfScope ps(prof, "solver_reduce", s);
+    hipLaunchKernelGGL(k_solver_local, dim3(1), dim3(1024), 0, s, (const SolverPartial*)block_partials, solver_reduce_blocks(a.n), a.ctrl,
+                       a.solver_tot);
+}
+
+void launch_solver_decide(hipStream_t s, Profiler* prof, const SweepArgs& a, int iter, int residual_density, float max_avg_error,
+                          uint32_t max_iters)
+{
+    ProfScope ps(prof, "solver_decide", s);
+    hipLaunchKernelGGL(k_solver_decide, dim3(1), dim3(64), 0, s, a.solver_tot, a.ctrl, iter, residual_density, max_avg_error, max_iters,
+                       a.sp.rest_density, a.sp.dt);
 }
 
 void launch_vel_add_pacc(hipStream_t s, Profiler* prof, const SweepArgs& a)

@@ -40,6 +40,7 @@ FIELDS = {
     "stash": (15, np.float32, 1), "flag_is_fluid_surface": (16, np.uint8, 1),
     "flag_insufficient_neighs": (17, np.uint8, 1), "particle_size_class": (18, np.uint8, 1),
     "lambda_sum": (19, np.float32, 1), "lambda_grad_sum": (20, np.float32, 2), "cell_index": (21, np.uint32, 1),
+    "particle_id": (22, np.uint32, 1),
 }
 
 STATUS_NAMES = {
@@ -114,7 +115,7 @@ class SphError(RuntimeError):
 ABI_SYMBOLS = [
     "create", "destroy", "upload", "upload_field", "download", "download_neighbors", "num_particles", "time",
     "set_time", "step", "last_error", "grid", "profile_enable", "profile_reset", "profile_get",
-    "comm_unique_id", "comm_init",
+    "dist_configure", "comm_unique_id", "comm_init", "group_step",
 ]
 
 
@@ -161,6 +162,8 @@ class SphLibrary:
         self.profile_get = sig("profile_get", i32, [vp, C.POINTER(SphKernelTime), i32, C.POINTER(i32)], required=False)
         self.comm_unique_id = sig("comm_unique_id", i32, [C.POINTER(C.c_uint8)], required=False)
         self.comm_init = sig("comm_init", i32, [vp, C.POINTER(C.c_uint8), i32, i32], required=False)
+        self.dist_configure = sig("dist_configure", i32, [vp, i32, i32, C.c_float, C.c_float], required=False)
+        self.group_step = sig("group_step", i32, [C.POINTER(vp), i32, C.POINTER(SphParams), C.POINTER(SphStepStats)], required=False)
 
 
 _PRODUCT = None
@@ -285,6 +288,22 @@ class Context:
         self._check(self.lib.profile_get(self.handle, arr, cap, C.byref(n)))
         return {arr[i].name.decode(): (int(arr[i].launches), float(arr[i].total_ms)) for i in range(n.value)}
 
+    def dist_configure(self, rank: int, n_ranks: int, cut_lo: float, cut_hi: float):
+        self._check(self.lib.dist_configure(self.handle, int(rank), int(n_ranks), float(cut_lo), float(cut_hi)))
+
     def comm_init(self, unique_id: bytes, rank: int, n_ranks: int):
         buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
         self._check(self.lib.comm_init(self.handle, buf, int(rank), int(n_ranks)))
+
+
+def group_step(contexts, params: SphParams):
+    """Step k slab contexts of this process as ranks 0..k-1 (loopback transport); returns their stats."""
+    lib = contexts[0].lib
+    k = len(contexts)
+    handles = (C.c_void_p * k)(*[c.handle for c in contexts])
+    stats = (SphStepStats * k)()
+    rc = lib.group_step(handles, k, C.byref(params), stats)
+    if rc != 0:
+        msgs = [c.lib.last_error(c.handle) for c in contexts]
+        raise SphError(rc, " | ".join(m.decode(errors="replace") for m in msgs if m))
+    return list(stats)

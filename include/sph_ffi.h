@@ -155,7 +155,10 @@ enum {
     /* spatial-hash cell of each particle in the reference's CellGrid convention
      * (neighborhood_search.rs:253-255, 273-274, 383-395): linear index, x fastest */
     SPH_F_CELL_INDEX = 21,     /* u32[n]   */
-    SPH_F_COUNT_ = 22
+    /* slab (multi-GPU) contexts: particles migrate between ranks, so fields come back in device order
+     * and this field carries their identity (uploadable right after sph_upload; default 0..n-1) */
+    SPH_F_PARTICLE_ID = 22,    /* u32[n]   */
+    SPH_F_COUNT_ = 23
 };
 
 /* ---- status codes: one per reference guard ------------------------------------------------- */
@@ -245,13 +248,20 @@ int  sph_profile_reset(sph_ctx* ctx);
 int  sph_profile_get(sph_ctx* ctx, sph_kernel_time* out, int capacity, int* n_out);
 
 /* ---- multi-GPU: 1-D slab decomposition along x, one process (= one context) per GPU --------
- * The 128-byte RCCL unique id is created on rank 0 (sph_comm_unique_id) and broadcast by the
- * launcher (torch.distributed / MPI / a socket); every rank then calls sph_comm_init.
- * After that sph_upload takes this rank's particles only and sph_step exchanges ghost columns
- * with the x-neighbours over RCCL point-to-point and all-reduces the CFL minimum and the Jacobi
- * residual statistics. */
+ * (the reference has no counterpart: its only parallelism is rayon inside one process, concurrency.rs:110-204)
+ * sph_dist_configure makes `ctx` rank `rank` of `n_ranks`, owning the particles with cut_lo <= x < cut_hi
+ * (the outermost ranks ignore their open side); sph_upload then takes this rank's particles only.
+ * The 128-byte RCCL unique id is created on rank 0 (sph_comm_unique_id) and broadcast by the launcher
+ * (torch.distributed / MPI / a socket); every rank then calls sph_comm_init.  After that sph_step hands
+ * particles that left the slab to the x-neighbour, exchanges the ghost layer (one support radius) with the
+ * x-neighbours over RCCL point-to-point after every sweep whose output neighbours read, and all-reduces the
+ * CFL minimum and the Jacobi residual statistics so that every rank takes the same decisions.
+ * sph_group_step steps k contexts of ONE process as ranks 0..k-1 with plain copies as transport (one GPU or
+ * several): same algorithm, used to verify the decomposition against a single context. */
+int  sph_dist_configure(sph_ctx* ctx, int rank, int n_ranks, float cut_lo, float cut_hi);
 int  sph_comm_unique_id(uint8_t id_out[128]);
 int  sph_comm_init(sph_ctx* ctx, const uint8_t id[128], int rank, int n_ranks);
+int  sph_group_step(sph_ctx** ctxs, int n, const sph_params* params, sph_step_stats* outs);
 
 #ifdef __cplusplus
 }
