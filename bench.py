@@ -92,7 +92,7 @@ def main():
 
     if rank == 0:
         build.build_hip()
-    distributed = world > 1
+    distributed = world > 1 or bool(os.environ.get('BENCH_FORCE_DIST'))   # the env knob exercises the launcher glue with one rank
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
@@ -100,7 +100,7 @@ def main():
         dist.barrier()
     plib = ffi.load_product()
 
-    wl = args.workload or ("dam_break_1m" if world == 1 else "dam_break_8m")
+    wl = args.workload or ("dam_break_1m" if world == 1 else "dam_break_8m")   # strong scaling: N = 8M split over the ranks
     scene_f, params_f, desc = WORKLOADS[wl]
     scene, params = scene_f(), params_f()
     pos, mass, vel = sc.init_particles(scene)
