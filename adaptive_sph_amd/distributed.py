@@ -53,7 +53,8 @@ def make_slab_context(lib: ffi.SphLibrary, pos, mass, vel, planes, rank: int, wo
     ctx = ffi.Context(lib, _slab_capacity(len(mass), world), planes, device_id=local_rank)
     ctx.dist_configure(rank, world, cuts[rank], cuts[rank + 1])
     ctx.upload(mass[mine], pos[mine], vel[mine])
-    ctx.upload_field("particle_id", mine.astype(np.uint32))
+    if world > 1:
+        ctx.upload_field("particle_id", mine.astype(np.uint32))
     # RCCL unique id: created on rank 0, broadcast through the launcher's process group
     buf = torch.zeros(128, dtype=torch.uint8)
     if rank == 0:

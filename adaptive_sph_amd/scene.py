@@ -135,6 +135,19 @@ def dam_break_8m() -> SceneConfig:
                        [SceneFluidBlock([-1.9995, -0.9995], [1.4143, 1.4143], 0.00048828125, 0.93, [0.0, 0.0])])
 
 
+def dam_break_weak(n_gpus: int) -> SceneConfig:
+    """Weak-scaling family between configs[1] (1 GPU, 1M) and configs[3] (8 GPUs, 8M): ~1M particles per GPU.
+    2 GPUs: 1448 x 1448 = 2 096 704 (spacing 1/1448); 4 GPUs: 2048 x 2048 = 4 194 304 (spacing 1/2048)."""
+    if n_gpus <= 1:
+        return dam_break_1m()
+    if n_gpus >= 8:
+        return dam_break_8m()
+    side = 1448 if n_gpus < 4 else 2048
+    s = 1.0 / side
+    return SceneConfig(SceneBoundary("box", 4.0, 2.0),
+                       [SceneFluidBlock([-2.0 + 1.024 * s, -1.0 + 1.024 * s], [side * s + 0.5 * s, side * s + 0.5 * s], s, 0.93, [0.0, 0.0])])
+
+
 def dam_break_small(nx: int = 64, ny: int = 64, spacing: float = 1.0 / 64.0) -> SceneConfig:
     """A small dam break with the proportions of configs[1] (column one spacing off the left/bottom wall),
     for parity tests."""

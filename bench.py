@@ -100,7 +100,8 @@ def main():
         dist.barrier()
     plib = ffi.load_product()
 
-    wl = args.workload or ("dam_break_1m" if world == 1 else "dam_break_8m")   # strong scaling: N = 8M split over the ranks
+    # weak scaling, ~1M particles per GPU: configs[1] at N=1 ... configs[3] (8M) at N=8
+    wl = args.workload or {1: "dam_break_1m", 2: "dam_break_2m", 4: "dam_break_4m"}.get(world, "dam_break_8m")
     scene_f, params_f, desc = WORKLOADS[wl]
     scene, params = scene_f(), params_f()
     pos, mass, vel = sc.init_particles(scene)
@@ -195,7 +196,7 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed * 1e3 / args.steps,
         "higher_is_better": True,
-        "scaling": "strong" if distributed else "weak",
+        "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
