@@ -88,8 +88,9 @@ void launch_reorder(hipStream_t s, Profiler* prof, uint32_t n, GridP g, const ui
                     const float4* pm_in, const float2* vel_in, const uint32_t* orig_in, const float* lvl_in,
                     const float* lvlold_in, float4* pm_out, float2* vel_out, uint32_t* orig_out, float* lvl_out,
                     float* lvlold_out, uint32_t* cxy);
+size_t cell_start_scratch_bytes();
 void launch_cell_start(hipStream_t s, Profiler* prof, const uint32_t* sorted_key, uint32_t n, uint32_t ncells,
-                       uint32_t* cell_start /* [ncells+1] */);
+                       uint32_t* cell_start /* [ncells+1] */, void* scratch /* cell_start_scratch_bytes() */);
 void launch_build_tiles(hipStream_t s, Profiler* prof, GridP g, int TX, int TY, const uint32_t* cell_start,
                         uint32_t* tiles, uint32_t* n_tiles /* device counter, zeroed here */);
 

@@ -209,9 +209,20 @@ void launch_reorder(hipStream_t s, Profiler* prof, uint32_t n, GridP g, const ui
 
 // cell_start[c] = index of the first sorted particle whose cell is >= c; cell_start[ncells] = n.
 // Thread i (0..n) owns the boundary between sorted particles i-1 and i and fills the cells in
-// (key[i-1], key[i]].
+// (key[i-1], key[i]].  Short gaps (the normal case: adjacent occupied cells, row ends) are filled by the
+// owning thread; long gaps (empty regions of a sparse grid, e.g. after a particle escaped the box) go to
+// a work list that k_cell_fill spreads over whole workgroups -- no thread ever loops over more than
+// CS_INLINE cells.
+#define CS_INLINE 64u
+#define CS_WORK_CAP 65536u
+
+struct CellGap {
+    uint32_t lo, hi, val;
+};
+
 __global__ __launch_bounds__(256) void k_cell_start(const uint32_t* __restrict__ key, uint32_t n, uint32_t ncells,
-                                                     uint32_t* __restrict__ cell_start)
+                                                     uint32_t* __restrict__ cell_start, CellGap* __restrict__ work,
+                                                     uint32_t* __restrict__ work_count)
 {
     uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i > n) return;
@@ -228,13 +239,37 @@ __global__ __launch_bounds__(256) void k_cell_start(const uint32_t* __restrict__
         lo = a + 1;
         hi = b;
     }
+    if (hi - lo >= CS_INLINE) {
+        uint32_t slot = atomicAdd(work_count, 1u);
+        if (slot < CS_WORK_CAP) {
+            work[slot] = CellGap{lo, hi, i};
+            return;
+        }
+    }
     for (uint32_t c = lo; c <= hi; c++) cell_start[c] = i;
 }
 
-void launch_cell_start(hipStream_t s, Profiler* prof, const uint32_t* sorted_key, uint32_t n, uint32_t ncells, uint32_t* cell_start)
+__global__ __launch_bounds__(256) void k_cell_fill(const CellGap* __restrict__ work, const uint32_t* __restrict__ work_count,
+                                                    uint32_t* __restrict__ cell_start)
+{
+    const uint32_t cnt = min(*work_count, CS_WORK_CAP);
+    for (uint32_t e = blockIdx.x; e < cnt; e += gridDim.x) {
+        const CellGap g = work[e];
+        for (uint32_t c = g.lo + threadIdx.x; c <= g.hi; c += 256) cell_start[c] = g.val;
+    }
+}
+
+size_t cell_start_scratch_bytes() { return (size_t)CS_WORK_CAP * sizeof(CellGap) + 16; }
+
+void launch_cell_start(hipStream_t s, Profiler* prof, const uint32_t* sorted_key, uint32_t n, uint32_t ncells, uint32_t* cell_start,
+                       void* scratch)
 {
     ProfScope ps(prof, "cell_start", s);
-    hipLaunchKernelGGL(k_cell_start, dim3((n + 1 + 255) / 256), dim3(256), 0, s, sorted_key, n, ncells, cell_start);
+    uint32_t* count = (uint32_t*)scratch;
+    CellGap* work = (CellGap*)((char*)scratch + 16);
+    (void)hipMemsetAsync(count, 0, sizeof(uint32_t), s);
+    hipLaunchKernelGGL(k_cell_start, dim3((n + 1 + 255) / 256), dim3(256), 0, s, sorted_key, n, ncells, cell_start, work, count);
+    hipLaunchKernelGGL(k_cell_fill, dim3(512), dim3(256), 0, s, work, count, cell_start);
 }
 
 // list of tiles (TX x TY cells) that own at least one particle; wave-aggregated append keeps

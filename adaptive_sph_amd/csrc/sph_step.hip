@@ -980,7 +980,8 @@ static int group_step(Group& G, const sph_params* p, sph_step_stats* outs)
             c->cur = k ^ 1;
             c->pcur ^= 1;
         }
-        launch_cell_start(s, prof, c->key[0].as<uint32_t>(), n, g.ncells, c->cell_start.as<uint32_t>());
+        HIPCHK(c, c->cs_scratch.ensure(cell_start_scratch_bytes()));
+        launch_cell_start(s, prof, c->key[0].as<uint32_t>(), n, g.ncells, c->cell_start.as<uint32_t>(), c->cs_scratch.p);
         if (c->dist.on) {
             auto& d = c->dist;
             if (n)
