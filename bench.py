@@ -39,6 +39,25 @@ ALGO_BYTES = {
 }
 
 
+# rocprofv3 kernel names of the sweeps (profiles/*_kernel_summary.json keys)
+PMC_NAMES = {"density": "OpDensity[build]", "aii_constfield": "OpAiiConst", "non_pressure_accel": "OpNonPressure",
+             "source_term": "OpSource", "pressure_accel": "OpPressureAccel", "pressure_accel_final": "OpPressureAccel",
+             "jacobi_update": "OpJacobi"}
+
+
+def committed_pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 --pmc summary (FETCH_SIZE and
+    WRITE_SIZE are collected in their own passes, outside bench.py: scripts/summarize_profile.py)."""
+    files = sorted((REPO / "profiles").glob("*_kernel_summary.json"))
+    if not files or kernel not in PMC_NAMES:
+        return None, None
+    try:
+        e = json.load(open(files[-1])).get(PMC_NAMES[kernel], {})
+        return e.get("hbm_traffic_bytes_per_launch"), files[-1].name
+    except Exception:  # noqa: BLE001
+        return None, None
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -166,9 +185,10 @@ def main():
             return None
         avg_s = total_ms * 1e-3 / launches
         achieved = ALGO_BYTES[name] * n_local / avg_s / 1e9
+        traffic, src = committed_pmc_traffic(name) if wl == "dam_break_1m" and not distributed else (None, None)
         return {"kernel": name, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_us": avg_s * 1e6,
-                "algorithmic_bytes_per_particle": ALGO_BYTES[name]}
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src, "avg_us": avg_s * 1e6,
+                "algorithmic_bytes_per_particle": ALGO_BYTES[name], "algorithmic_bytes_per_launch": ALGO_BYTES[name] * n_local}
 
     total_prof_ms = sum(v[1] for v in prof_all.values()) or 1.0
     kernels = []

@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Condense a gpurun_out/<run>/ directory (bench.json, rocprofv3 kernel-trace stats, PMC passes) into the
+files committed under profiles/:   python scripts/summarize_profile.py gpurun_out/r1 profiles/r1"""
+import collections
+import csv
+import json
+import shutil
+import statistics
+import sys
+from pathlib import Path
+
+src, dst = Path(sys.argv[1]), sys.argv[2]
+Path(dst).parent.mkdir(parents=True, exist_ok=True)
+shutil.copy(src / "bench.json", dst + "_bench.json")
+shutil.copy(next((src / "kt").glob("*kernel_stats.csv")), dst + "_rocprofv3_kernel_stats.csv")
+
+
+def short(name):
+    n = name.split("(")[0].replace("void ", "")
+    return n.replace("k_sweep<", "").replace("<MathUniform>", "").replace(", false>", "").replace(", true>", "[build]")
+
+
+# per-kernel durations of the launches that did real work (speculative Jacobi launches past the stop decision
+# exit in ~1-2 us and would drag the plain average down)
+trace = list(csv.DictReader(open(next((src / "kt").glob("*kernel_trace.csv")))))
+dur = collections.defaultdict(list)
+for r in trace:
+    dur[short(r["Kernel_Name"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+
+
+def pmc(dirname, counter):
+    f = next((src / dirname).glob("*counter_collection.csv"), None)
+    out = collections.defaultdict(list)
+    if f:
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == counter:
+                out[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+    return out
+
+
+fetch, write = pmc("pmc_fetch", "FETCH_SIZE"), pmc("pmc_write", "WRITE_SIZE")
+summary = {}
+for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
+    real = [x for x in v if x > 0.25 * max(v)]
+    e = {"launches": len(v), "working_launches": len(real), "median_us_working": statistics.median(real), "total_ms": sum(v) / 1e3}
+    # FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 64 B per 128-B request -> x2 (MI355X_MICROARCH.md,
+    # confirmed here on k_cell_keys: 16 B/particle read -> 8203 KiB reported for 2^20 particles) ; WRITE_SIZE is exact
+    # (k_cell_keys writes 8 B/particle -> 8192 KiB)
+    if k in fetch and k in write:
+        fr = [x for x in fetch[k] if x > 0.25 * max(fetch[k])]
+        wr = [x for x in write[k] if x > 0.25 * max(write[k])]
+        e["hbm_read_bytes_per_launch"] = statistics.median(fr) * 1024 * 2
+        e["hbm_write_bytes_per_launch"] = statistics.median(wr) * 1024
+        e["hbm_traffic_bytes_per_launch"] = e["hbm_read_bytes_per_launch"] + e["hbm_write_bytes_per_launch"]
+    summary[k] = e
+json.dump(summary, open(dst + "_kernel_summary.json", "w"), indent=1)
+with open(dst + "_kernel_summary.md", "w") as fh:
+    fh.write("| kernel | launches | working | median us (working) | total ms | HBM read MB | HBM write MB |\n|---|---|---|---|---|---|---|\n")
+    for k, e in summary.items():
+        fh.write(f"| {k} | {e['launches']} | {e['working_launches']} | {e['median_us_working']:.1f} | {e['total_ms']:.2f} | "
+                 f"{e.get('hbm_read_bytes_per_launch', 0) / 1e6:.1f} | {e.get('hbm_write_bytes_per_launch', 0) / 1e6:.1f} |\n")
+print(open(dst + "_kernel_summary.md").read())
