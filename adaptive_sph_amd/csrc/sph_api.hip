@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256) void k_cell_index_host(uint32_t n, GridP g, co
 }
 
 // CSR export of the neighbour lists (NeighborhoodCache) in host particle order
-__global__ __launch_bounds__(256) void k_fill_neighbors(uint32_t n, GridP g, const uint32_t* __restrict__ cell_start,
+__global__ __launch_bounds__(256) void k_fill_neighbors(uint32_t n, GridP g, TileP t, const uint32_t* __restrict__ cell_start,
                                                          const uint32_t* __restrict__ cxy, const uint32_t* __restrict__ orig,
                                                          const float4* __restrict__ pm, const uint32_t* __restrict__ offsets_host,
                                                          uint32_t* __restrict__ indices)
@@ -241,11 +241,12 @@ __global__ __launch_bounds__(256) void k_fill_neighbors(uint32_t n, GridP g, con
     const uint32_t c = cxy[i];
     const int cx = c & 0xffffu, cy = c >> 16;
     uint32_t w = offsets_host[orig[i]];
-    for (int dy = -1; dy <= 1; dy++) {
+    const int R = stencil_radius(g, t, Ai.w, cx, cy);
+    for (int dy = -R; dy <= R; dy++) {
         int yy = cy + dy;
         if (yy < 0 || yy >= g.sy) continue;
-        uint32_t b = cell_start[(uint32_t)yy * g.sx + max(cx - 1, 0)];
-        uint32_t e = cell_start[(uint32_t)yy * g.sx + min(cx + 2, g.sx)];
+        uint32_t b = cell_start[(uint32_t)yy * g.sx + max(cx - R, 0)];
+        uint32_t e = cell_start[(uint32_t)yy * g.sx + min(cx + R + 1, g.sx)];
         for (uint32_t j = b; j < e; j++) {
             const float4 Aj = pm[j];
             const float dx = Ai.x - Aj.x, dyy = Ai.y - Aj.y;
@@ -360,7 +361,7 @@ extern "C" void sph_destroy(sph_ctx* c)
     dist_release(c);
     DevBuf* all[] = {&c->pm[0], &c->pm[1], &c->vel[0], &c->vel[1], &c->orig[0], &c->orig[1], &c->lvl[0], &c->lvl[1], &c->lvlold[0],
                      &c->lvlold[1], &c->vel_tmp, &c->key[0], &c->key[1], &c->val[0], &c->val[1], &c->sort_scratch, &c->cxy, &c->cell_start,
-                     &c->cs_scratch, &c->nl, &c->nl_ok, &c->mrho, &c->pt0, &c->pt1, &c->rho, &c->lam_sum, &c->lam_grad, &c->constf, &c->aii, &c->src, &c->p0, &c->p1, &c->pacc, &c->dens_err,
+                     &c->cs_scratch, &c->nl, &c->nlx, &c->tile_raw, &c->tile_h, &c->nl_ok, &c->mrho, &c->pt0, &c->pt1, &c->rho, &c->lam_sum, &c->lam_grad, &c->constf, &c->aii, &c->src, &c->p0, &c->p1, &c->pacc, &c->dens_err,
                      &c->stat, &c->ncount, &c->planes_d, &c->lam_lut, &c->dlam_lut, &c->hdr_partials, &c->hdr_out, &c->ctrl, &c->status,
                      &c->n_tiles, &c->red_partials, &c->scratch};
     for (auto b : all) b->release();
@@ -488,9 +489,16 @@ extern "C" int sph_download(sph_ctx* c, int field, void* dst, uint64_t bytes)
         if (c->dist.on) return download_slab(c, G_U32, c->key[0].p, 4, dst, bytes);
         if (bytes != (uint64_t)n * 4) return c->fail(SPH_ERR_INVALID_ARGUMENT, "field %d: size mismatch", field);
         if (n == 0) return SPH_OK;
-        // sorted cell keys of the positions the last step started from
-        hipLaunchKernelGGL(k_to_host_order, dim3((n + 255) / 256), dim3(256), 0, s, n, (int)G_U32, c->orig[k].as<uint32_t>(),
-                           (const void*)c->key[0].p, c->scratch.p);
+        if (c->uniform_h) {
+            // sorted cell keys of the positions the last step started from
+            hipLaunchKernelGGL(k_to_host_order, dim3((n + 255) / 256), dim3(256), 0, s, n, (int)G_U32, c->orig[k].as<uint32_t>(),
+                               (const void*)c->key[0].p, c->scratch.p);
+        } else {
+            // multi-resolution scenes sort by a finer grid: recompute the reference-convention index (cell = largest
+            // support) from the sorted pre-step snapshot pm[pcur ^ 1]
+            hipLaunchKernelGGL(k_cell_index_host, dim3((n + 255) / 256), dim3(256), 0, s, n, c->grid, c->orig[k].as<uint32_t>(),
+                               c->pm[c->pcur ^ 1].as<float4>(), c->scratch.as<uint32_t>());
+        }
         HIPCHK(c, hipMemcpyAsync(dst, c->scratch.p, bytes, hipMemcpyDeviceToHost, s));
         HIPCHK(c, hipStreamSynchronize(s));
         return SPH_OK;
@@ -609,7 +617,8 @@ extern "C" int sph_download_neighbors(sph_ctx* c, uint32_t* offsets, uint32_t* i
     HIPCHK(c, d_idx.ensure((size_t)tot * 4));
     hipStream_t s = c->stream;
     HIPCHK(c, hipMemcpyAsync(d_off.p, off.data(), ((size_t)n + 1) * 4, hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(k_fill_neighbors, dim3((n + 255) / 256), dim3(256), 0, s, n, c->grid, c->cell_start.as<uint32_t>(), c->cxy.as<uint32_t>(),
+    hipLaunchKernelGGL(k_fill_neighbors, dim3((n + 255) / 256), dim3(256), 0, s, n, c->fgrid,
+                       TileP{c->tile_ts, c->tile_tsx, c->tile_tsy, c->tile_h.as<uint32_t>()}, c->cell_start.as<uint32_t>(), c->cxy.as<uint32_t>(),
                        c->orig[c->cur].as<uint32_t>(), c->pm[c->pcur ^ 1].as<float4>(), d_off.as<uint32_t>(), d_idx.as<uint32_t>());
     HIPCHK(c, hipMemcpyAsync(indices, d_idx.p, (size_t)tot * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));

@@ -87,6 +87,9 @@ struct sph_ctx {
 
     GridP grid{};
     bool grid_valid = false;
+    GridP fgrid{};          // the grid the particles are sorted by (== grid in uniform scenes)
+    int tile_ts = 0, tile_tsx = 0, tile_tsy = 0;
+    DevBuf tile_raw, tile_h, nlx;
     uint32_t pressure_cur = 0;
     uint32_t last_div_iters = 2, last_dens_iters = 2;
     hipEvent_t ev[8];

@@ -27,8 +27,16 @@ struct GridP {
     float cs;            // cell size = support radius of the largest particle
     int minx, miny;      // cells_min  (neighborhood_search.rs:273)
     int sx, sy;          // grid size  (cells_max - cells_min)
-    int ntx, nty;        // tiles per axis
     uint32_t ncells;
+};
+
+// Multi-resolution scenes sort by a grid whose cell is the support of the SMALLEST particle.  A tile is
+// ts x ts cells with ts * cs >= the largest support, so every neighbour of a particle lives in the 3 x 3
+// tiles around its own; hmax[tile] is the largest h found in those 3 x 3 tiles, i.e. an upper bound on h_j of
+// any neighbour j.  ts == 0: uniform scene, every stencil is 3 x 3 cells.
+struct TileP {
+    int ts, tsx, tsy;
+    const uint32_t* __restrict__ hmax;   // float bits (h > 0, so unsigned order == float order)
 };
 
 // per-step scalars the kernels read (subset of sph_params + dt)
@@ -139,6 +147,15 @@ __device__ __forceinline__ float h_from_mass(float mass, float rest_density)
 {
     float volume = mass / rest_density;
     return SPH_ETA * sqrtf(volume * SPH_FRAC_1_PI_F);
+}
+
+// stencil half-width in cells that is guaranteed to cover every j with |x_ij| < h_i + h_j: such a j is closer than
+// h_i + hmax, hence at most floor((h_i + hmax) / cs) + 1 cells away on either axis
+__device__ __forceinline__ int stencil_radius(const GridP& g, const TileP& t, float h_i, int cx, int cy)
+{
+    if (t.ts <= 0) return 1;
+    const float hn = __uint_as_float(t.hmax[(uint32_t)(cy / t.ts) * (uint32_t)t.tsx + (uint32_t)(cx / t.ts)]);
+    return (int)floorf((h_i + hn) / g.cs) + 1;
 }
 
 // LookupTable1D::get with (min,max,steps) = (-1,1,10000); caller guarantees -1 <= x < 1

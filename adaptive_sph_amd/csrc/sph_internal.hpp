@@ -91,8 +91,8 @@ void launch_reorder(hipStream_t s, Profiler* prof, uint32_t n, GridP g, const ui
 size_t cell_start_scratch_bytes();
 void launch_cell_start(hipStream_t s, Profiler* prof, const uint32_t* sorted_key, uint32_t n, uint32_t ncells,
                        uint32_t* cell_start /* [ncells+1] */, void* scratch /* cell_start_scratch_bytes() */);
-void launch_build_tiles(hipStream_t s, Profiler* prof, GridP g, int TX, int TY, const uint32_t* cell_start,
-                        uint32_t* tiles, uint32_t* n_tiles /* device counter, zeroed here */);
+void launch_tile_hmax(hipStream_t s, Profiler* prof, uint32_t n, const float4* pm, GridP g, int ts, int tsx, int tsy, uint32_t* raw,
+                      uint32_t* out /* dilated */);
 
 // ---- sph_sweeps.hip ----------------------------------------------------------------------------
 struct SweepArgs {
@@ -122,6 +122,8 @@ struct SweepArgs {
     float* stat;
     uint32_t* ncount;
     uint4* nl;          // neighbour list words (sph_sweeps.hip)
+    uint4* nlx;         // explicit index lists (multi-resolution scenes)
+    TileP t;            // stencil bound per tile (multi-resolution scenes; ts = 0: uniform)
     float* partials;    // per-block solver statistics
     const uint8_t* owned;  // slab decomposition: 1 owned, 0 ghost (nullptr: everything is owned)
     double* solver_tot; // multi-rank: all-reduced solver totals
@@ -138,6 +140,7 @@ struct SweepArgs {
 };
 
 size_t sweep_list_bytes(uint32_t n);
+size_t sweep_index_list_bytes(uint32_t n);   // explicit index lists (multi-resolution scenes)
 uint32_t solver_reduce_blocks(uint32_t n);
 void launch_density(hipStream_t s, Profiler* prof, const SweepArgs& a);
 void launch_aii_const(hipStream_t s, Profiler* prof, const SweepArgs& a);

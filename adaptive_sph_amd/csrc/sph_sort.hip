@@ -272,40 +272,47 @@ void launch_cell_start(hipStream_t s, Profiler* prof, const uint32_t* sorted_key
     hipLaunchKernelGGL(k_cell_fill, dim3(512), dim3(256), 0, s, work, count, cell_start);
 }
 
-// list of tiles (TX x TY cells) that own at least one particle; wave-aggregated append keeps
-// runs of 64 consecutive tiles in order (the order only affects scheduling, never results)
-__global__ __launch_bounds__(256) void k_build_tiles(GridP g, int TX, int TY, const uint32_t* __restrict__ cell_start,
-                                                      uint32_t* __restrict__ tiles, uint32_t* __restrict__ n_tiles)
+// per-tile largest smoothing length (TileP, sph_device.h): atomicMax over the particles of the tile, then the
+// maximum over the 3 x 3 tiles around each tile
+__global__ __launch_bounds__(256) void k_tile_hmax(uint32_t n, const float4* __restrict__ pm, GridP g, int ts, int tsx, uint32_t* __restrict__ raw)
 {
-    uint32_t t = blockIdx.x * 256 + threadIdx.x;
-    uint32_t ntiles = (uint32_t)g.ntx * (uint32_t)g.nty;
-    uint32_t cnt = 0;
-    if (t < ntiles) {
-        int tx = t % g.ntx, ty = t / g.ntx;
-        int cx0 = tx * TX, cy0 = ty * TY;
-        int cxe = min(cx0 + TX, g.sx);
-        for (int r = 0; r < TY; r++) {
-            int cy = cy0 + r;
-            if (cy >= g.sy) break;
-            cnt += cell_start[(uint32_t)cy * g.sx + cxe] - cell_start[(uint32_t)cy * g.sx + cx0];
-        }
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    uint32_t tile = 0xffffffffu, hb = 0u;
+    if (i < n) {
+        const float4 p = pm[i];
+        const int cx = (int)floorf(p.x / g.cs) - g.minx, cy = (int)floorf(p.y / g.cs) - g.miny;
+        tile = (uint32_t)(cy / ts) * (uint32_t)tsx + (uint32_t)(cx / ts);
+        hb = __float_as_uint(p.w);
     }
-    bool has = cnt > 0;
-    uint64_t m = __ballot(has);
-    if (m == 0) return;
-    int lane = threadIdx.x & 63;
-    uint32_t base = 0;
-    int leader = __ffsll((unsigned long long)m) - 1;
-    if (lane == leader) base = atomicAdd(n_tiles, (uint32_t)__popcll(m));
-    base = __shfl(base, leader, 64);
-    if (has) tiles[base + __popcll(m & ((1ull << lane) - 1ull))] = t;
+    // the array is cell-sorted, so a wave usually sits in one or two tiles: one atomic per run of equal tiles (the
+    // lane that starts the run carries the maximum of the run) instead of 64 atomics on the same address
+    const int lane = threadIdx.x & 63;
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t ot = (uint32_t)__shfl_down((int)tile, o, 64), oh = (uint32_t)__shfl_down((int)hb, o, 64);
+        if (lane + o < 64 && ot == tile) hb = max(hb, oh);   // suffix maximum within the run (runs are contiguous)
+    }
+    const uint32_t prev = (uint32_t)__shfl_up((int)tile, 1, 64);
+    if (i < n && (lane == 0 || prev != tile)) atomicMax(&raw[tile], hb);
+}
+__global__ __launch_bounds__(256) void k_tile_dilate(int tsx, int tsy, const uint32_t* __restrict__ raw, uint32_t* __restrict__ out)
+{
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= (uint32_t)tsx * (uint32_t)tsy) return;
+    const int tx = (int)(t % (uint32_t)tsx), ty = (int)(t / (uint32_t)tsx);
+    uint32_t m = 0;
+    for (int dy = -1; dy <= 1; dy++)
+        for (int dx = -1; dx <= 1; dx++) {
+            const int x = tx + dx, y = ty + dy;
+            if (x >= 0 && x < tsx && y >= 0 && y < tsy) m = max(m, raw[(uint32_t)y * (uint32_t)tsx + (uint32_t)x]);
+        }
+    out[t] = m;
 }
 
-void launch_build_tiles(hipStream_t s, Profiler* prof, GridP g, int TX, int TY, const uint32_t* cell_start, uint32_t* tiles,
-                        uint32_t* n_tiles)
+void launch_tile_hmax(hipStream_t s, Profiler* prof, uint32_t n, const float4* pm, GridP g, int ts, int tsx, int tsy, uint32_t* raw, uint32_t* out)
 {
-    ProfScope ps(prof, "build_tiles", s);
-    hipMemsetAsync(n_tiles, 0, sizeof(uint32_t), s);
-    uint32_t ntiles = (uint32_t)g.ntx * (uint32_t)g.nty;
-    hipLaunchKernelGGL(k_build_tiles, dim3((ntiles + 255) / 256), dim3(256), 0, s, g, TX, TY, cell_start, tiles, n_tiles);
+    ProfScope ps(prof, "tile_hmax", s);
+    const uint32_t nt = (uint32_t)tsx * (uint32_t)tsy;
+    (void)hipMemsetAsync(raw, 0, (size_t)nt * 4, s);
+    if (n) hipLaunchKernelGGL(k_tile_hmax, dim3((n + 255) / 256), dim3(256), 0, s, n, pm, g, ts, tsx, raw);
+    hipLaunchKernelGGL(k_tile_dilate, dim3((nt + 255) / 256), dim3(256), 0, s, tsx, tsy, raw, out);
 }

@@ -31,7 +31,7 @@ SweepArgs make_args(sph_ctx* c, const StepP& sp)
 {
     SweepArgs a{};
     const int k = c->cur;
-    a.g = c->grid;
+    a.g = c->fgrid;
     a.sp = sp;
     a.n = c->dist.on ? c->dist.n_tot : (uint32_t)c->n;
     a.exact = c->exact;
@@ -53,6 +53,8 @@ SweepArgs make_args(sph_ctx* c, const StepP& sp)
     a.stat = c->stat.as<float>();
     a.ncount = c->ncount.as<uint32_t>();
     a.nl = c->nl.as<uint4>();
+    a.nlx = c->nlx.as<uint4>();
+    a.t = TileP{c->tile_ts, c->tile_tsx, c->tile_tsy, c->tile_h.as<uint32_t>()};
     a.partials = c->red_partials.as<float>();
     a.mrho = c->mrho.as<float>();
     a.pt0 = c->pt0.as<float>();
@@ -918,30 +920,64 @@ static int group_step(Group& G, const sph_params* p, sph_step_stats* outs)
         (void)hipSetDevice(c->device);
         const HeaderOut hdr = *c->hdr_host;
         const uint32_t n = m.n;
-        // CellGrid (neighborhood_search.rs:261-275) with cell = support radius of the largest particle
+        // CellGrid (neighborhood_search.rs:261-275) with cell = support radius of the largest particle: the grid the
+        // reference's convention defines (sph_grid, cell_index).  Uniform scenes sort by it.  Multi-resolution scenes sort
+        // by a finer grid `fg` (cell = support of the smallest particle, doubled until the table fits) and give every
+        // particle its own stencil width (TileP, sph_device.h), so a fine particle far from any coarse one still looks
+        // at 3 x 3 small cells instead of 3 x 3 large ones.
+        auto make_grid = [&](float cs, GridP& out) -> bool {
+            out = GridP{};
+            out.cs = cs;
+            if (!n) {
+                out.sx = out.sy = 1;
+                out.ncells = 1;
+                return true;
+            }
+            out.minx = (int)floorf(hdr.min_x / cs) - 1;
+            out.miny = (int)floorf(hdr.min_y / cs) - 1;
+            const long long sx = (long long)((int)floorf(hdr.max_x / cs) + 2) - out.minx;
+            const long long sy = (long long)((int)floorf(hdr.max_y / cs) + 2) - out.miny;
+            if (sx <= 0 || sy <= 0 || sx >= 65536 || sy >= 65536 || sx * sy >= (1ll << 27)) return false;
+            out.sx = (int)sx;
+            out.sy = (int)sy;
+            out.ncells = (uint32_t)sx * (uint32_t)sy;
+            return true;
+        };
+        if (n && (!std::isfinite(hdr.min_x) || !std::isfinite(hdr.max_x) || !std::isfinite(hdr.min_y) || !std::isfinite(hdr.max_y)))
+            return agree(G, c->fail(SPH_ERR_POSITION_NOT_FINITE, "particle positions are not finite"));
         GridP g{};
-        g.cs = h_max_g * 2.f;
-        if (n) {
-            if (!std::isfinite(hdr.min_x) || !std::isfinite(hdr.max_x) || !std::isfinite(hdr.min_y) || !std::isfinite(hdr.max_y))
-                return agree(G, c->fail(SPH_ERR_POSITION_NOT_FINITE, "particle positions are not finite"));
-            g.minx = (int)floorf(hdr.min_x / g.cs) - 1;
-            g.miny = (int)floorf(hdr.min_y / g.cs) - 1;
-            const long long sx = (long long)((int)floorf(hdr.max_x / g.cs) + 2) - g.minx;
-            const long long sy = (long long)((int)floorf(hdr.max_y / g.cs) + 2) - g.miny;
-            if (sx <= 0 || sy <= 0 || sx >= 65536 || sy >= 65536 || sx * sy >= (1ll << 31))
-                return agree(G, c->fail(SPH_ERR_UNSUPPORTED, "cell grid %lld x %lld is too large for this build", sx, sy));
-            g.sx = (int)sx;
-            g.sy = (int)sy;
-        } else {
-            g.sx = g.sy = 1;
-        }
-        g.ncells = (uint32_t)g.sx * (uint32_t)g.sy;
-        g.ntx = g.nty = 0;
-        c->grid = g;
-        c->grid_valid = true;
-        HIPCHK(c, c->cell_start.ensure(((size_t)g.ncells + 1) * sizeof(uint32_t)));
+        const bool coarse_ok = make_grid(h_max_g * 2.f, g);
         c->uniform_h = (h_min_g == h_max_g);
         c->h_uniform = h_max_g;
+        GridP fg = g;
+        c->tile_ts = 0;
+        if (!c->uniform_h) {
+            float cs = h_min_g * 2.f;
+            bool ok = false;
+            for (int k = 0; k < 24 && cs < g.cs; k++, cs *= 2.f)
+                if ((ok = make_grid(cs, fg))) break;
+            if (ok) {
+                int ts = (int)ceilf(g.cs / fg.cs);
+                while ((float)ts * fg.cs < g.cs) ts++;
+                c->tile_ts = ts;
+                c->tile_tsx = (fg.sx + ts - 1) / ts;
+                c->tile_tsy = (fg.sy + ts - 1) / ts;
+            } else {
+                fg = g;   // the finest grid that fits is the coarse one: a one-cell tile, 3 x 3 stencils
+                if (coarse_ok) {
+                    c->tile_ts = 1;
+                    c->tile_tsx = fg.sx;
+                    c->tile_tsy = fg.sy;
+                }
+            }
+        }
+        if (!coarse_ok)
+            return agree(G, c->fail(SPH_ERR_UNSUPPORTED, "cell grid of cell size %g is too large for this build", (double)g.cs));
+        c->grid = g;
+        c->fgrid = fg;
+        c->grid_valid = true;
+        g = fg;   // everything below (keys, sort, cell ranges, sweeps) works on the sorting grid
+        HIPCHK(c, c->cell_start.ensure(((size_t)g.ncells + 1) * sizeof(uint32_t)));
 
         StepP sp{};
         sp.rest_density = p->rest_density;
@@ -982,6 +1018,14 @@ static int group_step(Group& G, const sph_params* p, sph_step_stats* outs)
         }
         HIPCHK(c, c->cs_scratch.ensure(cell_start_scratch_bytes()));
         launch_cell_start(s, prof, c->key[0].as<uint32_t>(), n, g.ncells, c->cell_start.as<uint32_t>(), c->cs_scratch.p);
+        if (c->tile_ts > 0) {
+            const size_t nt = (size_t)c->tile_tsx * (size_t)c->tile_tsy;
+            HIPCHK(c, c->tile_raw.ensure(nt * 4));
+            HIPCHK(c, c->tile_h.ensure(nt * 4));
+            launch_tile_hmax(s, prof, n, c->pm[c->pcur].as<float4>(), g, c->tile_ts, c->tile_tsx, c->tile_tsy, c->tile_raw.as<uint32_t>(),
+                             c->tile_h.as<uint32_t>());
+        }
+        if (c->exact || !c->uniform_h) HIPCHK(c, c->nlx.ensure(sweep_index_list_bytes(n ? n : 1)));
         if (c->dist.on) {
             auto& d = c->dist;
             if (n)

@@ -37,17 +37,28 @@
 //             is sorted particle  cell_start[(cy+r-1)*sx + cx-1] + b  (the row's candidate range
 //             is contiguous because cells are ordered x-fastest); the bases are re-read from the
 //             L2-resident cell table, which costs no HBM traffic;
-//   w       : neighbour count (bits 0..15) | NL_OK (list complete: every row has <= 32 candidates)
+//   w       : neighbour count (bits 0..15) | NL_OK   (mask list complete: 3x3 stencil, every row <= 32 candidates)
+//                                          | NL_IDX  (explicit index list in nlx: particles whose stencil is
+//                                                     wider than 3x3 cells or whose rows hold > 32 candidates --
+//                                                     the interface particles of a multi-resolution scene)
 //                                          | NL_WALL (particle has boundary terms: lambda != 0)
+// Index list: group g (4 neighbour indices, one uint4) of particle i lives at nlx[g * n + i], so a wave reads
+// one coalesced 1 KB line per trip.  Particles with more than NLX_CAP neighbours have neither flag and walk
+// their candidates in every sweep.
 #define NL_OK 0x80000000u
 #define NL_WALL 0x40000000u
+#define NL_IDX 0x20000000u
+#define NLX_GROUPS 32
+#define NLX_CAP (4 * NLX_GROUPS)
 
 struct SweepCommon {
-    GridP g;
+    GridP g;       // the grid the particles are sorted by (cell = support of the SMALLEST particle)
+    TileP t;       // per-tile bound on the neighbours' h => stencil radius of a particle (uniform scenes: 3x3)
     uint32_t n;
     uint32_t nblocks;
     const uint32_t* __restrict__ cell_start;
-    uint4* __restrict__ nl;   // neighbour list words
+    uint4* __restrict__ nl;    // neighbour list words
+    uint4* __restrict__ nlx;   // explicit index lists (nullptr in uniform scenes)
     const uint8_t* __restrict__ owned;  // slab decomposition: ghost lanes idle (their values come from their owner)
 };
 
@@ -69,39 +80,14 @@ __device__ __forceinline__ void raise_error(DeviceStatus* st, uint32_t code, uin
 //   void   pair(acc, Aj, NBj, dx, dy, r2, hij)  one accepted pair
 //   void   finish(acc, i, Ai, wall)             boundary terms (only if `wall`), outputs, guards
 //   void   epilogue(acc, active, blk)           optional block-level tail (HAS_EPILOGUE)
+//
+// Measured negatives (MI355X, N = 1M; DESIGN.md "What bounds the sweeps"): staging the wave's three row ranges
+// in LDS (random ds_read_b128 costs what the L1 gathers cost, and the LDS cuts occupancy: Jacobi 38.9 vs 28.5 us);
+// flattening the three rows into one batch loop; FMA / packed-f32 pair math (fewer VALU instructions, same time).
 // ------------------------------------------------------------------------------------------------
-// LDS slot type of the per-neighbour payload: 12-byte payloads are padded to 16 B (ds_read_b128)
-template <class NB, int SZ = sizeof(NB)>
-struct NBSlot {
-    NB v;
-};
-template <class NB>
-struct NBSlot<NB, 12> {
-    NB v;
-    float pad;
-};
-
-#define STAGE_CAP 256   // staged particles per wave: 3 rows x (64 particles + 2 cells) of the rest lattice ~ 220
-
-// pair loops of one particle, against LDS (STAGED) or against global memory / L2
-template <class Op, bool BUILD, bool STAGED>
-__device__ __forceinline__ void run_pairs(const Op& op, typename Op::Acc& acc, const float4 Ai, const uint32_t (&rb)[3],
-                                          const uint32_t (&re)[3], const bool walk, uint4& lw, const float4* __restrict__ sA,
-                                          const NBSlot<typename Op::NB>* __restrict__ sN, const int (&soff)[3])
-{
-    typedef typename Op::Math Math;
-    typedef typename Op::NB NB;
-#define SPH_FETCH(J, DR, AOUT, NOUT)                                                      \
-    float4 AOUT;                                                                          \
-    NB NOUT;                                                                              \
-    if (STAGED) {                                                                         \
-        const int sl = soff[DR] + (int)(J);                                               \
-        AOUT = sA[sl];                                                                    \
-        NOUT = sN[sl].v;                                                                  \
-    } else {                                                                              \
-        AOUT = op.loadA(J);                                                               \
-        NOUT = op.nb(acc, J, AOUT);                                                       \
-    }
+#define SPH_FETCH(J, AOUT, NOUT)                                                          \
+    const float4 AOUT = op.loadA(J);                                                      \
+    const typename Op::NB NOUT = op.nb(acc, J, AOUT);
 #define SPH_PAIR(AJ, NJ, ON)                                                              \
     {                                                                                     \
         const float dx = Ai.x - AJ.x, dy = Ai.y - AJ.y;                                   \
@@ -109,52 +95,95 @@ __device__ __forceinline__ void run_pairs(const Op& op, typename Op::Acc& acc, c
         const float hij = Math::UNIFORM ? op.m.h : (Ai.w + AJ.w) * 0.5f;                  \
         if (ON) op.pair(acc, AJ, NJ, dx, dy, r2, hij);                                    \
     }
-    if (!walk) {
-        // ---- list replay: per row, up to 4 set bits per trip (4 independent fetches in flight) ----------
-        const uint32_t masks[3] = {lw.x, lw.y, lw.z};
+
+// ---- list replay, row masks: per row up to 4 set bits per trip (4 independent fetches in flight) ----------
+template <class Op>
+__device__ __forceinline__ void replay_masks(const Op& op, typename Op::Acc& acc, const float4 Ai, const uint32_t (&rb)[3], const uint4 lw)
+{
+    typedef typename Op::Math Math;
+    const uint32_t masks[3] = {lw.x, lw.y, lw.z};
 #pragma unroll
-        for (int dr = 0; dr < 3; dr++) {
-            uint32_t mk = masks[dr];
-            const uint32_t base = rb[dr];
-            while (mk) {
-                const uint32_t b0 = __ffs(mk) - 1;
-                mk &= mk - 1;
-                const bool v1 = mk != 0;
-                const uint32_t b1 = v1 ? __ffs(mk) - 1 : b0;
-                mk &= mk - 1;
-                const bool v2 = mk != 0;
-                const uint32_t b2 = v2 ? __ffs(mk) - 1 : b0;
-                mk &= mk - 1;
-                const bool v3 = mk != 0;
-                const uint32_t b3 = v3 ? __ffs(mk) - 1 : b0;
-                mk &= mk - 1;
-                const uint32_t j0 = base + b0, j1 = base + b1, j2 = base + b2, j3 = base + b3;
-                SPH_FETCH(j0, dr, A0, N0)
-                SPH_FETCH(j1, dr, A1, N1)
-                SPH_FETCH(j2, dr, A2, N2)
-                SPH_FETCH(j3, dr, A3, N3)
-                SPH_PAIR(A0, N0, true)
-                SPH_PAIR(A1, N1, v1)
-                SPH_PAIR(A2, N2, v2)
-                SPH_PAIR(A3, N3, v3)
-            }
+    for (int dr = 0; dr < 3; dr++) {
+        uint32_t mk = masks[dr];
+        const uint32_t base = rb[dr];
+        while (mk) {
+            const uint32_t b0 = __ffs(mk) - 1;
+            mk &= mk - 1;
+            const bool v1 = mk != 0;
+            const uint32_t b1 = v1 ? __ffs(mk) - 1 : b0;
+            mk &= mk - 1;
+            const bool v2 = mk != 0;
+            const uint32_t b2 = v2 ? __ffs(mk) - 1 : b0;
+            mk &= mk - 1;
+            const bool v3 = mk != 0;
+            const uint32_t b3 = v3 ? __ffs(mk) - 1 : b0;
+            mk &= mk - 1;
+            const uint32_t j0 = base + b0, j1 = base + b1, j2 = base + b2, j3 = base + b3;
+            SPH_FETCH(j0, A0, N0)
+            SPH_FETCH(j1, A1, N1)
+            SPH_FETCH(j2, A2, N2)
+            SPH_FETCH(j3, A3, N3)
+            SPH_PAIR(A0, N0, true)
+            SPH_PAIR(A1, N1, v1)
+            SPH_PAIR(A2, N2, v2)
+            SPH_PAIR(A3, N3, v3)
         }
-    } else {
-        // ---- candidate walk: 3 rows x 3 cells, exact reference predicate, 4 candidates per trip ----------
-        uint32_t mk[3] = {0u, 0u, 0u};
-        uint32_t nacc = 0;
-        bool ok_list = true;
-#pragma unroll
-        for (int dr = 0; dr < 3; dr++) {
-            const uint32_t b = rb[dr], e = re[dr];
-            ok_list = ok_list && (e - b) <= 32u;
-            for (uint32_t j = b; j < e; j += 4) {
-                const bool v1 = j + 1 < e, v2 = j + 2 < e, v3 = j + 3 < e;
-                const uint32_t j1 = v1 ? j + 1 : j, j2 = v2 ? j + 2 : j, j3 = v3 ? j + 3 : j;
-                SPH_FETCH(j, dr, A0, N0)
-                SPH_FETCH(j1, dr, A1, N1)
-                SPH_FETCH(j2, dr, A2, N2)
-                SPH_FETCH(j3, dr, A3, N3)
+    }
+}
+
+// ---- list replay, explicit indices: one coalesced uint4 (4 neighbours) per trip ---------------------------
+template <class Op>
+__device__ __forceinline__ void replay_indices(const Op& op, typename Op::Acc& acc, const float4 Ai, const uint32_t i, const uint32_t cnt,
+                                               const uint4* __restrict__ nlx, const uint32_t n)
+{
+    typedef typename Op::Math Math;
+    for (uint32_t k = 0; k < cnt; k += 4) {
+        const uint4 q = nlx[(size_t)(k >> 2) * n + i];
+        const bool v1 = k + 1 < cnt, v2 = k + 2 < cnt, v3 = k + 3 < cnt;
+        const uint32_t j0 = q.x, j1 = v1 ? q.y : q.x, j2 = v2 ? q.z : q.x, j3 = v3 ? q.w : q.x;
+        SPH_FETCH(j0, A0, N0)
+        SPH_FETCH(j1, A1, N1)
+        SPH_FETCH(j2, A2, N2)
+        SPH_FETCH(j3, A3, N3)
+        SPH_PAIR(A0, N0, true)
+        SPH_PAIR(A1, N1, v1)
+        SPH_PAIR(A2, N2, v2)
+        SPH_PAIR(A3, N3, v3)
+    }
+}
+
+// recorder of an explicit index list (BUILD): 4 accepted indices are collected in registers, then stored as one uint4
+struct IdxRecorder {
+    uint4 cur;
+    __device__ __forceinline__ void push(uint32_t j, uint32_t nacc, uint4* __restrict__ nlx, uint32_t n, uint32_t i)
+    {
+        const uint32_t s = nacc & 3u;
+        cur.x = s == 0u ? j : cur.x;
+        cur.y = s == 1u ? j : cur.y;
+        cur.z = s == 2u ? j : cur.z;
+        cur.w = s == 3u ? j : cur.w;
+        if (s == 3u && nacc < NLX_CAP) nlx[(size_t)(nacc >> 2) * n + i] = cur;
+    }
+    __device__ __forceinline__ void flush(uint32_t nacc, uint4* __restrict__ nlx, uint32_t n, uint32_t i)
+    {
+        if ((nacc & 3u) && nacc < NLX_CAP) nlx[(size_t)(nacc >> 2) * n + i] = cur;
+    }
+};
+
+// one row of the candidate walk: exact reference predicate, 4 candidates per trip.  MASKS: accepted candidates set
+// bits of `mk` (bit = j - b); REC: accepted candidates are appended to the explicit index list.
+template <class Op, bool MASKS, bool REC>
+__device__ __forceinline__ void walk_row(const Op& op, typename Op::Acc& acc, const float4 Ai, const uint32_t b, const uint32_t e, uint32_t& mk,
+                                         uint32_t& nacc, IdxRecorder& rec, uint4* __restrict__ nlx, const uint32_t n, const uint32_t i)
+{
+    typedef typename Op::Math Math;
+    for (uint32_t j = b; j < e; j += 4) {
+        const bool v1 = j + 1 < e, v2 = j + 2 < e, v3 = j + 3 < e;
+        const uint32_t j1 = v1 ? j + 1 : j, j2 = v2 ? j + 2 : j, j3 = v3 ? j + 3 : j;
+        SPH_FETCH(j, A0, N0)
+        SPH_FETCH(j1, A1, N1)
+        SPH_FETCH(j2, A2, N2)
+        SPH_FETCH(j3, A3, N3)
 #define SPH_CAND(JJ, AJ, NJ, VALID)                                                       \
     {                                                                                     \
         /* neighbour predicate, exactly the reference's operations (no FMA, strict <) */  \
@@ -164,36 +193,28 @@ __device__ __forceinline__ void run_pairs(const Op& op, typename Op::Acc& acc, c
         const float s = hij * 2.f;                                                        \
         if ((VALID) && r2 < s * s) {                                                      \
             op.pair(acc, AJ, NJ, dx, dy, r2, hij);                                        \
-            const uint32_t bit = (JJ) - b;                                                \
-            if (bit < 32u) mk[dr] |= 1u << bit;                                           \
+            if (MASKS) {                                                                  \
+                const uint32_t bit = (JJ) - b;                                            \
+                if (bit < 32u) mk |= 1u << bit;                                           \
+            }                                                                             \
+            if (REC) rec.push(JJ, nacc, nlx, n, i);                                       \
             nacc++;                                                                       \
         }                                                                                 \
     }
-                SPH_CAND(j, A0, N0, true)
-                SPH_CAND(j1, A1, N1, v1)
-                SPH_CAND(j2, A2, N2, v2)
-                SPH_CAND(j3, A3, N3, v3)
-            }
-        }
-        if (BUILD) lw = make_uint4(mk[0], mk[1], mk[2], (nacc & 0xffffu) | (ok_list ? NL_OK : 0u));
+        SPH_CAND(j, A0, N0, true)
+        SPH_CAND(j1, A1, N1, v1)
+        SPH_CAND(j2, A2, N2, v2)
+        SPH_CAND(j3, A3, N3, v3)
+#undef SPH_CAND
     }
+}
 #undef SPH_FETCH
 #undef SPH_PAIR
-#undef SPH_CAND
-}
 
 template <class Op, bool BUILD>
 __global__ __launch_bounds__(SWEEP_THREADS) void k_sweep(Op op, SweepCommon c)
 {
-    typedef typename Op::NB NB;
-#ifdef SPH_USE_STAGING
-    __shared__ float4 s_A[SWEEP_THREADS / 64][STAGE_CAP];
-    __shared__ NBSlot<NB> s_N[SWEEP_THREADS / 64][STAGE_CAP];
-#else
-    __shared__ float4 s_A[1][1];
-    __shared__ NBSlot<NB> s_N[1][1];
-#endif
-
+    typedef typename Op::Math Math;
     if (op.skip()) return;
     // XCD-aware block order: the dispatcher places block b on XCD b % 8; give every XCD a contiguous
     // band of the cell-sorted array so that vertically adjacent waves (which share neighbour rows)
@@ -205,93 +226,81 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_sweep(Op op, SweepCommon c)
     const bool active = i < c.n && (!c.owned || c.owned[i < c.n ? i : 0]);
     const GridP g = c.g;
     typename Op::Acc acc;
-    op.init(acc);  // lane-independent state (valid on lanes past the end too: they help staging)
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    op.init(acc);  // lane-independent state
 
-    float4 Ai = make_float4(0.f, 0.f, 0.f, 0.f);
-    uint4 lw = make_uint4(0, 0, 0, 0);
-    uint32_t rb[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, re[3] = {0u, 0u, 0u};
-    bool walk = false;
-    int cy = -1;
     if (active) {
-        Ai = op.loadA(i);
+        const float4 Ai = op.loadA(i);
+        uint4 lw = make_uint4(0, 0, 0, 0);
         if (!BUILD) lw = c.nl[i];
         op.begin(acc, i, Ai);
-        // own cell (the same IEEE expression the sort key was computed from) and the three row bases
-        const int cx = (int)floorf(Ai.x / g.cs) - g.minx;
-        cy = (int)floorf(Ai.y / g.cs) - g.miny;
-        walk = BUILD || !(lw.w & NL_OK);
-        const uint32_t mk[3] = {lw.x, lw.y, lw.z};
+        if (!BUILD && !Math::UNIFORM && (lw.w & NL_IDX)) {
+            replay_indices(op, acc, Ai, i, lw.w & 0xffffu, c.nlx, c.n);
+        } else {
+            // own cell (the same IEEE expression the sort key was computed from)
+            const int cx = (int)floorf(Ai.x / g.cs) - g.minx;
+            const int cy = (int)floorf(Ai.y / g.cs) - g.miny;
+            const bool walk = BUILD || !(lw.w & NL_OK);
+            const int R = (Math::UNIFORM || !walk) ? 1 : stencil_radius(g, c.t, Ai.w, cx, cy);
+            if (R == 1) {
+                // 3 x 3 cells: three contiguous candidate ranges
+                uint32_t rb[3], re[3];
+                bool ok_list = true;
 #pragma unroll
-        for (int dr = 0; dr < 3; dr++) {
-            const int yy = cy + dr - 1;
-            const bool ok = yy >= 0 && yy < g.sy;
-            const uint32_t base = (uint32_t)(ok ? yy : 0) * (uint32_t)g.sx;
-            rb[dr] = ok ? c.cell_start[base + (uint32_t)max(cx - 1, 0)] : 0u;
-            // end of what this lane will touch in the row: the candidate range end (walk) or the highest set bit
-            if (walk) re[dr] = ok ? c.cell_start[base + (uint32_t)min(cx + 2, g.sx)] : rb[dr];
-            else re[dr] = rb[dr] + (mk[dr] ? 32u - (uint32_t)__clz(mk[dr]) : 0u);
-        }
-        // the particle itself is on its own list (the reference keeps it there), but in the gradient sweeps its pair
-        // term is exactly zero (grad W(0) = 0, Q_i - Q_i = 0): drop its bit, which brings the middle row of the rest
-        // lattice from 5 to 4 set bits = one trip instead of two
-        if (!BUILD && Op::SKIP_SELF && !walk) {
-            const uint32_t sb = i - rb[1];
-            if (sb < 32u) lw.y &= ~(1u << sb);
-        }
-    }
-
-    // ---- stage the wave's three row ranges into LDS (coalesced), if the wave sits in one cell row ---------
-    int soff[3] = {0, 0, 0};
-    bool staged = false;
-    {
-        const int cy0 = __shfl(cy, 0, 64);
-        const bool same_row = __all(!active || cy == cy0) && cy0 >= 0;
-        uint32_t lo[3], hi[3], T = 0;
+                for (int dr = 0; dr < 3; dr++) {
+                    const int yy = cy + dr - 1;
+                    const bool ok = yy >= 0 && yy < g.sy;
+                    const uint32_t base = (uint32_t)(ok ? yy : 0) * (uint32_t)g.sx;
+                    rb[dr] = ok ? c.cell_start[base + (uint32_t)max(cx - 1, 0)] : 0u;
+                    re[dr] = rb[dr];
+                    if (walk) {
+                        re[dr] = ok ? c.cell_start[base + (uint32_t)min(cx + 2, g.sx)] : rb[dr];
+                        ok_list = ok_list && (re[dr] - rb[dr]) <= 32u;
+                    }
+                }
+                if (!walk) {
+                    // the particle itself is on its own list (the reference keeps it there), but in the gradient sweeps
+                    // its pair term is exactly zero (grad W(0) = 0, Q_i - Q_i = 0): drop its bit, which brings the middle
+                    // row of the rest lattice from 5 to 4 set bits = one trip instead of two
+                    if (Op::SKIP_SELF) {
+                        const uint32_t sb = i - rb[1];
+                        if (sb < 32u) lw.y &= ~(1u << sb);
+                    }
+                    replay_masks(op, acc, Ai, rb, lw);
+                } else {
+                    uint32_t mk[3] = {0u, 0u, 0u}, nacc = 0;
+                    IdxRecorder rec;
+                    rec.cur = make_uint4(0, 0, 0, 0);
+                    const bool rec_idx = BUILD && !Math::UNIFORM && !ok_list;
+                    if (rec_idx) {
 #pragma unroll
-        for (int dr = 0; dr < 3; dr++) {
-            uint32_t l = rb[dr], h = active ? re[dr] : 0u;
-            for (int o = 32; o > 0; o >>= 1) {
-                l = min(l, (uint32_t)__shfl_xor((int)l, o, 64));
-                h = max(h, (uint32_t)__shfl_xor((int)h, o, 64));
+                        for (int dr = 0; dr < 3; dr++) walk_row<Op, false, true>(op, acc, Ai, rb[dr], re[dr], mk[dr], nacc, rec, c.nlx, c.n, i);
+                        rec.flush(nacc, c.nlx, c.n, i);
+                    } else {
+#pragma unroll
+                        for (int dr = 0; dr < 3; dr++) walk_row<Op, BUILD, false>(op, acc, Ai, rb[dr], re[dr], mk[dr], nacc, rec, c.nlx, c.n, i);
+                    }
+                    if (BUILD)
+                        lw = make_uint4(mk[0], mk[1], mk[2],
+                                        (nacc & 0xffffu) | (ok_list ? NL_OK : 0u) | (rec_idx && nacc <= NLX_CAP ? NL_IDX : 0u));
+                }
+            } else {
+                // wide stencil (a large neighbour may be around): (2R+1) rows, explicit index list
+                uint32_t dummy = 0, nacc = 0;
+                IdxRecorder rec;
+                rec.cur = make_uint4(0, 0, 0, 0);
+                const int x0 = max(cx - R, 0), x1 = min(cx + R + 1, g.sx);
+                for (int yy = max(cy - R, 0); yy <= min(cy + R, g.sy - 1); yy++) {
+                    const uint32_t base = (uint32_t)yy * (uint32_t)g.sx;
+                    const uint32_t b = c.cell_start[base + (uint32_t)x0], e = c.cell_start[base + (uint32_t)x1];
+                    if (BUILD) walk_row<Op, false, true>(op, acc, Ai, b, e, dummy, nacc, rec, c.nlx, c.n, i);
+                    else walk_row<Op, false, false>(op, acc, Ai, b, e, dummy, nacc, rec, c.nlx, c.n, i);
+                }
+                if (BUILD) {
+                    rec.flush(nacc, c.nlx, c.n, i);
+                    lw = make_uint4(0, 0, 0, (nacc & 0xffffu) | (nacc <= NLX_CAP ? NL_IDX : 0u));
+                }
             }
-            lo[dr] = l;
-            hi[dr] = h > l ? h : l;
-            soff[dr] = (int)T - (int)l;  // slot of global index j in row dr = soff[dr] + j
-            T += hi[dr] - lo[dr];
         }
-        staged = same_row && T <= STAGE_CAP;
-#ifndef SPH_USE_STAGING
-        // measured on MI355X at N = 1M: staging is SLOWER than gathering through L1/L2 (Jacobi 38.9 vs 28.5 us,
-        // source 40 vs 27 us): random ds_read_b128 costs as much as the L1 gathers it replaces and the 16-32 KB
-        // of LDS per block cut occupancy.  Kept as a compile-time option (-DSPH_USE_STAGING).
-        staged = false;
-#endif
-#ifdef SPH_USE_STAGING
-        if (staged) {
-            for (uint32_t t = lane; t < T; t += 64) {
-                const uint32_t t1 = hi[0] - lo[0], t2 = t1 + (hi[1] - lo[1]);
-                const int dr = t < t1 ? 0 : (t < t2 ? 1 : 2);
-                const uint32_t j = (dr == 0 ? lo[0] + t : (dr == 1 ? lo[1] + (t - t1) : lo[2] + (t - t2)));
-                const float4 Aj = op.loadA(j);
-                s_A[wv][t] = Aj;
-                s_N[wv][t].v = op.nb(acc, j, Aj);
-            }
-            // the wave's own LDS writes are read back by other lanes of the same wave only: LDS operations of
-            // one wave execute in order, so a compiler barrier + counter wait is all that is needed
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        }
-#endif
-    }
-
-    if (active) {
-#ifdef SPH_USE_STAGING
-        if (staged) run_pairs<Op, BUILD, true>(op, acc, Ai, rb, re, walk, lw, s_A[wv], s_N[wv], soff);
-        else
-#endif
-            run_pairs<Op, BUILD, false>(op, acc, Ai, rb, re, walk, lw, s_A[0], s_N[0], soff);
         const bool wall = op.finish(acc, i, Ai, BUILD ? true : (lw.w & NL_WALL) != 0u);
         if (BUILD) {
             if (wall) lw.w |= NL_WALL;
@@ -1107,7 +1116,7 @@ __global__ __launch_bounds__(256) void k_integrate(uint32_t n, float dt, float v
 // ------------------------------------------------------------------------------------------------
 static SweepCommon common_of(const SweepArgs& a)
 {
-    return SweepCommon{a.g, a.n, (a.n + SWEEP_THREADS - 1) / SWEEP_THREADS, a.cell_start, a.nl, a.owned};
+    return SweepCommon{a.g, a.t, a.n, (a.n + SWEEP_THREADS - 1) / SWEEP_THREADS, a.cell_start, a.nl, a.nlx, a.owned};
 }
 
 template <class Op, bool BUILD>
@@ -1120,6 +1129,7 @@ static void launch_sweep(hipStream_t s, const SweepArgs& a, const Op& op)
 }
 
 size_t sweep_list_bytes(uint32_t n) { return (size_t)n * sizeof(uint4); }
+size_t sweep_index_list_bytes(uint32_t n) { return (size_t)n * sizeof(uint4) * NLX_GROUPS; }
 uint32_t solver_reduce_blocks(uint32_t n) { return (n + SWEEP_THREADS - 1) / SWEEP_THREADS; }
 
 static MathUniform uniform_math(float h)

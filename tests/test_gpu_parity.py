@@ -136,6 +136,35 @@ def test_adaptive_h_two_size_classes(product_lib, oracle_lib):
         assert rel_err(g.download(f), o.download(f)) < TOL.get(f, REL_TOL_FIELDS), f
 
 
+@pytest.mark.parametrize("ratio", [4, 12])
+def test_multi_resolution_stencils_and_index_lists(product_lib, oracle_lib, ratio):
+    """4:1 (BASELINE configs[2]) and 12:1 radius ratios.  The product sorts by a grid of the SMALL particles and widens
+    the stencil near large ones; interface particles keep explicit index lists, and at 12:1 a coarse particle has more
+    neighbours than an index list holds (128), so it walks its candidates in every sweep.  Sets bit-exact either way."""
+    fine = 0.02
+    scn = sc.SceneConfig(sc.SceneBoundary("box", 3.0, 3.0),
+                         [sc.SceneFluidBlock([-0.95, -0.5], [0.55, 1.4], fine, 0.93, [0.5, 0]),
+                          sc.SceneFluidBlock([-0.40 + 0.3 * fine * ratio, -0.5], [0.7, 1.4], fine * ratio, 0.93, [-0.5, 0])])
+    g, o = make_pair(product_lib, oracle_lib, scn)
+    p = forced(max_iters=3, check_neighborhood=True).to_ffi()
+    for s in range(4):
+        sg, so = g.step(p), o.step(p)
+        assert abs(sg.dt - so.dt) <= 1e-5 * so.dt   # CFL-limited here: dt follows the (1e-7-different) velocities
+    gg, og = g.grid(), o.grid()   # the reported grid stays the reference convention (cell = largest support)
+    assert (gg.cell_size, gg.cells_min_x, gg.cells_min_y, gg.size_x, gg.size_y) == \
+           (og.cell_size, og.cells_min_x, og.cells_min_y, og.size_x, og.size_y)
+    for f in ["h2", "neighbor_count", "cell_index"]:
+        assert np.array_equal(g.download(f), o.download(f)), f
+    assert_same_neighbor_sets(g, o)
+    nmax = g.download("neighbor_count").max()
+    assert nmax > (128 if ratio == 12 else 20), nmax
+    # 12:1 is far outside what the reference is run at (a coarse particle sums ~280 fine neighbours of 1/144 its mass):
+    # the pressure field there is only good to the documented 2e-3, and v += dt a^p carries that into the velocities
+    tol = dict(TOL, velocity=1e-3) if ratio == 12 else TOL
+    for f in ALL_FIELDS:
+        assert rel_err(g.download(f), o.download(f)) < tol.get(f, REL_TOL_FIELDS), f
+
+
 def test_free_running_iteration_counts(product_lib, oracle_lib):
     g, o = make_pair(product_lib, oracle_lib, sc.dam_break_small(48, 48, 1 / 48))
     p = dam_break_params().to_ffi()
