@@ -181,7 +181,7 @@ __global__ void k_publish(const SolverCtrl* __restrict__ ctrl, const DeviceStatu
     }
 }
 
-enum { G_F32 = 0, G_F32X2 = 1, G_PM_X = 2, G_PM_M = 3, G_PM_H = 4, G_U32 = 5, G_H2NEXT = 6 };
+enum { G_F32 = 0, G_F32X2 = 1, G_PM_X = 2, G_PM_M = 3, G_PM_H = 4, G_U32 = 5, G_H2NEXT = 6, G_U8 = 7 };
 
 // dst[orig[i]] = field[i]: back to host particle order
 __global__ __launch_bounds__(256) void k_to_host_order(uint32_t n, int kind, const uint32_t* __restrict__ orig, const void* __restrict__ src,
@@ -193,6 +193,7 @@ __global__ __launch_bounds__(256) void k_to_host_order(uint32_t n, int kind, con
     switch (kind) {
     case G_F32: ((float*)dst)[o] = ((const float*)src)[i]; break;
     case G_U32: ((uint32_t*)dst)[o] = ((const uint32_t*)src)[i]; break;
+    case G_U8: ((uint8_t*)dst)[o] = ((const uint8_t*)src)[i]; break;
     case G_F32X2: ((float2*)dst)[o] = ((const float2*)src)[i]; break;
     case G_PM_X: { float4 p = ((const float4*)src)[i]; ((float2*)dst)[o] = make_float2(p.x, p.y); } break;
     case G_PM_M: ((float*)dst)[o] = ((const float4*)src)[i].z; break;
@@ -241,7 +242,7 @@ __global__ __launch_bounds__(256) void k_fill_neighbors(uint32_t n, GridP g, Til
     const uint32_t c = cxy[i];
     const int cx = c & 0xffffu, cy = c >> 16;
     uint32_t w = offsets_host[orig[i]];
-    const int R = stencil_radius(g, t, Ai.w, cx, cy);
+    const int R = stencil_radius(g, t, Ai.w, cx, cy, 2.f);
     for (int dy = -R; dy <= R; dy++) {
         int yy = cy + dy;
         if (yy < 0 || yy >= g.sy) continue;
@@ -335,6 +336,8 @@ extern "C" int sph_create(uint64_t n_capacity, int device_id, const sph_plane* p
     if (hipHostMalloc((void**)&c->hdr_host, sizeof(HeaderOut), hipHostMallocMapped) != hipSuccess) return bail(SPH_ERR_DEVICE);
     if (hipHostMalloc((void**)&c->ctrl_host, sizeof(SolverCtrl), hipHostMallocMapped) != hipSuccess) return bail(SPH_ERR_DEVICE);
     if (hipHostMalloc((void**)&c->status_host, sizeof(DeviceStatus), hipHostMallocMapped) != hipSuccess) return bail(SPH_ERR_DEVICE);
+    if (hipHostMalloc((void**)&c->lvl_changed, 64 * sizeof(uint32_t), hipHostMallocMapped) != hipSuccess) return bail(SPH_ERR_DEVICE);
+    if (hipHostGetDevicePointer((void**)&c->lvl_changed_dev, c->lvl_changed, 0) != hipSuccess) return bail(SPH_ERR_DEVICE);
     if (hipHostGetDevicePointer((void**)&c->hdr_host_dev, c->hdr_host, 0) != hipSuccess) return bail(SPH_ERR_DEVICE);
     if (hipHostGetDevicePointer((void**)&c->ctrl_host_dev, c->ctrl_host, 0) != hipSuccess) return bail(SPH_ERR_DEVICE);
     if (hipHostGetDevicePointer((void**)&c->status_host_dev, c->status_host, 0) != hipSuccess) return bail(SPH_ERR_DEVICE);
@@ -361,13 +364,15 @@ extern "C" void sph_destroy(sph_ctx* c)
     dist_release(c);
     DevBuf* all[] = {&c->pm[0], &c->pm[1], &c->vel[0], &c->vel[1], &c->orig[0], &c->orig[1], &c->lvl[0], &c->lvl[1], &c->lvlold[0],
                      &c->lvlold[1], &c->vel_tmp, &c->key[0], &c->key[1], &c->val[0], &c->val[1], &c->sort_scratch, &c->cxy, &c->cell_start,
-                     &c->cs_scratch, &c->nl, &c->nlx, &c->tile_raw, &c->tile_h, &c->nl_ok, &c->mrho, &c->pt0, &c->pt1, &c->rho, &c->lam_sum, &c->lam_grad, &c->constf, &c->aii, &c->src, &c->p0, &c->p1, &c->pacc, &c->dens_err,
+                     &c->cs_scratch, &c->nl, &c->nlx, &c->tile_raw, &c->tile_h, &c->lvl_tmp, &c->lvl_nrm, &c->lvl_state, &c->lvl_when, &c->lvl_mark, &c->flag_surface,
+                     &c->flag_insufficient, &c->size_class, &c->stash, &c->nl_ext, &c->nlx_ext, &c->nl_ok, &c->mrho, &c->pt0, &c->pt1, &c->rho, &c->lam_sum, &c->lam_grad, &c->constf, &c->aii, &c->src, &c->p0, &c->p1, &c->pacc, &c->dens_err,
                      &c->stat, &c->ncount, &c->planes_d, &c->lam_lut, &c->dlam_lut, &c->hdr_partials, &c->hdr_out, &c->ctrl, &c->status,
                      &c->n_tiles, &c->red_partials, &c->scratch};
     for (auto b : all) b->release();
     if (c->hdr_host) hipHostFree(c->hdr_host);
     if (c->ctrl_host) hipHostFree(c->ctrl_host);
     if (c->status_host) hipHostFree(c->status_host);
+    if (c->lvl_changed) hipHostFree(c->lvl_changed);
     for (auto& e : c->ev)
         if (e) hipEventDestroy(e);
     if (c->ev_sync) hipEventDestroy(c->ev_sync);
@@ -398,6 +403,7 @@ extern "C" int sph_upload(sph_ctx* c, uint64_t n, const float* mass, const float
     c->dist.have_flags = false;
     c->dist.n_tot = (uint32_t)n;
     c->grid_valid = false;
+    c->have_level = false;
     if (n == 0) return SPH_OK;
     // stage host arrays through scratch buffers: mass -> key[1], pos -> scratch, vel -> vel_tmp
     HIPCHK(c, hipMemcpyAsync(c->key[1].p, mass, n * sizeof(float), hipMemcpyHostToDevice, s));
@@ -505,10 +511,22 @@ extern "C" int sph_download(sph_ctx* c, int field, void* dst, uint64_t bytes)
     }
     if (field == SPH_F_STASH || field == SPH_F_FLAG_IS_FLUID_SURFACE || field == SPH_F_FLAG_INSUFFICIENT_NEIGHS ||
         field == SPH_F_PARTICLE_SIZE_CLASS) {
-        // level-estimation outputs: not produced on the device yet -> defaults of ParticleVec
+        // level-estimation outputs (simulation.rs:539-927).  Before the first step with a level_estimation_method they are
+        // the defaults of ParticleVec.
         size_t elem = field == SPH_F_STASH ? 4 : 1;
         if (bytes != (uint64_t)n * elem) return c->fail(SPH_ERR_INVALID_ARGUMENT, "field %d: size mismatch", field);
-        memset(dst, field == SPH_F_PARTICLE_SIZE_CLASS ? 2 : 0, bytes);
+        if (!c->have_level || c->dist.on) {
+            memset(dst, field == SPH_F_PARTICLE_SIZE_CLASS ? 2 : 0, bytes);
+            return SPH_OK;
+        }
+        if (n == 0) return SPH_OK;
+        const void* src = field == SPH_F_STASH ? c->stash.p
+                          : field == SPH_F_FLAG_IS_FLUID_SURFACE ? c->flag_surface.p
+                          : field == SPH_F_FLAG_INSUFFICIENT_NEIGHS ? c->flag_insufficient.p : c->size_class.p;
+        hipLaunchKernelGGL(k_to_host_order, dim3((n + 255) / 256), dim3(256), 0, s, n, field == SPH_F_STASH ? (int)G_F32 : (int)G_U8,
+                           c->orig[k].as<uint32_t>(), src, c->scratch.p);
+        HIPCHK(c, hipMemcpyAsync(dst, c->scratch.p, bytes, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipStreamSynchronize(s));
         return SPH_OK;
     }
     FieldRef r;

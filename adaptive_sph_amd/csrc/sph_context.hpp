@@ -90,6 +90,11 @@ struct sph_ctx {
     GridP fgrid{};          // the grid the particles are sorted by (== grid in uniform scenes)
     int tile_ts = 0, tile_tsx = 0, tile_tsy = 0;
     DevBuf tile_raw, tile_h, nlx;
+    // level estimation (simulation.rs:539-927), sorted order
+    DevBuf lvl_tmp, lvl_nrm, lvl_state, lvl_when, lvl_mark, flag_surface, flag_insufficient, size_class, stash, nl_ext, nlx_ext;
+    bool have_level = false;            // the level-estimation outputs above are those of the last step
+    uint32_t* lvl_changed = nullptr;    // mapped pinned host words written by the propagation sweeps
+    uint32_t* lvl_changed_dev = nullptr;
     uint32_t pressure_cur = 0;
     uint32_t last_div_iters = 2, last_dens_iters = 2;
     hipEvent_t ev[8];

@@ -149,13 +149,14 @@ __device__ __forceinline__ float h_from_mass(float mass, float rest_density)
     return SPH_ETA * sqrtf(volume * SPH_FRAC_1_PI_F);
 }
 
-// stencil half-width in cells that is guaranteed to cover every j with |x_ij| < h_i + h_j: such a j is closer than
-// h_i + hmax, hence at most floor((h_i + hmax) / cs) + 1 cells away on either axis
-__device__ __forceinline__ int stencil_radius(const GridP& g, const TileP& t, float h_i, int cx, int cy)
+// stencil half-width in cells that is guaranteed to cover every j with |x_ij| < (h_i + h_j) * 0.5 * k (k = 2: the
+// SPH support; k = level_estimation_range / ETA: the extended lists of the level estimation): such a j is closer
+// than (h_i + hmax) * 0.5 * k, hence at most floor(that / cs) + 1 cells away on either axis
+__device__ __forceinline__ int stencil_radius(const GridP& g, const TileP& t, float h_i, int cx, int cy, float k)
 {
-    if (t.ts <= 0) return 1;
-    const float hn = __uint_as_float(t.hmax[(uint32_t)(cy / t.ts) * (uint32_t)t.tsx + (uint32_t)(cx / t.ts)]);
-    return (int)floorf((h_i + hn) / g.cs) + 1;
+    float hn = h_i;   // uniform scene: every h is h_i
+    if (t.ts > 0) hn = __uint_as_float(t.hmax[(uint32_t)(cy / t.ts) * (uint32_t)t.tsx + (uint32_t)(cx / t.ts)]);
+    return (int)floorf(((h_i + hn) * 0.5f * k) / g.cs) + 1;
 }
 
 // LookupTable1D::get with (min,max,steps) = (-1,1,10000); caller guarantees -1 <= x < 1

@@ -123,6 +123,8 @@ struct SweepArgs {
     uint32_t* ncount;
     uint4* nl;          // neighbour list words (sph_sweeps.hip)
     uint4* nlx;         // explicit index lists (multi-resolution scenes)
+    uint4* nl_ext;      // list words / index lists of the extended-range lists (level estimation)
+    uint4* nlx_ext;
     TileP t;            // stencil bound per tile (multi-resolution scenes; ts = 0: uniform)
     float* partials;    // per-block solver statistics
     const uint8_t* owned;  // slab decomposition: 1 owned, 0 ghost (nullptr: everything is owned)
@@ -153,5 +155,27 @@ void launch_solver_decide(hipStream_t s, Profiler* prof, const SweepArgs& a, int
                           uint32_t max_iters);
 void launch_solver_reduce(hipStream_t s, Profiler* prof, const SweepArgs& a, int iter, int residual_density, float max_avg_error,
                           uint32_t max_iters, float* block_partials);
+// level estimation (sorted order)
+struct LevelArgs {
+    float k;                       // level_estimation_range / ETA
+    float threshold;               // cos(50 degrees)
+    float max_surface_distance;
+    int boundary_is_fluid_surface;
+    float2* nrm;
+    uint8_t* state;
+    uint8_t* flag_surface;
+    uint8_t* flag_insufficient;
+    uint8_t* size_class;
+    float* level;                  // the level field (detection output, propagated in place)
+    uint32_t* when;                // propagation sweep that assigned the value (sph_sweeps.hip)
+    uint32_t* mark;
+    float* level_old;
+    float* stash_first;            // stash filled right after the detection (SurfaceDistanceFirst) or nullptr
+};
+void launch_level_detect(hipStream_t s, Profiler* prof, const SweepArgs& a, const LevelArgs& l);
+void launch_level_propagate(hipStream_t s, Profiler* prof, const SweepArgs& a, const LevelArgs& l, uint32_t t, uint32_t* changed);
+void launch_fill_stash(hipStream_t s, Profiler* prof, const SweepArgs& a, const LevelArgs& l, float* stash);
+void launch_level_smooth(hipStream_t s, Profiler* prof, const SweepArgs& a, const LevelArgs& l, const float4* pm_new, const float* in, float* out);
+void launch_classify(hipStream_t s, Profiler* prof, const SweepArgs& a, const LevelArgs& l, const float* level, const sph_params* p);
 void launch_vel_add_pacc(hipStream_t s, Profiler* prof, const SweepArgs& a);               // v += dt a^p
 void launch_integrate(hipStream_t s, Profiler* prof, const SweepArgs& a, float4* pm_out, int mode);  // 0: v+=dt a; x+=dt v   1: hybrid

@@ -54,6 +54,8 @@ SweepArgs make_args(sph_ctx* c, const StepP& sp)
     a.ncount = c->ncount.as<uint32_t>();
     a.nl = c->nl.as<uint4>();
     a.nlx = c->nlx.as<uint4>();
+    a.nl_ext = c->nl_ext.as<uint4>();
+    a.nlx_ext = c->nlx_ext.as<uint4>();
     a.t = TileP{c->tile_ts, c->tile_tsx, c->tile_tsy, c->tile_h.as<uint32_t>()};
     a.partials = c->red_partials.as<float>();
     a.mrho = c->mrho.as<float>();
@@ -85,6 +87,7 @@ const char* status_message(uint32_t code)
     case SPH_ERR_POSITION_NOT_FINITE: return "Assertion 'p_position[d].is_finite()' failed!";
     case SPH_ERR_VISCOSITY_NOT_FINITE: return "Assertion 'viscosity_accel[d].is_finite()' failed!";
     case SPH_ERR_CHECK_NEIGHBORHOOD: return "neighbour list differs from the brute-force definition";
+    case SPH_ERR_LEVEL_WEIGHT: return "weight is <=0 in smooth_level_estimation_field";
     default: return "device-side guard failed";
     }
 }
@@ -861,8 +864,12 @@ static int group_step(Group& G, const sph_params* p, sph_step_stats* outs)
         return c0->fail(SPH_ERR_UNSUPPORTED, "support_length_estimation other than FromMass is not covered yet");
     if (p->constrain_neighborhood_count) return c0->fail(SPH_ERR_UNSUPPORTED, "constrain_neighborhood_count is not covered yet");
     if (p->pressure_solver_method == SPH_SOLVER_IISPH2) return c0->fail(SPH_ERR_UNSUPPORTED, "IISPH2 is not covered yet");
-    if (p->level_estimation_method != SPH_LEVEL_NONE)
-        return c0->fail(SPH_ERR_UNSUPPORTED, "level estimation on the device is not covered yet (SURVEY.md 8f rank 1)");
+    const bool level_on = p->level_estimation_method != SPH_LEVEL_NONE;
+    if (level_on && G.multi()) return c0->fail(SPH_ERR_UNSUPPORTED, "level estimation on a slab decomposition is not covered yet");
+    if (level_on && p->level_estimation_after_advection)
+        return c0->fail(SPH_ERR_UNSUPPORTED, "level_estimation_after_advection is not covered yet (needs the neighbourhood of the advected positions)");
+    if (level_on && p->level_estimation_method == SPH_LEVEL_CENTER_DIFF)   // simulation.rs:2029-2031
+        return c0->fail(SPH_ERR_INVALID_ARGUMENT, "center diff level estimation method needs density values");
     if (p->check_aii) return c0->fail(SPH_ERR_UNSUPPORTED, "check_aii is not covered yet");
     if (!p->level_estimation_after_advection && !p->use_extended_range_for_level_estimation)
         return c0->fail(SPH_ERR_INVALID_ARGUMENT, "assertion failed: simulation_params.use_extended_range_for_level_estimation");
@@ -1040,6 +1047,63 @@ static int group_step(Group& G, const sph_params* p, sph_step_stats* outs)
     }
     g_trace.mark(2);
 
+    // ---- level estimation on the extended-range lists (simulation.rs:2018-2046, 862-927) ------------------------------
+    LevelArgs lv{};
+    if (level_on) {
+        const auto t_lvl0 = std::chrono::steady_clock::now();
+        Member& m = M[0];
+        sph_ctx* c = m.c;
+        const size_t n = m.n ? m.n : 1;
+        HIPCHK(c, c->lvl_tmp.ensure(n * 4));
+        HIPCHK(c, c->lvl_nrm.ensure(n * 8));
+        HIPCHK(c, c->lvl_when.ensure(n * 4));
+        HIPCHK(c, c->lvl_mark.ensure(n * 4));
+        HIPCHK(c, c->stash.ensure(n * 4));
+        for (DevBuf* b : {&c->lvl_state, &c->flag_surface, &c->flag_insufficient, &c->size_class}) HIPCHK(c, b->ensure(n));
+        HIPCHK(c, c->nl_ext.ensure(sweep_list_bytes((uint32_t)n)));
+        HIPCHK(c, c->nlx_ext.ensure(sweep_index_list_bytes((uint32_t)n)));
+        m.a = make_args(c, m.sp);
+        lv.k = p->level_estimation_range / SPH_ETA;                    // simulation.rs:2036
+        lv.threshold = cosf(50.f * (SPH_PI_F / 180.f));                // simulation.rs:544
+        lv.max_surface_distance = p->maximum_surface_distance;
+        lv.boundary_is_fluid_surface = p->boundary_is_fluid_surface;
+        lv.nrm = c->lvl_nrm.as<float2>();
+        lv.state = c->lvl_state.as<uint8_t>();
+        lv.flag_surface = c->flag_surface.as<uint8_t>();
+        lv.flag_insufficient = c->flag_insufficient.as<uint8_t>();
+        lv.size_class = c->size_class.as<uint8_t>();
+        lv.level = c->lvl[c->cur].as<float>();
+        lv.when = c->lvl_when.as<uint32_t>();
+        lv.mark = c->lvl_mark.as<uint32_t>();
+        lv.level_old = c->lvlold[c->cur].as<float>();
+        lv.stash_first = p->fill_stash_with == SPH_STASH_SURFACE_DISTANCE_FIRST ? c->stash.as<float>() : nullptr;
+        if (m.n) {
+            if (p->fill_stash_with == SPH_STASH_NONE) (void)hipMemsetAsync(c->stash.p, 0, n * 4, c->stream);
+            (void)hipMemsetAsync(c->size_class.p, 2, n, c->stream);   // ParticleSizeClass::Optimal until classified
+            launch_level_detect(c->stream, &c->prof, m.a, lv);
+            // propagate until a sweep assigns nothing (`while changed`, simulation.rs:740-800); sweeps are queued in batches
+            // of 8 and the per-sweep flags read once per batch -- a sweep behind the last effective one has no candidates
+            launch_level_propagate(c->stream, &c->prof, m.a, lv, 0u, c->lvl_changed_dev);   // surface particles mark their neighbours
+            const int B = 8;
+            uint32_t t = 1;
+            for (bool done = false; !done;) {
+                for (int b = 0; b < B; b++) c->lvl_changed[b] = 0u;
+                for (int b = 0; b < B; b++, t++) {
+                    launch_level_propagate(c->stream, &c->prof, m.a, lv, t, c->lvl_changed_dev + b);
+                    if (t == 1u && p->fill_stash_with == SPH_STASH_SURFACE_DISTANCE_MIDDLE)   // num_iter == 1, simulation.rs:769-779
+                        launch_fill_stash(c->stream, &c->prof, m.a, lv, c->stash.as<float>());
+                }
+                if ((rc = wait_stream(c))) return rc;
+                for (int b = 0; b < B; b++)
+                    if (!c->lvl_changed[b]) done = true;
+            }
+        }
+        c->have_level = true;
+        m.st.ms_level_estimation = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_lvl0).count();
+    } else {
+        for (auto& m : M) m.c->have_level = false;
+    }
+
     // ---- density + boundary lambda + neighbour count (simulation.rs:2072-2074, 2179-2180, 2204) -----------
     for (auto& m : M) {
         (void)hipSetDevice(m.c->device);
@@ -1117,6 +1181,20 @@ static int group_step(Group& G, const sph_params* p, sph_step_stats* outs)
     rec(6);
     if (p->viscosity_type == SPH_VISC_XSPH)  // simulation.rs:2673-2676
         return c0->fail(SPH_ERR_XSPH_TODO, "not yet implemented (XSPH velocity smoothing)");
+
+    // ---- smooth_level_estimation_field + classify_particles (simulation.rs:2709-2722) --------------------------------------
+    if (level_on) {
+        const auto t_lvl0 = std::chrono::steady_clock::now();
+        Member& m = M[0];
+        sph_ctx* c = m.c;
+        if (m.n) {
+            launch_level_smooth(c->stream, &c->prof, m.a, lv, c->pm[c->pcur ^ 1].as<float4>(), c->lvl[c->cur].as<float>(), c->lvl_tmp.as<float>());
+            std::swap(c->lvl[c->cur], c->lvl_tmp);
+            launch_classify(c->stream, &c->prof, m.a, lv, c->lvl[c->cur].as<float>(), p);
+        }
+        if ((rc = sync_ctrl(G))) return rc;
+        m.st.ms_level_estimation += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_lvl0).count();
+    }
 
     for (size_t i = 0; i < M.size(); i++) {
         Member& m = M[i];

@@ -73,6 +73,7 @@ __device__ __forceinline__ void raise_error(DeviceStatus* st, uint32_t code, uin
 // Op interface:
 //   typedef Math;  Math m;                      math policy (sph_device.h)
 //   bool   skip()                               launch-uniform early exit (speculative Jacobi iterations)
+//   bool   lane_skip(i)                         particle i has nothing to do in this sweep (level-set propagation)
 //   float4 loadA(j)                             (x, y, m, h) of particle j
 //   NB     nb(acc, j, Aj)                       per-neighbour payload of particle j
 //   void   init(acc)                            lane-independent state (e.g. which pressure buffer is current)
@@ -80,6 +81,8 @@ __device__ __forceinline__ void raise_error(DeviceStatus* st, uint32_t code, uin
 //   void   pair(acc, Aj, NBj, dx, dy, r2, hij)  one accepted pair
 //   void   finish(acc, i, Ai, wall)             boundary terms (only if `wall`), outputs, guards
 //   void   epilogue(acc, active, blk)           optional block-level tail (HAS_EPILOGUE)
+//   float  krange()                             neighbour predicate |x_ij| < h_ij * krange(): 2 (SPH support), or the
+//                                               extended range of the level estimation (EXTENDED ops, own list arrays)
 //
 // Measured negatives (MI355X, N = 1M; DESIGN.md "What bounds the sweeps"): staging the wave's three row ranges
 // in LDS (random ds_read_b128 costs what the L1 gathers cost, and the LDS cuts occupancy: Jacobi 38.9 vs 28.5 us);
@@ -190,7 +193,7 @@ __device__ __forceinline__ void walk_row(const Op& op, typename Op::Acc& acc, co
         const float dx = Ai.x - AJ.x, dy = Ai.y - AJ.y;                                   \
         const float r2 = dx * dx + dy * dy;                                               \
         const float hij = Math::UNIFORM ? op.m.h : (Ai.w + AJ.w) * 0.5f;                  \
-        const float s = hij * 2.f;                                                        \
+        const float s = hij * op.krange();                                                \
         if ((VALID) && r2 < s * s) {                                                      \
             op.pair(acc, AJ, NJ, dx, dy, r2, hij);                                        \
             if (MASKS) {                                                                  \
@@ -223,7 +226,7 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_sweep(Op op, SweepCommon c)
     const uint32_t blk = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
     if (blk >= c.nblocks) return;
     const uint32_t i = blk * SWEEP_THREADS + threadIdx.x;
-    const bool active = i < c.n && (!c.owned || c.owned[i < c.n ? i : 0]);
+    const bool active = i < c.n && (!c.owned || c.owned[i < c.n ? i : 0]) && !op.lane_skip(i);
     const GridP g = c.g;
     typename Op::Acc acc;
     op.init(acc);  // lane-independent state
@@ -233,14 +236,16 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_sweep(Op op, SweepCommon c)
         uint4 lw = make_uint4(0, 0, 0, 0);
         if (!BUILD) lw = c.nl[i];
         op.begin(acc, i, Ai);
-        if (!BUILD && !Math::UNIFORM && (lw.w & NL_IDX)) {
+        // explicit index lists exist in multi-resolution scenes and for the extended-range lists of the level estimation
+        constexpr bool IDX = !Math::UNIFORM || Op::EXTENDED;
+        if (!BUILD && IDX && (lw.w & NL_IDX)) {
             replay_indices(op, acc, Ai, i, lw.w & 0xffffu, c.nlx, c.n);
         } else {
             // own cell (the same IEEE expression the sort key was computed from)
             const int cx = (int)floorf(Ai.x / g.cs) - g.minx;
             const int cy = (int)floorf(Ai.y / g.cs) - g.miny;
             const bool walk = BUILD || !(lw.w & NL_OK);
-            const int R = (Math::UNIFORM || !walk) ? 1 : stencil_radius(g, c.t, Ai.w, cx, cy);
+            const int R = (!IDX || !walk) ? 1 : stencil_radius(g, c.t, Ai.w, cx, cy, op.krange());
             if (R == 1) {
                 // 3 x 3 cells: three contiguous candidate ranges
                 uint32_t rb[3], re[3];
@@ -254,7 +259,7 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_sweep(Op op, SweepCommon c)
                     re[dr] = rb[dr];
                     if (walk) {
                         re[dr] = ok ? c.cell_start[base + (uint32_t)min(cx + 2, g.sx)] : rb[dr];
-                        ok_list = ok_list && (re[dr] - rb[dr]) <= 32u;
+                        ok_list = ok_list && !Op::EXTENDED && (re[dr] - rb[dr]) <= 32u;
                     }
                 }
                 if (!walk) {
@@ -270,7 +275,7 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_sweep(Op op, SweepCommon c)
                     uint32_t mk[3] = {0u, 0u, 0u}, nacc = 0;
                     IdxRecorder rec;
                     rec.cur = make_uint4(0, 0, 0, 0);
-                    const bool rec_idx = BUILD && !Math::UNIFORM && !ok_list;
+                    const bool rec_idx = BUILD && IDX && !ok_list;
                     if (rec_idx) {
 #pragma unroll
                         for (int dr = 0; dr < 3; dr++) walk_row<Op, false, true>(op, acc, Ai, rb[dr], re[dr], mk[dr], nacc, rec, c.nlx, c.n, i);
@@ -322,6 +327,8 @@ template <class MathT>
 struct OpDensity {
     typedef MathT Math;
     static constexpr bool HAS_EPILOGUE = false, SKIP_SELF = false;
+    static constexpr bool EXTENDED = false;
+    __device__ constexpr float krange() const { return 2.f; }
     typedef NBNone NB;
     MathT m;
     const float4* __restrict__ pm;
@@ -342,6 +349,7 @@ struct OpDensity {
         bool wall;
     };
     __device__ bool skip() const { return false; }
+    __device__ bool lane_skip(uint32_t) const { return false; }
     __device__ void init(Acc&) const {}
     __device__ void epilogue(Acc&, bool, uint32_t) const {}
     __device__ float4 loadA(uint32_t j) const { return pm[j]; }
@@ -425,6 +433,8 @@ template <class MathT>
 struct OpAiiConst {
     typedef MathT Math;
     static constexpr bool HAS_EPILOGUE = false, SKIP_SELF = false;   // W(0) != 0 in the constant field
+    static constexpr bool EXTENDED = false;
+    __device__ constexpr float krange() const { return 2.f; }
     typedef float NB;  // m_j / rho_j
     MathT m;
     const float4* __restrict__ pm;
@@ -441,6 +451,7 @@ struct OpAiiConst {
         float cf, ax, ay, a2, bx, by;
     };
     __device__ bool skip() const { return false; }
+    __device__ bool lane_skip(uint32_t) const { return false; }
     __device__ void init(Acc&) const {}
     __device__ void epilogue(Acc&, bool, uint32_t) const {}
     __device__ float4 loadA(uint32_t j) const { return pm[j]; }
@@ -505,6 +516,8 @@ template <class MathT>
 struct OpNonPressure {
     typedef MathT Math;
     static constexpr bool HAS_EPILOGUE = false, SKIP_SELF = true;
+    static constexpr bool EXTENDED = false;
+    __device__ constexpr float krange() const { return 2.f; }
     typedef NBRhoVel NB;
     MathT m;
     const float4* __restrict__ pm;
@@ -518,6 +531,7 @@ struct OpNonPressure {
         float vx, vy, rho_i, vix, viy;
     };
     __device__ bool skip() const { return false; }
+    __device__ bool lane_skip(uint32_t) const { return false; }
     __device__ void init(Acc&) const {}
     __device__ void epilogue(Acc&, bool, uint32_t) const {}
     __device__ float4 loadA(uint32_t j) const { return pm[j]; }
@@ -627,6 +641,8 @@ template <class MathT>
 struct OpSource {
     typedef MathT Math;
     static constexpr bool HAS_EPILOGUE = true, SKIP_SELF = true;
+    static constexpr bool EXTENDED = false;
+    __device__ constexpr float krange() const { return 2.f; }
     typedef NBVecMr NB;
     MathT m;
     const float4* __restrict__ pm;
@@ -651,6 +667,7 @@ struct OpSource {
         uint32_t cls;
     };
     __device__ bool skip() const { return false; }
+    __device__ bool lane_skip(uint32_t) const { return false; }
     __device__ void init(Acc&) const {}
     __device__ float4 loadA(uint32_t j) const { return pm[j]; }
     __device__ NB nb(const Acc&, uint32_t j, float4) const
@@ -754,6 +771,8 @@ template <class MathT>
 struct OpPressureAccel {
     typedef MathT Math;
     static constexpr bool HAS_EPILOGUE = false, SKIP_SELF = true;
+    static constexpr bool EXTENDED = false;
+    __device__ constexpr float krange() const { return 2.f; }
     typedef float NB;  // p_j / (rho_j * rho_j)
     MathT m;
     const float4* __restrict__ pm;
@@ -778,6 +797,7 @@ struct OpPressureAccel {
         const float* p;
     };
     __device__ bool skip() const { return iter >= 0 ? ctrl->done != 0u : ctrl->done == 0u; }
+    __device__ bool lane_skip(uint32_t) const { return false; }
     __device__ void epilogue(Acc&, bool, uint32_t) const {}
     __device__ float4 loadA(uint32_t j) const { return pm[j]; }
     __device__ NB nb(const Acc& a, uint32_t j, float4) const { return a.pt[j]; }
@@ -854,6 +874,8 @@ template <class MathT>
 struct OpJacobi {
     typedef MathT Math;
     static constexpr bool HAS_EPILOGUE = true, SKIP_SELF = true;
+    static constexpr bool EXTENDED = false;
+    __device__ constexpr float krange() const { return 2.f; }
     typedef NBVecMr NB;
     MathT m;
     const float4* __restrict__ pm;
@@ -880,6 +902,7 @@ struct OpJacobi {
         uint32_t cls;    // 0 normal, 1 singular, 2 negative (PressureSolverStatistics, simulation.rs:397-445)
     };
     __device__ bool skip() const { return ctrl->done != 0u; }
+    __device__ bool lane_skip(uint32_t) const { return false; }
     __device__ void init(Acc&) const {}
     __device__ float4 loadA(uint32_t j) const { return pm[j]; }
     __device__ NB nb(const Acc&, uint32_t j, float4) const
@@ -951,6 +974,317 @@ struct OpJacobi {
     }
     __device__ void epilogue(Acc& a, bool active, uint32_t blk) const { solver_block_partial(partials, active ? a.cls : 3u, a.err, blk); }
 };
+
+
+// ================================================================================================
+// Level estimation (distance-to-surface field of the adaptivity; simulation.rs:539-927).  It works on its own
+// neighbour lists of range k = level_estimation_range / ETA (use_extended_range_for_level_estimation; build_
+// neighborhood_list with that k, simulation.rs:2018-2046), built by OpLevelNormal and replayed by the others.
+// ================================================================================================
+#define LVL_UNASSIGNED 0xffffffffu   // OpLevelPropagate::when of a particle without a value
+
+// Op: surface detection, part 1 (surface_detection_by_empty_angle, simulation.rs:539-583): the "normal"
+//   n_i = - sum_j (m_i / rho_0) grad W_ij  and the cheap classifications.  state: 0 interior, 1 surface,
+//   2 decided by the cone test of part 2.
+template <class MathT>
+struct OpLevelNormal {
+    typedef MathT Math;
+    static constexpr bool HAS_EPILOGUE = false, SKIP_SELF = false, EXTENDED = true;
+    typedef NBNone NB;
+    MathT m;
+    const float4* __restrict__ pm;
+    float2* __restrict__ nrm;
+    uint8_t* __restrict__ state;
+    uint8_t* __restrict__ flag_insufficient;
+    const PlaneP* __restrict__ planes;
+    StepP sp;
+    float k;
+    int boundary_is_fluid_surface;
+    struct Acc {
+        float nx, ny, f;
+        uint32_t cnt;
+    };
+    __device__ float krange() const { return k; }
+    __device__ bool skip() const { return false; }
+    __device__ bool lane_skip(uint32_t) const { return false; }
+    __device__ void init(Acc&) const {}
+    __device__ void epilogue(Acc&, bool, uint32_t) const {}
+    __device__ float4 loadA(uint32_t j) const { return pm[j]; }
+    __device__ NB nb(const Acc&, uint32_t, float4) const { return NB{}; }
+    __device__ void begin(Acc& a, uint32_t, float4 Ai) const
+    {
+        a.nx = a.ny = 0.f;
+        a.cnt = 0;
+        a.f = Ai.z / sp.rest_density;
+    }
+    __device__ void pair(Acc& a, float4, NB, float dx, float dy, float r2, float hij) const
+    {
+        float gx, gy;
+        m.grad(dx, dy, r2, hij, gx, gy);
+        a.nx -= a.f * gx;
+        a.ny -= a.f * gy;
+        a.cnt++;
+    }
+    __device__ bool finish(Acc& a, uint32_t i, float4 Ai, bool) const
+    {
+        uint8_t st, insufficient = 0;
+        const float n2 = a.nx * a.nx + a.ny * a.ny;
+        if (a.cnt < 3u) {   // neighs.len() < 2 * D - 1
+            st = 1;
+            insufficient = 1;
+        } else if (n2 < 0.00001f) {
+            st = 0;
+        } else {
+            float dist = __uint_as_float(0x7f800000u);   // BoundaryHandler::distance_to_boundary (boundary_winchenbach2020.rs:320-325)
+            for (int q = 0; q < sp.n_planes; q++) dist = fminf(dist, (planes[q].dx * Ai.x + planes[q].dy * Ai.y) + planes[q].delta);
+            if (!boundary_is_fluid_surface && dist < Ai.w * 1.5f) {
+                st = 0;
+            } else {
+                st = 2;
+                const float nn = sqrtf(n2);
+                nrm[i] = make_float2(a.nx / nn, a.ny / nn);
+            }
+        }
+        state[i] = st;
+        flag_insufficient[i] = insufficient;
+        return false;
+    }
+};
+
+// Op: surface detection, part 2 (simulation.rs:584-625): a particle whose normal cone (50 degrees) contains no
+// neighbour is on the surface: level 0 (FluidSurface(0)), everything else NaN (FluidInterior).
+template <class MathT>
+struct OpLevelCone {
+    typedef MathT Math;
+    static constexpr bool HAS_EPILOGUE = false, SKIP_SELF = false, EXTENDED = true;
+    typedef NBNone NB;
+    MathT m;
+    const float4* __restrict__ pm;
+    const float2* __restrict__ nrm;
+    const uint8_t* __restrict__ state;
+    float* __restrict__ level;
+    uint32_t* __restrict__ when;   // propagation sweep that gave the particle its value: 0 surface, LVL_UNASSIGNED none yet
+    uint32_t* __restrict__ mark;
+    uint8_t* __restrict__ flag_surface;
+    float* __restrict__ stash;   // fill_stash_with == SurfaceDistanceFirst (simulation.rs:886-893), else nullptr
+    float k, threshold, max_surface_distance;
+    struct Acc {
+        float nx, ny;
+        uint32_t st;
+        bool hit;
+    };
+    __device__ float krange() const { return k; }
+    __device__ bool skip() const { return false; }
+    __device__ bool lane_skip(uint32_t) const { return false; }
+    __device__ void init(Acc&) const {}
+    __device__ void epilogue(Acc&, bool, uint32_t) const {}
+    __device__ float4 loadA(uint32_t j) const { return pm[j]; }
+    __device__ NB nb(const Acc&, uint32_t, float4) const { return NB{}; }
+    __device__ void begin(Acc& a, uint32_t i, float4) const
+    {
+        a.st = state[i];
+        a.hit = false;
+        a.nx = a.ny = 0.f;
+        if (a.st == 2u) {
+            const float2 n = nrm[i];
+            a.nx = n.x;
+            a.ny = n.y;
+        }
+    }
+    __device__ void pair(Acc& a, float4, NB, float dx, float dy, float r2, float) const
+    {
+        if (a.st != 2u) return;
+        // x_j - x_i = -(x_i - x_j) exactly; its norm_squared is r2
+        const float dn = sqrtf(r2) + 0.000001f;
+        const float ux = -dx / dn, uy = -dy / dn;
+        if (ux * a.nx + uy * a.ny > threshold) a.hit = true;
+    }
+    __device__ bool finish(Acc& a, uint32_t i, float4, bool) const
+    {
+        const bool interior = a.st == 0u || (a.st == 2u && a.hit);
+        const float v = interior ? __uint_as_float(0x7fc00000u) : 0.f;
+        level[i] = v;
+        when[i] = interior ? LVL_UNASSIGNED : 0u;
+        mark[i] = 0u;
+        flag_surface[i] = interior ? 0 : 1;
+        if (stash) stash[i] = interior ? -max_surface_distance : v;
+        return false;
+    }
+};
+
+// Op: one propagation sweep (propagate_level_set_from_surface_detection, simulation.rs:729-801): a particle without a
+// value takes max_j (level_j - |x_ij|) over the neighbours that had one when the sweep started; valued particles keep
+// theirs.  The reference re-evaluates every particle in every sweep (K ~ depth / range sweeps over N particles).  Here a
+// value is final once written, so `when[i]` (the sweep that wrote it) replaces the reference's double buffer -- sweep t
+// reads only neighbours with when < t -- and only the frontier works: a particle assigned in sweep t-1 marks its
+// unassigned neighbours for sweep t while it walks its list, everyone else leaves after two loads.  Same values, same
+// sweep count (a particle is assigned in the first sweep t in which a neighbour has when <= t-1, and then one of them
+// has when == t-1 and has marked it).  Sweep 0 only lets the surface particles mark their neighbours.
+struct NBLevel {
+    uint32_t w;
+    float lv;
+};
+template <class MathT>
+struct OpLevelPropagate {
+    typedef MathT Math;
+    static constexpr bool HAS_EPILOGUE = false, SKIP_SELF = false, EXTENDED = true;
+    typedef NBLevel NB;
+    MathT m;
+    const float4* __restrict__ pm;
+    float* __restrict__ level;
+    uint32_t* __restrict__ when;
+    uint32_t* __restrict__ mark;
+    uint32_t* __restrict__ changed;   // one word per sweep of the batch
+    float k;
+    uint32_t t;
+    struct Acc {
+        float best;
+        bool have;
+    };
+    __device__ float krange() const { return k; }
+    __device__ bool skip() const { return false; }
+    __device__ bool lane_skip(uint32_t i) const { return t == 0u ? when[i] != 0u : !(when[i] == LVL_UNASSIGNED && mark[i] == t); }
+    __device__ void init(Acc&) const {}
+    __device__ void epilogue(Acc&, bool, uint32_t) const {}
+    __device__ float4 loadA(uint32_t j) const { return pm[j]; }
+    __device__ NB nb(const Acc&, uint32_t j, float4) const
+    {
+        const uint32_t w = when[j];
+        // a candidate of sweep t is assigned in sweep t; its unassigned neighbours are the candidates of sweep t+1.  (In the
+        // candidate-walk fallback this also marks non-neighbours: they look, find nothing, and wait for a real mark.)
+        if (w == LVL_UNASSIGNED) mark[j] = t + 1u;
+        return NB{w, w < t ? level[j] : 0.f};
+    }
+    __device__ void begin(Acc& a, uint32_t, float4) const
+    {
+        a.best = 0.f;
+        a.have = false;
+    }
+    __device__ void pair(Acc& a, float4, NB Bj, float, float, float r2, float) const
+    {
+        if (!(Bj.w < t)) return;
+        const float est = Bj.lv - sqrtf(r2);
+        a.best = a.have ? fmaxf(a.best, est) : est;
+        a.have = true;
+    }
+    __device__ bool finish(Acc& a, uint32_t i, float4, bool) const
+    {
+        if (t > 0u && a.have) {
+            level[i] = a.best;
+            when[i] = t;
+            *changed = 1u;   // same value from every lane
+        }
+        return false;
+    }
+};
+
+// fill_stash_with (simulation.rs:886-893, 769-779): the level field as it stands, interior -> -maximum_surface_distance
+__global__ __launch_bounds__(256) void k_fill_stash(uint32_t n, const float* __restrict__ level, float* __restrict__ stash, float max_surface_distance)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float v = level[i];
+    stash[i] = isnan(v) ? -max_surface_distance : v;
+}
+
+// Op: smooth_level_estimation_field (simulation.rs:803-857): Shepard-normalised SPH average of the clamped field over
+// the k = 2 lists of the step, evaluated at the ADVECTED positions (the lists are those of the start of the step).
+struct NBSmooth {
+    float x, y, mr, dist;
+};
+template <class MathT>
+struct OpLevelSmooth {
+    typedef MathT Math;
+    static constexpr bool HAS_EPILOGUE = false, SKIP_SELF = false, EXTENDED = false;
+    typedef NBSmooth NB;
+    MathT m;
+    const float4* __restrict__ pm;       // positions the lists were built from (cell lookup, walk predicate)
+    const float4* __restrict__ pm_new;   // advected positions
+    const uint32_t* __restrict__ orig;
+    const float* __restrict__ mrho;
+    const float* __restrict__ level_in;
+    float* __restrict__ level_out;
+    float* __restrict__ level_old;
+    DeviceStatus* status;
+    float max_surface_distance;
+    struct Acc {
+        float x, y, level, weight;
+    };
+    __device__ constexpr float krange() const { return 2.f; }
+    __device__ bool skip() const { return false; }
+    __device__ bool lane_skip(uint32_t) const { return false; }
+    __device__ void init(Acc&) const {}
+    __device__ void epilogue(Acc&, bool, uint32_t) const {}
+    __device__ float4 loadA(uint32_t j) const { return pm[j]; }
+    __device__ NB nb(const Acc&, uint32_t j, float4) const
+    {
+        const float4 q = pm_new[j];
+        const float lj = level_in[j];
+        const float dist = isnan(lj) ? -max_surface_distance : fmaxf(lj, -max_surface_distance);
+        return NB{q.x, q.y, mrho[j], dist};
+    }
+    __device__ void begin(Acc& a, uint32_t i, float4) const
+    {
+        const float4 q = pm_new[i];
+        a.x = q.x;
+        a.y = q.y;
+        a.level = a.weight = 0.f;
+    }
+    __device__ void pair(Acc& a, float4, NB Bj, float, float, float, float hij) const
+    {
+        const float dx = a.x - Bj.x, dy = a.y - Bj.y;
+        const float w = m.w(dx * dx + dy * dy, hij);
+        a.level += Bj.dist * Bj.mr * w;
+        a.weight += Bj.mr * w;
+    }
+    __device__ bool finish(Acc& a, uint32_t i, float4, bool) const
+    {
+        if (!isfinite(a.weight) || a.weight <= 0.f) {
+            raise_error(status, SPH_ERR_LEVEL_WEIGHT, orig[i]);
+            return false;
+        }
+        const float v = a.level / a.weight;
+        if (!isfinite(v)) raise_error(status, SPH_ERR_LEVEL_WEIGHT, orig[i]);
+        level_old[i] = v;
+        level_out[i] = v;
+        return false;
+    }
+};
+
+// LevelEstimationState::target_mass + classify_particle (simulation.rs:213-237, adaptivity/mod.rs:32-59)
+__global__ __launch_bounds__(256) void k_classify(uint32_t n, const float4* __restrict__ pm, const float* __restrict__ level,
+                                                   uint8_t* __restrict__ size_class, float max_surface_distance, float rest_density,
+                                                   int sizing_function, float radius_fine, float radius_base)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float lv = level[i];
+    if (isnan(lv)) return;   // unreachable!() in the reference: every particle has a value after smoothing
+    const float lvl = fmaxf(lv, -max_surface_distance);
+    const float interp = lvl / -max_surface_distance;
+    // DimensionUtils2d::radius_to_sphere_volume (sph_kernels.rs:208-211): PI * r^2
+    const float mass_fine = (SPH_PI_F * radius_fine * radius_fine) * rest_density;
+    const float mass_base = (SPH_PI_F * radius_base * radius_base) * rest_density;
+    float target;
+    if (sizing_function == SPH_SIZING_MASS) {
+        target = mass_fine * (1.f - interp) + mass_base * interp;
+    } else if (sizing_function == SPH_SIZING_RADIUS) {
+        const float r = radius_fine * (1.f - interp) + radius_base * interp;
+        target = (SPH_PI_F * r * r) * rest_density;
+    } else {
+        const float e = 1.f / 2.f;
+        const float r = radius_fine * (1.f - powf(interp, e)) + radius_base * powf(interp, e);
+        target = (SPH_PI_F * r * r) * rest_density;
+    }
+    const float mrel = pm[i].z / target;
+    uint8_t cls;
+    if (mrel <= 0.5f) cls = 0;
+    else if (mrel <= 1.f / 1.1f) cls = 1;
+    else if (mrel < 1.1f) cls = 2;
+    else if (mrel < 2.0f) cls = 3;
+    else cls = 4;
+    size_class[i] = cls;
+}
 
 // ------------------------------------------------------------------------------------------------
 // residual reduction + stop decision    (PressureSolverStatistics simulation.rs:397-469,
@@ -1114,9 +1448,9 @@ __global__ __launch_bounds__(256) void k_integrate(uint32_t n, float dt, float v
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
-static SweepCommon common_of(const SweepArgs& a)
+static SweepCommon common_of(const SweepArgs& a, bool ext)
 {
-    return SweepCommon{a.g, a.t, a.n, (a.n + SWEEP_THREADS - 1) / SWEEP_THREADS, a.cell_start, a.nl, a.nlx, a.owned};
+    return SweepCommon{a.g, a.t, a.n, (a.n + SWEEP_THREADS - 1) / SWEEP_THREADS, a.cell_start, ext ? a.nl_ext : a.nl, ext ? a.nlx_ext : a.nlx, a.owned};
 }
 
 template <class Op, bool BUILD>
@@ -1125,7 +1459,7 @@ static void launch_sweep(hipStream_t s, const SweepArgs& a, const Op& op)
     if (a.n == 0) return;
     const uint32_t nblocks = (a.n + SWEEP_THREADS - 1) / SWEEP_THREADS;
     const uint32_t grid = ((nblocks + 7) / 8) * 8;  // XCD remap needs a multiple of 8
-    hipLaunchKernelGGL((k_sweep<Op, BUILD>), dim3(grid), dim3(SWEEP_THREADS), 0, s, op, common_of(a));
+    hipLaunchKernelGGL((k_sweep<Op, BUILD>), dim3(grid), dim3(SWEEP_THREADS), 0, s, op, common_of(a, Op::EXTENDED));
 }
 
 size_t sweep_list_bytes(uint32_t n) { return (size_t)n * sizeof(uint4); }
@@ -1230,4 +1564,43 @@ void launch_integrate(hipStream_t s, Profiler* prof, const SweepArgs& a, float4*
     ProfScope ps(prof, "integrate", s);
     hipLaunchKernelGGL(k_integrate, dim3((a.n + 255) / 256), dim3(256), 0, s, a.n, a.sp.dt, a.sp.hyb_vfactor, mode, a.pm, pm_out, a.vel, a.pacc,
                        a.orig, a.status);
+}
+
+// ---- level estimation (simulation.rs:862-927, 803-857; adaptivity/mod.rs:32-59) ---------------------------------
+void launch_level_detect(hipStream_t s, Profiler* prof, const SweepArgs& a, const LevelArgs& l)
+{
+    {
+        ProfScope ps(prof, "level_normal", s);
+        SPH_DISPATCH(OpLevelNormal, true, a.pm, l.nrm, l.state, l.flag_insufficient, a.planes, a.sp, l.k, l.boundary_is_fluid_surface)
+    }
+    {
+        ProfScope ps(prof, "level_cone", s);
+        SPH_DISPATCH(OpLevelCone, false, a.pm, l.nrm, l.state, l.level, l.when, l.mark, l.flag_surface, l.stash_first, l.k, l.threshold, l.max_surface_distance)
+    }
+}
+
+void launch_level_propagate(hipStream_t s, Profiler* prof, const SweepArgs& a, const LevelArgs& l, uint32_t t, uint32_t* changed)
+{
+    ProfScope ps(prof, "level_propagate", s);
+    SPH_DISPATCH(OpLevelPropagate, false, a.pm, l.level, l.when, l.mark, changed, l.k, t)
+}
+
+void launch_fill_stash(hipStream_t s, Profiler* prof, const SweepArgs& a, const LevelArgs& l, float* stash)
+{
+    ProfScope ps(prof, "level_stash", s);
+    if (a.n) hipLaunchKernelGGL(k_fill_stash, dim3((a.n + 255) / 256), dim3(256), 0, s, a.n, l.level, stash, l.max_surface_distance);
+}
+
+void launch_level_smooth(hipStream_t s, Profiler* prof, const SweepArgs& a, const LevelArgs& l, const float4* pm_new, const float* in, float* out)
+{
+    ProfScope ps(prof, "level_smooth", s);
+    SPH_DISPATCH(OpLevelSmooth, false, a.pm, pm_new, a.orig, a.mrho, in, out, l.level_old, a.status, l.max_surface_distance)
+}
+
+void launch_classify(hipStream_t s, Profiler* prof, const SweepArgs& a, const LevelArgs& l, const float* level, const sph_params* p)
+{
+    ProfScope ps(prof, "classify", s);
+    if (a.n)
+        hipLaunchKernelGGL(k_classify, dim3((a.n + 255) / 256), dim3(256), 0, s, a.n, a.pm, level, l.size_class, p->maximum_surface_distance,
+                           p->rest_density, p->sizing_function, p->particle_radius_fine, p->particle_radius_base);
 }

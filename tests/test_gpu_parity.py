@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 
 from adaptive_sph_amd import ffi, scene as sc
-from adaptive_sph_amd.workloads import dam_break_params
+from adaptive_sph_amd.workloads import dam_break_params, default_params
 from tests.oracle_harness import csr_sets
 
 pytestmark = pytest.mark.gpu
@@ -163,6 +163,54 @@ def test_multi_resolution_stencils_and_index_lists(product_lib, oracle_lib, rati
     tol = dict(TOL, velocity=1e-3) if ratio == 12 else TOL
     for f in ALL_FIELDS:
         assert rel_err(g.download(f), o.download(f)) < tol.get(f, REL_TOL_FIELDS), f
+
+
+def _level_fields_match(g, o):
+    """Level-estimation outputs after a step: flags/classes identical, distances within tolerance."""
+    sg, so = g.download("flag_is_fluid_surface"), o.download("flag_is_fluid_surface")
+    assert 0 < so.sum() < len(so)
+    assert np.array_equal(sg, so), f"{(sg != so).sum()} surface flags differ"
+    assert np.array_equal(g.download("flag_insufficient_neighs"), o.download("flag_insufficient_neighs"))
+    for f in ["level_estimation", "level_old", "stash"]:
+        a, b = g.download(f), o.download(f)
+        assert np.array_equal(np.isnan(a), np.isnan(b)), f
+        scale = max(float(np.nanmax(np.abs(b))), 1e-30)
+        assert float(np.nanmax(np.abs(a - b))) / scale < REL_TOL_FIELDS, f
+    cg, co = g.download("particle_size_class"), o.download("particle_size_class")
+    assert (cg != co).mean() < 1e-3      # a class boundary sits on a float comparison of the smoothed distance
+
+
+@pytest.mark.parametrize("stash", [None, "SurfaceDistanceFirstIteration", "SurfaceDistanceMiddle"])
+def test_level_estimation_uniform_block(product_lib, oracle_lib, stash):
+    """EmptyAngle surface detection -> level-set propagation -> smoothing -> size classes (simulation.rs:539-927,
+    adaptivity/mod.rs:32-59) on a uniform dam-break: many propagation sweeps (block depth / range)."""
+    g, o = make_pair(product_lib, oracle_lib, sc.dam_break_small(48, 40, 1 / 48))
+    P = dam_break_params(level_estimation_method="EmptyAngle", maximum_surface_distance=0.2, particle_radius_fine=0.004,
+                         particle_radius_base=0.02)
+    P.fill_stash_with = stash     # an Option without a key in default-config.yaml
+    p = P.to_ffi()
+    for s in range(3):
+        sg, so = g.step(p), o.step(p)
+        assert sg.dt == so.dt
+        _level_fields_match(g, o)
+    for f in ALL_FIELDS:
+        assert rel_err(g.download(f), o.download(f)) < TOL.get(f, REL_TOL_FIELDS), f
+
+
+def test_level_estimation_default_config_scene(product_lib, oracle_lib):
+    """BASELINE configs[0]: default-config.yaml + default-scene.yaml (two particle sizes, EmptyAngle, extended range 5.5,
+    HybridDFSPH) -- the plumbing case, on the device."""
+    scn = sc.SceneConfig.from_yaml(str(Path(__file__).resolve().parent / "golden" / "default-scene.yaml"))
+    g, o = make_pair(product_lib, oracle_lib, scn)
+    assert g.n == 1035
+    p = default_params(merging=False, sharing=False, splitting=False).to_ffi()
+    for s in range(4):
+        sg, so = g.step(p), o.step(p)
+        assert abs(sg.dt - so.dt) <= 1e-5 * so.dt
+        _level_fields_match(g, o)
+    assert_same_neighbor_sets(g, o)
+    for f in ALL_FIELDS:
+        assert rel_err(g.download(f), o.download(f)) < TOL.get(f, REL_TOL_FIELDS), f
 
 
 def test_free_running_iteration_counts(product_lib, oracle_lib):
