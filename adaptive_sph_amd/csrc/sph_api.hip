@@ -28,7 +28,7 @@ int Profiler::find(const char* name)
 {
     for (size_t i = 0; i < recs.size(); i++)
         if (recs[i].name == name) return (int)i;
-    recs.push_back(Rec{name, 0, 0});
+    recs.push_back(Rec{name, 0, 0, {}});
     return (int)recs.size() - 1;
 }
 bool Profiler::wants(const char* name) const
@@ -68,6 +68,7 @@ void Profiler::collect()
         if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
             recs[p.rec].launches++;
             recs[p.rec].total_ms += ms;
+            recs[p.rec].samples.push_back(ms);
         }
         pool.push_back(p.a);
         pool.push_back(p.b);
@@ -600,10 +601,48 @@ extern "C" int sph_profile_get(sph_ctx* c, sph_kernel_time* out, int capacity, i
             strncpy(out[k].name, r.name.c_str(), sizeof(out[k].name) - 1);
             out[k].launches = r.launches;
             out[k].total_ms = r.total_ms;
+            float mx = 0.f;
+            for (float v : r.samples) mx = v > mx ? v : mx;
+            for (float v : r.samples)
+                if (v > 0.25f * mx) {
+                    out[k].working_launches++;
+                    out[k].working_ms += v;
+                }
         }
         k++;
     }
     *n_out = k < capacity ? k : capacity;
+    return SPH_OK;
+}
+
+__global__ void k_empty() {}
+
+extern "C" int sph_profile_event_overhead(sph_ctx* c, double* microseconds)
+{
+    if (!c || !microseconds) return SPH_ERR_INVALID_ARGUMENT;
+    HIPCHK(c, hipSetDevice(c->device));
+    // event pair around ONE empty kernel: T1 = o + e ; around TWO: T2 = o + 2 e  =>  o = 2 T1 - T2 is what the pair itself
+    // adds (e = an empty kernel's own dispatch + execution, which a real kernel's duration already contains)
+    const int reps = 200;
+    std::vector<hipEvent_t> ev(2 * reps);
+    for (auto& e : ev) HIPCHK(c, hipEventCreate(&e));
+    double t[2] = {0, 0};
+    for (int nk = 1; nk <= 2; nk++) {
+        for (int k = 0; k < reps; k++) {
+            HIPCHK(c, hipEventRecord(ev[2 * k], c->stream));
+            for (int q = 0; q < nk; q++) hipLaunchKernelGGL(k_empty, dim3(1), dim3(64), 0, c->stream);
+            HIPCHK(c, hipEventRecord(ev[2 * k + 1], c->stream));
+        }
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        for (int k = 0; k < reps; k++) {
+            float ms = 0.f;
+            HIPCHK(c, hipEventElapsedTime(&ms, ev[2 * k], ev[2 * k + 1]));
+            t[nk - 1] += ms;
+        }
+    }
+    for (auto& e : ev) (void)hipEventDestroy(e);
+    const double o = (2.0 * t[0] - t[1]) / reps * 1e3;
+    *microseconds = o > 0 ? o : 0;
     return SPH_OK;
 }
 

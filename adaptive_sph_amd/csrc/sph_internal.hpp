@@ -18,6 +18,7 @@ struct Profiler {
         std::string name;
         uint64_t launches = 0;
         double total_ms = 0;
+        std::vector<float> samples;   // per-launch ms
     };
     struct Pending {
         int rec;

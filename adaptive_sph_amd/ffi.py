@@ -100,7 +100,8 @@ class SphGridInfo(C.Structure):
 
 
 class SphKernelTime(C.Structure):
-    _fields_ = [("name", C.c_char * 48), ("launches", C.c_uint64), ("total_ms", C.c_double)]
+    _fields_ = [("name", C.c_char * 48), ("launches", C.c_uint64), ("total_ms", C.c_double),
+                ("working_launches", C.c_uint64), ("working_ms", C.c_double)]
 
 
 class SphError(RuntimeError):
@@ -114,7 +115,7 @@ class SphError(RuntimeError):
 # every symbol include/sph_ffi.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
     "create", "destroy", "upload", "upload_field", "download", "download_neighbors", "num_particles", "time",
-    "set_time", "step", "last_error", "grid", "profile_enable", "profile_reset", "profile_get",
+    "set_time", "step", "last_error", "grid", "profile_enable", "profile_reset", "profile_get", "profile_event_overhead",
     "dist_configure", "comm_unique_id", "comm_init", "group_step",
 ]
 
@@ -160,6 +161,7 @@ class SphLibrary:
         self.profile_enable = sig("profile_enable", i32, [vp, i32], required=False)
         self.profile_reset = sig("profile_reset", i32, [vp], required=False)
         self.profile_get = sig("profile_get", i32, [vp, C.POINTER(SphKernelTime), i32, C.POINTER(i32)], required=False)
+        self.profile_event_overhead = sig("profile_event_overhead", i32, [vp, C.POINTER(C.c_double)], required=False)
         self.comm_unique_id = sig("comm_unique_id", i32, [C.POINTER(C.c_uint8)], required=False)
         self.comm_init = sig("comm_init", i32, [vp, C.POINTER(C.c_uint8), i32, i32], required=False)
         self.dist_configure = sig("dist_configure", i32, [vp, i32, i32, C.c_float, C.c_float], required=False)
@@ -287,6 +289,19 @@ class Context:
         n = C.c_int(0)
         self._check(self.lib.profile_get(self.handle, arr, cap, C.byref(n)))
         return {arr[i].name.decode(): (int(arr[i].launches), float(arr[i].total_ms)) for i in range(n.value)}
+
+    def profile_get_working(self) -> dict:
+        """name -> (launches that did work, their total ms): speculative launches behind a stop decision excluded."""
+        cap = 64
+        arr = (SphKernelTime * cap)()
+        n = C.c_int(0)
+        self._check(self.lib.profile_get(self.handle, arr, cap, C.byref(n)))
+        return {arr[i].name.decode(): (int(arr[i].working_launches), float(arr[i].working_ms)) for i in range(n.value)}
+
+    def profile_event_overhead_us(self) -> float:
+        v = C.c_double(0.0)
+        self._check(self.lib.profile_event_overhead(self.handle, C.byref(v)))
+        return float(v.value)
 
     def dist_configure(self, rank: int, n_ranks: int, cut_lo: float, cut_hi: float):
         self._check(self.lib.dist_configure(self.handle, int(rank), int(n_ranks), float(cut_lo), float(cut_hi)))

@@ -67,7 +67,30 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--profile-steps", type=int, default=20)
+    ap.add_argument("--no-extra", action="store_true", help="skip the short runs of the other single-GPU BASELINE configs")
     return ap.parse_args()
+
+
+def short_run(plib, name, steps=40, warmup=10, **param_overrides):
+    """A short untimed-warm-up + timed run of another BASELINE config on the same GPU (reported under "other_configs";
+    never part of `value`)."""
+    from adaptive_sph_amd import ffi, scene as sc
+    from adaptive_sph_amd.workloads import WORKLOADS
+    scene_f, params_f, desc = WORKLOADS[name]
+    scn, P = scene_f(), params_f(**param_overrides)
+    pos, mass, vel = sc.init_particles(scn)
+    ctx = ffi.Context(plib, len(mass), sc.boundary_planes(scn.boundary))
+    ctx.upload(mass, pos, vel)
+    p = P.to_ffi()
+    for _ in range(warmup):
+        ctx.step(p)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ctx.step(p)
+    dt = time.perf_counter() - t0
+    ctx.close()
+    return {"workload": f"{name}: {desc}", "overrides": param_overrides, "particles": len(mass), "steps": steps, "warmup": warmup,
+            "ms_per_step": dt * 1e3 / steps, "particle_steps_per_s": len(mass) * steps / dt}
 
 
 def cpu_baseline(scene, params, budget_s: float):
@@ -165,13 +188,15 @@ def main():
     n_local = ctx.n
 
     # ---- instrumented pass: HIP events around every kernel on the library's own stream
-    prof_all = {}
+    prof_all, prof_work, ev_overhead_us = {}, {}, 0.0
     if args.profile_steps > 0:
         ctx.profile_reset()
         ctx.profile_enable(1)
         for _ in range(args.profile_steps):
             ctx.step(p)
         prof_all = ctx.profile_get()
+        prof_work = ctx.profile_get_working()     # without the speculative launches that return at once
+        ev_overhead_us = ctx.profile_event_overhead_us()
         ctx.profile_enable(0)
 
     if rank != 0:
@@ -181,30 +206,35 @@ def main():
         return
 
     def roof(name, launches, total_ms):
+        """Launch duration = HIP-event time of the launches that did work, minus what the event pair itself adds
+        (measured live with empty kernels): the quantity rocprofv3 reports as the kernel's duration."""
         if not launches or name not in ALGO_BYTES:
             return None
-        avg_s = total_ms * 1e-3 / launches
+        raw_us = total_ms * 1e3 / launches
+        avg_s = max(raw_us - ev_overhead_us, 1e-3) * 1e-6
         achieved = ALGO_BYTES[name] * n_local / avg_s / 1e9
         traffic, src = committed_pmc_traffic(name) if wl == "dam_break_1m" and not distributed else (None, None)
         return {"kernel": name, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src, "avg_us": avg_s * 1e6,
+                "avg_us_hip_events": raw_us, "event_overhead_us": ev_overhead_us, "launches_timed": launches,
                 "algorithmic_bytes_per_particle": ALGO_BYTES[name], "algorithmic_bytes_per_launch": ALGO_BYTES[name] * n_local}
 
     total_prof_ms = sum(v[1] for v in prof_all.values()) or 1.0
     kernels = []
     for name, (launches, total_ms) in sorted(prof_all.items(), key=lambda kv: -kv[1][1]):
-        k = {"name": name, "launches_per_step": launches / max(args.profile_steps, 1), "avg_us": total_ms * 1e3 / max(launches, 1),
+        k = {"name": name, "launches_per_step": launches / max(args.profile_steps, 1), "avg_us_hip_events": total_ms * 1e3 / max(launches, 1),
              "time_share": total_ms / total_prof_ms}
-        r = roof(name, launches, total_ms)
+        r = roof(name, *prof_work.get(name, (launches, total_ms)))
         if r:
             k["achieved_GBs"] = r["achieved"]
             k["frac_hbm_peak"] = r["frac"]
         kernels.append(k)
     dominant = next((k["name"] for k in kernels if k["name"] in ALGO_BYTES), None)
-    roofline = roof(dominant, *prof_all[dominant]) if dominant else None
-    roofline_density = roof("density", *prof_all["density"]) if "density" in prof_all else None
+    roofline = roof(dominant, *prof_work[dominant]) if dominant else None
+    roofline_density = roof("density", *prof_work["density"]) if "density" in prof_work else None
     timing_note = (f"HIP events on the library's stream, instrumented pass of {args.profile_steps} steps continuing the same "
-                   f"workload right after the timed region (events perturb dispatch, so the timed region is uninstrumented)")
+                   f"workload right after the timed region (events perturb dispatch, so the timed region is uninstrumented); "
+                   f"avg_us = event time of the working launches - what an event pair adds (sph_profile_event_overhead)")
     for r in (roofline, roofline_density):
         if r:
             r["timing"] = timing_note
@@ -227,6 +257,14 @@ def main():
         "roofline_density": roofline_density,
         "kernels": kernels,
     }
+    if not args.no_extra and not distributed and wl == "dam_break_1m":
+        ctx.close()
+        out["other_configs"] = [
+            short_run(plib, "dam_break_1m_adaptive"),                                       # configs[2]: 4:1 radius ratio
+            short_run(plib, "dam_break_8m", steps=20, warmup=10),                            # configs[3] on ONE GPU
+            short_run(plib, "dam_break_1m", steps=5, warmup=2, level_estimation_method="EmptyAngle",
+                      maximum_surface_distance=0.2, particle_radius_fine=0.0005, particle_radius_base=0.002),   # + level estimation
+        ]
     if not args.no_cpu_baseline and not distributed:
         out["cpu_baseline"] = cpu_baseline(scene, params, args.cpu_seconds)
     print(json.dumps(out))

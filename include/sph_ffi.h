@@ -242,10 +242,16 @@ typedef struct sph_kernel_time {
     char     name[48];
     uint64_t launches;
     double   total_ms;           /* HIP-event time on the context's stream */
+    uint64_t working_launches;   /* launches longer than a quarter of the longest one: a speculatively queued Jacobi
+                                  * iteration behind the stop decision returns at once and is not a sweep */
+    double   working_ms;
 } sph_kernel_time;
 int  sph_profile_enable(sph_ctx* ctx, int enable);
 int  sph_profile_reset(sph_ctx* ctx);
 int  sph_profile_get(sph_ctx* ctx, sph_kernel_time* out, int capacity, int* n_out);
+/* what a HIP-event pair adds to the duration of the kernel it brackets (microseconds), measured with empty kernels:
+ * 2 x (pair around one) - (pair around two).  bench.py subtracts it to compare with rocprofv3's kernel durations. */
+int  sph_profile_event_overhead(sph_ctx* ctx, double* microseconds);
 
 /* ---- multi-GPU: 1-D slab decomposition along x, one process (= one context) per GPU --------
  * (the reference has no counterpart: its only parallelism is rayon inside one process, concurrency.rs:110-204)

@@ -36,7 +36,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(ffi.SphSolverStats) == 28
     assert C.sizeof(ffi.SphStepStats) == 8 + 8 + 8 + 28 + 28 + 5 * 8
     assert C.sizeof(ffi.SphGridInfo) == 20
-    assert C.sizeof(ffi.SphKernelTime) == 64
+    assert C.sizeof(ffi.SphKernelTime) == 80
 
 
 def test_no_gpu_create_fails_loudly(product_lib, gpu_available):
