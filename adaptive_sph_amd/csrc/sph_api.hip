@@ -98,14 +98,21 @@ Profiler::~Profiler()
 // neighborhood_search.rs:261-275), h_max/h_min, CFL term min_i (2h_i)^2 / (|v_i|^2 + 0.01)
 // (simulation.rs:2182-2189)
 __global__ __launch_bounds__(256) void k_header(float4* __restrict__ pm, const float2* __restrict__ vel, uint32_t n, float rest_density,
-                                                 int from_mass, HeaderOut* __restrict__ partials)
+                                                 int from_mass, float* __restrict__ h2_next, HeaderOut* __restrict__ partials)
 {
     const float INF = __uint_as_float(0x7f800000u);
     float mnx = INF, mny = INF, mxx = -INF, mxy = -INF, hmx = 0.f, hmn = INF, cfl = INF;
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
         float4 p = pm[i];
-        if (from_mass) {
+        if (from_mass == 1) {
             p.w = h_from_mass(p.z, rest_density);
+            pm[i] = p;
+        } else if (from_mass == 2) {
+            // FromDistribution*: "only apply the support length that was estimated in the last step": mem::swap(h2, h2_next)
+            // (simulation.rs:2004-2014)
+            const float t = p.w;
+            p.w = h2_next[i];
+            h2_next[i] = t;
             pm[i] = p;
         }
         float2 v = vel[i];
@@ -159,12 +166,14 @@ __global__ __launch_bounds__(256) void k_header_final(const HeaderOut* __restric
 
 __global__ __launch_bounds__(256) void k_pack_upload(uint32_t n, const float* __restrict__ mass, const float2* __restrict__ pos,
                                                       const float2* __restrict__ velin, float4* __restrict__ pm, float2* __restrict__ vel,
-                                                      uint32_t* __restrict__ orig, float* __restrict__ lvl, float* __restrict__ lvlold)
+                                                      uint32_t* __restrict__ orig, float* __restrict__ lvl, float* __restrict__ lvlold,
+                                                      float* __restrict__ h2_next)
 {
     uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     float2 p = pos[i];
     pm[i] = make_float4(p.x, p.y, mass[i], 0.f);
+    h2_next[i] = h_from_mass(mass[i], 1.f);   // FluidSimulation::new: h_init with INIT_REST_DENSITY (simulation.rs:505-520, 344)
     vel[i] = velin[i];
     orig[i] = i;
     lvl[i] = __uint_as_float(0x7fc00000u);  // LevelEstimationState::FluidInterior
@@ -289,6 +298,7 @@ static int alloc_particle_buffers(sph_ctx* c)
         HIPCHK(c, c->orig[k].ensure(n * sizeof(uint32_t)));
         HIPCHK(c, c->lvl[k].ensure(n * sizeof(float)));
         HIPCHK(c, c->lvlold[k].ensure(n * sizeof(float)));
+        HIPCHK(c, c->h2n[k].ensure(n * sizeof(float)));
         HIPCHK(c, c->key[k].ensure(n * sizeof(uint32_t)));
         HIPCHK(c, c->val[k].ensure(n * sizeof(uint32_t)));
     }
@@ -299,6 +309,7 @@ static int alloc_particle_buffers(sph_ctx* c)
                     &c->mrho, &c->pt0, &c->pt1};
     for (auto b : f1) HIPCHK(c, b->ensure(n * sizeof(float)));
     HIPCHK(c, c->lam_grad.ensure(n * sizeof(float2)));
+    HIPCHK(c, c->lam_prev.ensure(n * sizeof(float)));
     HIPCHK(c, c->pacc.ensure(n * sizeof(float2)));
     HIPCHK(c, c->scratch.ensure(n * sizeof(float4)));
     HIPCHK(c, c->nl.ensure(sweep_list_bytes((uint32_t)n)));
@@ -365,7 +376,7 @@ extern "C" void sph_destroy(sph_ctx* c)
     dist_release(c);
     DevBuf* all[] = {&c->pm[0], &c->pm[1], &c->vel[0], &c->vel[1], &c->orig[0], &c->orig[1], &c->lvl[0], &c->lvl[1], &c->lvlold[0],
                      &c->lvlold[1], &c->vel_tmp, &c->key[0], &c->key[1], &c->val[0], &c->val[1], &c->sort_scratch, &c->cxy, &c->cell_start,
-                     &c->cs_scratch, &c->nl, &c->nlx, &c->tile_raw, &c->tile_h, &c->lvl_tmp, &c->lvl_nrm, &c->lvl_state, &c->lvl_when, &c->lvl_mark, &c->flag_surface,
+                     &c->cs_scratch, &c->h2n[0], &c->h2n[1], &c->lam_prev, &c->nl, &c->nlx, &c->tile_raw, &c->tile_h, &c->lvl_tmp, &c->lvl_nrm, &c->lvl_state, &c->lvl_when, &c->lvl_mark, &c->flag_surface,
                      &c->flag_insufficient, &c->size_class, &c->stash, &c->nl_ext, &c->nlx_ext, &c->nl_ok, &c->mrho, &c->pt0, &c->pt1, &c->rho, &c->lam_sum, &c->lam_grad, &c->constf, &c->aii, &c->src, &c->p0, &c->p1, &c->pacc, &c->dens_err,
                      &c->stat, &c->ncount, &c->planes_d, &c->lam_lut, &c->dlam_lut, &c->hdr_partials, &c->hdr_out, &c->ctrl, &c->status,
                      &c->n_tiles, &c->red_partials, &c->scratch};
@@ -412,7 +423,7 @@ extern "C" int sph_upload(sph_ctx* c, uint64_t n, const float* mass, const float
     HIPCHK(c, hipMemcpyAsync(c->vel_tmp.p, vel, n * sizeof(float2), hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(k_pack_upload, dim3((n + 255) / 256), dim3(256), 0, s, (uint32_t)n, c->key[1].as<float>(), c->scratch.as<float2>(),
                        c->vel_tmp.as<float2>(), c->pm[0].as<float4>(), c->vel[0].as<float2>(), c->orig[0].as<uint32_t>(),
-                       c->lvl[0].as<float>(), c->lvlold[0].as<float>());
+                       c->lvl[0].as<float>(), c->lvlold[0].as<float>(), c->h2n[0].as<float>());
     DevBuf* zero[] = {&c->rho, &c->lam_sum, &c->constf, &c->aii, &c->src, &c->p0, &c->p1, &c->dens_err, &c->ncount};
     for (auto b : zero) HIPCHK(c, hipMemsetAsync(b->p, 0, n * sizeof(float), s));
     HIPCHK(c, hipMemsetAsync(c->lam_grad.p, 0, n * sizeof(float2), s));
@@ -443,7 +454,7 @@ static bool field_ref(sph_ctx* c, int field, FieldRef* r)
     case SPH_F_AII: *r = {G_F32, c->aii.p, 4, false}; return true;
     case SPH_F_DENSITY_ERROR: *r = {G_F32, c->dens_err.p, 4, false}; return true;
     case SPH_F_H2: *r = {G_PM_H, c->pm[c->pcur].p, 4, true}; return true;
-    case SPH_F_H2_NEXT: *r = {G_H2NEXT, c->pm[c->pcur].p, 4, false}; return true;
+    case SPH_F_H2_NEXT: *r = {G_F32, c->h2n[k].p, 4, true}; return true;
     case SPH_F_CONSTANT_FIELD: *r = {G_F32, c->constf.p, 4, false}; return true;
     case SPH_F_NEIGHBOR_COUNT: *r = {G_U32, c->ncount.p, 4, false}; return true;
     case SPH_F_LEVEL_ESTIMATION: *r = {G_F32, c->lvl[k].p, 4, true}; return true;
@@ -688,7 +699,7 @@ extern "C" int sph_download_neighbors(sph_ctx* c, uint32_t* offsets, uint32_t* i
 // ------------------------------------------------------------------------------------------------
 // launch wrappers used by the step driver (sph_step.hip)
 // ------------------------------------------------------------------------------------------------
-void launch_header(sph_ctx* c, uint32_t n, float rest_density, int from_mass, HeaderOut* out_dev)
+void launch_header(sph_ctx* c, uint32_t n, float rest_density, int from_mass /* 0 keep h, 1 from mass, 2 swap with h2_next */, HeaderOut* out_dev)
 {
     hipStream_t s = c->stream;
     ProfScope ps(&c->prof, "header", s);
@@ -696,7 +707,7 @@ void launch_header(sph_ctx* c, uint32_t n, float rest_density, int from_mass, He
     if (nb > HDR_BLOCKS) nb = HDR_BLOCKS;
     if (nb < 1) nb = 1;
     hipLaunchKernelGGL(k_header, dim3(nb), dim3(256), 0, s, c->pm[c->pcur].as<float4>(), c->vel[c->cur].as<float2>(), n, rest_density, from_mass,
-                       c->hdr_partials.as<HeaderOut>());
+                       c->h2n[c->cur].as<float>(), c->hdr_partials.as<HeaderOut>());
     hipLaunchKernelGGL(k_header_final, dim3(1), dim3(256), 0, s, c->hdr_partials.as<HeaderOut>(), nb, out_dev);
 }
 

@@ -90,6 +90,8 @@ struct sph_ctx {
     GridP fgrid{};          // the grid the particles are sorted by (== grid in uniform scenes)
     int tile_ts = 0, tile_tsx = 0, tile_tsy = 0;
     DevBuf tile_raw, tile_h, nlx;
+    DevBuf h2n[2];     // ParticleVec::h2_next (FromDistribution* support-length estimation), ping-pong across the reorder
+    DevBuf lam_prev;   // lambda_sum of the previous step in this step's order (estimate_h_next_from_distribution)
     // level estimation (simulation.rs:539-927), sorted order
     DevBuf lvl_tmp, lvl_nrm, lvl_state, lvl_when, lvl_mark, flag_surface, flag_insufficient, size_class, stash, nl_ext, nlx_ext;
     bool have_level = false;            // the level-estimation outputs above are those of the last step

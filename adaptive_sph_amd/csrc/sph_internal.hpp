@@ -88,7 +88,8 @@ void launch_cell_keys(hipStream_t s, Profiler* prof, const float4* pm, uint32_t 
 void launch_reorder(hipStream_t s, Profiler* prof, uint32_t n, GridP g, const uint32_t* sorted_key, const uint32_t* perm,
                     const float4* pm_in, const float2* vel_in, const uint32_t* orig_in, const float* lvl_in,
                     const float* lvlold_in, float4* pm_out, float2* vel_out, uint32_t* orig_out, float* lvl_out,
-                    float* lvlold_out, uint32_t* cxy);
+                    float* lvlold_out, uint32_t* cxy, const float* h2n_in = nullptr, float* h2n_out = nullptr,
+                    const float* lam_in = nullptr, float* lam_prev_out = nullptr);
 size_t cell_start_scratch_bytes();
 void launch_cell_start(hipStream_t s, Profiler* prof, const uint32_t* sorted_key, uint32_t n, uint32_t ncells,
                        uint32_t* cell_start /* [ncells+1] */, void* scratch /* cell_start_scratch_bytes() */);
@@ -124,6 +125,9 @@ struct SweepArgs {
     uint32_t* ncount;
     uint4* nl;          // neighbour list words (sph_sweeps.hip)
     uint4* nlx;         // explicit index lists (multi-resolution scenes)
+    int h_mode;         // support_length_estimation (SPH_H_*)
+    float* h2_next;     // FromDistribution*: the estimate for the next step is written here by the density sweep
+    const float* lam_prev;
     uint4* nl_ext;      // list words / index lists of the extended-range lists (level estimation)
     uint4* nlx_ext;
     TileP t;            // stencil bound per tile (multi-resolution scenes; ts = 0: uniform)

@@ -181,11 +181,15 @@ __global__ __launch_bounds__(256) void k_reorder(uint32_t n, GridP g, const uint
                                                   const float* __restrict__ lvl_in, const float* __restrict__ lvlold_in,
                                                   float4* __restrict__ pm_out, float2* __restrict__ vel_out,
                                                   uint32_t* __restrict__ orig_out, float* __restrict__ lvl_out,
-                                                  float* __restrict__ lvlold_out, uint32_t* __restrict__ cxy)
+                                                  float* __restrict__ lvlold_out, uint32_t* __restrict__ cxy,
+                                                  const float* __restrict__ h2n_in, float* __restrict__ h2n_out,
+                                                  const float* __restrict__ lam_in, float* __restrict__ lam_prev_out)
 {
     uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     uint32_t src = perm[i];
+    if (h2n_in) h2n_out[i] = h2n_in[src];
+    if (lam_in) lam_prev_out[i] = lam_in[src];
     pm_out[i] = pm_in[src];
     vel_out[i] = vel_in[src];
     orig_out[i] = orig_in[src];
@@ -200,11 +204,11 @@ __global__ __launch_bounds__(256) void k_reorder(uint32_t n, GridP g, const uint
 void launch_reorder(hipStream_t s, Profiler* prof, uint32_t n, GridP g, const uint32_t* sorted_key, const uint32_t* perm,
                     const float4* pm_in, const float2* vel_in, const uint32_t* orig_in, const float* lvl_in,
                     const float* lvlold_in, float4* pm_out, float2* vel_out, uint32_t* orig_out, float* lvl_out,
-                    float* lvlold_out, uint32_t* cxy)
+                    float* lvlold_out, uint32_t* cxy, const float* h2n_in, float* h2n_out, const float* lam_in, float* lam_prev_out)
 {
     ProfScope ps(prof, "reorder", s);
     hipLaunchKernelGGL(k_reorder, dim3((n + 255) / 256), dim3(256), 0, s, n, g, sorted_key, perm, pm_in, vel_in, orig_in, lvl_in,
-                       lvlold_in, pm_out, vel_out, orig_out, lvl_out, lvlold_out, cxy);
+                       lvlold_in, pm_out, vel_out, orig_out, lvl_out, lvlold_out, cxy, h2n_in, h2n_out, lam_in, lam_prev_out);
 }
 
 // cell_start[c] = index of the first sorted particle whose cell is >= c; cell_start[ncells] = n.

@@ -54,6 +54,9 @@ SweepArgs make_args(sph_ctx* c, const StepP& sp)
     a.ncount = c->ncount.as<uint32_t>();
     a.nl = c->nl.as<uint4>();
     a.nlx = c->nlx.as<uint4>();
+    a.h_mode = SPH_H_FROM_MASS;   // set by the step driver
+    a.h2_next = c->h2n[k].as<float>();
+    a.lam_prev = c->lam_prev.as<float>();
     a.nl_ext = c->nl_ext.as<uint4>();
     a.nlx_ext = c->nlx_ext.as<uint4>();
     a.t = TileP{c->tile_ts, c->tile_tsx, c->tile_tsy, c->tile_h.as<uint32_t>()};
@@ -88,6 +91,7 @@ const char* status_message(uint32_t code)
     case SPH_ERR_VISCOSITY_NOT_FINITE: return "Assertion 'viscosity_accel[d].is_finite()' failed!";
     case SPH_ERR_CHECK_NEIGHBORHOOD: return "neighbour list differs from the brute-force definition";
     case SPH_ERR_LEVEL_WEIGHT: return "weight is <=0 in smooth_level_estimation_field";
+    case SPH_ERR_VOLUME_ESTIMATE: return "assertion failed: volume_estimate >= 0.";
     default: return "device-side guard failed";
     }
 }
@@ -860,8 +864,9 @@ static int group_step(Group& G, const sph_params* p, sph_step_stats* outs)
     sph_ctx* c0 = G.m[0];
     // ---- parameter combinations this build does not cover are refused, never approximated ---------------
     if (c0->n_planes == 0) return c0->fail(SPH_ERR_NO_BOUNDARY, "not implemented: NoBoundaryHandler::iisph_aii");
-    if (p->support_length_estimation != SPH_H_FROM_MASS)
-        return c0->fail(SPH_ERR_UNSUPPORTED, "support_length_estimation other than FromMass is not covered yet");
+    const bool h_from_mass_mode = p->support_length_estimation == SPH_H_FROM_MASS;
+    if (!h_from_mass_mode && G.multi())
+        return c0->fail(SPH_ERR_UNSUPPORTED, "FromDistribution support lengths on a slab decomposition are not covered yet");
     if (p->constrain_neighborhood_count) return c0->fail(SPH_ERR_UNSUPPORTED, "constrain_neighborhood_count is not covered yet");
     if (p->pressure_solver_method == SPH_SOLVER_IISPH2) return c0->fail(SPH_ERR_UNSUPPORTED, "IISPH2 is not covered yet");
     const bool level_on = p->level_estimation_method != SPH_LEVEL_NONE;
@@ -893,7 +898,7 @@ static int group_step(Group& G, const sph_params* p, sph_step_stats* outs)
     g_trace.mark(0);
     for (auto& m : M) {
         (void)hipSetDevice(m.c->device);
-        launch_header(m.c, (uint32_t)m.c->n, p->rest_density, 1, m.c->hdr_host_dev);
+        launch_header(m.c, (uint32_t)m.c->n, p->rest_density, h_from_mass_mode ? 1 : 2, m.c->hdr_host_dev);
     }
     if ((rc = agree(G, wait_all(G)))) return rc;
     for (size_t i = 0; i < M.size(); i++) {
@@ -916,7 +921,7 @@ static int group_step(Group& G, const sph_params* p, sph_step_stats* outs)
         // bounding box of owned + ghosts
         for (auto& m : M) {
             (void)hipSetDevice(m.c->device);
-            launch_header(m.c, m.n, p->rest_density, 1, m.c->hdr_host_dev);
+            launch_header(m.c, m.n, p->rest_density, 0, m.c->hdr_host_dev);   // h is set; only the bounding box changed
         }
         if ((rc = agree(G, wait_all(G)))) return rc;
     }
@@ -958,7 +963,9 @@ static int group_step(Group& G, const sph_params* p, sph_step_stats* outs)
         c->h_uniform = h_max_g;
         GridP fg = g;
         c->tile_ts = 0;
-        if (!c->uniform_h) {
+        // (a narrow h distribution -- FromDistribution* support lengths wander by a few percent -- keeps the one-cell stencil
+        //  of the coarse grid: the fine grid only pays once 3 x 3 coarse cells hold several times the needed candidates)
+        if (!c->uniform_h && h_max_g >= 1.75f * h_min_g) {
             float cs = h_min_g * 2.f;
             bool ok = false;
             for (int k = 0; k < 24 && cs < g.cs; k++, cs *= 2.f)
@@ -1019,7 +1026,8 @@ static int group_step(Group& G, const sph_params* p, sph_step_stats* outs)
             launch_reorder(s, prof, n, g, c->key[0].as<uint32_t>(), c->val[0].as<uint32_t>(), c->pm[c->pcur].as<float4>(), c->vel[k].as<float2>(),
                            c->orig[k].as<uint32_t>(), c->lvl[k].as<float>(), c->lvlold[k].as<float>(), c->pm[c->pcur ^ 1].as<float4>(),
                            c->vel[k ^ 1].as<float2>(), c->orig[k ^ 1].as<uint32_t>(), c->lvl[k ^ 1].as<float>(), c->lvlold[k ^ 1].as<float>(),
-                           c->cxy.as<uint32_t>());
+                           c->cxy.as<uint32_t>(), c->h2n[k].as<float>(), c->h2n[k ^ 1].as<float>(), c->lam_sum.as<float>(),
+                           c->lam_prev.as<float>());
             c->cur = k ^ 1;
             c->pcur ^= 1;
         }
@@ -1042,6 +1050,7 @@ static int group_step(Group& G, const sph_params* p, sph_step_stats* outs)
         }
         if (tev) (void)hipEventRecord(c->ev[1], s);
         m.a = make_args(c, sp);
+        m.a.h_mode = p->support_length_estimation;
         m.st.n_particles = c->n;
         m.st.dt = dt;
     }
@@ -1063,6 +1072,7 @@ static int group_step(Group& G, const sph_params* p, sph_step_stats* outs)
         HIPCHK(c, c->nl_ext.ensure(sweep_list_bytes((uint32_t)n)));
         HIPCHK(c, c->nlx_ext.ensure(sweep_index_list_bytes((uint32_t)n)));
         m.a = make_args(c, m.sp);
+        m.a.h_mode = p->support_length_estimation;
         lv.k = p->level_estimation_range / SPH_ETA;                    // simulation.rs:2036
         lv.threshold = cosf(50.f * (SPH_PI_F / 180.f));                // simulation.rs:544
         lv.max_surface_distance = p->maximum_surface_distance;

@@ -343,8 +343,13 @@ struct OpDensity {
     const float* __restrict__ dlam_lut;
     DeviceStatus* status;
     StepP sp;
+    // support_length_estimation FromDistribution* (estimate_h_next_from_distribution / _distribution2, simulation.rs:1873-1971):
+    // the W sums ride along with the density sum; h2_next holds the h of the previous step on entry
+    int h_mode;
+    float* __restrict__ h2_next;
+    const float* __restrict__ lam_prev;   // lambda_sum(i) of the PREVIOUS step (update_after_advect runs later in the step)
     struct Acc {
-        float sum, lam;
+        float sum, lam, wsum, vwsum;
         uint32_t cnt;
         bool wall;
     };
@@ -360,6 +365,7 @@ struct OpDensity {
     __device__ void begin(Acc& a, uint32_t i, float4 Ai) const
     {
         a.sum = 0.f;
+        a.wsum = a.vwsum = 0.f;
         a.cnt = 0;
         // semi-analytic boundary: every IEEE op as in the reference (same values as the oracle)
         const float x = Ai.x, y = Ai.y;
@@ -408,7 +414,12 @@ struct OpDensity {
     }
     __device__ void pair(Acc& a, float4 Aj, NB, float, float, float r2, float hij) const
     {
-        a.sum += Aj.z * m.w(r2, hij);
+        const float w = m.w(r2, hij);
+        a.sum += Aj.z * w;
+        if (h_mode != SPH_H_FROM_MASS) {   // launch-uniform
+            a.wsum += w;
+            a.vwsum += (Aj.z / sp.rest_density) * w;
+        }
         a.cnt++;
     }
     __device__ bool finish(Acc& a, uint32_t i, float4 Ai, bool) const
@@ -420,6 +431,18 @@ struct OpDensity {
         if (!isfinite(d)) raise_error(status, SPH_ERR_DENSITY_NOT_FINITE, orig[i]);
         else if (!(d > 0.0001f)) raise_error(status, SPH_ERR_DENSITY_TOO_SMALL, orig[i]);
         if (a.cnt > 20000u) raise_error(status, SPH_ERR_TOO_MANY_NEIGHBORS, orig[i]);
+        if (h_mode != SPH_H_FROM_MASS) {
+            const float bv = lam_prev[i];
+            float vol;
+            if (h_mode == SPH_H_FROM_DISTRIBUTION2) vol = (Ai.z / sp.rest_density) / (a.vwsum + bv);
+            else vol = (1.f - fminf(bv, 0.5f)) / a.wsum;
+            if (!(vol >= 0.f)) raise_error(status, SPH_ERR_VOLUME_ESTIMATE, orig[i]);
+            const float h_new = SPH_ETA * sqrtf(vol * SPH_FRAC_1_PI_F);
+            float hn = 0.5f * h_new + (1.f - 0.5f) * Ai.w;
+            if (h_mode == SPH_H_FROM_DISTRIBUTION_CLAMPED1) hn = fminf(hn, 1.f * h_from_mass(Ai.z, sp.rest_density));
+            if (h_mode == SPH_H_FROM_DISTRIBUTION_CLAMPED2) hn = fminf(hn, 2.f * h_from_mass(Ai.z, sp.rest_density));
+            h2_next[i] = hn;
+        }
         return a.wall;
     }
 };
@@ -1491,7 +1514,8 @@ static MathUniform uniform_math(float h)
 void launch_density(hipStream_t s, Profiler* prof, const SweepArgs& a)
 {
     ProfScope ps(prof, "density", s);
-    SPH_DISPATCH(OpDensity, true, a.pm, a.orig, a.rho, a.mrho, a.lam_sum, a.lam_grad, a.ncount, a.planes, a.lam_lut, a.dlam_lut, a.status, a.sp)
+    SPH_DISPATCH(OpDensity, true, a.pm, a.orig, a.rho, a.mrho, a.lam_sum, a.lam_grad, a.ncount, a.planes, a.lam_lut, a.dlam_lut, a.status, a.sp,
+                 a.h_mode, a.h2_next, a.lam_prev)
 }
 
 void launch_aii_const(hipStream_t s, Profiler* prof, const SweepArgs& a)

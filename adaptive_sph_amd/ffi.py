@@ -49,7 +49,7 @@ STATUS_NAMES = {
     13: "SPH_ERR_AII_NEGATIVE", 14: "SPH_ERR_AP_NOT_FINITE", 15: "SPH_ERR_PRESSURE_NOT_FINITE",
     16: "SPH_ERR_TOO_MANY_NEIGHBORS", 17: "SPH_ERR_VELOCITY_NOT_FINITE", 18: "SPH_ERR_POSITION_NOT_FINITE",
     19: "SPH_ERR_VISCOSITY_NOT_FINITE", 20: "SPH_ERR_XSPH_TODO", 21: "SPH_ERR_CHECK_NEIGHBORHOOD",
-    22: "SPH_ERR_CHECK_AII", 23: "SPH_ERR_LEVEL_WEIGHT", 30: "SPH_ERR_UNSUPPORTED",
+    22: "SPH_ERR_CHECK_AII", 23: "SPH_ERR_LEVEL_WEIGHT", 24: "SPH_ERR_VOLUME_ESTIMATE", 30: "SPH_ERR_UNSUPPORTED",
 }
 
 

@@ -182,6 +182,7 @@ enum {
     SPH_ERR_CHECK_NEIGHBORHOOD = 21,    /* sim.rs:1810-1863 */
     SPH_ERR_CHECK_AII = 22,             /* sim.rs:1347-1375 */
     SPH_ERR_LEVEL_WEIGHT = 23,          /* sim.rs:843-845 */
+    SPH_ERR_VOLUME_ESTIMATE = 24,       /* sim.rs:1903-1909, 1961  volume_estimate >= 0 */
     SPH_ERR_UNSUPPORTED = 30            /* a SimulationParams combination this build does not cover */
 };
 

@@ -775,6 +775,48 @@ static int integrate_v_then_x(oracle_ctx* c, float dt) /* simulation.rs:2433-244
     return SPH_OK;
 }
 
+/* estimate_h_next_from_distribution / _distribution2 (simulation.rs:1873-1971).  lambda_sum(i) is the boundary handler's
+ * state of the PREVIOUS step (update_after_advect runs later in the step; empty lists = 0 before the first step). */
+static int estimate_h_next_from_distribution(oracle_ctx* c, const sph_params* p)
+{
+    int bad = 0;
+    const int mode = p->support_length_estimation;
+#pragma omp parallel for schedule(static) reduction(| : bad)
+    for (int64_t ii = 0; ii < (int64_t)c->n; ii++) {
+        uint64_t i = (uint64_t)ii;
+        const float* pos = c->pos;
+        const float w = 0.5f;
+        float volume_estimate;
+        const float boundary_volume = density_boundary_term(c, i);   /* == lambda_sum(i), boundary_winchenbach2020.rs:47-49 */
+        if (mode == SPH_H_FROM_DISTRIBUTION2) {
+            float v_w_sum = 0.f;
+            NB_LOOP(c, i, j) {
+                float hij = orc_hij(c->h2[i], c->h2[j]);
+                float vj = c->mass[j] / p->rest_density;
+                v_w_sum += vj * orc_kernelh(pos[2 * i] - pos[2 * j], pos[2 * i + 1] - pos[2 * j + 1], hij);
+            }
+            float vi = c->mass[i] / p->rest_density;
+            volume_estimate = vi / (v_w_sum + boundary_volume);
+        } else {
+            float w_sum = 0.f;
+            NB_LOOP(c, i, j) {
+                float hij = orc_hij(c->h2[i], c->h2[j]);
+                w_sum += orc_kernelh(pos[2 * i] - pos[2 * j], pos[2 * i + 1] - pos[2 * j + 1], hij);
+            }
+            volume_estimate = (1.f - fminf(boundary_volume, 0.5f)) / w_sum;
+        }
+        if (!(volume_estimate >= 0.f)) { bad = 1; continue; }
+        float h_new = ORC_ETA * orc_sphere_volume_to_radius(volume_estimate);
+        float h_old = c->h2[i];
+        float hn = w * h_new + (1.f - w) * h_old;
+        if (mode == SPH_H_FROM_DISTRIBUTION_CLAMPED1) hn = fminf(hn, 1.f * orc_h_from_mass(c->mass[i], p->rest_density));
+        if (mode == SPH_H_FROM_DISTRIBUTION_CLAMPED2) hn = fminf(hn, 2.f * orc_h_from_mass(c->mass[i], p->rest_density));
+        c->h2_next[i] = hn;
+    }
+    if (bad) return orc_fail(c, SPH_ERR_VOLUME_ESTIMATE, "assertion failed: volume_estimate >= 0.");
+    return SPH_OK;
+}
+
 int orc_step(oracle_ctx* c, const sph_params* p, sph_step_stats* out)
 {
     double t_step0 = omp_get_wtime();
@@ -785,14 +827,19 @@ int orc_step(oracle_ctx* c, const sph_params* p, sph_step_stats* out)
     st.n_particles = c->n;
 
     if (c->n_planes == 0) return orc_fail(c, SPH_ERR_NO_BOUNDARY, "not implemented: NoBoundaryHandler::iisph_aii");
-    if (p->support_length_estimation != SPH_H_FROM_MASS)
-        return orc_fail(c, SPH_ERR_UNSUPPORTED, "support_length_estimation other than FromMass is not covered yet");
     if (p->constrain_neighborhood_count) return orc_fail(c, SPH_ERR_UNSUPPORTED, "constrain_neighborhood_count is not covered yet");
     if (p->pressure_solver_method == SPH_SOLVER_IISPH2) return orc_fail(c, SPH_ERR_UNSUPPORTED, "IISPH2 is not covered yet");
 
     /* simulation.rs:1998-2016, 1865-1871 */
-    PARFOR
-    for (int64_t i = 0; i < (int64_t)c->n; i++) c->h2[i] = orc_h_from_mass(c->mass[i], p->rest_density);
+    if (p->support_length_estimation == SPH_H_FROM_MASS) {
+        PARFOR
+        for (int64_t i = 0; i < (int64_t)c->n; i++) c->h2[i] = orc_h_from_mass(c->mass[i], p->rest_density);
+    } else {
+        /* only apply the support length that was estimated in the last step: mem::swap(h2, h2_next) */
+        float* t = c->h2;
+        c->h2 = c->h2_next;
+        c->h2_next = t;
+    }
 
     orc_cell_indices(c);
 
@@ -819,6 +866,9 @@ int orc_step(oracle_ctx* c, const sph_params* p, sph_step_stats* out)
     /* simulation.rs:2072-2088 */
     for (uint64_t i = 0; i < c->n; i++) c->neighbor_count[i] = (uint32_t)(c->nb_off[i + 1] - c->nb_off[i]);
     if (p->check_neighborhood && (rc = orc_check_neighborhood(c))) return rc;
+
+    /* simulation.rs:2090-2143 */
+    if (p->support_length_estimation != SPH_H_FROM_MASS && (rc = estimate_h_next_from_distribution(c, p))) return rc;
 
     /* simulation.rs:2179-2180 */
     update_after_advect(c, p);
