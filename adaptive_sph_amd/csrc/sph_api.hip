@@ -329,7 +329,7 @@ extern "C" int sph_create(uint64_t n_capacity, int device_id, const sph_plane* p
     c->device = device_id;
     c->cap = n_capacity;
     c->n_planes = n_planes;
-    for (int k = 0; k < n_planes; k++) c->planes_h[k] = PlaneP{planes[k].dir_x, planes[k].dir_y, planes[k].delta};
+    for (int k = 0; k < n_planes; k++) c->bnd_h.planes[k] = PlaneP{planes[k].dir_x, planes[k].dir_y, planes[k].delta};
     const char* ex = getenv("SPH_HIP_EXACT");
     c->exact = (ex && ex[0] == '1') ? 1 : 0;
     auto bail = [&](int code) {
@@ -340,7 +340,7 @@ extern "C" int sph_create(uint64_t n_capacity, int device_id, const sph_plane* p
     for (auto& e : c->ev)
         if (hipEventCreate(&e) != hipSuccess) return bail(SPH_ERR_DEVICE);
     if (alloc_particle_buffers(c) != SPH_OK) return bail(SPH_ERR_DEVICE);
-    bool ok = c->planes_d.ensure(sizeof(PlaneP) * SPH_MAX_PLANES) == hipSuccess && c->lam_lut.ensure(10001 * 4) == hipSuccess &&
+    bool ok = c->planes_d.ensure(sizeof(BoundaryP)) == hipSuccess && c->lam_lut.ensure(10001 * 4) == hipSuccess &&
               c->dlam_lut.ensure(10001 * 4) == hipSuccess && c->hdr_partials.ensure(sizeof(HeaderOut) * HDR_BLOCKS) == hipSuccess &&
               c->hdr_out.ensure(sizeof(HeaderOut)) == hipSuccess && c->ctrl.ensure(sizeof(SolverCtrl)) == hipSuccess &&
               c->status.ensure(sizeof(DeviceStatus)) == hipSuccess && c->n_tiles.ensure(16) == hipSuccess;
@@ -360,11 +360,45 @@ extern "C" int sph_create(uint64_t n_capacity, int device_id, const sph_plane* p
     sph_lambda::build_luts(lam, dlam);
     hipMemcpy(c->lam_lut.p, lam.data(), lam.size() * 4, hipMemcpyHostToDevice);
     hipMemcpy(c->dlam_lut.p, dlam.data(), dlam.size() * 4, hipMemcpyHostToDevice);
-    hipMemcpy(c->planes_d.p, c->planes_h, sizeof(PlaneP) * SPH_MAX_PLANES, hipMemcpyHostToDevice);
+    hipMemcpy(c->planes_d.p, &c->bnd_h, sizeof(BoundaryP), hipMemcpyHostToDevice);
     hipMemset(c->status.p, 0, sizeof(DeviceStatus));
     hipMemset(c->ctrl.p, 0, sizeof(SolverCtrl));
     hipDeviceSynchronize();
     *out = c;
+    return SPH_OK;
+}
+
+// Sdf2D::new_boundary_box / Sdf2DConnectedComponents::from_points (sdf/sdf2d.rs:36-75, 167-179)
+extern "C" int sph_set_boundary_polygon(sph_ctx* c, const float* pts, int n)
+{
+    if (!c || !pts || n < 3 || n > SPH_MAX_POLYGON_POINTS) return SPH_ERR_INVALID_ARGUMENT;
+    HIPCHK(c, hipSetDevice(c->device));
+    BoundaryP b = c->bnd_h;
+    for (int i = 0; i < n; i++) {
+        b.px[i] = pts[2 * i];
+        b.py[i] = pts[2 * i + 1];
+    }
+    for (int i = 0; i < n; i++) {
+        const int i1 = (i + 1) % n;
+        const float dx = b.px[i1] - b.px[i], dy = b.py[i1] - b.py[i];
+        const float n2 = dx * dx + dy * dy;
+        if (!(n2 > 0.00001f)) return c->fail(SPH_ERR_INVALID_ARGUMENT, "assertion failed: line_dir.norm_squared() > 0.00001");
+        const float nn = sqrtf(n2);   // normalize_mut
+        b.dx[i] = dx / nn;
+        b.dy[i] = dy / nn;
+    }
+    for (int i = 0; i < n; i++) {
+        const int pi = i == 0 ? n - 1 : i - 1;
+        const float px = -b.dy[pi] + -b.dy[i], py = b.dx[pi] + b.dx[i];   // rotate_left_90_degrees of both edge directions
+        if (!(px * px + py * py > 0.00001f)) return c->fail(SPH_ERR_INVALID_ARGUMENT, "assertion failed: pseudo_normal.norm_squared() > 0.00001");
+        b.nx[i] = px;
+        b.ny[i] = py;
+    }
+    b.poly_n = n;
+    c->bnd_h = b;
+    c->n_planes = 1;   // one Sdf
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(c->planes_d.p, &c->bnd_h, sizeof(BoundaryP), hipMemcpyHostToDevice));
     return SPH_OK;
 }
 

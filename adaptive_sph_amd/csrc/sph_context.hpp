@@ -40,7 +40,7 @@ struct sph_ctx {
     uint64_t cap = 0, n = 0;
     hipStream_t stream = nullptr;
     int n_planes = 0;
-    PlaneP planes_h[SPH_MAX_PLANES];
+    BoundaryP bnd_h{};   // planes, or one Sdf2D polygon (sph_set_boundary_polygon)
     float time = 0.f;
     uint64_t step_number = 0;
     std::string err;

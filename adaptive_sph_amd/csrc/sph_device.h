@@ -18,6 +18,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "sph_ffi.h"
+
 #define SPH_PI_F 3.14159274101257324219f          // std::f32::consts::PI
 #define SPH_FRAC_1_PI_F 0.318309873342514038086f  // std::f32::consts::FRAC_1_PI
 #define SPH_ETA 1.9f                              // simulation.rs:369
@@ -51,6 +53,16 @@ struct PlaneP {
     float dx, dy, delta;
 };
 #define SPH_MAX_PLANES 8
+
+// The boundary handler's list of SDFs (BoundaryWinchenbach2020::sdf): up to SPH_MAX_PLANES SdfPlane, or -- poly_n > 0 --
+// ONE Sdf2D connected component (sdf/sdf2d.rs:4-16) that replaces them.
+struct BoundaryP {
+    PlaneP planes[SPH_MAX_PLANES];
+    int poly_n;
+    float px[SPH_MAX_POLYGON_POINTS], py[SPH_MAX_POLYGON_POINTS];   // point
+    float dx[SPH_MAX_POLYGON_POINTS], dy[SPH_MAX_POLYGON_POINTS];   // normalized_line_dir
+    float nx[SPH_MAX_POLYGON_POINTS], ny[SPH_MAX_POLYGON_POINTS];   // point_pseudo_normal
+};
 
 struct SolverPartial {
     uint32_t normal, singular, negative;
@@ -157,6 +169,54 @@ __device__ __forceinline__ int stencil_radius(const GridP& g, const TileP& t, fl
     float hn = h_i;   // uniform scene: every h is h_i
     if (t.ts > 0) hn = __uint_as_float(t.hmax[(uint32_t)(cy / t.ts) * (uint32_t)t.tsx + (uint32_t)(cx / t.ts)]);
     return (int)floorf(((h_i + hn) * 0.5f * k) / g.cs) + 1;
+}
+
+// Sdf2D::probe = find_min_dist_object + to_dist_and_dir (sdf/sdf2d.rs:77-160, 196-228), IEEE operations in the
+// reference's order: the nearest edge (if the point projects inside it) or corner; positive on the air side
+__device__ __forceinline__ float polygon_probe(const BoundaryP* __restrict__ b, float x, float y)
+{
+    const int n = b->poly_n;
+    float min_dist_sq = __uint_as_float(0x7f800000u);
+    bool is_line = false;
+    int point_idx = 0;
+    float line_dist = 0.f, pdx = 0.f, pdy = 0.f, pt_dist_sq = min_dist_sq;
+    for (int i = 0; i < n; i++) {
+        const int i1 = i + 1 == n ? 0 : i + 1;
+        const float sx = b->px[i], sy = b->py[i];
+        const float lx = b->px[i1] - sx, ly = b->py[i1] - sy;
+        const float line_len_sq = lx * lx + ly * ly;
+        const float dx = b->dx[i], dy = b->dy[i];
+        const float qx = x - sx, qy = y - sy;   // point_dir
+        const float projection_len = qx * dx + qy * dy;
+        if (projection_len > 0.f && projection_len * projection_len < line_len_sq) {
+            const float d = qx * -dy + qy * dx;   // dot(point_dir, rotate_left_90_degrees(line_dir))
+            const float d2 = d * d;
+            if (d2 < min_dist_sq) {
+                is_line = true;
+                line_dist = d;
+                min_dist_sq = d2;
+            }
+        }
+        const float corner_dist_sq = qx * qx + qy * qy;
+        if (corner_dist_sq < min_dist_sq) {
+            is_line = false;
+            point_idx = i;
+            pt_dist_sq = corner_dist_sq;
+            pdx = qx;
+            pdy = qy;
+            min_dist_sq = corner_dist_sq;
+        }
+    }
+    if (is_line) return line_dist;
+    const float sign = (b->nx[point_idx] * pdx + b->ny[point_idx] * pdy) >= 0.f ? 1.0f : -1.0f;
+    return sqrtf(pt_dist_sq) * sign;
+}
+// Sdf::probe of SDF number k (SdfPlane::probe, sdf_plane.rs:36-38, or the polygon)
+__device__ __forceinline__ float sdf_probe(const BoundaryP* __restrict__ b, int k, float x, float y)
+{
+    if (b->poly_n > 0) return polygon_probe(b, x, y);
+    const PlaneP pl = b->planes[k];
+    return (pl.dx * x + pl.dy * y) + pl.delta;
 }
 
 // LookupTable1D::get with (min,max,steps) = (-1,1,10000); caller guarantees -1 <= x < 1

@@ -138,7 +138,7 @@ struct SweepArgs {
     float* pt0;         // p / rho^2 for pressure buffer 0 / 1
     float* pt1;
     // boundary
-    const PlaneP* planes;
+    const BoundaryP* planes;
     const float* lam_lut;
     const float* dlam_lut;
     // control

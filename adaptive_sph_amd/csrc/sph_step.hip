@@ -66,7 +66,7 @@ SweepArgs make_args(sph_ctx* c, const StepP& sp)
     a.pt1 = c->pt1.as<float>();
     a.uniform_h = c->uniform_h ? 1 : 0;
     a.h_uniform = c->h_uniform;
-    a.planes = c->planes_d.as<PlaneP>();
+    a.planes = c->planes_d.as<BoundaryP>();
     a.lam_lut = c->lam_lut.as<float>();
     a.dlam_lut = c->dlam_lut.as<float>();
     a.ctrl = c->ctrl.as<SolverCtrl>();

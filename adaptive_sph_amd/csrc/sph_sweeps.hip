@@ -338,7 +338,7 @@ struct OpDensity {
     float* __restrict__ lam_sum;
     float2* __restrict__ lam_grad;
     uint32_t* __restrict__ ncount;
-    const PlaneP* __restrict__ planes;
+    const BoundaryP* __restrict__ planes;
     const float* __restrict__ lam_lut;
     const float* __restrict__ dlam_lut;
     DeviceStatus* status;
@@ -360,7 +360,6 @@ struct OpDensity {
     __device__ float4 loadA(uint32_t j) const { return pm[j]; }
     __device__ NB nb(const Acc&, uint32_t, float4) const { return NB{}; }
 
-    __device__ static float probe(const PlaneP& pl, float x, float y) { return (pl.dx * x + pl.dy * y) + pl.delta; }
 
     __device__ void begin(Acc& a, uint32_t i, float4 Ai) const
     {
@@ -372,13 +371,12 @@ struct OpDensity {
         const float sr_i = Ai.w * 2.f;
         float ls = 0.f, gxs = 0.f, gys = 0.f;
         for (int k = 0; k < sp.n_planes; k++) {
-            const PlaneP pl = planes[k];
-            float d = probe(pl, x, y) / sr_i;
+            float d = sdf_probe(planes, k, x, y) / sr_i;
             if (!(d < 1.f)) continue;
             const float eps = sp.sdf_eps;
             const float inv_2eps = 1.f / (2.f * eps);
-            float gx = (probe(pl, x + eps, y) - probe(pl, x - eps, y)) * inv_2eps;
-            float gy = (probe(pl, x, y + eps) - probe(pl, x, y - eps)) * inv_2eps;
+            float gx = (sdf_probe(planes, k, x + eps, y) - sdf_probe(planes, k, x - eps, y)) * inv_2eps;
+            float gy = (sdf_probe(planes, k, x, y + eps) - sdf_probe(planes, k, x, y - eps)) * inv_2eps;
             float gn = sqrtf(gx * gx + gy * gy);
             if (!(gn >= 0.00001f)) continue;
             gx /= gn;
@@ -1019,7 +1017,7 @@ struct OpLevelNormal {
     float2* __restrict__ nrm;
     uint8_t* __restrict__ state;
     uint8_t* __restrict__ flag_insufficient;
-    const PlaneP* __restrict__ planes;
+    const BoundaryP* __restrict__ planes;
     StepP sp;
     float k;
     int boundary_is_fluid_surface;
@@ -1059,7 +1057,7 @@ struct OpLevelNormal {
             st = 0;
         } else {
             float dist = __uint_as_float(0x7f800000u);   // BoundaryHandler::distance_to_boundary (boundary_winchenbach2020.rs:320-325)
-            for (int q = 0; q < sp.n_planes; q++) dist = fminf(dist, (planes[q].dx * Ai.x + planes[q].dy * Ai.y) + planes[q].delta);
+            for (int q = 0; q < sp.n_planes; q++) dist = fminf(dist, sdf_probe(planes, q, Ai.x, Ai.y));
             if (!boundary_is_fluid_surface && dist < Ai.w * 1.5f) {
                 st = 0;
             } else {

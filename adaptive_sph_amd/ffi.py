@@ -115,7 +115,7 @@ class SphError(RuntimeError):
 # every symbol include/sph_ffi.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
     "create", "destroy", "upload", "upload_field", "download", "download_neighbors", "num_particles", "time",
-    "set_time", "step", "last_error", "grid", "profile_enable", "profile_reset", "profile_get", "profile_event_overhead",
+    "set_time", "step", "last_error", "grid", "set_boundary_polygon", "profile_enable", "profile_reset", "profile_get", "profile_event_overhead",
     "dist_configure", "comm_unique_id", "comm_init", "group_step",
 ]
 
@@ -147,6 +147,7 @@ class SphLibrary:
 
         self.create = sig("create", i32, [u64, i32, C.POINTER(SphPlane), i32, C.POINTER(vp)])
         self.destroy = sig("destroy", None, [vp])
+        self.set_boundary_polygon = sig("set_boundary_polygon", i32, [vp, C.POINTER(C.c_float), i32])
         self.upload = sig("upload", i32, [vp, u64, vp, vp, vp])
         self.upload_field = sig("upload_field", i32, [vp, i32, vp, u64])
         self.download = sig("download", i32, [vp, i32, vp, u64])
@@ -197,8 +198,11 @@ class Context:
     """One simulation context (``FluidSimulation`` state container on the library side)."""
 
     def __init__(self, lib: SphLibrary, n_capacity: int, planes, device_id: int = 0):
+        """`planes`: the (dir_x, dir_y, delta) planes of an AnalyticOverestimate box, or a scene.BoundaryPolygon (the single
+        Sdf2D of AnalyticUnderestimate)."""
         self.lib = lib
-        planes = list(planes)
+        polygon = getattr(planes, "points", None)
+        planes = [] if polygon is not None else list(planes)
         arr = (SphPlane * max(1, len(planes)))()
         for k, (dx, dy, delta) in enumerate(planes):
             arr[k] = SphPlane(dx, dy, delta)
@@ -208,6 +212,9 @@ class Context:
             raise SphError(rc, "create failed")
         self.handle = h
         self.capacity = int(n_capacity)
+        if polygon is not None:
+            flat = [float(v) for pt in polygon for v in pt]
+            self._check(lib.set_boundary_polygon(h, (C.c_float * len(flat))(*flat), len(polygon)))
 
     def close(self):
         if getattr(self, "handle", None):

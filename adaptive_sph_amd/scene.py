@@ -85,14 +85,29 @@ def add_fluid_block(block: SceneFluidBlock):
     return pos.reshape(n, 2), mass, vel
 
 
+@dataclass
+class BoundaryPolygon:
+    """One Sdf2D connected component (sdf/sdf2d.rs): closed polygon, air on the left of every edge."""
+    points: List[Tuple[float, float]]
+
+
 def boundary_planes(boundary: SceneBoundary, init_boundary_handler: str = "AnalyticOverestimate"):
-    """Planes (dir_x, dir_y, delta) of the boundary handler built by init_fluid_sim (:3137-3213)."""
+    """The boundary handler built by init_fluid_sim (:3137-3213): planes (dir_x, dir_y, delta) of the SdfPlane box
+    (AnalyticOverestimate), or the BoundaryPolygon of Sdf2D::new_boundary_box (AnalyticUnderestimate, sdf2d.rs:167-179)."""
     if init_boundary_handler == "NoBoundary":
         return []
+    if init_boundary_handler == "AnalyticUnderestimate":
+        if boundary.type != "box":
+            raise NotImplementedError(f"boundary type {boundary.type!r}")
+        w, h = f32(boundary.width), f32(boundary.height)
+        min_x, min_y = f32(0.0) - w / f32(2.0), f32(0.0) - h / f32(2.0)
+        max_x, max_y = f32(0.0) + w / f32(2.0), f32(0.0) + h / f32(2.0)
+        return BoundaryPolygon([(float(min_x), float(min_y)), (float(max_x), float(min_y)), (float(max_x), float(max_y)),
+                                (float(min_x), float(max_y))])
     if init_boundary_handler != "AnalyticOverestimate":
-        # AnalyticUnderestimate = Sdf2D polygon, Particles = Akinci particles: SURVEY.md section 8f "next"
+        # Particles = Akinci boundary particles (ParticleBasedBoundaryHandler): not on the covered path
         raise NotImplementedError(f"init_boundary_handler={init_boundary_handler} is outside the covered path "
-                                  f"(only the SdfPlane box of AnalyticOverestimate is)")
+                                  f"(the SdfPlane box of AnalyticOverestimate and the Sdf2D box of AnalyticUnderestimate are)")
     if boundary.type != "box":
         raise NotImplementedError(f"boundary type {boundary.type!r}")
     w, h = f32(boundary.width), f32(boundary.height)

@@ -194,6 +194,14 @@ typedef struct sph_ctx sph_ctx;
  * `device_id` is the HIP device ordinal this context owns (one process per GPU).
  * "Restart" in the GUI = destroy + create (main_loop.rs:269-278). */
 int  sph_create(uint64_t n_capacity, int device_id, const sph_plane* planes, int n_planes, sph_ctx** out);
+
+/* Replace the boundary by ONE Sdf2D connected component (sdf/sdf2d.rs:36-210): the closed polygon p0 .. p(n-1), air on the
+ * left-hand side of every edge p_i -> p_(i+1).  init_fluid_sim's AnalyticUnderestimate handler is the box polygon
+ * (min.x,min.y), (max.x,min.y), (max.x,max.y), (min.x,max.y) (simulation.rs:3195-3206, sdf2d.rs:167-179): one SDF whose
+ * value is the distance to the NEAREST wall, where AnalyticOverestimate sums four planes.  Fails with
+ * SPH_ERR_INVALID_ARGUMENT on the conditions Sdf2DConnectedComponents::from_points asserts (sdf2d.rs:43, 59). */
+#define SPH_MAX_POLYGON_POINTS 16
+int  sph_set_boundary_polygon(sph_ctx* ctx, const float* points_xy, int n_points);
 void sph_destroy(sph_ctx* ctx);
 
 /* Replace the whole particle set (FluidSimulation::new arguments, and what the host must do

@@ -27,6 +27,35 @@ int orc_fail(oracle_ctx* c, int code, const char* fmt, ...)
 
 #define ALLOC(ptr, count, type) ((ptr) = (type*)calloc((size_t)(count) + 1, sizeof(type)))
 
+/* Sdf2D::new_boundary_box / Sdf2DConnectedComponents::from_points (sdf/sdf2d.rs:36-75, 167-179) */
+int oracle_set_boundary_polygon(oracle_ctx* c, const float* pts, int n)
+{
+    if (!c || !pts || n < 3 || n > SPH_MAX_POLYGON_POINTS) return SPH_ERR_INVALID_ARGUMENT;
+    for (int i = 0; i < n; i++) {
+        c->poly_x[i] = pts[2 * i];
+        c->poly_y[i] = pts[2 * i + 1];
+    }
+    for (int i = 0; i < n; i++) {
+        float dx = c->poly_x[(i + 1) % n] - c->poly_x[i], dy = c->poly_y[(i + 1) % n] - c->poly_y[i];
+        float n2 = dx * dx + dy * dy;
+        if (!(n2 > 0.00001f)) return orc_fail(c, SPH_ERR_INVALID_ARGUMENT, "assertion failed: line_dir.norm_squared() > 0.00001");
+        float nn = sqrtf(n2); /* normalize_mut */
+        c->poly_dx[i] = dx / nn;
+        c->poly_dy[i] = dy / nn;
+    }
+    for (int i = 0; i < n; i++) {
+        int pi = i == 0 ? n - 1 : i - 1;
+        /* rotate_left_90_degrees(v) = (-v.y, v.x) */
+        float px = -c->poly_dy[pi] + -c->poly_dy[i], py = c->poly_dx[pi] + c->poly_dx[i];
+        if (!(px * px + py * py > 0.00001f)) return orc_fail(c, SPH_ERR_INVALID_ARGUMENT, "assertion failed: pseudo_normal.norm_squared() > 0.00001");
+        c->poly_nx[i] = px;
+        c->poly_ny[i] = py;
+    }
+    c->poly_n = n;
+    c->n_planes = 1; /* one Sdf */
+    return SPH_OK;
+}
+
 int oracle_create(uint64_t n_capacity, int device_id, const sph_plane* planes, int n_planes, oracle_ctx** out)
 {
     (void)device_id;

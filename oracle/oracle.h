@@ -27,6 +27,11 @@ typedef struct oracle_ctx {
     uint64_t cap, n;
     int n_planes;
     sph_plane planes[ORC_MAX_PLANES];
+    /* Sdf2D with one connected component (sdf/sdf2d.rs:4-16); poly_n > 0 replaces the planes */
+    int poly_n;
+    float poly_x[SPH_MAX_POLYGON_POINTS], poly_y[SPH_MAX_POLYGON_POINTS];       /* point */
+    float poly_dx[SPH_MAX_POLYGON_POINTS], poly_dy[SPH_MAX_POLYGON_POINTS];     /* normalized_line_dir */
+    float poly_nx[SPH_MAX_POLYGON_POINTS], poly_ny[SPH_MAX_POLYGON_POINTS];     /* point_pseudo_normal */
     orc_lut lambda_lut, dlambda_lut;
 
     /* ParticleVec (simulation.rs:284-334); VF<2> arrays are interleaved x,y */

@@ -30,6 +30,52 @@
 /* sdf_plane.rs:36-38 */
 static inline float plane_probe(const sph_plane* pl, float x, float y) { return (pl->dir_x * x + pl->dir_y * y) + pl->delta; }
 
+/* Sdf2D::probe = find_min_dist_object + to_dist_and_dir (sdf/sdf2d.rs:77-160, 196-228), one connected component */
+static float polygon_probe(const oracle_ctx* c, float x, float y)
+{
+    const int n = c->poly_n;
+    float min_dist_sq = INFINITY;
+    int is_line = 0, point_idx = 0;
+    float line_dist = 0.f, pdx = 0.f, pdy = 0.f, pt_dist_sq = INFINITY;
+    for (int i = 0; i < n; i++) {
+        const float sx = c->poly_x[i], sy = c->poly_y[i];
+        const float ex = c->poly_x[(i + 1) % n], ey = c->poly_y[(i + 1) % n];
+        const float lx = ex - sx, ly = ey - sy;
+        const float line_len_sq = lx * lx + ly * ly;
+        const float dx = c->poly_dx[i], dy = c->poly_dy[i];
+        const float qx = x - sx, qy = y - sy;                 /* point_dir */
+        const float leftx = -dy, lefty = dx;                   /* left_normalized_dir */
+        const float projection_len = qx * dx + qy * dy;
+        if (projection_len > 0.f && projection_len * projection_len < line_len_sq) {
+            const float d = qx * leftx + qy * lefty;
+            const float d2 = d * d;
+            if (d2 < min_dist_sq) {
+                is_line = 1;
+                line_dist = d;
+                min_dist_sq = d2;
+            }
+        }
+        const float corner_dist_sq = qx * qx + qy * qy;
+        if (corner_dist_sq < min_dist_sq) {
+            is_line = 0;
+            point_idx = i;
+            pt_dist_sq = corner_dist_sq;
+            pdx = qx;
+            pdy = qy;
+            min_dist_sq = corner_dist_sq;
+        }
+    }
+    if (is_line) return line_dist;
+    const float sign = (c->poly_nx[point_idx] * pdx + c->poly_ny[point_idx] * pdy) >= 0.f ? 1.0f : -1.0f;
+    return sqrtf(pt_dist_sq) * sign;
+}
+
+/* Sdf::probe of SDF number k (sdf.rs): the polygon replaces the planes */
+static inline float sdf_probe(const oracle_ctx* c, int k, float x, float y)
+{
+    return c->poly_n > 0 ? polygon_probe(c, x, y) : plane_probe(&c->planes[k], x, y);
+}
+
 /* boundary_winchenbach2020.rs:58-152 (+ sdf.rs:50-62 finite_diff_gradient) */
 static void update_after_advect(oracle_ctx* c, const sph_params* p)
 {
@@ -41,13 +87,12 @@ static void update_after_advect(oracle_ctx* c, const sph_params* p)
         const float sr_i = c->h2[i] * 2.f;
         int cnt = 0;
         for (int k = 0; k < np; k++) {
-            const sph_plane* pl = &c->planes[k];
-            float d = plane_probe(pl, x, y) / sr_i;
+            float d = sdf_probe(c, k, x, y) / sr_i;
             if (!(d < 1.f)) continue;
             const float eps = p->sdf_gradient_eps;
             const float inv_2eps = 1.f / (2.f * eps);
-            float gx = (plane_probe(pl, x + eps, y) - plane_probe(pl, x - eps, y)) * inv_2eps;
-            float gy = (plane_probe(pl, x, y + eps) - plane_probe(pl, x, y - eps)) * inv_2eps;
+            float gx = (sdf_probe(c, k, x + eps, y) - sdf_probe(c, k, x - eps, y)) * inv_2eps;
+            float gy = (sdf_probe(c, k, x, y + eps) - sdf_probe(c, k, x, y - eps)) * inv_2eps;
             float gn = sqrtf(orc_norm_sq(gx, gy));
             if (!(gn >= 0.00001f)) continue;
             gx /= gn;
@@ -185,7 +230,7 @@ static float iisph_aii(const oracle_ctx* c, const sph_params* p, uint64_t i)
 static inline float distance_to_boundary(const oracle_ctx* c, uint64_t i)
 {
     float m = INFINITY;
-    for (int k = 0; k < c->n_planes; k++) m = fminf(m, plane_probe(&c->planes[k], c->pos[2 * i], c->pos[2 * i + 1]));
+    for (int k = 0; k < c->n_planes; k++) m = fminf(m, sdf_probe(c, k, c->pos[2 * i], c->pos[2 * i + 1]));
     return m;
 }
 

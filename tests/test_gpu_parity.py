@@ -43,9 +43,9 @@ def forced(**kw):
                             iisph_max_avg_density_error=0.0, **kw)
 
 
-def make_pair(product_lib, oracle_lib, scn):
+def make_pair(product_lib, oracle_lib, scn, handler="AnalyticOverestimate"):
     pos, mass, vel = sc.init_particles(scn)
-    planes = sc.boundary_planes(scn.boundary)
+    planes = sc.boundary_planes(scn.boundary, handler)
     g = ffi.Context(product_lib, len(mass), planes)
     o = ffi.Context(oracle_lib, len(mass), planes)
     g.upload(mass, pos, vel)
@@ -234,6 +234,40 @@ def test_support_length_from_distribution(product_lib, oracle_lib, mode):
         assert h.max() > 1.05 * h.min()        # the estimate really moved h away from the mass-derived value
     for f in ALL_FIELDS:
         assert rel_err(g.download(f), o.download(f)) < TOL.get(f, REL_TOL_FIELDS), f
+
+
+@pytest.mark.parametrize("solver", ["HybridDFSPH", "IISPH"])
+def test_sdf2d_polygon_boundary(product_lib, oracle_lib, solver):
+    """init_boundary_handler: AnalyticUnderestimate (47 of the reference's media configs): ONE Sdf2D box polygon
+    (sdf/sdf2d.rs) -- distance to the nearest wall or corner -- instead of four planes."""
+    g, o = make_pair(product_lib, oracle_lib, sc.dam_break_small(40, 36, 1 / 40), "AnalyticUnderestimate")
+    p = forced(max_iters=3, pressure_solver_method=solver, check_neighborhood=True).to_ffi()
+    for s in range(6):
+        sg, so = g.step(p), o.step(p)
+        assert sg.dt == so.dt
+    for f in BITEXACT:
+        assert np.array_equal(g.download(f), o.download(f)), f
+    lam = o.download("lambda_sum")
+    assert lam.max() > 0 and (lam > 0).sum() > 40
+    assert_same_neighbor_sets(g, o)
+    for f in ALL_FIELDS:
+        assert rel_err(g.download(f), o.download(f)) < TOL.get(f, REL_TOL_FIELDS), f
+    # the corner particle sees ONE wall distance here, two summed planes in the overestimate
+    g2, o2 = make_pair(product_lib, oracle_lib, sc.dam_break_small(40, 36, 1 / 40), "AnalyticOverestimate")
+    o2.step(p)
+    o3 = make_pair(product_lib, oracle_lib, sc.dam_break_small(40, 36, 1 / 40), "AnalyticUnderestimate")[1]
+    o3.step(p)
+    assert o2.download("lambda_sum").max() > 1.5 * o3.download("lambda_sum").max()
+
+
+def test_polygon_boundary_rejects_degenerate_input(product_lib):
+    """Sdf2DConnectedComponents::from_points asserts (sdf2d.rs:43, 59) come back as SPH_ERR_INVALID_ARGUMENT."""
+    with pytest.raises(ffi.SphError) as e:
+        ffi.Context(product_lib, 16, sc.BoundaryPolygon([(0.0, 0.0), (0.0, 0.0), (1.0, 1.0)]))   # zero-length edge
+    assert e.value.status == 1
+    with pytest.raises(ffi.SphError) as e:
+        ffi.Context(product_lib, 16, sc.BoundaryPolygon([(0.0, 0.0), (1.0, 0.0)]))                 # fewer than 3 points
+    assert e.value.status == 1
 
 
 def test_free_running_iteration_counts(product_lib, oracle_lib):

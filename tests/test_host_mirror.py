@@ -67,6 +67,8 @@ def test_add_fluid_block_layout():
 def test_scene_yaml():
     scn = sc.SceneConfig.from_yaml(str(REPO / "tests" / "golden" / "default-scene.yaml"))
     assert scn.boundary.type == "box" and scn.boundary.width == 2 and len(scn.blocks) == 2
+    poly = sc.boundary_planes(scn.boundary, "AnalyticUnderestimate")   # Sdf2D::new_boundary_box (sdf2d.rs:167-179)
+    assert poly.points == [(-1.0, -1.0), (1.0, -1.0), (1.0, 1.0), (-1.0, 1.0)]
     with pytest.raises(NotImplementedError):
-        sc.boundary_planes(scn.boundary, "AnalyticUnderestimate")
+        sc.boundary_planes(scn.boundary, "Particles")
     assert sc.boundary_planes(scn.boundary, "NoBoundary") == []
