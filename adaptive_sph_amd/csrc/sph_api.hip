@@ -164,6 +164,39 @@ __global__ __launch_bounds__(256) void k_header_final(const HeaderOut* __restric
     }
 }
 
+// the same reduction over the partials the integrating final sweep wrote (one per 256-particle block); it runs behind that
+// sweep and, like it, only once the stop decision has been taken
+__global__ __launch_bounds__(256) void k_header_ahead(const HeaderOut* __restrict__ partials, uint32_t nparts, const SolverCtrl* __restrict__ ctrl,
+                                                       HeaderOut* __restrict__ out)
+{
+    if (ctrl->done == 0u) return;
+    const float INF = __uint_as_float(0x7f800000u);
+    HeaderOut o{INF, INF, -INF, -INF, 0.f, INF, INF, 0};
+    for (uint32_t k = threadIdx.x; k < nparts; k += 256) {
+        const HeaderOut q = partials[k];
+        o.min_x = fminf(o.min_x, q.min_x); o.min_y = fminf(o.min_y, q.min_y);
+        o.max_x = fmaxf(o.max_x, q.max_x); o.max_y = fmaxf(o.max_y, q.max_y);
+        o.h_max = fmaxf(o.h_max, q.h_max); o.h_min = fminf(o.h_min, q.h_min);
+        o.min_cfl = fminf(o.min_cfl, q.min_cfl);
+    }
+    o.min_x = wave_min(o.min_x); o.min_y = wave_min(o.min_y); o.max_x = wave_max(o.max_x); o.max_y = wave_max(o.max_y);
+    o.h_max = wave_max(o.h_max); o.h_min = wave_min(o.h_min); o.min_cfl = wave_min(o.min_cfl);
+    __shared__ HeaderOut s[4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) s[w] = o;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        HeaderOut r = s[0];
+        for (int k = 1; k < 4; k++) {
+            r.min_x = fminf(r.min_x, s[k].min_x); r.min_y = fminf(r.min_y, s[k].min_y);
+            r.max_x = fmaxf(r.max_x, s[k].max_x); r.max_y = fmaxf(r.max_y, s[k].max_y);
+            r.h_max = fmaxf(r.h_max, s[k].h_max); r.h_min = fminf(r.h_min, s[k].h_min);
+            r.min_cfl = fminf(r.min_cfl, s[k].min_cfl);
+        }
+        *out = r;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_pack_upload(uint32_t n, const float* __restrict__ mass, const float2* __restrict__ pos,
                                                       const float2* __restrict__ velin, float4* __restrict__ pm, float2* __restrict__ vel,
                                                       uint32_t* __restrict__ orig, float* __restrict__ lvl, float* __restrict__ lvlold,
@@ -315,6 +348,7 @@ static int alloc_particle_buffers(sph_ctx* c)
     HIPCHK(c, c->nl.ensure(sweep_list_bytes((uint32_t)n)));
     HIPCHK(c, c->nl_ok.ensure(n));
     HIPCHK(c, c->red_partials.ensure(sizeof(SolverPartial) * (size_t)solver_reduce_blocks((uint32_t)n)));
+    HIPCHK(c, c->hdr_ahead_partials.ensure(sizeof(HeaderOut) * (size_t)solver_reduce_blocks((uint32_t)n)));
     return SPH_OK;
 }
 
@@ -410,7 +444,7 @@ extern "C" void sph_destroy(sph_ctx* c)
     dist_release(c);
     DevBuf* all[] = {&c->pm[0], &c->pm[1], &c->vel[0], &c->vel[1], &c->orig[0], &c->orig[1], &c->lvl[0], &c->lvl[1], &c->lvlold[0],
                      &c->lvlold[1], &c->vel_tmp, &c->key[0], &c->key[1], &c->val[0], &c->val[1], &c->sort_scratch, &c->cxy, &c->cell_start,
-                     &c->cs_scratch, &c->h2n[0], &c->h2n[1], &c->lam_prev, &c->nl, &c->nlx, &c->tile_raw, &c->tile_h, &c->lvl_tmp, &c->lvl_nrm, &c->lvl_state, &c->lvl_when, &c->lvl_mark, &c->flag_surface,
+                     &c->cs_scratch, &c->hdr_ahead_partials, &c->h2n[0], &c->h2n[1], &c->lam_prev, &c->nl, &c->nlx, &c->tile_raw, &c->tile_h, &c->lvl_tmp, &c->lvl_nrm, &c->lvl_state, &c->lvl_when, &c->lvl_mark, &c->flag_surface,
                      &c->flag_insufficient, &c->size_class, &c->stash, &c->nl_ext, &c->nlx_ext, &c->nl_ok, &c->mrho, &c->pt0, &c->pt1, &c->rho, &c->lam_sum, &c->lam_grad, &c->constf, &c->aii, &c->src, &c->p0, &c->p1, &c->pacc, &c->dens_err,
                      &c->stat, &c->ncount, &c->planes_d, &c->lam_lut, &c->dlam_lut, &c->hdr_partials, &c->hdr_out, &c->ctrl, &c->status,
                      &c->n_tiles, &c->red_partials, &c->scratch};
@@ -450,6 +484,7 @@ extern "C" int sph_upload(sph_ctx* c, uint64_t n, const float* mass, const float
     c->dist.n_tot = (uint32_t)n;
     c->grid_valid = false;
     c->have_level = false;
+    c->hdr_ahead = false;
     if (n == 0) return SPH_OK;
     // stage host arrays through scratch buffers: mass -> key[1], pos -> scratch, vel -> vel_tmp
     HIPCHK(c, hipMemcpyAsync(c->key[1].p, mass, n * sizeof(float), hipMemcpyHostToDevice, s));
@@ -598,6 +633,7 @@ extern "C" int sph_upload_field(sph_ctx* c, int field, const void* src, uint64_t
         return c->fail(SPH_ERR_INVALID_ARGUMENT, "field %d cannot be uploaded", field);
     if (c->dist.on && c->dist.have_flags) return c->fail(SPH_ERR_INVALID_ARGUMENT, "slab contexts accept field uploads only right after sph_upload");
     const uint32_t n = (uint32_t)c->n;
+    c->hdr_ahead = false;   // the header computed at the end of the last step no longer describes the state
     if (bytes != (uint64_t)n * r.elem) return c->fail(SPH_ERR_INVALID_ARGUMENT, "field %d: size mismatch", field);
     if (n == 0) return SPH_OK;
     hipStream_t s = c->stream;
@@ -743,6 +779,12 @@ void launch_header(sph_ctx* c, uint32_t n, float rest_density, int from_mass /* 
     hipLaunchKernelGGL(k_header, dim3(nb), dim3(256), 0, s, c->pm[c->pcur].as<float4>(), c->vel[c->cur].as<float2>(), n, rest_density, from_mass,
                        c->h2n[c->cur].as<float>(), c->hdr_partials.as<HeaderOut>());
     hipLaunchKernelGGL(k_header_final, dim3(1), dim3(256), 0, s, c->hdr_partials.as<HeaderOut>(), nb, out_dev);
+}
+
+void launch_header_ahead(sph_ctx* c, uint32_t nblocks, HeaderOut* out_dev)
+{
+    ProfScope ps(&c->prof, "header_ahead", c->stream);
+    hipLaunchKernelGGL(k_header_ahead, dim3(1), dim3(256), 0, c->stream, c->hdr_ahead_partials.as<HeaderOut>(), nblocks, c->ctrl.as<SolverCtrl>(), out_dev);
 }
 
 void launch_publish(sph_ctx* c)

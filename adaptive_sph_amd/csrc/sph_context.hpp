@@ -90,6 +90,9 @@ struct sph_ctx {
     GridP fgrid{};          // the grid the particles are sorted by (== grid in uniform scenes)
     int tile_ts = 0, tile_tsx = 0, tile_tsy = 0;
     DevBuf tile_raw, tile_h, nlx;
+    DevBuf hdr_ahead_partials;   // per sweep block: next step's header terms from the integrating final sweep
+    bool hdr_ahead = false;      // hdr_host already holds the header of the state on the device (no k_header needed)
+    float hdr_ahead_rest_density = 0.f;
     DevBuf h2n[2];     // ParticleVec::h2_next (FromDistribution* support-length estimation), ping-pong across the reorder
     DevBuf lam_prev;   // lambda_sum of the previous step in this step's order (estimate_h_next_from_distribution)
     // level estimation (simulation.rs:539-927), sorted order

@@ -125,6 +125,7 @@ struct SweepArgs {
     uint32_t* ncount;
     uint4* nl;          // neighbour list words (sph_sweeps.hip)
     uint4* nlx;         // explicit index lists (multi-resolution scenes)
+    HeaderOut* hdr_partials;   // per-block partials of the NEXT step's header, written by the integrating final sweep (or nullptr)
     int h_mode;         // support_length_estimation (SPH_H_*)
     float* h2_next;     // FromDistribution*: the estimate for the next step is written here by the density sweep
     const float* lam_prev;
@@ -182,5 +183,7 @@ void launch_level_propagate(hipStream_t s, Profiler* prof, const SweepArgs& a, c
 void launch_fill_stash(hipStream_t s, Profiler* prof, const SweepArgs& a, const LevelArgs& l, float* stash);
 void launch_level_smooth(hipStream_t s, Profiler* prof, const SweepArgs& a, const LevelArgs& l, const float4* pm_new, const float* in, float* out);
 void launch_classify(hipStream_t s, Profiler* prof, const SweepArgs& a, const LevelArgs& l, const float* level, const sph_params* p);
+// reduce the per-block header partials of the integrating final sweep into `out_dev` (skipped while the solve is not done)
+void launch_header_ahead(sph_ctx* c, uint32_t nblocks, HeaderOut* out_dev);
 void launch_vel_add_pacc(hipStream_t s, Profiler* prof, const SweepArgs& a);               // v += dt a^p
 void launch_integrate(hipStream_t s, Profiler* prof, const SweepArgs& a, float4* pm_out, int mode);  // 0: v+=dt a; x+=dt v   1: hybrid

@@ -54,6 +54,7 @@ SweepArgs make_args(sph_ctx* c, const StepP& sp)
     a.ncount = c->ncount.as<uint32_t>();
     a.nl = c->nl.as<uint4>();
     a.nlx = c->nlx.as<uint4>();
+    a.hdr_partials = (!c->dist.on) ? c->hdr_ahead_partials.as<HeaderOut>() : nullptr;
     a.h_mode = SPH_H_FROM_MASS;   // set by the step driver
     a.h2_next = c->h2n[k].as<float>();
     a.lam_prev = c->lam_prev.as<float>();
@@ -829,6 +830,8 @@ static int pressure_iterations(Group& G, std::vector<Member>& M, float max_avg_e
         for (auto& m : M) {
             (void)hipSetDevice(m.c->device);
             if (m.n) launch_pressure_accel(m.c->stream, &m.c->prof, m.a, -1, tail, m.c->pm[m.c->pcur ^ 1].as<float4>());
+            if (m.n && tail >= 2 /* TAIL_VX, TAIL_HYBRID */ && m.a.hdr_partials)
+                launch_header_ahead(m.c, solver_reduce_blocks(m.n), m.c->hdr_host_dev);
         }
         if ((rc = sync_ctrl(G))) return rc;
         if (M[0].c->ctrl_host->done) break;
@@ -896,11 +899,18 @@ static int group_step(Group& G, const sph_params* p, sph_step_stats* outs)
         if ((rc = partition_and_migrate(G, M))) return rc;  // only needs the cuts
     }
     g_trace.mark(0);
-    for (auto& m : M) {
-        (void)hipSetDevice(m.c->device);
-        launch_header(m.c, (uint32_t)m.c->n, p->rest_density, h_from_mass_mode ? 1 : 2, m.c->hdr_host_dev);
+    // The integrating final sweep of the previous step already reduced this step's header into hdr_host (sph_sweeps.hip,
+    // OpPressureAccel::epilogue): nothing to launch, nothing to wait for -- unless the host touched the state, the
+    // smoothing lengths are not the mass-derived ones, or the particles are about to be re-partitioned.
+    const bool header_ready = !G.multi() && h_from_mass_mode && c0->hdr_ahead && c0->hdr_ahead_rest_density == p->rest_density;
+    if (!header_ready) {
+        for (auto& m : M) {
+            (void)hipSetDevice(m.c->device);
+            launch_header(m.c, (uint32_t)m.c->n, p->rest_density, h_from_mass_mode ? 1 : 2, m.c->hdr_host_dev);
+        }
+        if ((rc = agree(G, wait_all(G)))) return rc;
     }
-    if ((rc = agree(G, wait_all(G)))) return rc;
+    c0->hdr_ahead = false;
     for (size_t i = 0; i < M.size(); i++) {
         const HeaderOut h = *M[i].c->hdr_host;
         red[i][0] = M[i].c->n ? -h.h_max : 0.f;
@@ -1210,6 +1220,9 @@ static int group_step(Group& G, const sph_params* p, sph_step_stats* outs)
         Member& m = M[i];
         sph_ctx* c = m.c;
         c->pcur ^= 1;  // integrated positions live in the other pm buffer; the old one keeps the pre-step snapshot
+        // every solver mode ends in an integrating final sweep, which left the next step's header in hdr_host
+        c->hdr_ahead = !G.multi() && h_from_mass_mode && m.n > 0 && m.a.hdr_partials != nullptr;
+        c->hdr_ahead_rest_density = p->rest_density;
         c->last_div_iters = m.st.div_solver.iters;
         c->last_dens_iters = m.st.density_solver.iters;
         c->time += dt;  // simulation.rs:2724-2725
@@ -1278,6 +1291,7 @@ extern "C" int sph_dist_configure(sph_ctx* c, int rank, int n_ranks, float cut_l
     c->dist.cut_lo = cut_lo;
     c->dist.cut_hi = cut_hi;
     c->dist.have_flags = false;
+    c->hdr_ahead = false;
     c->dist.n_tot = (uint32_t)c->n;
     if (c->dist.on) {
         HIPCHK(c, hipSetDevice(c->device));

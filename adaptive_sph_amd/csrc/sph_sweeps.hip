@@ -791,7 +791,7 @@ enum { TAIL_NONE = 0, TAIL_VEL = 1, TAIL_VX = 2, TAIL_HYBRID = 3 };
 template <class MathT>
 struct OpPressureAccel {
     typedef MathT Math;
-    static constexpr bool HAS_EPILOGUE = false, SKIP_SELF = true;
+    static constexpr bool HAS_EPILOGUE = true, SKIP_SELF = true;   // epilogue: next step's header (integrating tails only)
     static constexpr bool EXTENDED = false;
     __device__ constexpr float krange() const { return 2.f; }
     typedef float NB;  // p_j / (rho_j * rho_j)
@@ -812,14 +812,42 @@ struct OpPressureAccel {
     StepP sp;
     int iter;  // >= 0: Jacobi iteration `iter` (reads buffer iter&1, skipped when the solve is done); < 0: final sweep
     int tail;
+    // The integrating tails know the positions and velocities the NEXT step starts from: they also reduce that step's
+    // header (bounding box, h and mass range, CFL term -- what k_header computes) per block, so the next step starts
+    // without the header kernels and without the host wait behind them.  nullptr: not wanted.
+    HeaderOut* __restrict__ hdr_partials;
     struct Acc {
         float ax, ay, p1t;
         const float* pt;
         const float* p;
+        float nx, ny, ncfl, nh;   // next-step header contributions of this particle
     };
     __device__ bool skip() const { return iter >= 0 ? ctrl->done != 0u : ctrl->done == 0u; }
     __device__ bool lane_skip(uint32_t) const { return false; }
-    __device__ void epilogue(Acc&, bool, uint32_t) const {}
+    __device__ void epilogue(Acc& a, bool active, uint32_t blk) const
+    {
+        if (!hdr_partials || tail < TAIL_VX) return;   // launch-uniform
+        const float INF = __uint_as_float(0x7f800000u);
+        float mnx = active ? a.nx : INF, mxx = active ? a.nx : -INF, mny = active ? a.ny : INF, mxy = active ? a.ny : -INF;
+        float hmx = active ? a.nh : 0.f, hmn = active ? a.nh : INF;
+        float cfl = active ? a.ncfl : INF;
+        mnx = wave_min(mnx); mny = wave_min(mny); mxx = wave_max(mxx); mxy = wave_max(mxy);
+        hmx = wave_max(hmx); hmn = wave_min(hmn); cfl = wave_min(cfl);
+        __shared__ HeaderOut s_h[SWEEP_THREADS / 64];
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        if (lane == 0) s_h[w] = HeaderOut{mnx, mny, mxx, mxy, hmx, hmn, cfl, 0};
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            HeaderOut o = s_h[0];
+            for (int k = 1; k < SWEEP_THREADS / 64; k++) {
+                o.min_x = fminf(o.min_x, s_h[k].min_x); o.min_y = fminf(o.min_y, s_h[k].min_y);
+                o.max_x = fmaxf(o.max_x, s_h[k].max_x); o.max_y = fmaxf(o.max_y, s_h[k].max_y);
+                o.h_max = fmaxf(o.h_max, s_h[k].h_max); o.h_min = fminf(o.h_min, s_h[k].h_min);
+                o.min_cfl = fminf(o.min_cfl, s_h[k].min_cfl);
+            }
+            hdr_partials[blk] = o;
+        }
+    }
     __device__ float4 loadA(uint32_t j) const { return pm[j]; }
     __device__ NB nb(const Acc& a, uint32_t j, float4) const { return a.pt[j]; }
     __device__ void init(Acc& a) const
@@ -857,12 +885,12 @@ struct OpPressureAccel {
         if (tail != TAIL_NONE) {
             const float dt = sp.dt;
             float2 v = vel[i];
+            float4 p = Ai;   // integrated position (tails VX / HYBRID)
             if (tail == TAIL_VEL) {
                 v.x += dt * ap.x;
                 v.y += dt * ap.y;
                 if (!isfinite(v.x) || !isfinite(v.y)) raise_error(status, SPH_ERR_VELOCITY_NOT_FINITE, orig[i]);
             } else if (tail == TAIL_VX) {
-                float4 p = Ai;
                 v.x += dt * ap.x;
                 v.y += dt * ap.y;
                 p.x += dt * v.x;
@@ -870,7 +898,6 @@ struct OpPressureAccel {
                 if (!isfinite(v.x) || !isfinite(v.y)) raise_error(status, SPH_ERR_VELOCITY_NOT_FINITE, orig[i]);
                 pm_out[i] = p;
             } else {
-                float4 p = Ai;
                 p.x += dt * v.x + dt * dt * ap.x;
                 p.y += dt * v.y + dt * dt * ap.y;
                 v.x += dt * ap.x * sp.hyb_vfactor;
@@ -879,6 +906,13 @@ struct OpPressureAccel {
                 pm_out[i] = p;
             }
             vel[i] = v;
+            if (tail >= TAIL_VX) {   // k_header's per-particle terms (sph_api.hip), from the values just written
+                a.nx = p.x;
+                a.ny = p.y;
+                a.nh = Ai.w;
+                const float sr = Ai.w * 2.f;
+                a.ncfl = sr * sr / ((v.x * v.x + v.y * v.y) + 0.01f);   // simulation.rs:2182-2189
+            }
         }
         return wall;
     }
@@ -1539,7 +1573,7 @@ void launch_pressure_accel(hipStream_t s, Profiler* prof, const SweepArgs& a, in
 {
     ProfScope ps(prof, iter >= 0 ? "pressure_accel" : "pressure_accel_final", s);
     SPH_DISPATCH(OpPressureAccel, false, a.pm, a.orig, a.rho, a.p0, a.p1, a.pt0, a.pt1, a.lam_grad, a.pacc, a.vel, pm_out, a.ctrl, a.status, a.sp,
-                 iter, tail)
+                 iter, tail, (iter < 0 && tail >= TAIL_VX) ? a.hdr_partials : nullptr)
 }
 
 void launch_jacobi_update(hipStream_t s, Profiler* prof, const SweepArgs& a, int iter, int residual_density)

@@ -270,6 +270,34 @@ def test_polygon_boundary_rejects_degenerate_input(product_lib):
     assert e.value.status == 1
 
 
+def test_host_writes_between_steps_invalidate_the_precomputed_header(product_lib, oracle_lib):
+    """The last sweep of a step leaves the NEXT step's header (bounding box, CFL term) behind; a host write in between
+    (adaptivity: sph_upload_field) must make the next step recompute it.  Fast velocities make dt CFL-limited, so a stale
+    header would show up in dt."""
+    g, o = make_pair(product_lib, oracle_lib, sc.dam_break_small(32, 32, 1 / 32))
+    p = forced(max_iters=3).to_ffi()
+    for s in range(2):
+        sg, so = g.step(p), o.step(p)
+        assert sg.dt == so.dt
+    v = o.download("velocity")
+    v[:, 0] += 30.0
+    x = o.download("position")
+    x[:, 0] += 0.25          # the block moves: the grid origin of the next step changes with it
+    for c in (g, o):
+        c.upload_field("velocity", v)
+        c.upload_field("position", x)
+    sg, so = g.step(p), o.step(p)
+    assert so.dt < 0.5 * p.max_dt                  # CFL-limited now
+    assert sg.dt == so.dt
+    gg, og = g.grid(), o.grid()
+    assert (gg.cells_min_x, gg.size_x) == (og.cells_min_x, og.size_x)
+    assert np.array_equal(g.download("cell_index"), o.download("cell_index"))
+    sg, so = g.step(p), o.step(p)                  # and the step after that uses the precomputed header again
+    assert abs(sg.dt - so.dt) <= 1e-5 * so.dt
+    for f in ["position", "velocity", "density"]:
+        assert rel_err(g.download(f), o.download(f)) < REL_TOL_FIELDS, f
+
+
 def test_free_running_iteration_counts(product_lib, oracle_lib):
     g, o = make_pair(product_lib, oracle_lib, sc.dam_break_small(48, 48, 1 / 48))
     p = dam_break_params().to_ffi()
