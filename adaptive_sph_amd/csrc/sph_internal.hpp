@@ -89,10 +89,11 @@ void launch_reorder(hipStream_t s, Profiler* prof, uint32_t n, GridP g, const ui
                     const float4* pm_in, const float2* vel_in, const uint32_t* orig_in, const float* lvl_in,
                     const float* lvlold_in, float4* pm_out, float2* vel_out, uint32_t* orig_out, float* lvl_out,
                     float* lvlold_out, uint32_t* cxy, const float* h2n_in = nullptr, float* h2n_out = nullptr,
-                    const float* lam_in = nullptr, float* lam_prev_out = nullptr);
+                    const float* lam_in = nullptr, float* lam_prev_out = nullptr, void* cell_start_scratch = nullptr);
 size_t cell_start_scratch_bytes();
 void launch_cell_start(hipStream_t s, Profiler* prof, const uint32_t* sorted_key, uint32_t n, uint32_t ncells,
-                       uint32_t* cell_start /* [ncells+1] */, void* scratch /* cell_start_scratch_bytes() */);
+                       uint32_t* cell_start /* [ncells+1] */, void* scratch /* cell_start_scratch_bytes() */,
+                       bool count_zeroed = false /* launch_reorder(.., scratch) already cleared the work-list counter */);
 void launch_tile_hmax(hipStream_t s, Profiler* prof, uint32_t n, const float4* pm, GridP g, int ts, int tsx, int tsy, uint32_t* raw,
                       uint32_t* out /* dilated */);
 

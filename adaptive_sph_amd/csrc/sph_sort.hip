@@ -183,9 +183,11 @@ __global__ __launch_bounds__(256) void k_reorder(uint32_t n, GridP g, const uint
                                                   uint32_t* __restrict__ orig_out, float* __restrict__ lvl_out,
                                                   float* __restrict__ lvlold_out, uint32_t* __restrict__ cxy,
                                                   const float* __restrict__ h2n_in, float* __restrict__ h2n_out,
-                                                  const float* __restrict__ lam_in, float* __restrict__ lam_prev_out)
+                                                  const float* __restrict__ lam_in, float* __restrict__ lam_prev_out,
+                                                  uint32_t* __restrict__ zero_word)
 {
     uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i == 0 && zero_word) *zero_word = 0u;   // work-list counter of the cell-range kernels that follow
     if (i >= n) return;
     uint32_t src = perm[i];
     if (h2n_in) h2n_out[i] = h2n_in[src];
@@ -204,11 +206,13 @@ __global__ __launch_bounds__(256) void k_reorder(uint32_t n, GridP g, const uint
 void launch_reorder(hipStream_t s, Profiler* prof, uint32_t n, GridP g, const uint32_t* sorted_key, const uint32_t* perm,
                     const float4* pm_in, const float2* vel_in, const uint32_t* orig_in, const float* lvl_in,
                     const float* lvlold_in, float4* pm_out, float2* vel_out, uint32_t* orig_out, float* lvl_out,
-                    float* lvlold_out, uint32_t* cxy, const float* h2n_in, float* h2n_out, const float* lam_in, float* lam_prev_out)
+                    float* lvlold_out, uint32_t* cxy, const float* h2n_in, float* h2n_out, const float* lam_in, float* lam_prev_out,
+                    void* cell_start_scratch)
 {
     ProfScope ps(prof, "reorder", s);
     hipLaunchKernelGGL(k_reorder, dim3((n + 255) / 256), dim3(256), 0, s, n, g, sorted_key, perm, pm_in, vel_in, orig_in, lvl_in,
-                       lvlold_in, pm_out, vel_out, orig_out, lvl_out, lvlold_out, cxy, h2n_in, h2n_out, lam_in, lam_prev_out);
+                       lvlold_in, pm_out, vel_out, orig_out, lvl_out, lvlold_out, cxy, h2n_in, h2n_out, lam_in, lam_prev_out,
+                       (uint32_t*)cell_start_scratch);
 }
 
 // cell_start[c] = index of the first sorted particle whose cell is >= c; cell_start[ncells] = n.
@@ -266,12 +270,12 @@ __global__ __launch_bounds__(256) void k_cell_fill(const CellGap* __restrict__ w
 size_t cell_start_scratch_bytes() { return (size_t)CS_WORK_CAP * sizeof(CellGap) + 16; }
 
 void launch_cell_start(hipStream_t s, Profiler* prof, const uint32_t* sorted_key, uint32_t n, uint32_t ncells, uint32_t* cell_start,
-                       void* scratch)
+                       void* scratch, bool count_zeroed)
 {
     ProfScope ps(prof, "cell_start", s);
     uint32_t* count = (uint32_t*)scratch;
     CellGap* work = (CellGap*)((char*)scratch + 16);
-    (void)hipMemsetAsync(count, 0, sizeof(uint32_t), s);
+    if (!count_zeroed) (void)hipMemsetAsync(count, 0, sizeof(uint32_t), s);
     hipLaunchKernelGGL(k_cell_start, dim3((n + 1 + 255) / 256), dim3(256), 0, s, sorted_key, n, ncells, cell_start, work, count);
     hipLaunchKernelGGL(k_cell_fill, dim3(512), dim3(256), 0, s, work, count, cell_start);
 }

@@ -1025,6 +1025,7 @@ static int group_step(Group& G, const sph_params* p, sph_step_stats* outs)
         hipStream_t s = c->stream;
         Profiler* prof = &c->prof;
         int k = c->cur;
+        HIPCHK(c, c->cs_scratch.ensure(cell_start_scratch_bytes()));
         if (n) {
             launch_cell_keys(s, prof, c->pm[c->pcur].as<float4>(), n, g, c->key[0].as<uint32_t>(), c->val[0].as<uint32_t>());
             int res = radix_sort_pairs(s, prof, c->key[0].as<uint32_t>(), c->val[0].as<uint32_t>(), c->key[1].as<uint32_t>(),
@@ -1037,12 +1038,11 @@ static int group_step(Group& G, const sph_params* p, sph_step_stats* outs)
                            c->orig[k].as<uint32_t>(), c->lvl[k].as<float>(), c->lvlold[k].as<float>(), c->pm[c->pcur ^ 1].as<float4>(),
                            c->vel[k ^ 1].as<float2>(), c->orig[k ^ 1].as<uint32_t>(), c->lvl[k ^ 1].as<float>(), c->lvlold[k ^ 1].as<float>(),
                            c->cxy.as<uint32_t>(), c->h2n[k].as<float>(), c->h2n[k ^ 1].as<float>(), c->lam_sum.as<float>(),
-                           c->lam_prev.as<float>());
+                           c->lam_prev.as<float>(), c->cs_scratch.p);
             c->cur = k ^ 1;
             c->pcur ^= 1;
         }
-        HIPCHK(c, c->cs_scratch.ensure(cell_start_scratch_bytes()));
-        launch_cell_start(s, prof, c->key[0].as<uint32_t>(), n, g.ncells, c->cell_start.as<uint32_t>(), c->cs_scratch.p);
+        launch_cell_start(s, prof, c->key[0].as<uint32_t>(), n, g.ncells, c->cell_start.as<uint32_t>(), c->cs_scratch.p, n > 0);
         if (c->tile_ts > 0) {
             const size_t nt = (size_t)c->tile_tsx * (size_t)c->tile_tsy;
             HIPCHK(c, c->tile_raw.ensure(nt * 4));
@@ -1151,7 +1151,7 @@ static int group_step(Group& G, const sph_params* p, sph_step_stats* outs)
     auto begin_solve = [&](int kind, int residual_density) {
         for (auto& m : M) {
             (void)hipSetDevice(m.c->device);
-            (void)hipMemsetAsync(m.c->ctrl.p, 0, sizeof(SolverCtrl), m.c->stream);
+            if (!m.n) (void)hipMemsetAsync(m.c->ctrl.p, 0, sizeof(SolverCtrl), m.c->stream);   // else: reset by the source-term sweep
             if (m.n) launch_source_term(m.c->stream, &m.c->prof, m.a, kind, residual_density);  // + Jacobi iteration 0
         }
     };

@@ -678,6 +678,7 @@ struct OpSource {
     float* __restrict__ pterm_out;
     float* __restrict__ dens_err;
     SolverPartial* __restrict__ partials;
+    SolverCtrl* __restrict__ ctrl_reset;   // the solve's control block starts from zero (first kernel of a solve)
     DeviceStatus* status;
     StepP sp;
     int kind;  // 0 divergence, 1 full, 2 only density
@@ -770,7 +771,11 @@ struct OpSource {
         }
         return wall;
     }
-    __device__ void epilogue(Acc& a, bool active, uint32_t blk) const { solver_block_partial(partials, active ? a.cls : 3u, a.err, blk); }
+    __device__ void epilogue(Acc& a, bool active, uint32_t blk) const
+    {
+        solver_block_partial(partials, active ? a.cls : 3u, a.err, blk);
+        if (blk == 0u && threadIdx.x == 0) *ctrl_reset = SolverCtrl{};
+    }
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -1566,7 +1571,7 @@ void launch_source_term(hipStream_t s, Profiler* prof, const SweepArgs& a, int k
 {
     ProfScope ps(prof, "source_term", s);
     SPH_DISPATCH(OpSource, false, a.pm, a.orig, a.rho, a.mrho, a.vel, a.lam_grad, a.aii, a.src, a.p1, a.pt1, a.dens_err,
-                 (SolverPartial*)a.partials, a.status, a.sp, kind, residual_density)
+                 (SolverPartial*)a.partials, a.ctrl, a.status, a.sp, kind, residual_density)
 }
 
 void launch_pressure_accel(hipStream_t s, Profiler* prof, const SweepArgs& a, int iter, int tail, float4* pm_out)
