@@ -45,19 +45,19 @@ hipEvent_t Profiler::get_event()
         return e;
     }
     hipEvent_t e;
-    hipEventCreate(&e);
+    (void)hipEventCreate(&e);
     return e;
 }
 void Profiler::begin(const char* name, hipStream_t s)
 {
     cur = find(name);
     cur_a = get_event();
-    hipEventRecord(cur_a, s);
+    (void)hipEventRecord(cur_a, s);
 }
 void Profiler::end(hipStream_t s)
 {
     hipEvent_t b = get_event();
-    hipEventRecord(b, s);
+    (void)hipEventRecord(b, s);
     pending.push_back(Pending{cur, cur_a, b});
     cur = -1;
 }
@@ -83,10 +83,10 @@ void Profiler::reset()
 Profiler::~Profiler()
 {
     for (auto& p : pending) {
-        hipEventDestroy(p.a);
-        hipEventDestroy(p.b);
+        (void)hipEventDestroy(p.a);
+        (void)hipEventDestroy(p.b);
     }
-    for (auto e : pool) hipEventDestroy(e);
+    for (auto e : pool) (void)hipEventDestroy(e);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -392,12 +392,12 @@ extern "C" int sph_create(uint64_t n_capacity, int device_id, const sph_plane* p
     // BoundaryWinchenbach2020::new (boundary_winchenbach2020.rs:33-36)
     std::vector<float> lam, dlam;
     sph_lambda::build_luts(lam, dlam);
-    hipMemcpy(c->lam_lut.p, lam.data(), lam.size() * 4, hipMemcpyHostToDevice);
-    hipMemcpy(c->dlam_lut.p, dlam.data(), dlam.size() * 4, hipMemcpyHostToDevice);
-    hipMemcpy(c->planes_d.p, &c->bnd_h, sizeof(BoundaryP), hipMemcpyHostToDevice);
-    hipMemset(c->status.p, 0, sizeof(DeviceStatus));
-    hipMemset(c->ctrl.p, 0, sizeof(SolverCtrl));
-    hipDeviceSynchronize();
+    (void)hipMemcpy(c->lam_lut.p, lam.data(), lam.size() * 4, hipMemcpyHostToDevice);
+    (void)hipMemcpy(c->dlam_lut.p, dlam.data(), dlam.size() * 4, hipMemcpyHostToDevice);
+    (void)hipMemcpy(c->planes_d.p, &c->bnd_h, sizeof(BoundaryP), hipMemcpyHostToDevice);
+    (void)hipMemset(c->status.p, 0, sizeof(DeviceStatus));
+    (void)hipMemset(c->ctrl.p, 0, sizeof(SolverCtrl));
+    (void)hipDeviceSynchronize();
     *out = c;
     return SPH_OK;
 }
@@ -439,8 +439,8 @@ extern "C" int sph_set_boundary_polygon(sph_ctx* c, const float* pts, int n)
 extern "C" void sph_destroy(sph_ctx* c)
 {
     if (!c) return;
-    hipSetDevice(c->device);
-    if (c->stream) hipStreamSynchronize(c->stream);
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
     dist_release(c);
     DevBuf* all[] = {&c->pm[0], &c->pm[1], &c->vel[0], &c->vel[1], &c->orig[0], &c->orig[1], &c->lvl[0], &c->lvl[1], &c->lvlold[0],
                      &c->lvlold[1], &c->vel_tmp, &c->key[0], &c->key[1], &c->val[0], &c->val[1], &c->sort_scratch, &c->cxy, &c->cell_start,
@@ -449,14 +449,14 @@ extern "C" void sph_destroy(sph_ctx* c)
                      &c->stat, &c->ncount, &c->planes_d, &c->lam_lut, &c->dlam_lut, &c->hdr_partials, &c->hdr_out, &c->ctrl, &c->status,
                      &c->n_tiles, &c->red_partials, &c->scratch};
     for (auto b : all) b->release();
-    if (c->hdr_host) hipHostFree(c->hdr_host);
-    if (c->ctrl_host) hipHostFree(c->ctrl_host);
-    if (c->status_host) hipHostFree(c->status_host);
-    if (c->lvl_changed) hipHostFree(c->lvl_changed);
+    if (c->hdr_host) (void)hipHostFree(c->hdr_host);
+    if (c->ctrl_host) (void)hipHostFree(c->ctrl_host);
+    if (c->status_host) (void)hipHostFree(c->status_host);
+    if (c->lvl_changed) (void)hipHostFree(c->lvl_changed);
     for (auto& e : c->ev)
-        if (e) hipEventDestroy(e);
-    if (c->ev_sync) hipEventDestroy(c->ev_sync);
-    if (c->stream) hipStreamDestroy(c->stream);
+        if (e) (void)hipEventDestroy(e);
+    if (c->ev_sync) (void)hipEventDestroy(c->ev_sync);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
 
@@ -664,16 +664,16 @@ extern "C" int sph_profile_enable(sph_ctx* c, int enable)
 extern "C" int sph_profile_reset(sph_ctx* c)
 {
     if (!c) return SPH_ERR_INVALID_ARGUMENT;
-    hipSetDevice(c->device);
-    hipStreamSynchronize(c->stream);
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
     c->prof.reset();
     return SPH_OK;
 }
 extern "C" int sph_profile_get(sph_ctx* c, sph_kernel_time* out, int capacity, int* n_out)
 {
     if (!c || !n_out) return SPH_ERR_INVALID_ARGUMENT;
-    hipSetDevice(c->device);
-    hipStreamSynchronize(c->stream);
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
     c->prof.collect();
     int k = 0;
     for (auto& r : c->prof.recs) {

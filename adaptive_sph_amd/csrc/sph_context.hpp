@@ -17,7 +17,7 @@ struct DevBuf {
     hipError_t ensure(size_t need)
     {
         if (need <= bytes) return hipSuccess;
-        if (p) hipFree(p);
+        if (p) (void)hipFree(p);
         p = nullptr;
         bytes = 0;
         size_t grow = need + need / 4 + 256;
@@ -27,7 +27,7 @@ struct DevBuf {
     }
     void release()
     {
-        if (p) hipFree(p);
+        if (p) (void)hipFree(p);
         p = nullptr;
         bytes = 0;
     }
