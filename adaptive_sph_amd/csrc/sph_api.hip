@@ -392,12 +392,12 @@ extern "C" int sph_create(uint64_t n_capacity, int device_id, const sph_plane* p
     // BoundaryWinchenbach2020::new (boundary_winchenbach2020.rs:33-36)
     std::vector<float> lam, dlam;
     sph_lambda::build_luts(lam, dlam);
-    (void)hipMemcpy(c->lam_lut.p, lam.data(), lam.size() * 4, hipMemcpyHostToDevice);
-    (void)hipMemcpy(c->dlam_lut.p, dlam.data(), dlam.size() * 4, hipMemcpyHostToDevice);
-    (void)hipMemcpy(c->planes_d.p, &c->bnd_h, sizeof(BoundaryP), hipMemcpyHostToDevice);
-    (void)hipMemset(c->status.p, 0, sizeof(DeviceStatus));
-    (void)hipMemset(c->ctrl.p, 0, sizeof(SolverCtrl));
-    (void)hipDeviceSynchronize();
+    if (hipMemcpy(c->lam_lut.p, lam.data(), lam.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(c->dlam_lut.p, dlam.data(), dlam.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(c->planes_d.p, &c->bnd_h, sizeof(BoundaryP), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemset(c->status.p, 0, sizeof(DeviceStatus)) != hipSuccess || hipMemset(c->ctrl.p, 0, sizeof(SolverCtrl)) != hipSuccess ||
+        hipDeviceSynchronize() != hipSuccess)
+        return bail(SPH_ERR_DEVICE);
     *out = c;
     return SPH_OK;
 }
