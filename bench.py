@@ -274,4 +274,12 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except BaseException:  # noqa: BLE001
+        # a rank that dies while the others sit in a collective would hang the whole launch: report and leave at once
+        # (torch.distributed.run then tears the other ranks down)
+        import traceback
+        traceback.print_exc()
+        sys.stderr.flush()
+        os._exit(1)
