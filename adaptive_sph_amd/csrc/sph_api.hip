@@ -727,6 +727,42 @@ extern "C" int sph_profile_event_overhead(sph_ctx* c, double* microseconds)
     return SPH_OK;
 }
 
+__global__ __launch_bounds__(256) void k_copy4(const float4* __restrict__ src, float4* __restrict__ dst, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+
+extern "C" int sph_profile_copy_bandwidth(sph_ctx* c, uint64_t bytes, double* gb_per_s)
+{
+    if (!c || !gb_per_s || bytes < 1024) return SPH_ERR_INVALID_ARGUMENT;
+    HIPCHK(c, hipSetDevice(c->device));
+    DevBuf a, b;
+    HIPCHK(c, a.ensure(bytes));
+    HIPCHK(c, b.ensure(bytes));
+    HIPCHK(c, hipMemsetAsync(a.p, 0, bytes, c->stream));
+    hipEvent_t e0, e1;
+    HIPCHK(c, hipEventCreate(&e0));
+    HIPCHK(c, hipEventCreate(&e1));
+    const size_t n4 = bytes / 16;
+    double best = 0;
+    for (int rep = 0; rep < 6; rep++) {
+        HIPCHK(c, hipEventRecord(e0, c->stream));
+        hipLaunchKernelGGL(k_copy4, dim3(256 * 16), dim3(256), 0, c->stream, a.as<float4>(), b.as<float4>(), n4);
+        HIPCHK(c, hipEventRecord(e1, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        float ms = 0.f;
+        HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
+        const double g = 2.0 * (double)(n4 * 16) / (ms * 1e-3) / 1e9;
+        if (rep > 0 && g > best) best = g;   // first run warms up
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    a.release();
+    b.release();
+    *gb_per_s = best;
+    return SPH_OK;
+}
+
 extern "C" int sph_download_neighbors(sph_ctx* c, uint32_t* offsets, uint32_t* indices, uint64_t cap, uint64_t* n_indices)
 {
     if (!c) return SPH_ERR_INVALID_ARGUMENT;

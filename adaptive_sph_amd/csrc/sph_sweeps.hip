@@ -323,7 +323,9 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_sweep(Op op, SweepCommon c)
 // ------------------------------------------------------------------------------------------------
 struct NBNone {};
 
-template <class MathT>
+// HDIST: support_length_estimation FromDistribution* -- compiled apart, the density sweep is VALU-bound and the two
+// extra sums cost 3.5 us at N = 1M even behind a launch-uniform branch
+template <class MathT, bool HDIST>
 struct OpDensity {
     typedef MathT Math;
     static constexpr bool HAS_EPILOGUE = false, SKIP_SELF = false;
@@ -414,7 +416,7 @@ struct OpDensity {
     {
         const float w = m.w(r2, hij);
         a.sum += Aj.z * w;
-        if (h_mode != SPH_H_FROM_MASS) {   // launch-uniform
+        if (HDIST) {
             a.wsum += w;
             a.vwsum += (Aj.z / sp.rest_density) * w;
         }
@@ -429,7 +431,7 @@ struct OpDensity {
         if (!isfinite(d)) raise_error(status, SPH_ERR_DENSITY_NOT_FINITE, orig[i]);
         else if (!(d > 0.0001f)) raise_error(status, SPH_ERR_DENSITY_TOO_SMALL, orig[i]);
         if (a.cnt > 20000u) raise_error(status, SPH_ERR_TOO_MANY_NEIGHBORS, orig[i]);
-        if (h_mode != SPH_H_FROM_MASS) {
+        if (HDIST) {
             const float bv = lam_prev[i];
             float vol;
             if (h_mode == SPH_H_FROM_DISTRIBUTION2) vol = (Ai.z / sp.rest_density) / (a.vwsum + bv);
@@ -1548,10 +1550,20 @@ static MathUniform uniform_math(float h)
         launch_sweep<OPNAME<MathFast>, BUILD>(s, a, op);                                   \
     }
 
+template <class M>
+using OpDensityMass = OpDensity<M, false>;
+template <class M>
+using OpDensityDist = OpDensity<M, true>;
+
 void launch_density(hipStream_t s, Profiler* prof, const SweepArgs& a)
 {
     ProfScope ps(prof, "density", s);
-    SPH_DISPATCH(OpDensity, true, a.pm, a.orig, a.rho, a.mrho, a.lam_sum, a.lam_grad, a.ncount, a.planes, a.lam_lut, a.dlam_lut, a.status, a.sp,
+    if (a.h_mode != SPH_H_FROM_MASS) {
+        SPH_DISPATCH(OpDensityDist, true, a.pm, a.orig, a.rho, a.mrho, a.lam_sum, a.lam_grad, a.ncount, a.planes, a.lam_lut, a.dlam_lut, a.status, a.sp,
+                     a.h_mode, a.h2_next, a.lam_prev)
+        return;
+    }
+    SPH_DISPATCH(OpDensityMass, true, a.pm, a.orig, a.rho, a.mrho, a.lam_sum, a.lam_grad, a.ncount, a.planes, a.lam_lut, a.dlam_lut, a.status, a.sp,
                  a.h_mode, a.h2_next, a.lam_prev)
 }
 

@@ -115,7 +115,7 @@ class SphError(RuntimeError):
 # every symbol include/sph_ffi.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
     "create", "destroy", "upload", "upload_field", "download", "download_neighbors", "num_particles", "time",
-    "set_time", "step", "last_error", "grid", "set_boundary_polygon", "profile_enable", "profile_reset", "profile_get", "profile_event_overhead",
+    "set_time", "step", "last_error", "grid", "set_boundary_polygon", "profile_enable", "profile_reset", "profile_get", "profile_event_overhead", "profile_copy_bandwidth",
     "dist_configure", "comm_unique_id", "comm_init", "group_step",
 ]
 
@@ -163,6 +163,7 @@ class SphLibrary:
         self.profile_reset = sig("profile_reset", i32, [vp], required=False)
         self.profile_get = sig("profile_get", i32, [vp, C.POINTER(SphKernelTime), i32, C.POINTER(i32)], required=False)
         self.profile_event_overhead = sig("profile_event_overhead", i32, [vp, C.POINTER(C.c_double)], required=False)
+        self.profile_copy_bandwidth = sig("profile_copy_bandwidth", i32, [vp, u64, C.POINTER(C.c_double)], required=False)
         self.comm_unique_id = sig("comm_unique_id", i32, [C.POINTER(C.c_uint8)], required=False)
         self.comm_init = sig("comm_init", i32, [vp, C.POINTER(C.c_uint8), i32, i32], required=False)
         self.dist_configure = sig("dist_configure", i32, [vp, i32, i32, C.c_float, C.c_float], required=False)
@@ -304,6 +305,11 @@ class Context:
         n = C.c_int(0)
         self._check(self.lib.profile_get(self.handle, arr, cap, C.byref(n)))
         return {arr[i].name.decode(): (int(arr[i].working_launches), float(arr[i].working_ms)) for i in range(n.value)}
+
+    def profile_copy_bandwidth_gbs(self, nbytes: int = 1 << 30) -> float:
+        v = C.c_double(0.0)
+        self._check(self.lib.profile_copy_bandwidth(self.handle, int(nbytes), C.byref(v)))
+        return float(v.value)
 
     def profile_event_overhead_us(self) -> float:
         v = C.c_double(0.0)

@@ -198,6 +198,7 @@ def main():
         prof_work = ctx.profile_get_working()     # without the speculative launches that return at once
         ev_overhead_us = ctx.profile_event_overhead_us()
         ctx.profile_enable(0)
+    copy_gbs = ctx.profile_copy_bandwidth_gbs(1 << 30) if rank == 0 else 0.0   # achievable HBM rate of this device, same run
 
     if rank != 0:
         if distributed:
@@ -217,6 +218,7 @@ def main():
         return {"kernel": name, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src, "avg_us": avg_s * 1e6,
                 "avg_us_hip_events": raw_us, "event_overhead_us": ev_overhead_us, "launches_timed": launches,
+                "copy_kernel_GBs": copy_gbs, "frac_of_copy_kernel": (achieved / copy_gbs) if copy_gbs else None,
                 "algorithmic_bytes_per_particle": ALGO_BYTES[name], "algorithmic_bytes_per_launch": ALGO_BYTES[name] * n_local}
 
     total_prof_ms = sum(v[1] for v in prof_all.values()) or 1.0

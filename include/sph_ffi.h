@@ -261,6 +261,9 @@ int  sph_profile_get(sph_ctx* ctx, sph_kernel_time* out, int capacity, int* n_ou
 /* what a HIP-event pair adds to the duration of the kernel it brackets (microseconds), measured with empty kernels:
  * 2 x (pair around one) - (pair around two).  bench.py subtracts it to compare with rocprofv3's kernel durations. */
 int  sph_profile_event_overhead(sph_ctx* ctx, double* microseconds);
+/* bandwidth of a plain float4 copy kernel over `bytes` of device memory (read + write, GB/s, best of 5): the achievable
+ * HBM rate on this device, reported next to the 8 TB/s spec peak */
+int  sph_profile_copy_bandwidth(sph_ctx* ctx, uint64_t bytes, double* gb_per_s);
 
 /* ---- multi-GPU: 1-D slab decomposition along x, one process (= one context) per GPU --------
  * (the reference has no counterpart: its only parallelism is rayon inside one process, concurrency.rs:110-204)

@@ -10,7 +10,7 @@ import csv, collections, statistics, glob
 f = glob.glob("$GRAFT_REPO_ROOT/$OUT/kt/**/*kernel_trace.csv", recursive=True)[0]
 d = collections.defaultdict(list)
 for r in csv.DictReader(open(f)):
-    n = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("k_sweep<", "").replace("<MathUniform>", "").replace(", false>", "").replace(", true>", "[build]")
+    n = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("k_sweep<", "").replace("<MathUniform, false>", "").replace("<MathUniform, true>", "<dist>").replace("<MathUniform>", "").replace(", false>", "").replace(", true>", "[build]")
     d[n].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 tot = 0
 for n, v in sorted(d.items(), key=lambda kv: -sum(kv[1])):

@@ -17,7 +17,7 @@ shutil.copy(next((src / "kt").glob("*kernel_stats.csv")), dst + "_rocprofv3_kern
 
 def short(name):
     n = name.split("(")[0].replace("void ", "")
-    return n.replace("k_sweep<", "").replace("<MathUniform>", "").replace(", false>", "").replace(", true>", "[build]")
+    return n.replace("k_sweep<", "").replace("<MathUniform, false>", "").replace("<MathUniform, true>", "<dist>").replace("<MathUniform>", "").replace(", false>", "").replace(", true>", "[build]")
 
 
 # per-kernel durations of the launches that did real work (speculative Jacobi launches past the stop decision
