@@ -65,6 +65,10 @@ class FluidSimulation:
         self.ctx.upload(mass, position, velocity)
         self.particles = _ParticleView(self.ctx)
         self.counters_enabled = counters_enabled
+        if counters_enabled and self.lib.profile_enable is not None:
+            # PerformanceCounters::new(counters_enabled) (simulation.rs:137-189): per-phase times need the library's event
+            # instrumentation (neighbourhood / level estimation / the two solves); it perturbs dispatch, like `-p` does
+            self.ctx.profile_enable(1)
         self.pcounters: Dict[str, _Counter] = {}
         self.vcounters: Dict[str, _Counter] = {}
         self.step_number = 0
