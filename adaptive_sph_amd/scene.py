@@ -152,12 +152,17 @@ def dam_break_8m() -> SceneConfig:
 
 def dam_break_weak(n_gpus: int) -> SceneConfig:
     """Weak-scaling family between configs[1] (1 GPU, 1M) and configs[3] (8 GPUs, 8M): ~1M particles per GPU.
-    2 GPUs: 1448 x 1448 = 2 096 704 (spacing 1/1448); 4 GPUs: 2048 x 2048 = 4 194 304 (spacing 1/2048)."""
+    2 GPUs: configs[1]'s column twice as wide, 2048 x 1024 = 2 097 152 at spacing 1/1024; 4 GPUs: 2048 x 2048 = 4 194 304
+    at spacing 1/2048.  (A 1448 x 1448 column at spacing 1/1448 was tried first: with the proportionally scaled max_dt it
+    diverges at step 3 -- in the CPU oracle identically -- so it is no benchmark scene.)"""
     if n_gpus <= 1:
         return dam_break_1m()
     if n_gpus >= 8:
         return dam_break_8m()
-    side = 1448 if n_gpus < 4 else 2048
+    if n_gpus < 4:
+        return SceneConfig(SceneBoundary("box", 4.0, 2.0),
+                           [SceneFluidBlock([-1.999, -0.999], [2.0005, 1.0005], 0.0009765625, 0.93, [0.0, 0.0])])
+    side = 2048
     s = 1.0 / side
     return SceneConfig(SceneBoundary("box", 4.0, 2.0),
                        [SceneFluidBlock([-2.0 + 1.024 * s, -1.0 + 1.024 * s], [side * s + 0.5 * s, side * s + 0.5 * s], s, 0.93, [0.0, 0.0])])

@@ -65,7 +65,7 @@ WORKLOADS = {
     "dam_break_1m": (sc.dam_break_1m, dam_break_params, "2D dam-break, 1024x1024 = 1 048 576 uniform-h particles, HybridDFSPH"),
     "dam_break_1m_adaptive": (sc.dam_break_1m_adaptive, dam_break_params, "2D dam-break, 1 000 960 particles, 4:1 radius ratio"),
     "dam_break_8m": (sc.dam_break_8m, dam_break_params_scaled(1.0 / 2048), "2D dam-break, 2896x2896 = 8 386 816 particles, max_dt 0.001"),
-    "dam_break_2m": (lambda: sc.dam_break_weak(2), dam_break_params_scaled(1.0 / 1448), "2D dam-break, 1448x1448 = 2 096 704 particles, max_dt 0.00141"),
+    "dam_break_2m": (lambda: sc.dam_break_weak(2), dam_break_params, "2D dam-break, 2048x1024 = 2 097 152 particles (configs[1]'s column twice as wide)"),
     "dam_break_4m": (lambda: sc.dam_break_weak(4), dam_break_params_scaled(1.0 / 2048), "2D dam-break, 2048x2048 = 4 194 304 particles, max_dt 0.001"),
     "dam_break_64k": (lambda: sc.dam_break_small(256, 256, 1.0 / 256), dam_break_params, "2D dam-break, 256x256 particles (smoke)"),
 }
