@@ -54,3 +54,38 @@ def test_product_package_does_not_reference_oracle():
         if f.suffix in (".py", ".hip", ".h", ".hpp") and f.is_file():
             txt = f.read_text()
             assert "liboracle" not in txt and "oracle_harness" not in txt, f
+
+
+def test_rust_shim_mirrors_the_header():
+    """rust_shim/src/lib.rs cannot be compiled here (no cargo): keep its #[repr(C)] structs, field ids and extern block in
+    step with include/sph_ffi.h textually."""
+    import re
+    root = Path(__file__).resolve().parent.parent
+    header = (root / "include" / "sph_ffi.h").read_text()
+    rust = (root / "rust_shim" / "src" / "lib.rs").read_text()
+
+    def c_fields(struct):
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (struct, struct), header, re.S).group(1)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        names = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            names += [re.sub(r"\[.*\]", "", x.strip().split()[-1]) for x in decl.split(",")]
+        return names
+
+    def rust_fields(struct):
+        body = re.search(r"pub struct %s \{(.*?)\n    \}" % struct, rust, re.S).group(1)
+        return re.findall(r"pub (\w+):", body)
+
+    for c_name, r_name in [("sph_params", "SphParams"), ("sph_plane", "SphPlane"), ("sph_solver_stats", "SphSolverStats"),
+                           ("sph_step_stats", "SphStepStats"), ("sph_grid_info", "SphGridInfo")]:
+        assert c_fields(c_name) == rust_fields(r_name), c_name
+    # every SPH_F_* / enum constant the shim declares has the header's value
+    for name, val in re.findall(r"pub const (SPH_\w+): (?:i32|c_int) = (\d+);", rust):
+        m = re.search(r"\b%s = (\d+)" % name, header)
+        assert m and int(m.group(1)) == int(val), name
+    # every function of the extern block is declared by the header
+    for fn in re.findall(r"pub fn (sph_\w+)\(", rust):
+        assert re.search(r"\b%s\(" % fn, header), fn
