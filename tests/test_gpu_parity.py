@@ -455,3 +455,30 @@ def test_full_size_parity_1m_against_the_oracle(product_lib, oracle_lib):
     # the corner particles are ejected at ~20 m/s in these steps by an unconverged (4 forced iterations) pressure field,
     # whose summation-order sensitivity is the documented 2e-3 (TOL): v += dt a^p carries it
     assert rel_err(g.download("velocity"), o.download("velocity")) < 1e-3
+
+
+def test_full_size_parity_adaptive_4to1_against_the_oracle(product_lib, oracle_lib):
+    """BASELINE.json configs[2] at full size (942 080 fine + 58 880 coarse particles, radius ratio 4:1): the product sorts by
+    the fine particles' grid with per-particle stencils, the oracle by the reference's single coarse grid -- same sets."""
+    scn = sc.dam_break_1m_adaptive()
+    g, o = make_pair(product_lib, oracle_lib, scn)
+    assert g.n == 1000960
+    p = forced(max_iters=3).to_ffi()
+    for s in range(3):
+        sg, so = g.step(p), o.step(p)
+        assert abs(sg.dt - so.dt) <= 1e-6 * so.dt, s
+    gg, og = g.grid(), o.grid()
+    assert (gg.cell_size, gg.cells_min_x, gg.cells_min_y, gg.size_x, gg.size_y) == \
+           (og.cell_size, og.cells_min_x, og.cells_min_y, og.size_x, og.size_y)
+    assert np.array_equal(g.download("h2"), o.download("h2"))
+    assert np.array_equal(g.download("cell_index"), o.download("cell_index"))
+    assert np.array_equal(g.download("neighbor_count"), o.download("neighbor_count"))
+    go, gi = g.download_neighbors()
+    oo, oi = o.download_neighbors()
+    assert np.array_equal(go, oo)
+    seg = np.repeat(np.arange(g.n), np.diff(go).astype(np.int64))
+    for power in (1, 2):
+        assert np.array_equal(np.bincount(seg, weights=gi.astype(np.float64) ** power, minlength=g.n),
+                              np.bincount(seg, weights=oi.astype(np.float64) ** power, minlength=g.n)), power
+    for f in ["position", "density", "aii", "ppe_source_term"]:
+        assert rel_err(g.download(f), o.download(f)) < REL_TOL_FIELDS, f
