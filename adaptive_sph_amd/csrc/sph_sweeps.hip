@@ -10,21 +10,25 @@
 //     reference's neighbour predicate
 //         |x_ij|^2 < ((h_i + h_j) * 0.5 * 2)^2        (neighborhood_search.rs:143-146)
 //     with exactly the reference's operations, so the accepted set IS the reference's list.  It
-//     records the accepted candidates as 16-bit index deltas (j - i), 4 per 8-byte word,
-//     transposed per wave (word g of lane l at [wave][g][l]) so that every later access to the
-//     list is one coalesced 512-B wave load;
+//     records the accepted candidates as three 32-bit row masks (bit b of row r = candidate b of
+//     that row's contiguous range) plus count and flags: one uint4 per particle, one coalesced
+//     1-KB load per wave in every later sweep;
 //   * all later sweeps of the step (positions do not change until the final integrate) replay
-//     that list: per group of 4 neighbours one 8-B list load (prefetched one group ahead), four
-//     independent gathers of the neighbour payload and four pair evaluations -- 13 instead of
-//     ~38 candidate evaluations per particle, 4-way ILP, no barriers, no LDS, full occupancy.
+//     that word: per row, up to 4 set bits per trip -> four independent gathers of the neighbour
+//     record and its per-neighbour payload -> four pair evaluations -- 13 instead of ~38
+//     candidate evaluations per particle, 4-way ILP, no barriers, no LDS, 8 waves per SIMD.
 //     Neighbours of neighbouring lanes are adjacent in memory (cell-sorted order), so the gathers
 //     hit the same few cache lines per wave; per-neighbour derived quantities (p_j/rho_j^2,
 //     m_j/rho_j) are produced once per particle by the sweep that owns them, not once per pair;
 //   * every particle writes only its own outputs (gather-only, no atomics); the visiting order
 //     (rows bottom-to-top, sorted index ascending) is identical on both paths, so results do not
-//     depend on which path ran.
-// Particles with more than NL_MAXN neighbours or with a neighbour further than +-32767 slots away
-// (extreme size ratios, enormous rows) fall back to the candidate walk in every sweep.
+//     depend on which path ran;
+//   * multi-resolution scenes sort by the SMALL particles' grid; a particle's stencil is as wide
+//     as the largest h that can be around it (TileP, sph_device.h), particles with a wide stencil
+//     or crowded rows record explicit index lists (nlx) instead of masks, and only those with
+//     more than NLX_CAP neighbours walk their candidates in every sweep;
+//   * the level estimation (EmptyAngle surface detection, level-set propagation, smoothing) runs
+//     in the same skeleton on its own extended-range lists.
 //
 // Each Op below cites the reference sweep it implements (src/simulation/simulation.rs and
 // src/simulation/boundary_handler/sdf_boundary_handler/boundary_winchenbach2020.rs).
