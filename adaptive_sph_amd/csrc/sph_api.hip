@@ -5,8 +5,9 @@
 // maps each sorted slot back to the host's particle index, so uploads/downloads speak the
 // reference's indices.
 //
-// sph_step sequences the sweeps exactly like single_step_without_adaptivity
-// (/root/reference/src/simulation/simulation.rs:1980-2730); the citations sit next to each call.
+// This file: context lifetime, upload / download (host particle order), boundary description, the step header kernels and
+// the measurement hooks.  The step itself (single_step_without_adaptivity, simulation.rs:1980-2730) is sequenced in
+// sph_step.hip.
 #include <hip/hip_runtime.h>
 
 #include <chrono>

@@ -1,5 +1,5 @@
 // Spatial-hash neighbour build for gfx950: cell index -> stable LSD radix sort of (cell, particle)
-// pairs -> cell-range table -> list of occupied tiles.
+// pairs -> cell-range table (-> per-tile bound on the neighbours' h in multi-resolution scenes).
 //
 // What is computed follows the reference's own uniform-grid scheme
 // (/root/reference/src/simulation/neighborhood_search.rs:243-321 and CellGrid :355-410):
