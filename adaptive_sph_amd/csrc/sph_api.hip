@@ -622,6 +622,159 @@ extern "C" int sph_download(sph_ctx* c, int field, void* dst, uint64_t bytes)
     return SPH_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// sparse edits (sph_ffi.h): the script is resolved on the host into "final index f holds object o" + the last value
+// written to each field of each touched object; one kernel then gathers the persistent state into final-index order
+// ------------------------------------------------------------------------------------------------
+struct EditSrc {
+    uint32_t obj;      // object: < n_old = the particle with that OLD host index, else a default particle of an EXTEND
+    uint32_t set_idx;  // index into the override records, or 0xffffffff
+};
+struct EditSet {
+    uint32_t fields;
+    float mass, px, py, vx, vy, h2, h2_next, lvl, lvlold;
+};
+
+__global__ __launch_bounds__(256) void k_edit_inverse(uint32_t n_old, const uint32_t* __restrict__ orig, uint32_t* __restrict__ slot_of)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n_old) slot_of[orig[i]] = i;
+}
+
+__global__ __launch_bounds__(256) void k_edit_apply(uint32_t n_new, uint32_t n_old, const EditSrc* __restrict__ src, const EditSet* __restrict__ sets,
+                                                     const uint32_t* __restrict__ slot_of, const float4* __restrict__ pm_in,
+                                                     const float2* __restrict__ vel_in, const float* __restrict__ lvl_in,
+                                                     const float* __restrict__ lvlold_in, const float* __restrict__ h2n_in,
+                                                     const float* __restrict__ lam_in, float4* __restrict__ pm_out, float2* __restrict__ vel_out,
+                                                     uint32_t* __restrict__ orig_out, float* __restrict__ lvl_out, float* __restrict__ lvlold_out,
+                                                     float* __restrict__ h2n_out, float* __restrict__ lam_out)
+{
+    const uint32_t f = blockIdx.x * 256 + threadIdx.x;
+    if (f >= n_new) return;
+    const EditSrc e = src[f];
+    // ParticleVec defaults (simulation.rs:284-334)
+    float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+    float2 v = make_float2(0.f, 0.f);
+    float lv = __uint_as_float(0x7fc00000u), lo = 0.f, hn = 0.f, lam = 0.f;
+    if (e.obj < n_old) {
+        const uint32_t s = slot_of[e.obj];
+        p = pm_in[s];
+        v = vel_in[s];
+        lv = lvl_in[s];
+        lo = lvlold_in[s];
+        hn = h2n_in[s];
+        lam = lam_in[s];
+    }
+    if (e.set_idx != 0xffffffffu) {
+        const EditSet q = sets[e.set_idx];
+        if (q.fields & SPH_EDIT_F_MASS) p.z = q.mass;
+        if (q.fields & SPH_EDIT_F_POSITION) { p.x = q.px; p.y = q.py; }
+        if (q.fields & SPH_EDIT_F_VELOCITY) { v.x = q.vx; v.y = q.vy; }
+        if (q.fields & SPH_EDIT_F_H2) p.w = q.h2;
+        if (q.fields & SPH_EDIT_F_H2_NEXT) hn = q.h2_next;
+        if (q.fields & SPH_EDIT_F_LEVEL_ESTIMATION) lv = q.lvl;
+        if (q.fields & SPH_EDIT_F_LEVEL_OLD) lo = q.lvlold;
+    }
+    pm_out[f] = p;
+    vel_out[f] = v;
+    orig_out[f] = f;
+    lvl_out[f] = lv;
+    lvlold_out[f] = lo;
+    h2n_out[f] = hn;
+    lam_out[f] = lam;
+}
+
+extern "C" int sph_apply_edits(sph_ctx* c, const sph_edit_op* ops, uint64_t n_ops)
+{
+    if (!c || (n_ops && !ops)) return SPH_ERR_INVALID_ARGUMENT;
+    if (c->dist.on) return c->fail(SPH_ERR_UNSUPPORTED, "sparse edits on a slab context are not covered yet");
+    HIPCHK(c, hipSetDevice(c->device));
+    const uint32_t n_old = (uint32_t)c->n;
+    // ---- resolve the script: which object sits at which index, and the last value written to each field of an object
+    std::vector<uint32_t> at(n_old);
+    for (uint32_t i = 0; i < n_old; i++) at[i] = i;
+    uint32_t next_obj = n_old;
+    std::vector<EditSet> sets;
+    std::vector<uint32_t> set_of;   // object -> record (grown on demand)
+    auto record = [&](uint32_t obj) -> EditSet& {
+        if (set_of.size() <= obj) set_of.resize((size_t)obj + 1, 0xffffffffu);
+        if (set_of[obj] == 0xffffffffu) {
+            set_of[obj] = (uint32_t)sets.size();
+            sets.push_back(EditSet{0u, 0, 0, 0, 0, 0, 0, 0, 0, 0});
+        }
+        return sets[set_of[obj]];
+    };
+    for (uint64_t k = 0; k < n_ops; k++) {
+        const sph_edit_op& o = ops[k];
+        switch (o.kind) {
+        case SPH_EDIT_SET: {
+            if (o.a >= at.size()) return c->fail(SPH_ERR_INVALID_ARGUMENT, "edit %llu: index %u out of bounds (len %zu)", (unsigned long long)k, o.a, at.size());
+            EditSet& q = record(at[o.a]);
+            q.fields |= o.fields;
+            if (o.fields & SPH_EDIT_F_MASS) q.mass = o.mass;
+            if (o.fields & SPH_EDIT_F_POSITION) { q.px = o.position[0]; q.py = o.position[1]; }
+            if (o.fields & SPH_EDIT_F_VELOCITY) { q.vx = o.velocity[0]; q.vy = o.velocity[1]; }
+            if (o.fields & SPH_EDIT_F_H2) q.h2 = o.h2;
+            if (o.fields & SPH_EDIT_F_H2_NEXT) q.h2_next = o.h2_next;
+            if (o.fields & SPH_EDIT_F_LEVEL_ESTIMATION) q.lvl = o.level_estimation;
+            if (o.fields & SPH_EDIT_F_LEVEL_OLD) q.lvlold = o.level_old;
+        } break;
+        case SPH_EDIT_SWAP:
+            if (o.a >= at.size() || o.b >= at.size())
+                return c->fail(SPH_ERR_INVALID_ARGUMENT, "edit %llu: swap(%u, %u) out of bounds (len %zu)", (unsigned long long)k, o.a, o.b, at.size());
+            std::swap(at[o.a], at[o.b]);
+            break;
+        case SPH_EDIT_TRUNCATE:
+            if (o.a < at.size()) at.resize(o.a);   // Vec::truncate: no effect if len is greater
+            break;
+        case SPH_EDIT_EXTEND:
+            if (at.size() + (size_t)o.a > c->cap)
+                return c->fail(SPH_ERR_CAPACITY, "edit %llu: %zu particles exceed the capacity %llu", (unsigned long long)k, at.size() + (size_t)o.a,
+                               (unsigned long long)c->cap);
+            for (uint32_t q = 0; q < o.a; q++) at.push_back(next_obj++);
+            break;
+        default: return c->fail(SPH_ERR_INVALID_ARGUMENT, "edit %llu: unknown kind %d", (unsigned long long)k, o.kind);
+        }
+    }
+    const uint32_t n_new = (uint32_t)at.size();
+    std::vector<EditSrc> src(n_new ? n_new : 1);
+    for (uint32_t f = 0; f < n_new; f++) src[f] = EditSrc{at[f], at[f] < set_of.size() ? set_of[at[f]] : 0xffffffffu};
+    if (sets.empty()) sets.push_back(EditSet{0u, 0, 0, 0, 0, 0, 0, 0, 0, 0});
+
+    // ---- one gather on the device into final-index order (slot f = host index f, like a fresh upload)
+    hipStream_t s = c->stream;
+    HIPCHK(c, hipStreamSynchronize(s));
+    DevBuf d_src, d_sets, d_slot, d_lam;
+    HIPCHK(c, d_src.ensure(src.size() * sizeof(EditSrc)));
+    HIPCHK(c, d_sets.ensure(sets.size() * sizeof(EditSet)));
+    HIPCHK(c, d_slot.ensure(((size_t)n_old + 1) * 4));
+    HIPCHK(c, d_lam.ensure(((size_t)n_new + 1) * 4));
+    HIPCHK(c, hipMemcpyAsync(d_src.p, src.data(), src.size() * sizeof(EditSrc), hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(d_sets.p, sets.data(), sets.size() * sizeof(EditSet), hipMemcpyHostToDevice, s));
+    const int k = c->cur;
+    if (n_old) hipLaunchKernelGGL(k_edit_inverse, dim3((n_old + 255) / 256), dim3(256), 0, s, n_old, c->orig[k].as<uint32_t>(), d_slot.as<uint32_t>());
+    if (n_new)
+        hipLaunchKernelGGL(k_edit_apply, dim3((n_new + 255) / 256), dim3(256), 0, s, n_new, n_old, d_src.as<EditSrc>(), d_sets.as<EditSet>(),
+                           d_slot.as<uint32_t>(), c->pm[c->pcur].as<float4>(), c->vel[k].as<float2>(), c->lvl[k].as<float>(),
+                           c->lvlold[k].as<float>(), c->h2n[k].as<float>(), c->lam_sum.as<float>(), c->pm[c->pcur ^ 1].as<float4>(),
+                           c->vel[k ^ 1].as<float2>(), c->orig[k ^ 1].as<uint32_t>(), c->lvl[k ^ 1].as<float>(), c->lvlold[k ^ 1].as<float>(),
+                           c->h2n[k ^ 1].as<float>(), d_lam.as<float>());
+    if (n_new) HIPCHK(c, hipMemcpyAsync(c->lam_sum.p, d_lam.p, (size_t)n_new * 4, hipMemcpyDeviceToDevice, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    d_src.release();
+    d_sets.release();
+    d_slot.release();
+    d_lam.release();
+    c->cur = k ^ 1;
+    c->pcur ^= 1;
+    c->n = n_new;
+    c->dist.n_tot = n_new;
+    c->grid_valid = false;   // lists, cell indices and per-step outputs belong to the vector before the edit
+    c->have_level = false;
+    c->hdr_ahead = false;
+    return SPH_OK;
+}
+
 extern "C" int sph_upload_field(sph_ctx* c, int field, const void* src, uint64_t bytes)
 {
     if (!c || !src) return SPH_ERR_INVALID_ARGUMENT;

@@ -99,6 +99,16 @@ class SphGridInfo(C.Structure):
                 ("size_x", C.c_int32), ("size_y", C.c_int32)]
 
 
+class SphEditOp(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("a", C.c_uint32), ("b", C.c_uint32), ("fields", C.c_uint32), ("mass", C.c_float),
+                ("position", C.c_float * 2), ("velocity", C.c_float * 2), ("h2", C.c_float), ("h2_next", C.c_float),
+                ("level_estimation", C.c_float), ("level_old", C.c_float)]
+
+
+EDIT_SET, EDIT_SWAP, EDIT_TRUNCATE, EDIT_EXTEND = 0, 1, 2, 3
+EDIT_FIELD_BITS = {"mass": 1, "position": 2, "velocity": 4, "h2": 8, "h2_next": 16, "level_estimation": 32, "level_old": 64}
+
+
 class SphKernelTime(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("launches", C.c_uint64), ("total_ms", C.c_double),
                 ("working_launches", C.c_uint64), ("working_ms", C.c_double)]
@@ -115,7 +125,7 @@ class SphError(RuntimeError):
 # every symbol include/sph_ffi.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
     "create", "destroy", "upload", "upload_field", "download", "download_neighbors", "num_particles", "time",
-    "set_time", "step", "last_error", "grid", "set_boundary_polygon", "profile_enable", "profile_reset", "profile_get", "profile_event_overhead", "profile_copy_bandwidth",
+    "set_time", "step", "last_error", "grid", "set_boundary_polygon", "apply_edits", "profile_enable", "profile_reset", "profile_get", "profile_event_overhead", "profile_copy_bandwidth",
     "dist_configure", "comm_unique_id", "comm_init", "group_step",
 ]
 
@@ -150,6 +160,7 @@ class SphLibrary:
         self.set_boundary_polygon = sig("set_boundary_polygon", i32, [vp, C.POINTER(C.c_float), i32])
         self.upload = sig("upload", i32, [vp, u64, vp, vp, vp])
         self.upload_field = sig("upload_field", i32, [vp, i32, vp, u64])
+        self.apply_edits = sig("apply_edits", i32, [vp, C.POINTER(SphEditOp), u64])
         self.download = sig("download", i32, [vp, i32, vp, u64])
         self.download_neighbors = sig("download_neighbors", i32, [vp, vp, vp, u64, C.POINTER(u64)])
         self.num_particles = sig("num_particles", u64, [vp])
@@ -255,6 +266,30 @@ class Context:
         fid, dt, w = FIELDS[name]
         a = np.ascontiguousarray(values, dtype=dt)
         self._check(self.lib.upload_field(self.handle, fid, a.ctypes.data, a.nbytes))
+
+    def apply_edits(self, ops) -> None:
+        """Sparse edits between steps (sph_ffi.h): ops = [("set", i, {field: value, ...}) | ("swap", i, j) | ("truncate", n) |
+        ("extend", k)], applied in order with Vec semantics in host index space."""
+        arr = (SphEditOp * max(1, len(ops)))()
+        for k, op in enumerate(ops):
+            e = arr[k]
+            if op[0] == "set":
+                e.kind, e.a = EDIT_SET, int(op[1])
+                for name, val in op[2].items():
+                    e.fields |= EDIT_FIELD_BITS[name]
+                    if name in ("position", "velocity"):
+                        getattr(e, name)[0], getattr(e, name)[1] = float(val[0]), float(val[1])
+                    else:
+                        setattr(e, name, float(val))
+            elif op[0] == "swap":
+                e.kind, e.a, e.b = EDIT_SWAP, int(op[1]), int(op[2])
+            elif op[0] == "truncate":
+                e.kind, e.a = EDIT_TRUNCATE, int(op[1])
+            elif op[0] == "extend":
+                e.kind, e.a = EDIT_EXTEND, int(op[1])
+            else:
+                raise ValueError(op[0])
+        self._check(self.lib.apply_edits(self.handle, arr, len(ops)))
 
     def download(self, name: str) -> np.ndarray:
         fid, dt, w = FIELDS[name]

@@ -215,6 +215,37 @@ int  sph_upload(sph_ctx* ctx, uint64_t n, const float* mass, const float* positi
  * particle_sharing.rs:202-237) without changing N. */
 int  sph_upload_field(sph_ctx* ctx, int field, const void* src, uint64_t src_bytes);
 
+/* ---- sparse edits between two steps -------------------------------------------------------------------------------
+ * What particle sharing / merging / splitting do to ParticleVec (adaptivity/particle_sharing.rs:202-237,
+ * particle_merging.rs:319-370, splitting.rs:52-79), replayed on the device-resident state instead of re-uploading all of it:
+ * the Rust side records the element writes and the ParticleVec::swap / truncate / extend calls (simulation.rs:248-271) it
+ * makes -- the same calls reach neighs and boundary_handler -- and hands the script over once.  The ops apply in order, in
+ * HOST index space, with exactly the Vec semantics:
+ *   SET       particle a gets the values whose bit is set in `fields` (the fields adaptivity writes)
+ *   SWAP      particles a and b trade places (every field, the boundary handler's lambda entries included)
+ *   TRUNCATE  the vector keeps its first a particles
+ *   EXTEND    a particles with ParticleVec's defaults are appended (mass 0, zero vectors, h2 = h2_next = 0,
+ *             LevelEstimationState::FluidInterior, level_old 0, no boundary terms)
+ * Afterwards sph_num_particles() is the new length and downloads speak the new indices.  Per-step outputs (density,
+ * pressure, neighbour lists, ...) are those of the last step and no longer line up with the edited vector. */
+enum { SPH_EDIT_SET = 0, SPH_EDIT_SWAP = 1, SPH_EDIT_TRUNCATE = 2, SPH_EDIT_EXTEND = 3 };
+enum {
+    SPH_EDIT_F_MASS = 1, SPH_EDIT_F_POSITION = 2, SPH_EDIT_F_VELOCITY = 4, SPH_EDIT_F_H2 = 8, SPH_EDIT_F_H2_NEXT = 16,
+    SPH_EDIT_F_LEVEL_ESTIMATION = 32, SPH_EDIT_F_LEVEL_OLD = 64
+};
+typedef struct sph_edit_op {
+    int32_t  kind;
+    uint32_t a, b;
+    uint32_t fields;
+    float    mass;
+    float    position[2];
+    float    velocity[2];
+    float    h2, h2_next;
+    float    level_estimation;   /* NaN = FluidInterior */
+    float    level_old;
+} sph_edit_op;
+int  sph_apply_edits(sph_ctx* ctx, const sph_edit_op* ops, uint64_t n_ops);
+
 /* Read one field back in HOST particle order. */
 int  sph_download(sph_ctx* ctx, int field, void* dst, uint64_t dst_bytes);
 

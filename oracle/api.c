@@ -120,6 +120,58 @@ int oracle_upload(oracle_ctx* c, uint64_t n, const float* mass, const float* pos
     return SPH_OK;
 }
 
+/* The edit script of sph_ffi.h applied the way the reference does it: element writes and ParticleVec::swap / truncate /
+ * extend (simulation.rs:248-271; the same calls reach neighs and boundary_handler: particle_merging.rs:357-370,
+ * splitting.rs:56-58), one op after the other on the host arrays. */
+static void swapf(float* a, uint64_t i, uint64_t j, int w)
+{
+    for (int d = 0; d < w; d++) { float t = a[w * i + d]; a[w * i + d] = a[w * j + d]; a[w * j + d] = t; }
+}
+
+int oracle_apply_edits(oracle_ctx* c, const sph_edit_op* ops, uint64_t n_ops)
+{
+    if (!c || (n_ops && !ops)) return SPH_ERR_INVALID_ARGUMENT;
+    for (uint64_t k = 0; k < n_ops; k++) {
+        const sph_edit_op* o = &ops[k];
+        switch (o->kind) {
+        case SPH_EDIT_SET: {
+            if (o->a >= c->n) return orc_fail(c, SPH_ERR_INVALID_ARGUMENT, "edit %llu: index out of bounds", (unsigned long long)k);
+            const uint64_t i = o->a;
+            if (o->fields & SPH_EDIT_F_MASS) c->mass[i] = o->mass;
+            if (o->fields & SPH_EDIT_F_POSITION) { c->pos[2 * i] = o->position[0]; c->pos[2 * i + 1] = o->position[1]; }
+            if (o->fields & SPH_EDIT_F_VELOCITY) { c->vel[2 * i] = o->velocity[0]; c->vel[2 * i + 1] = o->velocity[1]; }
+            if (o->fields & SPH_EDIT_F_H2) c->h2[i] = o->h2;
+            if (o->fields & SPH_EDIT_F_H2_NEXT) c->h2_next[i] = o->h2_next;
+            if (o->fields & SPH_EDIT_F_LEVEL_ESTIMATION) c->level[i] = o->level_estimation;
+            if (o->fields & SPH_EDIT_F_LEVEL_OLD) c->level_old[i] = o->level_old;
+        } break;
+        case SPH_EDIT_SWAP: {
+            if (o->a >= c->n || o->b >= c->n) return orc_fail(c, SPH_ERR_INVALID_ARGUMENT, "edit %llu: swap out of bounds", (unsigned long long)k);
+            const uint64_t i = o->a, j = o->b;
+            swapf(c->mass, i, j, 1); swapf(c->pos, i, j, 2); swapf(c->vel, i, j, 2); swapf(c->h2, i, j, 1); swapf(c->h2_next, i, j, 1);
+            swapf(c->level, i, j, 1); swapf(c->level_old, i, j, 1);
+            swapf(c->lam, i, j, ORC_MAX_PLANES); swapf(c->lam_gx, i, j, ORC_MAX_PLANES); swapf(c->lam_gy, i, j, ORC_MAX_PLANES);
+            uint8_t t = c->lam_n[i]; c->lam_n[i] = c->lam_n[j]; c->lam_n[j] = t;
+        } break;
+        case SPH_EDIT_TRUNCATE:
+            if (o->a < c->n) c->n = o->a;
+            break;
+        case SPH_EDIT_EXTEND:
+            if (c->n + o->a > c->cap) return orc_fail(c, SPH_ERR_CAPACITY, "edit %llu exceeds the capacity", (unsigned long long)k);
+            for (uint64_t i = c->n; i < c->n + o->a; i++) {
+                c->mass[i] = 0.f; c->pos[2 * i] = c->pos[2 * i + 1] = 0.f; c->vel[2 * i] = c->vel[2 * i + 1] = 0.f;
+                c->h2[i] = 0.f; c->h2_next[i] = 0.f; c->level[i] = NAN; c->level_old[i] = 0.f; c->lam_n[i] = 0;
+            }
+            c->n += o->a;
+            break;
+        default: return orc_fail(c, SPH_ERR_INVALID_ARGUMENT, "edit %llu: unknown kind %d", (unsigned long long)k, o->kind);
+        }
+    }
+    /* per-step outputs and the neighbour lists belong to the vector before the edit */
+    memset(c->nb_off, 0, (c->n + 1) * sizeof(uint64_t));
+    return SPH_OK;
+}
+
 typedef struct { void* ptr; size_t elem; int width; } field_ref;
 
 static field_ref field_of(oracle_ctx* c, int field)

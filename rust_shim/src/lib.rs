@@ -153,12 +153,42 @@ pub mod ffi {
 
     pub const SPH_OK: c_int = 0;
 
+    // ---- sparse edits between steps (sph_apply_edits) ------------------------------------------------------------
+    pub const SPH_EDIT_SET: i32 = 0;
+    pub const SPH_EDIT_SWAP: i32 = 1;
+    pub const SPH_EDIT_TRUNCATE: i32 = 2;
+    pub const SPH_EDIT_EXTEND: i32 = 3;
+    pub const SPH_EDIT_F_MASS: u32 = 1;
+    pub const SPH_EDIT_F_POSITION: u32 = 2;
+    pub const SPH_EDIT_F_VELOCITY: u32 = 4;
+    pub const SPH_EDIT_F_H2: u32 = 8;
+    pub const SPH_EDIT_F_H2_NEXT: u32 = 16;
+    pub const SPH_EDIT_F_LEVEL_ESTIMATION: u32 = 32;
+    pub const SPH_EDIT_F_LEVEL_OLD: u32 = 64;
+
+    #[repr(C)]
+    #[derive(Clone, Copy, Debug, Default)]
+    pub struct SphEditOp {
+        pub kind: i32,
+        pub a: u32,
+        pub b: u32,
+        pub fields: u32,
+        pub mass: f32,
+        pub position: [f32; 2],
+        pub velocity: [f32; 2],
+        pub h2: f32,
+        pub h2_next: f32,
+        pub level_estimation: f32,
+        pub level_old: f32,
+    }
+
     extern "C" {
         pub fn sph_create(n_capacity: u64, device_id: c_int, planes: *const SphPlane, n_planes: c_int, out: *mut *mut c_void) -> c_int;
         pub fn sph_set_boundary_polygon(ctx: *mut c_void, points_xy: *const f32, n_points: c_int) -> c_int;
         pub fn sph_destroy(ctx: *mut c_void);
         pub fn sph_upload(ctx: *mut c_void, n: u64, mass: *const f32, position_xy: *const f32, velocity_xy: *const f32) -> c_int;
         pub fn sph_upload_field(ctx: *mut c_void, field: c_int, src: *const c_void, src_bytes: u64) -> c_int;
+        pub fn sph_apply_edits(ctx: *mut c_void, ops: *const SphEditOp, n_ops: u64) -> c_int;
         pub fn sph_download(ctx: *mut c_void, field: c_int, dst: *mut c_void, dst_bytes: u64) -> c_int;
         pub fn sph_download_neighbors(ctx: *mut c_void, offsets: *mut u32, indices: *mut u32, indices_capacity: u64, n_indices: *mut u64) -> c_int;
         pub fn sph_num_particles(ctx: *const c_void) -> u64;
@@ -226,6 +256,13 @@ impl HipStep {
         self.check(unsafe {
             ffi::sph_upload_field(self.ctx, field, values.as_ptr() as *const c_void, (values.len() * std::mem::size_of::<T>()) as u64)
         });
+    }
+
+    /// The edit log of one single_step_adaptivity (element writes + ParticleVec::swap / truncate / extend, in call order).
+    /// Cheaper than `upload` when few particles changed: one small host->device copy and one gather on the device.
+    pub fn apply_edits(&mut self, log: &[ffi::SphEditOp]) {
+        self.check(unsafe { ffi::sph_apply_edits(self.ctx, log.as_ptr(), log.len() as u64) });
+        self.dirty = false;
     }
 
     pub fn download<T: Copy>(&self, field: i32, out: &mut [T]) {

@@ -482,3 +482,39 @@ def test_full_size_parity_adaptive_4to1_against_the_oracle(product_lib, oracle_l
                               np.bincount(seg, weights=oi.astype(np.float64) ** power, minlength=g.n)), power
     for f in ["position", "density", "aii", "ppe_source_term"]:
         assert rel_err(g.download(f), o.download(f)) < REL_TOL_FIELDS, f
+
+
+@pytest.mark.parametrize("mode", ["FromMass", "FromDistributionClamped1"])
+def test_sparse_edits_between_steps(product_lib, oracle_lib, mode):
+    """sph_apply_edits: the merge / split bookkeeping of the host (value writes, swap-to-end deletes, truncate, extend +
+    child writes) replayed on the device-resident state; then both sides keep stepping.  FromDistribution* also needs the
+    boundary handler's lambda sums to travel with the particles (boundary_handler.swap / extend)."""
+    from tests.test_oracle_step import _edit_script, _apply_model, EDIT_FIELDS
+    g, o = make_pair(product_lib, oracle_lib, sc.dam_break_small(24, 24, 1 / 24))
+    p = forced(max_iters=3, level_estimation_method="EmptyAngle", maximum_surface_distance=0.2, support_length_estimation=mode).to_ffi()
+    for s in range(2):
+        g.step(p), o.step(p)
+    before = {f: o.download(f) for f in EDIT_FIELDS}
+    ops, n_new = _edit_script(np.random.default_rng(11), g.n)
+    # keep the edited particles inside the fluid block so that the scene stays sane
+    for op in ops:
+        if op[0] == "set" and "position" in op[2]:
+            op[2]["position"] = [-1.9 + 0.3 * abs(op[2]["position"][0]), -0.9 + 0.3 * abs(op[2]["position"][1])]
+            op[2]["mass"] = float(before["mass"][0])
+            op[2]["h2_next"] = float(before["h2_next"][0])
+    g.apply_edits(ops)
+    o.apply_edits(ops)
+    assert g.n == o.n == n_new
+    for f in EDIT_FIELDS:
+        a, b = g.download(f), o.download(f)
+        if f in ("position", "velocity", "mass", "h2_next", "level_old"):
+            assert rel_err(a, b) < 1e-6, f          # carried / written values (device state vs oracle state before the edit: 1e-7)
+        assert np.array_equal(np.isnan(a), np.isnan(b)), f
+    with pytest.raises(ffi.SphError):
+        g.download_neighbors()                      # lists belong to the vector before the edit
+    for s in range(2):
+        sg, so = g.step(p), o.step(p)
+        assert abs(sg.dt - so.dt) <= 1e-5 * so.dt
+    assert np.array_equal(g.download("neighbor_count"), o.download("neighbor_count")) or mode != "FromMass"
+    for f in ["position", "velocity", "density"]:
+        assert rel_err(g.download(f), o.download(f)) < 1e-3, f

@@ -101,3 +101,62 @@ def test_level_estimation_default_config(oracle_lib):
     assert 0 < surf.sum() < len(mass)
     cls = c.download("particle_size_class")
     assert set(np.unique(cls)) <= {0, 1, 2, 3, 4}
+
+
+def _edit_script(rng, n):
+    """What merge (value writes, swap-to-end deletes, truncate) and split (extend, child writes) do, as a script."""
+    ops, length = [], n
+    for i in rng.choice(n, 12, replace=False):          # sharing / merging: mass, position, velocity, h2_next of survivors
+        ops.append(("set", int(i), {"mass": float(rng.uniform(1e-4, 3e-4)), "position": rng.uniform(-0.5, 0.5, 2),
+                                    "velocity": rng.uniform(-1, 1, 2), "h2_next": float(rng.uniform(0.01, 0.03))}))
+    last = n - 1
+    for i in sorted(rng.choice(n // 2, 9, replace=False)):   # merge_particles: delete by swapping to the end
+        ops.append(("swap", int(i), last))
+        last -= 1
+    ops.append(("truncate", last + 1))
+    length = last + 1
+    ops.append(("extend", 7))                           # split_particles: children appended, then written
+    for q in range(7):
+        ops.append(("set", length + q, {"mass": 1.5e-4, "position": rng.uniform(-0.5, 0.5, 2), "velocity": [0.1, -0.2],
+                                        "h2_next": 0.02, "level_estimation": -0.05, "level_old": -0.04}))
+    ops.append(("set", 3, {"h2": 0.0123, "level_old": -0.5}))
+    return ops, length + 7
+
+
+def _apply_model(ops, fields):
+    """The same script on plain Python lists (Vec semantics)."""
+    defaults = {"mass": 0.0, "position": [0.0, 0.0], "velocity": [0.0, 0.0], "h2": 0.0, "h2_next": 0.0,
+                "level_estimation": float("nan"), "level_old": 0.0}
+    rows = [{k: (list(v[i]) if np.ndim(v[i]) else float(v[i])) for k, v in fields.items()} for i in range(len(fields["mass"]))]
+    for op in ops:
+        if op[0] == "set":
+            for k, v in op[2].items():
+                rows[op[1]][k] = [float(np.float32(x)) for x in v] if np.ndim(v) else float(np.float32(v))
+        elif op[0] == "swap":
+            rows[op[1]], rows[op[2]] = rows[op[2]], rows[op[1]]
+        elif op[0] == "truncate":
+            del rows[op[1]:]
+        else:
+            rows += [dict((k, list(v) if isinstance(v, list) else v) for k, v in defaults.items()) for _ in range(op[1])]
+    return {k: np.array([r[k] for r in rows], dtype=np.float32) for k in defaults}
+
+
+EDIT_FIELDS = ["mass", "position", "velocity", "h2", "h2_next", "level_estimation", "level_old"]
+
+
+def test_sparse_edits_follow_vec_semantics(oracle_lib):
+    """sph_apply_edits (include/sph_ffi.h): SET / SWAP / TRUNCATE / EXTEND in host index space, like the ParticleVec calls of
+    merge_particles and split_particles (particle_merging.rs:341-370, splitting.rs:52-79)."""
+    scn = sc.dam_break_small(20, 20, 1 / 20)
+    c, pos, mass, vel = _ctx(oracle_lib, scn)
+    p = dam_break_params(level_estimation_method="EmptyAngle", maximum_surface_distance=0.2).to_ffi()
+    c.step(p)
+    before = {f: c.download(f) for f in EDIT_FIELDS}
+    ops, n_new = _edit_script(np.random.default_rng(5), len(mass))
+    c.apply_edits(ops)
+    assert c.n == n_new
+    want = _apply_model(ops, before)
+    for f in EDIT_FIELDS:
+        assert np.array_equal(c.download(f), want[f], equal_nan=True), f
+    with pytest.raises(ffi.SphError):
+        c.apply_edits([("swap", 0, n_new)])          # out of bounds, like the Vec index panic
