@@ -333,6 +333,7 @@ static int alloc_particle_buffers(sph_ctx* c)
         HIPCHK(c, c->lvl[k].ensure(n * sizeof(float)));
         HIPCHK(c, c->lvlold[k].ensure(n * sizeof(float)));
         HIPCHK(c, c->h2n[k].ensure(n * sizeof(float)));
+        HIPCHK(c, c->szc[k].ensure(n));
         HIPCHK(c, c->key[k].ensure(n * sizeof(uint32_t)));
         HIPCHK(c, c->val[k].ensure(n * sizeof(uint32_t)));
     }
@@ -344,6 +345,7 @@ static int alloc_particle_buffers(sph_ctx* c)
     for (auto b : f1) HIPCHK(c, b->ensure(n * sizeof(float)));
     HIPCHK(c, c->lam_grad.ensure(n * sizeof(float2)));
     HIPCHK(c, c->lam_prev.ensure(n * sizeof(float)));
+    HIPCHK(c, c->omega.ensure(n * sizeof(float)));
     HIPCHK(c, c->pacc.ensure(n * sizeof(float2)));
     HIPCHK(c, c->scratch.ensure(n * sizeof(float4)));
     HIPCHK(c, c->nl.ensure(sweep_list_bytes((uint32_t)n)));
@@ -446,7 +448,7 @@ extern "C" void sph_destroy(sph_ctx* c)
     DevBuf* all[] = {&c->pm[0], &c->pm[1], &c->vel[0], &c->vel[1], &c->orig[0], &c->orig[1], &c->lvl[0], &c->lvl[1], &c->lvlold[0],
                      &c->lvlold[1], &c->vel_tmp, &c->key[0], &c->key[1], &c->val[0], &c->val[1], &c->sort_scratch, &c->cxy, &c->cell_start,
                      &c->cs_scratch, &c->hdr_ahead_partials, &c->h2n[0], &c->h2n[1], &c->lam_prev, &c->nl, &c->nlx, &c->tile_raw, &c->tile_h, &c->lvl_tmp, &c->lvl_nrm, &c->lvl_state, &c->lvl_when, &c->lvl_mark, &c->flag_surface,
-                     &c->flag_insufficient, &c->size_class, &c->stash, &c->nl_ext, &c->nlx_ext, &c->nl_ok, &c->mrho, &c->pt0, &c->pt1, &c->rho, &c->lam_sum, &c->lam_grad, &c->constf, &c->aii, &c->src, &c->p0, &c->p1, &c->pacc, &c->dens_err,
+                     &c->flag_insufficient, &c->szc[0], &c->szc[1], &c->omega, &c->stash, &c->nl_ext, &c->nlx_ext, &c->nl_ok, &c->mrho, &c->pt0, &c->pt1, &c->rho, &c->lam_sum, &c->lam_grad, &c->constf, &c->aii, &c->src, &c->p0, &c->p1, &c->pacc, &c->dens_err,
                      &c->stat, &c->ncount, &c->planes_d, &c->lam_lut, &c->dlam_lut, &c->hdr_partials, &c->hdr_out, &c->ctrl, &c->status,
                      &c->n_tiles, &c->red_partials, &c->scratch};
     for (auto b : all) b->release();
@@ -494,6 +496,7 @@ extern "C" int sph_upload(sph_ctx* c, uint64_t n, const float* mass, const float
     hipLaunchKernelGGL(k_pack_upload, dim3((n + 255) / 256), dim3(256), 0, s, (uint32_t)n, c->key[1].as<float>(), c->scratch.as<float2>(),
                        c->vel_tmp.as<float2>(), c->pm[0].as<float4>(), c->vel[0].as<float2>(), c->orig[0].as<uint32_t>(),
                        c->lvl[0].as<float>(), c->lvlold[0].as<float>(), c->h2n[0].as<float>());
+    HIPCHK(c, hipMemsetAsync(c->szc[0].p, 2, n, s));   // ParticleSizeClass::Optimal (simulation.rs:318)
     DevBuf* zero[] = {&c->rho, &c->lam_sum, &c->constf, &c->aii, &c->src, &c->p0, &c->p1, &c->dens_err, &c->ncount};
     for (auto b : zero) HIPCHK(c, hipMemsetAsync(b->p, 0, n * sizeof(float), s));
     HIPCHK(c, hipMemsetAsync(c->lam_grad.p, 0, n * sizeof(float2), s));
@@ -597,14 +600,14 @@ extern "C" int sph_download(sph_ctx* c, int field, void* dst, uint64_t bytes)
         // the defaults of ParticleVec.
         size_t elem = field == SPH_F_STASH ? 4 : 1;
         if (bytes != (uint64_t)n * elem) return c->fail(SPH_ERR_INVALID_ARGUMENT, "field %d: size mismatch", field);
-        if (!c->have_level || c->dist.on) {
+        if (c->dist.on || (!c->have_level && field != SPH_F_PARTICLE_SIZE_CLASS)) {
             memset(dst, field == SPH_F_PARTICLE_SIZE_CLASS ? 2 : 0, bytes);
             return SPH_OK;
         }
         if (n == 0) return SPH_OK;
         const void* src = field == SPH_F_STASH ? c->stash.p
                           : field == SPH_F_FLAG_IS_FLUID_SURFACE ? c->flag_surface.p
-                          : field == SPH_F_FLAG_INSUFFICIENT_NEIGHS ? c->flag_insufficient.p : c->size_class.p;
+                          : field == SPH_F_FLAG_INSUFFICIENT_NEIGHS ? c->flag_insufficient.p : c->szc[k].p;
         hipLaunchKernelGGL(k_to_host_order, dim3((n + 255) / 256), dim3(256), 0, s, n, field == SPH_F_STASH ? (int)G_F32 : (int)G_U8,
                            c->orig[k].as<uint32_t>(), src, c->scratch.p);
         HIPCHK(c, hipMemcpyAsync(dst, c->scratch.p, bytes, hipMemcpyDeviceToHost, s));
@@ -645,7 +648,8 @@ __global__ __launch_bounds__(256) void k_edit_apply(uint32_t n_new, uint32_t n_o
                                                      const uint32_t* __restrict__ slot_of, const float4* __restrict__ pm_in,
                                                      const float2* __restrict__ vel_in, const float* __restrict__ lvl_in,
                                                      const float* __restrict__ lvlold_in, const float* __restrict__ h2n_in,
-                                                     const float* __restrict__ lam_in, float4* __restrict__ pm_out, float2* __restrict__ vel_out,
+                                                     const float* __restrict__ lam_in, const uint8_t* __restrict__ szc_in,
+                                                     uint8_t* __restrict__ szc_out, float4* __restrict__ pm_out, float2* __restrict__ vel_out,
                                                      uint32_t* __restrict__ orig_out, float* __restrict__ lvl_out, float* __restrict__ lvlold_out,
                                                      float* __restrict__ h2n_out, float* __restrict__ lam_out)
 {
@@ -656,8 +660,10 @@ __global__ __launch_bounds__(256) void k_edit_apply(uint32_t n_new, uint32_t n_o
     float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
     float2 v = make_float2(0.f, 0.f);
     float lv = __uint_as_float(0x7fc00000u), lo = 0.f, hn = 0.f, lam = 0.f;
+    uint8_t cls = 2;   // ParticleSizeClass::Optimal
     if (e.obj < n_old) {
         const uint32_t s = slot_of[e.obj];
+        cls = szc_in[s];
         p = pm_in[s];
         v = vel_in[s];
         lv = lvl_in[s];
@@ -682,6 +688,7 @@ __global__ __launch_bounds__(256) void k_edit_apply(uint32_t n_new, uint32_t n_o
     lvlold_out[f] = lo;
     h2n_out[f] = hn;
     lam_out[f] = lam;
+    szc_out[f] = cls;
 }
 
 extern "C" int sph_apply_edits(sph_ctx* c, const sph_edit_op* ops, uint64_t n_ops)
@@ -756,7 +763,8 @@ extern "C" int sph_apply_edits(sph_ctx* c, const sph_edit_op* ops, uint64_t n_op
     if (n_new)
         hipLaunchKernelGGL(k_edit_apply, dim3((n_new + 255) / 256), dim3(256), 0, s, n_new, n_old, d_src.as<EditSrc>(), d_sets.as<EditSet>(),
                            d_slot.as<uint32_t>(), c->pm[c->pcur].as<float4>(), c->vel[k].as<float2>(), c->lvl[k].as<float>(),
-                           c->lvlold[k].as<float>(), c->h2n[k].as<float>(), c->lam_sum.as<float>(), c->pm[c->pcur ^ 1].as<float4>(),
+                           c->lvlold[k].as<float>(), c->h2n[k].as<float>(), c->lam_sum.as<float>(), c->szc[k].as<uint8_t>(), c->szc[k ^ 1].as<uint8_t>(),
+                           c->pm[c->pcur ^ 1].as<float4>(),
                            c->vel[k ^ 1].as<float2>(), c->orig[k ^ 1].as<uint32_t>(), c->lvl[k ^ 1].as<float>(), c->lvlold[k ^ 1].as<float>(),
                            c->h2n[k ^ 1].as<float>(), d_lam.as<float>());
     if (n_new) HIPCHK(c, hipMemcpyAsync(c->lam_sum.p, d_lam.p, (size_t)n_new * 4, hipMemcpyDeviceToDevice, s));

@@ -89,7 +89,8 @@ void launch_reorder(hipStream_t s, Profiler* prof, uint32_t n, GridP g, const ui
                     const float4* pm_in, const float2* vel_in, const uint32_t* orig_in, const float* lvl_in,
                     const float* lvlold_in, float4* pm_out, float2* vel_out, uint32_t* orig_out, float* lvl_out,
                     float* lvlold_out, uint32_t* cxy, const float* h2n_in = nullptr, float* h2n_out = nullptr,
-                    const float* lam_in = nullptr, float* lam_prev_out = nullptr, void* cell_start_scratch = nullptr);
+                    const float* lam_in = nullptr, float* lam_prev_out = nullptr, void* cell_start_scratch = nullptr,
+                    const uint8_t* szc_in = nullptr, uint8_t* szc_out = nullptr);
 size_t cell_start_scratch_bytes();
 void launch_cell_start(hipStream_t s, Profiler* prof, const uint32_t* sorted_key, uint32_t n, uint32_t ncells,
                        uint32_t* cell_start /* [ncells+1] */, void* scratch /* cell_start_scratch_bytes() */,
@@ -129,6 +130,8 @@ struct SweepArgs {
     HeaderOut* hdr_partials;   // per-block partials of the NEXT step's header, written by the integrating final sweep (or nullptr)
     int h_mode;         // support_length_estimation (SPH_H_*)
     float* h2_next;     // FromDistribution*: the estimate for the next step is written here by the density sweep
+    float* omega;       // IISPH2
+    const uint8_t* size_class;
     const float* lam_prev;
     uint4* nl_ext;      // list words / index lists of the extended-range lists (level estimation)
     uint4* nlx_ext;
@@ -186,5 +189,7 @@ void launch_level_smooth(hipStream_t s, Profiler* prof, const SweepArgs& a, cons
 void launch_classify(hipStream_t s, Profiler* prof, const SweepArgs& a, const LevelArgs& l, const float* level, const sph_params* p);
 // reduce the per-block header partials of the integrating final sweep into `out_dev` (skipped while the solve is not done)
 void launch_header_ahead(sph_ctx* c, uint32_t nblocks, HeaderOut* out_dev);
+// IISPH2: p /= sqrt(omega) on the current pressure buffer (+ p / rho^2), simulation.rs:2358-2360
+void launch_iisph2_scale(hipStream_t s, Profiler* prof, const SweepArgs& a);
 void launch_vel_add_pacc(hipStream_t s, Profiler* prof, const SweepArgs& a);               // v += dt a^p
 void launch_integrate(hipStream_t s, Profiler* prof, const SweepArgs& a, float4* pm_out, int mode);  // 0: v+=dt a; x+=dt v   1: hybrid

@@ -184,7 +184,8 @@ __global__ __launch_bounds__(256) void k_reorder(uint32_t n, GridP g, const uint
                                                   float* __restrict__ lvlold_out, uint32_t* __restrict__ cxy,
                                                   const float* __restrict__ h2n_in, float* __restrict__ h2n_out,
                                                   const float* __restrict__ lam_in, float* __restrict__ lam_prev_out,
-                                                  uint32_t* __restrict__ zero_word)
+                                                  uint32_t* __restrict__ zero_word, const uint8_t* __restrict__ szc_in,
+                                                  uint8_t* __restrict__ szc_out)
 {
     uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i == 0 && zero_word) *zero_word = 0u;   // work-list counter of the cell-range kernels that follow
@@ -192,6 +193,7 @@ __global__ __launch_bounds__(256) void k_reorder(uint32_t n, GridP g, const uint
     uint32_t src = perm[i];
     if (h2n_in) h2n_out[i] = h2n_in[src];
     if (lam_in) lam_prev_out[i] = lam_in[src];
+    if (szc_in) szc_out[i] = szc_in[src];
     pm_out[i] = pm_in[src];
     vel_out[i] = vel_in[src];
     orig_out[i] = orig_in[src];
@@ -207,12 +209,12 @@ void launch_reorder(hipStream_t s, Profiler* prof, uint32_t n, GridP g, const ui
                     const float4* pm_in, const float2* vel_in, const uint32_t* orig_in, const float* lvl_in,
                     const float* lvlold_in, float4* pm_out, float2* vel_out, uint32_t* orig_out, float* lvl_out,
                     float* lvlold_out, uint32_t* cxy, const float* h2n_in, float* h2n_out, const float* lam_in, float* lam_prev_out,
-                    void* cell_start_scratch)
+                    void* cell_start_scratch, const uint8_t* szc_in, uint8_t* szc_out)
 {
     ProfScope ps(prof, "reorder", s);
     hipLaunchKernelGGL(k_reorder, dim3((n + 255) / 256), dim3(256), 0, s, n, g, sorted_key, perm, pm_in, vel_in, orig_in, lvl_in,
                        lvlold_in, pm_out, vel_out, orig_out, lvl_out, lvlold_out, cxy, h2n_in, h2n_out, lam_in, lam_prev_out,
-                       (uint32_t*)cell_start_scratch);
+                       (uint32_t*)cell_start_scratch, szc_in, szc_out);
 }
 
 // cell_start[c] = index of the first sorted particle whose cell is >= c; cell_start[ncells] = n.

@@ -57,6 +57,8 @@ SweepArgs make_args(sph_ctx* c, const StepP& sp)
     a.hdr_partials = (!c->dist.on) ? c->hdr_ahead_partials.as<HeaderOut>() : nullptr;
     a.h_mode = SPH_H_FROM_MASS;   // set by the step driver
     a.h2_next = c->h2n[k].as<float>();
+    a.omega = c->omega.as<float>();
+    a.size_class = c->szc[k].as<uint8_t>();
     a.lam_prev = c->lam_prev.as<float>();
     a.nl_ext = c->nl_ext.as<uint4>();
     a.nlx_ext = c->nlx_ext.as<uint4>();
@@ -871,7 +873,6 @@ static int group_step(Group& G, const sph_params* p, sph_step_stats* outs)
     if (!h_from_mass_mode && G.multi())
         return c0->fail(SPH_ERR_UNSUPPORTED, "FromDistribution support lengths on a slab decomposition are not covered yet");
     if (p->constrain_neighborhood_count) return c0->fail(SPH_ERR_UNSUPPORTED, "constrain_neighborhood_count is not covered yet");
-    if (p->pressure_solver_method == SPH_SOLVER_IISPH2) return c0->fail(SPH_ERR_UNSUPPORTED, "IISPH2 is not covered yet");
     const bool level_on = p->level_estimation_method != SPH_LEVEL_NONE;
     if (level_on && G.multi()) return c0->fail(SPH_ERR_UNSUPPORTED, "level estimation on a slab decomposition is not covered yet");
     if (level_on && p->level_estimation_after_advection)
@@ -1038,7 +1039,7 @@ static int group_step(Group& G, const sph_params* p, sph_step_stats* outs)
                            c->orig[k].as<uint32_t>(), c->lvl[k].as<float>(), c->lvlold[k].as<float>(), c->pm[c->pcur ^ 1].as<float4>(),
                            c->vel[k ^ 1].as<float2>(), c->orig[k ^ 1].as<uint32_t>(), c->lvl[k ^ 1].as<float>(), c->lvlold[k ^ 1].as<float>(),
                            c->cxy.as<uint32_t>(), c->h2n[k].as<float>(), c->h2n[k ^ 1].as<float>(), c->lam_sum.as<float>(),
-                           c->lam_prev.as<float>(), c->cs_scratch.p);
+                           c->lam_prev.as<float>(), c->cs_scratch.p, c->szc[k].as<uint8_t>(), c->szc[k ^ 1].as<uint8_t>());
             c->cur = k ^ 1;
             c->pcur ^= 1;
         }
@@ -1078,7 +1079,7 @@ static int group_step(Group& G, const sph_params* p, sph_step_stats* outs)
         HIPCHK(c, c->lvl_when.ensure(n * 4));
         HIPCHK(c, c->lvl_mark.ensure(n * 4));
         HIPCHK(c, c->stash.ensure(n * 4));
-        for (DevBuf* b : {&c->lvl_state, &c->flag_surface, &c->flag_insufficient, &c->size_class}) HIPCHK(c, b->ensure(n));
+        for (DevBuf* b : {&c->lvl_state, &c->flag_surface, &c->flag_insufficient}) HIPCHK(c, b->ensure(n));
         HIPCHK(c, c->nl_ext.ensure(sweep_list_bytes((uint32_t)n)));
         HIPCHK(c, c->nlx_ext.ensure(sweep_index_list_bytes((uint32_t)n)));
         m.a = make_args(c, m.sp);
@@ -1091,7 +1092,7 @@ static int group_step(Group& G, const sph_params* p, sph_step_stats* outs)
         lv.state = c->lvl_state.as<uint8_t>();
         lv.flag_surface = c->flag_surface.as<uint8_t>();
         lv.flag_insufficient = c->flag_insufficient.as<uint8_t>();
-        lv.size_class = c->size_class.as<uint8_t>();
+        lv.size_class = c->szc[c->cur].as<uint8_t>();
         lv.level = c->lvl[c->cur].as<float>();
         lv.when = c->lvl_when.as<uint32_t>();
         lv.mark = c->lvl_mark.as<uint32_t>();
@@ -1099,7 +1100,6 @@ static int group_step(Group& G, const sph_params* p, sph_step_stats* outs)
         lv.stash_first = p->fill_stash_with == SPH_STASH_SURFACE_DISTANCE_FIRST ? c->stash.as<float>() : nullptr;
         if (m.n) {
             if (p->fill_stash_with == SPH_STASH_NONE) (void)hipMemsetAsync(c->stash.p, 0, n * 4, c->stream);
-            (void)hipMemsetAsync(c->size_class.p, 2, n, c->stream);   // ParticleSizeClass::Optimal until classified
             launch_level_detect(c->stream, &c->prof, m.a, lv);
             // propagate until a sweep assigns nothing (`while changed`, simulation.rs:740-800); sweeps are queued in batches
             // of 8 and the per-sweep flags read once per batch -- a sweep behind the last effective one has no candidates
@@ -1171,6 +1171,24 @@ static int group_step(Group& G, const sph_params* p, sph_step_stats* outs)
         rec(4);
         begin_solve(1, 1);
         if ((rc = pressure_iterations(G, M, p->iisph_max_avg_density_error, 1, p->max_iters, c0->last_dens_iters, T_VX, true))) return rc;
+        rec(5);
+        break;
+    case SPH_SOLVER_IISPH2:  // simulation.rs:2262-2387: omega rides in the source-term sweep; p /= sqrt(omega) before the last a^p
+        if ((rc = non_pressure())) return rc;
+        rec(4);
+        begin_solve(3, 1);
+        if ((rc = pressure_iterations(G, M, p->iisph_max_avg_density_error, 1, p->max_iters, c0->last_dens_iters, T_NONE, true))) return rc;
+        for (auto& m : M) {
+            (void)hipSetDevice(m.c->device);
+            if (m.n) launch_iisph2_scale(m.c->stream, &m.c->prof, m.a);
+        }
+        if ((rc = refresh_ghosts(G, M, M[0].c->pressure_cur ? sel_pt1 : sel_pt0, 1, "pt"))) return rc;
+        for (auto& m : M) {
+            (void)hipSetDevice(m.c->device);
+            if (m.n) launch_pressure_accel(m.c->stream, &m.c->prof, m.a, -1, T_VX, m.c->pm[m.c->pcur ^ 1].as<float4>());
+            if (m.n && m.a.hdr_partials) launch_header_ahead(m.c, solver_reduce_blocks(m.n), m.c->hdr_host_dev);
+        }
+        if ((rc = sync_ctrl(G))) return rc;
         rec(5);
         break;
     case SPH_SOLVER_ONLY_DIVERGENCE:  // simulation.rs:2448-2500

@@ -664,10 +664,12 @@ __device__ __forceinline__ void solver_block_partial(SolverPartial* __restrict__
     }
 }
 
-template <class MathT>
+// OMEGA: IISPH2's source term (calculate_source_term_full_with_omega, simulation.rs:1678-1710) with the per-particle omega of
+// simulation.rs:2263-2311 summed in the same pass (its self term W(0)-like is not zero, so the own bit stays on the list)
+template <class MathT, bool OMEGA>
 struct OpSource {
     typedef MathT Math;
-    static constexpr bool HAS_EPILOGUE = true, SKIP_SELF = true;
+    static constexpr bool HAS_EPILOGUE = true, SKIP_SELF = !OMEGA;
     static constexpr bool EXTENDED = false;
     __device__ constexpr float krange() const { return 2.f; }
     typedef NBVecMr NB;
@@ -687,12 +689,16 @@ struct OpSource {
     SolverCtrl* __restrict__ ctrl_reset;   // the solve's control block starts from zero (first kernel of a solve)
     DeviceStatus* status;
     StepP sp;
-    int kind;  // 0 divergence, 1 full, 2 only density
+    int kind;  // 0 divergence, 1 full, 2 only density, 3 full with omega (OMEGA)
     int residual_density;
+    float* __restrict__ omega;              // OMEGA only
+    const uint8_t* __restrict__ size_class;
     struct Acc {
         float sum, rho_i, inv_rho_i, qx, qy;
         float err;
         uint32_t cls;
+        float om, om_c;   // OMEGA: running omega and H_i / (3 rho_i)
+        bool large;
     };
     __device__ bool skip() const { return false; }
     __device__ bool lane_skip(uint32_t) const { return false; }
@@ -715,9 +721,27 @@ struct OpSource {
         a.qy = v.y;
         a.err = 0.f;
         a.cls = 3u;
+        a.om = 1.f;
+        a.om_c = 0.f;
+        a.large = false;
+        if (OMEGA) {
+            const float4 Ai = pm[i];
+            a.om_c = (Ai.w * 2.f) / (3.f * a.rho_i);
+            a.large = size_class[i] == 3;   // ParticleSizeClass::Large (adaptivity/mod.rs:12-23)
+            if (a.large) a.om += a.om_c * Ai.z * dwdh(0.f, Ai.w * 2.f);   // simulation.rs:2277-2288
+        }
+    }
+    // dwdh of simulation.rs:2267-2276 (2-D): derivative of the normalised kernel with respect to the support radius H
+    __device__ static float dwdh(float d, float H)
+    {
+        const float q = d / H;
+        const float cd = 40.f / (7.f * SPH_PI_F);
+        const float w = cubic_unnorm(q), wd = cubic_unnorm_deriv(q);
+        return cd * -(2.f) / (H * H * H) * w + cd / (H * H) * wd * (-d / (H * H));
     }
     __device__ void pair(Acc& a, float4 Aj, NB Bj, float dx, float dy, float r2, float hij) const
     {
+        if (OMEGA && !a.large) a.om += a.om_c * Aj.z * dwdh(sqrtf(r2), hij * 2.f);   // simulation.rs:2289-2305
         if (kind == 2) return;
         float gx, gy;
         m.grad(dx, dy, r2, hij, gx, gy);
@@ -740,7 +764,11 @@ struct OpSource {
             const float bdiv = sp.opdisc == SPH_OP_WINCHENBACH2020 ? bdot : rho_b / rho_i * bdot;
             const float vdiv = a.sum + (sp.n_planes ? bdiv : 0.f);
             if (kind == 0) s = -vdiv / dt;
-            else s = -(sp.rest_density - rho_i) / (nde * dt * dt) - vdiv / dt;
+            else if (OMEGA) {
+                const float om = fminf(2.5f, fmaxf(a.om, 0.125f));
+                omega[i] = om;
+                s = -(sp.rest_density - rho_i) / (sp.rest_density * dt * dt) - vdiv / (dt * om);
+            } else s = -(sp.rest_density - rho_i) / (nde * dt * dt) - vdiv / dt;
         }
         src[i] = s;
         // ---- Jacobi iteration 0 (iisph_single_pressure_iteration, simulation.rs:1207-1322) in closed form:
@@ -1471,6 +1499,27 @@ __global__ void k_solver_decide(const double* __restrict__ tot, SolverCtrl* ctrl
 // ------------------------------------------------------------------------------------------------
 // per-particle maps
 // ------------------------------------------------------------------------------------------------
+// IISPH2 after the solve: pressure /= sqrt(omega) (simulation.rs:2358-2360), and the p / rho^2 payload of the
+// pressure-acceleration sweep that follows
+__global__ __launch_bounds__(256) void k_iisph2_scale(uint32_t n, const SolverCtrl* __restrict__ ctrl, float* __restrict__ p0, float* __restrict__ p1,
+                                                       float* __restrict__ pt0, float* __restrict__ pt1, const float* __restrict__ omega,
+                                                       const float* __restrict__ rho)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float* p = ctrl->cur ? p1 : p0;
+    float* pt = ctrl->cur ? pt1 : pt0;
+    const float v = p[i] / sqrtf(omega[i]);
+    const float r = rho[i];
+    p[i] = v;
+    pt[i] = v / (r * r);
+}
+void launch_iisph2_scale(hipStream_t s, Profiler* prof, const SweepArgs& a)
+{
+    ProfScope ps(prof, "iisph2_scale", s);
+    if (a.n) hipLaunchKernelGGL(k_iisph2_scale, dim3((a.n + 255) / 256), dim3(256), 0, s, a.n, a.ctrl, a.p0, a.p1, a.pt0, a.pt1, a.omega, a.rho);
+}
+
 // HybridDFSPH after the divergence solve: v += dt * a^p   (simulation.rs:2547-2560)
 __global__ __launch_bounds__(256) void k_vel_add_pacc(uint32_t n, float dt, float2* __restrict__ vel, const float2* __restrict__ pacc,
                                                        const uint32_t* __restrict__ orig, DeviceStatus* status)
@@ -1583,11 +1632,21 @@ void launch_non_pressure(hipStream_t s, Profiler* prof, const SweepArgs& a)
     SPH_DISPATCH(OpNonPressure, false, a.pm, a.orig, a.rho, a.vel, a.vel_tmp, a.status, a.sp)
 }
 
+template <class M>
+using OpSourcePlain = OpSource<M, false>;
+template <class M>
+using OpSourceOmega = OpSource<M, true>;
+
 void launch_source_term(hipStream_t s, Profiler* prof, const SweepArgs& a, int kind, int residual_density)
 {
     ProfScope ps(prof, "source_term", s);
-    SPH_DISPATCH(OpSource, false, a.pm, a.orig, a.rho, a.mrho, a.vel, a.lam_grad, a.aii, a.src, a.p1, a.pt1, a.dens_err,
-                 (SolverPartial*)a.partials, a.ctrl, a.status, a.sp, kind, residual_density)
+    if (kind == 3) {
+        SPH_DISPATCH(OpSourceOmega, false, a.pm, a.orig, a.rho, a.mrho, a.vel, a.lam_grad, a.aii, a.src, a.p1, a.pt1, a.dens_err,
+                     (SolverPartial*)a.partials, a.ctrl, a.status, a.sp, kind, residual_density, a.omega, a.size_class)
+        return;
+    }
+    SPH_DISPATCH(OpSourcePlain, false, a.pm, a.orig, a.rho, a.mrho, a.vel, a.lam_grad, a.aii, a.src, a.p1, a.pt1, a.dens_err,
+                 (SolverPartial*)a.partials, a.ctrl, a.status, a.sp, kind, residual_density, nullptr, nullptr)
 }
 
 void launch_pressure_accel(hipStream_t s, Profiler* prof, const SweepArgs& a, int iter, int tail, float4* pm_out)

@@ -72,7 +72,7 @@ int oracle_create(uint64_t n_capacity, int device_id, const sph_plane* planes, i
     ALLOC(c->mass, n, float); ALLOC(c->pos, 2 * n, float); ALLOC(c->vel, 2 * n, float); ALLOC(c->vel_tmp, 2 * n, float);
     ALLOC(c->pacc, 2 * n, float); ALLOC(c->density, n, float); ALLOC(c->source, n, float); ALLOC(c->pressure, n, float);
     ALLOC(c->pressure_next, n, float); ALLOC(c->aii, n, float); ALLOC(c->density_error, n, float);
-    ALLOC(c->h2, n, float); ALLOC(c->h2_next, n, float); ALLOC(c->level, n, float); ALLOC(c->level_tmp, n, float);
+    ALLOC(c->h2, n, float); ALLOC(c->h2_next, n, float); ALLOC(c->omega, n, float); ALLOC(c->level, n, float); ALLOC(c->level_tmp, n, float);
     ALLOC(c->level_old, n, float); ALLOC(c->constant_field, n, float); ALLOC(c->stash, n, float);
     ALLOC(c->flag_surface, n, uint8_t); ALLOC(c->flag_insufficient, n, uint8_t); ALLOC(c->size_class, n, uint8_t);
     ALLOC(c->neighbor_count, n, uint32_t); ALLOC(c->lam_n, n, uint8_t);
@@ -88,7 +88,7 @@ void oracle_destroy(oracle_ctx* c)
 {
     if (!c) return;
     free(c->mass); free(c->pos); free(c->vel); free(c->vel_tmp); free(c->pacc); free(c->density); free(c->source);
-    free(c->pressure); free(c->pressure_next); free(c->aii); free(c->density_error); free(c->h2); free(c->h2_next);
+    free(c->pressure); free(c->pressure_next); free(c->aii); free(c->density_error); free(c->h2); free(c->h2_next); free(c->omega);
     free(c->level); free(c->level_tmp); free(c->level_old); free(c->constant_field); free(c->stash);
     free(c->flag_surface); free(c->flag_insufficient); free(c->size_class); free(c->neighbor_count); free(c->lam_n);
     free(c->lam); free(c->lam_gx); free(c->lam_gy); free(c->nb_off); free(c->nb_idx); free(c->cell_index);

@@ -38,6 +38,7 @@ typedef struct oracle_ctx {
     float *mass, *pos, *vel, *vel_tmp, *pacc;
     float *density, *source, *pressure, *pressure_next, *aii, *density_error;
     float *h2, *h2_next;
+    float* omega; /* IISPH2 (simulation.rs:2262-2311) */
     float *level, *level_tmp, *level_old; /* LevelEstimationState: NaN = FluidInterior */
     float *constant_field, *stash;
     uint8_t *flag_surface, *flag_insufficient, *size_class;

@@ -443,7 +443,41 @@ static int update_velocity_with_non_pressure_accel(oracle_ctx* c, const sph_para
     return SPH_OK;
 }
 
-enum { SRC_DIVERGENCE, SRC_FULL, SRC_ONLY_DENSITY };
+enum { SRC_DIVERGENCE, SRC_FULL, SRC_ONLY_DENSITY, SRC_FULL_WITH_OMEGA };
+
+/* IISPH2's per-particle omega (simulation.rs:2263-2311; serial in the reference, independent per particle) */
+static inline float iisph2_dwdh(float d, float H)
+{
+    float q = d / H;
+    float cd = 40.f / (7.f * ORC_PI);
+    float w = orc_cubic_unnormalized(q);
+    float wd = orc_cubic_unnormalized_deriv(q);
+    return cd * -(2.f) / (H * H * H) * w + cd / (H * H) * wd * (-d / (H * H));
+}
+
+static void iisph2_omega(oracle_ctx* c)
+{
+    PARFOR
+    for (int64_t ii = 0; ii < (int64_t)c->n; ii++) {
+        uint64_t i = (uint64_t)ii;
+        float omega = 1.f;
+        if (c->size_class[i] == 3 /* ParticleSizeClass::Large (adaptivity/mod.rs:12-23) */) {
+            float h_ii = c->h2[i];
+            float H_i = c->h2[i] * 2.f, H_ii = h_ii * 2.f;
+            omega += H_i / (3.f * c->density[i]) * c->mass[i] * iisph2_dwdh(0.f, H_ii);
+        } else {
+            NB_LOOP(c, i, j) {
+                float dx = c->pos[2 * i] - c->pos[2 * j], dy = c->pos[2 * i + 1] - c->pos[2 * j + 1];
+                float h_ij = orc_hij(c->h2[i], c->h2[j]);
+                float H_i = c->h2[i] * 2.f, H_ij = h_ij * 2.f;
+                float d = sqrtf(orc_norm_sq(dx, dy));
+                omega += H_i / (3.f * c->density[i]) * c->mass[j] * iisph2_dwdh(d, H_ij);
+            }
+        }
+        omega = fminf(2.5f, fmaxf(omega, 0.125f));
+        c->omega[i] = omega;
+    }
+}
 
 /* prepare_ppe_divergence / prepare_full_ppe / prepare_only_density_part_ppe
  * (simulation.rs:1127-1204) with the source terms of :1633-1676, :1712-1748 */
@@ -459,6 +493,9 @@ static void prepare_ppe(oracle_ctx* c, const sph_params* p, float dt, int kind)
             s = -vdiv / dt;
         } else if (kind == SRC_ONLY_DENSITY) {
             s = -(p->rest_density - c->density[i]) / (next_density_estimate(c, p, i) * dt * dt);
+        } else if (kind == SRC_FULL_WITH_OMEGA) { /* calculate_source_term_full_with_omega, simulation.rs:1678-1710 */
+            float vdiv = divergence_iisph(c, p, c->vel, i);
+            s = -(p->rest_density - c->density[i]) / (p->rest_density * dt * dt) - vdiv / (dt * c->omega[i]);
         } else {
             float vdiv = divergence_iisph(c, p, c->vel, i);
             s = -(p->rest_density - c->density[i]) / (next_density_estimate(c, p, i) * dt * dt) - vdiv / dt;
@@ -873,7 +910,6 @@ int orc_step(oracle_ctx* c, const sph_params* p, sph_step_stats* out)
 
     if (c->n_planes == 0) return orc_fail(c, SPH_ERR_NO_BOUNDARY, "not implemented: NoBoundaryHandler::iisph_aii");
     if (p->constrain_neighborhood_count) return orc_fail(c, SPH_ERR_UNSUPPORTED, "constrain_neighborhood_count is not covered yet");
-    if (p->pressure_solver_method == SPH_SOLVER_IISPH2) return orc_fail(c, SPH_ERR_UNSUPPORTED, "IISPH2 is not covered yet");
 
     /* simulation.rs:1998-2016, 1865-1871 */
     if (p->support_length_estimation == SPH_H_FROM_MASS) {
@@ -943,6 +979,17 @@ int orc_step(oracle_ctx* c, const sph_params* p, sph_step_stats* out)
         prepare_ppe(c, p, dt, SRC_FULL);
         if ((rc = pressure_iterations(c, p, dt, p->iisph_max_avg_density_error, RES_DENSITY, 1, &st.density_solver))) return rc;
         ms_dens += (omp_get_wtime() - t0) * 1e3;
+        if ((rc = integrate_v_then_x(c, dt))) return rc;
+        break;
+    case SPH_SOLVER_IISPH2: /* simulation.rs:2262-2387 */
+        iisph2_omega(c);
+        if ((rc = update_velocity_with_non_pressure_accel(c, p, dt))) return rc;
+        t0 = omp_get_wtime();
+        prepare_ppe(c, p, dt, SRC_FULL_WITH_OMEGA);
+        if ((rc = pressure_iterations(c, p, dt, p->iisph_max_avg_density_error, RES_DENSITY, 1, &st.density_solver))) return rc;
+        ms_dens += (omp_get_wtime() - t0) * 1e3;
+        for (uint64_t i = 0; i < c->n; i++) c->pressure[i] /= sqrtf(c->omega[i]);
+        all_pressure_accels(c, p);
         if ((rc = integrate_v_then_x(c, dt))) return rc;
         break;
     case SPH_SOLVER_ONLY_DIVERGENCE: /* simulation.rs:2448-2500 */

@@ -518,3 +518,30 @@ def test_sparse_edits_between_steps(product_lib, oracle_lib, mode):
     assert np.array_equal(g.download("neighbor_count"), o.download("neighbor_count")) or mode != "FromMass"
     for f in ["position", "velocity", "density"]:
         assert rel_err(g.download(f), o.download(f)) < 1e-3, f
+
+
+@pytest.mark.parametrize("with_classes", [False, True])
+def test_iisph2_solver(product_lib, oracle_lib, with_classes):
+    """PressureSolverMethod::IISPH2 (simulation.rs:2262-2387): per-particle omega (own sum over the neighbours, or the
+    single self term for ParticleSizeClass::Large particles), source term divided by omega, p /= sqrt(omega) before the
+    last pressure acceleration.  A block compressed to 1.06 rho_0 keeps the solver busy."""
+    s = 1 / 28
+    scn = sc.SceneConfig(sc.SceneBoundary("box", 4.0, 2.0),
+                         [sc.SceneFluidBlock([-2 + s, -1 + s], [28 * s + 0.5 * s, 24 * s + 0.5 * s], s, 1.06, [-0.5, 0.0])])
+    g, o = make_pair(product_lib, oracle_lib, scn)
+    kw = dict(max_iters=4, pressure_solver_method="IISPH2", max_dt=0.0005)
+    if with_classes:   # classes come from the level estimation of the previous step: some particles end up Large
+        kw.update(level_estimation_method="EmptyAngle", maximum_surface_distance=0.3, particle_radius_fine=0.016, particle_radius_base=0.022)
+    p = forced(**kw).to_ffi()
+    for step in range(5):
+        sg, so = g.step(p), o.step(p)
+        assert sg.dt == so.dt
+        assert sg.density_solver.iters == so.density_solver.iters == 4
+    if with_classes:
+        cls = o.download("particle_size_class")
+        assert (cls == 3).sum() > 10 and (cls != 3).sum() > 10
+        assert (g.download("particle_size_class") != cls).mean() < 1e-3
+    assert o.download("pressure").max() > 0
+    assert_same_neighbor_sets(g, o)
+    for f in ALL_FIELDS:
+        assert rel_err(g.download(f), o.download(f)) < TOL.get(f, REL_TOL_FIELDS), f
