@@ -6,8 +6,8 @@
 //   cell      = floor(x / cell_size) per axis as i32                     (:253-255)
 //   cells_min = floor(min / cell_size) - 1, cells_max = floor(max / cell_size) + 2   (:273-274)
 //   linear    = (cx - minx) + (cy - miny) * size_x, x fastest            (:383-395)
-// How it is computed is MI355X-native: one-wave (64-lane) workgroups rank keys with ballot-based
-// match-any, digit histograms are scanned row-wise, and the cell-range table is written by the
+// How it is computed is MI355X-native: 1024-key tiles, four waves per tile, each wave ranks its 256 keys
+// with ballot-based match-any (no LDS atomics in the ranking), digit histograms are scanned row-wise, and the cell-range table is written by the
 // threads that sit on a key boundary of the sorted sequence (no atomics, deterministic).
 #include "sph_internal.hpp"
 
@@ -17,21 +17,39 @@
 // ------------------------------------------------------------------------------------------------
 // radix sort
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_rs_hist(const uint32_t* __restrict__ key, uint32_t n, int shift, uint32_t nblocks,
-                                                 uint32_t* __restrict__ hist)
+// digit of a key and, within the wave, which lanes hold the same digit (match-any by ballots: no LDS atomics)
+__device__ __forceinline__ uint64_t rs_peers(uint32_t d, bool valid)
+{
+    uint64_t peers = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < 8; b++) {
+        const bool bit = (d >> b) & 1u;
+        const uint64_t m = __ballot(bit);
+        peers &= bit ? m : ~m;
+    }
+    return peers;
+}
+
+// per-tile digit histogram: 256 threads, wave w owns keys [256 w, 256 w + 256) of the tile in 4 rounds of 64
+__global__ __launch_bounds__(256) void k_rs_hist(const uint32_t* __restrict__ key, uint32_t n, int shift, uint32_t nblocks,
+                                                  uint32_t* __restrict__ hist)
 {
     __shared__ uint32_t h[256];
-    const int lane = threadIdx.x;
-    for (int d = lane; d < 256; d += 64) h[d] = 0;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    h[tid] = 0;
     __syncthreads();
-    const uint32_t base = blockIdx.x * RS_TILE;
+    const uint32_t base = blockIdx.x * RS_TILE + w * (RS_TILE / 4);
+    const uint64_t lt = (1ull << lane) - 1ull;
 #pragma unroll
-    for (int i = 0; i < RS_ITEMS; i++) {
-        uint32_t idx = base + i * 64 + lane;
-        if (idx < n) atomicAdd(&h[(key[idx] >> shift) & 255u], 1u);
+    for (int r = 0; r < RS_ITEMS / 4; r++) {
+        const uint32_t idx = base + r * 64 + lane;
+        const bool valid = idx < n;
+        const uint32_t d = valid ? (key[idx] >> shift) & 255u : 0u;
+        const uint64_t peers = rs_peers(d, valid);
+        if (valid && (peers & lt) == 0ull) atomicAdd(&h[d], (uint32_t)__popcll(peers));   // one add per distinct digit of the round
     }
     __syncthreads();
-    for (int d = lane; d < 256; d += 64) hist[(size_t)d * nblocks + blockIdx.x] = h[d];
+    hist[(size_t)tid * nblocks + blockIdx.x] = h[tid];
 }
 
 // one workgroup per digit: exclusive scan of that digit's per-block counts, total -> totals[d]
@@ -65,55 +83,71 @@ __global__ __launch_bounds__(256) void k_rs_rowscan(uint32_t* __restrict__ hist,
     if (tid == 0) totals[blockIdx.x] = carry_s;
 }
 
-__global__ __launch_bounds__(64) void k_rs_scatter(const uint32_t* __restrict__ key_in, const uint32_t* __restrict__ val_in,
-                                                    uint32_t* __restrict__ key_out, uint32_t* __restrict__ val_out, uint32_t n,
-                                                    int shift, uint32_t nblocks, const uint32_t* __restrict__ hist,
-                                                    const uint32_t* __restrict__ totals)
+// stable scatter of one tile: wave w ranks its 256 keys in 4 rounds (match-any), the per-wave digit counts give each wave
+// its offset behind the waves before it, the row-scanned histogram gives the tile its offset behind the tiles before it
+__global__ __launch_bounds__(256) void k_rs_scatter(const uint32_t* __restrict__ key_in, const uint32_t* __restrict__ val_in,
+                                                     uint32_t* __restrict__ key_out, uint32_t* __restrict__ val_out, uint32_t n,
+                                                     int shift, uint32_t nblocks, const uint32_t* __restrict__ hist,
+                                                     const uint32_t* __restrict__ totals)
 {
-    __shared__ uint32_t running[256];
-    const int lane = threadIdx.x;
-    // exclusive scan of the 256 digit totals (4 per lane) + this block's row-scanned offsets
+    __shared__ uint32_t wcount[4][256];   // digit counts of each wave, then its running offsets
+    __shared__ uint32_t gbase[256];       // global offset of the tile's first key of each digit
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    for (int k = 0; k < 4; k++) wcount[k][tid] = 0;
+    // exclusive scan of the 256 digit totals (one per thread) + this tile's row-scanned offset
     {
-        uint32_t t0 = totals[4 * lane], t1 = totals[4 * lane + 1], t2 = totals[4 * lane + 2], t3 = totals[4 * lane + 3];
-        uint32_t s = t0 + t1 + t2 + t3;
-        uint32_t x = s;
+        __shared__ uint32_t wsum[4];
+        const uint32_t t = totals[tid];
+        uint32_t x = t;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
-            uint32_t y = __shfl_up(x, o, 64);
+            const uint32_t y = __shfl_up(x, o, 64);
             if (lane >= o) x += y;
         }
-        uint32_t ex = x - s;
-        const uint32_t* hb = hist + blockIdx.x;
-        running[4 * lane] = ex + hb[(size_t)(4 * lane) * nblocks];
-        running[4 * lane + 1] = ex + t0 + hb[(size_t)(4 * lane + 1) * nblocks];
-        running[4 * lane + 2] = ex + t0 + t1 + hb[(size_t)(4 * lane + 2) * nblocks];
-        running[4 * lane + 3] = ex + t0 + t1 + t2 + hb[(size_t)(4 * lane + 3) * nblocks];
+        if (lane == 63) wsum[w] = x;
+        __syncthreads();
+        uint32_t off = 0;
+        for (int k = 0; k < w; k++) off += wsum[k];
+        gbase[tid] = off + x - t + hist[(size_t)tid * nblocks + blockIdx.x];
+    }
+    const uint32_t base = blockIdx.x * RS_TILE + w * (RS_TILE / 4);
+    const uint64_t lt = (1ull << lane) - 1ull;
+    uint32_t k_[RS_ITEMS / 4], v_[RS_ITEMS / 4], d_[RS_ITEMS / 4], rank_[RS_ITEMS / 4];
+    bool ok_[RS_ITEMS / 4];
+    __syncthreads();
+    // phase 1: rank inside the wave (rounds in order => stable), count per digit
+#pragma unroll
+    for (int r = 0; r < RS_ITEMS / 4; r++) {
+        const uint32_t idx = base + r * 64 + lane;
+        ok_[r] = idx < n;
+        k_[r] = ok_[r] ? key_in[idx] : 0u;
+        v_[r] = ok_[r] ? val_in[idx] : 0u;
+        d_[r] = (k_[r] >> shift) & 255u;
+        const uint64_t peers = rs_peers(d_[r], ok_[r]);
+        const uint32_t before = wcount[w][d_[r]];          // keys of this digit in the wave's earlier rounds
+        rank_[r] = before + (uint32_t)__popcll(peers & lt);
+        // the wave's own LDS row: one writer per digit and round, ordered by the wave's program order
+        __builtin_amdgcn_wave_barrier();
+        if (ok_[r] && (peers & lt) == 0ull) wcount[w][d_[r]] = before + (uint32_t)__popcll(peers);
+        __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
-    const uint32_t base = blockIdx.x * RS_TILE;
-    const uint64_t lt = (1ull << lane) - 1ull;
-    for (int i = 0; i < RS_ITEMS; i++) {
-        uint32_t idx = base + i * 64 + lane;
-        bool valid = idx < n;
-        uint32_t k = valid ? key_in[idx] : 0u;
-        uint32_t v = valid ? val_in[idx] : 0u;
-        uint32_t d = (k >> shift) & 255u;
-        uint64_t peers = __ballot(valid);
-#pragma unroll
-        for (int b = 0; b < 8; b++) {
-            bool bit = (d >> b) & 1u;
-            uint64_t m = __ballot(bit);
-            peers &= bit ? m : ~m;
+    // phase 2: offsets of the waves behind each other (thread d handles digit d)
+    {
+        uint32_t run = gbase[tid];
+        for (int k = 0; k < 4; k++) {
+            const uint32_t c = wcount[k][tid];
+            wcount[k][tid] = run;
+            run += c;
         }
-        uint32_t rank = __popcll(peers & lt);
-        uint32_t cnt = __popcll(peers);
-        uint32_t off = running[d];
-        __syncthreads();
-        if (valid && rank == 0) running[d] = off + cnt;
-        __syncthreads();
-        if (valid) {
-            key_out[off + rank] = k;
-            val_out[off + rank] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < RS_ITEMS / 4; r++) {
+        if (ok_[r]) {
+            const uint32_t dst = wcount[w][d_[r]] + rank_[r];
+            key_out[dst] = k_[r];
+            val_out[dst] = v_[r];
         }
     }
 }
@@ -138,7 +172,7 @@ int radix_sort_pairs(hipStream_t s, Profiler* prof, uint32_t* keyA, uint32_t* va
         uint32_t *ki = cur ? keyB : keyA, *vi = cur ? valB : valA, *ko = cur ? keyA : keyB, *vo = cur ? valA : valB;
         {
             ProfScope ps(prof, "sort_hist", s);
-            hipLaunchKernelGGL(k_rs_hist, dim3(nblocks), dim3(64), 0, s, ki, n, p * 8, nblocks, hist);
+            hipLaunchKernelGGL(k_rs_hist, dim3(nblocks), dim3(256), 0, s, ki, n, p * 8, nblocks, hist);
         }
         {
             ProfScope ps(prof, "sort_rowscan", s);
@@ -146,7 +180,7 @@ int radix_sort_pairs(hipStream_t s, Profiler* prof, uint32_t* keyA, uint32_t* va
         }
         {
             ProfScope ps(prof, "sort_scatter", s);
-            hipLaunchKernelGGL(k_rs_scatter, dim3(nblocks), dim3(64), 0, s, ki, vi, ko, vo, n, p * 8, nblocks, hist, totals);
+            hipLaunchKernelGGL(k_rs_scatter, dim3(nblocks), dim3(256), 0, s, ki, vi, ko, vo, n, p * 8, nblocks, hist, totals);
         }
         cur ^= 1;
     }
