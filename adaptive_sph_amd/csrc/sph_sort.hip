@@ -18,11 +18,12 @@
 // radix sort
 // ------------------------------------------------------------------------------------------------
 // digit of a key and, within the wave, which lanes hold the same digit (match-any by ballots: no LDS atomics)
+template <int NB>
 __device__ __forceinline__ uint64_t rs_peers(uint32_t d, bool valid)
 {
     uint64_t peers = __ballot(valid);
 #pragma unroll
-    for (int b = 0; b < 8; b++) {
+    for (int b = 0; b < NB; b++) {
         const bool bit = (d >> b) & 1u;
         const uint64_t m = __ballot(bit);
         peers &= bit ? m : ~m;
@@ -30,13 +31,16 @@ __device__ __forceinline__ uint64_t rs_peers(uint32_t d, bool valid)
     return peers;
 }
 
+// NB = digit width in bits (8, 9 or 10: the fewest passes that cover the key; 18-bit cell ids take two 9-bit passes).
 // per-tile digit histogram: 256 threads, wave w owns keys [256 w, 256 w + 256) of the tile in 4 rounds of 64
+template <int NB>
 __global__ __launch_bounds__(256) void k_rs_hist(const uint32_t* __restrict__ key, uint32_t n, int shift, uint32_t nblocks,
                                                   uint32_t* __restrict__ hist)
 {
-    __shared__ uint32_t h[256];
+    constexpr int DIG = 1 << NB;
+    __shared__ uint32_t h[DIG];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    h[tid] = 0;
+    for (int d = tid; d < DIG; d += 256) h[d] = 0;
     __syncthreads();
     const uint32_t base = blockIdx.x * RS_TILE + w * (RS_TILE / 4);
     const uint64_t lt = (1ull << lane) - 1ull;
@@ -44,12 +48,12 @@ __global__ __launch_bounds__(256) void k_rs_hist(const uint32_t* __restrict__ ke
     for (int r = 0; r < RS_ITEMS / 4; r++) {
         const uint32_t idx = base + r * 64 + lane;
         const bool valid = idx < n;
-        const uint32_t d = valid ? (key[idx] >> shift) & 255u : 0u;
-        const uint64_t peers = rs_peers(d, valid);
+        const uint32_t d = valid ? (key[idx] >> shift) & (uint32_t)(DIG - 1) : 0u;
+        const uint64_t peers = rs_peers<NB>(d, valid);
         if (valid && (peers & lt) == 0ull) atomicAdd(&h[d], (uint32_t)__popcll(peers));   // one add per distinct digit of the round
     }
     __syncthreads();
-    hist[(size_t)tid * nblocks + blockIdx.x] = h[tid];
+    for (int d = tid; d < DIG; d += 256) hist[(size_t)d * nblocks + blockIdx.x] = h[d];
 }
 
 // one workgroup per digit: exclusive scan of that digit's per-block counts, total -> totals[d]
@@ -85,20 +89,27 @@ __global__ __launch_bounds__(256) void k_rs_rowscan(uint32_t* __restrict__ hist,
 
 // stable scatter of one tile: wave w ranks its 256 keys in 4 rounds (match-any), the per-wave digit counts give each wave
 // its offset behind the waves before it, the row-scanned histogram gives the tile its offset behind the tiles before it
+template <int NB>
 __global__ __launch_bounds__(256) void k_rs_scatter(const uint32_t* __restrict__ key_in, const uint32_t* __restrict__ val_in,
                                                      uint32_t* __restrict__ key_out, uint32_t* __restrict__ val_out, uint32_t n,
                                                      int shift, uint32_t nblocks, const uint32_t* __restrict__ hist,
                                                      const uint32_t* __restrict__ totals)
 {
-    __shared__ uint32_t wcount[4][256];   // digit counts of each wave, then its running offsets
-    __shared__ uint32_t gbase[256];       // global offset of the tile's first key of each digit
+    constexpr int DIG = 1 << NB, PER = DIG / 256;   // digits per thread in the per-digit phases
+    __shared__ uint32_t wcount[4][DIG];   // digit counts of each wave, then its running offsets
+    __shared__ uint32_t gbase[DIG];       // global offset of the tile's first key of each digit
+    __shared__ uint32_t wsum[4];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    for (int k = 0; k < 4; k++) wcount[k][tid] = 0;
-    // exclusive scan of the 256 digit totals (one per thread) + this tile's row-scanned offset
+    for (int k = 0; k < 4; k++)
+        for (int q = 0; q < PER; q++) wcount[k][tid * PER + q] = 0;
+    // exclusive scan of the digit totals (PER consecutive digits per thread) + this tile's row-scanned offsets
     {
-        __shared__ uint32_t wsum[4];
-        const uint32_t t = totals[tid];
-        uint32_t x = t;
+        uint32_t t[PER], sum = 0;
+        for (int q = 0; q < PER; q++) {
+            t[q] = totals[tid * PER + q];
+            sum += t[q];
+        }
+        uint32_t x = sum;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             const uint32_t y = __shfl_up(x, o, 64);
@@ -106,9 +117,12 @@ __global__ __launch_bounds__(256) void k_rs_scatter(const uint32_t* __restrict__
         }
         if (lane == 63) wsum[w] = x;
         __syncthreads();
-        uint32_t off = 0;
+        uint32_t off = x - sum;
         for (int k = 0; k < w; k++) off += wsum[k];
-        gbase[tid] = off + x - t + hist[(size_t)tid * nblocks + blockIdx.x];
+        for (int q = 0; q < PER; q++) {
+            gbase[tid * PER + q] = off + hist[(size_t)(tid * PER + q) * nblocks + blockIdx.x];
+            off += t[q];
+        }
     }
     const uint32_t base = blockIdx.x * RS_TILE + w * (RS_TILE / 4);
     const uint64_t lt = (1ull << lane) - 1ull;
@@ -122,8 +136,8 @@ __global__ __launch_bounds__(256) void k_rs_scatter(const uint32_t* __restrict__
         ok_[r] = idx < n;
         k_[r] = ok_[r] ? key_in[idx] : 0u;
         v_[r] = ok_[r] ? val_in[idx] : 0u;
-        d_[r] = (k_[r] >> shift) & 255u;
-        const uint64_t peers = rs_peers(d_[r], ok_[r]);
+        d_[r] = (k_[r] >> shift) & (uint32_t)(DIG - 1);
+        const uint64_t peers = rs_peers<NB>(d_[r], ok_[r]);
         const uint32_t before = wcount[w][d_[r]];          // keys of this digit in the wave's earlier rounds
         rank_[r] = before + (uint32_t)__popcll(peers & lt);
         // the wave's own LDS row: one writer per digit and round, ordered by the wave's program order
@@ -132,12 +146,13 @@ __global__ __launch_bounds__(256) void k_rs_scatter(const uint32_t* __restrict__
         __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
-    // phase 2: offsets of the waves behind each other (thread d handles digit d)
-    {
-        uint32_t run = gbase[tid];
+    // phase 2: offsets of the waves behind each other (each thread handles its PER digits)
+    for (int q = 0; q < PER; q++) {
+        const int d = tid * PER + q;
+        uint32_t run = gbase[d];
         for (int k = 0; k < 4; k++) {
-            const uint32_t c = wcount[k][tid];
-            wcount[k][tid] = run;
+            const uint32_t c = wcount[k][d];
+            wcount[k][d] = run;
             run += c;
         }
     }
@@ -152,10 +167,30 @@ __global__ __launch_bounds__(256) void k_rs_scatter(const uint32_t* __restrict__
     }
 }
 
+#define RS_MAX_DIGITS 1024
+
 size_t radix_sort_scratch_elems(uint32_t n)
 {
     size_t nblocks = ((size_t)n + RS_TILE - 1) / RS_TILE;
-    return 256 * (nblocks ? nblocks : 1) + 256;
+    return RS_MAX_DIGITS * (nblocks ? nblocks : 1) + RS_MAX_DIGITS;
+}
+
+template <int NB>
+static void radix_pass(hipStream_t s, Profiler* prof, const uint32_t* ki, const uint32_t* vi, uint32_t* ko, uint32_t* vo, uint32_t n, int shift,
+                       uint32_t nblocks, uint32_t* hist, uint32_t* totals)
+{
+    {
+        ProfScope ps(prof, "sort_hist", s);
+        hipLaunchKernelGGL(k_rs_hist<NB>, dim3(nblocks), dim3(256), 0, s, ki, n, shift, nblocks, hist);
+    }
+    {
+        ProfScope ps(prof, "sort_rowscan", s);
+        hipLaunchKernelGGL(k_rs_rowscan, dim3(1 << NB), dim3(256), 0, s, hist, nblocks, totals);
+    }
+    {
+        ProfScope ps(prof, "sort_scatter", s);
+        hipLaunchKernelGGL(k_rs_scatter<NB>, dim3(nblocks), dim3(256), 0, s, ki, vi, ko, vo, n, shift, nblocks, hist, totals);
+    }
 }
 
 int radix_sort_pairs(hipStream_t s, Profiler* prof, uint32_t* keyA, uint32_t* valA, uint32_t* keyB, uint32_t* valB, uint32_t n,
@@ -164,24 +199,18 @@ int radix_sort_pairs(hipStream_t s, Profiler* prof, uint32_t* keyA, uint32_t* va
     if (n == 0) return 0;
     uint32_t nblocks = (n + RS_TILE - 1) / RS_TILE;
     uint32_t* hist = scratch;
-    uint32_t* totals = scratch + (size_t)256 * nblocks;
-    int passes = (bits + 7) / 8;
-    if (passes < 1) passes = 1;
+    uint32_t* totals = scratch + (size_t)RS_MAX_DIGITS * nblocks;
+    if (bits < 1) bits = 1;
+    // the fewest passes with digits of at most 10 bits, then the narrowest digit that still covers the key in that many
+    const int passes = (bits + 9) / 10;
+    int nb = (bits + passes - 1) / passes;
+    if (nb < 8) nb = 8;
     int cur = 0;
     for (int p = 0; p < passes; p++) {
         uint32_t *ki = cur ? keyB : keyA, *vi = cur ? valB : valA, *ko = cur ? keyA : keyB, *vo = cur ? valA : valB;
-        {
-            ProfScope ps(prof, "sort_hist", s);
-            hipLaunchKernelGGL(k_rs_hist, dim3(nblocks), dim3(256), 0, s, ki, n, p * 8, nblocks, hist);
-        }
-        {
-            ProfScope ps(prof, "sort_rowscan", s);
-            hipLaunchKernelGGL(k_rs_rowscan, dim3(256), dim3(256), 0, s, hist, nblocks, totals);
-        }
-        {
-            ProfScope ps(prof, "sort_scatter", s);
-            hipLaunchKernelGGL(k_rs_scatter, dim3(nblocks), dim3(256), 0, s, ki, vi, ko, vo, n, p * 8, nblocks, hist, totals);
-        }
+        if (nb == 8) radix_pass<8>(s, prof, ki, vi, ko, vo, n, p * nb, nblocks, hist, totals);
+        else if (nb == 9) radix_pass<9>(s, prof, ki, vi, ko, vo, n, p * nb, nblocks, hist, totals);
+        else radix_pass<10>(s, prof, ki, vi, ko, vo, n, p * nb, nblocks, hist, totals);
         cur ^= 1;
     }
     return cur;
