@@ -11,7 +11,7 @@
 // threads that sit on a key boundary of the sorted sequence (no atomics, deterministic).
 #include "sph_internal.hpp"
 
-#define RS_ITEMS 16
+#define RS_ITEMS 32
 #define RS_TILE (64 * RS_ITEMS)
 
 // ------------------------------------------------------------------------------------------------
