@@ -129,6 +129,7 @@ struct SweepArgs {
     uint4* nlx;         // explicit index lists (multi-resolution scenes)
     HeaderOut* hdr_partials;   // per-block partials of the NEXT step's header, written by the integrating final sweep (or nullptr)
     int h_mode;         // support_length_estimation (SPH_H_*)
+    int sp_check_aii;   // SimulationParams::check_aii
     float* h2_next;     // FromDistribution*: the estimate for the next step is written here by the density sweep
     float* omega;       // IISPH2
     const uint8_t* size_class;
@@ -191,5 +192,6 @@ void launch_classify(hipStream_t s, Profiler* prof, const SweepArgs& a, const Le
 void launch_header_ahead(sph_ctx* c, uint32_t nblocks, HeaderOut* out_dev);
 // IISPH2: p /= sqrt(omega) on the current pressure buffer (+ p / rho^2), simulation.rs:2358-2360
 void launch_iisph2_scale(hipStream_t s, Profiler* prof, const SweepArgs& a);
+void launch_check_aii(hipStream_t s, Profiler* prof, const SweepArgs& a);   // after launch_aii_const when check_aii is set
 void launch_vel_add_pacc(hipStream_t s, Profiler* prof, const SweepArgs& a);               // v += dt a^p
 void launch_integrate(hipStream_t s, Profiler* prof, const SweepArgs& a, float4* pm_out, int mode);  // 0: v+=dt a; x+=dt v   1: hybrid

@@ -93,6 +93,7 @@ const char* status_message(uint32_t code)
     case SPH_ERR_POSITION_NOT_FINITE: return "Assertion 'p_position[d].is_finite()' failed!";
     case SPH_ERR_VISCOSITY_NOT_FINITE: return "Assertion 'viscosity_accel[d].is_finite()' failed!";
     case SPH_ERR_CHECK_NEIGHBORHOOD: return "neighbour list differs from the brute-force definition";
+    case SPH_ERR_CHECK_AII: return "a_ii value not equal with a tolerance of 0.01";
     case SPH_ERR_LEVEL_WEIGHT: return "weight is <=0 in smooth_level_estimation_field";
     case SPH_ERR_VOLUME_ESTIMATE: return "assertion failed: volume_estimate >= 0.";
     default: return "device-side guard failed";
@@ -873,13 +874,13 @@ static int group_step(Group& G, const sph_params* p, sph_step_stats* outs)
     if (!h_from_mass_mode && G.multi())
         return c0->fail(SPH_ERR_UNSUPPORTED, "FromDistribution support lengths on a slab decomposition are not covered yet");
     if (p->constrain_neighborhood_count) return c0->fail(SPH_ERR_UNSUPPORTED, "constrain_neighborhood_count is not covered yet");
+    if (p->check_aii && G.multi()) return c0->fail(SPH_ERR_UNSUPPORTED, "check_aii on a slab decomposition is not covered yet");
     const bool level_on = p->level_estimation_method != SPH_LEVEL_NONE;
     if (level_on && G.multi()) return c0->fail(SPH_ERR_UNSUPPORTED, "level estimation on a slab decomposition is not covered yet");
     if (level_on && p->level_estimation_after_advection)
         return c0->fail(SPH_ERR_UNSUPPORTED, "level_estimation_after_advection is not covered yet (needs the neighbourhood of the advected positions)");
     if (level_on && p->level_estimation_method == SPH_LEVEL_CENTER_DIFF)   // simulation.rs:2029-2031
         return c0->fail(SPH_ERR_INVALID_ARGUMENT, "center diff level estimation method needs density values");
-    if (p->check_aii) return c0->fail(SPH_ERR_UNSUPPORTED, "check_aii is not covered yet");
     if (!p->level_estimation_after_advection && !p->use_extended_range_for_level_estimation)
         return c0->fail(SPH_ERR_INVALID_ARGUMENT, "assertion failed: simulation_params.use_extended_range_for_level_estimation");
     if (!G.multi() && c0->n == 0) return c0->fail(SPH_ERR_INVALID_ARGUMENT, "called `Option::unwrap()` on a `None` value (no particles)");
@@ -1062,6 +1063,7 @@ static int group_step(Group& G, const sph_params* p, sph_step_stats* outs)
         if (tev) (void)hipEventRecord(c->ev[1], s);
         m.a = make_args(c, sp);
         m.a.h_mode = p->support_length_estimation;
+        m.a.sp_check_aii = p->check_aii;
         m.st.n_particles = c->n;
         m.st.dt = dt;
     }
@@ -1084,6 +1086,7 @@ static int group_step(Group& G, const sph_params* p, sph_step_stats* outs)
         HIPCHK(c, c->nlx_ext.ensure(sweep_index_list_bytes((uint32_t)n)));
         m.a = make_args(c, m.sp);
         m.a.h_mode = p->support_length_estimation;
+        m.a.sp_check_aii = p->check_aii;
         lv.k = p->level_estimation_range / SPH_ETA;                    // simulation.rs:2036
         lv.threshold = cosf(50.f * (SPH_PI_F / 180.f));                // simulation.rs:544
         lv.max_surface_distance = p->maximum_surface_distance;
@@ -1136,6 +1139,7 @@ static int group_step(Group& G, const sph_params* p, sph_step_stats* outs)
     for (auto& m : M) {
         (void)hipSetDevice(m.c->device);
         if (m.n) launch_aii_const(m.c->stream, &m.c->prof, m.a);
+        if (m.n && p->check_aii && !G.multi()) launch_check_aii(m.c->stream, &m.c->prof, m.a);   // simulation.rs:1109-1123
     }
     auto non_pressure = [&]() -> int {  // update_velocity_with_non_pressure_accel: velocity_temp, then mem::swap
         for (auto& m : M) {

@@ -474,6 +474,7 @@ struct OpAiiConst {
     float* __restrict__ constf;
     DeviceStatus* status;
     StepP sp;
+    float2* __restrict__ ap_unit;   // check_aii only: a^p_i for the pressure field e_i (input of OpCheckAii), else nullptr
     struct Acc {
         float cf, ax, ay, a2, bx, by;
     };
@@ -526,6 +527,14 @@ struct OpAiiConst {
         }
         aii[i] = v;
         if (!isfinite(v)) raise_error(status, SPH_ERR_AII_NOT_FINITE, orig[i]);
+        if (ap_unit) {
+            // calculate_particle_pressure_accel with p = e_i at particle i itself (simulation.rs:1750-1808, boundary
+            // boundary_winchenbach2020.rs:164-194): -sum_k m_k (1/rho_i^2 + 0) grad W_ik - rho_b (1/rho_i^2 + p_ib/rho_b^2) sum grad lambda
+            const float pti = 1.f / (rho_i * rho_i);
+            const float p_ib = sp.opdisc == SPH_OP_SYMMETRIC_GRADIENT ? 1.f : 0.f;
+            const float fb = -rho_b * (1.f / (rho_i * rho_i) + p_ib / (rho_b * rho_b));
+            ap_unit[i] = make_float2(-(pti * a.ax) + fb * gl.x, -(pti * a.ay) + fb * gl.y);
+        }
         return wall;
     }
 };
@@ -1069,6 +1078,71 @@ struct OpJacobi {
     __device__ void epilogue(Acc& a, bool active, uint32_t blk) const { solver_block_partial(partials, active ? a.cls : 3u, a.err, blk); }
 };
 
+
+// ------------------------------------------------------------------------------------------------
+// Op: check_aii (simulation.rs:1347-1375): a_ii against the operator applied to the unit pressure field e_i
+//   calculate_aii_inefficiently = div( a^p[e_i] )_i  (simulation.rs:1324-1345, 1594-1631), tolerance 0.01 in f32.
+// With p = e_i only two kinds of pressure acceleration are non-zero: a^p_i (OpAiiConst stored it) and, for a neighbour j,
+// a^p_j = -m_i (0 + 1/rho_i^2) grad W_ji = (m_i / rho_i^2) grad W_ij -- so the composition is one more sweep.
+// ------------------------------------------------------------------------------------------------
+template <class MathT>
+struct OpCheckAii {
+    typedef MathT Math;
+    static constexpr bool HAS_EPILOGUE = false, SKIP_SELF = true;
+    static constexpr bool EXTENDED = false;
+    __device__ constexpr float krange() const { return 2.f; }
+    typedef float NB;   // m_j / rho_j
+    MathT m;
+    const float4* __restrict__ pm;
+    const uint32_t* __restrict__ orig;
+    const float* __restrict__ rho;
+    const float* __restrict__ mrho;
+    const float2* __restrict__ lam_grad;
+    const float* __restrict__ aii;
+    const float2* __restrict__ ap_unit;
+    DeviceStatus* status;
+    StepP sp;
+    struct Acc {
+        float sum, rho_i, c_i, qx, qy;
+    };
+    __device__ bool skip() const { return false; }
+    __device__ bool lane_skip(uint32_t) const { return false; }
+    __device__ void init(Acc&) const {}
+    __device__ void epilogue(Acc&, bool, uint32_t) const {}
+    __device__ float4 loadA(uint32_t j) const { return pm[j]; }
+    __device__ NB nb(const Acc&, uint32_t j, float4) const { return mrho[j]; }
+    __device__ void begin(Acc& a, uint32_t i, float4 Ai) const
+    {
+        a.sum = 0.f;
+        a.rho_i = rho[i];
+        a.c_i = Ai.z / (a.rho_i * a.rho_i);   // m_i / rho_i^2
+        const float2 q = ap_unit[i];
+        a.qx = q.x;
+        a.qy = q.y;
+    }
+    __device__ void pair(Acc& a, float4 Aj, NB mrj, float dx, float dy, float r2, float hij) const
+    {
+        float gx, gy;
+        m.grad(dx, dy, r2, hij, gx, gy);
+        // the self pair has grad W = 0: its (Q_i - Q_i) term vanishes either way
+        const float dot = (a.c_i * gx - a.qx) * gx + (a.c_i * gy - a.qy) * gy;   // (a^p_j - a^p_i) . grad W_ij
+        if (sp.opdisc == SPH_OP_WINCHENBACH2020) a.sum += mrj * dot;
+        else a.sum += Aj.z / a.rho_i * dot;
+    }
+    __device__ bool finish(Acc& a, uint32_t i, float4, bool wall) const
+    {
+        float bdiv = 0.f;
+        if (sp.n_planes && wall) {
+            const float2 gl = lam_grad[i];
+            const float bdot = (0.f - a.qx) * gl.x + (0.f - a.qy) * gl.y;
+            bdiv = sp.opdisc == SPH_OP_WINCHENBACH2020 ? bdot : sp.rest_density / a.rho_i * bdot;
+        }
+        const float real = a.sum + bdiv;
+        const float v = aii[i];
+        if (!(real <= v + 0.01f && real >= v - 0.01f)) raise_error(status, SPH_ERR_CHECK_AII, orig[i]);   // assert_ft_approx_eq
+        return wall;
+    }
+};
 
 // ================================================================================================
 // Level estimation (distance-to-surface field of the adaptivity; simulation.rs:539-927).  It works on its own
@@ -1623,7 +1697,14 @@ void launch_density(hipStream_t s, Profiler* prof, const SweepArgs& a)
 void launch_aii_const(hipStream_t s, Profiler* prof, const SweepArgs& a)
 {
     ProfScope ps(prof, "aii_constfield", s);
-    SPH_DISPATCH(OpAiiConst, false, a.pm, a.orig, a.rho, a.mrho, a.lam_sum, a.lam_grad, a.aii, a.constf, a.status, a.sp)
+    SPH_DISPATCH(OpAiiConst, false, a.pm, a.orig, a.rho, a.mrho, a.lam_sum, a.lam_grad, a.aii, a.constf, a.status, a.sp,
+                 a.sp_check_aii ? a.pacc : nullptr)
+}
+
+void launch_check_aii(hipStream_t s, Profiler* prof, const SweepArgs& a)
+{
+    ProfScope ps(prof, "check_aii", s);
+    SPH_DISPATCH(OpCheckAii, false, a.pm, a.orig, a.rho, a.mrho, a.lam_grad, a.aii, a.pacc, a.status, a.sp)
 }
 
 void launch_non_pressure(hipStream_t s, Profiler* prof, const SweepArgs& a)

@@ -100,11 +100,18 @@ def test_trajectory_forced_iterations(product_lib, oracle_lib, solver):
 @pytest.mark.parametrize("op", ["ConsistentSymmetricGradient", "Winchenbach2020"])
 def test_operator_discretizations(product_lib, oracle_lib, op):
     g, o = make_pair(product_lib, oracle_lib, sc.dam_break_small(32, 32, 1 / 32))
-    p = forced(max_iters=3, operator_discretization=op).to_ffi()
+    # check_aii: the closed-form a_ii of every particle against the operator applied to e_i (simulation.rs:1347-1375) --
+    # on both sides, for each discretisation
+    p = forced(max_iters=3, operator_discretization=op, check_aii=True).to_ffi()
     for s in range(5):
         g.step(p), o.step(p)
     for f in ALL_FIELDS:
         assert rel_err(g.download(f), o.download(f)) < TOL.get(f, REL_TOL_FIELDS), f
+    g.profile_reset()
+    g.profile_enable(1)
+    g.step(p)
+    assert g.profile_get()["check_aii"][0] == 1      # the check sweep really ran
+    g.profile_enable(0)
 
 
 def test_wcsph_viscosity_and_penalty_terms(product_lib, oracle_lib):
