@@ -34,7 +34,9 @@
 // src/simulation/boundary_handler/sdf_boundary_handler/boundary_winchenbach2020.rs).
 #include "sph_internal.hpp"
 
-#define SWEEP_THREADS 256
+#ifndef SWEEP_THREADS
+#define SWEEP_THREADS 256   // measured: 128 and 512 are within 1 % of 256 (scripts/ablate.sh)
+#endif
 
 // Neighbour list word (one uint4 = 16 B per particle, coalesced 1 KB per wave):
 //   x, y, z : accepted-candidate bit masks of the three cell rows cy-1, cy, cy+1.  Bit b of row r
