@@ -129,6 +129,8 @@ def main():
             raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
     import torch
     import torch.distributed as dist
+    if torch.cuda.is_available():
+        local_rank %= max(torch.cuda.device_count(), 1)   # more ranks than devices: only for functional checks on a small box
     from adaptive_sph_amd import build, ffi, scene as sc
     from adaptive_sph_amd.workloads import WORKLOADS
 
@@ -138,7 +140,7 @@ def main():
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         dist.barrier()
     plib = ffi.load_product()
 
