@@ -554,7 +554,12 @@ def test_iisph2_solver(product_lib, oracle_lib, with_classes):
         assert rel_err(g.download(f), o.download(f)) < TOL.get(f, REL_TOL_FIELDS), f
 
 
-# Two of the reference's own recipes that run without the host-side adaptivity (media/*.yaml: `update_attributes` on top of
+SCENE_RATIO_2TO1 = dict(boundary=dict(type="box", width=2, height=2),
+                        blocks=[dict(pos=[-0.95, -0.5], size=[0.55, 1.4], spacing=0.03, volume_fill_ratio=0.93, velocity=[0, 0]),
+                                dict(pos=[0.4, -0.5], size=[0.55, 1.4], spacing=0.06, volume_fill_ratio=0.93, velocity=[0, 0])])
+
+
+# Three of the reference's own recipes that run without the host-side adaptivity (media/*.yaml: `update_attributes` on top of
 # default-config.yaml + a scene file).  The values below are those files' data.
 RECIPES = {
     # media/ratio-stress-test-video.yaml + media/ratio-stress-test-scene.yaml: 50:1 radius ratio, IISPH, the Sdf2D box
@@ -567,6 +572,11 @@ RECIPES = {
                      dict(pos=[-0.95, -0.5], size=[0.55, 1.4], spacing=0.008, volume_fill_ratio=0.93, velocity=[0, 0])]),
         11832 + 3),
     # media/motivation-video.yaml (uniform variant) + media/motivation-scene2.yaml: the recipe BASELINE configs[1] scales up
+    # media/neighbor-numbers.yaml (first entry) + media/scene-ratio2to1.yaml: distribution-based smoothing lengths, 2:1 radii
+    "neighbor-numbers-from-distribution": (
+        dict(merging=False, sharing=False, splitting=False, support_length_estimation="FromDistributionClamped1"),
+        SCENE_RATIO_2TO1,
+        None),
     "motivation-uniform": (
         dict(merging=False, sharing=False, splitting=False, support_length_estimation="FromMass", hybrid_dfsph_factor=20000000.0,
              pressure_solver_method="HybridDFSPH", cfl_factor=0.4, max_dt=0.002, viscosity=0.001, iisph_max_avg_density_error=0.002,
@@ -586,16 +596,21 @@ def test_reference_media_recipes(product_lib, oracle_lib, name):
     P = default_params(**overrides)
     scn = sc.SceneConfig.from_mapping(scene_map)
     g, o = make_pair(product_lib, oracle_lib, scn, P.init_boundary_handler)
-    assert g.n == n_expected                    # floor(size / spacing) per axis in f32 (simulation.rs:2968-2971)
+    if n_expected is not None:
+        assert g.n == n_expected                # floor(size / spacing) per axis in f32 (simulation.rs:2968-2971)
     P = P.replace(max_iters=4, iisph_max_avg_density_error=0.0, hybrid_dfsph_max_avg_density_error=0.0,
                   hybrid_dfsph_max_avg_divergence_error=0.0)
     p = P.to_ffi()
     for s in range(3):
         sg, so = g.step(p), o.step(p)
         assert abs(sg.dt - so.dt) <= 1e-5 * so.dt
-    assert np.array_equal(g.download("neighbor_count"), o.download("neighbor_count"))
-    assert_same_neighbor_sets(g, o)
+    if P.support_length_estimation == "FromMass":
+        assert np.array_equal(g.download("neighbor_count"), o.download("neighbor_count"))
+        assert_same_neighbor_sets(g, o)
+    else:   # h carries 1e-7 differences after the first estimate: a pair on the support boundary may flip
+        assert (g.download("neighbor_count") != o.download("neighbor_count")).mean() < 0.02
+        assert rel_err(g.download("h2"), o.download("h2")) < 1e-5
     for f in ["position", "velocity", "density", "aii", "ppe_source_term"]:
         assert rel_err(g.download(f), o.download(f)) < TOL.get(f, REL_TOL_FIELDS), f
-    if P.level_estimation_method != "None":
+    if P.level_estimation_method != "None" and P.support_length_estimation == "FromMass":
         _level_fields_match(g, o)
