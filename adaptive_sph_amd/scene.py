@@ -150,6 +150,14 @@ def dam_break_8m() -> SceneConfig:
                        [SceneFluidBlock([-1.9995, -0.9995], [1.4143, 1.4143], 0.00048828125, 0.93, [0.0, 0.0])])
 
 
+def ratio_stress_4m() -> SceneConfig:
+    """configs[4]: the geometry of media/ratio-stress-test-scene.yaml at 50:1 radius ratio with 4 002 768 fine + 1 575 coarse
+    particles."""
+    return SceneConfig(SceneBoundary("box", 2.0, 2.0),
+                       [SceneFluidBlock([0.4, -0.5], [0.55, 1.4], 0.021925, 0.93, [0.0, 0.0]),
+                        SceneFluidBlock([-0.95, -0.5], [0.55, 1.4], 0.0004385, 0.93, [0.0, 0.0])])
+
+
 def dam_break_weak(n_gpus: int) -> SceneConfig:
     """Weak-scaling family between configs[1] (1 GPU, 1M) and configs[3] (8 GPUs, 8M): ~1M particles per GPU.
     2 GPUs: configs[1]'s column twice as wide, 2048 x 1024 = 2 097 152 at spacing 1/1024; 4 GPUs: 2048 x 2048 = 4 194 304

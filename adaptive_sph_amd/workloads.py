@@ -67,5 +67,10 @@ WORKLOADS = {
     "dam_break_8m": (sc.dam_break_8m, dam_break_params_scaled(1.0 / 2048), "2D dam-break, 2896x2896 = 8 386 816 particles, max_dt 0.001"),
     "dam_break_2m": (lambda: sc.dam_break_weak(2), dam_break_params, "2D dam-break, 2048x1024 = 2 097 152 particles (configs[1]'s column twice as wide)"),
     "dam_break_4m": (lambda: sc.dam_break_weak(4), dam_break_params_scaled(1.0 / 2048), "2D dam-break, 2048x2048 = 4 194 304 particles, max_dt 0.001"),
+    # configs[4] without the host-side adaptivity: media/ratio-stress-test-video.yaml's IISPH recipe on the 4M-particle scene
+    "ratio_stress_4m": (sc.ratio_stress_4m, lambda **kw: default_params(**dict(dict(
+        merging=False, sharing=False, splitting=False, support_length_estimation="FromMass", pressure_solver_method="IISPH",
+        cfl_factor=0.2, max_dt=0.001, iisph_max_avg_density_error=0.001, init_boundary_handler="AnalyticUnderestimate",
+        level_estimation_method="None"), **kw)), "ratio-stress-test geometry, 4 004 343 particles at 50:1 radii, IISPH, Sdf2D box"),
     "dam_break_64k": (lambda: sc.dam_break_small(256, 256, 1.0 / 256), dam_break_params, "2D dam-break, 256x256 particles (smoke)"),
 }

@@ -79,7 +79,7 @@ def short_run(plib, name, steps=40, warmup=10, **param_overrides):
     scene_f, params_f, desc = WORKLOADS[name]
     scn, P = scene_f(), params_f(**param_overrides)
     pos, mass, vel = sc.init_particles(scn)
-    ctx = ffi.Context(plib, len(mass), sc.boundary_planes(scn.boundary))
+    ctx = ffi.Context(plib, len(mass), sc.boundary_planes(scn.boundary, P.init_boundary_handler))
     ctx.upload(mass, pos, vel)
     p = P.to_ffi()
     for _ in range(warmup):
@@ -266,6 +266,7 @@ def main():
         out["other_configs"] = [
             short_run(plib, "dam_break_1m_adaptive"),                                       # configs[2]: 4:1 radius ratio
             short_run(plib, "dam_break_8m", steps=20, warmup=10),                            # configs[3] on ONE GPU
+            short_run(plib, "ratio_stress_4m", steps=20, warmup=5),                         # configs[4]'s scene (50:1, 4M), no adaptivity
             short_run(plib, "dam_break_1m", steps=5, warmup=2, level_estimation_method="EmptyAngle",
                       maximum_surface_distance=0.2, particle_radius_fine=0.0005, particle_radius_base=0.002),   # + level estimation
         ]

@@ -12,7 +12,7 @@ scene_f, params_f, _ = WORKLOADS[wl]
 scn, P = scene_f(), params_f()
 pos, mass, vel = sc.init_particles(scn)
 lib = ffi.load_product()
-g = ffi.Context(lib, len(mass), sc.boundary_planes(scn.boundary))
+g = ffi.Context(lib, len(mass), sc.boundary_planes(scn.boundary, P.init_boundary_handler))
 g.upload(mass, pos, vel)
 p = P.to_ffi()
 for _ in range(20): g.step(p)
