@@ -100,7 +100,8 @@ struct sph_ctx {
     DevBuf szc[2];     // ParticleVec::particle_size_class (u8), persistent: IISPH2's omega reads the class of the previous step
     DevBuf omega;      // IISPH2 (simulation.rs:2262-2311)
     bool have_level = false;            // the level-estimation outputs above are those of the last step
-    uint32_t* lvl_changed = nullptr;    // mapped pinned host words written by the propagation sweeps
+    DevBuf lvl_changed_d;               // per-sweep "assigned something" words of a batch (device), published once per batch
+    uint32_t* lvl_changed = nullptr;    // mapped pinned host copy
     uint32_t* lvl_changed_dev = nullptr;
     uint32_t pressure_cur = 0;
     uint32_t last_div_iters = 2, last_dens_iters = 2;

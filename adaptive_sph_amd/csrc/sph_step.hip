@@ -1106,16 +1106,21 @@ static int group_step(Group& G, const sph_params* p, sph_step_stats* outs)
             launch_level_detect(c->stream, &c->prof, m.a, lv);
             // propagate until a sweep assigns nothing (`while changed`, simulation.rs:740-800); sweeps are queued in batches
             // of 8 and the per-sweep flags read once per batch -- a sweep behind the last effective one has no candidates
-            launch_level_propagate(c->stream, &c->prof, m.a, lv, 0u, c->lvl_changed_dev);   // surface particles mark their neighbours
+            HIPCHK(c, c->lvl_changed_d.ensure(64 * sizeof(uint32_t)));
+            uint32_t* chg = c->lvl_changed_d.as<uint32_t>();
+            launch_level_propagate(c->stream, &c->prof, m.a, lv, 0u, chg + 63);   // surface particles mark their neighbours
             const int B = 8;
             uint32_t t = 1;
             for (bool done = false; !done;) {
-                for (int b = 0; b < B; b++) c->lvl_changed[b] = 0u;
+                // the flags live in device memory (a store to mapped host memory from every assigning lane made each sweep
+                // wait for PCIe at its end) and go to the host once per batch
+                (void)hipMemsetAsync(chg, 0, B * sizeof(uint32_t), c->stream);
                 for (int b = 0; b < B; b++, t++) {
-                    launch_level_propagate(c->stream, &c->prof, m.a, lv, t, c->lvl_changed_dev + b);
+                    launch_level_propagate(c->stream, &c->prof, m.a, lv, t, chg + b);
                     if (t == 1u && p->fill_stash_with == SPH_STASH_SURFACE_DISTANCE_MIDDLE)   // num_iter == 1, simulation.rs:769-779
                         launch_fill_stash(c->stream, &c->prof, m.a, lv, c->stash.as<float>());
                 }
+                HIPCHK(c, hipMemcpyAsync(c->lvl_changed, chg, B * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
                 if ((rc = wait_stream(c))) return rc;
                 for (int b = 0; b < B; b++)
                     if (!c->lvl_changed[b]) done = true;

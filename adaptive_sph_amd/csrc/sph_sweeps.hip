@@ -1293,6 +1293,7 @@ struct OpLevelCone {
 struct NBLevel {
     uint32_t w;
     float lv;
+    uint32_t j;
 };
 template <class MathT>
 struct OpLevelPropagate {
@@ -1319,11 +1320,10 @@ struct OpLevelPropagate {
     __device__ float4 loadA(uint32_t j) const { return pm[j]; }
     __device__ NB nb(const Acc&, uint32_t j, float4) const
     {
-        const uint32_t w = when[j];
-        // a candidate of sweep t is assigned in sweep t; its unassigned neighbours are the candidates of sweep t+1.  (In the
-        // candidate-walk fallback this also marks non-neighbours: they look, find nothing, and wait for a real mark.)
-        if (w == LVL_UNASSIGNED) mark[j] = t + 1u;
-        return NB{w, w < t ? level[j] : 0.f};
+        // loads only, and both unconditionally: a store to mark[] between the loads of a trip (the compiler cannot rule out
+        // that it aliases when[] / level[]) or a level load that waits for `when` turns the four neighbours of a trip into
+        // four dependent round trips -- the sweep is nothing but such chains on a few frontier lanes
+        return NB{when[j], level[j], j};
     }
     __device__ void begin(Acc& a, uint32_t, float4) const
     {
@@ -1332,6 +1332,9 @@ struct OpLevelPropagate {
     }
     __device__ void pair(Acc& a, float4, NB Bj, float, float, float r2, float) const
     {
+        // a candidate of sweep t is assigned in sweep t; its unassigned neighbours are the candidates of sweep t+1.  (In the
+        // candidate-walk fallback only accepted pairs arrive here, so only real neighbours are marked.)
+        if (Bj.w == LVL_UNASSIGNED) mark[Bj.j] = t + 1u;
         if (!(Bj.w < t)) return;
         const float est = Bj.lv - sqrtf(r2);
         a.best = a.have ? fmaxf(a.best, est) : est;
