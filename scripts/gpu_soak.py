@@ -1,0 +1,29 @@
+"""Soak: many steps of several workloads; checks finiteness, particle bounds and that nothing errors (development aid)."""
+import sys, time
+from pathlib import Path
+REPO = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(REPO))
+import numpy as np
+from adaptive_sph_amd import ffi, scene as sc
+from adaptive_sph_amd.workloads import WORKLOADS
+lib = ffi.load_product()
+for wl, steps, kw in [("dam_break_1m", 12000, {}), ("dam_break_1m_adaptive", 4000, {}),
+                      ("dam_break_64k", 3000, dict(level_estimation_method="EmptyAngle", maximum_surface_distance=0.2)),
+                      ("dam_break_64k", 3000, dict(support_length_estimation="FromDistributionClamped1", pressure_solver_method="IISPH"))]:
+    scene_f, params_f, _ = WORKLOADS[wl]
+    scn, P = scene_f(), params_f(**kw)
+    pos, mass, vel = sc.init_particles(scn)
+    g = ffi.Context(lib, len(mass), sc.boundary_planes(scn.boundary, P.init_boundary_handler)); g.upload(mass, pos, vel)
+    p = P.to_ffi()
+    t0 = time.perf_counter()
+    try:
+        for s in range(steps):
+            st = g.step(p)
+    except ffi.SphError as e:
+        print(wl, kw, "FAILED at step", s, e); continue
+    dt = time.perf_counter() - t0
+    x, v, r = g.download("position"), g.download("velocity"), g.download("density")
+    inside = (np.abs(x[:, 0]) <= 2.001) & (np.abs(x[:, 1]) <= 1.001)
+    print(f"{wl} {kw}: {steps} steps, sim time {st.time:.3f} s, {dt/steps*1e3:.3f} ms/step, finite {np.isfinite(x).all() and np.isfinite(v).all()}, "
+          f"inside box {inside.mean()*100:.3f} %, |v|max {np.abs(v).max():.2f}, rho [{r.min():.3f}, {r.max():.3f}], mass sum {g.download('mass').sum():.6f} vs {mass.sum():.6f}")
+    g.close()
