@@ -448,7 +448,7 @@ extern "C" void sph_destroy(sph_ctx* c)
     DevBuf* all[] = {&c->pm[0], &c->pm[1], &c->vel[0], &c->vel[1], &c->orig[0], &c->orig[1], &c->lvl[0], &c->lvl[1], &c->lvlold[0],
                      &c->lvlold[1], &c->vel_tmp, &c->key[0], &c->key[1], &c->val[0], &c->val[1], &c->sort_scratch, &c->cxy, &c->cell_start,
                      &c->cs_scratch, &c->hdr_ahead_partials, &c->h2n[0], &c->h2n[1], &c->lam_prev, &c->nl, &c->nlx, &c->tile_raw, &c->tile_h, &c->lvl_changed_d, &c->lvl_tmp, &c->lvl_nrm, &c->lvl_state, &c->lvl_when, &c->lvl_mark, &c->flag_surface,
-                     &c->flag_insufficient, &c->szc[0], &c->szc[1], &c->omega, &c->stash, &c->nl_ext, &c->nlx_ext, &c->nl_ok, &c->mrho, &c->pt0, &c->pt1, &c->rho, &c->lam_sum, &c->lam_grad, &c->constf, &c->aii, &c->src, &c->p0, &c->p1, &c->pacc, &c->dens_err,
+                     &c->flag_insufficient, &c->con_thr, &c->con_consumed, &c->con_h, &c->flag_reduced, &c->szc[0], &c->szc[1], &c->omega, &c->stash, &c->nl_ext, &c->nlx_ext, &c->nl_ok, &c->mrho, &c->pt0, &c->pt1, &c->rho, &c->lam_sum, &c->lam_grad, &c->constf, &c->aii, &c->src, &c->p0, &c->p1, &c->pacc, &c->dens_err,
                      &c->stat, &c->ncount, &c->planes_d, &c->lam_lut, &c->dlam_lut, &c->hdr_partials, &c->hdr_out, &c->ctrl, &c->status,
                      &c->n_tiles, &c->red_partials, &c->scratch};
     for (auto b : all) b->release();
@@ -487,6 +487,7 @@ extern "C" int sph_upload(sph_ctx* c, uint64_t n, const float* mass, const float
     c->dist.n_tot = (uint32_t)n;
     c->grid_valid = false;
     c->have_level = false;
+    c->have_reduced = false;
     c->hdr_ahead = false;
     if (n == 0) return SPH_OK;
     // stage host arrays through scratch buffers: mass -> key[1], pos -> scratch, vel -> vel_tmp
@@ -610,6 +611,19 @@ extern "C" int sph_download(sph_ctx* c, int field, void* dst, uint64_t bytes)
                           : field == SPH_F_FLAG_INSUFFICIENT_NEIGHS ? c->flag_insufficient.p : c->szc[k].p;
         hipLaunchKernelGGL(k_to_host_order, dim3((n + 255) / 256), dim3(256), 0, s, n, field == SPH_F_STASH ? (int)G_F32 : (int)G_U8,
                            c->orig[k].as<uint32_t>(), src, c->scratch.p);
+        HIPCHK(c, hipMemcpyAsync(dst, c->scratch.p, bytes, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+        return SPH_OK;
+    }
+    if (field == SPH_F_FLAG_NEIGHBORHOOD_REDUCED) {   // simulation.rs:2164-2168; false before the first constrained step
+        if (bytes != (uint64_t)n) return c->fail(SPH_ERR_INVALID_ARGUMENT, "field %d: size mismatch", field);
+        if (c->dist.on || !c->have_reduced) {
+            memset(dst, 0, bytes);
+            return SPH_OK;
+        }
+        if (n == 0) return SPH_OK;
+        hipLaunchKernelGGL(k_to_host_order, dim3((n + 255) / 256), dim3(256), 0, s, n, (int)G_U8, c->orig[k].as<uint32_t>(),
+                           (const void*)c->flag_reduced.p, c->scratch.p);
         HIPCHK(c, hipMemcpyAsync(dst, c->scratch.p, bytes, hipMemcpyDeviceToHost, s));
         HIPCHK(c, hipStreamSynchronize(s));
         return SPH_OK;
@@ -779,6 +793,7 @@ extern "C" int sph_apply_edits(sph_ctx* c, const sph_edit_op* ops, uint64_t n_op
     c->dist.n_tot = n_new;
     c->grid_valid = false;   // lists, cell indices and per-step outputs belong to the vector before the edit
     c->have_level = false;
+    c->have_reduced = false;
     c->hdr_ahead = false;
     return SPH_OK;
 }

@@ -97,6 +97,8 @@ struct sph_ctx {
     DevBuf lam_prev;   // lambda_sum of the previous step in this step's order (estimate_h_next_from_distribution)
     // level estimation (simulation.rs:539-927), sorted order
     DevBuf lvl_tmp, lvl_nrm, lvl_state, lvl_when, lvl_mark, flag_surface, flag_insufficient, stash, nl_ext, nlx_ext;
+    DevBuf con_thr, con_consumed, con_h, flag_reduced;   // constrain_neighborhood_count
+    bool have_reduced = false;
     DevBuf szc[2];     // ParticleVec::particle_size_class (u8), persistent: IISPH2's omega reads the class of the previous step
     DevBuf omega;      // IISPH2 (simulation.rs:2262-2311)
     bool have_level = false;            // the level-estimation outputs above are those of the last step

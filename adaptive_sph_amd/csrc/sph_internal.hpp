@@ -156,6 +156,10 @@ size_t sweep_list_bytes(uint32_t n);
 size_t sweep_index_list_bytes(uint32_t n);   // explicit index lists (multi-resolution scenes)
 uint32_t solver_reduce_blocks(uint32_t n);
 void launch_density(hipStream_t s, Profiler* prof, const SweepArgs& a);
+void launch_density_replay(hipStream_t s, Profiler* prof, const SweepArgs& a);
+void launch_constrain_init(hipStream_t s, Profiler* prof, const SweepArgs& a, uint32_t target, float* thr, uint32_t* consumed, float* h_new, uint8_t* flag);
+void launch_constrain_pass(hipStream_t s, Profiler* prof, const SweepArgs& a, uint32_t target, float* thr, uint32_t* consumed, float* h_new, uint32_t* pending);
+void launch_constrain_apply(hipStream_t s, Profiler* prof, const SweepArgs& a, float4* pm, const float* h_new, float* h2_next);
 void launch_aii_const(hipStream_t s, Profiler* prof, const SweepArgs& a);
 void launch_non_pressure(hipStream_t s, Profiler* prof, const SweepArgs& a);                // vel -> vel_tmp
 void launch_source_term(hipStream_t s, Profiler* prof, const SweepArgs& a, int kind, int residual_density);  // kind: 0 div, 1 full, 2 only-density; includes Jacobi iteration 0

@@ -96,6 +96,8 @@ const char* status_message(uint32_t code)
     case SPH_ERR_CHECK_AII: return "a_ii value not equal with a tolerance of 0.01";
     case SPH_ERR_LEVEL_WEIGHT: return "weight is <=0 in smooth_level_estimation_field";
     case SPH_ERR_VOLUME_ESTIMATE: return "assertion failed: volume_estimate >= 0.";
+    case SPH_ERR_CONSTRAIN_NOT_SMALLER: return "assertion failed: *p_h_next < smoothing_length_single(&particles.h2, i, simulation_params)";
+    case SPH_ERR_CONSTRAIN_NEGATIVE: return "assertion failed: *p_h_next >= 0.";
     default: return "device-side guard failed";
     }
 }
@@ -381,6 +383,15 @@ struct LocalComm : Comm {
         int rc = wait_all(G);
         if (rc) return rc;
         const size_t n = G.m.size();
+        // the RCCL transport pairs every ncclSend with an ncclRecv of the same size: hold the loopback to the same rule,
+        // so that the single-GPU verification also proves the pairing
+        for (size_t i = 0; i + 1 < n; i++) {
+            if (x[i].send_bytes[1] != x[i + 1].recv_bytes[0] || x[i + 1].send_bytes[0] != x[i].recv_bytes[1])
+                return G.m[i]->fail(SPH_ERR_DEVICE, "halo exchange sizes of ranks %zu and %zu do not pair up (%zu->%zu, %zu<-%zu)", i, i + 1,
+                                    x[i].send_bytes[1], x[i + 1].recv_bytes[0], x[i].recv_bytes[1], x[i + 1].send_bytes[0]);
+        }
+        if (n && (x[0].send_bytes[0] || x[0].recv_bytes[0] || x[n - 1].send_bytes[1] || x[n - 1].recv_bytes[1]))
+            return G.m[0]->fail(SPH_ERR_DEVICE, "halo exchange across the outer edge of the slab row");
         for (size_t i = 0; i < n; i++) {
             sph_ctx* c = G.m[i];
             HIPCHK(c, hipSetDevice(c->device));
@@ -873,7 +884,8 @@ static int group_step(Group& G, const sph_params* p, sph_step_stats* outs)
     const bool h_from_mass_mode = p->support_length_estimation == SPH_H_FROM_MASS;
     if (!h_from_mass_mode && G.multi())
         return c0->fail(SPH_ERR_UNSUPPORTED, "FromDistribution support lengths on a slab decomposition are not covered yet");
-    if (p->constrain_neighborhood_count) return c0->fail(SPH_ERR_UNSUPPORTED, "constrain_neighborhood_count is not covered yet");
+    if (p->constrain_neighborhood_count && G.multi())
+        return c0->fail(SPH_ERR_UNSUPPORTED, "constrain_neighborhood_count on a slab decomposition is not covered yet");
     if (p->check_aii && G.multi()) return c0->fail(SPH_ERR_UNSUPPORTED, "check_aii on a slab decomposition is not covered yet");
     const bool level_on = p->level_estimation_method != SPH_LEVEL_NONE;
     if (level_on && G.multi()) return c0->fail(SPH_ERR_UNSUPPORTED, "level estimation on a slab decomposition is not covered yet");
@@ -971,7 +983,8 @@ static int group_step(Group& G, const sph_params* p, sph_step_stats* outs)
             return agree(G, c->fail(SPH_ERR_POSITION_NOT_FINITE, "particle positions are not finite"));
         GridP g{};
         const bool coarse_ok = make_grid(h_max_g * 2.f, g);
-        c->uniform_h = (h_min_g == h_max_g);
+        // (constrain_neighborhood_count changes individual smoothing lengths after the lists are built)
+        c->uniform_h = (h_min_g == h_max_g) && !p->constrain_neighborhood_count;
         c->h_uniform = h_max_g;
         GridP fg = g;
         c->tile_ts = 0;
@@ -1138,6 +1151,46 @@ static int group_step(Group& G, const sph_params* p, sph_step_stats* outs)
         if (m.n) launch_density(m.c->stream, &m.c->prof, m.a);
         if (p->check_neighborhood && !G.multi()) launch_check_neighborhood(m.c, m.a);
     }
+    // ---- constrain_neighborhood_count (simulation.rs:2145-2177): h2 of over-populated particles shrinks AFTER the lists are
+    // built; boundary terms (:2179), the CFL step (:2182-2191), the densities (:2204) follow with the new values
+    c0->have_reduced = false;
+    float dt_step = dt;
+    if (p->constrain_neighborhood_count) {
+        Member& m = M[0];
+        sph_ctx* c = m.c;
+        const size_t n = m.n ? m.n : 1;
+        HIPCHK(c, c->con_thr.ensure(n * 4));
+        HIPCHK(c, c->con_consumed.ensure(n * 4));
+        HIPCHK(c, c->con_h.ensure(n * 4));
+        HIPCHK(c, c->flag_reduced.ensure(n));
+        HIPCHK(c, c->lvl_changed_d.ensure(64 * sizeof(uint32_t)));
+        const float onn = (SPH_ETA * 2.f) * (SPH_ETA * 2.f);   // optimal_neighbor_number, simulation.rs:386-388
+        const uint32_t target = (uint32_t)onn + 5u;
+        uint32_t* pend = c->lvl_changed_d.as<uint32_t>();
+        launch_constrain_init(c->stream, &c->prof, m.a, target, c->con_thr.as<float>(), c->con_consumed.as<uint32_t>(), c->con_h.as<float>(),
+                              c->flag_reduced.as<uint8_t>());
+        for (bool done = (m.n == 0); !done;) {
+            const int B = 4;
+            (void)hipMemsetAsync(pend, 0, B * sizeof(uint32_t), c->stream);
+            for (int b = 0; b < B; b++)
+                launch_constrain_pass(c->stream, &c->prof, m.a, target, c->con_thr.as<float>(), c->con_consumed.as<uint32_t>(), c->con_h.as<float>(), pend + b);
+            HIPCHK(c, hipMemcpyAsync(c->lvl_changed, pend, B * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+            if ((rc = sync_ctrl(G))) return rc;   // also surfaces the two assertions of :2163-2165
+            done = !c->lvl_changed[B - 1];
+        }
+        if (m.n) {
+            launch_constrain_apply(c->stream, &c->prof, m.a, c->pm[c->pcur].as<float4>(), c->con_h.as<float>(), m.a.h2_next);
+            launch_header(c, m.n, p->rest_density, 0, c->hdr_host_dev);
+            if ((rc = sync_ctrl(G))) return rc;
+            dt_step = fminf(p->max_dt, p->cfl_factor * sqrtf(c->hdr_host->min_cfl));
+            m.sp.dt = dt_step;
+            m.sp.hyb_vfactor = fminf(dt_step * p->hybrid_dfsph_factor, 1.f);
+            m.a.sp = m.sp;
+            m.st.dt = dt_step;
+            launch_density_replay(c->stream, &c->prof, m.a);
+        }
+        c->have_reduced = true;
+    }
     if ((rc = refresh_ghosts(G, M, sel_rho, 1, "rho"))) return rc;
     if ((rc = refresh_ghosts(G, M, sel_mrho, 1, "mrho"))) return rc;
     // ---- constant_field + a_ii (simulation.rs:2235-2259) ---------------------------------------------------
@@ -1248,11 +1301,12 @@ static int group_step(Group& G, const sph_params* p, sph_step_stats* outs)
         sph_ctx* c = m.c;
         c->pcur ^= 1;  // integrated positions live in the other pm buffer; the old one keeps the pre-step snapshot
         // every solver mode ends in an integrating final sweep, which left the next step's header in hdr_host
-        c->hdr_ahead = !G.multi() && h_from_mass_mode && m.n > 0 && m.a.hdr_partials != nullptr;
+        // (constrain_neighborhood_count left reduced smoothing lengths in the records: the next step's k_header restores them)
+        c->hdr_ahead = !G.multi() && h_from_mass_mode && m.n > 0 && m.a.hdr_partials != nullptr && !p->constrain_neighborhood_count;
         c->hdr_ahead_rest_density = p->rest_density;
         c->last_div_iters = m.st.div_solver.iters;
         c->last_dens_iters = m.st.density_solver.iters;
-        c->time += dt;  // simulation.rs:2724-2725
+        c->time += dt_step;  // simulation.rs:2724-2725
         c->step_number += 1;
         m.st.time = c->time;
         m.st.step_number = c->step_number;

@@ -1599,6 +1599,101 @@ void launch_iisph2_scale(hipStream_t s, Profiler* prof, const SweepArgs& a)
     if (a.n) hipLaunchKernelGGL(k_iisph2_scale, dim3((a.n + 255) / 256), dim3(256), 0, s, a.n, a.ctrl, a.p0, a.p1, a.pt0, a.pt1, a.omega, a.rho);
 }
 
+// ------------------------------------------------------------------------------------------------
+// constrain_neighborhood_count (simulation.rs:2145-2177): a particle with more than `target` neighbours takes the
+// (count - target)-th largest "fringe" value 2 |x_ij| - 2 h_j as its smoothing length.  Selection without a per-lane
+// array: every pass replays the list and finds the largest fringe value below the lane's threshold and how often it occurs;
+// the rank reached so far is carried in `consumed`.  Passes are launched until no lane is pending (1-3 in practice, the
+// wanted rank is count - 19).
+// ------------------------------------------------------------------------------------------------
+#define CON_DONE 0xffffffffu
+__global__ __launch_bounds__(256) void k_constrain_init(uint32_t n, uint32_t target, const float4* __restrict__ pm, const uint32_t* __restrict__ ncount,
+                                                         float* __restrict__ thr, uint32_t* __restrict__ consumed, float* __restrict__ h_new,
+                                                         uint8_t* __restrict__ flag, const uint8_t* __restrict__ owned)
+{
+    uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const bool over = ncount[i] > target && (!owned || owned[i]);
+    thr[i] = INFINITY;
+    consumed[i] = over ? 0u : CON_DONE;
+    h_new[i] = pm[i].w;
+    flag[i] = over ? 1 : 0;
+}
+
+template <class MathT>
+struct OpConstrain {
+    typedef MathT Math;
+    static constexpr bool HAS_EPILOGUE = false, SKIP_SELF = false, EXTENDED = false;
+    __device__ constexpr float krange() const { return 2.f; }
+    typedef NBNone NB;
+    MathT m;
+    const float4* __restrict__ pm;
+    const uint32_t* __restrict__ orig;
+    const uint32_t* __restrict__ ncount;
+    float* __restrict__ thr;
+    uint32_t* __restrict__ consumed;
+    float* __restrict__ h_new;
+    uint32_t* __restrict__ pending;
+    DeviceStatus* status;
+    uint32_t target;
+    struct Acc {
+        float thr, best;
+        uint32_t cnt;
+    };
+    __device__ bool skip() const { return false; }
+    __device__ bool lane_skip(uint32_t i) const { return consumed[i] == CON_DONE; }
+    __device__ void init(Acc&) const {}
+    __device__ void epilogue(Acc&, bool, uint32_t) const {}
+    __device__ float4 loadA(uint32_t j) const { return pm[j]; }
+    __device__ NB nb(const Acc&, uint32_t, float4) const { return NB{}; }
+    __device__ void begin(Acc& a, uint32_t i, float4) const
+    {
+        a.thr = thr[i];
+        a.best = -INFINITY;
+        a.cnt = 0;
+    }
+    __device__ void pair(Acc& a, float4 Aj, NB, float, float, float r2, float) const
+    {
+        const float f = 2.f * sqrtf(r2) - Aj.w * 2.f;   // 2 |x_ij| - support_radius_single(j), simulation.rs:2155-2158
+        if (f < a.thr) {
+            if (f > a.best) {
+                a.best = f;
+                a.cnt = 1;
+            } else if (f == a.best) {
+                a.cnt++;
+            }
+        }
+    }
+    __device__ bool finish(Acc& a, uint32_t i, float4 Ai, bool) const
+    {
+        const uint32_t k = ncount[i] - target;   // index into the descending order (simulation.rs:2161)
+        const uint32_t have = consumed[i];
+        if (a.cnt == 0u || have + a.cnt > k) {
+            const float hn = a.best;
+            h_new[i] = hn;
+            consumed[i] = CON_DONE;
+            if (!(hn < Ai.w)) raise_error(status, SPH_ERR_CONSTRAIN_NOT_SMALLER, orig[i]);
+            else if (!(hn >= 0.f)) raise_error(status, SPH_ERR_CONSTRAIN_NEGATIVE, orig[i]);
+        } else {
+            consumed[i] = have + a.cnt;
+            thr[i] = a.best;
+            *pending = 1u;
+        }
+        return false;
+    }
+};
+
+// h2_next <- h2, h2 <- constrained value: the mem::swap of simulation.rs:2172 on the (x, y, m, h) records
+__global__ __launch_bounds__(256) void k_constrain_apply(uint32_t n, float4* __restrict__ pm, const float* __restrict__ h_new, float* __restrict__ h2_next)
+{
+    uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float4 a = pm[i];
+    h2_next[i] = a.w;
+    a.w = h_new[i];
+    pm[i] = a;
+}
+
 // HybridDFSPH after the divergence solve: v += dt * a^p   (simulation.rs:2547-2560)
 __global__ __launch_bounds__(256) void k_vel_add_pacc(uint32_t n, float dt, float2* __restrict__ vel, const float2* __restrict__ pacc,
                                                        const uint32_t* __restrict__ orig, DeviceStatus* status)
@@ -1697,6 +1792,33 @@ void launch_density(hipStream_t s, Profiler* prof, const SweepArgs& a)
     }
     SPH_DISPATCH(OpDensityMass, true, a.pm, a.orig, a.rho, a.mrho, a.lam_sum, a.lam_grad, a.ncount, a.planes, a.lam_lut, a.dlam_lut, a.status, a.sp,
                  a.h_mode, a.h2_next, a.lam_prev)
+}
+
+// the density sweep again, over the recorded lists (after constrain_neighborhood_count changed the smoothing lengths)
+void launch_density_replay(hipStream_t s, Profiler* prof, const SweepArgs& a)
+{
+    ProfScope ps(prof, "density_replay", s);
+    SPH_DISPATCH(OpDensityMass, false, a.pm, a.orig, a.rho, a.mrho, a.lam_sum, a.lam_grad, a.ncount, a.planes, a.lam_lut, a.dlam_lut, a.status, a.sp,
+                 a.h_mode, a.h2_next, a.lam_prev)
+}
+
+void launch_constrain_init(hipStream_t s, Profiler* prof, const SweepArgs& a, uint32_t target, float* thr, uint32_t* consumed, float* h_new, uint8_t* flag)
+{
+    ProfScope ps(prof, "constrain_init", s);
+    if (a.n) hipLaunchKernelGGL(k_constrain_init, dim3((a.n + 255) / 256), dim3(256), 0, s, a.n, target, a.pm, a.ncount, thr, consumed, h_new, flag, a.owned);
+}
+
+void launch_constrain_pass(hipStream_t s, Profiler* prof, const SweepArgs& a, uint32_t target, float* thr, uint32_t* consumed, float* h_new,
+                           uint32_t* pending)
+{
+    ProfScope ps(prof, "constrain_pass", s);
+    SPH_DISPATCH(OpConstrain, false, a.pm, a.orig, a.ncount, thr, consumed, h_new, pending, a.status, target)
+}
+
+void launch_constrain_apply(hipStream_t s, Profiler* prof, const SweepArgs& a, float4* pm, const float* h_new, float* h2_next)
+{
+    ProfScope ps(prof, "constrain_apply", s);
+    if (a.n) hipLaunchKernelGGL(k_constrain_apply, dim3((a.n + 255) / 256), dim3(256), 0, s, a.n, pm, h_new, h2_next);
 }
 
 void launch_aii_const(hipStream_t s, Profiler* prof, const SweepArgs& a)

@@ -40,7 +40,7 @@ FIELDS = {
     "stash": (15, np.float32, 1), "flag_is_fluid_surface": (16, np.uint8, 1),
     "flag_insufficient_neighs": (17, np.uint8, 1), "particle_size_class": (18, np.uint8, 1),
     "lambda_sum": (19, np.float32, 1), "lambda_grad_sum": (20, np.float32, 2), "cell_index": (21, np.uint32, 1),
-    "particle_id": (22, np.uint32, 1),
+    "particle_id": (22, np.uint32, 1), "flag_neighborhood_reduced": (23, np.uint8, 1),
 }
 
 STATUS_NAMES = {
@@ -49,7 +49,7 @@ STATUS_NAMES = {
     13: "SPH_ERR_AII_NEGATIVE", 14: "SPH_ERR_AP_NOT_FINITE", 15: "SPH_ERR_PRESSURE_NOT_FINITE",
     16: "SPH_ERR_TOO_MANY_NEIGHBORS", 17: "SPH_ERR_VELOCITY_NOT_FINITE", 18: "SPH_ERR_POSITION_NOT_FINITE",
     19: "SPH_ERR_VISCOSITY_NOT_FINITE", 20: "SPH_ERR_XSPH_TODO", 21: "SPH_ERR_CHECK_NEIGHBORHOOD",
-    22: "SPH_ERR_CHECK_AII", 23: "SPH_ERR_LEVEL_WEIGHT", 24: "SPH_ERR_VOLUME_ESTIMATE", 30: "SPH_ERR_UNSUPPORTED",
+    22: "SPH_ERR_CHECK_AII", 23: "SPH_ERR_LEVEL_WEIGHT", 24: "SPH_ERR_VOLUME_ESTIMATE", 25: "SPH_ERR_CONSTRAIN_NOT_SMALLER", 26: "SPH_ERR_CONSTRAIN_NEGATIVE", 30: "SPH_ERR_UNSUPPORTED",
 }
 
 

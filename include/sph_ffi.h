@@ -158,7 +158,8 @@ enum {
     /* slab (multi-GPU) contexts: particles migrate between ranks, so fields come back in device order
      * and this field carries their identity (uploadable right after sph_upload; default 0..n-1) */
     SPH_F_PARTICLE_ID = 22,    /* u32[n]   */
-    SPH_F_COUNT_ = 23
+    SPH_F_FLAG_NEIGHBORHOOD_REDUCED = 23, /* u8[n]: constrain_neighborhood_count, sim.rs:2145-2171 */
+    SPH_F_COUNT_ = 24
 };
 
 /* ---- status codes: one per reference guard ------------------------------------------------- */
@@ -183,6 +184,8 @@ enum {
     SPH_ERR_CHECK_AII = 22,             /* sim.rs:1347-1375 */
     SPH_ERR_LEVEL_WEIGHT = 23,          /* sim.rs:843-845 */
     SPH_ERR_VOLUME_ESTIMATE = 24,       /* sim.rs:1903-1909, 1961  volume_estimate >= 0 */
+    SPH_ERR_CONSTRAIN_NOT_SMALLER = 25, /* sim.rs:2163  *p_h_next < smoothing_length_single(h2, i) */
+    SPH_ERR_CONSTRAIN_NEGATIVE = 26,    /* sim.rs:2165  *p_h_next >= 0 */
     SPH_ERR_UNSUPPORTED = 30            /* a SimulationParams combination this build does not cover */
 };
 

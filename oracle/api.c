@@ -74,7 +74,7 @@ int oracle_create(uint64_t n_capacity, int device_id, const sph_plane* planes, i
     ALLOC(c->pressure_next, n, float); ALLOC(c->aii, n, float); ALLOC(c->density_error, n, float);
     ALLOC(c->h2, n, float); ALLOC(c->h2_next, n, float); ALLOC(c->omega, n, float); ALLOC(c->level, n, float); ALLOC(c->level_tmp, n, float);
     ALLOC(c->level_old, n, float); ALLOC(c->constant_field, n, float); ALLOC(c->stash, n, float);
-    ALLOC(c->flag_surface, n, uint8_t); ALLOC(c->flag_insufficient, n, uint8_t); ALLOC(c->size_class, n, uint8_t);
+    ALLOC(c->flag_surface, n, uint8_t); ALLOC(c->flag_insufficient, n, uint8_t); ALLOC(c->size_class, n, uint8_t); ALLOC(c->flag_reduced, n, uint8_t);
     ALLOC(c->neighbor_count, n, uint32_t); ALLOC(c->lam_n, n, uint8_t);
     ALLOC(c->lam, n * ORC_MAX_PLANES, float); ALLOC(c->lam_gx, n * ORC_MAX_PLANES, float); ALLOC(c->lam_gy, n * ORC_MAX_PLANES, float);
     ALLOC(c->nb_off, n + 1, uint64_t); ALLOC(c->cell_index, n, uint32_t);
@@ -90,7 +90,7 @@ void oracle_destroy(oracle_ctx* c)
     free(c->mass); free(c->pos); free(c->vel); free(c->vel_tmp); free(c->pacc); free(c->density); free(c->source);
     free(c->pressure); free(c->pressure_next); free(c->aii); free(c->density_error); free(c->h2); free(c->h2_next); free(c->omega);
     free(c->level); free(c->level_tmp); free(c->level_old); free(c->constant_field); free(c->stash);
-    free(c->flag_surface); free(c->flag_insufficient); free(c->size_class); free(c->neighbor_count); free(c->lam_n);
+    free(c->flag_surface); free(c->flag_insufficient); free(c->size_class); free(c->flag_reduced); free(c->neighbor_count); free(c->lam_n);
     free(c->lam); free(c->lam_gx); free(c->lam_gy); free(c->nb_off); free(c->nb_idx); free(c->cell_index);
     free(c);
 }
@@ -108,7 +108,7 @@ int oracle_upload(oracle_ctx* c, uint64_t n, const float* mass, const float* pos
     memset(c->vel_tmp, 0, 2 * f); memset(c->pacc, 0, 2 * f); memset(c->density, 0, f); memset(c->source, 0, f);
     memset(c->pressure, 0, f); memset(c->pressure_next, 0, f); memset(c->aii, 0, f); memset(c->density_error, 0, f);
     memset(c->h2, 0, f); memset(c->level_old, 0, f); memset(c->constant_field, 0, f); memset(c->stash, 0, f);
-    memset(c->flag_surface, 0, n); memset(c->flag_insufficient, 0, n); memset(c->lam_n, 0, n);
+    memset(c->flag_surface, 0, n); memset(c->flag_insufficient, 0, n); memset(c->flag_reduced, 0, n); memset(c->lam_n, 0, n);
     memset(c->neighbor_count, 0, n * sizeof(uint32_t)); memset(c->cell_index, 0, n * sizeof(uint32_t));
     memset(c->nb_off, 0, (n + 1) * sizeof(uint64_t));
     for (uint64_t i = 0; i < n; i++) {
@@ -197,6 +197,7 @@ static field_ref field_of(oracle_ctx* c, int field)
     case SPH_F_FLAG_IS_FLUID_SURFACE: r = (field_ref){c->flag_surface, 1, 1}; break;
     case SPH_F_FLAG_INSUFFICIENT_NEIGHS: r = (field_ref){c->flag_insufficient, 1, 1}; break;
     case SPH_F_PARTICLE_SIZE_CLASS: r = (field_ref){c->size_class, 1, 1}; break;
+    case SPH_F_FLAG_NEIGHBORHOOD_REDUCED: r = (field_ref){c->flag_reduced, 1, 1}; break;
     case SPH_F_CELL_INDEX: r = (field_ref){c->cell_index, 4, 1}; break;
     default: break;
     }

@@ -41,7 +41,7 @@ typedef struct oracle_ctx {
     float* omega; /* IISPH2 (simulation.rs:2262-2311) */
     float *level, *level_tmp, *level_old; /* LevelEstimationState: NaN = FluidInterior */
     float *constant_field, *stash;
-    uint8_t *flag_surface, *flag_insufficient, *size_class;
+    uint8_t *flag_surface, *flag_insufficient, *size_class, *flag_reduced;
     uint32_t* neighbor_count;
 
     /* BoundaryWinchenbach2020.lambda: Vec<Vec<(FT, VF<2>)>> (boundary_winchenbach2020.rs:27) */

@@ -899,6 +899,55 @@ static int estimate_h_next_from_distribution(oracle_ctx* c, const sph_params* p)
     return SPH_OK;
 }
 
+/* constrain_neighborhood_count (simulation.rs:2145-2177): a particle with more than optimal_neighbor_number() + 5 neighbours
+ * (simulation.rs:386-388: (ETA * 2)^2 = 14.44 -> 14 as usize, + 5 = 19; the particle itself is on its list) takes the
+ * (count - target)-th largest of the "fringe" values 2 |x_ij| - 2 h_j as its smoothing length; everybody else keeps h2.
+ * The values land in h2_next, then mem::swap(h2, h2_next).  The lists are NOT rebuilt (the TODO at :2174-2175). */
+static int cmp_desc_f32(const void* a, const void* b)
+{
+    float x = *(const float*)a, y = *(const float*)b;
+    return x > y ? -1 : (x < y ? 1 : 0);
+}
+static int constrain_neighborhood_count(oracle_ctx* c, const sph_params* p)
+{
+    const float onn = (ORC_ETA * 2.f) * (ORC_ETA * 2.f);   /* powi(2) */
+    const uint64_t target = (uint64_t)onn + 5u;
+    int bad_small = 0, bad_neg = 0;
+#pragma omp parallel for schedule(dynamic, 256) reduction(| : bad_small, bad_neg)
+    for (int64_t ii = 0; ii < (int64_t)c->n; ii++) {
+        uint64_t i = (uint64_t)ii;
+        const uint64_t cnt = c->nb_off[i + 1] - c->nb_off[i];
+        if (cnt > target) {
+            float* fringe = (float*)malloc(cnt * sizeof(float));
+            uint64_t k = 0;
+            NB_LOOP(c, i, j) {
+                float dx = c->pos[2 * i] - c->pos[2 * j], dy = c->pos[2 * i + 1] - c->pos[2 * j + 1];
+                float x_ij = sqrtf(dx * dx + dy * dy);
+                float srj = c->h2[j] * 2.f;
+                fringe[k++] = 2.f * x_ij - srj;
+            }
+            qsort(fringe, cnt, sizeof(float), cmp_desc_f32);
+            float hn = fringe[cnt - target];
+            free(fringe);
+            c->h2_next[i] = hn;
+            if (!(hn < c->h2[i])) bad_small = 1;
+            c->flag_reduced[i] = 1;
+            if (!(hn >= 0.f)) bad_neg = 1;
+        } else {
+            c->h2_next[i] = c->h2[i];
+            c->flag_reduced[i] = 0;
+        }
+    }
+    /* per particle the `<` assertion comes first; across particles the reference's order is the thread pool's: report the
+     * smaller code when both kinds occurred */
+    if (bad_small) return orc_fail(c, SPH_ERR_CONSTRAIN_NOT_SMALLER, "assertion failed: *p_h_next < smoothing_length_single(&particles.h2, i, simulation_params)");
+    if (bad_neg) return orc_fail(c, SPH_ERR_CONSTRAIN_NEGATIVE, "assertion failed: *p_h_next >= 0.");
+    float* t = c->h2;
+    c->h2 = c->h2_next;
+    c->h2_next = t;
+    return SPH_OK;
+}
+
 int orc_step(oracle_ctx* c, const sph_params* p, sph_step_stats* out)
 {
     double t_step0 = omp_get_wtime();
@@ -909,7 +958,6 @@ int orc_step(oracle_ctx* c, const sph_params* p, sph_step_stats* out)
     st.n_particles = c->n;
 
     if (c->n_planes == 0) return orc_fail(c, SPH_ERR_NO_BOUNDARY, "not implemented: NoBoundaryHandler::iisph_aii");
-    if (p->constrain_neighborhood_count) return orc_fail(c, SPH_ERR_UNSUPPORTED, "constrain_neighborhood_count is not covered yet");
 
     /* simulation.rs:1998-2016, 1865-1871 */
     if (p->support_length_estimation == SPH_H_FROM_MASS) {
@@ -950,6 +998,9 @@ int orc_step(oracle_ctx* c, const sph_params* p, sph_step_stats* out)
 
     /* simulation.rs:2090-2143 */
     if (p->support_length_estimation != SPH_H_FROM_MASS && (rc = estimate_h_next_from_distribution(c, p))) return rc;
+
+    /* simulation.rs:2145-2177 */
+    if (p->constrain_neighborhood_count && (rc = constrain_neighborhood_count(c, p))) return rc;
 
     /* simulation.rs:2179-2180 */
     update_after_advect(c, p);

@@ -150,6 +150,7 @@ pub mod ffi {
     pub const SPH_F_FLAG_IS_FLUID_SURFACE: c_int = 16;
     pub const SPH_F_FLAG_INSUFFICIENT_NEIGHS: c_int = 17;
     pub const SPH_F_PARTICLE_SIZE_CLASS: c_int = 18;
+    pub const SPH_F_FLAG_NEIGHBORHOOD_REDUCED: c_int = 23;
 
     pub const SPH_OK: c_int = 0;
 

@@ -93,3 +93,36 @@ def uniform_params(**kw):
     (media/motivation-video.yaml:42-57)."""
     from adaptive_sph_amd.workloads import dam_break_params
     return dam_break_params(**kw)
+
+
+def ring_scene(n_ring=20, h=0.05, radius_in_h=1.2, centre=(0.0, 0.0), jitter=0.0, seed=0):
+    """A particle in the middle of a ring of `n_ring` others at ~1.2 h: n_ring + 1 entries on its list (> 19) and every fringe
+    value 2 |x_ij| - 2 h_j in [0, h) -- the one geometry in which constrain_neighborhood_count (simulation.rs:2145-2177)
+    passes its own two assertions.  The ring particles see at most ~17 neighbours and keep their h.  `jitter` spreads the
+    ring radii (distinct fringe values)."""
+    rng = np.random.default_rng(seed)
+    ang = np.arange(n_ring, dtype=np.float64) * (2 * np.pi / n_ring)
+    rad = radius_in_h * h * (1.0 + jitter * rng.uniform(-1.0, 1.0, n_ring))
+    pos = np.zeros((n_ring + 1, 2), np.float32)
+    pos[:, 0] = centre[0]
+    pos[:, 1] = centre[1]
+    pos[1:, 0] += (rad * np.cos(ang)).astype(np.float32)
+    pos[1:, 1] += (rad * np.sin(ang)).astype(np.float32)
+    m = np.float32(np.pi * (h / 1.9) ** 2)            # h = 1.9 sqrt(m / pi) at rest_density 1
+    mass = np.full(n_ring + 1, m, np.float32)
+    vel = np.zeros((n_ring + 1, 2), np.float32)
+    return pos, mass, vel
+
+
+def rings_and_block_scene():
+    """Three jittered rings (21, 23, 25 list entries in the middle: ranks 2, 4, 6 of the descending fringe order) beside a
+    rest-lattice block in which nobody exceeds 19 neighbours."""
+    from adaptive_sph_amd import scene as sc
+    parts = [ring_scene(20, 0.05, 1.2, (-1.0, 0.5), 0.08, 1), ring_scene(22, 0.04, 1.2, (0.0, 0.6), 0.08, 2),
+             ring_scene(24, 0.06, 1.2, (1.0, 0.4), 0.08, 3)]
+    scn = sc.dam_break_small(24, 24, 1 / 24)
+    parts.append(sc.init_particles(scn))
+    pos = np.concatenate([p[0] for p in parts]).astype(np.float32)
+    mass = np.concatenate([p[1] for p in parts]).astype(np.float32)
+    vel = np.concatenate([p[2] for p in parts]).astype(np.float32)
+    return scn, pos, mass, vel

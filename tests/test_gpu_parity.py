@@ -15,7 +15,7 @@ import pytest
 
 from adaptive_sph_amd import ffi, scene as sc
 from adaptive_sph_amd.workloads import dam_break_params, default_params
-from tests.oracle_harness import csr_sets
+from tests.oracle_harness import csr_sets, rings_and_block_scene
 
 pytestmark = pytest.mark.gpu
 GOLD = Path(__file__).resolve().parent / "golden"
@@ -303,6 +303,53 @@ def test_host_writes_between_steps_invalidate_the_precomputed_header(product_lib
     assert abs(sg.dt - so.dt) <= 1e-5 * so.dt
     for f in ["position", "velocity", "density"]:
         assert rel_err(g.download(f), o.download(f)) < REL_TOL_FIELDS, f
+
+
+def test_constrain_neighborhood_count(product_lib, oracle_lib):
+    """simulation.rs:2145-2177: over-populated particles (> 19 list entries) take the (count - 19)-th largest fringe value as
+    their smoothing length AFTER the lists are built; boundary terms, CFL step, densities and everything behind use it.
+    Three jittered rings (ranks 2, 4, 6; see oracle_harness.ring_scene for why rings) beside a lattice block.  After the
+    first step the rings have contracted and the reference's own assertion `*p_h_next < h` fires -- same code on both sides."""
+    scn, pos, mass, vel = rings_and_block_scene()
+    planes = sc.boundary_planes(scn.boundary, "AnalyticOverestimate")
+    g, o = ffi.Context(product_lib, len(mass), planes), ffi.Context(oracle_lib, len(mass), planes)
+    g.upload(mass, pos, vel)
+    o.upload(mass, pos, vel)
+    p = forced(max_iters=3, constrain_neighborhood_count=True).to_ffi()
+    sg, so = g.step(p), o.step(p)
+    assert sg.dt == so.dt and sg.time == so.time
+    flag = o.download("flag_neighborhood_reduced")
+    assert flag.sum() == 3 and np.array_equal(g.download("flag_neighborhood_reduced"), flag)
+    for f in ("h2", "h2_next", "neighbor_count", "lambda_sum", "lambda_grad_sum"):
+        assert np.array_equal(g.download(f), o.download(f)), f                       # bit-exact
+    assert (o.download("h2")[flag == 1] < 0.6 * o.download("h2_next")[flag == 1]).all()
+    assert_same_neighbor_sets(g, o)
+    for f in ALL_FIELDS:
+        assert rel_err(g.download(f), o.download(f)) <= TOL.get(f, REL_TOL_FIELDS), f
+    for c in (g, o):
+        with pytest.raises(ffi.SphError) as e:
+            c.step(p)
+        assert e.value.status == 25      # SPH_ERR_CONSTRAIN_NOT_SMALLER
+
+    # nobody above 19 neighbours: the option changes nothing but h2_next := h2 (and the GPU's math policy: per-pair h)
+    g, o = make_pair(product_lib, oracle_lib, sc.dam_break_small(40, 40, 1 / 40))
+    for _ in range(2):
+        sg, so = g.step(p), o.step(p)
+    assert sg.dt == so.dt
+    assert not g.download("flag_neighborhood_reduced").any()
+    assert np.array_equal(g.download("h2_next"), g.download("h2")) and np.array_equal(g.download("h2"), o.download("h2"))
+    for f in ALL_FIELDS:
+        assert rel_err(g.download(f), o.download(f)) <= TOL.get(f, REL_TOL_FIELDS), f
+
+    # a lattice compressed to 1.56 x the rest density: ~21 neighbours everywhere, the `<` assertion fires
+    scn = sc.dam_break_small(24, 24, 1 / 24)
+    pos, mass, vel = sc.init_particles(scn)
+    pos = (pos * np.float32(0.8)).astype(np.float32)
+    g = ffi.Context(product_lib, len(mass), sc.boundary_planes(scn.boundary, "AnalyticOverestimate"))
+    g.upload(mass, pos, vel)
+    with pytest.raises(ffi.SphError) as e:
+        g.step(p)
+    assert e.value.status == 25
 
 
 def test_free_running_iteration_counts(product_lib, oracle_lib):
