@@ -89,7 +89,7 @@ struct sph_ctx {
     bool grid_valid = false;
     GridP fgrid{};          // the grid the particles are sorted by (== grid in uniform scenes)
     int tile_ts = 0, tile_tsx = 0, tile_tsy = 0;
-    DevBuf tile_raw, tile_h, nlx;
+    DevBuf tile_raw, tile_h, tile_h_ext, nlx;
     DevBuf hdr_ahead_partials;   // per sweep block: next step's header terms from the integrating final sweep
     bool hdr_ahead = false;      // hdr_host already holds the header of the state on the device (no k_header needed)
     float hdr_ahead_rest_density = 0.f;

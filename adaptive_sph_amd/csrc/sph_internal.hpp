@@ -96,7 +96,7 @@ void launch_cell_start(hipStream_t s, Profiler* prof, const uint32_t* sorted_key
                        uint32_t* cell_start /* [ncells+1] */, void* scratch /* cell_start_scratch_bytes() */,
                        bool count_zeroed = false /* launch_reorder(.., scratch) already cleared the work-list counter */);
 void launch_tile_hmax(hipStream_t s, Profiler* prof, uint32_t n, const float4* pm, GridP g, int ts, int tsx, int tsy, uint32_t* raw,
-                      uint32_t* out /* dilated */);
+                      uint32_t* out /* dilated by one tile */, uint32_t* out_ext = nullptr /* dilated by d_ext tiles */, int d_ext = 2);
 
 // ---- sph_sweeps.hip ----------------------------------------------------------------------------
 struct SweepArgs {
@@ -137,6 +137,7 @@ struct SweepArgs {
     uint4* nl_ext;      // list words / index lists of the extended-range lists (level estimation)
     uint4* nlx_ext;
     TileP t;            // stencil bound per tile (multi-resolution scenes; ts = 0: uniform)
+    TileP t_ext;        // the same bound over a wider tile neighbourhood, for the extended-range lists
     float* partials;    // per-block solver statistics
     const uint8_t* owned;  // slab decomposition: 1 owned, 0 ghost (nullptr: everything is owned)
     double* solver_tot; // multi-rank: all-reduced solver totals

@@ -346,7 +346,9 @@ void launch_cell_start(hipStream_t s, Profiler* prof, const uint32_t* sorted_key
 }
 
 // per-tile largest smoothing length (TileP, sph_device.h): atomicMax over the particles of the tile, then the
-// maximum over the 3 x 3 tiles around each tile
+// maximum over the (2D+1) x (2D+1) tiles around each tile.  A neighbour within range (h_i + h_j)/2 * k <= h_max * k sits at
+// most ceil(k * h_max / tile side) <= ceil(k / 2) tiles away (tile side >= 2 h_max): D = 1 for the SPH support (k = 2),
+// D = 2 for the extended lists of the level estimation (k = 5.5 / 1.9) -- `out_ext`, nullptr when not wanted
 __global__ __launch_bounds__(256) void k_tile_hmax(uint32_t n, const float4* __restrict__ pm, GridP g, int ts, int tsx, uint32_t* __restrict__ raw)
 {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
@@ -367,25 +369,27 @@ __global__ __launch_bounds__(256) void k_tile_hmax(uint32_t n, const float4* __r
     const uint32_t prev = (uint32_t)__shfl_up((int)tile, 1, 64);
     if (i < n && (lane == 0 || prev != tile)) atomicMax(&raw[tile], hb);
 }
-__global__ __launch_bounds__(256) void k_tile_dilate(int tsx, int tsy, const uint32_t* __restrict__ raw, uint32_t* __restrict__ out)
+__global__ __launch_bounds__(256) void k_tile_dilate(int tsx, int tsy, int D, const uint32_t* __restrict__ raw, uint32_t* __restrict__ out)
 {
     const uint32_t t = blockIdx.x * 256 + threadIdx.x;
     if (t >= (uint32_t)tsx * (uint32_t)tsy) return;
     const int tx = (int)(t % (uint32_t)tsx), ty = (int)(t / (uint32_t)tsx);
     uint32_t m = 0;
-    for (int dy = -1; dy <= 1; dy++)
-        for (int dx = -1; dx <= 1; dx++) {
+    for (int dy = -D; dy <= D; dy++)
+        for (int dx = -D; dx <= D; dx++) {
             const int x = tx + dx, y = ty + dy;
             if (x >= 0 && x < tsx && y >= 0 && y < tsy) m = max(m, raw[(uint32_t)y * (uint32_t)tsx + (uint32_t)x]);
         }
     out[t] = m;
 }
 
-void launch_tile_hmax(hipStream_t s, Profiler* prof, uint32_t n, const float4* pm, GridP g, int ts, int tsx, int tsy, uint32_t* raw, uint32_t* out)
+void launch_tile_hmax(hipStream_t s, Profiler* prof, uint32_t n, const float4* pm, GridP g, int ts, int tsx, int tsy, uint32_t* raw, uint32_t* out,
+                      uint32_t* out_ext, int d_ext)
 {
     ProfScope ps(prof, "tile_hmax", s);
     const uint32_t nt = (uint32_t)tsx * (uint32_t)tsy;
     (void)hipMemsetAsync(raw, 0, (size_t)nt * 4, s);
     if (n) hipLaunchKernelGGL(k_tile_hmax, dim3((n + 255) / 256), dim3(256), 0, s, n, pm, g, ts, tsx, raw);
-    hipLaunchKernelGGL(k_tile_dilate, dim3((nt + 255) / 256), dim3(256), 0, s, tsx, tsy, raw, out);
+    hipLaunchKernelGGL(k_tile_dilate, dim3((nt + 255) / 256), dim3(256), 0, s, tsx, tsy, 1, raw, out);
+    if (out_ext) hipLaunchKernelGGL(k_tile_dilate, dim3((nt + 255) / 256), dim3(256), 0, s, tsx, tsy, d_ext, raw, out_ext);
 }

@@ -63,6 +63,7 @@ SweepArgs make_args(sph_ctx* c, const StepP& sp)
     a.nl_ext = c->nl_ext.as<uint4>();
     a.nlx_ext = c->nlx_ext.as<uint4>();
     a.t = TileP{c->tile_ts, c->tile_tsx, c->tile_tsy, c->tile_h.as<uint32_t>()};
+    a.t_ext = TileP{c->tile_ts, c->tile_tsx, c->tile_tsy, c->tile_h_ext.as<uint32_t>()};
     a.partials = c->red_partials.as<float>();
     a.mrho = c->mrho.as<float>();
     a.pt0 = c->pt0.as<float>();
@@ -1062,8 +1063,13 @@ static int group_step(Group& G, const sph_params* p, sph_step_stats* outs)
             const size_t nt = (size_t)c->tile_tsx * (size_t)c->tile_tsy;
             HIPCHK(c, c->tile_raw.ensure(nt * 4));
             HIPCHK(c, c->tile_h.ensure(nt * 4));
+            // the extended-range lists reach k * h_max with k = level_estimation_range / ETA > 2: a larger particle may sit
+            // ceil(k / 2) tiles away (tile side >= 2 h_max)
+            const bool want_ext = p->level_estimation_method != SPH_LEVEL_NONE;
+            const int d_ext = want_ext ? (int)ceilf(fmaxf(p->level_estimation_range / SPH_ETA, 2.f) * 0.5f) : 1;
+            if (want_ext) HIPCHK(c, c->tile_h_ext.ensure(nt * 4));
             launch_tile_hmax(s, prof, n, c->pm[c->pcur].as<float4>(), g, c->tile_ts, c->tile_tsx, c->tile_tsy, c->tile_raw.as<uint32_t>(),
-                             c->tile_h.as<uint32_t>());
+                             c->tile_h.as<uint32_t>(), want_ext ? c->tile_h_ext.as<uint32_t>() : nullptr, d_ext);
         }
         if (c->exact || !c->uniform_h) HIPCHK(c, c->nlx.ensure(sweep_index_list_bytes(n ? n : 1)));
         if (c->dist.on) {

@@ -1739,7 +1739,7 @@ __global__ __launch_bounds__(256) void k_integrate(uint32_t n, float dt, float v
 // ------------------------------------------------------------------------------------------------
 static SweepCommon common_of(const SweepArgs& a, bool ext)
 {
-    return SweepCommon{a.g, a.t, a.n, (a.n + SWEEP_THREADS - 1) / SWEEP_THREADS, a.cell_start, ext ? a.nl_ext : a.nl, ext ? a.nlx_ext : a.nlx, a.owned};
+    return SweepCommon{a.g, ext ? a.t_ext : a.t, a.n, (a.n + SWEEP_THREADS - 1) / SWEEP_THREADS, a.cell_start, ext ? a.nl_ext : a.nl, ext ? a.nlx_ext : a.nlx, a.owned};
 }
 
 template <class Op, bool BUILD>

@@ -220,6 +220,28 @@ def test_level_estimation_default_config_scene(product_lib, oracle_lib):
         assert rel_err(g.download(f), o.download(f)) < TOL.get(f, REL_TOL_FIELDS), f
 
 
+@pytest.mark.parametrize("dx", [0.104, 0.108])
+def test_extended_lists_see_a_large_particle_two_tiles_away(product_lib, oracle_lib, dx):
+    """Three sizes (1 : 1/2 : 1/3.99).  A mid-size column stands 2.08 h_max from a coarse block: inside the extended range
+    (h_i + h_j)/2 * 5.5/1.9 = 2.17 h_max, but with the tile side at 2.005 h_max the coarse column can lie TWO tiles away from
+    the mid particle's tile -- the per-tile bound on the neighbours' h has to look that far for the extended lists
+    (k_tile_dilate, d_ext), or the coarse neighbour is missed and the column is classified as surface (23 flags differed at
+    these two offsets before the fix; scripts/gpu_three_sizes.py sweeps all offsets)."""
+    S = 0.1
+    B = sc.SceneFluidBlock
+    scn = sc.SceneConfig(sc.SceneBoundary("box", 4.0, 2.0),
+                         [B([0.0 + dx, -0.9], [0.6001, 1.2001], S, 0.93, [0, 0]),
+                          B([-0.815 + dx, -0.9], [0.6501, 1.2001], S / 2, 0.93, [0, 0]),
+                          B([-1.7, -0.9], [0.3001, 0.3001], S / 3.99, 0.93, [0, 0])])      # fixes the grid origin and h_min
+    g, o = make_pair(product_lib, oracle_lib, scn)
+    p = default_params(merging=False, sharing=False, splitting=False).to_ffi()
+    for _ in range(2):
+        sg, so = g.step(p), o.step(p)
+        assert abs(sg.dt - so.dt) <= 1e-5 * so.dt
+        _level_fields_match(g, o)
+    assert_same_neighbor_sets(g, o)
+
+
 @pytest.mark.parametrize("mode", ["FromDistribution", "FromDistributionClamped1", "FromDistributionClamped2", "FromDistribution2"])
 def test_support_length_from_distribution(product_lib, oracle_lib, mode):
     """estimate_h_next_from_distribution / _distribution2 (simulation.rs:1873-1971): h2 <- h2_next at the start of a step,
