@@ -126,3 +126,48 @@ def rings_and_block_scene():
     mass = np.concatenate([p[1] for p in parts]).astype(np.float32)
     vel = np.concatenate([p[2] for p in parts]).astype(np.float32)
     return scn, pos, mass, vel
+
+
+def quadtree_scene(seed):
+    rng = np.random.default_rng(seed)
+    levels = int(rng.integers(1, 6))                 # size ratio up to 32:1
+    s_max = float(rng.choice([0.08, 0.1, 0.16]))
+    kind = int(rng.integers(0, 4))
+    w, hgt = float(rng.uniform(0.8, 2.4)), float(rng.uniform(0.5, 1.4))
+    x0, y0 = -1.95 + float(rng.uniform(0, 0.3)), -0.95 + float(rng.uniform(0, 0.2))
+    cx, cy = x0 + w * rng.uniform(0.2, 0.8), y0 + hgt * rng.uniform(0.2, 0.8)
+    ang = rng.uniform(0, np.pi)
+
+    def size_at(x, y):          # wanted particle spacing
+        if kind == 0:           # fine disc in a coarse bath
+            d = np.hypot(x - cx, y - cy)
+            t = np.clip(d / (0.35 * min(w, hgt)), 0, 1)
+        elif kind == 1:         # sharp slanted interface
+            t = 1.0 if (x - cx) * np.cos(ang) + (y - cy) * np.sin(ang) > 0 else 0.0
+        elif kind == 2:         # smooth gradient
+            t = np.clip((x - x0) / w, 0, 1)
+        else:                   # fine layer at the top ("free surface")
+            t = np.clip((y0 + hgt - y) / (0.5 * hgt), 0, 1)
+        return s_max * 2.0 ** (-levels * (1.0 - t))
+
+    pts, sizes = [], []
+
+    def rec(x, y, s, depth):
+        if depth < levels and size_at(x + s / 2, y + s / 2) < s / 1.41:
+            for dx in (0, 1):
+                for dy in (0, 1):
+                    rec(x + dx * s / 2, y + dy * s / 2, s / 2, depth + 1)
+        else:
+            j = rng.uniform(-0.15, 0.15, 2) * s
+            pts.append((x + s / 2 + j[0], y + s / 2 + j[1]))
+            sizes.append(s)
+
+    nx, ny = max(int(w / s_max), 1), max(int(hgt / s_max), 1)
+    for ix in range(nx):
+        for iy in range(ny):
+            rec(x0 + ix * s_max, y0 + iy * s_max, s_max, 0)
+    pos = np.array(pts, np.float32)
+    sizes = np.array(sizes, np.float32)
+    mass = (np.float32(0.93) * sizes * sizes).astype(np.float32)
+    vel = (rng.normal(0, 0.05, pos.shape)).astype(np.float32)
+    return pos, mass, vel, dict(levels=levels, kind=kind, s_max=s_max)

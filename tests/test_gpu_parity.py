@@ -15,7 +15,7 @@ import pytest
 
 from adaptive_sph_amd import ffi, scene as sc
 from adaptive_sph_amd.workloads import dam_break_params, default_params
-from tests.oracle_harness import csr_sets, rings_and_block_scene
+from tests.oracle_harness import csr_sets, quadtree_scene, rings_and_block_scene
 
 pytestmark = pytest.mark.gpu
 GOLD = Path(__file__).resolve().parent / "golden"
@@ -372,6 +372,40 @@ def test_constrain_neighborhood_count(product_lib, oracle_lib):
     with pytest.raises(ffi.SphError) as e:
         g.step(p)
     assert e.value.status == 25
+
+
+@pytest.mark.parametrize("mode", ["plain", "level", "dist"])
+def test_graded_quadtree_distributions(product_lib, oracle_lib, mode):
+    """Particle distributions like the ones split/merge produces: jittered quadtree leaves, size ratios up to 32:1 with smooth
+    and sharp size fields (oracle_harness.quadtree_scene; scripts/gpu_fuzz.py runs hundreds of seeds).  Neighbour sets, counts,
+    cell indices bit-exact; h and the boundary terms bit-exact on the identical inputs of step 0; fields within tolerance."""
+    planes = sc.boundary_planes(sc.SceneBoundary("box", 4.0, 2.0), "AnalyticOverestimate")
+    for seed in (10, 13, 19, 104, 122, 2):     # incl. sharp interfaces with 100-360 neighbours per coarse particle
+        pos, mass, vel, info = quadtree_scene(seed)
+        kw = dict(hybrid_dfsph_max_avg_density_error=0.0, hybrid_dfsph_max_avg_divergence_error=0.0, max_iters=3, max_dt=0.0005)
+        if mode == "dist":
+            kw["support_length_estimation"] = ["FromDistribution", "FromDistributionClamped2", "FromDistribution2"][seed % 3]
+        P = default_params(merging=False, sharing=False, splitting=False, **kw) if mode == "level" else dam_break_params(**kw)
+        p = P.to_ffi()
+        g, o = ffi.Context(product_lib, len(mass), planes), ffi.Context(oracle_lib, len(mass), planes)
+        g.upload(mass, pos, vel)
+        o.upload(mass, pos, vel)
+        for step in range(2):
+            sg, so = g.step(p), o.step(p)
+            assert abs(sg.dt - so.dt) <= 1e-5 * so.dt, (seed, info)
+            for f in ("h2", "lambda_sum"):
+                if step == 0:
+                    assert np.array_equal(g.download(f), o.download(f)), (seed, f)
+                else:
+                    assert rel_err(g.download(f), o.download(f)) <= REL_TOL_FIELDS, (seed, f)
+            for f in ("neighbor_count", "cell_index"):
+                assert np.array_equal(g.download(f), o.download(f)), (seed, f)
+            assert_same_neighbor_sets(g, o)
+            for f in ("density", "aii", "position"):
+                assert rel_err(g.download(f), o.download(f)) <= REL_TOL_FIELDS, (seed, f)
+            assert rel_err(g.download("velocity"), o.download("velocity")) <= 1e-3, seed
+            if mode == "level":
+                _level_fields_match(g, o)
 
 
 def test_free_running_iteration_counts(product_lib, oracle_lib):
