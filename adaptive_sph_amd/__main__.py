@@ -35,6 +35,9 @@ def build_parser() -> argparse.ArgumentParser:
     run.add_argument("--without-adaptivity", action="store_true",
                      help="step with single_step_without_adaptivity even if the config enables merging/sharing/splitting")
     run.add_argument("--device", type=int, default=0)
+    # the reference's VtkExporter is compiled in but switched off (main_loop.rs:253 `export_vtk_data = false`); same writer here
+    run.add_argument("--vtk", default=None, metavar="FOLDER", help="write FOLDER/my-sph-NNNNN.vtk + my-sph.vtk.series (one snapshot per step)")
+    run.add_argument("--vtk-every", type=int, default=1, help="snapshot every N-th step")
     return ap
 
 
@@ -53,10 +56,20 @@ def run(args, lib: Optional[ffi.SphLibrary] = None, out=sys.stdout) -> int:
     counters = bool(args.statistics_enabled or args.statistics_path)
     sim = init_fluid_sim(params, scene, counters_enabled=counters, lib=lib, device_id=args.device)
     p = params.to_ffi()
+    vtk = None
+    if getattr(args, "vtk", None):
+        from .scene import boundary_planes
+        from .vtk_exporter import VtkExporter
+        vtk = VtkExporter(args.vtk, "my-sph")          # main_loop.rs:256
+        vtk_planes = boundary_planes(scene.boundary, params.init_boundary_handler)
     steps, t0 = 0, time.perf_counter()
     while (args.max_seconds is None or sim.time < args.max_seconds) and (args.max_steps is None or steps < args.max_steps):
         sim.single_step_without_adaptivity(p)
         steps += 1
+        if vtk is not None and steps % max(args.vtk_every, 1) == 0:
+            vtk.add_snapshot(sim.time, sim, vtk_planes)       # main_loop.rs:302-309
+    if vtk is not None:
+        vtk.close()
     wall = time.perf_counter() - t0
     print(f"{steps} steps, simulated time {sim.time:.6f} s, {sim.num_fluid_particles()} particles, "
           f"{sim.num_fluid_particles() * steps / max(wall, 1e-9) / 1e6:.2f} M particle-steps/s", file=out)
