@@ -181,6 +181,7 @@ struct LevelArgs {
     uint8_t* state;
     uint8_t* flag_surface;
     uint8_t* flag_insufficient;
+    float maximum_range;   // is_neighbor_in_level_estimation_range (FromDistribution / FromDistribution2), < 0: rule off
     uint8_t* size_class;
     float* level;                  // the level field (detection output, propagated in place)
     uint32_t* when;                // propagation sweep that assigned the value (sph_sweeps.hip)

@@ -1110,6 +1110,8 @@ static int group_step(Group& G, const sph_params* p, sph_step_stats* outs)
         lv.threshold = cosf(50.f * (SPH_PI_F / 180.f));                // simulation.rs:544
         lv.max_surface_distance = p->maximum_surface_distance;
         lv.boundary_is_fluid_surface = p->boundary_is_fluid_surface;
+        lv.maximum_range = (p->support_length_estimation == SPH_H_FROM_DISTRIBUTION || p->support_length_estimation == SPH_H_FROM_DISTRIBUTION2)
+                               ? p->maximum_range : -1.f;   // simulation.rs:705-721
         lv.nrm = c->lvl_nrm.as<float2>();
         lv.state = c->lvl_state.as<uint8_t>();
         lv.flag_surface = c->flag_surface.as<uint8_t>();

@@ -1153,6 +1153,16 @@ struct OpCheckAii {
 // ================================================================================================
 #define LVL_UNASSIGNED 0xffffffffu   // OpLevelPropagate::when of a particle without a value
 
+// (particle_radius * maximum_range)^2 of is_neighbor_in_level_estimation_range (simulation.rs:698-723), +inf when the rule is off
+// (maximum_range < 0 here); particle_radius = sphere_volume_to_radius(m / rho0) = sqrt((m / rho0) * (1 / pi)) (sph_kernels.rs:203-206)
+__device__ __forceinline__ float level_range_sq(float mass, float maximum_range, float rest_density)
+{
+    if (maximum_range < 0.f) return __uint_as_float(0x7f800000u);
+    const float pr = sqrtf((mass / rest_density) * SPH_FRAC_1_PI_F);
+    const float r = pr * maximum_range;
+    return r * r;
+}
+
 // Op: surface detection, part 1 (surface_detection_by_empty_angle, simulation.rs:539-583): the "normal"
 //   n_i = - sum_j (m_i / rho_0) grad W_ij  and the cheap classifications.  state: 0 interior, 1 surface,
 //   2 decided by the cone test of part 2.
@@ -1238,8 +1248,11 @@ struct OpLevelCone {
     uint8_t* __restrict__ flag_surface;
     float* __restrict__ stash;   // fill_stash_with == SurfaceDistanceFirst (simulation.rs:886-893), else nullptr
     float k, threshold, max_surface_distance;
+    // is_neighbor_in_level_estimation_range (simulation.rs:698-723): FromDistribution / FromDistribution2 only -- neighbours
+    // beyond particle_radius(i) * maximum_range do not count; range_factor2 = maximum_range^2 / rest_density / pi, or < 0: off
+    float range_factor, sp_rest_density;
     struct Acc {
-        float nx, ny;
+        float nx, ny, r2max;
         uint32_t st;
         bool hit;
     };
@@ -1250,11 +1263,12 @@ struct OpLevelCone {
     __device__ void epilogue(Acc&, bool, uint32_t) const {}
     __device__ float4 loadA(uint32_t j) const { return pm[j]; }
     __device__ NB nb(const Acc&, uint32_t, float4) const { return NB{}; }
-    __device__ void begin(Acc& a, uint32_t i, float4) const
+    __device__ void begin(Acc& a, uint32_t i, float4 Ai) const
     {
         a.st = state[i];
         a.hit = false;
         a.nx = a.ny = 0.f;
+        a.r2max = level_range_sq(Ai.z, range_factor, sp_rest_density);
         if (a.st == 2u) {
             const float2 n = nrm[i];
             a.nx = n.x;
@@ -1264,6 +1278,7 @@ struct OpLevelCone {
     __device__ void pair(Acc& a, float4, NB, float dx, float dy, float r2, float) const
     {
         if (a.st != 2u) return;
+        if (r2 > a.r2max) return;
         // x_j - x_i = -(x_i - x_j) exactly; its norm_squared is r2
         const float dn = sqrtf(r2) + 0.000001f;
         const float ux = -dx / dn, uy = -dy / dn;
@@ -1308,8 +1323,9 @@ struct OpLevelPropagate {
     uint32_t* __restrict__ changed;   // one word per sweep of the batch
     float k;
     uint32_t t;
+    float range_factor, sp_rest_density;   // see OpLevelCone
     struct Acc {
-        float best;
+        float best, r2max;
         bool have;
     };
     __device__ float krange() const { return k; }
@@ -1325,10 +1341,11 @@ struct OpLevelPropagate {
         // four dependent round trips -- the sweep is nothing but such chains on a few frontier lanes
         return NB{when[j], level[j], j};
     }
-    __device__ void begin(Acc& a, uint32_t, float4) const
+    __device__ void begin(Acc& a, uint32_t, float4 Ai) const
     {
         a.best = 0.f;
         a.have = false;
+        a.r2max = level_range_sq(Ai.z, range_factor, sp_rest_density);
     }
     __device__ void pair(Acc& a, float4, NB Bj, float, float, float r2, float) const
     {
@@ -1336,6 +1353,7 @@ struct OpLevelPropagate {
         // candidate-walk fallback only accepted pairs arrive here, so only real neighbours are marked.)
         if (Bj.w == LVL_UNASSIGNED) mark[Bj.j] = t + 1u;
         if (!(Bj.w < t)) return;
+        if (r2 > a.r2max) return;
         const float est = Bj.lv - sqrtf(r2);
         a.best = a.have ? fmaxf(a.best, est) : est;
         a.have = true;
@@ -1919,14 +1937,15 @@ void launch_level_detect(hipStream_t s, Profiler* prof, const SweepArgs& a, cons
     }
     {
         ProfScope ps(prof, "level_cone", s);
-        SPH_DISPATCH(OpLevelCone, false, a.pm, l.nrm, l.state, l.level, l.when, l.mark, l.flag_surface, l.stash_first, l.k, l.threshold, l.max_surface_distance)
+        SPH_DISPATCH(OpLevelCone, false, a.pm, l.nrm, l.state, l.level, l.when, l.mark, l.flag_surface, l.stash_first, l.k, l.threshold, l.max_surface_distance,
+                     l.maximum_range, a.sp.rest_density)
     }
 }
 
 void launch_level_propagate(hipStream_t s, Profiler* prof, const SweepArgs& a, const LevelArgs& l, uint32_t t, uint32_t* changed)
 {
     ProfScope ps(prof, "level_propagate", s);
-    SPH_DISPATCH(OpLevelPropagate, false, a.pm, l.level, l.when, l.mark, changed, l.k, t)
+    SPH_DISPATCH(OpLevelPropagate, false, a.pm, l.level, l.when, l.mark, changed, l.k, t, l.maximum_range, a.sp.rest_density)
 }
 
 void launch_fill_stash(hipStream_t s, Profiler* prof, const SweepArgs& a, const LevelArgs& l, float* stash)

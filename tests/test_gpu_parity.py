@@ -374,7 +374,7 @@ def test_constrain_neighborhood_count(product_lib, oracle_lib):
     assert e.value.status == 25
 
 
-@pytest.mark.parametrize("mode", ["plain", "level", "dist"])
+@pytest.mark.parametrize("mode", ["plain", "level", "dist", "level_dist"])
 def test_graded_quadtree_distributions(product_lib, oracle_lib, mode):
     """Particle distributions like the ones split/merge produces: jittered quadtree leaves, size ratios up to 32:1 with smooth
     and sharp size fields (oracle_harness.quadtree_scene; scripts/gpu_fuzz.py runs hundreds of seeds).  Neighbour sets, counts,
@@ -383,9 +383,10 @@ def test_graded_quadtree_distributions(product_lib, oracle_lib, mode):
     for seed in (10, 13, 19, 104, 122, 2):     # incl. sharp interfaces with 100-360 neighbours per coarse particle
         pos, mass, vel, info = quadtree_scene(seed)
         kw = dict(hybrid_dfsph_max_avg_density_error=0.0, hybrid_dfsph_max_avg_divergence_error=0.0, max_iters=3, max_dt=0.0005)
-        if mode == "dist":
+        if mode in ("dist", "level_dist"):
+            # (FromDistribution / FromDistribution2 also switch on is_neighbor_in_level_estimation_range, simulation.rs:698-723)
             kw["support_length_estimation"] = ["FromDistribution", "FromDistributionClamped2", "FromDistribution2"][seed % 3]
-        P = default_params(merging=False, sharing=False, splitting=False, **kw) if mode == "level" else dam_break_params(**kw)
+        P = default_params(merging=False, sharing=False, splitting=False, **kw) if mode.startswith("level") else dam_break_params(**kw)
         p = P.to_ffi()
         g, o = ffi.Context(product_lib, len(mass), planes), ffi.Context(oracle_lib, len(mass), planes)
         g.upload(mass, pos, vel)
@@ -404,7 +405,7 @@ def test_graded_quadtree_distributions(product_lib, oracle_lib, mode):
             for f in ("density", "aii", "position"):
                 assert rel_err(g.download(f), o.download(f)) <= REL_TOL_FIELDS, (seed, f)
             assert rel_err(g.download("velocity"), o.download("velocity")) <= 1e-3, seed
-            if mode == "level":
+            if mode.startswith("level"):
                 _level_fields_match(g, o)
 
 
