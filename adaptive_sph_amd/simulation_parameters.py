@@ -133,6 +133,10 @@ class SimulationParams:
 
     # ---- boundary crossing --------------------------------------------------------------------
     def to_ffi(self) -> ffi.SphParams:
+        if self.neighborhood_search_algorithm == "Grid":
+            # build_neighborhood_list (neighborhood_search.rs:334-342): the grid search exists only in the uniform-particle-sizes
+            # build; the default (adaptive) build the library replaces panics on it
+            raise ValueError("assertion failed: PARTICLE_SIZES == ParticleSizes::Uniform (neighborhood_search_algorithm: Grid)")
         p = ffi.SphParams()
         p.rest_density = self.rest_density
         p.cfl_factor = self.cfl_factor
