@@ -274,11 +274,18 @@ __global__ __launch_bounds__(256) void k_cell_index_host(uint32_t n, GridP g, co
     dst[orig[i]] = (uint32_t)cx + (uint32_t)cy * (uint32_t)g.sx;
 }
 
+// list lengths of the extended lists, host particle order
+__global__ __launch_bounds__(256) void k_ext_counts(uint32_t n, const uint4* __restrict__ nl_ext, const uint32_t* __restrict__ orig, uint32_t* __restrict__ dst)
+{
+    uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[orig[i]] = nl_ext[i].w & 0xffffu;
+}
+
 // CSR export of the neighbour lists (NeighborhoodCache) in host particle order
 __global__ __launch_bounds__(256) void k_fill_neighbors(uint32_t n, GridP g, TileP t, const uint32_t* __restrict__ cell_start,
                                                          const uint32_t* __restrict__ cxy, const uint32_t* __restrict__ orig,
                                                          const float4* __restrict__ pm, const uint32_t* __restrict__ offsets_host,
-                                                         uint32_t* __restrict__ indices)
+                                                         uint32_t* __restrict__ indices, float k)
 {
     uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
@@ -286,7 +293,7 @@ __global__ __launch_bounds__(256) void k_fill_neighbors(uint32_t n, GridP g, Til
     const uint32_t c = cxy[i];
     const int cx = c & 0xffffu, cy = c >> 16;
     uint32_t w = offsets_host[orig[i]];
-    const int R = stencil_radius(g, t, Ai.w, cx, cy, 2.f);
+    const int R = stencil_radius(g, t, Ai.w, cx, cy, k);
     for (int dy = -R; dy <= R; dy++) {
         int yy = cy + dy;
         if (yy < 0 || yy >= g.sy) continue;
@@ -296,7 +303,7 @@ __global__ __launch_bounds__(256) void k_fill_neighbors(uint32_t n, GridP g, Til
             const float4 Aj = pm[j];
             const float dx = Ai.x - Aj.x, dyy = Ai.y - Aj.y;
             const float r2 = dx * dx + dyy * dyy;
-            const float s = ((Ai.w + Aj.w) * 0.5f) * 2.f;
+            const float s = ((Ai.w + Aj.w) * 0.5f) * k;
             if (r2 < s * s) indices[w++] = orig[j];
         }
     }
@@ -488,6 +495,7 @@ extern "C" int sph_upload(sph_ctx* c, uint64_t n, const float* mass, const float
     c->grid_valid = false;
     c->have_level = false;
     c->have_reduced = false;
+    c->lists_after = false;
     c->hdr_ahead = false;
     if (n == 0) return SPH_OK;
     // stage host arrays through scratch buffers: mass -> key[1], pos -> scratch, vel -> vel_tmp
@@ -794,6 +802,7 @@ extern "C" int sph_apply_edits(sph_ctx* c, const sph_edit_op* ops, uint64_t n_op
     c->grid_valid = false;   // lists, cell indices and per-step outputs belong to the vector before the edit
     c->have_level = false;
     c->have_reduced = false;
+    c->lists_after = false;
     c->hdr_ahead = false;
     return SPH_OK;
 }
@@ -948,8 +957,20 @@ extern "C" int sph_download_neighbors(sph_ctx* c, uint32_t* offsets, uint32_t* i
     if (!c->grid_valid) return c->fail(SPH_ERR_INVALID_ARGUMENT, "no neighbour lists yet: run a step first");
     if (c->dist.on) return c->fail(SPH_ERR_UNSUPPORTED, "neighbour-list export of a slab context is not covered yet");
     std::vector<uint32_t> cnt(n), off((size_t)n + 1);
-    int rc = sph_download(c, SPH_F_NEIGHBOR_COUNT, cnt.data(), (uint64_t)n * 4);
-    if (rc) return rc;
+    int rc = SPH_OK;
+    hipStream_t s = c->stream;
+    // level_estimation_after_advection: `self.neighs` was rebuilt at the end of the step (simulation.rs:2678-2689) -- the cache
+    // then holds the EXTENDED lists of the ADVECTED positions, and that is what the host's partner searches iterate
+    const bool ext = c->lists_after;
+    if (!ext) {
+        rc = sph_download(c, SPH_F_NEIGHBOR_COUNT, cnt.data(), (uint64_t)n * 4);
+        if (rc) return rc;
+    } else if (n) {
+        HIPCHK(c, c->scratch.ensure((size_t)n * 4));
+        hipLaunchKernelGGL(k_ext_counts, dim3((n + 255) / 256), dim3(256), 0, s, n, c->nl_ext.as<uint4>(), c->orig[c->cur].as<uint32_t>(), c->scratch.as<uint32_t>());
+        HIPCHK(c, hipMemcpyAsync(cnt.data(), c->scratch.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+    }
     uint64_t tot = 0;
     for (uint32_t i = 0; i < n; i++) {
         off[i] = (uint32_t)tot;
@@ -966,11 +987,16 @@ extern "C" int sph_download_neighbors(sph_ctx* c, uint32_t* offsets, uint32_t* i
     DevBuf d_off, d_idx;
     HIPCHK(c, d_off.ensure(((size_t)n + 1) * 4));
     HIPCHK(c, d_idx.ensure((size_t)tot * 4));
-    hipStream_t s = c->stream;
     HIPCHK(c, hipMemcpyAsync(d_off.p, off.data(), ((size_t)n + 1) * 4, hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(k_fill_neighbors, dim3((n + 255) / 256), dim3(256), 0, s, n, c->fgrid,
-                       TileP{c->tile_ts, c->tile_tsx, c->tile_tsy, c->tile_h.as<uint32_t>()}, c->cell_start.as<uint32_t>(), c->cxy.as<uint32_t>(),
-                       c->orig[c->cur].as<uint32_t>(), c->pm[c->pcur ^ 1].as<float4>(), d_off.as<uint32_t>(), d_idx.as<uint32_t>());
+    if (!ext)
+        hipLaunchKernelGGL(k_fill_neighbors, dim3((n + 255) / 256), dim3(256), 0, s, n, c->fgrid,
+                           TileP{c->tile_ts, c->tile_tsx, c->tile_tsy, c->tile_h.as<uint32_t>(), 0.f}, c->cell_start.as<uint32_t>(), c->cxy.as<uint32_t>(),
+                           c->orig[c->cur].as<uint32_t>(), c->pm[c->pcur ^ 1].as<float4>(), d_off.as<uint32_t>(), d_idx.as<uint32_t>(), 2.f);
+    else   // cells (cxy) of the pre-step positions, geometry of the advected ones (pm[pcur]), ranges widened by the slack
+        hipLaunchKernelGGL(k_fill_neighbors, dim3((n + 255) / 256), dim3(256), 0, s, n, c->fgrid,
+                           TileP{c->tile_ts, c->tile_tsx, c->tile_tsy, c->tile_h_ext.as<uint32_t>(), c->lists_after_slack}, c->cell_start.as<uint32_t>(),
+                           c->cxy.as<uint32_t>(), c->orig[c->cur].as<uint32_t>(), c->pm[c->pcur].as<float4>(), d_off.as<uint32_t>(), d_idx.as<uint32_t>(),
+                           c->lists_after_k);
     HIPCHK(c, hipMemcpyAsync(indices, d_idx.p, (size_t)tot * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
     d_off.release();

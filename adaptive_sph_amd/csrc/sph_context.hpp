@@ -99,6 +99,9 @@ struct sph_ctx {
     DevBuf lvl_tmp, lvl_nrm, lvl_state, lvl_when, lvl_mark, flag_surface, flag_insufficient, stash, nl_ext, nlx_ext;
     DevBuf con_thr, con_consumed, con_h, flag_reduced;   // constrain_neighborhood_count
     bool have_reduced = false;
+    bool lists_after = false;        // the cache holds the extended lists of the advected positions (level_estimation_after_advection)
+    float lists_after_k = 0.f, lists_after_slack = 0.f;
+    float h_max_step = 0.f;   // largest smoothing length of the current step (all ranks)
     DevBuf szc[2];     // ParticleVec::particle_size_class (u8), persistent: IISPH2's omega reads the class of the previous step
     DevBuf omega;      // IISPH2 (simulation.rs:2262-2311)
     bool have_level = false;            // the level-estimation outputs above are those of the last step

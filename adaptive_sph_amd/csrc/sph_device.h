@@ -39,6 +39,8 @@ struct GridP {
 struct TileP {
     int ts, tsx, tsy;
     const uint32_t* __restrict__ hmax;   // float bits (h > 0, so unsigned order == float order)
+    float slack;   // added to every search range: the lists of the ADVECTED positions are gathered from the cells of the
+                   // pre-step positions (level_estimation_after_advection), slack = 2 x the largest displacement; else 0
 };
 
 // per-step scalars the kernels read (subset of sph_params + dt)
@@ -168,7 +170,7 @@ __device__ __forceinline__ int stencil_radius(const GridP& g, const TileP& t, fl
 {
     float hn = h_i;   // uniform scene: every h is h_i
     if (t.ts > 0) hn = __uint_as_float(t.hmax[(uint32_t)(cy / t.ts) * (uint32_t)t.tsx + (uint32_t)(cx / t.ts)]);
-    return (int)floorf(((h_i + hn) * 0.5f * k) / g.cs) + 1;
+    return (int)floorf(((h_i + hn) * 0.5f * k + t.slack) / g.cs) + 1;
 }
 
 // Sdf2D::probe = find_min_dist_object + to_dist_and_dir (sdf/sdf2d.rs:77-160, 196-228), IEEE operations in the

@@ -188,7 +188,10 @@ struct LevelArgs {
     uint32_t* mark;
     float* level_old;
     float* stash_first;            // stash filled right after the detection (SurfaceDistanceFirst) or nullptr
+    const float4* pm_cell;         // level estimation after advection: the pre-step positions (cells); a.pm = advected. Else nullptr
 };
+void launch_max_disp(hipStream_t s, Profiler* prof, uint32_t n, const float4* pm_old, const float4* pm_new, uint32_t* out);
+void launch_tile_redilate(hipStream_t s, Profiler* prof, int tsx, int tsy, int d, const uint32_t* raw, uint32_t* out);
 void launch_level_detect(hipStream_t s, Profiler* prof, const SweepArgs& a, const LevelArgs& l);
 void launch_level_propagate(hipStream_t s, Profiler* prof, const SweepArgs& a, const LevelArgs& l, uint32_t t, uint32_t* changed);
 void launch_fill_stash(hipStream_t s, Profiler* prof, const SweepArgs& a, const LevelArgs& l, float* stash);

@@ -393,3 +393,10 @@ void launch_tile_hmax(hipStream_t s, Profiler* prof, uint32_t n, const float4* p
     hipLaunchKernelGGL(k_tile_dilate, dim3((nt + 255) / 256), dim3(256), 0, s, tsx, tsy, 1, raw, out);
     if (out_ext) hipLaunchKernelGGL(k_tile_dilate, dim3((nt + 255) / 256), dim3(256), 0, s, tsx, tsy, d_ext, raw, out_ext);
 }
+
+void launch_tile_redilate(hipStream_t s, Profiler* prof, int tsx, int tsy, int d, const uint32_t* raw, uint32_t* out)
+{
+    ProfScope ps(prof, "tile_hmax", s);
+    const uint32_t nt = (uint32_t)tsx * (uint32_t)tsy;
+    hipLaunchKernelGGL(k_tile_dilate, dim3((nt + 255) / 256), dim3(256), 0, s, tsx, tsy, d, raw, out);
+}

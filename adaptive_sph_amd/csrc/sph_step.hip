@@ -890,9 +890,12 @@ static int group_step(Group& G, const sph_params* p, sph_step_stats* outs)
     if (p->check_aii && G.multi()) return c0->fail(SPH_ERR_UNSUPPORTED, "check_aii on a slab decomposition is not covered yet");
     const bool level_on = p->level_estimation_method != SPH_LEVEL_NONE;
     if (level_on && G.multi()) return c0->fail(SPH_ERR_UNSUPPORTED, "level estimation on a slab decomposition is not covered yet");
-    if (level_on && p->level_estimation_after_advection)
-        return c0->fail(SPH_ERR_UNSUPPORTED, "level_estimation_after_advection is not covered yet (needs the neighbourhood of the advected positions)");
-    if (level_on && p->level_estimation_method == SPH_LEVEL_CENTER_DIFF)   // simulation.rs:2029-2031
+    const bool level_after = level_on && p->level_estimation_after_advection;
+    if (level_after && !p->use_extended_range_for_level_estimation)
+        return c0->fail(SPH_ERR_UNSUPPORTED, "level_estimation_after_advection without the extended range (the step's lists replayed at the advected positions) is not covered");
+    if (level_after && p->level_estimation_method == SPH_LEVEL_CENTER_DIFF)
+        return c0->fail(SPH_ERR_UNSUPPORTED, "the CenterDiff surface detector is not covered");
+    if (level_on && !level_after && p->level_estimation_method == SPH_LEVEL_CENTER_DIFF)   // simulation.rs:2029-2031
         return c0->fail(SPH_ERR_INVALID_ARGUMENT, "center diff level estimation method needs density values");
     if (!p->level_estimation_after_advection && !p->use_extended_range_for_level_estimation)
         return c0->fail(SPH_ERR_INVALID_ARGUMENT, "assertion failed: simulation_params.use_extended_range_for_level_estimation");
@@ -987,6 +990,7 @@ static int group_step(Group& G, const sph_params* p, sph_step_stats* outs)
         // (constrain_neighborhood_count changes individual smoothing lengths after the lists are built)
         c->uniform_h = (h_min_g == h_max_g) && !p->constrain_neighborhood_count;
         c->h_uniform = h_max_g;
+        c->h_max_step = h_max_g;
         GridP fg = g;
         c->tile_ts = 0;
         // (a narrow h distribution -- FromDistribution* support lengths wander by a few percent -- keeps the one-cell stencil
@@ -1088,9 +1092,13 @@ static int group_step(Group& G, const sph_params* p, sph_step_stats* outs)
     }
     g_trace.mark(2);
 
-    // ---- level estimation on the extended-range lists (simulation.rs:2018-2046, 862-927) ------------------------------
+    // ---- level estimation on the extended-range lists (simulation.rs:2018-2046, 862-927; after advection: 2678-2707) ------
     LevelArgs lv{};
-    if (level_on) {
+    float lv_slack = 0.f;
+    // `pm_old` == nullptr: the positions the particles are sorted by (before advection).  Else: `al.pm` holds the ADVECTED
+    // positions, pm_old the pre-step ones, and the extended lists are gathered from the cells of the pre-step positions with
+    // every search range widened by 2 x the largest displacement (TileP::slack).
+    auto level_estimation = [&](const float4* pm_geo, const float4* pm_old) -> int {
         const auto t_lvl0 = std::chrono::steady_clock::now();
         Member& m = M[0];
         sph_ctx* c = m.c;
@@ -1103,9 +1111,16 @@ static int group_step(Group& G, const sph_params* p, sph_step_stats* outs)
         for (DevBuf* b : {&c->lvl_state, &c->flag_surface, &c->flag_insufficient}) HIPCHK(c, b->ensure(n));
         HIPCHK(c, c->nl_ext.ensure(sweep_list_bytes((uint32_t)n)));
         HIPCHK(c, c->nlx_ext.ensure(sweep_index_list_bytes((uint32_t)n)));
-        m.a = make_args(c, m.sp);
-        m.a.h_mode = p->support_length_estimation;
-        m.a.sp_check_aii = p->check_aii;
+        HIPCHK(c, c->lvl_changed_d.ensure(64 * sizeof(uint32_t)));
+        uint32_t* chg = c->lvl_changed_d.as<uint32_t>();
+        if (!pm_old) {
+            m.a = make_args(c, m.sp);
+            m.a.h_mode = p->support_length_estimation;
+            m.a.sp_check_aii = p->check_aii;
+        }
+        m.a.nl_ext = c->nl_ext.as<uint4>();   // (allocated just above when this is the first level estimation of the context)
+        m.a.nlx_ext = c->nlx_ext.as<uint4>();
+        SweepArgs al = m.a;
         lv.k = p->level_estimation_range / SPH_ETA;                    // simulation.rs:2036
         lv.threshold = cosf(50.f * (SPH_PI_F / 180.f));                // simulation.rs:544
         lv.max_surface_distance = p->maximum_surface_distance;
@@ -1122,14 +1137,31 @@ static int group_step(Group& G, const sph_params* p, sph_step_stats* outs)
         lv.mark = c->lvl_mark.as<uint32_t>();
         lv.level_old = c->lvlold[c->cur].as<float>();
         lv.stash_first = p->fill_stash_with == SPH_STASH_SURFACE_DISTANCE_FIRST ? c->stash.as<float>() : nullptr;
+        lv.pm_cell = pm_old;
+        lv_slack = 0.f;
+        if (pm_old && m.n) {
+            al.pm = pm_geo;
+            launch_max_disp(c->stream, &c->prof, m.n, pm_old, pm_geo, chg + 62);
+            HIPCHK(c, hipMemcpyAsync(c->lvl_changed, chg + 62, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+            if ((rc = wait_stream(c))) return rc;
+            float dmax;
+            memcpy(&dmax, (const void*)c->lvl_changed, 4);
+            if (!std::isfinite(dmax)) return c->fail(SPH_ERR_POSITION_NOT_FINITE, "Assertion 'p_position[d].is_finite()' failed!");
+            lv_slack = 2.f * dmax;
+            al.t_ext.slack = lv_slack;
+            if (c->tile_ts > 0) {
+                // a neighbour may now sit ceil((k h_max + slack) / tile side) tiles away
+                const float tile_side = (float)c->tile_ts * c->fgrid.cs;
+                const int d = (int)ceilf((lv.k * c->h_max_step + lv_slack) / tile_side);
+                launch_tile_redilate(c->stream, &c->prof, c->tile_tsx, c->tile_tsy, d < 1 ? 1 : d, c->tile_raw.as<uint32_t>(), c->tile_h_ext.as<uint32_t>());
+            }
+        }
         if (m.n) {
             if (p->fill_stash_with == SPH_STASH_NONE) (void)hipMemsetAsync(c->stash.p, 0, n * 4, c->stream);
-            launch_level_detect(c->stream, &c->prof, m.a, lv);
+            launch_level_detect(c->stream, &c->prof, al, lv);
             // propagate until a sweep assigns nothing (`while changed`, simulation.rs:740-800); sweeps are queued in batches
             // of 8 and the per-sweep flags read once per batch -- a sweep behind the last effective one has no candidates
-            HIPCHK(c, c->lvl_changed_d.ensure(64 * sizeof(uint32_t)));
-            uint32_t* chg = c->lvl_changed_d.as<uint32_t>();
-            launch_level_propagate(c->stream, &c->prof, m.a, lv, 0u, chg + 63);   // surface particles mark their neighbours
+            launch_level_propagate(c->stream, &c->prof, al, lv, 0u, chg + 63);   // surface particles mark their neighbours
             const int B = 8;
             uint32_t t = 1;
             for (bool done = false; !done;) {
@@ -1137,9 +1169,9 @@ static int group_step(Group& G, const sph_params* p, sph_step_stats* outs)
                 // wait for PCIe at its end) and go to the host once per batch
                 (void)hipMemsetAsync(chg, 0, B * sizeof(uint32_t), c->stream);
                 for (int b = 0; b < B; b++, t++) {
-                    launch_level_propagate(c->stream, &c->prof, m.a, lv, t, chg + b);
+                    launch_level_propagate(c->stream, &c->prof, al, lv, t, chg + b);
                     if (t == 1u && p->fill_stash_with == SPH_STASH_SURFACE_DISTANCE_MIDDLE)   // num_iter == 1, simulation.rs:769-779
-                        launch_fill_stash(c->stream, &c->prof, m.a, lv, c->stash.as<float>());
+                        launch_fill_stash(c->stream, &c->prof, al, lv, c->stash.as<float>());
                 }
                 HIPCHK(c, hipMemcpyAsync(c->lvl_changed, chg, B * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
                 if ((rc = wait_stream(c))) return rc;
@@ -1148,8 +1180,12 @@ static int group_step(Group& G, const sph_params* p, sph_step_stats* outs)
             }
         }
         c->have_level = true;
-        m.st.ms_level_estimation = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_lvl0).count();
-    } else {
+        m.st.ms_level_estimation += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_lvl0).count();
+        return SPH_OK;
+    };
+    if (level_on && !level_after) {
+        if ((rc = level_estimation(nullptr, nullptr))) return rc;
+    } else if (!level_on) {
         for (auto& m : M) m.c->have_level = false;
     }
 
@@ -1291,12 +1327,18 @@ static int group_step(Group& G, const sph_params* p, sph_step_stats* outs)
         return c0->fail(SPH_ERR_XSPH_TODO, "not yet implemented (XSPH velocity smoothing)");
 
     // ---- smooth_level_estimation_field + classify_particles (simulation.rs:2709-2722) --------------------------------------
+    if (level_after) {   // simulation.rs:2678-2707: lists of the advected positions, then detection + propagation there
+        sph_ctx* c = M[0].c;
+        if ((rc = level_estimation(c->pm[c->pcur ^ 1].as<float4>(), c->pm[c->pcur].as<float4>()))) return rc;
+    }
     if (level_on) {
         const auto t_lvl0 = std::chrono::steady_clock::now();
         Member& m = M[0];
         sph_ctx* c = m.c;
         if (m.n) {
-            launch_level_smooth(c->stream, &c->prof, m.a, lv, c->pm[c->pcur ^ 1].as<float4>(), c->lvl[c->cur].as<float>(), c->lvl_tmp.as<float>());
+            SweepArgs as = m.a;
+            as.t_ext.slack = lv_slack;
+            launch_level_smooth(c->stream, &c->prof, as, lv, c->pm[c->pcur ^ 1].as<float4>(), c->lvl[c->cur].as<float>(), c->lvl_tmp.as<float>());
             std::swap(c->lvl[c->cur], c->lvl_tmp);
             launch_classify(c->stream, &c->prof, m.a, lv, c->lvl[c->cur].as<float>(), p);
         }
@@ -1308,6 +1350,9 @@ static int group_step(Group& G, const sph_params* p, sph_step_stats* outs)
         Member& m = M[i];
         sph_ctx* c = m.c;
         c->pcur ^= 1;  // integrated positions live in the other pm buffer; the old one keeps the pre-step snapshot
+        c->lists_after = level_after;
+        c->lists_after_k = lv.k;
+        c->lists_after_slack = lv_slack;
         // every solver mode ends in an integrating final sweep, which left the next step's header in hdr_host
         // (constrain_neighborhood_count left reduced smoothing lengths in the records: the next step's k_header restores them)
         c->hdr_ahead = !G.multi() && h_from_mass_mode && m.n > 0 && m.a.hdr_partials != nullptr && !p->constrain_neighborhood_count;

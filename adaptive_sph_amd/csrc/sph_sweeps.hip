@@ -32,6 +32,7 @@
 //
 // Each Op below cites the reference sweep it implements (src/simulation/simulation.rs and
 // src/simulation/boundary_handler/sdf_boundary_handler/boundary_winchenbach2020.rs).
+#include <type_traits>
 #include "sph_internal.hpp"
 
 #ifndef SWEEP_THREADS
@@ -220,6 +221,17 @@ __device__ __forceinline__ void walk_row(const Op& op, typename Op::Acc& acc, co
 #undef SPH_FETCH
 #undef SPH_PAIR
 
+// optional Op hook `float2 cell_pos(i, Ai)`: the position the particle was SORTED by, when loadA() returns something else
+// (level estimation after advection: geometry from the advected positions, cells and list words from the pre-step ones)
+template <class Op, class = void>
+struct OpCellPos {
+    static __device__ __forceinline__ float2 get(const Op&, uint32_t, const float4& Ai) { return make_float2(Ai.x, Ai.y); }
+};
+template <class Op>
+struct OpCellPos<Op, std::void_t<decltype(&Op::cell_pos)>> {
+    static __device__ __forceinline__ float2 get(const Op& op, uint32_t i, const float4& Ai) { return op.cell_pos(i, Ai); }
+};
+
 template <class Op, bool BUILD>
 __global__ __launch_bounds__(SWEEP_THREADS) void k_sweep(Op op, SweepCommon c)
 {
@@ -248,8 +260,9 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_sweep(Op op, SweepCommon c)
             replay_indices(op, acc, Ai, i, lw.w & 0xffffu, c.nlx, c.n);
         } else {
             // own cell (the same IEEE expression the sort key was computed from)
-            const int cx = (int)floorf(Ai.x / g.cs) - g.minx;
-            const int cy = (int)floorf(Ai.y / g.cs) - g.miny;
+            const float2 cp = OpCellPos<Op>::get(op, i, Ai);
+            const int cx = (int)floorf(cp.x / g.cs) - g.minx;
+            const int cy = (int)floorf(cp.y / g.cs) - g.miny;
             const bool walk = BUILD || !(lw.w & NL_OK);
             const int R = (!IDX || !walk) ? 1 : stencil_radius(g, c.t, Ai.w, cx, cy, op.krange());
             if (R == 1) {
@@ -1173,6 +1186,7 @@ struct OpLevelNormal {
     typedef NBNone NB;
     MathT m;
     const float4* __restrict__ pm;
+    const float4* __restrict__ pm_cell;   // pre-step positions when pm holds the advected ones, else nullptr
     float2* __restrict__ nrm;
     uint8_t* __restrict__ state;
     uint8_t* __restrict__ flag_insufficient;
@@ -1189,6 +1203,12 @@ struct OpLevelNormal {
     __device__ bool lane_skip(uint32_t) const { return false; }
     __device__ void init(Acc&) const {}
     __device__ void epilogue(Acc&, bool, uint32_t) const {}
+    __device__ float2 cell_pos(uint32_t i, const float4& Ai) const
+    {
+        if (!pm_cell) return make_float2(Ai.x, Ai.y);
+        const float4 q = pm_cell[i];
+        return make_float2(q.x, q.y);
+    }
     __device__ float4 loadA(uint32_t j) const { return pm[j]; }
     __device__ NB nb(const Acc&, uint32_t, float4) const { return NB{}; }
     __device__ void begin(Acc& a, uint32_t, float4 Ai) const
@@ -1240,6 +1260,7 @@ struct OpLevelCone {
     typedef NBNone NB;
     MathT m;
     const float4* __restrict__ pm;
+    const float4* __restrict__ pm_cell;   // pre-step positions when pm holds the advected ones, else nullptr
     const float2* __restrict__ nrm;
     const uint8_t* __restrict__ state;
     float* __restrict__ level;
@@ -1261,6 +1282,12 @@ struct OpLevelCone {
     __device__ bool lane_skip(uint32_t) const { return false; }
     __device__ void init(Acc&) const {}
     __device__ void epilogue(Acc&, bool, uint32_t) const {}
+    __device__ float2 cell_pos(uint32_t i, const float4& Ai) const
+    {
+        if (!pm_cell) return make_float2(Ai.x, Ai.y);
+        const float4 q = pm_cell[i];
+        return make_float2(q.x, q.y);
+    }
     __device__ float4 loadA(uint32_t j) const { return pm[j]; }
     __device__ NB nb(const Acc&, uint32_t, float4) const { return NB{}; }
     __device__ void begin(Acc& a, uint32_t i, float4 Ai) const
@@ -1317,6 +1344,7 @@ struct OpLevelPropagate {
     typedef NBLevel NB;
     MathT m;
     const float4* __restrict__ pm;
+    const float4* __restrict__ pm_cell;   // pre-step positions when pm holds the advected ones, else nullptr
     float* __restrict__ level;
     uint32_t* __restrict__ when;
     uint32_t* __restrict__ mark;
@@ -1333,6 +1361,12 @@ struct OpLevelPropagate {
     __device__ bool lane_skip(uint32_t i) const { return t == 0u ? when[i] != 0u : !(when[i] == LVL_UNASSIGNED && mark[i] == t); }
     __device__ void init(Acc&) const {}
     __device__ void epilogue(Acc&, bool, uint32_t) const {}
+    __device__ float2 cell_pos(uint32_t i, const float4& Ai) const
+    {
+        if (!pm_cell) return make_float2(Ai.x, Ai.y);
+        const float4 q = pm_cell[i];
+        return make_float2(q.x, q.y);
+    }
     __device__ float4 loadA(uint32_t j) const { return pm[j]; }
     __device__ NB nb(const Acc&, uint32_t j, float4) const
     {
@@ -1383,13 +1417,17 @@ __global__ __launch_bounds__(256) void k_fill_stash(uint32_t n, const float* __r
 struct NBSmooth {
     float x, y, mr, dist;
 };
-template <class MathT>
-struct OpLevelSmooth {
+// EXT (level_estimation_after_advection with the extended range, simulation.rs:2678-2722): `self.neighs` then holds the
+// extended lists of the ADVECTED positions -- pm = pm_new = advected, pm_cell = pre-step (cells), lists = nl_ext / nlx_ext.
+template <class MathT, bool EXT>
+struct OpLevelSmoothT {
     typedef MathT Math;
-    static constexpr bool HAS_EPILOGUE = false, SKIP_SELF = false, EXTENDED = false;
+    static constexpr bool HAS_EPILOGUE = false, SKIP_SELF = false, EXTENDED = EXT;
     typedef NBSmooth NB;
     MathT m;
-    const float4* __restrict__ pm;       // positions the lists were built from (cell lookup, walk predicate)
+    const float4* __restrict__ pm;       // positions the lists were built from (walk predicate)
+    const float4* __restrict__ pm_cell;  // positions the particles are sorted by when they differ from pm, else nullptr
+    float k_ext;
     const float4* __restrict__ pm_new;   // advected positions
     const uint32_t* __restrict__ orig;
     const float* __restrict__ mrho;
@@ -1401,7 +1439,13 @@ struct OpLevelSmooth {
     struct Acc {
         float x, y, level, weight;
     };
-    __device__ constexpr float krange() const { return 2.f; }
+    __device__ float krange() const { return EXT ? k_ext : 2.f; }
+    __device__ float2 cell_pos(uint32_t i, const float4& Ai) const
+    {
+        if (!pm_cell) return make_float2(Ai.x, Ai.y);
+        const float4 q = pm_cell[i];
+        return make_float2(q.x, q.y);
+    }
     __device__ bool skip() const { return false; }
     __device__ bool lane_skip(uint32_t) const { return false; }
     __device__ void init(Acc&) const {}
@@ -1933,11 +1977,11 @@ void launch_level_detect(hipStream_t s, Profiler* prof, const SweepArgs& a, cons
 {
     {
         ProfScope ps(prof, "level_normal", s);
-        SPH_DISPATCH(OpLevelNormal, true, a.pm, l.nrm, l.state, l.flag_insufficient, a.planes, a.sp, l.k, l.boundary_is_fluid_surface)
+        SPH_DISPATCH(OpLevelNormal, true, a.pm, l.pm_cell, l.nrm, l.state, l.flag_insufficient, a.planes, a.sp, l.k, l.boundary_is_fluid_surface)
     }
     {
         ProfScope ps(prof, "level_cone", s);
-        SPH_DISPATCH(OpLevelCone, false, a.pm, l.nrm, l.state, l.level, l.when, l.mark, l.flag_surface, l.stash_first, l.k, l.threshold, l.max_surface_distance,
+        SPH_DISPATCH(OpLevelCone, false, a.pm, l.pm_cell, l.nrm, l.state, l.level, l.when, l.mark, l.flag_surface, l.stash_first, l.k, l.threshold, l.max_surface_distance,
                      l.maximum_range, a.sp.rest_density)
     }
 }
@@ -1945,7 +1989,7 @@ void launch_level_detect(hipStream_t s, Profiler* prof, const SweepArgs& a, cons
 void launch_level_propagate(hipStream_t s, Profiler* prof, const SweepArgs& a, const LevelArgs& l, uint32_t t, uint32_t* changed)
 {
     ProfScope ps(prof, "level_propagate", s);
-    SPH_DISPATCH(OpLevelPropagate, false, a.pm, l.level, l.when, l.mark, changed, l.k, t, l.maximum_range, a.sp.rest_density)
+    SPH_DISPATCH(OpLevelPropagate, false, a.pm, l.pm_cell, l.level, l.when, l.mark, changed, l.k, t, l.maximum_range, a.sp.rest_density)
 }
 
 void launch_fill_stash(hipStream_t s, Profiler* prof, const SweepArgs& a, const LevelArgs& l, float* stash)
@@ -1954,10 +1998,40 @@ void launch_fill_stash(hipStream_t s, Profiler* prof, const SweepArgs& a, const 
     if (a.n) hipLaunchKernelGGL(k_fill_stash, dim3((a.n + 255) / 256), dim3(256), 0, s, a.n, l.level, stash, l.max_surface_distance);
 }
 
+template <class M>
+using OpLevelSmooth = OpLevelSmoothT<M, false>;
+template <class M>
+using OpLevelSmoothExt = OpLevelSmoothT<M, true>;
+
+// largest displacement |x_new - x_old| (float bits, atomicMax on non-negative floats)
+__global__ __launch_bounds__(256) void k_max_disp(uint32_t n, const float4* __restrict__ a, const float4* __restrict__ b, uint32_t* __restrict__ out)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    float d = 0.f;
+    if (i < n) {
+        const float4 p = a[i], q = b[i];
+        const float dx = p.x - q.x, dy = p.y - q.y;
+        d = sqrtf(dx * dx + dy * dy);
+        if (!(d >= 0.f)) d = __uint_as_float(0x7f800000u);   // NaN -> inf: the caller reports non-finite positions
+    }
+    d = wave_max(d);
+    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(d));
+}
+void launch_max_disp(hipStream_t s, Profiler* prof, uint32_t n, const float4* pm_old, const float4* pm_new, uint32_t* out)
+{
+    ProfScope ps(prof, "level_max_disp", s);
+    (void)hipMemsetAsync(out, 0, 4, s);
+    if (n) hipLaunchKernelGGL(k_max_disp, dim3((n + 255) / 256), dim3(256), 0, s, n, pm_old, pm_new, out);
+}
+
 void launch_level_smooth(hipStream_t s, Profiler* prof, const SweepArgs& a, const LevelArgs& l, const float4* pm_new, const float* in, float* out)
 {
     ProfScope ps(prof, "level_smooth", s);
-    SPH_DISPATCH(OpLevelSmooth, false, a.pm, pm_new, a.orig, a.mrho, in, out, l.level_old, a.status, l.max_surface_distance)
+    if (l.pm_cell) {   // after advection, extended lists of the advected positions
+        SPH_DISPATCH(OpLevelSmoothExt, false, pm_new, l.pm_cell, l.k, pm_new, a.orig, a.mrho, in, out, l.level_old, a.status, l.max_surface_distance)
+        return;
+    }
+    SPH_DISPATCH(OpLevelSmooth, false, a.pm, nullptr, 2.f, pm_new, a.orig, a.mrho, in, out, l.level_old, a.status, l.max_surface_distance)
 }
 
 void launch_classify(hipStream_t s, Profiler* prof, const SweepArgs& a, const LevelArgs& l, const float* level, const sph_params* p)

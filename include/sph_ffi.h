@@ -256,7 +256,9 @@ int  sph_download(sph_ctx* ctx, int field, void* dst, uint64_t dst_bytes);
  * host particle order: offsets[n+1], indices[offsets[n]].  Call with indices == NULL to get the
  * total in *n_indices first.  Set: { j : |x_ij|^2 < ((h_i+h_j)/2 * 2)^2 }, self included
  * (neighborhood_search.rs:143-146, 187-238).  Order within a list is unspecified (the reference's
- * is R*-tree traversal order). */
+ * is R*-tree traversal order).  After a step with level_estimation_after_advection the cache holds what
+ * the reference rebuilt at the end of the step (simulation.rs:2678-2689): the lists of the ADVECTED positions
+ * with range (h_i+h_j)/2 * level_estimation_range / 1.9. */
 int  sph_download_neighbors(sph_ctx* ctx, uint32_t* offsets, uint32_t* indices, uint64_t indices_capacity,
                             uint64_t* n_indices);
 

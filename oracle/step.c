@@ -1094,8 +1094,15 @@ int orc_step(oracle_ctx* c, const sph_params* p, sph_step_stats* out)
 
     /* simulation.rs:2678-2707 */
     if (p->level_estimation_after_advection) {
-        if (p->use_extended_range_for_level_estimation)
-            if ((rc = orc_build_neighbors(c, p->level_estimation_range / ORC_ETA))) return rc;
+        if (p->use_extended_range_for_level_estimation) {
+            /* orc_build_neighbors counts into c->neighbor_count; the FIELD keeps the counts of simulation.rs:2072-2074 */
+            uint32_t* keep = (uint32_t*)malloc((c->n ? c->n : 1) * sizeof(uint32_t));
+            memcpy(keep, c->neighbor_count, c->n * sizeof(uint32_t));
+            rc = orc_build_neighbors(c, p->level_estimation_range / ORC_ETA);
+            memcpy(c->neighbor_count, keep, c->n * sizeof(uint32_t));
+            free(keep);
+            if (rc) return rc;
+        }
         t0 = omp_get_wtime();
         perform_level_estimation(c, p);
         ms_level += (omp_get_wtime() - t0) * 1e3;

@@ -10,6 +10,7 @@ from adaptive_sph_amd.workloads import dam_break_params, default_params
 from tests.oracle_harness import load_oracle, csr_sets, quadtree_scene
 
 level = "--level" in sys.argv
+after = "--after" in sys.argv
 sys.argv = [a for a in sys.argv if not a.startswith("--")]
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 6
@@ -22,7 +23,7 @@ for seed in range(first, first + count):
     if len(mass) > 30000:
         continue
     vel = (vel * 20).astype(np.float32)        # violent: ~1 m/s random velocities on top of gravity
-    p = (default_params(merging=False, sharing=False, splitting=False, max_dt=0.002, max_iters=30) if level else dam_break_params(max_dt=0.002, max_iters=30)).to_ffi()
+    p = (default_params(merging=False, sharing=False, splitting=False, max_dt=0.002, max_iters=30, level_estimation_after_advection=after) if level else dam_break_params(max_dt=0.002, max_iters=30)).to_ffi()
     g, o = ffi.Context(glib, len(mass), planes), ffi.Context(olib, len(mass), planes)
     o.upload(mass, pos, vel)
     msgs = []

@@ -3,7 +3,7 @@ produces (sizes 1 .. 2^L, smooth or sharp size fields, jittered), stepped by the
 Compared per scene: neighbour sets (bit-exact), counts, h, lambda terms (bit-exact), fields (1e-4), level-estimation
 outputs.  A scene on which the oracle returns a reference guard must give the same code on the device.
 
-usage: gpu_fuzz.py [first_seed] [n_seeds] [--level] [--dist] [--params]"""
+usage: gpu_fuzz.py [first_seed] [n_seeds] [--level] [--dist] [--params] [--after]"""
 import sys
 import numpy as np
 sys.path.insert(0, ".")
@@ -26,6 +26,7 @@ def main():
     level = "--level" in sys.argv
     dist = "--dist" in sys.argv
     combos = "--params" in sys.argv
+    after = "--after" in sys.argv
     olib, glib = load_oracle(), ffi.load_product()
     bad = 0
     for seed in range(first, first + count):
@@ -50,6 +51,8 @@ def main():
         planes = sc.boundary_planes(sc.SceneBoundary("box", 4.0, 2.0), handler)
         if dist:
             kw["support_length_estimation"] = ["FromDistribution", "FromDistributionClamped2", "FromDistribution2"][seed % 3]
+        if after:
+            kw["level_estimation_after_advection"] = True
         if level:
             P = default_params(merging=False, sharing=False, splitting=False, **kw)
         else:
@@ -90,11 +93,17 @@ def main():
                 elif step > 0 and rel(a, b) > 1e-4:
                     msgs.append(f"step {step}: {f} rel err {rel(a, b):.2e}")
             for f in ("neighbor_count", "cell_index"):
-                if not np.array_equal(g.download(f), o.download(f)):
-                    msgs.append(f"step {step}: {f} differs in {(g.download(f) != o.download(f)).sum()} places")
+                nd = int((g.download(f) != o.download(f)).sum())
+                if nd > (0 if step == 0 else 4):
+                    msgs.append(f"step {step}: {f} differs in {nd} places")
             go, gi = g.download_neighbors(); oo, oi = o.download_neighbors()
-            if not np.array_equal(go, oo) or any(not np.array_equal(a, b) for a, b in zip(csr_sets(go, gi), csr_sets(oo, oi))):
-                msgs.append(f"step {step}: neighbour sets differ")
+            flips = sum(len(np.setxor1d(a, b)) for a, b in zip(csr_sets(go, gi), csr_sets(oo, oi)))
+            # after the first step the inputs differ in the last bits: a pair ON the range may flip (gpu_fuzz_uniform.py checks
+            # that flipped pairs do sit there); identical inputs must give identical sets
+            if flips > (0 if step == 0 else max(4, int(2e-5 * len(oi)))):
+                msgs.append(f"step {step}: neighbour sets differ in {flips} entries")
+            elif flips:
+                notes.append(f"step {step}: {flips} list entries flipped")
             for f in ("density", "aii", "velocity", "position"):
                 r = rel(g.download(f), o.download(f))
                 if not r <= (1e-3 if f == "velocity" else 1e-4):

@@ -220,6 +220,45 @@ def test_level_estimation_default_config_scene(product_lib, oracle_lib):
         assert rel_err(g.download(f), o.download(f)) < TOL.get(f, REL_TOL_FIELDS), f
 
 
+@pytest.mark.parametrize("scene", ["uniform", "two_sizes", "graded"])
+def test_level_estimation_after_advection(product_lib, oracle_lib, scene):
+    """level_estimation_after_advection (simulation.rs:2018-2070 skipped, 2678-2722): the extended lists are those of the
+    ADVECTED positions, detection / propagation / smoothing run on them at the end of the step.  The device gathers them from
+    the cells of the pre-step positions with the search range widened by twice the largest displacement."""
+    kw = dict(merging=False, sharing=False, splitting=False, level_estimation_after_advection=True)
+    if scene == "uniform":
+        g, o = make_pair(product_lib, oracle_lib, sc.dam_break_small(48, 40, 1 / 48))
+        P = dam_break_params(level_estimation_method="EmptyAngle", maximum_surface_distance=0.2, particle_radius_fine=0.004,
+                             particle_radius_base=0.02, level_estimation_after_advection=True)
+    elif scene == "two_sizes":
+        scn = sc.SceneConfig.from_yaml(str(Path(__file__).resolve().parent / "golden" / "default-scene.yaml"))
+        g, o = make_pair(product_lib, oracle_lib, scn)
+        P = default_params(**kw)
+    else:
+        pos, mass, vel, _ = quadtree_scene(3)
+        vel = (vel * 20).astype(np.float32)          # ~1 m/s: displacements of a good fraction of the small supports
+        planes = sc.boundary_planes(sc.SceneBoundary("box", 4.0, 2.0), "AnalyticOverestimate")
+        g, o = ffi.Context(product_lib, len(mass), planes), ffi.Context(oracle_lib, len(mass), planes)
+        g.upload(mass, pos, vel)
+        o.upload(mass, pos, vel)
+        P = default_params(max_dt=0.002, **kw)
+    p = P.to_ffi()
+    for s in range(4):
+        sg, so = g.step(p), o.step(p)
+        assert abs(sg.dt - so.dt) <= 1e-5 * so.dt
+        _level_fields_match(g, o)
+        if s == 0:
+            # the field keeps the k = 2 counts of simulation.rs:2072-2074 ...
+            assert np.array_equal(g.download("neighbor_count"), o.download("neighbor_count"))
+            # ... while the cache (what the host's partner searches iterate) now holds the EXTENDED lists of the advected
+            # positions (simulation.rs:2680-2688); identical inputs on the first step -> identical sets
+            go, gi = g.download_neighbors()
+            assert (np.diff(go) > g.download("neighbor_count")).mean() > 0.5
+            assert_same_neighbor_sets(g, o)
+    for f in ALL_FIELDS:
+        assert rel_err(g.download(f), o.download(f)) < TOL.get(f, REL_TOL_FIELDS), f
+
+
 @pytest.mark.parametrize("dx", [0.104, 0.108])
 def test_extended_lists_see_a_large_particle_two_tiles_away(product_lib, oracle_lib, dx):
     """Three sizes (1 : 1/2 : 1/3.99).  A mid-size column stands 2.08 h_max from a coarse block: inside the extended range
