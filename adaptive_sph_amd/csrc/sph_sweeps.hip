@@ -1352,6 +1352,11 @@ struct OpLevelPropagate {
     float k;
     uint32_t t;
     float range_factor, sp_rest_density;   // see OpLevelCone
+    // Values at or below -maximum_surface_distance never leave the step: the smoothing clamps them (and the unassigned) to that
+    // bound before anything reads the field (simulation.rs:826-832).  A sweep whose assignments all lie there ends the loop: a
+    // particle still unassigned has no neighbour from an earlier sweep (it would have been assigned then), so everything
+    // later derives from this sweep's values and lies deeper still.  `changed` therefore means "assigned something above the bound".
+    float useful_above;
     struct Acc {
         float best, r2max;
         bool have;
@@ -1397,7 +1402,7 @@ struct OpLevelPropagate {
         if (t > 0u && a.have) {
             level[i] = a.best;
             when[i] = t;
-            *changed = 1u;   // same value from every lane
+            if (a.best > useful_above) *changed = 1u;   // same value from every lane
         }
         return false;
     }
@@ -1989,7 +1994,8 @@ void launch_level_detect(hipStream_t s, Profiler* prof, const SweepArgs& a, cons
 void launch_level_propagate(hipStream_t s, Profiler* prof, const SweepArgs& a, const LevelArgs& l, uint32_t t, uint32_t* changed)
 {
     ProfScope ps(prof, "level_propagate", s);
-    SPH_DISPATCH(OpLevelPropagate, false, a.pm, l.pm_cell, l.level, l.when, l.mark, changed, l.k, t, l.maximum_range, a.sp.rest_density)
+    SPH_DISPATCH(OpLevelPropagate, false, a.pm, l.pm_cell, l.level, l.when, l.mark, changed, l.k, t, l.maximum_range, a.sp.rest_density,
+                 -l.max_surface_distance)
 }
 
 void launch_fill_stash(hipStream_t s, Profiler* prof, const SweepArgs& a, const LevelArgs& l, float* stash)
