@@ -893,8 +893,6 @@ static int group_step(Group& G, const sph_params* p, sph_step_stats* outs)
     const bool level_after = level_on && p->level_estimation_after_advection;
     if (level_after && !p->use_extended_range_for_level_estimation)
         return c0->fail(SPH_ERR_UNSUPPORTED, "level_estimation_after_advection without the extended range (the step's lists replayed at the advected positions) is not covered");
-    if (level_after && p->level_estimation_method == SPH_LEVEL_CENTER_DIFF)
-        return c0->fail(SPH_ERR_UNSUPPORTED, "the CenterDiff surface detector is not covered");
     if (level_on && !level_after && p->level_estimation_method == SPH_LEVEL_CENTER_DIFF)   // simulation.rs:2029-2031
         return c0->fail(SPH_ERR_INVALID_ARGUMENT, "center diff level estimation method needs density values");
     if (!p->level_estimation_after_advection && !p->use_extended_range_for_level_estimation)
@@ -1138,6 +1136,7 @@ static int group_step(Group& G, const sph_params* p, sph_step_stats* outs)
         lv.level_old = c->lvlold[c->cur].as<float>();
         lv.stash_first = p->fill_stash_with == SPH_STASH_SURFACE_DISTANCE_FIRST ? c->stash.as<float>() : nullptr;
         lv.pm_cell = pm_old;
+        lv.center_diff = p->level_estimation_method == SPH_LEVEL_CENTER_DIFF;
         lv_slack = 0.f;
         if (pm_old && m.n) {
             al.pm = pm_geo;
@@ -1158,6 +1157,8 @@ static int group_step(Group& G, const sph_params* p, sph_step_stats* outs)
         }
         if (m.n) {
             if (p->fill_stash_with == SPH_STASH_NONE) (void)hipMemsetAsync(c->stash.p, 0, n * 4, c->stream);
+            // (the CenterDiff detector leaves flag_insufficient_neighs alone: its default, false)
+            if (lv.center_diff) (void)hipMemsetAsync(c->flag_insufficient.p, 0, n, c->stream);
             launch_level_detect(c->stream, &c->prof, al, lv);
             // propagate until a sweep assigns nothing (`while changed`, simulation.rs:740-800); sweeps are queued in batches
             // of 8 and the per-sweep flags read once per batch -- a sweep behind the last effective one has no candidates

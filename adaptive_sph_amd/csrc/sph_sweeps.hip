@@ -1324,6 +1324,78 @@ struct OpLevelCone {
     }
 };
 
+// Op: surface_detection_by_center_diff (simulation.rs:631-695, "Mass preserving multi-scale SPH"): phi = |x_i - weighted mean of
+// the neighbours' positions| - weighted mean radius; surface if phi >= -0.85 mean radius.  Only reachable after advection (the
+// reference refuses it before, simulation.rs:2029-2031).  BUILD sweep of the extended lists, like OpLevelNormal.
+template <class MathT>
+struct OpLevelCenterDiff {
+    typedef MathT Math;
+    static constexpr bool HAS_EPILOGUE = false, SKIP_SELF = false, EXTENDED = true;
+    typedef NBNone NB;
+    MathT m;
+    const float4* __restrict__ pm;
+    const float4* __restrict__ pm_cell;   // pre-step positions when pm holds the advected ones, else nullptr
+    float* __restrict__ level;
+    uint32_t* __restrict__ when;
+    uint32_t* __restrict__ mark;
+    uint8_t* __restrict__ flag_surface;
+    float* __restrict__ stash;   // fill_stash_with == SurfaceDistanceFirst, else nullptr
+    float k, max_surface_distance, rest_density;
+    struct Acc {
+        float cx, cy, rad, wsum;
+        uint32_t num;
+    };
+    __device__ float krange() const { return k; }
+    __device__ bool skip() const { return false; }
+    __device__ bool lane_skip(uint32_t) const { return false; }
+    __device__ void init(Acc&) const {}
+    __device__ void epilogue(Acc&, bool, uint32_t) const {}
+    __device__ float2 cell_pos(uint32_t i, const float4& Ai) const
+    {
+        if (!pm_cell) return make_float2(Ai.x, Ai.y);
+        const float4 q = pm_cell[i];
+        return make_float2(q.x, q.y);
+    }
+    __device__ float4 loadA(uint32_t j) const { return pm[j]; }
+    __device__ NB nb(const Acc&, uint32_t, float4) const { return NB{}; }
+    __device__ void begin(Acc& a, uint32_t, float4) const
+    {
+        a.cx = a.cy = a.rad = a.wsum = 0.f;
+        a.num = 0;
+    }
+    __device__ void pair(Acc& a, float4 Aj, NB, float, float, float r2, float hij) const
+    {
+        const float vol = Aj.z / rest_density;
+        const float r = sqrtf(vol * SPH_FRAC_1_PI_F);
+        const float w = m.w(r2, hij) * vol;
+        a.cx += Aj.x * w;
+        a.cy += Aj.y * w;
+        a.rad += r * w;
+        a.wsum += w;
+        a.num++;
+    }
+    __device__ bool finish(Acc& a, uint32_t i, float4 Ai, bool) const
+    {
+        const float rad = a.rad / a.wsum;
+        const float surface_level = -0.85f * rad;
+        float phi;
+        if (a.num < 5u) {
+            phi = surface_level;
+        } else {
+            const float dx = Ai.x - a.cx / a.wsum, dy = Ai.y - a.cy / a.wsum;
+            phi = sqrtf(dx * dx + dy * dy) - rad;
+        }
+        const bool surface = phi >= surface_level;
+        const float v = surface ? phi : __uint_as_float(0x7fc00000u);
+        level[i] = v;
+        when[i] = surface ? 0u : LVL_UNASSIGNED;
+        mark[i] = 0u;
+        flag_surface[i] = surface ? 1 : 0;
+        if (stash) stash[i] = surface ? v : -max_surface_distance;
+        return false;
+    }
+};
+
 // Op: one propagation sweep (propagate_level_set_from_surface_detection, simulation.rs:729-801): a particle without a
 // value takes max_j (level_j - |x_ij|) over the neighbours that had one when the sweep started; valued particles keep
 // theirs.  The reference re-evaluates every particle in every sweep (K ~ depth / range sweeps over N particles).  Here a
@@ -1980,6 +2052,12 @@ void launch_integrate(hipStream_t s, Profiler* prof, const SweepArgs& a, float4*
 // ---- level estimation (simulation.rs:862-927, 803-857; adaptivity/mod.rs:32-59) ---------------------------------
 void launch_level_detect(hipStream_t s, Profiler* prof, const SweepArgs& a, const LevelArgs& l)
 {
+    if (l.center_diff) {
+        ProfScope ps(prof, "level_center_diff", s);
+        SPH_DISPATCH(OpLevelCenterDiff, true, a.pm, l.pm_cell, l.level, l.when, l.mark, l.flag_surface, l.stash_first, l.k, l.max_surface_distance,
+                     a.sp.rest_density)
+        return;
+    }
     {
         ProfScope ps(prof, "level_normal", s);
         SPH_DISPATCH(OpLevelNormal, true, a.pm, l.pm_cell, l.nrm, l.state, l.flag_insufficient, a.planes, a.sp, l.k, l.boundary_is_fluid_surface)

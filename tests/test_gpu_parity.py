@@ -259,6 +259,29 @@ def test_level_estimation_after_advection(product_lib, oracle_lib, scene):
         assert rel_err(g.download(f), o.download(f)) < TOL.get(f, REL_TOL_FIELDS), f
 
 
+def test_center_diff_detector_after_advection(product_lib, oracle_lib):
+    """media/surface-detection.yaml's first recipe: CenterDiff on the 2:1 scene with boundary_is_fluid_surface.  The reference
+    only accepts the detector when the level estimation runs after advection (simulation.rs:2029-2031), which is how it is run
+    here; before advection both sides refuse it."""
+    scn = sc.SceneConfig.from_yaml(str(Path(__file__).resolve().parent / "golden" / "default-scene.yaml"))
+    g, o = make_pair(product_lib, oracle_lib, scn, "AnalyticUnderestimate")
+    kw = dict(merging=False, sharing=False, splitting=False, support_length_estimation="FromMass", level_estimation_method="CenterDiff",
+              boundary_is_fluid_surface=True)
+    p = default_params(level_estimation_after_advection=True, **kw).to_ffi()
+    for s in range(4):
+        sg, so = g.step(p), o.step(p)
+        assert abs(sg.dt - so.dt) <= 1e-5 * so.dt
+        fg, fo = g.download("flag_is_fluid_surface"), o.download("flag_is_fluid_surface")
+        assert 0 < fo.sum() < len(fo) and (fg != fo).sum() <= 2          # phi >= -0.85 r sits on a float comparison
+        if np.array_equal(fg, fo):
+            _level_fields_match(g, o)
+    pb = default_params(**kw).to_ffi()
+    for c in (g, o):
+        with pytest.raises(ffi.SphError) as e:
+            c.step(pb)
+        assert e.value.status == 1      # SPH_ERR_INVALID_ARGUMENT: "center diff level estimation method needs density values"
+
+
 @pytest.mark.parametrize("dx", [0.104, 0.108])
 def test_extended_lists_see_a_large_particle_two_tiles_away(product_lib, oracle_lib, dx):
     """Three sizes (1 : 1/2 : 1/3.99).  A mid-size column stands 2.08 h_max from a coarse block: inside the extended range
