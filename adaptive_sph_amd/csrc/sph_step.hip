@@ -99,6 +99,7 @@ const char* status_message(uint32_t code)
     case SPH_ERR_VOLUME_ESTIMATE: return "assertion failed: volume_estimate >= 0.";
     case SPH_ERR_CONSTRAIN_NOT_SMALLER: return "assertion failed: *p_h_next < smoothing_length_single(&particles.h2, i, simulation_params)";
     case SPH_ERR_CONSTRAIN_NEGATIVE: return "assertion failed: *p_h_next >= 0.";
+    case SPH_ERR_UNSUPPORTED: return "a particle's neighbour list exceeds what is recorded (it re-walks its candidates): replaying the step's lists at the advected positions is not covered for it";
     default: return "device-side guard failed";
     }
 }
@@ -891,8 +892,6 @@ static int group_step(Group& G, const sph_params* p, sph_step_stats* outs)
     const bool level_on = p->level_estimation_method != SPH_LEVEL_NONE;
     if (level_on && G.multi()) return c0->fail(SPH_ERR_UNSUPPORTED, "level estimation on a slab decomposition is not covered yet");
     const bool level_after = level_on && p->level_estimation_after_advection;
-    if (level_after && !p->use_extended_range_for_level_estimation)
-        return c0->fail(SPH_ERR_UNSUPPORTED, "level_estimation_after_advection without the extended range (the step's lists replayed at the advected positions) is not covered");
     if (level_on && !level_after && p->level_estimation_method == SPH_LEVEL_CENTER_DIFF)   // simulation.rs:2029-2031
         return c0->fail(SPH_ERR_INVALID_ARGUMENT, "center diff level estimation method needs density values");
     if (!p->level_estimation_after_advection && !p->use_extended_range_for_level_estimation)
@@ -1118,7 +1117,6 @@ static int group_step(Group& G, const sph_params* p, sph_step_stats* outs)
         }
         m.a.nl_ext = c->nl_ext.as<uint4>();   // (allocated just above when this is the first level estimation of the context)
         m.a.nlx_ext = c->nlx_ext.as<uint4>();
-        SweepArgs al = m.a;
         lv.k = p->level_estimation_range / SPH_ETA;                    // simulation.rs:2036
         lv.threshold = cosf(50.f * (SPH_PI_F / 180.f));                // simulation.rs:544
         lv.max_surface_distance = p->maximum_surface_distance;
@@ -1137,8 +1135,15 @@ static int group_step(Group& G, const sph_params* p, sph_step_stats* outs)
         lv.stash_first = p->fill_stash_with == SPH_STASH_SURFACE_DISTANCE_FIRST ? c->stash.as<float>() : nullptr;
         lv.pm_cell = pm_old;
         lv.center_diff = p->level_estimation_method == SPH_LEVEL_CENTER_DIFF;
+        lv.replay_step_lists = pm_old != nullptr && !p->use_extended_range_for_level_estimation;   // simulation.rs:2680: no rebuild
+        if (lv.replay_step_lists) {
+            m.a.nl_ext = m.a.nl;
+            m.a.nlx_ext = m.a.nlx;
+        }
+        SweepArgs al = m.a;
         lv_slack = 0.f;
-        if (pm_old && m.n) {
+        if (pm_old && m.n && lv.replay_step_lists) al.pm = pm_geo;
+        if (pm_old && m.n && !lv.replay_step_lists) {
             al.pm = pm_geo;
             launch_max_disp(c->stream, &c->prof, m.n, pm_old, pm_geo, chg + 62);
             HIPCHK(c, hipMemcpyAsync(c->lvl_changed, chg + 62, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
@@ -1351,7 +1356,7 @@ static int group_step(Group& G, const sph_params* p, sph_step_stats* outs)
         Member& m = M[i];
         sph_ctx* c = m.c;
         c->pcur ^= 1;  // integrated positions live in the other pm buffer; the old one keeps the pre-step snapshot
-        c->lists_after = level_after;
+        c->lists_after = level_after && p->use_extended_range_for_level_estimation;
         c->lists_after_k = lv.k;
         c->lists_after_slack = lv_slack;
         // every solver mode ends in an integrating final sweep, which left the next step's header in hdr_host

@@ -2050,8 +2050,39 @@ void launch_integrate(hipStream_t s, Profiler* prof, const SweepArgs& a, float4*
 }
 
 // ---- level estimation (simulation.rs:862-927, 803-857; adaptivity/mod.rs:32-59) ---------------------------------
+// a particle whose list word is neither a valid mask list nor an index list walks its candidates with the neighbour predicate
+// in every sweep -- which must not happen when the lists are replayed at OTHER positions than they were built from
+__global__ __launch_bounds__(256) void k_require_recorded_lists(uint32_t n, const uint4* __restrict__ nl, const uint32_t* __restrict__ orig,
+                                                                 const uint8_t* __restrict__ owned, DeviceStatus* status)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n || (owned && !owned[i])) return;
+    if (!(nl[i].w & (NL_OK | NL_IDX))) raise_error(status, SPH_ERR_UNSUPPORTED, orig[i]);
+}
+
 void launch_level_detect(hipStream_t s, Profiler* prof, const SweepArgs& a, const LevelArgs& l)
 {
+    if (l.replay_step_lists) {
+        // level estimation after advection WITHOUT the extended range: the step's own lists (a.nl_ext / a.nlx_ext point at them),
+        // geometry of the advected positions
+        if (a.n) hipLaunchKernelGGL(k_require_recorded_lists, dim3((a.n + 255) / 256), dim3(256), 0, s, a.n, a.nl_ext, a.orig, a.owned, a.status);
+        if (l.center_diff) {
+            ProfScope ps(prof, "level_center_diff", s);
+            SPH_DISPATCH(OpLevelCenterDiff, false, a.pm, l.pm_cell, l.level, l.when, l.mark, l.flag_surface, l.stash_first, l.k, l.max_surface_distance,
+                         a.sp.rest_density)
+            return;
+        }
+        {
+            ProfScope ps(prof, "level_normal", s);
+            SPH_DISPATCH(OpLevelNormal, false, a.pm, l.pm_cell, l.nrm, l.state, l.flag_insufficient, a.planes, a.sp, l.k, l.boundary_is_fluid_surface)
+        }
+        {
+            ProfScope ps(prof, "level_cone", s);
+            SPH_DISPATCH(OpLevelCone, false, a.pm, l.pm_cell, l.nrm, l.state, l.level, l.when, l.mark, l.flag_surface, l.stash_first, l.k, l.threshold, l.max_surface_distance,
+                         l.maximum_range, a.sp.rest_density)
+        }
+        return;
+    }
     if (l.center_diff) {
         ProfScope ps(prof, "level_center_diff", s);
         SPH_DISPATCH(OpLevelCenterDiff, true, a.pm, l.pm_cell, l.level, l.when, l.mark, l.flag_surface, l.stash_first, l.k, l.max_surface_distance,
@@ -2111,7 +2142,7 @@ void launch_max_disp(hipStream_t s, Profiler* prof, uint32_t n, const float4* pm
 void launch_level_smooth(hipStream_t s, Profiler* prof, const SweepArgs& a, const LevelArgs& l, const float4* pm_new, const float* in, float* out)
 {
     ProfScope ps(prof, "level_smooth", s);
-    if (l.pm_cell) {   // after advection, extended lists of the advected positions
+    if (l.pm_cell && !l.replay_step_lists) {   // after advection, extended lists of the advected positions
         SPH_DISPATCH(OpLevelSmoothExt, false, pm_new, l.pm_cell, l.k, pm_new, a.orig, a.mrho, in, out, l.level_old, a.status, l.max_surface_distance)
         return;
     }

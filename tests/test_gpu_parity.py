@@ -220,16 +220,18 @@ def test_level_estimation_default_config_scene(product_lib, oracle_lib):
         assert rel_err(g.download(f), o.download(f)) < TOL.get(f, REL_TOL_FIELDS), f
 
 
+@pytest.mark.parametrize("ext", [True, False])
 @pytest.mark.parametrize("scene", ["uniform", "two_sizes", "graded"])
-def test_level_estimation_after_advection(product_lib, oracle_lib, scene):
+def test_level_estimation_after_advection(product_lib, oracle_lib, scene, ext):
     """level_estimation_after_advection (simulation.rs:2018-2070 skipped, 2678-2722): the extended lists are those of the
     ADVECTED positions, detection / propagation / smoothing run on them at the end of the step.  The device gathers them from
     the cells of the pre-step positions with the search range widened by twice the largest displacement."""
-    kw = dict(merging=False, sharing=False, splitting=False, level_estimation_after_advection=True)
+    # ext = False: no rebuild (simulation.rs:2680) -- the step's own k = 2 lists, replayed at the advected positions
+    kw = dict(merging=False, sharing=False, splitting=False, level_estimation_after_advection=True, use_extended_range_for_level_estimation=ext)
     if scene == "uniform":
         g, o = make_pair(product_lib, oracle_lib, sc.dam_break_small(48, 40, 1 / 48))
         P = dam_break_params(level_estimation_method="EmptyAngle", maximum_surface_distance=0.2, particle_radius_fine=0.004,
-                             particle_radius_base=0.02, level_estimation_after_advection=True)
+                             particle_radius_base=0.02, level_estimation_after_advection=True, use_extended_range_for_level_estimation=ext)
     elif scene == "two_sizes":
         scn = sc.SceneConfig.from_yaml(str(Path(__file__).resolve().parent / "golden" / "default-scene.yaml"))
         g, o = make_pair(product_lib, oracle_lib, scn)
@@ -253,7 +255,7 @@ def test_level_estimation_after_advection(product_lib, oracle_lib, scene):
             # ... while the cache (what the host's partner searches iterate) now holds the EXTENDED lists of the advected
             # positions (simulation.rs:2680-2688); identical inputs on the first step -> identical sets
             go, gi = g.download_neighbors()
-            assert (np.diff(go) > g.download("neighbor_count")).mean() > 0.5
+            assert ((np.diff(go) > g.download("neighbor_count")).mean() > 0.5) == ext
             assert_same_neighbor_sets(g, o)
     for f in ALL_FIELDS:
         assert rel_err(g.download(f), o.download(f)) < TOL.get(f, REL_TOL_FIELDS), f
