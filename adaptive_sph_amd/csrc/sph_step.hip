@@ -184,6 +184,38 @@ __global__ __launch_bounds__(256) void k_classify_migrate(uint32_t n, const floa
     }
 }
 
+// ---- slab re-balancing: x range and x histogram of the owned particles --------------------------------------
+__device__ __forceinline__ uint32_t f32_ordered(float f)   // monotone map float -> uint (for atomicMin / atomicMax)
+{
+    const uint32_t b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+static float f32_from_ordered(uint32_t u)
+{
+    const uint32_t b = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+    float f;
+    memcpy(&f, &b, 4);
+    return f;
+}
+__global__ __launch_bounds__(256) void k_minmax_x(uint32_t n, const float4* __restrict__ pm, const uint8_t* __restrict__ owned, uint32_t* __restrict__ out)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n || (owned && !owned[i])) return;
+    const uint32_t u = f32_ordered(pm[i].x);
+    atomicMin(&out[0], u);
+    atomicMax(&out[1], u);
+}
+#define REBALANCE_BINS 4096
+__global__ __launch_bounds__(256) void k_hist_x(uint32_t n, const float4* __restrict__ pm, const uint8_t* __restrict__ owned, float gmin, float binw,
+                                                 uint32_t* __restrict__ hist)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n || (owned && !owned[i])) return;
+    int b = (int)floorf((pm[i].x - gmin) / binw);
+    b = b < 0 ? 0 : (b >= REBALANCE_BINS ? REBALANCE_BINS - 1 : b);
+    atomicAdd(&hist[b], 1u);
+}
+
 // owned particles within `w` of a cut are ghosts of that neighbour: 1 left halo, 2 right halo, 0 none
 __global__ __launch_bounds__(256) void k_classify_halo(uint32_t n, const float4* __restrict__ pm, float lo_edge, float hi_edge, int has_left,
                                                         int has_right, uint32_t* __restrict__ key, uint32_t* __restrict__ val,
@@ -328,6 +360,7 @@ struct Comm {
     // reduce k host values per member element-wise over ALL ranks; every member's row receives the result
     virtual int allreduce_min_f32(Group& G, std::vector<std::vector<float>>& rows) = 0;
     virtual int allreduce_max_i32(Group& G, std::vector<int>& vals) = 0;
+    virtual int allreduce_sum_u32(Group& G, std::vector<std::vector<uint32_t>>& rows) = 0;   // element-wise, REBALANCE_BINS words
     // every member learns the (to-left, to-right) counts its x-neighbours are about to send it
     virtual int neighbour_counts(Group& G, const std::vector<uint32_t>& to_left, const std::vector<uint32_t>& to_right,
                                  std::vector<uint32_t>& from_left, std::vector<uint32_t>& from_right) = 0;
@@ -368,6 +401,15 @@ struct LocalComm : Comm {
         int v = 0;
         for (int x : vals) v = x > v ? x : v;
         for (int& x : vals) x = v;
+        return SPH_OK;
+    }
+    int allreduce_sum_u32(Group& G, std::vector<std::vector<uint32_t>>& rows) override
+    {
+        for (size_t k = 0; k < rows[0].size(); k++) {
+            uint32_t v = 0;
+            for (auto& r : rows) v += r[k];
+            for (auto& r : rows) r[k] = v;
+        }
         return SPH_OK;
     }
     int neighbour_counts(Group& G, const std::vector<uint32_t>& tl, const std::vector<uint32_t>& tr, std::vector<uint32_t>& fl,
@@ -442,6 +484,16 @@ struct RcclComm : Comm {
     int allreduce_max_i32(Group& G, std::vector<int>& vals) override
     {
         return host_allreduce(G.m[0], vals.data(), vals.size() * 4, vals.size(), ncclInt32, ncclMax);
+    }
+    int allreduce_sum_u32(Group& G, std::vector<std::vector<uint32_t>>& rows) override
+    {
+        sph_ctx* c = G.m[0];
+        ncclComm_t nc = (ncclComm_t)c->dist.nccl;
+        void* d = c->dist.hist.p;   // the histogram's own device buffer is the staging area
+        HIPCHK(c, hipMemcpyAsync(d, rows[0].data(), rows[0].size() * 4, hipMemcpyHostToDevice, c->stream));
+        NCCLCHK(c, ncclAllReduce(d, d, rows[0].size(), ncclUint32, ncclSum, nc, c->stream));
+        HIPCHK(c, hipMemcpyAsync(rows[0].data(), d, rows[0].size() * 4, hipMemcpyDeviceToHost, c->stream));
+        return wait_stream(c);
     }
     int neighbour_counts(Group& G, const std::vector<uint32_t>& tl, const std::vector<uint32_t>& tr, std::vector<uint32_t>& fl,
                          std::vector<uint32_t>& fr) override
@@ -619,7 +671,7 @@ __global__ void k_copy_counts(const uint32_t* __restrict__ src, uint32_t* __rest
 
 // ---- slab maintenance (multi-rank only) ---------------------------------------------------------------
 // part 1: drop last step's ghosts, hand over particles that left the slab
-static int partition_and_migrate(Group& G, std::vector<Member>& M)
+static int partition_and_migrate(Group& G, std::vector<Member>& M, std::vector<int>* moved = nullptr)
 {
     const size_t nm = M.size();
     int rc = SPH_OK;
@@ -662,6 +714,8 @@ static int partition_and_migrate(Group& G, std::vector<Member>& M)
         tl[i] = M[i].c->dist.counts_host[1];
         tr[i] = M[i].c->dist.counts_host[2];
     }
+    if (moved)
+        for (size_t i = 0; i < nm; i++) (*moved)[i] = (int)(tl[i] + tr[i]);
     if ((rc = G.comm->neighbour_counts(G, tl, tr, fl, fr))) return rc;
     std::vector<Xfer> x(nm);
     for (size_t i = 0; i < nm; i++) {
@@ -706,6 +760,87 @@ static int partition_and_migrate(Group& G, std::vector<Member>& M)
         d.n_tot = (uint32_t)c->n;
         M[i].n = (uint32_t)c->n;
     }
+    return SPH_OK;
+}
+
+// Move the cuts so that every rank owns the same number of particles ("rebalance every M steps by
+// shifting column cuts"): global x range (all-reduce min) -> histogram of the owned x over REBALANCE_BINS bins (all-reduce sum)
+// -> cuts at the quantiles, identical on every rank (same integers, same floats).  Cuts that would make a slab narrower than
+// the ghost exchange allows are not applied.  The particles follow in the migration rounds of the caller.
+static int rebalance_cuts(Group& G, std::vector<Member>& M, bool* applied)
+{
+    const size_t nm = M.size();
+    int rc;
+    *applied = false;
+    for (auto& m : M) {
+        sph_ctx* c = m.c;
+        auto& d = c->dist;
+        (void)hipSetDevice(c->device);
+        if ((rc = ensure_dist_buffers(c, m.n))) return rc;
+        HIPCHK(c, d.hist.ensure(REBALANCE_BINS * 4));
+        const uint32_t n_prev = d.have_flags ? d.n_tot : (uint32_t)c->n;
+        uint32_t* mm = d.counts.as<uint32_t>() + 8;
+        const uint32_t init[2] = {0xffffffffu, 0u};
+        HIPCHK(c, hipMemcpyAsync(mm, init, 8, hipMemcpyHostToDevice, c->stream));
+        if (n_prev)
+            hipLaunchKernelGGL(k_minmax_x, dim3((n_prev + 255) / 256), dim3(256), 0, c->stream, n_prev, c->pm[c->pcur].as<float4>(),
+                               d.have_flags ? d.owned.as<uint8_t>() : (const uint8_t*)nullptr, mm);
+        HIPCHK(c, hipMemcpyAsync(d.counts_host + 8, mm, 8, hipMemcpyDeviceToHost, c->stream));
+    }
+    if ((rc = agree(G, wait_all(G)))) return rc;
+    std::vector<std::vector<float>> mmr(nm, std::vector<float>(2));
+    for (size_t i = 0; i < nm; i++) {
+        const uint32_t lo = M[i].c->dist.counts_host[8], hi = M[i].c->dist.counts_host[9];
+        const bool any = lo <= hi;
+        mmr[i][0] = any ? f32_from_ordered(lo) : INFINITY;
+        mmr[i][1] = any ? -f32_from_ordered(hi) : INFINITY;
+    }
+    if ((rc = G.comm->allreduce_min_f32(G, mmr))) return rc;
+    const float gmin = mmr[0][0], gmax = -mmr[0][1];
+    if (!(gmax > gmin) || !std::isfinite(gmin) || !std::isfinite(gmax)) return SPH_OK;
+    const float binw = (gmax - gmin) / (float)REBALANCE_BINS;
+    if (!(binw > 0.f)) return SPH_OK;
+    std::vector<std::vector<uint32_t>> hist(nm, std::vector<uint32_t>(REBALANCE_BINS));
+    for (size_t i = 0; i < nm; i++) {
+        sph_ctx* c = M[i].c;
+        auto& d = c->dist;
+        (void)hipSetDevice(c->device);
+        ProfScope ps(&c->prof, "slab_rebalance", c->stream);
+        const uint32_t n_prev = d.have_flags ? d.n_tot : (uint32_t)c->n;
+        (void)hipMemsetAsync(d.hist.p, 0, REBALANCE_BINS * 4, c->stream);
+        if (n_prev)
+            hipLaunchKernelGGL(k_hist_x, dim3((n_prev + 255) / 256), dim3(256), 0, c->stream, n_prev, c->pm[c->pcur].as<float4>(),
+                               d.have_flags ? d.owned.as<uint8_t>() : (const uint8_t*)nullptr, gmin, binw, d.hist.as<uint32_t>());
+        HIPCHK(c, hipMemcpyAsync(hist[i].data(), d.hist.p, REBALANCE_BINS * 4, hipMemcpyDeviceToHost, c->stream));
+    }
+    if ((rc = agree(G, wait_all(G)))) return rc;
+    if ((rc = G.comm->allreduce_sum_u32(G, hist))) return rc;
+    const int nr = M[0].c->dist.nranks;
+    uint64_t total = 0;
+    for (uint32_t v : hist[0]) total += v;
+    if (total == 0) return SPH_OK;
+    std::vector<float> cuts((size_t)nr + 1);
+    cuts[0] = gmin;
+    cuts[(size_t)nr] = gmax;
+    uint64_t cum = 0;
+    int b = 0;
+    for (int r = 1; r < nr; r++) {
+        const uint64_t target = total * (uint64_t)r / (uint64_t)nr;
+        while (b < REBALANCE_BINS && cum + hist[0][b] < target) cum += hist[0][b++];
+        // the cut sits at the upper edge of the bin in which the cumulative count reaches the target
+        cuts[(size_t)r] = gmin + (float)(b + 1) * binw;
+    }
+    // every slab must stay wider than two ghost layers (build_ghost_layer refuses narrower ones): keep the old cuts otherwise
+    const float min_width = 4.5f * M[0].c->h_max_step;
+    for (int r = 0; r < nr; r++)
+        if (!(cuts[(size_t)r + 1] - cuts[(size_t)r] >= min_width)) return SPH_OK;
+    for (auto& m : M) {
+        auto& d = m.c->dist;
+        if (d.rank > 0) d.cut_lo = cuts[(size_t)d.rank];
+        if (d.rank + 1 < nr) d.cut_hi = cuts[(size_t)d.rank + 1];
+        d.rebalances++;
+    }
+    *applied = true;
     return SPH_OK;
 }
 
@@ -911,7 +1046,19 @@ static int group_step(Group& G, const sph_params* p, sph_step_stats* outs)
     //  for that the header has to run on the partitioned arrays, so decompose() is split around it)
     std::vector<std::vector<float>> red(M.size(), std::vector<float>(3));
     if (G.multi()) {
-        if ((rc = partition_and_migrate(G, M))) return rc;  // only needs the cuts
+        bool rebalanced = false;
+        const int every = c0->dist.rebalance_every;
+        if (every > 0 && c0->step_number > 0 && c0->step_number % (uint64_t)every == 0 && c0->h_max_step > 0.f)
+            if ((rc = rebalance_cuts(G, M, &rebalanced))) return rc;
+        // particles follow the cuts to the x-neighbour; after a re-balance a particle may have to cross several slabs:
+        // repeat until nobody moved (the all-reduced count), at most once per rank
+        std::vector<int> moved(M.size(), 0);
+        for (int round = 0;; round++) {
+            if ((rc = partition_and_migrate(G, M, &moved))) return rc;  // only needs the cuts
+            if (!rebalanced) break;
+            if ((rc = G.comm->allreduce_max_i32(G, moved))) return rc;
+            if (moved[0] == 0 || round + 1 >= c0->dist.nranks) break;
+        }
     }
     g_trace.mark(0);
     // The integrating final sweep of the previous step already reduced this step's header into hdr_host (sph_sweeps.hip,
@@ -1440,6 +1587,22 @@ extern "C" int sph_dist_configure(sph_ctx* c, int rank, int n_ranks, float cut_l
     return SPH_OK;
 }
 
+extern "C" int sph_dist_set_rebalance(sph_ctx* c, int every_n_steps)
+{
+    if (!c || every_n_steps < 0) return SPH_ERR_INVALID_ARGUMENT;
+    c->dist.rebalance_every = every_n_steps;
+    return SPH_OK;
+}
+
+extern "C" int sph_dist_get_cuts(sph_ctx* c, float* cut_lo, float* cut_hi, uint32_t* n_rebalances)
+{
+    if (!c) return SPH_ERR_INVALID_ARGUMENT;
+    if (cut_lo) *cut_lo = c->dist.cut_lo;
+    if (cut_hi) *cut_hi = c->dist.cut_hi;
+    if (n_rebalances) *n_rebalances = c->dist.rebalances;
+    return SPH_OK;
+}
+
 extern "C" int sph_comm_unique_id(uint8_t id_out[128])
 {
     if (!id_out) return SPH_ERR_INVALID_ARGUMENT;
@@ -1470,7 +1633,7 @@ void dist_release(sph_ctx* c)
     auto& d = c->dist;
     if (d.nccl) ncclCommDestroy((ncclComm_t)d.nccl);
     d.nccl = nullptr;
-    DevBuf* all[] = {&d.owned, &d.halo_idx, &d.halo_pos, &d.halo_src, &d.ghost_dst, &d.send[0], &d.send[1], &d.recv[0], &d.recv[1], &d.counts, &d.solver_tot};
+    DevBuf* all[] = {&d.owned, &d.halo_idx, &d.halo_pos, &d.halo_src, &d.ghost_dst, &d.send[0], &d.send[1], &d.recv[0], &d.recv[1], &d.counts, &d.solver_tot, &d.hist};
     for (auto b : all) b->release();
     if (d.counts_host) (void)hipHostFree(d.counts_host);
     d.counts_host = nullptr;

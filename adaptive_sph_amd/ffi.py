@@ -126,7 +126,7 @@ class SphError(RuntimeError):
 ABI_SYMBOLS = [
     "create", "destroy", "upload", "upload_field", "download", "download_neighbors", "num_particles", "time",
     "set_time", "step", "last_error", "grid", "set_boundary_polygon", "apply_edits", "profile_enable", "profile_reset", "profile_get", "profile_event_overhead", "profile_copy_bandwidth",
-    "dist_configure", "comm_unique_id", "comm_init", "group_step",
+    "dist_configure", "dist_set_rebalance", "dist_get_cuts", "comm_unique_id", "comm_init", "group_step",
 ]
 
 
@@ -179,6 +179,8 @@ class SphLibrary:
         self.comm_init = sig("comm_init", i32, [vp, C.POINTER(C.c_uint8), i32, i32], required=False)
         self.dist_configure = sig("dist_configure", i32, [vp, i32, i32, C.c_float, C.c_float], required=False)
         self.group_step = sig("group_step", i32, [C.POINTER(vp), i32, C.POINTER(SphParams), C.POINTER(SphStepStats)], required=False)
+        self.dist_set_rebalance = sig("dist_set_rebalance", i32, [vp, i32], required=False)
+        self.dist_get_cuts = sig("dist_get_cuts", i32, [vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_uint32)], required=False)
 
 
 _PRODUCT = None
@@ -353,6 +355,15 @@ class Context:
 
     def dist_configure(self, rank: int, n_ranks: int, cut_lo: float, cut_hi: float):
         self._check(self.lib.dist_configure(self.handle, int(rank), int(n_ranks), float(cut_lo), float(cut_hi)))
+
+    def dist_set_rebalance(self, every_n_steps: int):
+        self._check(self.lib.dist_set_rebalance(self.handle, int(every_n_steps)))
+
+    def dist_get_cuts(self):
+        """-> (cut_lo, cut_hi, number of times the cuts moved)"""
+        lo, hi, k = C.c_float(), C.c_float(), C.c_uint32()
+        self._check(self.lib.dist_get_cuts(self.handle, C.byref(lo), C.byref(hi), C.byref(k)))
+        return lo.value, hi.value, k.value
 
     def comm_init(self, unique_id: bytes, rank: int, n_ranks: int):
         buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)

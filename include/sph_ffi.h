@@ -313,6 +313,12 @@ int  sph_profile_copy_bandwidth(sph_ctx* ctx, uint64_t bytes, double* gb_per_s);
  * sph_group_step steps k contexts of ONE process as ranks 0..k-1 with plain copies as transport (one GPU or
  * several): same algorithm, used to verify the decomposition against a single context. */
 int  sph_dist_configure(sph_ctx* ctx, int rank, int n_ranks, float cut_lo, float cut_hi);
+/* Slab re-balancing: every `every_n_steps` steps (0 = never, the default) the cuts move to the quantiles of the particles' x
+ * (x range and a 4096-bin histogram, all-reduced) so that every rank owns the same number of particles again; particles follow
+ * through the ordinary hand-over to the x-neighbour, repeated until nobody moves.  Cuts that would make a slab narrower than
+ * two ghost layers are not applied.  Set the same value on every rank.  sph_dist_get_cuts reads the current cuts back. */
+int  sph_dist_set_rebalance(sph_ctx* ctx, int every_n_steps);
+int  sph_dist_get_cuts(sph_ctx* ctx, float* cut_lo, float* cut_hi, uint32_t* n_rebalances);
 int  sph_comm_unique_id(uint8_t id_out[128]);
 int  sph_comm_init(sph_ctx* ctx, const uint8_t id[128], int rank, int n_ranks);
 int  sph_group_step(sph_ctx** ctxs, int n, const sph_params* params, sph_step_stats* outs);

@@ -1,6 +1,6 @@
 """Randomised check of the slab decomposition on ONE GPU (loopback group vs a single context) over graded quadtree
 distributions (tests/oracle_harness.quadtree_scene): multi-resolution stencils + ghost layers + migration together.
-usage: gpu_fuzz_slabs.py [first_seed] [n_seeds]"""
+usage: gpu_fuzz_slabs.py [first_seed] [n_seeds] [--rebalance]"""
 import sys
 import numpy as np
 sys.path.insert(0, ".")
@@ -16,6 +16,8 @@ def rel(a, b):
     return np.abs(a - b).max() / (s if s > 0 else 1.0)
 
 
+rebalance = "--rebalance" in sys.argv
+sys.argv = [a for a in sys.argv if not a.startswith("--")]
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 lib = ffi.load_product()
@@ -30,6 +32,9 @@ for seed in range(first, first + count):
     single = ffi.Context(lib, len(mass), planes)
     single.upload(mass, pos, vel)
     grp = D.make_loopback_group(lib, pos, mass, vel, planes, k)
+    if rebalance:
+        for c in grp:
+            c.dist_set_rebalance(2)
     msgs = []
     try:
         for step in range(6):

@@ -85,6 +85,48 @@ def test_loopback_group_on_graded_distributions(product_lib, seed, k):
         assert rel_err(D.gather_by_id(grp, f, len(mass)), single.download(f)) <= tol, (f, info)
 
 
+@pytest.mark.parametrize("k", [2, 4])
+def test_rebalancing_moves_the_cuts_and_keeps_the_physics(product_lib, k):
+    """sph_dist_set_rebalance: a column that drifts to the right leaves the static cuts behind (the left slab drains); with the
+    cuts re-set to the x quantiles every 5 steps the counts stay level, particles cross as many slabs as they have to, and the
+    fields still equal the single context's."""
+    scn = sc.dam_break_small(96, 48, 1 / 48)
+    pos, mass, vel = sc.init_particles(scn)
+    vel = vel.copy()
+    vel[:, 0] = 1.5
+    planes = sc.boundary_planes(scn.boundary)
+    p = forced(max_iters=4).to_ffi()
+    single = ffi.Context(product_lib, len(mass), planes)
+    single.upload(mass, pos, vel)
+    static = D.make_loopback_group(product_lib, pos, mass, vel, planes, k)
+    moving = D.make_loopback_group(product_lib, pos, mass, vel, planes, k)
+    for c in moving:
+        c.dist_set_rebalance(5)
+    cuts0 = [c.dist_get_cuts()[:2] for c in moving]
+    for s in range(60):
+        st1 = single.step(p)
+        ffi.group_step(static, p)
+        sts = ffi.group_step(moving, p)
+        assert all(abs(st.dt - st1.dt) <= 1e-5 * st1.dt for st in sts)
+    n_static, n_moving = [c.n for c in static], [c.n for c in moving]
+    assert sum(n_moving) == len(mass)
+    # level again: to within a lattice column or two (48 particles each) plus the drift since the last re-set
+    assert max(n_moving) - min(n_moving) < 0.12 * len(mass) / k
+    assert max(n_static) - min(n_static) > 2 * (max(n_moving) - min(n_moving))   # the static cuts did drift out of balance
+    cuts1 = [c.dist_get_cuts() for c in moving]
+    assert all(c[2] >= 10 for c in cuts1)
+    for r in range(k - 1):
+        assert cuts1[r][1] == cuts1[r + 1][0] and cuts1[r][1] > cuts0[r][1]     # shared, and moved with the fluid
+    ids = np.concatenate([c.download("particle_id") for c in moving])
+    assert np.array_equal(np.sort(ids), np.arange(len(mass)))
+    # 60 steps with the column hitting the right wall: summation-order differences grow to a few 1e-4 in v -- the group with
+    # the static cuts shows the same
+    for f, tol in (("position", 1e-5), ("velocity", 1e-3), ("density", 1e-4)):
+        assert rel_err(D.gather_by_id(moving, f, len(mass)), single.download(f)) <= tol, f
+        assert rel_err(D.gather_by_id(static, f, len(mass)), single.download(f)) <= tol, f
+    assert (D.gather_by_id(moving, "neighbor_count", len(mass)) != single.download("neighbor_count")).mean() < 1e-3
+
+
 def test_group_of_one_is_the_plain_step(product_lib):
     scn = sc.dam_break_small(32, 32, 1 / 32)
     pos, mass, vel = sc.init_particles(scn)
