@@ -872,15 +872,15 @@ static int build_ghost_layer(Group& G, std::vector<Member>& M, float halo_width)
         }
         hipLaunchKernelGGL(k_copy_counts, dim3(1), dim3(64), 0, c->stream, d.counts.as<uint32_t>(), d.counts_host_dev);
     }
-    if ((rc = agree(G, wait_all(G)))) return rc;
-    for (size_t i = 0; i < nm; i++) {
+    // one agreement for both the wait and the width check (every rank leaves together)
+    rc = wait_all(G);
+    for (size_t i = 0; i < nm && !rc; i++) {
         auto& d = M[i].c->dist;
-        if (d.counts_host[4 + 3])
-            return agree(G, M[i].c->fail(SPH_ERR_UNSUPPORTED, "slab of rank %d is narrower than two support radii", d.rank));
+        if (d.counts_host[4 + 3]) rc = M[i].c->fail(SPH_ERR_UNSUPPORTED, "slab of rank %d is narrower than two support radii", d.rank);
         tl[i] = d.counts_host[4 + 1];
         tr[i] = d.counts_host[4 + 2];
     }
-    if ((rc = agree(G, SPH_OK))) return rc;
+    if ((rc = agree(G, rc))) return rc;
     if ((rc = G.comm->neighbour_counts(G, tl, tr, fl, fr))) return rc;
     for (size_t i = 0; i < nm; i++) {
         sph_ctx* c = M[i].c;

@@ -9,7 +9,9 @@ from adaptive_sph_amd.workloads import WORKLOADS
 lib = ffi.load_product()
 for wl, steps, kw in [("dam_break_1m", 12000, {}), ("dam_break_1m_adaptive", 4000, {}),
                       ("dam_break_64k", 3000, dict(level_estimation_method="EmptyAngle", maximum_surface_distance=0.2)),
-                      ("dam_break_64k", 3000, dict(support_length_estimation="FromDistributionClamped1", pressure_solver_method="IISPH"))]:
+                      ("dam_break_64k", 3000, dict(support_length_estimation="FromDistributionClamped1", pressure_solver_method="IISPH")),
+                      ("dam_break_64k", 3000, dict(level_estimation_method="EmptyAngle", maximum_surface_distance=0.2, level_estimation_after_advection=True)),
+                      ("dam_break_1m", 600, dict(level_estimation_method="EmptyAngle", maximum_surface_distance=0.2))]:
     scene_f, params_f, _ = WORKLOADS[wl]
     scn, P = scene_f(), params_f(**kw)
     pos, mass, vel = sc.init_particles(scn)
