@@ -166,8 +166,14 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    # warm-up = steps 0..W-1 from rest (SURVEY.md section 8d also wants them reported: the rest lattice).  Timed on the side,
+    # never part of `value`.
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    t_w0 = time.perf_counter()
     for _ in range(args.warmup):
         ctx.step(p)
+    warmup_elapsed = time.perf_counter() - t_w0
 
     # ---- timed region: exactly K steps, uninstrumented.  (Recording ANY timing-enabled HIP event switches the
     # ROCm queue into per-dispatch profiling for the rest of the process: +~8 us per launch, +0.38 ms per step
@@ -260,6 +266,19 @@ def main():
         "roofline": roofline,
         "roofline_density": roofline_density,
         "kernels": kernels,
+    }
+    # whole-step algorithmic bytes B_step = 388 + 100 (n_div + n_dens) B per particle-step with the
+    # iteration counts of the timed steps (sweeps only; the neighbour build is listed apart), and the steps from rest
+    b_step = 388.0 + 100.0 * (float(np.mean(div_iters)) + float(np.mean(dens_iters)))
+    step_gbs = b_step * n_total * args.steps / elapsed / 1e9
+    out["whole_step"] = {
+        "algorithmic_bytes_per_particle_step": b_step,
+        "achieved_GBs": step_gbs, "frac_hbm_peak": step_gbs / (HBM_PEAK_GBS * world),
+        # cell keys 16r + 8w; two radix passes of (4r histogram + 8r + 8w scatter); reorder 40r + 40w (value, record, velocity,
+        # id, level state); cell-range table 4r
+        "neighbour_build_algorithmic_bytes_per_particle": 24 + 2 * 20 + 80 + 4,
+        "steps_from_rest": {"steps": args.warmup, "ms_per_step": warmup_elapsed * 1e3 / max(args.warmup, 1),
+                            "note": "steps 0..warmup-1 (rest lattice, first launches included); rank 0's clock, not part of `value`"},
     }
     if not args.no_extra and not distributed and wl == "dam_break_1m":
         ctx.close()
