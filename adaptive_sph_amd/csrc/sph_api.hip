@@ -609,7 +609,7 @@ extern "C" int sph_download(sph_ctx* c, int field, void* dst, uint64_t bytes)
         // the defaults of ParticleVec.
         size_t elem = field == SPH_F_STASH ? 4 : 1;
         if (bytes != (uint64_t)n * elem) return c->fail(SPH_ERR_INVALID_ARGUMENT, "field %d: size mismatch", field);
-        if (c->dist.on || (!c->have_level && field != SPH_F_PARTICLE_SIZE_CLASS)) {
+        if ((!c->have_level && field != SPH_F_PARTICLE_SIZE_CLASS) || (c->dist.on && !c->have_level)) {
             memset(dst, field == SPH_F_PARTICLE_SIZE_CLASS ? 2 : 0, bytes);
             return SPH_OK;
         }
@@ -617,6 +617,7 @@ extern "C" int sph_download(sph_ctx* c, int field, void* dst, uint64_t bytes)
         const void* src = field == SPH_F_STASH ? c->stash.p
                           : field == SPH_F_FLAG_IS_FLUID_SURFACE ? c->flag_surface.p
                           : field == SPH_F_FLAG_INSUFFICIENT_NEIGHS ? c->flag_insufficient.p : c->szc[k].p;
+        if (c->dist.on) return download_slab(c, field == SPH_F_STASH ? (int)G_F32 : (int)G_U8, src, elem, dst, bytes);
         hipLaunchKernelGGL(k_to_host_order, dim3((n + 255) / 256), dim3(256), 0, s, n, field == SPH_F_STASH ? (int)G_F32 : (int)G_U8,
                            c->orig[k].as<uint32_t>(), src, c->scratch.p);
         HIPCHK(c, hipMemcpyAsync(dst, c->scratch.p, bytes, hipMemcpyDeviceToHost, s));

@@ -556,6 +556,7 @@ struct Member {
     SweepArgs a;
     sph_step_stats st;
     std::chrono::steady_clock::time_point wall0;
+    float *lv_level = nullptr, *lv_when = nullptr, *lv_pmnew = nullptr;   // level estimation fields whose ghosts are refreshed
 };
 
 // collective error check at a wait point: returns the first error of this process, or (multi-rank) a generic
@@ -640,6 +641,9 @@ static float* sel_vel(Member& m) { return (float*)m.a.vel; }
 static float* sel_pacc(Member& m) { return (float*)m.a.pacc; }
 static float* sel_pt0(Member& m) { return m.a.pt0; }
 static float* sel_pt1(Member& m) { return m.a.pt1; }
+static float* sel_lv_level(Member& m) { return m.lv_level; }
+static float* sel_lv_when(Member& m) { return m.lv_when; }
+static float* sel_lv_pmnew(Member& m) { return m.lv_pmnew; }
 
 static int ensure_dist_buffers(sph_ctx* c, uint32_t n)
 {
@@ -1025,7 +1029,8 @@ static int group_step(Group& G, const sph_params* p, sph_step_stats* outs)
         return c0->fail(SPH_ERR_UNSUPPORTED, "constrain_neighborhood_count on a slab decomposition is not covered yet");
     if (p->check_aii && G.multi()) return c0->fail(SPH_ERR_UNSUPPORTED, "check_aii on a slab decomposition is not covered yet");
     const bool level_on = p->level_estimation_method != SPH_LEVEL_NONE;
-    if (level_on && G.multi()) return c0->fail(SPH_ERR_UNSUPPORTED, "level estimation on a slab decomposition is not covered yet");
+    if (level_on && G.multi() && p->level_estimation_after_advection)
+        return c0->fail(SPH_ERR_UNSUPPORTED, "level_estimation_after_advection on a slab decomposition is not covered yet");
     const bool level_after = level_on && p->level_estimation_after_advection;
     if (level_on && !level_after && p->level_estimation_method == SPH_LEVEL_CENTER_DIFF)   // simulation.rs:2029-2031
         return c0->fail(SPH_ERR_INVALID_ARGUMENT, "center diff level estimation method needs density values");
@@ -1089,7 +1094,9 @@ static int group_step(Group& G, const sph_params* p, sph_step_stats* outs)
 
     if (G.multi()) {
         // ghost layer with the real width: one support radius of the largest particle anywhere
-        if ((rc = build_ghost_layer(G, M, h_max_g * 2.f))) return rc;
+        // (the extended lists of the level estimation reach level_estimation_range / ETA smoothing lengths)
+        const float halo_k = level_on ? fmaxf(2.f, p->level_estimation_range / SPH_ETA) : 2.f;
+        if ((rc = build_ghost_layer(G, M, h_max_g * halo_k))) return rc;
         // bounding box of owned + ghosts
         for (auto& m : M) {
             (void)hipSetDevice(m.c->device);
@@ -1336,7 +1343,100 @@ static int group_step(Group& G, const sph_params* p, sph_step_stats* outs)
         m.st.ms_level_estimation += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_lvl0).count();
         return SPH_OK;
     };
-    if (level_on && !level_after) {
+    // the same on a slab decomposition (before advection): ghost lanes idle, the ghosts' (level, when) refreshed from their
+    // owners after the detection and after every sweep, propagation without frontier marks, the stop decision all-reduced
+    std::vector<LevelArgs> LV(M.size());
+    auto level_estimation_slabs = [&]() -> int {
+        const auto t_lvl0 = std::chrono::steady_clock::now();
+        for (size_t i = 0; i < M.size(); i++) {
+            Member& m = M[i];
+            sph_ctx* c = m.c;
+            (void)hipSetDevice(c->device);
+            const size_t n = m.n ? m.n : 1;
+            HIPCHK(c, c->lvl_tmp.ensure(n * 4));
+            HIPCHK(c, c->lvl_nrm.ensure(n * 8));
+            HIPCHK(c, c->lvl_when.ensure(n * 4));
+            HIPCHK(c, c->lvl_mark.ensure(n * 4));
+            HIPCHK(c, c->stash.ensure(n * 4));
+            for (DevBuf* b : {&c->lvl_state, &c->flag_surface, &c->flag_insufficient}) HIPCHK(c, b->ensure(n));
+            HIPCHK(c, c->nl_ext.ensure(sweep_list_bytes((uint32_t)n)));
+            HIPCHK(c, c->nlx_ext.ensure(sweep_index_list_bytes((uint32_t)n)));
+            HIPCHK(c, c->lvl_changed_d.ensure(64 * sizeof(uint32_t)));
+            m.a = make_args(c, m.sp);
+            m.a.h_mode = p->support_length_estimation;
+            m.a.sp_check_aii = p->check_aii;
+            LevelArgs& l = LV[i];
+            l = LevelArgs{};
+            l.k = p->level_estimation_range / SPH_ETA;
+            l.threshold = cosf(50.f * (SPH_PI_F / 180.f));
+            l.max_surface_distance = p->maximum_surface_distance;
+            l.boundary_is_fluid_surface = p->boundary_is_fluid_surface;
+            l.maximum_range = -1.f;   // FromDistribution* is refused on slabs
+            l.nrm = c->lvl_nrm.as<float2>();
+            l.state = c->lvl_state.as<uint8_t>();
+            l.flag_surface = c->flag_surface.as<uint8_t>();
+            l.flag_insufficient = c->flag_insufficient.as<uint8_t>();
+            l.size_class = c->szc[c->cur].as<uint8_t>();
+            l.level = c->lvl[c->cur].as<float>();
+            l.when = c->lvl_when.as<uint32_t>();
+            l.mark = c->lvl_mark.as<uint32_t>();
+            l.level_old = c->lvlold[c->cur].as<float>();
+            l.stash_first = p->fill_stash_with == SPH_STASH_SURFACE_DISTANCE_FIRST ? c->stash.as<float>() : nullptr;
+            l.plain_propagate = 1;
+            m.lv_level = (float*)l.level;
+            m.lv_when = (float*)l.when;
+            if (m.n) {
+                if (p->fill_stash_with == SPH_STASH_NONE) (void)hipMemsetAsync(c->stash.p, 0, n * 4, c->stream);
+                // (flags / states of the ghost slots are never read; zero them so that downloads see defined bytes)
+                (void)hipMemsetAsync(c->flag_surface.p, 0, n, c->stream);
+                (void)hipMemsetAsync(c->flag_insufficient.p, 0, n, c->stream);
+                launch_level_detect(c->stream, &c->prof, m.a, l);
+            }
+        }
+        if ((rc = refresh_ghosts(G, M, sel_lv_level, 1, "level"))) return rc;
+        if ((rc = refresh_ghosts(G, M, sel_lv_when, 1, "when"))) return rc;
+        const int B = 8;
+        uint32_t t = 1;
+        for (bool done = false; !done;) {
+            for (auto& m : M) {
+                (void)hipSetDevice(m.c->device);
+                (void)hipMemsetAsync(m.c->lvl_changed_d.p, 0, B * sizeof(uint32_t), m.c->stream);
+            }
+            for (int b = 0; b < B; b++, t++) {
+                for (size_t i = 0; i < M.size(); i++) {
+                    Member& m = M[i];
+                    sph_ctx* c = m.c;
+                    (void)hipSetDevice(c->device);
+                    if (!m.n) continue;
+                    launch_level_propagate(c->stream, &c->prof, m.a, LV[i], t, c->lvl_changed_d.as<uint32_t>() + b);
+                    if (t == 1u && p->fill_stash_with == SPH_STASH_SURFACE_DISTANCE_MIDDLE)
+                        launch_fill_stash(c->stream, &c->prof, m.a, LV[i], c->stash.as<float>());
+                }
+                if ((rc = refresh_ghosts(G, M, sel_lv_level, 1, "level"))) return rc;
+                if ((rc = refresh_ghosts(G, M, sel_lv_when, 1, "when"))) return rc;
+            }
+            for (auto& m : M) {
+                (void)hipSetDevice(m.c->device);
+                HIPCHK(m.c, hipMemcpyAsync(m.c->lvl_changed, m.c->lvl_changed_d.p, B * sizeof(uint32_t), hipMemcpyDeviceToHost, m.c->stream));
+            }
+            if ((rc = agree(G, wait_all(G)))) return rc;
+            // "nobody assigned anything" is final once it happens: the flags of a batch are ones followed by zeros, on every rank
+            std::vector<int> last(M.size(), 0);
+            for (size_t i = 0; i < M.size(); i++)
+                for (int b = 0; b < B; b++)
+                    if (M[i].c->lvl_changed[b]) last[i] = b + 1;
+            if ((rc = G.comm->allreduce_max_i32(G, last))) return rc;
+            done = last[0] < B;
+        }
+        for (auto& m : M) {
+            m.c->have_level = true;
+            m.st.ms_level_estimation += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_lvl0).count();
+        }
+        return SPH_OK;
+    };
+    if (level_on && G.multi()) {
+        if ((rc = level_estimation_slabs())) return rc;
+    } else if (level_on && !level_after) {
         if ((rc = level_estimation(nullptr, nullptr))) return rc;
     } else if (!level_on) {
         for (auto& m : M) m.c->have_level = false;
@@ -1480,11 +1580,32 @@ static int group_step(Group& G, const sph_params* p, sph_step_stats* outs)
         return c0->fail(SPH_ERR_XSPH_TODO, "not yet implemented (XSPH velocity smoothing)");
 
     // ---- smooth_level_estimation_field + classify_particles (simulation.rs:2709-2722) --------------------------------------
+    if (level_on && G.multi()) {
+        const auto t_lvl0 = std::chrono::steady_clock::now();
+        for (auto& m : M) {
+            m.lv_level = m.c->lvl[m.c->cur].as<float>();
+            m.lv_pmnew = (float*)m.c->pm[m.c->pcur ^ 1].as<float4>();
+        }
+        // the ghosts' level values and ADVECTED records (ghost lanes do not integrate) come from their owners
+        if ((rc = refresh_ghosts(G, M, sel_lv_level, 1, "level"))) return rc;
+        if ((rc = refresh_ghosts(G, M, sel_lv_pmnew, 4, "pm_new"))) return rc;
+        for (size_t i = 0; i < M.size(); i++) {
+            Member& m = M[i];
+            sph_ctx* c = m.c;
+            (void)hipSetDevice(c->device);
+            if (!m.n) continue;
+            launch_level_smooth(c->stream, &c->prof, m.a, LV[i], c->pm[c->pcur ^ 1].as<float4>(), c->lvl[c->cur].as<float>(), c->lvl_tmp.as<float>());
+            std::swap(c->lvl[c->cur], c->lvl_tmp);
+            launch_classify(c->stream, &c->prof, m.a, LV[i], c->lvl[c->cur].as<float>(), p);
+        }
+        if ((rc = sync_ctrl(G))) return rc;
+        for (auto& m : M) m.st.ms_level_estimation += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_lvl0).count();
+    }
     if (level_after) {   // simulation.rs:2678-2707: lists of the advected positions, then detection + propagation there
         sph_ctx* c = M[0].c;
         if ((rc = level_estimation(c->pm[c->pcur ^ 1].as<float4>(), c->pm[c->pcur].as<float4>()))) return rc;
     }
-    if (level_on) {
+    if (level_on && !G.multi()) {
         const auto t_lvl0 = std::chrono::steady_clock::now();
         Member& m = M[0];
         sph_ctx* c = m.c;

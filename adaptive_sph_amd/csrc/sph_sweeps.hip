@@ -1429,13 +1429,19 @@ struct OpLevelPropagate {
     // particle still unassigned has no neighbour from an earlier sweep (it would have been assigned then), so everything
     // later derives from this sweep's values and lies deeper still.  `changed` therefore means "assigned something above the bound".
     float useful_above;
+    int plain;   // slab decomposition: no frontier marks (a ghost cannot mark for its owner's rank) -- every unassigned particle
+                 // looks at its list in every sweep, like the reference does
     struct Acc {
         float best, r2max;
         bool have;
     };
     __device__ float krange() const { return k; }
     __device__ bool skip() const { return false; }
-    __device__ bool lane_skip(uint32_t i) const { return t == 0u ? when[i] != 0u : !(when[i] == LVL_UNASSIGNED && mark[i] == t); }
+    __device__ bool lane_skip(uint32_t i) const
+    {
+        if (plain) return t == 0u || when[i] != LVL_UNASSIGNED;
+        return t == 0u ? when[i] != 0u : !(when[i] == LVL_UNASSIGNED && mark[i] == t);
+    }
     __device__ void init(Acc&) const {}
     __device__ void epilogue(Acc&, bool, uint32_t) const {}
     __device__ float2 cell_pos(uint32_t i, const float4& Ai) const
@@ -1462,7 +1468,7 @@ struct OpLevelPropagate {
     {
         // a candidate of sweep t is assigned in sweep t; its unassigned neighbours are the candidates of sweep t+1.  (In the
         // candidate-walk fallback only accepted pairs arrive here, so only real neighbours are marked.)
-        if (Bj.w == LVL_UNASSIGNED) mark[Bj.j] = t + 1u;
+        if (!plain && Bj.w == LVL_UNASSIGNED) mark[Bj.j] = t + 1u;
         if (!(Bj.w < t)) return;
         if (r2 > a.r2max) return;
         const float est = Bj.lv - sqrtf(r2);
@@ -2104,7 +2110,7 @@ void launch_level_propagate(hipStream_t s, Profiler* prof, const SweepArgs& a, c
 {
     ProfScope ps(prof, "level_propagate", s);
     SPH_DISPATCH(OpLevelPropagate, false, a.pm, l.pm_cell, l.level, l.when, l.mark, changed, l.k, t, l.maximum_range, a.sp.rest_density,
-                 -l.max_surface_distance)
+                 -l.max_surface_distance, l.plain_propagate)
 }
 
 void launch_fill_stash(hipStream_t s, Profiler* prof, const SweepArgs& a, const LevelArgs& l, float* stash)

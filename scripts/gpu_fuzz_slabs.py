@@ -1,12 +1,12 @@
 """Randomised check of the slab decomposition on ONE GPU (loopback group vs a single context) over graded quadtree
 distributions (tests/oracle_harness.quadtree_scene): multi-resolution stencils + ghost layers + migration together.
-usage: gpu_fuzz_slabs.py [first_seed] [n_seeds] [--rebalance]"""
+usage: gpu_fuzz_slabs.py [first_seed] [n_seeds] [--rebalance] [--level]"""
 import sys
 import numpy as np
 sys.path.insert(0, ".")
 import torch  # noqa: F401
 from adaptive_sph_amd import distributed as D, ffi, scene as sc
-from adaptive_sph_amd.workloads import dam_break_params
+from adaptive_sph_amd.workloads import dam_break_params, default_params
 from tests.oracle_harness import quadtree_scene
 
 
@@ -17,6 +17,7 @@ def rel(a, b):
 
 
 rebalance = "--rebalance" in sys.argv
+level = "--level" in sys.argv
 sys.argv = [a for a in sys.argv if not a.startswith("--")]
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 20
@@ -28,7 +29,8 @@ for seed in range(first, first + count):
     vel = vel.copy()
     vel[:, 0] += 0.5
     k = 2 + seed % 3
-    p = dam_break_params(hybrid_dfsph_max_avg_density_error=0.0, hybrid_dfsph_max_avg_divergence_error=0.0, max_iters=3, max_dt=0.001).to_ffi()
+    kw = dict(hybrid_dfsph_max_avg_density_error=0.0, hybrid_dfsph_max_avg_divergence_error=0.0, max_iters=3, max_dt=0.001)
+    p = (default_params(merging=False, sharing=False, splitting=False, **kw) if level else dam_break_params(**kw)).to_ffi()
     single = ffi.Context(lib, len(mass), planes)
     single.upload(mass, pos, vel)
     grp = D.make_loopback_group(lib, pos, mass, vel, planes, k)
@@ -50,6 +52,15 @@ for seed in range(first, first + count):
             r = rel(D.gather_by_id(grp, f, len(mass)), single.download(f))
             if not r <= tol:
                 msgs.append(f"{f} {r:.2e}")
+        if level:
+            n = len(mass)
+            fa, fb = D.gather_by_id(grp, "flag_is_fluid_surface", n), single.download("flag_is_fluid_surface")
+            if (fa != fb).sum() > 2:
+                msgs.append(f"{(fa != fb).sum()} surface flags differ")
+            elif np.array_equal(fa, fb):
+                a, b = D.gather_by_id(grp, "level_estimation", n), single.download("level_estimation")
+                if not np.array_equal(np.isnan(a), np.isnan(b)) or np.nanmax(np.abs(a - b)) > 1e-4 * max(np.nanmax(np.abs(b)), 1e-30):
+                    msgs.append("level_estimation differs")
     except ffi.SphError as e:
         if e.status == 30 and "narrower" in str(e):
             skipped += 1

@@ -127,6 +127,39 @@ def test_rebalancing_moves_the_cuts_and_keeps_the_physics(product_lib, k):
     assert (D.gather_by_id(moving, "neighbor_count", len(mass)) != single.download("neighbor_count")).mean() < 1e-3
 
 
+@pytest.mark.parametrize("k", [2, 3])
+def test_level_estimation_on_slabs(product_lib, k):
+    """EmptyAngle detection, propagation, smoothing and size classes across the cuts: the ghost layer widens to the extended
+    range, the ghosts' (level, when) follow their owners after every sweep, the stop decision is all-reduced.  Same flags,
+    same distances, same classes as the single context (whose propagation runs in frontier form)."""
+    scn = sc.dam_break_small(96, 48, 1 / 48)
+    pos, mass, vel = sc.init_particles(scn)
+    vel = vel.copy()
+    vel[:, 0] = 0.8
+    planes = sc.boundary_planes(scn.boundary)
+    P = forced(max_iters=4, level_estimation_method="EmptyAngle", maximum_surface_distance=0.2, particle_radius_fine=0.004,
+               particle_radius_base=0.02)
+    P.fill_stash_with = "SurfaceDistanceMiddle"
+    p = P.to_ffi()
+    single = ffi.Context(product_lib, len(mass), planes)
+    single.upload(mass, pos, vel)
+    grp = D.make_loopback_group(product_lib, pos, mass, vel, planes, k)
+    for s in range(12):
+        single.step(p)
+        ffi.group_step(grp, p)
+    n = len(mass)
+    for f in ("flag_is_fluid_surface", "flag_insufficient_neighs"):
+        assert np.array_equal(D.gather_by_id(grp, f, n), single.download(f)), f
+    assert 0 < single.download("flag_is_fluid_surface").sum() < n
+    for f in ("level_estimation", "level_old", "stash"):
+        a, b = D.gather_by_id(grp, f, n), single.download(f)
+        assert np.array_equal(np.isnan(a), np.isnan(b)), f
+        assert np.nanmax(np.abs(a - b)) <= 1e-4 * max(np.nanmax(np.abs(b)), 1e-30), f
+    assert (D.gather_by_id(grp, "particle_size_class", n) != single.download("particle_size_class")).mean() < 1e-3
+    for f, tol in (("position", 1e-5), ("velocity", 1e-4), ("density", 1e-5)):
+        assert rel_err(D.gather_by_id(grp, f, n), single.download(f)) <= tol, f
+
+
 def test_group_of_one_is_the_plain_step(product_lib):
     scn = sc.dam_break_small(32, 32, 1 / 32)
     pos, mass, vel = sc.init_particles(scn)
