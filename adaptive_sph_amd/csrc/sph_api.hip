@@ -312,10 +312,13 @@ __global__ __launch_bounds__(256) void k_fill_neighbors(uint32_t n, GridP g, Til
 // check_correct_neighborhood (simulation.rs:1810-1863) against the O(N^2) definition: the sweeps only
 // ever visit pairs that satisfy the predicate, so equal COUNTS imply equal sets.
 __global__ __launch_bounds__(256) void k_check_neighborhood(uint32_t n, const float4* __restrict__ pm, const uint32_t* __restrict__ ncount,
-                                                             const uint32_t* __restrict__ orig, DeviceStatus* status)
+                                                             const uint32_t* __restrict__ orig, DeviceStatus* status, const uint8_t* __restrict__ owned)
 {
     uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
+    // slab decomposition: an owned particle's neighbours are all among owned + ghosts, so the O(N^2) count over the local arrays
+    // is the global one; ghost lanes have no list
+    if (owned && !owned[i]) return;
     const float4 Ai = pm[i];
     uint32_t cnt = 0;
     for (uint32_t j = 0; j < n; j++) {
@@ -1036,5 +1039,5 @@ void launch_publish(sph_ctx* c)
 void launch_check_neighborhood(sph_ctx* c, const SweepArgs& a)
 {
     ProfScope ps(&c->prof, "check_neighborhood", c->stream);
-    hipLaunchKernelGGL(k_check_neighborhood, dim3((a.n + 255) / 256), dim3(256), 0, c->stream, a.n, a.pm, a.ncount, a.orig, a.status);
+    hipLaunchKernelGGL(k_check_neighborhood, dim3((a.n + 255) / 256), dim3(256), 0, c->stream, a.n, a.pm, a.ncount, a.orig, a.status, a.owned);
 }

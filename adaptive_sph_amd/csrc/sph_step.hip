@@ -237,10 +237,11 @@ __global__ __launch_bounds__(256) void k_classify_halo(uint32_t n, const float4*
 }
 
 // migrant record: x, y, m, h, vx, vy, id, level, level_old
-#define MIG_WORDS 9
+#define MIG_WORDS 12
 __global__ __launch_bounds__(256) void k_pack_migrants(uint32_t base, uint32_t cnt, const float4* __restrict__ pm, const float2* __restrict__ vel,
                                                         const uint32_t* __restrict__ orig, const float* __restrict__ lvl,
-                                                        const float* __restrict__ lvlold, float* __restrict__ rec)
+                                                        const float* __restrict__ lvlold, const float* __restrict__ h2n,
+                                                        const float* __restrict__ lam_sum, const uint8_t* __restrict__ szc, float* __restrict__ rec)
 {
     uint32_t k = blockIdx.x * 256 + threadIdx.x;
     if (k >= cnt) return;
@@ -252,10 +253,14 @@ __global__ __launch_bounds__(256) void k_pack_migrants(uint32_t base, uint32_t c
     r[6] = __uint_as_float(orig[i]);
     r[7] = lvl[i];
     r[8] = lvlold[i];
+    r[9] = h2n[i];        // h2_next and the previous step's lambda sum: FromDistribution* support lengths
+    r[10] = lam_sum[i];
+    r[11] = __uint_as_float((uint32_t)szc[i]);
 }
 __global__ __launch_bounds__(256) void k_unpack_migrants(uint32_t base, uint32_t cnt, const float* __restrict__ rec, float4* __restrict__ pm,
                                                           float2* __restrict__ vel, uint32_t* __restrict__ orig, float* __restrict__ lvl,
-                                                          float* __restrict__ lvlold)
+                                                          float* __restrict__ lvlold, float* __restrict__ h2n, float* __restrict__ lam_sum,
+                                                          uint8_t* __restrict__ szc)
 {
     uint32_t k = blockIdx.x * 256 + threadIdx.x;
     if (k >= cnt) return;
@@ -266,6 +271,9 @@ __global__ __launch_bounds__(256) void k_unpack_migrants(uint32_t base, uint32_t
     orig[i] = __float_as_uint(r[6]);
     lvl[i] = r[7];
     lvlold[i] = r[8];
+    h2n[i] = r[9];
+    lam_sum[i] = r[10];
+    szc[i] = (uint8_t)__float_as_uint(r[11]);
 }
 
 // ghost record (static per step): x, y, m, h, vx, vy
@@ -705,9 +713,11 @@ static int partition_and_migrate(Group& G, std::vector<Member>& M, std::vector<i
             launch_reorder(c->stream, &c->prof, n_prev, g1, c->key[0].as<uint32_t>(), c->val[0].as<uint32_t>(), c->pm[c->pcur].as<float4>(),
                            c->vel[k].as<float2>(), c->orig[k].as<uint32_t>(), c->lvl[k].as<float>(), c->lvlold[k].as<float>(),
                            c->pm[c->pcur ^ 1].as<float4>(), c->vel[k ^ 1].as<float2>(), c->orig[k ^ 1].as<uint32_t>(), c->lvl[k ^ 1].as<float>(),
-                           c->lvlold[k ^ 1].as<float>(), c->cxy.as<uint32_t>());
+                           c->lvlold[k ^ 1].as<float>(), c->cxy.as<uint32_t>(), c->h2n[k].as<float>(), c->h2n[k ^ 1].as<float>(),
+                           c->lam_sum.as<float>(), c->lam_prev.as<float>(), nullptr, c->szc[k].as<uint8_t>(), c->szc[k ^ 1].as<uint8_t>());
             c->cur = k ^ 1;
             c->pcur ^= 1;
+            std::swap(c->lam_sum, c->lam_prev);   // the permuted lambda sums are the CURRENT ones again (the cell sort moves them on)
         }
         hipLaunchKernelGGL(k_copy_counts, dim3(1), dim3(64), 0, c->stream, d.counts.as<uint32_t>(), d.counts_host_dev);
     }
@@ -737,7 +747,8 @@ static int partition_and_migrate(Group& G, std::vector<Member>& M, std::vector<i
             if (cnt[side])
                 hipLaunchKernelGGL(k_pack_migrants, dim3((cnt[side] + 255) / 256), dim3(256), 0, c->stream, base[side], cnt[side],
                                    c->pm[c->pcur].as<float4>(), c->vel[k].as<float2>(), c->orig[k].as<uint32_t>(), c->lvl[k].as<float>(),
-                                   c->lvlold[k].as<float>(), d.send[side].as<float>());
+                                   c->lvlold[k].as<float>(), c->h2n[k].as<float>(), c->lam_sum.as<float>(), c->szc[k].as<uint8_t>(),
+                                   d.send[side].as<float>());
             x[i].send[side] = d.send[side].p;
             x[i].send_bytes[side] = (size_t)cnt[side] * MIG_WORDS * 4;
             x[i].recv[side] = d.recv[side].p;
@@ -758,7 +769,8 @@ static int partition_and_migrate(Group& G, std::vector<Member>& M, std::vector<i
             if (cnt[side])
                 hipLaunchKernelGGL(k_unpack_migrants, dim3((cnt[side] + 255) / 256), dim3(256), 0, c->stream, base[side], cnt[side],
                                    d.recv[side].as<float>(), c->pm[c->pcur].as<float4>(), c->vel[k].as<float2>(), c->orig[k].as<uint32_t>(),
-                                   c->lvl[k].as<float>(), c->lvlold[k].as<float>());
+                                   c->lvl[k].as<float>(), c->lvlold[k].as<float>(), c->h2n[k].as<float>(), c->lam_sum.as<float>(),
+                                   c->szc[k].as<uint8_t>());
         c->n = n_stay + fl[i] + fr[i];
         d.have_flags = false;
         d.n_tot = (uint32_t)c->n;
@@ -1023,11 +1035,8 @@ static int group_step(Group& G, const sph_params* p, sph_step_stats* outs)
     // ---- parameter combinations this build does not cover are refused, never approximated ---------------
     if (c0->n_planes == 0) return c0->fail(SPH_ERR_NO_BOUNDARY, "not implemented: NoBoundaryHandler::iisph_aii");
     const bool h_from_mass_mode = p->support_length_estimation == SPH_H_FROM_MASS;
-    if (!h_from_mass_mode && G.multi())
-        return c0->fail(SPH_ERR_UNSUPPORTED, "FromDistribution support lengths on a slab decomposition are not covered yet");
     if (p->constrain_neighborhood_count && G.multi())
         return c0->fail(SPH_ERR_UNSUPPORTED, "constrain_neighborhood_count on a slab decomposition is not covered yet");
-    if (p->check_aii && G.multi()) return c0->fail(SPH_ERR_UNSUPPORTED, "check_aii on a slab decomposition is not covered yet");
     const bool level_on = p->level_estimation_method != SPH_LEVEL_NONE;
     if (level_on && G.multi() && p->level_estimation_after_advection)
         return c0->fail(SPH_ERR_UNSUPPORTED, "level_estimation_after_advection on a slab decomposition is not covered yet");
@@ -1371,7 +1380,8 @@ static int group_step(Group& G, const sph_params* p, sph_step_stats* outs)
             l.threshold = cosf(50.f * (SPH_PI_F / 180.f));
             l.max_surface_distance = p->maximum_surface_distance;
             l.boundary_is_fluid_surface = p->boundary_is_fluid_surface;
-            l.maximum_range = -1.f;   // FromDistribution* is refused on slabs
+            l.maximum_range = (p->support_length_estimation == SPH_H_FROM_DISTRIBUTION || p->support_length_estimation == SPH_H_FROM_DISTRIBUTION2)
+                                  ? p->maximum_range : -1.f;   // simulation.rs:705-721
             l.nrm = c->lvl_nrm.as<float2>();
             l.state = c->lvl_state.as<uint8_t>();
             l.flag_surface = c->flag_surface.as<uint8_t>();
@@ -1446,7 +1456,7 @@ static int group_step(Group& G, const sph_params* p, sph_step_stats* outs)
     for (auto& m : M) {
         (void)hipSetDevice(m.c->device);
         if (m.n) launch_density(m.c->stream, &m.c->prof, m.a);
-        if (p->check_neighborhood && !G.multi()) launch_check_neighborhood(m.c, m.a);
+        if (p->check_neighborhood && m.n) launch_check_neighborhood(m.c, m.a);
     }
     // ---- constrain_neighborhood_count (simulation.rs:2145-2177): h2 of over-populated particles shrinks AFTER the lists are
     // built; boundary terms (:2179), the CFL step (:2182-2191), the densities (:2204) follow with the new values
@@ -1494,7 +1504,8 @@ static int group_step(Group& G, const sph_params* p, sph_step_stats* outs)
     for (auto& m : M) {
         (void)hipSetDevice(m.c->device);
         if (m.n) launch_aii_const(m.c->stream, &m.c->prof, m.a);
-        if (m.n && p->check_aii && !G.multi()) launch_check_aii(m.c->stream, &m.c->prof, m.a);   // simulation.rs:1109-1123
+        // (slabs: the check reads the particle's own unit-pressure acceleration and the neighbours' m/rho, which the ghosts have)
+        if (m.n && p->check_aii) launch_check_aii(m.c->stream, &m.c->prof, m.a);   // simulation.rs:1109-1123
     }
     auto non_pressure = [&]() -> int {  // update_velocity_with_non_pressure_accel: velocity_temp, then mem::swap
         for (auto& m : M) {

@@ -160,6 +160,33 @@ def test_level_estimation_on_slabs(product_lib, k):
         assert rel_err(D.gather_by_id(grp, f, n), single.download(f)) <= tol, f
 
 
+@pytest.mark.parametrize("mode", ["FromDistribution", "FromDistribution2"])
+def test_support_length_from_distribution_on_slabs(product_lib, mode):
+    """h2_next and the previous step's lambda sums travel with the particles (partition, hand-over to the neighbour, cell sort);
+    check_neighborhood / check_aii run on the owned particles of every slab."""
+    scn = sc.dam_break_small(96, 48, 1 / 48)
+    pos, mass, vel = sc.init_particles(scn)
+    vel = vel.copy()
+    vel[:, 0] = 0.8
+    planes = sc.boundary_planes(scn.boundary)
+    p = forced(max_iters=4, support_length_estimation=mode, check_neighborhood=True, check_aii=True).to_ffi()
+    single = ffi.Context(product_lib, len(mass), planes)
+    single.upload(mass, pos, vel)
+    grp = D.make_loopback_group(product_lib, pos, mass, vel, planes, 3)
+    n0 = [c.n for c in grp]
+    for s in range(15):
+        st1 = single.step(p)
+        sts = ffi.group_step(grp, p)
+        assert all(abs(st.dt - st1.dt) <= 1e-5 * st1.dt for st in sts)
+    assert [c.n for c in grp] != n0
+    n = len(mass)
+    h = single.download("h2")
+    assert h.max() > h.min()                               # the estimate did move the smoothing lengths
+    for f, tol in (("h2", 1e-5), ("h2_next", 1e-5), ("position", 1e-5), ("velocity", 1e-4), ("density", 1e-5)):
+        assert rel_err(D.gather_by_id(grp, f, n), single.download(f)) <= tol, f
+    assert np.array_equal(D.gather_by_id(grp, "neighbor_count", n), single.download("neighbor_count"))
+
+
 def test_group_of_one_is_the_plain_step(product_lib):
     scn = sc.dam_break_small(32, 32, 1 / 32)
     pos, mass, vel = sc.init_particles(scn)
