@@ -49,14 +49,18 @@ hipEvent_t Profiler::get_event()
     (void)hipEventCreate(&e);
     return e;
 }
+// Scopes nest in slab mode (the partition / halo selection run the radix sort and the reorder, which open their own): only the
+// outermost scope is timed, the inner launches are part of it.
 void Profiler::begin(const char* name, hipStream_t s)
 {
+    if (depth++ > 0) return;
     cur = find(name);
     cur_a = get_event();
     (void)hipEventRecord(cur_a, s);
 }
 void Profiler::end(hipStream_t s)
 {
+    if (--depth > 0) return;
     hipEvent_t b = get_event();
     (void)hipEventRecord(b, s);
     pending.push_back(Pending{cur, cur_a, b});

@@ -37,6 +37,7 @@ struct Profiler {
     void reset();
     ~Profiler();
     int cur = -1;
+    int depth = 0;   // open scopes (only the outermost is timed)
     hipEvent_t cur_a = nullptr;
 };
 

@@ -159,6 +159,21 @@ struct HostTrace {
 };
 static HostTrace g_trace;
 
+// class counts of a 256-thread block -> at most one atomic per class per block (one per wave on the same four words cost
+// ~100 us per launch at 512k particles: 32k same-address atomics)
+__device__ __forceinline__ void block_class_counts(uint32_t cls, uint32_t* __restrict__ counts)
+{
+    __shared__ uint32_t s_cnt[4];
+    if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0u;
+    __syncthreads();
+    for (uint32_t k = 0; k < 4; k++) {
+        const uint64_t m = __ballot(cls == k);
+        if (m && (threadIdx.x & 63) == (uint32_t)(__ffsll((unsigned long long)m) - 1)) atomicAdd(&s_cnt[k], (uint32_t)__popcll(m));
+    }
+    __syncthreads();
+    if (threadIdx.x < 4 && s_cnt[threadIdx.x]) atomicAdd(&counts[threadIdx.x], s_cnt[threadIdx.x]);
+}
+
 // ------------------------------------------------------------------------------------------------
 // kernels of the slab decomposition
 // ------------------------------------------------------------------------------------------------
@@ -178,10 +193,7 @@ __global__ __launch_bounds__(256) void k_classify_migrate(uint32_t n, const floa
         key[i] = cls;
         val[i] = i;
     }
-    for (uint32_t k = 0; k < 4; k++) {
-        uint64_t m = __ballot(cls == k);
-        if (m && (threadIdx.x & 63) == (uint32_t)(__ffsll((unsigned long long)m) - 1)) atomicAdd(&counts[k], (uint32_t)__popcll(m));
-    }
+    block_class_counts(cls, counts);
 }
 
 // ---- slab re-balancing: x range and x histogram of the owned particles --------------------------------------
@@ -230,10 +242,7 @@ __global__ __launch_bounds__(256) void k_classify_halo(uint32_t n, const float4*
         key[i] = cls;
         val[i] = i;
     }
-    for (uint32_t k = 0; k < 4; k++) {
-        uint64_t m = __ballot(cls == k);
-        if (m && (threadIdx.x & 63) == (uint32_t)(__ffsll((unsigned long long)m) - 1)) atomicAdd(&counts[4 + k], (uint32_t)__popcll(m));
-    }
+    block_class_counts(cls, counts + 4);
 }
 
 // migrant record: x, y, m, h, vx, vy, id, level, level_old
@@ -329,21 +338,24 @@ __global__ __launch_bounds__(256) void k_build_maps(uint32_t n_tot, uint32_t n_o
 }
 
 // refresh one field of the ghosts: gather my halo particles' values / scatter the received ones
-__global__ __launch_bounds__(256) void k_pack_field(const uint32_t* __restrict__ src_idx, uint32_t cnt, int words, const float* __restrict__ field,
-                                                     float* __restrict__ out)
+// both sides in one launch: entries [0, cnt0) belong to the left neighbour's staging buffer, [cnt0, cnt0 + cnt1) to the right one's
+__global__ __launch_bounds__(256) void k_pack_field(const uint32_t* __restrict__ src_idx, uint32_t cnt0, uint32_t cnt1, int words,
+                                                     const float* __restrict__ field, float* __restrict__ out0, float* __restrict__ out1)
 {
     uint32_t k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= cnt) return;
+    if (k >= cnt0 + cnt1) return;
     const uint32_t i = src_idx[k];
-    for (int w = 0; w < words; w++) out[(size_t)k * words + w] = field[(size_t)i * words + w];
+    float* out = k < cnt0 ? out0 + (size_t)k * words : out1 + (size_t)(k - cnt0) * words;
+    for (int w = 0; w < words; w++) out[w] = field[(size_t)i * words + w];
 }
-__global__ __launch_bounds__(256) void k_unpack_field(const uint32_t* __restrict__ dst_idx, uint32_t cnt, int words, const float* __restrict__ in,
-                                                       float* __restrict__ field)
+__global__ __launch_bounds__(256) void k_unpack_field(const uint32_t* __restrict__ dst_idx, uint32_t cnt0, uint32_t cnt1, int words,
+                                                       const float* __restrict__ in0, const float* __restrict__ in1, float* __restrict__ field)
 {
     uint32_t k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= cnt) return;
+    if (k >= cnt0 + cnt1) return;
     const uint32_t i = dst_idx[k];
-    for (int w = 0; w < words; w++) field[(size_t)i * words + w] = in[(size_t)k * words + w];
+    const float* in = k < cnt0 ? in0 + (size_t)k * words : in1 + (size_t)(k - cnt0) * words;
+    for (int w = 0; w < words; w++) field[(size_t)i * words + w] = in[w];
 }
 
 __global__ void k_fill_u8(uint8_t* p, uint32_t n, uint8_t v)
@@ -612,12 +624,12 @@ static int refresh_ghosts(Group& G, std::vector<Member>& M, float* (*sel)(Member
         (void)hipSetDevice(c->device);
         ProfScope ps(&c->prof, "ghost_pack", c->stream);
         float* field = sel(M[i]);
+        const uint32_t nh = c->dist.n_halo[0] + c->dist.n_halo[1];
+        if (nh)
+            hipLaunchKernelGGL(k_pack_field, dim3((nh + 255) / 256), dim3(256), 0, c->stream, c->dist.halo_src.as<uint32_t>(), c->dist.n_halo[0],
+                               c->dist.n_halo[1], words, field, c->dist.send[0].as<float>(), c->dist.send[1].as<float>());
         for (int side = 0; side < 2; side++) {
             const uint32_t cnt = c->dist.n_halo[side];
-            const uint32_t off = side == 0 ? 0 : c->dist.n_halo[0];
-            if (cnt)
-                hipLaunchKernelGGL(k_pack_field, dim3((cnt + 255) / 256), dim3(256), 0, c->stream, c->dist.halo_src.as<uint32_t>() + off, cnt, words,
-                                   field, c->dist.send[side].as<float>());
             x[i].send[side] = c->dist.send[side].p;
             x[i].send_bytes[side] = (size_t)cnt * words * 4;
             x[i].recv[side] = c->dist.recv[side].p;
@@ -631,13 +643,10 @@ static int refresh_ghosts(Group& G, std::vector<Member>& M, float* (*sel)(Member
         (void)hipSetDevice(c->device);
         ProfScope ps(&c->prof, "ghost_unpack", c->stream);
         float* field = sel(M[i]);
-        for (int side = 0; side < 2; side++) {
-            const uint32_t cnt = c->dist.n_ghost[side];
-            const uint32_t off = side == 0 ? 0 : c->dist.n_ghost[0];
-            if (cnt)
-                hipLaunchKernelGGL(k_unpack_field, dim3((cnt + 255) / 256), dim3(256), 0, c->stream, c->dist.ghost_dst.as<uint32_t>() + off, cnt,
-                                   words, c->dist.recv[side].as<float>(), field);
-        }
+        const uint32_t ng = c->dist.n_ghost[0] + c->dist.n_ghost[1];
+        if (ng)
+            hipLaunchKernelGGL(k_unpack_field, dim3((ng + 255) / 256), dim3(256), 0, c->stream, c->dist.ghost_dst.as<uint32_t>(), c->dist.n_ghost[0],
+                               c->dist.n_ghost[1], words, c->dist.recv[0].as<float>(), c->dist.recv[1].as<float>(), field);
     }
     (void)what;
     return SPH_OK;

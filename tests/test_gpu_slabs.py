@@ -187,6 +187,27 @@ def test_support_length_from_distribution_on_slabs(product_lib, mode):
     assert np.array_equal(D.gather_by_id(grp, "neighbor_count", n), single.download("neighbor_count"))
 
 
+def test_profiling_a_slab_group(product_lib):
+    """The instrumented pass of bench.py on a decomposition: the slab partition opens a profiler scope around the radix sort
+    and the reorder, which open their own -- nested scopes once corrupted the profiler (hang); only the outermost is timed."""
+    scn = sc.dam_break_small(96, 48, 1 / 48)
+    pos, mass, vel = sc.init_particles(scn)
+    planes = sc.boundary_planes(scn.boundary)
+    p = forced(max_iters=4).to_ffi()
+    grp = D.make_loopback_group(product_lib, pos, mass, vel, planes, 2)
+    for c in grp:
+        c.profile_reset()
+        c.profile_enable(1)
+    for _ in range(6):
+        ffi.group_step(grp, p)
+    for c in grp:
+        prof = c.profile_get()
+        assert prof["slab_partition"][0] == 6 and prof["jacobi_update"][0] >= 12 and "ghost_pack" in prof
+        assert all(ms >= 0 for _, ms in prof.values())
+        c.profile_enable(0)
+    ffi.group_step(grp, p)
+
+
 def test_group_of_one_is_the_plain_step(product_lib):
     scn = sc.dam_break_small(32, 32, 1 / 32)
     pos, mass, vel = sc.init_particles(scn)
