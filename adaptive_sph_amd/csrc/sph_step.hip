@@ -730,7 +730,7 @@ static int partition_and_migrate(Group& G, std::vector<Member>& M, std::vector<i
         }
         hipLaunchKernelGGL(k_copy_counts, dim3(1), dim3(64), 0, c->stream, d.counts.as<uint32_t>(), d.counts_host_dev);
     }
-    if ((rc = agree(G, wait_all(G)))) return rc;
+    if ((rc = wait_all(G))) return rc;   // (a device failure here is fatal for the whole job; logical errors are agreed on below)
     // (2) migrants: counts -> neighbours, then the records
     std::vector<uint32_t> tl(nm), tr(nm), fl(nm), fr(nm);
     for (size_t i = 0; i < nm; i++) {
@@ -1067,7 +1067,8 @@ static int group_step(Group& G, const sph_params* p, sph_step_stats* outs)
     // ---- step header over the OWNED particles: h from mass (simulation.rs:1998-2003), CFL term, h_max ------
     // (multi-rank: ghosts of the previous step are still interleaved -> partition first, inside decompose();
     //  for that the header has to run on the partitioned arrays, so decompose() is split around it)
-    std::vector<std::vector<float>> red(M.size(), std::vector<float>(3));
+    std::vector<std::vector<float>> red(M.size(), std::vector<float>(4));
+    int hdr_rc = SPH_OK, setup_rc = SPH_OK;
     if (G.multi()) {
         bool rebalanced = false;
         const int every = c0->dist.rebalance_every;
@@ -1093,7 +1094,8 @@ static int group_step(Group& G, const sph_params* p, sph_step_stats* outs)
             (void)hipSetDevice(m.c->device);
             launch_header(m.c, (uint32_t)m.c->n, p->rest_density, h_from_mass_mode ? 1 : 2, m.c->hdr_host_dev);
         }
-        if ((rc = agree(G, wait_all(G)))) return rc;
+        hdr_rc = wait_all(G);
+        if (hdr_rc && !G.multi()) return hdr_rc;
     }
     c0->hdr_ahead = false;
     for (size_t i = 0; i < M.size(); i++) {
@@ -1101,8 +1103,12 @@ static int group_step(Group& G, const sph_params* p, sph_step_stats* outs)
         red[i][0] = M[i].c->n ? -h.h_max : 0.f;
         red[i][1] = M[i].c->n ? h.h_min : INFINITY;
         red[i][2] = M[i].c->n ? h.min_cfl : INFINITY;
+        red[i][3] = -(float)hdr_rc;   // the agreement on this wait point rides in the same all-reduce (min of -status)
     }
     if (G.multi() && (rc = G.comm->allreduce_min_f32(G, red))) return rc;
+    if (hdr_rc) return hdr_rc;
+    if (red[0][3] < 0.f)
+        return c0->fail((int)-red[0][3], "another rank of the slab decomposition reported status %d", (int)-red[0][3]);
     const float h_max_g = -red[0][0], h_min_g = red[0][1], min_cfl_g = red[0][2];
     if (!(h_max_g > 0.f) || !std::isfinite(h_max_g))
         return agree(G, c0->fail(SPH_ERR_POSITION_NOT_FINITE, "particle positions or smoothing lengths are not finite"));
@@ -1120,11 +1126,11 @@ static int group_step(Group& G, const sph_params* p, sph_step_stats* outs)
             (void)hipSetDevice(m.c->device);
             launch_header(m.c, m.n, p->rest_density, 0, m.c->hdr_host_dev);   // h is set; only the bounding box changed
         }
-        if ((rc = agree(G, wait_all(G)))) return rc;
+        setup_rc = wait_all(G);   // agreed on below, together with the per-rank grid checks
     }
     g_trace.mark(1);
 
-    for (auto& m : M) {
+    auto setup_member = [&](Member& m) -> int {
         sph_ctx* c = m.c;
         (void)hipSetDevice(c->device);
         const HeaderOut hdr = *c->hdr_host;
@@ -1153,7 +1159,7 @@ static int group_step(Group& G, const sph_params* p, sph_step_stats* outs)
             return true;
         };
         if (n && (!std::isfinite(hdr.min_x) || !std::isfinite(hdr.max_x) || !std::isfinite(hdr.min_y) || !std::isfinite(hdr.max_y)))
-            return agree(G, c->fail(SPH_ERR_POSITION_NOT_FINITE, "particle positions are not finite"));
+            return c->fail(SPH_ERR_POSITION_NOT_FINITE, "particle positions are not finite");
         GridP g{};
         const bool coarse_ok = make_grid(h_max_g * 2.f, g);
         // (constrain_neighborhood_count changes individual smoothing lengths after the lists are built)
@@ -1185,7 +1191,7 @@ static int group_step(Group& G, const sph_params* p, sph_step_stats* outs)
             }
         }
         if (!coarse_ok)
-            return agree(G, c->fail(SPH_ERR_UNSUPPORTED, "cell grid of cell size %g is too large for this build", (double)g.cs));
+            return c->fail(SPH_ERR_UNSUPPORTED, "cell grid of cell size %g is too large for this build", (double)g.cs);
         c->grid = g;
         c->fgrid = fg;
         c->grid_valid = true;
@@ -1258,7 +1264,11 @@ static int group_step(Group& G, const sph_params* p, sph_step_stats* outs)
         m.a.sp_check_aii = p->check_aii;
         m.st.n_particles = c->n;
         m.st.dt = dt;
-    }
+        return SPH_OK;
+    };
+    for (auto& m : M)
+        if (!setup_rc) setup_rc = setup_member(m);
+    if ((rc = agree(G, setup_rc))) return rc;   // bounding-box wait + grid checks of every rank
     g_trace.mark(2);
 
     // ---- level estimation on the extended-range lists (simulation.rs:2018-2046, 862-927; after advection: 2678-2707) ------
@@ -1713,7 +1723,8 @@ extern "C" int sph_group_step(sph_ctx** ctxs, int n, const sph_params* p, sph_st
 extern "C" int sph_dist_configure(sph_ctx* c, int rank, int n_ranks, float cut_lo, float cut_hi)
 {
     if (!c || rank < 0 || n_ranks < 1 || rank >= n_ranks) return SPH_ERR_INVALID_ARGUMENT;
-    c->dist.on = n_ranks > 1;
+    // SPH_FORCE_SLAB_MODE=1: run the slab driver and the RCCL collectives with ONE rank (a single-GPU check of that code path)
+    c->dist.on = n_ranks > 1 || (getenv("SPH_FORCE_SLAB_MODE") != nullptr);
     c->dist.rank = rank;
     c->dist.nranks = n_ranks;
     c->dist.cut_lo = cut_lo;
@@ -1757,7 +1768,7 @@ extern "C" int sph_comm_unique_id(uint8_t id_out[128])
 extern "C" int sph_comm_init(sph_ctx* c, const uint8_t id[128], int rank, int n_ranks)
 {
     if (!c || !id || rank < 0 || n_ranks < 1 || rank >= n_ranks) return SPH_ERR_INVALID_ARGUMENT;
-    if (n_ranks == 1) return SPH_OK;
+    if (n_ranks == 1 && !c->dist.on) return SPH_OK;
     if (!c->dist.on || c->dist.rank != rank || c->dist.nranks != n_ranks)
         return c->fail(SPH_ERR_INVALID_ARGUMENT, "call sph_dist_configure(rank, n_ranks, cuts) before sph_comm_init");
     HIPCHK(c, hipSetDevice(c->device));

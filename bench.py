@@ -123,6 +123,21 @@ def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # RCCL prints a version banner to stdout when a communicator is created (torch's and the library's): keep stdout for the ONE
+    # JSON line -- everything else that writes to fd 1 goes to stderr until the line is printed
+    real_stdout = os.dup(1)
+    sys.stdout.flush()
+    os.dup2(2, 1)
+
+    def emit(line):
+        import ctypes
+        sys.stdout.flush()
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:  # noqa: BLE001
+            pass
+        os.write(real_stdout, (line + "\n").encode())
+
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
@@ -293,7 +308,7 @@ def main():
         ]
     if not args.no_cpu_baseline and not distributed:
         out["cpu_baseline"] = cpu_baseline(scene, params, args.cpu_seconds)
-    print(json.dumps(out))
+    emit(json.dumps(out))
     if distributed:
         dist.barrier()
         dist.destroy_process_group()

@@ -224,6 +224,34 @@ def test_group_of_one_is_the_plain_step(product_lib):
         assert np.array_equal(a.download(f), b.download(f)), f
 
 
+def test_rccl_collectives_with_one_rank(product_lib, monkeypatch):
+    """SPH_FORCE_SLAB_MODE: the slab driver with the RCCL transport on a communicator of ONE rank -- every ncclAllReduce of the
+    step (CFL minimum, error agreement, Jacobi totals) and the empty send/recv groups really run through RCCL; only the
+    neighbour exchange needs a second GPU.  Same trajectory as the plain context."""
+    import ctypes as C
+    scn = sc.dam_break_small(64, 48, 1 / 48)
+    pos, mass, vel = sc.init_particles(scn)
+    planes = sc.boundary_planes(scn.boundary)
+    p = forced(max_iters=4).to_ffi()
+    plain = ffi.Context(product_lib, len(mass), planes)
+    plain.upload(mass, pos, vel)
+    monkeypatch.setenv("SPH_FORCE_SLAB_MODE", "1")
+    raw = (C.c_uint8 * 128)()
+    assert product_lib.comm_unique_id(raw) == 0
+    c = ffi.Context(product_lib, len(mass) + 1024, planes)
+    c.dist_configure(0, 1, -D.INF, D.INF)
+    c.comm_init(bytes(raw), 0, 1)
+    monkeypatch.delenv("SPH_FORCE_SLAB_MODE")
+    c.upload(mass, pos, vel)
+    c.upload_field("particle_id", np.arange(len(mass), dtype=np.uint32))
+    for _ in range(10):
+        s0, s1 = plain.step(p), c.step(p)
+        assert s0.dt == s1.dt and s0.div_solver.iters == s1.div_solver.iters
+    assert c.n == len(mass)
+    for f, tol in (("position", 1e-6), ("velocity", 1e-5), ("density", 1e-6)):
+        assert rel_err(D.gather_by_id([c], f, len(mass)), plain.download(f)) <= tol, f
+
+
 def test_rccl_single_rank_roundtrip(product_lib):
     """world_size 1 through the RCCL entry points (more ranks need more GPUs than this box has)."""
     import ctypes as C
