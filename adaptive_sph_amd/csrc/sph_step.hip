@@ -171,7 +171,9 @@ __device__ __forceinline__ void block_class_counts(uint32_t cls, uint32_t* __res
         if (m && (threadIdx.x & 63) == (uint32_t)(__ffsll((unsigned long long)m) - 1)) atomicAdd(&s_cnt[k], (uint32_t)__popcll(m));
     }
     __syncthreads();
-    if (threadIdx.x < 4 && s_cnt[threadIdx.x]) atomicAdd(&counts[threadIdx.x], s_cnt[threadIdx.x]);
+    // class 0 (stay / no halo) is nearly everybody: 4096 adds on ONE word cost ~40 us.  It is not counted -- the host derives it
+    // from the total (classes 1..3 are the few particles near a cut)
+    if (threadIdx.x >= 1 && threadIdx.x < 4 && s_cnt[threadIdx.x]) atomicAdd(&counts[threadIdx.x], s_cnt[threadIdx.x]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -696,6 +698,7 @@ static int partition_and_migrate(Group& G, std::vector<Member>& M, std::vector<i
 {
     const size_t nm = M.size();
     int rc = SPH_OK;
+    std::vector<uint32_t> n_prev_of;
     // (1) classify the previous arrays: stay / migrate left / migrate right / drop (ghost); stable partition by a
     //     1-pass radix sort on the 2-bit class (reuses the neighbour-build sort: deterministic order)
     for (auto& m : M) {
@@ -704,6 +707,7 @@ static int partition_and_migrate(Group& G, std::vector<Member>& M, std::vector<i
         (void)hipSetDevice(c->device);
         if ((rc = ensure_dist_buffers(c, m.n))) return rc;
         const uint32_t n_prev = d.have_flags ? d.n_tot : (uint32_t)c->n;
+        n_prev_of.push_back(n_prev);
         (void)hipMemsetAsync(d.counts.p, 0, 64, c->stream);
         if (n_prev) {
             ProfScope ps(&c->prof, "slab_partition", c->stream);
@@ -734,8 +738,11 @@ static int partition_and_migrate(Group& G, std::vector<Member>& M, std::vector<i
     // (2) migrants: counts -> neighbours, then the records
     std::vector<uint32_t> tl(nm), tr(nm), fl(nm), fr(nm);
     for (size_t i = 0; i < nm; i++) {
-        tl[i] = M[i].c->dist.counts_host[1];
-        tr[i] = M[i].c->dist.counts_host[2];
+        auto& d = M[i].c->dist;
+        tl[i] = d.counts_host[1];
+        tr[i] = d.counts_host[2];
+        // class 0 = everybody else (see block_class_counts); class 3 = ghosts of the previous step, dropped
+        d.counts_host[0] = n_prev_of[i] - d.counts_host[1] - d.counts_host[2] - d.counts_host[3];
     }
     if (moved)
         for (size_t i = 0; i < nm; i++) (*moved)[i] = (int)(tl[i] + tr[i]);
@@ -904,6 +911,7 @@ static int build_ghost_layer(Group& G, std::vector<Member>& M, float halo_width)
         if (d.counts_host[4 + 3]) rc = M[i].c->fail(SPH_ERR_UNSUPPORTED, "slab of rank %d is narrower than two support radii", d.rank);
         tl[i] = d.counts_host[4 + 1];
         tr[i] = d.counts_host[4 + 2];
+        d.counts_host[4 + 0] = (uint32_t)M[i].c->n - tl[i] - tr[i] - d.counts_host[4 + 3];   // class 0 is not counted on the device
     }
     if ((rc = agree(G, rc))) return rc;
     if ((rc = G.comm->neighbour_counts(G, tl, tr, fl, fr))) return rc;
