@@ -494,10 +494,17 @@ struct RcclComm : Comm {
     {
         ncclComm_t nc = (ncclComm_t)c->dist.nccl;
         void* d = c->dist.counts.as<uint32_t>() + 16;  // scratch area behind the counters
-        HIPCHK(c, hipMemcpyAsync(d, host, bytes, hipMemcpyHostToDevice, c->stream));
+        // staged through pinned memory: copies from / to pageable vectors are synchronous and several times slower
+        uint8_t* stage = (uint8_t*)c->dist.counts_host + 64;
+        if (bytes > 128) return c->fail(SPH_ERR_INVALID_ARGUMENT, "host all-reduce of %zu bytes", bytes);
+        memcpy(stage, host, bytes);
+        HIPCHK(c, hipMemcpyAsync(d, stage, bytes, hipMemcpyHostToDevice, c->stream));
         NCCLCHK(c, ncclAllReduce(d, d, count, dt, op, nc, c->stream));
-        HIPCHK(c, hipMemcpyAsync(host, d, bytes, hipMemcpyDeviceToHost, c->stream));
-        return wait_stream(c);
+        HIPCHK(c, hipMemcpyAsync(stage, d, bytes, hipMemcpyDeviceToHost, c->stream));
+        int rc = wait_stream(c);
+        if (rc) return rc;
+        memcpy(host, stage, bytes);
+        return SPH_OK;
     }
     int allreduce_min_f32(Group& G, std::vector<std::vector<float>>& rows) override
     {
@@ -524,7 +531,10 @@ struct RcclComm : Comm {
         ncclComm_t nc = (ncclComm_t)c->dist.nccl;
         const int r = c->dist.rank, nr = c->dist.nranks;
         uint32_t* d = c->dist.counts.as<uint32_t>() + 16;  // [0]=to_left [1]=to_right [2]=from_left [3]=from_right
-        uint32_t h[4] = {tl[0], tr[0], 0, 0};
+        uint32_t* h = (uint32_t*)((uint8_t*)c->dist.counts_host + 64);   // pinned staging
+        h[0] = tl[0];
+        h[1] = tr[0];
+        h[2] = h[3] = 0;
         HIPCHK(c, hipMemcpyAsync(d, h, 16, hipMemcpyHostToDevice, c->stream));
         NCCLCHK(c, ncclGroupStart());
         if (r > 0) {
@@ -681,7 +691,7 @@ static int ensure_dist_buffers(sph_ctx* c, uint32_t n)
     HIPCHK(c, d.counts.ensure(256));
     HIPCHK(c, d.solver_tot.ensure(64));
     if (!d.counts_host) {
-        HIPCHK(c, hipHostMalloc((void**)&d.counts_host, 64, hipHostMallocMapped));
+        HIPCHK(c, hipHostMalloc((void**)&d.counts_host, 256, hipHostMallocMapped));   // 64 B of counters + 192 B of staging
         HIPCHK(c, hipHostGetDevicePointer((void**)&d.counts_host_dev, d.counts_host, 0));
     }
     return SPH_OK;
