@@ -76,6 +76,7 @@ struct sph_ctx {
         bool have_flags = false;     // `owned` describes the current arrays (after a step)
         uint32_t n_halo[2] = {0, 0}, n_ghost[2] = {0, 0};   // [left, right]
         DevBuf owned;                // u8 per slot: 1 owned, 0 ghost
+        DevBuf ring1, ring1_src;     // u8 per slot / per ghost ordinal: ghost within one support radius of the cut
         DevBuf halo_idx, halo_pos, halo_src, ghost_dst;      // index lists / maps (u32)
         DevBuf send[2], recv[2];     // staging, [left, right]
         DevBuf counts;               // device counters

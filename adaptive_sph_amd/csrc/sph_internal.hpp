@@ -141,6 +141,7 @@ struct SweepArgs {
     TileP t_ext;        // the same bound over a wider tile neighbourhood, for the extended-range lists
     float* partials;    // per-block solver statistics
     const uint8_t* owned;  // slab decomposition: 1 owned, 0 ghost (nullptr: everything is owned)
+    const uint8_t* ring1;  // slab decomposition: 1 = ghost within one support radius of the cut (runs the RING1 ops)
     double* solver_tot; // multi-rank: all-reduced solver totals
     float* mrho;        // m / rho
     float* pt0;         // p / rho^2 for pressure buffer 0 / 1

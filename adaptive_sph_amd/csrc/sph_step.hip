@@ -76,6 +76,7 @@ SweepArgs make_args(sph_ctx* c, const StepP& sp)
     a.ctrl = c->ctrl.as<SolverCtrl>();
     a.status = c->status.as<DeviceStatus>();
     a.owned = c->dist.on ? c->dist.owned.as<uint8_t>() : nullptr;
+    a.ring1 = c->dist.on ? c->dist.ring1.as<uint8_t>() : nullptr;
     a.solver_tot = c->dist.solver_tot.as<double>();
     return a;
 }
@@ -302,12 +303,15 @@ __global__ __launch_bounds__(256) void k_pack_ghosts(const uint32_t* __restrict_
 }
 __global__ __launch_bounds__(256) void k_unpack_ghosts(uint32_t base, uint32_t cnt, const float* __restrict__ rec, float4* __restrict__ pm,
                                                         float2* __restrict__ vel, uint32_t* __restrict__ orig, float* __restrict__ lvl,
-                                                        float* __restrict__ lvlold)
+                                                        float* __restrict__ lvlold, uint8_t* __restrict__ ring1_src, uint32_t ord_base, float ring_edge,
+                                                        int side)
 {
     uint32_t k = blockIdx.x * 256 + threadIdx.x;
     if (k >= cnt) return;
     const uint32_t i = base + k;
     const float* r = rec + (size_t)k * GHOST_WORDS;
+    // first ring = within one support radius of the cut: its pressure acceleration is computed here, not fetched
+    ring1_src[ord_base + k] = (side == 0 ? r[0] >= ring_edge : r[0] < ring_edge) ? 1 : 0;
     pm[i] = make_float4(r[0], r[1], r[2], r[3]);
     vel[i] = make_float2(r[4], r[5]);
     orig[i] = 0xffffffffu;
@@ -324,13 +328,15 @@ __global__ __launch_bounds__(256) void k_halo_pos(const uint32_t* __restrict__ h
 // after the cell sort: where did my halo particles and my ghosts end up?  perm[s] = pre-sort index of slot s
 __global__ __launch_bounds__(256) void k_build_maps(uint32_t n_tot, uint32_t n_own, const uint32_t* __restrict__ perm,
                                                      const uint32_t* __restrict__ halo_pos, uint32_t* __restrict__ halo_src,
-                                                     uint32_t* __restrict__ ghost_dst, uint8_t* __restrict__ owned)
+                                                     uint32_t* __restrict__ ghost_dst, uint8_t* __restrict__ owned, const uint8_t* __restrict__ ring1_src,
+                                                     uint8_t* __restrict__ ring1)
 {
     uint32_t s = blockIdx.x * 256 + threadIdx.x;
     if (s >= n_tot) return;
     const uint32_t old = perm[s];
     const bool own = old < n_own;
     owned[s] = own ? 1 : 0;
+    ring1[s] = own ? 0 : ring1_src[old - n_own];
     if (own) {
         const uint32_t k = halo_pos[old];
         if (k != 0xffffffffu) halo_src[k] = s;
@@ -667,7 +673,6 @@ static int refresh_ghosts(Group& G, std::vector<Member>& M, float* (*sel)(Member
 static float* sel_rho(Member& m) { return m.a.rho; }
 static float* sel_mrho(Member& m) { return m.a.mrho; }
 static float* sel_vel(Member& m) { return (float*)m.a.vel; }
-static float* sel_pacc(Member& m) { return (float*)m.a.pacc; }
 static float* sel_pt0(Member& m) { return m.a.pt0; }
 static float* sel_pt1(Member& m) { return m.a.pt1; }
 static float* sel_lv_level(Member& m) { return m.lv_level; }
@@ -680,6 +685,8 @@ static int ensure_dist_buffers(sph_ctx* c, uint32_t n)
     const size_t cap = c->cap ? c->cap : 1;
     (void)n;
     HIPCHK(c, d.owned.ensure(cap));
+    HIPCHK(c, d.ring1.ensure(cap));
+    HIPCHK(c, d.ring1_src.ensure(cap));
     HIPCHK(c, d.halo_idx.ensure(cap * 4));
     HIPCHK(c, d.halo_pos.ensure(cap * 4));
     HIPCHK(c, d.halo_src.ensure(cap * 4));
@@ -888,7 +895,7 @@ static int rebalance_cuts(Group& G, std::vector<Member>& M, bool* applied)
 
 // part 2: ghost layer -- owned particles within halo_width of a cut are copied to that neighbour, in array
 // order (stable partition again)
-static int build_ghost_layer(Group& G, std::vector<Member>& M, float halo_width)
+static int build_ghost_layer(Group& G, std::vector<Member>& M, float halo_width, float ring1_width)
 {
     const size_t nm = M.size();
     int rc = SPH_OK;
@@ -918,7 +925,7 @@ static int build_ghost_layer(Group& G, std::vector<Member>& M, float halo_width)
     rc = wait_all(G);
     for (size_t i = 0; i < nm && !rc; i++) {
         auto& d = M[i].c->dist;
-        if (d.counts_host[4 + 3]) rc = M[i].c->fail(SPH_ERR_UNSUPPORTED, "slab of rank %d is narrower than two support radii", d.rank);
+        if (d.counts_host[4 + 3]) rc = M[i].c->fail(SPH_ERR_UNSUPPORTED, "slab of rank %d is narrower than two ghost layers", d.rank);
         tl[i] = d.counts_host[4 + 1];
         tr[i] = d.counts_host[4 + 2];
         d.counts_host[4 + 0] = (uint32_t)M[i].c->n - tl[i] - tr[i] - d.counts_host[4 + 3];   // class 0 is not counted on the device
@@ -965,7 +972,8 @@ static int build_ghost_layer(Group& G, std::vector<Member>& M, float halo_width)
             if (d.n_ghost[side])
                 hipLaunchKernelGGL(k_unpack_ghosts, dim3((d.n_ghost[side] + 255) / 256), dim3(256), 0, c->stream, base[side], d.n_ghost[side],
                                    d.recv[side].as<float>(), c->pm[c->pcur].as<float4>(), c->vel[k].as<float2>(), c->orig[k].as<uint32_t>(),
-                                   c->lvl[k].as<float>(), c->lvlold[k].as<float>());
+                                   c->lvl[k].as<float>(), c->lvlold[k].as<float>(), d.ring1_src.as<uint8_t>(), side == 0 ? 0u : d.n_ghost[0],
+                                   side == 0 ? d.cut_lo - ring1_width : d.cut_hi + ring1_width, side);
         d.n_tot = n + d.n_ghost[0] + d.n_ghost[1];
         M[i].n = d.n_tot;
         // pre-sort index -> position in my halo list
@@ -1013,7 +1021,7 @@ static int pressure_iterations(Group& G, std::vector<Member>& M, float max_avg_e
                 (void)hipSetDevice(m.c->device);
                 if (m.n) launch_pressure_accel(m.c->stream, &m.c->prof, m.a, (int)k, 0, nullptr);
             }
-            if ((rc = refresh_ghosts(G, M, sel_pacc, 2, "pacc"))) return rc;
+            // (no exchange of a^p: the first ghost ring computed its own in the sweep above)
             for (auto& m : M) {
                 (void)hipSetDevice(m.c->device);
                 if (m.n) launch_jacobi_update(m.c->stream, &m.c->prof, m.a, (int)k, residual_density);
@@ -1137,8 +1145,10 @@ static int group_step(Group& G, const sph_params* p, sph_step_stats* outs)
     if (G.multi()) {
         // ghost layer with the real width: one support radius of the largest particle anywhere
         // (the extended lists of the level estimation reach level_estimation_range / ETA smoothing lengths)
-        const float halo_k = level_on ? fmaxf(2.f, p->level_estimation_range / SPH_ETA) : 2.f;
-        if ((rc = build_ghost_layer(G, M, h_max_g * halo_k))) return rc;
+        // Two rings of one support radius (2 h_max) each: ghosts of the first ring compute their pressure acceleration here
+        // (their neighbours are all inside the second), so a Jacobi iteration exchanges p / rho^2 only.
+        const float halo_k = fmaxf(4.f, level_on ? p->level_estimation_range / SPH_ETA : 0.f);
+        if ((rc = build_ghost_layer(G, M, h_max_g * halo_k, h_max_g * 2.f))) return rc;
         // bounding box of owned + ghosts
         for (auto& m : M) {
             (void)hipSetDevice(m.c->device);
@@ -1273,7 +1283,8 @@ static int group_step(Group& G, const sph_params* p, sph_step_stats* outs)
             auto& d = c->dist;
             if (n)
                 hipLaunchKernelGGL(k_build_maps, dim3((n + 255) / 256), dim3(256), 0, s, n, (uint32_t)c->n, c->val[0].as<uint32_t>(),
-                                   d.halo_pos.as<uint32_t>(), d.halo_src.as<uint32_t>(), d.ghost_dst.as<uint32_t>(), d.owned.as<uint8_t>());
+                                   d.halo_pos.as<uint32_t>(), d.halo_src.as<uint32_t>(), d.ghost_dst.as<uint32_t>(), d.owned.as<uint8_t>(),
+                                   d.ring1_src.as<uint8_t>(), d.ring1.as<uint8_t>());
             d.have_flags = true;
         }
         if (tev) (void)hipEventRecord(c->ev[1], s);
@@ -1803,7 +1814,7 @@ void dist_release(sph_ctx* c)
     auto& d = c->dist;
     if (d.nccl) ncclCommDestroy((ncclComm_t)d.nccl);
     d.nccl = nullptr;
-    DevBuf* all[] = {&d.owned, &d.halo_idx, &d.halo_pos, &d.halo_src, &d.ghost_dst, &d.send[0], &d.send[1], &d.recv[0], &d.recv[1], &d.counts, &d.solver_tot, &d.hist};
+    DevBuf* all[] = {&d.owned, &d.ring1, &d.ring1_src, &d.halo_idx, &d.halo_pos, &d.halo_src, &d.ghost_dst, &d.send[0], &d.send[1], &d.recv[0], &d.recv[1], &d.counts, &d.solver_tot, &d.hist};
     for (auto b : all) b->release();
     if (d.counts_host) (void)hipHostFree(d.counts_host);
     d.counts_host = nullptr;

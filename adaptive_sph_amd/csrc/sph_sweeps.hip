@@ -67,6 +67,7 @@ struct SweepCommon {
     uint4* __restrict__ nl;    // neighbour list words
     uint4* __restrict__ nlx;   // explicit index lists (nullptr in uniform scenes)
     const uint8_t* __restrict__ owned;  // slab decomposition: ghost lanes idle (their values come from their owner)
+    const uint8_t* __restrict__ ring1;  // ... except, in RING1 ops, the ghosts within one support radius of the cut
 };
 
 __device__ __forceinline__ void raise_error(DeviceStatus* st, uint32_t code, uint32_t info)
@@ -232,6 +233,14 @@ struct OpCellPos<Op, std::void_t<decltype(&Op::cell_pos)>> {
     static __device__ __forceinline__ float2 get(const Op& op, uint32_t i, const float4& Ai) { return op.cell_pos(i, Ai); }
 };
 
+// Ops with `static constexpr bool RING1 = true` (density BUILD, pressure acceleration) also run on the FIRST ghost ring of a
+// slab: those ghosts then carry a neighbour list and a locally computed a^p, and the Jacobi iteration needs ONE neighbour
+// exchange (p / rho^2) instead of two (+ a^p).
+template <class Op, class = void>
+struct OpRing1 : std::false_type {};
+template <class Op>
+struct OpRing1<Op, std::void_t<decltype(Op::RING1)>> : std::bool_constant<Op::RING1> {};
+
 template <class Op, bool BUILD>
 __global__ __launch_bounds__(SWEEP_THREADS) void k_sweep(Op op, SweepCommon c)
 {
@@ -244,7 +253,9 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_sweep(Op op, SweepCommon c)
     const uint32_t blk = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
     if (blk >= c.nblocks) return;
     const uint32_t i = blk * SWEEP_THREADS + threadIdx.x;
-    const bool active = i < c.n && (!c.owned || c.owned[i < c.n ? i : 0]) && !op.lane_skip(i);
+    const uint32_t ic = i < c.n ? i : 0;
+    const bool mine = !c.owned || c.owned[ic] || (OpRing1<Op>::value && c.ring1 && c.ring1[ic]);
+    const bool active = i < c.n && mine && !op.lane_skip(i);
     const GridP g = c.g;
     typename Op::Acc acc;
     op.init(acc);  // lane-independent state
@@ -348,7 +359,7 @@ template <class MathT, bool HDIST>
 struct OpDensity {
     typedef MathT Math;
     static constexpr bool HAS_EPILOGUE = false, SKIP_SELF = false;
-    static constexpr bool EXTENDED = false;
+    static constexpr bool EXTENDED = false, RING1 = true;
     __device__ constexpr float krange() const { return 2.f; }
     typedef NBNone NB;
     MathT m;
@@ -369,6 +380,7 @@ struct OpDensity {
     int h_mode;
     float* __restrict__ h2_next;
     const float* __restrict__ lam_prev;   // lambda_sum(i) of the PREVIOUS step (update_after_advect runs later in the step)
+    const uint8_t* __restrict__ owned_flag;   // slab decomposition (else nullptr): ring-1 ghost lanes record their list, nothing more
     struct Acc {
         float sum, lam, wsum, vwsum;
         uint32_t cnt;
@@ -450,7 +462,7 @@ struct OpDensity {
         if (!isfinite(d)) raise_error(status, SPH_ERR_DENSITY_NOT_FINITE, orig[i]);
         else if (!(d > 0.0001f)) raise_error(status, SPH_ERR_DENSITY_TOO_SMALL, orig[i]);
         if (a.cnt > 20000u) raise_error(status, SPH_ERR_TOO_MANY_NEIGHBORS, orig[i]);
-        if (HDIST) {
+        if (HDIST && (!owned_flag || owned_flag[i])) {
             const float bv = lam_prev[i];
             float vol;
             if (h_mode == SPH_H_FROM_DISTRIBUTION2) vol = (Ai.z / sp.rest_density) / (a.vwsum + bv);
@@ -855,7 +867,7 @@ template <class MathT>
 struct OpPressureAccel {
     typedef MathT Math;
     static constexpr bool HAS_EPILOGUE = true, SKIP_SELF = true;   // epilogue: next step's header (integrating tails only)
-    static constexpr bool EXTENDED = false;
+    static constexpr bool EXTENDED = false, RING1 = true;
     __device__ constexpr float krange() const { return 2.f; }
     typedef float NB;  // p_j / (rho_j * rho_j)
     MathT m;
@@ -879,6 +891,7 @@ struct OpPressureAccel {
     // header (bounding box, h and mass range, CFL term -- what k_header computes) per block, so the next step starts
     // without the header kernels and without the host wait behind them.  nullptr: not wanted.
     HeaderOut* __restrict__ hdr_partials;
+    const uint8_t* __restrict__ owned_flag;   // slab decomposition (else nullptr): ring-1 ghost lanes compute a^p, no tail
     struct Acc {
         float ax, ay, p1t;
         const float* pt;
@@ -935,17 +948,21 @@ struct OpPressureAccel {
     __device__ bool finish(Acc& a, uint32_t i, float4 Ai, bool wall) const
     {
         float bx = 0.f, by = 0.f;
+        const bool own = !owned_flag || owned_flag[i];
         if (sp.n_planes && wall) {
-            const float p_i = a.p[i], rho_i = rho[i], rho_b = sp.rest_density;
+            const float rho_i = rho[i], rho_b = sp.rest_density;
+            // a ghost has p / rho^2 (refreshed from its owner every iteration), not p
+            const float pr2 = own ? a.p[i] / (rho_i * rho_i) : a.p1t;
+            const float p_i = own ? a.p[i] : a.p1t * (rho_i * rho_i);
             const float p_ib = sp.opdisc == SPH_OP_SYMMETRIC_GRADIENT ? p_i : 0.f;
-            const float f = -rho_b * (p_i / (rho_i * rho_i) + p_ib / (rho_b * rho_b));
+            const float f = -rho_b * (pr2 + p_ib / (rho_b * rho_b));
             const float2 gl = lam_grad[i];
             bx = f * gl.x;
             by = f * gl.y;
         }
         const float2 ap = make_float2(a.ax + bx, a.ay + by);
         pacc[i] = ap;
-        if (tail != TAIL_NONE) {
+        if (tail != TAIL_NONE && own) {
             const float dt = sp.dt;
             float2 v = vel[i];
             float4 p = Ai;   // integrated position (tails VX / HYBRID)
@@ -1884,7 +1901,7 @@ __global__ __launch_bounds__(256) void k_integrate(uint32_t n, float dt, float v
 // ------------------------------------------------------------------------------------------------
 static SweepCommon common_of(const SweepArgs& a, bool ext)
 {
-    return SweepCommon{a.g, ext ? a.t_ext : a.t, a.n, (a.n + SWEEP_THREADS - 1) / SWEEP_THREADS, a.cell_start, ext ? a.nl_ext : a.nl, ext ? a.nlx_ext : a.nlx, a.owned};
+    return SweepCommon{a.g, ext ? a.t_ext : a.t, a.n, (a.n + SWEEP_THREADS - 1) / SWEEP_THREADS, a.cell_start, ext ? a.nl_ext : a.nl, ext ? a.nlx_ext : a.nlx, a.owned, a.ring1};
 }
 
 template <class Op, bool BUILD>
@@ -1932,11 +1949,11 @@ void launch_density(hipStream_t s, Profiler* prof, const SweepArgs& a)
     ProfScope ps(prof, "density", s);
     if (a.h_mode != SPH_H_FROM_MASS) {
         SPH_DISPATCH(OpDensityDist, true, a.pm, a.orig, a.rho, a.mrho, a.lam_sum, a.lam_grad, a.ncount, a.planes, a.lam_lut, a.dlam_lut, a.status, a.sp,
-                     a.h_mode, a.h2_next, a.lam_prev)
+                     a.h_mode, a.h2_next, a.lam_prev, a.owned)
         return;
     }
     SPH_DISPATCH(OpDensityMass, true, a.pm, a.orig, a.rho, a.mrho, a.lam_sum, a.lam_grad, a.ncount, a.planes, a.lam_lut, a.dlam_lut, a.status, a.sp,
-                 a.h_mode, a.h2_next, a.lam_prev)
+                 a.h_mode, a.h2_next, a.lam_prev, a.owned)
 }
 
 // the density sweep again, over the recorded lists (after constrain_neighborhood_count changed the smoothing lengths)
@@ -1944,7 +1961,7 @@ void launch_density_replay(hipStream_t s, Profiler* prof, const SweepArgs& a)
 {
     ProfScope ps(prof, "density_replay", s);
     SPH_DISPATCH(OpDensityMass, false, a.pm, a.orig, a.rho, a.mrho, a.lam_sum, a.lam_grad, a.ncount, a.planes, a.lam_lut, a.dlam_lut, a.status, a.sp,
-                 a.h_mode, a.h2_next, a.lam_prev)
+                 a.h_mode, a.h2_next, a.lam_prev, a.owned)
 }
 
 void launch_constrain_init(hipStream_t s, Profiler* prof, const SweepArgs& a, uint32_t target, float* thr, uint32_t* consumed, float* h_new, uint8_t* flag)
@@ -2006,7 +2023,7 @@ void launch_pressure_accel(hipStream_t s, Profiler* prof, const SweepArgs& a, in
 {
     ProfScope ps(prof, iter >= 0 ? "pressure_accel" : "pressure_accel_final", s);
     SPH_DISPATCH(OpPressureAccel, false, a.pm, a.orig, a.rho, a.p0, a.p1, a.pt0, a.pt1, a.lam_grad, a.pacc, a.vel, pm_out, a.ctrl, a.status, a.sp,
-                 iter, tail, (iter < 0 && tail >= TAIL_VX) ? a.hdr_partials : nullptr)
+                 iter, tail, (iter < 0 && tail >= TAIL_VX) ? a.hdr_partials : nullptr, a.owned)
 }
 
 void launch_jacobi_update(hipStream_t s, Profiler* prof, const SweepArgs& a, int iter, int residual_density)

@@ -64,7 +64,7 @@ for seed in range(first, first + count):
     except ffi.SphError as e:
         if e.status == 30 and "narrower" in str(e):
             skipped += 1
-            print(f"seed {seed}: n={len(mass)} k={k} {info} skipped (slab narrower than two support radii)", flush=True)
+            print(f"seed {seed}: n={len(mass)} k={k} {info} skipped (slab narrower than two ghost layers)", flush=True)
             continue
         msgs.append(str(e))
     print(f"seed {seed}: n={len(mass)} k={k} {info} " + ("OK" if not msgs else "MISMATCH " + "; ".join(msgs)), flush=True)
