@@ -366,6 +366,16 @@ __global__ __launch_bounds__(256) void k_unpack_field(const uint32_t* __restrict
     for (int w = 0; w < words; w++) field[(size_t)i * words + w] = in[w];
 }
 
+// m / rho of the ghosts from the refreshed rho (the same expression the owner evaluated: bit-identical, no second exchange)
+__global__ __launch_bounds__(256) void k_ghost_mrho(const uint32_t* __restrict__ dst_idx, uint32_t cnt, const float4* __restrict__ pm,
+                                                     const float* __restrict__ rho, float* __restrict__ mrho)
+{
+    uint32_t k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= cnt) return;
+    const uint32_t i = dst_idx[k];
+    mrho[i] = pm[i].z / rho[i];
+}
+
 __global__ void k_fill_u8(uint8_t* p, uint32_t n, uint8_t v)
 {
     uint32_t i = blockIdx.x * 256 + threadIdx.x;
@@ -671,7 +681,6 @@ static int refresh_ghosts(Group& G, std::vector<Member>& M, float* (*sel)(Member
 }
 
 static float* sel_rho(Member& m) { return m.a.rho; }
-static float* sel_mrho(Member& m) { return m.a.mrho; }
 static float* sel_vel(Member& m) { return (float*)m.a.vel; }
 static float* sel_pt0(Member& m) { return m.a.pt0; }
 static float* sel_pt1(Member& m) { return m.a.pt1; }
@@ -1547,7 +1556,15 @@ static int group_step(Group& G, const sph_params* p, sph_step_stats* outs)
         c->have_reduced = true;
     }
     if ((rc = refresh_ghosts(G, M, sel_rho, 1, "rho"))) return rc;
-    if ((rc = refresh_ghosts(G, M, sel_mrho, 1, "mrho"))) return rc;
+    if (G.multi())
+        for (auto& m : M) {
+            sph_ctx* c = m.c;
+            (void)hipSetDevice(c->device);
+            const uint32_t ng = c->dist.n_ghost[0] + c->dist.n_ghost[1];
+            if (ng)
+                hipLaunchKernelGGL(k_ghost_mrho, dim3((ng + 255) / 256), dim3(256), 0, c->stream, c->dist.ghost_dst.as<uint32_t>(), ng, m.a.pm, m.a.rho,
+                                   m.a.mrho);
+        }
     // ---- constant_field + a_ii (simulation.rs:2235-2259) ---------------------------------------------------
     for (auto& m : M) {
         (void)hipSetDevice(m.c->device);
