@@ -164,6 +164,7 @@ void launch_constrain_init(hipStream_t s, Profiler* prof, const SweepArgs& a, ui
 void launch_constrain_pass(hipStream_t s, Profiler* prof, const SweepArgs& a, uint32_t target, float* thr, uint32_t* consumed, float* h_new, uint32_t* pending);
 void launch_constrain_apply(hipStream_t s, Profiler* prof, const SweepArgs& a, float4* pm, const float* h_new, float* h2_next);
 void launch_aii_const(hipStream_t s, Profiler* prof, const SweepArgs& a);
+void launch_aii_const_non_pressure(hipStream_t s, Profiler* prof, const SweepArgs& a);   // + the non-pressure acceleration, one sweep
 void launch_non_pressure(hipStream_t s, Profiler* prof, const SweepArgs& a);                // vel -> vel_tmp
 void launch_source_term(hipStream_t s, Profiler* prof, const SweepArgs& a, int kind, int residual_density);  // kind: 0 div, 1 full, 2 only-density; includes Jacobi iteration 0
 void launch_pressure_accel(hipStream_t s, Profiler* prof, const SweepArgs& a, int iter, int tail, float4* pm_out);  // iter < 0: final sweep (runs once ctrl->done), tail = TAIL_*

@@ -1566,8 +1566,16 @@ static int group_step(Group& G, const sph_params* p, sph_step_stats* outs)
                                    m.a.mrho);
         }
     // ---- constant_field + a_ii (simulation.rs:2235-2259) ---------------------------------------------------
+    // the non-pressure acceleration directly follows in every mode but HybridDFSPH-with-forces-behind-the-divergence-solve:
+    // then it shares the sweep (one replay of the lists, one gradient per pair)
+    const bool np_first = p->pressure_solver_method != SPH_SOLVER_HYBRID_DFSPH || p->hybrid_dfsph_non_pressure_accel_before_divergence_free;
+    const bool np_fused = np_first && !p->check_aii && getenv("SPH_NO_FUSE") == nullptr;
     for (auto& m : M) {
         (void)hipSetDevice(m.c->device);
+        if (m.n && np_fused) {
+            launch_aii_const_non_pressure(m.c->stream, &m.c->prof, m.a);
+            continue;
+        }
         if (m.n) launch_aii_const(m.c->stream, &m.c->prof, m.a);
         // (slabs: the check reads the particle's own unit-pressure acceleration and the neighbours' m/rho, which the ghosts have)
         if (m.n && p->check_aii) launch_check_aii(m.c->stream, &m.c->prof, m.a);   // simulation.rs:1109-1123
@@ -1576,7 +1584,7 @@ static int group_step(Group& G, const sph_params* p, sph_step_stats* outs)
         for (auto& m : M) {
             sph_ctx* c = m.c;
             (void)hipSetDevice(c->device);
-            if (m.n) launch_non_pressure(c->stream, &c->prof, m.a);
+            if (m.n && !np_fused) launch_non_pressure(c->stream, &c->prof, m.a);
             std::swap(c->vel[c->cur], c->vel_tmp);
             m.a.vel = c->vel[c->cur].as<float2>();
             m.a.vel_tmp = c->vel_tmp.as<float2>();

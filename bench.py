@@ -35,6 +35,7 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s;
 # algorithmic HBM bytes per particle per launch (DESIGN.md "Kernels")
 ALGO_BYTES = {
     "density": 20, "aii_constfield": 40, "non_pressure_accel": 36, "source_term": 44,
+    "aii_nonpressure": 56,   # the two above in one sweep: x, y, m, h, rho, lambda terms, v read once; a_ii, constant_field, v' written
     "pressure_accel": 40, "pressure_accel_final": 40, "jacobi_update": 60,
 }
 
