@@ -220,12 +220,18 @@ __global__ __launch_bounds__(256) void k_pack_upload(uint32_t n, const float* __
 
 // copy the Jacobi control block and the error word into mapped pinned host memory (one lane); the host
 // busy-polls an event recorded right behind this kernel
+// `seq` lands in the host copy's last pad word AFTER everything else: the host spins on that word of mapped memory instead of
+// polling an event (sync_ctrl), which shortens the device -> host leg of the two waits of a step
 __global__ void k_publish(const SolverCtrl* __restrict__ ctrl, const DeviceStatus* __restrict__ status, SolverCtrl* __restrict__ h_ctrl,
-                          DeviceStatus* __restrict__ h_status)
+                          DeviceStatus* __restrict__ h_status, uint32_t seq)
 {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
-        *h_ctrl = *ctrl;
+        SolverCtrl v = *ctrl;
+        v.pad[2] = seq - 1u;
+        *h_ctrl = v;
         *h_status = *status;
+        __threadfence_system();
+        ((volatile SolverCtrl*)h_ctrl)->pad[2] = seq;
     }
 }
 
@@ -401,6 +407,7 @@ extern "C" int sph_create(uint64_t n_capacity, int device_id, const sph_plane* p
     if (hipHostMalloc((void**)&c->status_host, sizeof(DeviceStatus), hipHostMallocMapped) != hipSuccess) return bail(SPH_ERR_DEVICE);
     if (hipHostMalloc((void**)&c->lvl_changed, 64 * sizeof(uint32_t), hipHostMallocMapped) != hipSuccess) return bail(SPH_ERR_DEVICE);
     if (hipHostGetDevicePointer((void**)&c->lvl_changed_dev, c->lvl_changed, 0) != hipSuccess) return bail(SPH_ERR_DEVICE);
+    memset(c->lvl_changed, 0, 64 * sizeof(uint32_t));
     if (hipHostGetDevicePointer((void**)&c->hdr_host_dev, c->hdr_host, 0) != hipSuccess) return bail(SPH_ERR_DEVICE);
     if (hipHostGetDevicePointer((void**)&c->ctrl_host_dev, c->ctrl_host, 0) != hipSuccess) return bail(SPH_ERR_DEVICE);
     if (hipHostGetDevicePointer((void**)&c->status_host_dev, c->status_host, 0) != hipSuccess) return bail(SPH_ERR_DEVICE);
@@ -1036,8 +1043,10 @@ void launch_header_ahead(sph_ctx* c, uint32_t nblocks, HeaderOut* out_dev)
 
 void launch_publish(sph_ctx* c)
 {
+    c->publish_seq++;
+    if (c->publish_seq == 0u) c->publish_seq = 1u;
     hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, c->stream, c->ctrl.as<SolverCtrl>(), c->status.as<DeviceStatus>(), c->ctrl_host_dev,
-                       c->status_host_dev);
+                       c->status_host_dev, c->publish_seq);
 }
 
 void launch_check_neighborhood(sph_ctx* c, const SweepArgs& a)

@@ -60,6 +60,7 @@ struct sph_ctx {
     DevBuf planes_d, lam_lut, dlam_lut, hdr_partials, hdr_out, ctrl, status, n_tiles, red_partials, scratch;
     // mapped pinned host memory: written by kernels directly (no D2H copy launches)
     HeaderOut* hdr_host = nullptr;
+    uint32_t publish_seq = 0;   // sequence number of the last k_publish (the host spins on its arrival in ctrl_host)
     SolverCtrl* ctrl_host = nullptr;
     DeviceStatus* status_host = nullptr;
     HeaderOut* hdr_host_dev = nullptr;

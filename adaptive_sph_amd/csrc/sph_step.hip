@@ -13,6 +13,7 @@
 // output is read through neighbour gathers (rho, m/rho, v, p/rho^2, a^p) is followed by a ghost refresh
 // of exactly that field; CFL dt and the Jacobi residual statistics are all-reduced so that every rank
 // takes the same stop decision.  Ghost lanes are idle in the sweeps (their values come from their owner).
+#include <atomic>
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
@@ -118,6 +119,32 @@ int wait_stream(sph_ctx* c)
         if (e != hipErrorNotReady) return c->fail(SPH_ERR_DEVICE, "hipEventQuery failed: %s", hipGetErrorString(e));
         if ((spins & 0xfffu) == 0xfffu && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 120.0)
             return c->fail(SPH_ERR_DEVICE, "device did not finish the queued work within 120 s");
+    }
+}
+
+// Wait for the k_publish just queued: its sequence number arrives in mapped host memory as the kernel's last store, behind
+// everything queued before it.  Falls back to the event wait if it does not show up (or SPH_EVENT_WAIT is set).
+static int wait_word(sph_ctx* c, volatile uint32_t* word, uint32_t want)
+{
+    static const bool event_wait = getenv("SPH_EVENT_WAIT") != nullptr;
+    if (event_wait) return wait_stream(c);
+    auto t0 = std::chrono::steady_clock::now();
+    for (uint64_t spins = 0; *word != want; spins++) {
+        if ((spins & 0xffffu) == 0xffffu && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 2.0)
+            return wait_stream(c);   // e.g. a faulted kernel: let the event path report it
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    return SPH_OK;
+}
+static int wait_publish(sph_ctx* c) { return wait_word(c, &((volatile SolverCtrl*)c->ctrl_host)->pad[2], c->publish_seq); }
+
+// a few device words -> mapped host memory, the sequence number last (same idea as k_publish)
+__global__ void k_publish_words(const uint32_t* __restrict__ src, uint32_t n, uint32_t* __restrict__ dst_host, uint32_t seq_slot, uint32_t seq)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        for (uint32_t k = 0; k < n; k++) dst_host[k] = src[k];
+        __threadfence_system();
+        ((volatile uint32_t*)dst_host)[seq_slot] = seq;
     }
 }
 
@@ -629,7 +656,7 @@ static int sync_ctrl(Group& G)
         launch_publish(c);
     }
     for (auto c : G.m) {
-        int r = wait_stream(c);
+        int r = wait_publish(c);
         if (r && !rc) rc = r;
         if (!r && c->status_host->error) {
             uint32_t code = c->status_host->error, info = c->status_host->info;
@@ -1399,8 +1426,10 @@ static int group_step(Group& G, const sph_params* p, sph_step_stats* outs)
                     if (t == 1u && p->fill_stash_with == SPH_STASH_SURFACE_DISTANCE_MIDDLE)   // num_iter == 1, simulation.rs:769-779
                         launch_fill_stash(c->stream, &c->prof, al, lv, c->stash.as<float>());
                 }
-                HIPCHK(c, hipMemcpyAsync(c->lvl_changed, chg, B * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-                if ((rc = wait_stream(c))) return rc;
+                c->publish_seq++;
+                if (c->publish_seq == 0u) c->publish_seq = 1u;
+                hipLaunchKernelGGL(k_publish_words, dim3(1), dim3(64), 0, c->stream, chg, (uint32_t)B, c->lvl_changed_dev, 63u, c->publish_seq);
+                if ((rc = wait_word(c, (volatile uint32_t*)c->lvl_changed + 63, c->publish_seq))) return rc;
                 for (int b = 0; b < B; b++)
                     if (!c->lvl_changed[b]) done = true;
             }
