@@ -1627,15 +1627,18 @@ __global__ __launch_bounds__(256) void k_classify(uint32_t n, const float4* __re
 // One 1024-thread block adds the Jacobi kernel's per-block partials in a fixed order (deterministic;
 // the reference's rayon tree order is not) and takes the stop decision on the device.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_solver_final(const SolverPartial* __restrict__ partials, uint32_t nparts, SolverCtrl* ctrl, int iter,
+#ifndef SF_THREADS
+#define SF_THREADS 1024
+#endif
+__global__ __launch_bounds__(SF_THREADS) void k_solver_final(const SolverPartial* __restrict__ partials, uint32_t nparts, SolverCtrl* ctrl, int iter,
                                                         int residual_density, float max_avg_error, uint32_t max_iters, float rest_density,
                                                         float dt)
 {
     if (ctrl->done) return;
-    __shared__ SolverPartial s_w[16];
+    __shared__ SolverPartial s_w[SF_THREADS / 64];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     SolverPartial t{0, 0, 0, 0.f, 0.f};
-    for (uint32_t k = tid; k < nparts; k += 1024) {
+    for (uint32_t k = tid; k < nparts; k += SF_THREADS) {
         const SolverPartial q = partials[k];
         t.normal += q.normal;
         t.singular += q.singular;
@@ -1652,7 +1655,7 @@ __global__ __launch_bounds__(1024) void k_solver_final(const SolverPartial* __re
     __syncthreads();
     if (tid == 0) {
         t = s_w[0];
-        for (int k = 1; k < 16; k++) {
+        for (int k = 1; k < SF_THREADS / 64; k++) {
             t.normal += s_w[k].normal;
             t.singular += s_w[k].singular;
             t.negative += s_w[k].negative;
@@ -2108,7 +2111,7 @@ void launch_solver_reduce(hipStream_t s, Profiler* prof, const SweepArgs& a, int
                           uint32_t max_iters, float* block_partials)
 {
     ProfScope ps(prof, "solver_reduce", s);
-    hipLaunchKernelGGL(k_solver_final, dim3(1), dim3(1024), 0, s, (const SolverPartial*)block_partials, solver_reduce_blocks(a.n), a.ctrl, iter,
+    hipLaunchKernelGGL(k_solver_final, dim3(1), dim3(SF_THREADS), 0, s, (const SolverPartial*)block_partials, solver_reduce_blocks(a.n), a.ctrl, iter,
                        residual_density, max_avg_error, max_iters, a.sp.rest_density, a.sp.dt);
 }
 
