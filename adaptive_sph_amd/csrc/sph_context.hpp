@@ -112,6 +112,7 @@ struct sph_ctx {
     bool have_level = false;            // the level-estimation outputs above are those of the last step
     DevBuf lvl_changed_d;               // per-sweep "assigned something" words of a batch (device), published once per batch
     uint32_t* lvl_changed = nullptr;    // mapped pinned host copy
+    uint32_t last_level_sweeps = 0;     // effective propagation sweeps of the previous step (length of the next first batch)
     uint32_t* lvl_changed_dev = nullptr;
     uint32_t pressure_cur = 0;
     uint32_t last_div_iters = 2, last_dens_iters = 2;

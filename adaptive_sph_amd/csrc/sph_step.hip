@@ -138,11 +138,14 @@ static int wait_word(sph_ctx* c, volatile uint32_t* word, uint32_t want)
 }
 static int wait_publish(sph_ctx* c) { return wait_word(c, &((volatile SolverCtrl*)c->ctrl_host)->pad[2], c->publish_seq); }
 
-// a few device words -> mapped host memory, the sequence number last (same idea as k_publish)
-__global__ void k_publish_words(const uint32_t* __restrict__ src, uint32_t n, uint32_t* __restrict__ dst_host, uint32_t seq_slot, uint32_t seq)
+// sum of a batch's 0/1 flags -> mapped host memory, the sequence number last (same idea as k_publish)
+__global__ void k_publish_count(const uint32_t* __restrict__ flags, uint32_t n, uint32_t* __restrict__ dst_host, uint32_t seq_slot, uint32_t seq)
 {
+    uint32_t v = 0;
+    for (uint32_t k = threadIdx.x; k < n; k += 64) v += flags[k] ? 1u : 0u;
+    v = wave_sum_u32(v);
     if (threadIdx.x == 0 && blockIdx.x == 0) {
-        for (uint32_t k = 0; k < n; k++) dst_host[k] = src[k];
+        dst_host[0] = v;
         __threadfence_system();
         ((volatile uint32_t*)dst_host)[seq_slot] = seq;
     }
@@ -1355,7 +1358,7 @@ static int group_step(Group& G, const sph_params* p, sph_step_stats* outs)
         for (DevBuf* b : {&c->lvl_state, &c->flag_surface, &c->flag_insufficient}) HIPCHK(c, b->ensure(n));
         HIPCHK(c, c->nl_ext.ensure(sweep_list_bytes((uint32_t)n)));
         HIPCHK(c, c->nlx_ext.ensure(sweep_index_list_bytes((uint32_t)n)));
-        HIPCHK(c, c->lvl_changed_d.ensure(64 * sizeof(uint32_t)));
+        HIPCHK(c, c->lvl_changed_d.ensure(1024 * sizeof(uint32_t)));   // [0, 1000): flags of a batch; 1022, 1023: see below
         uint32_t* chg = c->lvl_changed_d.as<uint32_t>();
         if (!pm_old) {
             m.a = make_args(c, m.sp);
@@ -1392,8 +1395,8 @@ static int group_step(Group& G, const sph_params* p, sph_step_stats* outs)
         if (pm_old && m.n && lv.replay_step_lists) al.pm = pm_geo;
         if (pm_old && m.n && !lv.replay_step_lists) {
             al.pm = pm_geo;
-            launch_max_disp(c->stream, &c->prof, m.n, pm_old, pm_geo, chg + 62);
-            HIPCHK(c, hipMemcpyAsync(c->lvl_changed, chg + 62, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+            launch_max_disp(c->stream, &c->prof, m.n, pm_old, pm_geo, chg + 1022);
+            HIPCHK(c, hipMemcpyAsync(c->lvl_changed, chg + 1022, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
             if ((rc = wait_stream(c))) return rc;
             float dmax;
             memcpy(&dmax, (const void*)c->lvl_changed, 4);
@@ -1412,15 +1415,18 @@ static int group_step(Group& G, const sph_params* p, sph_step_stats* outs)
             // (the CenterDiff detector leaves flag_insufficient_neighs alone: its default, false)
             if (lv.center_diff) (void)hipMemsetAsync(c->flag_insufficient.p, 0, n, c->stream);
             launch_level_detect(c->stream, &c->prof, al, lv);
-            // propagate until a sweep assigns nothing (`while changed`, simulation.rs:740-800); sweeps are queued in batches
-            // of 8 and the per-sweep flags read once per batch -- a sweep behind the last effective one has no candidates
-            launch_level_propagate(c->stream, &c->prof, al, lv, 0u, chg + 63);   // surface particles mark their neighbours
-            const int B = 8;
-            uint32_t t = 1;
-            for (bool done = false; !done;) {
+            // propagate until a sweep assigns nothing (`while changed`, simulation.rs:740-800).  Sweeps are queued in batches and the
+            // host learns once per batch how many of them assigned something (a sweep behind the last effective one has no
+            // candidates and costs a scan).  The first batch is as long as the previous step's propagation + 1 -- the fluid's
+            // depth hardly changes from step to step -- so a step usually waits once instead of once per 8 sweeps.
+            launch_level_propagate(c->stream, &c->prof, al, lv, 0u, chg + 1023);   // surface particles mark their neighbours
+            uint32_t t = 1, effective = 0;
+            int B = (int)std::min<uint32_t>(std::max<uint32_t>(c->last_level_sweeps + 1u, 8u), 1000u);
+            if (getenv("SPH_LEVEL_BATCH8")) B = 8;   // measurement aid: the fixed batches of 8
+            for (bool done = false; !done; B = 8) {
                 // the flags live in device memory (a store to mapped host memory from every assigning lane made each sweep
-                // wait for PCIe at its end) and go to the host once per batch
-                (void)hipMemsetAsync(chg, 0, B * sizeof(uint32_t), c->stream);
+                // wait for PCIe at its end); their sum goes to the host once per batch
+                (void)hipMemsetAsync(chg, 0, (size_t)B * sizeof(uint32_t), c->stream);
                 for (int b = 0; b < B; b++, t++) {
                     launch_level_propagate(c->stream, &c->prof, al, lv, t, chg + b);
                     if (t == 1u && p->fill_stash_with == SPH_STASH_SURFACE_DISTANCE_MIDDLE)   // num_iter == 1, simulation.rs:769-779
@@ -1428,11 +1434,13 @@ static int group_step(Group& G, const sph_params* p, sph_step_stats* outs)
                 }
                 c->publish_seq++;
                 if (c->publish_seq == 0u) c->publish_seq = 1u;
-                hipLaunchKernelGGL(k_publish_words, dim3(1), dim3(64), 0, c->stream, chg, (uint32_t)B, c->lvl_changed_dev, 63u, c->publish_seq);
+                hipLaunchKernelGGL(k_publish_count, dim3(1), dim3(64), 0, c->stream, chg, (uint32_t)B, c->lvl_changed_dev, 63u, c->publish_seq);
                 if ((rc = wait_word(c, (volatile uint32_t*)c->lvl_changed + 63, c->publish_seq))) return rc;
-                for (int b = 0; b < B; b++)
-                    if (!c->lvl_changed[b]) done = true;
+                const uint32_t changed = c->lvl_changed[0];   // "nobody assigned anything" is final: the flags are ones, then zeros
+                effective += changed;
+                done = changed < (uint32_t)B;
             }
+            c->last_level_sweeps = effective;
         }
         c->have_level = true;
         m.st.ms_level_estimation += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_lvl0).count();
