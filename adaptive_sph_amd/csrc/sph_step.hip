@@ -1422,7 +1422,8 @@ static int group_step(Group& G, const sph_params* p, sph_step_stats* outs)
             launch_level_propagate(c->stream, &c->prof, al, lv, 0u, chg + 1023);   // surface particles mark their neighbours
             uint32_t t = 1, effective = 0;
             int B = (int)std::min<uint32_t>(std::max<uint32_t>(c->last_level_sweeps + 1u, 8u), 1000u);
-            if (getenv("SPH_LEVEL_BATCH8")) B = 8;   // measurement aid: the fixed batches of 8
+            static const bool batch8 = getenv("SPH_LEVEL_BATCH8") != nullptr;   // measurement aid: the fixed batches of 8
+            if (batch8) B = 8;
             for (bool done = false; !done; B = 8) {
                 // the flags live in device memory (a store to mapped host memory from every assigning lane made each sweep
                 // wait for PCIe at its end); their sum goes to the host once per batch
@@ -1606,7 +1607,8 @@ static int group_step(Group& G, const sph_params* p, sph_step_stats* outs)
     // the non-pressure acceleration directly follows in every mode but HybridDFSPH-with-forces-behind-the-divergence-solve:
     // then it shares the sweep (one replay of the lists, one gradient per pair)
     const bool np_first = p->pressure_solver_method != SPH_SOLVER_HYBRID_DFSPH || p->hybrid_dfsph_non_pressure_accel_before_divergence_free;
-    const bool np_fused = np_first && !p->check_aii && getenv("SPH_NO_FUSE") == nullptr;
+    static const bool no_fuse = getenv("SPH_NO_FUSE") != nullptr;   // measurement aid: the two sweeps apart
+    const bool np_fused = np_first && !p->check_aii && !no_fuse;
     for (auto& m : M) {
         (void)hipSetDevice(m.c->device);
         if (m.n && np_fused) {
