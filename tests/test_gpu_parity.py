@@ -261,6 +261,30 @@ def test_level_estimation_after_advection(product_lib, oracle_lib, scene, ext):
         assert rel_err(g.download(f), o.download(f)) < TOL.get(f, REL_TOL_FIELDS), f
 
 
+def test_replaying_step_lists_needs_recorded_lists(product_lib):
+    """level_estimation_after_advection without the extended range replays the step's own lists at the advected positions.  A
+    particle whose list is not recorded (here: a uniform scene compressed until the three cell rows hold more than 32 candidates,
+    so the mask word is invalid and the particle re-walks its candidates in every sweep) cannot be replayed at other positions:
+    the step says so instead of evaluating the neighbour predicate at the wrong positions."""
+    scn = sc.dam_break_small(48, 40, 1 / 48)
+    pos, mass, vel = sc.init_particles(scn)
+    pos = (pos * np.float32(0.55)).astype(np.float32)            # 3.3 x the rest density: ~14 particles per cell
+    g = ffi.Context(product_lib, len(mass), sc.boundary_planes(scn.boundary))
+    g.upload(mass, pos, vel)
+    P = dam_break_params(level_estimation_method="EmptyAngle", maximum_surface_distance=0.2, particle_radius_fine=0.004,
+                         particle_radius_base=0.02, level_estimation_after_advection=True, use_extended_range_for_level_estimation=False,
+                         max_dt=1e-5, pressure_solver_method="OnlyDivergence", gravity=0.0)   # at rest: zero source, zero pressure
+    with pytest.raises(ffi.SphError) as e:
+        g.step(P.to_ffi())
+    assert e.value.status == 30 and "recorded" in str(e.value)     # SPH_ERR_UNSUPPORTED
+    # the same scene with the extended range (lists rebuilt at the advected positions) steps
+    g2 = ffi.Context(product_lib, len(mass), sc.boundary_planes(scn.boundary))
+    g2.upload(mass, pos, vel)
+    P.use_extended_range_for_level_estimation = True
+    g2.step(P.to_ffi())
+    assert g2.download("neighbor_count").max() > 32
+
+
 def test_center_diff_detector_after_advection(product_lib, oracle_lib):
     """media/surface-detection.yaml's first recipe: CenterDiff on the 2:1 scene with boundary_is_fluid_surface.  The reference
     only accepts the detector when the level estimation runs after advection (simulation.rs:2029-2031), which is how it is run
