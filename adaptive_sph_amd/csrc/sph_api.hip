@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void k_header(float4* __restrict__ pm, const f
     }
 }
 
-__global__ __launch_bounds__(256) void k_header_final(const HeaderOut* __restrict__ partials, int nparts, HeaderOut* __restrict__ out)
+__global__ __launch_bounds__(256) void k_header_final(const HeaderOut* __restrict__ partials, int nparts, HeaderOut* __restrict__ out, uint32_t seq)
 {
     const float INF = __uint_as_float(0x7f800000u);
     HeaderOut o{INF, INF, -INF, -INF, 0.f, INF, INF, 0};
@@ -165,7 +165,12 @@ __global__ __launch_bounds__(256) void k_header_final(const HeaderOut* __restric
             r.h_max = fmaxf(r.h_max, s[k].h_max); r.h_min = fminf(r.h_min, s[k].h_min);
             r.min_cfl = fminf(r.min_cfl, s[k].min_cfl);
         }
+        r.pad = seq - 1u;
         *out = r;
+        if (seq) {   // the host may be spinning on the pad word of the mapped copy (wait hint)
+            __threadfence_system();
+            ((volatile HeaderOut*)out)->pad = seq;
+        }
     }
 }
 
@@ -1032,7 +1037,14 @@ void launch_header(sph_ctx* c, uint32_t n, float rest_density, int from_mass /* 
     if (nb < 1) nb = 1;
     hipLaunchKernelGGL(k_header, dim3(nb), dim3(256), 0, s, c->pm[c->pcur].as<float4>(), c->vel[c->cur].as<float2>(), n, rest_density, from_mass,
                        c->h2n[c->cur].as<float>(), c->hdr_partials.as<HeaderOut>());
-    hipLaunchKernelGGL(k_header_final, dim3(1), dim3(256), 0, s, c->hdr_partials.as<HeaderOut>(), nb, out_dev);
+    c->publish_seq++;
+    if (c->publish_seq == 0u) c->publish_seq = 1u;
+    const bool mapped = out_dev == c->hdr_host_dev;
+    hipLaunchKernelGGL(k_header_final, dim3(1), dim3(256), 0, s, c->hdr_partials.as<HeaderOut>(), nb, out_dev, mapped ? c->publish_seq : 0u);
+    if (mapped) {   // nothing may be queued between this launch and the wait that uses the hint
+        c->hint_word = &((volatile HeaderOut*)c->hdr_host)->pad;
+        c->hint_seq = c->publish_seq;
+    }
 }
 
 void launch_header_ahead(sph_ctx* c, uint32_t nblocks, HeaderOut* out_dev)

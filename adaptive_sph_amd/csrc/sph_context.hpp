@@ -60,6 +60,8 @@ struct sph_ctx {
     DevBuf planes_d, lam_lut, dlam_lut, hdr_partials, hdr_out, ctrl, status, n_tiles, red_partials, scratch;
     // mapped pinned host memory: written by kernels directly (no D2H copy launches)
     HeaderOut* hdr_host = nullptr;
+    volatile uint32_t* hint_word = nullptr;   // the kernel queued LAST stores hint_seq here as its final store: the next wait spins on it
+    uint32_t hint_seq = 0;
     uint32_t publish_seq = 0;   // sequence number of the last k_publish (the host spins on its arrival in ctrl_host)
     SolverCtrl* ctrl_host = nullptr;
     DeviceStatus* status_host = nullptr;

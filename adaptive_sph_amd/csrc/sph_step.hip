@@ -108,8 +108,21 @@ const char* status_message(uint32_t code)
 
 // Wait for everything queued on the context's stream.  Busy-polls an event instead of
 // hipStreamSynchronize: the blocking wait's wake-up latency would otherwise be paid at every wait point.
+static int wait_word(sph_ctx* c, volatile uint32_t* word, uint32_t want);
+// Only for a wait that DIRECTLY follows the launch that armed the hint (k_header_final, k_copy_counts): that kernel announces its
+// end in mapped memory as its last store, and the host spins there instead of polling an event.  Every other wait drops the hint.
+static int wait_hinted(sph_ctx* c)
+{
+    if (c->hint_word) {
+        volatile uint32_t* w = c->hint_word;
+        c->hint_word = nullptr;
+        return wait_word(c, w, c->hint_seq);
+    }
+    return wait_stream(c);
+}
 int wait_stream(sph_ctx* c)
 {
+    c->hint_word = nullptr;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipEventRecord(c->ev_sync, c->stream));
     auto t0 = std::chrono::steady_clock::now();
@@ -136,7 +149,31 @@ static int wait_word(sph_ctx* c, volatile uint32_t* word, uint32_t want)
     std::atomic_thread_fence(std::memory_order_acquire);
     return SPH_OK;
 }
-static int wait_publish(sph_ctx* c) { return wait_word(c, &((volatile SolverCtrl*)c->ctrl_host)->pad[2], c->publish_seq); }
+static int wait_publish(sph_ctx* c)
+{
+    c->hint_word = nullptr;
+    return wait_word(c, &((volatile SolverCtrl*)c->ctrl_host)->pad[2], c->publish_seq);
+}
+
+// a few device words -> mapped host memory, the sequence number last (same idea as k_publish): the result of a host-value
+// collective reaches the host without a copy engine round trip and without polling an event
+__global__ void k_publish_words(const uint32_t* __restrict__ src, uint32_t n, uint32_t* __restrict__ dst_host, uint32_t* __restrict__ seq_host,
+                                uint32_t seq)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        for (uint32_t k = 0; k < n; k++) dst_host[k] = src[k];
+        __threadfence_system();
+        *(volatile uint32_t*)seq_host = seq;
+    }
+}
+static int publish_and_wait(sph_ctx* c, const void* dev_words, uint32_t n_words)   // -> counts_host[16 ..), sequence in counts_host[63]
+{
+    c->publish_seq++;
+    if (c->publish_seq == 0u) c->publish_seq = 1u;
+    hipLaunchKernelGGL(k_publish_words, dim3(1), dim3(64), 0, c->stream, (const uint32_t*)dev_words, n_words, c->dist.counts_host_dev + 16,
+                       c->dist.counts_host_dev + 63, c->publish_seq);
+    return wait_word(c, (volatile uint32_t*)c->dist.counts_host + 63, c->publish_seq);
+}
 
 // sum of a batch's 0/1 flags -> mapped host memory, the sequence number last (same idea as k_publish)
 __global__ void k_publish_count(const uint32_t* __restrict__ flags, uint32_t n, uint32_t* __restrict__ dst_host, uint32_t seq_slot, uint32_t seq)
@@ -444,6 +481,14 @@ struct Group {
     bool multi() const { return comm != nullptr; }
 };
 
+static int wait_all_hinted(Group& G)   // see wait_hinted
+{
+    for (auto c : G.m) {
+        int rc = wait_hinted(c);
+        if (rc) return rc;
+    }
+    return SPH_OK;
+}
 static int wait_all(Group& G)
 {
     for (auto c : G.m) {
@@ -546,8 +591,7 @@ struct RcclComm : Comm {
         memcpy(stage, host, bytes);
         HIPCHK(c, hipMemcpyAsync(d, stage, bytes, hipMemcpyHostToDevice, c->stream));
         NCCLCHK(c, ncclAllReduce(d, d, count, dt, op, nc, c->stream));
-        HIPCHK(c, hipMemcpyAsync(stage, d, bytes, hipMemcpyDeviceToHost, c->stream));
-        int rc = wait_stream(c);
+        int rc = publish_and_wait(c, d, (uint32_t)((bytes + 3) / 4));
         if (rc) return rc;
         memcpy(host, stage, bytes);
         return SPH_OK;
@@ -592,8 +636,7 @@ struct RcclComm : Comm {
             NCCLCHK(c, ncclRecv(d + 3, 1, ncclUint32, r + 1, nc, c->stream));
         }
         NCCLCHK(c, ncclGroupEnd());
-        HIPCHK(c, hipMemcpyAsync(h, d, 16, hipMemcpyDeviceToHost, c->stream));
-        int rc = wait_stream(c);
+        int rc = publish_and_wait(c, d, 4);
         if (rc) return rc;
         fl[0] = r > 0 ? h[2] : 0;
         fr[0] = r + 1 < nr ? h[3] : 0;
@@ -739,13 +782,26 @@ static int ensure_dist_buffers(sph_ctx* c, uint32_t n)
     if (!d.counts_host) {
         HIPCHK(c, hipHostMalloc((void**)&d.counts_host, 256, hipHostMallocMapped));   // 64 B of counters + 192 B of staging
         HIPCHK(c, hipHostGetDevicePointer((void**)&d.counts_host_dev, d.counts_host, 0));
+        memset(d.counts_host, 0, 256);
     }
     return SPH_OK;
 }
 
-__global__ void k_copy_counts(const uint32_t* __restrict__ src, uint32_t* __restrict__ host_dst)
+__global__ void k_copy_counts(const uint32_t* __restrict__ src, uint32_t* __restrict__ host_dst, uint32_t seq)
 {
     if (threadIdx.x < 8) host_dst[threadIdx.x] = src[threadIdx.x];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) ((volatile uint32_t*)host_dst)[15] = seq;   // wait hint
+}
+static void launch_copy_counts(sph_ctx* c)
+{
+    auto& d = c->dist;
+    c->publish_seq++;
+    if (c->publish_seq == 0u) c->publish_seq = 1u;
+    hipLaunchKernelGGL(k_copy_counts, dim3(1), dim3(64), 0, c->stream, d.counts.as<uint32_t>(), d.counts_host_dev, c->publish_seq);
+    c->hint_word = (volatile uint32_t*)d.counts_host + 15;   // nothing may be queued between this launch and the wait
+    c->hint_seq = c->publish_seq;
 }
 
 // ---- slab maintenance (multi-rank only) ---------------------------------------------------------------
@@ -788,9 +844,9 @@ static int partition_and_migrate(Group& G, std::vector<Member>& M, std::vector<i
             c->pcur ^= 1;
             std::swap(c->lam_sum, c->lam_prev);   // the permuted lambda sums are the CURRENT ones again (the cell sort moves them on)
         }
-        hipLaunchKernelGGL(k_copy_counts, dim3(1), dim3(64), 0, c->stream, d.counts.as<uint32_t>(), d.counts_host_dev);
+        launch_copy_counts(c);
     }
-    if ((rc = wait_all(G))) return rc;   // (a device failure here is fatal for the whole job; logical errors are agreed on below)
+    if ((rc = wait_all_hinted(G))) return rc;   // (a device failure here is fatal for the whole job; logical errors are agreed on below)
     // (2) migrants: counts -> neighbours, then the records
     std::vector<uint32_t> tl(nm), tr(nm), fl(nm), fr(nm);
     for (size_t i = 0; i < nm; i++) {
@@ -958,10 +1014,10 @@ static int build_ghost_layer(Group& G, std::vector<Member>& M, float halo_width,
                 std::swap(c->val[0], c->val[1]);
             }
         }
-        hipLaunchKernelGGL(k_copy_counts, dim3(1), dim3(64), 0, c->stream, d.counts.as<uint32_t>(), d.counts_host_dev);
+        launch_copy_counts(c);
     }
     // one agreement for both the wait and the width check (every rank leaves together)
-    rc = wait_all(G);
+    rc = wait_all_hinted(G);
     for (size_t i = 0; i < nm && !rc; i++) {
         auto& d = M[i].c->dist;
         if (d.counts_host[4 + 3]) rc = M[i].c->fail(SPH_ERR_UNSUPPORTED, "slab of rank %d is narrower than two ghost layers", d.rank);
@@ -1159,7 +1215,7 @@ static int group_step(Group& G, const sph_params* p, sph_step_stats* outs)
             (void)hipSetDevice(m.c->device);
             launch_header(m.c, (uint32_t)m.c->n, p->rest_density, h_from_mass_mode ? 1 : 2, m.c->hdr_host_dev);
         }
-        hdr_rc = wait_all(G);
+        hdr_rc = wait_all_hinted(G);
         if (hdr_rc && !G.multi()) return hdr_rc;
     }
     c0->hdr_ahead = false;
@@ -1193,7 +1249,7 @@ static int group_step(Group& G, const sph_params* p, sph_step_stats* outs)
             (void)hipSetDevice(m.c->device);
             launch_header(m.c, m.n, p->rest_density, 0, m.c->hdr_host_dev);   // h is set; only the bounding box changed
         }
-        setup_rc = wait_all(G);   // agreed on below, together with the per-rank grid checks
+        setup_rc = wait_all_hinted(G);   // agreed on below, together with the per-rank grid checks
     }
     g_trace.mark(1);
 
