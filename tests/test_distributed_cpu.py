@@ -1,7 +1,8 @@
-"""N>1 on CPU: two gloo ranks run the slab decomposition's host logic (cuts, partition, ghost selection by
-support radius, all-reduced CFL term) and check with the CPU oracle that a rank's owned + ghost particles
-reproduce the GLOBAL neighbour sets and densities of its owned particles -- the property the device-side
-halo exchange relies on.  (The device path itself is covered on the GPU by tests/test_gpu_slabs.py.)"""
+"""N>1 on CPU: two gloo ranks run the slab decomposition's host logic (cuts, partition, ghost selection over TWO support
+radii, all-reduced CFL term) and check with the CPU oracle the two properties the device-side halo exchange relies on: a rank's
+owned + ghost particles reproduce the GLOBAL neighbour sets and densities of its owned particles, AND of its first ghost ring
+(ghosts within one support radius of the cut) -- which is why those ghosts can compute their own pressure acceleration and a
+Jacobi iteration needs one neighbour exchange.  (The device path itself is covered on the GPU by tests/test_gpu_slabs.py.)"""
 import os
 import socket
 
@@ -49,7 +50,8 @@ def _worker(rank, world, port, q):
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         h_max = -t[0].item()
         assert abs(h_max - float((np.float32(1.9) * np.sqrt(mass * np.float32(1 / np.pi))).max())) < 1e-7
-        w = 2.0 * h_max
+        support = 2.0 * h_max
+        w = 2.0 * support      # two ghost rings
 
         # ghost layer: my owned particles within w of a cut go to that neighbour (send/recv over gloo)
         recv = []
@@ -90,6 +92,17 @@ def _worker(rank, world, port, q):
             assert np.array_equal(np.sort(local[ls[k]]), fs[mine[k]])
         d_loc, d_full = loc.download("density")[:n_own], full.download("density")[mine]
         assert np.abs(d_loc - d_full).max() <= 2e-6 * d_full.max()     # same neighbours, different summation order
+        # first ghost ring: complete neighbourhoods as well (their neighbours lie inside the second ring)
+        gx = pos[ghosts, 0]
+        ring1 = np.zeros(len(ghosts), bool)
+        if rank > 0:
+            ring1 |= (gx < cuts[rank]) & (gx >= cuts[rank] - support)
+        if rank + 1 < world:
+            ring1 |= (gx >= cuts[rank + 1]) & (gx < cuts[rank + 1] + support)
+        assert ring1.any() and not ring1.all()
+        for k in np.nonzero(ring1)[0][::5]:
+            assert np.array_equal(np.sort(local[ls[n_own + k]]), fs[ghosts[k]])
+        assert np.array_equal(loc.download("neighbor_count")[n_own:][ring1], full.download("neighbor_count")[ghosts][ring1])
         q.put((rank, "ok", n_own, len(ghosts)))
     except Exception as e:  # noqa: BLE001
         import traceback
