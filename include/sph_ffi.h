@@ -307,9 +307,10 @@ int  sph_profile_copy_bandwidth(sph_ctx* ctx, uint64_t bytes, double* gb_per_s);
  * (the outermost ranks ignore their open side); sph_upload then takes this rank's particles only.
  * The 128-byte RCCL unique id is created on rank 0 (sph_comm_unique_id) and broadcast by the launcher
  * (torch.distributed / MPI / a socket); every rank then calls sph_comm_init.  After that sph_step hands
- * particles that left the slab to the x-neighbour, exchanges the ghost layer (one support radius) with the
- * x-neighbours over RCCL point-to-point after every sweep whose output neighbours read, and all-reduces the
- * CFL minimum and the Jacobi residual statistics so that every rank takes the same decisions.
+ * particles that left the slab to the x-neighbour, exchanges the ghost layer (two support radii: the ghosts of the first
+ * ring compute their own pressure acceleration) with the x-neighbours over RCCL point-to-point after every sweep whose
+ * output neighbours read -- once per Jacobi iteration --, and all-reduces the CFL minimum and the Jacobi residual
+ * statistics so that every rank takes the same decisions.  A slab narrower than two ghost layers is refused.
  * sph_group_step steps k contexts of ONE process as ranks 0..k-1 with plain copies as transport (one GPU or
  * several): same algorithm, used to verify the decomposition against a single context. */
 int  sph_dist_configure(sph_ctx* ctx, int rank, int n_ranks, float cut_lo, float cut_hi);
