@@ -304,7 +304,7 @@ def main():
             short_run(plib, "dam_break_1m_adaptive"),                                       # configs[2]: 4:1 radius ratio
             short_run(plib, "dam_break_8m", steps=20, warmup=10),                            # configs[3] on ONE GPU
             short_run(plib, "ratio_stress_4m", steps=20, warmup=5),                         # configs[4]'s scene (50:1, 4M), no adaptivity
-            short_run(plib, "dam_break_1m", steps=5, warmup=2, level_estimation_method="EmptyAngle",
+            short_run(plib, "dam_break_1m", steps=20, warmup=20, level_estimation_method="EmptyAngle",
                       maximum_surface_distance=0.2, particle_radius_fine=0.0005, particle_radius_base=0.002),   # + level estimation
         ]
     if not args.no_cpu_baseline and not distributed:
