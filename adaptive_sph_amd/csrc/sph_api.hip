@@ -272,6 +272,7 @@ __global__ __launch_bounds__(256) void k_from_host_order(uint32_t n, int kind, c
     case G_F32: ((float*)dst)[i] = ((const float*)src)[o]; break;
     case G_U32: ((uint32_t*)dst)[i] = ((const uint32_t*)src)[o]; break;
     case G_F32X2: ((float2*)dst)[i] = ((const float2*)src)[o]; break;
+    case G_U8: ((uint8_t*)dst)[i] = ((const uint8_t*)src)[o]; break;
     case G_PM_X: { float2 p = ((const float2*)src)[o]; float4 q = ((float4*)dst)[i]; q.x = p.x; q.y = p.y; ((float4*)dst)[i] = q; } break;
     case G_PM_M: { float4 q = ((float4*)dst)[i]; q.z = ((const float*)src)[o]; ((float4*)dst)[i] = q; } break;
     case G_PM_H: { float4 q = ((float4*)dst)[i]; q.w = ((const float*)src)[o]; ((float4*)dst)[i] = q; } break;
@@ -509,6 +510,7 @@ extern "C" int sph_upload(sph_ctx* c, uint64_t n, const float* mass, const float
     c->n = n;
     c->cur = 0;
     c->pcur = 0;
+    c->poisoned = false;
     c->dist.have_flags = false;
     c->dist.n_tot = (uint32_t)n;
     c->grid_valid = false;
@@ -560,6 +562,7 @@ static bool field_ref(sph_ctx* c, int field, FieldRef* r)
     case SPH_F_NEIGHBOR_COUNT: *r = {G_U32, c->ncount.p, 4, false}; return true;
     case SPH_F_LEVEL_ESTIMATION: *r = {G_F32, c->lvl[k].p, 4, true}; return true;
     case SPH_F_LEVEL_OLD: *r = {G_F32, c->lvlold[k].p, 4, true}; return true;
+    case SPH_F_PARTICLE_SIZE_CLASS: *r = {G_U8, c->szc[k].p, 1, true}; return true;
     case SPH_F_LAMBDA_SUM: *r = {G_F32, c->lam_sum.p, 4, false}; return true;
     case SPH_F_LAMBDA_GRAD_SUM: *r = {G_F32X2, c->lam_grad.p, 8, false}; return true;
     default: return false;
@@ -622,20 +625,17 @@ extern "C" int sph_download(sph_ctx* c, int field, void* dst, uint64_t bytes)
         HIPCHK(c, hipStreamSynchronize(s));
         return SPH_OK;
     }
-    if (field == SPH_F_STASH || field == SPH_F_FLAG_IS_FLUID_SURFACE || field == SPH_F_FLAG_INSUFFICIENT_NEIGHS ||
-        field == SPH_F_PARTICLE_SIZE_CLASS) {
+    if (field == SPH_F_STASH || field == SPH_F_FLAG_IS_FLUID_SURFACE || field == SPH_F_FLAG_INSUFFICIENT_NEIGHS) {
         // level-estimation outputs (simulation.rs:539-927).  Before the first step with a level_estimation_method they are
         // the defaults of ParticleVec.
         size_t elem = field == SPH_F_STASH ? 4 : 1;
         if (bytes != (uint64_t)n * elem) return c->fail(SPH_ERR_INVALID_ARGUMENT, "field %d: size mismatch", field);
-        if ((!c->have_level && field != SPH_F_PARTICLE_SIZE_CLASS) || (c->dist.on && !c->have_level)) {
-            memset(dst, field == SPH_F_PARTICLE_SIZE_CLASS ? 2 : 0, bytes);
+        if (!c->have_level) {
+            memset(dst, 0, bytes);
             return SPH_OK;
         }
         if (n == 0) return SPH_OK;
-        const void* src = field == SPH_F_STASH ? c->stash.p
-                          : field == SPH_F_FLAG_IS_FLUID_SURFACE ? c->flag_surface.p
-                          : field == SPH_F_FLAG_INSUFFICIENT_NEIGHS ? c->flag_insufficient.p : c->szc[k].p;
+        const void* src = field == SPH_F_STASH ? c->stash.p : field == SPH_F_FLAG_IS_FLUID_SURFACE ? c->flag_surface.p : c->flag_insufficient.p;
         if (c->dist.on) return download_slab(c, field == SPH_F_STASH ? (int)G_F32 : (int)G_U8, src, elem, dst, bytes);
         hipLaunchKernelGGL(k_to_host_order, dim3((n + 255) / 256), dim3(256), 0, s, n, field == SPH_F_STASH ? (int)G_F32 : (int)G_U8,
                            c->orig[k].as<uint32_t>(), src, c->scratch.p);
@@ -737,6 +737,7 @@ extern "C" int sph_apply_edits(sph_ctx* c, const sph_edit_op* ops, uint64_t n_op
 {
     if (!c || (n_ops && !ops)) return SPH_ERR_INVALID_ARGUMENT;
     if (c->dist.on) return c->fail(SPH_ERR_UNSUPPORTED, "sparse edits on a slab context are not covered yet");
+    if (c->poisoned) return c->fail(SPH_ERR_POISONED, "an earlier step failed inside the step: the particle state is undefined until sph_upload");
     HIPCHK(c, hipSetDevice(c->device));
     const uint32_t n_old = (uint32_t)c->n;
     // ---- resolve the script: which object sits at which index, and the last value written to each field of an object

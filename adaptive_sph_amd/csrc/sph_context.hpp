@@ -43,6 +43,7 @@ struct sph_ctx {
     BoundaryP bnd_h{};   // planes, or one Sdf2D polygon (sph_set_boundary_polygon)
     float time = 0.f;
     uint64_t step_number = 0;
+    bool poisoned = false;   // a guard fired inside a step: state undefined until sph_upload (sph_ffi.h)
     std::string err;
     Profiler prof;
     int exact = 0;

@@ -202,7 +202,8 @@ void launch_level_detect(hipStream_t s, Profiler* prof, const SweepArgs& a, cons
 void launch_level_propagate(hipStream_t s, Profiler* prof, const SweepArgs& a, const LevelArgs& l, uint32_t t, uint32_t* changed);
 void launch_fill_stash(hipStream_t s, Profiler* prof, const SweepArgs& a, const LevelArgs& l, float* stash);
 void launch_level_smooth(hipStream_t s, Profiler* prof, const SweepArgs& a, const LevelArgs& l, const float4* pm_new, const float* in, float* out);
-void launch_classify(hipStream_t s, Profiler* prof, const SweepArgs& a, const LevelArgs& l, const float* level, const sph_params* p);
+void launch_classify(hipStream_t s, Profiler* prof, uint32_t n, const float4* pm, const float* level, uint8_t* size_class, const uint8_t* owned,
+                     const uint32_t* orig, DeviceStatus* status, const sph_params* p);
 // reduce the per-block header partials of the integrating final sweep into `out_dev` (skipped while the solve is not done)
 void launch_header_ahead(sph_ctx* c, uint32_t nblocks, HeaderOut* out_dev);
 // IISPH2: p /= sqrt(omega) on the current pressure buffer (+ p / rho^2), simulation.rs:2358-2360

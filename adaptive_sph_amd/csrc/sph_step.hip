@@ -1150,7 +1150,7 @@ static int pressure_iterations(Group& G, std::vector<Member>& M, float max_avg_e
     return SPH_OK;
 }
 
-static int group_step(Group& G, const sph_params* p, sph_step_stats* outs)
+static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs, bool* started)
 {
     int rc = SPH_OK;
     g_trace.start();
@@ -1176,6 +1176,15 @@ static int group_step(Group& G, const sph_params* p, sph_step_stats* outs)
     if (!p->level_estimation_after_advection && !p->use_extended_range_for_level_estimation)
         return c0->fail(SPH_ERR_INVALID_ARGUMENT, "assertion failed: simulation_params.use_extended_range_for_level_estimation");
     if (!G.multi() && c0->n == 0) return c0->fail(SPH_ERR_INVALID_ARGUMENT, "called `Option::unwrap()` on a `None` value (no particles)");
+    // Level estimation before advection builds the lists at k = level_estimation_range / ETA and filter_down(2) only REMOVES
+    // entries (neighborhood_search.rs:56-70; simulation.rs:2018-2070 -- also with level_estimation_method None): below k = 2 the
+    // whole step runs on the narrower k-range lists.  The sweeps here are built for the SPH support (k = 2): refuse, never widen.
+    if (!p->level_estimation_after_advection && !(p->level_estimation_range / SPH_ETA >= 2.f))
+        return c0->fail(SPH_ERR_UNSUPPORTED, "level_estimation_range / 1.9 = %g < 2: the reference then steps on lists narrower than the SPH support, which this build does not cover",
+                        (double)(p->level_estimation_range / SPH_ETA));
+    for (auto c : G.m)
+        if (c->poisoned) return c->fail(SPH_ERR_POISONED, "an earlier step failed inside the step: the particle state is undefined until sph_upload");
+    *started = true;   // from here on a failure leaves the state half-stepped
 
     // ---- slab maintenance part 1 needs no global scalar: partition + migrate (multi-rank) -----------------
     // (the ghost layer needs the all-reduced h_max, so the header of the owned particles comes first)
@@ -1758,7 +1767,7 @@ static int group_step(Group& G, const sph_params* p, sph_step_stats* outs)
     if (p->viscosity_type == SPH_VISC_XSPH)  // simulation.rs:2673-2676
         return c0->fail(SPH_ERR_XSPH_TODO, "not yet implemented (XSPH velocity smoothing)");
 
-    // ---- smooth_level_estimation_field + classify_particles (simulation.rs:2709-2722) --------------------------------------
+    // ---- smooth_level_estimation_field (simulation.rs:2709-2722) ------------------------------------------------------------
     if (level_on && G.multi()) {
         const auto t_lvl0 = std::chrono::steady_clock::now();
         for (auto& m : M) {
@@ -1775,7 +1784,7 @@ static int group_step(Group& G, const sph_params* p, sph_step_stats* outs)
             if (!m.n) continue;
             launch_level_smooth(c->stream, &c->prof, m.a, LV[i], c->pm[c->pcur ^ 1].as<float4>(), c->lvl[c->cur].as<float>(), c->lvl_tmp.as<float>());
             std::swap(c->lvl[c->cur], c->lvl_tmp);
-            launch_classify(c->stream, &c->prof, m.a, LV[i], c->lvl[c->cur].as<float>(), p);
+            // (no classify_particles here: the reference's step never calls it -- sph_classify is the host's call)
         }
         if ((rc = sync_ctrl(G))) return rc;
         for (auto& m : M) m.st.ms_level_estimation += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_lvl0).count();
@@ -1793,7 +1802,6 @@ static int group_step(Group& G, const sph_params* p, sph_step_stats* outs)
             as.t_ext.slack = lv_slack;
             launch_level_smooth(c->stream, &c->prof, as, lv, c->pm[c->pcur ^ 1].as<float4>(), c->lvl[c->cur].as<float>(), c->lvl_tmp.as<float>());
             std::swap(c->lvl[c->cur], c->lvl_tmp);
-            launch_classify(c->stream, &c->prof, m.a, lv, c->lvl[c->cur].as<float>(), p);
         }
         if ((rc = sync_ctrl(G))) return rc;
         m.st.ms_level_estimation += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_lvl0).count();
@@ -1836,6 +1844,18 @@ static int group_step(Group& G, const sph_params* p, sph_step_stats* outs)
     return SPH_OK;
 }
 
+static int group_step(Group& G, const sph_params* p, sph_step_stats* outs)
+{
+    bool started = false;
+    const int rc = group_step_inner(G, p, outs, &started);
+    if (rc && started)
+        for (auto c : G.m) {
+            c->poisoned = true;
+            c->hdr_ahead = false;
+        }
+    return rc;
+}
+
 // ------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------
@@ -1853,6 +1873,23 @@ extern "C" int sph_step(sph_ctx* c, const sph_params* p, sph_step_stats* out)
         G.comm = &g_rccl;
     }
     return group_step(G, p, out);
+}
+
+// classify_particles (adaptivity/mod.rs:50-59) on the device-resident state: the level field and masses as they stand
+extern "C" int sph_classify(sph_ctx* c, const sph_params* p)
+{
+    if (!c || !p) return SPH_ERR_INVALID_ARGUMENT;
+    if (c->poisoned) return c->fail(SPH_ERR_POISONED, "an earlier step failed inside the step: the particle state is undefined until sph_upload");
+    HIPCHK(c, hipSetDevice(c->device));
+    const bool flags = c->dist.on && c->dist.have_flags;
+    const uint32_t n = flags ? c->dist.n_tot : (uint32_t)c->n;
+    launch_classify(c->stream, &c->prof, n, c->pm[c->pcur].as<float4>(), c->lvl[c->cur].as<float>(), c->szc[c->cur].as<uint8_t>(),
+                    flags ? c->dist.owned.as<uint8_t>() : nullptr, c->orig[c->cur].as<uint32_t>(), c->status.as<DeviceStatus>(), p);
+    Group G;
+    G.m.push_back(c);
+    int rc = sync_ctrl(G);   // surfaces the unreachable!() of a particle without a level value
+    if (rc == SPH_ERR_INVALID_ARGUMENT) c->err = "internal error: entered unreachable code (LevelEstimationState::level of FluidInterior) -- " + c->err;
+    return rc;
 }
 
 extern "C" int sph_group_step(sph_ctx** ctxs, int n, const sph_params* p, sph_step_stats* outs)

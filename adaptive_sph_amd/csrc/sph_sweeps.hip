@@ -1587,30 +1587,37 @@ struct OpLevelSmoothT {
 };
 
 // LevelEstimationState::target_mass + classify_particle (simulation.rs:213-237, adaptivity/mod.rs:32-59)
-__global__ __launch_bounds__(256) void k_classify(uint32_t n, const float4* __restrict__ pm, const float* __restrict__ level,
-                                                   uint8_t* __restrict__ size_class, float max_surface_distance, float rest_density,
-                                                   int sizing_function, float radius_fine, float radius_base)
+__device__ __forceinline__ float level_target_mass(float lv, float max_surface_distance, float rest_density, int sizing_function, float radius_fine,
+                                                   float radius_base)
 {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const float lv = level[i];
-    if (isnan(lv)) return;   // unreachable!() in the reference: every particle has a value after smoothing
     const float lvl = fmaxf(lv, -max_surface_distance);
     const float interp = lvl / -max_surface_distance;
     // DimensionUtils2d::radius_to_sphere_volume (sph_kernels.rs:208-211): PI * r^2
     const float mass_fine = (SPH_PI_F * radius_fine * radius_fine) * rest_density;
     const float mass_base = (SPH_PI_F * radius_base * radius_base) * rest_density;
-    float target;
-    if (sizing_function == SPH_SIZING_MASS) {
-        target = mass_fine * (1.f - interp) + mass_base * interp;
-    } else if (sizing_function == SPH_SIZING_RADIUS) {
+    if (sizing_function == SPH_SIZING_MASS) return mass_fine * (1.f - interp) + mass_base * interp;
+    if (sizing_function == SPH_SIZING_RADIUS) {
         const float r = radius_fine * (1.f - interp) + radius_base * interp;
-        target = (SPH_PI_F * r * r) * rest_density;
-    } else {
-        const float e = 1.f / 2.f;
-        const float r = radius_fine * (1.f - powf(interp, e)) + radius_base * powf(interp, e);
-        target = (SPH_PI_F * r * r) * rest_density;
+        return (SPH_PI_F * r * r) * rest_density;
     }
+    const float e = 1.f / 2.f;
+    const float r = radius_fine * (1.f - powf(interp, e)) + radius_base * powf(interp, e);
+    return (SPH_PI_F * r * r) * rest_density;
+}
+
+__global__ __launch_bounds__(256) void k_classify(uint32_t n, const float4* __restrict__ pm, const float* __restrict__ level,
+                                                   uint8_t* __restrict__ size_class, const uint8_t* __restrict__ owned,
+                                                   const uint32_t* __restrict__ orig, DeviceStatus* status, float max_surface_distance,
+                                                   float rest_density, int sizing_function, float radius_fine, float radius_base)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n || (owned && !owned[i])) return;
+    const float lv = level[i];
+    if (isnan(lv)) {   // LevelEstimationState::level() of FluidInterior: unreachable!()
+        raise_error(status, SPH_ERR_INVALID_ARGUMENT, orig[i]);
+        return;
+    }
+    const float target = level_target_mass(lv, max_surface_distance, rest_density, sizing_function, radius_fine, radius_base);
     const float mrel = pm[i].z / target;
     uint8_t cls;
     if (mrel <= 0.5f) cls = 0;
@@ -2243,10 +2250,11 @@ void launch_level_smooth(hipStream_t s, Profiler* prof, const SweepArgs& a, cons
     SPH_DISPATCH(OpLevelSmooth, false, a.pm, nullptr, 2.f, pm_new, a.orig, a.mrho, in, out, l.level_old, a.status, l.max_surface_distance)
 }
 
-void launch_classify(hipStream_t s, Profiler* prof, const SweepArgs& a, const LevelArgs& l, const float* level, const sph_params* p)
+void launch_classify(hipStream_t s, Profiler* prof, uint32_t n, const float4* pm, const float* level, uint8_t* size_class, const uint8_t* owned,
+                     const uint32_t* orig, DeviceStatus* status, const sph_params* p)
 {
     ProfScope ps(prof, "classify", s);
-    if (a.n)
-        hipLaunchKernelGGL(k_classify, dim3((a.n + 255) / 256), dim3(256), 0, s, a.n, a.pm, level, l.size_class, p->maximum_surface_distance,
+    if (n)
+        hipLaunchKernelGGL(k_classify, dim3((n + 255) / 256), dim3(256), 0, s, n, pm, level, size_class, owned, orig, status, p->maximum_surface_distance,
                            p->rest_density, p->sizing_function, p->particle_radius_fine, p->particle_radius_base);
 }

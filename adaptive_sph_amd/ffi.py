@@ -49,7 +49,7 @@ STATUS_NAMES = {
     13: "SPH_ERR_AII_NEGATIVE", 14: "SPH_ERR_AP_NOT_FINITE", 15: "SPH_ERR_PRESSURE_NOT_FINITE",
     16: "SPH_ERR_TOO_MANY_NEIGHBORS", 17: "SPH_ERR_VELOCITY_NOT_FINITE", 18: "SPH_ERR_POSITION_NOT_FINITE",
     19: "SPH_ERR_VISCOSITY_NOT_FINITE", 20: "SPH_ERR_XSPH_TODO", 21: "SPH_ERR_CHECK_NEIGHBORHOOD",
-    22: "SPH_ERR_CHECK_AII", 23: "SPH_ERR_LEVEL_WEIGHT", 24: "SPH_ERR_VOLUME_ESTIMATE", 25: "SPH_ERR_CONSTRAIN_NOT_SMALLER", 26: "SPH_ERR_CONSTRAIN_NEGATIVE", 30: "SPH_ERR_UNSUPPORTED",
+    22: "SPH_ERR_CHECK_AII", 23: "SPH_ERR_LEVEL_WEIGHT", 24: "SPH_ERR_VOLUME_ESTIMATE", 25: "SPH_ERR_CONSTRAIN_NOT_SMALLER", 26: "SPH_ERR_CONSTRAIN_NEGATIVE", 30: "SPH_ERR_UNSUPPORTED", 31: "SPH_ERR_POISONED",
 }
 
 
@@ -125,7 +125,7 @@ class SphError(RuntimeError):
 # every symbol include/sph_ffi.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
     "create", "destroy", "upload", "upload_field", "download", "download_neighbors", "num_particles", "time",
-    "set_time", "step", "last_error", "grid", "set_boundary_polygon", "apply_edits", "profile_enable", "profile_reset", "profile_get", "profile_event_overhead", "profile_copy_bandwidth",
+    "set_time", "step", "classify", "last_error", "grid", "set_boundary_polygon", "apply_edits", "profile_enable", "profile_reset", "profile_get", "profile_event_overhead", "profile_copy_bandwidth",
     "dist_configure", "dist_set_rebalance", "dist_get_cuts", "comm_unique_id", "comm_init", "group_step",
 ]
 
@@ -167,6 +167,7 @@ class SphLibrary:
         self.time = sig("time", C.c_float, [vp])
         self.set_time = sig("set_time", i32, [vp, C.c_float, u64])
         self.step = sig("step", i32, [vp, C.POINTER(SphParams), C.POINTER(SphStepStats)])
+        self.classify = sig("classify", i32, [vp, C.POINTER(SphParams)])
         self.last_error = sig("last_error", C.c_char_p, [vp])
         self.grid = sig("grid", i32, [vp, C.POINTER(SphGridInfo)])
         # product-only entry points (the oracle has no device, profiler or communicator)
@@ -315,6 +316,10 @@ class Context:
         st = SphStepStats()
         self._check(self.lib.step(self.handle, C.byref(params), C.byref(st)))
         return st
+
+    def classify(self, params: SphParams) -> None:
+        """classify_particles (adaptivity/mod.rs:50-59): the host's call, never part of the step."""
+        self._check(self.lib.classify(self.handle, C.byref(params)))
 
     def grid(self) -> SphGridInfo:
         g = SphGridInfo()

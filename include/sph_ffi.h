@@ -147,7 +147,8 @@ enum {
     SPH_F_STASH = 15,          /* f32[n]   */
     SPH_F_FLAG_IS_FLUID_SURFACE = 16,     /* u8[n] */
     SPH_F_FLAG_INSUFFICIENT_NEIGHS = 17,  /* u8[n] */
-    SPH_F_PARTICLE_SIZE_CLASS = 18,       /* u8[n]: adaptivity/mod.rs:12-23 order */
+    SPH_F_PARTICLE_SIZE_CLASS = 18,       /* u8[n]: adaptivity/mod.rs:12-23 order; default Optimal (simulation.rs:318).  Written only by
+                                           * sph_classify (the step never classifies, like single_step_without_adaptivity) or uploaded */
     /* BoundaryWinchenbach2020.lambda folded per particle (boundary_winchenbach2020.rs:27):
      * sum of lambda and sum of grad-lambda over the planes -- all downstream uses are linear */
     SPH_F_LAMBDA_SUM = 19,     /* f32[n]   */
@@ -186,7 +187,8 @@ enum {
     SPH_ERR_VOLUME_ESTIMATE = 24,       /* sim.rs:1903-1909, 1961  volume_estimate >= 0 */
     SPH_ERR_CONSTRAIN_NOT_SMALLER = 25, /* sim.rs:2163  *p_h_next < smoothing_length_single(h2, i) */
     SPH_ERR_CONSTRAIN_NEGATIVE = 26,    /* sim.rs:2165  *p_h_next >= 0 */
-    SPH_ERR_UNSUPPORTED = 30            /* a SimulationParams combination this build does not cover */
+    SPH_ERR_UNSUPPORTED = 30,           /* a SimulationParams combination this build does not cover */
+    SPH_ERR_POISONED = 31               /* an earlier step failed inside the step: state undefined until sph_upload */
 };
 
 typedef struct sph_ctx sph_ctx;
@@ -268,8 +270,22 @@ int      sph_set_time(sph_ctx* ctx, float time, uint64_t step_number);
 
 /* ---- THE hot path ---------------------------------------------------------------------------
  * sph_step  <->  single_step_without_adaptivity (sim.rs:1980-2730).  Synchronous: returns after
- * dt and the statistics are on the host.  `out` may be NULL. */
+ * dt and the statistics are on the host.  `out` may be NULL.
+ * A non-zero status that comes from a guard INSIDE the step (the reference panics there and its caller drops the
+ * simulation, main_loop.rs:300-311) leaves the particle state undefined -- velocities may be advanced and positions not:
+ * the context is then POISONED: sph_step / sph_group_step / sph_apply_edits and the adaptivity entry points return
+ * SPH_ERR_POISONED until sph_upload replaces the particle set; downloads still work (diagnostics).  Refusals taken before
+ * anything is launched (SPH_ERR_INVALID_ARGUMENT, SPH_ERR_NO_BOUNDARY, SPH_ERR_UNSUPPORTED for a parameter combination)
+ * leave the context as it was. */
 int  sph_step(sph_ctx* ctx, const sph_params* params, sph_step_stats* out);
+
+/* classify_particles (adaptivity/mod.rs:50-59): particle_size_class from LevelEstimationState::target_mass
+ * (simulation.rs:213-237) and the thresholds 0.5, 1/1.1, 1.1, 2.  The reference calls it from single_step_adaptivity only
+ * (simulation.rs:2749, 2764, 2778), never from the step: IISPH2's omega (simulation.rs:2277-2288) therefore reads whatever
+ * the last adaptivity pass left behind (Optimal if there never was one).  Reads params->maximum_surface_distance,
+ * rest_density, sizing_function, particle_radius_fine / _base.  A particle without a level value (FluidInterior) is
+ * `unreachable!()` in the reference: SPH_ERR_INVALID_ARGUMENT here. */
+int  sph_classify(sph_ctx* ctx, const sph_params* params);
 
 /* Message for the last non-zero status of this context (what the Rust shim puts in panic!). */
 const char* sph_last_error(const sph_ctx* ctx);

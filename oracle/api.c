@@ -269,6 +269,12 @@ int oracle_step(oracle_ctx* c, const sph_params* p, sph_step_stats* out)
     return orc_step(c, p, out);
 }
 
+int oracle_classify(oracle_ctx* c, const sph_params* p)
+{
+    if (!c || !p) return SPH_ERR_INVALID_ARGUMENT;
+    return orc_classify_particles(c, p);
+}
+
 const char* oracle_last_error(const oracle_ctx* c) { return c ? c->err : "null context"; }
 
 int oracle_grid(const oracle_ctx* c, sph_grid_info* out)

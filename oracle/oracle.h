@@ -75,6 +75,7 @@ void orc_cell_indices(oracle_ctx* c);                 /* CellGrid convention, ce
 
 /* step.c */
 int orc_step(oracle_ctx* c, const sph_params* p, sph_step_stats* out);
+int orc_classify_particles(oracle_ctx* c, const sph_params* p); /* adaptivity/mod.rs:50-59 */
 
 int orc_fail(oracle_ctx* c, int code, const char* fmt, ...);
 

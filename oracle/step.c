@@ -807,11 +807,12 @@ static int smooth_level_estimation_field(oracle_ctx* c, const sph_params* p)
 }
 
 /* LevelEstimationState::target_mass + classify_particle (simulation.rs:213-237, adaptivity/mod.rs:32-59) */
-static void classify_particles(oracle_ctx* c, const sph_params* p)
+int orc_classify_particles(oracle_ctx* c, const sph_params* p)
 {
-    if (p->level_estimation_method == SPH_LEVEL_NONE) return;
     for (uint64_t i = 0; i < c->n; i++) {
-        if (!lvl_is_surface(c->level[i])) continue; /* unreachable!() in the reference */
+        if (!lvl_is_surface(c->level[i])) /* LevelEstimationState::level() of FluidInterior (simulation.rs:205-211) */
+            return orc_fail(c, SPH_ERR_INVALID_ARGUMENT, "internal error: entered unreachable code (LevelEstimationState::level of FluidInterior), particle i=%llu",
+                            (unsigned long long)i);
         float level = fmaxf(c->level[i], -p->maximum_surface_distance);
         float interp = level / -p->maximum_surface_distance;
         float target;
@@ -835,6 +836,7 @@ static void classify_particles(oracle_ctx* c, const sph_params* p)
         else cls = 4;
         c->size_class[i] = cls;
     }
+    return SPH_OK;
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -1111,7 +1113,7 @@ int orc_step(oracle_ctx* c, const sph_params* p, sph_step_stats* out)
     t0 = omp_get_wtime();
     if ((rc = smooth_level_estimation_field(c, p))) return rc;
     ms_level += (omp_get_wtime() - t0) * 1e3;
-    classify_particles(c, p);
+    /* (classify_particles is NOT part of the step: only single_step_adaptivity calls it, simulation.rs:2749-2778) */
 
     c->time += dt;
     c->step_number += 1;

@@ -118,6 +118,7 @@ def main():
                     msgs.append(f"step {step}: level NaN pattern differs")
                 elif np.nanmax(np.abs(a - b)) > 1e-4 * max(np.nanmax(np.abs(b)), 1e-30):
                     msgs.append(f"step {step}: level differs by {np.nanmax(np.abs(a - b)):.2e}")
+                g.classify(p), o.classify(p)
                 ca, cb = g.download("particle_size_class"), o.download("particle_size_class")
                 if (ca != cb).mean() > 2e-3:
                     msgs.append(f"step {step}: {(ca != cb).sum()} size classes differ")

@@ -155,6 +155,10 @@ def test_level_estimation_on_slabs(product_lib, k):
         a, b = D.gather_by_id(grp, f, n), single.download(f)
         assert np.array_equal(np.isnan(a), np.isnan(b)), f
         assert np.nanmax(np.abs(a - b)) <= 1e-4 * max(np.nanmax(np.abs(b)), 1e-30), f
+    single.classify(p)
+    for c in grp:
+        c.classify(p)
+    assert len(np.unique(single.download("particle_size_class"))) > 1
     assert (D.gather_by_id(grp, "particle_size_class", n) != single.download("particle_size_class")).mean() < 1e-3
     for f, tol in (("position", 1e-5), ("velocity", 1e-4), ("density", 1e-5)):
         assert rel_err(D.gather_by_id(grp, f, n), single.download(f)) <= tol, f

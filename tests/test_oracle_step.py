@@ -99,8 +99,10 @@ def test_level_estimation_default_config(oracle_lib):
     assert np.all(np.isfinite(lvl)) and np.all(lvl <= 1e-6)     # smoothed level set: everyone has a distance <= 0
     surf = c.download("flag_is_fluid_surface")
     assert 0 < surf.sum() < len(mass)
+    assert (c.download("particle_size_class") == 2).all()    # the step never classifies (simulation.rs:2749-2778): default Optimal
+    c.classify(p)
     cls = c.download("particle_size_class")
-    assert set(np.unique(cls)) <= {0, 1, 2, 3, 4}
+    assert set(np.unique(cls)) <= {0, 1, 2, 3, 4} and len(np.unique(cls)) > 1
 
 
 def _edit_script(rng, n):
