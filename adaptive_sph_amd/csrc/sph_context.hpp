@@ -43,6 +43,7 @@ struct sph_ctx {
     BoundaryP bnd_h{};   // planes, or one Sdf2D polygon (sph_set_boundary_polygon)
     float time = 0.f;
     uint64_t step_number = 0;
+    uint64_t n_waits = 0;    // host waits on the device since the last sph_dist_get_stats(reset)
     bool poisoned = false;   // a guard fired inside a step: state undefined until sph_upload (sph_ffi.h)
     std::string err;
     Profiler prof;
@@ -91,6 +92,7 @@ struct sph_ctx {
         int rebalance_every = 0;     // move the cuts to equal particle counts every so many steps (0: static cuts)
         DevBuf hist;                 // x histogram of the owned particles (rebalancing)
         uint32_t rebalances = 0;     // how often the cuts moved
+        uint64_t stat_exchanges = 0, stat_bytes_sent = 0, stat_bytes_recv = 0, stat_allreduces = 0, stat_step0 = 0;   // sph_dist_get_stats
     } dist;
 
     GridP grid{};

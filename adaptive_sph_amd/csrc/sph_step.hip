@@ -123,6 +123,7 @@ static int wait_hinted(sph_ctx* c)
 int wait_stream(sph_ctx* c)
 {
     c->hint_word = nullptr;
+    c->n_waits++;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipEventRecord(c->ev_sync, c->stream));
     auto t0 = std::chrono::steady_clock::now();
@@ -141,6 +142,7 @@ static int wait_word(sph_ctx* c, volatile uint32_t* word, uint32_t want)
 {
     static const bool event_wait = getenv("SPH_EVENT_WAIT") != nullptr;
     if (event_wait) return wait_stream(c);
+    c->n_waits++;
     auto t0 = std::chrono::steady_clock::now();
     for (uint64_t spins = 0; *word != want; spins++) {
         if ((spins & 0xffffu) == 0xffffu && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 2.0)
@@ -551,6 +553,9 @@ struct LocalComm : Comm {
             return G.m[0]->fail(SPH_ERR_DEVICE, "halo exchange across the outer edge of the slab row");
         for (size_t i = 0; i < n; i++) {
             sph_ctx* c = G.m[i];
+            c->dist.stat_exchanges++;
+            c->dist.stat_bytes_sent += x[i].send_bytes[0] + x[i].send_bytes[1];
+            c->dist.stat_bytes_recv += x[i].recv_bytes[0] + x[i].recv_bytes[1];
             HIPCHK(c, hipSetDevice(c->device));
             if (i > 0 && x[i].recv_bytes[0]) HIPCHK(c, hipMemcpyAsync(x[i].recv[0], x[i - 1].send[1], x[i].recv_bytes[0], hipMemcpyDefault, c->stream));
             if (i + 1 < n && x[i].recv_bytes[1]) HIPCHK(c, hipMemcpyAsync(x[i].recv[1], x[i + 1].send[0], x[i].recv_bytes[1], hipMemcpyDefault, c->stream));
@@ -590,7 +595,11 @@ struct RcclComm : Comm {
         if (bytes > 128) return c->fail(SPH_ERR_INVALID_ARGUMENT, "host all-reduce of %zu bytes", bytes);
         memcpy(stage, host, bytes);
         HIPCHK(c, hipMemcpyAsync(d, stage, bytes, hipMemcpyHostToDevice, c->stream));
-        NCCLCHK(c, ncclAllReduce(d, d, count, dt, op, nc, c->stream));
+        c->dist.stat_allreduces++;
+        {
+            ProfScope ps(&c->prof, "rccl_allreduce", c->stream);
+            NCCLCHK(c, ncclAllReduce(d, d, count, dt, op, nc, c->stream));
+        }
         int rc = publish_and_wait(c, d, (uint32_t)((bytes + 3) / 4));
         if (rc) return rc;
         memcpy(host, stage, bytes);
@@ -647,6 +656,10 @@ struct RcclComm : Comm {
         sph_ctx* c = G.m[0];
         ncclComm_t nc = (ncclComm_t)c->dist.nccl;
         const int r = c->dist.rank, nr = c->dist.nranks;
+        c->dist.stat_exchanges++;
+        c->dist.stat_bytes_sent += (r > 0 ? x[0].send_bytes[0] : 0) + (r + 1 < nr ? x[0].send_bytes[1] : 0);
+        c->dist.stat_bytes_recv += (r > 0 ? x[0].recv_bytes[0] : 0) + (r + 1 < nr ? x[0].recv_bytes[1] : 0);
+        ProfScope ps(&c->prof, "rccl_sendrecv", c->stream);
         NCCLCHK(c, ncclGroupStart());
         if (r > 0) {
             if (x[0].send_bytes[0]) NCCLCHK(c, ncclSend(x[0].send[0], x[0].send_bytes[0], ncclChar, r - 1, nc, c->stream));
@@ -662,6 +675,8 @@ struct RcclComm : Comm {
     int allreduce_solver(Group& G) override
     {
         sph_ctx* c = G.m[0];
+        c->dist.stat_allreduces++;
+        ProfScope ps(&c->prof, "rccl_allreduce", c->stream);
         NCCLCHK(c, ncclAllReduce(c->dist.solver_tot.p, c->dist.solver_tot.p, 4, ncclFloat64, ncclSum, (ncclComm_t)c->dist.nccl, c->stream));
         return SPH_OK;
     }
@@ -1938,6 +1953,30 @@ extern "C" int sph_dist_get_cuts(sph_ctx* c, float* cut_lo, float* cut_hi, uint3
     if (cut_lo) *cut_lo = c->dist.cut_lo;
     if (cut_hi) *cut_hi = c->dist.cut_hi;
     if (n_rebalances) *n_rebalances = c->dist.rebalances;
+    return SPH_OK;
+}
+
+extern "C" int sph_dist_get_stats(sph_ctx* c, sph_dist_stats* out, int reset)
+{
+    if (!c || !out) return SPH_ERR_INVALID_ARGUMENT;
+    auto& d = c->dist;
+    memset(out, 0, sizeof(*out));
+    out->steps = c->step_number - d.stat_step0;
+    out->exchanges = d.stat_exchanges;
+    out->bytes_sent = d.stat_bytes_sent;
+    out->bytes_received = d.stat_bytes_recv;
+    out->allreduces = d.stat_allreduces;
+    out->host_waits = c->n_waits;
+    out->n_owned = c->n;
+    out->n_halo[0] = d.n_halo[0];
+    out->n_halo[1] = d.n_halo[1];
+    out->n_ghost[0] = d.n_ghost[0];
+    out->n_ghost[1] = d.n_ghost[1];
+    if (reset) {
+        d.stat_exchanges = d.stat_bytes_sent = d.stat_bytes_recv = d.stat_allreduces = 0;
+        d.stat_step0 = c->step_number;
+        c->n_waits = 0;
+    }
     return SPH_OK;
 }
 

@@ -114,6 +114,12 @@ class SphKernelTime(C.Structure):
                 ("working_launches", C.c_uint64), ("working_ms", C.c_double)]
 
 
+class SphDistStats(C.Structure):
+    _fields_ = [("steps", C.c_uint64), ("exchanges", C.c_uint64), ("bytes_sent", C.c_uint64), ("bytes_received", C.c_uint64),
+                ("allreduces", C.c_uint64), ("host_waits", C.c_uint64), ("n_owned", C.c_uint64), ("n_halo", C.c_uint32 * 2),
+                ("n_ghost", C.c_uint32 * 2)]
+
+
 class SphError(RuntimeError):
     """Non-zero status from the library == a panic!/assert! of the reference step."""
 
@@ -126,7 +132,7 @@ class SphError(RuntimeError):
 ABI_SYMBOLS = [
     "create", "destroy", "upload", "upload_field", "download", "download_neighbors", "num_particles", "time",
     "set_time", "step", "classify", "last_error", "grid", "set_boundary_polygon", "apply_edits", "profile_enable", "profile_reset", "profile_get", "profile_event_overhead", "profile_copy_bandwidth",
-    "dist_configure", "dist_set_rebalance", "dist_get_cuts", "comm_unique_id", "comm_init", "group_step",
+    "dist_configure", "dist_set_rebalance", "dist_get_cuts", "dist_get_stats", "comm_unique_id", "comm_init", "group_step",
 ]
 
 
@@ -182,6 +188,7 @@ class SphLibrary:
         self.group_step = sig("group_step", i32, [C.POINTER(vp), i32, C.POINTER(SphParams), C.POINTER(SphStepStats)], required=False)
         self.dist_set_rebalance = sig("dist_set_rebalance", i32, [vp, i32], required=False)
         self.dist_get_cuts = sig("dist_get_cuts", i32, [vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_uint32)], required=False)
+        self.dist_get_stats = sig("dist_get_stats", i32, [vp, C.POINTER(SphDistStats), i32], required=False)
 
 
 _PRODUCT = None
@@ -369,6 +376,14 @@ class Context:
         lo, hi, k = C.c_float(), C.c_float(), C.c_uint32()
         self._check(self.lib.dist_get_cuts(self.handle, C.byref(lo), C.byref(hi), C.byref(k)))
         return lo.value, hi.value, k.value
+
+    def dist_get_stats(self, reset: bool = False) -> dict:
+        """Communication counters of this rank since the last reset (sph_dist_stats)."""
+        st = SphDistStats()
+        self._check(self.lib.dist_get_stats(self.handle, C.byref(st), 1 if reset else 0))
+        return {"steps": int(st.steps), "exchanges": int(st.exchanges), "bytes_sent": int(st.bytes_sent), "bytes_received": int(st.bytes_received),
+                "allreduces": int(st.allreduces), "host_waits": int(st.host_waits), "n_owned": int(st.n_owned),
+                "n_halo": [int(st.n_halo[0]), int(st.n_halo[1])], "n_ghost": [int(st.n_ghost[0]), int(st.n_ghost[1])]}
 
     def comm_init(self, unique_id: bytes, rank: int, n_ranks: int):
         buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)

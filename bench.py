@@ -4,9 +4,13 @@
   python bench.py [--gpus N] [--steps K] [--warmup W] [--workload dam_break_1m]
 
 A "step" is one `sph_step` (= single_step_without_adaptivity, simulation.rs:1980-2730) over the whole
-particle set, inputs resident in HBM.  N=1 runs BASELINE.json configs[1] (2D dam-break, 1 048 576
-uniform-h particles, HybridDFSPH).  For N>1 the driver launches one rank per GPU through
-torch.distributed.run; the particle set is split into x-slabs (one per rank, RCCL halo exchange).
+particle set, inputs resident in HBM.  Every N runs BASELINE.json configs[1] (2D dam-break, 1 048 576
+uniform-h particles, HybridDFSPH): for N>1 the driver launches one rank per GPU through
+torch.distributed.run and the SAME particle set is split into x-slabs (one per rank, RCCL halo exchange) --
+STRONG scaling, the experiment north_star names ("N=1M at 1, 2, 4 and 8 GPUs").  north_star's second target,
+>= 6x from 1 to 8 GPUs at N=8M, is measured in the same invocation on configs[3] (8 386 816 particles) and
+reported under "strong_8m" at every N (at N=1: the whole scene on one GPU).  --scaling weak keeps last
+round's ~1M-particles-per-GPU series as a side experiment.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   roofline      dominant neighbour sweep by time share: algorithmic bytes / HIP-event launch time vs 8 TB/s HBM
@@ -69,6 +73,8 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--profile-steps", type=int, default=20)
     ap.add_argument("--no-extra", action="store_true", help="skip the short runs of the other single-GPU BASELINE configs")
+    ap.add_argument("--no-8m", action="store_true", help="skip the strong-scaling leg on configs[3] (8.4M particles)")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
     return ap.parse_args()
 
 
@@ -160,21 +166,12 @@ def main():
         dist.barrier()
     plib = ffi.load_product()
 
-    # weak scaling, ~1M particles per GPU: configs[1] at N=1 ... configs[3] (8M) at N=8
-    wl = args.workload or {1: "dam_break_1m", 2: "dam_break_2m", 4: "dam_break_4m"}.get(world, "dam_break_8m")
+    # strong scaling: the metric's workload (configs[1], 1M particles) at every N.  (--scaling weak: ~1M particles per GPU,
+    # configs[1] at N=1 ... configs[3] (8M) at N=8 -- a side experiment.)
+    weak_wl = {1: "dam_break_1m", 2: "dam_break_2m", 4: "dam_break_4m"}.get(world, "dam_break_8m")
+    wl = args.workload or (weak_wl if args.scaling == "weak" else "dam_break_1m")
     scene_f, params_f, desc = WORKLOADS[wl]
     scene, params = scene_f(), params_f()
-    pos, mass, vel = sc.init_particles(scene)
-    planes = sc.boundary_planes(scene.boundary)
-    n_total = len(mass)
-
-    if distributed:
-        from adaptive_sph_amd.distributed import make_slab_context
-        ctx = make_slab_context(plib, pos, mass, vel, planes, rank, world, local_rank)
-    else:
-        ctx = ffi.Context(plib, n_total, planes, device_id=local_rank)
-        ctx.upload(mass, pos, vel)
-    p = params.to_ffi()
 
     def barrier():
         torch.cuda.synchronize()
@@ -182,32 +179,58 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    # warm-up = steps 0..W-1 from rest (SURVEY.md section 8d also wants them reported: the rest lattice).  Timed on the side,
-    # never part of `value`.
-    if torch.cuda.is_available():
-        torch.cuda.synchronize()
-    t_w0 = time.perf_counter()
-    for _ in range(args.warmup):
-        ctx.step(p)
-    warmup_elapsed = time.perf_counter() - t_w0
+    def make_context(scn, P):
+        pos, mass, vel = sc.init_particles(scn)
+        planes = sc.boundary_planes(scn.boundary, P.init_boundary_handler)
+        if distributed:
+            from adaptive_sph_amd.distributed import make_slab_context
+            c = make_slab_context(plib, pos, mass, vel, planes, rank, world, local_rank)
+        else:
+            c = ffi.Context(plib, len(mass), planes, device_id=local_rank)
+            c.upload(mass, pos, vel)
+        return c, len(mass)
 
-    # ---- timed region: exactly K steps, uninstrumented.  (Recording ANY timing-enabled HIP event switches the
-    # ROCm queue into per-dispatch profiling for the rest of the process: +~8 us per launch, +0.38 ms per step
-    # here -- measured -- so the per-kernel HIP-event timings below come from an instrumented pass that
-    # continues the same workload right after the timed region; `value` is never taken from it.)
-    div_iters, dens_iters = [], []
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        st = ctx.step(p)
-        div_iters.append(int(st.div_solver.iters) + 1)
-        dens_iters.append(int(st.density_solver.iters) + 1)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if distributed:
-        tt = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    def timed_run(c, p, warmup, steps):
+        """W untimed warm-up steps, then EXACTLY K steps between barriers; the MAX over ranks of the elapsed time."""
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        t_w0 = time.perf_counter()
+        for _ in range(warmup):
+            c.step(p)
+        warm = time.perf_counter() - t_w0
+        c.dist_get_stats(reset=True)
+        div_it, dens_it = [], []
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            st = c.step(p)
+            div_it.append(int(st.div_solver.iters) + 1)
+            dens_it.append(int(st.density_solver.iters) + 1)
+        barrier()
+        el = time.perf_counter() - t0
+        if distributed:
+            tt = torch.tensor([el], device="cuda", dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        return el, warm, div_it, dens_it, c.dist_get_stats()
+
+    def comm_record(stats, steps):
+        """what this rank put on the wire per step (sph_dist_get_stats): latency-bound messages, so count and size both matter"""
+        k = max(steps, 1)
+        return {"exchanges_per_step": stats["exchanges"] / k, "allreduces_per_step": stats["allreduces"] / k,
+                "halo_bytes_sent_per_step": stats["bytes_sent"] / k, "halo_bytes_received_per_step": stats["bytes_received"] / k,
+                "host_waits_per_step": stats["host_waits"] / k, "owned_particles": stats["n_owned"],
+                "ghost_particles": stats["n_ghost"], "halo_particles": stats["n_halo"], "rank": rank}
+
+    ctx, n_total = make_context(scene, params)
+    p = params.to_ffi()
+
+    # ---- timed region: warm-up = steps 0..W-1 from rest (SURVEY.md section 8d also wants them reported: the rest lattice;
+    # timed on the side, never part of `value`), then exactly K steps, uninstrumented.  (Recording ANY timing-enabled HIP
+    # event switches the ROCm queue into per-dispatch profiling for the rest of the process: +~8 us per launch, +0.38 ms per
+    # step here -- measured -- so the per-kernel HIP-event timings below come from an instrumented pass that continues the same
+    # workload right after the timed region; `value` is never taken from it.)
+    elapsed, warmup_elapsed, div_iters, dens_iters, comm_stats = timed_run(ctx, p, args.warmup, args.steps)
 
     n_local = ctx.n
 
@@ -225,6 +248,20 @@ def main():
         ev_overhead_us = ctx.profile_event_overhead_us()
         ctx.profile_enable(0)
     copy_gbs = ctx.profile_copy_bandwidth_gbs(1 << 30) if rank == 0 else 0.0   # achievable HBM rate of this device, same run
+    ctx.close()
+
+    # ---- north_star's second strong-scaling target: configs[3], 8.4M particles, same K / W, same protocol -------------------
+    strong_8m = None
+    if not args.no_8m and wl == "dam_break_1m":
+        s8, p8f, d8 = WORKLOADS["dam_break_8m"]
+        P8 = p8f()
+        c8, n8 = make_context(s8(), P8)
+        el8, _, di8, de8, st8 = timed_run(c8, P8.to_ffi(), args.warmup, args.steps)
+        strong_8m = {"workload": f"dam_break_8m: {d8}", "particles": n8, "value": n8 * args.steps / el8, "unit": "particle-steps/s",
+                     "ms_per_step": el8 * 1e3 / args.steps, "steps": args.steps, "warmup": args.warmup, "n_gpus": world, "scaling": "strong",
+                     "mean_div_iterations": float(np.mean(di8)), "mean_density_iterations": float(np.mean(de8)),
+                     "comm_rank0": comm_record(st8, args.steps) if distributed else None}
+        c8.close()
 
     if rank != 0:
         if distributed:
@@ -238,12 +275,13 @@ def main():
         if not launches or name not in ALGO_BYTES:
             return None
         raw_us = total_ms * 1e3 / launches
-        avg_s = max(raw_us - ev_overhead_us, 1e-3) * 1e-6
+        avg_s = raw_us * 1e-6   # the HIP-event bracket as it is: it also holds the ~1-5 us an event pair adds (`event_overhead_us`,
+                                # reported, NOT subtracted), so `frac` errs low; rocprofv3's duration for the same kernel is in profiles/
         achieved = ALGO_BYTES[name] * n_local / avg_s / 1e9
         traffic, src = committed_pmc_traffic(name) if wl == "dam_break_1m" and not distributed else (None, None)
         return {"kernel": name, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src, "avg_us": avg_s * 1e6,
-                "avg_us_hip_events": raw_us, "event_overhead_us": ev_overhead_us, "launches_timed": launches,
+                "avg_us_minus_event_overhead": raw_us - ev_overhead_us, "event_overhead_us": ev_overhead_us, "launches_timed": launches,
                 "copy_kernel_GBs": copy_gbs, "frac_of_copy_kernel": (achieved / copy_gbs) if copy_gbs else None,
                 "algorithmic_bytes_per_particle": ALGO_BYTES[name], "algorithmic_bytes_per_launch": ALGO_BYTES[name] * n_local}
 
@@ -262,7 +300,8 @@ def main():
     roofline_density = roof("density", *prof_work["density"]) if "density" in prof_work else None
     timing_note = (f"HIP events on the library's stream, instrumented pass of {args.profile_steps} steps continuing the same "
                    f"workload right after the timed region (events perturb dispatch, so the timed region is uninstrumented); "
-                   f"avg_us = event time of the working launches - what an event pair adds (sph_profile_event_overhead)")
+                   f"avg_us = event time of the launches that did work, nothing subtracted; `traffic` is not measured in this run: "
+                   f"it is the FETCH_SIZE x2 + WRITE_SIZE figure of the rocprofv3 --pmc passes summarised in `traffic_source`")
     for r in (roofline, roofline_density):
         if r:
             r["timing"] = timing_note
@@ -274,7 +313,7 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed * 1e3 / args.steps,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": args.scaling,
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
@@ -284,14 +323,25 @@ def main():
         "roofline": roofline,
         "roofline_density": roofline_density,
         "kernels": kernels,
+        "strong_8m": strong_8m,
+        "comm_rank0": comm_record(comm_stats, args.steps) if distributed else {"host_waits_per_step": comm_stats["host_waits"] / max(args.steps, 1)},
     }
+    if distributed:   # time inside RCCL per step, from the instrumented pass (HIP events around the grouped send/recv and the all-reduces)
+        out["comm_rank0"]["rccl_us_per_step_instrumented"] = {
+            k: prof_all[k][1] * 1e3 / max(args.profile_steps, 1) for k in ("rccl_sendrecv", "rccl_allreduce") if k in prof_all}
     # whole-step algorithmic bytes B_step = 388 + 100 (n_div + n_dens) B per particle-step with the
     # iteration counts of the timed steps (sweeps only; the neighbour build is listed apart), and the steps from rest
     b_step = 388.0 + 100.0 * (float(np.mean(div_iters)) + float(np.mean(dens_iters)))
     step_gbs = b_step * n_total * args.steps / elapsed / 1e9
+    # iteration 0 of each solve is evaluated in closed form inside the source-term sweep (p = 0 => a^p = 0, Ap = 0): its two
+    # sweeps never run, so the figure WITHOUT their 100 B each is what the launched kernels were asked to move
+    n_solves = 2 if params.pressure_solver_method == "HybridDFSPH" else 1
+    step_gbs_launched = (b_step - 100.0 * n_solves) * n_total * args.steps / elapsed / 1e9
     out["whole_step"] = {
         "algorithmic_bytes_per_particle_step": b_step,
         "achieved_GBs": step_gbs, "frac_hbm_peak": step_gbs / (HBM_PEAK_GBS * world),
+        "without_closed_form_iteration_0": {"algorithmic_bytes_per_particle_step": b_step - 100.0 * n_solves, "achieved_GBs": step_gbs_launched,
+                                            "frac_hbm_peak": step_gbs_launched / (HBM_PEAK_GBS * world)},
         # cell keys 16r + 8w; two radix passes of (4r histogram + 8r + 8w scatter); reorder 40r + 40w (value, record, velocity,
         # id, level state); cell-range table 4r
         "neighbour_build_algorithmic_bytes_per_particle": 24 + 2 * 20 + 80 + 4,
@@ -299,10 +349,8 @@ def main():
                             "note": "steps 0..warmup-1 (rest lattice, first launches included); rank 0's clock, not part of `value`"},
     }
     if not args.no_extra and not distributed and wl == "dam_break_1m":
-        ctx.close()
         out["other_configs"] = [
             short_run(plib, "dam_break_1m_adaptive"),                                       # configs[2]: 4:1 radius ratio
-            short_run(plib, "dam_break_8m", steps=20, warmup=10),                            # configs[3] on ONE GPU
             short_run(plib, "ratio_stress_4m", steps=20, warmup=5),                         # configs[4]'s scene (50:1, 4M), no adaptivity
             short_run(plib, "dam_break_1m", steps=20, warmup=20, level_estimation_method="EmptyAngle",
                       maximum_surface_distance=0.2, particle_radius_fine=0.0005, particle_radius_base=0.002),   # + level estimation

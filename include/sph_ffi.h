@@ -336,6 +336,16 @@ int  sph_dist_configure(sph_ctx* ctx, int rank, int n_ranks, float cut_lo, float
  * two ghost layers are not applied.  Set the same value on every rank.  sph_dist_get_cuts reads the current cuts back. */
 int  sph_dist_set_rebalance(sph_ctx* ctx, int every_n_steps);
 int  sph_dist_get_cuts(sph_ctx* ctx, float* cut_lo, float* cut_hi, uint32_t* n_rebalances);
+/* Communication counters of this rank since the last reset (measurement hook, bench.py): neighbour exchanges (one grouped
+ * ncclSend/ncclRecv pair per x-neighbour), bytes through them, all-reduces, host waits on the device (also counted on a plain
+ * context), and the sizes of the current decomposition. */
+typedef struct sph_dist_stats {
+    uint64_t steps, exchanges, bytes_sent, bytes_received, allreduces, host_waits;
+    uint64_t n_owned;
+    uint32_t n_halo[2];    /* owned particles copied to the left / right neighbour as its ghosts */
+    uint32_t n_ghost[2];   /* ghosts received from the left / right neighbour */
+} sph_dist_stats;
+int  sph_dist_get_stats(sph_ctx* ctx, sph_dist_stats* out, int reset);
 int  sph_comm_unique_id(uint8_t id_out[128]);
 int  sph_comm_init(sph_ctx* ctx, const uint8_t id[128], int rank, int n_ranks);
 int  sph_group_step(sph_ctx** ctxs, int n, const sph_params* params, sph_step_stats* outs);

@@ -101,22 +101,30 @@ int oracle_upload(oracle_ctx* c, uint64_t n, const float* mass, const float* pos
     if (!c || (n && (!mass || !pos || !vel))) return SPH_ERR_INVALID_ARGUMENT;
     if (n > c->cap) return orc_fail(c, SPH_ERR_CAPACITY, "n=%llu exceeds capacity %llu", (unsigned long long)n, (unsigned long long)c->cap);
     c->n = n;
-    memcpy(c->mass, mass, n * sizeof(float));
-    memcpy(c->pos, pos, 2 * n * sizeof(float));
-    memcpy(c->vel, vel, 2 * n * sizeof(float));
-    const size_t f = n * sizeof(float);
-    memset(c->vel_tmp, 0, 2 * f); memset(c->pacc, 0, 2 * f); memset(c->density, 0, f); memset(c->source, 0, f);
-    memset(c->pressure, 0, f); memset(c->pressure_next, 0, f); memset(c->aii, 0, f); memset(c->density_error, 0, f);
-    memset(c->h2, 0, f); memset(c->level_old, 0, f); memset(c->constant_field, 0, f); memset(c->stash, 0, f);
-    memset(c->flag_surface, 0, n); memset(c->flag_insufficient, 0, n); memset(c->flag_reduced, 0, n); memset(c->lam_n, 0, n);
-    memset(c->neighbor_count, 0, n * sizeof(uint32_t)); memset(c->cell_index, 0, n * sizeof(uint32_t));
-    memset(c->nb_off, 0, (n + 1) * sizeof(uint64_t));
-    for (uint64_t i = 0; i < n; i++) {
+    /* written by the threads that will read them: pages are placed on first touch, and a 128-core host has several NUMA nodes
+     * (the buffers come from calloc, so nothing has been touched before the first upload) */
+#pragma omp parallel for schedule(static)
+    for (int64_t ii = 0; ii < (int64_t)n; ii++) {
+        const uint64_t i = (uint64_t)ii;
+        c->mass[i] = mass[i];
+        for (int d = 0; d < 2; d++) {
+            c->pos[2 * i + d] = pos[2 * i + d];
+            c->vel[2 * i + d] = vel[2 * i + d];
+            c->vel_tmp[2 * i + d] = 0.f;
+            c->pacc[2 * i + d] = 0.f;
+        }
+        c->density[i] = c->source[i] = c->pressure[i] = c->pressure_next[i] = c->aii[i] = c->density_error[i] = 0.f;
+        c->h2[i] = c->level_old[i] = c->constant_field[i] = c->stash[i] = c->omega[i] = 0.f;
+        c->flag_surface[i] = c->flag_insufficient[i] = c->flag_reduced[i] = c->lam_n[i] = 0;
+        c->neighbor_count[i] = c->cell_index[i] = 0;
+        c->nb_off[i] = 0;
+        for (int q = 0; q < ORC_MAX_PLANES; q++) c->lam[i * ORC_MAX_PLANES + q] = c->lam_gx[i * ORC_MAX_PLANES + q] = c->lam_gy[i * ORC_MAX_PLANES + q] = 0.f;
         c->h2_next[i] = orc_h_from_mass(mass[i], 1.f /* INIT_REST_DENSITY, simulation.rs:344 */);
         c->level[i] = NAN; /* LevelEstimationState::FluidInterior */
         c->level_tmp[i] = NAN;
         c->size_class[i] = 2; /* ParticleSizeClass::Optimal */
     }
+    c->nb_off[n] = 0;
     return SPH_OK;
 }
 

@@ -11,8 +11,9 @@ from pathlib import Path
 
 src, dst = Path(sys.argv[1]), sys.argv[2]
 Path(dst).parent.mkdir(parents=True, exist_ok=True)
-shutil.copy(src / "bench.json", dst + "_bench.json")
-shutil.copy(next((src / "kt").glob("*kernel_stats.csv")), dst + "_rocprofv3_kernel_stats.csv")
+if (src / "bench.json").exists():
+    shutil.copy(src / "bench.json", dst + "_bench.json")
+shutil.copy(next((src / "kt").rglob("*kernel_stats.csv")), dst + "_rocprofv3_kernel_stats.csv")
 
 
 def short(name):
@@ -22,14 +23,14 @@ def short(name):
 
 # per-kernel durations of the launches that did real work (speculative Jacobi launches past the stop decision
 # exit in ~1-2 us and would drag the plain average down)
-trace = list(csv.DictReader(open(next((src / "kt").glob("*kernel_trace.csv")))))
+trace = list(csv.DictReader(open(next((src / "kt").rglob("*kernel_trace.csv")))))
 dur = collections.defaultdict(list)
 for r in trace:
     dur[short(r["Kernel_Name"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 
 
 def pmc(dirname, counter):
-    f = next((src / dirname).glob("*counter_collection.csv"), None)
+    f = next((src / dirname).rglob("*counter_collection.csv"), None)
     out = collections.defaultdict(list)
     if f:
         for r in csv.DictReader(open(f)):

@@ -1,0 +1,150 @@
+"""BASELINE.json configs[3] (2D dam-break, 8 386 816 particles, slab decomposition) and configs[4] (ratio-stress scene,
+4 004 343 particles at 50:1 radii, IISPH, Sdf2D box, EmptyAngle level estimation) at FULL size, through the C ABI.
+
+configs[3]: against the CPU oracle (bit-exact cell / neighbour indices, positions and densities within 1e-4 after N steps with
+the iteration counts forced equal), and the 8-slab decomposition (loopback transport: 8 contexts of this process on one GPU,
+the driver code the RCCL transport runs) against the single context.
+configs[4]: the step path of the scene against the oracle at full size -- the oracle enumerates candidates with one grid
+per size class (oracle/neigh.c), so 50:1 at 4M particles takes seconds per step, not hours.  The scene's host-side adaptivity
+(split / merge / share) is exercised by tests/test_gpu_adaptivity.py.
+"""
+import numpy as np
+import pytest
+
+from adaptive_sph_amd import distributed as D, ffi, scene as sc
+from adaptive_sph_amd.workloads import WORKLOADS
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL_FIELDS = 1e-4     # north_star: fp32 positions / densities within 1e-4 relative after N steps
+FORCED = dict(hybrid_dfsph_max_avg_density_error=0.0, hybrid_dfsph_max_avg_divergence_error=0.0, iisph_max_avg_density_error=0.0)
+
+
+def rel_err(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    s = np.abs(b).max()
+    return np.abs(a - b).max() / (s if s > 0 else 1.0)
+
+
+def same_sets(g, o):
+    """Equal CSR offsets and, per particle, equal sums and sums of squares of the neighbour indices (exact integer arithmetic):
+    the order inside a list is unspecified (cell-sorted here, ascending in the oracle)."""
+    go, gi = g.download_neighbors()
+    oo, oi = o.download_neighbors()
+    assert np.array_equal(go, oo)
+    starts = go[:-1].astype(np.int64)
+    assert (np.diff(go.astype(np.int64)) > 0).all()          # every particle is on its own list
+    for power in (1, 2):
+        a = np.add.reduceat(gi.astype(np.uint64) ** power, starts)
+        b = np.add.reduceat(oi.astype(np.uint64) ** power, starts)
+        assert np.array_equal(a, b), power
+
+
+def make_pair(product_lib, oracle_lib, name, **overrides):
+    scene_f, params_f, _ = WORKLOADS[name]
+    scn, P = scene_f(), params_f(**overrides)
+    pos, mass, vel = sc.init_particles(scn)
+    planes = sc.boundary_planes(scn.boundary, P.init_boundary_handler)
+    g, o = ffi.Context(product_lib, len(mass), planes), ffi.Context(oracle_lib, len(mass), planes)
+    g.upload(mass, pos, vel)
+    o.upload(mass, pos, vel)
+    return g, o, P
+
+
+def test_config3_dam_break_8m_against_the_oracle(product_lib, oracle_lib):
+    g, o, P = make_pair(product_lib, oracle_lib, "dam_break_8m", max_iters=3, **FORCED)
+    assert g.n == 8386816
+    p = P.to_ffi()
+    for s in range(3):
+        sg, so = g.step(p), o.step(p)
+        assert abs(sg.dt - so.dt) <= 1e-6 * so.dt, s
+        assert sg.div_solver.iters == so.div_solver.iters and sg.density_solver.iters == so.density_solver.iters
+    gg, og = g.grid(), o.grid()
+    assert (gg.cell_size, gg.cells_min_x, gg.cells_min_y, gg.size_x, gg.size_y) == \
+           (og.cell_size, og.cells_min_x, og.cells_min_y, og.size_x, og.size_y)
+    for f in ("h2", "cell_index", "neighbor_count", "lambda_sum"):
+        assert np.array_equal(g.download(f), o.download(f)), f
+    same_sets(g, o)
+    for f in ("position", "density", "aii", "ppe_source_term"):
+        assert rel_err(g.download(f), o.download(f)) < REL_TOL_FIELDS, f
+    assert rel_err(g.download("velocity"), o.download("velocity")) < 1e-3     # carries the unconverged (3 iterations) pressure field
+
+
+def test_config3_dam_break_8m_eight_slabs_against_the_single_context(product_lib):
+    scene_f, params_f, _ = WORKLOADS["dam_break_8m"]
+    scn, P = scene_f(), params_f(max_iters=3, **FORCED)
+    pos, mass, vel = sc.init_particles(scn)
+    planes = sc.boundary_planes(scn.boundary)
+    p = P.to_ffi()
+    single = ffi.Context(product_lib, len(mass), planes)
+    single.upload(mass, pos, vel)
+    grp = D.make_loopback_group(product_lib, pos, mass, vel, planes, 8)
+    assert sum(c.n for c in grp) == len(mass) and min(c.n for c in grp) > 1000000
+    for s in range(3):
+        st1 = single.step(p)
+        sts = ffi.group_step(grp, p)
+        assert all(st.dt == st1.dt for st in sts)
+        assert all(st.div_solver.iters == st1.div_solver.iters and st.density_solver.iters == st1.density_solver.iters for st in sts)
+    n = len(mass)
+    ids = np.concatenate([c.download("particle_id") for c in grp])
+    assert np.array_equal(np.sort(ids), np.arange(n))                              # nothing lost or duplicated
+    assert np.array_equal(D.gather_by_id(grp, "neighbor_count", n), single.download("neighbor_count"))
+    for f, tol in (("position", 1e-5), ("velocity", 1e-4), ("density", 1e-5), ("mass", 0.0)):
+        assert rel_err(D.gather_by_id(grp, f, n), single.download(f)) <= tol, f
+    st = grp[3].dist_get_stats()
+    assert st["n_ghost"][0] > 0 and st["n_ghost"][1] > 0 and st["exchanges"] > 0    # an inner slab has two neighbours
+
+
+def test_config4_ratio_stress_4m_against_the_oracle(product_lib, oracle_lib):
+    """The step path of configs[4] with the recipe's own parameters (media/ratio-stress-test-video.yaml: IISPH, cfl 0.2,
+    AnalyticUnderestimate = the Sdf2D box) and default-config.yaml's EmptyAngle level estimation, iteration counts pinned."""
+    g, o, P = make_pair(product_lib, oracle_lib, "ratio_stress_4m", level_estimation_method="EmptyAngle", max_iters=3, **FORCED)
+    assert g.n == 4002768 + 1575
+    p = P.to_ffi()
+    for s in range(2):
+        sg, so = g.step(p), o.step(p)
+        assert abs(sg.dt - so.dt) <= 1e-6 * so.dt, s
+    h = o.download("h2")
+    assert 49.9 < h.max() / h.min() < 50.1                                         # the 50:1 radius ratio is the scene's purpose
+    gg, og = g.grid(), o.grid()
+    assert (gg.cell_size, gg.cells_min_x, gg.cells_min_y, gg.size_x, gg.size_y) == \
+           (og.cell_size, og.cells_min_x, og.cells_min_y, og.size_x, og.size_y)
+    for f in ("h2", "cell_index", "neighbor_count", "lambda_sum", "flag_is_fluid_surface", "flag_insufficient_neighs"):
+        assert np.array_equal(g.download(f), o.download(f)), f
+    same_sets(g, o)
+    assert 0 < o.download("flag_is_fluid_surface").sum() < g.n
+    for f in ("position", "density", "aii", "ppe_source_term", "velocity"):
+        assert rel_err(g.download(f), o.download(f)) < REL_TOL_FIELDS, f
+    for f in ("level_estimation", "level_old"):
+        a, b = g.download(f), o.download(f)
+        assert np.array_equal(np.isnan(a), np.isnan(b)), f
+        assert float(np.nanmax(np.abs(a - b))) / max(float(np.nanmax(np.abs(b))), 1e-30) < REL_TOL_FIELDS, f
+    g.classify(p), o.classify(p)
+    cg, co = g.download("particle_size_class"), o.download("particle_size_class")
+    assert (cg != co).mean() < 1e-3
+
+
+def test_config4_ratio_stress_4m_blocks_in_contact(product_lib, oracle_lib):
+    """The same scene with the fine block moved against the coarse one: a coarse particle then has thousands of fine
+    neighbours (beyond every recorded-list form: it walks its candidates in each sweep), a fine particle at the interface a
+    stencil dozens of cells wide.  Sets bit-exact, fields within tolerance."""
+    scene_f, params_f, _ = WORKLOADS["ratio_stress_4m"]
+    scn, P = scene_f(), params_f(max_iters=3, **FORCED)
+    scn.blocks[1].pos[0] = 0.4 - 0.55 - 0.0004385 * 20       # fine block's right edge ~one coarse spacing left of the coarse block
+    pos, mass, vel = sc.init_particles(scn)
+    planes = sc.boundary_planes(scn.boundary, P.init_boundary_handler)
+    g, o = ffi.Context(product_lib, len(mass), planes), ffi.Context(oracle_lib, len(mass), planes)
+    g.upload(mass, pos, vel)
+    o.upload(mass, pos, vel)
+    p = P.to_ffi()
+    for s in range(2):
+        sg, so = g.step(p), o.step(p)
+        assert abs(sg.dt - so.dt) <= 1e-5 * so.dt, s
+    cnt = o.download("neighbor_count")
+    assert cnt.max() > 2000                                   # coarse particles buried in fine neighbours
+    assert np.array_equal(g.download("neighbor_count"), cnt)
+    assert np.array_equal(g.download("cell_index"), o.download("cell_index"))
+    same_sets(g, o)
+    for f in ("position", "density", "aii"):
+        assert rel_err(g.download(f), o.download(f)) < REL_TOL_FIELDS, f
