@@ -188,7 +188,7 @@ struct LevelArgs {
     uint8_t* size_class;
     float* level;                  // the level field (detection output, propagated in place)
     uint32_t* when;                // propagation sweep that assigned the value (sph_sweeps.hip)
-    uint32_t* mark;
+    uint32_t* mark;                // 2 n words: frontier marks, double-buffered by sweep parity
     float* level_old;
     float* stash_first;            // stash filled right after the detection (SurfaceDistanceFirst) or nullptr
     int center_diff;               // surface_detection_by_center_diff instead of the empty-angle detector

@@ -1433,7 +1433,7 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
         HIPCHK(c, c->lvl_tmp.ensure(n * 4));
         HIPCHK(c, c->lvl_nrm.ensure(n * 8));
         HIPCHK(c, c->lvl_when.ensure(n * 4));
-        HIPCHK(c, c->lvl_mark.ensure(n * 4));
+        HIPCHK(c, c->lvl_mark.ensure(n * 8));   // two parity buffers (OpLevelPropagate)
         HIPCHK(c, c->stash.ensure(n * 4));
         for (DevBuf* b : {&c->lvl_state, &c->flag_surface, &c->flag_insufficient}) HIPCHK(c, b->ensure(n));
         HIPCHK(c, c->nl_ext.ensure(sweep_list_bytes((uint32_t)n)));
@@ -1540,7 +1540,7 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
             HIPCHK(c, c->lvl_tmp.ensure(n * 4));
             HIPCHK(c, c->lvl_nrm.ensure(n * 8));
             HIPCHK(c, c->lvl_when.ensure(n * 4));
-            HIPCHK(c, c->lvl_mark.ensure(n * 4));
+            HIPCHK(c, c->lvl_mark.ensure(n * 8));   // two parity buffers (OpLevelPropagate)
             HIPCHK(c, c->stash.ensure(n * 4));
             for (DevBuf* b : {&c->lvl_state, &c->flag_surface, &c->flag_insufficient}) HIPCHK(c, b->ensure(n));
             HIPCHK(c, c->nl_ext.ensure(sweep_list_bytes((uint32_t)n)));

@@ -1282,7 +1282,8 @@ struct OpLevelCone {
     const uint8_t* __restrict__ state;
     float* __restrict__ level;
     uint32_t* __restrict__ when;   // propagation sweep that gave the particle its value: 0 surface, LVL_UNASSIGNED none yet
-    uint32_t* __restrict__ mark;
+    uint32_t* __restrict__ mark;   // two frontier-mark words per particle: [i] read by even sweeps, [i + mark_stride] by odd ones
+    uint32_t mark_stride;
     uint8_t* __restrict__ flag_surface;
     float* __restrict__ stash;   // fill_stash_with == SurfaceDistanceFirst (simulation.rs:886-893), else nullptr
     float k, threshold, max_surface_distance;
@@ -1335,6 +1336,7 @@ struct OpLevelCone {
         level[i] = v;
         when[i] = interior ? LVL_UNASSIGNED : 0u;
         mark[i] = 0u;
+        mark[i + mark_stride] = 0u;
         flag_surface[i] = interior ? 0 : 1;
         if (stash) stash[i] = interior ? -max_surface_distance : v;
         return false;
@@ -1355,6 +1357,7 @@ struct OpLevelCenterDiff {
     float* __restrict__ level;
     uint32_t* __restrict__ when;
     uint32_t* __restrict__ mark;
+    uint32_t mark_stride;
     uint8_t* __restrict__ flag_surface;
     float* __restrict__ stash;   // fill_stash_with == SurfaceDistanceFirst, else nullptr
     float k, max_surface_distance, rest_density;
@@ -1407,6 +1410,7 @@ struct OpLevelCenterDiff {
         level[i] = v;
         when[i] = surface ? 0u : LVL_UNASSIGNED;
         mark[i] = 0u;
+        mark[i + mark_stride] = 0u;
         flag_surface[i] = surface ? 1 : 0;
         if (stash) stash[i] = surface ? v : -max_surface_distance;
         return false;
@@ -1421,6 +1425,11 @@ struct OpLevelCenterDiff {
 // unassigned neighbours for sweep t while it walks its list, everyone else leaves after two loads.  Same values, same
 // sweep count (a particle is assigned in the first sweep t in which a neighbour has when <= t-1, and then one of them
 // has when == t-1 and has marked it).  Sweep 0 only lets the surface particles mark their neighbours.
+// The marks are double-buffered by sweep parity: sweep t tests mark_cur[i] == t and writes t + 1 into mark_next.  With ONE
+// array a candidate of sweep t could find its own mark already overwritten with t + 1 by an EARLIER block of the same launch
+// (a neighbouring candidate that still saw it unassigned) and sit the sweep out; assigned one sweep late, it was invisible to
+// the neighbours that needed it -- 0.5 % of the particles of BASELINE configs[4] (4M particles, blocks of one launch start
+// milliseconds apart) ended up with a longer path, up to 10 spacings deeper than the reference's field.
 struct NBLevel {
     uint32_t w;
     float lv;
@@ -1436,7 +1445,8 @@ struct OpLevelPropagate {
     const float4* __restrict__ pm_cell;   // pre-step positions when pm holds the advected ones, else nullptr
     float* __restrict__ level;
     uint32_t* __restrict__ when;
-    uint32_t* __restrict__ mark;
+    const uint32_t* __restrict__ mark_cur;   // marks for THIS sweep (written by sweep t - 1)
+    uint32_t* __restrict__ mark_next;        // marks for sweep t + 1
     uint32_t* __restrict__ changed;   // one word per sweep of the batch
     float k;
     uint32_t t;
@@ -1457,7 +1467,7 @@ struct OpLevelPropagate {
     __device__ bool lane_skip(uint32_t i) const
     {
         if (plain) return t == 0u || when[i] != LVL_UNASSIGNED;
-        return t == 0u ? when[i] != 0u : !(when[i] == LVL_UNASSIGNED && mark[i] == t);
+        return t == 0u ? when[i] != 0u : !(when[i] == LVL_UNASSIGNED && mark_cur[i] == t);
     }
     __device__ void init(Acc&) const {}
     __device__ void epilogue(Acc&, bool, uint32_t) const {}
@@ -1485,7 +1495,7 @@ struct OpLevelPropagate {
     {
         // a candidate of sweep t is assigned in sweep t; its unassigned neighbours are the candidates of sweep t+1.  (In the
         // candidate-walk fallback only accepted pairs arrive here, so only real neighbours are marked.)
-        if (!plain && Bj.w == LVL_UNASSIGNED) mark[Bj.j] = t + 1u;
+        if (!plain && Bj.w == LVL_UNASSIGNED) mark_next[Bj.j] = t + 1u;
         if (!(Bj.w < t)) return;
         if (r2 > a.r2max) return;
         const float est = Bj.lv - sqrtf(r2);
@@ -2169,7 +2179,7 @@ void launch_level_detect(hipStream_t s, Profiler* prof, const SweepArgs& a, cons
         if (a.n) hipLaunchKernelGGL(k_require_recorded_lists, dim3((a.n + 255) / 256), dim3(256), 0, s, a.n, a.nl_ext, a.orig, a.owned, a.status);
         if (l.center_diff) {
             ProfScope ps(prof, "level_center_diff", s);
-            SPH_DISPATCH(OpLevelCenterDiff, false, a.pm, l.pm_cell, l.level, l.when, l.mark, l.flag_surface, l.stash_first, l.k, l.max_surface_distance,
+            SPH_DISPATCH(OpLevelCenterDiff, false, a.pm, l.pm_cell, l.level, l.when, l.mark, a.n, l.flag_surface, l.stash_first, l.k, l.max_surface_distance,
                          a.sp.rest_density)
             return;
         }
@@ -2179,14 +2189,14 @@ void launch_level_detect(hipStream_t s, Profiler* prof, const SweepArgs& a, cons
         }
         {
             ProfScope ps(prof, "level_cone", s);
-            SPH_DISPATCH(OpLevelCone, false, a.pm, l.pm_cell, l.nrm, l.state, l.level, l.when, l.mark, l.flag_surface, l.stash_first, l.k, l.threshold, l.max_surface_distance,
+            SPH_DISPATCH(OpLevelCone, false, a.pm, l.pm_cell, l.nrm, l.state, l.level, l.when, l.mark, a.n, l.flag_surface, l.stash_first, l.k, l.threshold, l.max_surface_distance,
                          l.maximum_range, a.sp.rest_density)
         }
         return;
     }
     if (l.center_diff) {
         ProfScope ps(prof, "level_center_diff", s);
-        SPH_DISPATCH(OpLevelCenterDiff, true, a.pm, l.pm_cell, l.level, l.when, l.mark, l.flag_surface, l.stash_first, l.k, l.max_surface_distance,
+        SPH_DISPATCH(OpLevelCenterDiff, true, a.pm, l.pm_cell, l.level, l.when, l.mark, a.n, l.flag_surface, l.stash_first, l.k, l.max_surface_distance,
                      a.sp.rest_density)
         return;
     }
@@ -2196,7 +2206,7 @@ void launch_level_detect(hipStream_t s, Profiler* prof, const SweepArgs& a, cons
     }
     {
         ProfScope ps(prof, "level_cone", s);
-        SPH_DISPATCH(OpLevelCone, false, a.pm, l.pm_cell, l.nrm, l.state, l.level, l.when, l.mark, l.flag_surface, l.stash_first, l.k, l.threshold, l.max_surface_distance,
+        SPH_DISPATCH(OpLevelCone, false, a.pm, l.pm_cell, l.nrm, l.state, l.level, l.when, l.mark, a.n, l.flag_surface, l.stash_first, l.k, l.threshold, l.max_surface_distance,
                      l.maximum_range, a.sp.rest_density)
     }
 }
@@ -2204,7 +2214,9 @@ void launch_level_detect(hipStream_t s, Profiler* prof, const SweepArgs& a, cons
 void launch_level_propagate(hipStream_t s, Profiler* prof, const SweepArgs& a, const LevelArgs& l, uint32_t t, uint32_t* changed)
 {
     ProfScope ps(prof, "level_propagate", s);
-    SPH_DISPATCH(OpLevelPropagate, false, a.pm, l.pm_cell, l.level, l.when, l.mark, changed, l.k, t, l.maximum_range, a.sp.rest_density,
+    const uint32_t* mark_cur = l.mark + ((t & 1u) ? a.n : 0u);
+    uint32_t* mark_next = l.mark + ((t & 1u) ? 0u : a.n);
+    SPH_DISPATCH(OpLevelPropagate, false, a.pm, l.pm_cell, l.level, l.when, mark_cur, mark_next, changed, l.k, t, l.maximum_range, a.sp.rest_density,
                  -l.max_surface_distance, l.plain_propagate)
 }
 
