@@ -232,11 +232,11 @@ __global__ void k_publish(const SolverCtrl* __restrict__ ctrl, const DeviceStatu
 {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         SolverCtrl v = *ctrl;
-        v.pad[2] = seq - 1u;
+        v.seq = seq - 1u;
         *h_ctrl = v;
         *h_status = *status;
         __threadfence_system();
-        ((volatile SolverCtrl*)h_ctrl)->pad[2] = seq;
+        ((volatile SolverCtrl*)h_ctrl)->seq = seq;
     }
 }
 

@@ -69,7 +69,8 @@ struct SolverCtrl {
     uint32_t ticket;  // reduce-kernel arrival counter
     uint32_t normal, singular, negative;
     float sum_err, max_err;
-    uint32_t pad[3];
+    uint32_t slot_done[2];   // stop decision as seen by the launches of one iteration (written by sweep A(k) into slot k & 1, sph_sweeps.hip)
+    uint32_t seq;            // host copy only: sequence number of the k_publish that wrote it (wait_publish)
 };
 
 // error word layout: first failing guard wins (atomicCAS from 0)
@@ -167,13 +168,12 @@ void launch_aii_const(hipStream_t s, Profiler* prof, const SweepArgs& a);
 void launch_aii_const_non_pressure(hipStream_t s, Profiler* prof, const SweepArgs& a);   // + the non-pressure acceleration, one sweep
 void launch_non_pressure(hipStream_t s, Profiler* prof, const SweepArgs& a);                // vel -> vel_tmp
 void launch_source_term(hipStream_t s, Profiler* prof, const SweepArgs& a, int kind, int residual_density);  // kind: 0 div, 1 full, 2 only-density; includes Jacobi iteration 0
-void launch_pressure_accel(hipStream_t s, Profiler* prof, const SweepArgs& a, int iter, int tail, float4* pm_out);  // iter < 0: final sweep (runs once ctrl->done), tail = TAIL_*
+// sweep A of iteration iter >= 1 (+ the stop decision of iteration iter - 1, taken by its block 0); iter < 0: a^p from the solve's final pressures
+void launch_pressure_accel(hipStream_t s, Profiler* prof, const SweepArgs& a, int iter, int residual_density, float max_avg_error, uint32_t max_iters, int multi);
+void launch_solver_tail(hipStream_t s, Profiler* prof, const SweepArgs& a, int tail, float4* pm_out);   // integrate map of the solver mode, once the solve is done
 void launch_jacobi_update(hipStream_t s, Profiler* prof, const SweepArgs& a, int iter, int residual_density);
-void launch_solver_local(hipStream_t s, Profiler* prof, const SweepArgs& a, float* block_partials);
 void launch_solver_decide(hipStream_t s, Profiler* prof, const SweepArgs& a, int iter, int residual_density, float max_avg_error,
                           uint32_t max_iters);
-void launch_solver_reduce(hipStream_t s, Profiler* prof, const SweepArgs& a, int iter, int residual_density, float max_avg_error,
-                          uint32_t max_iters, float* block_partials);
 // level estimation (sorted order)
 struct LevelArgs {
     float k;                       // level_estimation_range / ETA

@@ -154,7 +154,7 @@ static int wait_word(sph_ctx* c, volatile uint32_t* word, uint32_t want)
 static int wait_publish(sph_ctx* c)
 {
     c->hint_word = nullptr;
-    return wait_word(c, &((volatile SolverCtrl*)c->ctrl_host)->pad[2], c->publish_seq);
+    return wait_word(c, &((volatile SolverCtrl*)c->ctrl_host)->seq, c->publish_seq);
 }
 
 // a few device words -> mapped host memory, the sequence number last (same idea as k_publish): the result of a host-value
@@ -1094,27 +1094,39 @@ static int build_ghost_layer(Group& G, std::vector<Member>& M, float halo_width,
     return SPH_OK;
 }
 
-// iisph_pressure_iterations (simulation.rs:1377-1516).  Iteration 0 was folded into the source-term sweep
-// (closed form, see OpSource); its statistics are reduced here.  Iterations are enqueued speculatively up to
-// the predicted count, followed by the FINAL pressure-acceleration sweep with its fused tail; every kernel
-// checks the device-side `done` flag first, so iterations queued past the stop decision cost a launch and
-// nothing else, and the final sweep only runs once the decision is taken.  One host wait per chunk.
+// iisph_pressure_iterations (simulation.rs:1377-1516).  Iteration 0 was folded into the source-term sweep (closed form, see
+// OpSource).  An iteration is two launches: sweep B(k) (Jacobi update + per-block residual partials) and sweep A(k + 1), whose
+// block 0 first reduces those partials and takes the stop decision of iteration k while the other blocks already compute a^p
+// from the new pressures -- if the decision is "stop", that launch WAS the solve's last pressure-acceleration sweep
+// (simulation.rs:1499-1509) and everything queued behind it returns at once.  Iterations are queued speculatively up to the
+// predicted count, followed by the solve's tail (the integrate map of the solver mode, k_solver_tail), which runs only once the
+// decision is taken.  One host wait per chunk.
+// Slab decomposition: block 0 of A(k + 1) adds up the rank's totals; the all-reduce and the decision (k_solver_decide) follow
+// behind that sweep, i.e. the decision on iteration k is taken one sweep late and the reduction kernel between B and A is gone.
 static int pressure_iterations(Group& G, std::vector<Member>& M, float max_avg_error, int residual_density, uint32_t max_iters,
                                uint32_t predicted_iters, int tail, bool density_solver)
 {
     int rc;
-    auto reduce_and_decide = [&](int iter) -> int {
+    const int multi = G.multi() ? 1 : 0;
+    // sweep A of iteration k: a^p from pressure buffer k & 1, and the stop decision of iteration k - 1
+    auto sweep_a = [&](uint32_t k) -> int {
         for (auto& m : M) {
             (void)hipSetDevice(m.c->device);
-            if (!G.multi()) launch_solver_reduce(m.c->stream, &m.c->prof, m.a, iter, residual_density, max_avg_error, max_iters, m.a.partials);
-            else launch_solver_local(m.c->stream, &m.c->prof, m.a, m.a.partials);
+            if (m.n) launch_pressure_accel(m.c->stream, &m.c->prof, m.a, (int)k, residual_density, max_avg_error, max_iters, multi);
+            else if (!multi) {   // a context without particles: nothing to iterate on (n_normal == 0)
+                SolverCtrl z{};
+                z.done = 1u;
+                z.slot_done[0] = z.slot_done[1] = 1u;
+                z.cur = k & 1u;
+                (void)hipMemcpyAsync(m.c->ctrl.p, &z, sizeof z, hipMemcpyHostToDevice, m.c->stream);
+            } else (void)hipMemsetAsync(m.c->dist.solver_tot.p, 0, 40, m.c->stream);   // an empty slab contributes zeros
         }
-        if (G.multi()) {
+        if (multi) {
             int r = G.comm->allreduce_solver(G);
             if (r) return r;
             for (auto& m : M) {
                 (void)hipSetDevice(m.c->device);
-                launch_solver_decide(m.c->stream, &m.c->prof, m.a, iter, residual_density, max_avg_error, max_iters);
+                launch_solver_decide(m.c->stream, &m.c->prof, m.a, (int)k - 1, residual_density, max_avg_error, max_iters);
             }
         }
         return SPH_OK;
@@ -1122,32 +1134,30 @@ static int pressure_iterations(Group& G, std::vector<Member>& M, float max_avg_e
     auto pt_of = [&](int cur) { return cur ? sel_pt1 : sel_pt0; };
     // iteration 0 wrote pressure buffer 1
     if ((rc = refresh_ghosts(G, M, sel_pt1, 1, "pt"))) return rc;
-    if ((rc = reduce_and_decide(0))) return rc;
+    if ((rc = sweep_a(1))) return rc;
     uint32_t k = 1;
     uint32_t upto = predicted_iters > 2 ? predicted_iters : 2;
     for (;;) {
         for (; k <= upto && k <= max_iters; k++) {
             for (auto& m : M) {
                 (void)hipSetDevice(m.c->device);
-                if (m.n) launch_pressure_accel(m.c->stream, &m.c->prof, m.a, (int)k, 0, nullptr);
-            }
-            // (no exchange of a^p: the first ghost ring computed its own in the sweep above)
-            for (auto& m : M) {
-                (void)hipSetDevice(m.c->device);
                 if (m.n) launch_jacobi_update(m.c->stream, &m.c->prof, m.a, (int)k, residual_density);
             }
+            // (no exchange of a^p: the first ghost ring computes its own in sweep A)
             if ((rc = refresh_ghosts(G, M, pt_of((k + 1) & 1), 1, "pt"))) return rc;
-            if ((rc = reduce_and_decide((int)k))) return rc;
+            if ((rc = sweep_a(k + 1))) return rc;
         }
         for (auto& m : M) {
             (void)hipSetDevice(m.c->device);
-            if (m.n) launch_pressure_accel(m.c->stream, &m.c->prof, m.a, -1, tail, m.c->pm[m.c->pcur ^ 1].as<float4>());
-            if (m.n && tail >= 2 /* TAIL_VX, TAIL_HYBRID */ && m.a.hdr_partials)
-                launch_header_ahead(m.c, solver_reduce_blocks(m.n), m.c->hdr_host_dev);
+            if (!m.n || tail == 0 /* TAIL_NONE */) continue;
+            launch_solver_tail(m.c->stream, &m.c->prof, m.a, tail, m.c->pm[m.c->pcur ^ 1].as<float4>());
+            if (tail >= 2 /* TAIL_VX, TAIL_HYBRID */ && m.a.hdr_partials) launch_header_ahead(m.c, (m.n + 255u) / 256u, m.c->hdr_host_dev);
         }
         if ((rc = sync_ctrl(G))) return rc;
         if (M[0].c->ctrl_host->done) break;
-        if (k > max_iters) break;  // cannot happen: iteration max_iters always sets done
+        if (k > max_iters) break;  // cannot happen: the decision on iteration max_iters is always "stop"
+        // the prediction (the previous step's count) fell short: two more iterations per wait -- a skipped iteration costs two
+        // empty launches, a wait the round trip to the host
         upto = k + 1;
     }
     for (auto& m : M) {
@@ -1745,10 +1755,12 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
             if (m.n) launch_iisph2_scale(m.c->stream, &m.c->prof, m.a);
         }
         if ((rc = refresh_ghosts(G, M, M[0].c->pressure_cur ? sel_pt1 : sel_pt0, 1, "pt"))) return rc;
-        for (auto& m : M) {
+        for (auto& m : M) {   // a^p again, from the rescaled pressures (simulation.rs:2362-2373), then v += dt a^p ; x += dt v
             (void)hipSetDevice(m.c->device);
-            if (m.n) launch_pressure_accel(m.c->stream, &m.c->prof, m.a, -1, T_VX, m.c->pm[m.c->pcur ^ 1].as<float4>());
-            if (m.n && m.a.hdr_partials) launch_header_ahead(m.c, solver_reduce_blocks(m.n), m.c->hdr_host_dev);
+            if (!m.n) continue;
+            launch_pressure_accel(m.c->stream, &m.c->prof, m.a, -1, 1, 0.f, 0u, G.multi() ? 1 : 0);
+            launch_solver_tail(m.c->stream, &m.c->prof, m.a, T_VX, m.c->pm[m.c->pcur ^ 1].as<float4>());
+            if (m.a.hdr_partials) launch_header_ahead(m.c, (m.n + 255u) / 256u, m.c->hdr_host_dev);
         }
         if ((rc = sync_ctrl(G))) return rc;
         rec(5);

@@ -38,6 +38,9 @@
 #ifndef SWEEP_THREADS
 #define SWEEP_THREADS 256   // measured: 128 and 512 are within 1 % of 256 (scripts/ablate.sh)
 #endif
+#ifndef SPH_TILE_DEFAULT
+#define SPH_TILE_DEFAULT 0
+#endif
 
 // Neighbour list word (one uint4 = 16 B per particle, coalesced 1 KB per wave):
 //   x, y, z : accepted-candidate bit masks of the three cell rows cy-1, cy, cy+1.  Bit b of row r
@@ -241,11 +244,116 @@ struct OpRing1 : std::false_type {};
 template <class Op>
 struct OpRing1<Op, std::void_t<decltype(Op::RING1)>> : std::bool_constant<Op::RING1> {};
 
+// Ops with `static constexpr bool TILE = true` may run through the LDS-staged form (k_sweep_tile): they read the particle's own
+// cell from loadA(i) and touch neighbours only through loadA / nb / pair.
+template <class Op, class = void>
+struct OpTile : std::false_type {};
+template <class Op>
+struct OpTile<Op, std::void_t<decltype(Op::TILE)>> : std::bool_constant<Op::TILE> {};
+
+// optional Op hook `bool prologue(raw_block)`: block-uniform work at the start of the launch (the Jacobi stop decision, taken by
+// block 0 of the NEXT pressure-acceleration sweep while the other blocks already sweep); returns true to leave.  Default: skip().
+template <class Op, class = void>
+struct OpPrologue {
+    static __device__ __forceinline__ bool run(const Op& op, uint32_t) { return op.skip(); }
+};
+template <class Op>
+struct OpPrologue<Op, std::void_t<decltype(&Op::prologue)>> {
+    static __device__ __forceinline__ bool run(const Op& op, uint32_t raw_block) { return op.prologue(raw_block); }
+};
+
+// one particle of a sweep, every list form: mask word, explicit index list, candidate walk (3 x 3 cells or a wide stencil)
+template <class Op, bool BUILD>
+__device__ __forceinline__ void sweep_particle(const Op& op, const SweepCommon& c, typename Op::Acc& acc, const uint32_t i)
+{
+    typedef typename Op::Math Math;
+    const GridP g = c.g;
+    const float4 Ai = op.loadA(i);
+    uint4 lw = make_uint4(0, 0, 0, 0);
+    if (!BUILD) lw = c.nl[i];
+    op.begin(acc, i, Ai);
+    // explicit index lists exist in multi-resolution scenes and for the extended-range lists of the level estimation
+    constexpr bool IDX = !Math::UNIFORM || Op::EXTENDED;
+    if (!BUILD && IDX && (lw.w & NL_IDX)) {
+        replay_indices(op, acc, Ai, i, lw.w & 0xffffu, c.nlx, c.n);
+    } else {
+        // own cell (the same IEEE expression the sort key was computed from)
+        const float2 cp = OpCellPos<Op>::get(op, i, Ai);
+        const int cx = (int)floorf(cp.x / g.cs) - g.minx;
+        const int cy = (int)floorf(cp.y / g.cs) - g.miny;
+        const bool walk = BUILD || !(lw.w & NL_OK);
+        const int R = (!IDX || !walk) ? 1 : stencil_radius(g, c.t, Ai.w, cx, cy, op.krange());
+        if (R == 1) {
+            // 3 x 3 cells: three contiguous candidate ranges
+            uint32_t rb[3], re[3];
+            bool ok_list = true;
+#pragma unroll
+            for (int dr = 0; dr < 3; dr++) {
+                const int yy = cy + dr - 1;
+                const bool ok = yy >= 0 && yy < g.sy;
+                const uint32_t base = (uint32_t)(ok ? yy : 0) * (uint32_t)g.sx;
+                rb[dr] = ok ? c.cell_start[base + (uint32_t)max(cx - 1, 0)] : 0u;
+                re[dr] = rb[dr];
+                if (walk) {
+                    re[dr] = ok ? c.cell_start[base + (uint32_t)min(cx + 2, g.sx)] : rb[dr];
+                    ok_list = ok_list && !Op::EXTENDED && (re[dr] - rb[dr]) <= 32u;
+                }
+            }
+            if (!walk) {
+                // the particle itself is on its own list (the reference keeps it there), but in the gradient sweeps
+                // its pair term is exactly zero (grad W(0) = 0, Q_i - Q_i = 0): drop its bit, which brings the middle
+                // row of the rest lattice from 5 to 4 set bits = one trip instead of two
+                if (Op::SKIP_SELF) {
+                    const uint32_t sb = i - rb[1];
+                    if (sb < 32u) lw.y &= ~(1u << sb);
+                }
+                replay_masks(op, acc, Ai, rb, lw);
+            } else {
+                uint32_t mk[3] = {0u, 0u, 0u}, nacc = 0;
+                IdxRecorder rec;
+                rec.cur = make_uint4(0, 0, 0, 0);
+                const bool rec_idx = BUILD && IDX && !ok_list;
+                if (rec_idx) {
+#pragma unroll
+                    for (int dr = 0; dr < 3; dr++) walk_row<Op, false, true>(op, acc, Ai, rb[dr], re[dr], mk[dr], nacc, rec, c.nlx, c.n, i);
+                    rec.flush(nacc, c.nlx, c.n, i);
+                } else {
+#pragma unroll
+                    for (int dr = 0; dr < 3; dr++) walk_row<Op, BUILD, false>(op, acc, Ai, rb[dr], re[dr], mk[dr], nacc, rec, c.nlx, c.n, i);
+                }
+                if (BUILD)
+                    lw = make_uint4(mk[0], mk[1], mk[2],
+                                    (nacc & 0xffffu) | (ok_list ? NL_OK : 0u) | (rec_idx && nacc <= NLX_CAP ? NL_IDX : 0u));
+            }
+        } else {
+            // wide stencil (a large neighbour may be around): (2R+1) rows, explicit index list
+            uint32_t dummy = 0, nacc = 0;
+            IdxRecorder rec;
+            rec.cur = make_uint4(0, 0, 0, 0);
+            const int x0 = max(cx - R, 0), x1 = min(cx + R + 1, g.sx);
+            for (int yy = max(cy - R, 0); yy <= min(cy + R, g.sy - 1); yy++) {
+                const uint32_t base = (uint32_t)yy * (uint32_t)g.sx;
+                const uint32_t b = c.cell_start[base + (uint32_t)x0], e = c.cell_start[base + (uint32_t)x1];
+                if (BUILD) walk_row<Op, false, true>(op, acc, Ai, b, e, dummy, nacc, rec, c.nlx, c.n, i);
+                else walk_row<Op, false, false>(op, acc, Ai, b, e, dummy, nacc, rec, c.nlx, c.n, i);
+            }
+            if (BUILD) {
+                rec.flush(nacc, c.nlx, c.n, i);
+                lw = make_uint4(0, 0, 0, (nacc & 0xffffu) | (nacc <= NLX_CAP ? NL_IDX : 0u));
+            }
+        }
+    }
+    const bool wall = op.finish(acc, i, Ai, BUILD ? true : (lw.w & NL_WALL) != 0u);
+    if (BUILD) {
+        if (wall) lw.w |= NL_WALL;
+        c.nl[i] = lw;
+    }
+}
+
 template <class Op, bool BUILD>
 __global__ __launch_bounds__(SWEEP_THREADS) void k_sweep(Op op, SweepCommon c)
 {
-    typedef typename Op::Math Math;
-    if (op.skip()) return;
+    if (OpPrologue<Op>::run(op, blockIdx.x)) return;
     // XCD-aware block order: the dispatcher places block b on XCD b % 8; give every XCD a contiguous
     // band of the cell-sorted array so that vertically adjacent waves (which share neighbour rows)
     // hit the same L2.
@@ -256,90 +364,168 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_sweep(Op op, SweepCommon c)
     const uint32_t ic = i < c.n ? i : 0;
     const bool mine = !c.owned || c.owned[ic] || (OpRing1<Op>::value && c.ring1 && c.ring1[ic]);
     const bool active = i < c.n && mine && !op.lane_skip(i);
-    const GridP g = c.g;
     typename Op::Acc acc;
     op.init(acc);  // lane-independent state
+    if (active) sweep_particle<Op, BUILD>(op, c, acc, i);
+    if (Op::HAS_EPILOGUE) op.epilogue(acc, active, blk);
+}
 
-    if (active) {
-        const float4 Ai = op.loadA(i);
+// ------------------------------------------------------------------------------------------------
+// The same sweep with the wave's candidate rows staged in LDS (uniform-h scenes, mask lists).
+// The 64 particles of a wave are consecutive in the cell-sorted order; when they sit in ONE row of cells, their three
+// candidate rows are three contiguous index ranges shared by all lanes: [start(cy+r-1, cx_first-1), start(cy+r-1, cx_last+2)),
+// ~80 records each on the rest lattice.  Those records (and the per-neighbour payload of the op) are loaded ONCE per wave,
+// coalesced, into the wave's own LDS region; every lane then reads its candidates / replays its mask bits from LDS instead
+// of issuing 16 per-lane global gathers per neighbour slot.  BUILD runs in two phases: the reference predicate over the
+// candidates, branch-free, into the three row masks; then the density sum over the accepted bits only (13 of ~38).
+// Same visiting order and the same arithmetic as the gather form, so the results are bit-identical; a wave that straddles
+// two cell rows, has a row longer than TILE_CAP records, a lane with more than 32 candidates in a row, or a lane without a
+// mask list falls back to the gather form (sweep_particle).
+// ------------------------------------------------------------------------------------------------
+#ifndef TILE_CAP
+#define TILE_CAP 96
+#endif
+
+template <class NB, bool EMPTY = std::is_empty<NB>::value>
+struct TileNB {
+    NB v[SWEEP_THREADS / 64][3 * TILE_CAP];
+    __device__ __forceinline__ void put(uint32_t w, uint32_t k, const NB& x) { v[w][k] = x; }
+    __device__ __forceinline__ NB get(uint32_t w, uint32_t k) const { return v[w][k]; }
+};
+template <class NB>
+struct TileNB<NB, true> {
+    __device__ __forceinline__ void put(uint32_t, uint32_t, const NB&) {}
+    __device__ __forceinline__ NB get(uint32_t, uint32_t) const { return NB{}; }
+};
+
+template <class Op, bool BUILD>
+__global__ __launch_bounds__(SWEEP_THREADS) void k_sweep_tile(Op op, SweepCommon c)
+{
+    typedef typename Op::Math Math;
+    typedef typename Op::NB NB;
+    static_assert(Math::UNIFORM && !Op::EXTENDED, "tile sweep: uniform-h scenes, SPH-support lists");
+    if (OpPrologue<Op>::run(op, blockIdx.x)) return;
+    const uint32_t per_xcd = (c.nblocks + 7) >> 3;
+    const uint32_t blk = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    if (blk >= c.nblocks) return;
+    __shared__ float4 s_A[SWEEP_THREADS / 64][3 * TILE_CAP];
+    __shared__ TileNB<NB> s_nb;
+    const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t wbase = blk * SWEEP_THREADS + w * 64u;
+    const uint32_t i = wbase + lane;
+    const uint32_t nvalid = __builtin_amdgcn_readfirstlane(wbase < c.n ? min(64u, c.n - wbase) : 0u);
+    const uint32_t ic = i < c.n ? i : 0;
+    const bool mine = !c.owned || c.owned[ic] || (OpRing1<Op>::value && c.ring1 && c.ring1[ic]);
+    const bool active = i < c.n && mine && !op.lane_skip(i);
+    const GridP g = c.g;
+    typename Op::Acc acc;
+    op.init(acc);
+    if (nvalid) {   // wave-uniform
+        const float4 Ai = op.loadA(lane < nvalid ? i : wbase);
+        const int cx = (int)floorf(Ai.x / g.cs) - g.minx;
+        const int cy = (int)floorf(Ai.y / g.cs) - g.miny;
+        const int cxf = __builtin_amdgcn_readfirstlane(cx), cyf = __builtin_amdgcn_readfirstlane(cy);
+        const int cxl = __builtin_amdgcn_readlane(cx, (int)nvalid - 1), cyl = __builtin_amdgcn_readlane(cy, (int)nvalid - 1);
+        bool tile_ok = cyf == cyl;   // one row of cells: cx is non-decreasing over the lanes
+        uint32_t sb[3], sl[3], rb[3], re[3];
         uint4 lw = make_uint4(0, 0, 0, 0);
-        if (!BUILD) lw = c.nl[i];
-        op.begin(acc, i, Ai);
-        // explicit index lists exist in multi-resolution scenes and for the extended-range lists of the level estimation
-        constexpr bool IDX = !Math::UNIFORM || Op::EXTENDED;
-        if (!BUILD && IDX && (lw.w & NL_IDX)) {
-            replay_indices(op, acc, Ai, i, lw.w & 0xffffu, c.nlx, c.n);
-        } else {
-            // own cell (the same IEEE expression the sort key was computed from)
-            const float2 cp = OpCellPos<Op>::get(op, i, Ai);
-            const int cx = (int)floorf(cp.x / g.cs) - g.minx;
-            const int cy = (int)floorf(cp.y / g.cs) - g.miny;
-            const bool walk = BUILD || !(lw.w & NL_OK);
-            const int R = (!IDX || !walk) ? 1 : stencil_radius(g, c.t, Ai.w, cx, cy, op.krange());
-            if (R == 1) {
-                // 3 x 3 cells: three contiguous candidate ranges
-                uint32_t rb[3], re[3];
-                bool ok_list = true;
+        if (!BUILD) lw = c.nl[lane < nvalid ? i : wbase];
+        bool lane_ok = true;
 #pragma unroll
-                for (int dr = 0; dr < 3; dr++) {
-                    const int yy = cy + dr - 1;
-                    const bool ok = yy >= 0 && yy < g.sy;
-                    const uint32_t base = (uint32_t)(ok ? yy : 0) * (uint32_t)g.sx;
-                    rb[dr] = ok ? c.cell_start[base + (uint32_t)max(cx - 1, 0)] : 0u;
-                    re[dr] = rb[dr];
-                    if (walk) {
-                        re[dr] = ok ? c.cell_start[base + (uint32_t)min(cx + 2, g.sx)] : rb[dr];
-                        ok_list = ok_list && !Op::EXTENDED && (re[dr] - rb[dr]) <= 32u;
-                    }
-                }
-                if (!walk) {
-                    // the particle itself is on its own list (the reference keeps it there), but in the gradient sweeps
-                    // its pair term is exactly zero (grad W(0) = 0, Q_i - Q_i = 0): drop its bit, which brings the middle
-                    // row of the rest lattice from 5 to 4 set bits = one trip instead of two
-                    if (Op::SKIP_SELF) {
-                        const uint32_t sb = i - rb[1];
-                        if (sb < 32u) lw.y &= ~(1u << sb);
-                    }
-                    replay_masks(op, acc, Ai, rb, lw);
-                } else {
-                    uint32_t mk[3] = {0u, 0u, 0u}, nacc = 0;
-                    IdxRecorder rec;
-                    rec.cur = make_uint4(0, 0, 0, 0);
-                    const bool rec_idx = BUILD && IDX && !ok_list;
-                    if (rec_idx) {
-#pragma unroll
-                        for (int dr = 0; dr < 3; dr++) walk_row<Op, false, true>(op, acc, Ai, rb[dr], re[dr], mk[dr], nacc, rec, c.nlx, c.n, i);
-                        rec.flush(nacc, c.nlx, c.n, i);
-                    } else {
-#pragma unroll
-                        for (int dr = 0; dr < 3; dr++) walk_row<Op, BUILD, false>(op, acc, Ai, rb[dr], re[dr], mk[dr], nacc, rec, c.nlx, c.n, i);
-                    }
-                    if (BUILD)
-                        lw = make_uint4(mk[0], mk[1], mk[2],
-                                        (nacc & 0xffffu) | (ok_list ? NL_OK : 0u) | (rec_idx && nacc <= NLX_CAP ? NL_IDX : 0u));
-                }
-            } else {
-                // wide stencil (a large neighbour may be around): (2R+1) rows, explicit index list
-                uint32_t dummy = 0, nacc = 0;
-                IdxRecorder rec;
-                rec.cur = make_uint4(0, 0, 0, 0);
-                const int x0 = max(cx - R, 0), x1 = min(cx + R + 1, g.sx);
-                for (int yy = max(cy - R, 0); yy <= min(cy + R, g.sy - 1); yy++) {
-                    const uint32_t base = (uint32_t)yy * (uint32_t)g.sx;
-                    const uint32_t b = c.cell_start[base + (uint32_t)x0], e = c.cell_start[base + (uint32_t)x1];
-                    if (BUILD) walk_row<Op, false, true>(op, acc, Ai, b, e, dummy, nacc, rec, c.nlx, c.n, i);
-                    else walk_row<Op, false, false>(op, acc, Ai, b, e, dummy, nacc, rec, c.nlx, c.n, i);
-                }
-                if (BUILD) {
-                    rec.flush(nacc, c.nlx, c.n, i);
-                    lw = make_uint4(0, 0, 0, (nacc & 0xffffu) | (nacc <= NLX_CAP ? NL_IDX : 0u));
-                }
+        for (int dr = 0; dr < 3; dr++) {
+            const int yy = cyf + dr - 1;
+            const bool ok = yy >= 0 && yy < g.sy;
+            const uint32_t base = (uint32_t)(ok ? yy : 0) * (uint32_t)g.sx;
+            sb[dr] = ok ? c.cell_start[base + (uint32_t)max(cxf - 1, 0)] : 0u;
+            const uint32_t se = ok ? c.cell_start[base + (uint32_t)min(cxl + 2, g.sx)] : sb[dr];
+            sl[dr] = se - sb[dr];
+            tile_ok = tile_ok && sl[dr] <= (uint32_t)TILE_CAP;
+            rb[dr] = ok ? c.cell_start[base + (uint32_t)max(cx - 1, 0)] : 0u;
+            re[dr] = rb[dr];
+            if (BUILD) {
+                re[dr] = ok ? c.cell_start[base + (uint32_t)min(cx + 2, g.sx)] : rb[dr];
+                lane_ok = lane_ok && (re[dr] - rb[dr]) <= 32u;
             }
         }
-        const bool wall = op.finish(acc, i, Ai, BUILD ? true : (lw.w & NL_WALL) != 0u);
-        if (BUILD) {
-            if (wall) lw.w |= NL_WALL;
-            c.nl[i] = lw;
+        if (!BUILD) lane_ok = (lw.w & NL_OK) != 0u;
+        tile_ok = tile_ok && __ballot(lane < nvalid && !lane_ok) == 0ull;
+        if (!tile_ok) {
+            if (active) sweep_particle<Op, BUILD>(op, c, acc, i);
+        } else {
+            // ---- stage the three rows: coalesced loads, one record (+ payload) per lane and trip
+#pragma unroll
+            for (int dr = 0; dr < 3; dr++) {
+                for (uint32_t k = lane; k < sl[dr]; k += 64u) {
+                    const uint32_t j = sb[dr] + k;
+                    const float4 Aj = op.loadA(j);
+                    s_A[w][dr * TILE_CAP + k] = Aj;
+                    s_nb.put(w, dr * TILE_CAP + k, op.nb(acc, j, Aj));
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (active) {
+                op.begin(acc, i, Ai);
+                uint32_t off[3];
+#pragma unroll
+                for (int dr = 0; dr < 3; dr++) off[dr] = dr * TILE_CAP + (rb[dr] - sb[dr]);
+                if (BUILD) {
+                    // phase 1: the neighbour predicate, exactly the reference's operations (no FMA, strict <), branch-free
+                    const float s = op.m.h * op.krange();
+                    const float s2 = s * s;
+                    uint32_t mk[3];
+#pragma unroll
+                    for (int dr = 0; dr < 3; dr++) {
+                        uint32_t m = 0u;
+                        const uint32_t len = re[dr] - rb[dr];
+                        for (uint32_t t = 0; t < len; t += 2u) {
+                            const float4 A0 = s_A[w][off[dr] + t];
+                            const float4 A1 = s_A[w][off[dr] + min(t + 1u, len - 1u)];
+                            const float dx0 = Ai.x - A0.x, dy0 = Ai.y - A0.y, dx1 = Ai.x - A1.x, dy1 = Ai.y - A1.y;
+                            const float r0 = dx0 * dx0 + dy0 * dy0, r1 = dx1 * dx1 + dy1 * dy1;
+                            m |= (r0 < s2 ? 1u : 0u) << t;
+                            m |= ((t + 1u < len && r1 < s2) ? 2u : 0u) << t;
+                        }
+                        mk[dr] = m;
+                    }
+                    lw = make_uint4(mk[0], mk[1], mk[2], 0u);
+                }
+                uint32_t masks[3] = {lw.x, lw.y, lw.z};
+                if (!BUILD && Op::SKIP_SELF) {   // see k_sweep: the own pair term is exactly zero in the gradient sweeps
+                    const uint32_t sbit = i - rb[1];
+                    if (sbit < 32u) masks[1] &= ~(1u << sbit);
+                }
+                // phase 2 / replay: the accepted candidates in the order of the gather form (rows bottom to top, index ascending)
+#pragma unroll
+                for (int dr = 0; dr < 3; dr++) {
+                    uint32_t mk = masks[dr];
+                    const uint32_t o = off[dr];
+                    while (mk) {
+                        const uint32_t b0 = __ffs(mk) - 1;
+                        mk &= mk - 1;
+                        const bool v1 = mk != 0;
+                        const uint32_t b1 = v1 ? __ffs(mk) - 1 : b0;
+                        mk &= mk - 1;
+                        const float4 A0 = s_A[w][o + b0], A1 = s_A[w][o + b1];
+                        const NB N0 = s_nb.get(w, o + b0), N1 = s_nb.get(w, o + b1);
+                        {
+                            const float dx = Ai.x - A0.x, dy = Ai.y - A0.y;
+                            op.pair(acc, A0, N0, dx, dy, dx * dx + dy * dy, op.m.h);
+                        }
+                        if (v1) {
+                            const float dx = Ai.x - A1.x, dy = Ai.y - A1.y;
+                            op.pair(acc, A1, N1, dx, dy, dx * dx + dy * dy, op.m.h);
+                        }
+                    }
+                }
+                if (BUILD) lw.w = (uint32_t)(__popc(lw.x) + __popc(lw.y) + __popc(lw.z)) | NL_OK;
+                const bool wall = op.finish(acc, i, Ai, BUILD ? true : (lw.w & NL_WALL) != 0u);
+                if (BUILD) {
+                    if (wall) lw.w |= NL_WALL;
+                    c.nl[i] = lw;
+                }
+            }
         }
     }
     if (Op::HAS_EPILOGUE) op.epilogue(acc, active, blk);
@@ -357,6 +543,7 @@ struct NBNone {};
 // extra sums cost 3.5 us at N = 1M even behind a launch-uniform branch
 template <class MathT, bool HDIST>
 struct OpDensity {
+    static constexpr bool TILE = true;
     typedef MathT Math;
     static constexpr bool HAS_EPILOGUE = false, SKIP_SELF = false;
     static constexpr bool EXTENDED = false, RING1 = true;
@@ -485,6 +672,7 @@ struct OpDensity {
 // ------------------------------------------------------------------------------------------------
 template <class MathT>
 struct OpAiiConst {
+    static constexpr bool TILE = true;
     typedef MathT Math;
     static constexpr bool HAS_EPILOGUE = false, SKIP_SELF = false;   // W(0) != 0 in the constant field
     static constexpr bool EXTENDED = false;
@@ -577,6 +765,7 @@ struct NBRhoVel {
 
 template <class MathT>
 struct OpNonPressure {
+    static constexpr bool TILE = true;
     typedef MathT Math;
     static constexpr bool HAS_EPILOGUE = false, SKIP_SELF = true;
     static constexpr bool EXTENDED = false;
@@ -704,6 +893,7 @@ __device__ __forceinline__ void solver_block_partial(SolverPartial* __restrict__
 // simulation.rs:2263-2311 summed in the same pass (its self term W(0)-like is not zero, so the own bit stays on the list)
 template <class MathT, bool OMEGA>
 struct OpSource {
+    static constexpr bool TILE = true;
     typedef MathT Math;
     static constexpr bool HAS_EPILOGUE = true, SKIP_SELF = !OMEGA;
     static constexpr bool EXTENDED = false;
@@ -854,19 +1044,88 @@ struct OpSource {
 //   iisph_boundary_pressure_accel                                  boundary_winchenbach2020.rs:164-194
 // The neighbour payload p_j / rho_j^2 is written once per particle by the sweep that produced p.
 // ------------------------------------------------------------------------------------------------
-// tail modes of the FINAL sweep (the one after the stop decision, simulation.rs:1499-1509):
-//   TAIL_NONE                 just a^p
+// What follows the LAST pressure-acceleration sweep of a solve (k_solver_tail, a per-particle map):
+//   TAIL_NONE                 nothing
 //   TAIL_VEL      HybridDFSPH after the divergence solve: v += dt a^p                    (simulation.rs:2547-2560)
 //   TAIL_VX       IISPH / OnlyDivergence: v += dt a^p ; x += dt v                         (simulation.rs:2433-2445, 2486-2499)
 //   TAIL_HYBRID   HybridDFSPH: x += dt v + dt^2 a^p ; v += dt a^p * min(dt*factor, 1)   (simulation.rs:2644-2646)
-// The final sweep is queued speculatively behind the predicted last iteration and runs only once the
-// device-side stop decision has been taken (ctrl->done).
 enum { TAIL_NONE = 0, TAIL_VEL = 1, TAIL_VX = 2, TAIL_HYBRID = 3 };
 
+// parameters of the stop rule (iisph_pressure_iterations, simulation.rs:1453-1479)
+struct SolveP {
+    int residual_density;
+    float max_avg_error;
+    uint32_t max_iters;
+    int multi;   // slab decomposition: block 0 only adds up this rank's totals; the decision follows the all-reduce (k_solver_decide)
+};
+
+// PressureSolverStatistics of iteration `iter` from the per-block partials (fixed order: deterministic; the reference's rayon
+// tree order is not) and the stop rule of simulation.rs:1453-1479.  Called by ALL threads of one block.
+__device__ __forceinline__ void solver_reduce_decide(const SolverPartial* __restrict__ partials, uint32_t nparts, SolverCtrl* ctrl, double* __restrict__ tot,
+                                                     int iter, const SolveP& q, float rest_density, float dt)
+{
+    __shared__ SolverPartial s_r[SWEEP_THREADS / 64];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    SolverPartial t{0, 0, 0, 0.f, 0.f};
+    for (uint32_t k = tid; k < nparts; k += SWEEP_THREADS) {
+        const SolverPartial v = partials[k];
+        t.normal += v.normal;
+        t.singular += v.singular;
+        t.negative += v.negative;
+        t.sum_err += v.sum_err;
+        t.max_err = fmaxf(t.max_err, v.max_err);
+    }
+    t.normal = wave_sum_u32(t.normal);
+    t.singular = wave_sum_u32(t.singular);
+    t.negative = wave_sum_u32(t.negative);
+    t.sum_err = wave_sum(t.sum_err);
+    t.max_err = wave_max(t.max_err);
+    if (lane == 0) s_r[w] = t;
+    __syncthreads();
+    if (tid != 0) return;
+    t = s_r[0];
+    for (int k = 1; k < SWEEP_THREADS / 64; k++) {
+        t.normal += s_r[k].normal;
+        t.singular += s_r[k].singular;
+        t.negative += s_r[k].negative;
+        t.sum_err += s_r[k].sum_err;
+        t.max_err = fmaxf(t.max_err, s_r[k].max_err);
+    }
+    if (q.multi) {   // local totals (doubles, exact for the counts) -> all-reduce(sum) over the ranks -> k_solver_decide
+        tot[0] = (double)t.normal;
+        tot[1] = (double)t.singular;
+        tot[2] = (double)t.negative;
+        tot[3] = (double)t.sum_err;
+        tot[4] = (double)t.max_err;   // not all-reduced: local maximum, informational
+        return;
+    }
+    const float avg = t.normal > 0 ? t.sum_err / (float)t.normal : __uint_as_float(0x7fc00000u);
+    bool stop;
+    if (q.residual_density) stop = t.normal == 0 || (fabsf(avg / rest_density) < q.max_avg_error && iter > 1);
+    else stop = t.normal == 0 || (fabsf(avg) < q.max_avg_error / dt && iter > 1);
+    if (!stop && (uint32_t)iter == q.max_iters) stop = true;
+    ctrl->normal = t.normal;
+    ctrl->singular = t.singular;
+    ctrl->negative = t.negative;
+    ctrl->sum_err = t.sum_err;
+    ctrl->max_err = t.max_err;
+    ctrl->iters = (uint32_t)iter;
+    ctrl->cur = (uint32_t)((iter + 1) & 1);  // mem::swap(pressure, pressure_next_iter)
+    ctrl->slot_done[(iter + 1) & 1] = stop ? 1u : 0u;
+    if (stop) ctrl->done = 1u;
+}
+
+// Sweep A of iteration `iter` >= 1 reads pressure buffer iter & 1 -- and its block 0 first takes the stop decision of iteration
+// iter - 1 from the partials sweep B left behind, while the other blocks already sweep (no reduction kernel, no launch gap
+// between B and the next A).  If that decision is "stop", this launch WAS the solve's last pressure-acceleration sweep
+// (simulation.rs:1499-1509: a^p from the final pressures) and every later launch of the solve returns at once.  The flag a
+// launch writes is never one its own blocks read: slot_done[iter & 1] is written here and read by B(iter) and A(iter + 1);
+// slot_done[(iter - 1) & 1] is what this launch tests.
 template <class MathT>
 struct OpPressureAccel {
+    static constexpr bool TILE = true;
     typedef MathT Math;
-    static constexpr bool HAS_EPILOGUE = true, SKIP_SELF = true;   // epilogue: next step's header (integrating tails only)
+    static constexpr bool HAS_EPILOGUE = false, SKIP_SELF = true;
     static constexpr bool EXTENDED = false, RING1 = true;
     __device__ constexpr float krange() const { return 2.f; }
     typedef float NB;  // p_j / (rho_j * rho_j)
@@ -880,50 +1139,33 @@ struct OpPressureAccel {
     const float* __restrict__ pt1;
     const float2* __restrict__ lam_grad;
     float2* __restrict__ pacc;
-    float2* __restrict__ vel;
-    float4* __restrict__ pm_out;
-    const SolverCtrl* __restrict__ ctrl;
+    SolverCtrl* ctrl;
+    const SolverPartial* __restrict__ partials;
+    uint32_t nparts;
+    double* __restrict__ tot;
     DeviceStatus* status;
     StepP sp;
-    int iter;  // >= 0: Jacobi iteration `iter` (reads buffer iter&1, skipped when the solve is done); < 0: final sweep
-    int tail;
-    // The integrating tails know the positions and velocities the NEXT step starts from: they also reduce that step's
-    // header (bounding box, h and mass range, CFL term -- what k_header computes) per block, so the next step starts
-    // without the header kernels and without the host wait behind them.  nullptr: not wanted.
-    HeaderOut* __restrict__ hdr_partials;
-    const uint8_t* __restrict__ owned_flag;   // slab decomposition (else nullptr): ring-1 ghost lanes compute a^p, no tail
+    SolveP solve;
+    int iter;  // >= 1: Jacobi iteration `iter`; < 0: explicit sweep with the solve's final pressures (IISPH2 after its rescaling)
+    const uint8_t* __restrict__ owned_flag;   // slab decomposition (else nullptr): ring-1 ghost lanes compute a^p as well
     struct Acc {
         float ax, ay, p1t;
         const float* pt;
         const float* p;
-        float nx, ny, ncfl, nh;   // next-step header contributions of this particle
     };
-    __device__ bool skip() const { return iter >= 0 ? ctrl->done != 0u : ctrl->done == 0u; }
-    __device__ bool lane_skip(uint32_t) const { return false; }
-    __device__ void epilogue(Acc& a, bool active, uint32_t blk) const
+    __device__ bool skip() const { return false; }
+    __device__ bool prologue(uint32_t raw_block) const
     {
-        if (!hdr_partials || tail < TAIL_VX) return;   // launch-uniform
-        const float INF = __uint_as_float(0x7f800000u);
-        float mnx = active ? a.nx : INF, mxx = active ? a.nx : -INF, mny = active ? a.ny : INF, mxy = active ? a.ny : -INF;
-        float hmx = active ? a.nh : 0.f, hmn = active ? a.nh : INF;
-        float cfl = active ? a.ncfl : INF;
-        mnx = wave_min(mnx); mny = wave_min(mny); mxx = wave_max(mxx); mxy = wave_max(mxy);
-        hmx = wave_max(hmx); hmn = wave_min(hmn); cfl = wave_min(cfl);
-        __shared__ HeaderOut s_h[SWEEP_THREADS / 64];
-        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-        if (lane == 0) s_h[w] = HeaderOut{mnx, mny, mxx, mxy, hmx, hmn, cfl, 0};
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            HeaderOut o = s_h[0];
-            for (int k = 1; k < SWEEP_THREADS / 64; k++) {
-                o.min_x = fminf(o.min_x, s_h[k].min_x); o.min_y = fminf(o.min_y, s_h[k].min_y);
-                o.max_x = fmaxf(o.max_x, s_h[k].max_x); o.max_y = fmaxf(o.max_y, s_h[k].max_y);
-                o.h_max = fmaxf(o.h_max, s_h[k].h_max); o.h_min = fminf(o.h_min, s_h[k].h_min);
-                o.min_cfl = fminf(o.min_cfl, s_h[k].min_cfl);
-            }
-            hdr_partials[blk] = o;
+        if (iter < 0) return ctrl->done == 0u;
+        if (ctrl->slot_done[(iter - 1) & 1] != 0u) {   // the solve ended before this launch: hand the flag on, leave
+            if (raw_block == 0u && threadIdx.x == 0 && !solve.multi) ctrl->slot_done[iter & 1] = 1u;
+            return true;
         }
+        if (raw_block == 0u) solver_reduce_decide(partials, nparts, ctrl, tot, iter - 1, solve, sp.rest_density, sp.dt);
+        return false;
     }
+    __device__ bool lane_skip(uint32_t) const { return false; }
+    __device__ void epilogue(Acc&, bool, uint32_t) const {}
     __device__ float4 loadA(uint32_t j) const { return pm[j]; }
     __device__ NB nb(const Acc& a, uint32_t j, float4) const { return a.pt[j]; }
     __device__ void init(Acc& a) const
@@ -945,7 +1187,7 @@ struct OpPressureAccel {
         a.ax += f * gx;
         a.ay += f * gy;
     }
-    __device__ bool finish(Acc& a, uint32_t i, float4 Ai, bool wall) const
+    __device__ bool finish(Acc& a, uint32_t i, float4, bool wall) const
     {
         float bx = 0.f, by = 0.f;
         const bool own = !owned_flag || owned_flag[i];
@@ -960,43 +1202,77 @@ struct OpPressureAccel {
             bx = f * gl.x;
             by = f * gl.y;
         }
-        const float2 ap = make_float2(a.ax + bx, a.ay + by);
-        pacc[i] = ap;
-        if (tail != TAIL_NONE && own) {
-            const float dt = sp.dt;
-            float2 v = vel[i];
-            float4 p = Ai;   // integrated position (tails VX / HYBRID)
-            if (tail == TAIL_VEL) {
-                v.x += dt * ap.x;
-                v.y += dt * ap.y;
-                if (!isfinite(v.x) || !isfinite(v.y)) raise_error(status, SPH_ERR_VELOCITY_NOT_FINITE, orig[i]);
-            } else if (tail == TAIL_VX) {
-                v.x += dt * ap.x;
-                v.y += dt * ap.y;
-                p.x += dt * v.x;
-                p.y += dt * v.y;
-                if (!isfinite(v.x) || !isfinite(v.y)) raise_error(status, SPH_ERR_VELOCITY_NOT_FINITE, orig[i]);
-                pm_out[i] = p;
-            } else {
-                p.x += dt * v.x + dt * dt * ap.x;
-                p.y += dt * v.y + dt * dt * ap.y;
-                v.x += dt * ap.x * sp.hyb_vfactor;
-                v.y += dt * ap.y * sp.hyb_vfactor;
-                if (!isfinite(p.x) || !isfinite(p.y)) raise_error(status, SPH_ERR_POSITION_NOT_FINITE, orig[i]);
-                pm_out[i] = p;
-            }
-            vel[i] = v;
-            if (tail >= TAIL_VX) {   // k_header's per-particle terms (sph_api.hip), from the values just written
-                a.nx = p.x;
-                a.ny = p.y;
-                a.nh = Ai.w;
-                const float sr = Ai.w * 2.f;
-                a.ncfl = sr * sr / ((v.x * v.x + v.y * v.y) + 0.01f);   // simulation.rs:2182-2189
-            }
-        }
+        pacc[i] = make_float2(a.ax + bx, a.ay + by);
         return wall;
     }
 };
+
+// The solve's tail: the integrate map of the solver mode (TAIL_*) on the owned particles, run once the stop decision is taken.
+// The integrating tails know the positions and velocities the NEXT step starts from: they also reduce that step's header
+// (bounding box, h range, CFL term -- what k_header computes) per block, so the next step starts without the header kernels
+// and without the host wait behind them (hdr_partials == nullptr: not wanted).
+__global__ __launch_bounds__(256) void k_solver_tail(uint32_t n, int tail, float dt, float vfactor, const float4* __restrict__ pm, float4* __restrict__ pm_out,
+                                                      float2* __restrict__ vel, const float2* __restrict__ pacc, const uint32_t* __restrict__ orig,
+                                                      const uint8_t* __restrict__ owned, const SolverCtrl* __restrict__ ctrl, HeaderOut* __restrict__ hdr_partials,
+                                                      DeviceStatus* status)
+{
+    if (ctrl->done == 0u) return;
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    const bool active = i < n && (!owned || owned[i]);
+    float nx = 0.f, ny = 0.f, nh = 0.f, ncfl = 0.f;
+    if (active) {
+        const float4 Ai = pm[i];
+        const float2 ap = pacc[i];
+        float2 v = vel[i];
+        float4 p = Ai;
+        if (tail == TAIL_VEL) {
+            v.x += dt * ap.x;
+            v.y += dt * ap.y;
+            if (!isfinite(v.x) || !isfinite(v.y)) raise_error(status, SPH_ERR_VELOCITY_NOT_FINITE, orig[i]);
+        } else if (tail == TAIL_VX) {
+            v.x += dt * ap.x;
+            v.y += dt * ap.y;
+            p.x += dt * v.x;
+            p.y += dt * v.y;
+            if (!isfinite(v.x) || !isfinite(v.y)) raise_error(status, SPH_ERR_VELOCITY_NOT_FINITE, orig[i]);
+            pm_out[i] = p;
+        } else {
+            p.x += dt * v.x + dt * dt * ap.x;
+            p.y += dt * v.y + dt * dt * ap.y;
+            v.x += dt * ap.x * vfactor;
+            v.y += dt * ap.y * vfactor;
+            if (!isfinite(p.x) || !isfinite(p.y)) raise_error(status, SPH_ERR_POSITION_NOT_FINITE, orig[i]);
+            pm_out[i] = p;
+        }
+        vel[i] = v;
+        nx = p.x;
+        ny = p.y;
+        nh = Ai.w;
+        const float sr = Ai.w * 2.f;
+        ncfl = sr * sr / ((v.x * v.x + v.y * v.y) + 0.01f);   // simulation.rs:2182-2189
+    }
+    if (!hdr_partials || tail < TAIL_VX) return;   // launch-uniform
+    const float INF = __uint_as_float(0x7f800000u);
+    float mnx = active ? nx : INF, mxx = active ? nx : -INF, mny = active ? ny : INF, mxy = active ? ny : -INF;
+    float hmx = active ? nh : 0.f, hmn = active ? nh : INF;
+    float cfl = active ? ncfl : INF;
+    mnx = wave_min(mnx); mny = wave_min(mny); mxx = wave_max(mxx); mxy = wave_max(mxy);
+    hmx = wave_max(hmx); hmn = wave_min(hmn); cfl = wave_min(cfl);
+    __shared__ HeaderOut s_h[4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) s_h[w] = HeaderOut{mnx, mny, mxx, mxy, hmx, hmn, cfl, 0};
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        HeaderOut o = s_h[0];
+        for (int k = 1; k < 4; k++) {
+            o.min_x = fminf(o.min_x, s_h[k].min_x); o.min_y = fminf(o.min_y, s_h[k].min_y);
+            o.max_x = fmaxf(o.max_x, s_h[k].max_x); o.max_y = fmaxf(o.max_y, s_h[k].max_y);
+            o.h_max = fmaxf(o.h_max, s_h[k].h_max); o.h_min = fminf(o.h_min, s_h[k].h_min);
+            o.min_cfl = fminf(o.min_cfl, s_h[k].min_cfl);
+        }
+        hdr_partials[blockIdx.x] = o;
+    }
+}
 
 // ------------------------------------------------------------------------------------------------
 // Op: relaxed-Jacobi pressure update (sweep B)
@@ -1007,6 +1283,7 @@ struct OpPressureAccel {
 // ------------------------------------------------------------------------------------------------
 template <class MathT>
 struct OpJacobi {
+    static constexpr bool TILE = true;
     typedef MathT Math;
     static constexpr bool HAS_EPILOGUE = true, SKIP_SELF = true;
     static constexpr bool EXTENDED = false;
@@ -1036,7 +1313,7 @@ struct OpJacobi {
         float err;       // residual of a "normal" particle
         uint32_t cls;    // 0 normal, 1 singular, 2 negative (PressureSolverStatistics, simulation.rs:397-445)
     };
-    __device__ bool skip() const { return ctrl->done != 0u; }
+    __device__ bool skip() const { return ctrl->slot_done[iter & 1] != 0u; }   // the decision A(iter) took on iteration iter - 1
     __device__ bool lane_skip(uint32_t) const { return false; }
     __device__ void init(Acc&) const {}
     __device__ float4 loadA(uint32_t j) const { return pm[j]; }
@@ -1639,107 +1916,18 @@ __global__ __launch_bounds__(256) void k_classify(uint32_t n, const float4* __re
 }
 
 // ------------------------------------------------------------------------------------------------
-// residual reduction + stop decision    (PressureSolverStatistics simulation.rs:397-469,
-// stopping rule of iisph_pressure_iterations simulation.rs:1453-1479)
-// One 1024-thread block adds the Jacobi kernel's per-block partials in a fixed order (deterministic;
-// the reference's rayon tree order is not) and takes the stop decision on the device.
+// stop decision of a slab decomposition: the ranks' totals of iteration `iter` (solver_reduce_decide, multi) were all-reduced
+// (RCCL, in stream); every rank takes the same decision here (stopping rule of iisph_pressure_iterations, simulation.rs:1453-1479)
 // ------------------------------------------------------------------------------------------------
-#ifndef SF_THREADS
-#define SF_THREADS 1024
-#endif
-__global__ __launch_bounds__(SF_THREADS) void k_solver_final(const SolverPartial* __restrict__ partials, uint32_t nparts, SolverCtrl* ctrl, int iter,
-                                                        int residual_density, float max_avg_error, uint32_t max_iters, float rest_density,
-                                                        float dt)
-{
-    if (ctrl->done) return;
-    __shared__ SolverPartial s_w[SF_THREADS / 64];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    SolverPartial t{0, 0, 0, 0.f, 0.f};
-    for (uint32_t k = tid; k < nparts; k += SF_THREADS) {
-        const SolverPartial q = partials[k];
-        t.normal += q.normal;
-        t.singular += q.singular;
-        t.negative += q.negative;
-        t.sum_err += q.sum_err;
-        t.max_err = fmaxf(t.max_err, q.max_err);
-    }
-    t.normal = wave_sum_u32(t.normal);
-    t.singular = wave_sum_u32(t.singular);
-    t.negative = wave_sum_u32(t.negative);
-    t.sum_err = wave_sum(t.sum_err);
-    t.max_err = wave_max(t.max_err);
-    if (lane == 0) s_w[w] = t;
-    __syncthreads();
-    if (tid == 0) {
-        t = s_w[0];
-        for (int k = 1; k < SF_THREADS / 64; k++) {
-            t.normal += s_w[k].normal;
-            t.singular += s_w[k].singular;
-            t.negative += s_w[k].negative;
-            t.sum_err += s_w[k].sum_err;
-            t.max_err = fmaxf(t.max_err, s_w[k].max_err);
-        }
-        const float avg = t.normal > 0 ? t.sum_err / (float)t.normal : __uint_as_float(0x7fc00000u);
-        bool stop;
-        if (residual_density) stop = t.normal == 0 || (fabsf(avg / rest_density) < max_avg_error && iter > 1);
-        else stop = t.normal == 0 || (fabsf(avg) < max_avg_error / dt && iter > 1);
-        if (!stop && (uint32_t)iter == max_iters) stop = true;
-        ctrl->normal = t.normal;
-        ctrl->singular = t.singular;
-        ctrl->negative = t.negative;
-        ctrl->sum_err = t.sum_err;
-        ctrl->max_err = t.max_err;
-        ctrl->iters = (uint32_t)iter;
-        ctrl->cur = (uint32_t)((iter + 1) & 1);  // mem::swap(pressure, pressure_next_iter)
-        if (stop) ctrl->done = 1u;
-    }
-}
-
-// multi-rank variant: local totals (doubles, exact for the counts) -> all-reduce(sum) over the ranks (RCCL, in
-// stream) -> the same stop decision on every rank
-__global__ __launch_bounds__(1024) void k_solver_local(const SolverPartial* __restrict__ partials, uint32_t nparts, const SolverCtrl* ctrl,
-                                                        double* __restrict__ tot)
-{
-    if (ctrl->done) return;
-    __shared__ SolverPartial s_w[16];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    SolverPartial t{0, 0, 0, 0.f, 0.f};
-    for (uint32_t k = tid; k < nparts; k += 1024) {
-        const SolverPartial q = partials[k];
-        t.normal += q.normal;
-        t.singular += q.singular;
-        t.negative += q.negative;
-        t.sum_err += q.sum_err;
-        t.max_err = fmaxf(t.max_err, q.max_err);
-    }
-    t.normal = wave_sum_u32(t.normal);
-    t.singular = wave_sum_u32(t.singular);
-    t.negative = wave_sum_u32(t.negative);
-    t.sum_err = wave_sum(t.sum_err);
-    t.max_err = wave_max(t.max_err);
-    if (lane == 0) s_w[w] = t;
-    __syncthreads();
-    if (tid == 0) {
-        t = s_w[0];
-        for (int k = 1; k < 16; k++) {
-            t.normal += s_w[k].normal;
-            t.singular += s_w[k].singular;
-            t.negative += s_w[k].negative;
-            t.sum_err += s_w[k].sum_err;
-            t.max_err = fmaxf(t.max_err, s_w[k].max_err);
-        }
-        tot[0] = (double)t.normal;
-        tot[1] = (double)t.singular;
-        tot[2] = (double)t.negative;
-        tot[3] = (double)t.sum_err;
-        tot[4] = (double)t.max_err;  // not all-reduced: local maximum, informational
-    }
-}
-
 __global__ void k_solver_decide(const double* __restrict__ tot, SolverCtrl* ctrl, int iter, int residual_density, float max_avg_error,
                                 uint32_t max_iters, float rest_density, float dt)
 {
-    if (threadIdx.x != 0 || ctrl->done) return;
+    if (threadIdx.x != 0) return;
+    const uint32_t slot = (uint32_t)(iter + 1) & 1u;
+    if (ctrl->slot_done[iter & 1] != 0u) {   // decided earlier: hand the flag on (the totals are stale)
+        ctrl->slot_done[slot] = 1u;
+        return;
+    }
     const uint32_t normal = (uint32_t)tot[0];
     const float sum_err = (float)tot[3];
     const float avg = normal > 0 ? sum_err / (float)normal : __uint_as_float(0x7fc00000u);
@@ -1754,6 +1942,7 @@ __global__ void k_solver_decide(const double* __restrict__ tot, SolverCtrl* ctrl
     ctrl->max_err = (float)tot[4];
     ctrl->iters = (uint32_t)iter;
     ctrl->cur = (uint32_t)((iter + 1) & 1);
+    ctrl->slot_done[slot] = stop ? 1u : 0u;
     if (stop) ctrl->done = 1u;
 }
 
@@ -1884,6 +2073,7 @@ __global__ __launch_bounds__(256) void k_constrain_apply(uint32_t n, float4* __r
 // ------------------------------------------------------------------------------------------------
 template <class A, class B>
 struct OpFuse {
+    static constexpr bool TILE = true;
     typedef typename A::Math Math;
     static constexpr bool HAS_EPILOGUE = false, SKIP_SELF = A::SKIP_SELF && B::SKIP_SELF, EXTENDED = false;
     __device__ constexpr float krange() const { return 2.f; }
@@ -1974,12 +2164,36 @@ static SweepCommon common_of(const SweepArgs& a, bool ext)
     return SweepCommon{a.g, ext ? a.t_ext : a.t, a.n, (a.n + SWEEP_THREADS - 1) / SWEEP_THREADS, a.cell_start, ext ? a.nl_ext : a.nl, ext ? a.nlx_ext : a.nlx, a.owned, a.ring1};
 }
 
+// SPH_TILE: bit 0 = the BUILD sweep (density), bit 1 = the replay sweeps through the LDS-staged form (k_sweep_tile) in
+// uniform-h scenes.  Measured on MI355X: profiles/r2_variants.md.
+static int g_tile_mode = -1;
+static int tile_mode()
+{
+    if (g_tile_mode < 0) {
+        const char* e = getenv("SPH_TILE");
+        g_tile_mode = e ? atoi(e) : SPH_TILE_DEFAULT;
+    }
+    return g_tile_mode;
+}
+extern "C" int sph_set_sweep_variant(int mode)
+{
+    if (mode < 0 || mode > 3) return SPH_ERR_INVALID_ARGUMENT;
+    g_tile_mode = mode;
+    return SPH_OK;
+}
+
 template <class Op, bool BUILD>
 static void launch_sweep(hipStream_t s, const SweepArgs& a, const Op& op)
 {
     if (a.n == 0) return;
     const uint32_t nblocks = (a.n + SWEEP_THREADS - 1) / SWEEP_THREADS;
     const uint32_t grid = ((nblocks + 7) / 8) * 8;  // XCD remap needs a multiple of 8
+    if constexpr (Op::Math::UNIFORM && !Op::EXTENDED && OpTile<Op>::value) {
+        if (tile_mode() & (BUILD ? 1 : 2)) {
+            hipLaunchKernelGGL((k_sweep_tile<Op, BUILD>), dim3(grid), dim3(SWEEP_THREADS), 0, s, op, common_of(a, Op::EXTENDED));
+            return;
+        }
+    }
     hipLaunchKernelGGL((k_sweep<Op, BUILD>), dim3(grid), dim3(SWEEP_THREADS), 0, s, op, common_of(a, Op::EXTENDED));
 }
 
@@ -2107,11 +2321,20 @@ void launch_source_term(hipStream_t s, Profiler* prof, const SweepArgs& a, int k
                  (SolverPartial*)a.partials, a.ctrl, a.status, a.sp, kind, residual_density, nullptr, nullptr)
 }
 
-void launch_pressure_accel(hipStream_t s, Profiler* prof, const SweepArgs& a, int iter, int tail, float4* pm_out)
+void launch_pressure_accel(hipStream_t s, Profiler* prof, const SweepArgs& a, int iter, int residual_density, float max_avg_error, uint32_t max_iters, int multi)
 {
-    ProfScope ps(prof, iter >= 0 ? "pressure_accel" : "pressure_accel_final", s);
-    SPH_DISPATCH(OpPressureAccel, false, a.pm, a.orig, a.rho, a.p0, a.p1, a.pt0, a.pt1, a.lam_grad, a.pacc, a.vel, pm_out, a.ctrl, a.status, a.sp,
-                 iter, tail, (iter < 0 && tail >= TAIL_VX) ? a.hdr_partials : nullptr, a.owned)
+    ProfScope ps(prof, "pressure_accel", s);
+    const SolveP q{residual_density, max_avg_error, max_iters, multi};
+    SPH_DISPATCH(OpPressureAccel, false, a.pm, a.orig, a.rho, a.p0, a.p1, a.pt0, a.pt1, a.lam_grad, a.pacc, a.ctrl, (const SolverPartial*)a.partials,
+                 solver_reduce_blocks(a.n), a.solver_tot, a.status, a.sp, q, iter, a.owned)
+}
+
+void launch_solver_tail(hipStream_t s, Profiler* prof, const SweepArgs& a, int tail, float4* pm_out)
+{
+    ProfScope ps(prof, "solver_tail", s);
+    if (a.n && tail != TAIL_NONE)
+        hipLaunchKernelGGL(k_solver_tail, dim3((a.n + 255) / 256), dim3(256), 0, s, a.n, tail, a.sp.dt, a.sp.hyb_vfactor, a.pm, pm_out, a.vel, a.pacc, a.orig,
+                           a.owned, a.ctrl, tail >= TAIL_VX ? a.hdr_partials : nullptr, a.status);
 }
 
 void launch_jacobi_update(hipStream_t s, Profiler* prof, const SweepArgs& a, int iter, int residual_density)
@@ -2122,21 +2345,6 @@ void launch_jacobi_update(hipStream_t s, Profiler* prof, const SweepArgs& a, int
     float* ptout = (iter & 1) ? a.pt0 : a.pt1;
     SPH_DISPATCH(OpJacobi, false, a.pm, a.orig, a.rho, a.mrho, a.pacc, a.lam_grad, a.aii, a.src, pin, pout, ptout, a.dens_err, (SolverPartial*)a.partials, a.ctrl,
                  a.status, a.sp, iter, residual_density)
-}
-
-void launch_solver_reduce(hipStream_t s, Profiler* prof, const SweepArgs& a, int iter, int residual_density, float max_avg_error,
-                          uint32_t max_iters, float* block_partials)
-{
-    ProfScope ps(prof, "solver_reduce", s);
-    hipLaunchKernelGGL(k_solver_final, dim3(1), dim3(SF_THREADS), 0, s, (const SolverPartial*)block_partials, solver_reduce_blocks(a.n), a.ctrl, iter,
-                       residual_density, max_avg_error, max_iters, a.sp.rest_density, a.sp.dt);
-}
-
-void launch_solver_local(hipStream_t s, Profiler* prof, const SweepArgs& a, float* block_partials)
-{
-    ProfScope ps(prof, "solver_reduce", s);
-    hipLaunchKernelGGL(k_solver_local, dim3(1), dim3(1024), 0, s, (const SolverPartial*)block_partials, solver_reduce_blocks(a.n), a.ctrl,
-                       a.solver_tot);
 }
 
 void launch_solver_decide(hipStream_t s, Profiler* prof, const SweepArgs& a, int iter, int residual_density, float max_avg_error,

@@ -131,7 +131,7 @@ class SphError(RuntimeError):
 # every symbol include/sph_ffi.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
     "create", "destroy", "upload", "upload_field", "download", "download_neighbors", "num_particles", "time",
-    "set_time", "step", "classify", "last_error", "grid", "set_boundary_polygon", "apply_edits", "profile_enable", "profile_reset", "profile_get", "profile_event_overhead", "profile_copy_bandwidth",
+    "set_time", "step", "classify", "last_error", "grid", "set_boundary_polygon", "apply_edits", "profile_enable", "profile_reset", "profile_get", "profile_event_overhead", "profile_copy_bandwidth", "set_sweep_variant",
     "dist_configure", "dist_set_rebalance", "dist_get_cuts", "dist_get_stats", "comm_unique_id", "comm_init", "group_step",
 ]
 
@@ -182,6 +182,7 @@ class SphLibrary:
         self.profile_get = sig("profile_get", i32, [vp, C.POINTER(SphKernelTime), i32, C.POINTER(i32)], required=False)
         self.profile_event_overhead = sig("profile_event_overhead", i32, [vp, C.POINTER(C.c_double)], required=False)
         self.profile_copy_bandwidth = sig("profile_copy_bandwidth", i32, [vp, u64, C.POINTER(C.c_double)], required=False)
+        self.set_sweep_variant = sig("set_sweep_variant", i32, [i32], required=False)
         self.comm_unique_id = sig("comm_unique_id", i32, [C.POINTER(C.c_uint8)], required=False)
         self.comm_init = sig("comm_init", i32, [vp, C.POINTER(C.c_uint8), i32, i32], required=False)
         self.dist_configure = sig("dist_configure", i32, [vp, i32, i32, C.c_float, C.c_float], required=False)

@@ -40,14 +40,14 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s;
 ALGO_BYTES = {
     "density": 20, "aii_constfield": 40, "non_pressure_accel": 36, "source_term": 44,
     "aii_nonpressure": 56,   # the two above in one sweep: x, y, m, h, rho, lambda terms, v read once; a_ii, constant_field, v' written
-    "pressure_accel": 40, "pressure_accel_final": 40, "jacobi_update": 60,
+    "pressure_accel": 40, "jacobi_update": 60,
+    "solver_tail": 40,       # the integrate map behind the last pressure-acceleration sweep of a solve: x, y, vx, vy, a^p -> x, y, vx, vy
 }
 
 
 # rocprofv3 kernel names of the sweeps (profiles/*_kernel_summary.json keys)
 PMC_NAMES = {"density": "OpDensity[build]", "aii_constfield": "OpAiiConst", "non_pressure_accel": "OpNonPressure",
-             "source_term": "OpSource", "pressure_accel": "OpPressureAccel", "pressure_accel_final": "OpPressureAccel",
-             "jacobi_update": "OpJacobi"}
+             "source_term": "OpSource", "pressure_accel": "OpPressureAccel", "jacobi_update": "OpJacobi"}
 
 
 def committed_pmc_traffic(kernel):

@@ -317,6 +317,12 @@ int  sph_profile_event_overhead(sph_ctx* ctx, double* microseconds);
  * HBM rate on this device, reported next to the 8 TB/s spec peak */
 int  sph_profile_copy_bandwidth(sph_ctx* ctx, uint64_t bytes, double* gb_per_s);
 
+/* Which form of the neighbour sweeps runs in uniform-h scenes (process-wide; both forms give bit-identical results, the
+ * ablation harness scripts/variants/ times them): bit 0 = the density / list-building sweep, bit 1 = the list-replaying sweeps
+ * through the LDS-staged form (the wave's three candidate rows loaded once, coalesced, into LDS) instead of per-lane gathers.
+ * The environment variable SPH_TILE sets the initial value. */
+int sph_set_sweep_variant(int mode);
+
 /* ---- multi-GPU: 1-D slab decomposition along x, one process (= one context) per GPU --------
  * (the reference has no counterpart: its only parallelism is rayon inside one process, concurrency.rs:110-204)
  * sph_dist_configure makes `ctx` rank `rank` of `n_ranks`, owning the particles with cut_lo <= x < cut_hi

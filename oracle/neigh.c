@@ -15,6 +15,7 @@
 #include "sphmath.h"
 
 #include <math.h>
+#include <omp.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -197,10 +198,13 @@ int orc_build_neighbors(oracle_ctx* c, float k)
         }
         free(fill);
     }
-    /* pass 1: counts; pass 2: fill (lists sorted ascending) */
+    /* pass 1: counts; pass 2: fill (lists sorted ascending).  One size class: every particle costs the same, and a static
+     * schedule touches the list memory from the threads that read it in the sweeps (first touch on a multi-socket host);
+     * several classes: a coarse particle among fine ones tests thousands of candidates, so the work is handed out dynamically */
     int too_many = 0;
+    omp_set_schedule(ncls == 1 ? omp_sched_static : omp_sched_dynamic, ncls == 1 ? 0 : 256);
     if (!rc) {
-#pragma omp parallel for schedule(dynamic, 256) reduction(| : too_many)
+#pragma omp parallel for schedule(runtime) reduction(| : too_many)
         for (int64_t ii = 0; ii < (int64_t)n; ii++) {
             const uint32_t cnt = visit_candidates(G, ncls, pos, h, k, (uint64_t)ii, NULL);
             if (cnt > ORC_MAX_NEIGHBOR_COUNT) too_many = 1;
@@ -220,7 +224,7 @@ int orc_build_neighbors(oracle_ctx* c, float k)
         }
     }
     if (!rc) {
-#pragma omp parallel for schedule(dynamic, 256)
+#pragma omp parallel for schedule(runtime)
         for (int64_t ii = 0; ii < (int64_t)n; ii++) {
             uint32_t* out = c->nb_idx + c->nb_off[ii];
             const uint32_t cnt = visit_candidates(G, ncls, pos, h, k, (uint64_t)ii, out);
