@@ -2,10 +2,11 @@
 window (platform/desktop/main_loop.rs:36-82, 105-181, 346-350), on the HIP library.
 
 Same arguments, same YAML formats, same override rule (`-c FILE`: every key of FILE must already exist in the
-simulation config, main_loop.rs:113-126), same statistics text (`-p`, `-w PATH`; simulation.rs:3279-3359).  What it
-does NOT do is the host-side adaptivity (single_step_adaptivity, simulation.rs:2732-2796: split / merge / share): that
-stays in the Rust host.  A config with merging / sharing / splitting enabled is therefore refused
-unless `--without-adaptivity` says that only single_step_without_adaptivity is wanted.
+simulation config, main_loop.rs:113-126), same statistics text (`-p`, `-w PATH`; simulation.rs:3279-3359).  A config that
+enables merging / sharing / splitting runs single_step (the step + single_step_adaptivity, simulation.rs:1973-1978): the
+partner decisions on the host (adaptivity.py), the particle data on the device; the split patterns come from
+`./split-patterns.yaml` like in the reference (main_loop.rs:200-203) or from `--split-patterns`.
+`--without-adaptivity` steps with single_step_without_adaptivity only.
 """
 from __future__ import annotations
 
@@ -30,10 +31,12 @@ def build_parser() -> argparse.ArgumentParser:
     run.add_argument("-c", "--overwrite-config-file", default=None, help="Overwrite config")
     run.add_argument("-p", "--statistics-enabled", action="store_true", help="Track performance of individual steps")
     run.add_argument("-w", "--statistics-path", default=None, help="Where to write statistics to")
-    # not in the reference: the window's close button has no headless equivalent, and adaptivity is not on this path
+    # not in the reference: the window's close button has no headless equivalent
     run.add_argument("--max-steps", type=int, default=None, help="Stop after this many steps (headless replacement of closing the window)")
     run.add_argument("--without-adaptivity", action="store_true",
                      help="step with single_step_without_adaptivity even if the config enables merging/sharing/splitting")
+    run.add_argument("--split-patterns", default="./split-patterns.yaml", help="SplitPatterns file (load_split_patterns_from_file)")
+    run.add_argument("--capacity-factor", type=float, default=4.0, help="device capacity = this x the initial particle count (splitting adds particles)")
     run.add_argument("--device", type=int, default=0)
     # the reference's VtkExporter is compiled in but switched off (main_loop.rs:253 `export_vtk_data = false`); same writer here
     run.add_argument("--vtk", default=None, metavar="FOLDER", help="write FOLDER/my-sph-NNNNN.vtk + my-sph.vtk.series (one snapshot per step)")
@@ -49,12 +52,18 @@ def run(args, lib: Optional[ffi.SphLibrary] = None, out=sys.stdout) -> int:
     print(scene, file=out)
     if args.max_seconds is None and args.max_steps is None:
         raise SystemExit("headless run: give --max-seconds and/or --max-steps (there is no window to close)")
-    if (params.merging or params.sharing or params.splitting) and not args.without_adaptivity:
-        raise SystemExit("this config enables merging/sharing/splitting: single_step_adaptivity stays on the reference host; "
-                         "pass --without-adaptivity to run single_step_without_adaptivity only")
+    adaptive = (params.merging or params.sharing or params.splitting) and not args.without_adaptivity
     params = init_simulation_params(params, scene)
     counters = bool(args.statistics_enabled or args.statistics_path)
-    sim = init_fluid_sim(params, scene, counters_enabled=counters, lib=lib, device_id=args.device)
+    split_patterns, capacity = None, None
+    if adaptive:
+        from .adaptivity import SplitPatterns
+        from .scene import init_particles
+        if params.splitting:
+            split_patterns = SplitPatterns.load_from_file(args.split_patterns)
+        capacity = int(len(init_particles(scene)[1]) * args.capacity_factor) + 1024
+    sim = init_fluid_sim(params, scene, counters_enabled=counters, lib=lib, device_id=args.device, split_patterns=split_patterns,
+                         n_capacity=capacity)
     p = params.to_ffi()
     vtk = None
     if getattr(args, "vtk", None):
@@ -64,7 +73,10 @@ def run(args, lib: Optional[ffi.SphLibrary] = None, out=sys.stdout) -> int:
         vtk_planes = boundary_planes(scene.boundary, params.init_boundary_handler)
     steps, t0 = 0, time.perf_counter()
     while (args.max_seconds is None or sim.time < args.max_seconds) and (args.max_steps is None or steps < args.max_steps):
-        sim.single_step_without_adaptivity(p)
+        if adaptive:
+            sim.single_step(params)
+        else:
+            sim.single_step_without_adaptivity(p)
         steps += 1
         if vtk is not None and steps % max(args.vtk_every, 1) == 0:
             vtk.add_snapshot(sim.time, sim, vtk_planes)       # main_loop.rs:302-309

@@ -477,7 +477,7 @@ extern "C" void sph_destroy(sph_ctx* c)
                      &c->cs_scratch, &c->hdr_ahead_partials, &c->h2n[0], &c->h2n[1], &c->lam_prev, &c->nl, &c->nlx, &c->tile_raw, &c->tile_h, &c->tile_h_ext, &c->lvl_changed_d, &c->lvl_tmp, &c->lvl_nrm, &c->lvl_state, &c->lvl_when, &c->lvl_mark, &c->flag_surface,
                      &c->flag_insufficient, &c->con_thr, &c->con_consumed, &c->con_h, &c->flag_reduced, &c->szc[0], &c->szc[1], &c->omega, &c->stash, &c->nl_ext, &c->nlx_ext, &c->nl_ok, &c->mrho, &c->pt0, &c->pt1, &c->rho, &c->lam_sum, &c->lam_grad, &c->constf, &c->aii, &c->src, &c->p0, &c->p1, &c->pacc, &c->dens_err,
                      &c->stat, &c->ncount, &c->planes_d, &c->lam_lut, &c->dlam_lut, &c->hdr_partials, &c->hdr_out, &c->ctrl, &c->status,
-                     &c->n_tiles, &c->red_partials, &c->scratch};
+                     &c->n_tiles, &c->red_partials, &c->scratch, &c->split_patterns};
     for (auto b : all) b->release();
     if (c->hdr_host) (void)hipHostFree(c->hdr_host);
     if (c->ctrl_host) (void)hipHostFree(c->ctrl_host);
@@ -671,15 +671,6 @@ extern "C" int sph_download(sph_ctx* c, int field, void* dst, uint64_t bytes)
 // sparse edits (sph_ffi.h): the script is resolved on the host into "final index f holds object o" + the last value
 // written to each field of each touched object; one kernel then gathers the persistent state into final-index order
 // ------------------------------------------------------------------------------------------------
-struct EditSrc {
-    uint32_t obj;      // object: < n_old = the particle with that OLD host index, else a default particle of an EXTEND
-    uint32_t set_idx;  // index into the override records, or 0xffffffff
-};
-struct EditSet {
-    uint32_t fields;
-    float mass, px, py, vx, vy, h2, h2_next, lvl, lvlold;
-};
-
 __global__ __launch_bounds__(256) void k_edit_inverse(uint32_t n_old, const uint32_t* __restrict__ orig, uint32_t* __restrict__ slot_of)
 {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
@@ -793,18 +784,29 @@ extern "C" int sph_apply_edits(sph_ctx* c, const sph_edit_op* ops, uint64_t n_op
 
     // ---- one gather on the device into final-index order (slot f = host index f, like a fresh upload)
     hipStream_t s = c->stream;
-    HIPCHK(c, hipStreamSynchronize(s));
-    DevBuf d_src, d_sets, d_slot, d_lam;
+    DevBuf d_src, d_sets;
     HIPCHK(c, d_src.ensure(src.size() * sizeof(EditSrc)));
     HIPCHK(c, d_sets.ensure(sets.size() * sizeof(EditSet)));
-    HIPCHK(c, d_slot.ensure(((size_t)n_old + 1) * 4));
-    HIPCHK(c, d_lam.ensure(((size_t)n_new + 1) * 4));
     HIPCHK(c, hipMemcpyAsync(d_src.p, src.data(), src.size() * sizeof(EditSrc), hipMemcpyHostToDevice, s));
     HIPCHK(c, hipMemcpyAsync(d_sets.p, sets.data(), sets.size() * sizeof(EditSet), hipMemcpyHostToDevice, s));
+    const int rc = regather_host_order(c, n_new, d_src.as<EditSrc>(), d_sets.as<EditSet>());
+    d_src.release();
+    d_sets.release();
+    return rc;
+}
+
+int regather_host_order(sph_ctx* c, uint32_t n_new, const EditSrc* d_src, const EditSet* d_sets)
+{
+    hipStream_t s = c->stream;
+    const uint32_t n_old = (uint32_t)c->n;
+    if (n_new > c->cap) return c->fail(SPH_ERR_CAPACITY, "%u particles exceed the capacity %llu", n_new, (unsigned long long)c->cap);
+    DevBuf d_slot, d_lam;
+    HIPCHK(c, d_slot.ensure(((size_t)n_old + 1) * 4));
+    HIPCHK(c, d_lam.ensure(((size_t)n_new + 1) * 4));
     const int k = c->cur;
     if (n_old) hipLaunchKernelGGL(k_edit_inverse, dim3((n_old + 255) / 256), dim3(256), 0, s, n_old, c->orig[k].as<uint32_t>(), d_slot.as<uint32_t>());
     if (n_new)
-        hipLaunchKernelGGL(k_edit_apply, dim3((n_new + 255) / 256), dim3(256), 0, s, n_new, n_old, d_src.as<EditSrc>(), d_sets.as<EditSet>(),
+        hipLaunchKernelGGL(k_edit_apply, dim3((n_new + 255) / 256), dim3(256), 0, s, n_new, n_old, d_src, d_sets,
                            d_slot.as<uint32_t>(), c->pm[c->pcur].as<float4>(), c->vel[k].as<float2>(), c->lvl[k].as<float>(),
                            c->lvlold[k].as<float>(), c->h2n[k].as<float>(), c->lam_sum.as<float>(), c->szc[k].as<uint8_t>(), c->szc[k ^ 1].as<uint8_t>(),
                            c->pm[c->pcur ^ 1].as<float4>(),
@@ -812,8 +814,6 @@ extern "C" int sph_apply_edits(sph_ctx* c, const sph_edit_op* ops, uint64_t n_op
                            c->h2n[k ^ 1].as<float>(), d_lam.as<float>());
     if (n_new) HIPCHK(c, hipMemcpyAsync(c->lam_sum.p, d_lam.p, (size_t)n_new * 4, hipMemcpyDeviceToDevice, s));
     HIPCHK(c, hipStreamSynchronize(s));
-    d_src.release();
-    d_sets.release();
     d_slot.release();
     d_lam.release();
     c->cur = k ^ 1;

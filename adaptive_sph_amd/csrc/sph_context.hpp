@@ -114,6 +114,8 @@ struct sph_ctx {
     float h_max_step = 0.f;   // largest smoothing length of the current step (all ranks)
     DevBuf szc[2];     // ParticleVec::particle_size_class (u8), persistent: IISPH2's omega reads the class of the previous step
     DevBuf omega;      // IISPH2 (simulation.rs:2262-2311)
+    DevBuf split_patterns;            // SplitPatterns::pos_s of every pattern, concatenated float2 (sph_set_split_patterns)
+    uint32_t n_split_patterns = 0;
     bool have_level = false;            // the level-estimation outputs above are those of the last step
     DevBuf lvl_changed_d;               // per-sweep "assigned something" words of a batch (device), published once per batch
     uint32_t* lvl_changed = nullptr;    // mapped pinned host copy

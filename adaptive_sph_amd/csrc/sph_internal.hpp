@@ -211,3 +211,19 @@ void launch_iisph2_scale(hipStream_t s, Profiler* prof, const SweepArgs& a);
 void launch_check_aii(hipStream_t s, Profiler* prof, const SweepArgs& a);   // after launch_aii_const when check_aii is set
 void launch_vel_add_pacc(hipStream_t s, Profiler* prof, const SweepArgs& a);               // v += dt a^p
 void launch_integrate(hipStream_t s, Profiler* prof, const SweepArgs& a, float4* pm_out, int mode);  // 0: v+=dt a; x+=dt v   1: hybrid
+
+// ---- regather of the persistent state into a new HOST-index order (sparse edits, merging, splitting; sph_api.hip) ----
+struct EditSrc {
+    uint32_t obj;      // object: < n_old = the particle with that OLD host index, else a default particle of an EXTEND
+    uint32_t set_idx;  // index into the override records, or 0xffffffff
+};
+struct EditSet {
+    uint32_t fields;   // SPH_EDIT_F_* of the values to take from this record
+    float mass, px, py, vx, vy, h2, h2_next, lvl, lvlold;
+};
+struct sph_ctx;
+// final index f holds object d_src[f].obj (+ the overrides of d_sets[d_src[f].set_idx]); both arrays live on the DEVICE.
+// Slot f = host index f afterwards, like a fresh upload; per-step outputs, lists and the header are invalidated.
+int regather_host_order(sph_ctx* c, uint32_t n_new, const EditSrc* d_src, const EditSet* d_sets);
+// out[i] = sum of in[0 .. i) ; *total (device word) = sum of all.  scratch: >= (n / 2048 + 2) words
+void device_exclusive_scan_u32(hipStream_t s, const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* scratch, uint32_t* total);

@@ -49,7 +49,7 @@ STATUS_NAMES = {
     13: "SPH_ERR_AII_NEGATIVE", 14: "SPH_ERR_AP_NOT_FINITE", 15: "SPH_ERR_PRESSURE_NOT_FINITE",
     16: "SPH_ERR_TOO_MANY_NEIGHBORS", 17: "SPH_ERR_VELOCITY_NOT_FINITE", 18: "SPH_ERR_POSITION_NOT_FINITE",
     19: "SPH_ERR_VISCOSITY_NOT_FINITE", 20: "SPH_ERR_XSPH_TODO", 21: "SPH_ERR_CHECK_NEIGHBORHOOD",
-    22: "SPH_ERR_CHECK_AII", 23: "SPH_ERR_LEVEL_WEIGHT", 24: "SPH_ERR_VOLUME_ESTIMATE", 25: "SPH_ERR_CONSTRAIN_NOT_SMALLER", 26: "SPH_ERR_CONSTRAIN_NEGATIVE", 30: "SPH_ERR_UNSUPPORTED", 31: "SPH_ERR_POISONED",
+    22: "SPH_ERR_CHECK_AII", 23: "SPH_ERR_LEVEL_WEIGHT", 24: "SPH_ERR_VOLUME_ESTIMATE", 25: "SPH_ERR_CONSTRAIN_NOT_SMALLER", 26: "SPH_ERR_CONSTRAIN_NEGATIVE", 27: "SPH_ERR_NO_SPLIT_PATTERN", 30: "SPH_ERR_UNSUPPORTED", 31: "SPH_ERR_POISONED",
 }
 
 
@@ -114,6 +114,18 @@ class SphKernelTime(C.Structure):
                 ("working_launches", C.c_uint64), ("working_ms", C.c_double)]
 
 
+class SphAdaptParams(C.Structure):
+    _fields_ = [("dt", C.c_float), ("max_mass_transfer_sharing", C.c_float), ("minimum_share_partners", C.c_uint32),
+                ("minimum_merge_partners", C.c_uint32), ("fail_on_missing_split_pattern", C.c_int32),
+                ("max_share_distance", C.c_float), ("max_merge_distance", C.c_float),
+                ("allow_share_with_optimal_particle", C.c_int32), ("allow_share_with_too_small_particle", C.c_int32),
+                ("allow_merge_with_optimal_particle", C.c_int32), ("allow_merge_on_size_difference", C.c_int32)]
+
+
+MERGE_PARTNER_AVAILABLE = 0xFFFFFFFF   # adaptivity/mod.rs:29
+MERGE_PARTNER_DELETE = 0xFFFFFFFE      # adaptivity/mod.rs:30
+
+
 class SphDistStats(C.Structure):
     _fields_ = [("steps", C.c_uint64), ("exchanges", C.c_uint64), ("bytes_sent", C.c_uint64), ("bytes_received", C.c_uint64),
                 ("allreduces", C.c_uint64), ("host_waits", C.c_uint64), ("n_owned", C.c_uint64), ("n_halo", C.c_uint32 * 2),
@@ -131,7 +143,7 @@ class SphError(RuntimeError):
 # every symbol include/sph_ffi.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
     "create", "destroy", "upload", "upload_field", "download", "download_neighbors", "num_particles", "time",
-    "set_time", "step", "classify", "last_error", "grid", "set_boundary_polygon", "apply_edits", "profile_enable", "profile_reset", "profile_get", "profile_event_overhead", "profile_copy_bandwidth", "set_sweep_variant",
+    "set_time", "step", "classify", "share_particles", "merge_particles", "set_split_patterns", "split_particles", "host_find_partners", "last_error", "grid", "set_boundary_polygon", "apply_edits", "profile_enable", "profile_reset", "profile_get", "profile_event_overhead", "profile_copy_bandwidth", "set_sweep_variant",
     "dist_configure", "dist_set_rebalance", "dist_get_cuts", "dist_get_stats", "comm_unique_id", "comm_init", "group_step",
 ]
 
@@ -174,6 +186,13 @@ class SphLibrary:
         self.set_time = sig("set_time", i32, [vp, C.c_float, u64])
         self.step = sig("step", i32, [vp, C.POINTER(SphParams), C.POINTER(SphStepStats)])
         self.classify = sig("classify", i32, [vp, C.POINTER(SphParams)])
+        ap = C.POINTER(SphAdaptParams)
+        self.share_particles = sig("share_particles", i32, [vp, C.POINTER(SphParams), ap, vp, vp])
+        self.merge_particles = sig("merge_particles", i32, [vp, C.POINTER(SphParams), ap, vp, vp])
+        self.set_split_patterns = sig("set_split_patterns", i32, [vp, C.c_uint32, vp])
+        self.split_particles = sig("split_particles", i32, [vp, C.POINTER(SphParams), ap])
+        self.host_find_partners = sig("host_find_partners", i32, [i32, u64, vp, vp, vp, vp, vp, vp, vp, C.POINTER(SphParams), ap, vp, vp, C.POINTER(u64)],
+                                      required=False)
         self.last_error = sig("last_error", C.c_char_p, [vp])
         self.grid = sig("grid", i32, [vp, C.POINTER(SphGridInfo)])
         # product-only entry points (the oracle has no device, profiler or communicator)
@@ -328,6 +347,34 @@ class Context:
     def classify(self, params: SphParams) -> None:
         """classify_particles (adaptivity/mod.rs:50-59): the host's call, never part of the step."""
         self._check(self.lib.classify(self.handle, C.byref(params)))
+
+    # ---- adaptivity data path: decisions on the host, data on the device (sph_ffi.h) ----
+    def _partner_arrays(self, merge_partner, merge_counter):
+        mp = np.ascontiguousarray(merge_partner, dtype=np.uint32)
+        mc = np.ascontiguousarray(merge_counter, dtype=np.uint16)
+        if mp.shape != (self.n,) or mc.shape != (self.n,):
+            raise ValueError("merge_partner / merge_counter must have one entry per particle")
+        return mp, mc
+
+    def share_particles(self, params: SphParams, ap: "SphAdaptParams", merge_partner, merge_counter) -> None:
+        mp, mc = self._partner_arrays(merge_partner, merge_counter)
+        self._check(self.lib.share_particles(self.handle, C.byref(params), C.byref(ap), mp.ctypes.data, mc.ctypes.data))
+
+    def merge_particles(self, params: SphParams, ap: "SphAdaptParams", merge_partner, merge_counter) -> None:
+        mp, mc = self._partner_arrays(merge_partner, merge_counter)
+        self._check(self.lib.merge_particles(self.handle, C.byref(params), C.byref(ap), mp.ctypes.data, mc.ctypes.data))
+
+    def set_split_patterns(self, patterns) -> None:
+        """patterns[k] = (k + 2, 2) array of child offsets pos_s (SplitPatterns, splitting.rs:84-120)."""
+        for k, q in enumerate(patterns):
+            if np.asarray(q).shape != (k + 2, 2):
+                raise ValueError(f"assertion failed: sp.pos_s.len() == i + 2 (pattern {k})")
+        flat = np.ascontiguousarray(np.concatenate([np.asarray(q, np.float32).reshape(-1, 2) for q in patterns]) if patterns
+                                    else np.zeros((0, 2)), dtype=np.float32)
+        self._check(self.lib.set_split_patterns(self.handle, len(patterns), flat.ctypes.data))
+
+    def split_particles(self, params: SphParams, ap: "SphAdaptParams") -> None:
+        self._check(self.lib.split_particles(self.handle, C.byref(params), C.byref(ap)))
 
     def grid(self) -> SphGridInfo:
         g = SphGridInfo()

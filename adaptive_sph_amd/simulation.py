@@ -57,13 +57,15 @@ class FluidSimulation:
     """Drop-in for ``FluidSimulation<DimensionUtils2d, 2>`` on the step path."""
 
     def __init__(self, position, velocity, mass, planes, counters_enabled: bool = False,
-                 lib: Optional[ffi.SphLibrary] = None, device_id: int = 0, n_capacity: Optional[int] = None):
+                 lib: Optional[ffi.SphLibrary] = None, device_id: int = 0, n_capacity: Optional[int] = None, split_patterns=None):
         self.lib = lib if lib is not None else ffi.load_product()
         mass = np.ascontiguousarray(mass, dtype=np.float32)
         n = mass.shape[0]
         self.ctx = ffi.Context(self.lib, n_capacity if n_capacity is not None else max(n, 1), planes, device_id)
         self.ctx.upload(mass, position, velocity)
         self.particles = _ParticleView(self.ctx)
+        self.split_patterns = split_patterns       # adaptivity.SplitPatterns (FluidSimulation.split_patterns, simulation.rs:476)
+        self._adaptivity = None
         self.counters_enabled = counters_enabled
         if counters_enabled and self.lib.profile_enable is not None:
             # PerformanceCounters::new(counters_enabled) (simulation.rs:137-189): per-phase times need the library's event
@@ -105,13 +107,26 @@ class FluidSimulation:
         return float(st.dt)
 
     def single_step(self, simulation_params: SimulationParams) -> None:
-        """simulation.rs:1973-1978.  The adaptive half (single_step_adaptivity, :2732-2796) is host
-        bookkeeping that stays on the Rust side (out of scope); with
-        merging/sharing/splitting all off it is a no-op apart from classification."""
-        if simulation_params.merging or simulation_params.sharing or simulation_params.splitting:
-            raise NotImplementedError("single_step_adaptivity (split/merge/share) stays on the reference host; "
-                                      "call single_step_without_adaptivity and run adaptivity there")
-        self.single_step_without_adaptivity(simulation_params)
+        """simulation.rs:1973-1978: the step, then single_step_adaptivity with its dt."""
+        dt = self.single_step_without_adaptivity(simulation_params)
+        self.single_step_adaptivity(simulation_params, dt)
+
+    def single_step_adaptivity(self, simulation_params: SimulationParams, dt: float) -> dict:
+        """simulation.rs:2732-2796.  The partner decisions are taken here on the host (the reference's sequential loops,
+        adaptivity.py); the particle data stays on the device (sph_share_particles / sph_merge_particles / sph_split_particles)."""
+        P = simulation_params
+        if not (P.sharing or P.merging or P.splitting):
+            return {"n_before": self.ctx.n, "n_after": self.ctx.n, "shares": 0, "merges": 0, "splits": 0}
+        if self._adaptivity is None:
+            from .adaptivity import AdaptivityDriver
+            if P.splitting and self.split_patterns is None:
+                raise RuntimeError("splitting needs split patterns: FluidSimulation(..., split_patterns=SplitPatterns.load_from_file('split-patterns.yaml'))")
+            self._adaptivity = AdaptivityDriver(self.ctx, self.split_patterns)
+        t0 = _time.perf_counter()
+        info = self._adaptivity.single_step_adaptivity(P, dt, self.step_number)
+        if self.counters_enabled:
+            self._p("adaptivity", (_time.perf_counter() - t0) * 1e3)        # pcounters "adaptivity" (:2734, 2793)
+        return info
 
     def neighbors(self):
         """NeighborhoodCache as CSR (offsets, indices), host particle order."""
@@ -153,11 +168,14 @@ def init_simulation_params(simulation_params: SimulationParams, scene_config: Sc
 
 
 def init_fluid_sim(simulation_params: SimulationParams, scene_config: SceneConfig, counters_enabled: bool = False,
-                   lib: Optional[ffi.SphLibrary] = None, device_id: int = 0) -> FluidSimulation:
-    """simulation.rs:3074-3231."""
+                   lib: Optional[ffi.SphLibrary] = None, device_id: int = 0, split_patterns=None,
+                   n_capacity: Optional[int] = None) -> FluidSimulation:
+    """simulation.rs:3074-3231.  `n_capacity`: room for the particles splitting will add (the reference's Vecs grow on demand;
+    the device arrays are sized once)."""
     pos, mass, vel = init_particles(scene_config)
     planes = boundary_planes(scene_config.boundary, simulation_params.init_boundary_handler)
-    return FluidSimulation(pos, vel, mass, planes, counters_enabled, lib=lib, device_id=device_id)
+    return FluidSimulation(pos, vel, mass, planes, counters_enabled, lib=lib, device_id=device_id, split_patterns=split_patterns,
+                           n_capacity=n_capacity)
 
 
 def run_until(fluid_simulation: FluidSimulation, simulation_params: SimulationParams, max_seconds: float,

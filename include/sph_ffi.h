@@ -187,6 +187,7 @@ enum {
     SPH_ERR_VOLUME_ESTIMATE = 24,       /* sim.rs:1903-1909, 1961  volume_estimate >= 0 */
     SPH_ERR_CONSTRAIN_NOT_SMALLER = 25, /* sim.rs:2163  *p_h_next < smoothing_length_single(h2, i) */
     SPH_ERR_CONSTRAIN_NEGATIVE = 26,    /* sim.rs:2165  *p_h_next >= 0 */
+    SPH_ERR_NO_SPLIT_PATTERN = 27,      /* splitting.rs:35, 41, 108: no split pattern for a 1-to-n split / num_children > 1 */
     SPH_ERR_UNSUPPORTED = 30,           /* a SimulationParams combination this build does not cover */
     SPH_ERR_POISONED = 31               /* an earlier step failed inside the step: state undefined until sph_upload */
 };
@@ -250,6 +251,58 @@ typedef struct sph_edit_op {
     float    level_old;
 } sph_edit_op;
 int  sph_apply_edits(sph_ctx* ctx, const sph_edit_op* ops, uint64_t n_ops);
+
+/* ---- adaptivity data path (single_step_adaptivity, simulation.rs:2732-2796) ------------------------------------------------
+ * The DECISIONS stay on the host, where the reference takes them sequentially (find_share_partner_sequential,
+ * particle_sharing.rs:14-117; find_merge_partner_sequential, particle_merging.rs:16-125): the host reads the fields and the
+ * neighbour lists it needs (sph_download, sph_download_neighbors), fills merge_partner / merge_counter exactly as the reference
+ * does and hands the two arrays over.  The DATA never leaves the device: the gather-form mass / momentum transfers, the
+ * swap-to-end deletion order and the appended split children are computed there, with the Vec semantics of the reference
+ * (host indices after the call are the reference's indices).  Afterwards per-step outputs and neighbour lists belong to the old
+ * vector, as after sph_apply_edits.  Not available on slab contexts (SPH_ERR_UNSUPPORTED). */
+typedef struct sph_adapt_params {
+    float    dt;                          /* the step's dt (single_step, simulation.rs:1973-1978) */
+    float    max_mass_transfer_sharing;   /* dropped_mass_sharing, particle_sharing.rs:242-253 */
+    uint32_t minimum_share_partners;      /* particle_sharing.rs:176, 220 */
+    uint32_t minimum_merge_partners;      /* particle_merging.rs:287, 345 */
+    int32_t  fail_on_missing_split_pattern;   /* splitting.rs:33-39 */
+    /* read by the partner searches only (sph_host_find_partners) */
+    float    max_share_distance, max_merge_distance;                  /* particle_sharing.rs:63-67, particle_merging.rs:75-79 */
+    int32_t  allow_share_with_optimal_particle, allow_share_with_too_small_particle;   /* particle_sharing.rs:52-58 */
+    int32_t  allow_merge_with_optimal_particle, allow_merge_on_size_difference;       /* particle_merging.rs:59-67 */
+} sph_adapt_params;
+#define SPH_MERGE_PARTNER_AVAILABLE 0xFFFFFFFFu   /* adaptivity/mod.rs:29 */
+#define SPH_MERGE_PARTNER_DELETE    0xFFFFFFFEu   /* adaptivity/mod.rs:30 */
+/* share_particles (particle_sharing.rs:152-240): a receiver i (merge_partner[i] = donor index j) takes
+ * dropped_mass_sharing(j) / merge_counter[j] of the donor's mass and momentum, position mass-weighted; a donor
+ * (merge_partner = DELETE) then loses what it dropped; h2_next from the new masses.  n is unchanged. */
+int  sph_share_particles(sph_ctx* ctx, const sph_params* params, const sph_adapt_params* ap, const uint32_t* merge_partner,
+                         const uint16_t* merge_counter);
+/* merge_particles (particle_merging.rs:270-370): the same transfer with the donor's WHOLE mass, then the donors whose mass
+ * fell below 1e-6 are deleted by the reference's swap-with-the-last loop (the k-th hole from the front receives the k-th
+ * surviving particle from the back) and the vector is truncated.  sph_num_particles() is the new length. */
+int  sph_merge_particles(sph_ctx* ctx, const sph_params* params, const sph_adapt_params* ap, const uint32_t* merge_partner,
+                         const uint16_t* merge_counter);
+/* SplitPatterns (splitting.rs:84-120; split-patterns.yaml): pattern k (k = 0 .. n_patterns-1) holds the k + 2 child offsets
+ * pos_s of a 1-to-(k+2) split in units of the parent's radius, concatenated as (x, y) pairs. */
+int  sph_set_split_patterns(sph_ctx* ctx, uint32_t n_patterns, const float* pos_s_xy);
+/* split_particles (splitting.rs:19-82): every TooLarge particle (by the classes sph_classify left) becomes
+ * round(mass / target_mass) children (at most the largest pattern, or SPH_ERR_NO_SPLIT_PATTERN with
+ * fail_on_missing_split_pattern): child 0 replaces the parent, the others are appended in the order of the parents' indices.
+ * Reproduces the reference's quirk that children >= 1 write h2 and level_old into the PARENT's slot (splitting.rs:73, 76):
+ * an appended child keeps h2 = 0 and level_old = 0 (harmless under FromMass, where h2 is recomputed every step). */
+int  sph_split_particles(sph_ctx* ctx, const sph_params* params, const sph_adapt_params* ap);
+
+/* find_share_partner_sequential (particle_sharing.rs:14-117, kind = 0) / find_merge_partner_sequential (particle_merging.rs:16-125,
+ * kind = 1) as HOST code: the reference's sequential greedy loop over the particles, each over its neighbour list in list order,
+ * on host arrays (what sph_download / sph_download_neighbors returned) -- no device, no context.  For hosts that do not bring
+ * their own implementation (the Rust side has one; the Python mirror uses this for million-particle scenes).  Writes
+ * merge_partner[n] / merge_counter[n] and runs the reference's validate_*_partners assertions (SPH_ERR_INVALID_ARGUMENT if one
+ * fails). */
+int  sph_host_find_partners(int kind, uint64_t n, const uint8_t* particle_size_class, const float* mass, const float* level_estimation,
+                            const float* position_xy, const float* h2, const uint32_t* offsets, const uint32_t* indices,
+                            const sph_params* params, const sph_adapt_params* ap, uint32_t* merge_partner, uint16_t* merge_counter,
+                            uint64_t* n_transfers);
 
 /* Read one field back in HOST particle order. */
 int  sph_download(sph_ctx* ctx, int field, void* dst, uint64_t dst_bytes);

@@ -1,0 +1,201 @@
+"""Adaptivity data path on the device (sph_share_particles / sph_merge_particles / sph_split_particles, sph_ffi.h) against the
+CPU oracle's statement-by-statement restatement of share_particles / merge_particles / split_particles (oracle/adapt.c), with
+the partner decisions taken ONCE (adaptivity.py, from the oracle's state) and applied to both sides; then whole adaptive runs
+(single_step = step + single_step_adaptivity) of BASELINE configs[0] and of configs[4]'s scene."""
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from adaptive_sph_amd import adaptivity as A, ffi, scene as sc
+from adaptive_sph_amd.simulation import init_fluid_sim
+from adaptive_sph_amd.workloads import WORKLOADS, default_params
+
+pytestmark = pytest.mark.gpu
+REPO = Path(__file__).resolve().parent.parent
+PATTERNS = REPO / "tests" / "golden" / "split-patterns.yaml"
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    s = np.abs(b).max()
+    return np.abs(a - b).max() / (s if s > 0 else 1.0)
+
+
+def pair(product_lib, oracle_lib, cap=70000, steps=2, **overrides):
+    scn = sc.SceneConfig.from_yaml(str(REPO / "tests" / "golden" / "default-scene.yaml"))
+    pos, mass, vel = sc.init_particles(scn)
+    planes = sc.boundary_planes(scn.boundary)
+    g, o = ffi.Context(product_lib, cap, planes), ffi.Context(oracle_lib, cap, planes)
+    g.upload(mass, pos, vel)
+    o.upload(mass, pos, vel)
+    P = default_params(**overrides)
+    p = P.to_ffi()
+    for _ in range(steps):
+        sg, so = g.step(p), o.step(p)
+    return g, o, P, p, float(so.dt)
+
+
+def same_state(g, o, tol=1e-5):
+    assert g.n == o.n
+    for f in ("mass", "position", "velocity", "h2_next", "level_old"):
+        assert rel_err(g.download(f), o.download(f)) < tol, f
+    a, b = g.download("level_estimation"), o.download("level_estimation")
+    assert np.array_equal(np.isnan(a), np.isnan(b))
+    assert np.nanmax(np.abs(a - b)) <= 1e-4 * max(np.nanmax(np.abs(b)), 1e-30)
+
+
+def decisions(o, kind, P, p, dt):
+    o.classify(p)
+    cls = o.download("particle_size_class")
+    off, idx = o.download_neighbors()
+    mp, mc = A._find_partners(kind, cls, o.download("mass"), o.download("level_estimation"), o.download("position"), o.download("h2"), off, idx, P, dt)
+    A.validate_partners(kind, cls, mp, mc, off, idx)
+    return cls, off, idx, mp, mc
+
+
+@pytest.mark.parametrize("kind", ["share", "merge"])
+def test_share_and_merge_match_the_oracle(product_lib, oracle_lib, kind):
+    # radii that put the two particle sizes of the default scene on both sides of the class thresholds
+    g, o, P, p, dt = pair(product_lib, oracle_lib, particle_radius_fine=0.012, particle_radius_base=0.05, maximum_surface_distance=0.3)
+    cls, off, idx, mp, mc = decisions(o, kind, P, p, dt)
+    assert mc.sum() > 20, (np.bincount(cls, minlength=5), mc.sum())
+    # the compiled partner search of the library is the same loop
+    mp2, mc2 = A.find_partners_native(product_lib, kind, cls, o.download("mass"), o.download("level_estimation"), o.download("position"),
+                                      o.download("h2"), off, idx, P, dt)
+    assert np.array_equal(mp, mp2) and np.array_equal(mc, mc2)
+    ap = A.adapt_params(P, dt)
+    n0, m0 = o.n, float(o.download("mass").sum())
+    for c in (g, o):
+        (c.share_particles if kind == "share" else c.merge_particles)(p, ap, mp, mc)
+    assert (o.n < n0) == (kind == "merge")
+    same_state(g, o)
+    assert abs(float(g.download("mass").sum()) - m0) < 1e-5 * m0
+    with pytest.raises(ffi.SphError):
+        g.download_neighbors()                          # the lists belong to the state before the transfer
+    for _ in range(2):                                  # both sides keep stepping on the edited vector
+        sg, so = g.step(p), o.step(p)
+        assert abs(sg.dt - so.dt) <= 1e-5 * so.dt
+    assert (g.download("neighbor_count") != o.download("neighbor_count")).mean() < 0.01
+    for f in ("position", "velocity", "density"):
+        assert rel_err(g.download(f), o.download(f)) < 1e-3, f
+
+
+def test_merge_deletion_order_with_random_partners(product_lib, oracle_lib):
+    """The swap-with-the-last loop of merge_particles in its closed form (prefix sums) against the sequential loop: random
+    donors anywhere in the vector, also in its tail, minimum_merge_partners leaving some donors alone."""
+    for seed in range(4):
+        rng = np.random.default_rng(seed)
+        g, o, P, p, dt = pair(product_lib, oracle_lib)
+        n = o.n
+        partner = np.full(n, ffi.MERGE_PARTNER_AVAILABLE, np.uint32)
+        counter = np.zeros(n, np.uint16)
+        free = list(rng.permutation(n))
+        tail_first = sorted(free, reverse=True)[:40] if seed % 2 else []
+        for d in tail_first + [free.pop() for _ in range(150)]:
+            if partner[d] != ffi.MERGE_PARTNER_AVAILABLE:
+                continue
+            k = int(rng.integers(1, 4))
+            recv = []
+            while len(recv) < k and free:
+                r = free.pop()
+                if partner[r] == ffi.MERGE_PARTNER_AVAILABLE and r != d:
+                    recv.append(r)
+            partner[d] = ffi.MERGE_PARTNER_DELETE
+            for r in recv:
+                partner[r] = d
+            counter[d] = len(recv)
+        ap = A.adapt_params(P, dt)
+        ap.minimum_merge_partners = 2 if seed >= 2 else 0
+        ident = np.arange(n, dtype=np.float32)           # level_old carries each particle's old index through the reordering
+        for c in (g, o):
+            c.upload_field("level_old", ident)
+            c.merge_particles(p, ap, partner, counter)
+        assert g.n == o.n < n
+        assert np.array_equal(g.download("level_old"), o.download("level_old"))     # the same particle in every slot
+        same_state(g, o)
+
+
+def test_split_matches_the_oracle(product_lib, oracle_lib):
+    sp = A.SplitPatterns.load_from_file(PATTERNS)
+    g, o, P, p, dt = pair(product_lib, oracle_lib)
+    for c in (g, o):
+        c.set_split_patterns(sp.patterns)
+    # identical inputs for the rounding in num_children = round(mass / target_mass): the oracle's level field and classes
+    o.classify(p)
+    g.upload_field("level_estimation", o.download("level_estimation"))
+    g.upload_field("particle_size_class", o.download("particle_size_class"))
+    n0 = o.n
+    ap = A.adapt_params(P, dt)
+    for c in (g, o):
+        c.split_particles(p, ap)
+    assert g.n == o.n > 2 * n0
+    for f in ("mass", "h2", "h2_next", "level_old", "particle_size_class"):
+        assert np.array_equal(g.download(f), o.download(f)), f          # IEEE operations on identical inputs
+    assert rel_err(g.download("position"), o.download("position")) < 1e-6
+    assert rel_err(g.download("velocity"), o.download("velocity")) < 1e-5
+    for _ in range(2):
+        sg, so = g.step(p), o.step(p)
+        assert abs(sg.dt - so.dt) <= 1e-4 * so.dt
+    assert rel_err(g.download("density"), o.download("density")) < 1e-3
+    # no patterns set / table too small with fail_on_missing_split_pattern
+    g2, o2, P2, p2, dt2 = pair(product_lib, oracle_lib, cap=5000)
+    g2.classify(p2)
+    with pytest.raises(ffi.SphError) as e:
+        g2.split_particles(p2, A.adapt_params(P2, dt2))
+    assert e.value.status == 27
+    g2.set_split_patterns(sp.patterns[:2])
+    with pytest.raises(ffi.SphError) as e:
+        g2.split_particles(p2, A.adapt_params(P2.replace(fail_on_missing_split_pattern=True), dt2))
+    assert e.value.status == 27
+
+
+def test_adaptive_run_of_the_default_config(product_lib, oracle_lib):
+    """BASELINE configs[0] the way the reference runs it (default-config.yaml: merging, sharing, splitting on): 12 calls of
+    single_step on the device and on the oracle.  The two runs take their own decisions from their own (1e-7 different) states,
+    so they are compared through what the reference itself asserts -- mass conservation -- and through the particle counts."""
+    P = default_params()
+    scn = sc.SceneConfig.from_yaml(str(REPO / "tests" / "golden" / "default-scene.yaml"))
+    sp = A.SplitPatterns.load_from_file(PATTERNS)
+    sims = [init_fluid_sim(P, scn, lib=lib, split_patterns=sp, n_capacity=120000) for lib in (product_lib, oracle_lib)]
+    m0 = float(sims[0].particles.mass.sum())
+    counts = [[], []]
+    for s in range(12):
+        for k, sim in enumerate(sims):
+            sim.single_step(P)
+            counts[k].append(sim.num_fluid_particles())
+    assert counts[0][0] > 1035                              # step 1 splits
+    assert max(abs(a - b) for a, b in zip(*counts)) <= 0.02 * max(counts[1]), counts
+    for sim in sims:
+        assert abs(float(sim.particles.mass.sum()) - m0) < 0.005 * 12
+        x = sim.particles.position
+        assert np.isfinite(x).all() and np.abs(x).max() < 1.0
+
+
+def test_config4_ratio_stress_4m_adaptive_steps(product_lib):
+    """BASELINE configs[4] WITH its adaptivity at full size: the 4 004 343-particle scene (50:1 radii, IISPH, Sdf2D box, EmptyAngle
+    level estimation), sizing radii scaled with the scene (fine = the fine particles' radius, base = the coarse ones'), four calls
+    of single_step: sharing every step, splitting on odd and merging on even step numbers -- decisions by the library's compiled
+    sequential partner search, data on the device.  Checked through the reference's own invariants."""
+    scene_f, params_f, _ = WORKLOADS["ratio_stress_4m"]
+    scn = scene_f()
+    r_fine = float(np.sqrt(np.float32(0.0004385) ** 2 * 0.93 / np.pi))
+    P = params_f(level_estimation_method="EmptyAngle", merging=True, sharing=True, splitting=True, particle_radius_fine=r_fine,
+                 particle_radius_base=50 * r_fine, maximum_surface_distance=0.3)
+    sp = A.SplitPatterns.load_from_file(PATTERNS)
+    sim = init_fluid_sim(P, scn, lib=product_lib, split_patterns=sp, n_capacity=6000000)
+    n0 = sim.num_fluid_particles()
+    assert n0 == 4004343
+    m0 = float(sim.particles.mass.sum(dtype=np.float64))
+    events = {"shares": 0, "merges": 0, "splits": 0}
+    for s in range(4):
+        dt = sim.single_step_without_adaptivity(P)
+        info = sim.single_step_adaptivity(P, dt)
+        for k in events:
+            events[k] += info[k]
+    assert events["merges"] > 1000 and events["splits"] > 0, events     # the bulk of the fine block merges, coarse surface particles split
+    assert sim.num_fluid_particles() != n0
+    assert abs(float(sim.particles.mass.sum(dtype=np.float64)) - m0) < 1e-4 * m0
+    x = sim.particles.position
+    assert np.isfinite(x).all() and np.abs(x).max() < 1.0
+    sim.single_step_without_adaptivity(P)                   # and the edited vector steps

@@ -95,9 +95,17 @@ def test_run_subcommand_headless(tmp_path):
     text = stat.read_text()
     assert "simulation-time:" in text and "dt: min:" in text and "particle-count:" in text
     assert "max_dt=0.001" in out.getvalue().replace(" ", "") or "max_dt: 0.001" in out.getvalue() or "0.001" in out.getvalue()
-    # adaptivity is not on this path: refused unless asked for explicitly; an unknown override key is the reference's panic
-    with pytest.raises(SystemExit):
-        run(build_parser().parse_args(["run", cfg, scn, "-s", "0.001"]), lib=load_oracle(), out=io.StringIO())
+    # with adaptivity (the config enables merging / sharing / splitting): single_step = the step + single_step_adaptivity; the
+    # split patterns are read like the reference reads ./split-patterns.yaml -- a missing file is its unwrap() panic
+    with pytest.raises(FileNotFoundError):
+        run(build_parser().parse_args(["run", cfg, scn, "-s", "0.001", "--split-patterns", str(tmp_path / "nope.yaml")]), lib=load_oracle(), out=io.StringIO())
+    out2 = io.StringIO()
+    steps2 = run(build_parser().parse_args(["run", cfg, scn, "--max-steps", "3", "--split-patterns", str(REPO / "tests" / "golden" / "split-patterns.yaml"),
+                                            "--capacity-factor", "40"]), lib=load_oracle(), out=out2)
+    assert steps2 == 3
+    n_final = int(out2.getvalue().split(" particles")[0].split()[-1])
+    assert n_final > 1035                                # splitting at step 1 (odd step numbers, simulation.rs:2759-2785)
+    # an unknown override key is the reference's panic
     bad = tmp_path / "bad.yaml"
     bad.write_text("no_such_key: 1\n")
     with pytest.raises(KeyError):
