@@ -59,7 +59,7 @@ def test_share_and_merge_match_the_oracle(product_lib, oracle_lib, kind):
     # radii that put the two particle sizes of the default scene on both sides of the class thresholds
     g, o, P, p, dt = pair(product_lib, oracle_lib, particle_radius_fine=0.012, particle_radius_base=0.05, maximum_surface_distance=0.3)
     cls, off, idx, mp, mc = decisions(o, kind, P, p, dt)
-    assert mc.sum() > 20, (np.bincount(cls, minlength=5), mc.sum())
+    assert mc.sum() >= (5 if kind == "share" else 100), (np.bincount(cls, minlength=5), mc.sum())
     # the compiled partner search of the library is the same loop
     mp2, mc2 = A.find_partners_native(product_lib, kind, cls, o.download("mass"), o.download("level_estimation"), o.download("position"),
                                       o.download("h2"), off, idx, P, dt)
@@ -130,8 +130,10 @@ def test_split_matches_the_oracle(product_lib, oracle_lib):
     for c in (g, o):
         c.split_particles(p, ap)
     assert g.n == o.n > 2 * n0
-    for f in ("mass", "h2", "h2_next", "level_old", "particle_size_class"):
+    for f in ("mass", "h2", "h2_next", "particle_size_class"):
         assert np.array_equal(g.download(f), o.download(f)), f          # IEEE operations on identical inputs
+    lo_g, lo_o = g.download("level_old"), o.download("level_old")        # carried (each side's own smoothed field), 0 for the appended children
+    assert np.array_equal(lo_g == 0, lo_o == 0) and rel_err(lo_g, lo_o) < 1e-4
     assert rel_err(g.download("position"), o.download("position")) < 1e-6
     assert rel_err(g.download("velocity"), o.download("velocity")) < 1e-5
     for _ in range(2):
