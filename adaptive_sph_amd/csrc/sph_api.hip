@@ -103,11 +103,13 @@ Profiler::~Profiler()
 // neighborhood_search.rs:261-275), h_max/h_min, CFL term min_i (2h_i)^2 / (|v_i|^2 + 0.01)
 // (simulation.rs:2182-2189)
 __global__ __launch_bounds__(256) void k_header(float4* __restrict__ pm, const float2* __restrict__ vel, uint32_t n, float rest_density,
-                                                 int from_mass, float* __restrict__ h2_next, HeaderOut* __restrict__ partials)
+                                                 int from_mass, float* __restrict__ h2_next, HeaderOut* __restrict__ partials,
+                                                 const uint8_t* __restrict__ owned)
 {
     const float INF = __uint_as_float(0x7f800000u);
     float mnx = INF, mny = INF, mxx = -INF, mxy = -INF, hmx = 0.f, hmn = INF, cfl = INF;
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        if (owned && !owned[i]) continue;   // slab decomposition: last step's ghosts are still interleaved
         float4 p = pm[i];
         if (from_mass == 1) {
             p.w = h_from_mass(p.z, rest_density);
@@ -1029,7 +1031,8 @@ extern "C" int sph_download_neighbors(sph_ctx* c, uint32_t* offsets, uint32_t* i
 // ------------------------------------------------------------------------------------------------
 // launch wrappers used by the step driver (sph_step.hip)
 // ------------------------------------------------------------------------------------------------
-void launch_header(sph_ctx* c, uint32_t n, float rest_density, int from_mass /* 0 keep h, 1 from mass, 2 swap with h2_next */, HeaderOut* out_dev)
+void launch_header(sph_ctx* c, uint32_t n, float rest_density, int from_mass /* 0 keep h, 1 from mass, 2 swap with h2_next */, HeaderOut* out_dev,
+                   const uint8_t* owned)
 {
     hipStream_t s = c->stream;
     ProfScope ps(&c->prof, "header", s);
@@ -1037,7 +1040,7 @@ void launch_header(sph_ctx* c, uint32_t n, float rest_density, int from_mass /* 
     if (nb > HDR_BLOCKS) nb = HDR_BLOCKS;
     if (nb < 1) nb = 1;
     hipLaunchKernelGGL(k_header, dim3(nb), dim3(256), 0, s, c->pm[c->pcur].as<float4>(), c->vel[c->cur].as<float2>(), n, rest_density, from_mass,
-                       c->h2n[c->cur].as<float>(), c->hdr_partials.as<HeaderOut>());
+                       c->h2n[c->cur].as<float>(), c->hdr_partials.as<HeaderOut>(), owned);
     c->publish_seq++;
     if (c->publish_seq == 0u) c->publish_seq = 1u;
     const bool mapped = out_dev == c->hdr_host_dev;

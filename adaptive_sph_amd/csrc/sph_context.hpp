@@ -150,7 +150,7 @@ const char* status_message(uint32_t code);
 SweepArgs make_args(sph_ctx* c, const StepP& sp);
 
 // ---- small launch wrappers owned by sph_api.hip -----------------------------------------------
-void launch_header(sph_ctx* c, uint32_t n, float rest_density, int from_mass, HeaderOut* out_dev);
+void launch_header(sph_ctx* c, uint32_t n, float rest_density, int from_mass, HeaderOut* out_dev, const uint8_t* owned = nullptr);
 void launch_publish(sph_ctx* c);
 void launch_check_neighborhood(sph_ctx* c, const SweepArgs& a);
 void dist_release(sph_ctx* c);  // sph_step.hip

@@ -66,7 +66,7 @@ struct SolverCtrl {
     uint32_t done;    // stop decision taken (iisph_pressure_iterations break)
     uint32_t iters;   // num_pressure_iters at the break
     uint32_t cur;     // index of the pressure buffer holding the current iterate
-    uint32_t ticket;  // reduce-kernel arrival counter
+    uint32_t peer_error;   // slab decomposition: a device-side guard fired on some rank (the solve was ended on every rank)
     uint32_t normal, singular, negative;
     float sum_err, max_err;
     uint32_t slot_done[2];   // stop decision as seen by the launches of one iteration (written by sweep A(k) into slot k & 1, sph_sweeps.hip)
@@ -171,7 +171,7 @@ void launch_source_term(hipStream_t s, Profiler* prof, const SweepArgs& a, int k
 // sweep A of iteration iter >= 1 (+ the stop decision of iteration iter - 1, taken by its block 0); iter < 0: a^p from the solve's final pressures
 void launch_pressure_accel(hipStream_t s, Profiler* prof, const SweepArgs& a, int iter, int residual_density, float max_avg_error, uint32_t max_iters, int multi);
 void launch_solver_tail(hipStream_t s, Profiler* prof, const SweepArgs& a, int tail, float4* pm_out);   // integrate map of the solver mode, once the solve is done
-void launch_jacobi_update(hipStream_t s, Profiler* prof, const SweepArgs& a, int iter, int residual_density);
+void launch_jacobi_update(hipStream_t s, Profiler* prof, const SweepArgs& a, int iter, int residual_density, float max_avg_error, uint32_t max_iters, int multi);
 void launch_solver_decide(hipStream_t s, Profiler* prof, const SweepArgs& a, int iter, int residual_density, float max_avg_error,
                           uint32_t max_iters);
 // level estimation (sorted order)

@@ -21,6 +21,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <vector>
 
 #include "sph_context.hpp"
@@ -55,7 +56,7 @@ SweepArgs make_args(sph_ctx* c, const StepP& sp)
     a.ncount = c->ncount.as<uint32_t>();
     a.nl = c->nl.as<uint4>();
     a.nlx = c->nlx.as<uint4>();
-    a.hdr_partials = (!c->dist.on) ? c->hdr_ahead_partials.as<HeaderOut>() : nullptr;
+    a.hdr_partials = c->hdr_ahead_partials.as<HeaderOut>();
     a.h_mode = SPH_H_FROM_MASS;   // set by the step driver
     a.h2_next = c->h2n[k].as<float>();
     a.omega = c->omega.as<float>();
@@ -451,6 +452,28 @@ __global__ void k_fill_u8(uint8_t* p, uint32_t n, uint8_t v)
     if (i < n) p[i] = v;
 }
 
+// counts_round (RCCL): out[0] = to_left, out[1] = to_right, out[2] = out[3] = 0 (received below), out[4] = status,
+// out[5 .. 8] = this rank's four class counts
+__global__ void k_counts_stage(const uint32_t* __restrict__ counts, uint32_t* __restrict__ out, uint32_t status_in, int narrow_is_error)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    out[0] = counts[1];
+    out[1] = counts[2];
+    out[2] = out[3] = 0u;
+    uint32_t st = status_in;
+    if (narrow_is_error && counts[3] != 0u && st < (uint32_t)SPH_ERR_UNSUPPORTED) st = (uint32_t)SPH_ERR_UNSUPPORTED;
+    out[4] = st;
+    for (int k = 0; k < 4; k++) out[5 + k] = counts[k];
+}
+__global__ void k_guard_stage(const DeviceStatus* __restrict__ status, uint32_t* __restrict__ out)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) *out = status->error;
+}
+__global__ void k_guard_merge(const uint32_t* __restrict__ agreed, SolverCtrl* __restrict__ ctrl)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0 && *agreed > ctrl->peer_error) ctrl->peer_error = *agreed;
+}
+
 // ------------------------------------------------------------------------------------------------
 // transports
 // ------------------------------------------------------------------------------------------------
@@ -468,19 +491,32 @@ struct Comm {
     virtual int allreduce_min_f32(Group& G, std::vector<std::vector<float>>& rows) = 0;
     virtual int allreduce_max_i32(Group& G, std::vector<int>& vals) = 0;
     virtual int allreduce_sum_u32(Group& G, std::vector<std::vector<uint32_t>>& rows) = 0;   // element-wise, REBALANCE_BINS words
-    // every member learns the (to-left, to-right) counts its x-neighbours are about to send it
+    // every member learns the (to-left, to-right) counts its x-neighbours are about to send it; `status` (optional): this
+    // process's status of the phase, replaced by the maximum over ALL ranks in the same round trip
     virtual int neighbour_counts(Group& G, const std::vector<uint32_t>& to_left, const std::vector<uint32_t>& to_right,
-                                 std::vector<uint32_t>& from_left, std::vector<uint32_t>& from_right) = 0;
+                                 std::vector<uint32_t>& from_left, std::vector<uint32_t>& from_right, int* status = nullptr) = 0;
     // device buffers; ordered after everything queued on the members' streams
     virtual int exchange(Group& G, std::vector<Xfer>& x) = 0;
-    // element-wise sum of the members' 4 device doubles (solver totals), result in every member's buffer
+    // element-wise sum of the members' 6 device doubles (solver totals + error flag), result in every member's buffer
     virtual int allreduce_solver(Group& G) = 0;
+    virtual bool host_collectives_wait() const = 0;
+    // ONE round trip for a decomposition phase: the class counts the phase's classify kernel left in dist.counts[base ..
+    // base + 3] (1 = to the left neighbour, 2 = to the right, 3 = dropped / too narrow; class 0 is derived by the caller) reach
+    // the host (counts_host[base ..)), the x-neighbours' counts arrive as from_left / from_right, `red` (optional) is
+    // min-reduced element-wise over ALL ranks and `status` (optional) max-reduced -- on the device the status also becomes
+    // SPH_ERR_UNSUPPORTED if this rank's class-3 count of the halo phase (base 4) is non-zero (slab narrower than two ghost layers).
+    virtual int counts_round(Group& G, int base, std::vector<std::vector<float>>* red, int* status, std::vector<uint32_t>& to_left,
+                             std::vector<uint32_t>& to_right, std::vector<uint32_t>& from_left, std::vector<uint32_t>& from_right) = 0;
+    // queued, no wait: the maximum over all ranks of the device-side guard word lands in every rank's ctrl->peer_error, which the
+    // next publish brings to the host (the step's one agreement on the guards, without a round trip of its own)
+    virtual int agree_guards_queued(Group& G) = 0;
 };
 
 struct Group {
     std::vector<sph_ctx*> m;
     Comm* comm = nullptr;  // nullptr: one rank, nothing to exchange
     bool multi() const { return comm != nullptr; }
+    bool comm_waits() const { return comm && comm->host_collectives_wait(); }   // its host-value collectives end with a wait on the members' streams
 };
 
 static int wait_all_hinted(Group& G)   // see wait_hinted
@@ -502,6 +538,7 @@ static int wait_all(Group& G)
 
 // ---- loopback: all ranks are contexts of this process ---------------------------------------------
 struct LocalComm : Comm {
+    bool host_collectives_wait() const override { return false; }   // plain host arithmetic on values the caller already has
     int allreduce_min_f32(Group& G, std::vector<std::vector<float>>& rows) override
     {
         for (size_t k = 0; k < rows[0].size(); k++) {
@@ -528,8 +565,9 @@ struct LocalComm : Comm {
         return SPH_OK;
     }
     int neighbour_counts(Group& G, const std::vector<uint32_t>& tl, const std::vector<uint32_t>& tr, std::vector<uint32_t>& fl,
-                         std::vector<uint32_t>& fr) override
+                         std::vector<uint32_t>& fr, int* status) override
     {
+        (void)status;   // one process: its own status is the maximum
         const size_t n = G.m.size();
         for (size_t i = 0; i < n; i++) {
             fl[i] = i > 0 ? tr[i - 1] : 0;
@@ -562,17 +600,34 @@ struct LocalComm : Comm {
         }
         return wait_all(G);  // senders may reuse their staging buffers afterwards
     }
+    int counts_round(Group& G, int base, std::vector<std::vector<float>>* red, int* status, std::vector<uint32_t>& tl, std::vector<uint32_t>& tr,
+                     std::vector<uint32_t>& fl, std::vector<uint32_t>& fr) override
+    {
+        int rc = wait_all(G);
+        if (rc) return rc;
+        for (size_t i = 0; i < G.m.size(); i++) {
+            sph_ctx* c = G.m[i];
+            HIPCHK(c, hipSetDevice(c->device));
+            HIPCHK(c, hipMemcpy(c->dist.counts_host + base, c->dist.counts.as<uint32_t>() + base, 16, hipMemcpyDeviceToHost));
+            tl[i] = c->dist.counts_host[base + 1];
+            tr[i] = c->dist.counts_host[base + 2];
+            if (status && base == 4 && c->dist.counts_host[base + 3] && *status < SPH_ERR_UNSUPPORTED) *status = SPH_ERR_UNSUPPORTED;
+        }
+        if (red) allreduce_min_f32(G, *red);
+        return neighbour_counts(G, tl, tr, fl, fr, nullptr);
+    }
+    int agree_guards_queued(Group&) override { return SPH_OK; }   // one process: sync_ctrl sees every member's guard word
     int allreduce_solver(Group& G) override
     {
         int rc = wait_all(G);
         if (rc) return rc;
-        double tot[4] = {0, 0, 0, 0};
-        std::vector<std::array<double, 4>> rows(G.m.size());
+        double tot[6] = {0, 0, 0, 0, 0, 0};
+        std::vector<std::array<double, 6>> rows(G.m.size());
         for (size_t i = 0; i < G.m.size(); i++) {
-            HIPCHK(G.m[i], hipMemcpy(rows[i].data(), G.m[i]->dist.solver_tot.p, 32, hipMemcpyDeviceToHost));
-            for (int k = 0; k < 4; k++) tot[k] += rows[i][k];
+            HIPCHK(G.m[i], hipMemcpy(rows[i].data(), G.m[i]->dist.solver_tot.p, 48, hipMemcpyDeviceToHost));
+            for (int k = 0; k < 6; k++) tot[k] += rows[i][k];
         }
-        for (auto c : G.m) HIPCHK(c, hipMemcpy(c->dist.solver_tot.p, tot, 32, hipMemcpyHostToDevice));
+        for (auto c : G.m) HIPCHK(c, hipMemcpy(c->dist.solver_tot.p, tot, 48, hipMemcpyHostToDevice));
         return SPH_OK;
     }
 };
@@ -585,6 +640,7 @@ struct LocalComm : Comm {
     } while (0)
 
 struct RcclComm : Comm {
+    bool host_collectives_wait() const override { return true; }    // publish_and_wait behind the collective
     // small device scratch for host-value collectives
     static int host_allreduce(sph_ctx* c, void* host, size_t bytes, size_t count, ncclDataType_t dt, ncclRedOp_t op)
     {
@@ -624,17 +680,22 @@ struct RcclComm : Comm {
         return wait_stream(c);
     }
     int neighbour_counts(Group& G, const std::vector<uint32_t>& tl, const std::vector<uint32_t>& tr, std::vector<uint32_t>& fl,
-                         std::vector<uint32_t>& fr) override
+                         std::vector<uint32_t>& fr, int* status) override
     {
         sph_ctx* c = G.m[0];
         ncclComm_t nc = (ncclComm_t)c->dist.nccl;
         const int r = c->dist.rank, nr = c->dist.nranks;
-        uint32_t* d = c->dist.counts.as<uint32_t>() + 16;  // [0]=to_left [1]=to_right [2]=from_left [3]=from_right
+        uint32_t* d = c->dist.counts.as<uint32_t>() + 16;  // [0]=to_left [1]=to_right [2]=from_left [3]=from_right [4]=status
         uint32_t* h = (uint32_t*)((uint8_t*)c->dist.counts_host + 64);   // pinned staging
         h[0] = tl[0];
         h[1] = tr[0];
         h[2] = h[3] = 0;
-        HIPCHK(c, hipMemcpyAsync(d, h, 16, hipMemcpyHostToDevice, c->stream));
+        h[4] = status ? (uint32_t)*status : 0u;
+        HIPCHK(c, hipMemcpyAsync(d, h, 20, hipMemcpyHostToDevice, c->stream));
+        if (status) {
+            c->dist.stat_allreduces++;
+            NCCLCHK(c, ncclAllReduce(d + 4, d + 4, 1, ncclUint32, ncclMax, nc, c->stream));
+        }
         NCCLCHK(c, ncclGroupStart());
         if (r > 0) {
             NCCLCHK(c, ncclSend(d + 0, 1, ncclUint32, r - 1, nc, c->stream));
@@ -645,10 +706,74 @@ struct RcclComm : Comm {
             NCCLCHK(c, ncclRecv(d + 3, 1, ncclUint32, r + 1, nc, c->stream));
         }
         NCCLCHK(c, ncclGroupEnd());
-        int rc = publish_and_wait(c, d, 4);
+        int rc = publish_and_wait(c, d, 5);
         if (rc) return rc;
+        // (publish_and_wait lands in counts_host[16 ..), the staging words above sit at counts_host[16 ..) too: same words)
         fl[0] = r > 0 ? h[2] : 0;
         fr[0] = r + 1 < nr ? h[3] : 0;
+        if (status) *status = (int)h[4];
+        return SPH_OK;
+    }
+    int counts_round(Group& G, int base, std::vector<std::vector<float>>* red, int* status, std::vector<uint32_t>& tl, std::vector<uint32_t>& tr,
+                     std::vector<uint32_t>& fl, std::vector<uint32_t>& fr) override
+    {
+        sph_ctx* c = G.m[0];
+        ncclComm_t nc = (ncclComm_t)c->dist.nccl;
+        const int r = c->dist.rank, nr = c->dist.nranks;
+        // device scratch behind the counters: [0 .. 7] the min-reduced floats, [8 .. 16] k_counts_stage's words
+        uint32_t* d = c->dist.counts.as<uint32_t>() + 16;
+        uint32_t* h = (uint32_t*)((uint8_t*)c->dist.counts_host + 64);   // pinned staging / publish destination (same words)
+        const size_t nred = red ? (*red)[0].size() : 0;
+        if (nred > 8) return c->fail(SPH_ERR_INVALID_ARGUMENT, "counts_round: %zu reduced values", nred);
+        if (nred) {
+            memcpy(h, (*red)[0].data(), nred * 4);
+            HIPCHK(c, hipMemcpyAsync(d, h, nred * 4, hipMemcpyHostToDevice, c->stream));
+            c->dist.stat_allreduces++;
+            ProfScope ps(&c->prof, "rccl_allreduce", c->stream);
+            NCCLCHK(c, ncclAllReduce(d, d, nred, ncclFloat32, ncclMin, nc, c->stream));
+        }
+        hipLaunchKernelGGL(k_counts_stage, dim3(1), dim3(64), 0, c->stream, c->dist.counts.as<uint32_t>() + base, d + 8, status ? (uint32_t)*status : 0u,
+                           base == 4 ? 1 : 0);
+        if (status) {
+            c->dist.stat_allreduces++;
+            ProfScope ps(&c->prof, "rccl_allreduce", c->stream);
+            NCCLCHK(c, ncclAllReduce(d + 12, d + 12, 1, ncclUint32, ncclMax, nc, c->stream));
+        }
+        {
+            ProfScope ps(&c->prof, "rccl_sendrecv", c->stream);
+            NCCLCHK(c, ncclGroupStart());
+            if (r > 0) {
+                NCCLCHK(c, ncclSend(d + 8, 1, ncclUint32, r - 1, nc, c->stream));
+                NCCLCHK(c, ncclRecv(d + 10, 1, ncclUint32, r - 1, nc, c->stream));
+            }
+            if (r + 1 < nr) {
+                NCCLCHK(c, ncclSend(d + 9, 1, ncclUint32, r + 1, nc, c->stream));
+                NCCLCHK(c, ncclRecv(d + 11, 1, ncclUint32, r + 1, nc, c->stream));
+            }
+            NCCLCHK(c, ncclGroupEnd());
+        }
+        int rc = publish_and_wait(c, d, 17);
+        if (rc) return rc;
+        for (size_t k = 0; k < nred; k++) memcpy(&(*red)[0][k], &h[k], 4);
+        tl[0] = h[8];
+        tr[0] = h[9];
+        fl[0] = r > 0 ? h[10] : 0;
+        fr[0] = r + 1 < nr ? h[11] : 0;
+        if (status) *status = (int)h[12];
+        for (int k = 0; k < 4; k++) c->dist.counts_host[base + k] = h[13 + k];
+        return SPH_OK;
+    }
+    int agree_guards_queued(Group& G) override
+    {
+        sph_ctx* c = G.m[0];
+        uint32_t* d = c->dist.counts.as<uint32_t>() + 40;
+        hipLaunchKernelGGL(k_guard_stage, dim3(1), dim3(64), 0, c->stream, c->status.as<DeviceStatus>(), d);
+        c->dist.stat_allreduces++;
+        {
+            ProfScope ps(&c->prof, "rccl_allreduce", c->stream);
+            NCCLCHK(c, ncclAllReduce(d, d, 1, ncclUint32, ncclMax, (ncclComm_t)c->dist.nccl, c->stream));
+        }
+        hipLaunchKernelGGL(k_guard_merge, dim3(1), dim3(64), 0, c->stream, d, c->ctrl.as<SolverCtrl>());
         return SPH_OK;
     }
     int exchange(Group& G, std::vector<Xfer>& x) override
@@ -677,7 +802,7 @@ struct RcclComm : Comm {
         sph_ctx* c = G.m[0];
         c->dist.stat_allreduces++;
         ProfScope ps(&c->prof, "rccl_allreduce", c->stream);
-        NCCLCHK(c, ncclAllReduce(c->dist.solver_tot.p, c->dist.solver_tot.p, 4, ncclFloat64, ncclSum, (ncclComm_t)c->dist.nccl, c->stream));
+        NCCLCHK(c, ncclAllReduce(c->dist.solver_tot.p, c->dist.solver_tot.p, 6, ncclFloat64, ncclSum, (ncclComm_t)c->dist.nccl, c->stream));
         return SPH_OK;
     }
 };
@@ -708,17 +833,28 @@ static int agree(Group& G, int local_rc)
     return SPH_OK;
 }
 
-// publish ctrl + status of every member to the host and wait; device-side guards -> status code
-static int sync_ctrl(Group& G)
+// publish ctrl + status of every member to the host and wait; device-side guards -> status code.
+//   SYNC_AGREE  one rank, or a slab wait point that agrees on the guards with a collective of its own (level estimation)
+//   SYNC_DEFER  slab decomposition, inside a solve: the guards are NOT turned into a status here -- a rank that left alone would
+//               leave the others in the next collective.  A guard that fired ends the solve on every rank through the
+//               all-reduced totals (solver_decide_multi) and the step runs to its end
+//   SYNC_FINAL  slab decomposition, the step's last wait: the guards were agreed on the device (Comm::agree_guards_queued put
+//               the maximum over the ranks into ctrl->peer_error before this publish), so every rank reports together without
+//               another round trip
+enum { SYNC_AGREE = 0, SYNC_DEFER = 1, SYNC_FINAL = 2 };
+static int sync_ctrl(Group& G, int mode = SYNC_AGREE)
 {
     int rc = SPH_OK;
+    if (!G.multi()) mode = SYNC_AGREE;
     for (auto c : G.m) {
         (void)hipSetDevice(c->device);
         launch_publish(c);
     }
+    uint32_t peer = 0;
     for (auto c : G.m) {
         int r = wait_publish(c);
         if (r && !rc) rc = r;
+        if (mode == SYNC_DEFER) continue;
         if (!r && c->status_host->error) {
             uint32_t code = c->status_host->error, info = c->status_host->info;
             (void)hipMemsetAsync(c->status.p, 0, sizeof(DeviceStatus), c->stream);
@@ -726,6 +862,11 @@ static int sync_ctrl(Group& G)
             r = c->fail((int)code, "%s (particle i=%u)", status_message(code), info);
             if (!rc) rc = r;
         }
+        if (!r && c->ctrl_host->peer_error > peer) peer = c->ctrl_host->peer_error;
+    }
+    if (mode == SYNC_FINAL) {
+        if (!rc && peer) rc = G.m[0]->fail(peer > 1 ? (int)peer : SPH_ERR_DEVICE, "another rank of the slab decomposition reported status %u", peer);
+        return rc;
     }
     return agree(G, rc);
 }
@@ -802,26 +943,11 @@ static int ensure_dist_buffers(sph_ctx* c, uint32_t n)
     return SPH_OK;
 }
 
-__global__ void k_copy_counts(const uint32_t* __restrict__ src, uint32_t* __restrict__ host_dst, uint32_t seq)
-{
-    if (threadIdx.x < 8) host_dst[threadIdx.x] = src[threadIdx.x];
-    __threadfence_system();
-    __syncthreads();
-    if (threadIdx.x == 0) ((volatile uint32_t*)host_dst)[15] = seq;   // wait hint
-}
-static void launch_copy_counts(sph_ctx* c)
-{
-    auto& d = c->dist;
-    c->publish_seq++;
-    if (c->publish_seq == 0u) c->publish_seq = 1u;
-    hipLaunchKernelGGL(k_copy_counts, dim3(1), dim3(64), 0, c->stream, d.counts.as<uint32_t>(), d.counts_host_dev, c->publish_seq);
-    c->hint_word = (volatile uint32_t*)d.counts_host + 15;   // nothing may be queued between this launch and the wait
-    c->hint_seq = c->publish_seq;
-}
-
 // ---- slab maintenance (multi-rank only) ---------------------------------------------------------------
 // part 1: drop last step's ghosts, hand over particles that left the slab
-static int partition_and_migrate(Group& G, std::vector<Member>& M, std::vector<int>* moved = nullptr)
+// `red`: the step's header values, min-reduced over all ranks in the SAME round trip that brings the partition counts to the
+// host and exchanges them with the x-neighbours (Comm::counts_round)
+static int partition_and_migrate(Group& G, std::vector<Member>& M, std::vector<int>* moved = nullptr, std::vector<std::vector<float>>* red = nullptr)
 {
     const size_t nm = M.size();
     int rc = SPH_OK;
@@ -859,21 +985,18 @@ static int partition_and_migrate(Group& G, std::vector<Member>& M, std::vector<i
             c->pcur ^= 1;
             std::swap(c->lam_sum, c->lam_prev);   // the permuted lambda sums are the CURRENT ones again (the cell sort moves them on)
         }
-        launch_copy_counts(c);
     }
-    if ((rc = wait_all_hinted(G))) return rc;   // (a device failure here is fatal for the whole job; logical errors are agreed on below)
-    // (2) migrants: counts -> neighbours, then the records
+    // (2) migrants: counts -> host and x-neighbours in one round trip, then the records
     std::vector<uint32_t> tl(nm), tr(nm), fl(nm), fr(nm);
+    for (auto& m : M) m.c->hint_word = nullptr;
+    if ((rc = G.comm->counts_round(G, 0, red, nullptr, tl, tr, fl, fr))) return rc;   // (a device failure here is fatal for the whole job)
     for (size_t i = 0; i < nm; i++) {
         auto& d = M[i].c->dist;
-        tl[i] = d.counts_host[1];
-        tr[i] = d.counts_host[2];
         // class 0 = everybody else (see block_class_counts); class 3 = ghosts of the previous step, dropped
         d.counts_host[0] = n_prev_of[i] - d.counts_host[1] - d.counts_host[2] - d.counts_host[3];
     }
     if (moved)
         for (size_t i = 0; i < nm; i++) (*moved)[i] = (int)(tl[i] + tr[i]);
-    if ((rc = G.comm->neighbour_counts(G, tl, tr, fl, fr))) return rc;
     std::vector<Xfer> x(nm);
     for (size_t i = 0; i < nm; i++) {
         sph_ctx* c = M[i].c;
@@ -1005,7 +1128,7 @@ static int rebalance_cuts(Group& G, std::vector<Member>& M, bool* applied)
 
 // part 2: ghost layer -- owned particles within halo_width of a cut are copied to that neighbour, in array
 // order (stable partition again)
-static int build_ghost_layer(Group& G, std::vector<Member>& M, float halo_width, float ring1_width)
+static int build_ghost_layer(Group& G, std::vector<Member>& M, float halo_width, float ring1_width, int status_in)
 {
     const size_t nm = M.size();
     int rc = SPH_OK;
@@ -1029,19 +1152,22 @@ static int build_ghost_layer(Group& G, std::vector<Member>& M, float halo_width,
                 std::swap(c->val[0], c->val[1]);
             }
         }
-        launch_copy_counts(c);
     }
-    // one agreement for both the wait and the width check (every rank leaves together)
-    rc = wait_all_hinted(G);
-    for (size_t i = 0; i < nm && !rc; i++) {
-        auto& d = M[i].c->dist;
-        if (d.counts_host[4 + 3]) rc = M[i].c->fail(SPH_ERR_UNSUPPORTED, "slab of rank %d is narrower than two ghost layers", d.rank);
-        tl[i] = d.counts_host[4 + 1];
-        tr[i] = d.counts_host[4 + 2];
-        d.counts_host[4 + 0] = (uint32_t)M[i].c->n - tl[i] - tr[i] - d.counts_host[4 + 3];   // class 0 is not counted on the device
+    // one round trip: the halo counts to the host and to the x-neighbours, and one agreement over all ranks on the width check
+    // (a slab narrower than two ghost layers) and on whatever the caller brings (`status_in`) -- every rank leaves together
+    for (auto& m : M) m.c->hint_word = nullptr;
+    {
+        int agreed = status_in;
+        if ((rc = G.comm->counts_round(G, 4, nullptr, &agreed, tl, tr, fl, fr))) return rc;
+        for (size_t i = 0; i < nm; i++) {
+            auto& d = M[i].c->dist;
+            if (d.counts_host[4 + 3]) rc = M[i].c->fail(SPH_ERR_UNSUPPORTED, "slab of rank %d is narrower than two ghost layers", d.rank);
+            d.counts_host[4 + 0] = (uint32_t)M[i].c->n - tl[i] - tr[i] - d.counts_host[4 + 3];   // class 0 is not counted on the device
+        }
+        if (rc) return rc;
+        if (status_in) return status_in;
+        if (agreed) return M[0].c->fail(agreed, "another rank of the slab decomposition reported status %d", agreed);
     }
-    if ((rc = agree(G, rc))) return rc;
-    if ((rc = G.comm->neighbour_counts(G, tl, tr, fl, fr))) return rc;
     for (size_t i = 0; i < nm; i++) {
         sph_ctx* c = M[i].c;
         auto& d = c->dist;
@@ -1104,7 +1230,7 @@ static int build_ghost_layer(Group& G, std::vector<Member>& M, float halo_width,
 // Slab decomposition: block 0 of A(k + 1) adds up the rank's totals; the all-reduce and the decision (k_solver_decide) follow
 // behind that sweep, i.e. the decision on iteration k is taken one sweep late and the reduction kernel between B and A is gone.
 static int pressure_iterations(Group& G, std::vector<Member>& M, float max_avg_error, int residual_density, uint32_t max_iters,
-                               uint32_t predicted_iters, int tail, bool density_solver)
+                               uint32_t predicted_iters, int tail, bool density_solver, bool final_solve)
 {
     int rc;
     const int multi = G.multi() ? 1 : 0;
@@ -1119,17 +1245,19 @@ static int pressure_iterations(Group& G, std::vector<Member>& M, float max_avg_e
                 z.slot_done[0] = z.slot_done[1] = 1u;
                 z.cur = k & 1u;
                 (void)hipMemcpyAsync(m.c->ctrl.p, &z, sizeof z, hipMemcpyHostToDevice, m.c->stream);
-            } else (void)hipMemsetAsync(m.c->dist.solver_tot.p, 0, 40, m.c->stream);   // an empty slab contributes zeros
+            } else (void)hipMemsetAsync(m.c->dist.solver_tot.p, 0, 48, m.c->stream);   // an empty slab contributes zeros
         }
-        if (multi) {
-            int r = G.comm->allreduce_solver(G);
-            if (r) return r;
-            for (auto& m : M) {
-                (void)hipSetDevice(m.c->device);
-                launch_solver_decide(m.c->stream, &m.c->prof, m.a, (int)k - 1, residual_density, max_avg_error, max_iters);
-            }
-        }
+        // slab decomposition: the totals of iteration k - 1 are all-reduced behind this sweep; the decision is evaluated by the
+        // blocks of B(k) themselves (OpJacobi::prologue), or by decide() before a solve's tail
+        if (multi) return G.comm->allreduce_solver(G);
         return SPH_OK;
+    };
+    auto decide = [&](uint32_t k_decided) {
+        if (!multi) return;
+        for (auto& m : M) {
+            (void)hipSetDevice(m.c->device);
+            launch_solver_decide(m.c->stream, &m.c->prof, m.a, (int)k_decided, residual_density, max_avg_error, max_iters);
+        }
     };
     auto pt_of = [&](int cur) { return cur ? sel_pt1 : sel_pt0; };
     // iteration 0 wrote pressure buffer 1
@@ -1141,24 +1269,27 @@ static int pressure_iterations(Group& G, std::vector<Member>& M, float max_avg_e
         for (; k <= upto && k <= max_iters; k++) {
             for (auto& m : M) {
                 (void)hipSetDevice(m.c->device);
-                if (m.n) launch_jacobi_update(m.c->stream, &m.c->prof, m.a, (int)k, residual_density);
+                if (m.n) launch_jacobi_update(m.c->stream, &m.c->prof, m.a, (int)k, residual_density, max_avg_error, max_iters, multi);
+                else if (multi) launch_solver_decide(m.c->stream, &m.c->prof, m.a, (int)k - 1, residual_density, max_avg_error, max_iters);   // an empty slab has no sweep B to take it
             }
             // (no exchange of a^p: the first ghost ring computes its own in sweep A)
             if ((rc = refresh_ghosts(G, M, pt_of((k + 1) & 1), 1, "pt"))) return rc;
             if ((rc = sweep_a(k + 1))) return rc;
         }
+        decide(k - 1);   // (slab decomposition) the last queued sweep A(k) left the totals of iteration k - 1 behind
         for (auto& m : M) {
             (void)hipSetDevice(m.c->device);
             if (!m.n || tail == 0 /* TAIL_NONE */) continue;
             launch_solver_tail(m.c->stream, &m.c->prof, m.a, tail, m.c->pm[m.c->pcur ^ 1].as<float4>());
             if (tail >= 2 /* TAIL_VX, TAIL_HYBRID */ && m.a.hdr_partials) launch_header_ahead(m.c, (m.n + 255u) / 256u, m.c->hdr_host_dev);
         }
-        if ((rc = sync_ctrl(G))) return rc;
+        if (multi && final_solve && (rc = G.comm->agree_guards_queued(G))) return rc;
+        if ((rc = sync_ctrl(G, multi ? (final_solve ? SYNC_FINAL : SYNC_DEFER) : SYNC_AGREE))) return rc;
         if (M[0].c->ctrl_host->done) break;
         if (k > max_iters) break;  // cannot happen: the decision on iteration max_iters is always "stop"
-        // the prediction (the previous step's count) fell short: two more iterations per wait -- a skipped iteration costs two
-        // empty launches, a wait the round trip to the host
-        upto = k + 1;
+        // the prediction (the previous step's count) fell short: a quarter more iterations per wait, at least two -- a skipped
+        // iteration costs two empty launches (~9 us), a wait the round trip to the host (and on slabs an agreement)
+        upto = k + std::max(1u, k / 4u);
     }
     for (auto& m : M) {
         const SolverCtrl& h = *m.c->ctrl_host;
@@ -1219,78 +1350,112 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
         if (tev) (void)hipEventRecord(m.c->ev[0], m.c->stream);
     }
 
-    // ---- step header over the OWNED particles: h from mass (simulation.rs:1998-2003), CFL term, h_max ------
-    // (multi-rank: ghosts of the previous step are still interleaved -> partition first, inside decompose();
-    //  for that the header has to run on the partitioned arrays, so decompose() is split around it)
-    std::vector<std::vector<float>> red(M.size(), std::vector<float>(4));
+    // ---- step header (h from mass, simulation.rs:1998-2003; CFL term; h_max; bounding box) and, on slabs, the hand-over of the
+    // particles that left their slab -------------------------------------------------------------------------------------
+    // per rank: -h_max, h_min, CFL term, -status, and the bounding box of the owned particles (min x, -max x, min y, -max y): all min-reduced
+    std::vector<std::vector<float>> red(M.size(), std::vector<float>(8));
     int hdr_rc = SPH_OK, setup_rc = SPH_OK;
+    // The tail of the previous step's last solve already reduced this step's header into hdr_host (k_solver_tail,
+    // k_header_ahead): nothing to launch, nothing to wait for -- unless the host touched the state or the smoothing lengths are
+    // not the mass-derived ones.  On a slab the header describes the particles the rank owned at the END of that step; the ones
+    // about to migrate are some other rank's soon, but every value below is reduced over ALL ranks (or replaced by the cuts).
+    auto header_ready = [&](sph_ctx* c) { return h_from_mass_mode && c->hdr_ahead && c->hdr_ahead_rest_density == p->rest_density; };
+    auto fill_red = [&]() {
+        for (size_t i = 0; i < M.size(); i++) {
+            const HeaderOut h = *M[i].c->hdr_host;
+            const bool any = M[i].c->n > 0;
+            red[i][0] = any ? -h.h_max : 0.f;
+            red[i][1] = any ? h.h_min : INFINITY;
+            red[i][2] = any ? h.min_cfl : INFINITY;
+            red[i][3] = -(float)hdr_rc;   // the agreement on this wait point rides in the same all-reduce (min of -status)
+            red[i][4] = any ? h.min_x : INFINITY;
+            red[i][5] = any ? -h.max_x : INFINITY;
+            red[i][6] = any ? h.min_y : INFINITY;
+            red[i][7] = any ? -h.max_y : INFINITY;
+            M[i].c->hdr_ahead = false;
+        }
+    };
     if (G.multi()) {
         bool rebalanced = false;
         const int every = c0->dist.rebalance_every;
         if (every > 0 && c0->step_number > 0 && c0->step_number % (uint64_t)every == 0 && c0->h_max_step > 0.f)
             if ((rc = rebalance_cuts(G, M, &rebalanced))) return rc;
+        // header of the particles each rank owns NOW (before the hand-over: the global values do not care who owns a particle)
+        bool launched = false;
+        for (auto& m : M) {
+            sph_ctx* c = m.c;
+            if (header_ready(c)) continue;
+            (void)hipSetDevice(c->device);
+            const uint32_t n_prev = c->dist.have_flags ? c->dist.n_tot : (uint32_t)c->n;
+            launch_header(c, n_prev, p->rest_density, h_from_mass_mode ? 1 : 2, c->hdr_host_dev, c->dist.have_flags ? c->dist.owned.as<uint8_t>() : nullptr);
+            launched = true;
+        }
+        if (launched) hdr_rc = wait_all_hinted(G);   // (first step, after uploads, FromDistribution*: the values must be on the host before the all-reduce)
+        fill_red();
         // particles follow the cuts to the x-neighbour; after a re-balance a particle may have to cross several slabs:
-        // repeat until nobody moved (the all-reduced count), at most once per rank
+        // repeat until nobody moved (the all-reduced count), at most once per rank.  The header all-reduce rides in the round
+        // trip of the first partition's counts.
         std::vector<int> moved(M.size(), 0);
         for (int round = 0;; round++) {
-            if ((rc = partition_and_migrate(G, M, &moved))) return rc;  // only needs the cuts
+            if ((rc = partition_and_migrate(G, M, &moved, round == 0 ? &red : nullptr))) return rc;
             if (!rebalanced) break;
             if ((rc = G.comm->allreduce_max_i32(G, moved))) return rc;
             if (moved[0] == 0 || round + 1 >= c0->dist.nranks) break;
         }
+    } else {
+        if (!header_ready(c0)) {
+            launch_header(c0, (uint32_t)c0->n, p->rest_density, h_from_mass_mode ? 1 : 2, c0->hdr_host_dev);
+            if ((hdr_rc = wait_all_hinted(G))) return hdr_rc;
+        }
+        fill_red();
     }
     g_trace.mark(0);
-    // The integrating final sweep of the previous step already reduced this step's header into hdr_host (sph_sweeps.hip,
-    // OpPressureAccel::epilogue): nothing to launch, nothing to wait for -- unless the host touched the state, the
-    // smoothing lengths are not the mass-derived ones, or the particles are about to be re-partitioned.
-    const bool header_ready = !G.multi() && h_from_mass_mode && c0->hdr_ahead && c0->hdr_ahead_rest_density == p->rest_density;
-    if (!header_ready) {
-        for (auto& m : M) {
-            (void)hipSetDevice(m.c->device);
-            launch_header(m.c, (uint32_t)m.c->n, p->rest_density, h_from_mass_mode ? 1 : 2, m.c->hdr_host_dev);
-        }
-        hdr_rc = wait_all_hinted(G);
-        if (hdr_rc && !G.multi()) return hdr_rc;
-    }
-    c0->hdr_ahead = false;
-    for (size_t i = 0; i < M.size(); i++) {
-        const HeaderOut h = *M[i].c->hdr_host;
-        red[i][0] = M[i].c->n ? -h.h_max : 0.f;
-        red[i][1] = M[i].c->n ? h.h_min : INFINITY;
-        red[i][2] = M[i].c->n ? h.min_cfl : INFINITY;
-        red[i][3] = -(float)hdr_rc;   // the agreement on this wait point rides in the same all-reduce (min of -status)
-    }
-    if (G.multi() && (rc = G.comm->allreduce_min_f32(G, red))) return rc;
     if (hdr_rc) return hdr_rc;
     if (red[0][3] < 0.f)
         return c0->fail((int)-red[0][3], "another rank of the slab decomposition reported status %d", (int)-red[0][3]);
     const float h_max_g = -red[0][0], h_min_g = red[0][1], min_cfl_g = red[0][2];
+    // (identical on every rank: all-reduced values only)
     if (!(h_max_g > 0.f) || !std::isfinite(h_max_g))
-        return agree(G, c0->fail(SPH_ERR_POSITION_NOT_FINITE, "particle positions or smoothing lengths are not finite"));
+        return c0->fail(SPH_ERR_POSITION_NOT_FINITE, "particle positions or smoothing lengths are not finite");
+    const HeaderOut gbox{red[0][4], red[0][6], -red[0][5], -red[0][7], h_max_g, h_min_g, min_cfl_g, 0};   // global bounding box
     // CFL (simulation.rs:2190-2191)
     const float cfl_dt = p->cfl_factor * sqrtf(min_cfl_g);
     const float dt = fminf(p->max_dt, cfl_dt);
 
+    std::vector<HeaderOut> boxes(M.size(), gbox);   // bounding box of what each member sorts: owned + ghosts
     if (G.multi()) {
+        // Checks every rank evaluates on the SAME all-reduced numbers (no agreement needed): the cell grid of the global box
+        // bounds every rank's own grid.
+        int status_in = SPH_OK;
+        if (!std::isfinite(gbox.min_x) || !std::isfinite(gbox.max_x) || !std::isfinite(gbox.min_y) || !std::isfinite(gbox.max_y))
+            return c0->fail(SPH_ERR_POSITION_NOT_FINITE, "particle positions are not finite");
+        {
+            const float cs = h_max_g * 2.f;
+            const long long gx = (long long)floorf(gbox.max_x / cs) - (long long)floorf(gbox.min_x / cs) + 3, gy = (long long)floorf(gbox.max_y / cs) - (long long)floorf(gbox.min_y / cs) + 3;
+            if (gx <= 0 || gy <= 0 || gx >= 65536 || gy >= 65536 || gx * gy >= (1ll << 27))
+                return c0->fail(SPH_ERR_UNSUPPORTED, "cell grid of cell size %g is too large for this build", (double)cs);
+        }
         // ghost layer with the real width: one support radius of the largest particle anywhere
         // (the extended lists of the level estimation reach level_estimation_range / ETA smoothing lengths)
         // Two rings of one support radius (2 h_max) each: ghosts of the first ring compute their pressure acceleration here
         // (their neighbours are all inside the second), so a Jacobi iteration exchanges p / rho^2 only.
         const float halo_k = fmaxf(4.f, level_on ? p->level_estimation_range / SPH_ETA : 0.f);
-        if ((rc = build_ghost_layer(G, M, h_max_g * halo_k, h_max_g * 2.f))) return rc;
-        // bounding box of owned + ghosts
-        for (auto& m : M) {
-            (void)hipSetDevice(m.c->device);
-            launch_header(m.c, m.n, p->rest_density, 0, m.c->hdr_host_dev);   // h is set; only the bounding box changed
+        const float halo_w = h_max_g * halo_k;
+        if ((rc = build_ghost_layer(G, M, halo_w, h_max_g * 2.f, status_in))) return rc;
+        // bounding box of owned + ghosts from the cuts: an owned particle lies between them, a ghost within halo_w beyond one
+        for (size_t i = 0; i < M.size(); i++) {
+            const auto& d = M[i].c->dist;
+            if (d.rank > 0) boxes[i].min_x = fmaxf(gbox.min_x, d.cut_lo - halo_w);
+            if (d.rank + 1 < d.nranks) boxes[i].max_x = fminf(gbox.max_x, d.cut_hi + halo_w);
+            if (!(boxes[i].max_x >= boxes[i].min_x)) boxes[i].max_x = boxes[i].min_x;   // an empty slab beyond the fluid
         }
-        setup_rc = wait_all_hinted(G);   // agreed on below, together with the per-rank grid checks
     }
     g_trace.mark(1);
 
     auto setup_member = [&](Member& m) -> int {
         sph_ctx* c = m.c;
         (void)hipSetDevice(c->device);
-        const HeaderOut hdr = *c->hdr_host;
+        const HeaderOut hdr = boxes[(size_t)(&m - M.data())];
         const uint32_t n = m.n;
         // CellGrid (neighborhood_search.rs:261-275) with cell = support radius of the largest particle: the grid the
         // reference's convention defines (sph_grid, cell_index).  Uniform scenes sort by it.  Multi-resolution scenes sort
@@ -1426,7 +1591,7 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
     };
     for (auto& m : M)
         if (!setup_rc) setup_rc = setup_member(m);
-    if ((rc = agree(G, setup_rc))) return rc;   // bounding-box wait + grid checks of every rank
+    if (setup_rc) return setup_rc;   // (slabs: the grid checks were taken on all-reduced numbers above, identically on every rank)
     g_trace.mark(2);
 
     // ---- level estimation on the extended-range lists (simulation.rs:2018-2046, 862-927; after advection: 2678-2707) ------
@@ -1742,14 +1907,14 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
         if ((rc = non_pressure())) return rc;
         rec(4);
         begin_solve(1, 1);
-        if ((rc = pressure_iterations(G, M, p->iisph_max_avg_density_error, 1, p->max_iters, c0->last_dens_iters, T_VX, true))) return rc;
+        if ((rc = pressure_iterations(G, M, p->iisph_max_avg_density_error, 1, p->max_iters, c0->last_dens_iters, T_VX, true, !level_on))) return rc;
         rec(5);
         break;
     case SPH_SOLVER_IISPH2:  // simulation.rs:2262-2387: omega rides in the source-term sweep; p /= sqrt(omega) before the last a^p
         if ((rc = non_pressure())) return rc;
         rec(4);
         begin_solve(3, 1);
-        if ((rc = pressure_iterations(G, M, p->iisph_max_avg_density_error, 1, p->max_iters, c0->last_dens_iters, T_NONE, true))) return rc;
+        if ((rc = pressure_iterations(G, M, p->iisph_max_avg_density_error, 1, p->max_iters, c0->last_dens_iters, T_NONE, true, false))) return rc;
         for (auto& m : M) {
             (void)hipSetDevice(m.c->device);
             if (m.n) launch_iisph2_scale(m.c->stream, &m.c->prof, m.a);
@@ -1762,14 +1927,15 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
             launch_solver_tail(m.c->stream, &m.c->prof, m.a, T_VX, m.c->pm[m.c->pcur ^ 1].as<float4>());
             if (m.a.hdr_partials) launch_header_ahead(m.c, (m.n + 255u) / 256u, m.c->hdr_host_dev);
         }
-        if ((rc = sync_ctrl(G))) return rc;
+        if (G.multi() && !level_on && (rc = G.comm->agree_guards_queued(G))) return rc;
+        if ((rc = sync_ctrl(G, G.multi() ? (level_on ? SYNC_DEFER : SYNC_FINAL) : SYNC_AGREE))) return rc;
         rec(5);
         break;
     case SPH_SOLVER_ONLY_DIVERGENCE:  // simulation.rs:2448-2500
         if ((rc = non_pressure())) return rc;
         rec(2);
         begin_solve(0, 0);
-        if ((rc = pressure_iterations(G, M, p->hybrid_dfsph_max_avg_divergence_error, 0, p->max_iters, c0->last_div_iters, T_VX, false))) return rc;
+        if ((rc = pressure_iterations(G, M, p->hybrid_dfsph_max_avg_divergence_error, 0, p->max_iters, c0->last_div_iters, T_VX, false, !level_on))) return rc;
         rec(3);
         break;
     default:  // HybridDFSPH, simulation.rs:2502-2670
@@ -1777,7 +1943,7 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
             if ((rc = non_pressure())) return rc;
         rec(2);
         begin_solve(0, 0);
-        if ((rc = pressure_iterations(G, M, p->hybrid_dfsph_max_avg_divergence_error, 0, p->max_iters, c0->last_div_iters, T_VEL, false))) return rc;
+        if ((rc = pressure_iterations(G, M, p->hybrid_dfsph_max_avg_divergence_error, 0, p->max_iters, c0->last_div_iters, T_VEL, false, false))) return rc;
         g_trace.mark(4);
         rec(3);
         if ((rc = refresh_ghosts(G, M, sel_vel, 2, "vel"))) return rc;  // v += dt a^p happened in the final sweep
@@ -1785,7 +1951,7 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
             if ((rc = non_pressure())) return rc;
         rec(4);
         begin_solve(p->hybrid_dfsph_density_source_term == SPH_ONLY_DENSITY ? 2 : 1, 1);
-        if ((rc = pressure_iterations(G, M, p->hybrid_dfsph_max_avg_density_error, 1, p->max_iters, c0->last_dens_iters, T_HYBRID, true))) return rc;
+        if ((rc = pressure_iterations(G, M, p->hybrid_dfsph_max_avg_density_error, 1, p->max_iters, c0->last_dens_iters, T_HYBRID, true, !level_on))) return rc;
         g_trace.mark(5);
         rec(5);
         break;
@@ -1813,7 +1979,8 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
             std::swap(c->lvl[c->cur], c->lvl_tmp);
             // (no classify_particles here: the reference's step never calls it -- sph_classify is the host's call)
         }
-        if ((rc = sync_ctrl(G))) return rc;
+        if ((rc = G.comm->agree_guards_queued(G))) return rc;
+        if ((rc = sync_ctrl(G, SYNC_FINAL))) return rc;
         for (auto& m : M) m.st.ms_level_estimation += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_lvl0).count();
     }
     if (level_after) {   // simulation.rs:2678-2707: lists of the advected positions, then detection + propagation there
@@ -1843,7 +2010,7 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
         c->lists_after_slack = lv_slack;
         // every solver mode ends in an integrating final sweep, which left the next step's header in hdr_host
         // (constrain_neighborhood_count left reduced smoothing lengths in the records: the next step's k_header restores them)
-        c->hdr_ahead = !G.multi() && h_from_mass_mode && m.n > 0 && m.a.hdr_partials != nullptr && !p->constrain_neighborhood_count;
+        c->hdr_ahead = h_from_mass_mode && m.n > 0 && m.a.hdr_partials != nullptr && !p->constrain_neighborhood_count;
         c->hdr_ahead_rest_density = p->rest_density;
         c->last_div_iters = m.st.div_solver.iters;
         c->last_dens_iters = m.st.density_solver.iters;

@@ -1059,10 +1059,52 @@ struct SolveP {
     int multi;   // slab decomposition: block 0 only adds up this rank's totals; the decision follows the all-reduce (k_solver_decide)
 };
 
+// stopping rule of iisph_pressure_iterations (simulation.rs:1453-1479) for iteration `iter`
+__device__ __forceinline__ bool solver_stop_rule(uint32_t normal, float sum_err, int iter, const SolveP& q, float rest_density, float dt)
+{
+    const float avg = normal > 0 ? sum_err / (float)normal : __uint_as_float(0x7fc00000u);
+    bool stop;
+    if (q.residual_density) stop = normal == 0 || (fabsf(avg / rest_density) < q.max_avg_error && iter > 1);
+    else stop = normal == 0 || (fabsf(avg) < q.max_avg_error / dt && iter > 1);
+    if (!stop && (uint32_t)iter == q.max_iters) stop = true;
+    return stop;
+}
+
+// Slab decomposition: the ranks' totals of iteration `iter` (tot[0..5], all-reduced behind sweep A(iter + 1)) -> the decision,
+// evaluated by whoever needs it (every block of sweep B(iter + 1), k_solver_decide before a solve's tail).  tot[5] counts the
+// ranks whose device-side guards fired: the solve then ends on every rank together (ctrl->peer_error) instead of leaving the
+// others in a collective.  `publish`: this thread also writes the control block.
+__device__ __forceinline__ bool solver_decide_multi(const double* __restrict__ tot, SolverCtrl* ctrl, int iter, const SolveP& q, float rest_density, float dt,
+                                                    bool publish)
+{
+    const uint32_t slot = (uint32_t)(iter + 1) & 1u;
+    if (ctrl->slot_done[iter & 1] != 0u) {   // decided earlier: hand the flag on (the totals are stale)
+        if (publish) ctrl->slot_done[slot] = 1u;
+        return true;
+    }
+    const uint32_t normal = (uint32_t)tot[0];
+    const float sum_err = (float)tot[3];
+    const bool failed = tot[5] > 0.0;
+    const bool stop = failed || solver_stop_rule(normal, sum_err, iter, q, rest_density, dt);
+    if (publish) {
+        ctrl->normal = normal;
+        ctrl->singular = (uint32_t)tot[1];
+        ctrl->negative = (uint32_t)tot[2];
+        ctrl->sum_err = sum_err;
+        ctrl->max_err = (float)tot[4];
+        ctrl->iters = (uint32_t)iter;
+        ctrl->cur = (uint32_t)((iter + 1) & 1);
+        ctrl->slot_done[slot] = stop ? 1u : 0u;
+        if (failed) ctrl->peer_error = 1u;
+        if (stop) ctrl->done = 1u;
+    }
+    return stop;
+}
+
 // PressureSolverStatistics of iteration `iter` from the per-block partials (fixed order: deterministic; the reference's rayon
 // tree order is not) and the stop rule of simulation.rs:1453-1479.  Called by ALL threads of one block.
 __device__ __forceinline__ void solver_reduce_decide(const SolverPartial* __restrict__ partials, uint32_t nparts, SolverCtrl* ctrl, double* __restrict__ tot,
-                                                     int iter, const SolveP& q, float rest_density, float dt)
+                                                     int iter, const SolveP& q, float rest_density, float dt, const DeviceStatus* status)
 {
     __shared__ SolverPartial s_r[SWEEP_THREADS / 64];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -1096,14 +1138,11 @@ __device__ __forceinline__ void solver_reduce_decide(const SolverPartial* __rest
         tot[1] = (double)t.singular;
         tot[2] = (double)t.negative;
         tot[3] = (double)t.sum_err;
-        tot[4] = (double)t.max_err;   // not all-reduced: local maximum, informational
+        tot[4] = (double)t.max_err;   // summed over the ranks: informational
+        tot[5] = status->error != 0u ? 1.0 : 0.0;   // a guard fired on this rank: every rank ends the solve (solver_decide_multi)
         return;
     }
-    const float avg = t.normal > 0 ? t.sum_err / (float)t.normal : __uint_as_float(0x7fc00000u);
-    bool stop;
-    if (q.residual_density) stop = t.normal == 0 || (fabsf(avg / rest_density) < q.max_avg_error && iter > 1);
-    else stop = t.normal == 0 || (fabsf(avg) < q.max_avg_error / dt && iter > 1);
-    if (!stop && (uint32_t)iter == q.max_iters) stop = true;
+    const bool stop = solver_stop_rule(t.normal, t.sum_err, iter, q, rest_density, dt);
     ctrl->normal = t.normal;
     ctrl->singular = t.singular;
     ctrl->negative = t.negative;
@@ -1161,7 +1200,7 @@ struct OpPressureAccel {
             if (raw_block == 0u && threadIdx.x == 0 && !solve.multi) ctrl->slot_done[iter & 1] = 1u;
             return true;
         }
-        if (raw_block == 0u) solver_reduce_decide(partials, nparts, ctrl, tot, iter - 1, solve, sp.rest_density, sp.dt);
+        if (raw_block == 0u) solver_reduce_decide(partials, nparts, ctrl, tot, iter - 1, solve, sp.rest_density, sp.dt, status);
         return false;
     }
     __device__ bool lane_skip(uint32_t) const { return false; }
@@ -1303,7 +1342,7 @@ struct OpJacobi {
     float* __restrict__ pterm_out;
     float* __restrict__ dens_err;
     SolverPartial* __restrict__ partials;
-    const SolverCtrl* __restrict__ ctrl;
+    SolverCtrl* ctrl;
     DeviceStatus* status;
     StepP sp;
     int iter;
@@ -1313,7 +1352,16 @@ struct OpJacobi {
         float err;       // residual of a "normal" particle
         uint32_t cls;    // 0 normal, 1 singular, 2 negative (PressureSolverStatistics, simulation.rs:397-445)
     };
-    __device__ bool skip() const { return ctrl->slot_done[iter & 1] != 0u; }   // the decision A(iter) took on iteration iter - 1
+    SolveP solve;
+    const double* __restrict__ tot;
+    __device__ bool skip() const { return false; }
+    // the decision on iteration iter - 1: taken by block 0 of A(iter) (single rank), or -- slab decomposition -- evaluated here by
+    // every block from the all-reduced totals, published by block 0 for the launches behind this one
+    __device__ bool prologue(uint32_t raw_block) const
+    {
+        if (!solve.multi) return ctrl->slot_done[iter & 1] != 0u;
+        return solver_decide_multi(tot, ctrl, iter - 1, solve, sp.rest_density, sp.dt, raw_block == 0u && threadIdx.x == 0);
+    }
     __device__ bool lane_skip(uint32_t) const { return false; }
     __device__ void init(Acc&) const {}
     __device__ float4 loadA(uint32_t j) const { return pm[j]; }
@@ -1919,31 +1967,9 @@ __global__ __launch_bounds__(256) void k_classify(uint32_t n, const float4* __re
 // stop decision of a slab decomposition: the ranks' totals of iteration `iter` (solver_reduce_decide, multi) were all-reduced
 // (RCCL, in stream); every rank takes the same decision here (stopping rule of iisph_pressure_iterations, simulation.rs:1453-1479)
 // ------------------------------------------------------------------------------------------------
-__global__ void k_solver_decide(const double* __restrict__ tot, SolverCtrl* ctrl, int iter, int residual_density, float max_avg_error,
-                                uint32_t max_iters, float rest_density, float dt)
+__global__ void k_solver_decide(const double* __restrict__ tot, SolverCtrl* ctrl, int iter, SolveP q, float rest_density, float dt)
 {
-    if (threadIdx.x != 0) return;
-    const uint32_t slot = (uint32_t)(iter + 1) & 1u;
-    if (ctrl->slot_done[iter & 1] != 0u) {   // decided earlier: hand the flag on (the totals are stale)
-        ctrl->slot_done[slot] = 1u;
-        return;
-    }
-    const uint32_t normal = (uint32_t)tot[0];
-    const float sum_err = (float)tot[3];
-    const float avg = normal > 0 ? sum_err / (float)normal : __uint_as_float(0x7fc00000u);
-    bool stop;
-    if (residual_density) stop = normal == 0 || (fabsf(avg / rest_density) < max_avg_error && iter > 1);
-    else stop = normal == 0 || (fabsf(avg) < max_avg_error / dt && iter > 1);
-    if (!stop && (uint32_t)iter == max_iters) stop = true;
-    ctrl->normal = normal;
-    ctrl->singular = (uint32_t)tot[1];
-    ctrl->negative = (uint32_t)tot[2];
-    ctrl->sum_err = sum_err;
-    ctrl->max_err = (float)tot[4];
-    ctrl->iters = (uint32_t)iter;
-    ctrl->cur = (uint32_t)((iter + 1) & 1);
-    ctrl->slot_done[slot] = stop ? 1u : 0u;
-    if (stop) ctrl->done = 1u;
+    if (threadIdx.x == 0) solver_decide_multi(tot, ctrl, iter, q, rest_density, dt, true);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2337,21 +2363,22 @@ void launch_solver_tail(hipStream_t s, Profiler* prof, const SweepArgs& a, int t
                            a.owned, a.ctrl, tail >= TAIL_VX ? a.hdr_partials : nullptr, a.status);
 }
 
-void launch_jacobi_update(hipStream_t s, Profiler* prof, const SweepArgs& a, int iter, int residual_density)
+void launch_jacobi_update(hipStream_t s, Profiler* prof, const SweepArgs& a, int iter, int residual_density, float max_avg_error, uint32_t max_iters, int multi)
 {
     ProfScope ps(prof, "jacobi_update", s);
     const float* pin = (iter & 1) ? a.p1 : a.p0;
     float* pout = (iter & 1) ? a.p0 : a.p1;
     float* ptout = (iter & 1) ? a.pt0 : a.pt1;
+    const SolveP q{residual_density, max_avg_error, max_iters, multi};
     SPH_DISPATCH(OpJacobi, false, a.pm, a.orig, a.rho, a.mrho, a.pacc, a.lam_grad, a.aii, a.src, pin, pout, ptout, a.dens_err, (SolverPartial*)a.partials, a.ctrl,
-                 a.status, a.sp, iter, residual_density)
+                 a.status, a.sp, iter, residual_density, q, a.solver_tot)
 }
 
 void launch_solver_decide(hipStream_t s, Profiler* prof, const SweepArgs& a, int iter, int residual_density, float max_avg_error,
                           uint32_t max_iters)
 {
     ProfScope ps(prof, "solver_decide", s);
-    hipLaunchKernelGGL(k_solver_decide, dim3(1), dim3(64), 0, s, a.solver_tot, a.ctrl, iter, residual_density, max_avg_error, max_iters,
+    hipLaunchKernelGGL(k_solver_decide, dim3(1), dim3(64), 0, s, a.solver_tot, a.ctrl, iter, SolveP{residual_density, max_avg_error, max_iters, 1},
                        a.sp.rest_density, a.sp.dt);
 }
 

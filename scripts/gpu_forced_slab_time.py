@@ -23,4 +23,6 @@ for _ in range(20):
 t0 = time.perf_counter()
 for _ in range(steps):
     c.step(p)
-print(f"forced slab mode, 1 rank, dam_break_1m: {(time.perf_counter() - t0) / steps * 1e3:.3f} ms/step")
+w = c.dist_get_stats()
+print(f"forced slab mode, 1 rank, dam_break_1m: {(time.perf_counter() - t0) / steps * 1e3:.3f} ms/step; per step over the whole run: host waits {w['host_waits'] / (steps + 20):.2f}, "
+      f"all-reduces {w['allreduces'] / (steps + 20):.2f}, exchanges {w['exchanges'] / (steps + 20):.2f}")
