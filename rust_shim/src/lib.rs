@@ -182,6 +182,23 @@ pub mod ffi {
         pub level_estimation: f32,
         pub level_old: f32,
     }
+    /// sph_adapt_params: the SimulationParams fields the apply half of single_step_adaptivity reads (+ the step's dt)
+    #[repr(C)]
+    #[derive(Clone, Copy, Default)]
+    pub struct SphAdaptParams {
+        pub dt: f32,
+        pub max_mass_transfer_sharing: f32,
+        pub minimum_share_partners: u32,
+        pub minimum_merge_partners: u32,
+        pub fail_on_missing_split_pattern: i32,
+        pub max_share_distance: f32,
+        pub max_merge_distance: f32,
+        pub allow_share_with_optimal_particle: i32,
+        pub allow_share_with_too_small_particle: i32,
+        pub allow_merge_with_optimal_particle: i32,
+        pub allow_merge_on_size_difference: i32,
+    }
+
 
     extern "C" {
         pub fn sph_create(n_capacity: u64, device_id: c_int, planes: *const SphPlane, n_planes: c_int, out: *mut *mut c_void) -> c_int;
@@ -196,6 +213,13 @@ pub mod ffi {
         pub fn sph_time(ctx: *const c_void) -> f32;
         pub fn sph_set_time(ctx: *mut c_void, time: f32, step_number: u64) -> c_int;
         pub fn sph_step(ctx: *mut c_void, params: *const SphParams, out: *mut SphStepStats) -> c_int;
+        pub fn sph_classify(ctx: *mut c_void, params: *const SphParams) -> c_int;
+        pub fn sph_share_particles(ctx: *mut c_void, params: *const SphParams, ap: *const SphAdaptParams, merge_partner: *const u32,
+                                   merge_counter: *const u16) -> c_int;
+        pub fn sph_merge_particles(ctx: *mut c_void, params: *const SphParams, ap: *const SphAdaptParams, merge_partner: *const u32,
+                                   merge_counter: *const u16) -> c_int;
+        pub fn sph_set_split_patterns(ctx: *mut c_void, n_patterns: u32, pos_s_xy: *const f32) -> c_int;
+        pub fn sph_split_particles(ctx: *mut c_void, params: *const SphParams, ap: *const SphAdaptParams) -> c_int;
         pub fn sph_last_error(ctx: *const c_void) -> *const c_char;
         pub fn sph_grid(ctx: *const c_void, out: *mut SphGridInfo) -> c_int;
     }
@@ -287,6 +311,35 @@ impl HipStep {
         let mut st = ffi::SphStepStats::default();
         self.check(unsafe { ffi::sph_step(self.ctx, params, &mut st) });
         st
+    }
+
+    /// classify_particles (adaptivity/mod.rs:50-59) on the device-resident state; read the classes back with
+    /// `download(SPH_F_PARTICLE_SIZE_CLASS, ..)` for the partner searches.
+    pub fn classify(&mut self, params: &ffi::SphParams) {
+        self.check(unsafe { ffi::sph_classify(self.ctx, params) });
+    }
+
+    /// share_particles (particle_sharing.rs:152-240) with the merge_partner / merge_counter arrays find_share_partner_sequential
+    /// filled (AtomicU32 has the layout of u32): the particle data never leaves the device.
+    pub fn share_particles(&mut self, params: &ffi::SphParams, ap: &ffi::SphAdaptParams, merge_partner: &[u32], merge_counter: &[u16]) {
+        assert!(merge_partner.len() == self.num_particles() && merge_counter.len() == merge_partner.len());
+        self.check(unsafe { ffi::sph_share_particles(self.ctx, params, ap, merge_partner.as_ptr(), merge_counter.as_ptr()) });
+    }
+
+    /// merge_particles (particle_merging.rs:270-370): transfer + the swap-with-the-last deletion; `num_particles()` is the new length.
+    pub fn merge_particles(&mut self, params: &ffi::SphParams, ap: &ffi::SphAdaptParams, merge_partner: &[u32], merge_counter: &[u16]) {
+        assert!(merge_partner.len() == self.num_particles() && merge_counter.len() == merge_partner.len());
+        self.check(unsafe { ffi::sph_merge_particles(self.ctx, params, ap, merge_partner.as_ptr(), merge_counter.as_ptr()) });
+    }
+
+    /// SplitPatterns (splitting.rs:84-120): `pos_s_xy` = the pos_s of every pattern, concatenated (pattern k has k + 2 children).
+    pub fn set_split_patterns(&mut self, n_patterns: usize, pos_s_xy: &[f32]) {
+        self.check(unsafe { ffi::sph_set_split_patterns(self.ctx, n_patterns as u32, pos_s_xy.as_ptr()) });
+    }
+
+    /// split_particles (splitting.rs:19-82) for the TooLarge particles of the last `classify`.
+    pub fn split_particles(&mut self, params: &ffi::SphParams, ap: &ffi::SphAdaptParams) {
+        self.check(unsafe { ffi::sph_split_particles(self.ctx, params, ap) });
     }
 
     pub fn time(&self) -> f32 {

@@ -38,6 +38,8 @@ def test_struct_layouts_match_header():
     assert C.sizeof(ffi.SphGridInfo) == 20
     assert C.sizeof(ffi.SphKernelTime) == 80
     assert C.sizeof(ffi.SphEditOp) == 52
+    assert C.sizeof(ffi.SphAdaptParams) == 11 * 4
+    assert C.sizeof(ffi.SphDistStats) == 7 * 8 + 4 * 4
 
 
 def test_no_gpu_create_fails_loudly(product_lib, gpu_available):
@@ -81,7 +83,8 @@ def test_rust_shim_mirrors_the_header():
         return re.findall(r"pub (\w+):", body)
 
     for c_name, r_name in [("sph_params", "SphParams"), ("sph_plane", "SphPlane"), ("sph_solver_stats", "SphSolverStats"),
-                           ("sph_step_stats", "SphStepStats"), ("sph_grid_info", "SphGridInfo"), ("sph_edit_op", "SphEditOp")]:
+                           ("sph_step_stats", "SphStepStats"), ("sph_grid_info", "SphGridInfo"), ("sph_edit_op", "SphEditOp"),
+                           ("sph_adapt_params", "SphAdaptParams")]:
         assert c_fields(c_name) == rust_fields(r_name), c_name
     # every SPH_F_* / enum constant the shim declares has the header's value
     for name, val in re.findall(r"pub const (SPH_\w+): (?:i32|u32|c_int) = (\d+);", rust):
