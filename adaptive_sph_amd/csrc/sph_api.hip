@@ -402,6 +402,8 @@ extern "C" int sph_create(uint64_t n_capacity, int device_id, const sph_plane* p
         return code;
     };
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return bail(SPH_ERR_DEVICE);
+    if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess) return bail(SPH_ERR_DEVICE);
+    if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess) return bail(SPH_ERR_DEVICE);
     for (auto& e : c->ev)
         if (hipEventCreate(&e) != hipSuccess) return bail(SPH_ERR_DEVICE);
     if (alloc_particle_buffers(c) != SPH_OK) return bail(SPH_ERR_DEVICE);
@@ -473,6 +475,7 @@ extern "C" void sph_destroy(sph_ctx* c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->stream2) (void)hipStreamSynchronize(c->stream2);
     dist_release(c);
     DevBuf* all[] = {&c->pm[0], &c->pm[1], &c->vel[0], &c->vel[1], &c->orig[0], &c->orig[1], &c->lvl[0], &c->lvl[1], &c->lvlold[0],
                      &c->lvlold[1], &c->vel_tmp, &c->key[0], &c->key[1], &c->val[0], &c->val[1], &c->sort_scratch, &c->cxy, &c->cell_start,
@@ -489,6 +492,8 @@ extern "C" void sph_destroy(sph_ctx* c)
         if (e) (void)hipEventDestroy(e);
     if (c->ev_sync) (void)hipEventDestroy(c->ev_sync);
     if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     delete c;
 }
 

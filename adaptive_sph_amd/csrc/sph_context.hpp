@@ -39,6 +39,9 @@ struct sph_ctx {
     int device = 0;
     uint64_t cap = 0, n = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;   // side stream: the level estimation before advection runs under the step's own sweeps
+    hipEvent_t ev_fork = nullptr;    // main -> side stream dependency
+    uint32_t level_seq = 0;          // sequence number of the side stream's publishes (lvl_changed[63])
     int n_planes = 0;
     BoundaryP bnd_h{};   // planes, or one Sdf2D polygon (sph_set_boundary_polygon)
     float time = 0.f;

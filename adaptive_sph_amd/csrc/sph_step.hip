@@ -1596,14 +1596,28 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
 
     // ---- level estimation on the extended-range lists (simulation.rs:2018-2046, 862-927; after advection: 2678-2707) ------
     LevelArgs lv{};
+    SweepArgs lv_args{};   // the arguments of a propagation queued on the side stream (level_estimation_finish)
     float lv_slack = 0.f;
     // `pm_old` == nullptr: the positions the particles are sorted by (before advection).  Else: `al.pm` holds the ADVECTED
     // positions, pm_old the pre-step ones, and the extended lists are gathered from the cells of the pre-step positions with
     // every search range widened by 2 x the largest displacement (TileP::slack).
-    auto level_estimation = [&](const float4* pm_geo, const float4* pm_old) -> int {
+    // `side`: detection and propagation are queued on the context's SECOND stream and the call returns without waiting
+    // (level estimation BEFORE advection: nothing of it is read until the smoothing at the end of the step, so the ~100
+    // latency-bound propagation sweeps run under the step's own sweeps); level_estimation_finish() collects it.
+    struct LevelPending {
+        bool on = false;
+        uint32_t t = 1, effective = 0;
+        int B = 8;
+    } lvp;
+    auto level_estimation = [&](const float4* pm_geo, const float4* pm_old, bool side) -> int {
         const auto t_lvl0 = std::chrono::steady_clock::now();
         Member& m = M[0];
         sph_ctx* c = m.c;
+        hipStream_t ls = side ? c->stream2 : c->stream;
+        if (side) {   // everything queued so far (sort, cell ranges, tile bounds) comes first
+            HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+            HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+        }
         const size_t n = m.n ? m.n : 1;
         HIPCHK(c, c->lvl_tmp.ensure(n * 4));
         HIPCHK(c, c->lvl_nrm.ensure(n * 8));
@@ -1650,8 +1664,8 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
         if (pm_old && m.n && lv.replay_step_lists) al.pm = pm_geo;
         if (pm_old && m.n && !lv.replay_step_lists) {
             al.pm = pm_geo;
-            launch_max_disp(c->stream, &c->prof, m.n, pm_old, pm_geo, chg + 1022);
-            HIPCHK(c, hipMemcpyAsync(c->lvl_changed, chg + 1022, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+            launch_max_disp(ls, &c->prof, m.n, pm_old, pm_geo, chg + 1022);
+            HIPCHK(c, hipMemcpyAsync(c->lvl_changed, chg + 1022, sizeof(uint32_t), hipMemcpyDeviceToHost, ls));
             if ((rc = wait_stream(c))) return rc;
             float dmax;
             memcpy(&dmax, (const void*)c->lvl_changed, 4);
@@ -1662,19 +1676,19 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
                 // a neighbour may now sit ceil((k h_max + slack) / tile side) tiles away
                 const float tile_side = (float)c->tile_ts * c->fgrid.cs;
                 const int d = (int)ceilf((lv.k * c->h_max_step + lv_slack) / tile_side);
-                launch_tile_redilate(c->stream, &c->prof, c->tile_tsx, c->tile_tsy, d < 1 ? 1 : d, c->tile_raw.as<uint32_t>(), c->tile_h_ext.as<uint32_t>());
+                launch_tile_redilate(ls, &c->prof, c->tile_tsx, c->tile_tsy, d < 1 ? 1 : d, c->tile_raw.as<uint32_t>(), c->tile_h_ext.as<uint32_t>());
             }
         }
         if (m.n) {
-            if (p->fill_stash_with == SPH_STASH_NONE) (void)hipMemsetAsync(c->stash.p, 0, n * 4, c->stream);
+            if (p->fill_stash_with == SPH_STASH_NONE) (void)hipMemsetAsync(c->stash.p, 0, n * 4, ls);
             // (the CenterDiff detector leaves flag_insufficient_neighs alone: its default, false)
-            if (lv.center_diff) (void)hipMemsetAsync(c->flag_insufficient.p, 0, n, c->stream);
-            launch_level_detect(c->stream, &c->prof, al, lv);
+            if (lv.center_diff) (void)hipMemsetAsync(c->flag_insufficient.p, 0, n, ls);
+            launch_level_detect(ls, &c->prof, al, lv);
             // propagate until a sweep assigns nothing (`while changed`, simulation.rs:740-800).  Sweeps are queued in batches and the
             // host learns once per batch how many of them assigned something (a sweep behind the last effective one has no
             // candidates and costs a scan).  The first batch is as long as the previous step's propagation + 1 -- the fluid's
             // depth hardly changes from step to step -- so a step usually waits once instead of once per 8 sweeps.
-            launch_level_propagate(c->stream, &c->prof, al, lv, 0u, chg + 1023);   // surface particles mark their neighbours
+            launch_level_propagate(ls, &c->prof, al, lv, 0u, chg + 1023);   // surface particles mark their neighbours
             uint32_t t = 1, effective = 0;
             int B = (int)std::min<uint32_t>(std::max<uint32_t>(c->last_level_sweeps + 1u, 8u), 1000u);
             static const bool batch8 = getenv("SPH_LEVEL_BATCH8") != nullptr;   // measurement aid: the fixed batches of 8
@@ -1682,23 +1696,60 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
             for (bool done = false; !done; B = 8) {
                 // the flags live in device memory (a store to mapped host memory from every assigning lane made each sweep
                 // wait for PCIe at its end); their sum goes to the host once per batch
-                (void)hipMemsetAsync(chg, 0, (size_t)B * sizeof(uint32_t), c->stream);
+                (void)hipMemsetAsync(chg, 0, (size_t)B * sizeof(uint32_t), ls);
                 for (int b = 0; b < B; b++, t++) {
-                    launch_level_propagate(c->stream, &c->prof, al, lv, t, chg + b);
+                    launch_level_propagate(ls, &c->prof, al, lv, t, chg + b);
                     if (t == 1u && p->fill_stash_with == SPH_STASH_SURFACE_DISTANCE_MIDDLE)   // num_iter == 1, simulation.rs:769-779
-                        launch_fill_stash(c->stream, &c->prof, al, lv, c->stash.as<float>());
+                        launch_fill_stash(ls, &c->prof, al, lv, c->stash.as<float>());
                 }
-                c->publish_seq++;
-                if (c->publish_seq == 0u) c->publish_seq = 1u;
-                hipLaunchKernelGGL(k_publish_count, dim3(1), dim3(64), 0, c->stream, chg, (uint32_t)B, c->lvl_changed_dev, 63u, c->publish_seq);
-                if ((rc = wait_word(c, (volatile uint32_t*)c->lvl_changed + 63, c->publish_seq))) return rc;
+                c->level_seq++;
+                if (c->level_seq == 0u) c->level_seq = 1u;
+                hipLaunchKernelGGL(k_publish_count, dim3(1), dim3(64), 0, ls, chg, (uint32_t)B, c->lvl_changed_dev, 63u, c->level_seq);
+                if (side) {   // collected by level_estimation_finish()
+                    lvp.on = true;
+                    lvp.t = t;
+                    lvp.B = B;
+                    lvp.effective = effective;
+                    lv_args = al;
+                    break;
+                }
+                if ((rc = wait_word(c, (volatile uint32_t*)c->lvl_changed + 63, c->level_seq))) return rc;
                 const uint32_t changed = c->lvl_changed[0];   // "nobody assigned anything" is final: the flags are ones, then zeros
                 effective += changed;
                 done = changed < (uint32_t)B;
             }
-            c->last_level_sweeps = effective;
+            if (!side) c->last_level_sweeps = effective;
         }
         c->have_level = true;
+        m.st.ms_level_estimation += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_lvl0).count();
+        return SPH_OK;
+    };
+    // the rest of a propagation that was queued on the side stream: wait for its first batch, continue in batches of 8 if the
+    // prediction (the previous step's sweep count + 1) fell short
+    auto level_estimation_finish = [&]() -> int {
+        if (!lvp.on) return SPH_OK;
+        lvp.on = false;
+        const auto t_lvl0 = std::chrono::steady_clock::now();
+        Member& m = M[0];
+        sph_ctx* c = m.c;
+        hipStream_t ls = c->stream2;
+        uint32_t* chg = c->lvl_changed_d.as<uint32_t>();
+        uint32_t t = lvp.t, effective = lvp.effective;
+        int B = lvp.B;
+        for (;;) {
+            if ((rc = wait_word(c, (volatile uint32_t*)c->lvl_changed + 63, c->level_seq))) return rc;
+            const uint32_t changed = c->lvl_changed[0];
+            effective += changed;
+            if (changed < (uint32_t)B) break;
+            B = 8;
+            (void)hipMemsetAsync(chg, 0, (size_t)B * sizeof(uint32_t), ls);
+            for (int b = 0; b < B; b++, t++) launch_level_propagate(ls, &c->prof, lv_args, lv, t, chg + b);
+            c->level_seq++;
+            if (c->level_seq == 0u) c->level_seq = 1u;
+            hipLaunchKernelGGL(k_publish_count, dim3(1), dim3(64), 0, ls, chg, (uint32_t)B, c->lvl_changed_dev, 63u, c->level_seq);
+        }
+        c->last_level_sweeps = effective;
+        // (the host saw the side stream's last publish: everything queued there has finished before the main stream goes on)
         m.st.ms_level_estimation += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_lvl0).count();
         return SPH_OK;
     };
@@ -1797,7 +1848,8 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
     if (level_on && G.multi()) {
         if ((rc = level_estimation_slabs())) return rc;
     } else if (level_on && !level_after) {
-        if ((rc = level_estimation(nullptr, nullptr))) return rc;
+        static const bool no_side = getenv("SPH_LEVEL_SERIAL") != nullptr;   // measurement aid: everything on one stream
+        if ((rc = level_estimation(nullptr, nullptr, !no_side))) return rc;
     } else if (!level_on) {
         for (auto& m : M) m.c->have_level = false;
     }
@@ -1985,9 +2037,10 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
     }
     if (level_after) {   // simulation.rs:2678-2707: lists of the advected positions, then detection + propagation there
         sph_ctx* c = M[0].c;
-        if ((rc = level_estimation(c->pm[c->pcur ^ 1].as<float4>(), c->pm[c->pcur].as<float4>()))) return rc;
+        if ((rc = level_estimation(c->pm[c->pcur ^ 1].as<float4>(), c->pm[c->pcur].as<float4>(), false))) return rc;
     }
     if (level_on && !G.multi()) {
+        if ((rc = level_estimation_finish())) return rc;   // (before advection: queued on the side stream at the start of the step)
         const auto t_lvl0 = std::chrono::steady_clock::now();
         Member& m = M[0];
         sph_ctx* c = m.c;
@@ -2046,6 +2099,8 @@ static int group_step(Group& G, const sph_params* p, sph_step_stats* outs)
         for (auto c : G.m) {
             c->poisoned = true;
             c->hdr_ahead = false;
+            (void)hipSetDevice(c->device);
+            if (c->stream2) (void)hipStreamSynchronize(c->stream2);   // a level estimation may still be running on the side stream
         }
     return rc;
 }

@@ -53,7 +53,9 @@ PMC_NAMES = {"density": "OpDensity[build]", "aii_constfield": "OpAiiConst", "non
 def committed_pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the newest committed rocprofv3 --pmc summary (FETCH_SIZE and
     WRITE_SIZE are collected in their own passes, outside bench.py: scripts/summarize_profile.py)."""
-    files = sorted((REPO / "profiles").glob("*_kernel_summary.json"))
+    import re
+    # profiles/<round>_kernel_summary.json = configs[1] (the other configs carry their name: r2a_dam_break_8m_kernel_summary.json)
+    files = sorted(f for f in (REPO / "profiles").glob("*_kernel_summary.json") if re.fullmatch(r"r\d+[a-z]?_kernel_summary\.json", f.name))
     if not files or kernel not in PMC_NAMES:
         return None, None
     try:
@@ -295,7 +297,9 @@ def main():
             k["achieved_GBs"] = r["achieved"]
             k["frac_hbm_peak"] = r["frac"]
         kernels.append(k)
-    dominant = next((k["name"] for k in kernels if k["name"] in ALGO_BYTES), None)
+    # the dominant kernel: largest total time of the launches that did WORK (speculative launches behind the stop decision are
+    # event overhead, not sweeps)
+    dominant = max((n for n in prof_work if n in ALGO_BYTES), key=lambda n: prof_work[n][1], default=None)
     roofline = roof(dominant, *prof_work[dominant]) if dominant else None
     roofline_density = roof("density", *prof_work["density"]) if "density" in prof_work else None
     timing_note = (f"HIP events on the library's stream, instrumented pass of {args.profile_steps} steps continuing the same "

@@ -91,7 +91,7 @@ void oracle_destroy(oracle_ctx* c)
     free(c->pressure); free(c->pressure_next); free(c->aii); free(c->density_error); free(c->h2); free(c->h2_next); free(c->omega);
     free(c->level); free(c->level_tmp); free(c->level_old); free(c->constant_field); free(c->stash);
     free(c->flag_surface); free(c->flag_insufficient); free(c->size_class); free(c->flag_reduced); free(c->neighbor_count); free(c->lam_n);
-    free(c->lam); free(c->lam_gx); free(c->lam_gy); free(c->nb_off); free(c->nb_idx); free(c->cell_index);
+    free(c->lam); free(c->lam_gx); free(c->lam_gy); free(c->nb_off); free(c->nb_idx); free(c->nb_idx2); free(c->cell_index);
     free(c);
 }
 

@@ -247,11 +247,16 @@ void orc_filter_down(oracle_ctx* c, float k)
     const float* h = c->h2;
     if (n == 0) return;
     /* retain() per list, order kept: survivors are counted, offsets re-summed, then written to a second buffer */
+    /* the second index buffer is kept across steps (fresh pages every step cost more than the filter itself) */
+    if (c->nb_cap2 < c->nb_cap) {
+        free(c->nb_idx2);
+        c->nb_idx2 = (uint32_t*)malloc((c->nb_cap ? c->nb_cap : 1) * sizeof(uint32_t));
+        c->nb_cap2 = c->nb_idx2 ? c->nb_cap : 0;
+    }
     uint64_t* keep = (uint64_t*)malloc((n + 1) * sizeof(uint64_t));
-    uint32_t* out = (uint32_t*)malloc((c->nb_cap ? c->nb_cap : 1) * sizeof(uint32_t));
+    uint32_t* out = c->nb_idx2;
     if (!keep || !out) {   /* out of memory: the sequential in-place form */
         free(keep);
-        free(out);
         uint64_t w = 0;
         for (uint64_t i = 0; i < n; i++) {
             uint64_t b = c->nb_off[i], e = c->nb_off[i + 1];
@@ -292,7 +297,8 @@ void orc_filter_down(oracle_ctx* c, float k)
         }
     }
     memcpy(c->nb_off, keep, (n + 1) * sizeof(uint64_t));
-    free(c->nb_idx);
+    c->nb_idx2 = c->nb_idx;   /* ping-pong: both buffers hold nb_cap entries */
+    c->nb_cap2 = c->nb_cap;
     c->nb_idx = out;
     free(keep);
 }

@@ -52,6 +52,8 @@ typedef struct oracle_ctx {
     uint64_t* nb_off;
     uint32_t* nb_idx;
     uint64_t nb_cap;
+    uint32_t* nb_idx2; /* orc_filter_down's second buffer */
+    uint64_t nb_cap2;
 
     sph_grid_info grid;
     uint32_t* cell_index;
