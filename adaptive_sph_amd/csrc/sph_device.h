@@ -94,6 +94,43 @@ __device__ __forceinline__ float cubic_unnorm_deriv(float q)
     return q < 0.5f ? a : (q < 1.f ? b : 0.f);
 }
 
+// Variant switches of the FAST / UNIFORM pair values (scripts/variants; EXACT is never touched):
+//   SPH_PAIR_FMA   contraction allowed inside the kernel-gradient / kernel-value functions and the ops' pair() bodies
+//   SPH_PAIR_TP    cubic spline and its derivative in truncated-power form, no selects:
+//                  W(q) = 2 [ (1-q)+^3 - 4 (1/2-q)+^3 ],  W'(q) = 6 [ 4 (1/2-q)+^2 - (1-q)+^2 ]
+#ifndef SPH_PAIR_FMA
+#define SPH_PAIR_FMA 0
+#endif
+#ifndef SPH_PAIR_TP
+#define SPH_PAIR_TP 0
+#endif
+#if SPH_PAIR_FMA
+#define SPH_PAIR_CONTRACT _Pragma("clang fp contract(fast)")
+#else
+#define SPH_PAIR_CONTRACT
+#endif
+
+__device__ __forceinline__ float cubic_fast(float q)
+{
+#if SPH_PAIR_TP
+    SPH_PAIR_CONTRACT
+    const float u = fmaxf(1.f - q, 0.f), t = fmaxf(0.5f - q, 0.f);
+    return 2.f * (u * u * u - 4.f * (t * t * t));
+#else
+    return cubic_unnorm(q);
+#endif
+}
+__device__ __forceinline__ float cubic_deriv_fast(float q)
+{
+#if SPH_PAIR_TP
+    SPH_PAIR_CONTRACT
+    const float u = fmaxf(1.f - q, 0.f), t = fmaxf(0.5f - q, 0.f);
+    return 6.f * (4.f * (t * t) - u * u);
+#else
+    return cubic_unnorm_deriv(q);
+#endif
+}
+
 // Math policies.  EXACT: IEEE division / sqrt in the reference's operation order.  FAST: hardware
 // v_rcp_f32 / v_rsq_f32 / v_sqrt_f32 (1 ulp).  UNIFORM: FAST with every h_ij == h (all particles
 // carry the bit-identical smoothing length), so the normalisation and 1/(2h) are launch constants.
@@ -123,18 +160,20 @@ struct MathFast {
     float h;  // unused
     __device__ __forceinline__ float w(float r2, float hij) const
     {
+        SPH_PAIR_CONTRACT
         float r = fast_sqrt(r2);
         float nf = 10.f * fast_rcp(SPH_SEVEN_PI * (hij * hij));
-        return nf * cubic_unnorm(r * fast_rcp(2.f * hij));
+        return nf * cubic_fast(r * fast_rcp(2.f * hij));
     }
     __device__ __forceinline__ void grad(float dx, float dy, float r2, float hij, float& gx, float& gy) const
     {
+        SPH_PAIR_CONTRACT
         float rinv = fast_rsq(r2);
         float r = r2 * rinv;
         float inv2h = fast_rcp(2.f * hij);
         float q = r * inv2h;
         float nf = 10.f * fast_rcp(SPH_SEVEN_PI * (hij * hij));
-        float s = nf * cubic_unnorm_deriv(q) * inv2h * rinv;
+        float s = nf * cubic_deriv_fast(q) * inv2h * rinv;
         s = (q > 1.0e-5f) ? s : 0.f;  // also covers r2 == 0 (rinv = inf, r = nan)
         gx = s * dx;
         gy = s * dy;
@@ -143,12 +182,13 @@ struct MathFast {
 struct MathUniform {
     static constexpr bool EXACT = false, UNIFORM = true;
     float h, nf, inv2h;
-    __device__ __forceinline__ float w(float r2, float) const { return nf * cubic_unnorm(fast_sqrt(r2) * inv2h); }
+    __device__ __forceinline__ float w(float r2, float) const { return nf * cubic_fast(fast_sqrt(r2) * inv2h); }
     __device__ __forceinline__ void grad(float dx, float dy, float r2, float, float& gx, float& gy) const
     {
+        SPH_PAIR_CONTRACT
         float rinv = fast_rsq(r2);
         float q = (r2 * rinv) * inv2h;
-        float s = nf * cubic_unnorm_deriv(q) * inv2h * rinv;
+        float s = nf * cubic_deriv_fast(q) * inv2h * rinv;
         s = (q > 1.0e-5f) ? s : 0.f;
         gx = s * dx;
         gy = s * dy;

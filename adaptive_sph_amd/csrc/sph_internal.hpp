@@ -158,6 +158,7 @@ struct SweepArgs {
 
 size_t sweep_list_bytes(uint32_t n);
 size_t sweep_index_list_bytes(uint32_t n);   // explicit index lists (multi-resolution scenes)
+bool sweep_forces_index_lists();             // build variant SPH_FORCE_IDX
 uint32_t solver_reduce_blocks(uint32_t n);
 void launch_density(hipStream_t s, Profiler* prof, const SweepArgs& a);
 void launch_density_replay(hipStream_t s, Profiler* prof, const SweepArgs& a);

@@ -1572,7 +1572,7 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
             launch_tile_hmax(s, prof, n, c->pm[c->pcur].as<float4>(), g, c->tile_ts, c->tile_tsx, c->tile_tsy, c->tile_raw.as<uint32_t>(),
                              c->tile_h.as<uint32_t>(), want_ext ? c->tile_h_ext.as<uint32_t>() : nullptr, d_ext);
         }
-        if (c->exact || !c->uniform_h) HIPCHK(c, c->nlx.ensure(sweep_index_list_bytes(n ? n : 1)));
+        if (c->exact || !c->uniform_h || sweep_forces_index_lists()) HIPCHK(c, c->nlx.ensure(sweep_index_list_bytes(n ? n : 1)));
         if (c->dist.on) {
             auto& d = c->dist;
             if (n)

@@ -41,6 +41,9 @@
 #ifndef SPH_TILE_DEFAULT
 #define SPH_TILE_DEFAULT 0
 #endif
+#ifndef SPH_FORCE_IDX
+#define SPH_FORCE_IDX 0
+#endif
 
 // Neighbour list word (one uint4 = 16 B per particle, coalesced 1 KB per wave):
 //   x, y, z : accepted-candidate bit masks of the three cell rows cy-1, cy, cy+1.  Bit b of row r
@@ -99,18 +102,37 @@ __device__ __forceinline__ void raise_error(DeviceStatus* st, uint32_t code, uin
 // in LDS (random ds_read_b128 costs what the L1 gathers cost, and the LDS cuts occupancy: Jacobi 38.9 vs 28.5 us);
 // flattening the three rows into one batch loop; FMA / packed-f32 pair math (fewer VALU instructions, same time).
 // ------------------------------------------------------------------------------------------------
+// SPH_DBG_NOGATHER (measurement only, results are garbage): every lane "gathers" one of the first 64 records, i.e. the loads
+// cost what a broadcast costs -- what is left of a sweep's time is its instruction issue
+#ifdef SPH_DBG_NOGATHER
+#define SPH_GIDX(J) ((J) & 63u)
+#else
+#define SPH_GIDX(J) (J)
+#endif
+// SPH_DBG_NOMATH (measurement only): the pair bodies are never executed (r2 is never negative) -- what is left is the loop
+// skeleton, the mask decoding and the position gathers
+#ifdef SPH_DBG_NOMATH
+#define SPH_DBG_PAIR_GATE &&r2 < -1.f
+#else
+#define SPH_DBG_PAIR_GATE
+#endif
 #define SPH_FETCH(J, AOUT, NOUT)                                                          \
-    const float4 AOUT = op.loadA(J);                                                      \
-    const typename Op::NB NOUT = op.nb(acc, J, AOUT);
+    const float4 AOUT = op.loadA(SPH_GIDX(J));                                            \
+    const typename Op::NB NOUT = op.nb(acc, SPH_GIDX(J), AOUT);
 #define SPH_PAIR(AJ, NJ, ON)                                                              \
     {                                                                                     \
         const float dx = Ai.x - AJ.x, dy = Ai.y - AJ.y;                                   \
         const float r2 = dx * dx + dy * dy;                                               \
         const float hij = Math::UNIFORM ? op.m.h : (Ai.w + AJ.w) * 0.5f;                  \
-        if (ON) op.pair(acc, AJ, NJ, dx, dy, r2, hij);                                    \
+        if ((ON)SPH_DBG_PAIR_GATE) op.pair(acc, AJ, NJ, dx, dy, r2, hij);                 \
     }
 
-// ---- list replay, row masks: per row up to 4 set bits per trip (4 independent fetches in flight) ----------
+// ---- list replay, row masks: per row up to SPH_TRIP set bits per trip (that many independent fetches in flight) ----------
+// A wave runs a trip as long as ANY of its lanes has bits left in the row, and every trip issues SPH_TRIP pair slots for all
+// lanes: with 3-6 neighbours per row and lane, trips of 4 execute 8 slots per row where trips of 2 execute 6.
+#ifndef SPH_TRIP
+#define SPH_TRIP 4
+#endif
 template <class Op>
 __device__ __forceinline__ void replay_masks(const Op& op, typename Op::Acc& acc, const float4 Ai, const uint32_t (&rb)[3], const uint4 lw)
 {
@@ -126,6 +148,7 @@ __device__ __forceinline__ void replay_masks(const Op& op, typename Op::Acc& acc
             const bool v1 = mk != 0;
             const uint32_t b1 = v1 ? __ffs(mk) - 1 : b0;
             mk &= mk - 1;
+#if SPH_TRIP == 4
             const bool v2 = mk != 0;
             const uint32_t b2 = v2 ? __ffs(mk) - 1 : b0;
             mk &= mk - 1;
@@ -141,6 +164,13 @@ __device__ __forceinline__ void replay_masks(const Op& op, typename Op::Acc& acc
             SPH_PAIR(A1, N1, v1)
             SPH_PAIR(A2, N2, v2)
             SPH_PAIR(A3, N3, v3)
+#else
+            const uint32_t j0 = base + b0, j1 = base + b1;
+            SPH_FETCH(j0, A0, N0)
+            SPH_FETCH(j1, A1, N1)
+            SPH_PAIR(A0, N0, true)
+            SPH_PAIR(A1, N1, v1)
+#endif
         }
     }
 }
@@ -186,6 +216,9 @@ struct IdxRecorder {
 
 // one row of the candidate walk: exact reference predicate, 4 candidates per trip.  MASKS: accepted candidates set
 // bits of `mk` (bit = j - b); REC: accepted candidates are appended to the explicit index list.
+#define SPH_FETCH_W(J, AOUT, NOUT)                                                        \
+    const float4 AOUT = op.loadA(J);                                                      \
+    const typename Op::NB NOUT = op.nb(acc, J, AOUT);
 template <class Op, bool MASKS, bool REC>
 __device__ __forceinline__ void walk_row(const Op& op, typename Op::Acc& acc, const float4 Ai, const uint32_t b, const uint32_t e, uint32_t& mk,
                                          uint32_t& nacc, IdxRecorder& rec, uint4* __restrict__ nlx, const uint32_t n, const uint32_t i)
@@ -194,10 +227,10 @@ __device__ __forceinline__ void walk_row(const Op& op, typename Op::Acc& acc, co
     for (uint32_t j = b; j < e; j += 4) {
         const bool v1 = j + 1 < e, v2 = j + 2 < e, v3 = j + 3 < e;
         const uint32_t j1 = v1 ? j + 1 : j, j2 = v2 ? j + 2 : j, j3 = v3 ? j + 3 : j;
-        SPH_FETCH(j, A0, N0)
-        SPH_FETCH(j1, A1, N1)
-        SPH_FETCH(j2, A2, N2)
-        SPH_FETCH(j3, A3, N3)
+        SPH_FETCH_W(j, A0, N0)
+        SPH_FETCH_W(j1, A1, N1)
+        SPH_FETCH_W(j2, A2, N2)
+        SPH_FETCH_W(j3, A3, N3)
 #define SPH_CAND(JJ, AJ, NJ, VALID)                                                       \
     {                                                                                     \
         /* neighbour predicate, exactly the reference's operations (no FMA, strict <) */  \
@@ -222,6 +255,7 @@ __device__ __forceinline__ void walk_row(const Op& op, typename Op::Acc& acc, co
 #undef SPH_CAND
     }
 }
+#undef SPH_FETCH_W
 #undef SPH_FETCH
 #undef SPH_PAIR
 
@@ -273,7 +307,9 @@ __device__ __forceinline__ void sweep_particle(const Op& op, const SweepCommon& 
     if (!BUILD) lw = c.nl[i];
     op.begin(acc, i, Ai);
     // explicit index lists exist in multi-resolution scenes and for the extended-range lists of the level estimation
-    constexpr bool IDX = !Math::UNIFORM || Op::EXTENDED;
+    // SPH_FORCE_IDX (variant): explicit index lists in uniform scenes too -- no mask decoding per neighbour slot, one more coalesced
+    // 16-byte load per 4 neighbours
+    constexpr bool IDX = !Math::UNIFORM || Op::EXTENDED || SPH_FORCE_IDX;
     if (!BUILD && IDX && (lw.w & NL_IDX)) {
         replay_indices(op, acc, Ai, i, lw.w & 0xffffu, c.nlx, c.n);
     } else {
@@ -312,7 +348,7 @@ __device__ __forceinline__ void sweep_particle(const Op& op, const SweepCommon& 
                 uint32_t mk[3] = {0u, 0u, 0u}, nacc = 0;
                 IdxRecorder rec;
                 rec.cur = make_uint4(0, 0, 0, 0);
-                const bool rec_idx = BUILD && IDX && !ok_list;
+                const bool rec_idx = BUILD && IDX && (!ok_list || (SPH_FORCE_IDX && !Op::EXTENDED));
                 if (rec_idx) {
 #pragma unroll
                     for (int dr = 0; dr < 3; dr++) walk_row<Op, false, true>(op, acc, Ai, rb[dr], re[dr], mk[dr], nacc, rec, c.nlx, c.n, i);
@@ -702,6 +738,7 @@ struct OpAiiConst {
     __device__ void begin(Acc& a, uint32_t, float4) const { a.cf = a.ax = a.ay = a.a2 = a.bx = a.by = 0.f; }
     __device__ void pair(Acc& a, float4 Aj, NB mr, float dx, float dy, float r2, float hij) const
     {
+        SPH_PAIR_CONTRACT
         a.cf += mr * m.w(r2, hij);
         float gx, gy;
         m.grad(dx, dy, r2, hij, gx, gy);
@@ -802,6 +839,7 @@ struct OpNonPressure {
     }
     __device__ void pair(Acc& a, float4 Aj, NB Bj, float dx, float dy, float r2, float hij) const
     {
+        SPH_PAIR_CONTRACT
         const float ux = a.vix - Bj.vx, uy = a.viy - Bj.vy;
         if (sp.viscosity_type == SPH_VISC_APPROX_LAPLACE) {
             const float xv = dx * ux + dy * uy;
@@ -967,6 +1005,7 @@ struct OpSource {
     }
     __device__ void pair(Acc& a, float4 Aj, NB Bj, float dx, float dy, float r2, float hij) const
     {
+        SPH_PAIR_CONTRACT
         if (OMEGA && !a.large) a.om += a.om_c * Aj.z * dwdh(sqrtf(r2), hij * 2.f);   // simulation.rs:2289-2305
         if (kind == 2) return;
         float gx, gy;
@@ -1220,6 +1259,7 @@ struct OpPressureAccel {
     }
     __device__ void pair(Acc& a, float4 Aj, NB ptj, float dx, float dy, float r2, float hij) const
     {
+        SPH_PAIR_CONTRACT
         float gx, gy;
         m.grad(dx, dy, r2, hij, gx, gy);
         const float f = -Aj.z * (a.p1t + ptj);
@@ -1385,6 +1425,7 @@ struct OpJacobi {
     }
     __device__ void pair(Acc& a, float4 Aj, NB Bj, float dx, float dy, float r2, float hij) const
     {
+        SPH_PAIR_CONTRACT
         float gx, gy;
         m.grad(dx, dy, r2, hij, gx, gy);
         const float dot = (Bj.qx - a.qx) * gx + (Bj.qy - a.qy) * gy;
@@ -2225,6 +2266,7 @@ static void launch_sweep(hipStream_t s, const SweepArgs& a, const Op& op)
 
 size_t sweep_list_bytes(uint32_t n) { return (size_t)n * sizeof(uint4); }
 size_t sweep_index_list_bytes(uint32_t n) { return (size_t)n * sizeof(uint4) * NLX_GROUPS; }
+bool sweep_forces_index_lists() { return SPH_FORCE_IDX != 0; }
 uint32_t solver_reduce_blocks(uint32_t n) { return (n + SWEEP_THREADS - 1) / SWEEP_THREADS; }
 
 static MathUniform uniform_math(float h)
