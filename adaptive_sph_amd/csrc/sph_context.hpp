@@ -84,6 +84,13 @@ struct sph_ctx {
         bool have_flags = false;     // `owned` describes the current arrays (after a step)
         uint32_t n_halo[2] = {0, 0}, n_ghost[2] = {0, 0};   // [left, right]
         DevBuf owned;                // u8 per slot: 1 owned, 0 ghost
+        // fused refresh (sph_step.hip, slab_refresh_fused): class byte per slot of the previous step's arrays, per-block class
+        // counts / offsets; `pre_*` describe the arrays between the refresh and the cell sort, which drops the slots that left
+        DevBuf cls, blk;
+        bool pre = false;            // the arrays still hold slots that left this rank (class >= SC_GONE_FROM in cls[0 .. pre_cls_n))
+        uint32_t pre_n = 0;          // slots in the arrays before the cell sort (live + gone)
+        uint32_t pre_cls_n = 0;      // slots cls describes (the previous step's arrays)
+        uint32_t pre_own = 0;        // pre-sort slots below this index are owned (if live), the ghosts follow
         DevBuf ring1, ring1_src;     // u8 per slot / per ghost ordinal: ghost within one support radius of the cut
         DevBuf halo_idx, halo_pos, halo_src, ghost_dst;      // index lists / maps (u32)
         DevBuf send[2], recv[2];     // staging, [left, right]

@@ -219,23 +219,32 @@ int radix_sort_pairs(hipStream_t s, Profiler* prof, uint32_t* keyA, uint32_t* va
 // ------------------------------------------------------------------------------------------------
 // cell keys / reorder / cell-range table / tiles
 // ------------------------------------------------------------------------------------------------
+// `gone` (slab decomposition, optional): slots [0, n_gone) whose class byte is >= gone_from left this rank's arrays (last step's
+// ghosts, particles handed to a neighbour).  They get the key `ncells`, one past the last cell: the sort moves them behind
+// the live particles and nothing after it looks at them -- the compaction of the arrays rides in the cell sort.
 __global__ __launch_bounds__(256) void k_cell_keys(const float4* __restrict__ pm, uint32_t n, GridP g, uint32_t* __restrict__ key,
-                                                    uint32_t* __restrict__ val)
+                                                    uint32_t* __restrict__ val, const uint8_t* __restrict__ gone, uint32_t n_gone,
+                                                    uint32_t gone_from)
 {
     uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
+    val[i] = i;
+    if (gone && i < n_gone && gone[i] >= gone_from) {
+        key[i] = g.ncells;
+        return;
+    }
     float4 p = pm[i];
     // IEEE division, like `(particle_pos / kernel_support_radius).map(|x| x.floor() as i32)`
     int cx = (int)floorf(p.x / g.cs) - g.minx;
     int cy = (int)floorf(p.y / g.cs) - g.miny;
     key[i] = (uint32_t)cx + (uint32_t)cy * (uint32_t)g.sx;
-    val[i] = i;
 }
 
-void launch_cell_keys(hipStream_t s, Profiler* prof, const float4* pm, uint32_t n, GridP g, uint32_t* key, uint32_t* val)
+void launch_cell_keys(hipStream_t s, Profiler* prof, const float4* pm, uint32_t n, GridP g, uint32_t* key, uint32_t* val,
+                      const uint8_t* gone, uint32_t n_gone, uint32_t gone_from)
 {
     ProfScope ps(prof, "cell_keys", s);
-    hipLaunchKernelGGL(k_cell_keys, dim3((n + 255) / 256), dim3(256), 0, s, pm, n, g, key, val);
+    hipLaunchKernelGGL(k_cell_keys, dim3((n + 255) / 256), dim3(256), 0, s, pm, n, g, key, val, gone, n_gone, gone_from);
 }
 
 __global__ __launch_bounds__(256) void k_reorder(uint32_t n, GridP g, const uint32_t* __restrict__ sorted_key,

@@ -446,6 +446,147 @@ __global__ __launch_bounds__(256) void k_ghost_mrho(const uint32_t* __restrict__
     mrho[i] = pm[i].z / rho[i];
 }
 
+// ------------------------------------------------------------------------------------------------
+// The fused slab refresh (ordinary steps; slab_refresh_fused below): ONE pass classifies every slot of the previous step's
+// arrays, ONE round trip carries the four counts, nothing is reordered -- the slots that left are dropped by the cell sort.
+//   0 stays, interior   1 stays, within halo_w of the left cut   2 stays, within halo_w of the right cut
+//   3 migrates left     4 migrates right                          5 ghost of the previous step
+// A migrant is by construction a member of its receiver's halo towards the sender (it is within one step's displacement of the
+// cut), so the receiver's ghost-record count is known without a second round trip: `bad` = a migrant that the receiver's own
+// halo test would reject, or a particle in both halos (slab narrower than two ghost layers) -> the general path takes over.
+// ------------------------------------------------------------------------------------------------
+enum { SC_STAY = 0, SC_HALO_L = 1, SC_HALO_R = 2, SC_MIG_L = 3, SC_MIG_R = 4, SC_GHOST = 5, SC_GONE_FROM = 3 };
+__global__ __launch_bounds__(256) void k_slab_classify(uint32_t n, const float4* __restrict__ pm, const uint8_t* __restrict__ owned, float cut_lo,
+                                                        float cut_hi, float halo_w, int has_left, int has_right, uint8_t* __restrict__ cls,
+                                                        uint32_t* __restrict__ blk_cnt, uint32_t* __restrict__ flags)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    uint32_t c = 7u;
+    bool bad = false;
+    if (i < n) {
+        const float x = pm[i].x;
+        if (owned && !owned[i]) c = SC_GHOST;
+        else if (has_left && x < cut_lo) {
+            c = SC_MIG_L;
+            bad = x < cut_lo - halo_w;          // the left rank's halo test is !(x < its cut_hi - halo_w), its cut_hi == my cut_lo
+        } else if (has_right && !(x < cut_hi)) {
+            c = SC_MIG_R;
+            bad = !(x < cut_hi + halo_w);       // the right rank's: x < its cut_lo + halo_w
+        } else {
+            const bool l = has_left && x < cut_lo + halo_w, r = has_right && !(x < cut_hi - halo_w);
+            bad = l && r;
+            c = l ? SC_HALO_L : (r ? SC_HALO_R : SC_STAY);
+        }
+        cls[i] = (uint8_t)c;
+    }
+    __shared__ uint32_t s_cnt[4][4];   // [wave][class - 1]
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+#pragma unroll
+    for (uint32_t k = 1; k <= 4; k++) {
+        const uint64_t m = __ballot(c == k);
+        if (lane == 0) s_cnt[wave][k - 1] = (uint32_t)__popcll(m);
+    }
+    if (__ballot(bad) != 0ull && lane == 0) atomicOr(flags, 1u);
+    __syncthreads();
+    if (threadIdx.x < 4) blk_cnt[blockIdx.x * 4 + threadIdx.x] = s_cnt[0][threadIdx.x] + s_cnt[1][threadIdx.x] + s_cnt[2][threadIdx.x] + s_cnt[3][threadIdx.x];
+}
+
+// exclusive scan of the per-block class counts (4 classes) over the blocks, one 1024-thread block: thread t owns a contiguous
+// run of blocks.  counts[0 .. 3] = totals of classes 1 .. 4, counts[4] = the bad flag
+__global__ __launch_bounds__(1024) void k_slab_scan(uint32_t nb, const uint32_t* __restrict__ blk_cnt, uint32_t* __restrict__ blk_off,
+                                                     uint32_t* __restrict__ counts, const uint32_t* __restrict__ flags)
+{
+    __shared__ uint32_t s_wave[16][4];
+    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    const uint32_t per = (nb + 1023u) / 1024u;
+    const uint32_t b0 = min(nb, t * per), b1 = min(nb, b0 + per);
+    uint32_t sum[4] = {0u, 0u, 0u, 0u};
+    for (uint32_t b = b0; b < b1; b++)
+        for (int k = 0; k < 4; k++) sum[k] += blk_cnt[b * 4 + k];
+    uint32_t inc[4];
+    for (int k = 0; k < 4; k++) {
+        uint32_t v = sum[k];
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t u = __shfl_up(v, d);
+            if ((int)lane >= d) v += u;
+        }
+        inc[k] = v;
+        if (lane == 63u) s_wave[wave][k] = v;
+    }
+    __syncthreads();
+    uint32_t run[4];
+    for (int k = 0; k < 4; k++) {
+        uint32_t base = 0;
+        for (uint32_t w = 0; w < wave; w++) base += s_wave[w][k];
+        run[k] = base + inc[k] - sum[k];
+    }
+    for (uint32_t b = b0; b < b1; b++)
+        for (int k = 0; k < 4; k++) {
+            blk_off[b * 4 + k] = run[k];
+            run[k] += blk_cnt[b * 4 + k];
+        }
+    if (t == 1023u) {
+        for (int k = 0; k < 4; k++) counts[k] = run[k];
+        counts[4] = flags[0];
+    }
+}
+
+// pass 2: migrant records and the halo index lists, in slot order (deterministic: the same arrays give the same order)
+__global__ __launch_bounds__(256) void k_slab_pack(uint32_t n, const uint8_t* __restrict__ cls, const uint32_t* __restrict__ blk_off,
+                                                    const float4* __restrict__ pm, const float2* __restrict__ vel, const uint32_t* __restrict__ orig,
+                                                    const float* __restrict__ lvl, const float* __restrict__ lvlold, const float* __restrict__ h2n,
+                                                    const float* __restrict__ lam_sum, const uint8_t* __restrict__ szc, float* __restrict__ send_l,
+                                                    float* __restrict__ send_r, uint32_t* __restrict__ halo_idx, uint32_t halo_r_base)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t c = i < n ? (uint32_t)cls[i] : 7u;
+    __shared__ uint32_t s_cnt[4][4];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    uint32_t my_rank = 0;
+#pragma unroll
+    for (uint32_t k = 1; k <= 4; k++) {
+        const uint64_t m = __ballot(c == k);
+        if (lane == 0) s_cnt[wave][k - 1] = (uint32_t)__popcll(m);
+        if (c == k) my_rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    }
+    __syncthreads();
+    if (c < 1u || c > 4u) return;
+    uint32_t pos = blk_off[blockIdx.x * 4 + (c - 1u)] + my_rank;
+    for (uint32_t w = 0; w < wave; w++) pos += s_cnt[w][c - 1u];
+    if (c == SC_HALO_L) halo_idx[pos] = i;
+    else if (c == SC_HALO_R) halo_idx[halo_r_base + pos] = i;
+    else {
+        const float4 p = pm[i];
+        const float2 v = vel[i];
+        float* r = (c == SC_MIG_L ? send_l : send_r) + (size_t)pos * MIG_WORDS;
+        r[0] = p.x; r[1] = p.y; r[2] = p.z; r[3] = p.w; r[4] = v.x; r[5] = v.y;
+        r[6] = __uint_as_float(orig[i]);
+        r[7] = lvl[i];
+        r[8] = lvlold[i];
+        r[9] = h2n[i];
+        r[10] = lam_sum[i];
+        r[11] = __uint_as_float((uint32_t)szc[i]);
+    }
+}
+__global__ __launch_bounds__(256) void k_iota_u32(uint32_t* __restrict__ out, uint32_t cnt, uint32_t first)
+{
+    const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+    if (k < cnt) out[k] = first + k;
+}
+// refresh_round (RCCL): out[0 .. 1] = (migrants, halo members) for the left neighbour, out[2 .. 3] for the right one, out[4] = status,
+// out[5] = "take the general path", out[6 .. 9] = 0 (received below)
+__global__ void k_refresh_stage(const uint32_t* __restrict__ counts, uint32_t* __restrict__ out, uint32_t status_in, uint32_t fallback_in)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    out[0] = counts[2];   // SC_MIG_L
+    out[1] = counts[0];   // SC_HALO_L
+    out[2] = counts[3];   // SC_MIG_R
+    out[3] = counts[1];   // SC_HALO_R
+    out[4] = status_in;
+    out[5] = (fallback_in || counts[4]) ? 1u : 0u;
+    out[6] = out[7] = out[8] = out[9] = 0u;
+}
+
 __global__ void k_fill_u8(uint8_t* p, uint32_t n, uint8_t v)
 {
     uint32_t i = blockIdx.x * 256 + threadIdx.x;
@@ -485,6 +626,11 @@ struct Xfer {
     size_t recv_bytes[2];
 };
 
+struct RefreshCounts {
+    uint32_t mig[2], halo[2];         // this rank: migrants to / halo members (that stay) towards [left, right]
+    uint32_t in_mig[2], in_halo[2];   // the neighbours': migrants for me / their halo members towards me, from [left, right]
+};
+
 struct Comm {
     virtual ~Comm() {}
     // reduce k host values per member element-wise over ALL ranks; every member's row receives the result
@@ -507,6 +653,9 @@ struct Comm {
     // SPH_ERR_UNSUPPORTED if this rank's class-3 count of the halo phase (base 4) is non-zero (slab narrower than two ghost layers).
     virtual int counts_round(Group& G, int base, std::vector<std::vector<float>>* red, int* status, std::vector<uint32_t>& to_left,
                              std::vector<uint32_t>& to_right, std::vector<uint32_t>& from_left, std::vector<uint32_t>& from_right) = 0;
+    // ONE round trip of the fused refresh: the class totals k_slab_scan left in dist.counts[0 .. 4] reach the host, the x-neighbours'
+    // (migrants, halo members) arrive, `red` is min-reduced and `status` / `fallback` are max-reduced over ALL ranks
+    virtual int refresh_round(Group& G, std::vector<std::vector<float>>* red, int* status, int* fallback, std::vector<RefreshCounts>& rc) = 0;
     // queued, no wait: the maximum over all ranks of the device-side guard word lands in every rank's ctrl->peer_error, which the
     // next publish brings to the host (the step's one agreement on the guards, without a round trip of its own)
     virtual int agree_guards_queued(Group& G) = 0;
@@ -615,6 +764,32 @@ struct LocalComm : Comm {
         }
         if (red) allreduce_min_f32(G, *red);
         return neighbour_counts(G, tl, tr, fl, fr, nullptr);
+    }
+    int refresh_round(Group& G, std::vector<std::vector<float>>* red, int* status, int* fallback, std::vector<RefreshCounts>& rcs) override
+    {
+        (void)status;   // one process: its own status is the maximum
+        int rc = wait_all(G);
+        if (rc) return rc;
+        const size_t n = G.m.size();
+        for (size_t i = 0; i < n; i++) {
+            sph_ctx* c = G.m[i];
+            HIPCHK(c, hipSetDevice(c->device));
+            uint32_t w[5];
+            HIPCHK(c, hipMemcpy(w, c->dist.counts.p, 20, hipMemcpyDeviceToHost));
+            rcs[i].halo[0] = w[0];
+            rcs[i].halo[1] = w[1];
+            rcs[i].mig[0] = w[2];
+            rcs[i].mig[1] = w[3];
+            if (w[4]) *fallback = 1;
+        }
+        for (size_t i = 0; i < n; i++) {
+            rcs[i].in_mig[0] = i > 0 ? rcs[i - 1].mig[1] : 0;
+            rcs[i].in_halo[0] = i > 0 ? rcs[i - 1].halo[1] : 0;
+            rcs[i].in_mig[1] = i + 1 < n ? rcs[i + 1].mig[0] : 0;
+            rcs[i].in_halo[1] = i + 1 < n ? rcs[i + 1].halo[0] : 0;
+        }
+        if (red) allreduce_min_f32(G, *red);
+        return SPH_OK;
     }
     int agree_guards_queued(Group&) override { return SPH_OK; }   // one process: sync_ctrl sees every member's guard word
     int allreduce_solver(Group& G) override
@@ -763,6 +938,58 @@ struct RcclComm : Comm {
         for (int k = 0; k < 4; k++) c->dist.counts_host[base + k] = h[13 + k];
         return SPH_OK;
     }
+    int refresh_round(Group& G, std::vector<std::vector<float>>* red, int* status, int* fallback, std::vector<RefreshCounts>& rcs) override
+    {
+        sph_ctx* c = G.m[0];
+        ncclComm_t nc = (ncclComm_t)c->dist.nccl;
+        const int r = c->dist.rank, nr = c->dist.nranks;
+        // device scratch behind the counters: [0 .. 7] the min-reduced floats, [8 .. 17] k_refresh_stage's words
+        uint32_t* d = c->dist.counts.as<uint32_t>() + 16;
+        uint32_t* h = (uint32_t*)((uint8_t*)c->dist.counts_host + 64);   // pinned staging / publish destination (same words)
+        const size_t nred = red ? (*red)[0].size() : 0;
+        if (nred > 8) return c->fail(SPH_ERR_INVALID_ARGUMENT, "refresh_round: %zu reduced values", nred);
+        if (nred) {
+            memcpy(h, (*red)[0].data(), nred * 4);
+            HIPCHK(c, hipMemcpyAsync(d, h, nred * 4, hipMemcpyHostToDevice, c->stream));
+            c->dist.stat_allreduces++;
+            ProfScope ps(&c->prof, "rccl_allreduce", c->stream);
+            NCCLCHK(c, ncclAllReduce(d, d, nred, ncclFloat32, ncclMin, nc, c->stream));
+        }
+        hipLaunchKernelGGL(k_refresh_stage, dim3(1), dim3(64), 0, c->stream, c->dist.counts.as<uint32_t>(), d + 8, (uint32_t)*status, (uint32_t)*fallback);
+        {
+            c->dist.stat_allreduces++;
+            ProfScope ps(&c->prof, "rccl_allreduce", c->stream);
+            NCCLCHK(c, ncclAllReduce(d + 12, d + 12, 2, ncclUint32, ncclMax, nc, c->stream));
+        }
+        {
+            ProfScope ps(&c->prof, "rccl_sendrecv", c->stream);
+            NCCLCHK(c, ncclGroupStart());
+            if (r > 0) {
+                NCCLCHK(c, ncclSend(d + 8, 2, ncclUint32, r - 1, nc, c->stream));
+                NCCLCHK(c, ncclRecv(d + 14, 2, ncclUint32, r - 1, nc, c->stream));
+            }
+            if (r + 1 < nr) {
+                NCCLCHK(c, ncclSend(d + 10, 2, ncclUint32, r + 1, nc, c->stream));
+                NCCLCHK(c, ncclRecv(d + 16, 2, ncclUint32, r + 1, nc, c->stream));
+            }
+            NCCLCHK(c, ncclGroupEnd());
+        }
+        int rc = publish_and_wait(c, d, 18);
+        if (rc) return rc;
+        for (size_t k = 0; k < nred; k++) memcpy(&(*red)[0][k], &h[k], 4);
+        RefreshCounts& o = rcs[0];
+        o.mig[0] = h[8];
+        o.halo[0] = h[9];
+        o.mig[1] = h[10];
+        o.halo[1] = h[11];
+        *status = (int)h[12];
+        *fallback = (int)h[13];
+        o.in_mig[0] = r > 0 ? h[14] : 0;
+        o.in_halo[0] = r > 0 ? h[15] : 0;
+        o.in_mig[1] = r + 1 < nr ? h[16] : 0;
+        o.in_halo[1] = r + 1 < nr ? h[17] : 0;
+        return SPH_OK;
+    }
     int agree_guards_queued(Group& G) override
     {
         sph_ctx* c = G.m[0];
@@ -813,6 +1040,7 @@ struct RcclComm : Comm {
 struct Member {
     sph_ctx* c;
     uint32_t n;  // particles in the arrays (owned + ghosts)
+    uint32_t n_sort = 0;   // slots the cell sort looks at (fused slab refresh: n + the slots that left, which it drops); 0: n
     StepP sp;
     SweepArgs a;
     sph_step_stats st;
@@ -868,6 +1096,8 @@ static int sync_ctrl(Group& G, int mode = SYNC_AGREE)
         if (!rc && peer) rc = G.m[0]->fail(peer > 1 ? (int)peer : SPH_ERR_DEVICE, "another rank of the slab decomposition reported status %u", peer);
         return rc;
     }
+    // (SYNC_DEFER: rc can only be a wait that failed, i.e. a lost device -- nothing a collective on that device could agree on)
+    if (mode == SYNC_DEFER) return rc;
     return agree(G, rc);
 }
 
@@ -935,6 +1165,8 @@ static int ensure_dist_buffers(sph_ctx* c, uint32_t n)
     }
     HIPCHK(c, d.counts.ensure(256));
     HIPCHK(c, d.solver_tot.ensure(64));
+    HIPCHK(c, d.cls.ensure(cap));
+    HIPCHK(c, d.blk.ensure(((cap + 255) / 256) * 8 * sizeof(uint32_t)));
     if (!d.counts_host) {
         HIPCHK(c, hipHostMalloc((void**)&d.counts_host, 256, hipHostMallocMapped));   // 64 B of counters + 192 B of staging
         HIPCHK(c, hipHostGetDevicePointer((void**)&d.counts_host_dev, d.counts_host, 0));
@@ -1220,6 +1452,161 @@ static int build_ghost_layer(Group& G, std::vector<Member>& M, float halo_width,
     return SPH_OK;
 }
 
+// The ordinary step's slab maintenance in ONE round trip (the general path above takes two, plus two partition sorts and a
+// reorder of every array): classify every slot of the previous arrays once -- stay / stay in a halo / migrate / old ghost --,
+// exchange the counts, hand over the migrants, append them and the neighbours' ghost records BEHIND the previous arrays, and let
+// the cell sort drop the slots that left (key = one past the last cell).  A migrant belongs to its receiver's halo towards the
+// sender, so each side knows the ghost-record counts from the first round: mine from the left = the left rank's staying halo
+// members + my own migrants to it.
+// `h_pred`: the ghost width is a multiple of the all-reduced h_max, which only arrives with the round -- the previous step's
+// value stands in (masses do not change inside a step) and is compared afterwards.  *fused = false: nothing was applied
+// (a rank without a prediction, a different h_max, a deep migrant, a narrow slab) and the caller takes the general path;
+// `red` is reduced either way.
+static int slab_refresh_fused(Group& G, std::vector<Member>& M, std::vector<std::vector<float>>& red, float halo_k, bool* fused)
+{
+    const size_t nm = M.size();
+    int rc = SPH_OK;
+    *fused = false;
+    int fallback = 0, status = SPH_OK;
+    const float h_pred = M[0].c->h_max_step;
+    std::vector<uint32_t> n_prev_of(nm);
+    for (size_t i = 0; i < nm; i++) {
+        sph_ctx* c = M[i].c;
+        auto& d = c->dist;
+        (void)hipSetDevice(c->device);
+        if ((rc = ensure_dist_buffers(c, M[i].n))) return rc;
+        const uint32_t n_prev = d.have_flags ? d.n_tot : (uint32_t)c->n;
+        n_prev_of[i] = n_prev;
+        if (!(c->h_max_step > 0.f) || c->h_max_step != h_pred) fallback = 1;
+        const float halo_w = h_pred * halo_k;
+        const bool has_l = d.rank > 0, has_r = d.rank + 1 < d.nranks;
+        if (has_l && has_r && !(d.cut_hi - halo_w >= d.cut_lo + halo_w)) fallback = 1;   // narrower than two ghost layers: the general path reports it
+        (void)hipMemsetAsync(d.counts.p, 0, 64, c->stream);
+        const uint32_t nb = (n_prev + 255u) / 256u;
+        ProfScope ps(&c->prof, "slab_refresh", c->stream);
+        if (n_prev)
+            hipLaunchKernelGGL(k_slab_classify, dim3(nb), dim3(256), 0, c->stream, n_prev, c->pm[c->pcur].as<float4>(),
+                               d.have_flags ? d.owned.as<uint8_t>() : (const uint8_t*)nullptr, d.cut_lo, d.cut_hi, halo_w, has_l ? 1 : 0, has_r ? 1 : 0,
+                               d.cls.as<uint8_t>(), d.blk.as<uint32_t>(), d.counts.as<uint32_t>() + 5);
+        hipLaunchKernelGGL(k_slab_scan, dim3(1), dim3(1024), 0, c->stream, nb, d.blk.as<uint32_t>(), d.blk.as<uint32_t>() + (size_t)nb * 4,
+                           d.counts.as<uint32_t>(), d.counts.as<uint32_t>() + 5);
+        c->hint_word = nullptr;
+    }
+    std::vector<RefreshCounts> rcs(nm);
+    if ((rc = G.comm->refresh_round(G, &red, &status, &fallback, rcs))) return rc;
+    if (status) return M[0].c->fail(status, "another rank of the slab decomposition reported status %d", status);
+    if (red[0][3] < 0.f) return SPH_OK;                       // a rank's header wait failed: the caller reports it (same value everywhere)
+    if (fallback || !(-red[0][0] == h_pred)) return SPH_OK;   // identical on every rank: all-reduced values only
+    const float halo_w = h_pred * halo_k, ring1_w = h_pred * 2.f;
+
+    std::vector<Xfer> x(nm);
+    for (size_t i = 0; i < nm; i++) {
+        sph_ctx* c = M[i].c;
+        auto& d = c->dist;
+        const RefreshCounts& q = rcs[i];
+        const uint32_t n_prev = n_prev_of[i];
+        const uint64_t n_pre = (uint64_t)n_prev + q.in_mig[0] + q.in_mig[1] + q.in_halo[0] + q.mig[0] + q.in_halo[1] + q.mig[1];
+        if (n_pre > c->cap)
+            return agree(G, c->fail(SPH_ERR_CAPACITY, "slab of rank %d + arrivals + ghosts needs %llu slots, capacity %llu", d.rank, (unsigned long long)n_pre,
+                                    (unsigned long long)c->cap));
+    }
+    // ---- migrants
+    for (size_t i = 0; i < nm; i++) {
+        sph_ctx* c = M[i].c;
+        auto& d = c->dist;
+        const RefreshCounts& q = rcs[i];
+        (void)hipSetDevice(c->device);
+        const int k = c->cur;
+        const uint32_t n_prev = n_prev_of[i];
+        d.n_halo[0] = q.halo[0] + q.in_mig[0];
+        d.n_halo[1] = q.halo[1] + q.in_mig[1];
+        d.n_ghost[0] = q.in_halo[0] + q.mig[0];
+        d.n_ghost[1] = q.in_halo[1] + q.mig[1];
+        if (n_prev && (q.mig[0] | q.mig[1] | q.halo[0] | q.halo[1])) {
+            ProfScope ps(&c->prof, "slab_refresh", c->stream);
+            const uint32_t nb = (n_prev + 255u) / 256u;
+            hipLaunchKernelGGL(k_slab_pack, dim3(nb), dim3(256), 0, c->stream, n_prev, d.cls.as<uint8_t>(), d.blk.as<uint32_t>() + (size_t)nb * 4,
+                               c->pm[c->pcur].as<float4>(), c->vel[k].as<float2>(), c->orig[k].as<uint32_t>(), c->lvl[k].as<float>(),
+                               c->lvlold[k].as<float>(), c->h2n[k].as<float>(), c->lam_sum.as<float>(), c->szc[k].as<uint8_t>(), d.send[0].as<float>(),
+                               d.send[1].as<float>(), d.halo_idx.as<uint32_t>(), d.n_halo[0]);
+        }
+        for (int side = 0; side < 2; side++) {
+            x[i].send[side] = d.send[side].p;
+            x[i].send_bytes[side] = (size_t)q.mig[side] * MIG_WORDS * 4;
+            x[i].recv[side] = d.recv[side].p;
+            x[i].recv_bytes[side] = (size_t)q.in_mig[side] * MIG_WORDS * 4;
+        }
+    }
+    bool any_mig = false;
+    for (size_t i = 0; i < nm; i++) any_mig = any_mig || rcs[i].mig[0] || rcs[i].mig[1] || rcs[i].in_mig[0] || rcs[i].in_mig[1];
+    // (one rank per process: no migrant in either direction = nothing to pair up, the neighbours see the same zeros)
+    if (any_mig && (rc = G.comm->exchange(G, x))) return rc;
+    // ---- arrivals behind the previous arrays, then the ghost records: [previous slots | from left | from right | ghosts left | ghosts right]
+    for (size_t i = 0; i < nm; i++) {
+        sph_ctx* c = M[i].c;
+        auto& d = c->dist;
+        const RefreshCounts& q = rcs[i];
+        (void)hipSetDevice(c->device);
+        const int k = c->cur;
+        const uint32_t n_prev = n_prev_of[i];
+        const uint32_t base[2] = {n_prev, n_prev + q.in_mig[0]};
+        const uint32_t hoff[2] = {q.halo[0], d.n_halo[0] + q.halo[1]};   // the arrivals close the halo list of the side they came from
+        for (int side = 0; side < 2; side++) {
+            const uint32_t cnt = q.in_mig[side];
+            if (!cnt) continue;
+            hipLaunchKernelGGL(k_unpack_migrants, dim3((cnt + 255) / 256), dim3(256), 0, c->stream, base[side], cnt, d.recv[side].as<float>(),
+                               c->pm[c->pcur].as<float4>(), c->vel[k].as<float2>(), c->orig[k].as<uint32_t>(), c->lvl[k].as<float>(),
+                               c->lvlold[k].as<float>(), c->h2n[k].as<float>(), c->lam_sum.as<float>(), c->szc[k].as<uint8_t>());
+            hipLaunchKernelGGL(k_iota_u32, dim3((cnt + 255) / 256), dim3(256), 0, c->stream, d.halo_idx.as<uint32_t>() + hoff[side], cnt, base[side]);
+        }
+        for (int side = 0; side < 2; side++) {
+            const uint32_t cnt = d.n_halo[side], off = side == 0 ? 0 : d.n_halo[0];
+            if (cnt)
+                hipLaunchKernelGGL(k_pack_ghosts, dim3((cnt + 255) / 256), dim3(256), 0, c->stream, d.halo_idx.as<uint32_t>() + off, cnt,
+                                   c->pm[c->pcur].as<float4>(), c->vel[k].as<float2>(), d.send[side].as<float>());
+            x[i].send[side] = d.send[side].p;
+            x[i].send_bytes[side] = (size_t)cnt * GHOST_WORDS * 4;
+            x[i].recv[side] = d.recv[side].p;
+            x[i].recv_bytes[side] = (size_t)d.n_ghost[side] * GHOST_WORDS * 4;
+        }
+    }
+    if ((rc = G.comm->exchange(G, x))) return rc;
+    for (size_t i = 0; i < nm; i++) {
+        sph_ctx* c = M[i].c;
+        auto& d = c->dist;
+        const RefreshCounts& q = rcs[i];
+        (void)hipSetDevice(c->device);
+        const int k = c->cur;
+        const uint32_t n_prev = n_prev_of[i];
+        const uint32_t n_own_prev = (uint32_t)c->n;                         // owned slots of the previous arrays
+        const uint32_t n_stay = n_own_prev - q.mig[0] - q.mig[1];
+        const uint32_t n_in = q.in_mig[0] + q.in_mig[1];
+        const uint32_t own_end = n_prev + n_in;
+        const uint32_t base[2] = {own_end, own_end + d.n_ghost[0]};
+        for (int side = 0; side < 2; side++)
+            if (d.n_ghost[side])
+                hipLaunchKernelGGL(k_unpack_ghosts, dim3((d.n_ghost[side] + 255) / 256), dim3(256), 0, c->stream, base[side], d.n_ghost[side],
+                                   d.recv[side].as<float>(), c->pm[c->pcur].as<float4>(), c->vel[k].as<float2>(), c->orig[k].as<uint32_t>(),
+                                   c->lvl[k].as<float>(), c->lvlold[k].as<float>(), d.ring1_src.as<uint8_t>(), side == 0 ? 0u : d.n_ghost[0],
+                                   side == 0 ? d.cut_lo - ring1_w : d.cut_hi + ring1_w, side);
+        d.pre = true;
+        d.pre_cls_n = n_prev;
+        d.pre_own = own_end;
+        d.pre_n = own_end + d.n_ghost[0] + d.n_ghost[1];
+        c->n = n_stay + n_in;
+        d.n_tot = (uint32_t)c->n + d.n_ghost[0] + d.n_ghost[1];
+        d.have_flags = false;
+        M[i].n = d.n_tot;
+        M[i].n_sort = d.pre_n;
+        if (d.pre_n) (void)hipMemsetAsync(d.halo_pos.p, 0xff, (size_t)d.pre_n * 4, c->stream);
+        const uint32_t nh = d.n_halo[0] + d.n_halo[1];
+        if (nh) hipLaunchKernelGGL(k_halo_pos, dim3((nh + 255) / 256), dim3(256), 0, c->stream, d.halo_idx.as<uint32_t>(), nh, d.halo_pos.as<uint32_t>());
+    }
+    (void)halo_w;
+    *fused = true;
+    return SPH_OK;
+}
+
 // iisph_pressure_iterations (simulation.rs:1377-1516).  Iteration 0 was folded into the source-term sweep (closed form, see
 // OpSource).  An iteration is two launches: sweep B(k) (Jacobi update + per-block residual partials) and sweep A(k + 1), whose
 // block 0 first reduces those partials and takes the stop decision of iteration k while the other blocks already compute a^p
@@ -1355,6 +1742,7 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
     // per rank: -h_max, h_min, CFL term, -status, and the bounding box of the owned particles (min x, -max x, min y, -max y): all min-reduced
     std::vector<std::vector<float>> red(M.size(), std::vector<float>(8));
     int hdr_rc = SPH_OK, setup_rc = SPH_OK;
+    bool slab_fused = false;   // the ghost layer is already in place (slab_refresh_fused)
     // The tail of the previous step's last solve already reduced this step's header into hdr_host (k_solver_tail,
     // k_header_ahead): nothing to launch, nothing to wait for -- unless the host touched the state or the smoothing lengths are
     // not the mass-derived ones.  On a slab the header describes the particles the rank owned at the END of that step; the ones
@@ -1395,9 +1783,20 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
         // particles follow the cuts to the x-neighbour; after a re-balance a particle may have to cross several slabs:
         // repeat until nobody moved (the all-reduced count), at most once per rank.  The header all-reduce rides in the round
         // trip of the first partition's counts.
+        // ordinary steps: the fused refresh (one round trip, no partition sort); it reduces `red` whether or not it applies
+        const float halo_k_f = fmaxf(4.f, level_on ? p->level_estimation_range / SPH_ETA : 0.f);
+        const bool no_fused = getenv("SPH_SLAB_GENERAL") != nullptr;   // measurement / test aid: always the general path (read per step)
+        const bool attempt = h_from_mass_mode && !rebalanced && !no_fused;     // (parameters and all-reduced values: the same on every rank)
+        if (attempt) {
+            if ((rc = slab_refresh_fused(G, M, red, halo_k_f, &slab_fused))) return rc;
+            if (!slab_fused && (hdr_rc || red[0][3] < 0.f)) {
+                if (hdr_rc) return hdr_rc;
+                return c0->fail((int)-red[0][3], "another rank of the slab decomposition reported status %d", (int)-red[0][3]);
+            }
+        }
         std::vector<int> moved(M.size(), 0);
-        for (int round = 0;; round++) {
-            if ((rc = partition_and_migrate(G, M, &moved, round == 0 ? &red : nullptr))) return rc;
+        for (int round = 0; !slab_fused; round++) {
+            if ((rc = partition_and_migrate(G, M, &moved, round == 0 && !attempt ? &red : nullptr))) return rc;
             if (!rebalanced) break;
             if ((rc = G.comm->allreduce_max_i32(G, moved))) return rc;
             if (moved[0] == 0 || round + 1 >= c0->dist.nranks) break;
@@ -1441,7 +1840,7 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
         // (their neighbours are all inside the second), so a Jacobi iteration exchanges p / rho^2 only.
         const float halo_k = fmaxf(4.f, level_on ? p->level_estimation_range / SPH_ETA : 0.f);
         const float halo_w = h_max_g * halo_k;
-        if ((rc = build_ghost_layer(G, M, halo_w, h_max_g * 2.f, status_in))) return rc;
+        if (!slab_fused && (rc = build_ghost_layer(G, M, halo_w, h_max_g * 2.f, status_in))) return rc;
         // bounding box of owned + ghosts from the cuts: an owned particle lies between them, a ghost within halo_w beyond one
         for (size_t i = 0; i < M.size(); i++) {
             const auto& d = M[i].c->dist;
@@ -1543,19 +1942,25 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
         Profiler* prof = &c->prof;
         int k = c->cur;
         HIPCHK(c, c->cs_scratch.ensure(cell_start_scratch_bytes()));
-        if (n) {
-            launch_cell_keys(s, prof, c->pm[c->pcur].as<float4>(), n, g, c->key[0].as<uint32_t>(), c->val[0].as<uint32_t>());
+        // (fused slab refresh: the arrays still hold the slots that left this rank -- they sort behind the last cell and stay there)
+        const bool pre = c->dist.on && c->dist.pre;
+        const uint32_t n_sort = pre ? m.n_sort : n;
+        c->dist.pre = false;
+        if (n_sort) {
+            launch_cell_keys(s, prof, c->pm[c->pcur].as<float4>(), n_sort, g, c->key[0].as<uint32_t>(), c->val[0].as<uint32_t>(),
+                             pre ? c->dist.cls.as<uint8_t>() : nullptr, pre ? c->dist.pre_cls_n : 0u, (uint32_t)SC_GONE_FROM);
             int res = radix_sort_pairs(s, prof, c->key[0].as<uint32_t>(), c->val[0].as<uint32_t>(), c->key[1].as<uint32_t>(),
-                                       c->val[1].as<uint32_t>(), n, ilog2_ceil(g.ncells), c->sort_scratch.as<uint32_t>());
+                                       c->val[1].as<uint32_t>(), n_sort, ilog2_ceil(g.ncells + (pre ? 1u : 0u)), c->sort_scratch.as<uint32_t>());
             if (res == 1) {  // keep the sorted keys in key[0] / val[0]
                 std::swap(c->key[0], c->key[1]);
                 std::swap(c->val[0], c->val[1]);
             }
-            launch_reorder(s, prof, n, g, c->key[0].as<uint32_t>(), c->val[0].as<uint32_t>(), c->pm[c->pcur].as<float4>(), c->vel[k].as<float2>(),
-                           c->orig[k].as<uint32_t>(), c->lvl[k].as<float>(), c->lvlold[k].as<float>(), c->pm[c->pcur ^ 1].as<float4>(),
-                           c->vel[k ^ 1].as<float2>(), c->orig[k ^ 1].as<uint32_t>(), c->lvl[k ^ 1].as<float>(), c->lvlold[k ^ 1].as<float>(),
-                           c->cxy.as<uint32_t>(), c->h2n[k].as<float>(), c->h2n[k ^ 1].as<float>(), c->lam_sum.as<float>(),
-                           c->lam_prev.as<float>(), c->cs_scratch.p, c->szc[k].as<uint8_t>(), c->szc[k ^ 1].as<uint8_t>());
+            if (n)
+                launch_reorder(s, prof, n, g, c->key[0].as<uint32_t>(), c->val[0].as<uint32_t>(), c->pm[c->pcur].as<float4>(), c->vel[k].as<float2>(),
+                               c->orig[k].as<uint32_t>(), c->lvl[k].as<float>(), c->lvlold[k].as<float>(), c->pm[c->pcur ^ 1].as<float4>(),
+                               c->vel[k ^ 1].as<float2>(), c->orig[k ^ 1].as<uint32_t>(), c->lvl[k ^ 1].as<float>(), c->lvlold[k ^ 1].as<float>(),
+                               c->cxy.as<uint32_t>(), c->h2n[k].as<float>(), c->h2n[k ^ 1].as<float>(), c->lam_sum.as<float>(),
+                               c->lam_prev.as<float>(), c->cs_scratch.p, c->szc[k].as<uint8_t>(), c->szc[k ^ 1].as<uint8_t>());
             c->cur = k ^ 1;
             c->pcur ^= 1;
         }
@@ -1576,7 +1981,7 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
         if (c->dist.on) {
             auto& d = c->dist;
             if (n)
-                hipLaunchKernelGGL(k_build_maps, dim3((n + 255) / 256), dim3(256), 0, s, n, (uint32_t)c->n, c->val[0].as<uint32_t>(),
+                hipLaunchKernelGGL(k_build_maps, dim3((n + 255) / 256), dim3(256), 0, s, n, pre ? d.pre_own : (uint32_t)c->n, c->val[0].as<uint32_t>(),
                                    d.halo_pos.as<uint32_t>(), d.halo_src.as<uint32_t>(), d.ghost_dst.as<uint32_t>(), d.owned.as<uint8_t>(),
                                    d.ring1_src.as<uint8_t>(), d.ring1.as<uint8_t>());
             d.have_flags = true;
@@ -2244,7 +2649,7 @@ void dist_release(sph_ctx* c)
     auto& d = c->dist;
     if (d.nccl) ncclCommDestroy((ncclComm_t)d.nccl);
     d.nccl = nullptr;
-    DevBuf* all[] = {&d.owned, &d.ring1, &d.ring1_src, &d.halo_idx, &d.halo_pos, &d.halo_src, &d.ghost_dst, &d.send[0], &d.send[1], &d.recv[0], &d.recv[1], &d.counts, &d.solver_tot, &d.hist};
+    DevBuf* all[] = {&d.owned, &d.ring1, &d.ring1_src, &d.halo_idx, &d.halo_pos, &d.halo_src, &d.ghost_dst, &d.send[0], &d.send[1], &d.recv[0], &d.recv[1], &d.counts, &d.solver_tot, &d.hist, &d.cls, &d.blk};
     for (auto b : all) b->release();
     if (d.counts_host) (void)hipHostFree(d.counts_host);
     d.counts_host = nullptr;

@@ -297,14 +297,13 @@ struct OpPrologue<Op, std::void_t<decltype(&Op::prologue)>> {
 };
 
 // one particle of a sweep, every list form: mask word, explicit index list, candidate walk (3 x 3 cells or a wide stencil)
+// (Ai, lw: the particle's record and list word, loaded by the caller BEFORE it looks at the slab flags -- one memory round trip
+//  at the head of every wave instead of two)
 template <class Op, bool BUILD>
-__device__ __forceinline__ void sweep_particle(const Op& op, const SweepCommon& c, typename Op::Acc& acc, const uint32_t i)
+__device__ __forceinline__ void sweep_particle(const Op& op, const SweepCommon& c, typename Op::Acc& acc, const uint32_t i, const float4 Ai, uint4 lw)
 {
     typedef typename Op::Math Math;
     const GridP g = c.g;
-    const float4 Ai = op.loadA(i);
-    uint4 lw = make_uint4(0, 0, 0, 0);
-    if (!BUILD) lw = c.nl[i];
     op.begin(acc, i, Ai);
     // explicit index lists exist in multi-resolution scenes and for the extended-range lists of the level estimation
     // SPH_FORCE_IDX (variant): explicit index lists in uniform scenes too -- no mask decoding per neighbour slot, one more coalesced
@@ -398,11 +397,26 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_sweep(Op op, SweepCommon c)
     if (blk >= c.nblocks) return;
     const uint32_t i = blk * SWEEP_THREADS + threadIdx.x;
     const uint32_t ic = i < c.n ? i : 0;
-    const bool mine = !c.owned || c.owned[ic] || (OpRing1<Op>::value && c.ring1 && c.ring1[ic]);
+    // slab decomposition: the record and the list word are requested together with the flags (one memory round trip at the head
+    // of every wave instead of two); otherwise only by the lanes that have work (level-set propagation skips most)
+    const bool slab = c.owned != nullptr;   // launch-uniform
+    float4 Ai = make_float4(0.f, 0.f, 0.f, 0.f);
+    uint4 lw = make_uint4(0, 0, 0, 0);
+    if (slab) {
+        Ai = op.loadA(ic);
+        if (!BUILD) lw = c.nl[ic];
+    }
+    const bool mine = !slab || c.owned[ic] || (OpRing1<Op>::value && c.ring1 && c.ring1[ic]);
     const bool active = i < c.n && mine && !op.lane_skip(i);
     typename Op::Acc acc;
     op.init(acc);  // lane-independent state
-    if (active) sweep_particle<Op, BUILD>(op, c, acc, i);
+    if (active) {
+        if (!slab) {
+            Ai = op.loadA(i);
+            if (!BUILD) lw = c.nl[i];
+        }
+        sweep_particle<Op, BUILD>(op, c, acc, i, Ai, lw);
+    }
     if (Op::HAS_EPILOGUE) op.epilogue(acc, active, blk);
 }
 
@@ -486,7 +500,7 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_sweep_tile(Op op, SweepCommon
         if (!BUILD) lane_ok = (lw.w & NL_OK) != 0u;
         tile_ok = tile_ok && __ballot(lane < nvalid && !lane_ok) == 0ull;
         if (!tile_ok) {
-            if (active) sweep_particle<Op, BUILD>(op, c, acc, i);
+            if (active) sweep_particle<Op, BUILD>(op, c, acc, i, Ai, lw);
         } else {
             // ---- stage the three rows: coalesced loads, one record (+ payload) per lane and trip
 #pragma unroll

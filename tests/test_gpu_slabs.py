@@ -192,8 +192,10 @@ def test_support_length_from_distribution_on_slabs(product_lib, mode):
 
 
 def test_profiling_a_slab_group(product_lib):
-    """The instrumented pass of bench.py on a decomposition: the slab partition opens a profiler scope around the radix sort
-    and the reorder, which open their own -- nested scopes once corrupted the profiler (hang); only the outermost is timed."""
+    """The instrumented pass of bench.py on a decomposition.  The first step takes the general path (no h_max of a previous
+    step to size the ghost layer with): its slab partition opens a profiler scope around the radix sort and the reorder, which
+    open their own -- nested scopes once corrupted the profiler (hang); only the outermost is timed.  The other five steps take
+    the fused refresh (two scopes per step: classify + scan, pack)."""
     scn = sc.dam_break_small(96, 48, 1 / 48)
     pos, mass, vel = sc.init_particles(scn)
     planes = sc.boundary_planes(scn.boundary)
@@ -206,10 +208,46 @@ def test_profiling_a_slab_group(product_lib):
         ffi.group_step(grp, p)
     for c in grp:
         prof = c.profile_get()
-        assert prof["slab_partition"][0] == 6 and prof["jacobi_update"][0] >= 12 and "ghost_pack" in prof
+        assert prof["slab_partition"][0] == 1 and prof["slab_refresh"][0] >= 6 and prof["jacobi_update"][0] >= 12 and "ghost_pack" in prof
         assert all(ms >= 0 for _, ms in prof.values())
         c.profile_enable(0)
     ffi.group_step(grp, p)
+
+
+def test_fused_refresh_is_bit_identical_to_the_general_path(product_lib, monkeypatch):
+    """Ordinary steps maintain the slabs in one round trip (classify once, arrivals appended, the cell sort drops what left);
+    the general path (SPH_SLAB_GENERAL: partition sort + reorder, then the halo selection -- also what the first step, re-balancing
+    steps and FromDistribution* support lengths take) must leave the same particles in the same order: every field bit for bit."""
+    scn = sc.dam_break_small(96, 48, 1 / 48)
+    pos, mass, vel = sc.init_particles(scn)
+    vel = vel.copy()
+    vel[:, 0] = 0.8                               # particles cross the cuts in both paths
+    planes = sc.boundary_planes(scn.boundary)
+    p = forced(max_iters=4).to_ffi()
+    groups = {}
+    for name in ("fused", "general"):
+        if name == "general":
+            monkeypatch.setenv("SPH_SLAB_GENERAL", "1")
+        grp = D.make_loopback_group(product_lib, pos, mass, vel, planes, 3)
+        for c in grp:
+            c.profile_enable(1)
+        moved = 0
+        for s in range(30):
+            before = [c.n for c in grp]
+            ffi.group_step(grp, p)
+            moved += sum(abs(a - c.n) for a, c in zip(before, grp))
+        assert moved > 0
+        prof = grp[1].profile_get()
+        if name == "fused":
+            assert prof["slab_partition"][0] == 1 and prof["slab_refresh"][0] >= 29     # only the first step took the general path
+        else:
+            assert prof["slab_partition"][0] == 30 and "slab_refresh" not in prof
+        groups[name] = grp
+    monkeypatch.delenv("SPH_SLAB_GENERAL")
+    for a, b in zip(groups["fused"], groups["general"]):
+        assert a.n == b.n
+        for f in ("particle_id", "position", "velocity", "density", "neighbor_count", "mass"):
+            assert np.array_equal(a.download(f), b.download(f)), f
 
 
 def test_group_of_one_is_the_plain_step(product_lib):
