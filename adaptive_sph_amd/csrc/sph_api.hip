@@ -409,11 +409,11 @@ extern "C" int sph_create(uint64_t n_capacity, int device_id, const sph_plane* p
     if (alloc_particle_buffers(c) != SPH_OK) return bail(SPH_ERR_DEVICE);
     bool ok = c->planes_d.ensure(sizeof(BoundaryP)) == hipSuccess && c->lam_lut.ensure(10001 * 4) == hipSuccess &&
               c->dlam_lut.ensure(10001 * 4) == hipSuccess && c->hdr_partials.ensure(sizeof(HeaderOut) * HDR_BLOCKS) == hipSuccess &&
-              c->hdr_out.ensure(sizeof(HeaderOut)) == hipSuccess && c->ctrl.ensure(sizeof(SolverCtrl)) == hipSuccess &&
+              c->hdr_out.ensure(sizeof(HeaderOut)) == hipSuccess && c->ctrl.ensure(3 * sizeof(SolverCtrl)) == hipSuccess &&
               c->status.ensure(sizeof(DeviceStatus)) == hipSuccess && c->n_tiles.ensure(16) == hipSuccess;
     if (!ok) return bail(SPH_ERR_DEVICE);
     if (hipHostMalloc((void**)&c->hdr_host, sizeof(HeaderOut), hipHostMallocMapped) != hipSuccess) return bail(SPH_ERR_DEVICE);
-    if (hipHostMalloc((void**)&c->ctrl_host, sizeof(SolverCtrl), hipHostMallocMapped) != hipSuccess) return bail(SPH_ERR_DEVICE);
+    if (hipHostMalloc((void**)&c->ctrl_host, 2 * sizeof(SolverCtrl), hipHostMallocMapped) != hipSuccess) return bail(SPH_ERR_DEVICE);
     if (hipHostMalloc((void**)&c->status_host, sizeof(DeviceStatus), hipHostMallocMapped) != hipSuccess) return bail(SPH_ERR_DEVICE);
     if (hipHostMalloc((void**)&c->lvl_changed, 64 * sizeof(uint32_t), hipHostMallocMapped) != hipSuccess) return bail(SPH_ERR_DEVICE);
     if (hipHostGetDevicePointer((void**)&c->lvl_changed_dev, c->lvl_changed, 0) != hipSuccess) return bail(SPH_ERR_DEVICE);
@@ -423,6 +423,7 @@ extern "C" int sph_create(uint64_t n_capacity, int device_id, const sph_plane* p
     if (hipHostGetDevicePointer((void**)&c->status_host_dev, c->status_host, 0) != hipSuccess) return bail(SPH_ERR_DEVICE);
     if (hipEventCreateWithFlags(&c->ev_sync, hipEventDisableTiming) != hipSuccess) return bail(SPH_ERR_DEVICE);
     memset(c->status_host, 0, sizeof(DeviceStatus));
+    memset((void*)c->ctrl_host, 0, 2 * sizeof(SolverCtrl));
     // BoundaryWinchenbach2020::new (boundary_winchenbach2020.rs:33-36)
     std::vector<float> lam, dlam;
     sph_lambda::build_luts(lam, dlam);

@@ -133,6 +133,7 @@ struct sph_ctx {
     uint32_t* lvl_changed_dev = nullptr;
     uint32_t pressure_cur = 0;
     uint32_t last_div_iters = 2, last_dens_iters = 2;
+    uint32_t prev_div_iters = 0;   // the step before: the solves are chained only while the divergence solve's count repeats
     hipEvent_t ev[8];
 
     int fail(int code, const char* fmt, ...)

@@ -1616,80 +1616,106 @@ static int slab_refresh_fused(Group& G, std::vector<Member>& M, std::vector<std:
 // decision is taken.  One host wait per chunk.
 // Slab decomposition: block 0 of A(k + 1) adds up the rank's totals; the all-reduce and the decision (k_solver_decide) follow
 // behind that sweep, i.e. the decision on iteration k is taken one sweep late and the reduction kernel between B and A is gone.
+// The queueing state of one solve.
+struct SolveQ {
+    float max_avg_error;
+    int residual_density;
+    uint32_t max_iters;
+    int tail;
+    bool density_solver;
+    uint32_t k = 1, upto = 2;
+    void extend() { upto = k + std::max(1u, k / 4u); }   // a quarter more iterations per wait, at least one: a skipped
+                                                         // iteration costs two empty launches (~9 us), a wait the round trip to the host
+};
+// sweep A of iteration k: a^p from pressure buffer k & 1, and the stop decision of iteration k - 1
+static int solve_sweep_a(Group& G, std::vector<Member>& M, const SolveQ& q, uint32_t k)
+{
+    const int multi = G.multi() ? 1 : 0;
+    for (auto& m : M) {
+        (void)hipSetDevice(m.c->device);
+        if (m.n) launch_pressure_accel(m.c->stream, &m.c->prof, m.a, (int)k, q.residual_density, q.max_avg_error, q.max_iters, multi);
+        else if (!multi) {   // a context without particles: nothing to iterate on (n_normal == 0)
+            SolverCtrl z{};
+            z.done = 1u;
+            z.slot_done[0] = z.slot_done[1] = 1u;
+            z.cur = k & 1u;
+            (void)hipMemcpyAsync(m.c->ctrl.p, &z, sizeof z, hipMemcpyHostToDevice, m.c->stream);
+        } else (void)hipMemsetAsync(m.c->dist.solver_tot.p, 0, 48, m.c->stream);   // an empty slab contributes zeros
+    }
+    // slab decomposition: the totals of iteration k - 1 are all-reduced behind this sweep; the decision is evaluated by the
+    // blocks of B(k) themselves (OpJacobi::prologue), or by k_solver_decide before a solve's tail
+    if (multi) return G.comm->allreduce_solver(G);
+    return SPH_OK;
+}
+static int solve_begin(Group& G, std::vector<Member>& M, SolveQ& q, uint32_t predicted_iters)
+{
+    int rc;
+    // iteration 0 wrote pressure buffer 1
+    if ((rc = refresh_ghosts(G, M, sel_pt1, 1, "pt"))) return rc;
+    if ((rc = solve_sweep_a(G, M, q, 1))) return rc;
+    q.k = 1;
+    q.upto = predicted_iters > 2 ? predicted_iters : 2;
+    return SPH_OK;
+}
+// iterations k .. upto, the (late) decision on the last one and the solve's tail
+static int solve_queue(Group& G, std::vector<Member>& M, SolveQ& q)
+{
+    int rc;
+    const int multi = G.multi() ? 1 : 0;
+    for (; q.k <= q.upto && q.k <= q.max_iters; q.k++) {
+        const uint32_t k = q.k;
+        for (auto& m : M) {
+            (void)hipSetDevice(m.c->device);
+            if (m.n) launch_jacobi_update(m.c->stream, &m.c->prof, m.a, (int)k, q.residual_density, q.max_avg_error, q.max_iters, multi);
+            else if (multi) launch_solver_decide(m.c->stream, &m.c->prof, m.a, (int)k - 1, q.residual_density, q.max_avg_error, q.max_iters);   // an empty slab has no sweep B to take it
+        }
+        // (no exchange of a^p: the first ghost ring computes its own in sweep A)
+        if ((rc = refresh_ghosts(G, M, ((k + 1) & 1) ? sel_pt1 : sel_pt0, 1, "pt"))) return rc;
+        if ((rc = solve_sweep_a(G, M, q, k + 1))) return rc;
+    }
+    if (multi)   // the last queued sweep A(k) left the totals of iteration k - 1 behind
+        for (auto& m : M) {
+            (void)hipSetDevice(m.c->device);
+            launch_solver_decide(m.c->stream, &m.c->prof, m.a, (int)q.k - 1, q.residual_density, q.max_avg_error, q.max_iters);
+        }
+    for (auto& m : M) {
+        (void)hipSetDevice(m.c->device);
+        if (!m.n || q.tail == 0 /* TAIL_NONE */) continue;
+        launch_solver_tail(m.c->stream, &m.c->prof, m.a, q.tail, m.c->pm[m.c->pcur ^ 1].as<float4>());
+        if (q.tail >= 2 /* TAIL_VX, TAIL_HYBRID */ && m.a.hdr_partials) launch_header_ahead(m.c, (m.n + 255u) / 256u, m.c->hdr_host_dev);
+    }
+    return SPH_OK;
+}
+static void solve_stats(Member& m, const SolveQ& q, const SolverCtrl& h)
+{
+    m.c->pressure_cur = h.cur;
+    sph_solver_stats* st = q.density_solver ? &m.st.density_solver : &m.st.div_solver;
+    st->iters = h.iters;
+    st->converged = 1;
+    st->normal_count = h.normal;
+    st->singular_count = h.singular;
+    st->negative_count = h.negative;
+    st->avg_error = h.normal > 0 ? h.sum_err / (float)h.normal : NAN;
+    st->max_error = h.max_err;
+}
+
+// iisph_pressure_iterations (simulation.rs:1377-1516) with a host wait of its own
 static int pressure_iterations(Group& G, std::vector<Member>& M, float max_avg_error, int residual_density, uint32_t max_iters,
                                uint32_t predicted_iters, int tail, bool density_solver, bool final_solve)
 {
     int rc;
     const int multi = G.multi() ? 1 : 0;
-    // sweep A of iteration k: a^p from pressure buffer k & 1, and the stop decision of iteration k - 1
-    auto sweep_a = [&](uint32_t k) -> int {
-        for (auto& m : M) {
-            (void)hipSetDevice(m.c->device);
-            if (m.n) launch_pressure_accel(m.c->stream, &m.c->prof, m.a, (int)k, residual_density, max_avg_error, max_iters, multi);
-            else if (!multi) {   // a context without particles: nothing to iterate on (n_normal == 0)
-                SolverCtrl z{};
-                z.done = 1u;
-                z.slot_done[0] = z.slot_done[1] = 1u;
-                z.cur = k & 1u;
-                (void)hipMemcpyAsync(m.c->ctrl.p, &z, sizeof z, hipMemcpyHostToDevice, m.c->stream);
-            } else (void)hipMemsetAsync(m.c->dist.solver_tot.p, 0, 48, m.c->stream);   // an empty slab contributes zeros
-        }
-        // slab decomposition: the totals of iteration k - 1 are all-reduced behind this sweep; the decision is evaluated by the
-        // blocks of B(k) themselves (OpJacobi::prologue), or by decide() before a solve's tail
-        if (multi) return G.comm->allreduce_solver(G);
-        return SPH_OK;
-    };
-    auto decide = [&](uint32_t k_decided) {
-        if (!multi) return;
-        for (auto& m : M) {
-            (void)hipSetDevice(m.c->device);
-            launch_solver_decide(m.c->stream, &m.c->prof, m.a, (int)k_decided, residual_density, max_avg_error, max_iters);
-        }
-    };
-    auto pt_of = [&](int cur) { return cur ? sel_pt1 : sel_pt0; };
-    // iteration 0 wrote pressure buffer 1
-    if ((rc = refresh_ghosts(G, M, sel_pt1, 1, "pt"))) return rc;
-    if ((rc = sweep_a(1))) return rc;
-    uint32_t k = 1;
-    uint32_t upto = predicted_iters > 2 ? predicted_iters : 2;
+    SolveQ q{max_avg_error, residual_density, max_iters, tail, density_solver};
+    if ((rc = solve_begin(G, M, q, predicted_iters))) return rc;
     for (;;) {
-        for (; k <= upto && k <= max_iters; k++) {
-            for (auto& m : M) {
-                (void)hipSetDevice(m.c->device);
-                if (m.n) launch_jacobi_update(m.c->stream, &m.c->prof, m.a, (int)k, residual_density, max_avg_error, max_iters, multi);
-                else if (multi) launch_solver_decide(m.c->stream, &m.c->prof, m.a, (int)k - 1, residual_density, max_avg_error, max_iters);   // an empty slab has no sweep B to take it
-            }
-            // (no exchange of a^p: the first ghost ring computes its own in sweep A)
-            if ((rc = refresh_ghosts(G, M, pt_of((k + 1) & 1), 1, "pt"))) return rc;
-            if ((rc = sweep_a(k + 1))) return rc;
-        }
-        decide(k - 1);   // (slab decomposition) the last queued sweep A(k) left the totals of iteration k - 1 behind
-        for (auto& m : M) {
-            (void)hipSetDevice(m.c->device);
-            if (!m.n || tail == 0 /* TAIL_NONE */) continue;
-            launch_solver_tail(m.c->stream, &m.c->prof, m.a, tail, m.c->pm[m.c->pcur ^ 1].as<float4>());
-            if (tail >= 2 /* TAIL_VX, TAIL_HYBRID */ && m.a.hdr_partials) launch_header_ahead(m.c, (m.n + 255u) / 256u, m.c->hdr_host_dev);
-        }
+        if ((rc = solve_queue(G, M, q))) return rc;
         if (multi && final_solve && (rc = G.comm->agree_guards_queued(G))) return rc;
         if ((rc = sync_ctrl(G, multi ? (final_solve ? SYNC_FINAL : SYNC_DEFER) : SYNC_AGREE))) return rc;
         if (M[0].c->ctrl_host->done) break;
-        if (k > max_iters) break;  // cannot happen: the decision on iteration max_iters is always "stop"
-        // the prediction (the previous step's count) fell short: a quarter more iterations per wait, at least two -- a skipped
-        // iteration costs two empty launches (~9 us), a wait the round trip to the host (and on slabs an agreement)
-        upto = k + std::max(1u, k / 4u);
+        if (q.k > max_iters) break;  // cannot happen: the decision on iteration max_iters is always "stop"
+        q.extend();   // the prediction (the previous step's count) fell short
     }
-    for (auto& m : M) {
-        const SolverCtrl& h = *m.c->ctrl_host;
-        m.c->pressure_cur = h.cur;
-        sph_solver_stats* st = density_solver ? &m.st.density_solver : &m.st.div_solver;
-        st->iters = h.iters;
-        st->converged = 1;
-        st->normal_count = h.normal;
-        st->singular_count = h.singular;
-        st->negative_count = h.negative;
-        st->avg_error = h.normal > 0 ? h.sum_err / (float)h.normal : NAN;
-        st->max_error = h.max_err;
-    }
+    for (auto& m : M) solve_stats(m, q, *m.c->ctrl_host);
     return SPH_OK;
 }
 
@@ -2395,11 +2421,64 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
         if ((rc = pressure_iterations(G, M, p->hybrid_dfsph_max_avg_divergence_error, 0, p->max_iters, c0->last_div_iters, T_VX, false, !level_on))) return rc;
         rec(3);
         break;
-    default:  // HybridDFSPH, simulation.rs:2502-2670
+    default: {  // HybridDFSPH, simulation.rs:2502-2670
         if (p->hybrid_dfsph_non_pressure_accel_before_divergence_free)
             if ((rc = non_pressure())) return rc;
         rec(2);
         begin_solve(0, 0);
+        // One context, forces in front of the divergence solve (the default): the two solves are CHAINED -- the density solve is
+        // queued right behind the divergence solve's tail, its launches gated on the device by "the divergence solve ended"
+        // (k_solver_handoff), and the step waits once, at its end.  If the divergence solve needed more iterations than were
+        // queued, the gated launches cost a few us each, and both are queued again from where the first one stands.
+        // Chained only while the divergence solve's iteration count repeats from step to step (SPH_CHAIN=1: always, =0: never):
+        // in the first steps of a dam break it jumps by factors (4, 15, 17, 7, ...), and a short-fall there throws away a
+        // density solve's worth of gated launches (measured: 1.38 vs 1.27 ms/step over steps 5-24 when always chained).
+        const char* chain_env = getenv("SPH_CHAIN");
+        const bool chain_wanted = chain_env ? chain_env[0] == '1' : c0->last_div_iters == c0->prev_div_iters;
+        const bool chain = !G.multi() && M[0].n > 0 && p->hybrid_dfsph_non_pressure_accel_before_divergence_free && chain_wanted;
+        if (chain) {
+            Member& m = M[0];
+            sph_ctx* c = m.c;
+            SolverCtrl* ctrl_d = c->ctrl.as<SolverCtrl>();
+            uint32_t* gate = (uint32_t*)(ctrl_d + 2);
+            SolveQ qd{p->hybrid_dfsph_max_avg_divergence_error, 0, p->max_iters, T_VEL, false};
+            SolveQ qs{p->hybrid_dfsph_max_avg_density_error, 1, p->max_iters, T_HYBRID, true};
+            const int kind = p->hybrid_dfsph_density_source_term == SPH_ONLY_DENSITY ? 2 : 1;
+            if ((rc = solve_begin(G, M, qd, c0->last_div_iters))) return rc;
+            for (bool div_done = false;;) {
+                if (!div_done) {
+                    m.a.gate = nullptr;
+                    if ((rc = solve_queue(G, M, qd))) return rc;
+                    launch_solver_handoff(c->stream, &c->prof, ctrl_d, c->ctrl_host_dev + 1, gate);
+                    g_trace.mark(4);
+                    rec(3);
+                    rec(4);
+                    m.a.gate = gate;
+                    begin_solve(kind, 1);   // the density solve from its start
+                    if ((rc = solve_begin(G, M, qs, c0->last_dens_iters))) return rc;
+                }
+                if ((rc = solve_queue(G, M, qs))) return rc;
+                if ((rc = sync_ctrl(G))) return rc;
+                if (!div_done) {
+                    const SolverCtrl dv = c->ctrl_host[1];
+                    if (!dv.done) {   // the divergence solve fell short: nothing of the density solve ran
+                        if (qd.k > p->max_iters) return c->fail(SPH_ERR_DEVICE, "divergence solve: no decision after max_iters iterations");
+                        qd.extend();
+                        continue;
+                    }
+                    div_done = true;
+                    solve_stats(m, qd, dv);
+                }
+                if (c->ctrl_host->done) break;
+                if (qs.k > p->max_iters) break;
+                qs.extend();
+            }
+            m.a.gate = nullptr;
+            solve_stats(m, qs, *c->ctrl_host);
+            g_trace.mark(5);
+            rec(5);
+            break;
+        }
         if ((rc = pressure_iterations(G, M, p->hybrid_dfsph_max_avg_divergence_error, 0, p->max_iters, c0->last_div_iters, T_VEL, false, false))) return rc;
         g_trace.mark(4);
         rec(3);
@@ -2412,6 +2491,7 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
         g_trace.mark(5);
         rec(5);
         break;
+    }
     }
     rec(6);
     if (p->viscosity_type == SPH_VISC_XSPH)  // simulation.rs:2673-2676
@@ -2470,6 +2550,7 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
         // (constrain_neighborhood_count left reduced smoothing lengths in the records: the next step's k_header restores them)
         c->hdr_ahead = h_from_mass_mode && m.n > 0 && m.a.hdr_partials != nullptr && !p->constrain_neighborhood_count;
         c->hdr_ahead_rest_density = p->rest_density;
+        c->prev_div_iters = c->last_div_iters;
         c->last_div_iters = m.st.div_solver.iters;
         c->last_dens_iters = m.st.density_solver.iters;
         c->time += dt_step;  // simulation.rs:2724-2725

@@ -971,6 +971,7 @@ struct OpSource {
     int residual_density;
     float* __restrict__ omega;              // OMEGA only
     const uint8_t* __restrict__ size_class;
+    const uint32_t* __restrict__ gate;      // chained solves (else nullptr): 0 = the solve before this one has not ended, leave
     struct Acc {
         float sum, rho_i, inv_rho_i, qx, qy;
         float err;
@@ -978,6 +979,7 @@ struct OpSource {
         float om, om_c;   // OMEGA: running omega and H_i / (3 rho_i)
         bool large;
     };
+    __device__ bool prologue(uint32_t) const { return gate && *gate == 0u; }
     __device__ bool skip() const { return false; }
     __device__ bool lane_skip(uint32_t) const { return false; }
     __device__ void init(Acc&) const {}
@@ -1240,6 +1242,7 @@ struct OpPressureAccel {
     SolveP solve;
     int iter;  // >= 1: Jacobi iteration `iter`; < 0: explicit sweep with the solve's final pressures (IISPH2 after its rescaling)
     const uint8_t* __restrict__ owned_flag;   // slab decomposition (else nullptr): ring-1 ghost lanes compute a^p as well
+    const uint32_t* __restrict__ gate;        // chained solves (else nullptr), see OpSource
     struct Acc {
         float ax, ay, p1t;
         const float* pt;
@@ -1248,6 +1251,7 @@ struct OpPressureAccel {
     __device__ bool skip() const { return false; }
     __device__ bool prologue(uint32_t raw_block) const
     {
+        if (gate && *gate == 0u) return true;
         if (iter < 0) return ctrl->done == 0u;
         if (ctrl->slot_done[(iter - 1) & 1] != 0u) {   // the solve ended before this launch: hand the flag on, leave
             if (raw_block == 0u && threadIdx.x == 0 && !solve.multi) ctrl->slot_done[iter & 1] = 1u;
@@ -1307,8 +1311,9 @@ struct OpPressureAccel {
 __global__ __launch_bounds__(256) void k_solver_tail(uint32_t n, int tail, float dt, float vfactor, const float4* __restrict__ pm, float4* __restrict__ pm_out,
                                                       float2* __restrict__ vel, const float2* __restrict__ pacc, const uint32_t* __restrict__ orig,
                                                       const uint8_t* __restrict__ owned, const SolverCtrl* __restrict__ ctrl, HeaderOut* __restrict__ hdr_partials,
-                                                      DeviceStatus* status)
+                                                      DeviceStatus* status, const uint32_t* __restrict__ gate)
 {
+    if (gate && *gate == 0u) return;
     if (ctrl->done == 0u) return;
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     const bool active = i < n && (!owned || owned[i]);
@@ -1408,11 +1413,13 @@ struct OpJacobi {
     };
     SolveP solve;
     const double* __restrict__ tot;
+    const uint32_t* __restrict__ gate;   // chained solves (else nullptr), see OpSource
     __device__ bool skip() const { return false; }
     // the decision on iteration iter - 1: taken by block 0 of A(iter) (single rank), or -- slab decomposition -- evaluated here by
     // every block from the all-reduced totals, published by block 0 for the launches behind this one
     __device__ bool prologue(uint32_t raw_block) const
     {
+        if (gate && *gate == 0u) return true;
         if (!solve.multi) return ctrl->slot_done[iter & 1] != 0u;
         return solver_decide_multi(tot, ctrl, iter - 1, solve, sp.rest_density, sp.dt, raw_block == 0u && threadIdx.x == 0);
     }
@@ -2396,11 +2403,11 @@ void launch_source_term(hipStream_t s, Profiler* prof, const SweepArgs& a, int k
     ProfScope ps(prof, "source_term", s);
     if (kind == 3) {
         SPH_DISPATCH(OpSourceOmega, false, a.pm, a.orig, a.rho, a.mrho, a.vel, a.lam_grad, a.aii, a.src, a.p1, a.pt1, a.dens_err,
-                     (SolverPartial*)a.partials, a.ctrl, a.status, a.sp, kind, residual_density, a.omega, a.size_class)
+                     (SolverPartial*)a.partials, a.ctrl, a.status, a.sp, kind, residual_density, a.omega, a.size_class, a.gate)
         return;
     }
     SPH_DISPATCH(OpSourcePlain, false, a.pm, a.orig, a.rho, a.mrho, a.vel, a.lam_grad, a.aii, a.src, a.p1, a.pt1, a.dens_err,
-                 (SolverPartial*)a.partials, a.ctrl, a.status, a.sp, kind, residual_density, nullptr, nullptr)
+                 (SolverPartial*)a.partials, a.ctrl, a.status, a.sp, kind, residual_density, nullptr, nullptr, a.gate)
 }
 
 void launch_pressure_accel(hipStream_t s, Profiler* prof, const SweepArgs& a, int iter, int residual_density, float max_avg_error, uint32_t max_iters, int multi)
@@ -2408,7 +2415,7 @@ void launch_pressure_accel(hipStream_t s, Profiler* prof, const SweepArgs& a, in
     ProfScope ps(prof, "pressure_accel", s);
     const SolveP q{residual_density, max_avg_error, max_iters, multi};
     SPH_DISPATCH(OpPressureAccel, false, a.pm, a.orig, a.rho, a.p0, a.p1, a.pt0, a.pt1, a.lam_grad, a.pacc, a.ctrl, (const SolverPartial*)a.partials,
-                 solver_reduce_blocks(a.n), a.solver_tot, a.status, a.sp, q, iter, a.owned)
+                 solver_reduce_blocks(a.n), a.solver_tot, a.status, a.sp, q, iter, a.owned, a.gate)
 }
 
 void launch_solver_tail(hipStream_t s, Profiler* prof, const SweepArgs& a, int tail, float4* pm_out)
@@ -2416,7 +2423,24 @@ void launch_solver_tail(hipStream_t s, Profiler* prof, const SweepArgs& a, int t
     ProfScope ps(prof, "solver_tail", s);
     if (a.n && tail != TAIL_NONE)
         hipLaunchKernelGGL(k_solver_tail, dim3((a.n + 255) / 256), dim3(256), 0, s, a.n, tail, a.sp.dt, a.sp.hyb_vfactor, a.pm, pm_out, a.vel, a.pacc, a.orig,
-                           a.owned, a.ctrl, tail >= TAIL_VX ? a.hdr_partials : nullptr, a.status);
+                           a.owned, a.ctrl, tail >= TAIL_VX ? a.hdr_partials : nullptr, a.status, a.gate);
+}
+
+// Chained solves (HybridDFSPH, one context): the host does not wait between the divergence solve and the density solve.  Behind
+// the first solve's tail this kernel hands its control block to the host (mapped memory, read after the step's final wait) and
+// opens the gate of the second solve's launches only if the first one ended within its queued iterations.
+__global__ void k_solver_handoff(const SolverCtrl* __restrict__ ctrl, SolverCtrl* __restrict__ saved_host, uint32_t* __restrict__ gate)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const SolverCtrl v = *ctrl;
+    *saved_host = v;
+    __threadfence_system();
+    *gate = v.done ? 1u : 0u;
+}
+void launch_solver_handoff(hipStream_t s, Profiler* prof, SolverCtrl* ctrl, SolverCtrl* saved_host, uint32_t* gate)
+{
+    ProfScope ps(prof, "solver_handoff", s);
+    hipLaunchKernelGGL(k_solver_handoff, dim3(1), dim3(64), 0, s, ctrl, saved_host, gate);
 }
 
 void launch_jacobi_update(hipStream_t s, Profiler* prof, const SweepArgs& a, int iter, int residual_density, float max_avg_error, uint32_t max_iters, int multi)
@@ -2427,7 +2451,7 @@ void launch_jacobi_update(hipStream_t s, Profiler* prof, const SweepArgs& a, int
     float* ptout = (iter & 1) ? a.pt0 : a.pt1;
     const SolveP q{residual_density, max_avg_error, max_iters, multi};
     SPH_DISPATCH(OpJacobi, false, a.pm, a.orig, a.rho, a.mrho, a.pacc, a.lam_grad, a.aii, a.src, pin, pout, ptout, a.dens_err, (SolverPartial*)a.partials, a.ctrl,
-                 a.status, a.sp, iter, residual_density, q, a.solver_tot)
+                 a.status, a.sp, iter, residual_density, q, a.solver_tot, a.gate)
 }
 
 void launch_solver_decide(hipStream_t s, Profiler* prof, const SweepArgs& a, int iter, int residual_density, float max_avg_error,

@@ -1,0 +1,59 @@
+"""HybridDFSPH on one context: the density solve is queued behind the divergence solve without a host wait in between (chained
+solves, sph_step.hip), its launches gated on the device.  Whatever the gate does -- open at once, or closed because the divergence
+solve needed more iterations than were queued, so that both solves are queued again -- the step must be the step: every field
+and every iteration count bit for bit what the two-wait form gives."""
+import numpy as np
+import pytest
+
+from adaptive_sph_amd import ffi, scene as sc
+from adaptive_sph_amd.workloads import dam_break_params
+
+pytestmark = pytest.mark.gpu
+
+
+def run(product_lib, monkeypatch, chain, steps, **overrides):
+    monkeypatch.setenv("SPH_CHAIN", chain)
+    scn = sc.dam_break_small(128, 96, 1 / 64)
+    pos, mass, vel = sc.init_particles(scn)
+    P = dam_break_params(**overrides)
+    g = ffi.Context(product_lib, len(mass), sc.boundary_planes(scn.boundary, P.init_boundary_handler))
+    g.upload(mass, pos, vel)
+    p = P.to_ffi()
+    its = []
+    for _ in range(steps):
+        st = g.step(p)
+        its.append((int(st.div_solver.iters), int(st.density_solver.iters), int(st.div_solver.normal_count), int(st.density_solver.normal_count),
+                    np.float32(st.div_solver.avg_error).view(np.uint32).item(), np.float32(st.density_solver.avg_error).view(np.uint32).item()))
+    waits = g.dist_get_stats()["host_waits"]
+    monkeypatch.delenv("SPH_CHAIN")
+    return g, its, waits
+
+
+@pytest.mark.parametrize("overrides", [dict(), dict(hybrid_dfsph_density_source_term="OnlyDensity")])
+def test_chained_solves_are_bit_identical_to_the_two_wait_form(product_lib, monkeypatch, overrides):
+    steps = 40
+    a, ia, wa = run(product_lib, monkeypatch, "1", steps, **overrides)
+    b, ib, wb = run(product_lib, monkeypatch, "0", steps, **overrides)
+    assert ia == ib
+    div = [t[0] for t in ia]
+    assert max(div) > min(div) and any(div[k + 1] > div[k] for k in range(len(div) - 1))   # a chained divergence solve fell short at least once
+    assert wa < wb                                                                        # fewer host waits when chained
+    for f in ("position", "velocity", "density", "pressure", "aii", "ppe_source_term", "neighbor_count"):
+        assert np.array_equal(a.download(f), b.download(f)), f
+
+
+def test_default_policy_chains_once_the_iteration_count_repeats(product_lib, monkeypatch):
+    monkeypatch.delenv("SPH_CHAIN", raising=False)
+    scn = sc.dam_break_small(128, 96, 1 / 64)
+    pos, mass, vel = sc.init_particles(scn)
+    P = dam_break_params(hybrid_dfsph_max_avg_density_error=0.0, hybrid_dfsph_max_avg_divergence_error=0.0, max_iters=3)   # the divergence solve's count pinned
+    g = ffi.Context(product_lib, len(mass), sc.boundary_planes(scn.boundary, P.init_boundary_handler))
+    g.upload(mass, pos, vel)
+    p = P.to_ffi()
+    for _ in range(4):
+        g.step(p)
+    g.dist_get_stats(reset=True)
+    for _ in range(10):
+        st = g.step(p)
+        assert st.div_solver.iters == 3
+    assert g.dist_get_stats()["host_waits"] == 10      # one wait per step: header from the previous step's tail, solves chained
