@@ -303,14 +303,18 @@ __global__ __launch_bounds__(256) void k_ext_counts(uint32_t n, const uint4* __r
 __global__ __launch_bounds__(256) void k_fill_neighbors(uint32_t n, GridP g, TileP t, const uint32_t* __restrict__ cell_start,
                                                          const uint32_t* __restrict__ cxy, const uint32_t* __restrict__ orig,
                                                          const float4* __restrict__ pm, const uint32_t* __restrict__ offsets_host,
-                                                         uint32_t* __restrict__ indices, float k)
+                                                         uint32_t* __restrict__ indices, float k, const uint32_t* __restrict__ rowmap)
 {
     uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
+    // rowmap (slab context): row of slot i in the export = its rank among the owned slots, 0xffffffff for a ghost; the
+    // neighbours are named by their global ids (ghosts carry theirs)
+    const uint32_t row = rowmap ? rowmap[i] : orig[i];
+    if (row == 0xffffffffu) return;
     const float4 Ai = pm[i];
     const uint32_t c = cxy[i];
     const int cx = c & 0xffffu, cy = c >> 16;
-    uint32_t w = offsets_host[orig[i]];
+    uint32_t w = offsets_host[row];
     const int R = stencil_radius(g, t, Ai.w, cx, cy, k);
     for (int dy = -R; dy <= R; dy++) {
         int yy = cy + dy;
@@ -984,10 +988,50 @@ extern "C" int sph_download_neighbors(sph_ctx* c, uint32_t* offsets, uint32_t* i
     HIPCHK(c, hipSetDevice(c->device));
     const uint32_t n = (uint32_t)c->n;
     if (!c->grid_valid) return c->fail(SPH_ERR_INVALID_ARGUMENT, "no neighbour lists yet: run a step first");
-    if (c->dist.on) return c->fail(SPH_ERR_UNSUPPORTED, "neighbour-list export of a slab context is not covered yet");
     std::vector<uint32_t> cnt(n), off((size_t)n + 1);
     int rc = SPH_OK;
     hipStream_t s = c->stream;
+    if (c->dist.on) {
+        // Slab context: one row per OWNED particle, in the order of sph_download(SPH_F_PARTICLE_ID); the indices are global particle
+        // ids (an owned particle's neighbours are all among owned + ghosts, and the ghost records carry their ids).
+        if (!c->dist.have_flags) return c->fail(SPH_ERR_INVALID_ARGUMENT, "no neighbour lists yet: run a step first");
+        const uint32_t nt = c->dist.n_tot;
+        rc = sph_download(c, SPH_F_NEIGHBOR_COUNT, cnt.data(), (uint64_t)n * 4);
+        if (rc) return rc;
+        std::vector<uint8_t> flags(nt);
+        if (nt) HIPCHK(c, hipMemcpy(flags.data(), c->dist.owned.p, nt, hipMemcpyDeviceToHost));
+        std::vector<uint32_t> rowmap(nt);
+        uint32_t w = 0;
+        for (uint32_t i = 0; i < nt; i++) rowmap[i] = flags[i] ? w++ : 0xffffffffu;
+        if (w != n) return c->fail(SPH_ERR_DEVICE, "owned-particle count mismatch");
+        uint64_t tot = 0;
+        for (uint32_t i = 0; i < n; i++) {
+            off[i] = (uint32_t)tot;
+            tot += cnt[i];
+        }
+        off[n] = (uint32_t)tot;
+        if (n_indices) *n_indices = tot;
+        if (offsets) memcpy(offsets, off.data(), ((size_t)n + 1) * 4);
+        if (!indices) return SPH_OK;
+        if (cap < tot) return c->fail(SPH_ERR_INVALID_ARGUMENT, "indices buffer too small");
+        if (tot == 0) return SPH_OK;
+        DevBuf d_off, d_idx, d_row;
+        HIPCHK(c, d_off.ensure(((size_t)n + 1) * 4));
+        HIPCHK(c, d_idx.ensure((size_t)tot * 4));
+        HIPCHK(c, d_row.ensure((size_t)nt * 4));
+        HIPCHK(c, hipMemcpyAsync(d_off.p, off.data(), ((size_t)n + 1) * 4, hipMemcpyHostToDevice, s));
+        HIPCHK(c, hipMemcpyAsync(d_row.p, rowmap.data(), (size_t)nt * 4, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_fill_neighbors, dim3((nt + 255) / 256), dim3(256), 0, s, nt, c->fgrid,
+                           TileP{c->tile_ts, c->tile_tsx, c->tile_tsy, c->tile_h.as<uint32_t>(), 0.f}, c->cell_start.as<uint32_t>(), c->cxy.as<uint32_t>(),
+                           c->orig[c->cur].as<uint32_t>(), c->pm[c->pcur ^ 1].as<float4>(), d_off.as<uint32_t>(), d_idx.as<uint32_t>(), 2.f,
+                           d_row.as<uint32_t>());
+        HIPCHK(c, hipMemcpyAsync(indices, d_idx.p, (size_t)tot * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+        d_off.release();
+        d_idx.release();
+        d_row.release();
+        return SPH_OK;
+    }
     // level_estimation_after_advection: `self.neighs` was rebuilt at the end of the step (simulation.rs:2678-2689) -- the cache
     // then holds the EXTENDED lists of the ADVECTED positions, and that is what the host's partner searches iterate
     const bool ext = c->lists_after;
@@ -1020,12 +1064,12 @@ extern "C" int sph_download_neighbors(sph_ctx* c, uint32_t* offsets, uint32_t* i
     if (!ext)
         hipLaunchKernelGGL(k_fill_neighbors, dim3((n + 255) / 256), dim3(256), 0, s, n, c->fgrid,
                            TileP{c->tile_ts, c->tile_tsx, c->tile_tsy, c->tile_h.as<uint32_t>(), 0.f}, c->cell_start.as<uint32_t>(), c->cxy.as<uint32_t>(),
-                           c->orig[c->cur].as<uint32_t>(), c->pm[c->pcur ^ 1].as<float4>(), d_off.as<uint32_t>(), d_idx.as<uint32_t>(), 2.f);
+                           c->orig[c->cur].as<uint32_t>(), c->pm[c->pcur ^ 1].as<float4>(), d_off.as<uint32_t>(), d_idx.as<uint32_t>(), 2.f, (const uint32_t*)nullptr);
     else   // cells (cxy) of the pre-step positions, geometry of the advected ones (pm[pcur]), ranges widened by the slack
         hipLaunchKernelGGL(k_fill_neighbors, dim3((n + 255) / 256), dim3(256), 0, s, n, c->fgrid,
                            TileP{c->tile_ts, c->tile_tsx, c->tile_tsy, c->tile_h_ext.as<uint32_t>(), c->lists_after_slack}, c->cell_start.as<uint32_t>(),
                            c->cxy.as<uint32_t>(), c->orig[c->cur].as<uint32_t>(), c->pm[c->pcur].as<float4>(), d_off.as<uint32_t>(), d_idx.as<uint32_t>(),
-                           c->lists_after_k);
+                           c->lists_after_k, (const uint32_t*)nullptr);
     HIPCHK(c, hipMemcpyAsync(indices, d_idx.p, (size_t)tot * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
     d_off.release();

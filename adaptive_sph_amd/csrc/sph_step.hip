@@ -358,10 +358,10 @@ __global__ __launch_bounds__(256) void k_unpack_migrants(uint32_t base, uint32_t
     szc[i] = (uint8_t)__float_as_uint(r[11]);
 }
 
-// ghost record (static per step): x, y, m, h, vx, vy
-#define GHOST_WORDS 6
+// ghost record (static per step): x, y, m, h, vx, vy, id (the neighbour-list export of a slab names ghosts by their global id)
+#define GHOST_WORDS 7
 __global__ __launch_bounds__(256) void k_pack_ghosts(const uint32_t* __restrict__ idx, uint32_t cnt, const float4* __restrict__ pm,
-                                                      const float2* __restrict__ vel, float* __restrict__ rec)
+                                                      const float2* __restrict__ vel, const uint32_t* __restrict__ orig, float* __restrict__ rec)
 {
     uint32_t k = blockIdx.x * 256 + threadIdx.x;
     if (k >= cnt) return;
@@ -370,6 +370,7 @@ __global__ __launch_bounds__(256) void k_pack_ghosts(const uint32_t* __restrict_
     const float2 v = vel[i];
     float* r = rec + (size_t)k * GHOST_WORDS;
     r[0] = p.x; r[1] = p.y; r[2] = p.z; r[3] = p.w; r[4] = v.x; r[5] = v.y;
+    r[6] = __uint_as_float(orig[i]);
 }
 __global__ __launch_bounds__(256) void k_unpack_ghosts(uint32_t base, uint32_t cnt, const float* __restrict__ rec, float4* __restrict__ pm,
                                                         float2* __restrict__ vel, uint32_t* __restrict__ orig, float* __restrict__ lvl,
@@ -384,7 +385,7 @@ __global__ __launch_bounds__(256) void k_unpack_ghosts(uint32_t base, uint32_t c
     ring1_src[ord_base + k] = (side == 0 ? r[0] >= ring_edge : r[0] < ring_edge) ? 1 : 0;
     pm[i] = make_float4(r[0], r[1], r[2], r[3]);
     vel[i] = make_float2(r[4], r[5]);
-    orig[i] = 0xffffffffu;
+    orig[i] = __float_as_uint(r[6]);
     lvl[i] = __uint_as_float(0x7fc00000u);
     lvlold[i] = 0.f;
 }
@@ -1421,7 +1422,7 @@ static int build_ghost_layer(Group& G, std::vector<Member>& M, float halo_width,
             const uint32_t cnt = d.n_halo[side], off = side == 0 ? 0 : d.n_halo[0];
             if (cnt)
                 hipLaunchKernelGGL(k_pack_ghosts, dim3((cnt + 255) / 256), dim3(256), 0, c->stream, d.halo_idx.as<uint32_t>() + off, cnt,
-                                   c->pm[c->pcur].as<float4>(), c->vel[k].as<float2>(), d.send[side].as<float>());
+                                   c->pm[c->pcur].as<float4>(), c->vel[k].as<float2>(), c->orig[k].as<uint32_t>(), d.send[side].as<float>());
             x[i].send[side] = d.send[side].p;
             x[i].send_bytes[side] = (size_t)cnt * GHOST_WORDS * 4;
             x[i].recv[side] = d.recv[side].p;
@@ -1563,7 +1564,7 @@ static int slab_refresh_fused(Group& G, std::vector<Member>& M, std::vector<std:
             const uint32_t cnt = d.n_halo[side], off = side == 0 ? 0 : d.n_halo[0];
             if (cnt)
                 hipLaunchKernelGGL(k_pack_ghosts, dim3((cnt + 255) / 256), dim3(256), 0, c->stream, d.halo_idx.as<uint32_t>() + off, cnt,
-                                   c->pm[c->pcur].as<float4>(), c->vel[k].as<float2>(), d.send[side].as<float>());
+                                   c->pm[c->pcur].as<float4>(), c->vel[k].as<float2>(), c->orig[k].as<uint32_t>(), d.send[side].as<float>());
             x[i].send[side] = d.send[side].p;
             x[i].send_bytes[side] = (size_t)cnt * GHOST_WORDS * 4;
             x[i].recv[side] = d.recv[side].p;

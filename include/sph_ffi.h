@@ -313,7 +313,9 @@ int  sph_download(sph_ctx* ctx, int field, void* dst, uint64_t dst_bytes);
  * (neighborhood_search.rs:143-146, 187-238).  Order within a list is unspecified (the reference's
  * is R*-tree traversal order).  After a step with level_estimation_after_advection the cache holds what
  * the reference rebuilt at the end of the step (simulation.rs:2678-2689): the lists of the ADVECTED positions
- * with range (h_i+h_j)/2 * level_estimation_range / 1.9. */
+ * with range (h_i+h_j)/2 * level_estimation_range / 1.9.
+ * Slab context: one row per OWNED particle in the order of sph_download(SPH_F_PARTICLE_ID); the indices are global particle ids
+ * (an owned particle's neighbours are all among the rank's owned particles and ghosts, and ghost records carry their ids). */
 int  sph_download_neighbors(sph_ctx* ctx, uint32_t* offsets, uint32_t* indices, uint64_t indices_capacity,
                             uint64_t* n_indices);
 
@@ -386,6 +388,9 @@ int sph_set_sweep_variant(int mode);
  * ring compute their own pressure acceleration) with the x-neighbours over RCCL point-to-point after every sweep whose
  * output neighbours read -- once per Jacobi iteration --, and all-reduces the CFL minimum and the Jacobi residual
  * statistics so that every rank takes the same decisions.  A slab narrower than two ghost layers is refused.
+ * Every rank makes the SAME sequence of calls with the same parameters (sph_step, sph_upload*, sph_dist_set_rebalance): which
+ * collectives a step runs depends on that history (an ordinary step maintains the slabs in one round trip of counts, the first
+ * step after an upload and re-balancing steps take two or more), not on anything a rank could decide alone.
  * sph_group_step steps k contexts of ONE process as ranks 0..k-1 with plain copies as transport (one GPU or
  * several): same algorithm, used to verify the decomposition against a single context. */
 int  sph_dist_configure(sph_ctx* ctx, int rank, int n_ranks, float cut_lo, float cut_hi);

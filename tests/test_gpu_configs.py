@@ -94,6 +94,18 @@ def test_config3_dam_break_8m_eight_slabs_against_the_single_context(product_lib
         assert rel_err(D.gather_by_id(grp, f, n), single.download(f)) <= tol, f
     st = grp[3].dist_get_stats()
     assert st["n_ghost"][0] > 0 and st["n_ghost"][1] > 0 and st["exchanges"] > 0    # an inner slab has two neighbours
+    # the slabs' neighbour lists (global ids, ghosts included) are the single context's: per particle equal counts, equal sums
+    # and sums of squares of the neighbour ids (exact integer arithmetic)
+    so, si = single.download_neighbors()
+    starts = so[:-1].astype(np.int64)
+    ref = [np.add.reduceat(si.astype(np.uint64) ** power, starts) for power in (1, 2)]
+    del si
+    for c in grp:
+        pid = c.download("particle_id")
+        off, idx = c.download_neighbors()
+        assert np.array_equal(np.diff(off.astype(np.int64)), np.diff(so.astype(np.int64))[pid])
+        for power in (1, 2):
+            assert np.array_equal(np.add.reduceat(idx.astype(np.uint64) ** power, off[:-1].astype(np.int64)), ref[power - 1][pid]), power
 
 
 def test_config4_ratio_stress_4m_against_the_oracle(product_lib, oracle_lib):

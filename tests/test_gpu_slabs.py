@@ -250,6 +250,40 @@ def test_fused_refresh_is_bit_identical_to_the_general_path(product_lib, monkeyp
             assert np.array_equal(a.download(f), b.download(f)), f
 
 
+@pytest.mark.parametrize("k", [2, 3])
+def test_neighbour_lists_of_the_slabs_are_those_of_the_single_context(product_lib, k):
+    """sph_download_neighbors on a slab context: one row per owned particle (the order of the particle_id download), neighbours
+    named by their global ids -- ghosts included.  Over all ranks: exactly the single context's lists, as sets, bit for bit."""
+    scn = sc.dam_break_small(96, 48, 1 / 48)
+    pos, mass, vel = sc.init_particles(scn)
+    vel = vel.copy()
+    vel[:, 0] = 0.8
+    planes = sc.boundary_planes(scn.boundary)
+    p = forced(max_iters=3).to_ffi()
+    single = ffi.Context(product_lib, len(mass), planes)
+    single.upload(mass, pos, vel)
+    grp = D.make_loopback_group(product_lib, pos, mass, vel, planes, k)
+    for s in range(12):
+        single.step(p)
+        ffi.group_step(grp, p)
+    so, si = single.download_neighbors()
+    n = len(mass)
+    seen = np.zeros(n, bool)
+    crossing = 0
+    for c in grp:
+        ids = c.download("particle_id")
+        off, idx = c.download_neighbors()
+        assert len(off) == c.n + 1 and off[-1] == len(idx) and idx.max() < n
+        assert np.array_equal(np.diff(off.astype(np.int64)), c.download("neighbor_count"))
+        mine = np.zeros(n, bool)
+        mine[ids] = True
+        crossing += int((~mine[idx]).sum())                       # neighbours that are another rank's particles
+        for r, pid in enumerate(ids):
+            assert np.array_equal(np.sort(idx[off[r]:off[r + 1]]), np.sort(si[so[pid]:so[pid + 1]])), pid
+        seen[ids] = True
+    assert seen.all() and crossing > 0
+
+
 def test_group_of_one_is_the_plain_step(product_lib):
     scn = sc.dam_break_small(32, 32, 1 / 32)
     pos, mass, vel = sc.init_particles(scn)
