@@ -173,6 +173,7 @@ void launch_non_pressure(hipStream_t s, Profiler* prof, const SweepArgs& a);    
 void launch_source_term(hipStream_t s, Profiler* prof, const SweepArgs& a, int kind, int residual_density);  // kind: 0 div, 1 full, 2 only-density; includes Jacobi iteration 0
 // sweep A of iteration iter >= 1 (+ the stop decision of iteration iter - 1, taken by its block 0); iter < 0: a^p from the solve's final pressures
 void launch_pressure_accel(hipStream_t s, Profiler* prof, const SweepArgs& a, int iter, int residual_density, float max_avg_error, uint32_t max_iters, int multi);
+void launch_ctrl_reset(hipStream_t s, SolverCtrl* ctrl, const uint32_t* gate);
 void launch_solver_handoff(hipStream_t s, Profiler* prof, SolverCtrl* ctrl, SolverCtrl* saved_host, uint32_t* gate);
 void launch_solver_tail(hipStream_t s, Profiler* prof, const SweepArgs& a, int tail, float4* pm_out);   // integrate map of the solver mode, once the solve is done
 void launch_jacobi_update(hipStream_t s, Profiler* prof, const SweepArgs& a, int iter, int residual_density, float max_avg_error, uint32_t max_iters, int multi);

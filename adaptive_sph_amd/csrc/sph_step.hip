@@ -645,7 +645,7 @@ struct Comm {
     // device buffers; ordered after everything queued on the members' streams
     virtual int exchange(Group& G, std::vector<Xfer>& x) = 0;
     // element-wise sum of the members' 6 device doubles (solver totals + error flag), result in every member's buffer
-    virtual int allreduce_solver(Group& G) = 0;
+    virtual int allreduce_solver(Group& G, int slot) = 0;   // slot 1: the second solve of a chained pair keeps totals of its own
     virtual bool host_collectives_wait() const = 0;
     // ONE round trip for a decomposition phase: the class counts the phase's classify kernel left in dist.counts[base ..
     // base + 3] (1 = to the left neighbour, 2 = to the right, 3 = dropped / too narrow; class 0 is derived by the caller) reach
@@ -793,17 +793,17 @@ struct LocalComm : Comm {
         return SPH_OK;
     }
     int agree_guards_queued(Group&) override { return SPH_OK; }   // one process: sync_ctrl sees every member's guard word
-    int allreduce_solver(Group& G) override
+    int allreduce_solver(Group& G, int slot) override
     {
         int rc = wait_all(G);
         if (rc) return rc;
         double tot[6] = {0, 0, 0, 0, 0, 0};
         std::vector<std::array<double, 6>> rows(G.m.size());
         for (size_t i = 0; i < G.m.size(); i++) {
-            HIPCHK(G.m[i], hipMemcpy(rows[i].data(), G.m[i]->dist.solver_tot.p, 48, hipMemcpyDeviceToHost));
+            HIPCHK(G.m[i], hipMemcpy(rows[i].data(), G.m[i]->dist.solver_tot.as<double>() + 8 * slot, 48, hipMemcpyDeviceToHost));
             for (int k = 0; k < 6; k++) tot[k] += rows[i][k];
         }
-        for (auto c : G.m) HIPCHK(c, hipMemcpy(c->dist.solver_tot.p, tot, 48, hipMemcpyHostToDevice));
+        for (auto c : G.m) HIPCHK(c, hipMemcpy(c->dist.solver_tot.as<double>() + 8 * slot, tot, 48, hipMemcpyHostToDevice));
         return SPH_OK;
     }
 };
@@ -1025,12 +1025,13 @@ struct RcclComm : Comm {
         NCCLCHK(c, ncclGroupEnd());
         return SPH_OK;
     }
-    int allreduce_solver(Group& G) override
+    int allreduce_solver(Group& G, int slot) override
     {
         sph_ctx* c = G.m[0];
         c->dist.stat_allreduces++;
         ProfScope ps(&c->prof, "rccl_allreduce", c->stream);
-        NCCLCHK(c, ncclAllReduce(c->dist.solver_tot.p, c->dist.solver_tot.p, 6, ncclFloat64, ncclSum, (ncclComm_t)c->dist.nccl, c->stream));
+        double* t = c->dist.solver_tot.as<double>() + 8 * slot;
+        NCCLCHK(c, ncclAllReduce(t, t, 6, ncclFloat64, ncclSum, (ncclComm_t)c->dist.nccl, c->stream));
         return SPH_OK;
     }
 };
@@ -1165,7 +1166,7 @@ static int ensure_dist_buffers(sph_ctx* c, uint32_t n)
         HIPCHK(c, d.recv[s].ensure(cap * MIG_WORDS * 4 / 2 + 1024));
     }
     HIPCHK(c, d.counts.ensure(256));
-    HIPCHK(c, d.solver_tot.ensure(64));
+    HIPCHK(c, d.solver_tot.ensure(128));   // two slots of 6 doubles (chained solves)
     HIPCHK(c, d.cls.ensure(cap));
     HIPCHK(c, d.blk.ensure(((cap + 255) / 256) * 8 * sizeof(uint32_t)));
     if (!d.counts_host) {
@@ -1624,6 +1625,7 @@ struct SolveQ {
     uint32_t max_iters;
     int tail;
     bool density_solver;
+    int tot_slot = 0;   // slab decomposition: which totals buffer the solve all-reduces (1: the gated solve of a chained pair)
     uint32_t k = 1, upto = 2;
     void extend() { upto = k + std::max(1u, k / 4u); }   // a quarter more iterations per wait, at least one: a skipped
                                                          // iteration costs two empty launches (~9 us), a wait the round trip to the host
@@ -1641,11 +1643,11 @@ static int solve_sweep_a(Group& G, std::vector<Member>& M, const SolveQ& q, uint
             z.slot_done[0] = z.slot_done[1] = 1u;
             z.cur = k & 1u;
             (void)hipMemcpyAsync(m.c->ctrl.p, &z, sizeof z, hipMemcpyHostToDevice, m.c->stream);
-        } else (void)hipMemsetAsync(m.c->dist.solver_tot.p, 0, 48, m.c->stream);   // an empty slab contributes zeros
+        } else (void)hipMemsetAsync(m.c->dist.solver_tot.as<double>() + 8 * q.tot_slot, 0, 48, m.c->stream);   // an empty slab contributes zeros
     }
     // slab decomposition: the totals of iteration k - 1 are all-reduced behind this sweep; the decision is evaluated by the
     // blocks of B(k) themselves (OpJacobi::prologue), or by k_solver_decide before a solve's tail
-    if (multi) return G.comm->allreduce_solver(G);
+    if (multi) return G.comm->allreduce_solver(G, q.tot_slot);
     return SPH_OK;
 }
 static int solve_begin(Group& G, std::vector<Member>& M, SolveQ& q, uint32_t predicted_iters)
@@ -2372,7 +2374,7 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
     auto begin_solve = [&](int kind, int residual_density) {
         for (auto& m : M) {
             (void)hipSetDevice(m.c->device);
-            if (!m.n) (void)hipMemsetAsync(m.c->ctrl.p, 0, sizeof(SolverCtrl), m.c->stream);   // else: reset by the source-term sweep
+            if (!m.n) launch_ctrl_reset(m.c->stream, m.c->ctrl.as<SolverCtrl>(), m.a.gate);   // else: reset by the source-term sweep
             if (m.n) launch_source_term(m.c->stream, &m.c->prof, m.a, kind, residual_density);  // + Jacobi iteration 0
         }
     };
@@ -2427,55 +2429,67 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
             if ((rc = non_pressure())) return rc;
         rec(2);
         begin_solve(0, 0);
-        // One context, forces in front of the divergence solve (the default): the two solves are CHAINED -- the density solve is
-        // queued right behind the divergence solve's tail, its launches gated on the device by "the divergence solve ended"
-        // (k_solver_handoff), and the step waits once, at its end.  If the divergence solve needed more iterations than were
-        // queued, the gated launches cost a few us each, and both are queued again from where the first one stands.
+        // Forces in front of the divergence solve (the default): the two solves are CHAINED -- the density solve is queued right
+        // behind the divergence solve's tail, its launches gated on the device by "the divergence solve ended" (k_solver_handoff),
+        // and the step waits once, at its end.  If the divergence solve needed more iterations than were queued, the gated
+        // launches cost a few us each, and both are queued again from where the first one stands.  On a slab decomposition the
+        // gated solve all-reduces into totals of its own; the exchanges queued behind a closed gate re-send what the ghosts
+        // already hold.
         // Chained only while the divergence solve's iteration count repeats from step to step (SPH_CHAIN=1: always, =0: never):
         // in the first steps of a dam break it jumps by factors (4, 15, 17, 7, ...), and a short-fall there throws away a
         // density solve's worth of gated launches (measured: 1.38 vs 1.27 ms/step over steps 5-24 when always chained).
+        // (parameters and all-reduced iteration counts only: every rank decides the same)
         const char* chain_env = getenv("SPH_CHAIN");
         const bool chain_wanted = chain_env ? chain_env[0] == '1' : c0->last_div_iters == c0->prev_div_iters;
-        const bool chain = !G.multi() && M[0].n > 0 && p->hybrid_dfsph_non_pressure_accel_before_divergence_free && chain_wanted;
+        const bool chain = (G.multi() || M[0].n > 0) && p->hybrid_dfsph_non_pressure_accel_before_divergence_free && chain_wanted;
         if (chain) {
-            Member& m = M[0];
-            sph_ctx* c = m.c;
-            SolverCtrl* ctrl_d = c->ctrl.as<SolverCtrl>();
-            uint32_t* gate = (uint32_t*)(ctrl_d + 2);
+            const int multi = G.multi() ? 1 : 0;
+            const bool final_solve = !level_on;
             SolveQ qd{p->hybrid_dfsph_max_avg_divergence_error, 0, p->max_iters, T_VEL, false};
             SolveQ qs{p->hybrid_dfsph_max_avg_density_error, 1, p->max_iters, T_HYBRID, true};
+            qs.tot_slot = 1;
             const int kind = p->hybrid_dfsph_density_source_term == SPH_ONLY_DENSITY ? 2 : 1;
+            auto set_gate = [&](bool on) {
+                for (auto& m : M) {
+                    m.a.gate = on ? (const uint32_t*)(m.c->ctrl.as<SolverCtrl>() + 2) : nullptr;
+                    m.a.solver_tot = m.c->dist.solver_tot.as<double>() + (on && m.c->dist.solver_tot.p ? 8 : 0);
+                }
+            };
             if ((rc = solve_begin(G, M, qd, c0->last_div_iters))) return rc;
             for (bool div_done = false;;) {
                 if (!div_done) {
-                    m.a.gate = nullptr;
+                    set_gate(false);
                     if ((rc = solve_queue(G, M, qd))) return rc;
-                    launch_solver_handoff(c->stream, &c->prof, ctrl_d, c->ctrl_host_dev + 1, gate);
+                    for (auto& m : M) {
+                        (void)hipSetDevice(m.c->device);
+                        launch_solver_handoff(m.c->stream, &m.c->prof, m.c->ctrl.as<SolverCtrl>(), m.c->ctrl_host_dev + 1, (uint32_t*)(m.c->ctrl.as<SolverCtrl>() + 2));
+                    }
                     g_trace.mark(4);
                     rec(3);
+                    if ((rc = refresh_ghosts(G, M, sel_vel, 2, "vel"))) return rc;  // v += dt a^p happened in the tail (or nothing did: the same values again)
                     rec(4);
-                    m.a.gate = gate;
+                    set_gate(true);
                     begin_solve(kind, 1);   // the density solve from its start
                     if ((rc = solve_begin(G, M, qs, c0->last_dens_iters))) return rc;
                 }
                 if ((rc = solve_queue(G, M, qs))) return rc;
-                if ((rc = sync_ctrl(G))) return rc;
+                if (multi && final_solve && (rc = G.comm->agree_guards_queued(G))) return rc;
+                if ((rc = sync_ctrl(G, multi ? (final_solve ? SYNC_FINAL : SYNC_DEFER) : SYNC_AGREE))) return rc;
                 if (!div_done) {
-                    const SolverCtrl dv = c->ctrl_host[1];
-                    if (!dv.done) {   // the divergence solve fell short: nothing of the density solve ran
-                        if (qd.k > p->max_iters) return c->fail(SPH_ERR_DEVICE, "divergence solve: no decision after max_iters iterations");
+                    if (!M[0].c->ctrl_host[1].done) {   // the divergence solve fell short: nothing of the density solve ran (on any rank)
+                        if (qd.k > p->max_iters) return c0->fail(SPH_ERR_DEVICE, "divergence solve: no decision after max_iters iterations");
                         qd.extend();
                         continue;
                     }
                     div_done = true;
-                    solve_stats(m, qd, dv);
+                    for (auto& m : M) solve_stats(m, qd, m.c->ctrl_host[1]);
                 }
-                if (c->ctrl_host->done) break;
+                if (M[0].c->ctrl_host->done) break;
                 if (qs.k > p->max_iters) break;
                 qs.extend();
             }
-            m.a.gate = nullptr;
-            solve_stats(m, qs, *c->ctrl_host);
+            set_gate(false);
+            for (auto& m : M) solve_stats(m, qs, *m.c->ctrl_host);
             g_trace.mark(5);
             rec(5);
             break;

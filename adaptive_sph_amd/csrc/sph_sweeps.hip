@@ -2029,10 +2029,18 @@ __global__ __launch_bounds__(256) void k_classify(uint32_t n, const float4* __re
 // stop decision of a slab decomposition: the ranks' totals of iteration `iter` (solver_reduce_decide, multi) were all-reduced
 // (RCCL, in stream); every rank takes the same decision here (stopping rule of iisph_pressure_iterations, simulation.rs:1453-1479)
 // ------------------------------------------------------------------------------------------------
-__global__ void k_solver_decide(const double* __restrict__ tot, SolverCtrl* ctrl, int iter, SolveP q, float rest_density, float dt)
+__global__ void k_solver_decide(const double* __restrict__ tot, SolverCtrl* ctrl, int iter, SolveP q, float rest_density, float dt, const uint32_t* __restrict__ gate)
 {
+    if (gate && *gate == 0u) return;   // chained solves: the solve before this one has not ended
     if (threadIdx.x == 0) solver_decide_multi(tot, ctrl, iter, q, rest_density, dt, true);
 }
+// an empty slab's control block at the start of a (possibly gated) solve
+__global__ void k_ctrl_reset(SolverCtrl* ctrl, const uint32_t* __restrict__ gate)
+{
+    if (gate && *gate == 0u) return;
+    if (threadIdx.x == 0 && blockIdx.x == 0) *ctrl = SolverCtrl{};
+}
+void launch_ctrl_reset(hipStream_t s, SolverCtrl* ctrl, const uint32_t* gate) { hipLaunchKernelGGL(k_ctrl_reset, dim3(1), dim3(64), 0, s, ctrl, gate); }
 
 // ------------------------------------------------------------------------------------------------
 // per-particle maps
@@ -2459,7 +2467,7 @@ void launch_solver_decide(hipStream_t s, Profiler* prof, const SweepArgs& a, int
 {
     ProfScope ps(prof, "solver_decide", s);
     hipLaunchKernelGGL(k_solver_decide, dim3(1), dim3(64), 0, s, a.solver_tot, a.ctrl, iter, SolveP{residual_density, max_avg_error, max_iters, 1},
-                       a.sp.rest_density, a.sp.dt);
+                       a.sp.rest_density, a.sp.dt, a.gate);
 }
 
 void launch_vel_add_pacc(hipStream_t s, Profiler* prof, const SweepArgs& a)

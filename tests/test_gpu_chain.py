@@ -57,3 +57,33 @@ def test_default_policy_chains_once_the_iteration_count_repeats(product_lib, mon
         st = g.step(p)
         assert st.div_solver.iters == 3
     assert g.dist_get_stats()["host_waits"] == 10      # one wait per step: header from the previous step's tail, solves chained
+
+
+def test_chained_solves_on_slabs_are_bit_identical_to_the_two_wait_form(product_lib, monkeypatch):
+    """The same on a slab decomposition (loopback transport, 3 ranks): the gated solve all-reduces into totals of its own, the
+    exchanges behind a closed gate re-send what the ghosts already hold."""
+    from adaptive_sph_amd import distributed as D
+    scn = sc.dam_break_small(128, 96, 1 / 64)      # from rest: the iteration counts of the first steps jump about
+    pos, mass, vel = sc.init_particles(scn)
+    planes = sc.boundary_planes(scn.boundary)
+    p = dam_break_params().to_ffi()
+    out = {}
+    for chain in ("1", "0"):
+        monkeypatch.setenv("SPH_CHAIN", chain)
+        grp = D.make_loopback_group(product_lib, pos, mass, vel, planes, 3)
+        its = []
+        for _ in range(40):
+            sts = ffi.group_step(grp, p)
+            its.append((int(sts[0].div_solver.iters), int(sts[0].density_solver.iters), int(sts[1].div_solver.normal_count), int(sts[2].density_solver.normal_count)))
+        out[chain] = (grp, its, sum(c.dist_get_stats()["host_waits"] for c in grp))
+    monkeypatch.delenv("SPH_CHAIN")
+    (ga, ia, wa), (gb, ib, wb) = out["1"], out["0"]
+    assert ia == ib
+    div = [t[0] for t in ia]
+    # a chained divergence solve fell short at least once (the first step predicts 2 iterations)
+    assert div[0] > 2 or any(div[k + 1] > max(div[k], 2) for k in range(len(div) - 1)), div
+    # (no statement about host waits here: the loopback transport waits in every exchange)
+    for a, b in zip(ga, gb):
+        assert a.n == b.n
+        for f in ("particle_id", "position", "velocity", "density", "pressure", "neighbor_count"):
+            assert np.array_equal(a.download(f), b.download(f)), f
