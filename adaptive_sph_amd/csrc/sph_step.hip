@@ -230,6 +230,16 @@ struct HostTrace {
 };
 static HostTrace g_trace;
 
+// SPH_DEBUG_SYNC=1 (fault hunting): synchronise and name the phase just queued
+static void dbg_sync(sph_ctx* c, const char* what, int id = 0)
+{
+    static const int mask = getenv("SPH_DEBUG_SYNC") ? atoi(getenv("SPH_DEBUG_SYNC")) : 0;   // bit per sync point
+    if (!(mask & (1 << id))) return;
+    (void)hipSetDevice(c->device);
+    const hipError_t e = hipStreamSynchronize(c->stream);
+    fprintf(stderr, "[sph debug] rank %d step %llu: %s -> %s\n", c->dist.rank, (unsigned long long)c->step_number, what, hipGetErrorString(e));
+}
+
 // class counts of a 256-thread block -> at most one atomic per class per block (one per wave on the same four words cost
 // ~100 us per launch at 512k particles: 32k same-address atomics)
 __device__ __forceinline__ void block_class_counts(uint32_t cls, uint32_t* __restrict__ counts)
@@ -1494,8 +1504,14 @@ static int slab_refresh_fused(Group& G, std::vector<Member>& M, std::vector<std:
                            d.counts.as<uint32_t>(), d.counts.as<uint32_t>() + 5);
         c->hint_word = nullptr;
     }
+    for (auto& m : M) dbg_sync(m.c, "fused: classify + scan", 0);
     std::vector<RefreshCounts> rcs(nm);
     if ((rc = G.comm->refresh_round(G, &red, &status, &fallback, rcs))) return rc;
+    if (getenv("SPH_DEBUG_COUNTS"))
+        for (size_t i = 0; i < nm; i++)
+            fprintf(stderr, "[sph debug] rank %zu: n_prev %u owned %llu mig %u %u halo %u %u in_mig %u %u in_halo %u %u fallback %d cap %llu\n", i, n_prev_of[i],
+                    (unsigned long long)M[i].c->n, rcs[i].mig[0], rcs[i].mig[1], rcs[i].halo[0], rcs[i].halo[1], rcs[i].in_mig[0], rcs[i].in_mig[1],
+                    rcs[i].in_halo[0], rcs[i].in_halo[1], fallback, (unsigned long long)M[i].c->cap);
     if (status) return M[0].c->fail(status, "another rank of the slab decomposition reported status %d", status);
     if (red[0][3] < 0.f) return SPH_OK;                       // a rank's header wait failed: the caller reports it (same value everywhere)
     if (fallback || !(-red[0][0] == h_pred)) return SPH_OK;   // identical on every rank: all-reduced values only
@@ -1539,10 +1555,12 @@ static int slab_refresh_fused(Group& G, std::vector<Member>& M, std::vector<std:
             x[i].recv_bytes[side] = (size_t)q.in_mig[side] * MIG_WORDS * 4;
         }
     }
+    for (auto& m : M) dbg_sync(m.c, "fused: pack", 1);
     bool any_mig = false;
     for (size_t i = 0; i < nm; i++) any_mig = any_mig || rcs[i].mig[0] || rcs[i].mig[1] || rcs[i].in_mig[0] || rcs[i].in_mig[1];
     // (one rank per process: no migrant in either direction = nothing to pair up, the neighbours see the same zeros)
     if (any_mig && (rc = G.comm->exchange(G, x))) return rc;
+    for (auto& m : M) dbg_sync(m.c, "fused: migrants exchanged", 1);
     // ---- arrivals behind the previous arrays, then the ghost records: [previous slots | from left | from right | ghosts left | ghosts right]
     for (size_t i = 0; i < nm; i++) {
         sph_ctx* c = M[i].c;
@@ -1572,7 +1590,9 @@ static int slab_refresh_fused(Group& G, std::vector<Member>& M, std::vector<std:
             x[i].recv_bytes[side] = (size_t)d.n_ghost[side] * GHOST_WORDS * 4;
         }
     }
+    for (auto& m : M) dbg_sync(m.c, "fused: arrivals unpacked, ghost records packed", 1);
     if ((rc = G.comm->exchange(G, x))) return rc;
+    for (auto& m : M) dbg_sync(m.c, "fused: ghost records exchanged", 1);
     for (size_t i = 0; i < nm; i++) {
         sph_ctx* c = M[i].c;
         auto& d = c->dist;
@@ -1591,6 +1611,7 @@ static int slab_refresh_fused(Group& G, std::vector<Member>& M, std::vector<std:
                                    d.recv[side].as<float>(), c->pm[c->pcur].as<float4>(), c->vel[k].as<float2>(), c->orig[k].as<uint32_t>(),
                                    c->lvl[k].as<float>(), c->lvlold[k].as<float>(), d.ring1_src.as<uint8_t>(), side == 0 ? 0u : d.n_ghost[0],
                                    side == 0 ? d.cut_lo - ring1_w : d.cut_hi + ring1_w, side);
+        dbg_sync(c, "fused: ghosts unpacked (this rank)", 1);
         d.pre = true;
         d.pre_cls_n = n_prev;
         d.pre_own = own_end;
@@ -1601,10 +1622,13 @@ static int slab_refresh_fused(Group& G, std::vector<Member>& M, std::vector<std:
         M[i].n = d.n_tot;
         M[i].n_sort = d.pre_n;
         if (d.pre_n) (void)hipMemsetAsync(d.halo_pos.p, 0xff, (size_t)d.pre_n * 4, c->stream);
+        dbg_sync(c, "fused: halo_pos cleared", 1);
         const uint32_t nh = d.n_halo[0] + d.n_halo[1];
         if (nh) hipLaunchKernelGGL(k_halo_pos, dim3((nh + 255) / 256), dim3(256), 0, c->stream, d.halo_idx.as<uint32_t>(), nh, d.halo_pos.as<uint32_t>());
+        dbg_sync(c, "fused: halo_pos set", 1);
     }
     (void)halo_w;
+    for (auto& m : M) dbg_sync(m.c, "fused: ghosts unpacked", 2);
     *fused = true;
     return SPH_OK;
 }
@@ -2025,7 +2049,8 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
     };
     for (auto& m : M)
         if (!setup_rc) setup_rc = setup_member(m);
-    if (setup_rc) return setup_rc;   // (slabs: the grid checks were taken on all-reduced numbers above, identically on every rank)
+    if (setup_rc) return setup_rc;
+    for (auto& m : M) dbg_sync(m.c, "neighbourhood (sort, reorder, cell ranges, maps)", 3);   // (slabs: the grid checks were taken on all-reduced numbers above, identically on every rank)
     g_trace.mark(2);
 
     // ---- level estimation on the extended-range lists (simulation.rs:2018-2046, 862-927; after advection: 2678-2707) ------
@@ -2053,7 +2078,7 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
             HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
         }
         const size_t n = m.n ? m.n : 1;
-        HIPCHK(c, c->lvl_tmp.ensure(n * 4));
+        HIPCHK(c, c->lvl_tmp.ensure((c->cap ? c->cap : 1) * 4));   // swapped with lvl[cur] at the end of the step: a persistent array, capacity-sized
         HIPCHK(c, c->lvl_nrm.ensure(n * 8));
         HIPCHK(c, c->lvl_when.ensure(n * 4));
         HIPCHK(c, c->lvl_mark.ensure(n * 8));   // two parity buffers (OpLevelPropagate)
@@ -2197,7 +2222,7 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
             sph_ctx* c = m.c;
             (void)hipSetDevice(c->device);
             const size_t n = m.n ? m.n : 1;
-            HIPCHK(c, c->lvl_tmp.ensure(n * 4));
+            HIPCHK(c, c->lvl_tmp.ensure((c->cap ? c->cap : 1) * 4));   // swapped with lvl[cur] at the end of the step: a persistent array, capacity-sized
             HIPCHK(c, c->lvl_nrm.ensure(n * 8));
             HIPCHK(c, c->lvl_when.ensure(n * 4));
             HIPCHK(c, c->lvl_mark.ensure(n * 8));   // two parity buffers (OpLevelPropagate)
@@ -2281,6 +2306,7 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
     };
     if (level_on && G.multi()) {
         if ((rc = level_estimation_slabs())) return rc;
+        for (auto& m : M) dbg_sync(m.c, "level estimation (slabs)", 4);
     } else if (level_on && !level_after) {
         static const bool no_side = getenv("SPH_LEVEL_SERIAL") != nullptr;   // measurement aid: everything on one stream
         if ((rc = level_estimation(nullptr, nullptr, !no_side))) return rc;
