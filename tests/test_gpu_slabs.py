@@ -250,6 +250,35 @@ def test_fused_refresh_is_bit_identical_to_the_general_path(product_lib, monkeyp
             assert np.array_equal(a.download(f), b.download(f)), f
 
 
+@pytest.mark.parametrize("solver,extra", [("IISPH", {}), ("IISPH2", dict(max_dt=0.0005)), ("OnlyDivergence", {}),
+                                          ("HybridDFSPH", dict(hybrid_dfsph_non_pressure_accel_before_divergence_free=False)),
+                                          ("HybridDFSPH", dict(hybrid_dfsph_density_source_term="OnlyDensity", operator_discretization="ConsistentSymmetricGradient"))])
+def test_every_solver_mode_on_slabs(product_lib, solver, extra):
+    """The four sequencings of the step (simulation.rs:2262-2670) and the branches inside HybridDFSPH on a 3-rank loopback group
+    against the single context: each mode has its own ghost refreshes (IISPH2 refreshes the rescaled pressures before its last
+    pressure-acceleration sweep; forces behind the divergence solve add a velocity refresh) and its own final wait."""
+    scn = sc.dam_break_small(96, 48, 1 / 48)
+    pos, mass, vel = sc.init_particles(scn)
+    vel = vel.copy()
+    vel[:, 0] = 0.8
+    planes = sc.boundary_planes(scn.boundary)
+    p = forced(max_iters=4, pressure_solver_method=solver, **extra).to_ffi()
+    single = ffi.Context(product_lib, len(mass), planes)
+    single.upload(mass, pos, vel)
+    grp = D.make_loopback_group(product_lib, pos, mass, vel, planes, 3)
+    for s in range(15):
+        st1 = single.step(p)
+        sts = ffi.group_step(grp, p)
+        assert all(st.dt == st1.dt for st in sts)
+        assert all(st.div_solver.iters == st1.div_solver.iters and st.density_solver.iters == st1.density_solver.iters for st in sts)
+    n = len(mass)
+    ids = np.concatenate([c.download("particle_id") for c in grp])
+    assert np.array_equal(np.sort(ids), np.arange(n))
+    assert np.array_equal(D.gather_by_id(grp, "neighbor_count", n), single.download("neighbor_count"))
+    for f, tol in (("position", 1e-5), ("velocity", 1e-4), ("density", 1e-5), ("pressure", 2e-3)):
+        assert rel_err(D.gather_by_id(grp, f, n), single.download(f)) <= tol, f
+
+
 @pytest.mark.parametrize("k", [2, 3])
 def test_neighbour_lists_of_the_slabs_are_those_of_the_single_context(product_lib, k):
     """sph_download_neighbors on a slab context: one row per owned particle (the order of the particle_id download), neighbours
