@@ -175,7 +175,8 @@ void launch_source_term(hipStream_t s, Profiler* prof, const SweepArgs& a, int k
 void launch_pressure_accel(hipStream_t s, Profiler* prof, const SweepArgs& a, int iter, int residual_density, float max_avg_error, uint32_t max_iters, int multi);
 void launch_ctrl_reset(hipStream_t s, SolverCtrl* ctrl, const uint32_t* gate);
 void launch_solver_handoff(hipStream_t s, Profiler* prof, SolverCtrl* ctrl, SolverCtrl* saved_host, uint32_t* gate);
-void launch_solver_tail(hipStream_t s, Profiler* prof, const SweepArgs& a, int tail, float4* pm_out);   // integrate map of the solver mode, once the solve is done
+void launch_solver_tail(hipStream_t s, Profiler* prof, const SweepArgs& a, int tail, float4* pm_out, int decide_iter = -1, int residual_density = 0,
+                        float max_avg_error = 0.f, uint32_t max_iters = 0);   // decide_iter >= 0 (slabs): the stop decision of that iteration is taken here   // integrate map of the solver mode, once the solve is done
 void launch_jacobi_update(hipStream_t s, Profiler* prof, const SweepArgs& a, int iter, int residual_density, float max_avg_error, uint32_t max_iters, int multi);
 void launch_solver_decide(hipStream_t s, Profiler* prof, const SweepArgs& a, int iter, int residual_density, float max_avg_error,
                           uint32_t max_iters);

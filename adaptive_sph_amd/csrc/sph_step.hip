@@ -617,14 +617,6 @@ __global__ void k_counts_stage(const uint32_t* __restrict__ counts, uint32_t* __
     out[4] = st;
     for (int k = 0; k < 4; k++) out[5 + k] = counts[k];
 }
-__global__ void k_guard_stage(const DeviceStatus* __restrict__ status, uint32_t* __restrict__ out)
-{
-    if (threadIdx.x == 0 && blockIdx.x == 0) *out = status->error;
-}
-__global__ void k_guard_merge(const uint32_t* __restrict__ agreed, SolverCtrl* __restrict__ ctrl)
-{
-    if (threadIdx.x == 0 && blockIdx.x == 0 && *agreed > ctrl->peer_error) ctrl->peer_error = *agreed;
-}
 
 // ------------------------------------------------------------------------------------------------
 // transports
@@ -1004,14 +996,14 @@ struct RcclComm : Comm {
     int agree_guards_queued(Group& G) override
     {
         sph_ctx* c = G.m[0];
-        uint32_t* d = c->dist.counts.as<uint32_t>() + 40;
-        hipLaunchKernelGGL(k_guard_stage, dim3(1), dim3(64), 0, c->stream, c->status.as<DeviceStatus>(), d);
+        // out of place, straight from the guard word into the control block: max over the ranks of status.error (a rank whose
+        // guard fired during a solve also raised peer_error through the totals -- its own status.error is in this maximum)
         c->dist.stat_allreduces++;
         {
             ProfScope ps(&c->prof, "rccl_allreduce", c->stream);
-            NCCLCHK(c, ncclAllReduce(d, d, 1, ncclUint32, ncclMax, (ncclComm_t)c->dist.nccl, c->stream));
+            NCCLCHK(c, ncclAllReduce(&c->status.as<DeviceStatus>()->error, &c->ctrl.as<SolverCtrl>()->peer_error, 1, ncclUint32, ncclMax,
+                                     (ncclComm_t)c->dist.nccl, c->stream));
         }
-        hipLaunchKernelGGL(k_guard_merge, dim3(1), dim3(64), 0, c->stream, d, c->ctrl.as<SolverCtrl>());
         return SPH_OK;
     }
     int exchange(Group& G, std::vector<Xfer>& x) override
@@ -1700,15 +1692,14 @@ static int solve_queue(Group& G, std::vector<Member>& M, SolveQ& q)
         if ((rc = refresh_ghosts(G, M, ((k + 1) & 1) ? sel_pt1 : sel_pt0, 1, "pt"))) return rc;
         if ((rc = solve_sweep_a(G, M, q, k + 1))) return rc;
     }
-    if (multi)   // the last queued sweep A(k) left the totals of iteration k - 1 behind
-        for (auto& m : M) {
-            (void)hipSetDevice(m.c->device);
-            launch_solver_decide(m.c->stream, &m.c->prof, m.a, (int)q.k - 1, q.residual_density, q.max_avg_error, q.max_iters);
-        }
+    // slab decomposition: the last queued sweep A(k) left the totals of iteration k - 1 behind; the decision on them is taken by
+    // the tail itself (every block, from the all-reduced totals), or by a launch of its own where no tail follows
     for (auto& m : M) {
         (void)hipSetDevice(m.c->device);
+        if (multi && (!m.n || q.tail == 0)) launch_solver_decide(m.c->stream, &m.c->prof, m.a, (int)q.k - 1, q.residual_density, q.max_avg_error, q.max_iters);
         if (!m.n || q.tail == 0 /* TAIL_NONE */) continue;
-        launch_solver_tail(m.c->stream, &m.c->prof, m.a, q.tail, m.c->pm[m.c->pcur ^ 1].as<float4>());
+        launch_solver_tail(m.c->stream, &m.c->prof, m.a, q.tail, m.c->pm[m.c->pcur ^ 1].as<float4>(), multi ? (int)q.k - 1 : -1, q.residual_density,
+                           q.max_avg_error, q.max_iters);
         if (q.tail >= 2 /* TAIL_VX, TAIL_HYBRID */ && m.a.hdr_partials) launch_header_ahead(m.c, (m.n + 255u) / 256u, m.c->hdr_host_dev);
     }
     return SPH_OK;

@@ -1311,10 +1311,16 @@ struct OpPressureAccel {
 __global__ __launch_bounds__(256) void k_solver_tail(uint32_t n, int tail, float dt, float vfactor, const float4* __restrict__ pm, float4* __restrict__ pm_out,
                                                       float2* __restrict__ vel, const float2* __restrict__ pacc, const uint32_t* __restrict__ orig,
                                                       const uint8_t* __restrict__ owned, const SolverCtrl* __restrict__ ctrl, HeaderOut* __restrict__ hdr_partials,
-                                                      DeviceStatus* status, const uint32_t* __restrict__ gate)
+                                                      DeviceStatus* status, const uint32_t* __restrict__ gate, const double* __restrict__ tot,
+                                                      int decide_iter, SolveP solve, float rest_density)
 {
     if (gate && *gate == 0u) return;
-    if (ctrl->done == 0u) return;
+    // slab decomposition: the decision on the solve's last queued iteration has no sweep B behind it to take it -- every block
+    // evaluates it here from the all-reduced totals (the same values, the same decision), block 0 publishes it
+    // (what k_solver_decide did in a launch of its own)
+    if (decide_iter >= 0) {
+        if (!solver_decide_multi(tot, const_cast<SolverCtrl*>(ctrl), decide_iter, solve, rest_density, dt, blockIdx.x == 0 && threadIdx.x == 0)) return;
+    } else if (ctrl->done == 0u) return;
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     const bool active = i < n && (!owned || owned[i]);
     float nx = 0.f, ny = 0.f, nh = 0.f, ncfl = 0.f;
@@ -2426,12 +2432,14 @@ void launch_pressure_accel(hipStream_t s, Profiler* prof, const SweepArgs& a, in
                  solver_reduce_blocks(a.n), a.solver_tot, a.status, a.sp, q, iter, a.owned, a.gate)
 }
 
-void launch_solver_tail(hipStream_t s, Profiler* prof, const SweepArgs& a, int tail, float4* pm_out)
+void launch_solver_tail(hipStream_t s, Profiler* prof, const SweepArgs& a, int tail, float4* pm_out, int decide_iter, int residual_density,
+                        float max_avg_error, uint32_t max_iters)
 {
     ProfScope ps(prof, "solver_tail", s);
     if (a.n && tail != TAIL_NONE)
         hipLaunchKernelGGL(k_solver_tail, dim3((a.n + 255) / 256), dim3(256), 0, s, a.n, tail, a.sp.dt, a.sp.hyb_vfactor, a.pm, pm_out, a.vel, a.pacc, a.orig,
-                           a.owned, a.ctrl, tail >= TAIL_VX ? a.hdr_partials : nullptr, a.status, a.gate);
+                           a.owned, a.ctrl, tail >= TAIL_VX ? a.hdr_partials : nullptr, a.status, a.gate, a.solver_tot, decide_iter,
+                           SolveP{residual_density, max_avg_error, max_iters, 1}, a.sp.rest_density);
 }
 
 // Chained solves (HybridDFSPH, one context): the host does not wait between the divergence solve and the density solve.  Behind
