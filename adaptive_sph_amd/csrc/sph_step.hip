@@ -467,9 +467,19 @@ __global__ __launch_bounds__(256) void k_ghost_mrho(const uint32_t* __restrict__
 // halo test would reject, or a particle in both halos (slab narrower than two ghost layers) -> the general path takes over.
 // ------------------------------------------------------------------------------------------------
 enum { SC_STAY = 0, SC_HALO_L = 1, SC_HALO_R = 2, SC_MIG_L = 3, SC_MIG_R = 4, SC_GHOST = 5, SC_GONE_FROM = 3 };
+// what the host already knows when it queues the classification: the step's header values (to be min-reduced over the ranks)
+// and its status / "take the general path" words -- staged for the collective round by the kernel itself
+struct RefreshStage {
+    float red[8];
+    uint32_t status, fallback;
+};
+enum { RC_BAD = 12 };   // word of dist.counts: the bad flag being collected (zero between launches: k_slab_scan takes it)
+// launch 1: class byte per slot + per-block class counts
+// (a last-block-done ticket that would fold launch 2 into this one costs 230 us at N = 1M: 4096 device-scope fences + 4096 adds
+//  on one word -- measured, forced one-rank slab step 0.72 -> 0.95 ms)
 __global__ __launch_bounds__(256) void k_slab_classify(uint32_t n, const float4* __restrict__ pm, const uint8_t* __restrict__ owned, float cut_lo,
                                                         float cut_hi, float halo_w, int has_left, int has_right, uint8_t* __restrict__ cls,
-                                                        uint32_t* __restrict__ blk_cnt, uint32_t* __restrict__ flags)
+                                                        uint32_t* __restrict__ blk_cnt, uint32_t* __restrict__ counts)
 {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     uint32_t c = 7u;
@@ -491,21 +501,23 @@ __global__ __launch_bounds__(256) void k_slab_classify(uint32_t n, const float4*
         cls[i] = (uint8_t)c;
     }
     __shared__ uint32_t s_cnt[4][4];   // [wave][class - 1]
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t t = threadIdx.x, wave = t >> 6, lane = t & 63u;
 #pragma unroll
     for (uint32_t k = 1; k <= 4; k++) {
         const uint64_t m = __ballot(c == k);
         if (lane == 0) s_cnt[wave][k - 1] = (uint32_t)__popcll(m);
     }
-    if (__ballot(bad) != 0ull && lane == 0) atomicOr(flags, 1u);
+    if (__ballot(bad) != 0ull && lane == 0) atomicOr(&counts[RC_BAD], 1u);
     __syncthreads();
-    if (threadIdx.x < 4) blk_cnt[blockIdx.x * 4 + threadIdx.x] = s_cnt[0][threadIdx.x] + s_cnt[1][threadIdx.x] + s_cnt[2][threadIdx.x] + s_cnt[3][threadIdx.x];
+    if (t < 4) blk_cnt[blockIdx.x * 4 + t] = s_cnt[0][t] + s_cnt[1][t] + s_cnt[2][t] + s_cnt[3][t];
 }
 
-// exclusive scan of the per-block class counts (4 classes) over the blocks, one 1024-thread block: thread t owns a contiguous
-// run of blocks.  counts[0 .. 3] = totals of classes 1 .. 4, counts[4] = the bad flag
+// launch 2, one 1024-thread block: exclusive scan of the block counts over the blocks (thread t owns a contiguous run of blocks),
+// the totals (counts[0 .. 3] = classes 1 .. 4, counts[4] = bad) and the words of the collective round, staged behind the counters:
+//   stage[0 .. 7] header values, stage[8] = -status, stage[9] = -"general path" (floats: ONE min all-reduce takes all ten),
+//   stage[10 .. 11] = (migrants, halo members) for the left neighbour, stage[12 .. 13] for the right one, stage[14 .. 17] = 0 (received)
 __global__ __launch_bounds__(1024) void k_slab_scan(uint32_t nb, const uint32_t* __restrict__ blk_cnt, uint32_t* __restrict__ blk_off,
-                                                     uint32_t* __restrict__ counts, const uint32_t* __restrict__ flags)
+                                                     uint32_t* __restrict__ counts, uint32_t* __restrict__ stage, RefreshStage rs)
 {
     __shared__ uint32_t s_wave[16][4];
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
@@ -537,8 +549,18 @@ __global__ __launch_bounds__(1024) void k_slab_scan(uint32_t nb, const uint32_t*
             run[k] += blk_cnt[b * 4 + k];
         }
     if (t == 1023u) {
+        const uint32_t is_bad = counts[RC_BAD];
+        counts[RC_BAD] = 0u;
         for (int k = 0; k < 4; k++) counts[k] = run[k];
-        counts[4] = flags[0];
+        counts[4] = is_bad;
+        for (int k = 0; k < 8; k++) stage[k] = __float_as_uint(rs.red[k]);
+        stage[8] = __float_as_uint(-(float)rs.status);
+        stage[9] = __float_as_uint((rs.fallback || is_bad) ? -1.f : 0.f);
+        stage[10] = run[2];   // SC_MIG_L
+        stage[11] = run[0];   // SC_HALO_L
+        stage[12] = run[3];   // SC_MIG_R
+        stage[13] = run[1];   // SC_HALO_R
+        stage[14] = stage[15] = stage[16] = stage[17] = 0u;
     }
 }
 
@@ -584,20 +606,6 @@ __global__ __launch_bounds__(256) void k_iota_u32(uint32_t* __restrict__ out, ui
     const uint32_t k = blockIdx.x * 256 + threadIdx.x;
     if (k < cnt) out[k] = first + k;
 }
-// refresh_round (RCCL): out[0 .. 1] = (migrants, halo members) for the left neighbour, out[2 .. 3] for the right one, out[4] = status,
-// out[5] = "take the general path", out[6 .. 9] = 0 (received below)
-__global__ void k_refresh_stage(const uint32_t* __restrict__ counts, uint32_t* __restrict__ out, uint32_t status_in, uint32_t fallback_in)
-{
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    out[0] = counts[2];   // SC_MIG_L
-    out[1] = counts[0];   // SC_HALO_L
-    out[2] = counts[3];   // SC_MIG_R
-    out[3] = counts[1];   // SC_HALO_R
-    out[4] = status_in;
-    out[5] = (fallback_in || counts[4]) ? 1u : 0u;
-    out[6] = out[7] = out[8] = out[9] = 0u;
-}
-
 __global__ void k_fill_u8(uint8_t* p, uint32_t n, uint8_t v)
 {
     uint32_t i = blockIdx.x * 256 + threadIdx.x;
@@ -946,47 +954,42 @@ struct RcclComm : Comm {
         sph_ctx* c = G.m[0];
         ncclComm_t nc = (ncclComm_t)c->dist.nccl;
         const int r = c->dist.rank, nr = c->dist.nranks;
-        // device scratch behind the counters: [0 .. 7] the min-reduced floats, [8 .. 17] k_refresh_stage's words
+        // k_slab_classify's last block staged the round behind the counters: d[0 .. 7] header values, d[8] = -status,
+        // d[9] = -"general path" (ten floats, ONE min all-reduce), d[10 .. 13] my counts for the left / right neighbour, d[14 .. 17] theirs
         uint32_t* d = c->dist.counts.as<uint32_t>() + 16;
-        uint32_t* h = (uint32_t*)((uint8_t*)c->dist.counts_host + 64);   // pinned staging / publish destination (same words)
+        const uint32_t* h = (const uint32_t*)((const uint8_t*)c->dist.counts_host + 64);   // publish destination
         const size_t nred = red ? (*red)[0].size() : 0;
-        if (nred > 8) return c->fail(SPH_ERR_INVALID_ARGUMENT, "refresh_round: %zu reduced values", nred);
-        if (nred) {
-            memcpy(h, (*red)[0].data(), nred * 4);
-            HIPCHK(c, hipMemcpyAsync(d, h, nred * 4, hipMemcpyHostToDevice, c->stream));
-            c->dist.stat_allreduces++;
-            ProfScope ps(&c->prof, "rccl_allreduce", c->stream);
-            NCCLCHK(c, ncclAllReduce(d, d, nred, ncclFloat32, ncclMin, nc, c->stream));
-        }
-        hipLaunchKernelGGL(k_refresh_stage, dim3(1), dim3(64), 0, c->stream, c->dist.counts.as<uint32_t>(), d + 8, (uint32_t)*status, (uint32_t)*fallback);
+        if (nred != 8) return c->fail(SPH_ERR_INVALID_ARGUMENT, "refresh_round: %zu reduced values", nred);
         {
             c->dist.stat_allreduces++;
             ProfScope ps(&c->prof, "rccl_allreduce", c->stream);
-            NCCLCHK(c, ncclAllReduce(d + 12, d + 12, 2, ncclUint32, ncclMax, nc, c->stream));
+            NCCLCHK(c, ncclAllReduce(d, d, 10, ncclFloat32, ncclMin, nc, c->stream));
         }
-        {
+        if (nr > 1) {
             ProfScope ps(&c->prof, "rccl_sendrecv", c->stream);
             NCCLCHK(c, ncclGroupStart());
             if (r > 0) {
-                NCCLCHK(c, ncclSend(d + 8, 2, ncclUint32, r - 1, nc, c->stream));
+                NCCLCHK(c, ncclSend(d + 10, 2, ncclUint32, r - 1, nc, c->stream));
                 NCCLCHK(c, ncclRecv(d + 14, 2, ncclUint32, r - 1, nc, c->stream));
             }
             if (r + 1 < nr) {
-                NCCLCHK(c, ncclSend(d + 10, 2, ncclUint32, r + 1, nc, c->stream));
+                NCCLCHK(c, ncclSend(d + 12, 2, ncclUint32, r + 1, nc, c->stream));
                 NCCLCHK(c, ncclRecv(d + 16, 2, ncclUint32, r + 1, nc, c->stream));
             }
             NCCLCHK(c, ncclGroupEnd());
         }
         int rc = publish_and_wait(c, d, 18);
         if (rc) return rc;
-        for (size_t k = 0; k < nred; k++) memcpy(&(*red)[0][k], &h[k], 4);
+        float f[10];
+        memcpy(f, h, sizeof f);
+        for (size_t k = 0; k < 8; k++) (*red)[0][k] = f[k];
+        *status = (int)-f[8];
+        if (f[9] < 0.f) *fallback = 1;
         RefreshCounts& o = rcs[0];
-        o.mig[0] = h[8];
-        o.halo[0] = h[9];
-        o.mig[1] = h[10];
-        o.halo[1] = h[11];
-        *status = (int)h[12];
-        *fallback = (int)h[13];
+        o.mig[0] = h[10];
+        o.halo[0] = h[11];
+        o.mig[1] = h[12];
+        o.halo[1] = h[13];
         o.in_mig[0] = r > 0 ? h[14] : 0;
         o.in_halo[0] = r > 0 ? h[15] : 0;
         o.in_mig[1] = r + 1 < nr ? h[16] : 0;
@@ -1167,7 +1170,10 @@ static int ensure_dist_buffers(sph_ctx* c, uint32_t n)
         HIPCHK(c, d.send[s].ensure(cap * MIG_WORDS * 4 / 2 + 1024));
         HIPCHK(c, d.recv[s].ensure(cap * MIG_WORDS * 4 / 2 + 1024));
     }
-    HIPCHK(c, d.counts.ensure(256));
+    if (!d.counts.p) {
+        HIPCHK(c, d.counts.ensure(256));
+        HIPCHK(c, hipMemset(d.counts.p, 0, 256));   // (the bad-flag word of the fused refresh is taken and cleared by k_slab_scan)
+    }
     HIPCHK(c, d.solver_tot.ensure(128));   // two slots of 6 doubles (chained solves)
     HIPCHK(c, d.cls.ensure(cap));
     HIPCHK(c, d.blk.ensure(((cap + 255) / 256) * 8 * sizeof(uint32_t)));
@@ -1485,15 +1491,19 @@ static int slab_refresh_fused(Group& G, std::vector<Member>& M, std::vector<std:
         const float halo_w = h_pred * halo_k;
         const bool has_l = d.rank > 0, has_r = d.rank + 1 < d.nranks;
         if (has_l && has_r && !(d.cut_hi - halo_w >= d.cut_lo + halo_w)) fallback = 1;   // narrower than two ghost layers: the general path reports it
-        (void)hipMemsetAsync(d.counts.p, 0, 64, c->stream);
+        // two launches: classify + per-block counts; scan, totals and the staging of the round (no memset, no copy, no stage kernel)
         const uint32_t nb = (n_prev + 255u) / 256u;
+        RefreshStage rs{};
+        for (int k = 0; k < 8; k++) rs.red[k] = red[i][(size_t)k];
+        rs.status = 0u;
+        rs.fallback = (uint32_t)fallback;   // what this process knows so far (a later member's verdict reaches the round through the host)
         ProfScope ps(&c->prof, "slab_refresh", c->stream);
         if (n_prev)
             hipLaunchKernelGGL(k_slab_classify, dim3(nb), dim3(256), 0, c->stream, n_prev, c->pm[c->pcur].as<float4>(),
                                d.have_flags ? d.owned.as<uint8_t>() : (const uint8_t*)nullptr, d.cut_lo, d.cut_hi, halo_w, has_l ? 1 : 0, has_r ? 1 : 0,
-                               d.cls.as<uint8_t>(), d.blk.as<uint32_t>(), d.counts.as<uint32_t>() + 5);
+                               d.cls.as<uint8_t>(), d.blk.as<uint32_t>(), d.counts.as<uint32_t>());
         hipLaunchKernelGGL(k_slab_scan, dim3(1), dim3(1024), 0, c->stream, nb, d.blk.as<uint32_t>(), d.blk.as<uint32_t>() + (size_t)nb * 4,
-                           d.counts.as<uint32_t>(), d.counts.as<uint32_t>() + 5);
+                           d.counts.as<uint32_t>(), d.counts.as<uint32_t>() + 16, rs);
         c->hint_word = nullptr;
     }
     for (auto& m : M) dbg_sync(m.c, "fused: classify + scan", 0);
