@@ -407,10 +407,12 @@ __global__ __launch_bounds__(256) void k_halo_pos(const uint32_t* __restrict__ h
 }
 
 // after the cell sort: where did my halo particles and my ghosts end up?  perm[s] = pre-sort index of slot s
+// `cls` (fused refresh, else nullptr): halo_pos is only defined for the halo members then -- slots whose class byte says so and the
+// arrivals behind the n_cls previous slots -- and nothing had to clear the rest of it
 __global__ __launch_bounds__(256) void k_build_maps(uint32_t n_tot, uint32_t n_own, const uint32_t* __restrict__ perm,
                                                      const uint32_t* __restrict__ halo_pos, uint32_t* __restrict__ halo_src,
                                                      uint32_t* __restrict__ ghost_dst, uint8_t* __restrict__ owned, const uint8_t* __restrict__ ring1_src,
-                                                     uint8_t* __restrict__ ring1)
+                                                     uint8_t* __restrict__ ring1, const uint8_t* __restrict__ cls, uint32_t n_cls)
 {
     uint32_t s = blockIdx.x * 256 + threadIdx.x;
     if (s >= n_tot) return;
@@ -419,6 +421,7 @@ __global__ __launch_bounds__(256) void k_build_maps(uint32_t n_tot, uint32_t n_o
     owned[s] = own ? 1 : 0;
     ring1[s] = own ? 0 : ring1_src[old - n_own];
     if (own) {
+        if (cls && old < n_cls && cls[old] != 1 /* SC_HALO_L */ && cls[old] != 2 /* SC_HALO_R */) return;
         const uint32_t k = halo_pos[old];
         if (k != 0xffffffffu) halo_src[k] = s;
     } else {
@@ -1623,8 +1626,7 @@ static int slab_refresh_fused(Group& G, std::vector<Member>& M, std::vector<std:
         d.have_flags = false;
         M[i].n = d.n_tot;
         M[i].n_sort = d.pre_n;
-        if (d.pre_n) (void)hipMemsetAsync(d.halo_pos.p, 0xff, (size_t)d.pre_n * 4, c->stream);
-        dbg_sync(c, "fused: halo_pos cleared", 1);
+        // (halo_pos is not cleared: k_build_maps consults it for halo members only -- class byte 1 / 2, or an arrival)
         const uint32_t nh = d.n_halo[0] + d.n_halo[1];
         if (nh) hipLaunchKernelGGL(k_halo_pos, dim3((nh + 255) / 256), dim3(256), 0, c->stream, d.halo_idx.as<uint32_t>(), nh, d.halo_pos.as<uint32_t>());
         dbg_sync(c, "fused: halo_pos set", 1);
@@ -2037,7 +2039,7 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
             if (n)
                 hipLaunchKernelGGL(k_build_maps, dim3((n + 255) / 256), dim3(256), 0, s, n, pre ? d.pre_own : (uint32_t)c->n, c->val[0].as<uint32_t>(),
                                    d.halo_pos.as<uint32_t>(), d.halo_src.as<uint32_t>(), d.ghost_dst.as<uint32_t>(), d.owned.as<uint8_t>(),
-                                   d.ring1_src.as<uint8_t>(), d.ring1.as<uint8_t>());
+                                   d.ring1_src.as<uint8_t>(), d.ring1.as<uint8_t>(), pre ? d.cls.as<uint8_t>() : (const uint8_t*)nullptr, pre ? d.pre_cls_n : 0u);
             d.have_flags = true;
         }
         if (tev) (void)hipEventRecord(c->ev[1], s);
