@@ -36,7 +36,7 @@
 #include "sph_internal.hpp"
 
 #ifndef SWEEP_THREADS
-#define SWEEP_THREADS 256   // measured: 128 and 512 are within 1 % of 256 (scripts/ablate.sh)
+#define SWEEP_THREADS 256   // measured: 128 is slower (0.661 vs 0.624 ms/step, profiles/r2_variants.md context); 512 was within 1 % in round 1
 #endif
 #ifndef SPH_TILE_DEFAULT
 #define SPH_TILE_DEFAULT 0
