@@ -178,10 +178,23 @@ __global__ __launch_bounds__(256) void k_header_final(const HeaderOut* __restric
 
 // the same reduction over the partials the integrating final sweep wrote (one per 256-particle block); it runs behind that
 // sweep and, like it, only once the stop decision has been taken
+// `h_ctrl` != nullptr: the launch is the last one before a host wait and does k_publish's job as well (control block + guard
+// word to mapped host memory, the sequence number last) -- one launch less on the step's critical path
 __global__ __launch_bounds__(256) void k_header_ahead(const HeaderOut* __restrict__ partials, uint32_t nparts, const SolverCtrl* __restrict__ ctrl,
-                                                       HeaderOut* __restrict__ out)
+                                                       HeaderOut* __restrict__ out, const DeviceStatus* __restrict__ status, SolverCtrl* __restrict__ h_ctrl,
+                                                       DeviceStatus* __restrict__ h_status, uint32_t seq)
 {
-    if (ctrl->done == 0u) return;
+    if (ctrl->done == 0u) {
+        if (h_ctrl && threadIdx.x == 0) {
+            SolverCtrl v = *ctrl;
+            v.seq = seq - 1u;
+            *h_ctrl = v;
+            *h_status = *status;
+            __threadfence_system();
+            ((volatile SolverCtrl*)h_ctrl)->seq = seq;
+        }
+        return;
+    }
     const float INF = __uint_as_float(0x7f800000u);
     HeaderOut o{INF, INF, -INF, -INF, 0.f, INF, INF, 0};
     for (uint32_t k = threadIdx.x; k < nparts; k += 256) {
@@ -206,6 +219,14 @@ __global__ __launch_bounds__(256) void k_header_ahead(const HeaderOut* __restric
             r.min_cfl = fminf(r.min_cfl, s[k].min_cfl);
         }
         *out = r;
+        if (h_ctrl) {
+            SolverCtrl v = *ctrl;
+            v.seq = seq - 1u;
+            *h_ctrl = v;
+            *h_status = *status;
+            __threadfence_system();
+            ((volatile SolverCtrl*)h_ctrl)->seq = seq;
+        }
     }
 }
 
@@ -1101,14 +1122,26 @@ void launch_header(sph_ctx* c, uint32_t n, float rest_density, int from_mass /* 
     }
 }
 
-void launch_header_ahead(sph_ctx* c, uint32_t nblocks, HeaderOut* out_dev)
+void launch_header_ahead(sph_ctx* c, uint32_t nblocks, HeaderOut* out_dev, bool publish)
 {
     ProfScope ps(&c->prof, "header_ahead", c->stream);
-    hipLaunchKernelGGL(k_header_ahead, dim3(1), dim3(256), 0, c->stream, c->hdr_ahead_partials.as<HeaderOut>(), nblocks, c->ctrl.as<SolverCtrl>(), out_dev);
+    uint32_t seq = 0;
+    if (publish) {   // the launch_publish that follows has nothing left to do
+        c->publish_seq++;
+        if (c->publish_seq == 0u) c->publish_seq = 1u;
+        seq = c->publish_seq;
+        c->publish_folded = true;
+    }
+    hipLaunchKernelGGL(k_header_ahead, dim3(1), dim3(256), 0, c->stream, c->hdr_ahead_partials.as<HeaderOut>(), nblocks, c->ctrl.as<SolverCtrl>(), out_dev,
+                       c->status.as<DeviceStatus>(), publish ? c->ctrl_host_dev : (SolverCtrl*)nullptr, publish ? c->status_host_dev : (DeviceStatus*)nullptr, seq);
 }
 
 void launch_publish(sph_ctx* c)
 {
+    if (c->publish_folded) {   // k_header_ahead, queued just before, publishes
+        c->publish_folded = false;
+        return;
+    }
     c->publish_seq++;
     if (c->publish_seq == 0u) c->publish_seq = 1u;
     hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, c->stream, c->ctrl.as<SolverCtrl>(), c->status.as<DeviceStatus>(), c->ctrl_host_dev,

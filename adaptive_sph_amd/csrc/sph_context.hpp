@@ -68,6 +68,7 @@ struct sph_ctx {
     volatile uint32_t* hint_word = nullptr;   // the kernel queued LAST stores hint_seq here as its final store: the next wait spins on it
     uint32_t hint_seq = 0;
     uint32_t publish_seq = 0;   // sequence number of the last k_publish (the host spins on its arrival in ctrl_host)
+    bool publish_folded = false;   // the k_header_ahead queued last also publishes: launch_publish has nothing to launch
     SolverCtrl* ctrl_host = nullptr;
     DeviceStatus* status_host = nullptr;
     HeaderOut* hdr_host_dev = nullptr;

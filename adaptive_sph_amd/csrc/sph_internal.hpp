@@ -176,7 +176,8 @@ void launch_pressure_accel(hipStream_t s, Profiler* prof, const SweepArgs& a, in
 void launch_ctrl_reset(hipStream_t s, SolverCtrl* ctrl, const uint32_t* gate);
 void launch_solver_handoff(hipStream_t s, Profiler* prof, SolverCtrl* ctrl, SolverCtrl* saved_host, uint32_t* gate);
 void launch_solver_tail(hipStream_t s, Profiler* prof, const SweepArgs& a, int tail, float4* pm_out, int decide_iter = -1, int residual_density = 0,
-                        float max_avg_error = 0.f, uint32_t max_iters = 0);   // decide_iter >= 0 (slabs): the stop decision of that iteration is taken here   // integrate map of the solver mode, once the solve is done
+                        float max_avg_error = 0.f, uint32_t max_iters = 0, SolverCtrl* handoff_host = nullptr, uint32_t* gate_out = nullptr);
+// decide_iter >= 0 (slabs): the stop decision of that iteration is taken here; gate_out: the tail also does k_solver_handoff's job   // integrate map of the solver mode, once the solve is done
 void launch_jacobi_update(hipStream_t s, Profiler* prof, const SweepArgs& a, int iter, int residual_density, float max_avg_error, uint32_t max_iters, int multi);
 void launch_solver_decide(hipStream_t s, Profiler* prof, const SweepArgs& a, int iter, int residual_density, float max_avg_error,
                           uint32_t max_iters);
@@ -211,7 +212,7 @@ void launch_level_smooth(hipStream_t s, Profiler* prof, const SweepArgs& a, cons
 void launch_classify(hipStream_t s, Profiler* prof, uint32_t n, const float4* pm, const float* level, uint8_t* size_class, const uint8_t* owned,
                      const uint32_t* orig, DeviceStatus* status, const sph_params* p);
 // reduce the per-block header partials of the integrating final sweep into `out_dev` (skipped while the solve is not done)
-void launch_header_ahead(sph_ctx* c, uint32_t nblocks, HeaderOut* out_dev);
+void launch_header_ahead(sph_ctx* c, uint32_t nblocks, HeaderOut* out_dev, bool publish = false);   // publish: also k_publish's job (the next launch_publish is a no-op)
 // IISPH2: p /= sqrt(omega) on the current pressure buffer (+ p / rho^2), simulation.rs:2358-2360
 void launch_iisph2_scale(hipStream_t s, Profiler* prof, const SweepArgs& a);
 void launch_check_aii(hipStream_t s, Profiler* prof, const SweepArgs& a);   // after launch_aii_const when check_aii is set

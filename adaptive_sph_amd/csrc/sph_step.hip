@@ -1689,7 +1689,10 @@ static int solve_begin(Group& G, std::vector<Member>& M, SolveQ& q, uint32_t pre
     return SPH_OK;
 }
 // iterations k .. upto, the (late) decision on the last one and the solve's tail
-static int solve_queue(Group& G, std::vector<Member>& M, SolveQ& q)
+// `handoff`: the solve is the first of a chained pair -- its tail (or, where no tail runs, k_solver_handoff) hands the control block
+// over and sets the second solve's gate.  `publish_next`: the caller waits right behind this (sync_ctrl): the header kernel of an
+// integrating tail publishes as well.
+static int solve_queue(Group& G, std::vector<Member>& M, SolveQ& q, bool handoff = false, bool publish_next = false)
 {
     int rc;
     const int multi = G.multi() ? 1 : 0;
@@ -1709,10 +1712,15 @@ static int solve_queue(Group& G, std::vector<Member>& M, SolveQ& q)
     for (auto& m : M) {
         (void)hipSetDevice(m.c->device);
         if (multi && (!m.n || q.tail == 0)) launch_solver_decide(m.c->stream, &m.c->prof, m.a, (int)q.k - 1, q.residual_density, q.max_avg_error, q.max_iters);
-        if (!m.n || q.tail == 0 /* TAIL_NONE */) continue;
+        SolverCtrl* hand_host = handoff ? m.c->ctrl_host_dev + 1 : nullptr;
+        uint32_t* gate_out = handoff ? (uint32_t*)(m.c->ctrl.as<SolverCtrl>() + 2) : nullptr;
+        if (!m.n || q.tail == 0 /* TAIL_NONE */) {
+            if (handoff) launch_solver_handoff(m.c->stream, &m.c->prof, m.c->ctrl.as<SolverCtrl>(), hand_host, gate_out);
+            continue;
+        }
         launch_solver_tail(m.c->stream, &m.c->prof, m.a, q.tail, m.c->pm[m.c->pcur ^ 1].as<float4>(), multi ? (int)q.k - 1 : -1, q.residual_density,
-                           q.max_avg_error, q.max_iters);
-        if (q.tail >= 2 /* TAIL_VX, TAIL_HYBRID */ && m.a.hdr_partials) launch_header_ahead(m.c, (m.n + 255u) / 256u, m.c->hdr_host_dev);
+                           q.max_avg_error, q.max_iters, hand_host, gate_out);
+        if (q.tail >= 2 /* TAIL_VX, TAIL_HYBRID */ && m.a.hdr_partials) launch_header_ahead(m.c, (m.n + 255u) / 256u, m.c->hdr_host_dev, publish_next && !multi);
     }
     return SPH_OK;
 }
@@ -1738,7 +1746,7 @@ static int pressure_iterations(Group& G, std::vector<Member>& M, float max_avg_e
     SolveQ q{max_avg_error, residual_density, max_iters, tail, density_solver};
     if ((rc = solve_begin(G, M, q, predicted_iters))) return rc;
     for (;;) {
-        if ((rc = solve_queue(G, M, q))) return rc;
+        if ((rc = solve_queue(G, M, q, false, true))) return rc;
         if (multi && final_solve && (rc = G.comm->agree_guards_queued(G))) return rc;
         if ((rc = sync_ctrl(G, multi ? (final_solve ? SYNC_FINAL : SYNC_DEFER) : SYNC_AGREE))) return rc;
         if (M[0].c->ctrl_host->done) break;
@@ -1784,6 +1792,7 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
     for (auto c : G.m)
         if (c->poisoned) return c->fail(SPH_ERR_POISONED, "an earlier step failed inside the step: the particle state is undefined until sph_upload");
     *started = true;   // from here on a failure leaves the state half-stepped
+    for (auto c : G.m) c->publish_folded = false;
 
     // ---- slab maintenance part 1 needs no global scalar: partition + migrate (multi-rank) -----------------
     // (the ghost layer needs the all-reduced h_max, so the header of the owned particles comes first)
@@ -2488,11 +2497,7 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
             for (bool div_done = false;;) {
                 if (!div_done) {
                     set_gate(false);
-                    if ((rc = solve_queue(G, M, qd))) return rc;
-                    for (auto& m : M) {
-                        (void)hipSetDevice(m.c->device);
-                        launch_solver_handoff(m.c->stream, &m.c->prof, m.c->ctrl.as<SolverCtrl>(), m.c->ctrl_host_dev + 1, (uint32_t*)(m.c->ctrl.as<SolverCtrl>() + 2));
-                    }
+                    if ((rc = solve_queue(G, M, qd, true))) return rc;   // its tail hands over and sets the gate
                     g_trace.mark(4);
                     rec(3);
                     if ((rc = refresh_ghosts(G, M, sel_vel, 2, "vel"))) return rc;  // v += dt a^p happened in the tail (or nothing did: the same values again)
@@ -2501,7 +2506,7 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
                     begin_solve(kind, 1);   // the density solve from its start
                     if ((rc = solve_begin(G, M, qs, c0->last_dens_iters))) return rc;
                 }
-                if ((rc = solve_queue(G, M, qs))) return rc;
+                if ((rc = solve_queue(G, M, qs, false, true))) return rc;
                 if (multi && final_solve && (rc = G.comm->agree_guards_queued(G))) return rc;
                 if ((rc = sync_ctrl(G, multi ? (final_solve ? SYNC_FINAL : SYNC_DEFER) : SYNC_AGREE))) return rc;
                 if (!div_done) {

@@ -1312,15 +1312,26 @@ __global__ __launch_bounds__(256) void k_solver_tail(uint32_t n, int tail, float
                                                       float2* __restrict__ vel, const float2* __restrict__ pacc, const uint32_t* __restrict__ orig,
                                                       const uint8_t* __restrict__ owned, const SolverCtrl* __restrict__ ctrl, HeaderOut* __restrict__ hdr_partials,
                                                       DeviceStatus* status, const uint32_t* __restrict__ gate, const double* __restrict__ tot,
-                                                      int decide_iter, SolveP solve, float rest_density)
+                                                      int decide_iter, SolveP solve, float rest_density, SolverCtrl* __restrict__ handoff_host,
+                                                      uint32_t* __restrict__ gate_out)
 {
     if (gate && *gate == 0u) return;
     // slab decomposition: the decision on the solve's last queued iteration has no sweep B behind it to take it -- every block
     // evaluates it here from the all-reduced totals (the same values, the same decision), block 0 publishes it
     // (what k_solver_decide did in a launch of its own)
-    if (decide_iter >= 0) {
-        if (!solver_decide_multi(tot, const_cast<SolverCtrl*>(ctrl), decide_iter, solve, rest_density, dt, blockIdx.x == 0 && threadIdx.x == 0)) return;
-    } else if (ctrl->done == 0u) return;
+    const bool b0t0 = blockIdx.x == 0 && threadIdx.x == 0;
+    bool done;
+    if (decide_iter >= 0) done = solver_decide_multi(tot, const_cast<SolverCtrl*>(ctrl), decide_iter, solve, rest_density, dt, b0t0);
+    else done = ctrl->done != 0u;
+    // chained solves: this is the FIRST solve's tail -- hand its control block to the host and open (or keep shut) the gate of
+    // the second solve's launches (k_solver_handoff's job; the next kernel starts after every block of this one has finished)
+    if (gate_out && b0t0) {
+        const SolverCtrl v = *ctrl;
+        *handoff_host = v;
+        __threadfence_system();
+        *gate_out = done ? 1u : 0u;
+    }
+    if (!done) return;
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     const bool active = i < n && (!owned || owned[i]);
     float nx = 0.f, ny = 0.f, nh = 0.f, ncfl = 0.f;
@@ -2433,13 +2444,13 @@ void launch_pressure_accel(hipStream_t s, Profiler* prof, const SweepArgs& a, in
 }
 
 void launch_solver_tail(hipStream_t s, Profiler* prof, const SweepArgs& a, int tail, float4* pm_out, int decide_iter, int residual_density,
-                        float max_avg_error, uint32_t max_iters)
+                        float max_avg_error, uint32_t max_iters, SolverCtrl* handoff_host, uint32_t* gate_out)
 {
     ProfScope ps(prof, "solver_tail", s);
     if (a.n && tail != TAIL_NONE)
         hipLaunchKernelGGL(k_solver_tail, dim3((a.n + 255) / 256), dim3(256), 0, s, a.n, tail, a.sp.dt, a.sp.hyb_vfactor, a.pm, pm_out, a.vel, a.pacc, a.orig,
                            a.owned, a.ctrl, tail >= TAIL_VX ? a.hdr_partials : nullptr, a.status, a.gate, a.solver_tot, decide_iter,
-                           SolveP{residual_density, max_avg_error, max_iters, 1}, a.sp.rest_density);
+                           SolveP{residual_density, max_avg_error, max_iters, 1}, a.sp.rest_density, handoff_host, gate_out);
 }
 
 // Chained solves (HybridDFSPH, one context): the host does not wait between the divergence solve and the density solve.  Behind
