@@ -82,8 +82,16 @@ struct DeviceStatus {
 // ---- sph_sort.hip ------------------------------------------------------------------------------
 // Stable LSD radix sort of (key,val) pairs on `bits` key bits.  Returns 0 if the result is in
 // (keyA,valA), 1 if in (keyB,valB).
+// the cell sort's key source: cell index of a record; slots [0, n_gone) whose class byte is >= gone_from get the key ncells
+struct CellKeyGen {
+    const float4* pm;
+    GridP g;
+    const uint8_t* gone;
+    uint32_t n_gone, gone_from;
+};
+// keygen != nullptr: the first pass computes the keys (keyA) and the identity values (valA) itself
 int radix_sort_pairs(hipStream_t s, Profiler* prof, uint32_t* keyA, uint32_t* valA, uint32_t* keyB, uint32_t* valB,
-                     uint32_t n, int bits, uint32_t* hist_scratch /* >= 256 * nblocks + 256 */);
+                     uint32_t n, int bits, uint32_t* hist_scratch /* >= 256 * nblocks + 256 */, const CellKeyGen* keygen = nullptr);
 size_t radix_sort_scratch_elems(uint32_t n);
 
 void launch_cell_keys(hipStream_t s, Profiler* prof, const float4* pm, uint32_t n, GridP g, uint32_t* key, uint32_t* val,

@@ -33,9 +33,20 @@ __device__ __forceinline__ uint64_t rs_peers(uint32_t d, bool valid)
 
 // NB = digit width in bits (8, 9 or 10: the fewest passes that cover the key; 18-bit cell ids take two 9-bit passes).
 // per-tile digit histogram: 256 threads, wave w owns keys [256 w, 256 w + 256) of the tile in 4 rounds of 64
-template <int NB>
-__global__ __launch_bounds__(256) void k_rs_hist(const uint32_t* __restrict__ key, uint32_t n, int shift, uint32_t nblocks,
-                                                  uint32_t* __restrict__ hist)
+// KEYGEN: the first pass of the cell sort makes its keys itself -- cell index of particle idx from its record (what k_cell_keys
+// computes), stored for the scatter together with val = idx -- instead of reading them from a launch of their own
+__device__ __forceinline__ uint32_t cell_key_of(const CellKeyGen& kg, uint32_t i)
+{
+    if (kg.gone && i < kg.n_gone && kg.gone[i] >= kg.gone_from) return kg.g.ncells;
+    const float4 p = kg.pm[i];
+    // IEEE division, like `(particle_pos / kernel_support_radius).map(|x| x.floor() as i32)`
+    const int cx = (int)floorf(p.x / kg.g.cs) - kg.g.minx;
+    const int cy = (int)floorf(p.y / kg.g.cs) - kg.g.miny;
+    return (uint32_t)cx + (uint32_t)cy * (uint32_t)kg.g.sx;
+}
+template <int NB, bool KEYGEN>
+__global__ __launch_bounds__(256) void k_rs_hist(uint32_t* __restrict__ key, uint32_t* __restrict__ val, uint32_t n, int shift, uint32_t nblocks,
+                                                  uint32_t* __restrict__ hist, CellKeyGen kg)
 {
     constexpr int DIG = 1 << NB;
     __shared__ uint32_t h[DIG];
@@ -48,7 +59,15 @@ __global__ __launch_bounds__(256) void k_rs_hist(const uint32_t* __restrict__ ke
     for (int r = 0; r < RS_ITEMS / 4; r++) {
         const uint32_t idx = base + r * 64 + lane;
         const bool valid = idx < n;
-        const uint32_t d = valid ? (key[idx] >> shift) & (uint32_t)(DIG - 1) : 0u;
+        uint32_t kv = 0u;
+        if (valid) {
+            if (KEYGEN) {
+                kv = cell_key_of(kg, idx);
+                key[idx] = kv;
+                val[idx] = idx;
+            } else kv = key[idx];
+        }
+        const uint32_t d = valid ? (kv >> shift) & (uint32_t)(DIG - 1) : 0u;
         const uint64_t peers = rs_peers<NB>(d, valid);
         if (valid && (peers & lt) == 0ull) atomicAdd(&h[d], (uint32_t)__popcll(peers));   // one add per distinct digit of the round
     }
@@ -176,12 +195,13 @@ size_t radix_sort_scratch_elems(uint32_t n)
 }
 
 template <int NB>
-static void radix_pass(hipStream_t s, Profiler* prof, const uint32_t* ki, const uint32_t* vi, uint32_t* ko, uint32_t* vo, uint32_t n, int shift,
-                       uint32_t nblocks, uint32_t* hist, uint32_t* totals)
+static void radix_pass(hipStream_t s, Profiler* prof, uint32_t* ki, uint32_t* vi, uint32_t* ko, uint32_t* vo, uint32_t n, int shift,
+                       uint32_t nblocks, uint32_t* hist, uint32_t* totals, const CellKeyGen* kg)
 {
     {
         ProfScope ps(prof, "sort_hist", s);
-        hipLaunchKernelGGL(k_rs_hist<NB>, dim3(nblocks), dim3(256), 0, s, ki, n, shift, nblocks, hist);
+        if (kg) hipLaunchKernelGGL((k_rs_hist<NB, true>), dim3(nblocks), dim3(256), 0, s, ki, vi, n, shift, nblocks, hist, *kg);
+        else hipLaunchKernelGGL((k_rs_hist<NB, false>), dim3(nblocks), dim3(256), 0, s, ki, vi, n, shift, nblocks, hist, CellKeyGen{});
     }
     {
         ProfScope ps(prof, "sort_rowscan", s);
@@ -194,7 +214,7 @@ static void radix_pass(hipStream_t s, Profiler* prof, const uint32_t* ki, const 
 }
 
 int radix_sort_pairs(hipStream_t s, Profiler* prof, uint32_t* keyA, uint32_t* valA, uint32_t* keyB, uint32_t* valB, uint32_t n,
-                     int bits, uint32_t* scratch)
+                     int bits, uint32_t* scratch, const CellKeyGen* keygen)
 {
     if (n == 0) return 0;
     uint32_t nblocks = (n + RS_TILE - 1) / RS_TILE;
@@ -208,9 +228,10 @@ int radix_sort_pairs(hipStream_t s, Profiler* prof, uint32_t* keyA, uint32_t* va
     int cur = 0;
     for (int p = 0; p < passes; p++) {
         uint32_t *ki = cur ? keyB : keyA, *vi = cur ? valB : valA, *ko = cur ? keyA : keyB, *vo = cur ? valA : valB;
-        if (nb == 8) radix_pass<8>(s, prof, ki, vi, ko, vo, n, p * nb, nblocks, hist, totals);
-        else if (nb == 9) radix_pass<9>(s, prof, ki, vi, ko, vo, n, p * nb, nblocks, hist, totals);
-        else radix_pass<10>(s, prof, ki, vi, ko, vo, n, p * nb, nblocks, hist, totals);
+        const CellKeyGen* kg = p == 0 ? keygen : nullptr;   // (keygen: keyA / valA are written by the first pass itself)
+        if (nb == 8) radix_pass<8>(s, prof, ki, vi, ko, vo, n, p * nb, nblocks, hist, totals, kg);
+        else if (nb == 9) radix_pass<9>(s, prof, ki, vi, ko, vo, n, p * nb, nblocks, hist, totals, kg);
+        else radix_pass<10>(s, prof, ki, vi, ko, vo, n, p * nb, nblocks, hist, totals, kg);
         cur ^= 1;
     }
     return cur;

@@ -2012,10 +2012,10 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
         const uint32_t n_sort = pre ? m.n_sort : n;
         c->dist.pre = false;
         if (n_sort) {
-            launch_cell_keys(s, prof, c->pm[c->pcur].as<float4>(), n_sort, g, c->key[0].as<uint32_t>(), c->val[0].as<uint32_t>(),
-                             pre ? c->dist.cls.as<uint8_t>() : nullptr, pre ? c->dist.pre_cls_n : 0u, (uint32_t)SC_GONE_FROM);
+            // (the keys -- cell index, or one past the last cell for a slot that left -- are made by the sort's first pass)
+            const CellKeyGen kg{c->pm[c->pcur].as<float4>(), g, pre ? c->dist.cls.as<uint8_t>() : nullptr, pre ? c->dist.pre_cls_n : 0u, (uint32_t)SC_GONE_FROM};
             int res = radix_sort_pairs(s, prof, c->key[0].as<uint32_t>(), c->val[0].as<uint32_t>(), c->key[1].as<uint32_t>(),
-                                       c->val[1].as<uint32_t>(), n_sort, ilog2_ceil(g.ncells + (pre ? 1u : 0u)), c->sort_scratch.as<uint32_t>());
+                                       c->val[1].as<uint32_t>(), n_sort, ilog2_ceil(g.ncells + (pre ? 1u : 0u)), c->sort_scratch.as<uint32_t>(), &kg);
             if (res == 1) {  // keep the sorted keys in key[0] / val[0]
                 std::swap(c->key[0], c->key[1]);
                 std::swap(c->val[0], c->val[1]);
