@@ -404,7 +404,7 @@ static int alloc_particle_buffers(sph_ctx* c)
     HIPCHK(c, c->nl.ensure(sweep_list_bytes((uint32_t)n)));
     HIPCHK(c, c->nl_ok.ensure(n));
     HIPCHK(c, c->red_partials.ensure(sizeof(SolverPartial) * (size_t)solver_reduce_blocks((uint32_t)n)));
-    HIPCHK(c, c->hdr_ahead_partials.ensure(sizeof(HeaderOut) * (size_t)solver_reduce_blocks((uint32_t)n)));
+    HIPCHK(c, c->hdr_ahead_partials.ensure(sizeof(HeaderOut) * (((size_t)n + 255) / 256)));   // one per 256-thread block of k_solver_tail (not a sweep block)
     return SPH_OK;
 }
 

@@ -36,7 +36,7 @@
 #include "sph_internal.hpp"
 
 #ifndef SWEEP_THREADS
-#define SWEEP_THREADS 256   // measured: 128 is slower (0.661 vs 0.624 ms/step, profiles/r2_variants.md context); 512 was within 1 % in round 1
+#define SWEEP_THREADS 256   // measured (profiles/r2_variants.md, last table): 128 and 1024 are slower (0.662 / 0.637 vs 0.619 ms/step), 512 is the same
 #endif
 #ifndef SPH_TILE_DEFAULT
 #define SPH_TILE_DEFAULT 0
