@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 """One step of a rocprofv3 kernel trace as a timeline: every launch with its offset, duration and the idle time before it,
    plus per-kernel sums over the step.  The step is the one of median length among those delimited by the marker kernel.
-   usage: kt_step_timeline.py <dir with *kernel_trace.csv> [marker substring, default k_solver_tail] [--full]"""
+   usage: kt_step_timeline.py <dir with *kernel_trace.csv> [marker substring, default k_cell_start: one per step] [--full]"""
 import csv, glob, sys, collections, statistics
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
-marker = sys.argv[2] if len(sys.argv) > 2 and not sys.argv[2].startswith("--") else "k_solver_tail"
+marker = sys.argv[2] if len(sys.argv) > 2 and not sys.argv[2].startswith("--") else "k_cell_start"
 full = "--full" in sys.argv
 rows = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(f))), key=lambda t: t[0])
 def short(n):

@@ -9,8 +9,8 @@ cd $GRAFT_REPO_ROOT
 python scripts/gpu_time.py dam_break_1m 60 > $OUT/plain_time.txt 2>&1
 python scripts/gpu_forced_slab_time.py 60 > $OUT/slab_time.txt 2>&1
 tail -n 1 $OUT/plain_time.txt; grep "forced slab" $OUT/slab_time.txt
-python scripts/kt_step_timeline.py $OUT/plain k_cell_keys > $OUT/plain_timeline.txt
-python scripts/kt_step_timeline.py $OUT/slab k_cell_keys > $OUT/slab_timeline.txt
-python scripts/kt_step_timeline.py $OUT/slab k_cell_keys --full > $OUT/slab_timeline_full.txt
-python scripts/kt_step_timeline.py $OUT/plain k_cell_keys --full > $OUT/plain_timeline_full.txt
+python scripts/kt_step_timeline.py $OUT/plain k_cell_start > $OUT/plain_timeline.txt
+python scripts/kt_step_timeline.py $OUT/slab k_cell_start > $OUT/slab_timeline.txt
+python scripts/kt_step_timeline.py $OUT/slab k_cell_start --full > $OUT/slab_timeline_full.txt
+python scripts/kt_step_timeline.py $OUT/plain k_cell_start --full > $OUT/plain_timeline_full.txt
 rm -rf $OUT/plain $OUT/slab
