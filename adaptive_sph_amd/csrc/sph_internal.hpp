@@ -94,8 +94,6 @@ int radix_sort_pairs(hipStream_t s, Profiler* prof, uint32_t* keyA, uint32_t* va
                      uint32_t n, int bits, uint32_t* hist_scratch /* >= 256 * nblocks + 256 */, const CellKeyGen* keygen = nullptr);
 size_t radix_sort_scratch_elems(uint32_t n);
 
-void launch_cell_keys(hipStream_t s, Profiler* prof, const float4* pm, uint32_t n, GridP g, uint32_t* key, uint32_t* val,
-                      const uint8_t* gone = nullptr, uint32_t n_gone = 0, uint32_t gone_from = 0);
 void launch_reorder(hipStream_t s, Profiler* prof, uint32_t n, GridP g, const uint32_t* sorted_key, const uint32_t* perm,
                     const float4* pm_in, const float2* vel_in, const uint32_t* orig_in, const float* lvl_in,
                     const float* lvlold_in, float4* pm_out, float2* vel_out, uint32_t* orig_out, float* lvl_out,

@@ -33,8 +33,11 @@ __device__ __forceinline__ uint64_t rs_peers(uint32_t d, bool valid)
 
 // NB = digit width in bits (8, 9 or 10: the fewest passes that cover the key; 18-bit cell ids take two 9-bit passes).
 // per-tile digit histogram: 256 threads, wave w owns keys [256 w, 256 w + 256) of the tile in 4 rounds of 64
-// KEYGEN: the first pass of the cell sort makes its keys itself -- cell index of particle idx from its record (what k_cell_keys
-// computes), stored for the scatter together with val = idx -- instead of reading them from a launch of their own
+// KEYGEN: the first pass of the cell sort makes its keys itself -- cell index of particle idx from its record, stored for the
+// scatter together with val = idx -- instead of reading them from a launch of their own.  Slots [0, n_gone) whose class byte is
+// >= gone_from left this rank's arrays (slab decomposition: last step's ghosts, particles handed to a neighbour): they get the key
+// `ncells`, one past the last cell -- the sort moves them behind the live particles and nothing after it looks at them, i.e. the
+// compaction of the arrays rides in the cell sort.
 __device__ __forceinline__ uint32_t cell_key_of(const CellKeyGen& kg, uint32_t i)
 {
     if (kg.gone && i < kg.n_gone && kg.gone[i] >= kg.gone_from) return kg.g.ncells;
@@ -240,34 +243,6 @@ int radix_sort_pairs(hipStream_t s, Profiler* prof, uint32_t* keyA, uint32_t* va
 // ------------------------------------------------------------------------------------------------
 // cell keys / reorder / cell-range table / tiles
 // ------------------------------------------------------------------------------------------------
-// `gone` (slab decomposition, optional): slots [0, n_gone) whose class byte is >= gone_from left this rank's arrays (last step's
-// ghosts, particles handed to a neighbour).  They get the key `ncells`, one past the last cell: the sort moves them behind
-// the live particles and nothing after it looks at them -- the compaction of the arrays rides in the cell sort.
-__global__ __launch_bounds__(256) void k_cell_keys(const float4* __restrict__ pm, uint32_t n, GridP g, uint32_t* __restrict__ key,
-                                                    uint32_t* __restrict__ val, const uint8_t* __restrict__ gone, uint32_t n_gone,
-                                                    uint32_t gone_from)
-{
-    uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    val[i] = i;
-    if (gone && i < n_gone && gone[i] >= gone_from) {
-        key[i] = g.ncells;
-        return;
-    }
-    float4 p = pm[i];
-    // IEEE division, like `(particle_pos / kernel_support_radius).map(|x| x.floor() as i32)`
-    int cx = (int)floorf(p.x / g.cs) - g.minx;
-    int cy = (int)floorf(p.y / g.cs) - g.miny;
-    key[i] = (uint32_t)cx + (uint32_t)cy * (uint32_t)g.sx;
-}
-
-void launch_cell_keys(hipStream_t s, Profiler* prof, const float4* pm, uint32_t n, GridP g, uint32_t* key, uint32_t* val,
-                      const uint8_t* gone, uint32_t n_gone, uint32_t gone_from)
-{
-    ProfScope ps(prof, "cell_keys", s);
-    hipLaunchKernelGGL(k_cell_keys, dim3((n + 255) / 256), dim3(256), 0, s, pm, n, g, key, val, gone, n_gone, gone_from);
-}
-
 __global__ __launch_bounds__(256) void k_reorder(uint32_t n, GridP g, const uint32_t* __restrict__ sorted_key,
                                                   const uint32_t* __restrict__ perm, const float4* __restrict__ pm_in,
                                                   const float2* __restrict__ vel_in, const uint32_t* __restrict__ orig_in,

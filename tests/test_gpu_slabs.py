@@ -313,6 +313,30 @@ def test_neighbour_lists_of_the_slabs_are_those_of_the_single_context(product_li
     assert seen.all() and crossing > 0
 
 
+def test_a_slab_without_room_for_its_ghosts_says_so(product_lib):
+    """Between the refresh and the cell sort a slab holds its previous slots, the arrivals and the new ghosts: a context that
+    cannot fit them returns SPH_ERR_CAPACITY (and is poisoned) -- it never writes past its arrays."""
+    scn = sc.dam_break_small(96, 48, 1 / 48)
+    pos, mass, vel = sc.init_particles(scn)
+    planes = sc.boundary_planes(scn.boundary)
+    p = forced(max_iters=3).to_ffi()
+    cuts = D.slab_cuts(pos[:, 0], 2)
+    parts = D.partition(pos[:, 0], cuts)
+    grp = []
+    for r in range(2):
+        c = ffi.Context(product_lib, len(parts[r]) + 8, planes)          # room for the owned particles, not for a ghost layer
+        c.dist_configure(r, 2, cuts[r], cuts[r + 1])
+        c.upload(mass[parts[r]], pos[parts[r]], vel[parts[r]])
+        c.upload_field("particle_id", parts[r].astype(np.uint32))
+        grp.append(c)
+    with pytest.raises(ffi.SphError) as e:
+        for _ in range(3):
+            ffi.group_step(grp, p)
+    assert e.value.status == 3 and "capacity" in str(e.value)          # SPH_ERR_CAPACITY
+    with pytest.raises(ffi.SphError):
+        ffi.group_step(grp, p)                                          # poisoned until sph_upload
+
+
 def test_group_of_one_is_the_plain_step(product_lib):
     scn = sc.dam_break_small(32, 32, 1 / 32)
     pos, mass, vel = sc.init_particles(scn)
