@@ -42,15 +42,55 @@ class _ParticleView:
             raise AttributeError(name)
 
 
+def rust_display(x, f32: bool = False) -> str:
+    """What Rust's `{}` prints for an f32 / f64: the shortest digits that round-trip in that type, never an exponent, no
+    trailing ".0" (`1035f32` -> "1035", `0.1f32` -> "0.1"), "NaN" / "inf" for the non-finite."""
+    v = np.float32(x) if f32 else np.float64(x)
+    if np.isnan(v):
+        return "NaN"
+    if np.isinf(v):
+        return "inf" if v > 0 else "-inf"
+    return np.format_float_positional(v, unique=True, trim="-")
+
+
 class _Counter:
+    """Counter<FT> (values: f32; avg = sequential f32 sum / f32 count, simulation.rs:96-106)."""
+
     def __init__(self):
         self.values: List[float] = []
 
     def add_value(self, v: float):
-        self.values.append(float(v))
+        self.values.append(float(np.float32(v)))
 
     def avg(self):
-        return sum(self.values) / len(self.values) if self.values else float("nan")
+        if not self.values:
+            return float("nan")
+        acc = np.float32(0)
+        for v in self.values:
+            acc = np.float32(acc + np.float32(v))
+        return float(np.float32(acc / np.float32(len(self.values))))
+
+    def min(self):
+        return float(min(self.values)) if self.values else float(np.finfo(np.float32).max)     # fold from FT::max_value()
+
+    def max(self):
+        return float(max(self.values)) if self.values else float(np.finfo(np.float32).min)
+
+
+class _PCounter:
+    """Counter<Duration> (simulation.rs:108-135): whole nanoseconds; avg = sum / count in integer nanoseconds."""
+
+    def __init__(self):
+        self.values: List[int] = []
+
+    def add_value(self, ms: float):
+        self.values.append(int(round(float(ms) * 1e6)))
+
+    def sum_secs(self) -> float:
+        return sum(self.values) / 1e9
+
+    def avg_secs(self) -> float:
+        return (sum(self.values) // len(self.values)) / 1e9 if self.values else float("nan")
 
 
 class FluidSimulation:
@@ -71,7 +111,7 @@ class FluidSimulation:
             # PerformanceCounters::new(counters_enabled) (simulation.rs:137-189): per-phase times need the library's event
             # instrumentation (neighbourhood / level estimation / the two solves); it perturbs dispatch, like `-p` does
             self.ctx.profile_enable(1)
-        self.pcounters: Dict[str, _Counter] = {}
+        self.pcounters: Dict[str, _PCounter] = {}
         self.vcounters: Dict[str, _Counter] = {}
         self.step_number = 0
         self.last_stats: Optional[ffi.SphStepStats] = None
@@ -137,25 +177,27 @@ class FluidSimulation:
         self.vcounters.setdefault(key, _Counter()).add_value(v)
 
     def _p(self, key, ms):
-        self.pcounters.setdefault(key, _Counter()).add_value(ms)
+        self.pcounters.setdefault(key, _PCounter()).add_value(ms)
 
     def write_statistics(self) -> str:
+        """write_statistics (simulation.rs:3279-3359), number for number: `{:.2}` / `{:.02}` for the LaTeX row, Rust's `{}` for
+        everything else (rust_display); counters sorted by label."""
         pc, vc = self.pcounters, self.vcounters
-        sim_ms = sum(pc["simulation-step"].values)
+        sim_s = pc["simulation-step"].sum_secs()
         lines = []
-        lines.append("${:.2f}\\si{{\\second}}$ & {} & {:.02f} & {:.02f} & - \\\\".format(
-            sim_ms / 1e3, int(round(vc["particle-count"].avg())),
+        lines.append("${:.2f}\\si{{\\second}}$ & {} & {:.2f} & {:.2f} & - \\\\".format(
+            sim_s, int(np.copysign(np.floor(abs(vc["particle-count"].avg()) + 0.5), vc["particle-count"].avg())),   # f32::round: half away from zero
             vc["div-iterations"].avg() if "div-iterations" in vc else float("nan"),
             vc["density-iterations"].avg() if "density-iterations" in vc else float("nan")))
         lines.append("")
-        lines.append(f"simulation-time: {sim_ms}ms")
+        lines.append(f"simulation-time: {rust_display(sim_s * 1000.)}ms")
         lines.append("")
         for label in sorted(pc):
-            lines.append(f"{label}: avg:{pc[label].avg()}ms")
+            lines.append(f"{label}: avg:{rust_display(pc[label].avg_secs() * 1000.)}ms")
         lines.append("")
         for label in sorted(vc):
             c = vc[label]
-            lines.append(f"{label}: min:{min(c.values)} max:{max(c.values)} avg:{c.avg()}")
+            lines.append(f"{label}: min:{rust_display(c.min(), True)} max:{rust_display(c.max(), True)} avg:{rust_display(c.avg(), True)}")
         return "\n".join(lines) + "\n"
 
     def close(self):

@@ -174,3 +174,112 @@ def test_grid_search_is_the_uniform_builds_only():
     from adaptive_sph_amd.workloads import dam_break_params
     with pytest.raises(ValueError):
         dam_break_params(neighborhood_search_algorithm="Grid").to_ffi()
+
+
+def test_write_statistics_known_answer():
+    """write_statistics (simulation.rs:3279-3359) number for number.  The expected text is what the reference's format strings
+    give for these counters: `{:.2}` / `{:.02}` in the LaTeX row, Rust's `{}` elsewhere (shortest round-trip digits of the f32 /
+    f64, no exponent, no trailing `.0`), Counter<FT>::avg as a sequential f32 sum (:96-106), Counter<Duration>::avg in whole
+    nanoseconds (:127-129), labels sorted."""
+    from adaptive_sph_amd.simulation import FluidSimulation, _Counter, _PCounter, rust_display
+    assert rust_display(1035.0, True) == "1035" and rust_display(0.1, True) == "0.1" and rust_display(np.float32(1) / np.float32(3), True) == "0.33333334"
+    assert rust_display(1e-7) == "0.0000001" and rust_display(2.5) == "2.5" and rust_display(float("nan")) == "NaN" and rust_display(1234.5 * 1000.) == "1234500"
+    sim = FluidSimulation.__new__(FluidSimulation)
+    sim.pcounters, sim.vcounters = {}, {}
+    for ms in (1.5, 2.25, 0.75):                       # Durations of 1 500 000, 2 250 000 and 750 000 ns
+        sim.pcounters.setdefault("simulation-step", _PCounter()).add_value(ms)
+    for ms in (0.5, 0.25):
+        sim.pcounters.setdefault("neighborhood-search", _PCounter()).add_value(ms)
+    for n in (1035, 1035, 1036):
+        sim.vcounters.setdefault("particle-count", _Counter()).add_value(n)
+    for it in (3, 4, 3):
+        sim.vcounters.setdefault("div-iterations", _Counter()).add_value(it)
+    for it in (5, 5, 6):
+        sim.vcounters.setdefault("density-iterations", _Counter()).add_value(it)
+    for dt in (0.5, 0.25, 0.125):                      # exact in f32: the average is 0.875 / 3 rounded to f32
+        sim.vcounters.setdefault("dt", _Counter()).add_value(dt)
+    expected = (
+        "$0.00\\si{\\second}$ & 1035 & 3.33 & 5.33 & - \\\\\n"
+        "\n"
+        "simulation-time: 4.5ms\n"
+        "\n"
+        "neighborhood-search: avg:0.375ms\n"
+        "simulation-step: avg:1.5ms\n"
+        "\n"
+        "density-iterations: min:5 max:6 avg:5.3333335\n"
+        "div-iterations: min:3 max:4 avg:3.3333333\n"
+        "dt: min:0.125 max:0.5 avg:0.29166666\n"
+        "particle-count: min:1035 max:1036 avg:1035.3334\n")
+    assert sim.write_statistics() == expected
+
+
+def _read_legacy_vtk(path):
+    """An independent reader of the legacy VTK POLYDATA format (file-formats.pdf of VTK 4.2: header, POINTS, VERTICES, LINES,
+    POINT_DATA with SCALARS arrays; BINARY sections are big-endian), used to pin what VtkExporter writes."""
+    raw = open(path, "rb").read()
+    pos = 0
+
+    def line():
+        nonlocal pos
+        while raw[pos:pos + 1] == b"\n":
+            pos += 1
+        end = raw.index(b"\n", pos)
+        out = raw[pos:end].decode()
+        pos = end + 1
+        return out
+
+    def take(dtype, count):
+        nonlocal pos
+        a = np.frombuffer(raw, dtype, count, pos)
+        pos += a.nbytes
+        return a
+
+    out = {"version": line(), "title": line(), "encoding": line(), "dataset": line(), "arrays": []}
+    kw, n, ty = line().split()
+    assert kw == "POINTS" and ty == "float"
+    out["points"] = take(">f4", 3 * int(n)).reshape(-1, 3)
+    kw, nc, sz = line().split()
+    assert kw == "VERTICES"
+    out["verts"] = take(">i4", int(sz)).reshape(int(nc), -1)
+    nxt = line()
+    if nxt.startswith("LINES"):
+        _, nc, sz = nxt.split()
+        out["lines"] = take(">i4", int(sz)).reshape(int(nc), -1)
+        nxt = line()
+    kw, npd = nxt.split()
+    assert kw == "POINT_DATA"
+    out["n_point_data"] = int(npd)
+    while pos < len(raw) and raw[pos:].strip():
+        kw, name, ty, comps = line().split()
+        assert kw == "SCALARS" and line() == "LOOKUP_TABLE default"
+        dt = {"float": ">f4", "unsigned_char": "u1"}[ty]
+        out["arrays"].append((name, ty, int(comps), take(dt, int(npd) * int(comps)).reshape(int(npd), int(comps))))
+    return out
+
+
+def test_vtk_snapshot_read_back(tmp_path):
+    """What write_vtk_file / write_vtk_file2 (vtk_exporter.rs:82-152, 256-367) put into a snapshot: version 4.2, title, BINARY
+    big-endian POLYDATA, particles as VERTICES (`1 i`), Sdf2D edges as LINES over two extra points each, point data in the
+    reference's order, names, component counts and types with zeros on the line points."""
+    from adaptive_sph_amd.vtk_exporter import write_vtk_file2
+    rng = np.random.default_rng(3)
+    n = 37
+    pos = rng.random((n, 2), np.float32)
+    ft = [(k, rng.random(n, np.float32)) for k in ("density", "density_error", "density_error2", "pressure", "mass", "aii", "h", "ppe_source_term", "distances", "lambda")]
+    vec = [(k, rng.random((n, 2), np.float32)) for k in ("velocity", "pressure_accel")]
+    u8 = [(k, (rng.random(n) < 0.3).astype(np.uint8)) for k in ("flag_is_fluid_surface", "flag_neighborhood_reduced")]
+    lines = [((0.0, 0.0), (1.0, 0.0)), ((1.0, 0.0), (1.0, 1.0)), ((1.0, 1.0), (0.0, 0.0))]
+    path = tmp_path / "snap.vtk"
+    write_vtk_file2(path, pos, ft, vec, u8, lines)
+    v = _read_legacy_vtk(path)
+    assert (v["version"], v["title"], v["encoding"], v["dataset"]) == ("# vtk DataFile Version 4.2", "SPH Particles 1.0", "BINARY", "DATASET POLYDATA")
+    assert v["points"].shape == (n + 6, 3) and np.array_equal(v["points"][:n, :2], pos) and not v["points"][:, 2].any()
+    assert np.array_equal(v["points"][n:, :2].reshape(3, 2, 2), np.array(lines, np.float32))
+    assert np.array_equal(v["verts"], np.stack([np.ones(n, np.int32), np.arange(n, dtype=np.int32)], 1))
+    assert np.array_equal(v["lines"], np.array([[2, n + 2 * k, n + 2 * k + 1] for k in range(3)]))
+    assert v["n_point_data"] == n + 6
+    assert [(a[0], a[1], a[2]) for a in v["arrays"]] == [(k, "float", 1) for k, _ in ft] + [(k, "float", 3) for k, _ in vec] + [(k, "unsigned_char", 1) for k, _ in u8]
+    for (name, _, comps, got), (_, want) in zip(v["arrays"], ft + vec + u8):
+        w = np.asarray(want).reshape(n, -1)
+        assert np.array_equal(got[:n, :w.shape[1]], w), name
+        assert not got[n:].any() and not got[:, w.shape[1]:].any(), name       # dummy data on the line points, z = 0
