@@ -296,6 +296,34 @@ struct OpPrologue<Op, std::void_t<decltype(&Op::prologue)>> {
     static __device__ __forceinline__ bool run(const Op& op, uint32_t raw_block) { return op.prologue(raw_block); }
 };
 
+// SPH_BUILD_2PHASE (variant, scripts/variants): the BUILD sweep of a uniform scene in two phases, in registers -- the neighbour
+// predicate over a row's candidates, branch-free, into the row mask (4 unclamped loads per trip: the records behind a row's end
+// are other particles' or the allocation's slack, their bits are masked by the validity test); then the op's pair() over the
+// accepted bits only, through the same replay the later sweeps use.  Same visiting order and arithmetic as the walk.
+#ifndef SPH_BUILD_2PHASE
+#define SPH_BUILD_2PHASE 0
+#endif
+template <class Op>
+__device__ __forceinline__ uint32_t predicate_row(const Op& op, const float4 Ai, const uint32_t b, const uint32_t e, const float s2)
+{
+    uint32_t m = 0u;
+    for (uint32_t j = b; j < e; j += 4) {
+        const float4 A0 = op.loadA(j), A1 = op.loadA(j + 1), A2 = op.loadA(j + 2), A3 = op.loadA(j + 3);
+#define SPH_PRED(AJ, K)                                                                        \
+    {                                                                                          \
+        const float dx = Ai.x - AJ.x, dy = Ai.y - AJ.y;                                        \
+        const float r2 = dx * dx + dy * dy;                                                    \
+        m |= ((j + K < e && r2 < s2) ? 1u : 0u) << (j + K - b);                                \
+    }
+        SPH_PRED(A0, 0u)
+        SPH_PRED(A1, 1u)
+        SPH_PRED(A2, 2u)
+        SPH_PRED(A3, 3u)
+#undef SPH_PRED
+    }
+    return m;
+}
+
 // one particle of a sweep, every list form: mask word, explicit index list, candidate walk (3 x 3 cells or a wide stencil)
 // (Ai, lw: the particle's record and list word, loaded by the caller BEFORE it looks at the slab flags -- one memory round trip
 //  at the head of every wave instead of two)
@@ -348,7 +376,13 @@ __device__ __forceinline__ void sweep_particle(const Op& op, const SweepCommon& 
                 IdxRecorder rec;
                 rec.cur = make_uint4(0, 0, 0, 0);
                 const bool rec_idx = BUILD && IDX && (!ok_list || (SPH_FORCE_IDX && !Op::EXTENDED));
-                if (rec_idx) {
+                if (SPH_BUILD_2PHASE && BUILD && Math::UNIFORM && !Op::EXTENDED && !SPH_FORCE_IDX && ok_list) {
+                    const float s = op.m.h * op.krange();
+#pragma unroll
+                    for (int dr = 0; dr < 3; dr++) mk[dr] = predicate_row(op, Ai, rb[dr], re[dr], s * s);
+                    replay_masks(op, acc, Ai, rb, make_uint4(mk[0], mk[1], mk[2], 0u));
+                    nacc = (uint32_t)(__popc(mk[0]) + __popc(mk[1]) + __popc(mk[2]));
+                } else if (rec_idx) {
 #pragma unroll
                     for (int dr = 0; dr < 3; dr++) walk_row<Op, false, true>(op, acc, Ai, rb[dr], re[dr], mk[dr], nacc, rec, c.nlx, c.n, i);
                     rec.flush(nacc, c.nlx, c.n, i);
