@@ -1016,6 +1016,7 @@ extern "C" int sph_download_neighbors(sph_ctx* c, uint32_t* offsets, uint32_t* i
         // Slab context: one row per OWNED particle, in the order of sph_download(SPH_F_PARTICLE_ID); the indices are global particle
         // ids (an owned particle's neighbours are all among owned + ghosts, and the ghost records carry their ids).
         if (!c->dist.have_flags) return c->fail(SPH_ERR_INVALID_ARGUMENT, "no neighbour lists yet: run a step first");
+        if (c->lists_after) return c->fail(SPH_ERR_UNSUPPORTED, "neighbour-list export of a slab context after a step with level_estimation_after_advection (the extended lists of the advected positions) is not covered yet");
         const uint32_t nt = c->dist.n_tot;
         rc = sph_download(c, SPH_F_NEIGHBOR_COUNT, cnt.data(), (uint64_t)n * 4);
         if (rc) return rc;

@@ -123,6 +123,8 @@ struct sph_ctx {
     bool lists_after = false;        // the cache holds the extended lists of the advected positions (level_estimation_after_advection)
     float lists_after_k = 0.f, lists_after_slack = 0.f;
     float h_max_step = 0.f;   // largest smoothing length of the current step (all ranks)
+    float last_dmax = 0.f;    // slab decomposition, level estimation after advection: largest displacement of the previous step (all ranks)
+    float slab_slack_w = 0.f; // ... and the extra ghost width this step's layer was built with for it
     DevBuf szc[2];     // ParticleVec::particle_size_class (u8), persistent: IISPH2's omega reads the class of the previous step
     DevBuf omega;      // IISPH2 (simulation.rs:2262-2311)
     DevBuf split_patterns;            // SplitPatterns::pos_s of every pattern, concatenated float2 (sph_set_split_patterns)

@@ -1775,8 +1775,6 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
     if (p->constrain_neighborhood_count && G.multi())
         return c0->fail(SPH_ERR_UNSUPPORTED, "constrain_neighborhood_count on a slab decomposition is not covered yet");
     const bool level_on = p->level_estimation_method != SPH_LEVEL_NONE;
-    if (level_on && G.multi() && p->level_estimation_after_advection)
-        return c0->fail(SPH_ERR_UNSUPPORTED, "level_estimation_after_advection on a slab decomposition is not covered yet");
     const bool level_after = level_on && p->level_estimation_after_advection;
     if (level_on && !level_after && p->level_estimation_method == SPH_LEVEL_CENTER_DIFF)   // simulation.rs:2029-2031
         return c0->fail(SPH_ERR_INVALID_ARGUMENT, "center diff level estimation method needs density values");
@@ -1808,6 +1806,13 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
     std::vector<std::vector<float>> red(M.size(), std::vector<float>(8));
     int hdr_rc = SPH_OK, setup_rc = SPH_OK;
     bool slab_fused = false;   // the ghost layer is already in place (slab_refresh_fused)
+    // Ghost width in smoothing lengths of the largest particle: two rings of one support radius (2 h_max each), or the extended
+    // range of the level estimation.  Level estimation AFTER advection looks for neighbours at the advected positions among the
+    // ghosts selected BEFORE the step: the layer is widened by twice the largest displacement the step may produce -- 4 x the
+    // previous step's (all-reduced) largest displacement, at least 2 h_max -- and the step checks afterwards that it sufficed.
+    const float slab_slack_k = (level_on && p->level_estimation_after_advection && G.multi())
+                                   ? fmaxf(2.f, c0->h_max_step > 0.f ? 4.f * c0->last_dmax / c0->h_max_step : 0.f) : 0.f;
+    auto halo_factor = [&]() { return fmaxf(4.f, level_on ? p->level_estimation_range / SPH_ETA : 0.f) + slab_slack_k; };
     // The tail of the previous step's last solve already reduced this step's header into hdr_host (k_solver_tail,
     // k_header_ahead): nothing to launch, nothing to wait for -- unless the host touched the state or the smoothing lengths are
     // not the mass-derived ones.  On a slab the header describes the particles the rank owned at the END of that step; the ones
@@ -1849,7 +1854,7 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
         // repeat until nobody moved (the all-reduced count), at most once per rank.  The header all-reduce rides in the round
         // trip of the first partition's counts.
         // ordinary steps: the fused refresh (one round trip, no partition sort); it reduces `red` whether or not it applies
-        const float halo_k_f = fmaxf(4.f, level_on ? p->level_estimation_range / SPH_ETA : 0.f);
+        const float halo_k_f = halo_factor();
         const bool no_fused = getenv("SPH_SLAB_GENERAL") != nullptr;   // measurement / test aid: always the general path (read per step)
         const bool attempt = h_from_mass_mode && !rebalanced && !no_fused;     // (parameters and all-reduced values: the same on every rank)
         if (attempt) {
@@ -1903,7 +1908,8 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
         // (the extended lists of the level estimation reach level_estimation_range / ETA smoothing lengths)
         // Two rings of one support radius (2 h_max) each: ghosts of the first ring compute their pressure acceleration here
         // (their neighbours are all inside the second), so a Jacobi iteration exchanges p / rho^2 only.
-        const float halo_k = fmaxf(4.f, level_on ? p->level_estimation_range / SPH_ETA : 0.f);
+        const float halo_k = halo_factor();
+        for (auto& m : M) m.c->slab_slack_w = slab_slack_k * h_max_g;
         const float halo_w = h_max_g * halo_k;
         if (!slab_fused && (rc = build_ghost_layer(G, M, halo_w, h_max_g * 2.f, status_in))) return rc;
         // bounding box of owned + ghosts from the cuts: an owned particle lies between them, a ghost within halo_w beyond one
@@ -2227,8 +2233,48 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
     // the same on a slab decomposition (before advection): ghost lanes idle, the ghosts' (level, when) refreshed from their
     // owners after the detection and after every sweep, propagation without frontier marks, the stop decision all-reduced
     std::vector<LevelArgs> LV(M.size());
-    auto level_estimation_slabs = [&]() -> int {
+    std::vector<SweepArgs> AL(M.size());   // the sweep arguments the level estimation runs with (advected geometry when `after`)
+    float slab_lv_slack = 0.f;
+    // `after` (level_estimation_after_advection, simulation.rs:2678-2707): detection and propagation on the lists of the ADVECTED
+    // positions -- the ghosts' advected records come from their owners first; the extended lists are gathered from the cells of
+    // the pre-step positions with every range widened by twice the largest displacement over ALL ranks, which the ghost layer
+    // was sized for at the start of the step (slab_slack_k) and which is checked here
+    auto level_estimation_slabs = [&](bool after) -> int {
         const auto t_lvl0 = std::chrono::steady_clock::now();
+        const bool replay_step_lists = after && !p->use_extended_range_for_level_estimation;   // simulation.rs:2680: no rebuild
+        slab_lv_slack = 0.f;
+        if (after) {
+            for (auto& m : M) m.lv_pmnew = (float*)m.c->pm[m.c->pcur ^ 1].as<float4>();
+            if ((rc = refresh_ghosts(G, M, sel_lv_pmnew, 4, "pm_new"))) return rc;
+            if (!replay_step_lists) {
+                for (auto& m : M) {
+                    sph_ctx* c = m.c;
+                    (void)hipSetDevice(c->device);
+                    HIPCHK(c, c->lvl_changed_d.ensure(1024 * sizeof(uint32_t)));
+                    uint32_t* chg = c->lvl_changed_d.as<uint32_t>();
+                    (void)hipMemsetAsync(chg + 1022, 0, sizeof(uint32_t), c->stream);
+                    launch_max_disp(c->stream, &c->prof, m.n, c->pm[c->pcur].as<float4>(), c->pm[c->pcur ^ 1].as<float4>(), chg + 1022);
+                    HIPCHK(c, hipMemcpyAsync(c->lvl_changed, chg + 1022, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+                }
+                if ((rc = agree(G, wait_all(G)))) return rc;
+                std::vector<std::vector<float>> dm(M.size(), std::vector<float>(1));
+                for (size_t i = 0; i < M.size(); i++) {
+                    float d;
+                    memcpy(&d, (const void*)M[i].c->lvl_changed, 4);
+                    dm[i][0] = -d;   // (NaN stays NaN through fminf only by luck: tested below on the local value too)
+                    if (!std::isfinite(d)) dm[i][0] = -INFINITY;
+                }
+                if ((rc = G.comm->allreduce_min_f32(G, dm))) return rc;
+                const float dmax = -dm[0][0];
+                if (!std::isfinite(dmax)) return c0->fail(SPH_ERR_POSITION_NOT_FINITE, "Assertion 'p_position[d].is_finite()' failed!");
+                for (auto& m : M) m.c->last_dmax = dmax;
+                slab_lv_slack = 2.f * dmax;
+                // (all-reduced values only: every rank takes the same branch)
+                if (slab_lv_slack > c0->slab_slack_w)
+                    return c0->fail(SPH_ERR_UNSUPPORTED, "level estimation after advection on a slab decomposition: the particles moved %g in this step, the ghost layer "
+                                    "was widened for %g (4 x the previous step's largest displacement, at least 2 h_max)", (double)dmax, (double)(0.5f * c0->slab_slack_w));
+            }
+        }
         for (size_t i = 0; i < M.size(); i++) {
             Member& m = M[i];
             sph_ctx* c = m.c;
@@ -2242,10 +2288,14 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
             for (DevBuf* b : {&c->lvl_state, &c->flag_surface, &c->flag_insufficient}) HIPCHK(c, b->ensure(n));
             HIPCHK(c, c->nl_ext.ensure(sweep_list_bytes((uint32_t)n)));
             HIPCHK(c, c->nlx_ext.ensure(sweep_index_list_bytes((uint32_t)n)));
-            HIPCHK(c, c->lvl_changed_d.ensure(64 * sizeof(uint32_t)));
-            m.a = make_args(c, m.sp);
-            m.a.h_mode = p->support_length_estimation;
-            m.a.sp_check_aii = p->check_aii;
+            HIPCHK(c, c->lvl_changed_d.ensure(1024 * sizeof(uint32_t)));
+            if (!after) {
+                m.a = make_args(c, m.sp);
+                m.a.h_mode = p->support_length_estimation;
+                m.a.sp_check_aii = p->check_aii;
+            }
+            m.a.nl_ext = c->nl_ext.as<uint4>();
+            m.a.nlx_ext = c->nlx_ext.as<uint4>();
             LevelArgs& l = LV[i];
             l = LevelArgs{};
             l.k = p->level_estimation_range / SPH_ETA;
@@ -2265,6 +2315,24 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
             l.level_old = c->lvlold[c->cur].as<float>();
             l.stash_first = p->fill_stash_with == SPH_STASH_SURFACE_DISTANCE_FIRST ? c->stash.as<float>() : nullptr;
             l.plain_propagate = 1;
+            l.pm_cell = after ? c->pm[c->pcur].as<float4>() : nullptr;
+            l.center_diff = p->level_estimation_method == SPH_LEVEL_CENTER_DIFF;
+            l.replay_step_lists = replay_step_lists;
+            if (replay_step_lists) {
+                m.a.nl_ext = m.a.nl;
+                m.a.nlx_ext = m.a.nlx;
+            }
+            SweepArgs& al = AL[i];
+            al = m.a;
+            if (after) {
+                al.pm = c->pm[c->pcur ^ 1].as<float4>();
+                al.t_ext.slack = slab_lv_slack;
+                if (!replay_step_lists && c->tile_ts > 0) {
+                    const float tile_side = (float)c->tile_ts * c->fgrid.cs;
+                    const int dd = (int)ceilf((l.k * c->h_max_step + slab_lv_slack) / tile_side);
+                    launch_tile_redilate(c->stream, &c->prof, c->tile_tsx, c->tile_tsy, dd < 1 ? 1 : dd, c->tile_raw.as<uint32_t>(), c->tile_h_ext.as<uint32_t>());
+                }
+            }
             m.lv_level = (float*)l.level;
             m.lv_when = (float*)l.when;
             if (m.n) {
@@ -2272,7 +2340,7 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
                 // (flags / states of the ghost slots are never read; zero them so that downloads see defined bytes)
                 (void)hipMemsetAsync(c->flag_surface.p, 0, n, c->stream);
                 (void)hipMemsetAsync(c->flag_insufficient.p, 0, n, c->stream);
-                launch_level_detect(c->stream, &c->prof, m.a, l);
+                launch_level_detect(c->stream, &c->prof, al, l);
             }
         }
         if ((rc = refresh_ghosts(G, M, sel_lv_level, 1, "level"))) return rc;
@@ -2290,9 +2358,9 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
                     sph_ctx* c = m.c;
                     (void)hipSetDevice(c->device);
                     if (!m.n) continue;
-                    launch_level_propagate(c->stream, &c->prof, m.a, LV[i], t, c->lvl_changed_d.as<uint32_t>() + b);
+                    launch_level_propagate(c->stream, &c->prof, AL[i], LV[i], t, c->lvl_changed_d.as<uint32_t>() + b);
                     if (t == 1u && p->fill_stash_with == SPH_STASH_SURFACE_DISTANCE_MIDDLE)
-                        launch_fill_stash(c->stream, &c->prof, m.a, LV[i], c->stash.as<float>());
+                        launch_fill_stash(c->stream, &c->prof, AL[i], LV[i], c->stash.as<float>());
                 }
                 if ((rc = refresh_ghosts(G, M, sel_lv_level, 1, "level"))) return rc;
                 if ((rc = refresh_ghosts(G, M, sel_lv_when, 1, "when"))) return rc;
@@ -2316,8 +2384,8 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
         }
         return SPH_OK;
     };
-    if (level_on && G.multi()) {
-        if ((rc = level_estimation_slabs())) return rc;
+    if (level_on && G.multi() && !level_after) {
+        if ((rc = level_estimation_slabs(false))) return rc;
         for (auto& m : M) dbg_sync(m.c, "level estimation (slabs)", 4);
     } else if (level_on && !level_after) {
         static const bool no_side = getenv("SPH_LEVEL_SERIAL") != nullptr;   // measurement aid: everything on one stream
@@ -2548,6 +2616,7 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
 
     // ---- smooth_level_estimation_field (simulation.rs:2709-2722) ------------------------------------------------------------
     if (level_on && G.multi()) {
+        if (level_after && (rc = level_estimation_slabs(true))) return rc;   // simulation.rs:2678-2707, at the advected positions
         const auto t_lvl0 = std::chrono::steady_clock::now();
         for (auto& m : M) {
             m.lv_level = m.c->lvl[m.c->cur].as<float>();
@@ -2555,13 +2624,15 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
         }
         // the ghosts' level values and ADVECTED records (ghost lanes do not integrate) come from their owners
         if ((rc = refresh_ghosts(G, M, sel_lv_level, 1, "level"))) return rc;
-        if ((rc = refresh_ghosts(G, M, sel_lv_pmnew, 4, "pm_new"))) return rc;
+        if (!level_after && (rc = refresh_ghosts(G, M, sel_lv_pmnew, 4, "pm_new"))) return rc;
         for (size_t i = 0; i < M.size(); i++) {
             Member& m = M[i];
             sph_ctx* c = m.c;
             (void)hipSetDevice(c->device);
             if (!m.n) continue;
-            launch_level_smooth(c->stream, &c->prof, m.a, LV[i], c->pm[c->pcur ^ 1].as<float4>(), c->lvl[c->cur].as<float>(), c->lvl_tmp.as<float>());
+            SweepArgs as = level_after ? AL[i] : m.a;
+            as.pm = m.a.pm;   // (the smoothing takes the advected records as its own argument)
+            launch_level_smooth(c->stream, &c->prof, as, LV[i], c->pm[c->pcur ^ 1].as<float4>(), c->lvl[c->cur].as<float>(), c->lvl_tmp.as<float>());
             std::swap(c->lvl[c->cur], c->lvl_tmp);
             // (no classify_particles here: the reference's step never calls it -- sph_classify is the host's call)
         }
@@ -2569,7 +2640,7 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
         if ((rc = sync_ctrl(G, SYNC_FINAL))) return rc;
         for (auto& m : M) m.st.ms_level_estimation += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_lvl0).count();
     }
-    if (level_after) {   // simulation.rs:2678-2707: lists of the advected positions, then detection + propagation there
+    if (level_after && !G.multi()) {   // simulation.rs:2678-2707: lists of the advected positions, then detection + propagation there
         sph_ctx* c = M[0].c;
         if ((rc = level_estimation(c->pm[c->pcur ^ 1].as<float4>(), c->pm[c->pcur].as<float4>(), false))) return rc;
     }
@@ -2593,8 +2664,8 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
         sph_ctx* c = m.c;
         c->pcur ^= 1;  // integrated positions live in the other pm buffer; the old one keeps the pre-step snapshot
         c->lists_after = level_after && p->use_extended_range_for_level_estimation;
-        c->lists_after_k = lv.k;
-        c->lists_after_slack = lv_slack;
+        c->lists_after_k = G.multi() ? LV[i].k : lv.k;
+        c->lists_after_slack = G.multi() ? slab_lv_slack : lv_slack;
         // every solver mode ends in an integrating final sweep, which left the next step's header in hdr_host
         // (constrain_neighborhood_count left reduced smoothing lengths in the records: the next step's k_header restores them)
         c->hdr_ahead = h_from_mass_mode && m.n > 0 && m.a.hdr_partials != nullptr && !p->constrain_neighborhood_count;

@@ -388,6 +388,8 @@ int sph_set_sweep_variant(int mode);
  * ring compute their own pressure acceleration) with the x-neighbours over RCCL point-to-point after every sweep whose
  * output neighbours read -- once per Jacobi iteration --, and all-reduces the CFL minimum and the Jacobi residual
  * statistics so that every rank takes the same decisions.  A slab narrower than two ghost layers is refused.
+ * With level_estimation_after_advection the ghost layer is widened by 4 x the previous step's largest displacement (at least
+ * 2 h_max); a step in which the particles move further returns SPH_ERR_UNSUPPORTED on every rank.
  * Every rank makes the SAME sequence of calls with the same parameters (sph_step, sph_upload*, sph_dist_set_rebalance): which
  * collectives a step runs depends on that history (an ordinary step maintains the slabs in one round trip of counts, the first
  * step after an upload and re-balancing steps take two or more), not on anything a rank could decide alone.

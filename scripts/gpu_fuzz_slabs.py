@@ -1,6 +1,6 @@
 """Randomised check of the slab decomposition on ONE GPU (loopback group vs a single context) over graded quadtree
 distributions (tests/oracle_harness.quadtree_scene): multi-resolution stencils + ghost layers + migration together.
-usage: gpu_fuzz_slabs.py [first_seed] [n_seeds] [--rebalance] [--level]"""
+usage: gpu_fuzz_slabs.py [first_seed] [n_seeds] [--rebalance] [--level] [--after]"""
 import sys
 import numpy as np
 sys.path.insert(0, ".")
@@ -18,6 +18,7 @@ def rel(a, b):
 
 rebalance = "--rebalance" in sys.argv
 level = "--level" in sys.argv
+after = "--after" in sys.argv        # with --level: level_estimation_after_advection
 sys.argv = [a for a in sys.argv if not a.startswith("--")]
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 20
@@ -30,6 +31,8 @@ for seed in range(first, first + count):
     vel[:, 0] += 0.5
     k = 2 + seed % 3
     kw = dict(hybrid_dfsph_max_avg_density_error=0.0, hybrid_dfsph_max_avg_divergence_error=0.0, max_iters=3, max_dt=0.001)
+    if level and after:
+        kw["level_estimation_after_advection"] = True
     p = (default_params(merging=False, sharing=False, splitting=False, **kw) if level else dam_break_params(**kw)).to_ffi()
     single = ffi.Context(lib, len(mass), planes)
     single.upload(mass, pos, vel)
