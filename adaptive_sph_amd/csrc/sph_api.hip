@@ -1016,16 +1016,23 @@ extern "C" int sph_download_neighbors(sph_ctx* c, uint32_t* offsets, uint32_t* i
         // Slab context: one row per OWNED particle, in the order of sph_download(SPH_F_PARTICLE_ID); the indices are global particle
         // ids (an owned particle's neighbours are all among owned + ghosts, and the ghost records carry their ids).
         if (!c->dist.have_flags) return c->fail(SPH_ERR_INVALID_ARGUMENT, "no neighbour lists yet: run a step first");
-        if (c->lists_after) return c->fail(SPH_ERR_UNSUPPORTED, "neighbour-list export of a slab context after a step with level_estimation_after_advection (the extended lists of the advected positions) is not covered yet");
         const uint32_t nt = c->dist.n_tot;
-        rc = sph_download(c, SPH_F_NEIGHBOR_COUNT, cnt.data(), (uint64_t)n * 4);
-        if (rc) return rc;
+        const bool ext = c->lists_after;   // (as on a plain context: the extended lists of the ADVECTED positions)
         std::vector<uint8_t> flags(nt);
         if (nt) HIPCHK(c, hipMemcpy(flags.data(), c->dist.owned.p, nt, hipMemcpyDeviceToHost));
         std::vector<uint32_t> rowmap(nt);
         uint32_t w = 0;
         for (uint32_t i = 0; i < nt; i++) rowmap[i] = flags[i] ? w++ : 0xffffffffu;
         if (w != n) return c->fail(SPH_ERR_DEVICE, "owned-particle count mismatch");
+        if (!ext) {
+            rc = sph_download(c, SPH_F_NEIGHBOR_COUNT, cnt.data(), (uint64_t)n * 4);
+            if (rc) return rc;
+        } else if (nt) {   // counts of the extended lists: low 16 bits of the list words, owned slots in slot order
+            std::vector<uint4> words(nt);
+            HIPCHK(c, hipMemcpy(words.data(), c->nl_ext.p, (size_t)nt * sizeof(uint4), hipMemcpyDeviceToHost));
+            for (uint32_t i = 0; i < nt; i++)
+                if (flags[i]) cnt[rowmap[i]] = words[i].w & 0xffffu;
+        }
         uint64_t tot = 0;
         for (uint32_t i = 0; i < n; i++) {
             off[i] = (uint32_t)tot;
@@ -1043,10 +1050,16 @@ extern "C" int sph_download_neighbors(sph_ctx* c, uint32_t* offsets, uint32_t* i
         HIPCHK(c, d_row.ensure((size_t)nt * 4));
         HIPCHK(c, hipMemcpyAsync(d_off.p, off.data(), ((size_t)n + 1) * 4, hipMemcpyHostToDevice, s));
         HIPCHK(c, hipMemcpyAsync(d_row.p, rowmap.data(), (size_t)nt * 4, hipMemcpyHostToDevice, s));
-        hipLaunchKernelGGL(k_fill_neighbors, dim3((nt + 255) / 256), dim3(256), 0, s, nt, c->fgrid,
-                           TileP{c->tile_ts, c->tile_tsx, c->tile_tsy, c->tile_h.as<uint32_t>(), 0.f}, c->cell_start.as<uint32_t>(), c->cxy.as<uint32_t>(),
-                           c->orig[c->cur].as<uint32_t>(), c->pm[c->pcur ^ 1].as<float4>(), d_off.as<uint32_t>(), d_idx.as<uint32_t>(), 2.f,
-                           d_row.as<uint32_t>());
+        if (!ext)
+            hipLaunchKernelGGL(k_fill_neighbors, dim3((nt + 255) / 256), dim3(256), 0, s, nt, c->fgrid,
+                               TileP{c->tile_ts, c->tile_tsx, c->tile_tsy, c->tile_h.as<uint32_t>(), 0.f}, c->cell_start.as<uint32_t>(), c->cxy.as<uint32_t>(),
+                               c->orig[c->cur].as<uint32_t>(), c->pm[c->pcur ^ 1].as<float4>(), d_off.as<uint32_t>(), d_idx.as<uint32_t>(), 2.f,
+                               d_row.as<uint32_t>());
+        else   // cells (cxy) of the pre-step positions, geometry of the advected ones (pm[pcur]: the ghosts' were refreshed), ranges widened by the slack
+            hipLaunchKernelGGL(k_fill_neighbors, dim3((nt + 255) / 256), dim3(256), 0, s, nt, c->fgrid,
+                               TileP{c->tile_ts, c->tile_tsx, c->tile_tsy, c->tile_h_ext.as<uint32_t>(), c->lists_after_slack}, c->cell_start.as<uint32_t>(),
+                               c->cxy.as<uint32_t>(), c->orig[c->cur].as<uint32_t>(), c->pm[c->pcur].as<float4>(), d_off.as<uint32_t>(), d_idx.as<uint32_t>(),
+                               c->lists_after_k, d_row.as<uint32_t>());
         HIPCHK(c, hipMemcpyAsync(indices, d_idx.p, (size_t)tot * 4, hipMemcpyDeviceToHost, s));
         HIPCHK(c, hipStreamSynchronize(s));
         d_off.release();

@@ -197,6 +197,19 @@ def test_level_estimation_after_advection_on_slabs(product_lib, method, extended
     assert np.array_equal(D.gather_by_id(grp, "neighbor_count", n), single.download("neighbor_count"))
     for f, tol in (("position", 1e-5), ("velocity", 1e-4), ("density", 1e-5)):
         assert rel_err(D.gather_by_id(grp, f, n), single.download(f)) <= tol, f
+    # what the reference's cache holds now (and its partner searches would iterate): with the extended range the lists of the
+    # ADVECTED positions at that range, else the step's own -- exported per owned particle with global ids
+    so, si = single.download_neighbors()
+    differing = 0
+    for c in grp:
+        ids = c.download("particle_id")
+        off, idx = c.download_neighbors()
+        assert len(off) == c.n + 1
+        for r, pid in enumerate(ids):
+            differing += not np.array_equal(np.sort(idx[off[r]:off[r + 1]]), np.sort(si[so[pid]:so[pid + 1]]))
+    assert differing <= 2          # (positions differ in the last bits between the two runs: a pair ON the range may flip)
+    if extended:
+        assert (np.diff(so.astype(np.int64)) > single.download("neighbor_count")).any()     # wider than the k = 2 lists
 
 
 @pytest.mark.parametrize("mode", ["FromDistribution", "FromDistribution2"])
