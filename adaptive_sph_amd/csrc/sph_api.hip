@@ -678,10 +678,11 @@ extern "C" int sph_download(sph_ctx* c, int field, void* dst, uint64_t bytes)
     }
     if (field == SPH_F_FLAG_NEIGHBORHOOD_REDUCED) {   // simulation.rs:2164-2168; false before the first constrained step
         if (bytes != (uint64_t)n) return c->fail(SPH_ERR_INVALID_ARGUMENT, "field %d: size mismatch", field);
-        if (c->dist.on || !c->have_reduced) {
+        if (!c->have_reduced) {
             memset(dst, 0, bytes);
             return SPH_OK;
         }
+        if (c->dist.on) return download_slab(c, G_U8, c->flag_reduced.p, 1, dst, bytes);
         if (n == 0) return SPH_OK;
         hipLaunchKernelGGL(k_to_host_order, dim3((n + 255) / 256), dim3(256), 0, s, n, (int)G_U8, c->orig[k].as<uint32_t>(),
                            (const void*)c->flag_reduced.p, c->scratch.p);

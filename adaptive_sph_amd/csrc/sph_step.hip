@@ -1772,8 +1772,6 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
     // ---- parameter combinations this build does not cover are refused, never approximated ---------------
     if (c0->n_planes == 0) return c0->fail(SPH_ERR_NO_BOUNDARY, "not implemented: NoBoundaryHandler::iisph_aii");
     const bool h_from_mass_mode = p->support_length_estimation == SPH_H_FROM_MASS;
-    if (p->constrain_neighborhood_count && G.multi())
-        return c0->fail(SPH_ERR_UNSUPPORTED, "constrain_neighborhood_count on a slab decomposition is not covered yet");
     const bool level_on = p->level_estimation_method != SPH_LEVEL_NONE;
     const bool level_after = level_on && p->level_estimation_after_advection;
     if (level_on && !level_after && p->level_estimation_method == SPH_LEVEL_CENTER_DIFF)   // simulation.rs:2029-2031
@@ -2402,43 +2400,76 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
     }
     // ---- constrain_neighborhood_count (simulation.rs:2145-2177): h2 of over-populated particles shrinks AFTER the lists are
     // built; boundary terms (:2179), the CFL step (:2182-2191), the densities (:2204) follow with the new values
-    c0->have_reduced = false;
+    for (auto& m : M) m.c->have_reduced = false;
     float dt_step = dt;
     if (p->constrain_neighborhood_count) {
-        Member& m = M[0];
-        sph_ctx* c = m.c;
-        const size_t n = m.n ? m.n : 1;
-        HIPCHK(c, c->con_thr.ensure(n * 4));
-        HIPCHK(c, c->con_consumed.ensure(n * 4));
-        HIPCHK(c, c->con_h.ensure(n * 4));
-        HIPCHK(c, c->flag_reduced.ensure(n));
-        HIPCHK(c, c->lvl_changed_d.ensure(64 * sizeof(uint32_t)));
+        // (slab decomposition: every particle decides from its own list -- the ghosts' records are the pre-reduction ones its owner
+        //  sees too; the batch loop ends when no rank has a pass pending (all-reduced), the reduced smoothing lengths travel to the
+        //  ghosts before anything reads them, the CFL term of the new header is min-reduced over the ranks)
         const float onn = (SPH_ETA * 2.f) * (SPH_ETA * 2.f);   // optimal_neighbor_number, simulation.rs:386-388
         const uint32_t target = (uint32_t)onn + 5u;
-        uint32_t* pend = c->lvl_changed_d.as<uint32_t>();
-        launch_constrain_init(c->stream, &c->prof, m.a, target, c->con_thr.as<float>(), c->con_consumed.as<uint32_t>(), c->con_h.as<float>(),
-                              c->flag_reduced.as<uint8_t>());
-        for (bool done = (m.n == 0); !done;) {
-            const int B = 4;
-            (void)hipMemsetAsync(pend, 0, B * sizeof(uint32_t), c->stream);
-            for (int b = 0; b < B; b++)
-                launch_constrain_pass(c->stream, &c->prof, m.a, target, c->con_thr.as<float>(), c->con_consumed.as<uint32_t>(), c->con_h.as<float>(), pend + b);
-            HIPCHK(c, hipMemcpyAsync(c->lvl_changed, pend, B * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-            if ((rc = sync_ctrl(G))) return rc;   // also surfaces the two assertions of :2163-2165
-            done = !c->lvl_changed[B - 1];
+        for (auto& m : M) {
+            sph_ctx* c = m.c;
+            (void)hipSetDevice(c->device);
+            const size_t n = m.n ? m.n : 1;
+            HIPCHK(c, c->con_thr.ensure(n * 4));
+            HIPCHK(c, c->con_consumed.ensure(n * 4));
+            HIPCHK(c, c->con_h.ensure(n * 4));
+            HIPCHK(c, c->flag_reduced.ensure(n));
+            HIPCHK(c, c->lvl_changed_d.ensure(64 * sizeof(uint32_t)));
+            launch_constrain_init(c->stream, &c->prof, m.a, target, c->con_thr.as<float>(), c->con_consumed.as<uint32_t>(), c->con_h.as<float>(),
+                                  c->flag_reduced.as<uint8_t>());
         }
-        if (m.n) {
-            launch_constrain_apply(c->stream, &c->prof, m.a, c->pm[c->pcur].as<float4>(), c->con_h.as<float>(), m.a.h2_next);
-            launch_header(c, m.n, p->rest_density, 0, c->hdr_host_dev);
-            if ((rc = sync_ctrl(G))) return rc;
-            dt_step = fminf(p->max_dt, p->cfl_factor * sqrtf(c->hdr_host->min_cfl));
+        bool any = false;
+        for (auto& m : M) any = any || m.n > 0;
+        for (bool done = !any && !G.multi(); !done;) {
+            const int B = 4;
+            for (auto& m : M) {
+                sph_ctx* c = m.c;
+                (void)hipSetDevice(c->device);
+                uint32_t* pend = c->lvl_changed_d.as<uint32_t>();
+                (void)hipMemsetAsync(pend, 0, B * sizeof(uint32_t), c->stream);
+                for (int b = 0; b < B && m.n; b++)
+                    launch_constrain_pass(c->stream, &c->prof, m.a, target, c->con_thr.as<float>(), c->con_consumed.as<uint32_t>(), c->con_h.as<float>(), pend + b);
+                HIPCHK(c, hipMemcpyAsync(c->lvl_changed, pend, B * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+            }
+            if ((rc = sync_ctrl(G))) return rc;   // also surfaces the two assertions of :2163-2165
+            std::vector<int> pending(M.size(), 0);
+            for (size_t i = 0; i < M.size(); i++) pending[i] = M[i].c->lvl_changed[B - 1] ? 1 : 0;
+            if (G.multi() && (rc = G.comm->allreduce_max_i32(G, pending))) return rc;
+            done = true;
+            for (int v : pending) done = done && !v;
+        }
+        for (auto& m : M) {
+            sph_ctx* c = m.c;
+            (void)hipSetDevice(c->device);
+            if (m.n) launch_constrain_apply(c->stream, &c->prof, m.a, c->pm[c->pcur].as<float4>(), c->con_h.as<float>(), m.a.h2_next);
+            m.lv_pmnew = (float*)c->pm[c->pcur].as<float4>();
+        }
+        if ((rc = refresh_ghosts(G, M, sel_lv_pmnew, 4, "pm"))) return rc;   // the ghosts' records with their owners' new h
+        std::vector<std::vector<float>> cfl(M.size(), std::vector<float>(1, INFINITY));
+        for (auto& m : M) {
+            sph_ctx* c = m.c;
+            (void)hipSetDevice(c->device);
+            if (m.n) launch_header(c, m.n, p->rest_density, 0, c->hdr_host_dev, c->dist.on && c->dist.have_flags ? c->dist.owned.as<uint8_t>() : nullptr);
+        }
+        if ((rc = sync_ctrl(G))) return rc;
+        for (size_t i = 0; i < M.size(); i++)
+            if (M[i].n && M[i].c->n > 0) cfl[i][0] = M[i].c->hdr_host->min_cfl;
+        if (G.multi() && (rc = G.comm->allreduce_min_f32(G, cfl))) return rc;
+        if (!G.multi())
+            for (size_t i = 1; i < M.size(); i++) cfl[0][0] = fminf(cfl[0][0], cfl[i][0]);
+        dt_step = fminf(p->max_dt, p->cfl_factor * sqrtf(cfl[0][0]));
+        for (auto& m : M) {
+            sph_ctx* c = m.c;
+            (void)hipSetDevice(c->device);
             m.sp.dt = dt_step;
             m.sp.hyb_vfactor = fminf(dt_step * p->hybrid_dfsph_factor, 1.f);
             m.a.sp = m.sp;
             m.st.dt = dt_step;
-            launch_density_replay(c->stream, &c->prof, m.a);
+            if (m.n) launch_density_replay(c->stream, &c->prof, m.a);
+            c->have_reduced = true;
         }
-        c->have_reduced = true;
     }
     if ((rc = refresh_ghosts(G, M, sel_rho, 1, "rho"))) return rc;
     if (G.multi())

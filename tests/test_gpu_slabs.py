@@ -212,6 +212,33 @@ def test_level_estimation_after_advection_on_slabs(product_lib, method, extended
         assert (np.diff(so.astype(np.int64)) > single.download("neighbor_count")).any()     # wider than the k = 2 lists
 
 
+def test_constrain_neighborhood_count_on_slabs(product_lib, k=2):
+    """simulation.rs:2145-2177 across a cut (two slabs: with three the scene's slabs are narrower than two ghost layers): the
+    over-populated particles of three rings take their reduced smoothing length from their own lists, the reduced h travels to the ghosts before the density
+    replay, the CFL step of the new header is min-reduced.  Same flags, smoothing lengths (bit for bit), dt and fields as the
+    single context; the second step fires the reference's own assertion on every rank together."""
+    from tests.oracle_harness import rings_and_block_scene
+    scn, pos, mass, vel = rings_and_block_scene()
+    planes = sc.boundary_planes(scn.boundary, "AnalyticOverestimate")
+    p = forced(max_iters=3, constrain_neighborhood_count=True).to_ffi()
+    single = ffi.Context(product_lib, len(mass), planes)
+    single.upload(mass, pos, vel)
+    grp = D.make_loopback_group(product_lib, pos, mass, vel, planes, k)
+    st1 = single.step(p)
+    sts = ffi.group_step(grp, p)
+    assert all(st.dt == st1.dt for st in sts)
+    n = len(mass)
+    flag = single.download("flag_neighborhood_reduced")
+    assert flag.sum() == 3 and np.array_equal(D.gather_by_id(grp, "flag_neighborhood_reduced", n), flag)
+    for f in ("h2", "h2_next", "neighbor_count"):
+        assert np.array_equal(D.gather_by_id(grp, f, n), single.download(f)), f
+    for f, tol in (("position", 1e-6), ("velocity", 1e-5), ("density", 1e-6), ("aii", 1e-5)):
+        assert rel_err(D.gather_by_id(grp, f, n), single.download(f)) <= tol, f
+    with pytest.raises(ffi.SphError) as e:
+        ffi.group_step(grp, p)
+    assert e.value.status == 25          # SPH_ERR_CONSTRAIN_NOT_SMALLER, as on the single context
+
+
 @pytest.mark.parametrize("mode", ["FromDistribution", "FromDistribution2"])
 def test_support_length_from_distribution_on_slabs(product_lib, mode):
     """h2_next and the previous step's lambda sums travel with the particles (partition, hand-over to the neighbour, cell sort);
