@@ -718,11 +718,13 @@ __global__ __launch_bounds__(256) void k_edit_apply(uint32_t n_new, uint32_t n_o
                                                      const float* __restrict__ lam_in, const uint8_t* __restrict__ szc_in,
                                                      uint8_t* __restrict__ szc_out, float4* __restrict__ pm_out, float2* __restrict__ vel_out,
                                                      uint32_t* __restrict__ orig_out, float* __restrict__ lvl_out, float* __restrict__ lvlold_out,
-                                                     float* __restrict__ h2n_out, float* __restrict__ lam_out)
+                                                     float* __restrict__ h2n_out, float* __restrict__ lam_out, const uint32_t* __restrict__ id_in)
 {
     const uint32_t f = blockIdx.x * 256 + threadIdx.x;
     if (f >= n_new) return;
     const EditSrc e = src[f];
+    uint32_t id = f;   // slab context (id_in): a surviving particle keeps its global id, a new one has none until the host uploads it
+    if (id_in) id = e.obj < n_old ? id_in[slot_of[e.obj]] : 0xffffffffu;
     // ParticleVec defaults (simulation.rs:284-334)
     float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
     float2 v = make_float2(0.f, 0.f);
@@ -750,7 +752,7 @@ __global__ __launch_bounds__(256) void k_edit_apply(uint32_t n_new, uint32_t n_o
     }
     pm_out[f] = p;
     vel_out[f] = v;
-    orig_out[f] = f;
+    orig_out[f] = id;
     lvl_out[f] = lv;
     lvlold_out[f] = lo;
     h2n_out[f] = hn;
@@ -761,7 +763,6 @@ __global__ __launch_bounds__(256) void k_edit_apply(uint32_t n_new, uint32_t n_o
 extern "C" int sph_apply_edits(sph_ctx* c, const sph_edit_op* ops, uint64_t n_ops)
 {
     if (!c || (n_ops && !ops)) return SPH_ERR_INVALID_ARGUMENT;
-    if (c->dist.on) return c->fail(SPH_ERR_UNSUPPORTED, "sparse edits on a slab context are not covered yet");
     if (c->poisoned) return c->fail(SPH_ERR_POISONED, "an earlier step failed inside the step: the particle state is undefined until sph_upload");
     HIPCHK(c, hipSetDevice(c->device));
     const uint32_t n_old = (uint32_t)c->n;
@@ -838,14 +839,33 @@ int regather_host_order(sph_ctx* c, uint32_t n_new, const EditSrc* d_src, const 
     HIPCHK(c, d_slot.ensure(((size_t)n_old + 1) * 4));
     HIPCHK(c, d_lam.ensure(((size_t)n_new + 1) * 4));
     const int k = c->cur;
-    if (n_old) hipLaunchKernelGGL(k_edit_inverse, dim3((n_old + 255) / 256), dim3(256), 0, s, n_old, c->orig[k].as<uint32_t>(), d_slot.as<uint32_t>());
+    const bool slab = c->dist.on;
+    if (slab) {
+        // slab context: "host index" = row of the owned order (what sph_download returns); the arrays also hold the ghosts
+        std::vector<uint32_t> slot_of(n_old ? n_old : 1);
+        if (c->dist.have_flags) {
+            const uint32_t nt = c->dist.n_tot;
+            std::vector<uint8_t> flags(nt ? nt : 1);
+            if (nt) HIPCHK(c, hipMemcpy(flags.data(), c->dist.owned.p, nt, hipMemcpyDeviceToHost));
+            uint32_t w = 0;
+            for (uint32_t i = 0; i < nt; i++)
+                if (flags[i]) {
+                    if (w >= n_old) return c->fail(SPH_ERR_DEVICE, "owned-particle count mismatch");
+                    slot_of[w++] = i;
+                }
+            if (w != n_old) return c->fail(SPH_ERR_DEVICE, "owned-particle count mismatch");
+        } else
+            for (uint32_t i = 0; i < n_old; i++) slot_of[i] = i;
+        if (n_old) HIPCHK(c, hipMemcpyAsync(d_slot.p, slot_of.data(), (size_t)n_old * 4, hipMemcpyHostToDevice, s));
+        HIPCHK(c, hipStreamSynchronize(s));   // (slot_of is a local)
+    } else if (n_old) hipLaunchKernelGGL(k_edit_inverse, dim3((n_old + 255) / 256), dim3(256), 0, s, n_old, c->orig[k].as<uint32_t>(), d_slot.as<uint32_t>());
     if (n_new)
         hipLaunchKernelGGL(k_edit_apply, dim3((n_new + 255) / 256), dim3(256), 0, s, n_new, n_old, d_src, d_sets,
                            d_slot.as<uint32_t>(), c->pm[c->pcur].as<float4>(), c->vel[k].as<float2>(), c->lvl[k].as<float>(),
                            c->lvlold[k].as<float>(), c->h2n[k].as<float>(), c->lam_sum.as<float>(), c->szc[k].as<uint8_t>(), c->szc[k ^ 1].as<uint8_t>(),
                            c->pm[c->pcur ^ 1].as<float4>(),
                            c->vel[k ^ 1].as<float2>(), c->orig[k ^ 1].as<uint32_t>(), c->lvl[k ^ 1].as<float>(), c->lvlold[k ^ 1].as<float>(),
-                           c->h2n[k ^ 1].as<float>(), d_lam.as<float>());
+                           c->h2n[k ^ 1].as<float>(), d_lam.as<float>(), slab ? c->orig[k].as<uint32_t>() : (const uint32_t*)nullptr);
     if (n_new) HIPCHK(c, hipMemcpyAsync(c->lam_sum.p, d_lam.p, (size_t)n_new * 4, hipMemcpyDeviceToDevice, s));
     HIPCHK(c, hipStreamSynchronize(s));
     d_slot.release();
@@ -854,6 +874,8 @@ int regather_host_order(sph_ctx* c, uint32_t n_new, const EditSrc* d_src, const 
     c->pcur ^= 1;
     c->n = n_new;
     c->dist.n_tot = n_new;
+    c->dist.have_flags = false;   // (slab context: owned particles only, in row order; the next step selects new ghosts)
+    c->dist.n_ghost[0] = c->dist.n_ghost[1] = c->dist.n_halo[0] = c->dist.n_halo[1] = 0;
     c->grid_valid = false;   // lists, cell indices and per-step outputs belong to the vector before the edit
     c->have_level = false;
     c->have_reduced = false;

@@ -233,7 +233,11 @@ int  sph_upload_field(sph_ctx* ctx, int field, const void* src, uint64_t src_byt
  *   EXTEND    a particles with ParticleVec's defaults are appended (mass 0, zero vectors, h2 = h2_next = 0,
  *             LevelEstimationState::FluidInterior, level_old 0, no boundary terms)
  * Afterwards sph_num_particles() is the new length and downloads speak the new indices.  Per-step outputs (density,
- * pressure, neighbour lists, ...) are those of the last step and no longer line up with the edited vector. */
+ * pressure, neighbour lists, ...) are those of the last step and no longer line up with the edited vector.
+ * Slab context: the index space is the rank's OWNED particles in the order sph_download returns them (the ghosts are dropped
+ * by the call; the next step selects new ones); a surviving particle keeps its global id (SPH_F_PARTICLE_ID), an appended one
+ * has the id 0xffffffff until the host uploads the id field -- unique ids are the host's business, as are particles whose new
+ * position lies in another rank's slab (the next step hands them over). */
 enum { SPH_EDIT_SET = 0, SPH_EDIT_SWAP = 1, SPH_EDIT_TRUNCATE = 2, SPH_EDIT_EXTEND = 3 };
 enum {
     SPH_EDIT_F_MASS = 1, SPH_EDIT_F_POSITION = 2, SPH_EDIT_F_VELOCITY = 4, SPH_EDIT_F_H2 = 8, SPH_EDIT_F_H2_NEXT = 16,

@@ -388,6 +388,71 @@ def test_neighbour_lists_of_the_slabs_are_those_of_the_single_context(product_li
     assert seen.all() and crossing > 0
 
 
+def test_sparse_edits_on_slab_contexts(product_lib):
+    """sph_apply_edits on the ranks of a decomposition: indices are rows of the owned order, survivors keep their global ids,
+    an appended particle gets its id from the host.  The same logical script on the single context (by host index) and on the
+    ranks that own the particles (by row) -- SET of mass / velocity, a swap-with-the-last deletion, an appended particle -- then
+    both step on: same particles (matched by id), same fields."""
+    scn = sc.dam_break_small(96, 48, 1 / 48)
+    pos, mass, vel = sc.init_particles(scn)
+    planes = sc.boundary_planes(scn.boundary)
+    p = forced(max_iters=3).to_ffi()
+    n = len(mass)
+    single = ffi.Context(product_lib, n + 16, planes)
+    single.upload(mass, pos, vel)
+    grp = D.make_loopback_group(product_lib, pos, mass, vel, planes, 3)
+    for _ in range(3):
+        single.step(p)
+        ffi.group_step(grp, p)
+    ids_of = [c.download("particle_id") for c in grp]
+    # the script, in global ids: particle A gets a new velocity, particle B (interior of rank 1) is deleted, a new particle
+    # appears next to particle C on rank 2
+    gpos = single.download("position")
+    A, B, C = int(ids_of[0][len(ids_of[0]) // 2]), int(ids_of[1][len(ids_of[1]) // 3]), int(ids_of[2][len(ids_of[2]) // 2])
+    new_pos = (gpos[C] + np.array([0.25 / 48, 0.1 / 48], np.float32)).astype(np.float32)
+    new_mass, new_vel = float(mass[C]) * 0.5, (0.1, -0.2)
+
+    def E(kind, a=0, b=0, **f):
+        return {"set": ("set", a, f), "swap": ("swap", a, b), "truncate": ("truncate", a), "extend": ("extend", a)}[kind]
+
+    # single context: host index == id so far; deleting B moves the last particle (id n - 1) into index B
+    single.apply_edits([E("set", A, velocity=(0.3, 0.1)), E("swap", B, n - 1), E("truncate", n - 1), E("extend", 1),
+                        E("set", n - 1, mass=new_mass, position=tuple(new_pos), velocity=new_vel, h2_next=float(single.download("h2_next")[C]))])
+    label_single = np.arange(n)
+    label_single[B] = n - 1           # index B now holds the particle that had id n - 1
+    label_single[n - 1] = n           # the appended particle: label n
+    # ranks: rows of their owned order
+    for r, c in enumerate(grp):
+        ids = ids_of[r]
+        ops = []
+        if A in ids:
+            ops.append(E("set", int(np.nonzero(ids == A)[0][0]), velocity=(0.3, 0.1)))
+        if B in ids:
+            row, last = int(np.nonzero(ids == B)[0][0]), len(ids) - 1
+            ops += [E("swap", row, last), E("truncate", last)]
+        if C in ids:
+            m_after = len(ids) - (1 if B in ids else 0)
+            ops += [E("extend", 1), E("set", m_after, mass=new_mass, position=tuple(new_pos), velocity=new_vel, h2_next=float(c.download("h2_next")[np.nonzero(ids == C)[0][0]]))]
+        c.apply_edits(ops)
+        new_ids = c.download("particle_id")
+        assert (new_ids == 0xffffffff).sum() == (1 if C in ids else 0)
+        new_ids[new_ids == 0xffffffff] = n            # the host names the new particle
+        c.upload_field("particle_id", new_ids)
+    assert sum(c.n for c in grp) == n == single.n
+    for _ in range(4):
+        st1 = single.step(p)
+        sts = ffi.group_step(grp, p)
+        assert all(st.dt == st1.dt for st in sts)
+    order_s = np.argsort(label_single)
+    ids = np.concatenate([c.download("particle_id") for c in grp])
+    order_g = np.argsort(ids)
+    assert np.array_equal(np.sort(ids), np.sort(label_single))
+    for f, tol in (("position", 1e-5), ("velocity", 1e-4), ("density", 1e-5), ("mass", 0.0)):
+        a = np.concatenate([c.download(f) for c in grp])[order_g]
+        b = single.download(f)[order_s]
+        assert rel_err(a, b) <= tol, f
+
+
 def test_a_slab_without_room_for_its_ghosts_says_so(product_lib):
     """Between the refresh and the cell sort a slab holds its previous slots, the arrivals and the new ghosts: a context that
     cannot fit them returns SPH_ERR_CAPACITY (and is poisoned) -- it never writes past its arrays."""
