@@ -92,3 +92,40 @@ def test_media_recipe(product_lib, oracle_lib, k):
         assert abs(sg.dt - so.dt) <= 1e-5 * so.dt
     fields_close(("position", "density"))
     fields_close(("velocity",), 10.0)       # carries the unconverged (4 iterations), clamped pressure field of three steps
+
+
+ADAPTIVE = [k for k, r in enumerate(RECIPES) if any(r["update_attributes"].get(f) for f in ("merging", "sharing", "splitting"))]
+
+
+@pytest.mark.parametrize("k", ADAPTIVE, ids=[RECIPES[k]["recipe"] for k in ADAPTIVE])
+def test_media_recipe_with_its_adaptivity(product_lib, k):
+    """The recipes that resample (merging / sharing / splitting as the recipe sets them), the way the reference runs them:
+    single_step = the step on the device + single_step_adaptivity (decisions on the host, data on the device, split patterns from
+    the reference's table).  Eight steps; what the reference itself asserts afterwards -- mass conservation (simulation.rs:2792,
+    tolerance 5e-3 per call) -- plus finite positions inside the box."""
+    from adaptive_sph_amd import adaptivity as A
+    from adaptive_sph_amd.simulation import init_fluid_sim
+    from adaptive_sph_amd.workloads import DEFAULT_CONFIG
+    r = RECIPES[k]
+    attrs = {kk: v for kk, v in r["update_attributes"].items() if kk in DEFAULT_CONFIG}
+    P = default_params(**attrs).replace(**{kk: v for kk, v in r["update_attributes"].items() if kk not in DEFAULT_CONFIG})
+    scn = sc.SceneConfig.from_mapping(r["scene"])
+    sp = A.SplitPatterns.load_from_file(Path(__file__).parent / "golden" / "split-patterns.yaml")
+    n0 = len(sc.init_particles(scn)[1])
+    sim = init_fluid_sim(P, scn, lib=product_lib, split_patterns=sp, n_capacity=max(40 * n0, 60000) if n0 < 20000 else 4 * n0)
+    m0 = float(sim.particles.mass.sum(dtype=np.float64))
+    counts = []
+    try:
+        for s in range(8):
+            sim.single_step(P)
+            counts.append(sim.num_fluid_particles())
+    except ffi.SphError as e:
+        # the reference's own refusals for a recipe as written (e.g. CenterDiff before advection): nothing to compare
+        assert e.status in (1, 27), e
+        return
+    x = sim.particles.position
+    half_w, half_h = 0.5 * scn.boundary.width, 0.5 * scn.boundary.height
+    # (a split places children around the parent and the semi-analytic wall is soft: a particle may sit a few percent outside)
+    assert np.isfinite(x).all() and np.abs(x[:, 0]).max() < 1.05 * half_w and np.abs(x[:, 1]).max() < 1.05 * half_h
+    assert abs(float(sim.particles.mass.sum(dtype=np.float64)) - m0) < 0.005 * 8
+    assert min(counts) > 0
