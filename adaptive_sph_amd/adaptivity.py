@@ -213,12 +213,14 @@ class AdaptivityDriver:
         if split_patterns is not None:
             ctx.set_split_patterns(split_patterns.patterns)
 
-    def single_step_adaptivity(self, P: SimulationParams, dt: float, step_number: int) -> dict:
+    def single_step_adaptivity(self, P: SimulationParams, dt: float, step_number: int, lists=None) -> dict:
+        """`lists` = (offsets, indices): the step's neighbour lists when they do not live in `ctx` (slab decomposition: the ranks'
+        exports assembled in global index order, distributed.group_single_step_adaptivity)."""
         ctx, log = self.ctx, self.log
         p, ap = P.to_ffi(), adapt_params(P, dt)
         info = {"n_before": ctx.n, "shares": 0, "merges": 0, "splits": 0}
         total_mass1 = float(ctx.download("mass").sum(dtype=np.float32))
-        off, idx = ctx.download_neighbors()          # the lists single_step_without_adaptivity left behind (self.neighs)
+        off, idx = lists if lists is not None else ctx.download_neighbors()   # the lists single_step_without_adaptivity left behind (self.neighs)
 
         def decide(kind):
             ctx.classify(p)

@@ -5,6 +5,7 @@ unique id and the launcher's barrier; the halo exchange itself is RCCL inside li
   partition          indices of the particles each rank owns
   make_slab_context  context of this rank, configured, communicator initialised, particles uploaded
   make_loopback_group  k contexts in this process (ranks 0..k-1) for single-GPU verification
+  group_single_step_adaptivity  single_step_adaptivity for a slab group, through a gather to one context and back
 """
 from __future__ import annotations
 
@@ -92,3 +93,63 @@ def gather_by_id(contexts: Sequence[ffi.Context], name: str, n_total: int) -> np
         ids = c.download("particle_id")
         out[ids] = c.download(name)
     return out
+
+
+_ADAPT_FIELDS = ("h2", "h2_next", "level_estimation", "level_old", "particle_size_class")
+
+
+def group_single_step_adaptivity(lib: ffi.SphLibrary, contexts: Sequence[ffi.Context], planes, P, dt: float, step_number: int,
+                                 split_patterns=None, capacity: int = 0, log=None) -> dict:
+    """single_step_adaptivity (simulation.rs:2732-2796) for the ranks of a slab decomposition that have just stepped.
+
+    The reference decides sequentially over ALL particles in index order and a transfer's two partners may sit on different
+    ranks, so the exact form goes through one place: the owned particles of every rank (mass, position, velocity, h2, h2_next,
+    level values, size class) and their neighbour lists (global ids, ghosts included) are assembled in global index order -- the
+    particle ids ARE the reference's Vec indices --, uploaded to ONE plain context, the same decisions (adaptivity.py) and the
+    same device-side share / merge / split run there, and the result goes back: every rank is re-uploaded with the particles of
+    its slab, their new index as id.  Same arithmetic as on a single context; the price is a gather and a scatter over PCIe per
+    adaptive step (support lengths FromMass: the previous step's lambda sums do not travel).  In-process form (loopback group,
+    or one process driving several GPUs); with one process per GPU the same gather / scatter goes through the launcher."""
+    from .adaptivity import AdaptivityDriver
+    if P.support_length_estimation != "FromMass":
+        raise ValueError("group_single_step_adaptivity: support_length_estimation must be FromMass")
+    ids = [c.download("particle_id") for c in contexts]
+    n = int(sum(len(i) for i in ids))
+    allid = np.concatenate(ids)
+    if not np.array_equal(np.sort(allid), np.arange(n, dtype=allid.dtype)):
+        raise ValueError("group_single_step_adaptivity: the particle ids of the ranks are not the indices 0 .. n-1")
+    g = {f: gather_by_id(contexts, f, n) for f in ("mass", "position", "velocity") + _ADAPT_FIELDS}
+    # neighbour lists in index order
+    counts = np.zeros(n, np.int64)
+    rows = []
+    for c, i in zip(contexts, ids):
+        off, idx = c.download_neighbors()
+        counts[i] = np.diff(off.astype(np.int64))
+        rows.append((i, off.astype(np.int64), idx))
+    off_g = np.zeros(n + 1, np.int64)
+    np.cumsum(counts, out=off_g[1:])
+    idx_g = np.empty(int(off_g[-1]), np.uint32)
+    for i, off, idx in rows:
+        starts = off_g[i]
+        lens = np.diff(off)
+        dst = np.repeat(starts - off[:-1], lens) + np.arange(len(idx))          # row r of this rank -> its place in the global CSR
+        idx_g[dst] = idx
+    T = ffi.Context(lib, capacity or max(2 * n, n + 65536), planes, device_id=0)
+    try:
+        T.upload(g["mass"], g["position"], g["velocity"])
+        for f in _ADAPT_FIELDS:
+            T.upload_field(f, g[f])
+        info = AdaptivityDriver(T, split_patterns, log).single_step_adaptivity(P, dt, step_number, lists=(off_g.astype(np.uint32), idx_g))
+        new = {f: T.download(f) for f in ("mass", "position", "velocity") + _ADAPT_FIELDS}
+    finally:
+        T.close()
+    n_new = len(new["mass"])
+    cuts = [contexts[0].dist_get_cuts()[0]] + [c.dist_get_cuts()[1] for c in contexts]
+    parts = partition(new["position"][:, 0], [-INF] + [float(v) for v in cuts[1:-1]] + [INF])
+    for c, mine in zip(contexts, parts):
+        c.upload(new["mass"][mine], new["position"][mine], new["velocity"][mine])
+        for f in _ADAPT_FIELDS:
+            c.upload_field(f, new[f][mine])
+        c.upload_field("particle_id", mine.astype(np.uint32))
+    info["n_after"] = n_new
+    return info

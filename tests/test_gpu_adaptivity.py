@@ -201,3 +201,42 @@ def test_config4_ratio_stress_4m_adaptive_steps(product_lib):
     x = sim.particles.position
     assert np.isfinite(x).all() and np.abs(x).max() < 1.0
     sim.single_step_without_adaptivity(P)                   # and the edited vector steps
+
+
+def test_adaptive_run_on_a_slab_group(product_lib):
+    """single_step = step + single_step_adaptivity on a 2-rank slab group (distributed.group_single_step_adaptivity: the ranks'
+    particles and neighbour lists gathered in global index order, the decisions and the device-side share / merge / split on ONE
+    context, the result scattered back) against the single context's adaptive run of BASELINE configs[0].  The two runs take
+    their decisions from states that differ in the last digits, so they are compared like the single-context run is compared with
+    the oracle: particle counts step by step, mass conservation, positions in the box; the first adaptive step (inputs equal to
+    1e-7) must take the same number of splits."""
+    from adaptive_sph_amd import distributed as D
+    P = default_params()
+    scn = sc.SceneConfig.from_yaml(str(REPO / "tests" / "golden" / "default-scene.yaml"))
+    sp = A.SplitPatterns.load_from_file(PATTERNS)
+    single = init_fluid_sim(P, scn, lib=product_lib, split_patterns=sp, n_capacity=120000)
+    pos, mass, vel = sc.init_particles(scn)
+    planes = sc.boundary_planes(scn.boundary, P.init_boundary_handler)
+    grp = D.make_loopback_group(product_lib, pos, mass, vel, planes, 2)
+    m0 = float(mass.sum(dtype=np.float64))
+    p = P.to_ffi()
+    counts = [[], []]
+    events = {"shares": 0, "merges": 0, "splits": 0}
+    for s in range(12):
+        single.single_step(P)
+        counts[0].append(single.num_fluid_particles())
+        sts = ffi.group_step(grp, p)
+        info = D.group_single_step_adaptivity(product_lib, grp, planes, P, float(sts[0].dt), int(sts[0].step_number), split_patterns=sp, capacity=120000)
+        for k in events:
+            events[k] += info[k]
+        counts[1].append(sum(c.n for c in grp))
+        assert info["n_after"] == counts[1][-1]
+    assert counts[0][0] == counts[1][0] > 1035                         # step 1 splits, the same particles on both sides
+    assert max(abs(a - b) for a, b in zip(*counts)) <= 0.02 * max(counts[0]), counts
+    assert events["splits"] > 0 and events["merges"] + events["shares"] > 0, events
+    n = counts[1][-1]
+    ids = np.concatenate([c.download("particle_id") for c in grp])
+    assert np.array_equal(np.sort(ids), np.arange(n))                  # ids are the global indices again
+    assert abs(float(D.gather_by_id(grp, "mass", n).sum(dtype=np.float64)) - m0) < 0.005 * 12
+    x = D.gather_by_id(grp, "position", n)
+    assert np.isfinite(x).all() and np.abs(x).max() < 1.05
