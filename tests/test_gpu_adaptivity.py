@@ -240,3 +240,43 @@ def test_adaptive_run_on_a_slab_group(product_lib):
     assert abs(float(D.gather_by_id(grp, "mass", n).sum(dtype=np.float64)) - m0) < 0.005 * 12
     x = D.gather_by_id(grp, "position", n)
     assert np.isfinite(x).all() and np.abs(x).max() < 1.05
+
+
+def test_config4_ratio_stress_4m_adaptive_steps_on_two_slabs(product_lib):
+    """BASELINE configs[4] -- the 4 004 343-particle 50:1 scene, IISPH, Sdf2D box, EmptyAngle level estimation, merging / sharing /
+    splitting on -- as a slab group (two ranks: three would be narrower than two ghost layers of the COARSE particles): three calls
+    of step + group_single_step_adaptivity against the single context's first three adaptive steps.  Same event counts on the first
+    step (inputs equal to 1e-7), particle counts within 2 % afterwards, mass conserved, everybody inside the box."""
+    from adaptive_sph_amd import distributed as D
+    scene_f, params_f, _ = WORKLOADS["ratio_stress_4m"]
+    scn = scene_f()
+    r_fine = float(np.sqrt(np.float32(0.0004385) ** 2 * 0.93 / np.pi))
+    P = params_f(level_estimation_method="EmptyAngle", merging=True, sharing=True, splitting=True, particle_radius_fine=r_fine,
+                 particle_radius_base=50 * r_fine, maximum_surface_distance=0.3)
+    sp = A.SplitPatterns.load_from_file(PATTERNS)
+    single = init_fluid_sim(P, scn, lib=product_lib, split_patterns=sp, n_capacity=6000000)
+    pos, mass, vel = sc.init_particles(scn)
+    planes = sc.boundary_planes(scn.boundary, P.init_boundary_handler)
+    grp = D.make_loopback_group(product_lib, pos, mass, vel, planes, 2)
+    m0 = float(mass.sum(dtype=np.float64))
+    p = P.to_ffi()
+    counts = [[], []]
+    first = []
+    for s in range(3):
+        dt = single.single_step_without_adaptivity(P)
+        i1 = single.single_step_adaptivity(P, dt)
+        counts[0].append(single.num_fluid_particles())
+        sts = ffi.group_step(grp, p)
+        assert abs(float(sts[0].dt) - dt) <= 1e-5 * dt
+        i2 = D.group_single_step_adaptivity(product_lib, grp, planes, P, float(sts[0].dt), int(sts[0].step_number), split_patterns=sp, capacity=6000000)
+        counts[1].append(sum(c.n for c in grp))
+        if s == 0:
+            first = [(i1[k], i2[k]) for k in ("shares", "merges", "splits")]
+    assert all(abs(a - b) <= 0.001 * max(a, 1) for a, b in first), first
+    assert max(abs(a - b) for a, b in zip(*counts)) <= 0.02 * max(counts[0]), counts
+    assert counts[1][-1] != 4004343
+    n = counts[1][-1]
+    assert abs(float(D.gather_by_id(grp, "mass", n).sum(dtype=np.float64)) - m0) < 1e-4 * m0
+    x = D.gather_by_id(grp, "position", n)
+    assert np.isfinite(x).all() and np.abs(x).max() < 1.0
+    ffi.group_step(grp, p)                                   # and the re-uploaded slabs step
