@@ -1249,8 +1249,8 @@ static int partition_and_migrate(Group& G, std::vector<Member>& M, std::vector<i
         (void)hipSetDevice(c->device);
         const uint32_t n_stay = d.counts_host[0];
         if ((uint64_t)n_stay + fl[i] + fr[i] > c->cap)
-            return agree(G, c->fail(SPH_ERR_CAPACITY, "slab of rank %d needs %llu particles, capacity %llu", d.rank,
-                                    (unsigned long long)n_stay + fl[i] + fr[i], (unsigned long long)c->cap));
+            return c->fail(SPH_ERR_CAPACITY, "slab of rank %d needs %llu particles, capacity %llu", d.rank,
+                                    (unsigned long long)n_stay + fl[i] + fr[i], (unsigned long long)c->cap);   // (this rank alone knows: not a collective exit, see DESIGN.md section 6 "Known limits")
         const int k = c->cur;
         const uint32_t base[2] = {n_stay, n_stay + tl[i]};
         const uint32_t cnt[2] = {tl[i], tr[i]};
@@ -1419,8 +1419,8 @@ static int build_ghost_layer(Group& G, std::vector<Member>& M, float halo_width,
         (void)hipSetDevice(c->device);
         const uint32_t n = (uint32_t)c->n;
         if ((uint64_t)n + fl[i] + fr[i] > c->cap)
-            return agree(G, c->fail(SPH_ERR_CAPACITY, "slab of rank %d + ghosts needs %llu particles, capacity %llu", d.rank,
-                                    (unsigned long long)n + fl[i] + fr[i], (unsigned long long)c->cap));
+            return c->fail(SPH_ERR_CAPACITY, "slab of rank %d + ghosts needs %llu particles, capacity %llu", d.rank,
+                                    (unsigned long long)n + fl[i] + fr[i], (unsigned long long)c->cap);   // (this rank alone knows: not a collective exit, see DESIGN.md section 6 "Known limits")
         const uint32_t n_none = d.counts_host[4 + 0];
         d.n_halo[0] = tl[i];
         d.n_halo[1] = tr[i];
@@ -1530,8 +1530,8 @@ static int slab_refresh_fused(Group& G, std::vector<Member>& M, std::vector<std:
         const uint32_t n_prev = n_prev_of[i];
         const uint64_t n_pre = (uint64_t)n_prev + q.in_mig[0] + q.in_mig[1] + q.in_halo[0] + q.mig[0] + q.in_halo[1] + q.mig[1];
         if (n_pre > c->cap)
-            return agree(G, c->fail(SPH_ERR_CAPACITY, "slab of rank %d + arrivals + ghosts needs %llu slots, capacity %llu", d.rank, (unsigned long long)n_pre,
-                                    (unsigned long long)c->cap));
+            return c->fail(SPH_ERR_CAPACITY, "slab of rank %d + arrivals + ghosts needs %llu slots, capacity %llu", d.rank, (unsigned long long)n_pre,
+                                    (unsigned long long)c->cap);   // (this rank alone knows: not a collective exit, see DESIGN.md section 6 "Known limits")
     }
     // ---- migrants
     for (size_t i = 0; i < nm; i++) {
