@@ -222,6 +222,34 @@ pub mod ffi {
         pub fn sph_split_particles(ctx: *mut c_void, params: *const SphParams, ap: *const SphAdaptParams) -> c_int;
         pub fn sph_last_error(ctx: *const c_void) -> *const c_char;
         pub fn sph_grid(ctx: *const c_void, out: *mut SphGridInfo) -> c_int;
+        /// the sequential partner searches as compiled host code (no context; the reference keeps its own Rust loops)
+        pub fn sph_host_find_partners(kind: c_int, n: u64, particle_size_class: *const u8, mass: *const f32, level_estimation: *const f32,
+                                      position_xy: *const f32, h2: *const f32, offsets: *const u32, indices: *const u32, params: *const SphParams,
+                                      ap: *const SphAdaptParams, merge_partner: *mut u32, merge_counter: *mut u16, n_transfers: *mut u64) -> c_int;
+        // ---- multi-GPU: one process (= one context) per GPU, 1-D slabs along x (sph_ffi.h, "multi-GPU") --------------
+        pub fn sph_dist_configure(ctx: *mut c_void, rank: c_int, n_ranks: c_int, cut_lo: f32, cut_hi: f32) -> c_int;
+        pub fn sph_dist_set_rebalance(ctx: *mut c_void, every_n_steps: c_int) -> c_int;
+        pub fn sph_dist_get_cuts(ctx: *mut c_void, cut_lo: *mut f32, cut_hi: *mut f32, n_rebalances: *mut u32) -> c_int;
+        pub fn sph_dist_get_stats(ctx: *mut c_void, out: *mut SphDistStats, reset: c_int) -> c_int;
+        pub fn sph_comm_unique_id(id_out: *mut u8 /* [128] */) -> c_int;
+        pub fn sph_comm_init(ctx: *mut c_void, id: *const u8 /* [128] */, rank: c_int, n_ranks: c_int) -> c_int;
+        /// k contexts of ONE process as ranks 0..k-1 (plain copies as transport): the single-GPU check of the decomposition
+        pub fn sph_group_step(ctxs: *mut *mut c_void, n: c_int, params: *const SphParams, outs: *mut SphStepStats) -> c_int;
+    }
+
+    /// `sph_dist_stats`
+    #[repr(C)]
+    #[derive(Clone, Copy, Debug, Default)]
+    pub struct SphDistStats {
+        pub steps: u64,
+        pub exchanges: u64,
+        pub bytes_sent: u64,
+        pub bytes_received: u64,
+        pub allreduces: u64,
+        pub host_waits: u64,
+        pub n_owned: u64,
+        pub n_halo: [u32; 2],
+        pub n_ghost: [u32; 2],
     }
 }
 
