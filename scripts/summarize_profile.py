@@ -46,8 +46,8 @@ for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
     real = [x for x in v if x > 0.25 * ref]
     e = {"launches": len(v), "working_launches": len(real), "median_us_working": statistics.median(real), "total_ms": sum(v) / 1e3}
     # FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 64 B per 128-B request -> x2 (MI355X_MICROARCH.md,
-    # confirmed here on k_cell_keys: 16 B/particle read -> 8203 KiB reported for 2^20 particles) ; WRITE_SIZE is exact
-    # (k_cell_keys writes 8 B/particle -> 8192 KiB)
+    # confirmed in round 1 on the then separate key kernel: 16 B/particle read -> 8203 KiB reported for 2^20 particles) ; WRITE_SIZE is exact
+    # (that kernel wrote 8 B/particle -> 8192 KiB)
     if k in fetch and k in write and max(fetch[k]) > 0 and max(write[k]) > 0:
         # launches that did work: a skipped speculative launch reads a few hundred bytes.  (Threshold well below a quarter of the
         # maximum: the integrating final pressure sweep writes 4x what an iteration's sweep does, and the MEDIAN must be taken
