@@ -98,6 +98,24 @@ def gather_by_id(contexts: Sequence[ffi.Context], name: str, n_total: int) -> np
 _ADAPT_FIELDS = ("h2", "h2_next", "level_estimation", "level_old", "particle_size_class")
 
 
+def assemble_lists(ids: Sequence[np.ndarray], lists: Sequence, n: int):
+    """The ranks' exported neighbour lists -- rank r: rows of its owned particles in the order of ids[r], (offsets, indices) with
+    global ids as indices -- as ONE CSR in global index order: row i = the list of the particle with id i."""
+    counts = np.zeros(n, np.int64)
+    for i, (off, _) in zip(ids, lists):
+        counts[np.asarray(i, np.int64)] = np.diff(np.asarray(off, np.int64))
+    off_g = np.zeros(n + 1, np.int64)
+    np.cumsum(counts, out=off_g[1:])
+    idx_g = np.empty(int(off_g[-1]), np.uint32)
+    for i, (off, idx) in zip(ids, lists):
+        off = np.asarray(off, np.int64)
+        lens = np.diff(off)
+        # entry e of this rank's index array sits in row r(e); its place in the global CSR = start of that row's global row + (e - off[r])
+        dst = np.repeat(off_g[np.asarray(i, np.int64)] - off[:-1], lens) + np.arange(len(idx))
+        idx_g[dst] = idx
+    return off_g, idx_g
+
+
 def group_single_step_adaptivity(lib: ffi.SphLibrary, contexts: Sequence[ffi.Context], planes, P, dt: float, step_number: int,
                                  split_patterns=None, capacity: int = 0, log=None) -> dict:
     """single_step_adaptivity (simulation.rs:2732-2796) for the ranks of a slab decomposition that have just stepped.
@@ -119,21 +137,7 @@ def group_single_step_adaptivity(lib: ffi.SphLibrary, contexts: Sequence[ffi.Con
     if not np.array_equal(np.sort(allid), np.arange(n, dtype=allid.dtype)):
         raise ValueError("group_single_step_adaptivity: the particle ids of the ranks are not the indices 0 .. n-1")
     g = {f: gather_by_id(contexts, f, n) for f in ("mass", "position", "velocity") + _ADAPT_FIELDS}
-    # neighbour lists in index order
-    counts = np.zeros(n, np.int64)
-    rows = []
-    for c, i in zip(contexts, ids):
-        off, idx = c.download_neighbors()
-        counts[i] = np.diff(off.astype(np.int64))
-        rows.append((i, off.astype(np.int64), idx))
-    off_g = np.zeros(n + 1, np.int64)
-    np.cumsum(counts, out=off_g[1:])
-    idx_g = np.empty(int(off_g[-1]), np.uint32)
-    for i, off, idx in rows:
-        starts = off_g[i]
-        lens = np.diff(off)
-        dst = np.repeat(starts - off[:-1], lens) + np.arange(len(idx))          # row r of this rank -> its place in the global CSR
-        idx_g[dst] = idx
+    off_g, idx_g = assemble_lists(ids, [c.download_neighbors() for c in contexts], n)   # neighbour lists in index order
     T = ffi.Context(lib, capacity or max(2 * n, n + 65536), planes, device_id=0)
     try:
         T.upload(g["mass"], g["position"], g["velocity"])

@@ -283,3 +283,24 @@ def test_vtk_snapshot_read_back(tmp_path):
         w = np.asarray(want).reshape(n, -1)
         assert np.array_equal(got[:n, :w.shape[1]], w), name
         assert not got[n:].any() and not got[:, w.shape[1]:].any(), name       # dummy data on the line points, z = 0
+
+
+def test_assemble_lists_of_the_ranks_in_global_index_order():
+    """distributed.assemble_lists: the CSR exports of the ranks (rows in each rank's own order, global ids as indices) become one
+    CSR whose row i is the list of particle i -- what the sequential partner searches of an adaptive slab step iterate."""
+    from adaptive_sph_amd.distributed import assemble_lists
+    rng = np.random.default_rng(11)
+    n = 500
+    truth = [rng.choice(n, size=int(rng.integers(0, 9)), replace=False).astype(np.uint32) for _ in range(n)]
+    owner = rng.integers(0, 3, n)
+    ids, lists = [], []
+    for r in range(3):
+        mine = rng.permutation(np.nonzero(owner == r)[0])          # a rank's rows are in ITS order, not ascending ids
+        off = np.zeros(len(mine) + 1, np.uint32)
+        off[1:] = np.cumsum([len(truth[i]) for i in mine])
+        ids.append(mine.astype(np.uint32))
+        lists.append((off, np.concatenate([truth[i] for i in mine]) if len(mine) else np.zeros(0, np.uint32)))
+    off_g, idx_g = assemble_lists(ids, lists, n)
+    assert off_g[0] == 0 and off_g[-1] == sum(len(t) for t in truth)
+    for i in range(n):
+        assert np.array_equal(idx_g[off_g[i]:off_g[i + 1]], truth[i]), i
