@@ -100,6 +100,7 @@ struct sph_ctx {
         uint32_t* counts_host = nullptr;       // mapped pinned
         uint32_t* counts_host_dev = nullptr;
         void* nccl = nullptr;        // ncclComm_t
+        void* tgroup = nullptr;      // ThreadGroup*: in-process transport with one host thread per rank (sph_comm_init_threads)
         int rebalance_every = 0;     // move the cuts to equal particle counts every so many steps (0: static cuts)
         DevBuf hist;                 // x histogram of the owned particles (rebalancing)
         uint32_t rebalances = 0;     // how often the cuts moved

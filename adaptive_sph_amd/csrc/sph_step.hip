@@ -21,7 +21,9 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
 #include <functional>
+#include <mutex>
 #include <vector>
 
 #include "sph_context.hpp"
@@ -1041,6 +1043,234 @@ struct RcclComm : Comm {
         double* t = c->dist.solver_tot.as<double>() + 8 * slot;
         NCCLCHK(c, ncclAllReduce(t, t, 6, ncclFloat64, ncclSum, (ncclComm_t)c->dist.nccl, c->stream));
         return SPH_OK;
+    }
+};
+
+// ---- threads: one HOST THREAD per rank, all ranks in this process (and on whatever devices their contexts name) -----------------
+// The verification transport for the per-rank driver code: every rank runs sph_step on its own thread with a group of ONE member,
+// exactly as a rank of the RCCL transport does -- its own view of the counts, its own branches (an exchange only where it has
+// something to send or receive, ...) -- and the collectives are rendezvous in host memory.  A collective that not every rank
+// enters, or a send that no receive of the same size matches, is what would hang RCCL: here it is a time-out / an error message.
+struct ThreadGroup {
+    int n = 0;
+    std::mutex mu;
+    std::condition_variable cv;
+    int arrived = 0;
+    uint64_t gen = 0;
+    bool broken = false;
+    std::vector<Xfer> xf;
+    std::vector<std::array<double, 6>> tot;
+    std::vector<std::vector<float>> f32rows;
+    std::vector<std::vector<uint32_t>> u32rows;
+    std::vector<int> i32vals;
+    std::vector<std::array<uint32_t, 8>> words;
+    std::vector<int> op;          // which collective each rank is in (a mismatch is reported, not waited out)
+    explicit ThreadGroup(int k) : n(k), xf(k), tot(k), f32rows(k), u32rows(k), i32vals(k), words(k), op(k) {}
+    // all ranks meet; false: somebody did not come (60 s) or left with an error
+    bool barrier()
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        if (broken) return false;
+        const uint64_t g = gen;
+        if (++arrived == n) {
+            arrived = 0;
+            gen++;
+            cv.notify_all();
+            return true;
+        }
+        if (!cv.wait_for(lk, std::chrono::seconds(60), [&] { return gen != g || broken; })) broken = true;
+        if (broken) cv.notify_all();
+        return !broken;
+    }
+    void abandon()
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        broken = true;
+        cv.notify_all();
+    }
+};
+
+struct ThreadComm : Comm {
+    bool host_collectives_wait() const override { return true; }
+    static ThreadGroup* grp(Group& G) { return (ThreadGroup*)G.m[0]->dist.tgroup; }
+    // publish -> everybody is there -> consume -> everybody is done (the slots may be overwritten again)
+    template <class Pub, class Con>
+    static int meet(Group& G, int opcode, Pub pub, Con con)
+    {
+        sph_ctx* c = G.m[0];
+        ThreadGroup* g = grp(G);
+        const int r = c->dist.rank;
+        g->op[(size_t)r] = opcode;
+        pub(g, r);
+        if (!g->barrier()) return c->fail(SPH_ERR_DEVICE, "thread transport: a rank did not enter collective %d (it would hang over RCCL)", opcode);
+        int rc = SPH_OK;
+        for (int k = 0; k < g->n; k++)
+            if (g->op[(size_t)k] != opcode) rc = c->fail(SPH_ERR_DEVICE, "thread transport: rank %d is in collective %d, rank %d in %d", r, opcode, k, g->op[(size_t)k]);
+        if (!rc) rc = con(g, r);
+        if (!g->barrier() && !rc) rc = c->fail(SPH_ERR_DEVICE, "thread transport: a rank left collective %d early", opcode);
+        return rc;
+    }
+    int allreduce_min_f32(Group& G, std::vector<std::vector<float>>& rows) override
+    {
+        return meet(G, 1, [&](ThreadGroup* g, int r) { g->f32rows[(size_t)r] = rows[0]; },
+                    [&](ThreadGroup* g, int) {
+                        for (size_t k = 0; k < rows[0].size(); k++) {
+                            float v = rows[0][k];
+                            for (int q = 0; q < g->n; q++) {
+                                if (g->f32rows[(size_t)q].size() != rows[0].size()) return G.m[0]->fail(SPH_ERR_DEVICE, "thread transport: all-reduce sizes differ");
+                                v = fminf(v, g->f32rows[(size_t)q][k]);
+                            }
+                            rows[0][k] = v;
+                        }
+                        return (int)SPH_OK;
+                    });
+    }
+    int allreduce_max_i32(Group& G, std::vector<int>& vals) override
+    {
+        return meet(G, 2, [&](ThreadGroup* g, int r) { g->i32vals[(size_t)r] = vals[0]; },
+                    [&](ThreadGroup* g, int) {
+                        int v = vals[0];
+                        for (int q = 0; q < g->n; q++) v = std::max(v, g->i32vals[(size_t)q]);
+                        vals[0] = v;
+                        return (int)SPH_OK;
+                    });
+    }
+    int allreduce_sum_u32(Group& G, std::vector<std::vector<uint32_t>>& rows) override
+    {
+        std::vector<uint32_t> mine = rows[0];
+        return meet(G, 3, [&](ThreadGroup* g, int r) { g->u32rows[(size_t)r] = mine; },
+                    [&](ThreadGroup* g, int) {
+                        for (size_t k = 0; k < rows[0].size(); k++) {
+                            uint32_t v = 0;
+                            for (int q = 0; q < g->n; q++) v += g->u32rows[(size_t)q][k];
+                            rows[0][k] = v;
+                        }
+                        return (int)SPH_OK;
+                    });
+    }
+    int neighbour_counts(Group& G, const std::vector<uint32_t>& tl, const std::vector<uint32_t>& tr, std::vector<uint32_t>& fl,
+                         std::vector<uint32_t>& fr, int* status) override
+    {
+        return meet(G, 4, [&](ThreadGroup* g, int r) { g->words[(size_t)r] = {tl[0], tr[0], status ? (uint32_t)*status : 0u, 0, 0, 0, 0, 0}; },
+                    [&](ThreadGroup* g, int r) {
+                        fl[0] = r > 0 ? g->words[(size_t)r - 1][1] : 0;
+                        fr[0] = r + 1 < g->n ? g->words[(size_t)r + 1][0] : 0;
+                        if (status)
+                            for (int q = 0; q < g->n; q++) *status = std::max(*status, (int)g->words[(size_t)q][2]);
+                        return (int)SPH_OK;
+                    });
+    }
+    int counts_round(Group& G, int base, std::vector<std::vector<float>>* red, int* status, std::vector<uint32_t>& tl, std::vector<uint32_t>& tr,
+                     std::vector<uint32_t>& fl, std::vector<uint32_t>& fr) override
+    {
+        sph_ctx* c = G.m[0];
+        int rc = wait_stream(c);
+        if (rc) {
+            grp(G)->abandon();
+            return rc;
+        }
+        HIPCHK(c, hipMemcpy(c->dist.counts_host + base, c->dist.counts.as<uint32_t>() + base, 16, hipMemcpyDeviceToHost));
+        tl[0] = c->dist.counts_host[base + 1];
+        tr[0] = c->dist.counts_host[base + 2];
+        if (status && base == 4 && c->dist.counts_host[base + 3] && *status < SPH_ERR_UNSUPPORTED) *status = SPH_ERR_UNSUPPORTED;
+        if (red && (rc = allreduce_min_f32(G, *red))) return rc;
+        return neighbour_counts(G, tl, tr, fl, fr, status);
+    }
+    int refresh_round(Group& G, std::vector<std::vector<float>>* red, int* status, int* fallback, std::vector<RefreshCounts>& rcs) override
+    {
+        sph_ctx* c = G.m[0];
+        int rc = wait_stream(c);
+        if (rc) {
+            grp(G)->abandon();
+            return rc;
+        }
+        uint32_t w[5];
+        HIPCHK(c, hipMemcpy(w, c->dist.counts.p, 20, hipMemcpyDeviceToHost));
+        RefreshCounts& o = rcs[0];
+        o.halo[0] = w[0];
+        o.halo[1] = w[1];
+        o.mig[0] = w[2];
+        o.mig[1] = w[3];
+        if (w[4]) *fallback = 1;
+        rc = meet(G, 5, [&](ThreadGroup* g, int r) { g->words[(size_t)r] = {o.mig[0], o.halo[0], o.mig[1], o.halo[1], (uint32_t)*status, (uint32_t)*fallback, 0, 0}; },
+                  [&](ThreadGroup* g, int r) {
+                      o.in_mig[0] = r > 0 ? g->words[(size_t)r - 1][2] : 0;
+                      o.in_halo[0] = r > 0 ? g->words[(size_t)r - 1][3] : 0;
+                      o.in_mig[1] = r + 1 < g->n ? g->words[(size_t)r + 1][0] : 0;
+                      o.in_halo[1] = r + 1 < g->n ? g->words[(size_t)r + 1][1] : 0;
+                      for (int q = 0; q < g->n; q++) {
+                          *status = std::max(*status, (int)g->words[(size_t)q][4]);
+                          if (g->words[(size_t)q][5]) *fallback = 1;
+                      }
+                      return (int)SPH_OK;
+                  });
+        if (rc) return rc;
+        return red ? allreduce_min_f32(G, *red) : SPH_OK;
+    }
+    int exchange(Group& G, std::vector<Xfer>& x) override
+    {
+        sph_ctx* c = G.m[0];
+        c->dist.stat_exchanges++;
+        int rc = wait_stream(c);   // my staging buffers are packed
+        if (rc) {
+            grp(G)->abandon();
+            return rc;
+        }
+        return meet(G, 6, [&](ThreadGroup* g, int r) { g->xf[(size_t)r] = x[0]; },
+                    [&](ThreadGroup* g, int r) -> int {
+                        // RCCL pairs every ncclSend with an ncclRecv of the same size on the other side: the same rule, checked
+                        const Xfer zero{};
+                        const Xfer& L = r > 0 ? g->xf[(size_t)r - 1] : zero;
+                        const Xfer& R = r + 1 < g->n ? g->xf[(size_t)r + 1] : zero;
+                        if (x[0].recv_bytes[0] != L.send_bytes[1] || x[0].send_bytes[0] != L.recv_bytes[1] || x[0].recv_bytes[1] != R.send_bytes[0] ||
+                            x[0].send_bytes[1] != R.recv_bytes[0])
+                            return c->fail(SPH_ERR_DEVICE, "halo exchange sizes of rank %d do not pair up with its neighbours' (recv %zu/%zu vs sent %zu/%zu, send %zu/%zu vs expected %zu/%zu)",
+                                           r, x[0].recv_bytes[0], x[0].recv_bytes[1], L.send_bytes[1], R.send_bytes[0], x[0].send_bytes[0], x[0].send_bytes[1],
+                                           L.recv_bytes[1], R.recv_bytes[0]);
+                        c->dist.stat_bytes_sent += x[0].send_bytes[0] + x[0].send_bytes[1];
+                        c->dist.stat_bytes_recv += x[0].recv_bytes[0] + x[0].recv_bytes[1];
+                        if (x[0].recv_bytes[0]) HIPCHK(c, hipMemcpyAsync(x[0].recv[0], L.send[1], x[0].recv_bytes[0], hipMemcpyDefault, c->stream));
+                        if (x[0].recv_bytes[1]) HIPCHK(c, hipMemcpyAsync(x[0].recv[1], R.send[0], x[0].recv_bytes[1], hipMemcpyDefault, c->stream));
+                        return wait_stream(c);   // (the senders may reuse their staging buffers once everybody is past the closing barrier)
+                    });
+    }
+    int allreduce_solver(Group& G, int slot) override
+    {
+        sph_ctx* c = G.m[0];
+        c->dist.stat_allreduces++;
+        int rc = wait_stream(c);
+        if (rc) {
+            grp(G)->abandon();
+            return rc;
+        }
+        std::array<double, 6> mine{};
+        HIPCHK(c, hipMemcpy(mine.data(), c->dist.solver_tot.as<double>() + 8 * slot, 48, hipMemcpyDeviceToHost));
+        return meet(G, 7 + slot, [&](ThreadGroup* g, int r) { g->tot[(size_t)r] = mine; },
+                    [&](ThreadGroup* g, int) -> int {
+                        double t[6] = {0, 0, 0, 0, 0, 0};
+                        for (int q = 0; q < g->n; q++)
+                            for (int k = 0; k < 6; k++) t[k] += g->tot[(size_t)q][k];   // (rank order: the same sum on every rank)
+                        HIPCHK(c, hipMemcpy(c->dist.solver_tot.as<double>() + 8 * slot, t, 48, hipMemcpyHostToDevice));
+                        return SPH_OK;
+                    });
+    }
+    int agree_guards_queued(Group& G) override
+    {
+        sph_ctx* c = G.m[0];
+        int rc = wait_stream(c);
+        if (rc) {
+            grp(G)->abandon();
+            return rc;
+        }
+        uint32_t e = 0;
+        HIPCHK(c, hipMemcpy(&e, &c->status.as<DeviceStatus>()->error, 4, hipMemcpyDeviceToHost));
+        return meet(G, 9, [&](ThreadGroup* g, int r) { g->i32vals[(size_t)r] = (int)e; },
+                    [&](ThreadGroup* g, int) -> int {
+                        uint32_t m = 0;
+                        for (int q = 0; q < g->n; q++) m = std::max(m, (uint32_t)g->i32vals[(size_t)q]);
+                        HIPCHK(c, hipMemcpy(&c->ctrl.as<SolverCtrl>()->peer_error, &m, 4, hipMemcpyHostToDevice));
+                        return SPH_OK;
+                    });
     }
 };
 
@@ -2747,6 +2977,7 @@ static int group_step(Group& G, const sph_params* p, sph_step_stats* outs)
 // ------------------------------------------------------------------------------------------------
 static RcclComm g_rccl;
 static LocalComm g_local;
+static ThreadComm g_threads;
 
 extern "C" int sph_step(sph_ctx* c, const sph_params* p, sph_step_stats* out)
 {
@@ -2755,8 +2986,14 @@ extern "C" int sph_step(sph_ctx* c, const sph_params* p, sph_step_stats* out)
     Group G;
     G.m.push_back(c);
     if (c->dist.on) {
-        if (!c->dist.nccl) return c->fail(SPH_ERR_INVALID_ARGUMENT, "slab context without a communicator: call sph_comm_init or use sph_group_step");
-        G.comm = &g_rccl;
+        if (c->dist.tgroup) G.comm = &g_threads;
+        else if (!c->dist.nccl) return c->fail(SPH_ERR_INVALID_ARGUMENT, "slab context without a communicator: call sph_comm_init or use sph_group_step");
+        else G.comm = &g_rccl;
+    }
+    if (c->dist.on && c->dist.tgroup) {
+        const int rc = group_step(G, p, out);
+        if (rc) ((ThreadGroup*)c->dist.tgroup)->abandon();   // the other ranks' next collective reports it instead of waiting
+        return rc;
     }
     return group_step(G, p, out);
 }
@@ -2873,6 +3110,25 @@ extern "C" int sph_comm_init(sph_ctx* c, const uint8_t id[128], int rank, int n_
     ncclComm_t nc;
     NCCLCHK(c, ncclCommInitRank(&nc, n_ranks, uid, rank));
     c->dist.nccl = nc;
+    return SPH_OK;
+}
+
+extern "C" int sph_thread_group_create(int n_ranks, void** out)
+{
+    if (!out || n_ranks < 1) return SPH_ERR_INVALID_ARGUMENT;
+    *out = new ThreadGroup(n_ranks);
+    return SPH_OK;
+}
+extern "C" void sph_thread_group_destroy(void* group)
+{
+    delete (ThreadGroup*)group;
+}
+extern "C" int sph_comm_init_threads(sph_ctx* c, void* group, int rank, int n_ranks)
+{
+    if (!c || !group || rank < 0 || n_ranks < 1 || rank >= n_ranks || ((ThreadGroup*)group)->n != n_ranks) return SPH_ERR_INVALID_ARGUMENT;
+    if (!c->dist.on || c->dist.rank != rank || c->dist.nranks != n_ranks)
+        return c->fail(SPH_ERR_INVALID_ARGUMENT, "call sph_dist_configure(rank, n_ranks, cuts) before sph_comm_init_threads");
+    c->dist.tgroup = group;
     return SPH_OK;
 }
 

@@ -6,6 +6,7 @@ unique id and the launcher's barrier; the halo exchange itself is RCCL inside li
   make_slab_context  context of this rank, configured, communicator initialised, particles uploaded
   make_loopback_group  k contexts in this process (ranks 0..k-1) for single-GPU verification
   group_single_step_adaptivity  single_step_adaptivity for a slab group, through a gather to one context and back
+  ThreadedGroup      k ranks of this process, one host thread each, every rank calling sph_step by itself (verification of the per-rank code)
 """
 from __future__ import annotations
 
@@ -157,3 +158,53 @@ def group_single_step_adaptivity(lib: ffi.SphLibrary, contexts: Sequence[ffi.Con
         c.upload_field("particle_id", mine.astype(np.uint32))
     info["n_after"] = n_new
     return info
+
+
+class ThreadedGroup:
+    """k slab contexts of this process stepped the way the ranks of a multi-process run are: every rank calls sph_step on its OWN
+    context from its OWN thread (a group of one member, rank-local branches and counts), the collectives meet in host memory
+    (sph_thread_group_create / sph_comm_init_threads).  A collective that not every rank enters, ranks in different collectives or
+    a send without a matching receive -- what would hang the RCCL transport -- comes back as an error."""
+
+    def __init__(self, lib: ffi.SphLibrary, pos, mass, vel, planes, n_ranks: int, device_id: int = 0):
+        import ctypes as C
+        from concurrent.futures import ThreadPoolExecutor
+        self.lib = lib
+        self.group = C.c_void_p()
+        rc = lib.thread_group_create(n_ranks, C.byref(self.group))
+        if rc != 0:
+            raise ffi.SphError(rc, "sph_thread_group_create failed")
+        cuts = slab_cuts(pos[:, 0], n_ranks)
+        parts = partition(pos[:, 0], cuts)
+        self.contexts = []
+        for r in range(n_ranks):
+            c = ffi.Context(lib, _slab_capacity(len(mass), n_ranks), planes, device_id=device_id)
+            c.dist_configure(r, n_ranks, cuts[r], cuts[r + 1])
+            c.comm_init_threads(self.group, r, n_ranks)
+            c.upload(mass[parts[r]], pos[parts[r]], vel[parts[r]])
+            c.upload_field("particle_id", parts[r].astype(np.uint32))
+            self.contexts.append(c)
+        self.pool = ThreadPoolExecutor(n_ranks)
+
+    def step(self, p):
+        """One sph_step per rank, concurrently (ctypes drops the GIL inside the call).  Returns the ranks' stats; raises the first
+        rank's error after ALL ranks have returned."""
+        futs = [self.pool.submit(c.step, p) for c in self.contexts]
+        out, err = [], None
+        for f in futs:
+            try:
+                out.append(f.result())
+            except ffi.SphError as e:
+                err = err or e
+        if err:
+            raise err
+        return out
+
+    def close(self):
+        self.pool.shutdown(wait=True)
+        for c in self.contexts:
+            c.close()
+        self.contexts = []
+        if self.group:
+            self.lib.thread_group_destroy(self.group)
+            self.group = None

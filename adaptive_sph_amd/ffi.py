@@ -144,7 +144,7 @@ class SphError(RuntimeError):
 ABI_SYMBOLS = [
     "create", "destroy", "upload", "upload_field", "download", "download_neighbors", "num_particles", "time",
     "set_time", "step", "classify", "share_particles", "merge_particles", "set_split_patterns", "split_particles", "host_find_partners", "last_error", "grid", "set_boundary_polygon", "apply_edits", "profile_enable", "profile_reset", "profile_get", "profile_event_overhead", "profile_copy_bandwidth", "set_sweep_variant",
-    "dist_configure", "dist_set_rebalance", "dist_get_cuts", "dist_get_stats", "comm_unique_id", "comm_init", "group_step",
+    "dist_configure", "dist_set_rebalance", "dist_get_cuts", "dist_get_stats", "comm_unique_id", "comm_init", "group_step", "thread_group_create", "thread_group_destroy", "comm_init_threads",
 ]
 
 
@@ -206,6 +206,9 @@ class SphLibrary:
         self.comm_init = sig("comm_init", i32, [vp, C.POINTER(C.c_uint8), i32, i32], required=False)
         self.dist_configure = sig("dist_configure", i32, [vp, i32, i32, C.c_float, C.c_float], required=False)
         self.group_step = sig("group_step", i32, [C.POINTER(vp), i32, C.POINTER(SphParams), C.POINTER(SphStepStats)], required=False)
+        self.thread_group_create = sig("thread_group_create", i32, [i32, C.POINTER(vp)], required=False)
+        self.thread_group_destroy = sig("thread_group_destroy", None, [vp], required=False)
+        self.comm_init_threads = sig("comm_init_threads", i32, [vp, vp, i32, i32], required=False)
         self.dist_set_rebalance = sig("dist_set_rebalance", i32, [vp, i32], required=False)
         self.dist_get_cuts = sig("dist_get_cuts", i32, [vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_uint32)], required=False)
         self.dist_get_stats = sig("dist_get_stats", i32, [vp, C.POINTER(SphDistStats), i32], required=False)
@@ -432,6 +435,10 @@ class Context:
         return {"steps": int(st.steps), "exchanges": int(st.exchanges), "bytes_sent": int(st.bytes_sent), "bytes_received": int(st.bytes_received),
                 "allreduces": int(st.allreduces), "host_waits": int(st.host_waits), "n_owned": int(st.n_owned),
                 "n_halo": [int(st.n_halo[0]), int(st.n_halo[1])], "n_ghost": [int(st.n_ghost[0]), int(st.n_ghost[1])]}
+
+    def comm_init_threads(self, group, rank: int, n_ranks: int):
+        """Thread transport (sph_ffi.h): `group` from SphLibrary.thread_group_create; every rank then steps on a thread of its own."""
+        self._check(self.lib.comm_init_threads(self.handle, group, int(rank), int(n_ranks)))
 
     def comm_init(self, unique_id: bytes, rank: int, n_ranks: int):
         buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)

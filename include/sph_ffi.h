@@ -419,6 +419,14 @@ int  sph_dist_get_stats(sph_ctx* ctx, sph_dist_stats* out, int reset);
 int  sph_comm_unique_id(uint8_t id_out[128]);
 int  sph_comm_init(sph_ctx* ctx, const uint8_t id[128], int rank, int n_ranks);
 int  sph_group_step(sph_ctx** ctxs, int n, const sph_params* params, sph_step_stats* outs);
+/* Verification transport for the PER-RANK driver code: all ranks in this process, one HOST THREAD per rank, each calling sph_step
+ * on its own slab context -- a group of one member, its own view of the counts, its own branches, exactly as a rank of the RCCL
+ * transport runs -- with the collectives as rendezvous in host memory.  What would hang RCCL is an error here: a collective
+ * that not every rank enters (60 s), ranks in different collectives, a send without a receive of the same size on the other
+ * side.  sph_thread_group_create(n) once, sph_comm_init_threads on every rank's context instead of sph_comm_init. */
+int  sph_thread_group_create(int n_ranks, void** group_out);
+void sph_thread_group_destroy(void* group);
+int  sph_comm_init_threads(sph_ctx* ctx, void* group, int rank, int n_ranks);
 
 #ifdef __cplusplus
 }

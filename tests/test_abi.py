@@ -24,7 +24,7 @@ def test_header_symbols_exported(product_lib):
 
 def test_oracle_exports_same_surface(oracle_lib):
     for s in ffi.ABI_SYMBOLS:
-        if s.startswith(("profile_", "comm_", "dist_", "group_", "set_sweep_", "host_")):   # device / measurement entry points
+        if s.startswith(("profile_", "comm_", "dist_", "group_", "set_sweep_", "host_", "thread_")):   # device / measurement entry points
             continue
         assert hasattr(oracle_lib.lib, "oracle_" + s)
 

@@ -108,6 +108,32 @@ def test_config3_dam_break_8m_eight_slabs_against_the_single_context(product_lib
             assert np.array_equal(np.add.reduceat(idx.astype(np.uint64) ** power, off[:-1].astype(np.int64)), ref[power - 1][pid]), power
 
 
+def test_config3_dam_break_8m_eight_ranks_on_their_own_threads(product_lib):
+    """configs[3] the way 8 processes would run it: 8 slab contexts, one host thread each, every rank calling sph_step by itself
+    (thread transport: the per-rank driver code with its rank-local branches; a collective not entered by all or an unmatched
+    send is an error).  Bit for bit the loopback group's result."""
+    scene_f, params_f, _ = WORKLOADS["dam_break_8m"]
+    scn, P = scene_f(), params_f(max_iters=3, **FORCED)
+    pos, mass, vel = sc.init_particles(scn)
+    planes = sc.boundary_planes(scn.boundary)
+    p = P.to_ffi()
+    loop = D.make_loopback_group(product_lib, pos, mass, vel, planes, 8)
+    thr = D.ThreadedGroup(product_lib, pos, mass, vel, planes, 8)
+    try:
+        for s in range(3):
+            a = ffi.group_step(loop, p)
+            b = thr.step(p)
+            assert all(x.dt == y.dt and x.div_solver.iters == y.div_solver.iters for x, y in zip(a, b))
+        for ca, cb in zip(loop, thr.contexts):
+            assert ca.n == cb.n > 1000000
+            for f in ("particle_id", "position", "density", "neighbor_count"):
+                assert np.array_equal(ca.download(f), cb.download(f)), f
+        st = thr.contexts[4].dist_get_stats()
+        assert st["n_ghost"][0] > 0 and st["n_ghost"][1] > 0 and st["bytes_sent"] > 0
+    finally:
+        thr.close()
+
+
 def test_config4_ratio_stress_4m_against_the_oracle(product_lib, oracle_lib):
     """The step path of configs[4] with the recipe's own parameters (media/ratio-stress-test-video.yaml: IISPH, cfl 0.2,
     AnalyticUnderestimate = the Sdf2D box) and default-config.yaml's EmptyAngle level estimation, iteration counts pinned."""

@@ -453,6 +453,83 @@ def test_sparse_edits_on_slab_contexts(product_lib):
         assert rel_err(a, b) <= tol, f
 
 
+@pytest.mark.parametrize("k,level", [(2, False), (3, False), (4, False), (3, True)])
+def test_every_rank_on_its_own_thread_matches_the_loopback_group(product_lib, k, level):
+    """The per-rank driver code -- what every process of a multi-GPU run executes: a group of ONE member, the rank's own counts
+    and branches (an exchange only where it has something to send or receive), collectives it must enter together with the
+    others -- run for real: k ranks, one host thread each, each calling sph_step on its own context, the collectives as
+    rendezvous in host memory (thread transport, sph_ffi.h).  A collective that not every rank enters or a send without a
+    matching receive would be an error here (a hang over RCCL).  Same arithmetic in the same order as the loopback group
+    (sph_group_step drives all ranks from one loop): every field bit for bit, with particles migrating."""
+    scn = sc.dam_break_small(96, 48, 1 / 48)
+    pos, mass, vel = sc.init_particles(scn)
+    vel = vel.copy()
+    vel[:, 0] = 0.8
+    planes = sc.boundary_planes(scn.boundary)
+    kw = dict(level_estimation_method="EmptyAngle", maximum_surface_distance=0.2, particle_radius_fine=0.004, particle_radius_base=0.02) if level else {}
+    p = dam_break_params(**kw).to_ffi()          # free-running iteration counts: mispredicted solves, chained and unchained steps
+    loop = D.make_loopback_group(product_lib, pos, mass, vel, planes, k)
+    thr = D.ThreadedGroup(product_lib, pos, mass, vel, planes, k)
+    try:
+        moved = 0
+        for s in range(25):
+            before = [c.n for c in thr.contexts]
+            a = ffi.group_step(loop, p)
+            b = thr.step(p)
+            moved += sum(abs(x - c.n) for x, c in zip(before, thr.contexts))
+            for sa, sb in zip(a, b):
+                assert sa.dt == sb.dt and sa.div_solver.iters == sb.div_solver.iters and sa.density_solver.iters == sb.density_solver.iters, s
+        assert moved > 0
+        for ca, cb in zip(loop, thr.contexts):
+            assert ca.n == cb.n
+            for f in ("particle_id", "position", "velocity", "density", "pressure", "neighbor_count") + (("level_estimation", "flag_is_fluid_surface") if level else ()):
+                x, y = ca.download(f), cb.download(f)
+                assert np.array_equal(x, y, equal_nan=(x.dtype.kind == "f")), f
+        st = thr.contexts[1].dist_get_stats()
+        assert st["exchanges"] > 0 and st["bytes_sent"] > 0 and st["bytes_received"] > 0
+    finally:
+        thr.close()
+
+
+@pytest.mark.parametrize("mode", ["rebalance", "after_advection", "from_distribution", "general_path"])
+def test_ranks_on_threads_other_step_variants(product_lib, monkeypatch, mode):
+    """The same per-rank execution for the steps that take other collectives: re-balancing (x range, histogram, migration
+    rounds), level estimation after advection (all-reduced displacement, widened ghost layer), FromDistribution support lengths
+    (header launch + two-round slab maintenance every step), and the general slab maintenance forced on every step."""
+    scn = sc.dam_break_small(96, 48, 1 / 48)
+    pos, mass, vel = sc.init_particles(scn)
+    vel = vel.copy()
+    vel[:, 0] = 0.8
+    planes = sc.boundary_planes(scn.boundary)
+    kw = {}
+    if mode == "after_advection":
+        kw = dict(level_estimation_method="EmptyAngle", level_estimation_after_advection=True, maximum_surface_distance=0.2, particle_radius_fine=0.004,
+                  particle_radius_base=0.02)
+    if mode == "from_distribution":
+        kw = dict(support_length_estimation="FromDistribution")
+    if mode == "general_path":
+        monkeypatch.setenv("SPH_SLAB_GENERAL", "1")
+    p = forced(max_iters=4, **kw).to_ffi()
+    loop = D.make_loopback_group(product_lib, pos, mass, vel, planes, 3)
+    thr = D.ThreadedGroup(product_lib, pos, mass, vel, planes, 3)
+    try:
+        if mode == "rebalance":
+            for c in loop + thr.contexts:
+                c.dist_set_rebalance(2)
+        for s in range(12):
+            a = ffi.group_step(loop, p)
+            b = thr.step(p)
+            assert all(sa.dt == sb.dt for sa, sb in zip(a, b)), s
+        if mode == "rebalance":
+            assert thr.contexts[1].dist_get_cuts()[2] > 0 and thr.contexts[1].dist_get_cuts() == loop[1].dist_get_cuts()
+        for ca, cb in zip(loop, thr.contexts):
+            assert ca.n == cb.n
+            for f in ("particle_id", "position", "velocity", "density", "neighbor_count"):
+                assert np.array_equal(ca.download(f), cb.download(f)), f
+    finally:
+        thr.close()
+
+
 def test_a_slab_without_room_for_its_ghosts_says_so(product_lib):
     """Between the refresh and the cell sort a slab holds its previous slots, the arrivals and the new ghosts: a context that
     cannot fit them returns SPH_ERR_CAPACITY (and is poisoned) -- it never writes past its arrays."""
