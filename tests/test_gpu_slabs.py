@@ -530,6 +530,65 @@ def test_ranks_on_threads_other_step_variants(product_lib, monkeypatch, mode):
         thr.close()
 
 
+@pytest.mark.parametrize("solver,extra", [("IISPH", {}), ("IISPH2", dict(max_dt=0.0005)), ("OnlyDivergence", {}),
+                                          ("HybridDFSPH", dict(hybrid_dfsph_non_pressure_accel_before_divergence_free=False)),
+                                          ("HybridDFSPH", dict(check_neighborhood=True, check_aii=True))])
+def test_ranks_on_threads_every_solver_mode(product_lib, monkeypatch, solver, extra):
+    """Every sequencing of the step, per rank on its own thread, chained solves forced on (SPH_CHAIN=1: the gated second solve and
+    its short-fall path run on every rank together or not at all) -- bit for bit the loopback group."""
+    monkeypatch.setenv("SPH_CHAIN", "1")
+    scn = sc.dam_break_small(96, 48, 1 / 48)
+    pos, mass, vel = sc.init_particles(scn)
+    vel = vel.copy()
+    vel[:, 0] = 0.8
+    planes = sc.boundary_planes(scn.boundary)
+    p = dam_break_params(pressure_solver_method=solver, **extra).to_ffi()
+    loop = D.make_loopback_group(product_lib, pos, mass, vel, planes, 3)
+    thr = D.ThreadedGroup(product_lib, pos, mass, vel, planes, 3)
+    try:
+        for s in range(15):
+            a = ffi.group_step(loop, p)
+            b = thr.step(p)
+            assert all(x.dt == y.dt and x.div_solver.iters == y.div_solver.iters and x.density_solver.iters == y.density_solver.iters for x, y in zip(a, b)), s
+        for ca, cb in zip(loop, thr.contexts):
+            assert ca.n == cb.n
+            for f in ("particle_id", "position", "velocity", "density", "pressure"):
+                assert np.array_equal(ca.download(f), cb.download(f)), f
+    finally:
+        thr.close()
+
+
+def test_ranks_on_threads_fail_together(product_lib):
+    """A guard that fires on ONE rank (a NaN velocity uploaded there) ends the step on every rank -- through the all-reduced
+    totals and the guard agreement, not through a time-out -- and poisons every context."""
+    scn = sc.dam_break_small(96, 48, 1 / 48)
+    pos, mass, vel = sc.init_particles(scn)
+    planes = sc.boundary_planes(scn.boundary)
+    p = dam_break_params().to_ffi()
+    thr = D.ThreadedGroup(product_lib, pos, mass, vel, planes, 3)
+    try:
+        for _ in range(2):
+            thr.step(p)
+        c = thr.contexts[2]
+        v = c.download("velocity")
+        v[len(v) // 2] = np.nan
+        m, x, ids = c.download("mass"), c.download("position"), c.download("particle_id")
+        c.upload(m, x, v)
+        c.upload_field("particle_id", ids)
+        import time
+        t0 = time.perf_counter()
+        futs = [thr.pool.submit(cc.step, p) for cc in thr.contexts]
+        errs = []
+        for f in futs:
+            with pytest.raises(ffi.SphError) as e:
+                f.result()
+            errs.append(e.value.status)
+        assert time.perf_counter() - t0 < 30.0              # nobody waited for a rank that had left
+        assert errs[2] in (14, 15, 17, 18, 19) and all(e != 0 for e in errs), errs
+    finally:
+        thr.close()
+
+
 def test_a_slab_without_room_for_its_ghosts_says_so(product_lib):
     """Between the refresh and the cell sort a slab holds its previous slots, the arrivals and the new ghosts: a context that
     cannot fit them returns SPH_ERR_CAPACITY (and is poisoned) -- it never writes past its arrays."""
