@@ -100,6 +100,7 @@ struct sph_ctx {
         uint32_t* counts_host = nullptr;       // mapped pinned
         uint32_t* counts_host_dev = nullptr;
         void* nccl = nullptr;        // ncclComm_t
+        bool ghosts_ok = true;       // false: this rank ran out of room for its ghost layer (the step goes on without it and ends in SPH_ERR_CAPACITY on every rank)
         void* tgroup = nullptr;      // ThreadGroup*: in-process transport with one host thread per rank (sph_comm_init_threads)
         int rebalance_every = 0;     // move the cuts to equal particle counts every so many steps (0: static cuts)
         DevBuf hist;                 // x histogram of the owned particles (rebalancing)

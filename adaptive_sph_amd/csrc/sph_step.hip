@@ -105,6 +105,7 @@ const char* status_message(uint32_t code)
     case SPH_ERR_CONSTRAIN_NOT_SMALLER: return "assertion failed: *p_h_next < smoothing_length_single(&particles.h2, i, simulation_params)";
     case SPH_ERR_CONSTRAIN_NEGATIVE: return "assertion failed: *p_h_next >= 0.";
     case SPH_ERR_UNSUPPORTED: return "a particle's neighbour list exceeds what is recorded (it re-walks its candidates): replaying the step's lists at the advected positions is not covered for it";
+    case SPH_ERR_CAPACITY: return "a slab context ran out of room for the particles handed to it or for its ghost layer (it needs owned + arrivals + 2 x ghosts slots)";
     default: return "device-side guard failed";
     }
 }
@@ -611,6 +612,24 @@ __global__ __launch_bounds__(256) void k_iota_u32(uint32_t* __restrict__ out, ui
     const uint32_t k = blockIdx.x * 256 + threadIdx.x;
     if (k < cnt) out[k] = first + k;
 }
+// A rank that cannot take what its neighbours hand it must not leave the step alone (the others would wait in their next
+// collective): it raises the guard word, goes on WITHOUT the arrivals / ghosts -- every exchange keeps the sizes that were agreed --
+// and the step ends on every rank through the all-reduced guards (solver totals, agree_guards_queued) with SPH_ERR_CAPACITY.
+__global__ void k_raise(DeviceStatus* st, uint32_t code, uint32_t info)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0 && atomicCAS(&st->error, 0u, code) == 0u) st->info = info;
+}
+__global__ __launch_bounds__(256) void k_fill_u32(uint32_t* __restrict__ out, uint32_t cnt, uint32_t v)
+{
+    const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+    if (k < cnt) out[k] = v;
+}
+static void slab_out_of_room(sph_ctx* c, unsigned long long need)
+{
+    (void)c->fail(SPH_ERR_CAPACITY, "slab of rank %d needs %llu slots, capacity %llu", c->dist.rank, need, (unsigned long long)c->cap);
+    hipLaunchKernelGGL(k_raise, dim3(1), dim3(64), 0, c->stream, c->status.as<DeviceStatus>(), (uint32_t)SPH_ERR_CAPACITY, (uint32_t)c->dist.rank);
+}
+
 __global__ void k_fill_u8(uint8_t* p, uint32_t n, uint8_t v)
 {
     uint32_t i = blockIdx.x * 256 + threadIdx.x;
@@ -1370,7 +1389,7 @@ static int refresh_ghosts(Group& G, std::vector<Member>& M, float* (*sel)(Member
         (void)hipSetDevice(c->device);
         ProfScope ps(&c->prof, "ghost_unpack", c->stream);
         float* field = sel(M[i]);
-        const uint32_t ng = c->dist.n_ghost[0] + c->dist.n_ghost[1];
+        const uint32_t ng = c->dist.ghosts_ok ? c->dist.n_ghost[0] + c->dist.n_ghost[1] : 0u;   // (no ghost slots: received, dropped)
         if (ng)
             hipLaunchKernelGGL(k_unpack_field, dim3((ng + 255) / 256), dim3(256), 0, c->stream, c->dist.ghost_dst.as<uint32_t>(), c->dist.n_ghost[0],
                                c->dist.n_ghost[1], words, c->dist.recv[0].as<float>(), c->dist.recv[1].as<float>(), field);
@@ -1463,6 +1482,7 @@ static int partition_and_migrate(Group& G, std::vector<Member>& M, std::vector<i
     }
     // (2) migrants: counts -> host and x-neighbours in one round trip, then the records
     std::vector<uint32_t> tl(nm), tr(nm), fl(nm), fr(nm);
+    std::vector<char> over(nm, 0);
     for (auto& m : M) m.c->hint_word = nullptr;
     if ((rc = G.comm->counts_round(G, 0, red, nullptr, tl, tr, fl, fr))) return rc;   // (a device failure here is fatal for the whole job)
     for (size_t i = 0; i < nm; i++) {
@@ -1478,9 +1498,10 @@ static int partition_and_migrate(Group& G, std::vector<Member>& M, std::vector<i
         auto& d = c->dist;
         (void)hipSetDevice(c->device);
         const uint32_t n_stay = d.counts_host[0];
-        if ((uint64_t)n_stay + fl[i] + fr[i] > c->cap)
-            return c->fail(SPH_ERR_CAPACITY, "slab of rank %d needs %llu particles, capacity %llu", d.rank,
-                                    (unsigned long long)n_stay + fl[i] + fr[i], (unsigned long long)c->cap);   // (this rank alone knows: not a collective exit, see DESIGN.md section 6 "Known limits")
+        if ((uint64_t)n_stay + fl[i] + fr[i] > c->cap) {   // the arrivals are received (the sizes are agreed) and dropped
+            slab_out_of_room(c, (unsigned long long)n_stay + fl[i] + fr[i]);
+            over[i] = 1;
+        }
         const int k = c->cur;
         const uint32_t base[2] = {n_stay, n_stay + tl[i]};
         const uint32_t cnt[2] = {tl[i], tr[i]};
@@ -1504,15 +1525,15 @@ static int partition_and_migrate(Group& G, std::vector<Member>& M, std::vector<i
         (void)hipSetDevice(c->device);
         const int k = c->cur;
         const uint32_t n_stay = d.counts_host[0];
-        const uint32_t cnt[2] = {fl[i], fr[i]};
-        const uint32_t base[2] = {n_stay, n_stay + fl[i]};
+        const uint32_t cnt[2] = {over[i] ? 0u : fl[i], over[i] ? 0u : fr[i]};
+        const uint32_t base[2] = {n_stay, n_stay + cnt[0]};
         for (int side = 0; side < 2; side++)
             if (cnt[side])
                 hipLaunchKernelGGL(k_unpack_migrants, dim3((cnt[side] + 255) / 256), dim3(256), 0, c->stream, base[side], cnt[side],
                                    d.recv[side].as<float>(), c->pm[c->pcur].as<float4>(), c->vel[k].as<float2>(), c->orig[k].as<uint32_t>(),
                                    c->lvl[k].as<float>(), c->lvlold[k].as<float>(), c->h2n[k].as<float>(), c->lam_sum.as<float>(),
                                    c->szc[k].as<uint8_t>());
-        c->n = n_stay + fl[i] + fr[i];
+        c->n = n_stay + cnt[0] + cnt[1];
         d.have_flags = false;
         d.n_tot = (uint32_t)c->n;
         M[i].n = (uint32_t)c->n;
@@ -1648,9 +1669,11 @@ static int build_ghost_layer(Group& G, std::vector<Member>& M, float halo_width,
         auto& d = c->dist;
         (void)hipSetDevice(c->device);
         const uint32_t n = (uint32_t)c->n;
-        if ((uint64_t)n + fl[i] + fr[i] > c->cap)
-            return c->fail(SPH_ERR_CAPACITY, "slab of rank %d + ghosts needs %llu particles, capacity %llu", d.rank,
-                                    (unsigned long long)n + fl[i] + fr[i], (unsigned long long)c->cap);   // (this rank alone knows: not a collective exit, see DESIGN.md section 6 "Known limits")
+        d.ghosts_ok = true;
+        if ((uint64_t)n + fl[i] + fr[i] > c->cap) {   // the ghost records are received and dropped: no ghost slots in this step
+            slab_out_of_room(c, (unsigned long long)n + fl[i] + fr[i]);
+            d.ghosts_ok = false;
+        }
         const uint32_t n_none = d.counts_host[4 + 0];
         d.n_halo[0] = tl[i];
         d.n_halo[1] = tr[i];
@@ -1680,12 +1703,12 @@ static int build_ghost_layer(Group& G, std::vector<Member>& M, float halo_width,
         const uint32_t n = (uint32_t)c->n;
         const uint32_t base[2] = {n, n + d.n_ghost[0]};
         for (int side = 0; side < 2; side++)
-            if (d.n_ghost[side])
+            if (d.n_ghost[side] && d.ghosts_ok)
                 hipLaunchKernelGGL(k_unpack_ghosts, dim3((d.n_ghost[side] + 255) / 256), dim3(256), 0, c->stream, base[side], d.n_ghost[side],
                                    d.recv[side].as<float>(), c->pm[c->pcur].as<float4>(), c->vel[k].as<float2>(), c->orig[k].as<uint32_t>(),
                                    c->lvl[k].as<float>(), c->lvlold[k].as<float>(), d.ring1_src.as<uint8_t>(), side == 0 ? 0u : d.n_ghost[0],
                                    side == 0 ? d.cut_lo - ring1_width : d.cut_hi + ring1_width, side);
-        d.n_tot = n + d.n_ghost[0] + d.n_ghost[1];
+        d.n_tot = d.ghosts_ok ? n + d.n_ghost[0] + d.n_ghost[1] : n;
         M[i].n = d.n_tot;
         // pre-sort index -> position in my halo list
         if (d.n_tot) (void)hipMemsetAsync(d.halo_pos.p, 0xff, (size_t)d.n_tot * 4, c->stream);
@@ -1753,15 +1776,21 @@ static int slab_refresh_fused(Group& G, std::vector<Member>& M, std::vector<std:
     const float halo_w = h_pred * halo_k, ring1_w = h_pred * 2.f;
 
     std::vector<Xfer> x(nm);
+    std::vector<char> over(nm, 0);
     for (size_t i = 0; i < nm; i++) {
         sph_ctx* c = M[i].c;
         auto& d = c->dist;
         const RefreshCounts& q = rcs[i];
         const uint32_t n_prev = n_prev_of[i];
         const uint64_t n_pre = (uint64_t)n_prev + q.in_mig[0] + q.in_mig[1] + q.in_halo[0] + q.mig[0] + q.in_halo[1] + q.mig[1];
-        if (n_pre > c->cap)
-            return c->fail(SPH_ERR_CAPACITY, "slab of rank %d + arrivals + ghosts needs %llu slots, capacity %llu", d.rank, (unsigned long long)n_pre,
-                                    (unsigned long long)c->cap);   // (this rank alone knows: not a collective exit, see DESIGN.md section 6 "Known limits")
+        d.ghosts_ok = true;
+        if (n_pre > c->cap) {
+            // no room: the rank keeps its previous slots, receives what was agreed and drops it (see slab_out_of_room)
+            (void)hipSetDevice(c->device);
+            slab_out_of_room(c, (unsigned long long)n_pre);
+            over[i] = 1;
+            d.ghosts_ok = false;
+        }
     }
     // ---- migrants
     for (size_t i = 0; i < nm; i++) {
@@ -1809,6 +1838,10 @@ static int slab_refresh_fused(Group& G, std::vector<Member>& M, std::vector<std:
         for (int side = 0; side < 2; side++) {
             const uint32_t cnt = q.in_mig[side];
             if (!cnt) continue;
+            if (over[i]) {   // dropped: their places in the halo list (the agreed length stays) name slot 0 -- in bounds, content irrelevant
+                hipLaunchKernelGGL(k_fill_u32, dim3((cnt + 255) / 256), dim3(256), 0, c->stream, d.halo_idx.as<uint32_t>() + hoff[side], cnt, 0u);
+                continue;
+            }
             hipLaunchKernelGGL(k_unpack_migrants, dim3((cnt + 255) / 256), dim3(256), 0, c->stream, base[side], cnt, d.recv[side].as<float>(),
                                c->pm[c->pcur].as<float4>(), c->vel[k].as<float2>(), c->orig[k].as<uint32_t>(), c->lvl[k].as<float>(),
                                c->lvlold[k].as<float>(), c->h2n[k].as<float>(), c->lam_sum.as<float>(), c->szc[k].as<uint8_t>());
@@ -1837,11 +1870,15 @@ static int slab_refresh_fused(Group& G, std::vector<Member>& M, std::vector<std:
         const uint32_t n_prev = n_prev_of[i];
         const uint32_t n_own_prev = (uint32_t)c->n;                         // owned slots of the previous arrays
         const uint32_t n_stay = n_own_prev - q.mig[0] - q.mig[1];
-        const uint32_t n_in = q.in_mig[0] + q.in_mig[1];
+        const uint32_t n_in = over[i] ? 0u : q.in_mig[0] + q.in_mig[1];
         const uint32_t own_end = n_prev + n_in;
         const uint32_t base[2] = {own_end, own_end + d.n_ghost[0]};
+        if (over[i]) {   // every entry of the halo map must name a slot that exists (the dropped arrivals' never get one)
+            const uint32_t nh_all = d.n_halo[0] + d.n_halo[1];
+            if (nh_all) (void)hipMemsetAsync(d.halo_src.p, 0, (size_t)nh_all * 4, c->stream);
+        }
         for (int side = 0; side < 2; side++)
-            if (d.n_ghost[side])
+            if (d.n_ghost[side] && d.ghosts_ok)
                 hipLaunchKernelGGL(k_unpack_ghosts, dim3((d.n_ghost[side] + 255) / 256), dim3(256), 0, c->stream, base[side], d.n_ghost[side],
                                    d.recv[side].as<float>(), c->pm[c->pcur].as<float4>(), c->vel[k].as<float2>(), c->orig[k].as<uint32_t>(),
                                    c->lvl[k].as<float>(), c->lvlold[k].as<float>(), d.ring1_src.as<uint8_t>(), side == 0 ? 0u : d.n_ghost[0],
@@ -1850,9 +1887,10 @@ static int slab_refresh_fused(Group& G, std::vector<Member>& M, std::vector<std:
         d.pre = true;
         d.pre_cls_n = n_prev;
         d.pre_own = own_end;
-        d.pre_n = own_end + d.n_ghost[0] + d.n_ghost[1];
+        const uint32_t ng_slots = d.ghosts_ok ? d.n_ghost[0] + d.n_ghost[1] : 0u;
+        d.pre_n = own_end + ng_slots;
         c->n = n_stay + n_in;
-        d.n_tot = (uint32_t)c->n + d.n_ghost[0] + d.n_ghost[1];
+        d.n_tot = (uint32_t)c->n + ng_slots;
         d.have_flags = false;
         M[i].n = d.n_tot;
         M[i].n_sort = d.pre_n;
@@ -2706,7 +2744,7 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
         for (auto& m : M) {
             sph_ctx* c = m.c;
             (void)hipSetDevice(c->device);
-            const uint32_t ng = c->dist.n_ghost[0] + c->dist.n_ghost[1];
+            const uint32_t ng = c->dist.ghosts_ok ? c->dist.n_ghost[0] + c->dist.n_ghost[1] : 0u;
             if (ng)
                 hipLaunchKernelGGL(k_ghost_mrho, dim3((ng + 255) / 256), dim3(256), 0, c->stream, c->dist.ghost_dst.as<uint32_t>(), ng, m.a.pm, m.a.rho,
                                    m.a.mrho);

@@ -166,7 +166,7 @@ class ThreadedGroup:
     (sph_thread_group_create / sph_comm_init_threads).  A collective that not every rank enters, ranks in different collectives or
     a send without a matching receive -- what would hang the RCCL transport -- comes back as an error."""
 
-    def __init__(self, lib: ffi.SphLibrary, pos, mass, vel, planes, n_ranks: int, device_id: int = 0):
+    def __init__(self, lib: ffi.SphLibrary, pos, mass, vel, planes, n_ranks: int, device_id: int = 0, capacities=None):
         import ctypes as C
         from concurrent.futures import ThreadPoolExecutor
         self.lib = lib
@@ -178,7 +178,8 @@ class ThreadedGroup:
         parts = partition(pos[:, 0], cuts)
         self.contexts = []
         for r in range(n_ranks):
-            c = ffi.Context(lib, _slab_capacity(len(mass), n_ranks), planes, device_id=device_id)
+            cap = capacities[r] if capacities is not None and capacities[r] else _slab_capacity(len(mass), n_ranks)
+            c = ffi.Context(lib, cap, planes, device_id=device_id)
             c.dist_configure(r, n_ranks, cuts[r], cuts[r + 1])
             c.comm_init_threads(self.group, r, n_ranks)
             c.upload(mass[parts[r]], pos[parts[r]], vel[parts[r]])

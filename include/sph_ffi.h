@@ -168,7 +168,7 @@ enum {
     SPH_OK = 0,
     SPH_ERR_INVALID_ARGUMENT = 1,
     SPH_ERR_DEVICE = 2,                 /* HIP / RCCL runtime failure */
-    SPH_ERR_CAPACITY = 3,               /* n > n_capacity */
+    SPH_ERR_CAPACITY = 3,               /* n > n_capacity; on slabs: owned + arrivals + ghosts do not fit (every rank's step fails together) */
     SPH_ERR_NO_BOUNDARY = 4,            /* boundary_handler/mod.rs:35-46 unimplemented!() */
     SPH_ERR_DENSITY_NOT_FINITE = 10,    /* sim.rs:1046 */
     SPH_ERR_DENSITY_TOO_SMALL = 11,     /* sim.rs:1047  density > 0.0001 */

@@ -589,9 +589,47 @@ def test_ranks_on_threads_fail_together(product_lib):
         thr.close()
 
 
+@pytest.mark.parametrize("which", ["first step", "one-round refresh"])
+def test_ranks_on_threads_capacity_failure_is_collective(product_lib, which):
+    """One rank of three (each on its own thread) has no room for what its neighbours hand it -- at the first step (two-round slab
+    maintenance: owned + ghosts do not fit) or at the second (one-round refresh: previous slots + arrivals + new ghosts do not fit,
+    although the first step's owned + ghosts did).  Every rank's sph_step returns an error within that step; nobody waits for a
+    collective the starved rank never enters."""
+    import time
+    scn = sc.dam_break_small(96, 48, 1 / 48)
+    pos, mass, vel = sc.init_particles(scn)
+    planes = sc.boundary_planes(scn.boundary)
+    p = dam_break_params().to_ffi()
+    probe = D.ThreadedGroup(product_lib, pos, mass, vel, planes, 3)
+    try:
+        probe.step(p)
+        st = probe.contexts[1].dist_get_stats()
+    finally:
+        probe.close()
+    owned, ghosts = st["n_owned"], sum(st["n_ghost"])
+    assert ghosts > 64
+    cap = owned + 8 if which == "first step" else owned + ghosts + ghosts // 2
+    thr = D.ThreadedGroup(product_lib, pos, mass, vel, planes, 3, capacities=[None, cap, None])
+    try:
+        if which != "first step":
+            thr.step(p)
+        t0 = time.perf_counter()
+        futs = [thr.pool.submit(c.step, p) for c in thr.contexts]
+        errs = []
+        for f in futs:
+            with pytest.raises(ffi.SphError) as e:
+                f.result()
+            errs.append(e.value.status)
+        assert time.perf_counter() - t0 < 30.0
+        assert errs[1] == 3 and all(e != 0 for e in errs), errs               # SPH_ERR_CAPACITY on the starved rank, its status on the others
+    finally:
+        thr.close()
+
+
 def test_a_slab_without_room_for_its_ghosts_says_so(product_lib):
     """Between the refresh and the cell sort a slab holds its previous slots, the arrivals and the new ghosts: a context that
-    cannot fit them returns SPH_ERR_CAPACITY (and is poisoned) -- it never writes past its arrays."""
+    cannot fit them ends the step in SPH_ERR_CAPACITY (and is poisoned) -- it never writes past its arrays, and it does not leave
+    the step alone: it receives what was agreed, drops it, raises the guard word, and every rank fails together at the step's end."""
     scn = sc.dam_break_small(96, 48, 1 / 48)
     pos, mass, vel = sc.init_particles(scn)
     planes = sc.boundary_planes(scn.boundary)
@@ -608,7 +646,7 @@ def test_a_slab_without_room_for_its_ghosts_says_so(product_lib):
     with pytest.raises(ffi.SphError) as e:
         for _ in range(3):
             ffi.group_step(grp, p)
-    assert e.value.status == 3 and "capacity" in str(e.value)          # SPH_ERR_CAPACITY
+    assert e.value.status == 3 and "room" in str(e.value)              # SPH_ERR_CAPACITY
     with pytest.raises(ffi.SphError):
         ffi.group_step(grp, p)                                          # poisoned until sph_upload
 
