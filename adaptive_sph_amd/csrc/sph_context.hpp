@@ -100,6 +100,12 @@ struct sph_ctx {
         uint32_t* counts_host = nullptr;       // mapped pinned
         uint32_t* counts_host_dev = nullptr;
         void* nccl = nullptr;        // ncclComm_t
+        // Split sweep A (sph_step.hip, exchange_and_sweep_a): the ghost exchange and the all-reduce of an iteration are queued on a
+        // stream of their own and run under the sweep over the particles that have no ghost in reach
+        DevBuf edge;                 // u8 per slot: 1 = halo member or ghost
+        hipStream_t xstream = nullptr;
+        hipEvent_t ev_x[3] = {nullptr, nullptr, nullptr};
+        hipStream_t xs = nullptr;    // the stream the transports queue on / wait for right now (nullptr: the context's main stream)
         bool ghosts_ok = true;       // false: this rank ran out of room for its ghost layer (the step goes on without it and ends in SPH_ERR_CAPACITY on every rank)
         void* tgroup = nullptr;      // ThreadGroup*: in-process transport with one host thread per rank (sph_comm_init_threads)
         int rebalance_every = 0;     // move the cuts to equal particle counts every so many steps (0: static cuts)

@@ -150,6 +150,12 @@ struct SweepArgs {
     float* partials;    // per-block solver statistics
     const uint8_t* owned;  // slab decomposition: 1 owned, 0 ghost (nullptr: everything is owned)
     const uint8_t* ring1;  // slab decomposition: 1 = ghost within one support radius of the cut (runs the RING1 ops)
+    // slab decomposition, split sweep (SweepCommon): 1 = halo member or ghost; the halo members' slots, the ghosts' slots
+    const uint8_t* edge = nullptr;
+    const uint32_t* elist_a = nullptr;
+    const uint32_t* elist_b = nullptr;
+    uint32_t n_ea = 0, n_eb = 0;
+    int part = 0;
     double* solver_tot; // multi-rank: all-reduced solver totals
     float* mrho;        // m / rho
     float* pt0;         // p / rho^2 for pressure buffer 0 / 1
@@ -178,7 +184,11 @@ void launch_aii_const_non_pressure(hipStream_t s, Profiler* prof, const SweepArg
 void launch_non_pressure(hipStream_t s, Profiler* prof, const SweepArgs& a);                // vel -> vel_tmp
 void launch_source_term(hipStream_t s, Profiler* prof, const SweepArgs& a, int kind, int residual_density);  // kind: 0 div, 1 full, 2 only-density; includes Jacobi iteration 0
 // sweep A of iteration iter >= 1 (+ the stop decision of iteration iter - 1, taken by its block 0); iter < 0: a^p from the solve's final pressures
-void launch_pressure_accel(hipStream_t s, Profiler* prof, const SweepArgs& a, int iter, int residual_density, float max_avg_error, uint32_t max_iters, int multi);
+// part (slab decomposition): 0 one launch; 1 the lanes without a ghost in reach; 2 the halo members and the ghosts (SweepCommon) --
+// with part != 0 the rank's totals come from launch_solver_totals instead of this sweep's block 0
+void launch_pressure_accel(hipStream_t s, Profiler* prof, const SweepArgs& a, int iter, int residual_density, float max_avg_error, uint32_t max_iters, int multi,
+                           int part = 0);
+void launch_solver_totals(hipStream_t s, Profiler* prof, const SweepArgs& a, int iter, int residual_density, float max_avg_error, uint32_t max_iters);
 void launch_ctrl_reset(hipStream_t s, SolverCtrl* ctrl, const uint32_t* gate);
 void launch_solver_handoff(hipStream_t s, Profiler* prof, SolverCtrl* ctrl, SolverCtrl* saved_host, uint32_t* gate);
 void launch_solver_tail(hipStream_t s, Profiler* prof, const SweepArgs& a, int tail, float4* pm_out, int decide_iter = -1, int residual_density = 0,

@@ -81,6 +81,13 @@ SweepArgs make_args(sph_ctx* c, const StepP& sp)
     a.status = c->status.as<DeviceStatus>();
     a.owned = c->dist.on ? c->dist.owned.as<uint8_t>() : nullptr;
     a.ring1 = c->dist.on ? c->dist.ring1.as<uint8_t>() : nullptr;
+    if (c->dist.on) {
+        a.edge = c->dist.edge.as<uint8_t>();
+        a.elist_a = c->dist.halo_src.as<uint32_t>();
+        a.n_ea = c->dist.n_halo[0] + c->dist.n_halo[1];
+        a.elist_b = c->dist.ghost_dst.as<uint32_t>();
+        a.n_eb = c->dist.ghosts_ok ? c->dist.n_ghost[0] + c->dist.n_ghost[1] : 0u;
+    }
     a.solver_tot = c->dist.solver_tot.as<double>();
     return a;
 }
@@ -138,6 +145,18 @@ int wait_stream(sph_ctx* c)
         if ((spins & 0xfffu) == 0xfffu && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 120.0)
             return c->fail(SPH_ERR_DEVICE, "device did not finish the queued work within 120 s");
     }
+}
+
+// the stream the transports use right now (Dist::xs): the context's main stream, or the stream of the collectives while a
+// split sweep is being queued -- then the wait leaves the main stream alone (the sweep over the interior is running there)
+static hipStream_t xs_of(sph_ctx* c) { return c->dist.xs ? c->dist.xs : c->stream; }
+static int wait_xs(sph_ctx* c)
+{
+    if (!c->dist.xs || c->dist.xs == c->stream) return wait_stream(c);
+    c->n_waits++;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->dist.xs));
+    return SPH_OK;
 }
 
 // Wait for the k_publish just queued: its sequence number arrives in mapped host memory as the kernel's last store, behind
@@ -412,6 +431,13 @@ __global__ __launch_bounds__(256) void k_halo_pos(const uint32_t* __restrict__ h
 // after the cell sort: where did my halo particles and my ghosts end up?  perm[s] = pre-sort index of slot s
 // `cls` (fused refresh, else nullptr): halo_pos is only defined for the halo members then -- slots whose class byte says so and the
 // arrivals behind the n_cls previous slots -- and nothing had to clear the rest of it
+__global__ void k_edge_mark(const uint32_t* __restrict__ halo_src, uint32_t nh, const uint32_t* __restrict__ ghost_dst, uint32_t ng, uint8_t* __restrict__ edge)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < nh) edge[halo_src[t]] = 1;
+    else if (t < nh + ng) edge[ghost_dst[t - nh]] = 1;
+}
+
 __global__ __launch_bounds__(256) void k_build_maps(uint32_t n_tot, uint32_t n_own, const uint32_t* __restrict__ perm,
                                                      const uint32_t* __restrict__ halo_pos, uint32_t* __restrict__ halo_src,
                                                      uint32_t* __restrict__ ghost_dst, uint8_t* __restrict__ owned, const uint8_t* __restrict__ ring1_src,
@@ -720,6 +746,30 @@ static int wait_all(Group& G)
     return SPH_OK;
 }
 
+static int wait_all_xs(Group& G)   // on the streams the transports use right now (wait_xs)
+{
+    for (auto c : G.m) {
+        int rc = wait_xs(c);
+        if (rc) return rc;
+    }
+    return SPH_OK;
+}
+
+// Measurement hook of the loopback transport (scripts/gpu_split_sweep_timing.py): SPH_DEBUG_COMM_DELAY_US=<us> makes every ghost
+// exchange and every all-reduce of the solver totals occupy its stream for that long before it completes -- a stand-in for the
+// latency of a collective between GPUs, which one GPU cannot produce
+__global__ void k_spin_us(uint32_t us)
+{
+    const uint64_t t0 = wall_clock64();   // 100 MHz
+    while (wall_clock64() - t0 < (uint64_t)us * 100ull) __builtin_amdgcn_s_sleep(16);
+}
+static void debug_comm_delay(sph_ctx* c)
+{
+    const char* e = getenv("SPH_DEBUG_COMM_DELAY_US");
+    const int us = e ? atoi(e) : 0;
+    if (us > 0) hipLaunchKernelGGL(k_spin_us, dim3(1), dim3(1), 0, xs_of(c), (uint32_t)us);
+}
+
 // ---- loopback: all ranks are contexts of this process ---------------------------------------------
 struct LocalComm : Comm {
     bool host_collectives_wait() const override { return false; }   // plain host arithmetic on values the caller already has
@@ -761,7 +811,8 @@ struct LocalComm : Comm {
     }
     int exchange(Group& G, std::vector<Xfer>& x) override
     {
-        int rc = wait_all(G);
+        for (auto c : G.m) debug_comm_delay(c);
+        int rc = wait_all_xs(G);
         if (rc) return rc;
         const size_t n = G.m.size();
         // the RCCL transport pairs every ncclSend with an ncclRecv of the same size: hold the loopback to the same rule,
@@ -779,10 +830,10 @@ struct LocalComm : Comm {
             c->dist.stat_bytes_sent += x[i].send_bytes[0] + x[i].send_bytes[1];
             c->dist.stat_bytes_recv += x[i].recv_bytes[0] + x[i].recv_bytes[1];
             HIPCHK(c, hipSetDevice(c->device));
-            if (i > 0 && x[i].recv_bytes[0]) HIPCHK(c, hipMemcpyAsync(x[i].recv[0], x[i - 1].send[1], x[i].recv_bytes[0], hipMemcpyDefault, c->stream));
-            if (i + 1 < n && x[i].recv_bytes[1]) HIPCHK(c, hipMemcpyAsync(x[i].recv[1], x[i + 1].send[0], x[i].recv_bytes[1], hipMemcpyDefault, c->stream));
+            if (i > 0 && x[i].recv_bytes[0]) HIPCHK(c, hipMemcpyAsync(x[i].recv[0], x[i - 1].send[1], x[i].recv_bytes[0], hipMemcpyDefault, xs_of(c)));
+            if (i + 1 < n && x[i].recv_bytes[1]) HIPCHK(c, hipMemcpyAsync(x[i].recv[1], x[i + 1].send[0], x[i].recv_bytes[1], hipMemcpyDefault, xs_of(c)));
         }
-        return wait_all(G);  // senders may reuse their staging buffers afterwards
+        return wait_all_xs(G);  // senders may reuse their staging buffers afterwards
     }
     int counts_round(Group& G, int base, std::vector<std::vector<float>>* red, int* status, std::vector<uint32_t>& tl, std::vector<uint32_t>& tr,
                      std::vector<uint32_t>& fl, std::vector<uint32_t>& fr) override
@@ -829,7 +880,8 @@ struct LocalComm : Comm {
     int agree_guards_queued(Group&) override { return SPH_OK; }   // one process: sync_ctrl sees every member's guard word
     int allreduce_solver(Group& G, int slot) override
     {
-        int rc = wait_all(G);
+        for (auto c : G.m) debug_comm_delay(c);
+        int rc = wait_all_xs(G);
         if (rc) return rc;
         double tot[6] = {0, 0, 0, 0, 0, 0};
         std::vector<std::array<double, 6>> rows(G.m.size());
@@ -1041,15 +1093,15 @@ struct RcclComm : Comm {
         c->dist.stat_exchanges++;
         c->dist.stat_bytes_sent += (r > 0 ? x[0].send_bytes[0] : 0) + (r + 1 < nr ? x[0].send_bytes[1] : 0);
         c->dist.stat_bytes_recv += (r > 0 ? x[0].recv_bytes[0] : 0) + (r + 1 < nr ? x[0].recv_bytes[1] : 0);
-        ProfScope ps(&c->prof, "rccl_sendrecv", c->stream);
+        ProfScope ps(&c->prof, "rccl_sendrecv", xs_of(c));
         NCCLCHK(c, ncclGroupStart());
         if (r > 0) {
-            if (x[0].send_bytes[0]) NCCLCHK(c, ncclSend(x[0].send[0], x[0].send_bytes[0], ncclChar, r - 1, nc, c->stream));
-            if (x[0].recv_bytes[0]) NCCLCHK(c, ncclRecv(x[0].recv[0], x[0].recv_bytes[0], ncclChar, r - 1, nc, c->stream));
+            if (x[0].send_bytes[0]) NCCLCHK(c, ncclSend(x[0].send[0], x[0].send_bytes[0], ncclChar, r - 1, nc, xs_of(c)));
+            if (x[0].recv_bytes[0]) NCCLCHK(c, ncclRecv(x[0].recv[0], x[0].recv_bytes[0], ncclChar, r - 1, nc, xs_of(c)));
         }
         if (r + 1 < nr) {
-            if (x[0].send_bytes[1]) NCCLCHK(c, ncclSend(x[0].send[1], x[0].send_bytes[1], ncclChar, r + 1, nc, c->stream));
-            if (x[0].recv_bytes[1]) NCCLCHK(c, ncclRecv(x[0].recv[1], x[0].recv_bytes[1], ncclChar, r + 1, nc, c->stream));
+            if (x[0].send_bytes[1]) NCCLCHK(c, ncclSend(x[0].send[1], x[0].send_bytes[1], ncclChar, r + 1, nc, xs_of(c)));
+            if (x[0].recv_bytes[1]) NCCLCHK(c, ncclRecv(x[0].recv[1], x[0].recv_bytes[1], ncclChar, r + 1, nc, xs_of(c)));
         }
         NCCLCHK(c, ncclGroupEnd());
         return SPH_OK;
@@ -1058,9 +1110,9 @@ struct RcclComm : Comm {
     {
         sph_ctx* c = G.m[0];
         c->dist.stat_allreduces++;
-        ProfScope ps(&c->prof, "rccl_allreduce", c->stream);
+        ProfScope ps(&c->prof, "rccl_allreduce", xs_of(c));
         double* t = c->dist.solver_tot.as<double>() + 8 * slot;
-        NCCLCHK(c, ncclAllReduce(t, t, 6, ncclFloat64, ncclSum, (ncclComm_t)c->dist.nccl, c->stream));
+        NCCLCHK(c, ncclAllReduce(t, t, 6, ncclFloat64, ncclSum, (ncclComm_t)c->dist.nccl, xs_of(c)));
         return SPH_OK;
     }
 };
@@ -1230,7 +1282,7 @@ struct ThreadComm : Comm {
     {
         sph_ctx* c = G.m[0];
         c->dist.stat_exchanges++;
-        int rc = wait_stream(c);   // my staging buffers are packed
+        int rc = wait_xs(c);   // my staging buffers are packed
         if (rc) {
             grp(G)->abandon();
             return rc;
@@ -1248,16 +1300,16 @@ struct ThreadComm : Comm {
                                            L.recv_bytes[1], R.recv_bytes[0]);
                         c->dist.stat_bytes_sent += x[0].send_bytes[0] + x[0].send_bytes[1];
                         c->dist.stat_bytes_recv += x[0].recv_bytes[0] + x[0].recv_bytes[1];
-                        if (x[0].recv_bytes[0]) HIPCHK(c, hipMemcpyAsync(x[0].recv[0], L.send[1], x[0].recv_bytes[0], hipMemcpyDefault, c->stream));
-                        if (x[0].recv_bytes[1]) HIPCHK(c, hipMemcpyAsync(x[0].recv[1], R.send[0], x[0].recv_bytes[1], hipMemcpyDefault, c->stream));
-                        return wait_stream(c);   // (the senders may reuse their staging buffers once everybody is past the closing barrier)
+                        if (x[0].recv_bytes[0]) HIPCHK(c, hipMemcpyAsync(x[0].recv[0], L.send[1], x[0].recv_bytes[0], hipMemcpyDefault, xs_of(c)));
+                        if (x[0].recv_bytes[1]) HIPCHK(c, hipMemcpyAsync(x[0].recv[1], R.send[0], x[0].recv_bytes[1], hipMemcpyDefault, xs_of(c)));
+                        return wait_xs(c);   // (the senders may reuse their staging buffers once everybody is past the closing barrier)
                     });
     }
     int allreduce_solver(Group& G, int slot) override
     {
         sph_ctx* c = G.m[0];
         c->dist.stat_allreduces++;
-        int rc = wait_stream(c);
+        int rc = wait_xs(c);
         if (rc) {
             grp(G)->abandon();
             return rc;
@@ -1428,6 +1480,11 @@ static int ensure_dist_buffers(sph_ctx* c, uint32_t n)
     }
     HIPCHK(c, d.solver_tot.ensure(128));   // two slots of 6 doubles (chained solves)
     HIPCHK(c, d.cls.ensure(cap));
+    HIPCHK(c, d.edge.ensure(cap));
+    if (!d.xstream) {
+        HIPCHK(c, hipStreamCreateWithFlags(&d.xstream, hipStreamNonBlocking));
+        for (auto& e : d.ev_x) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
     HIPCHK(c, d.blk.ensure(((cap + 255) / 256) * 8 * sizeof(uint32_t)));
     if (!d.counts_host) {
         HIPCHK(c, hipHostMalloc((void**)&d.counts_host, 256, hipHostMallocMapped));   // 64 B of counters + 192 B of staging
@@ -1946,12 +2003,97 @@ static int solve_sweep_a(Group& G, std::vector<Member>& M, const SolveQ& q, uint
     if (multi) return G.comm->allreduce_solver(G, q.tot_slot);
     return SPH_OK;
 }
+// Slab decomposition with neighbours: sweep A in two launches around the iteration's communication.  On the main stream: pack the
+// halo members' p / rho^2, sweep A over the particles that have no ghost in reach (most of the slab), then -- once the ghosts
+// arrived -- sweep A over the halo members and the first ghost ring (a list launch, a few per cent of the slab), then -- once the
+// totals are all-reduced -- whatever follows (sweep B takes the decision from them).  On the stream of the collectives, behind the
+// pack: the exchange, the unpack, this rank's totals of the previous iteration (k_solver_totals: what block 0 of the unsplit sweep
+// adds up) and their all-reduce.  Same collectives in the same order as the unsplit form, same arithmetic per particle.
+// SPH_OVERLAP=0 keeps the unsplit form.
+static bool split_sweep_a(const Group& G)
+{
+    const char* e = getenv("SPH_OVERLAP");   // (read per call: the tests switch it between two runs of one process)
+    const int env = e ? atoi(e) : 1;
+    return env != 0 && G.comm != nullptr && G.m[0]->dist.nranks > 1 && G.m[0]->dist.xstream != nullptr;
+}
+struct XsScope {   // the transports queue on / wait for the members' collective streams while this lives
+    Group& G;
+    explicit XsScope(Group& g) : G(g)
+    {
+        for (auto c : G.m) c->dist.xs = c->dist.xstream;
+    }
+    ~XsScope()
+    {
+        for (auto c : G.m) c->dist.xs = nullptr;
+    }
+};
+// the ghosts' p / rho^2 of pressure buffer ka & 1, sweep A(ka), and the all-reduce of iteration ka - 1's totals
+static int exchange_and_sweep_a(Group& G, std::vector<Member>& M, const SolveQ& q, uint32_t ka)
+{
+    int rc;
+    float* (*sel)(Member&) = (ka & 1u) ? sel_pt1 : sel_pt0;
+    if (!split_sweep_a(G)) {
+        if ((rc = refresh_ghosts(G, M, sel, 1, "pt"))) return rc;
+        return solve_sweep_a(G, M, q, ka);
+    }
+    std::vector<Xfer> x(M.size());
+    for (size_t i = 0; i < M.size(); i++) {
+        sph_ctx* c = M[i].c;
+        auto& d = c->dist;
+        (void)hipSetDevice(c->device);
+        const uint32_t nh = d.n_halo[0] + d.n_halo[1];
+        {
+            ProfScope ps(&c->prof, "ghost_pack", c->stream);
+            if (nh)
+                hipLaunchKernelGGL(k_pack_field, dim3((nh + 255) / 256), dim3(256), 0, c->stream, d.halo_src.as<uint32_t>(), d.n_halo[0], d.n_halo[1], 1, sel(M[i]),
+                                   d.send[0].as<float>(), d.send[1].as<float>());
+        }
+        for (int side = 0; side < 2; side++) {
+            x[i].send[side] = d.send[side].p;
+            x[i].send_bytes[side] = (size_t)d.n_halo[side] * 4;
+            x[i].recv[side] = d.recv[side].p;
+            x[i].recv_bytes[side] = (size_t)d.n_ghost[side] * 4;
+        }
+        HIPCHK(c, hipEventRecord(d.ev_x[0], c->stream));
+        HIPCHK(c, hipStreamWaitEvent(d.xstream, d.ev_x[0], 0));
+        if (M[i].n) launch_pressure_accel(c->stream, &c->prof, M[i].a, (int)ka, q.residual_density, q.max_avg_error, q.max_iters, 1, 1);
+    }
+    {
+        XsScope scope(G);
+        if ((rc = G.comm->exchange(G, x))) return rc;
+        for (size_t i = 0; i < M.size(); i++) {
+            sph_ctx* c = M[i].c;
+            auto& d = c->dist;
+            (void)hipSetDevice(c->device);
+            const uint32_t ng = d.ghosts_ok ? d.n_ghost[0] + d.n_ghost[1] : 0u;   // (no ghost slots: received, dropped)
+            {
+                ProfScope ps(&c->prof, "ghost_unpack", d.xstream);
+                if (ng)
+                    hipLaunchKernelGGL(k_unpack_field, dim3((ng + 255) / 256), dim3(256), 0, d.xstream, d.ghost_dst.as<uint32_t>(), d.n_ghost[0], d.n_ghost[1], 1,
+                                       d.recv[0].as<float>(), d.recv[1].as<float>(), sel(M[i]));
+            }
+            HIPCHK(c, hipEventRecord(d.ev_x[1], d.xstream));
+            if (M[i].n) launch_solver_totals(d.xstream, &c->prof, M[i].a, (int)ka - 1, q.residual_density, q.max_avg_error, q.max_iters);
+            else HIPCHK(c, hipMemsetAsync(d.solver_tot.as<double>() + 8 * q.tot_slot, 0, 48, d.xstream));   // an empty slab contributes zeros
+        }
+        if ((rc = G.comm->allreduce_solver(G, q.tot_slot))) return rc;
+    }
+    for (size_t i = 0; i < M.size(); i++) {
+        sph_ctx* c = M[i].c;
+        auto& d = c->dist;
+        (void)hipSetDevice(c->device);
+        HIPCHK(c, hipEventRecord(d.ev_x[2], d.xstream));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, d.ev_x[1], 0));
+        if (M[i].n) launch_pressure_accel(c->stream, &c->prof, M[i].a, (int)ka, q.residual_density, q.max_avg_error, q.max_iters, 1, 2);
+        HIPCHK(c, hipStreamWaitEvent(c->stream, d.ev_x[2], 0));
+    }
+    return SPH_OK;
+}
 static int solve_begin(Group& G, std::vector<Member>& M, SolveQ& q, uint32_t predicted_iters)
 {
     int rc;
     // iteration 0 wrote pressure buffer 1
-    if ((rc = refresh_ghosts(G, M, sel_pt1, 1, "pt"))) return rc;
-    if ((rc = solve_sweep_a(G, M, q, 1))) return rc;
+    if ((rc = exchange_and_sweep_a(G, M, q, 1))) return rc;
     q.k = 1;
     q.upto = predicted_iters > 2 ? predicted_iters : 2;
     return SPH_OK;
@@ -1972,8 +2114,7 @@ static int solve_queue(Group& G, std::vector<Member>& M, SolveQ& q, bool handoff
             else if (multi) launch_solver_decide(m.c->stream, &m.c->prof, m.a, (int)k - 1, q.residual_density, q.max_avg_error, q.max_iters);   // an empty slab has no sweep B to take it
         }
         // (no exchange of a^p: the first ghost ring computes its own in sweep A)
-        if ((rc = refresh_ghosts(G, M, ((k + 1) & 1) ? sel_pt1 : sel_pt0, 1, "pt"))) return rc;
-        if ((rc = solve_sweep_a(G, M, q, k + 1))) return rc;
+        if ((rc = exchange_and_sweep_a(G, M, q, k + 1))) return rc;
     }
     // slab decomposition: the last queued sweep A(k) left the totals of iteration k - 1 behind; the decision on them is taken by
     // the tail itself (every block, from the all-reduced totals), or by a launch of its own where no tail follows
@@ -2321,6 +2462,15 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
                 hipLaunchKernelGGL(k_build_maps, dim3((n + 255) / 256), dim3(256), 0, s, n, pre ? d.pre_own : (uint32_t)c->n, c->val[0].as<uint32_t>(),
                                    d.halo_pos.as<uint32_t>(), d.halo_src.as<uint32_t>(), d.ghost_dst.as<uint32_t>(), d.owned.as<uint8_t>(),
                                    d.ring1_src.as<uint8_t>(), d.ring1.as<uint8_t>(), pre ? d.cls.as<uint8_t>() : (const uint8_t*)nullptr, pre ? d.pre_cls_n : 0u);
+            // split sweep A: the slots whose pressure acceleration reads a ghost (the halo members: every owned particle with a ghost
+            // in reach is one) or is one
+            if (n && d.nranks > 1) {
+                HIPCHK(c, hipMemsetAsync(d.edge.p, 0, n, s));
+                const uint32_t nh = d.n_halo[0] + d.n_halo[1], ng = d.ghosts_ok ? d.n_ghost[0] + d.n_ghost[1] : 0u;
+                if (nh + ng)
+                    hipLaunchKernelGGL(k_edge_mark, dim3((nh + ng + 255) / 256), dim3(256), 0, s, d.halo_src.as<uint32_t>(), nh, d.ghost_dst.as<uint32_t>(), ng,
+                                       d.edge.as<uint8_t>());
+            }
             d.have_flags = true;
         }
         if (tev) (void)hipEventRecord(c->ev[1], s);
@@ -3175,8 +3325,17 @@ void dist_release(sph_ctx* c)
     auto& d = c->dist;
     if (d.nccl) ncclCommDestroy((ncclComm_t)d.nccl);
     d.nccl = nullptr;
-    DevBuf* all[] = {&d.owned, &d.ring1, &d.ring1_src, &d.halo_idx, &d.halo_pos, &d.halo_src, &d.ghost_dst, &d.send[0], &d.send[1], &d.recv[0], &d.recv[1], &d.counts, &d.solver_tot, &d.hist, &d.cls, &d.blk};
+    DevBuf* all[] = {&d.owned, &d.ring1, &d.ring1_src, &d.halo_idx, &d.halo_pos, &d.halo_src, &d.ghost_dst, &d.send[0], &d.send[1], &d.recv[0], &d.recv[1], &d.counts, &d.solver_tot, &d.hist, &d.cls, &d.blk, &d.edge};
     for (auto b : all) b->release();
+    if (d.xstream) {
+        (void)hipStreamSynchronize(d.xstream);
+        (void)hipStreamDestroy(d.xstream);
+    }
+    d.xstream = d.xs = nullptr;
+    for (auto& e : d.ev_x) {
+        if (e) (void)hipEventDestroy(e);
+        e = nullptr;
+    }
     if (d.counts_host) (void)hipHostFree(d.counts_host);
     d.counts_host = nullptr;
 }

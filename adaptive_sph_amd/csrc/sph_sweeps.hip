@@ -74,6 +74,13 @@ struct SweepCommon {
     uint4* __restrict__ nlx;   // explicit index lists (nullptr in uniform scenes)
     const uint8_t* __restrict__ owned;  // slab decomposition: ghost lanes idle (their values come from their owner)
     const uint8_t* __restrict__ ring1;  // ... except, in RING1 ops, the ghosts within one support radius of the cut
+    // slab decomposition, a sweep in two launches (the ghost exchange runs under the first): part 1 = every lane whose `edge`
+    // byte is 0 (owned, no ghost within reach); part 2 = the listed slots (the halo members, then the ghosts); 0 = one launch
+    int part;
+    const uint8_t* __restrict__ edge;
+    const uint32_t* __restrict__ elist_a;
+    const uint32_t* __restrict__ elist_b;
+    uint32_t n_ea, n_eb;
 };
 
 __device__ __forceinline__ void raise_error(DeviceStatus* st, uint32_t code, uint32_t info)
@@ -429,7 +436,8 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_sweep(Op op, SweepCommon c)
     const uint32_t per_xcd = (c.nblocks + 7) >> 3;
     const uint32_t blk = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
     if (blk >= c.nblocks) return;
-    const uint32_t i = blk * SWEEP_THREADS + threadIdx.x;
+    uint32_t i = blk * SWEEP_THREADS + threadIdx.x;
+    if (c.part == 2) i = i < c.n_ea ? c.elist_a[i] : (i < c.n_ea + c.n_eb ? c.elist_b[i - c.n_ea] : c.n);   // (launch-uniform test)
     const uint32_t ic = i < c.n ? i : 0;
     // slab decomposition: the record and the list word are requested together with the flags (one memory round trip at the head
     // of every wave instead of two); otherwise only by the lanes that have work (level-set propagation skips most)
@@ -441,7 +449,7 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_sweep(Op op, SweepCommon c)
         if (!BUILD) lw = c.nl[ic];
     }
     const bool mine = !slab || c.owned[ic] || (OpRing1<Op>::value && c.ring1 && c.ring1[ic]);
-    const bool active = i < c.n && mine && !op.lane_skip(i);
+    const bool active = i < c.n && mine && !op.lane_skip(i) && !(c.part == 1 && c.edge[ic]);
     typename Op::Acc acc;
     op.init(acc);  // lane-independent state
     if (active) {
@@ -1146,6 +1154,7 @@ struct SolveP {
     float max_avg_error;
     uint32_t max_iters;
     int multi;   // slab decomposition: block 0 only adds up this rank's totals; the decision follows the all-reduce (k_solver_decide)
+                 // 2: ... and not even that -- k_solver_totals did, on the stream of the collectives (split sweep A)
 };
 
 // stopping rule of iisph_pressure_iterations (simulation.rs:1453-1479) for iteration `iter`
@@ -1291,7 +1300,7 @@ struct OpPressureAccel {
             if (raw_block == 0u && threadIdx.x == 0 && !solve.multi) ctrl->slot_done[iter & 1] = 1u;
             return true;
         }
-        if (raw_block == 0u) solver_reduce_decide(partials, nparts, ctrl, tot, iter - 1, solve, sp.rest_density, sp.dt, status);
+        if (raw_block == 0u && solve.multi != 2) solver_reduce_decide(partials, nparts, ctrl, tot, iter - 1, solve, sp.rest_density, sp.dt, status);
         return false;
     }
     __device__ bool lane_skip(uint32_t) const { return false; }
@@ -2308,7 +2317,8 @@ __global__ __launch_bounds__(256) void k_integrate(uint32_t n, float dt, float v
 // ------------------------------------------------------------------------------------------------
 static SweepCommon common_of(const SweepArgs& a, bool ext)
 {
-    return SweepCommon{a.g, ext ? a.t_ext : a.t, a.n, (a.n + SWEEP_THREADS - 1) / SWEEP_THREADS, a.cell_start, ext ? a.nl_ext : a.nl, ext ? a.nlx_ext : a.nlx, a.owned, a.ring1};
+    return SweepCommon{a.g, ext ? a.t_ext : a.t, a.n, (a.n + SWEEP_THREADS - 1) / SWEEP_THREADS, a.cell_start, ext ? a.nl_ext : a.nl, ext ? a.nlx_ext : a.nlx, a.owned, a.ring1,
+                       0, nullptr, nullptr, nullptr, 0u, 0u};
 }
 
 // SPH_TILE: bit 0 = the BUILD sweep (density), bit 1 = the replay sweeps through the LDS-staged form (k_sweep_tile) in
@@ -2333,6 +2343,19 @@ template <class Op, bool BUILD>
 static void launch_sweep(hipStream_t s, const SweepArgs& a, const Op& op)
 {
     if (a.n == 0) return;
+    if (a.part) {   // one of the two launches of a split sweep (slab decomposition, sph_step.hip)
+        SweepCommon c = common_of(a, Op::EXTENDED);
+        c.part = a.part;
+        c.edge = a.edge;
+        c.elist_a = a.elist_a;
+        c.elist_b = a.elist_b;
+        c.n_ea = a.n_ea;
+        c.n_eb = a.n_eb;
+        if (a.part == 2) c.nblocks = (a.n_ea + a.n_eb + SWEEP_THREADS - 1) / SWEEP_THREADS;
+        if (c.nblocks == 0) c.nblocks = 1;   // (the launch's prologue still runs)
+        hipLaunchKernelGGL((k_sweep<Op, BUILD>), dim3(((c.nblocks + 7) / 8) * 8), dim3(SWEEP_THREADS), 0, s, op, c);
+        return;
+    }
     const uint32_t nblocks = (a.n + SWEEP_THREADS - 1) / SWEEP_THREADS;
     const uint32_t grid = ((nblocks + 7) / 8) * 8;  // XCD remap needs a multiple of 8
     if constexpr (Op::Math::UNIFORM && !Op::EXTENDED && OpTile<Op>::value) {
@@ -2469,12 +2492,32 @@ void launch_source_term(hipStream_t s, Profiler* prof, const SweepArgs& a, int k
                  (SolverPartial*)a.partials, a.ctrl, a.status, a.sp, kind, residual_density, nullptr, nullptr, a.gate)
 }
 
-void launch_pressure_accel(hipStream_t s, Profiler* prof, const SweepArgs& a, int iter, int residual_density, float max_avg_error, uint32_t max_iters, int multi)
+void launch_pressure_accel(hipStream_t s, Profiler* prof, const SweepArgs& a0, int iter, int residual_density, float max_avg_error, uint32_t max_iters, int multi,
+                           int part)
 {
-    ProfScope ps(prof, "pressure_accel", s);
-    const SolveP q{residual_density, max_avg_error, max_iters, multi};
+    ProfScope ps(prof, part == 2 ? "pressure_accel_edge" : "pressure_accel", s);
+    SweepArgs a = a0;
+    a.part = part;
+    const SolveP q{residual_density, max_avg_error, max_iters, part ? 2 : multi};
     SPH_DISPATCH(OpPressureAccel, false, a.pm, a.orig, a.rho, a.p0, a.p1, a.pt0, a.pt1, a.lam_grad, a.pacc, a.ctrl, (const SolverPartial*)a.partials,
                  solver_reduce_blocks(a.n), a.solver_tot, a.status, a.sp, q, iter, a.owned, a.gate)
+}
+
+// Split sweep A (slab decomposition with neighbours): this rank's totals of iteration `iter` -- what block 0 of the unsplit sweep
+// A(iter + 1) adds up -- by a launch of its own on the stream of the collectives, so that the all-reduce runs under the sweep.
+__global__ __launch_bounds__(SWEEP_THREADS) void k_solver_totals(const SolverPartial* __restrict__ partials, uint32_t nparts, SolverCtrl* ctrl,
+                                                                 double* __restrict__ tot, int iter, SolveP q, float rest_density, float dt,
+                                                                 const DeviceStatus* status, const uint32_t* __restrict__ gate)
+{
+    if (gate && *gate == 0u) return;
+    if (ctrl->slot_done[iter & 1] != 0u) return;   // the solve ended before: the totals are stale, nobody reads them (solver_decide_multi)
+    solver_reduce_decide(partials, nparts, ctrl, tot, iter, q, rest_density, dt, status);
+}
+void launch_solver_totals(hipStream_t s, Profiler* prof, const SweepArgs& a, int iter, int residual_density, float max_avg_error, uint32_t max_iters)
+{
+    ProfScope ps(prof, "solver_totals", s);
+    hipLaunchKernelGGL(k_solver_totals, dim3(1), dim3(SWEEP_THREADS), 0, s, (const SolverPartial*)a.partials, solver_reduce_blocks(a.n), a.ctrl, a.solver_tot, iter,
+                       SolveP{residual_density, max_avg_error, max_iters, 2}, a.sp.rest_density, a.sp.dt, a.status, a.gate);
 }
 
 void launch_solver_tail(hipStream_t s, Profiler* prof, const SweepArgs& a, int tail, float4* pm_out, int decide_iter, int residual_density,

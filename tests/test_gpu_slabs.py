@@ -589,6 +589,47 @@ def test_ranks_on_threads_fail_together(product_lib):
         thr.close()
 
 
+@pytest.mark.parametrize("transport", ["loopback", "threads"])
+@pytest.mark.parametrize("solver,extra", [("HybridDFSPH", {}), ("IISPH", {}), ("OnlyDivergence", {}), ("IISPH2", dict(max_dt=0.0005))])
+def test_split_sweep_a_is_bit_identical_to_the_unsplit_form(product_lib, monkeypatch, transport, solver, extra):
+    """Slabs with neighbours run sweep A of every Jacobi iteration in two launches -- the particles without a ghost in reach while the
+    ghost exchange and the all-reduce of the totals run on a stream of their own, the halo members and the first ghost ring once
+    the ghosts arrived.  SPH_OVERLAP=0 keeps the one-launch form with everything on one stream: same particles, same arithmetic,
+    same decisions -- every field bit for bit, and the split form really ran (its list launch shows up in the profile)."""
+    scn = sc.dam_break_small(96, 48, 1 / 48)
+    pos, mass, vel = sc.init_particles(scn)
+    vel = vel.copy()
+    vel[:, 0] = 0.8
+    planes = sc.boundary_planes(scn.boundary)
+    p = dam_break_params(pressure_solver_method=solver, **extra).to_ffi()
+    runs = {}
+    for name in ("split", "unsplit"):
+        if name == "unsplit":
+            monkeypatch.setenv("SPH_OVERLAP", "0")
+        thr = None
+        if transport == "threads":
+            thr = D.ThreadedGroup(product_lib, pos, mass, vel, planes, 3)
+            grp, step = thr.contexts, (lambda: thr.step(p))
+        else:
+            grp = D.make_loopback_group(product_lib, pos, mass, vel, planes, 3)
+            step = (lambda: ffi.group_step(grp, p))
+        try:
+            grp[1].profile_enable(1)
+            stats = [step() for _ in range(12)]
+            prof = grp[1].profile_get()
+            assert ("pressure_accel_edge" in prof) == (name == "split") and ("solver_totals" in prof) == (name == "split")
+            runs[name] = ([(x.dt, x.div_solver.iters, x.density_solver.iters) for st in stats for x in st],
+                          [{f: c.download(f) for f in ("particle_id", "position", "velocity", "density", "pressure")} for c in grp])
+        finally:
+            if thr:
+                thr.close()
+    monkeypatch.delenv("SPH_OVERLAP")
+    assert runs["split"][0] == runs["unsplit"][0]
+    for a, b in zip(runs["split"][1], runs["unsplit"][1]):
+        for f in a:
+            assert np.array_equal(a[f], b[f]), f
+
+
 @pytest.mark.parametrize("which", ["first step", "one-round refresh"])
 def test_ranks_on_threads_capacity_failure_is_collective(product_lib, which):
     """One rank of three (each on its own thread) has no room for what its neighbours hand it -- at the first step (two-round slab
