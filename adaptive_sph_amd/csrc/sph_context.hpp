@@ -106,6 +106,11 @@ struct sph_ctx {
         hipStream_t xstream = nullptr;
         hipEvent_t ev_x[3] = {nullptr, nullptr, nullptr};
         hipStream_t xs = nullptr;    // the stream the transports queue on / wait for right now (nullptr: the context's main stream)
+        // loopback transport without host waits (LocalComm): my staging is packed / my copies from the neighbours are done / my
+        // totals are published; the group's totals meet in mapped host memory owned by member 0 (two parities x ranks x 8 doubles)
+        hipEvent_t ev_pack = nullptr, ev_copied = nullptr, ev_tot = nullptr;
+        double* gtot = nullptr;
+        uint32_t gtot_seq = 0;
         bool ghosts_ok = true;       // false: this rank ran out of room for its ghost layer (the step goes on without it and ends in SPH_ERR_CAPACITY on every rank)
         void* tgroup = nullptr;      // ThreadGroup*: in-process transport with one host thread per rank (sph_comm_init_threads)
         int rebalance_every = 0;     // move the cuts to equal particle counts every so many steps (0: static cuts)

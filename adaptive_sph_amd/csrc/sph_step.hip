@@ -250,7 +250,7 @@ struct HostTrace {
                     acc[0] / steps, acc[1] / steps, acc[2] / steps, acc[3] / steps, acc[4] / steps, acc[5] / steps);
     }
 };
-static HostTrace g_trace;
+static thread_local HostTrace g_trace;   // (diagnostic, SPH_HIP_TRACE=1; per host thread: contexts stepped from different threads do not share it)
 
 // SPH_DEBUG_SYNC=1 (fault hunting): synchronise and name the phase just queued
 static void dbg_sync(sph_ctx* c, const char* what, int id = 0)
@@ -763,6 +763,19 @@ __global__ void k_spin_us(uint32_t us)
     const uint64_t t0 = wall_clock64();   // 100 MHz
     while (wall_clock64() - t0 < (uint64_t)us * 100ull) __builtin_amdgcn_s_sleep(16);
 }
+// loopback all-reduce of the solver totals without a host wait (LocalComm::allreduce_solver)
+__global__ void k_tot_publish(const double* __restrict__ tot, double* __restrict__ row)
+{
+    if (threadIdx.x < 6) row[threadIdx.x] = tot[threadIdx.x];
+    __threadfence_system();
+}
+__global__ void k_tot_sum(double* __restrict__ tot, const double* __restrict__ table, int n)
+{
+    if (threadIdx.x >= 6) return;
+    double s = 0.0;
+    for (int j = 0; j < n; j++) s += ((const volatile double*)table)[8 * j + threadIdx.x];   // rank order
+    tot[threadIdx.x] = s;
+}
 static void debug_comm_delay(sph_ctx* c)
 {
     const char* e = getenv("SPH_DEBUG_COMM_DELAY_US");
@@ -809,11 +822,16 @@ struct LocalComm : Comm {
         }
         return SPH_OK;
     }
+    // SPH_LOOPBACK_SYNC=1: the exchanges and the solver all-reduce wait on the host (the first form of this transport, kept as the
+    // reference the event-ordered form is tested against).  Default: no host wait -- the copies are ordered by events between the
+    // members' streams, the totals meet in mapped host memory: what a host that drives k GPUs from one process runs.
+    static bool host_synchronous()
+    {
+        const char* e = getenv("SPH_LOOPBACK_SYNC");
+        return e && atoi(e) != 0;
+    }
     int exchange(Group& G, std::vector<Xfer>& x) override
     {
-        for (auto c : G.m) debug_comm_delay(c);
-        int rc = wait_all_xs(G);
-        if (rc) return rc;
         const size_t n = G.m.size();
         // the RCCL transport pairs every ncclSend with an ncclRecv of the same size: hold the loopback to the same rule,
         // so that the single-GPU verification also proves the pairing
@@ -824,16 +842,42 @@ struct LocalComm : Comm {
         }
         if (n && (x[0].send_bytes[0] || x[0].recv_bytes[0] || x[n - 1].send_bytes[1] || x[n - 1].recv_bytes[1]))
             return G.m[0]->fail(SPH_ERR_DEVICE, "halo exchange across the outer edge of the slab row");
+        const bool sync = host_synchronous();
+        int rc;
+        if (sync) {
+            for (auto c : G.m) debug_comm_delay(c);
+            if ((rc = wait_all_xs(G))) return rc;
+        } else {
+            for (auto c : G.m) {   // "my staging buffers are packed"
+                HIPCHK(c, hipSetDevice(c->device));
+                HIPCHK(c, hipEventRecord(c->dist.ev_pack, xs_of(c)));
+            }
+        }
         for (size_t i = 0; i < n; i++) {
             sph_ctx* c = G.m[i];
             c->dist.stat_exchanges++;
             c->dist.stat_bytes_sent += x[i].send_bytes[0] + x[i].send_bytes[1];
             c->dist.stat_bytes_recv += x[i].recv_bytes[0] + x[i].recv_bytes[1];
             HIPCHK(c, hipSetDevice(c->device));
-            if (i > 0 && x[i].recv_bytes[0]) HIPCHK(c, hipMemcpyAsync(x[i].recv[0], x[i - 1].send[1], x[i].recv_bytes[0], hipMemcpyDefault, xs_of(c)));
-            if (i + 1 < n && x[i].recv_bytes[1]) HIPCHK(c, hipMemcpyAsync(x[i].recv[1], x[i + 1].send[0], x[i].recv_bytes[1], hipMemcpyDefault, xs_of(c)));
+            const bool from_l = i > 0 && x[i].recv_bytes[0], from_r = i + 1 < n && x[i].recv_bytes[1];
+            if (!sync) {
+                if (from_l) HIPCHK(c, hipStreamWaitEvent(xs_of(c), G.m[i - 1]->dist.ev_pack, 0));
+                if (from_r) HIPCHK(c, hipStreamWaitEvent(xs_of(c), G.m[i + 1]->dist.ev_pack, 0));
+                if (from_l || from_r) debug_comm_delay(c);
+            }
+            if (from_l) HIPCHK(c, hipMemcpyAsync(x[i].recv[0], x[i - 1].send[1], x[i].recv_bytes[0], hipMemcpyDefault, xs_of(c)));
+            if (from_r) HIPCHK(c, hipMemcpyAsync(x[i].recv[1], x[i + 1].send[0], x[i].recv_bytes[1], hipMemcpyDefault, xs_of(c)));
+            if (!sync) HIPCHK(c, hipEventRecord(c->dist.ev_copied, xs_of(c)));
         }
-        return wait_all_xs(G);  // senders may reuse their staging buffers afterwards
+        if (sync) return wait_all_xs(G);  // senders may reuse their staging buffers afterwards
+        // a sender packs again (always on its main stream) only after the neighbours' copies out of its staging buffers
+        for (size_t i = 0; i < n; i++) {
+            sph_ctx* c = G.m[i];
+            HIPCHK(c, hipSetDevice(c->device));
+            if (i > 0 && x[i].send_bytes[0]) HIPCHK(c, hipStreamWaitEvent(c->stream, G.m[i - 1]->dist.ev_copied, 0));
+            if (i + 1 < n && x[i].send_bytes[1]) HIPCHK(c, hipStreamWaitEvent(c->stream, G.m[i + 1]->dist.ev_copied, 0));
+        }
+        return SPH_OK;
     }
     int counts_round(Group& G, int base, std::vector<std::vector<float>>* red, int* status, std::vector<uint32_t>& tl, std::vector<uint32_t>& tr,
                      std::vector<uint32_t>& fl, std::vector<uint32_t>& fr) override
@@ -880,16 +924,44 @@ struct LocalComm : Comm {
     int agree_guards_queued(Group&) override { return SPH_OK; }   // one process: sync_ctrl sees every member's guard word
     int allreduce_solver(Group& G, int slot) override
     {
-        for (auto c : G.m) debug_comm_delay(c);
-        int rc = wait_all_xs(G);
-        if (rc) return rc;
-        double tot[6] = {0, 0, 0, 0, 0, 0};
-        std::vector<std::array<double, 6>> rows(G.m.size());
-        for (size_t i = 0; i < G.m.size(); i++) {
-            HIPCHK(G.m[i], hipMemcpy(rows[i].data(), G.m[i]->dist.solver_tot.as<double>() + 8 * slot, 48, hipMemcpyDeviceToHost));
-            for (int k = 0; k < 6; k++) tot[k] += rows[i][k];
+        const size_t n = G.m.size();
+        if (host_synchronous()) {
+            for (auto c : G.m) debug_comm_delay(c);
+            int rc = wait_all_xs(G);
+            if (rc) return rc;
+            double tot[6] = {0, 0, 0, 0, 0, 0};
+            std::vector<std::array<double, 6>> rows(n);
+            for (size_t i = 0; i < n; i++) {
+                HIPCHK(G.m[i], hipMemcpy(rows[i].data(), G.m[i]->dist.solver_tot.as<double>() + 8 * slot, 48, hipMemcpyDeviceToHost));
+                for (int k = 0; k < 6; k++) tot[k] += rows[i][k];
+            }
+            for (auto c : G.m) HIPCHK(c, hipMemcpy(c->dist.solver_tot.as<double>() + 8 * slot, tot, 48, hipMemcpyHostToDevice));
+            return SPH_OK;
         }
-        for (auto c : G.m) HIPCHK(c, hipMemcpy(c->dist.solver_tot.as<double>() + 8 * slot, tot, 48, hipMemcpyHostToDevice));
+        // every member publishes its six doubles into its row of the group's table (mapped host memory: any device reaches it),
+        // then adds up all rows in rank order -- the sum the host-synchronous form computes.  Two tables, alternating: a member is
+        // at most one all-reduce ahead of the slowest (it needed everybody's row of the previous one).
+        sph_ctx* c0 = G.m[0];
+        if (!c0->dist.gtot) {
+            HIPCHK(c0, hipHostMalloc((void**)&c0->dist.gtot, 2 * 64 * 8 * sizeof(double), hipHostMallocMapped | hipHostMallocPortable));
+            memset(c0->dist.gtot, 0, 2 * 64 * 8 * sizeof(double));
+        }
+        if (n > 64) return c0->fail(SPH_ERR_INVALID_ARGUMENT, "loopback group of %zu members", n);
+        double* table = c0->dist.gtot + (size_t)(c0->dist.gtot_seq++ & 1u) * 64 * 8;
+        for (size_t i = 0; i < n; i++) {
+            sph_ctx* c = G.m[i];
+            HIPCHK(c, hipSetDevice(c->device));
+            hipLaunchKernelGGL(k_tot_publish, dim3(1), dim3(64), 0, xs_of(c), c->dist.solver_tot.as<double>() + 8 * slot, table + 8 * i);
+            HIPCHK(c, hipEventRecord(c->dist.ev_tot, xs_of(c)));
+        }
+        for (size_t i = 0; i < n; i++) {
+            sph_ctx* c = G.m[i];
+            HIPCHK(c, hipSetDevice(c->device));
+            for (size_t j = 0; j < n; j++)
+                if (j != i) HIPCHK(c, hipStreamWaitEvent(xs_of(c), G.m[j]->dist.ev_tot, 0));
+            debug_comm_delay(c);
+            hipLaunchKernelGGL(k_tot_sum, dim3(1), dim3(64), 0, xs_of(c), c->dist.solver_tot.as<double>() + 8 * slot, (const double*)table, (int)n);
+        }
         return SPH_OK;
     }
 };
@@ -1484,6 +1556,9 @@ static int ensure_dist_buffers(sph_ctx* c, uint32_t n)
     if (!d.xstream) {
         HIPCHK(c, hipStreamCreateWithFlags(&d.xstream, hipStreamNonBlocking));
         for (auto& e : d.ev_x) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        HIPCHK(c, hipEventCreateWithFlags(&d.ev_pack, hipEventDisableTiming));
+        HIPCHK(c, hipEventCreateWithFlags(&d.ev_copied, hipEventDisableTiming));
+        HIPCHK(c, hipEventCreateWithFlags(&d.ev_tot, hipEventDisableTiming));
     }
     HIPCHK(c, d.blk.ensure(((cap + 255) / 256) * 8 * sizeof(uint32_t)));
     if (!d.counts_host) {
@@ -2003,89 +2078,59 @@ static int solve_sweep_a(Group& G, std::vector<Member>& M, const SolveQ& q, uint
     if (multi) return G.comm->allreduce_solver(G, q.tot_slot);
     return SPH_OK;
 }
-// Slab decomposition with neighbours: sweep A in two launches around the iteration's communication.  On the main stream: pack the
-// halo members' p / rho^2, sweep A over the particles that have no ghost in reach (most of the slab), then -- once the ghosts
-// arrived -- sweep A over the halo members and the first ghost ring (a list launch, a few per cent of the slab), then -- once the
-// totals are all-reduced -- whatever follows (sweep B takes the decision from them).  On the stream of the collectives, behind the
-// pack: the exchange, the unpack, this rank's totals of the previous iteration (k_solver_totals: what block 0 of the unsplit sweep
-// adds up) and their all-reduce.  Same collectives in the same order as the unsplit form, same arithmetic per particle.
-// SPH_OVERLAP=0 keeps the unsplit form.
-static bool split_sweep_a(const Group& G)
+// Slab decomposition with neighbours: sweep A in two launches, so that the iteration's communication runs under compute.  The
+// interior -- every lane without a ghost in reach, most of the slab -- is swept on the context's SIDE stream as soon as sweep B is
+// done; the main stream meanwhile packs the halo members' p / rho^2, exchanges, unpacks, adds up this rank's totals of the previous
+// iteration (k_solver_totals: what block 0 of the one-launch sweep does) and all-reduces them; then it waits for the interior and
+// sweeps the halo members and the first ghost ring (a list launch, a few per cent of the slab).  The collectives stay on the main
+// stream on purpose: a dependency between two streams costs ~9.5 us on this platform (scripts/ubench/xstream_hop.hip), and this
+// way the two such hops (B -> interior, interior -> edge) sit beside the communication, not in its chain.  Same collectives in the
+// same order as the one-launch form, same arithmetic per particle; every rank decides for itself (nothing collective depends on
+// it): SPH_OVERLAP=0 never splits, =1 always (tests), default: slabs of at least SPLIT_MIN_PARTICLES.
+#ifndef SPLIT_MIN_PARTICLES
+#define SPLIT_MIN_PARTICLES 786432u   // the interior sweep (22 us per 1M particles) must outlast the two hops by a margin
+#endif
+static bool split_sweep_a(const Group& G, const std::vector<Member>& M)
 {
     const char* e = getenv("SPH_OVERLAP");   // (read per call: the tests switch it between two runs of one process)
-    const int env = e ? atoi(e) : 1;
-    return env != 0 && G.comm != nullptr && G.m[0]->dist.nranks > 1 && G.m[0]->dist.xstream != nullptr;
+    const int env = e ? atoi(e) : -1;
+    if (env == 0 || G.comm == nullptr || G.m[0]->dist.nranks <= 1 || G.m[0]->dist.xstream == nullptr) return false;
+    if (env > 0) return true;
+    uint32_t n_max = 0;
+    for (auto& m : M) n_max = std::max(n_max, m.n);
+    return n_max >= SPLIT_MIN_PARTICLES;
 }
-struct XsScope {   // the transports queue on / wait for the members' collective streams while this lives
-    Group& G;
-    explicit XsScope(Group& g) : G(g)
-    {
-        for (auto c : G.m) c->dist.xs = c->dist.xstream;
-    }
-    ~XsScope()
-    {
-        for (auto c : G.m) c->dist.xs = nullptr;
-    }
-};
 // the ghosts' p / rho^2 of pressure buffer ka & 1, sweep A(ka), and the all-reduce of iteration ka - 1's totals
 static int exchange_and_sweep_a(Group& G, std::vector<Member>& M, const SolveQ& q, uint32_t ka)
 {
     int rc;
     float* (*sel)(Member&) = (ka & 1u) ? sel_pt1 : sel_pt0;
-    if (!split_sweep_a(G)) {
+    if (!split_sweep_a(G, M)) {
         if ((rc = refresh_ghosts(G, M, sel, 1, "pt"))) return rc;
         return solve_sweep_a(G, M, q, ka);
     }
-    std::vector<Xfer> x(M.size());
-    for (size_t i = 0; i < M.size(); i++) {
-        sph_ctx* c = M[i].c;
+    for (auto& m : M) {   // the interior, beside everything below
+        sph_ctx* c = m.c;
         auto& d = c->dist;
         (void)hipSetDevice(c->device);
-        const uint32_t nh = d.n_halo[0] + d.n_halo[1];
-        {
-            ProfScope ps(&c->prof, "ghost_pack", c->stream);
-            if (nh)
-                hipLaunchKernelGGL(k_pack_field, dim3((nh + 255) / 256), dim3(256), 0, c->stream, d.halo_src.as<uint32_t>(), d.n_halo[0], d.n_halo[1], 1, sel(M[i]),
-                                   d.send[0].as<float>(), d.send[1].as<float>());
-        }
-        for (int side = 0; side < 2; side++) {
-            x[i].send[side] = d.send[side].p;
-            x[i].send_bytes[side] = (size_t)d.n_halo[side] * 4;
-            x[i].recv[side] = d.recv[side].p;
-            x[i].recv_bytes[side] = (size_t)d.n_ghost[side] * 4;
-        }
         HIPCHK(c, hipEventRecord(d.ev_x[0], c->stream));
         HIPCHK(c, hipStreamWaitEvent(d.xstream, d.ev_x[0], 0));
-        if (M[i].n) launch_pressure_accel(c->stream, &c->prof, M[i].a, (int)ka, q.residual_density, q.max_avg_error, q.max_iters, 1, 1);
+        if (m.n) launch_pressure_accel(d.xstream, &c->prof, m.a, (int)ka, q.residual_density, q.max_avg_error, q.max_iters, 1, 1);
+        HIPCHK(c, hipEventRecord(d.ev_x[1], d.xstream));
     }
-    {
-        XsScope scope(G);
-        if ((rc = G.comm->exchange(G, x))) return rc;
-        for (size_t i = 0; i < M.size(); i++) {
-            sph_ctx* c = M[i].c;
-            auto& d = c->dist;
-            (void)hipSetDevice(c->device);
-            const uint32_t ng = d.ghosts_ok ? d.n_ghost[0] + d.n_ghost[1] : 0u;   // (no ghost slots: received, dropped)
-            {
-                ProfScope ps(&c->prof, "ghost_unpack", d.xstream);
-                if (ng)
-                    hipLaunchKernelGGL(k_unpack_field, dim3((ng + 255) / 256), dim3(256), 0, d.xstream, d.ghost_dst.as<uint32_t>(), d.n_ghost[0], d.n_ghost[1], 1,
-                                       d.recv[0].as<float>(), d.recv[1].as<float>(), sel(M[i]));
-            }
-            HIPCHK(c, hipEventRecord(d.ev_x[1], d.xstream));
-            if (M[i].n) launch_solver_totals(d.xstream, &c->prof, M[i].a, (int)ka - 1, q.residual_density, q.max_avg_error, q.max_iters);
-            else HIPCHK(c, hipMemsetAsync(d.solver_tot.as<double>() + 8 * q.tot_slot, 0, 48, d.xstream));   // an empty slab contributes zeros
-        }
-        if ((rc = G.comm->allreduce_solver(G, q.tot_slot))) return rc;
-    }
-    for (size_t i = 0; i < M.size(); i++) {
-        sph_ctx* c = M[i].c;
-        auto& d = c->dist;
+    if ((rc = refresh_ghosts(G, M, sel, 1, "pt"))) return rc;
+    for (auto& m : M) {
+        sph_ctx* c = m.c;
         (void)hipSetDevice(c->device);
-        HIPCHK(c, hipEventRecord(d.ev_x[2], d.xstream));
-        HIPCHK(c, hipStreamWaitEvent(c->stream, d.ev_x[1], 0));
-        if (M[i].n) launch_pressure_accel(c->stream, &c->prof, M[i].a, (int)ka, q.residual_density, q.max_avg_error, q.max_iters, 1, 2);
-        HIPCHK(c, hipStreamWaitEvent(c->stream, d.ev_x[2], 0));
+        if (m.n) launch_solver_totals(c->stream, &c->prof, m.a, (int)ka - 1, q.residual_density, q.max_avg_error, q.max_iters);
+        else HIPCHK(c, hipMemsetAsync(c->dist.solver_tot.as<double>() + 8 * q.tot_slot, 0, 48, c->stream));   // an empty slab contributes zeros
+    }
+    if ((rc = G.comm->allreduce_solver(G, q.tot_slot))) return rc;
+    for (auto& m : M) {
+        sph_ctx* c = m.c;
+        (void)hipSetDevice(c->device);
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->dist.ev_x[1], 0));
+        if (m.n) launch_pressure_accel(c->stream, &c->prof, m.a, (int)ka, q.residual_density, q.max_avg_error, q.max_iters, 1, 2);
     }
     return SPH_OK;
 }
@@ -3163,6 +3208,7 @@ static int group_step(Group& G, const sph_params* p, sph_step_stats* outs)
 // ------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------
+// the transports carry no state of their own (everything lives in the contexts / the thread group): one object each serves every group
 static RcclComm g_rccl;
 static LocalComm g_local;
 static ThreadComm g_threads;
@@ -3336,6 +3382,12 @@ void dist_release(sph_ctx* c)
         if (e) (void)hipEventDestroy(e);
         e = nullptr;
     }
+    for (hipEvent_t* e : {&d.ev_pack, &d.ev_copied, &d.ev_tot}) {
+        if (*e) (void)hipEventDestroy(*e);
+        *e = nullptr;
+    }
+    if (d.gtot) (void)hipHostFree(d.gtot);
+    d.gtot = nullptr;
     if (d.counts_host) (void)hipHostFree(d.counts_host);
     d.counts_host = nullptr;
 }

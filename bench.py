@@ -257,13 +257,28 @@ def main():
     if not args.no_8m and wl == "dam_break_1m":
         s8, p8f, d8 = WORKLOADS["dam_break_8m"]
         P8 = p8f()
-        c8, n8 = make_context(s8(), P8)
-        el8, _, di8, de8, st8 = timed_run(c8, P8.to_ffi(), args.warmup, args.steps)
-        strong_8m = {"workload": f"dam_break_8m: {d8}", "particles": n8, "value": n8 * args.steps / el8, "unit": "particle-steps/s",
-                     "ms_per_step": el8 * 1e3 / args.steps, "steps": args.steps, "warmup": args.warmup, "n_gpus": world, "scaling": "strong",
-                     "mean_div_iterations": float(np.mean(di8)), "mean_density_iterations": float(np.mean(de8)),
-                     "comm_rank0": comm_record(st8, args.steps) if distributed else None}
-        c8.close()
+
+        def run_8m(overlap):
+            """overlap: None = the library's own rule (sweep A split around the iteration's communication on slabs of >= 786k particles
+            with neighbours), "0" / "1" = forced (SPH_OVERLAP, read by the library at every iteration; same results either way)."""
+            if overlap is None:
+                os.environ.pop("SPH_OVERLAP", None)
+            else:
+                os.environ["SPH_OVERLAP"] = overlap
+            c8, n8 = make_context(s8(), P8)
+            el8, _, di8, de8, st8 = timed_run(c8, P8.to_ffi(), args.warmup, args.steps)
+            c8.close()
+            os.environ.pop("SPH_OVERLAP", None)
+            return {"workload": f"dam_break_8m: {d8}", "particles": n8, "value": n8 * args.steps / el8, "unit": "particle-steps/s",
+                    "ms_per_step": el8 * 1e3 / args.steps, "steps": args.steps, "warmup": args.warmup, "n_gpus": world, "scaling": "strong",
+                    "mean_div_iterations": float(np.mean(di8)), "mean_density_iterations": float(np.mean(de8)),
+                    "comm_rank0": comm_record(st8, args.steps) if distributed else None}
+
+        strong_8m = run_8m(None)
+        if distributed:   # the same run with sweep A forced into one launch / forced split: what the overlap is worth on this node
+            strong_8m["sweep_a"] = "library rule (split on slabs of >= 786432 particles)"
+            strong_8m["sweep_a_one_launch"] = {k: v for k, v in run_8m("0").items() if k in ("value", "ms_per_step", "comm_rank0")}
+            strong_8m["sweep_a_split"] = {k: v for k, v in run_8m("1").items() if k in ("value", "ms_per_step", "comm_rank0")}
 
     if rank != 0:
         if distributed:

@@ -21,8 +21,8 @@ lib = ffi.load_product()
 p = P.to_ffi()
 delay = os.environ.get("SPH_DEBUG_COMM_DELAY_US", "0")
 print(f"{wl}: {len(mass)} particles, {steps} timed steps after 20, every loopback collective delayed by {delay} us")
-for transport in (("loopback",) if delay != "0" else ("loopback", "threads")):
-    for k in ((2,) if delay != "0" else (2, 4, 8)):
+for transport in (("loopback",) if (delay != "0" or len(mass) > 2_000_000) else ("loopback", "threads")):
+    for k in ((2,) if (delay != "0" or len(mass) > 2_000_000) else (2, 4, 8)):
         row = {}
         for mode in ("1", "0"):
             os.environ["SPH_OVERLAP"] = mode
@@ -44,8 +44,10 @@ for transport in (("loopback",) if delay != "0" else ("loopback", "threads")):
                     st = step()
                     its += st[0].div_solver.iters + st[0].density_solver.iters
                 dt = (time.perf_counter() - t0) / steps
-                waits = grp[0].dist_get_stats()["host_waits"] / steps
+                st0 = grp[0].dist_get_stats()
+                waits = st0["host_waits"] / steps
                 row[mode] = (dt * 1e3, its / steps, waits)
+                coll = (st0["exchanges"] / steps, st0["allreduces"] / steps)
             finally:
                 if thr:
                     thr.close()
@@ -53,4 +55,4 @@ for transport in (("loopback",) if delay != "0" else ("loopback", "threads")):
                     for c in grp:
                         c.close()
         (a, ia, wa), (b, ib, wb) = row["1"], row["0"]
-        print(f"{transport:9s} k={k}: split {a:.3f} ms/step ({ia:.1f} iterations, {wa:.1f} host waits)   one launch {b:.3f} ms/step ({ib:.1f}, {wb:.1f})   ratio {a / b:.3f}", flush=True)
+        print(f"{transport:9s} k={k}: split {a:.3f} ms/step ({ia:.1f} iterations, {wa:.1f} host waits)   one launch {b:.3f} ms/step ({ib:.1f}, {wb:.1f})   ratio {a / b:.3f}   [{coll[0]:.1f} exchanges + {coll[1]:.1f} all-reduces per step and rank]", flush=True)

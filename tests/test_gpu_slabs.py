@@ -589,13 +589,48 @@ def test_ranks_on_threads_fail_together(product_lib):
         thr.close()
 
 
+@pytest.mark.parametrize("overlap", ["1", "0"])
+def test_loopback_without_host_waits_is_bit_identical_to_the_host_synchronous_form(product_lib, monkeypatch, overlap):
+    """The loopback transport orders its copies by events between the members' streams and all-reduces the solver totals through
+    mapped host memory -- no host wait inside an exchange or a Jacobi iteration.  SPH_LOOPBACK_SYNC=1 is its first form (the host
+    waits for every member before and after every copy, sums the totals itself): same fields bit for bit, far fewer host waits.
+    Particles cross the cuts (both exchanges of the refresh), with the split sweep A and without."""
+    monkeypatch.setenv("SPH_OVERLAP", overlap)
+    scn = sc.dam_break_small(96, 48, 1 / 48)
+    pos, mass, vel = sc.init_particles(scn)
+    vel = vel.copy()
+    vel[:, 0] = 0.8
+    planes = sc.boundary_planes(scn.boundary)
+    p = dam_break_params().to_ffi()
+    runs = {}
+    for name in ("events", "host"):
+        if name == "host":
+            monkeypatch.setenv("SPH_LOOPBACK_SYNC", "1")
+        grp = D.make_loopback_group(product_lib, pos, mass, vel, planes, 4)
+        for _ in range(3):
+            ffi.group_step(grp, p)
+        for c in grp:
+            c.dist_get_stats(reset=True)
+        stats = [ffi.group_step(grp, p) for _ in range(20)]
+        runs[name] = ([(x.dt, x.div_solver.iters, x.density_solver.iters) for st in stats for x in st],
+                      [{f: c.download(f) for f in ("particle_id", "position", "velocity", "density", "pressure")} for c in grp],
+                      grp[1].dist_get_stats()["host_waits"] / 20)
+    monkeypatch.delenv("SPH_LOOPBACK_SYNC")
+    assert runs["events"][0] == runs["host"][0]
+    for a, b in zip(runs["events"][1], runs["host"][1]):
+        for f in a:
+            assert np.array_equal(a[f], b[f]), f
+    assert runs["events"][2] <= 6 and runs["host"][2] > 3 * runs["events"][2], (runs["events"][2], runs["host"][2])
+
+
 @pytest.mark.parametrize("transport", ["loopback", "threads"])
 @pytest.mark.parametrize("solver,extra", [("HybridDFSPH", {}), ("IISPH", {}), ("OnlyDivergence", {}), ("IISPH2", dict(max_dt=0.0005))])
 def test_split_sweep_a_is_bit_identical_to_the_unsplit_form(product_lib, monkeypatch, transport, solver, extra):
-    """Slabs with neighbours run sweep A of every Jacobi iteration in two launches -- the particles without a ghost in reach while the
-    ghost exchange and the all-reduce of the totals run on a stream of their own, the halo members and the first ghost ring once
-    the ghosts arrived.  SPH_OVERLAP=0 keeps the one-launch form with everything on one stream: same particles, same arithmetic,
-    same decisions -- every field bit for bit, and the split form really ran (its list launch shows up in the profile)."""
+    """Large slabs with neighbours run sweep A of every Jacobi iteration in two launches -- the particles without a ghost in reach on
+    the context's side stream, beside the ghost exchange and the all-reduce of the totals; the halo members and the first ghost ring
+    once the ghosts arrived and the interior is done.  SPH_OVERLAP=0 keeps the one-launch form with everything on one stream: same
+    particles, same arithmetic, same decisions -- every field bit for bit, and the split form really ran (its list launch shows up
+    in the profile)."""
     scn = sc.dam_break_small(96, 48, 1 / 48)
     pos, mass, vel = sc.init_particles(scn)
     vel = vel.copy()
@@ -604,8 +639,7 @@ def test_split_sweep_a_is_bit_identical_to_the_unsplit_form(product_lib, monkeyp
     p = dam_break_params(pressure_solver_method=solver, **extra).to_ffi()
     runs = {}
     for name in ("split", "unsplit"):
-        if name == "unsplit":
-            monkeypatch.setenv("SPH_OVERLAP", "0")
+        monkeypatch.setenv("SPH_OVERLAP", "1" if name == "split" else "0")   # (default: by slab size, these slabs are small)
         thr = None
         if transport == "threads":
             thr = D.ThreadedGroup(product_lib, pos, mass, vel, planes, 3)
