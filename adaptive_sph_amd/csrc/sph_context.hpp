@@ -100,12 +100,11 @@ struct sph_ctx {
         uint32_t* counts_host = nullptr;       // mapped pinned
         uint32_t* counts_host_dev = nullptr;
         void* nccl = nullptr;        // ncclComm_t
-        // Split sweep A (sph_step.hip, exchange_and_sweep_a): the ghost exchange and the all-reduce of an iteration are queued on a
-        // stream of their own and run under the sweep over the particles that have no ghost in reach
+        // Split sweep A (sph_step.hip, exchange_and_sweep_a): the sweep over the particles that have no ghost in reach runs on a
+        // stream of its own, beside the ghost exchange and the all-reduce of the iteration on the main stream
         DevBuf edge;                 // u8 per slot: 1 = halo member or ghost
         hipStream_t xstream = nullptr;
-        hipEvent_t ev_x[3] = {nullptr, nullptr, nullptr};
-        hipStream_t xs = nullptr;    // the stream the transports queue on / wait for right now (nullptr: the context's main stream)
+        hipEvent_t ev_x[3] = {nullptr, nullptr, nullptr};   // [0] sweep B done (main), [1] interior done (side)
         // loopback transport without host waits (LocalComm): my staging is packed / my copies from the neighbours are done / my
         // totals are published; the group's totals meet in mapped host memory owned by member 0 (two parities x ranks x 8 doubles)
         hipEvent_t ev_pack = nullptr, ev_copied = nullptr, ev_tot = nullptr;

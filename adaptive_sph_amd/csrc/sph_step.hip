@@ -147,18 +147,6 @@ int wait_stream(sph_ctx* c)
     }
 }
 
-// the stream the transports use right now (Dist::xs): the context's main stream, or the stream of the collectives while a
-// split sweep is being queued -- then the wait leaves the main stream alone (the sweep over the interior is running there)
-static hipStream_t xs_of(sph_ctx* c) { return c->dist.xs ? c->dist.xs : c->stream; }
-static int wait_xs(sph_ctx* c)
-{
-    if (!c->dist.xs || c->dist.xs == c->stream) return wait_stream(c);
-    c->n_waits++;
-    HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipStreamSynchronize(c->dist.xs));
-    return SPH_OK;
-}
-
 // Wait for the k_publish just queued: its sequence number arrives in mapped host memory as the kernel's last store, behind
 // everything queued before it.  Falls back to the event wait if it does not show up (or SPH_EVENT_WAIT is set).
 static int wait_word(sph_ctx* c, volatile uint32_t* word, uint32_t want)
@@ -746,15 +734,6 @@ static int wait_all(Group& G)
     return SPH_OK;
 }
 
-static int wait_all_xs(Group& G)   // on the streams the transports use right now (wait_xs)
-{
-    for (auto c : G.m) {
-        int rc = wait_xs(c);
-        if (rc) return rc;
-    }
-    return SPH_OK;
-}
-
 // Measurement hook of the loopback transport (scripts/gpu_split_sweep_timing.py): SPH_DEBUG_COMM_DELAY_US=<us> makes every ghost
 // exchange and every all-reduce of the solver totals occupy its stream for that long before it completes -- a stand-in for the
 // latency of a collective between GPUs, which one GPU cannot produce
@@ -780,7 +759,7 @@ static void debug_comm_delay(sph_ctx* c)
 {
     const char* e = getenv("SPH_DEBUG_COMM_DELAY_US");
     const int us = e ? atoi(e) : 0;
-    if (us > 0) hipLaunchKernelGGL(k_spin_us, dim3(1), dim3(1), 0, xs_of(c), (uint32_t)us);
+    if (us > 0) hipLaunchKernelGGL(k_spin_us, dim3(1), dim3(1), 0, c->stream, (uint32_t)us);
 }
 
 // ---- loopback: all ranks are contexts of this process ---------------------------------------------
@@ -846,11 +825,11 @@ struct LocalComm : Comm {
         int rc;
         if (sync) {
             for (auto c : G.m) debug_comm_delay(c);
-            if ((rc = wait_all_xs(G))) return rc;
+            if ((rc = wait_all(G))) return rc;
         } else {
             for (auto c : G.m) {   // "my staging buffers are packed"
                 HIPCHK(c, hipSetDevice(c->device));
-                HIPCHK(c, hipEventRecord(c->dist.ev_pack, xs_of(c)));
+                HIPCHK(c, hipEventRecord(c->dist.ev_pack, c->stream));
             }
         }
         for (size_t i = 0; i < n; i++) {
@@ -861,15 +840,15 @@ struct LocalComm : Comm {
             HIPCHK(c, hipSetDevice(c->device));
             const bool from_l = i > 0 && x[i].recv_bytes[0], from_r = i + 1 < n && x[i].recv_bytes[1];
             if (!sync) {
-                if (from_l) HIPCHK(c, hipStreamWaitEvent(xs_of(c), G.m[i - 1]->dist.ev_pack, 0));
-                if (from_r) HIPCHK(c, hipStreamWaitEvent(xs_of(c), G.m[i + 1]->dist.ev_pack, 0));
+                if (from_l) HIPCHK(c, hipStreamWaitEvent(c->stream, G.m[i - 1]->dist.ev_pack, 0));
+                if (from_r) HIPCHK(c, hipStreamWaitEvent(c->stream, G.m[i + 1]->dist.ev_pack, 0));
                 if (from_l || from_r) debug_comm_delay(c);
             }
-            if (from_l) HIPCHK(c, hipMemcpyAsync(x[i].recv[0], x[i - 1].send[1], x[i].recv_bytes[0], hipMemcpyDefault, xs_of(c)));
-            if (from_r) HIPCHK(c, hipMemcpyAsync(x[i].recv[1], x[i + 1].send[0], x[i].recv_bytes[1], hipMemcpyDefault, xs_of(c)));
-            if (!sync) HIPCHK(c, hipEventRecord(c->dist.ev_copied, xs_of(c)));
+            if (from_l) HIPCHK(c, hipMemcpyAsync(x[i].recv[0], x[i - 1].send[1], x[i].recv_bytes[0], hipMemcpyDefault, c->stream));
+            if (from_r) HIPCHK(c, hipMemcpyAsync(x[i].recv[1], x[i + 1].send[0], x[i].recv_bytes[1], hipMemcpyDefault, c->stream));
+            if (!sync) HIPCHK(c, hipEventRecord(c->dist.ev_copied, c->stream));
         }
-        if (sync) return wait_all_xs(G);  // senders may reuse their staging buffers afterwards
+        if (sync) return wait_all(G);  // senders may reuse their staging buffers afterwards
         // a sender packs again (always on its main stream) only after the neighbours' copies out of its staging buffers
         for (size_t i = 0; i < n; i++) {
             sph_ctx* c = G.m[i];
@@ -927,7 +906,7 @@ struct LocalComm : Comm {
         const size_t n = G.m.size();
         if (host_synchronous()) {
             for (auto c : G.m) debug_comm_delay(c);
-            int rc = wait_all_xs(G);
+            int rc = wait_all(G);
             if (rc) return rc;
             double tot[6] = {0, 0, 0, 0, 0, 0};
             std::vector<std::array<double, 6>> rows(n);
@@ -951,16 +930,16 @@ struct LocalComm : Comm {
         for (size_t i = 0; i < n; i++) {
             sph_ctx* c = G.m[i];
             HIPCHK(c, hipSetDevice(c->device));
-            hipLaunchKernelGGL(k_tot_publish, dim3(1), dim3(64), 0, xs_of(c), c->dist.solver_tot.as<double>() + 8 * slot, table + 8 * i);
-            HIPCHK(c, hipEventRecord(c->dist.ev_tot, xs_of(c)));
+            hipLaunchKernelGGL(k_tot_publish, dim3(1), dim3(64), 0, c->stream, c->dist.solver_tot.as<double>() + 8 * slot, table + 8 * i);
+            HIPCHK(c, hipEventRecord(c->dist.ev_tot, c->stream));
         }
         for (size_t i = 0; i < n; i++) {
             sph_ctx* c = G.m[i];
             HIPCHK(c, hipSetDevice(c->device));
             for (size_t j = 0; j < n; j++)
-                if (j != i) HIPCHK(c, hipStreamWaitEvent(xs_of(c), G.m[j]->dist.ev_tot, 0));
+                if (j != i) HIPCHK(c, hipStreamWaitEvent(c->stream, G.m[j]->dist.ev_tot, 0));
             debug_comm_delay(c);
-            hipLaunchKernelGGL(k_tot_sum, dim3(1), dim3(64), 0, xs_of(c), c->dist.solver_tot.as<double>() + 8 * slot, (const double*)table, (int)n);
+            hipLaunchKernelGGL(k_tot_sum, dim3(1), dim3(64), 0, c->stream, c->dist.solver_tot.as<double>() + 8 * slot, (const double*)table, (int)n);
         }
         return SPH_OK;
     }
@@ -1165,15 +1144,15 @@ struct RcclComm : Comm {
         c->dist.stat_exchanges++;
         c->dist.stat_bytes_sent += (r > 0 ? x[0].send_bytes[0] : 0) + (r + 1 < nr ? x[0].send_bytes[1] : 0);
         c->dist.stat_bytes_recv += (r > 0 ? x[0].recv_bytes[0] : 0) + (r + 1 < nr ? x[0].recv_bytes[1] : 0);
-        ProfScope ps(&c->prof, "rccl_sendrecv", xs_of(c));
+        ProfScope ps(&c->prof, "rccl_sendrecv", c->stream);
         NCCLCHK(c, ncclGroupStart());
         if (r > 0) {
-            if (x[0].send_bytes[0]) NCCLCHK(c, ncclSend(x[0].send[0], x[0].send_bytes[0], ncclChar, r - 1, nc, xs_of(c)));
-            if (x[0].recv_bytes[0]) NCCLCHK(c, ncclRecv(x[0].recv[0], x[0].recv_bytes[0], ncclChar, r - 1, nc, xs_of(c)));
+            if (x[0].send_bytes[0]) NCCLCHK(c, ncclSend(x[0].send[0], x[0].send_bytes[0], ncclChar, r - 1, nc, c->stream));
+            if (x[0].recv_bytes[0]) NCCLCHK(c, ncclRecv(x[0].recv[0], x[0].recv_bytes[0], ncclChar, r - 1, nc, c->stream));
         }
         if (r + 1 < nr) {
-            if (x[0].send_bytes[1]) NCCLCHK(c, ncclSend(x[0].send[1], x[0].send_bytes[1], ncclChar, r + 1, nc, xs_of(c)));
-            if (x[0].recv_bytes[1]) NCCLCHK(c, ncclRecv(x[0].recv[1], x[0].recv_bytes[1], ncclChar, r + 1, nc, xs_of(c)));
+            if (x[0].send_bytes[1]) NCCLCHK(c, ncclSend(x[0].send[1], x[0].send_bytes[1], ncclChar, r + 1, nc, c->stream));
+            if (x[0].recv_bytes[1]) NCCLCHK(c, ncclRecv(x[0].recv[1], x[0].recv_bytes[1], ncclChar, r + 1, nc, c->stream));
         }
         NCCLCHK(c, ncclGroupEnd());
         return SPH_OK;
@@ -1182,9 +1161,9 @@ struct RcclComm : Comm {
     {
         sph_ctx* c = G.m[0];
         c->dist.stat_allreduces++;
-        ProfScope ps(&c->prof, "rccl_allreduce", xs_of(c));
+        ProfScope ps(&c->prof, "rccl_allreduce", c->stream);
         double* t = c->dist.solver_tot.as<double>() + 8 * slot;
-        NCCLCHK(c, ncclAllReduce(t, t, 6, ncclFloat64, ncclSum, (ncclComm_t)c->dist.nccl, xs_of(c)));
+        NCCLCHK(c, ncclAllReduce(t, t, 6, ncclFloat64, ncclSum, (ncclComm_t)c->dist.nccl, c->stream));
         return SPH_OK;
     }
 };
@@ -1354,7 +1333,7 @@ struct ThreadComm : Comm {
     {
         sph_ctx* c = G.m[0];
         c->dist.stat_exchanges++;
-        int rc = wait_xs(c);   // my staging buffers are packed
+        int rc = wait_stream(c);   // my staging buffers are packed
         if (rc) {
             grp(G)->abandon();
             return rc;
@@ -1372,16 +1351,16 @@ struct ThreadComm : Comm {
                                            L.recv_bytes[1], R.recv_bytes[0]);
                         c->dist.stat_bytes_sent += x[0].send_bytes[0] + x[0].send_bytes[1];
                         c->dist.stat_bytes_recv += x[0].recv_bytes[0] + x[0].recv_bytes[1];
-                        if (x[0].recv_bytes[0]) HIPCHK(c, hipMemcpyAsync(x[0].recv[0], L.send[1], x[0].recv_bytes[0], hipMemcpyDefault, xs_of(c)));
-                        if (x[0].recv_bytes[1]) HIPCHK(c, hipMemcpyAsync(x[0].recv[1], R.send[0], x[0].recv_bytes[1], hipMemcpyDefault, xs_of(c)));
-                        return wait_xs(c);   // (the senders may reuse their staging buffers once everybody is past the closing barrier)
+                        if (x[0].recv_bytes[0]) HIPCHK(c, hipMemcpyAsync(x[0].recv[0], L.send[1], x[0].recv_bytes[0], hipMemcpyDefault, c->stream));
+                        if (x[0].recv_bytes[1]) HIPCHK(c, hipMemcpyAsync(x[0].recv[1], R.send[0], x[0].recv_bytes[1], hipMemcpyDefault, c->stream));
+                        return wait_stream(c);   // (the senders may reuse their staging buffers once everybody is past the closing barrier)
                     });
     }
     int allreduce_solver(Group& G, int slot) override
     {
         sph_ctx* c = G.m[0];
         c->dist.stat_allreduces++;
-        int rc = wait_xs(c);
+        int rc = wait_stream(c);
         if (rc) {
             grp(G)->abandon();
             return rc;
@@ -3377,7 +3356,7 @@ void dist_release(sph_ctx* c)
         (void)hipStreamSynchronize(d.xstream);
         (void)hipStreamDestroy(d.xstream);
     }
-    d.xstream = d.xs = nullptr;
+    d.xstream = nullptr;
     for (auto& e : d.ev_x) {
         if (e) (void)hipEventDestroy(e);
         e = nullptr;
