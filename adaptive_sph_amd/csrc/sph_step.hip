@@ -2036,6 +2036,7 @@ struct SolveQ {
     uint32_t k = 1, upto = 2;
     void extend() { upto = k + std::max(1u, k / 4u); }   // a quarter more iterations per wait, at least one: a skipped
                                                          // iteration costs two empty launches (~9 us), a wait the round trip to the host
+                                                         // (measured on the driver window, 5 runs each: k/4 1.279-1.295 ms per step, k/2 1.284-1.292, k 1.300-1.311)
 };
 // sweep A of iteration k: a^p from pressure buffer k & 1, and the stop decision of iteration k - 1
 static int solve_sweep_a(Group& G, std::vector<Member>& M, const SolveQ& q, uint32_t k)
