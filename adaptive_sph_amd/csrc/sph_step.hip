@@ -271,21 +271,28 @@ __device__ __forceinline__ void block_class_counts(uint32_t cls, uint32_t* __res
 // kernels of the slab decomposition
 // ------------------------------------------------------------------------------------------------
 // class of every slot of the previous step's arrays: 0 stay, 1 migrate left, 2 migrate right, 3 drop (ghost)
+enum { RC_FAR = 13 };   // word of dist.counts (general path): a migrant may need more than one hand-over
 __global__ __launch_bounds__(256) void k_classify_migrate(uint32_t n, const float4* __restrict__ pm, const uint8_t* __restrict__ owned,
                                                            float cut_lo, float cut_hi, int has_left, int has_right, uint32_t* __restrict__ key,
-                                                           uint32_t* __restrict__ val, uint32_t* __restrict__ counts)
+                                                           uint32_t* __restrict__ val, uint32_t* __restrict__ counts, float far_w)
 {
     uint32_t i = blockIdx.x * 256 + threadIdx.x;
     uint32_t cls = 4;
+    bool far = false;   // further past the cut than the narrowest slab allowed: the x-neighbour may not be its owner either
     if (i < n) {
         const float x = pm[i].x;
         if (owned && !owned[i]) cls = 3;
-        else if (has_left && x < cut_lo) cls = 1;
-        else if (has_right && !(x < cut_hi)) cls = 2;
-        else cls = 0;
+        else if (has_left && x < cut_lo) {
+            cls = 1;
+            far = x < cut_lo - far_w;
+        } else if (has_right && !(x < cut_hi)) {
+            cls = 2;
+            far = !(x < cut_hi + far_w);
+        } else cls = 0;
         key[i] = cls;
         val[i] = i;
     }
+    if (__ballot(far) != 0ull && (threadIdx.x & 63u) == 0u) atomicOr(&counts[RC_FAR], 1u);
     block_class_counts(cls, counts);
 }
 
@@ -651,10 +658,12 @@ __global__ void k_fill_u8(uint8_t* p, uint32_t n, uint8_t v)
 }
 
 // counts_round (RCCL): out[0] = to_left, out[1] = to_right, out[2] = out[3] = 0 (received below), out[4] = status,
-// out[5 .. 8] = this rank's four class counts
-__global__ void k_counts_stage(const uint32_t* __restrict__ counts, uint32_t* __restrict__ out, uint32_t status_in, int narrow_is_error)
+// out[5 .. 8] = this rank's four class counts, out[9] = its "a migrant is far" word
+__global__ void k_counts_stage(const uint32_t* __restrict__ counts, uint32_t* __restrict__ out, uint32_t status_in, int narrow_is_error,
+                               const uint32_t* __restrict__ far_word)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    out[9] = *far_word;
     out[0] = counts[1];
     out[1] = counts[2];
     out[2] = out[3] = 0u;
@@ -867,6 +876,7 @@ struct LocalComm : Comm {
             sph_ctx* c = G.m[i];
             HIPCHK(c, hipSetDevice(c->device));
             HIPCHK(c, hipMemcpy(c->dist.counts_host + base, c->dist.counts.as<uint32_t>() + base, 16, hipMemcpyDeviceToHost));
+            HIPCHK(c, hipMemcpy(c->dist.counts_host + RC_FAR, c->dist.counts.as<uint32_t>() + RC_FAR, 4, hipMemcpyDeviceToHost));
             tl[i] = c->dist.counts_host[base + 1];
             tr[i] = c->dist.counts_host[base + 2];
             if (status && base == 4 && c->dist.counts_host[base + 3] && *status < SPH_ERR_UNSUPPORTED) *status = SPH_ERR_UNSUPPORTED;
@@ -1033,7 +1043,7 @@ struct RcclComm : Comm {
         sph_ctx* c = G.m[0];
         ncclComm_t nc = (ncclComm_t)c->dist.nccl;
         const int r = c->dist.rank, nr = c->dist.nranks;
-        // device scratch behind the counters: [0 .. 7] the min-reduced floats, [8 .. 16] k_counts_stage's words
+        // device scratch behind the counters: [0 .. 7] the min-reduced floats, [8 .. 17] k_counts_stage's words
         uint32_t* d = c->dist.counts.as<uint32_t>() + 16;
         uint32_t* h = (uint32_t*)((uint8_t*)c->dist.counts_host + 64);   // pinned staging / publish destination (same words)
         const size_t nred = red ? (*red)[0].size() : 0;
@@ -1046,7 +1056,7 @@ struct RcclComm : Comm {
             NCCLCHK(c, ncclAllReduce(d, d, nred, ncclFloat32, ncclMin, nc, c->stream));
         }
         hipLaunchKernelGGL(k_counts_stage, dim3(1), dim3(64), 0, c->stream, c->dist.counts.as<uint32_t>() + base, d + 8, status ? (uint32_t)*status : 0u,
-                           base == 4 ? 1 : 0);
+                           base == 4 ? 1 : 0, c->dist.counts.as<uint32_t>() + RC_FAR);
         if (status) {
             c->dist.stat_allreduces++;
             ProfScope ps(&c->prof, "rccl_allreduce", c->stream);
@@ -1065,8 +1075,9 @@ struct RcclComm : Comm {
             }
             NCCLCHK(c, ncclGroupEnd());
         }
-        int rc = publish_and_wait(c, d, 17);
+        int rc = publish_and_wait(c, d, 18);
         if (rc) return rc;
+        c->dist.counts_host[RC_FAR] = h[17];
         for (size_t k = 0; k < nred; k++) memcpy(&(*red)[0][k], &h[k], 4);
         tl[0] = h[8];
         tr[0] = h[9];
@@ -1292,6 +1303,7 @@ struct ThreadComm : Comm {
             return rc;
         }
         HIPCHK(c, hipMemcpy(c->dist.counts_host + base, c->dist.counts.as<uint32_t>() + base, 16, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(c->dist.counts_host + RC_FAR, c->dist.counts.as<uint32_t>() + RC_FAR, 4, hipMemcpyDeviceToHost));
         tl[0] = c->dist.counts_host[base + 1];
         tr[0] = c->dist.counts_host[base + 2];
         if (status && base == 4 && c->dist.counts_host[base + 3] && *status < SPH_ERR_UNSUPPORTED) *status = SPH_ERR_UNSUPPORTED;
@@ -1571,7 +1583,8 @@ static int partition_and_migrate(Group& G, std::vector<Member>& M, std::vector<i
             ProfScope ps(&c->prof, "slab_partition", c->stream);
             hipLaunchKernelGGL(k_classify_migrate, dim3((n_prev + 255) / 256), dim3(256), 0, c->stream, n_prev, c->pm[c->pcur].as<float4>(),
                                d.have_flags ? d.owned.as<uint8_t>() : (const uint8_t*)nullptr, d.cut_lo, d.cut_hi, d.rank > 0 ? 1 : 0,
-                               d.rank + 1 < d.nranks ? 1 : 0, c->key[0].as<uint32_t>(), c->val[0].as<uint32_t>(), d.counts.as<uint32_t>());
+                               d.rank + 1 < d.nranks ? 1 : 0, c->key[0].as<uint32_t>(), c->val[0].as<uint32_t>(), d.counts.as<uint32_t>(),
+                               4.f * fmaxf(c->h_max_step, 0.f));   // every slab is at least two ghost layers (>= 8 h_max) wide
             int res = radix_sort_pairs(c->stream, &c->prof, c->key[0].as<uint32_t>(), c->val[0].as<uint32_t>(), c->key[1].as<uint32_t>(),
                                        c->val[1].as<uint32_t>(), n_prev, 2, c->sort_scratch.as<uint32_t>());
             if (res == 1) {
@@ -1601,8 +1614,8 @@ static int partition_and_migrate(Group& G, std::vector<Member>& M, std::vector<i
         // class 0 = everybody else (see block_class_counts); class 3 = ghosts of the previous step, dropped
         d.counts_host[0] = n_prev_of[i] - d.counts_host[1] - d.counts_host[2] - d.counts_host[3];
     }
-    if (moved)
-        for (size_t i = 0; i < nm; i++) (*moved)[i] = (int)(tl[i] + tr[i]);
+    if (moved)   // somebody may have to be handed on once more
+        for (size_t i = 0; i < nm; i++) (*moved)[i] = (tl[i] + tr[i]) && M[i].c->dist.counts_host[RC_FAR] ? 1 : 0;
     std::vector<Xfer> x(nm);
     for (size_t i = 0; i < nm; i++) {
         sph_ctx* c = M[i].c;
@@ -2299,7 +2312,9 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
         std::vector<int> moved(M.size(), 0);
         for (int round = 0; !slab_fused; round++) {
             if ((rc = partition_and_migrate(G, M, &moved, round == 0 && !attempt ? &red : nullptr))) return rc;
-            if (!rebalanced) break;
+            // one hand-over moves a particle to the x-neighbour; one that is further past the cut than the narrowest slab (after a
+            // re-balance; or because it crossed a slab in one step, which the fused refresh answers with this path) may need another:
+            // until no rank has such a migrant (the all-reduced flag)
             if ((rc = G.comm->allreduce_max_i32(G, moved))) return rc;
             if (moved[0] == 0 || round + 1 >= c0->dist.nranks) break;
         }

@@ -453,6 +453,56 @@ def test_sparse_edits_on_slab_contexts(product_lib):
         assert rel_err(a, b) <= tol, f
 
 
+@pytest.mark.parametrize("transport", ["loopback", "threads"])
+def test_a_particle_several_slabs_away_reaches_its_owner(product_lib, transport):
+    """One hand-over moves a particle to the x-neighbour.  A particle that is further from its slab than that -- here: set down
+    three slabs to the right by an edit; in a run: thrown across a slab by a solve that did not converge -- makes the one-round
+    refresh fall back to the general path, which hands over until nobody moves: after ONE step every particle sits on the rank
+    whose slab holds it, and the step is the single context's."""
+    scn = sc.dam_break_small(128, 32, 1 / 64)
+    pos, mass, vel = sc.init_particles(scn)
+    planes = sc.boundary_planes(scn.boundary)
+    p = forced(max_iters=3).to_ffi()
+    n, k = len(mass), 4
+    single = ffi.Context(product_lib, n, planes)
+    single.upload(mass, pos, vel)
+    thr = None
+    if transport == "threads":
+        thr = D.ThreadedGroup(product_lib, pos, mass, vel, planes, k)
+        grp, step = thr.contexts, (lambda: thr.step(p))
+    else:
+        grp = D.make_loopback_group(product_lib, pos, mass, vel, planes, k)
+        step = (lambda: ffi.group_step(grp, p))
+    try:
+        for _ in range(3):
+            single.step(p)
+            step()
+        ids0 = grp[0].download("particle_id")
+        x_hi = float(np.max(single.download("position")[:, 0]))
+        movers = [int(ids0[j]) for j in (5, len(ids0) // 2, len(ids0) - 7)]
+        # into the empty space right of the column, on the floor, a few spacings apart: rank 3's (open) slab
+        targets = [(x_hi + 0.2 + 0.05 * t, float(pos[:, 1].min()) + 0.02) for t in range(3)]
+        single.apply_edits([("set", g, dict(position=targets[t], velocity=(0.0, 0.0))) for t, g in enumerate(movers)])
+        grp[0].apply_edits([("set", int(np.nonzero(ids0 == g)[0][0]), dict(position=targets[t], velocity=(0.0, 0.0))) for t, g in enumerate(movers)])
+        for c in grp[1:]:
+            c.apply_edits([])                       # every rank makes the same sequence of calls
+        st1 = single.step(p)
+        sts = step()
+        assert all(st.dt == st1.dt for st in sts)
+        owners = {g: [r for r, c in enumerate(grp) if g in c.download("particle_id")] for g in movers}
+        assert all(v == [k - 1] for v in owners.values()), owners
+        assert sum(c.n for c in grp) == n
+        for _ in range(3):
+            st1 = single.step(p)
+            sts = step()
+            assert all(st.dt == st1.dt for st in sts)
+        for f, tol in (("position", 1e-5), ("velocity", 1e-4), ("density", 1e-5)):
+            assert rel_err(D.gather_by_id(grp, f, n), single.download(f)) <= tol, f
+    finally:
+        if thr:
+            thr.close()
+
+
 @pytest.mark.parametrize("k,level", [(2, False), (3, False), (4, False), (3, True)])
 def test_every_rank_on_its_own_thread_matches_the_loopback_group(product_lib, k, level):
     """The per-rank driver code -- what every process of a multi-GPU run executes: a group of ONE member, the rank's own counts
