@@ -397,8 +397,14 @@ int sph_set_sweep_variant(int mode);
  * Every rank makes the SAME sequence of calls with the same parameters (sph_step, sph_upload*, sph_dist_set_rebalance): which
  * collectives a step runs depends on that history (an ordinary step maintains the slabs in one round trip of counts, the first
  * step after an upload and re-balancing steps take two or more), not on anything a rank could decide alone.
- * sph_group_step steps k contexts of ONE process as ranks 0..k-1 with plain copies as transport (one GPU or
- * several): same algorithm, used to verify the decomposition against a single context. */
+ * A particle reaches its owner however far from its slab it is when a step begins (an edit set it down elsewhere, a diverged
+ * solve threw it across a slab): the hand-over to the x-neighbour repeats until nobody is further past a cut than the narrowest slab.
+ * On slabs of >= 786432 particles with a neighbour, the pressure-acceleration sweep of a Jacobi iteration runs in two launches
+ * (particles without a ghost in reach on a second stream, beside the iteration's exchange and all-reduce; then the rest): same
+ * results, SPH_OVERLAP=0 / 1 in the environment forces one form.
+ * sph_group_step steps k contexts of ONE process as ranks 0..k-1 with plain copies as transport (one GPU or several), ordered by
+ * events between the contexts' streams (no host wait inside an exchange): same algorithm, used to verify the decomposition
+ * against a single context, and the form a single-process host drives several GPUs with. */
 int  sph_dist_configure(sph_ctx* ctx, int rank, int n_ranks, float cut_lo, float cut_hi);
 /* Slab re-balancing: every `every_n_steps` steps (0 = never, the default) the cuts move to the quantiles of the particles' x
  * (x range and a 4096-bin histogram, all-reduced) so that every rank owns the same number of particles again; particles follow
