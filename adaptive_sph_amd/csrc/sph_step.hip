@@ -23,6 +23,7 @@
 #include <cstring>
 #include <condition_variable>
 #include <functional>
+#include <memory>
 #include <mutex>
 #include <vector>
 
@@ -1190,15 +1191,47 @@ struct ThreadGroup {
     std::condition_variable cv;
     int arrived = 0;
     uint64_t gen = 0;
-    bool broken = false;
-    std::vector<Xfer> xf;
+    std::atomic<bool> broken{false};
+    // a ghost / migrant exchange is point to point, as ncclSend / ncclRecv are: rank r meets only the x-neighbours it sends to or
+    // receives from (a rank with nothing for either neighbour does not enter at all).  One channel per adjacent pair (r, r + 1).
+    struct PairChan {
+        std::mutex mu;
+        std::condition_variable cv;
+        int arrived = 0;
+        uint64_t gen = 0;
+        Xfer xf[2];   // [0] the lower rank's, [1] the upper rank's
+    };
+    std::unique_ptr<PairChan[]> pair;
     std::vector<std::array<double, 6>> tot;
     std::vector<std::vector<float>> f32rows;
     std::vector<std::vector<uint32_t>> u32rows;
     std::vector<int> i32vals;
     std::vector<std::array<uint32_t, 8>> words;
     std::vector<int> op;          // which collective each rank is in (a mismatch is reported, not waited out)
-    explicit ThreadGroup(int k) : n(k), xf(k), tot(k), f32rows(k), u32rows(k), i32vals(k), words(k), op(k) {}
+    explicit ThreadGroup(int k) : n(k), pair(new PairChan[(size_t)std::max(k - 1, 1)]), tot(k), f32rows(k), u32rows(k), i32vals(k), words(k), op(k) {}
+    // the two ranks of a channel meet; false: the other one did not come (60 s) or somebody left with an error
+    bool pair_barrier(PairChan& ch)
+    {
+        std::unique_lock<std::mutex> lk(ch.mu);
+        if (broken) return false;
+        const uint64_t g = ch.gen;
+        if (++ch.arrived == 2) {
+            ch.arrived = 0;
+            ch.gen++;
+            ch.cv.notify_all();
+            return true;
+        }
+        const auto t_end = std::chrono::steady_clock::now() + std::chrono::seconds(60);
+        while (ch.gen == g && !broken) {
+            if (ch.cv.wait_until(lk, std::min(t_end, std::chrono::steady_clock::now() + std::chrono::milliseconds(50))) == std::cv_status::timeout &&
+                std::chrono::steady_clock::now() >= t_end) {
+                broken = true;
+                break;
+            }
+        }
+        if (broken) ch.cv.notify_all();
+        return ch.gen != g && !broken;
+    }
     // all ranks meet; false: somebody did not come (60 s) or left with an error
     bool barrier()
     {
@@ -1217,9 +1250,15 @@ struct ThreadGroup {
     }
     void abandon()
     {
-        std::lock_guard<std::mutex> lk(mu);
-        broken = true;
-        cv.notify_all();
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            broken = true;
+            cv.notify_all();
+        }
+        for (int i = 0; i + 1 < n; i++) {   // (the pair waits poll `broken` every 50 ms as well)
+            std::lock_guard<std::mutex> lk(pair[(size_t)i].mu);
+            pair[(size_t)i].cv.notify_all();
+        }
     }
 };
 
@@ -1344,29 +1383,52 @@ struct ThreadComm : Comm {
     int exchange(Group& G, std::vector<Xfer>& x) override
     {
         sph_ctx* c = G.m[0];
+        ThreadGroup* g = grp(G);
+        const int r = c->dist.rank;
         c->dist.stat_exchanges++;
         int rc = wait_stream(c);   // my staging buffers are packed
         if (rc) {
-            grp(G)->abandon();
+            g->abandon();
             return rc;
         }
-        return meet(G, 6, [&](ThreadGroup* g, int r) { g->xf[(size_t)r] = x[0]; },
-                    [&](ThreadGroup* g, int r) -> int {
-                        // RCCL pairs every ncclSend with an ncclRecv of the same size on the other side: the same rule, checked
-                        const Xfer zero{};
-                        const Xfer& L = r > 0 ? g->xf[(size_t)r - 1] : zero;
-                        const Xfer& R = r + 1 < g->n ? g->xf[(size_t)r + 1] : zero;
-                        if (x[0].recv_bytes[0] != L.send_bytes[1] || x[0].send_bytes[0] != L.recv_bytes[1] || x[0].recv_bytes[1] != R.send_bytes[0] ||
-                            x[0].send_bytes[1] != R.recv_bytes[0])
-                            return c->fail(SPH_ERR_DEVICE, "halo exchange sizes of rank %d do not pair up with its neighbours' (recv %zu/%zu vs sent %zu/%zu, send %zu/%zu vs expected %zu/%zu)",
-                                           r, x[0].recv_bytes[0], x[0].recv_bytes[1], L.send_bytes[1], R.send_bytes[0], x[0].send_bytes[0], x[0].send_bytes[1],
-                                           L.recv_bytes[1], R.recv_bytes[0]);
-                        c->dist.stat_bytes_sent += x[0].send_bytes[0] + x[0].send_bytes[1];
-                        c->dist.stat_bytes_recv += x[0].recv_bytes[0] + x[0].recv_bytes[1];
-                        if (x[0].recv_bytes[0]) HIPCHK(c, hipMemcpyAsync(x[0].recv[0], L.send[1], x[0].recv_bytes[0], hipMemcpyDefault, c->stream));
-                        if (x[0].recv_bytes[1]) HIPCHK(c, hipMemcpyAsync(x[0].recv[1], R.send[0], x[0].recv_bytes[1], hipMemcpyDefault, c->stream));
-                        return wait_stream(c);   // (the senders may reuse their staging buffers once everybody is past the closing barrier)
-                    });
+        // point to point, like the grouped ncclSend / ncclRecv of the RCCL transport: one rendezvous per x-neighbour this rank has
+        // something for or expects something from; RCCL pairs every send with a receive of the same size on the other side -- the
+        // same rule, checked; a neighbour that does not come is what would hang RCCL
+        for (int side = 0; side < 2; side++) {
+            const int nb = side == 0 ? r - 1 : r + 1;
+            if (nb < 0 || nb >= g->n) {
+                if (x[0].send_bytes[side] || x[0].recv_bytes[side]) return c->fail(SPH_ERR_DEVICE, "halo exchange across the outer edge of the slab row (rank %d)", r);
+                continue;
+            }
+            if (!x[0].send_bytes[side] && !x[0].recv_bytes[side]) continue;
+            ThreadGroup::PairChan& ch = g->pair[(size_t)std::min(r, nb)];
+            const int mine = r < nb ? 0 : 1;
+            {
+                std::lock_guard<std::mutex> lk(ch.mu);
+                ch.xf[mine] = x[0];
+            }
+            if (!g->pair_barrier(ch))
+                return c->fail(SPH_ERR_DEVICE, "thread transport: rank %d did not enter the exchange rank %d has %zu bytes to send to / %zu bytes to receive from it for (it would hang over RCCL)",
+                               nb, r, x[0].send_bytes[side], x[0].recv_bytes[side]);
+            const Xfer o = ch.xf[mine ^ 1];
+            const int oside = side ^ 1;   // my left neighbour's right side and vice versa
+            if (x[0].recv_bytes[side] != o.send_bytes[oside] || x[0].send_bytes[side] != o.recv_bytes[oside]) {
+                rc = c->fail(SPH_ERR_DEVICE, "halo exchange sizes of ranks %d and %d do not pair up (rank %d: send %zu recv %zu; rank %d: send %zu recv %zu)", r, nb, r,
+                             x[0].send_bytes[side], x[0].recv_bytes[side], nb, o.send_bytes[oside], o.recv_bytes[oside]);
+                g->abandon();
+                return rc;
+            }
+            c->dist.stat_bytes_sent += x[0].send_bytes[side];
+            c->dist.stat_bytes_recv += x[0].recv_bytes[side];
+            if (x[0].recv_bytes[side]) HIPCHK(c, hipMemcpyAsync(x[0].recv[side], o.send[oside], x[0].recv_bytes[side], hipMemcpyDefault, c->stream));
+            if ((rc = wait_stream(c))) {
+                g->abandon();
+                return rc;
+            }
+            // (the sender may reuse its staging buffer once both are past this)
+            if (!g->pair_barrier(ch)) return c->fail(SPH_ERR_DEVICE, "thread transport: rank %d left the exchange with rank %d early", nb, r);
+        }
+        return SPH_OK;
     }
     int allreduce_solver(Group& G, int slot) override
     {

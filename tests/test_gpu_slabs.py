@@ -541,6 +541,38 @@ def test_every_rank_on_its_own_thread_matches_the_loopback_group(product_lib, k,
         thr.close()
 
 
+def test_ranks_on_threads_exchange_point_to_point(product_lib):
+    """A collapsing column hands particles over at its right-hand cuts long before anything crosses the left-hand ones: for many steps
+    some ranks exchange migrants with one neighbour while others have nobody to send to or receive from and go straight on to the
+    ghost exchange.  That is legal point to point (ncclSend / ncclRecv pair up per neighbour) -- the thread transport meets per
+    neighbour pair, as RCCL does, and the run is the loopback group's bit for bit."""
+    from adaptive_sph_amd.workloads import dam_break_params_scaled
+    side, k = 128, 4
+    scn = sc.dam_break_small(side, side, 1.0 / side)
+    pos, mass, vel = sc.init_particles(scn)
+    planes = sc.boundary_planes(scn.boundary)
+    p = dam_break_params_scaled(1.0 / side)().to_ffi()
+    loop = D.make_loopback_group(product_lib, pos, mass, vel, planes, k)
+    thr = D.ThreadedGroup(product_lib, pos, mass, vel, planes, k)
+    try:
+        n0 = [c.n for c in loop]
+        uneven = 0
+        for s in range(60):
+            before = [c.n for c in loop]
+            a = ffi.group_step(loop, p)
+            b = thr.step(p)
+            assert all(x.dt == y.dt for x, y in zip(a, b)), s
+            changed = [c.n != m for c, m in zip(loop, before)]
+            uneven += any(changed) and not all(changed)
+        assert uneven > 0 and [c.n for c in loop] != n0      # steps in which only some ranks handed particles over
+        for ca, cb in zip(loop, thr.contexts):
+            assert ca.n == cb.n
+            for f in ("particle_id", "position", "velocity", "density"):
+                assert np.array_equal(ca.download(f), cb.download(f)), f
+    finally:
+        thr.close()
+
+
 @pytest.mark.parametrize("mode", ["rebalance", "after_advection", "from_distribution", "general_path"])
 def test_ranks_on_threads_other_step_variants(product_lib, monkeypatch, mode):
     """The same per-rank execution for the steps that take other collectives: re-balancing (x range, histogram, migration
