@@ -70,6 +70,25 @@ for seed in range(first, first + count):
             print(f"seed {seed}: n={len(mass)} k={k} {info} skipped (slab narrower than two ghost layers)", flush=True)
             continue
         msgs.append(str(e))
+    if msgs and not level and all(m.endswith(": dt") or m.split()[0] in ("position", "velocity", "density") for m in msgs):
+        # a scene that blows up under the forced three iterations amplifies the last bit of a sum: measure that on the single context
+        # (every 16th particle moved by one ulp in x: slabs change the order of every sum) and accept a slab run that is no further
+        # from it than such a twin
+        pos2 = pos.copy()
+        pos2[::16, 0] = np.nextafter(pos2[::16, 0], np.float32(10))
+        a, b = ffi.Context(lib, len(mass), planes), ffi.Context(lib, len(mass), planes)
+        a.upload(mass, pos, vel)
+        b.upload(mass, pos2, vel)
+        for step in range(6):
+            a.step(p)
+            b.step(p)
+        twin = {f: rel(a.download(f), b.download(f)) for f in ("position", "velocity", "density")}
+        mine = {f: rel(D.gather_by_id(grp, f, len(mass)), single.download(f)) for f in ("position", "velocity", "density")}
+        if all(mine[f] <= 4.0 * twin[f] + 1e-7 for f in twin):
+            msgs = []
+            info = dict(info, chaotic="a twin of the single context, every 16th particle one ulp aside, is as far: " + ", ".join(f"{f} {twin[f]:.1e} (slabs {mine[f]:.1e})" for f in twin))
+        a.close()
+        b.close()
     print(f"seed {seed}: n={len(mass)} k={k} {info} " + ("OK" if not msgs else "MISMATCH " + "; ".join(msgs)), flush=True)
     bad += bool(msgs)
 print(f"{'BAD' if bad else 'ALL OK'} ({skipped} skipped)")
