@@ -3258,6 +3258,7 @@ static int group_step(Group& G, const sph_params* p, sph_step_stats* outs)
             c->hdr_ahead = false;
             (void)hipSetDevice(c->device);
             if (c->stream2) (void)hipStreamSynchronize(c->stream2);   // a level estimation may still be running on the side stream
+            if (c->dist.xstream) (void)hipStreamSynchronize(c->dist.xstream);   // ... or the interior half of a split sweep A
         }
     return rc;
 }
