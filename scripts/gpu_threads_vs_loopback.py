@@ -2,7 +2,7 @@
 transport does) against the loopback group, in lockstep over many steps of a dam break with re-balancing -- including scenes whose solve
 diverges for a few steps (side 384: particles are thrown across slabs, the refresh falls back, the hand-over repeats).  A rank that
 takes a different branch from its peers shows up as a time-out / "different collective" error; a wrong exchange as a field that differs.
-usage: gpu_threads_vs_loopback.py [steps] [ranks] [n_side] [level]"""
+usage: gpu_threads_vs_loopback.py [steps] [ranks] [n_side] [level|plain] ["dict(param overrides)"]"""
 import os, sys
 sys.path.insert(0, __file__.rsplit("/scripts/", 1)[0])
 import numpy as np
@@ -17,6 +17,8 @@ scn = sc.dam_break_small(side, side, 1.0 / side)
 pos, mass, vel = sc.init_particles(scn)
 planes = sc.boundary_planes(scn.boundary)
 kw = dict(level_estimation_method="EmptyAngle", maximum_surface_distance=0.2, particle_radius_fine=0.5 / side, particle_radius_base=2.0 / side) if level else {}
+if len(sys.argv) > 5:
+    kw.update(eval(sys.argv[5]))
 p = dam_break_params_scaled(1.0 / side)(**kw).to_ffi()
 lib = ffi.load_product()
 A = D.make_loopback_group(lib, pos, mass, vel, planes, k)
