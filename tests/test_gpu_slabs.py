@@ -541,6 +541,68 @@ def test_every_rank_on_its_own_thread_matches_the_loopback_group(product_lib, k,
         thr.close()
 
 
+def test_ranks_that_start_empty(product_lib):
+    """Static cuts that leave two of four ranks without a single particle: an empty slab contributes zeros to the all-reduced totals,
+    takes its decisions from them, exchanges nothing -- and starts to own particles when the collapsing column reaches it.  Loopback
+    group and ranks on threads bit for bit; while the run is still regular (the first steps) also the single context's."""
+    import ctypes as C
+    from concurrent.futures import ThreadPoolExecutor
+    from adaptive_sph_amd.workloads import dam_break_params_scaled
+    side = 96
+    scn = sc.dam_break_small(side, side, 1.0 / side)
+    pos, mass, vel = sc.init_particles(scn)
+    planes = sc.boundary_planes(scn.boundary)
+    p = dam_break_params_scaled(1.0 / side)().to_ffi()
+    x_hi = float(pos[:, 0].max())
+    cuts = [-D.INF, float(np.median(pos[:, 0])), x_hi + 0.15, x_hi + 1.0, D.INF]    # ranks 2 and 3 start empty
+    k = len(cuts) - 1
+
+    def make(group):
+        ctxs = []
+        for r in range(k):
+            sel = np.nonzero((pos[:, 0] >= cuts[r]) & (pos[:, 0] < cuts[r + 1]))[0]
+            c = ffi.Context(product_lib, len(mass) + 4096, planes)
+            c.dist_configure(r, k, cuts[r], cuts[r + 1])
+            if group is not None:
+                c.comm_init_threads(group, r, k)
+            c.upload(mass[sel], pos[sel], vel[sel])
+            c.upload_field("particle_id", sel.astype(np.uint32))
+            ctxs.append(c)
+        return ctxs
+
+    group = C.c_void_p()
+    assert product_lib.thread_group_create(k, C.byref(group)) == 0
+    single = ffi.Context(product_lib, len(mass), planes)
+    single.upload(mass, pos, vel)
+    loop, thr = make(None), make(group)
+    pool = ThreadPoolExecutor(k)
+    try:
+        assert [c.n for c in loop][2:] == [0, 0]
+        for s in range(300):
+            a = ffi.group_step(loop, p)
+            b = [f.result() for f in [pool.submit(c.step, p) for c in thr]]
+            assert all(x.dt == y.dt for x, y in zip(a, b)), s
+            if s < 5:
+                st1 = single.step(p)
+                assert abs(a[0].dt - st1.dt) <= 1e-6 * st1.dt          # (CFL-limited: the sums run in another order on slabs)
+                for f, tol in (("position", 1e-5), ("density", 1e-4)):
+                    assert rel_err(D.gather_by_id(loop, f, len(mass)), single.download(f)) <= tol, (s, f)
+            if loop[2].n > 50:
+                break
+        assert loop[2].n > 50, [c.n for c in loop]                    # the third rank owns particles by now
+        assert sum(c.n for c in loop) == len(mass)
+        for ca, cb in zip(loop, thr):
+            assert ca.n == cb.n
+            if ca.n:
+                for f in ("particle_id", "position", "velocity", "density"):
+                    assert np.array_equal(ca.download(f), cb.download(f)), f
+    finally:
+        pool.shutdown(wait=True)
+        for c in thr + loop:
+            c.close()
+        product_lib.thread_group_destroy(group)
+
+
 def test_ranks_on_threads_exchange_point_to_point(product_lib):
     """A collapsing column hands particles over at its right-hand cuts long before anything crosses the left-hand ones: for many steps
     some ranks exchange migrants with one neighbour while others have nobody to send to or receive from and go straight on to the
