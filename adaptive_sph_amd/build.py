@@ -25,20 +25,47 @@ def _stale(target: Path, sources) -> bool:
     return any(Path(s).stat().st_mtime > t for s in sources)
 
 
-def build_hip(force: bool = False, verbose: bool = False) -> Path:
-    """hipcc --offload-arch=gfx950 -> adaptive_sph_amd/csrc/libsph_hip.so"""
-    out = CSRC / "libsph_hip.so"
+def build_hip(force: bool = False, verbose: bool = False, out_name: str = "libsph_hip.so") -> Path:
+    """hipcc --offload-arch=gfx950 -> adaptive_sph_amd/csrc/libsph_hip.so
+
+    Each translation unit is compiled to an object of its own (in parallel; only the stale ones), then linked: a change to
+    one kernel file costs that file's compile time, not the library's.  SPH_EXTRA_HIPCC_FLAGS (variants, scripts/variants)
+    goes to every compile; objects are kept under csrc/build/<hash of the flags>."""
+    import hashlib
+    from concurrent.futures import ThreadPoolExecutor
+    out = CSRC / out_name   # (variants are built HERE, next to the product library, and selected with SPH_HIP_LIBRARY: ffi.py)
     srcs = sorted(CSRC.glob("*.hip"))
-    deps = srcs + sorted(CSRC.glob("*.h")) + sorted(CSRC.glob("*.hpp")) + [REPO / "include" / "sph_ffi.h"]
-    if not force and not _stale(out, deps):
+    headers = sorted(CSRC.glob("*.h")) + sorted(CSRC.glob("*.hpp")) + [REPO / "include" / "sph_ffi.h"]
+    extra = os.environ.get("SPH_EXTRA_HIPCC_FLAGS", "").split()
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall",
+             "-I", str(REPO / "include")] + extra
+    tag = hashlib.sha1(" ".join(flags).encode()).hexdigest()[:10]
+    objdir = CSRC / "build" / tag
+    objdir.mkdir(parents=True, exist_ok=True)
+    stamp = objdir / ("linked-" + out_name)   # which flag set that .so was linked from
+    objs = [objdir / (s.stem + ".o") for s in srcs]
+    todo = [(s, o) for s, o in zip(srcs, objs) if force or _stale(o, [s] + headers)]
+    if not todo and out.exists() and stamp.exists() and not _stale(out, objs) and not _stale(stamp, [out]):
         return out
-    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-ffp-contract=off", "-fno-fast-math", "-fgpu-rdc=0" if False else "-Wall",
-           "-I", str(REPO / "include"), "-o", str(out)] + os.environ.get("SPH_EXTRA_HIPCC_FLAGS", "").split() + [str(s) for s in srcs] + ["-L/opt/rocm/lib", "-lrccl"]
-    cmd = [c for c in cmd if c]
+
+    def compile_one(so):
+        s, o = so
+        cmd = [hipcc_path()] + flags + ["-c", str(s), "-o", str(o)]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {s.name}:\n" + r.stdout + r.stderr)
+
+    with ThreadPoolExecutor(max_workers=min(len(todo), os.cpu_count() or 4) or 1) as ex:
+        list(ex.map(compile_one, todo))
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(out)] + [str(o) for o in objs] + ["-L/opt/rocm/lib", "-lrccl"]
     if verbose:
-        print(" ".join(cmd))
+        print(" ".join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
+        raise RuntimeError("link failed:\n" + r.stdout + r.stderr)
+    for other in (CSRC / "build").glob("*/linked-" + out_name):
+        other.unlink()
+    stamp.write_text("")
     return out

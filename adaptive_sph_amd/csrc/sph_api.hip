@@ -1026,6 +1026,50 @@ extern "C" int sph_profile_copy_bandwidth(sph_ctx* c, uint64_t bytes, double* gb
     return SPH_OK;
 }
 
+// list words of the last step by form (measurement hook): NL_OK 0x80000000, NL_WALL 0x40000000, NL_IDX 0x20000000 (sph_sweeps.hip)
+__global__ __launch_bounds__(256) void k_list_forms(uint32_t n, const uint4* __restrict__ nl, const uint8_t* __restrict__ owned, const uint8_t* __restrict__ ring1,
+                                                     unsigned long long* __restrict__ out)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    const bool on = i < n && (!owned || owned[i] || (ring1 && ring1[i]));
+    const uint32_t w = on ? nl[i].w : 0u;
+    const unsigned long long b_on = __ballot(on), b_ok = __ballot(on && (w & 0x80000000u)), b_ix = __ballot(on && !(w & 0x80000000u) && (w & 0x20000000u)),
+                             b_wall = __ballot(on && (w & 0x40000000u));
+    if ((threadIdx.x & 63) == 0 && b_on) {
+        const unsigned long long c_on = __popcll(b_on), c_ok = __popcll(b_ok), c_ix = __popcll(b_ix);
+        atomicAdd(&out[0], c_on);
+        atomicAdd(&out[1], c_ok);
+        atomicAdd(&out[2], c_ix);
+        atomicAdd(&out[3], c_on - c_ok - c_ix);
+        atomicAdd(&out[4], (unsigned long long)__popcll(b_wall));
+    }
+}
+
+extern "C" int sph_profile_list_forms(sph_ctx* c, sph_list_forms* out)
+{
+    if (!c || !out) return SPH_ERR_INVALID_ARGUMENT;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->grid_valid) return c->fail(SPH_ERR_INVALID_ARGUMENT, "no neighbour lists yet: run a step first");
+    const uint32_t n = c->dist.on && c->dist.have_flags ? c->dist.n_tot : (uint32_t)c->n;
+    DevBuf acc;
+    HIPCHK(c, acc.ensure(5 * sizeof(unsigned long long)));
+    HIPCHK(c, hipMemsetAsync(acc.p, 0, 5 * sizeof(unsigned long long), c->stream));
+    const bool flags = c->dist.on && c->dist.have_flags;
+    if (n)
+        hipLaunchKernelGGL(k_list_forms, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, c->nl.as<uint4>(), flags ? c->dist.owned.as<uint8_t>() : nullptr,
+                           flags ? c->dist.ring1.as<uint8_t>() : nullptr, acc.as<unsigned long long>());
+    unsigned long long h[5] = {0, 0, 0, 0, 0};
+    HIPCHK(c, hipMemcpyAsync(h, acc.p, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    acc.release();
+    out->n_lists = h[0];
+    out->n_mask = h[1];
+    out->n_index = h[2];
+    out->n_walk = h[3];
+    out->n_wall = h[4];
+    return SPH_OK;
+}
+
 extern "C" int sph_download_neighbors(sph_ctx* c, uint32_t* offsets, uint32_t* indices, uint64_t cap, uint64_t* n_indices)
 {
     if (!c) return SPH_ERR_INVALID_ARGUMENT;

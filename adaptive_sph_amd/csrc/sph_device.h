@@ -204,13 +204,19 @@ __device__ __forceinline__ float h_from_mass(float mass, float rest_density)
 }
 
 // stencil half-width in cells that is guaranteed to cover every j with |x_ij| < (h_i + h_j) * 0.5 * k (k = 2: the
-// SPH support; k = level_estimation_range / ETA: the extended lists of the level estimation): such a j is closer
-// than (h_i + hmax) * 0.5 * k, hence at most floor(that / cs) + 1 cells away on either axis
+// SPH support; k = level_estimation_range / ETA: the extended lists of the level estimation): such a j is STRICTLY closer
+// than S = (h_i + hmax) * 0.5 * k, hence at most ceil(S / cs) cells away on either axis -- floor(S / cs) + 1, less one
+// when S is a whole number of cells.  That case is the common one, not a corner: the sorting grid's cell IS the support of
+// the smallest particle (cs = 2 h_min), so a fine particle among fine ones has S == cs and a 3 x 3 stencil, exactly what the
+// uniform path (and the reference's own CellGrid, cell = support of the largest particle, 3 x 3 cells) relies on.
 __device__ __forceinline__ int stencil_radius(const GridP& g, const TileP& t, float h_i, int cx, int cy, float k)
 {
     float hn = h_i;   // uniform scene: every h is h_i
     if (t.ts > 0) hn = __uint_as_float(t.hmax[(uint32_t)(cy / t.ts) * (uint32_t)t.tsx + (uint32_t)(cx / t.ts)]);
-    return (int)floorf(((h_i + hn) * 0.5f * k + t.slack) / g.cs) + 1;
+    const float S = (h_i + hn) * 0.5f * k + t.slack;
+    int R = (int)floorf(S / g.cs) + 1;
+    if (R > 1 && (float)(R - 1) * g.cs >= S) R--;
+    return R;
 }
 
 // Sdf2D::probe = find_min_dist_object + to_dist_and_dir (sdf/sdf2d.rs:77-160, 196-228), IEEE operations in the

@@ -14,7 +14,9 @@ from pathlib import Path
 import numpy as np
 
 PKG_DIR = Path(__file__).resolve().parent
-PRODUCT_LIB = PKG_DIR / "csrc" / "libsph_hip.so"
+# SPH_HIP_LIBRARY: another build of the SAME sources next to the product library (scripts/variants: compile-time switches,
+# prebuilt where hipcc is, timed on the GPU box) -- a file name inside csrc/, never a path to anything else
+PRODUCT_LIB = PKG_DIR / "csrc" / os.path.basename(os.environ.get("SPH_HIP_LIBRARY", "libsph_hip.so"))
 
 # ---- enums (include/sph_ffi.h; names follow simulation_parameters.rs) ---------------------------
 VISCOSITY_TYPE = {"WCSPH": 0, "ApproxLaplace": 1, "XSPH": 2}
@@ -132,6 +134,10 @@ class SphDistStats(C.Structure):
                 ("n_ghost", C.c_uint32 * 2)]
 
 
+class SphListForms(C.Structure):
+    _fields_ = [("n_lists", C.c_uint64), ("n_mask", C.c_uint64), ("n_index", C.c_uint64), ("n_walk", C.c_uint64), ("n_wall", C.c_uint64)]
+
+
 class SphError(RuntimeError):
     """Non-zero status from the library == a panic!/assert! of the reference step."""
 
@@ -143,7 +149,7 @@ class SphError(RuntimeError):
 # every symbol include/sph_ffi.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
     "create", "destroy", "upload", "upload_field", "download", "download_neighbors", "num_particles", "time",
-    "set_time", "step", "classify", "share_particles", "merge_particles", "set_split_patterns", "split_particles", "host_find_partners", "last_error", "grid", "set_boundary_polygon", "apply_edits", "profile_enable", "profile_reset", "profile_get", "profile_event_overhead", "profile_copy_bandwidth", "set_sweep_variant",
+    "set_time", "step", "classify", "share_particles", "merge_particles", "set_split_patterns", "split_particles", "host_find_partners", "last_error", "grid", "set_boundary_polygon", "apply_edits", "profile_enable", "profile_reset", "profile_get", "profile_event_overhead", "profile_copy_bandwidth", "profile_list_forms", "set_sweep_variant",
     "dist_configure", "dist_set_rebalance", "dist_get_cuts", "dist_get_stats", "comm_unique_id", "comm_init", "group_step", "thread_group_create", "thread_group_destroy", "comm_init_threads",
 ]
 
@@ -201,6 +207,7 @@ class SphLibrary:
         self.profile_get = sig("profile_get", i32, [vp, C.POINTER(SphKernelTime), i32, C.POINTER(i32)], required=False)
         self.profile_event_overhead = sig("profile_event_overhead", i32, [vp, C.POINTER(C.c_double)], required=False)
         self.profile_copy_bandwidth = sig("profile_copy_bandwidth", i32, [vp, u64, C.POINTER(C.c_double)], required=False)
+        self.profile_list_forms = sig("profile_list_forms", i32, [vp, C.POINTER(SphListForms)], required=False)
         self.set_sweep_variant = sig("set_sweep_variant", i32, [i32], required=False)
         self.comm_unique_id = sig("comm_unique_id", i32, [C.POINTER(C.c_uint8)], required=False)
         self.comm_init = sig("comm_init", i32, [vp, C.POINTER(C.c_uint8), i32, i32], required=False)
@@ -410,6 +417,12 @@ class Context:
         v = C.c_double(0.0)
         self._check(self.lib.profile_copy_bandwidth(self.handle, int(nbytes), C.byref(v)))
         return float(v.value)
+
+    def profile_list_forms(self) -> dict:
+        """How the last step recorded its neighbour lists: {"n_lists", "n_mask", "n_index", "n_walk", "n_wall"} (sph_list_forms)."""
+        st = SphListForms()
+        self._check(self.lib.profile_list_forms(self.handle, C.byref(st)))
+        return {k: int(getattr(st, k)) for k, _ in SphListForms._fields_}
 
     def profile_event_overhead_us(self) -> float:
         v = C.c_double(0.0)

@@ -148,9 +148,18 @@ def main():
         os.write(real_stdout, (line + "\n").encode())
 
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started by itself (`python bench.py --gpus N`): become the launcher -- one rank per GPU through torch.distributed.run on
+        # this node, rendezvous on 127.0.0.1 and a free port; the ranks are this same script with the same flags
+        import socket
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        os.dup2(real_stdout, 1)
+        os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+                                  "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:])
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"bench.py --gpus {args.gpus} was launched with WORLD_SIZE={world}: one rank per GPU")
     import torch
     import torch.distributed as dist
     if torch.cuda.is_available():

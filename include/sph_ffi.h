@@ -375,6 +375,14 @@ int  sph_profile_event_overhead(sph_ctx* ctx, double* microseconds);
 /* bandwidth of a plain float4 copy kernel over `bytes` of device memory (read + write, GB/s, best of 5): the achievable
  * HBM rate on this device, reported next to the 8 TB/s spec peak */
 int  sph_profile_copy_bandwidth(sph_ctx* ctx, uint64_t bytes, double* gb_per_s);
+/* which form the neighbour lists of the LAST step were recorded in (counted over the list words the density sweep wrote:
+ * owned particles and, on a slab, the first ghost ring): row masks (3 x 3 cells of the sorting grid, <= 32 candidates per row:
+ * 16 B per particle, replayed without index loads), explicit index lists (particles next to larger ones, or crowded rows), or
+ * neither (> 128 neighbours: the candidates are walked in every sweep) */
+typedef struct sph_list_forms {
+    uint64_t n_lists, n_mask, n_index, n_walk, n_wall;   /* n_wall: particles with boundary terms (either form) */
+} sph_list_forms;
+int  sph_profile_list_forms(sph_ctx* ctx, sph_list_forms* out);
 
 /* Which form of the neighbour sweeps runs in uniform-h scenes (process-wide; both forms give bit-identical results, the
  * ablation harness scripts/variants/ times them): bit 0 = the density / list-building sweep, bit 1 = the list-replaying sweeps

@@ -171,3 +171,23 @@ def quadtree_scene(seed):
     mass = (np.float32(0.93) * sizes * sizes).astype(np.float32)
     vel = (rng.normal(0, 0.05, pos.shape)).astype(np.float32)
     return pos, mass, vel, dict(levels=levels, kind=kind, s_max=s_max)
+
+
+def displacement_bars(x_gpu, x_oracle, x0, rel=1e-3):
+    """Positions compared through the DISPLACEMENT from the uploaded positions x0 -- relative to max|x| (~2) a bar of 1e-4 is
+    0.2 mm absolute, more than a particle at rest-lattice spacing 1/1024 moves in the first steps, so that bar alone cannot fail.
+    Two figures, both against `rel` x the oracle's own displacement plus ONE ulp of the largest coordinate (positions are f32: two
+    correct integrations may round a coordinate to neighbouring floats, and that quantum is 2e-3 of a 6e-5 displacement):
+      * max over the particles of |dx_gpu - dx_oracle|  vs  rel * max|dx_oracle|  (the fastest particles)
+      * median of the same                              vs  rel * median|dx_oracle|  (the bulk, which the ejected corners do not hide)
+    Returns (ok, report); `report` carries the numbers for the assertion message.  A kernel that never moved a particle has
+    error == displacement and fails both by three orders of magnitude."""
+    xg, xo, x0 = (np.asarray(a, np.float64) for a in (x_gpu, x_oracle, x0))
+    dg, do = xg - x0, xo - x0
+    err = np.abs(dg - do).max(axis=1)
+    mag = np.abs(do).max(axis=1)
+    ulp = float(np.spacing(np.float32(np.abs(xo).max())))
+    rep = {"max_err": float(err.max()), "max_disp": float(mag.max()), "median_err": float(np.median(err)), "median_disp": float(np.median(mag)), "ulp": ulp}
+    meaningful = rep["max_disp"] > 50 * ulp and rep["median_disp"] > 10 * ulp      # the scene moved by more than rounding
+    ok = meaningful and rep["max_err"] <= rel * rep["max_disp"] + ulp and rep["median_err"] <= rel * rep["median_disp"] + ulp
+    return ok, rep

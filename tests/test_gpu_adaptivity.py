@@ -203,6 +203,95 @@ def test_config4_ratio_stress_4m_adaptive_steps(product_lib):
     sim.single_step_without_adaptivity(P)                   # and the edited vector steps
 
 
+def test_config4_first_adaptive_steps_with_the_oracles_decisions(product_lib, oracle_lib):
+    """BASELINE configs[4] at its full 4 004 343 particles, the adaptive half checked against the ORACLE (the invariants of the test
+    above cannot tell a wrong transfer from a right one): both sides step once (iteration counts pinned), then run
+    single_step_adaptivity of an odd step (simulation.rs:2732-2796: share, then split) and, after a second step, of an even one
+    (share, then merge) with the partner DECISIONS taken once, from the oracle's state, and applied to both sides -- the device's
+    gather-form transfers, closed-form deletion order and appended children against oracle/adapt.c's statement-by-statement
+    share_particles / merge_particles / split_particles on 4M particles."""
+    scene_f, params_f, _ = WORKLOADS["ratio_stress_4m"]
+    scn = scene_f()
+    r_fine = float(np.sqrt(np.float32(0.0004385) ** 2 * 0.93 / np.pi))
+    P = params_f(level_estimation_method="EmptyAngle", merging=True, sharing=True, splitting=True, particle_radius_fine=r_fine,
+                 particle_radius_base=50 * r_fine, maximum_surface_distance=0.3, max_iters=3, iisph_max_avg_density_error=0.0)
+    sp = A.SplitPatterns.load_from_file(PATTERNS)
+    pos, mass, vel = sc.init_particles(scn)
+    planes = sc.boundary_planes(scn.boundary, P.init_boundary_handler)
+    g, o = ffi.Context(product_lib, 6000000, planes), ffi.Context(oracle_lib, 6000000, planes)
+    for c in (g, o):
+        c.upload(mass, pos, vel)
+        c.set_split_patterns(sp.patterns)
+    p = P.to_ffi()
+    m0 = float(mass.sum(dtype=np.float64))
+
+    def decide(kind, dt):
+        """classes and partners from the ORACLE's state; the device gets the oracle's level field and classes, so that both sides
+        round num_children = round(mass / target_mass) and test `TooLarge` on identical inputs"""
+        o.classify(p)
+        cls = o.download("particle_size_class")
+        g.upload_field("particle_size_class", cls)
+        if kind == "split":
+            g.upload_field("level_estimation", o.download("level_estimation"))
+            return cls, None, None
+        mp, mc = A.find_partners_native(product_lib, kind, cls, o.download("mass"), o.download("level_estimation"), o.download("position"),
+                                        o.download("h2"), *lists, P, dt)
+        return cls, mp, mc
+
+    def same(tol=1e-5):
+        assert g.n == o.n
+        for f in ("mass", "position", "velocity", "h2_next"):
+            assert rel_err(g.download(f), o.download(f)) < tol, f
+        a, b = g.download("level_estimation"), o.download("level_estimation")
+        assert np.array_equal(np.isnan(a), np.isnan(b))
+        assert np.nanmax(np.abs(a - b)) <= 1e-4 * max(np.nanmax(np.abs(b)), 1e-30)
+
+    # ---- step 1 (odd): share, then split
+    sg, so = g.step(p), o.step(p)
+    assert abs(sg.dt - so.dt) <= 1e-6 * so.dt and int(so.step_number) == 1
+    dt = float(so.dt)
+    ap = A.adapt_params(P, dt)
+    lists = o.download_neighbors()
+    cls, mp, mc = decide("share", dt)
+    n_share = int(mc.sum())
+    for c in (g, o):
+        c.share_particles(p, ap, mp, mc)
+    same()
+    cls, _, _ = decide("split", dt)
+    n0 = o.n
+    for c in (g, o):
+        c.split_particles(p, ap)
+    assert g.n == o.n > n0                                   # the coarse surface particles split
+    same()
+    assert np.array_equal(g.download("particle_size_class"), o.download("particle_size_class"))
+    # ---- step 2 (even): share, then merge -- on the vector the first adaptive step left behind
+    sg, so = g.step(p), o.step(p)
+    assert abs(sg.dt - so.dt) <= 1e-5 * so.dt and int(so.step_number) == 2
+    assert (g.download("neighbor_count") != o.download("neighbor_count")).mean() < 1e-3
+    assert rel_err(g.download("density"), o.download("density")) < 1e-3
+    dt = float(so.dt)
+    ap = A.adapt_params(P, dt)
+    lists = o.download_neighbors()
+    cls, mp, mc = decide("share", dt)
+    n_share += int(mc.sum())
+    for c in (g, o):
+        c.share_particles(p, ap, mp, mc)
+    same(1e-4)
+    cls, mp, mc = decide("merge", dt)
+    n_merge = int(mc.sum())
+    n1 = o.n
+    for c in (g, o):
+        c.merge_particles(p, ap, mp, mc)
+    assert g.n == o.n < n1 and n_merge > 1000               # the bulk of the fine block merges
+    same(1e-4)
+    assert n_share >= 0
+    for c in (g, o):
+        assert abs(float(c.download("mass").sum(dtype=np.float64)) - m0) < 1e-4 * m0
+    sg, so = g.step(p), o.step(p)                            # and both edited vectors step
+    assert abs(sg.dt - so.dt) <= 1e-4 * so.dt
+    assert rel_err(g.download("density"), o.download("density")) < 2e-3
+
+
 def test_adaptive_run_on_a_slab_group(product_lib):
     """single_step = step + single_step_adaptivity on a 2-rank slab group (distributed.group_single_step_adaptivity: the ranks'
     particles and neighbour lists gathered in global index order, the decisions and the device-side share / merge / split on ONE

@@ -13,6 +13,7 @@ import pytest
 
 from adaptive_sph_amd import distributed as D, ffi, scene as sc
 from adaptive_sph_amd.workloads import WORKLOADS
+from tests.oracle_harness import displacement_bars
 
 pytestmark = pytest.mark.gpu
 
@@ -49,7 +50,13 @@ def make_pair(product_lib, oracle_lib, name, **overrides):
     g, o = ffi.Context(product_lib, len(mass), planes), ffi.Context(oracle_lib, len(mass), planes)
     g.upload(mass, pos, vel)
     o.upload(mass, pos, vel)
+    g.pos0 = pos
     return g, o, P
+
+
+def assert_displacements(g, o):
+    ok, rep = displacement_bars(g.download("position"), o.download("position"), g.pos0)
+    assert ok, rep
 
 
 def test_config3_dam_break_8m_against_the_oracle(product_lib, oracle_lib):
@@ -69,6 +76,7 @@ def test_config3_dam_break_8m_against_the_oracle(product_lib, oracle_lib):
     for f in ("position", "density", "aii", "ppe_source_term"):
         assert rel_err(g.download(f), o.download(f)) < REL_TOL_FIELDS, f
     assert rel_err(g.download("velocity"), o.download("velocity")) < 1e-3     # carries the unconverged (3 iterations) pressure field
+    assert_displacements(g, o)
 
 
 def test_config3_dam_break_8m_eight_slabs_against_the_single_context(product_lib):
@@ -154,6 +162,7 @@ def test_config4_ratio_stress_4m_against_the_oracle(product_lib, oracle_lib):
     assert 0 < o.download("flag_is_fluid_surface").sum() < g.n
     for f in ("position", "density", "aii", "ppe_source_term", "velocity"):
         assert rel_err(g.download(f), o.download(f)) < REL_TOL_FIELDS, f
+    assert_displacements(g, o)
     for f in ("level_estimation", "level_old"):
         a, b = g.download(f), o.download(f)
         assert np.array_equal(np.isnan(a), np.isnan(b)), f
@@ -161,6 +170,9 @@ def test_config4_ratio_stress_4m_against_the_oracle(product_lib, oracle_lib):
     g.classify(p), o.classify(p)
     cg, co = g.download("particle_size_class"), o.download("particle_size_class")
     assert (cg != co).mean() < 1e-3
+    # 4M fine particles far from the 1575 coarse ones: 3 x 3 stencils of the fine grid, row masks (sph_list_forms)
+    forms = g.profile_list_forms()
+    assert forms["n_lists"] == g.n and forms["n_mask"] >= 0.9 * g.n and forms["n_walk"] == 0, forms
 
 
 def test_config4_ratio_stress_4m_blocks_in_contact(product_lib, oracle_lib):
@@ -186,3 +198,5 @@ def test_config4_ratio_stress_4m_blocks_in_contact(product_lib, oracle_lib):
     same_sets(g, o)
     for f in ("position", "density", "aii"):
         assert rel_err(g.download(f), o.download(f)) < REL_TOL_FIELDS, f
+    ok, rep = displacement_bars(g.download("position"), o.download("position"), pos)
+    assert ok, rep

@@ -15,7 +15,7 @@ import pytest
 
 from adaptive_sph_amd import ffi, scene as sc
 from adaptive_sph_amd.workloads import dam_break_params, default_params
-from tests.oracle_harness import csr_sets, quadtree_scene, rings_and_block_scene
+from tests.oracle_harness import csr_sets, displacement_bars, quadtree_scene, rings_and_block_scene
 
 pytestmark = pytest.mark.gpu
 GOLD = Path(__file__).resolve().parent / "golden"
@@ -50,7 +50,14 @@ def make_pair(product_lib, oracle_lib, scn, handler="AnalyticOverestimate"):
     o = ffi.Context(oracle_lib, len(mass), planes)
     g.upload(mass, pos, vel)
     o.upload(mass, pos, vel)
+    g.pos0 = pos
     return g, o
+
+
+def assert_displacements(g, o, rel=1e-3):
+    """positions through the displacement from the uploaded ones (tests/oracle_harness.py): the bar that can fail"""
+    ok, rep = displacement_bars(g.download("position"), o.download("position"), g.pos0, rel)
+    assert ok, rep
 
 
 def assert_same_neighbor_sets(g, o):
@@ -668,6 +675,49 @@ def test_full_size_parity_1m_against_the_oracle(product_lib, oracle_lib):
     # the corner particles are ejected at ~20 m/s in these steps by an unconverged (4 forced iterations) pressure field,
     # whose summation-order sensitivity is the documented 2e-3 (TOL): v += dt a^p carries it
     assert rel_err(g.download("velocity"), o.download("velocity")) < 1e-3
+    assert_displacements(g, o)
+
+
+def test_bench_window_of_config1_against_the_oracle(product_lib, oracle_lib):
+    """The window bench.py's driver flags time (--warmup 5 --steps 20 = steps 0..24 of BASELINE configs[1] from rest), FREE-RUNNING
+    on both sides: configs[1]'s own tolerances, no forced iteration counts -- 25 steps of the 1 048 576-particle scene on the device
+    and on the oracle, every step compared.
+      * dt of every step within 1e-5 relative; iteration counts of BOTH solves within +-1 in every step (the stop rule of
+        simulation.rs:1453-1479 compares an average residual with a threshold: two summation orders may stop one iteration apart);
+      * while every count so far agreed EXACTLY the two sides ran the same arithmetic: density within 1e-4, displacement from the
+        uploaded positions within 1e-3 (tests/oracle_harness.displacement_bars) at that step;
+      * after the first differing count the trajectories differ by what one damped-Jacobi iteration changes in the violent
+        first steps: stated bars density 2e-3, displacement 2e-2 at the end of the window, counts still within +-1."""
+    scn = sc.dam_break_1m()
+    g, o = make_pair(product_lib, oracle_lib, scn)
+    assert g.n == 1048576
+    p = dam_break_params().to_ffi()
+    rows, agree = [], True
+    for s in range(25):
+        sg, so = g.step(p), o.step(p)
+        row = {"step": s, "dt_rel": abs(sg.dt - so.dt) / so.dt, "div": (int(sg.div_solver.iters), int(so.div_solver.iters)),
+               "dens": (int(sg.density_solver.iters), int(so.density_solver.iters))}
+        agree = agree and row["div"][0] == row["div"][1] and row["dens"][0] == row["dens"][1]
+        row["agree_so_far"] = agree
+        if agree or s == 24:
+            row["rho_err"] = rel_err(g.download("density"), o.download("density"))
+            row["disp_ok"], row["disp"] = displacement_bars(g.download("position"), o.download("position"), g.pos0, 1e-3 if agree else 2e-2)
+        rows.append(row)
+    report = "\n".join(str(r) for r in rows)
+    try:   # (kept with the run's other outputs when the suite runs under gpurun)
+        (Path(__file__).resolve().parent.parent / "gpurun_out").mkdir(exist_ok=True)
+        (Path(__file__).resolve().parent.parent / "gpurun_out" / "bench_window_parity.txt").write_text(report + "\n")
+    except OSError:
+        pass
+    for r in rows:
+        assert r["dt_rel"] <= 1e-5, report
+        assert abs(r["div"][0] - r["div"][1]) <= 1 and abs(r["dens"][0] - r["dens"][1]) <= 1, report
+        if r["agree_so_far"]:
+            assert r["rho_err"] <= REL_TOL_FIELDS and r["disp_ok"], report
+    assert sum(r["agree_so_far"] for r in rows) >= 3, report             # the comparison of identical arithmetic covered something
+    assert rows[-1]["rho_err"] <= 2e-3 and rows[-1]["disp_ok"], report
+    # the window is the violent one: the driver's line quotes ~11 + ~9 iterations per step on it
+    assert np.mean([r["div"][1] + r["dens"][1] + 2 for r in rows[5:]]) > 10, report
 
 
 def test_full_size_parity_adaptive_4to1_against_the_oracle(product_lib, oracle_lib):
@@ -695,6 +745,12 @@ def test_full_size_parity_adaptive_4to1_against_the_oracle(product_lib, oracle_l
                               np.bincount(seg, weights=oi.astype(np.float64) ** power, minlength=g.n)), power
     for f in ["position", "density", "aii", "ppe_source_term"]:
         assert rel_err(g.download(f), o.download(f)) < REL_TOL_FIELDS, f
+    assert_displacements(g, o)
+    # the sorting grid's cell is the support of the FINE particles: a fine particle away from the coarse block has a 3 x 3
+    # stencil and records row masks like a uniform scene (sph_list_forms); index lists only near the coarse particles
+    forms = g.profile_list_forms()
+    assert forms["n_lists"] == g.n and forms["n_mask"] >= 0.9 * g.n, forms
+    assert forms["n_walk"] == 0, forms
 
 
 @pytest.mark.parametrize("mode", ["FromMass", "FromDistributionClamped1"])
