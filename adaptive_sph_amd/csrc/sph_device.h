@@ -158,12 +158,15 @@ struct MathExact {
 struct MathFast {
     static constexpr bool EXACT = false, UNIFORM = false;
     float h;  // unused
+    // one reciprocal per pair (a transcendental issues at a quarter of the rate of a multiply, scripts/ubench/valu_issue.hip):
+    // 1 / (2 h_ij) and the normalisation 10 / (7 pi h_ij^2) = (40 / (7 pi)) (1 / (2 h_ij))^2 both come from it
     __device__ __forceinline__ float w(float r2, float hij) const
     {
         SPH_PAIR_CONTRACT
         float r = fast_sqrt(r2);
-        float nf = 10.f * fast_rcp(SPH_SEVEN_PI * (hij * hij));
-        return nf * cubic_fast(r * fast_rcp(2.f * hij));
+        float inv2h = fast_rcp(2.f * hij);
+        float nf = (40.f / SPH_SEVEN_PI) * (inv2h * inv2h);
+        return nf * cubic_fast(r * inv2h);
     }
     __device__ __forceinline__ void grad(float dx, float dy, float r2, float hij, float& gx, float& gy) const
     {
@@ -172,7 +175,7 @@ struct MathFast {
         float r = r2 * rinv;
         float inv2h = fast_rcp(2.f * hij);
         float q = r * inv2h;
-        float nf = 10.f * fast_rcp(SPH_SEVEN_PI * (hij * hij));
+        float nf = (40.f / SPH_SEVEN_PI) * (inv2h * inv2h);
         float s = nf * cubic_deriv_fast(q) * inv2h * rinv;
         s = (q > 1.0e-5f) ? s : 0.f;  // also covers r2 == 0 (rinv = inf, r = nan)
         gx = s * dx;

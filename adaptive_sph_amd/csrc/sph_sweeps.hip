@@ -1960,6 +1960,219 @@ struct OpLevelPropagate {
     }
 };
 
+// ------------------------------------------------------------------------------------------------
+// The WHOLE propagation in one launch.  A propagation is ~100 sweeps with a few thousand working particles each; launched one
+// by one, a sweep costs its dispatch (4096 workgroups that mostly read two words and leave) plus the chain of dependent,
+// cache-cold accesses of a few frontier lanes: 14 us per sweep, 1.5 of the 2.2 ms of a step with level estimation at N = 1M
+// (profiles/r2i_level_1m_kernel_summary.md).  Here <= 256 resident workgroups (one per CU) keep the sweep loop on the device:
+//   * block b owns the slots [b << shift, (b + 1) << shift) of the cell-sorted array and evaluates the candidates among them;
+//   * what a sweep reads of other blocks -- (level, when) of neighbours, the marks neighbours set -- comes from the blocks whose
+//     slots its particles' stencils reach (index ranges of the cell rows around them: blocks [blo, bhi], found once in the
+//     prologue).  A block therefore waits, before sweep t, only for THOSE blocks to have finished sweep t - 1 (one progress word
+//     per block), not for a grid barrier: neighbours run in lockstep, blocks far apart drift by as many sweeps as lie between them.
+//     The data is exchanged with agent-scope (sc1) loads and stores, which the L2s serve coherently -- no fences, no L1 lines to
+//     invalidate (MI355X_MICROARCH.md, inter-workgroup visibility: sc1 payload -> s_waitcnt vmcnt(0) in every storing wave ->
+//     sc1 flag).  `when` makes running ahead harmless: a value written by a later sweep fails the `when < t` test.
+//   * the end of the loop -- the first sweep in which NO block assigned a value above the bound (OpLevelPropagate::useful_above) --
+//     is seen lazily: every block adds (1 << 32 | assigned-something) to stat[t] when it finishes sweep t and leaves once it
+//     finds a complete stat[t'] without assignments.  The sweeps a block runs beyond that one assign nothing or values below
+//     the bound, which the smoothing clamps to the bound like the unassigned (simulation.rs:826-832): same outputs.
+// Every spin is bounded (2 s): a block that never shows up raises SPH_ERR_DEVICE instead of hanging the device.
+// Candidates with an index list (every particle of the extended-range lists) are evaluated 32 neighbours at a time, all index
+// words, then all (when, level, position) gathers in flight at once: three dependent round trips per candidate instead of two per
+// group of four.  Same values as the per-sweep launches (`max` over the same set), bit for bit.
+// ------------------------------------------------------------------------------------------------
+#define LP_THREADS 256
+#define LP_MAX_BLOCKS 256
+#define LP_TMAX 16384u
+struct LevelSync {                          // device memory, zeroed before every launch
+    uint32_t prog[LP_MAX_BLOCKS];           // prog[b] = t + 1 once block b has finished sweep t; 0xffffffff: it has left
+    uint32_t result[8];                     // [0] first sweep without an assignment above the bound, [1] 1 = LP_TMAX reached, [2] spin time-outs
+    unsigned long long stat[LP_TMAX];       // per sweep: blocks finished << 32 | blocks that assigned something above the bound
+};
+size_t level_sync_bytes() { return sizeof(LevelSync); }
+#define LP_LD(P) __hip_atomic_load((P), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define LP_ST(P, V) __hip_atomic_store((P), (V), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+
+// the propagation op with agent-scope accesses to everything another block writes during the launch (level, when, marks)
+template <class MathT>
+struct OpLevelPropagateP : OpLevelPropagate<MathT> {
+    typedef OpLevelPropagate<MathT> B;
+    typedef typename B::Acc Acc;
+    typedef NBLevel NB;
+    __device__ bool lane_skip(uint32_t i) const
+    {
+        const uint32_t w = LP_LD(&this->when[i]);
+        return this->t == 0u ? w != 0u : !(w == LVL_UNASSIGNED && LP_LD(&this->mark_cur[i]) == this->t);
+    }
+    __device__ NB nb(const Acc&, uint32_t j, float4) const { return NB{LP_LD(&this->when[j]), LP_LD(&this->level[j]), j}; }
+    __device__ void pair(Acc& a, float4, NB Bj, float, float, float r2, float) const
+    {
+        if (Bj.w == LVL_UNASSIGNED) LP_ST(&this->mark_next[Bj.j], this->t + 1u);
+        if (!(Bj.w < this->t)) return;
+        if (r2 > a.r2max) return;
+        const float est = Bj.lv - sqrtf(r2);
+        a.best = a.have ? fmaxf(a.best, est) : est;
+        a.have = true;
+    }
+    __device__ bool finish(Acc& a, uint32_t i, float4, bool) const
+    {
+        if (this->t > 0u && a.have) {
+            LP_ST(&this->level[i], a.best);
+            LP_ST(&this->when[i], this->t);
+        }
+        return false;
+    }
+};
+
+template <class MathT>
+__global__ __launch_bounds__(LP_THREADS) void k_level_propagate_all(OpLevelPropagateP<MathT> op0, SweepCommon c, uint32_t shift, uint32_t* mark, LevelSync* sy,
+                                                                    uint32_t t_first, float reach_k, DeviceStatus* status)
+{
+    typedef OpLevelPropagateP<MathT> Op;
+    const uint32_t b = blockIdx.x, nb = gridDim.x, tid = threadIdx.x;
+    const uint32_t s0 = b << shift, s1 = min(c.n, s0 + (1u << shift));
+    __shared__ uint32_t sh_lo[LP_THREADS / 64], sh_hi[LP_THREADS / 64], sh_stop;
+    Op op = op0;
+    // ---- the blocks this one exchanges with: index range of the stencils of its particles
+    uint32_t lo = s0, hi = s1;
+    for (uint32_t i = s0 + tid; i < s1; i += LP_THREADS) {
+        const float4 Ai = op.loadA(i);
+        const float2 cp = OpCellPos<Op>::get(op, i, Ai);
+        const int cx = (int)floorf(cp.x / c.g.cs) - c.g.minx, cy = (int)floorf(cp.y / c.g.cs) - c.g.miny;
+        const int R = stencil_radius(c.g, c.t, Ai.w, cx, cy, reach_k);
+        const int y0 = min(max(cy - R, 0), c.g.sy - 1), y1 = max(min(cy + R, c.g.sy - 1), 0);
+        const int x0 = min(max(cx - R, 0), c.g.sx), x1 = max(min(cx + R + 1, c.g.sx), 0);
+        lo = min(lo, c.cell_start[(uint32_t)y0 * (uint32_t)c.g.sx + (uint32_t)x0]);
+        hi = max(hi, c.cell_start[(uint32_t)y1 * (uint32_t)c.g.sx + (uint32_t)x1]);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        lo = min(lo, (uint32_t)__shfl_down((int)lo, o, 64));
+        hi = max(hi, (uint32_t)__shfl_down((int)hi, o, 64));
+    }
+    if ((tid & 63u) == 0u) {
+        sh_lo[tid >> 6] = lo;
+        sh_hi[tid >> 6] = hi;
+    }
+    if (tid == 0) sh_stop = 0u;
+    __syncthreads();
+    for (int k = 0; k < LP_THREADS / 64; k++) {
+        lo = min(lo, sh_lo[k]);
+        hi = max(hi, sh_hi[k]);
+    }
+    lo = __builtin_amdgcn_readfirstlane(lo);   // (every wave computed the same two numbers)
+    hi = __builtin_amdgcn_readfirstlane(hi);
+    const uint32_t blo = lo >> shift, bhi = min((max(hi, 1u) - 1u) >> shift, nb - 1u);
+    uint32_t chk = t_first;   // (thread 0) the first sweep whose statistics have not been looked at
+    uint32_t t = t_first;
+    for (; t < LP_TMAX; t++) {
+        if (t > t_first) {   // the neighbours' sweep t - 1 is complete
+            if (tid < 64u) {
+                const unsigned long long w0 = wall_clock64();
+                for (;;) {
+                    bool ok = true;
+                    for (uint32_t bb = blo + tid; bb <= bhi; bb += 64u) ok = ok && LP_LD(&sy->prog[bb]) >= t;
+                    if (__all(ok)) break;
+                    __builtin_amdgcn_s_sleep(2);
+                    if (wall_clock64() - w0 > 200000000ull) {   // 2 s at 100 MHz: a block that never became resident
+                        if (tid == 0) {
+                            sh_stop = 2u;
+                            atomicAdd(&sy->result[2], 1u);
+                            raise_error(status, SPH_ERR_DEVICE, t);
+                        }
+                        break;
+                    }
+                }
+            }
+            __syncthreads();
+            if (sh_stop) break;
+        }
+        op.t = t;
+        op.mark_cur = mark + ((t & 1u) ? c.n : 0u);
+        op.mark_next = mark + ((t & 1u) ? 0u : c.n);
+        bool useful = t == 0u;
+        for (uint32_t i = s0 + tid; i < s1; i += LP_THREADS) {
+            if (op.lane_skip(i)) continue;
+            const float4 Ai = op.loadA(i);
+            const uint4 lw = c.nl[i];
+            if ((lw.w & NL_IDX) && c.nlx) {
+                const uint32_t cnt = lw.w & 0xffffu;
+                const float r2max = level_range_sq(Ai.z, op.range_factor, op.sp_rest_density);
+                float best = 0.f;
+                bool have = false;
+                for (uint32_t k0 = 0; k0 < cnt; k0 += 32u) {
+                    uint32_t jj[32], wj[32];
+                    float lj[32];
+                    float2 xj[32];
+#pragma unroll
+                    for (int g = 0; g < 8; g++) {
+                        const uint32_t k = k0 + 4u * (uint32_t)g;
+                        const uint4 q = k < cnt ? c.nlx[(size_t)(k >> 2) * c.n + i] : make_uint4(i, i, i, i);
+                        jj[4 * g] = q.x;
+                        jj[4 * g + 1] = k + 1u < cnt ? q.y : i;
+                        jj[4 * g + 2] = k + 2u < cnt ? q.z : i;
+                        jj[4 * g + 3] = k + 3u < cnt ? q.w : i;
+                    }
+#pragma unroll
+                    for (int e = 0; e < 32; e++) {
+                        wj[e] = LP_LD(&op.when[jj[e]]);
+                        lj[e] = LP_LD(&op.level[jj[e]]);
+                        const float4* pj = op.pm + jj[e];
+                        xj[e] = *reinterpret_cast<const float2*>(pj);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 32; e++) {
+                        if (k0 + (uint32_t)e < cnt) {
+                            if (wj[e] == LVL_UNASSIGNED) LP_ST(&op.mark_next[jj[e]], t + 1u);
+                            if (wj[e] < t) {
+                                const float dx = Ai.x - xj[e].x, dy = Ai.y - xj[e].y;
+                                const float r2 = dx * dx + dy * dy;
+                                if (!(r2 > r2max)) {
+                                    const float est = lj[e] - sqrtf(r2);
+                                    best = have ? fmaxf(best, est) : est;
+                                    have = true;
+                                }
+                            }
+                        }
+                    }
+                }
+                if (t > 0u && have) {
+                    LP_ST(&op.level[i], best);
+                    LP_ST(&op.when[i], t);
+                    useful = useful || best > op.useful_above;
+                }
+            } else {
+                typename Op::Acc acc;
+                op.init(acc);
+                sweep_particle<Op, false>(op, c, acc, i, Ai, lw);
+                useful = useful || (t > 0u && acc.have && acc.best > op.useful_above);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every store of this sweep has left the wave before the progress word moves
+        const int any = __syncthreads_or(useful ? 1 : 0);
+        if (tid == 0) {
+            __hip_atomic_fetch_add(&sy->stat[t], (1ull << 32) | (any ? 1ull : 0ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            LP_ST(&sy->prog[b], t + 1u);
+            while (chk <= t) {   // lazy end-of-loop test: complete sweeps only, in order
+                const unsigned long long v = LP_LD(&sy->stat[chk]);
+                if ((uint32_t)(v >> 32) < nb) break;
+                if ((uint32_t)v == 0u) {
+                    sh_stop = 1u;
+                    if (b == 0u) sy->result[0] = chk;
+                    break;
+                }
+                chk++;
+            }
+        }
+        __syncthreads();
+        if (sh_stop) break;
+    }
+    if (tid == 0) {
+        LP_ST(&sy->prog[b], 0xffffffffu);   // nobody waits for a block that has left
+        if (t >= LP_TMAX) sy->result[1] = 1u;
+    }
+}
+
 // fill_stash_with (simulation.rs:886-893, 769-779): the level field as it stands, interior -> -maximum_surface_distance
 __global__ __launch_bounds__(256) void k_fill_stash(uint32_t n, const float* __restrict__ level, float* __restrict__ stash, float max_surface_distance)
 {
@@ -2637,6 +2850,44 @@ void launch_level_propagate(hipStream_t s, Profiler* prof, const SweepArgs& a, c
     uint32_t* mark_next = l.mark + ((t & 1u) ? 0u : a.n);
     SPH_DISPATCH(OpLevelPropagate, false, a.pm, l.pm_cell, l.level, l.when, mark_cur, mark_next, changed, l.k, t, l.maximum_range, a.sp.rest_density,
                  -l.max_surface_distance, l.plain_propagate)
+}
+
+// the propagation sweeps t_first, t_first + 1, ... until one assigns nothing above the bound, in ONE launch (k_level_propagate_all).
+// `sync`: level_sync_bytes() of device memory; result words land in `result_host` (pinned host memory, 8 words) behind the kernel.
+static uint32_t level_propagate_blocks(int device)
+{
+    static int cus[64] = {0};
+    if (device < 0 || device >= 64) return 64u;
+    if (!cus[device]) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || v <= 0) v = 64;
+        cus[device] = v;
+    }
+    return (uint32_t)std::min(cus[device], LP_MAX_BLOCKS);   // one resident workgroup per CU: the launch cannot strand a block
+}
+void launch_level_propagate_all(hipStream_t s, Profiler* prof, int device, const SweepArgs& a, const LevelArgs& l, uint32_t t_first, void* sync, uint32_t* result_host)
+{
+    if (!a.n) return;
+    ProfScope ps(prof, "level_propagate_all", s);
+    const uint32_t nbmax = level_propagate_blocks(device);
+    uint32_t shift = 6;
+    while (((a.n + (1u << shift) - 1u) >> shift) > nbmax) shift++;
+    const uint32_t nb = (a.n + (1u << shift) - 1u) >> shift;
+    (void)hipMemsetAsync(sync, 0, sizeof(LevelSync), s);
+    const float reach_k = fmaxf(l.k, 2.f);   // (after advection without the extended range the step's own k = 2 lists are replayed)
+    const SweepCommon c = common_of(a, true);
+    LevelSync* sy = (LevelSync*)sync;
+#define LP_LAUNCH(MATH, MINIT)                                                                                                                          \
+    {                                                                                                                                                   \
+        OpLevelPropagateP<MATH> op{{MINIT, a.pm, l.pm_cell, l.level, l.when, l.mark, l.mark, nullptr, l.k, 0u, l.maximum_range, a.sp.rest_density,       \
+                                    -l.max_surface_distance, 0}};                                                                                       \
+        hipLaunchKernelGGL((k_level_propagate_all<MATH>), dim3(nb), dim3(LP_THREADS), 0, s, op, c, shift, l.mark, sy, t_first, reach_k, a.status);        \
+    }
+    if (a.exact) LP_LAUNCH(MathExact, MathExact{0.f})
+    else if (a.uniform_h) LP_LAUNCH(MathUniform, uniform_math(a.h_uniform))
+    else LP_LAUNCH(MathFast, MathFast{0.f})
+#undef LP_LAUNCH
+    if (result_host) (void)hipMemcpyAsync(result_host, sy->result, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, s);
 }
 
 void launch_fill_stash(hipStream_t s, Profiler* prof, const SweepArgs& a, const LevelArgs& l, float* stash)

@@ -1,0 +1,545 @@
+// Jacobi-sweep laboratory: the relaxed-Jacobi update (sweep B, OpJacobi of csrc/sph_sweeps.hip) of a uniform-h scene as a
+// stand-alone program, in several STRUCTURES, timed on the same data and checked against the first one.  The product's sweep is
+// reproduced as variant `gather4`; the others answer "what bounds it" by construction rather than by counters.
+//
+//   build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -o jacobi_lab scripts/ubench/jacobi_lab.hip ; run: ./jacobi_lab [side=1024] [jitter=0.15] [reps=50]
+//
+// Data: side x side particles on a lattice of spacing d = 1/1024 (jittered), h = 1.9 sqrt(d^2 / pi), cell = 2 h, cell-sorted
+// x-fastest exactly like the product (stable by lattice order); list word = three 32-bit row masks (bit b of row r = candidate b of
+// the contiguous range of cell row cy + r - 1, cells cx - 1 .. cx + 1), own bit dropped from the middle row.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <string>
+#include <vector>
+
+#define CHECK(x)                                                                                                   \
+    do {                                                                                                           \
+        hipError_t e_ = (x);                                                                                       \
+        if (e_ != hipSuccess) {                                                                                    \
+            fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_));                              \
+            exit(1);                                                                                               \
+        }                                                                                                          \
+    } while (0)
+
+struct Grid {
+    float cs;
+    int minx, miny, sx, sy;
+};
+struct Math {
+    float h, nf, inv2h;
+};
+struct Args {
+    uint32_t n, nblocks;
+    Grid g;
+    Math m;
+    const uint32_t* __restrict__ cell_start;
+    const uint4* __restrict__ nl;
+    const float4* __restrict__ pm;     // x, y, m, h
+    const float2* __restrict__ pacc;   // a^p
+    const float4* __restrict__ comb;   // x, y, a^p.x, a^p.y
+    const float* __restrict__ rho;
+    const float* __restrict__ aii;
+    const float* __restrict__ src;
+    const float* __restrict__ p_in;
+    float* __restrict__ p_out;
+    float* __restrict__ pt_out;
+    float omega, mass;
+};
+
+__device__ __forceinline__ void grad_uniform(const Math& m, float dx, float dy, float r2, float& gx, float& gy)
+{
+    const float rinv = __builtin_amdgcn_rsqf(r2);
+    const float q = (r2 * rinv) * m.inv2h;
+    const float a = 18.f * q * q - 12.f * q;
+    const float v = 1.f - q;
+    const float b = -6.f * v * v;
+    const float d = q < 0.5f ? a : (q < 1.f ? b : 0.f);
+    float s = m.nf * d * m.inv2h * rinv;
+    s = (q > 1.0e-5f) ? s : 0.f;
+    gx = s * dx;
+    gy = s * dy;
+}
+
+struct Acc {
+    float sum, qx, qy, inv_rho;
+};
+__device__ __forceinline__ void pair(const Args& A, Acc& a, float xi, float yi, float xj, float yj, float apx, float apy, bool on)
+{
+    const float dx = xi - xj, dy = yi - yj;
+    const float r2 = dx * dx + dy * dy;
+    if (on) {
+        float gx, gy;
+        grad_uniform(A.m, dx, dy, r2, gx, gy);
+        const float dot = (apx - a.qx) * gx + (apy - a.qy) * gy;
+        a.sum += A.mass * a.inv_rho * dot;
+    }
+}
+__device__ __forceinline__ void finish(const Args& A, const Acc& a, uint32_t i, float rho_i)
+{
+    const float aii_i = A.aii[i];
+    const float pn = A.p_in[i] + A.omega * (A.src[i] - a.sum) / aii_i;
+    const bool pos = pn > 0.f;
+    A.p_out[i] = pos ? pn : 0.f;
+    A.pt_out[i] = pos ? pn / (rho_i * rho_i) : 0.f;
+}
+__device__ __forceinline__ uint32_t remap_block(uint32_t nblocks)
+{
+    const uint32_t per_xcd = (nblocks + 7) >> 3;
+    return (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+}
+__device__ __forceinline__ void row_bases(const Args& A, float x, float y, uint32_t (&rb)[3], int& cx, int& cy)
+{
+    cx = (int)floorf(x / A.g.cs) - A.g.minx;
+    cy = (int)floorf(y / A.g.cs) - A.g.miny;
+#pragma unroll
+    for (int dr = 0; dr < 3; dr++) {
+        const int yy = cy + dr - 1;
+        const bool ok = yy >= 0 && yy < A.g.sy;
+        rb[dr] = ok ? A.cell_start[(uint32_t)yy * (uint32_t)A.g.sx + (uint32_t)max(cx - 1, 0)] : 0u;
+    }
+}
+
+// ---- variant: the product's form.  4 set bits of a row per trip: 4 record gathers (16 B) + 4 payload gathers (8 B) in flight ----
+template <int COMB>   // COMB: one combined 16-B record {x, y, a^p} instead of record + payload
+__global__ __launch_bounds__(256) void k_gather4(Args A)
+{
+    const uint32_t blk = remap_block(A.nblocks);
+    if (blk >= A.nblocks) return;
+    const uint32_t i = blk * 256 + threadIdx.x;
+    if (i >= A.n) return;
+    const float4 Ai = A.pm[i];
+    const uint4 lw = A.nl[i];
+    uint32_t rb[3];
+    int cx, cy;
+    row_bases(A, Ai.x, Ai.y, rb, cx, cy);
+    Acc a;
+    a.sum = 0.f;
+    const float rho_i = A.rho[i];
+    a.inv_rho = __builtin_amdgcn_rcpf(rho_i);
+    const float2 q = A.pacc[i];
+    a.qx = q.x;
+    a.qy = q.y;
+    const uint32_t masks[3] = {lw.x, lw.y, lw.z};
+#pragma unroll
+    for (int dr = 0; dr < 3; dr++) {
+        uint32_t mk = masks[dr];
+        const uint32_t base = rb[dr];
+        while (mk) {
+            const uint32_t b0 = __ffs(mk) - 1;
+            mk &= mk - 1;
+            const bool v1 = mk != 0;
+            const uint32_t b1 = v1 ? __ffs(mk) - 1 : b0;
+            mk &= mk - 1;
+            const bool v2 = mk != 0;
+            const uint32_t b2 = v2 ? __ffs(mk) - 1 : b0;
+            mk &= mk - 1;
+            const bool v3 = mk != 0;
+            const uint32_t b3 = v3 ? __ffs(mk) - 1 : b0;
+            mk &= mk - 1;
+            if (COMB) {
+                const float4 R0 = A.comb[base + b0], R1 = A.comb[base + b1], R2 = A.comb[base + b2], R3 = A.comb[base + b3];
+                pair(A, a, Ai.x, Ai.y, R0.x, R0.y, R0.z, R0.w, true);
+                pair(A, a, Ai.x, Ai.y, R1.x, R1.y, R1.z, R1.w, v1);
+                pair(A, a, Ai.x, Ai.y, R2.x, R2.y, R2.z, R2.w, v2);
+                pair(A, a, Ai.x, Ai.y, R3.x, R3.y, R3.z, R3.w, v3);
+            } else {
+                const float4 R0 = A.pm[base + b0], R1 = A.pm[base + b1], R2 = A.pm[base + b2], R3 = A.pm[base + b3];
+                const float2 P0 = A.pacc[base + b0], P1 = A.pacc[base + b1], P2 = A.pacc[base + b2], P3 = A.pacc[base + b3];
+                pair(A, a, Ai.x, Ai.y, R0.x, R0.y, P0.x, P0.y, true);
+                pair(A, a, Ai.x, Ai.y, R1.x, R1.y, P1.x, P1.y, v1);
+                pair(A, a, Ai.x, Ai.y, R2.x, R2.y, P2.x, P2.y, v2);
+                pair(A, a, Ai.x, Ai.y, R3.x, R3.y, P3.x, P3.y, v3);
+            }
+        }
+    }
+    finish(A, a, i, rho_i);
+}
+
+// ---- variant: no neighbour work at all (own loads, finish, stores): the floor of the launch ----
+__global__ __launch_bounds__(256) void k_own_only(Args A)
+{
+    const uint32_t blk = remap_block(A.nblocks);
+    if (blk >= A.nblocks) return;
+    const uint32_t i = blk * 256 + threadIdx.x;
+    if (i >= A.n) return;
+    const float4 Ai = A.pm[i];
+    const uint4 lw = A.nl[i];
+    Acc a;
+    a.sum = Ai.x * 1e-30f + (float)lw.x * 1e-30f;
+    const float rho_i = A.rho[i];
+    a.inv_rho = __builtin_amdgcn_rcpf(rho_i);
+    const float2 q = A.pacc[i];
+    a.sum += q.x * 1e-30f;
+    finish(A, a, i, rho_i);
+}
+
+// ---- variants on LDS: every wave stages the three candidate windows of its 64 particles (contiguous index ranges: the cells
+// cx_first - 1 .. cx_last + 1 of the rows cy - 1, cy, cy + 1) as compact {x, y, a^p} records, coalesced, into its own LDS region;
+// the lanes then read neighbours from LDS.  A wave that straddles two cell rows, or whose window exceeds CAP, gathers from memory.
+//   LOOP = 0: the product's trips (4 set bits of a row per trip, padding slots for lanes with fewer)
+//   LOOP = 1: one set bit per iteration, no padding slots (the wave runs max-over-lanes(popcount) iterations per row)
+//   LOOP = 2: two set bits per iteration
+#ifndef CAP
+#define CAP 96
+#endif
+template <int LOOP>
+__global__ __launch_bounds__(256) void k_lds(Args A)
+{
+    __shared__ float4 s_rec[4][3 * CAP];
+    const uint32_t blk = remap_block(A.nblocks);
+    if (blk >= A.nblocks) return;
+    const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t wbase = blk * 256 + w * 64u;
+    if (wbase >= A.n) return;
+    const uint32_t nvalid = min(64u, A.n - wbase);
+    const uint32_t i = wbase + min(lane, nvalid - 1u);
+    const bool active = lane < nvalid;
+    const float4 Ai = A.pm[i];
+    const uint4 lw = A.nl[i];
+    uint32_t rb[3];
+    int cx, cy;
+    row_bases(A, Ai.x, Ai.y, rb, cx, cy);
+    const int cxf = __builtin_amdgcn_readfirstlane(cx), cyf = __builtin_amdgcn_readfirstlane(cy);
+    const int cxl = __builtin_amdgcn_readlane(cx, (int)nvalid - 1), cyl = __builtin_amdgcn_readlane(cy, (int)nvalid - 1);
+    bool ok = cyf == cyl;
+    uint32_t sb[3], sl[3];
+#pragma unroll
+    for (int dr = 0; dr < 3; dr++) {
+        const int yy = cyf + dr - 1;
+        const bool in = yy >= 0 && yy < A.g.sy;
+        const uint32_t row = (uint32_t)(in ? yy : 0) * (uint32_t)A.g.sx;
+        sb[dr] = in ? A.cell_start[row + (uint32_t)max(cxf - 1, 0)] : 0u;
+        const uint32_t se = in ? A.cell_start[row + (uint32_t)min(cxl + 2, A.g.sx)] : sb[dr];
+        sl[dr] = se - sb[dr];
+        ok = ok && sl[dr] <= (uint32_t)CAP;
+    }
+    Acc a;
+    a.sum = 0.f;
+    const float rho_i = A.rho[i];
+    a.inv_rho = __builtin_amdgcn_rcpf(rho_i);
+    const float2 q = A.pacc[i];
+    a.qx = q.x;
+    a.qy = q.y;
+    const uint32_t masks[3] = {lw.x, lw.y, lw.z};
+    if (!ok) {   // (wave-uniform) gather form
+        if (active) {
+#pragma unroll
+            for (int dr = 0; dr < 3; dr++) {
+                uint32_t mk = masks[dr];
+                while (mk) {
+                    const uint32_t b0 = __ffs(mk) - 1;
+                    mk &= mk - 1;
+                    const float4 R = A.pm[rb[dr] + b0];
+                    const float2 P = A.pacc[rb[dr] + b0];
+                    pair(A, a, Ai.x, Ai.y, R.x, R.y, P.x, P.y, true);
+                }
+            }
+            finish(A, a, i, rho_i);
+        }
+        return;
+    }
+    // stage: all loads of the wave in flight, then the LDS writes
+    float4 r_[3][2];
+    float2 p_[3][2];
+#pragma unroll
+    for (int dr = 0; dr < 3; dr++) {
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            const uint32_t k = lane + 64u * t;
+            const uint32_t j = sb[dr] + min(k, sl[dr] ? sl[dr] - 1u : 0u);
+            r_[dr][t] = A.pm[j];
+            p_[dr][t] = A.pacc[j];
+        }
+    }
+#pragma unroll
+    for (int dr = 0; dr < 3; dr++) {
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            const uint32_t k = lane + 64u * t;
+            if (k < sl[dr]) s_rec[w][dr * CAP + k] = make_float4(r_[dr][t].x, r_[dr][t].y, p_[dr][t].x, p_[dr][t].y);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (!active) return;
+#pragma unroll
+    for (int dr = 0; dr < 3; dr++) {
+        uint32_t mk = masks[dr];
+        const float4* __restrict__ S = &s_rec[w][dr * CAP + (rb[dr] - sb[dr])];
+        if (LOOP == 0) {
+            while (mk) {
+                const uint32_t b0 = __ffs(mk) - 1;
+                mk &= mk - 1;
+                const bool v1 = mk != 0;
+                const uint32_t b1 = v1 ? __ffs(mk) - 1 : b0;
+                mk &= mk - 1;
+                const bool v2 = mk != 0;
+                const uint32_t b2 = v2 ? __ffs(mk) - 1 : b0;
+                mk &= mk - 1;
+                const bool v3 = mk != 0;
+                const uint32_t b3 = v3 ? __ffs(mk) - 1 : b0;
+                mk &= mk - 1;
+                const float4 R0 = S[b0], R1 = S[b1], R2 = S[b2], R3 = S[b3];
+                pair(A, a, Ai.x, Ai.y, R0.x, R0.y, R0.z, R0.w, true);
+                pair(A, a, Ai.x, Ai.y, R1.x, R1.y, R1.z, R1.w, v1);
+                pair(A, a, Ai.x, Ai.y, R2.x, R2.y, R2.z, R2.w, v2);
+                pair(A, a, Ai.x, Ai.y, R3.x, R3.y, R3.z, R3.w, v3);
+            }
+        } else if (LOOP == 1) {
+            while (mk) {
+                const uint32_t b0 = __ffs(mk) - 1;
+                mk &= mk - 1;
+                const float4 R0 = S[b0];
+                pair(A, a, Ai.x, Ai.y, R0.x, R0.y, R0.z, R0.w, true);
+            }
+        } else {
+            while (mk) {
+                const uint32_t b0 = __ffs(mk) - 1;
+                mk &= mk - 1;
+                const bool v1 = mk != 0;
+                const uint32_t b1 = v1 ? __ffs(mk) - 1 : b0;
+                mk &= mk - 1;
+                const float4 R0 = S[b0], R1 = S[b1];
+                pair(A, a, Ai.x, Ai.y, R0.x, R0.y, R0.z, R0.w, true);
+                pair(A, a, Ai.x, Ai.y, R1.x, R1.y, R1.z, R1.w, v1);
+            }
+        }
+    }
+    finish(A, a, i, rho_i);
+}
+
+// ---- variant: gathers, one / two set bits per iteration (no padding slots; fewer loads in flight) ----
+template <int PER>
+__global__ __launch_bounds__(256) void k_gather_loop(Args A)
+{
+    const uint32_t blk = remap_block(A.nblocks);
+    if (blk >= A.nblocks) return;
+    const uint32_t i = blk * 256 + threadIdx.x;
+    if (i >= A.n) return;
+    const float4 Ai = A.pm[i];
+    const uint4 lw = A.nl[i];
+    uint32_t rb[3];
+    int cx, cy;
+    row_bases(A, Ai.x, Ai.y, rb, cx, cy);
+    Acc a;
+    a.sum = 0.f;
+    const float rho_i = A.rho[i];
+    a.inv_rho = __builtin_amdgcn_rcpf(rho_i);
+    const float2 q = A.pacc[i];
+    a.qx = q.x;
+    a.qy = q.y;
+    const uint32_t masks[3] = {lw.x, lw.y, lw.z};
+#pragma unroll
+    for (int dr = 0; dr < 3; dr++) {
+        uint32_t mk = masks[dr];
+        const uint32_t base = rb[dr];
+        while (mk) {
+            const uint32_t b0 = __ffs(mk) - 1;
+            mk &= mk - 1;
+            if (PER == 1) {
+                const float4 R0 = A.comb[base + b0];
+                pair(A, a, Ai.x, Ai.y, R0.x, R0.y, R0.z, R0.w, true);
+            } else {
+                const bool v1 = mk != 0;
+                const uint32_t b1 = v1 ? __ffs(mk) - 1 : b0;
+                mk &= mk - 1;
+                const float4 R0 = A.comb[base + b0], R1 = A.comb[base + b1];
+                pair(A, a, Ai.x, Ai.y, R0.x, R0.y, R0.z, R0.w, true);
+                pair(A, a, Ai.x, Ai.y, R1.x, R1.y, R1.z, R1.w, v1);
+            }
+        }
+    }
+    finish(A, a, i, rho_i);
+}
+
+// ---- variant: the pair arithmetic only -- every "neighbour" is a register value, no loads, no mask decoding: 20 pair slots per
+// particle as the product executes them (what the VALU alone costs) ----
+template <int SLOTS>
+__global__ __launch_bounds__(256) void k_math_only(Args A)
+{
+    const uint32_t blk = remap_block(A.nblocks);
+    if (blk >= A.nblocks) return;
+    const uint32_t i = blk * 256 + threadIdx.x;
+    if (i >= A.n) return;
+    const float4 Ai = A.pm[i];
+    Acc a;
+    a.sum = 0.f;
+    const float rho_i = A.rho[i];
+    a.inv_rho = __builtin_amdgcn_rcpf(rho_i);
+    const float2 q = A.pacc[i];
+    a.qx = q.x;
+    a.qy = q.y;
+    float xj = Ai.x + 0.0007f, yj = Ai.y - 0.0004f;
+#pragma unroll 4
+    for (int s = 0; s < SLOTS; s++) {
+        pair(A, a, Ai.x, Ai.y, xj, yj, q.y, q.x, true);
+        xj += 1e-5f;
+        yj -= 1e-5f;
+    }
+    finish(A, a, i, rho_i);
+}
+
+int main(int argc, char** argv)
+{
+    const int side = argc > 1 ? atoi(argv[1]) : 1024;
+    const float jitter = argc > 2 ? (float)atof(argv[2]) : 0.15f;
+    const int reps = argc > 3 ? atoi(argv[3]) : 50;
+    const uint32_t n = (uint32_t)side * (uint32_t)side;
+    const float d = 1.f / 1024.f, rho0 = 1.f, mass = rho0 * d * d;
+    const float h = 1.9f * sqrtf((mass / rho0) * 0.318309873342514038086f);
+    const float cs = 2.f * h;
+    std::mt19937 rng(1234);
+    std::uniform_real_distribution<float> U(-jitter * d, jitter * d);
+    std::vector<float> x(n), y(n);
+    for (int r = 0; r < side; r++)
+        for (int c = 0; c < side; c++) {
+            x[(size_t)r * side + c] = -1.9995f + c * d + U(rng);
+            y[(size_t)r * side + c] = -0.9995f + r * d + U(rng);
+        }
+    float mnx = 1e9f, mny = 1e9f, mxx = -1e9f, mxy = -1e9f;
+    for (uint32_t i = 0; i < n; i++) {
+        mnx = std::min(mnx, x[i]); mny = std::min(mny, y[i]); mxx = std::max(mxx, x[i]); mxy = std::max(mxy, y[i]);
+    }
+    Grid g;
+    g.cs = cs;
+    g.minx = (int)floorf(mnx / cs) - 1;
+    g.miny = (int)floorf(mny / cs) - 1;
+    g.sx = (int)floorf(mxx / cs) + 2 - g.minx;
+    g.sy = (int)floorf(mxy / cs) + 2 - g.miny;
+    const uint32_t ncells = (uint32_t)g.sx * (uint32_t)g.sy;
+    std::vector<uint32_t> key(n), perm(n);
+    for (uint32_t i = 0; i < n; i++) {
+        const int cx = (int)floorf(x[i] / cs) - g.minx, cy = (int)floorf(y[i] / cs) - g.miny;
+        key[i] = (uint32_t)cy * (uint32_t)g.sx + (uint32_t)cx;
+        perm[i] = i;
+    }
+    std::stable_sort(perm.begin(), perm.end(), [&](uint32_t a, uint32_t b) { return key[a] < key[b]; });
+    std::vector<float4> pm(n), comb(n);
+    std::vector<float2> pacc(n);
+    std::vector<uint32_t> cell_start(ncells + 1, 0), skey(n);
+    std::uniform_real_distribution<float> V(-1.f, 1.f);
+    for (uint32_t s = 0; s < n; s++) {
+        const uint32_t i = perm[s];
+        pm[s] = make_float4(x[i], y[i], mass, h);
+        pacc[s] = make_float2(10.f * V(rng), 10.f * V(rng));
+        comb[s] = make_float4(x[i], y[i], pacc[s].x, pacc[s].y);
+        skey[s] = key[i];
+        cell_start[key[i] + 1]++;
+    }
+    for (uint32_t c = 0; c < ncells; c++) cell_start[c + 1] += cell_start[c];
+    // list words
+    std::vector<uint4> nl(n);
+    double sum_cnt = 0, sum_slots4 = 0;
+    uint32_t overflow = 0;
+    for (uint32_t s = 0; s < n; s++) {
+        const int cx = (int)(skey[s] % (uint32_t)g.sx), cy = (int)(skey[s] / (uint32_t)g.sx);
+        uint32_t mk[3] = {0, 0, 0}, cnt = 0;
+        for (int dr = 0; dr < 3; dr++) {
+            const int yy = cy + dr - 1;
+            if (yy < 0 || yy >= g.sy) continue;
+            const uint32_t b = cell_start[(uint32_t)yy * g.sx + std::max(cx - 1, 0)], e = cell_start[(uint32_t)yy * g.sx + std::min(cx + 2, g.sx)];
+            if (e - b > 32) overflow++;
+            for (uint32_t j = b; j < e && j - b < 32; j++) {
+                const float dx = pm[s].x - pm[j].x, dy = pm[s].y - pm[j].y;
+                const float sr = ((h + h) * 0.5f) * 2.f;
+                if (dx * dx + dy * dy < sr * sr && j != s) {
+                    mk[dr] |= 1u << (j - b);
+                    cnt++;
+                }
+            }
+            sum_slots4 += 4 * ((__builtin_popcount(mk[dr]) + 3) / 4);
+        }
+        nl[s] = make_uint4(mk[0], mk[1], mk[2], cnt);
+        sum_cnt += cnt;
+    }
+    printf("n = %u, cells %d x %d, %.2f neighbours per particle (self excluded), %.2f slots per particle in trips of 4 (per lane), rows > 32 candidates: %u\n", n, g.sx,
+           g.sy, sum_cnt / n, sum_slots4 / n, overflow);
+    std::vector<float> rho(n), aii(n), src(n), pin(n);
+    for (uint32_t s = 0; s < n; s++) {
+        rho[s] = 1.f + 0.01f * V(rng);
+        aii[s] = 5.0e4f * (1.f + 0.1f * V(rng));
+        src[s] = 100.f * V(rng);
+        pin[s] = 1.0f + V(rng);
+    }
+    Args A{};
+    A.n = n;
+    A.nblocks = (n + 255) / 256;
+    A.g = g;
+    A.m = Math{h, 10.f / (7.f * 3.14159274101257324219f * (h * h)), 1.f / (2.f * h)};
+    A.omega = 0.5f;
+    A.mass = mass;
+    auto up = [&](const void* src_, size_t bytes) {
+        void* p;
+        CHECK(hipMalloc(&p, bytes));
+        CHECK(hipMemcpy(p, src_, bytes, hipMemcpyHostToDevice));
+        return p;
+    };
+    A.cell_start = (const uint32_t*)up(cell_start.data(), cell_start.size() * 4);
+    A.nl = (const uint4*)up(nl.data(), (size_t)n * 16);
+    A.pm = (const float4*)up(pm.data(), (size_t)n * 16);
+    A.pacc = (const float2*)up(pacc.data(), (size_t)n * 8);
+    A.comb = (const float4*)up(comb.data(), (size_t)n * 16);
+    A.rho = (const float*)up(rho.data(), (size_t)n * 4);
+    A.aii = (const float*)up(aii.data(), (size_t)n * 4);
+    A.src = (const float*)up(src.data(), (size_t)n * 4);
+    A.p_in = (const float*)up(pin.data(), (size_t)n * 4);
+    {
+        void *po, *pt;
+        CHECK(hipMalloc(&po, (size_t)n * 4));
+        CHECK(hipMalloc(&pt, (size_t)n * 4));
+        A.p_out = (float*)po;
+        A.pt_out = (float*)pt;
+    }
+    const uint32_t grid = ((A.nblocks + 7) / 8) * 8;
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    std::vector<float> ref(n), out(n);
+    struct V_ { const char* name; void (*k)(Args); bool check; };
+    const V_ vs[] = {
+        {"gather4 (product form: 16-B record + 8-B payload gathers, trips of 4)", k_gather4<0>, true},
+        {"gather4, one combined 16-B record {x, y, a^p}", k_gather4<1>, true},
+        {"gather, combined record, 2 bits per iteration (no padding beyond pairs)", k_gather_loop<2>, true},
+        {"gather, combined record, 1 bit per iteration (no padding slots)", k_gather_loop<1>, true},
+        {"LDS windows per wave, trips of 4", k_lds<0>, true},
+        {"LDS windows per wave, 2 bits per iteration", k_lds<2>, true},
+        {"LDS windows per wave, 1 bit per iteration (no padding slots)", k_lds<1>, true},
+        {"own loads + finish only (no neighbours)", k_own_only, false},
+        {"pair arithmetic only, 12 slots in registers (no loads, no decoding)", k_math_only<12>, false},
+        {"pair arithmetic only, 20 slots in registers", k_math_only<20>, false},
+    };
+    printf("| variant | us per launch (HIP events, %d launches back to back) | max rel diff of p' vs variant 0 |\n|---|---|---|\n", reps);
+    bool have_ref = false;
+    for (auto& v : vs) {
+        CHECK(hipMemset(A.p_out, 0, (size_t)n * 4));
+        hipLaunchKernelGGL(v.k, dim3(grid), dim3(256), 0, 0, A);
+        CHECK(hipDeviceSynchronize());
+        CHECK(hipMemcpy(out.data(), A.p_out, (size_t)n * 4, hipMemcpyDeviceToHost));
+        double err = 0, mx = 0;
+        if (!have_ref) {
+            ref = out;
+            have_ref = true;
+        }
+        if (v.check) {
+            for (uint32_t s = 0; s < n; s++) {
+                err = std::max(err, (double)fabsf(out[s] - ref[s]));
+                mx = std::max(mx, (double)fabsf(ref[s]));
+            }
+        }
+        CHECK(hipEventRecord(e0, 0));
+        for (int r = 0; r < reps; r++) hipLaunchKernelGGL(v.k, dim3(grid), dim3(256), 0, 0, A);
+        CHECK(hipEventRecord(e1, 0));
+        CHECK(hipDeviceSynchronize());
+        float ms = 0;
+        CHECK(hipEventElapsedTime(&ms, e0, e1));
+        if (v.check) printf("| %s | %.2f | %.2e |\n", v.name, ms * 1e3 / reps, mx > 0 ? err / mx : 0.0);
+        else printf("| %s | %.2f | - |\n", v.name, ms * 1e3 / reps);
+    }
+    return 0;
+}

