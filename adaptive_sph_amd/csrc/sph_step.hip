@@ -2601,7 +2601,7 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
     // latency-bound propagation sweeps run under the step's own sweeps); level_estimation_finish() collects it.
     struct LevelPending {
         bool on = false;
-        bool one_launch = false;   // the propagation ran as k_level_propagate_all: its result words are checked after the step's last wait
+        uint32_t* tmark = nullptr;   // tile marks when the sweeps run through k_level_sweep
         uint32_t t = 1, effective = 0;
         int B = 8;
     } lvp;
@@ -2684,29 +2684,18 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
             // host learns once per batch how many of them assigned something (a sweep behind the last effective one has no
             // candidates and costs a scan).  The first batch is as long as the previous step's propagation + 1 -- the fluid's
             // depth hardly changes from step to step -- so a step usually waits once instead of once per 8 sweeps.
-            if (!c->level_per_sweep) {
-                // the whole propagation in ONE launch (k_level_propagate_all): the sweep loop, its end and the hand-over between
-                // the blocks stay on the device; the result words (first sweep without an assignment above the bound, LP_TMAX
-                // reached, spin time-outs) land in mapped host memory behind it and are looked at after the step's last wait
-                HIPCHK(c, c->lvl_sync.ensure(level_sync_bytes()));
-                uint32_t t_first = 0u;
-                if (p->fill_stash_with == SPH_STASH_SURFACE_DISTANCE_MIDDLE) {   // num_iter == 1, simulation.rs:769-779: the field after the FIRST sweep
-                    (void)hipMemsetAsync(chg, 0, sizeof(uint32_t), ls);
-                    launch_level_propagate(ls, &c->prof, al, lv, 0u, chg + 1023);
-                    launch_level_propagate(ls, &c->prof, al, lv, 1u, chg);
-                    launch_fill_stash(ls, &c->prof, al, lv, c->stash.as<float>());
-                    t_first = 2u;
-                }
-                launch_level_propagate_all(ls, &c->prof, c->device, al, lv, t_first, c->lvl_sync.p, (uint32_t*)c->lvl_changed + 32);
-                lvp.one_launch = true;
-                if (side) {
-                    HIPCHK(c, hipEventRecord(c->ev_join, ls));
-                    lvp.on = true;
-                }
-                c->have_level = true;
-                m.st.ms_level_estimation += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_lvl0).count();
-                return SPH_OK;
+            // (single context, frontier form: the sweep kernel built for it; SPH_LEVEL_GENERIC keeps the generic skeleton)
+            uint32_t* tmark = nullptr;
+            if (!c->level_generic_sweeps) {
+                HIPCHK(c, c->lvl_tmark.ensure(level_tile_mark_bytes(m.n)));
+                tmark = c->lvl_tmark.as<uint32_t>();
+                (void)hipMemsetAsync(tmark, 0, level_tile_mark_bytes(m.n), ls);
             }
+            lvp.tmark = tmark;
+            auto launch_level_propagate = [tmark](hipStream_t st, Profiler* pr, const SweepArgs& aa, const LevelArgs& ll, uint32_t tt, uint32_t* changed) {
+                if (tmark) launch_level_sweep(st, pr, aa, ll, tt, changed, tmark);
+                else ::launch_level_propagate(st, pr, aa, ll, tt, changed);
+            };
             launch_level_propagate(ls, &c->prof, al, lv, 0u, chg + 1023);   // surface particles mark their neighbours
             uint32_t t = 1, effective = 0;
             int B = (int)std::min<uint32_t>(std::max<uint32_t>(c->last_level_sweeps + 1u, 8u), 1000u);
@@ -2752,10 +2741,6 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
         Member& m = M[0];
         sph_ctx* c = m.c;
         hipStream_t ls = c->stream2;
-        if (lvp.one_launch) {   // the main stream goes on behind the side stream's launch: no host wait
-            HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
-            return SPH_OK;
-        }
         uint32_t* chg = c->lvl_changed_d.as<uint32_t>();
         uint32_t t = lvp.t, effective = lvp.effective;
         int B = lvp.B;
@@ -2766,7 +2751,10 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
             if (changed < (uint32_t)B) break;
             B = 8;
             (void)hipMemsetAsync(chg, 0, (size_t)B * sizeof(uint32_t), ls);
-            for (int b = 0; b < B; b++, t++) launch_level_propagate(ls, &c->prof, lv_args, lv, t, chg + b);
+            for (int b = 0; b < B; b++, t++) {
+                if (lvp.tmark) launch_level_sweep(ls, &c->prof, lv_args, lv, t, chg + b, lvp.tmark);
+                else launch_level_propagate(ls, &c->prof, lv_args, lv, t, chg + b);
+            }
             c->level_seq++;
             if (c->level_seq == 0u) c->level_seq = 1u;
             hipLaunchKernelGGL(k_publish_count, dim3(1), dim3(64), 0, ls, chg, (uint32_t)B, c->lvl_changed_dev, 63u, c->level_seq);
@@ -3235,14 +3223,6 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
             std::swap(c->lvl[c->cur], c->lvl_tmp);
         }
         if ((rc = sync_ctrl(G))) return rc;
-        if (lvp.one_launch && m.n) {
-            const volatile uint32_t* res = c->lvl_changed + 32;
-            if (res[1] || res[2])
-                return c->fail(res[2] ? SPH_ERR_DEVICE : SPH_ERR_UNSUPPORTED,
-                               res[2] ? "level-set propagation: a workgroup of the one-launch propagation waited 2 s for its neighbours (not resident?)"
-                                      : "level-set propagation: more sweeps than the one-launch form keeps statistics for");
-            c->last_level_sweeps = res[0];
-        }
         m.st.ms_level_estimation += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_lvl0).count();
     }
 

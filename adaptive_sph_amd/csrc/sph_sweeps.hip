@@ -1961,216 +1961,150 @@ struct OpLevelPropagate {
 };
 
 // ------------------------------------------------------------------------------------------------
-// The WHOLE propagation in one launch.  A propagation is ~100 sweeps with a few thousand working particles each; launched one
-// by one, a sweep costs its dispatch (4096 workgroups that mostly read two words and leave) plus the chain of dependent,
-// cache-cold accesses of a few frontier lanes: 14 us per sweep, 1.5 of the 2.2 ms of a step with level estimation at N = 1M
-// (profiles/r2i_level_1m_kernel_summary.md).  Here <= 256 resident workgroups (one per CU) keep the sweep loop on the device:
-//   * block b owns the slots [b << shift, (b + 1) << shift) of the cell-sorted array and evaluates the candidates among them;
-//   * what a sweep reads of other blocks -- (level, when) of neighbours, the marks neighbours set -- comes from the blocks whose
-//     slots its particles' stencils reach (index ranges of the cell rows around them: blocks [blo, bhi], found once in the
-//     prologue).  A block therefore waits, before sweep t, only for THOSE blocks to have finished sweep t - 1 (one progress word
-//     per block), not for a grid barrier: neighbours run in lockstep, blocks far apart drift by as many sweeps as lie between them.
-//     The data is exchanged with agent-scope (sc1) loads and stores, which the L2s serve coherently -- no fences, no L1 lines to
-//     invalidate (MI355X_MICROARCH.md, inter-workgroup visibility: sc1 payload -> s_waitcnt vmcnt(0) in every storing wave ->
-//     sc1 flag).  `when` makes running ahead harmless: a value written by a later sweep fails the `when < t` test.
-//   * the end of the loop -- the first sweep in which NO block assigned a value above the bound (OpLevelPropagate::useful_above) --
-//     is seen lazily: every block adds (1 << 32 | assigned-something) to stat[t] when it finishes sweep t and leaves once it
-//     finds a complete stat[t'] without assignments.  The sweeps a block runs beyond that one assign nothing or values below
-//     the bound, which the smoothing clamps to the bound like the unassigned (simulation.rs:826-832): same outputs.
-// Every spin is bounded (2 s): a block that never shows up raises SPH_ERR_DEVICE instead of hanging the device.
-// Candidates with an index list (every particle of the extended-range lists) are evaluated 32 neighbours at a time, all index
-// words, then all (when, level, position) gathers in flight at once: three dependent round trips per candidate instead of two per
-// group of four.  Same values as the per-sweep launches (`max` over the same set), bit for bit.
+// A propagation sweep as a launch of its own, built for what a sweep IS: ~100 of them per step, a few thousand working
+// particles each, in a thin closed curve through the fluid.  Through the generic skeleton (k_sweep<OpLevelPropagate>) a sweep
+// costs 14 us at N = 1M whatever it does: 4096 workgroups are dispatched to read two words per lane and leave, and a frontier
+// lane walks its list in trips of four -- eight trips of two dependent, cache-cold round trips each.  Here:
+//   * besides the per-particle mark, a marker stores the sweep number into ONE WORD PER TILE of 64 consecutive slots (two
+//     parities, like the marks).  A wave owns LS_TILES consecutive tiles, asks for their words first and leaves if none carries
+//     this sweep's number: a quarter of the workgroups, one load per wave instead of two per lane;
+//   * a candidate with an index list (every particle of the extended-range lists) is evaluated 16 neighbours per trip, all their
+//     gathers in flight at once and the next trip's index words already requested -- three dependent round trips per candidate.
+// Same values as the generic sweep (`max` over the same neighbour set), bit for bit.
+// (Measured negative, round 3: the whole propagation as ONE persistent launch -- 256 resident workgroups, interleaved tile
+//  ownership, a progress word per workgroup as grid barrier, every shared word moved with agent-scope (sc1) loads and stores
+//  -- took 67 us per sweep, 7.8 ms per step against 2.2: a frontier lane's chain is five dependent round trips, and an sc1 round
+//  trip beside the step's streaming sweeps is 1-3 us where a cached load behind a kernel boundary is 0.3-0.5.
+//  profiles/r3_variants.md.)
 // ------------------------------------------------------------------------------------------------
-#define LP_THREADS 256
-#define LP_MAX_BLOCKS 256
-#define LP_TMAX 16384u
-struct LevelSync {                          // device memory, zeroed before every launch
-    uint32_t prog[LP_MAX_BLOCKS];           // prog[b] = t + 1 once block b has finished sweep t; 0xffffffff: it has left
-    uint32_t result[8];                     // [0] first sweep without an assignment above the bound, [1] 1 = LP_TMAX reached, [2] spin time-outs
-    unsigned long long stat[LP_TMAX];       // per sweep: blocks finished << 32 | blocks that assigned something above the bound
-};
-size_t level_sync_bytes() { return sizeof(LevelSync); }
-#define LP_LD(P) __hip_atomic_load((P), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-#define LP_ST(P, V) __hip_atomic_store((P), (V), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-
-// the propagation op with agent-scope accesses to everything another block writes during the launch (level, when, marks)
+#define LS_TILES 4
 template <class MathT>
-struct OpLevelPropagateP : OpLevelPropagate<MathT> {
-    typedef OpLevelPropagate<MathT> B;
-    typedef typename B::Acc Acc;
-    typedef NBLevel NB;
-    __device__ bool lane_skip(uint32_t i) const
-    {
-        const uint32_t w = LP_LD(&this->when[i]);
-        return this->t == 0u ? w != 0u : !(w == LVL_UNASSIGNED && LP_LD(&this->mark_cur[i]) == this->t);
-    }
-    __device__ NB nb(const Acc&, uint32_t j, float4) const { return NB{LP_LD(&this->when[j]), LP_LD(&this->level[j]), j}; }
-    __device__ void pair(Acc& a, float4, NB Bj, float, float, float r2, float) const
-    {
-        if (Bj.w == LVL_UNASSIGNED) LP_ST(&this->mark_next[Bj.j], this->t + 1u);
-        if (!(Bj.w < this->t)) return;
-        if (r2 > a.r2max) return;
-        const float est = Bj.lv - sqrtf(r2);
-        a.best = a.have ? fmaxf(a.best, est) : est;
-        a.have = true;
-    }
-    __device__ bool finish(Acc& a, uint32_t i, float4, bool) const
-    {
-        if (this->t > 0u && a.have) {
-            LP_ST(&this->level[i], a.best);
-            LP_ST(&this->when[i], this->t);
-        }
-        return false;
-    }
-};
-
-template <class MathT>
-__global__ __launch_bounds__(LP_THREADS) void k_level_propagate_all(OpLevelPropagateP<MathT> op0, SweepCommon c, uint32_t shift, uint32_t* mark, LevelSync* sy,
-                                                                    uint32_t t_first, float reach_k, DeviceStatus* status)
+__global__ __launch_bounds__(256) void k_level_sweep(OpLevelPropagate<MathT> op, SweepCommon c, const uint32_t* __restrict__ tm_cur, uint32_t* __restrict__ tm_next,
+                                                     int first)
 {
-    typedef OpLevelPropagateP<MathT> Op;
-    const uint32_t b = blockIdx.x, nb = gridDim.x, tid = threadIdx.x;
-    const uint32_t s0 = b << shift, s1 = min(c.n, s0 + (1u << shift));
-    __shared__ uint32_t sh_lo[LP_THREADS / 64], sh_hi[LP_THREADS / 64], sh_stop;
-    Op op = op0;
-    // ---- the blocks this one exchanges with: index range of the stencils of its particles
-    uint32_t lo = s0, hi = s1;
-    for (uint32_t i = s0 + tid; i < s1; i += LP_THREADS) {
+    typedef OpLevelPropagate<MathT> Op;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t gw = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const uint32_t ntiles = (c.n + 63u) >> 6;
+    const uint32_t tile0 = gw * LS_TILES;
+    if (tile0 >= ntiles) return;
+    const uint32_t t = op.t;
+    bool marked = false;
+    if (lane < LS_TILES && tile0 + lane < ntiles) marked = first || tm_cur[tile0 + lane] == t;
+    uint32_t todo = (uint32_t)__ballot(marked);
+    if (!todo) return;
+    bool useful = false;
+    // (a loop, not unrolled, and no generic list replay inlined: the kernel is a few KB, so that a sweep does not wait for its own code)
+#pragma unroll 1
+    while (todo) {
+        const uint32_t k = (uint32_t)__ffs(todo) - 1u;
+        todo &= todo - 1u;
+        const uint32_t i = ((tile0 + k) << 6) + lane;
+        if (i >= c.n) continue;
+        const uint32_t w_i = op.when[i], m_i = op.mark_cur[i];
+        if (!(t == 0u ? w_i == 0u : (w_i == LVL_UNASSIGNED && m_i == t))) continue;
         const float4 Ai = op.loadA(i);
-        const float2 cp = OpCellPos<Op>::get(op, i, Ai);
-        const int cx = (int)floorf(cp.x / c.g.cs) - c.g.minx, cy = (int)floorf(cp.y / c.g.cs) - c.g.miny;
-        const int R = stencil_radius(c.g, c.t, Ai.w, cx, cy, reach_k);
-        const int y0 = min(max(cy - R, 0), c.g.sy - 1), y1 = max(min(cy + R, c.g.sy - 1), 0);
-        const int x0 = min(max(cx - R, 0), c.g.sx), x1 = max(min(cx + R + 1, c.g.sx), 0);
-        lo = min(lo, c.cell_start[(uint32_t)y0 * (uint32_t)c.g.sx + (uint32_t)x0]);
-        hi = max(hi, c.cell_start[(uint32_t)y1 * (uint32_t)c.g.sx + (uint32_t)x1]);
-    }
-    for (int o = 32; o > 0; o >>= 1) {
-        lo = min(lo, (uint32_t)__shfl_down((int)lo, o, 64));
-        hi = max(hi, (uint32_t)__shfl_down((int)hi, o, 64));
-    }
-    if ((tid & 63u) == 0u) {
-        sh_lo[tid >> 6] = lo;
-        sh_hi[tid >> 6] = hi;
-    }
-    if (tid == 0) sh_stop = 0u;
-    __syncthreads();
-    for (int k = 0; k < LP_THREADS / 64; k++) {
-        lo = min(lo, sh_lo[k]);
-        hi = max(hi, sh_hi[k]);
-    }
-    lo = __builtin_amdgcn_readfirstlane(lo);   // (every wave computed the same two numbers)
-    hi = __builtin_amdgcn_readfirstlane(hi);
-    const uint32_t blo = lo >> shift, bhi = min((max(hi, 1u) - 1u) >> shift, nb - 1u);
-    uint32_t chk = t_first;   // (thread 0) the first sweep whose statistics have not been looked at
-    uint32_t t = t_first;
-    for (; t < LP_TMAX; t++) {
-        if (t > t_first) {   // the neighbours' sweep t - 1 is complete
-            if (tid < 64u) {
-                const unsigned long long w0 = wall_clock64();
-                for (;;) {
-                    bool ok = true;
-                    for (uint32_t bb = blo + tid; bb <= bhi; bb += 64u) ok = ok && LP_LD(&sy->prog[bb]) >= t;
-                    if (__all(ok)) break;
-                    __builtin_amdgcn_s_sleep(2);
-                    if (wall_clock64() - w0 > 200000000ull) {   // 2 s at 100 MHz: a block that never became resident
-                        if (tid == 0) {
-                            sh_stop = 2u;
-                            atomicAdd(&sy->result[2], 1u);
-                            raise_error(status, SPH_ERR_DEVICE, t);
-                        }
-                        break;
-                    }
+        const uint4 lw = c.nl[i];
+        const float r2max = level_range_sq(Ai.z, op.range_factor, op.sp_rest_density);
+        float best = 0.f;
+        bool have = false;
+        // one neighbour whose (when, level, position) have arrived
+        auto visit = [&](uint32_t j, uint32_t wj, float lj, float2 xj) {
+            if (wj == LVL_UNASSIGNED) {
+                op.mark_next[j] = t + 1u;
+                tm_next[j >> 6] = t + 1u;
+            }
+            if (wj < t) {
+                const float dx = Ai.x - xj.x, dy = Ai.y - xj.y;
+                const float r2 = dx * dx + dy * dy;
+                if (!(r2 > r2max)) {
+                    const float est = lj - sqrtf(r2);
+                    best = have ? fmaxf(best, est) : est;
+                    have = true;
                 }
             }
-            __syncthreads();
-            if (sh_stop) break;
-        }
-        op.t = t;
-        op.mark_cur = mark + ((t & 1u) ? c.n : 0u);
-        op.mark_next = mark + ((t & 1u) ? 0u : c.n);
-        bool useful = t == 0u;
-        for (uint32_t i = s0 + tid; i < s1; i += LP_THREADS) {
-            if (op.lane_skip(i)) continue;
-            const float4 Ai = op.loadA(i);
-            const uint4 lw = c.nl[i];
-            if ((lw.w & NL_IDX) && c.nlx) {
-                const uint32_t cnt = lw.w & 0xffffu;
-                const float r2max = level_range_sq(Ai.z, op.range_factor, op.sp_rest_density);
-                float best = 0.f;
-                bool have = false;
-                for (uint32_t k0 = 0; k0 < cnt; k0 += 32u) {
-                    uint32_t jj[32], wj[32];
-                    float lj[32];
-                    float2 xj[32];
+        };
+        if ((lw.w & NL_IDX) && c.nlx) {
+            // 16 neighbours per trip: their (when, level, position) gathers all in flight, the index words of the NEXT trip
+            // already requested -- a list of ~30 neighbours is three dependent round trips (index words, two trips of gathers)
+            const uint32_t cnt = lw.w & 0xffffu;
+            uint4 qn[4];
 #pragma unroll
-                    for (int g = 0; g < 8; g++) {
-                        const uint32_t k = k0 + 4u * (uint32_t)g;
-                        const uint4 q = k < cnt ? c.nlx[(size_t)(k >> 2) * c.n + i] : make_uint4(i, i, i, i);
-                        jj[4 * g] = q.x;
-                        jj[4 * g + 1] = k + 1u < cnt ? q.y : i;
-                        jj[4 * g + 2] = k + 2u < cnt ? q.z : i;
-                        jj[4 * g + 3] = k + 3u < cnt ? q.w : i;
-                    }
+            for (int g = 0; g < 4; g++) qn[g] = 4u * (uint32_t)g < cnt ? c.nlx[(size_t)g * c.n + i] : make_uint4(i, i, i, i);
+#pragma unroll 1
+            for (uint32_t q0 = 0; q0 < cnt; q0 += 16u) {
+                uint32_t jj[16], wj[16];
+                float lj[16];
+                float2 xj[16];
 #pragma unroll
-                    for (int e = 0; e < 32; e++) {
-                        wj[e] = LP_LD(&op.when[jj[e]]);
-                        lj[e] = LP_LD(&op.level[jj[e]]);
-                        const float4* pj = op.pm + jj[e];
-                        xj[e] = *reinterpret_cast<const float2*>(pj);
-                    }
-#pragma unroll
-                    for (int e = 0; e < 32; e++) {
-                        if (k0 + (uint32_t)e < cnt) {
-                            if (wj[e] == LVL_UNASSIGNED) LP_ST(&op.mark_next[jj[e]], t + 1u);
-                            if (wj[e] < t) {
-                                const float dx = Ai.x - xj[e].x, dy = Ai.y - xj[e].y;
-                                const float r2 = dx * dx + dy * dy;
-                                if (!(r2 > r2max)) {
-                                    const float est = lj[e] - sqrtf(r2);
-                                    best = have ? fmaxf(best, est) : est;
-                                    have = true;
-                                }
-                            }
-                        }
-                    }
+                for (int g = 0; g < 4; g++) {
+                    const uint32_t kq = q0 + 4u * (uint32_t)g;
+                    jj[4 * g] = kq < cnt ? qn[g].x : i;
+                    jj[4 * g + 1] = kq + 1u < cnt ? qn[g].y : i;
+                    jj[4 * g + 2] = kq + 2u < cnt ? qn[g].z : i;
+                    jj[4 * g + 3] = kq + 3u < cnt ? qn[g].w : i;
                 }
-                if (t > 0u && have) {
-                    LP_ST(&op.level[i], best);
-                    LP_ST(&op.when[i], t);
-                    useful = useful || best > op.useful_above;
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const uint32_t kq = q0 + 16u + 4u * (uint32_t)g;
+                    if (kq < cnt) qn[g] = c.nlx[(size_t)(kq >> 2) * c.n + i];
+                }
+#pragma unroll
+                for (int e = 0; e < 16; e++) {
+                    wj[e] = op.when[jj[e]];
+                    lj[e] = op.level[jj[e]];
+                    xj[e] = *reinterpret_cast<const float2*>(op.pm + jj[e]);
+                }
+#pragma unroll
+                for (int e = 0; e < 16; e++)
+                    if (q0 + (uint32_t)e < cnt) visit(jj[e], wj[e], lj[e], xj[e]);
+            }
+        } else {
+            // the rare forms, one neighbour at a time: a mask word (the step's own k = 2 lists replayed after advection), or no
+            // recorded list at all (> 128 neighbours): the candidates of the stencil with the neighbour predicate, exactly as
+            // sweep_particle walks them (same cells, same operations, same order)
+            const float2 cp = OpCellPos<Op>::get(op, i, Ai);
+            const int cx = (int)floorf(cp.x / c.g.cs) - c.g.minx, cy = (int)floorf(cp.y / c.g.cs) - c.g.miny;
+            if (lw.w & NL_OK) {
+#pragma unroll 1
+                for (int dr = 0; dr < 3; dr++) {
+                    const int yy = cy + dr - 1;
+                    if (yy < 0 || yy >= c.g.sy) continue;
+                    const uint32_t base = c.cell_start[(uint32_t)yy * (uint32_t)c.g.sx + (uint32_t)max(cx - 1, 0)];
+                    uint32_t mk = dr == 0 ? lw.x : (dr == 1 ? lw.y : lw.z);
+#pragma unroll 1
+                    while (mk) {
+                        const uint32_t j = base + (uint32_t)__ffs(mk) - 1u;
+                        mk &= mk - 1u;
+                        visit(j, op.when[j], op.level[j], *reinterpret_cast<const float2*>(op.pm + j));
+                    }
                 }
             } else {
-                typename Op::Acc acc;
-                op.init(acc);
-                sweep_particle<Op, false>(op, c, acc, i, Ai, lw);
-                useful = useful || (t > 0u && acc.have && acc.best > op.useful_above);
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every store of this sweep has left the wave before the progress word moves
-        const int any = __syncthreads_or(useful ? 1 : 0);
-        if (tid == 0) {
-            __hip_atomic_fetch_add(&sy->stat[t], (1ull << 32) | (any ? 1ull : 0ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            LP_ST(&sy->prog[b], t + 1u);
-            while (chk <= t) {   // lazy end-of-loop test: complete sweeps only, in order
-                const unsigned long long v = LP_LD(&sy->stat[chk]);
-                if ((uint32_t)(v >> 32) < nb) break;
-                if ((uint32_t)v == 0u) {
-                    sh_stop = 1u;
-                    if (b == 0u) sy->result[0] = chk;
-                    break;
+                const int R = stencil_radius(c.g, c.t, Ai.w, cx, cy, op.krange());
+                const int x0 = max(cx - R, 0), x1 = min(cx + R + 1, c.g.sx);
+#pragma unroll 1
+                for (int yy = max(cy - R, 0); yy <= min(cy + R, c.g.sy - 1); yy++) {
+                    const uint32_t row = (uint32_t)yy * (uint32_t)c.g.sx;
+                    const uint32_t jb = c.cell_start[row + (uint32_t)x0], je = c.cell_start[row + (uint32_t)x1];
+#pragma unroll 1
+                    for (uint32_t j = jb; j < je; j++) {
+                        const float4 Aj = op.loadA(j);
+                        const float dx = Ai.x - Aj.x, dy = Ai.y - Aj.y;
+                        const float r2 = dx * dx + dy * dy;
+                        const float hij = MathT::UNIFORM ? op.m.h : (Ai.w + Aj.w) * 0.5f;
+                        const float sr = hij * op.krange();
+                        if (r2 < sr * sr) visit(j, op.when[j], op.level[j], make_float2(Aj.x, Aj.y));
+                    }
                 }
-                chk++;
             }
         }
-        __syncthreads();
-        if (sh_stop) break;
+        if (t > 0u && have) {
+            op.level[i] = best;
+            op.when[i] = t;
+            useful = useful || best > op.useful_above;
+        }
     }
-    if (tid == 0) {
-        LP_ST(&sy->prog[b], 0xffffffffu);   // nobody waits for a block that has left
-        if (t >= LP_TMAX) sy->result[1] = 1u;
-    }
+    if (useful) *op.changed = 1u;   // (same value from every lane)
 }
 
 // fill_stash_with (simulation.rs:886-893, 769-779): the level field as it stands, interior -> -maximum_surface_distance
@@ -2852,42 +2786,30 @@ void launch_level_propagate(hipStream_t s, Profiler* prof, const SweepArgs& a, c
                  -l.max_surface_distance, l.plain_propagate)
 }
 
-// the propagation sweeps t_first, t_first + 1, ... until one assigns nothing above the bound, in ONE launch (k_level_propagate_all).
-// `sync`: level_sync_bytes() of device memory; result words land in `result_host` (pinned host memory, 8 words) behind the kernel.
-static uint32_t level_propagate_blocks(int device)
-{
-    static int cus[64] = {0};
-    if (device < 0 || device >= 64) return 64u;
-    if (!cus[device]) {
-        int v = 0;
-        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || v <= 0) v = 64;
-        cus[device] = v;
-    }
-    return (uint32_t)std::min(cus[device], LP_MAX_BLOCKS);   // one resident workgroup per CU: the launch cannot strand a block
-}
-void launch_level_propagate_all(hipStream_t s, Profiler* prof, int device, const SweepArgs& a, const LevelArgs& l, uint32_t t_first, void* sync, uint32_t* result_host)
+// one propagation sweep through k_level_sweep (single context, frontier form).  `tile_marks`: level_tile_mark_bytes(n) of device
+// memory, zeroed before sweep 0 of a propagation: two parities of one word per tile of 64 slots.
+size_t level_tile_mark_bytes(uint32_t n) { return 2 * ((size_t)(n + 63u) / 64u) * sizeof(uint32_t); }
+void launch_level_sweep(hipStream_t s, Profiler* prof, const SweepArgs& a, const LevelArgs& l, uint32_t t, uint32_t* changed, uint32_t* tile_marks)
 {
     if (!a.n) return;
-    ProfScope ps(prof, "level_propagate_all", s);
-    const uint32_t nbmax = level_propagate_blocks(device);
-    uint32_t shift = 6;
-    while (((a.n + (1u << shift) - 1u) >> shift) > nbmax) shift++;
-    const uint32_t nb = (a.n + (1u << shift) - 1u) >> shift;
-    (void)hipMemsetAsync(sync, 0, sizeof(LevelSync), s);
-    const float reach_k = fmaxf(l.k, 2.f);   // (after advection without the extended range the step's own k = 2 lists are replayed)
+    ProfScope ps(prof, "level_propagate", s);
+    const uint32_t ntiles = (a.n + 63u) / 64u;
+    const uint32_t* tm_cur = tile_marks + (t & 1u) * ntiles;
+    uint32_t* tm_next = tile_marks + ((t + 1u) & 1u) * ntiles;
+    const uint32_t* mark_cur = l.mark + ((t & 1u) ? a.n : 0u);
+    uint32_t* mark_next = l.mark + ((t & 1u) ? 0u : a.n);
+    const uint32_t waves = (ntiles + LS_TILES - 1u) / LS_TILES;
     const SweepCommon c = common_of(a, true);
-    LevelSync* sy = (LevelSync*)sync;
-#define LP_LAUNCH(MATH, MINIT)                                                                                                                          \
+#define LS_LAUNCH(MATH, MINIT)                                                                                                                          \
     {                                                                                                                                                   \
-        OpLevelPropagateP<MATH> op{{MINIT, a.pm, l.pm_cell, l.level, l.when, l.mark, l.mark, nullptr, l.k, 0u, l.maximum_range, a.sp.rest_density,       \
-                                    -l.max_surface_distance, 0}};                                                                                       \
-        hipLaunchKernelGGL((k_level_propagate_all<MATH>), dim3(nb), dim3(LP_THREADS), 0, s, op, c, shift, l.mark, sy, t_first, reach_k, a.status);        \
+        OpLevelPropagate<MATH> op{MINIT, a.pm, l.pm_cell, l.level, l.when, mark_cur, mark_next, changed, l.k, t, l.maximum_range, a.sp.rest_density,     \
+                                  -l.max_surface_distance, 0};                                                                                          \
+        hipLaunchKernelGGL((k_level_sweep<MATH>), dim3((waves + 3u) / 4u), dim3(256), 0, s, op, c, tm_cur, tm_next, t == 0u ? 1 : 0);                   \
     }
-    if (a.exact) LP_LAUNCH(MathExact, MathExact{0.f})
-    else if (a.uniform_h) LP_LAUNCH(MathUniform, uniform_math(a.h_uniform))
-    else LP_LAUNCH(MathFast, MathFast{0.f})
-#undef LP_LAUNCH
-    if (result_host) (void)hipMemcpyAsync(result_host, sy->result, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+    if (a.exact) LS_LAUNCH(MathExact, MathExact{0.f})
+    else if (a.uniform_h) LS_LAUNCH(MathUniform, uniform_math(a.h_uniform))
+    else LS_LAUNCH(MathFast, MathFast{0.f})
+#undef LS_LAUNCH
 }
 
 void launch_fill_stash(hipStream_t s, Profiler* prof, const SweepArgs& a, const LevelArgs& l, float* stash)

@@ -86,6 +86,13 @@ class _PCounter:
     def add_value(self, ms: float):
         self.values.append(int(round(float(ms) * 1e6)))
 
+    def add_to_last(self, ms: float):
+        """end_add_to_last (simulation.rs:159-189): the duration joins the LAST sample instead of becoming one."""
+        if self.values:
+            self.values[-1] += int(round(float(ms) * 1e6))
+        else:
+            self.add_value(ms)
+
     def sum_secs(self) -> float:
         return sum(self.values) / 1e9
 
@@ -165,7 +172,11 @@ class FluidSimulation:
         t0 = _time.perf_counter()
         info = self._adaptivity.single_step_adaptivity(P, dt, self.step_number)
         if self.counters_enabled:
-            self._p("adaptivity", (_time.perf_counter() - t0) * 1e3)        # pcounters "adaptivity" (:2734, 2793)
+            ms = (_time.perf_counter() - t0) * 1e3
+            self._p("adaptivity", ms)                                        # pcounters "adaptivity" (:2734, 2794)
+            # :2733, 2795: begin("simulation-step") ... end_add_to_last("simulation-step") -- the adaptivity time belongs to the
+            # step's own sample (and so to `simulation-time`), it does not open a new one
+            self.pcounters.setdefault("simulation-step", _PCounter()).add_to_last(ms)
         return info
 
     def neighbors(self):

@@ -65,6 +65,25 @@ __device__ __forceinline__ void grad_uniform(const Math& m, float dx, float dy, 
     gy = s * dy;
 }
 
+// LAB_CHECK=1: every gathered index is tested against its array's length; the first violation is recorded instead of faulting
+#ifndef LAB_CHECK
+#define LAB_CHECK 0
+#endif
+__device__ uint32_t g_bad[4];
+__device__ __forceinline__ uint32_t ix(uint32_t j, uint32_t lim, uint32_t tag)
+{
+#if LAB_CHECK
+    if (j >= lim) {
+        if (atomicCAS(&g_bad[0], 0u, tag) == 0u) {
+            g_bad[1] = j;
+            g_bad[2] = lim;
+            g_bad[3] = blockIdx.x * 256 + threadIdx.x;
+        }
+        return 0u;
+    }
+#endif
+    return j;
+}
 struct Acc {
     float sum, qx, qy, inv_rho;
 };
@@ -77,6 +96,23 @@ __device__ __forceinline__ void pair(const Args& A, Acc& a, float xi, float yi, 
         grad_uniform(A.m, dx, dy, r2, gx, gy);
         const float dot = (apx - a.qx) * gx + (apy - a.qy) * gy;
         a.sum += A.mass * a.inv_rho * dot;
+    }
+}
+// the same pair with the instruction mix of scripts/ubench/valu_issue.hip in mind (a compare or a select issues at half the rate of
+// a multiply, a transcendental at a quarter): truncated-power spline W'(q) = 6 [4 (1/2 - q)+^2 - (1 - q)+^2] (two v_max instead of
+// two compare + select pairs), r2 clamped away from 0 instead of the q > 1e-5 select (dx = dy = 0 then gives g = 0 by itself),
+// the constant factors folded (nf6 = 6 nf / (2h)), the mass / rho_i factor applied once per particle.
+__device__ __forceinline__ void pair_slim(const Args& A, Acc& a, float xi, float yi, float xj, float yj, float apx, float apy, bool on, float nf6)
+{
+    const float dx = xi - xj, dy = yi - yj;
+    const float r2 = fmaxf(dx * dx + dy * dy, 1.0e-30f);
+    if (on) {
+        const float rinv = __builtin_amdgcn_rsqf(r2);
+        const float q = (r2 * rinv) * A.m.inv2h;
+        const float u = fmaxf(1.f - q, 0.f), t = fmaxf(0.5f - q, 0.f);
+        const float d = fmaf(4.f * t, t, -(u * u));
+        const float s = nf6 * d * rinv;
+        a.sum = fmaf((apx - a.qx) * s, dx, fmaf((apy - a.qy) * s, dy, a.sum));
     }
 }
 __device__ __forceinline__ void finish(const Args& A, const Acc& a, uint32_t i, float rho_i)
@@ -100,7 +136,7 @@ __device__ __forceinline__ void row_bases(const Args& A, float x, float y, uint3
     for (int dr = 0; dr < 3; dr++) {
         const int yy = cy + dr - 1;
         const bool ok = yy >= 0 && yy < A.g.sy;
-        rb[dr] = ok ? A.cell_start[(uint32_t)yy * (uint32_t)A.g.sx + (uint32_t)max(cx - 1, 0)] : 0u;
+        rb[dr] = ok ? A.cell_start[ix((uint32_t)yy * (uint32_t)A.g.sx + (uint32_t)max(cx - 1, 0), (uint32_t)A.g.sx * (uint32_t)A.g.sy + 1u, 1u)] : 0u;
     }
 }
 
@@ -142,14 +178,14 @@ __global__ __launch_bounds__(256) void k_gather4(Args A)
             const uint32_t b3 = v3 ? __ffs(mk) - 1 : b0;
             mk &= mk - 1;
             if (COMB) {
-                const float4 R0 = A.comb[base + b0], R1 = A.comb[base + b1], R2 = A.comb[base + b2], R3 = A.comb[base + b3];
+                const float4 R0 = A.comb[ix(base + b0, A.n, 2u)], R1 = A.comb[ix(base + b1, A.n, 2u)], R2 = A.comb[ix(base + b2, A.n, 2u)], R3 = A.comb[ix(base + b3, A.n, 2u)];
                 pair(A, a, Ai.x, Ai.y, R0.x, R0.y, R0.z, R0.w, true);
                 pair(A, a, Ai.x, Ai.y, R1.x, R1.y, R1.z, R1.w, v1);
                 pair(A, a, Ai.x, Ai.y, R2.x, R2.y, R2.z, R2.w, v2);
                 pair(A, a, Ai.x, Ai.y, R3.x, R3.y, R3.z, R3.w, v3);
             } else {
-                const float4 R0 = A.pm[base + b0], R1 = A.pm[base + b1], R2 = A.pm[base + b2], R3 = A.pm[base + b3];
-                const float2 P0 = A.pacc[base + b0], P1 = A.pacc[base + b1], P2 = A.pacc[base + b2], P3 = A.pacc[base + b3];
+                const float4 R0 = A.pm[ix(base + b0, A.n, 2u)], R1 = A.pm[ix(base + b1, A.n, 2u)], R2 = A.pm[ix(base + b2, A.n, 2u)], R3 = A.pm[ix(base + b3, A.n, 2u)];
+                const float2 P0 = A.pacc[ix(base + b0, A.n, 2u)], P1 = A.pacc[ix(base + b1, A.n, 2u)], P2 = A.pacc[ix(base + b2, A.n, 2u)], P3 = A.pacc[ix(base + b3, A.n, 2u)];
                 pair(A, a, Ai.x, Ai.y, R0.x, R0.y, P0.x, P0.y, true);
                 pair(A, a, Ai.x, Ai.y, R1.x, R1.y, P1.x, P1.y, v1);
                 pair(A, a, Ai.x, Ai.y, R2.x, R2.y, P2.x, P2.y, v2);
@@ -158,6 +194,67 @@ __global__ __launch_bounds__(256) void k_gather4(Args A)
         }
     }
     finish(A, a, i, rho_i);
+}
+
+// ---- variant: combined record, trips of 4, slim pair arithmetic; HOIST: the finish's own loads (a_ii, s, p) requested at the top ----
+template <int HOIST>
+__global__ __launch_bounds__(256) void k_gather4_slim(Args A)
+{
+    const uint32_t blk = remap_block(A.nblocks);
+    if (blk >= A.nblocks) return;
+    const uint32_t i = blk * 256 + threadIdx.x;
+    if (i >= A.n) return;
+    const float4 Ai = A.comb[i];
+    const uint4 lw = A.nl[i];
+    const float rho_i = A.rho[i];
+    float aii_i = 0.f, src_i = 0.f, pin_i = 0.f;
+    if (HOIST) {
+        aii_i = A.aii[i];
+        src_i = A.src[i];
+        pin_i = A.p_in[i];
+    }
+    uint32_t rb[3];
+    int cx, cy;
+    row_bases(A, Ai.x, Ai.y, rb, cx, cy);
+    Acc a;
+    a.sum = 0.f;
+    a.inv_rho = __builtin_amdgcn_rcpf(rho_i);
+    a.qx = Ai.z;
+    a.qy = Ai.w;
+    const float nf6 = 6.f * A.m.nf * A.m.inv2h;
+    const uint32_t masks[3] = {lw.x, lw.y, lw.z};
+#pragma unroll
+    for (int dr = 0; dr < 3; dr++) {
+        uint32_t mk = masks[dr];
+        const uint32_t base = rb[dr];
+        while (mk) {
+            const uint32_t b0 = __ffs(mk) - 1;
+            mk &= mk - 1;
+            const bool v1 = mk != 0;
+            const uint32_t b1 = v1 ? __ffs(mk) - 1 : b0;
+            mk &= mk - 1;
+            const bool v2 = mk != 0;
+            const uint32_t b2 = v2 ? __ffs(mk) - 1 : b0;
+            mk &= mk - 1;
+            const bool v3 = mk != 0;
+            const uint32_t b3 = v3 ? __ffs(mk) - 1 : b0;
+            mk &= mk - 1;
+            const float4 R0 = A.comb[ix(base + b0, A.n, 2u)], R1 = A.comb[ix(base + b1, A.n, 2u)], R2 = A.comb[ix(base + b2, A.n, 2u)], R3 = A.comb[ix(base + b3, A.n, 2u)];
+            pair_slim(A, a, Ai.x, Ai.y, R0.x, R0.y, R0.z, R0.w, true, nf6);
+            pair_slim(A, a, Ai.x, Ai.y, R1.x, R1.y, R1.z, R1.w, v1, nf6);
+            pair_slim(A, a, Ai.x, Ai.y, R2.x, R2.y, R2.z, R2.w, v2, nf6);
+            pair_slim(A, a, Ai.x, Ai.y, R3.x, R3.y, R3.z, R3.w, v3, nf6);
+        }
+    }
+    a.sum *= A.mass * a.inv_rho;
+    if (HOIST) {
+        const float pn = pin_i + A.omega * (src_i - a.sum) / aii_i;
+        const bool pos = pn > 0.f;
+        A.p_out[i] = pos ? pn : 0.f;
+        A.pt_out[i] = pos ? pn / (rho_i * rho_i) : 0.f;
+    } else {
+        finish(A, a, i, rho_i);
+    }
 }
 
 // ---- variant: no neighbour work at all (own loads, finish, stores): the floor of the launch ----
@@ -213,8 +310,8 @@ __global__ __launch_bounds__(256) void k_lds(Args A)
         const int yy = cyf + dr - 1;
         const bool in = yy >= 0 && yy < A.g.sy;
         const uint32_t row = (uint32_t)(in ? yy : 0) * (uint32_t)A.g.sx;
-        sb[dr] = in ? A.cell_start[row + (uint32_t)max(cxf - 1, 0)] : 0u;
-        const uint32_t se = in ? A.cell_start[row + (uint32_t)min(cxl + 2, A.g.sx)] : sb[dr];
+        sb[dr] = in ? A.cell_start[ix(row + (uint32_t)max(cxf - 1, 0), (uint32_t)A.g.sx * (uint32_t)A.g.sy + 1u, 5u)] : 0u;
+        const uint32_t se = in ? A.cell_start[ix(row + (uint32_t)min(cxl + 2, A.g.sx), (uint32_t)A.g.sx * (uint32_t)A.g.sy + 1u, 6u)] : sb[dr];
         sl[dr] = se - sb[dr];
         ok = ok && sl[dr] <= (uint32_t)CAP;
     }
@@ -234,8 +331,8 @@ __global__ __launch_bounds__(256) void k_lds(Args A)
                 while (mk) {
                     const uint32_t b0 = __ffs(mk) - 1;
                     mk &= mk - 1;
-                    const float4 R = A.pm[rb[dr] + b0];
-                    const float2 P = A.pacc[rb[dr] + b0];
+                    const float4 R = A.pm[ix(rb[dr] + b0, A.n, 3u)];
+                    const float2 P = A.pacc[ix(rb[dr] + b0, A.n, 3u)];
                     pair(A, a, Ai.x, Ai.y, R.x, R.y, P.x, P.y, true);
                 }
             }
@@ -251,9 +348,9 @@ __global__ __launch_bounds__(256) void k_lds(Args A)
 #pragma unroll
         for (int t = 0; t < 2; t++) {
             const uint32_t k = lane + 64u * t;
-            const uint32_t j = sb[dr] + min(k, sl[dr] ? sl[dr] - 1u : 0u);
-            r_[dr][t] = A.pm[j];
-            p_[dr][t] = A.pacc[j];
+            const uint32_t j = sl[dr] ? sb[dr] + min(k, sl[dr] - 1u) : 0u;   // (an empty window may start at n: cells behind the last particle)
+            r_[dr][t] = A.pm[ix(j, A.n, 4u)];
+            p_[dr][t] = A.pacc[ix(j, A.n, 4u)];
         }
     }
 #pragma unroll
@@ -343,13 +440,13 @@ __global__ __launch_bounds__(256) void k_gather_loop(Args A)
             const uint32_t b0 = __ffs(mk) - 1;
             mk &= mk - 1;
             if (PER == 1) {
-                const float4 R0 = A.comb[base + b0];
+                const float4 R0 = A.comb[ix(base + b0, A.n, 2u)];
                 pair(A, a, Ai.x, Ai.y, R0.x, R0.y, R0.z, R0.w, true);
             } else {
                 const bool v1 = mk != 0;
                 const uint32_t b1 = v1 ? __ffs(mk) - 1 : b0;
                 mk &= mk - 1;
-                const float4 R0 = A.comb[base + b0], R1 = A.comb[base + b1];
+                const float4 R0 = A.comb[ix(base + b0, A.n, 2u)], R1 = A.comb[ix(base + b1, A.n, 2u)];
                 pair(A, a, Ai.x, Ai.y, R0.x, R0.y, R0.z, R0.w, true);
                 pair(A, a, Ai.x, Ai.y, R1.x, R1.y, R1.z, R1.w, v1);
             }
@@ -379,6 +476,32 @@ __global__ __launch_bounds__(256) void k_math_only(Args A)
 #pragma unroll 4
     for (int s = 0; s < SLOTS; s++) {
         pair(A, a, Ai.x, Ai.y, xj, yj, q.y, q.x, true);
+        xj += 1e-5f;
+        yj -= 1e-5f;
+    }
+    finish(A, a, i, rho_i);
+}
+
+template <int SLOTS>
+__global__ __launch_bounds__(256) void k_math_only_slim(Args A)
+{
+    const uint32_t blk = remap_block(A.nblocks);
+    if (blk >= A.nblocks) return;
+    const uint32_t i = blk * 256 + threadIdx.x;
+    if (i >= A.n) return;
+    const float4 Ai = A.pm[i];
+    Acc a;
+    a.sum = 0.f;
+    const float rho_i = A.rho[i];
+    a.inv_rho = __builtin_amdgcn_rcpf(rho_i);
+    const float2 q = A.pacc[i];
+    a.qx = q.x;
+    a.qy = q.y;
+    const float nf6 = 6.f * A.m.nf * A.m.inv2h;
+    float xj = Ai.x + 0.0007f, yj = Ai.y - 0.0004f;
+#pragma unroll 4
+    for (int s = 0; s < SLOTS; s++) {
+        pair_slim(A, a, Ai.x, Ai.y, xj, yj, q.y, q.x, true, nf6);
         xj += 1e-5f;
         yj -= 1e-5f;
     }
@@ -458,6 +581,7 @@ int main(int argc, char** argv)
         nl[s] = make_uint4(mk[0], mk[1], mk[2], cnt);
         sum_cnt += cnt;
     }
+    setvbuf(stdout, nullptr, _IOLBF, 0);
     printf("n = %u, cells %d x %d, %.2f neighbours per particle (self excluded), %.2f slots per particle in trips of 4 (per lane), rows > 32 candidates: %u\n", n, g.sx,
            g.sy, sum_cnt / n, sum_slots4 / n, overflow);
     std::vector<float> rho(n), aii(n), src(n), pin(n);
@@ -505,6 +629,8 @@ int main(int argc, char** argv)
     const V_ vs[] = {
         {"gather4 (product form: 16-B record + 8-B payload gathers, trips of 4)", k_gather4<0>, true},
         {"gather4, one combined 16-B record {x, y, a^p}", k_gather4<1>, true},
+        {"gather4, combined record, slim pair arithmetic (v_max spline, clamped r2, folded constants, fma)", k_gather4_slim<0>, true},
+        {"gather4, combined record, slim pair arithmetic, finish's loads requested at the top", k_gather4_slim<1>, true},
         {"gather, combined record, 2 bits per iteration (no padding beyond pairs)", k_gather_loop<2>, true},
         {"gather, combined record, 1 bit per iteration (no padding slots)", k_gather_loop<1>, true},
         {"LDS windows per wave, trips of 4", k_lds<0>, true},
@@ -513,6 +639,8 @@ int main(int argc, char** argv)
         {"own loads + finish only (no neighbours)", k_own_only, false},
         {"pair arithmetic only, 12 slots in registers (no loads, no decoding)", k_math_only<12>, false},
         {"pair arithmetic only, 20 slots in registers", k_math_only<20>, false},
+        {"slim pair arithmetic only, 12 slots in registers", k_math_only_slim<12>, false},
+        {"slim pair arithmetic only, 20 slots in registers", k_math_only_slim<20>, false},
     };
     printf("| variant | us per launch (HIP events, %d launches back to back) | max rel diff of p' vs variant 0 |\n|---|---|---|\n", reps);
     bool have_ref = false;
@@ -521,6 +649,15 @@ int main(int argc, char** argv)
         hipLaunchKernelGGL(v.k, dim3(grid), dim3(256), 0, 0, A);
         CHECK(hipDeviceSynchronize());
         CHECK(hipMemcpy(out.data(), A.p_out, (size_t)n * 4, hipMemcpyDeviceToHost));
+#if LAB_CHECK
+        {
+            uint32_t bad[4] = {0, 0, 0, 0}, zero[4] = {0, 0, 0, 0};
+            CHECK(hipMemcpyFromSymbol(bad, HIP_SYMBOL(g_bad), sizeof bad));
+            if (bad[0]) printf("!! %s: index check %u failed: index %u >= %u at thread %u\n", v.name, bad[0], bad[1], bad[2], bad[3]);
+            CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_bad), zero, sizeof zero));
+        }
+        fflush(stdout);
+#endif
         double err = 0, mx = 0;
         if (!have_ref) {
             ref = out;
@@ -540,6 +677,7 @@ int main(int argc, char** argv)
         CHECK(hipEventElapsedTime(&ms, e0, e1));
         if (v.check) printf("| %s | %.2f | %.2e |\n", v.name, ms * 1e3 / reps, mx > 0 ? err / mx : 0.0);
         else printf("| %s | %.2f | - |\n", v.name, ms * 1e3 / reps);
+        fflush(stdout);
     }
     return 0;
 }

@@ -220,11 +220,10 @@ def test_level_estimation_uniform_block(product_lib, oracle_lib, stash):
 
 @pytest.mark.parametrize("scene", ["uniform_256", "graded"])
 @pytest.mark.parametrize("stash", [None, "SurfaceDistanceMiddle"])
-def test_one_launch_propagation_is_bit_identical_to_one_launch_per_sweep(product_lib, monkeypatch, scene, stash):
-    """The level-set propagation as ONE launch (k_level_propagate_all: resident workgroups, neighbour-only hand-over, lazy end of
-    loop) against the form before it -- one launch per sweep, batches, a host wait per batch (SPH_LEVEL_LAUNCHES=1 at
-    sph_create): every level output bit for bit, over several steps, on a scene deep enough for ~50 sweeps with many blocks and
-    on a multi-resolution one (wide stencils: a block waits for more than its two neighbours)."""
+def test_dedicated_propagation_sweep_is_bit_identical_to_the_generic_one(product_lib, monkeypatch, scene, stash):
+    """The level-set propagation sweep as the kernel built for it (k_level_sweep: per-tile frontier marks, a candidate's whole
+    list gathered in one batch) against the same sweep through the generic skeleton (SPH_LEVEL_GENERIC=1 at sph_create): every
+    level output bit for bit, over several steps, on a scene deep enough for ~50 sweeps and on a multi-resolution one."""
     if scene == "uniform_256":
         scn = sc.dam_break_small(256, 256, 1 / 256)
         pos, mass, vel = sc.init_particles(scn)
@@ -238,9 +237,9 @@ def test_one_launch_propagation_is_bit_identical_to_one_launch_per_sweep(product
     P.fill_stash_with = stash
     p = P.to_ffi()
     a = ffi.Context(product_lib, len(mass), planes)
-    monkeypatch.setenv("SPH_LEVEL_LAUNCHES", "1")
+    monkeypatch.setenv("SPH_LEVEL_GENERIC", "1")
     b = ffi.Context(product_lib, len(mass), planes)
-    monkeypatch.delenv("SPH_LEVEL_LAUNCHES")
+    monkeypatch.delenv("SPH_LEVEL_GENERIC")
     for c in (a, b):
         c.upload(mass, pos, vel)
     for s in range(4):
@@ -727,8 +726,10 @@ def test_bench_window_of_config1_against_the_oracle(product_lib, oracle_lib):
       * while every count so far agreed: dt bit-equal within 1e-6, density 1e-4, displacement from the uploaded positions 1e-3
         (tests/oracle_harness.displacement_bars) at every such step, and at least the first 4 steps are such steps;
       * over the whole window the device stays as close to the oracle as to its own twin: mean |difference of the iteration
-        counts|, final dt, the BULK of the particles (median displacement error, median density error) each within 3 x the twin's
-        figure (+ the floor stated with it);
+        counts|, the largest dt difference, the BULK of the particles (median and 99th-percentile displacement error, median density
+        error) each within 3 x the twin's
+        figure (+ the floor stated with it); measured: counts 1.6 vs 0.8 apart on average, dt up to 6.9 % vs 4.9 %, median displacement
+        error 4e-7 vs 6e-7 of a 5.6e-4 median displacement, median density error 2e-7 vs 0;
       * the bulk itself: median displacement error <= 2e-3 of the median displacement, median |density error| <= 1e-4 rho_0."""
     scn = sc.dam_break_1m()
     g, o = make_pair(product_lib, oracle_lib, scn)
@@ -778,8 +779,9 @@ def test_bench_window_of_config1_against_the_oracle(product_lib, oracle_lib):
         assert r["dt_rel"] <= 1e-6 and r["rho_err"] <= REL_TOL_FIELDS and r["disp_ok"], report
     ulp = float(np.spacing(np.float32(2.0)))
     assert d_o <= 3.0 * d_t + 0.5, report
-    assert rows[-1]["dt_rel"] <= 3.0 * rows[-1]["dt_rel_twin"] + 1e-3, report
+    assert max(r["dt_rel"] for r in rows) <= 3.0 * max(r["dt_rel_twin"] for r in rows) + 1e-3, report     # (measured: 6.9 % vs 4.9 %)
     assert end_o["median_disp_err"] <= 3.0 * end_t["median_disp_err"] + 2 * ulp, report
+    assert end_o["p99_disp_err"] <= 3.0 * end_t["p99_disp_err"] + 2 * ulp, report
     assert end_o["median_rho_err"] <= 3.0 * end_t["median_rho_err"] + 1e-6, report
     assert end_o["median_disp_err"] <= 2e-3 * end_o["median_disp"] + ulp and end_o["median_rho_err"] <= 1e-4, report
     # the window is the violent one: the driver's line quotes ~11 + ~9 iterations per step on it
