@@ -427,9 +427,15 @@ extern "C" int sph_create(uint64_t n_capacity, int device_id, const sph_plane* p
         return code;
     };
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return bail(SPH_ERR_DEVICE);
-    if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess) return bail(SPH_ERR_DEVICE);
+    {
+        // the side stream carries the level-set propagation: ~100 tiny dependent launches that must slot in between the waves of
+        // the main stream's sweeps -- highest priority, so that the dispatcher serves it first whenever a CU has room
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        if (getenv("SPH_SIDE_STREAM_NORMAL") || hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, hi) != hipSuccess)
+            if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess) return bail(SPH_ERR_DEVICE);
+    }
     if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess) return bail(SPH_ERR_DEVICE);
-    c->level_generic_sweeps = getenv("SPH_LEVEL_GENERIC") != nullptr;
     for (auto& e : c->ev)
         if (hipEventCreate(&e) != hipSuccess) return bail(SPH_ERR_DEVICE);
     if (alloc_particle_buffers(c) != SPH_OK) return bail(SPH_ERR_DEVICE);
@@ -506,7 +512,7 @@ extern "C" void sph_destroy(sph_ctx* c)
     dist_release(c);
     DevBuf* all[] = {&c->pm[0], &c->pm[1], &c->vel[0], &c->vel[1], &c->orig[0], &c->orig[1], &c->lvl[0], &c->lvl[1], &c->lvlold[0],
                      &c->lvlold[1], &c->vel_tmp, &c->key[0], &c->key[1], &c->val[0], &c->val[1], &c->sort_scratch, &c->cxy, &c->cell_start,
-                     &c->cs_scratch, &c->hdr_ahead_partials, &c->h2n[0], &c->h2n[1], &c->lam_prev, &c->nl, &c->nlx, &c->tile_raw, &c->tile_h, &c->tile_h_ext, &c->lvl_changed_d, &c->lvl_tmark, &c->lvl_tmp, &c->lvl_nrm, &c->lvl_state, &c->lvl_when, &c->lvl_mark, &c->flag_surface,
+                     &c->cs_scratch, &c->hdr_ahead_partials, &c->h2n[0], &c->h2n[1], &c->lam_prev, &c->nl, &c->nlx, &c->tile_raw, &c->tile_h, &c->tile_h_ext, &c->lvl_changed_d, &c->lvl_tmp, &c->lvl_nrm, &c->lvl_state, &c->lvl_when, &c->lvl_mark, &c->flag_surface,
                      &c->flag_insufficient, &c->con_thr, &c->con_consumed, &c->con_h, &c->flag_reduced, &c->szc[0], &c->szc[1], &c->omega, &c->stash, &c->nl_ext, &c->nlx_ext, &c->nl_ok, &c->mrho, &c->pt0, &c->pt1, &c->rho, &c->lam_sum, &c->lam_grad, &c->constf, &c->aii, &c->src, &c->p0, &c->p1, &c->pacc, &c->dens_err,
                      &c->stat, &c->ncount, &c->planes_d, &c->lam_lut, &c->dlam_lut, &c->hdr_partials, &c->hdr_out, &c->ctrl, &c->status,
                      &c->n_tiles, &c->red_partials, &c->scratch, &c->split_patterns};

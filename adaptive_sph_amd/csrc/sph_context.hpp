@@ -41,7 +41,6 @@ struct sph_ctx {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;   // side stream: the level estimation before advection runs under the step's own sweeps
     hipEvent_t ev_fork = nullptr;    // main -> side stream dependency
-    bool level_generic_sweeps = false;   // SPH_LEVEL_GENERIC=1 at sph_create: propagation sweeps through the generic skeleton (the form before round 3; measurement, tests)
     uint32_t level_seq = 0;          // sequence number of the side stream's publishes (lvl_changed[63])
     int n_planes = 0;
     BoundaryP bnd_h{};   // planes, or one Sdf2D polygon (sph_set_boundary_polygon)
@@ -143,7 +142,6 @@ struct sph_ctx {
     DevBuf split_patterns;            // SplitPatterns::pos_s of every pattern, concatenated float2 (sph_set_split_patterns)
     uint32_t n_split_patterns = 0;
     bool have_level = false;            // the level-estimation outputs above are those of the last step
-    DevBuf lvl_tmark;                   // per-tile frontier marks of the propagation sweeps (k_level_sweep, sph_sweeps.hip)
     DevBuf lvl_changed_d;               // per-sweep "assigned something" words of a batch (device), published once per batch
     uint32_t* lvl_changed = nullptr;    // mapped pinned host copy
     uint32_t last_level_sweeps = 0;     // effective propagation sweeps of the previous step (length of the next first batch)

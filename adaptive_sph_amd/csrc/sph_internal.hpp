@@ -224,9 +224,6 @@ void launch_tile_redilate(hipStream_t s, Profiler* prof, int tsx, int tsy, int d
 void launch_level_detect(hipStream_t s, Profiler* prof, const SweepArgs& a, const LevelArgs& l);
 void launch_level_propagate(hipStream_t s, Profiler* prof, const SweepArgs& a, const LevelArgs& l, uint32_t t, uint32_t* changed);
 void launch_fill_stash(hipStream_t s, Profiler* prof, const SweepArgs& a, const LevelArgs& l, float* stash);
-// the same sweep through the kernel built for it (tile marks, batched candidate evaluation; single context, frontier form)
-size_t level_tile_mark_bytes(uint32_t n);
-void launch_level_sweep(hipStream_t s, Profiler* prof, const SweepArgs& a, const LevelArgs& l, uint32_t t, uint32_t* changed, uint32_t* tile_marks);
 void launch_level_smooth(hipStream_t s, Profiler* prof, const SweepArgs& a, const LevelArgs& l, const float4* pm_new, const float* in, float* out);
 void launch_classify(hipStream_t s, Profiler* prof, uint32_t n, const float4* pm, const float* level, uint8_t* size_class, const uint8_t* owned,
                      const uint32_t* orig, DeviceStatus* status, const sph_params* p);

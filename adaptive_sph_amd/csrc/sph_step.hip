@@ -2601,7 +2601,6 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
     // latency-bound propagation sweeps run under the step's own sweeps); level_estimation_finish() collects it.
     struct LevelPending {
         bool on = false;
-        uint32_t* tmark = nullptr;   // tile marks when the sweeps run through k_level_sweep
         uint32_t t = 1, effective = 0;
         int B = 8;
     } lvp;
@@ -2684,18 +2683,6 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
             // host learns once per batch how many of them assigned something (a sweep behind the last effective one has no
             // candidates and costs a scan).  The first batch is as long as the previous step's propagation + 1 -- the fluid's
             // depth hardly changes from step to step -- so a step usually waits once instead of once per 8 sweeps.
-            // (single context, frontier form: the sweep kernel built for it; SPH_LEVEL_GENERIC keeps the generic skeleton)
-            uint32_t* tmark = nullptr;
-            if (!c->level_generic_sweeps) {
-                HIPCHK(c, c->lvl_tmark.ensure(level_tile_mark_bytes(m.n)));
-                tmark = c->lvl_tmark.as<uint32_t>();
-                (void)hipMemsetAsync(tmark, 0, level_tile_mark_bytes(m.n), ls);
-            }
-            lvp.tmark = tmark;
-            auto launch_level_propagate = [tmark](hipStream_t st, Profiler* pr, const SweepArgs& aa, const LevelArgs& ll, uint32_t tt, uint32_t* changed) {
-                if (tmark) launch_level_sweep(st, pr, aa, ll, tt, changed, tmark);
-                else ::launch_level_propagate(st, pr, aa, ll, tt, changed);
-            };
             launch_level_propagate(ls, &c->prof, al, lv, 0u, chg + 1023);   // surface particles mark their neighbours
             uint32_t t = 1, effective = 0;
             int B = (int)std::min<uint32_t>(std::max<uint32_t>(c->last_level_sweeps + 1u, 8u), 1000u);
@@ -2751,10 +2738,7 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
             if (changed < (uint32_t)B) break;
             B = 8;
             (void)hipMemsetAsync(chg, 0, (size_t)B * sizeof(uint32_t), ls);
-            for (int b = 0; b < B; b++, t++) {
-                if (lvp.tmark) launch_level_sweep(ls, &c->prof, lv_args, lv, t, chg + b, lvp.tmark);
-                else launch_level_propagate(ls, &c->prof, lv_args, lv, t, chg + b);
-            }
+            for (int b = 0; b < B; b++, t++) launch_level_propagate(ls, &c->prof, lv_args, lv, t, chg + b);
             c->level_seq++;
             if (c->level_seq == 0u) c->level_seq = 1u;
             hipLaunchKernelGGL(k_publish_count, dim3(1), dim3(64), 0, ls, chg, (uint32_t)B, c->lvl_changed_dev, 63u, c->level_seq);

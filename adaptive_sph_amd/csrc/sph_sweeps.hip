@@ -1960,152 +1960,12 @@ struct OpLevelPropagate {
     }
 };
 
-// ------------------------------------------------------------------------------------------------
-// A propagation sweep as a launch of its own, built for what a sweep IS: ~100 of them per step, a few thousand working
-// particles each, in a thin closed curve through the fluid.  Through the generic skeleton (k_sweep<OpLevelPropagate>) a sweep
-// costs 14 us at N = 1M whatever it does: 4096 workgroups are dispatched to read two words per lane and leave, and a frontier
-// lane walks its list in trips of four -- eight trips of two dependent, cache-cold round trips each.  Here:
-//   * besides the per-particle mark, a marker stores the sweep number into ONE WORD PER TILE of 64 consecutive slots (two
-//     parities, like the marks).  A wave owns LS_TILES consecutive tiles, asks for their words first and leaves if none carries
-//     this sweep's number: a quarter of the workgroups, one load per wave instead of two per lane;
-//   * a candidate with an index list (every particle of the extended-range lists) is evaluated 16 neighbours per trip, all their
-//     gathers in flight at once and the next trip's index words already requested -- three dependent round trips per candidate.
-// Same values as the generic sweep (`max` over the same neighbour set), bit for bit.
-// (Measured negative, round 3: the whole propagation as ONE persistent launch -- 256 resident workgroups, interleaved tile
-//  ownership, a progress word per workgroup as grid barrier, every shared word moved with agent-scope (sc1) loads and stores
-//  -- took 67 us per sweep, 7.8 ms per step against 2.2: a frontier lane's chain is five dependent round trips, and an sc1 round
-//  trip beside the step's streaming sweeps is 1-3 us where a cached load behind a kernel boundary is 0.3-0.5.
-//  profiles/r3_variants.md.)
-// ------------------------------------------------------------------------------------------------
-#define LS_TILES 4
-template <class MathT>
-__global__ __launch_bounds__(256) void k_level_sweep(OpLevelPropagate<MathT> op, SweepCommon c, const uint32_t* __restrict__ tm_cur, uint32_t* __restrict__ tm_next,
-                                                     int first)
-{
-    typedef OpLevelPropagate<MathT> Op;
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t gw = blockIdx.x * 4u + (threadIdx.x >> 6);
-    const uint32_t ntiles = (c.n + 63u) >> 6;
-    const uint32_t tile0 = gw * LS_TILES;
-    if (tile0 >= ntiles) return;
-    const uint32_t t = op.t;
-    bool marked = false;
-    if (lane < LS_TILES && tile0 + lane < ntiles) marked = first || tm_cur[tile0 + lane] == t;
-    uint32_t todo = (uint32_t)__ballot(marked);
-    if (!todo) return;
-    bool useful = false;
-    // (a loop, not unrolled, and no generic list replay inlined: the kernel is a few KB, so that a sweep does not wait for its own code)
-#pragma unroll 1
-    while (todo) {
-        const uint32_t k = (uint32_t)__ffs(todo) - 1u;
-        todo &= todo - 1u;
-        const uint32_t i = ((tile0 + k) << 6) + lane;
-        if (i >= c.n) continue;
-        const uint32_t w_i = op.when[i], m_i = op.mark_cur[i];
-        if (!(t == 0u ? w_i == 0u : (w_i == LVL_UNASSIGNED && m_i == t))) continue;
-        const float4 Ai = op.loadA(i);
-        const uint4 lw = c.nl[i];
-        const float r2max = level_range_sq(Ai.z, op.range_factor, op.sp_rest_density);
-        float best = 0.f;
-        bool have = false;
-        // one neighbour whose (when, level, position) have arrived
-        auto visit = [&](uint32_t j, uint32_t wj, float lj, float2 xj) {
-            if (wj == LVL_UNASSIGNED) {
-                op.mark_next[j] = t + 1u;
-                tm_next[j >> 6] = t + 1u;
-            }
-            if (wj < t) {
-                const float dx = Ai.x - xj.x, dy = Ai.y - xj.y;
-                const float r2 = dx * dx + dy * dy;
-                if (!(r2 > r2max)) {
-                    const float est = lj - sqrtf(r2);
-                    best = have ? fmaxf(best, est) : est;
-                    have = true;
-                }
-            }
-        };
-        if ((lw.w & NL_IDX) && c.nlx) {
-            // 16 neighbours per trip: their (when, level, position) gathers all in flight, the index words of the NEXT trip
-            // already requested -- a list of ~30 neighbours is three dependent round trips (index words, two trips of gathers)
-            const uint32_t cnt = lw.w & 0xffffu;
-            uint4 qn[4];
-#pragma unroll
-            for (int g = 0; g < 4; g++) qn[g] = 4u * (uint32_t)g < cnt ? c.nlx[(size_t)g * c.n + i] : make_uint4(i, i, i, i);
-#pragma unroll 1
-            for (uint32_t q0 = 0; q0 < cnt; q0 += 16u) {
-                uint32_t jj[16], wj[16];
-                float lj[16];
-                float2 xj[16];
-#pragma unroll
-                for (int g = 0; g < 4; g++) {
-                    const uint32_t kq = q0 + 4u * (uint32_t)g;
-                    jj[4 * g] = kq < cnt ? qn[g].x : i;
-                    jj[4 * g + 1] = kq + 1u < cnt ? qn[g].y : i;
-                    jj[4 * g + 2] = kq + 2u < cnt ? qn[g].z : i;
-                    jj[4 * g + 3] = kq + 3u < cnt ? qn[g].w : i;
-                }
-#pragma unroll
-                for (int g = 0; g < 4; g++) {
-                    const uint32_t kq = q0 + 16u + 4u * (uint32_t)g;
-                    if (kq < cnt) qn[g] = c.nlx[(size_t)(kq >> 2) * c.n + i];
-                }
-#pragma unroll
-                for (int e = 0; e < 16; e++) {
-                    wj[e] = op.when[jj[e]];
-                    lj[e] = op.level[jj[e]];
-                    xj[e] = *reinterpret_cast<const float2*>(op.pm + jj[e]);
-                }
-#pragma unroll
-                for (int e = 0; e < 16; e++)
-                    if (q0 + (uint32_t)e < cnt) visit(jj[e], wj[e], lj[e], xj[e]);
-            }
-        } else {
-            // the rare forms, one neighbour at a time: a mask word (the step's own k = 2 lists replayed after advection), or no
-            // recorded list at all (> 128 neighbours): the candidates of the stencil with the neighbour predicate, exactly as
-            // sweep_particle walks them (same cells, same operations, same order)
-            const float2 cp = OpCellPos<Op>::get(op, i, Ai);
-            const int cx = (int)floorf(cp.x / c.g.cs) - c.g.minx, cy = (int)floorf(cp.y / c.g.cs) - c.g.miny;
-            if (lw.w & NL_OK) {
-#pragma unroll 1
-                for (int dr = 0; dr < 3; dr++) {
-                    const int yy = cy + dr - 1;
-                    if (yy < 0 || yy >= c.g.sy) continue;
-                    const uint32_t base = c.cell_start[(uint32_t)yy * (uint32_t)c.g.sx + (uint32_t)max(cx - 1, 0)];
-                    uint32_t mk = dr == 0 ? lw.x : (dr == 1 ? lw.y : lw.z);
-#pragma unroll 1
-                    while (mk) {
-                        const uint32_t j = base + (uint32_t)__ffs(mk) - 1u;
-                        mk &= mk - 1u;
-                        visit(j, op.when[j], op.level[j], *reinterpret_cast<const float2*>(op.pm + j));
-                    }
-                }
-            } else {
-                const int R = stencil_radius(c.g, c.t, Ai.w, cx, cy, op.krange());
-                const int x0 = max(cx - R, 0), x1 = min(cx + R + 1, c.g.sx);
-#pragma unroll 1
-                for (int yy = max(cy - R, 0); yy <= min(cy + R, c.g.sy - 1); yy++) {
-                    const uint32_t row = (uint32_t)yy * (uint32_t)c.g.sx;
-                    const uint32_t jb = c.cell_start[row + (uint32_t)x0], je = c.cell_start[row + (uint32_t)x1];
-#pragma unroll 1
-                    for (uint32_t j = jb; j < je; j++) {
-                        const float4 Aj = op.loadA(j);
-                        const float dx = Ai.x - Aj.x, dy = Ai.y - Aj.y;
-                        const float r2 = dx * dx + dy * dy;
-                        const float hij = MathT::UNIFORM ? op.m.h : (Ai.w + Aj.w) * 0.5f;
-                        const float sr = hij * op.krange();
-                        if (r2 < sr * sr) visit(j, op.when[j], op.level[j], make_float2(Aj.x, Aj.y));
-                    }
-                }
-            }
-        }
-        if (t > 0u && have) {
-            op.level[i] = best;
-            op.when[i] = t;
-            useful = useful || best > op.useful_above;
-        }
-    }
-    if (useful) *op.changed = 1u;   // (same value from every lane)
-}
+// (Measured negatives, round 3 -- profiles/r3_variants.md: (1) the whole propagation as ONE persistent launch, 256 resident
+//  workgroups, a progress word per workgroup as grid barrier, every shared word moved with agent-scope (sc1) loads and stores:
+//  67 us per sweep, 7.8 ms per step against 2.2 -- a frontier lane's chain is five dependent round trips, and an sc1 round trip
+//  beside the step's streaming sweeps is 1-3 us where a cached load behind a kernel boundary is 0.3-0.5; (2) a sweep kernel of
+//  its own with per-tile frontier marks and the whole list of a candidate gathered in batches of 4 / 8 / 16 / 32: 28-38 us per
+//  sweep against 14 through this skeleton, whatever the batch, the register count, the stream priority or the tile ownership.)
 
 // fill_stash_with (simulation.rs:886-893, 769-779): the level field as it stands, interior -> -maximum_surface_distance
 __global__ __launch_bounds__(256) void k_fill_stash(uint32_t n, const float* __restrict__ level, float* __restrict__ stash, float max_surface_distance)
@@ -2784,32 +2644,6 @@ void launch_level_propagate(hipStream_t s, Profiler* prof, const SweepArgs& a, c
     uint32_t* mark_next = l.mark + ((t & 1u) ? 0u : a.n);
     SPH_DISPATCH(OpLevelPropagate, false, a.pm, l.pm_cell, l.level, l.when, mark_cur, mark_next, changed, l.k, t, l.maximum_range, a.sp.rest_density,
                  -l.max_surface_distance, l.plain_propagate)
-}
-
-// one propagation sweep through k_level_sweep (single context, frontier form).  `tile_marks`: level_tile_mark_bytes(n) of device
-// memory, zeroed before sweep 0 of a propagation: two parities of one word per tile of 64 slots.
-size_t level_tile_mark_bytes(uint32_t n) { return 2 * ((size_t)(n + 63u) / 64u) * sizeof(uint32_t); }
-void launch_level_sweep(hipStream_t s, Profiler* prof, const SweepArgs& a, const LevelArgs& l, uint32_t t, uint32_t* changed, uint32_t* tile_marks)
-{
-    if (!a.n) return;
-    ProfScope ps(prof, "level_propagate", s);
-    const uint32_t ntiles = (a.n + 63u) / 64u;
-    const uint32_t* tm_cur = tile_marks + (t & 1u) * ntiles;
-    uint32_t* tm_next = tile_marks + ((t + 1u) & 1u) * ntiles;
-    const uint32_t* mark_cur = l.mark + ((t & 1u) ? a.n : 0u);
-    uint32_t* mark_next = l.mark + ((t & 1u) ? 0u : a.n);
-    const uint32_t waves = (ntiles + LS_TILES - 1u) / LS_TILES;
-    const SweepCommon c = common_of(a, true);
-#define LS_LAUNCH(MATH, MINIT)                                                                                                                          \
-    {                                                                                                                                                   \
-        OpLevelPropagate<MATH> op{MINIT, a.pm, l.pm_cell, l.level, l.when, mark_cur, mark_next, changed, l.k, t, l.maximum_range, a.sp.rest_density,     \
-                                  -l.max_surface_distance, 0};                                                                                          \
-        hipLaunchKernelGGL((k_level_sweep<MATH>), dim3((waves + 3u) / 4u), dim3(256), 0, s, op, c, tm_cur, tm_next, t == 0u ? 1 : 0);                   \
-    }
-    if (a.exact) LS_LAUNCH(MathExact, MathExact{0.f})
-    else if (a.uniform_h) LS_LAUNCH(MathUniform, uniform_math(a.h_uniform))
-    else LS_LAUNCH(MathFast, MathFast{0.f})
-#undef LS_LAUNCH
 }
 
 void launch_fill_stash(hipStream_t s, Profiler* prof, const SweepArgs& a, const LevelArgs& l, float* stash)

@@ -1,0 +1,22 @@
+#!/bin/bash
+OUT=$GRAFT_REPO_ROOT/gpurun_out/r3f
+mkdir -p $OUT
+cd $GRAFT_REPO_ROOT
+timeout -k 5 400 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "level or dedicated" > $OUT/pytest_level.log 2>&1; echo "pytest level rc=$?"; tail -3 $OUT/pytest_level.log
+LV="dict(level_estimation_method='EmptyAngle', maximum_surface_distance=0.2, particle_radius_fine=0.0005, particle_radius_base=0.002)"
+echo "batch 8, high-priority side stream:"; timeout -k 5 120 python scripts/gpu_time.py dam_break_1m 20 "$LV" 2>&1 | tail -1
+echo "batch 8, normal priority:"; SPH_SIDE_STREAM_NORMAL=1 timeout -k 5 120 python scripts/gpu_time.py dam_break_1m 20 "$LV" 2>&1 | tail -1
+echo "batch 16:"; SPH_HIP_LIBRARY=libsph_hip.b8.so timeout -k 5 120 python scripts/gpu_time.py dam_break_1m 20 "$LV" 2>&1 | tail -1
+echo "generic, high priority:"; SPH_LEVEL_GENERIC=1 timeout -k 5 120 python scripts/gpu_time.py dam_break_1m 20 "$LV" 2>&1 | tail -1
+echo "generic, normal priority:"; SPH_SIDE_STREAM_NORMAL=1 SPH_LEVEL_GENERIC=1 timeout -k 5 120 python scripts/gpu_time.py dam_break_1m 20 "$LV" 2>&1 | tail -1
+echo "serial (one stream), new sweep:"; SPH_LEVEL_SERIAL=1 timeout -k 5 120 python scripts/gpu_time.py dam_break_1m 20 "$LV" 2>&1 | tail -1
+echo "serial (one stream), generic:"; SPH_LEVEL_SERIAL=1 SPH_LEVEL_GENERIC=1 timeout -k 5 120 python scripts/gpu_time.py dam_break_1m 20 "$LV" 2>&1 | tail -1
+cd /tmp; export TMPDIR=/tmp
+SPH_LEVEL_SERIAL=1 SPH_TIME_WARMUP=20 timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/level_kt -o kt -- python $GRAFT_REPO_ROOT/scripts/gpu_time.py dam_break_1m 20 "$LV" > $OUT/level_kt.log 2>&1; echo "kt rc=$?"
+python - <<PY
+import csv,glob,collections,statistics
+f=glob.glob("$OUT/level_kt/**/*kernel_trace.csv",recursive=True)[0]
+d=collections.defaultdict(list)
+for r in csv.DictReader(open(f)): d[r["Kernel_Name"][:70]].append((int(r["End_Timestamp"])-int(r["Start_Timestamp"]))/1e3)
+for k,v in sorted(d.items(), key=lambda kv:-sum(kv[1]))[:6]: print(f"{k:72s} n={len(v):5d} med={statistics.median(v):7.1f} total_ms={sum(v)/1e3:8.2f}")
+PY

@@ -218,40 +218,6 @@ def test_level_estimation_uniform_block(product_lib, oracle_lib, stash):
         assert rel_err(g.download(f), o.download(f)) < TOL.get(f, REL_TOL_FIELDS), f
 
 
-@pytest.mark.parametrize("scene", ["uniform_256", "graded"])
-@pytest.mark.parametrize("stash", [None, "SurfaceDistanceMiddle"])
-def test_dedicated_propagation_sweep_is_bit_identical_to_the_generic_one(product_lib, monkeypatch, scene, stash):
-    """The level-set propagation sweep as the kernel built for it (k_level_sweep: per-tile frontier marks, a candidate's whole
-    list gathered in one batch) against the same sweep through the generic skeleton (SPH_LEVEL_GENERIC=1 at sph_create): every
-    level output bit for bit, over several steps, on a scene deep enough for ~50 sweeps and on a multi-resolution one."""
-    if scene == "uniform_256":
-        scn = sc.dam_break_small(256, 256, 1 / 256)
-        pos, mass, vel = sc.init_particles(scn)
-        planes = sc.boundary_planes(scn.boundary)
-        P = dam_break_params(level_estimation_method="EmptyAngle", maximum_surface_distance=0.25, particle_radius_fine=0.001,
-                             particle_radius_base=0.004)
-    else:
-        pos, mass, vel, _ = quadtree_scene(5)
-        planes = sc.boundary_planes(sc.SceneBoundary("box", 4.0, 2.0), "AnalyticOverestimate")
-        P = default_params(merging=False, sharing=False, splitting=False, max_dt=0.002)
-    P.fill_stash_with = stash
-    p = P.to_ffi()
-    a = ffi.Context(product_lib, len(mass), planes)
-    monkeypatch.setenv("SPH_LEVEL_GENERIC", "1")
-    b = ffi.Context(product_lib, len(mass), planes)
-    monkeypatch.delenv("SPH_LEVEL_GENERIC")
-    for c in (a, b):
-        c.upload(mass, pos, vel)
-    for s in range(4):
-        sa, sb = a.step(p), b.step(p)
-        assert sa.dt == sb.dt
-        for f in ("level_estimation", "level_old", "stash", "flag_is_fluid_surface", "flag_insufficient_neighs", "position", "density"):
-            x, y = a.download(f), b.download(f)
-            assert np.array_equal(x, y, equal_nan=True), (s, f)
-    lv = a.download("level_estimation")
-    assert np.isfinite(lv).all() and (lv < 0).sum() > 0.5 * len(lv)     # the field reaches the interior (clamped at the bound there)
-
-
 def test_level_estimation_default_config_scene(product_lib, oracle_lib):
     """BASELINE configs[0]: default-config.yaml + default-scene.yaml (two particle sizes, EmptyAngle, extended range 5.5,
     HybridDFSPH) -- the plumbing case, on the device."""
