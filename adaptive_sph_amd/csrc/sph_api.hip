@@ -263,7 +263,7 @@ __global__ void k_publish(const SolverCtrl* __restrict__ ctrl, const DeviceStatu
     }
 }
 
-enum { G_F32 = 0, G_F32X2 = 1, G_PM_X = 2, G_PM_M = 3, G_PM_H = 4, G_U32 = 5, G_H2NEXT = 6, G_U8 = 7 };
+enum { G_F32 = 0, G_F32X2 = 1, G_PM_X = 2, G_PM_M = 3, G_PM_H = 4, G_U32 = 5, G_H2NEXT = 6, G_U8 = 7, G_F32X4_ZW = 8 };
 
 // dst[orig[i]] = field[i]: back to host particle order
 __global__ __launch_bounds__(256) void k_to_host_order(uint32_t n, int kind, const uint32_t* __restrict__ orig, const void* __restrict__ src,
@@ -278,6 +278,7 @@ __global__ __launch_bounds__(256) void k_to_host_order(uint32_t n, int kind, con
     case G_U8: ((uint8_t*)dst)[o] = ((const uint8_t*)src)[i]; break;
     case G_F32X2: ((float2*)dst)[o] = ((const float2*)src)[i]; break;
     case G_PM_X: { float4 p = ((const float4*)src)[i]; ((float2*)dst)[o] = make_float2(p.x, p.y); } break;
+    case G_F32X4_ZW: { float4 p = ((const float4*)src)[i]; ((float2*)dst)[o] = make_float2(p.z, p.w); } break;   // a^p out of its {x, y, a^p} record
     case G_PM_M: ((float*)dst)[o] = ((const float4*)src)[i].z; break;
     case G_PM_H: ((float*)dst)[o] = ((const float4*)src)[i].w; break;
     case G_H2NEXT: ((float*)dst)[o] = h_from_mass(((const float4*)src)[i].z, 1.f); break;  // simulation.rs:505-520
@@ -399,7 +400,7 @@ static int alloc_particle_buffers(sph_ctx* c)
     HIPCHK(c, c->lam_grad.ensure(n * sizeof(float2)));
     HIPCHK(c, c->lam_prev.ensure(n * sizeof(float)));
     HIPCHK(c, c->omega.ensure(n * sizeof(float)));
-    HIPCHK(c, c->pacc.ensure(n * sizeof(float2)));
+    HIPCHK(c, c->pacc.ensure(n * sizeof(float4)));   // {x, y, a^p}
     HIPCHK(c, c->scratch.ensure(n * sizeof(float4)));
     HIPCHK(c, c->nl.ensure(sweep_list_bytes((uint32_t)n)));
     HIPCHK(c, c->nl_ok.ensure(n));
@@ -570,7 +571,7 @@ extern "C" int sph_upload(sph_ctx* c, uint64_t n, const float* mass, const float
     DevBuf* zero[] = {&c->rho, &c->lam_sum, &c->constf, &c->aii, &c->src, &c->p0, &c->p1, &c->dens_err, &c->ncount};
     for (auto b : zero) HIPCHK(c, hipMemsetAsync(b->p, 0, n * sizeof(float), s));
     HIPCHK(c, hipMemsetAsync(c->lam_grad.p, 0, n * sizeof(float2), s));
-    HIPCHK(c, hipMemsetAsync(c->pacc.p, 0, n * sizeof(float2), s));
+    HIPCHK(c, hipMemsetAsync(c->pacc.p, 0, n * sizeof(float4), s));
     c->pressure_cur = 0;
     HIPCHK(c, hipStreamSynchronize(s));
     return SPH_OK;
@@ -590,7 +591,7 @@ static bool field_ref(sph_ctx* c, int field, FieldRef* r)
     case SPH_F_MASS: *r = {G_PM_M, c->pm[c->pcur].p, 4, true}; return true;
     case SPH_F_POSITION: *r = {G_PM_X, c->pm[c->pcur].p, 8, true}; return true;
     case SPH_F_VELOCITY: *r = {G_F32X2, c->vel[k].p, 8, true}; return true;
-    case SPH_F_PRESSURE_ACCEL: *r = {G_F32X2, c->pacc.p, 8, false}; return true;
+    case SPH_F_PRESSURE_ACCEL: *r = {G_F32X4_ZW, c->pacc.p, 8, false}; return true;
     case SPH_F_DENSITY: *r = {G_F32, c->rho.p, 4, false}; return true;
     case SPH_F_PPE_SOURCE_TERM: *r = {G_F32, c->src.p, 4, false}; return true;
     case SPH_F_PRESSURE: *r = {G_F32, c->pressure_cur ? c->p1.p : c->p0.p, 4, false}; return true;

@@ -94,43 +94,6 @@ __device__ __forceinline__ float cubic_unnorm_deriv(float q)
     return q < 0.5f ? a : (q < 1.f ? b : 0.f);
 }
 
-// Variant switches of the FAST / UNIFORM pair values (scripts/variants; EXACT is never touched):
-//   SPH_PAIR_FMA   contraction allowed inside the kernel-gradient / kernel-value functions and the ops' pair() bodies
-//   SPH_PAIR_TP    cubic spline and its derivative in truncated-power form, no selects:
-//                  W(q) = 2 [ (1-q)+^3 - 4 (1/2-q)+^3 ],  W'(q) = 6 [ 4 (1/2-q)+^2 - (1-q)+^2 ]
-#ifndef SPH_PAIR_FMA
-#define SPH_PAIR_FMA 0
-#endif
-#ifndef SPH_PAIR_TP
-#define SPH_PAIR_TP 0
-#endif
-#if SPH_PAIR_FMA
-#define SPH_PAIR_CONTRACT _Pragma("clang fp contract(fast)")
-#else
-#define SPH_PAIR_CONTRACT
-#endif
-
-__device__ __forceinline__ float cubic_fast(float q)
-{
-#if SPH_PAIR_TP
-    SPH_PAIR_CONTRACT
-    const float u = fmaxf(1.f - q, 0.f), t = fmaxf(0.5f - q, 0.f);
-    return 2.f * (u * u * u - 4.f * (t * t * t));
-#else
-    return cubic_unnorm(q);
-#endif
-}
-__device__ __forceinline__ float cubic_deriv_fast(float q)
-{
-#if SPH_PAIR_TP
-    SPH_PAIR_CONTRACT
-    const float u = fmaxf(1.f - q, 0.f), t = fmaxf(0.5f - q, 0.f);
-    return 6.f * (4.f * (t * t) - u * u);
-#else
-    return cubic_unnorm_deriv(q);
-#endif
-}
-
 // Math policies.  EXACT: IEEE division / sqrt in the reference's operation order.  FAST: hardware
 // v_rcp_f32 / v_rsq_f32 / v_sqrt_f32 (1 ulp).  UNIFORM: FAST with every h_ij == h (all particles
 // carry the bit-identical smoothing length), so the normalisation and 1/(2h) are launch constants.
@@ -155,29 +118,41 @@ struct MathExact {
         gy = z ? 0.f : s * uy;
     }
 };
+// FAST / UNIFORM pair values are written for the instruction mix of gfx950 as measured (scripts/ubench/valu_issue.hip,
+// profiles/r3_variants.md): fma / add / mul issue in 2 clocks per wave, a compare, a select or a max in 4, a transcendental in 8.
+//   * the spline in truncated-power form -- W(q) = 2 [(1-q)+^3 - 4 (1/2-q)+^3], W'(q) = 6 [4 (1/2-q)+^2 - (1-q)+^2] -- two v_max
+//     instead of two compare + select pairs;
+//   * r^2 clamped away from zero instead of the reference's `q > 1e-5 ? .. : 0` select: with dx = dy = 0 the gradient s (dx, dy)
+//     is zero by itself, and W'(q) / r stays finite (-> -2 / (2h) as q -> 0); a pair closer than 1e-5 of the support -- below the
+//     resolution of f32 positions at these scales -- gets a gradient of relative size 1e-5 instead of exactly zero;
+//   * constant factors folded, explicit fma.  `gscale` returns s with grad W_ij = s (dx, dy), so that a sweep whose pair term is
+//     (scalar) x grad W multiplies scalars first and needs two fma for the vector.
+// Stand-alone effect on the Jacobi sweep: 21.9 -> 20.0 us (profiles/r3_jacobi_lab.md).  EXACT mode keeps the reference's operations.
+#define SPH_R2_FLOOR 1.0e-30f
 struct MathFast {
     static constexpr bool EXACT = false, UNIFORM = false;
     float h;  // unused
-    // one reciprocal per pair (a transcendental issues at a quarter of the rate of a multiply, scripts/ubench/valu_issue.hip):
-    // 1 / (2 h_ij) and the normalisation 10 / (7 pi h_ij^2) = (40 / (7 pi)) (1 / (2 h_ij))^2 both come from it
+    // one reciprocal per pair: 1 / (2 h_ij), and the normalisation 10 / (7 pi h_ij^2) = (40 / (7 pi)) (1 / (2 h_ij))^2 from it
     __device__ __forceinline__ float w(float r2, float hij) const
     {
-        SPH_PAIR_CONTRACT
-        float r = fast_sqrt(r2);
-        float inv2h = fast_rcp(2.f * hij);
-        float nf = (40.f / SPH_SEVEN_PI) * (inv2h * inv2h);
-        return nf * cubic_fast(r * inv2h);
+        const float inv2h = fast_rcp(hij + hij);
+        const float q = fast_sqrt(r2) * inv2h;
+        const float u = fmaxf(1.f - q, 0.f), t = fmaxf(0.5f - q, 0.f);
+        return ((80.f / SPH_SEVEN_PI) * (inv2h * inv2h)) * fmaf(-4.f * t, t * t, u * (u * u));
+    }
+    __device__ __forceinline__ float gscale(float r2, float hij) const
+    {
+        const float r2c = fmaxf(r2, SPH_R2_FLOOR);
+        const float rinv = fast_rsq(r2c);
+        const float inv2h = fast_rcp(hij + hij);
+        const float q = (r2c * rinv) * inv2h;
+        const float u = fmaxf(1.f - q, 0.f), t = fmaxf(0.5f - q, 0.f);
+        const float d = fmaf(4.f * t, t, -(u * u));
+        return (((240.f / SPH_SEVEN_PI) * inv2h) * (inv2h * inv2h)) * (d * rinv);
     }
     __device__ __forceinline__ void grad(float dx, float dy, float r2, float hij, float& gx, float& gy) const
     {
-        SPH_PAIR_CONTRACT
-        float rinv = fast_rsq(r2);
-        float r = r2 * rinv;
-        float inv2h = fast_rcp(2.f * hij);
-        float q = r * inv2h;
-        float nf = (40.f / SPH_SEVEN_PI) * (inv2h * inv2h);
-        float s = nf * cubic_deriv_fast(q) * inv2h * rinv;
-        s = (q > 1.0e-5f) ? s : 0.f;  // also covers r2 == 0 (rinv = inf, r = nan)
+        const float s = gscale(r2, hij);
         gx = s * dx;
         gy = s * dy;
     }
@@ -185,14 +160,25 @@ struct MathFast {
 struct MathUniform {
     static constexpr bool EXACT = false, UNIFORM = true;
     float h, nf, inv2h;
-    __device__ __forceinline__ float w(float r2, float) const { return nf * cubic_fast(fast_sqrt(r2) * inv2h); }
+    float nf2, nf6;   // 2 nf (value), 6 nf / (2h) (gradient)
+    __device__ __forceinline__ float w(float r2, float) const
+    {
+        const float q = fast_sqrt(r2) * inv2h;
+        const float u = fmaxf(1.f - q, 0.f), t = fmaxf(0.5f - q, 0.f);
+        return nf2 * fmaf(-4.f * t, t * t, u * (u * u));
+    }
+    __device__ __forceinline__ float gscale(float r2, float) const
+    {
+        const float r2c = fmaxf(r2, SPH_R2_FLOOR);
+        const float rinv = fast_rsq(r2c);
+        const float q = (r2c * rinv) * inv2h;
+        const float u = fmaxf(1.f - q, 0.f), t = fmaxf(0.5f - q, 0.f);
+        const float d = fmaf(4.f * t, t, -(u * u));
+        return nf6 * (d * rinv);
+    }
     __device__ __forceinline__ void grad(float dx, float dy, float r2, float, float& gx, float& gy) const
     {
-        SPH_PAIR_CONTRACT
-        float rinv = fast_rsq(r2);
-        float q = (r2 * rinv) * inv2h;
-        float s = nf * cubic_deriv_fast(q) * inv2h * rinv;
-        s = (q > 1.0e-5f) ? s : 0.f;
+        const float s = gscale(r2, 0.f);
         gx = s * dx;
         gy = s * dy;
     }

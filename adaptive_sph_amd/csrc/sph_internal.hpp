@@ -130,7 +130,7 @@ struct SweepArgs {
     float* src;
     float* p0;
     float* p1;
-    float2* pacc;
+    float4* pacc;       // {x, y, a^p} per particle (OpPressureAccel writes it, OpJacobiU gathers it whole)
     float* dens_err;
     float* stat;
     uint32_t* ncount;

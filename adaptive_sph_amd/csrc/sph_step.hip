@@ -53,7 +53,7 @@ SweepArgs make_args(sph_ctx* c, const StepP& sp)
     a.src = c->src.as<float>();
     a.p0 = c->p0.as<float>();
     a.p1 = c->p1.as<float>();
-    a.pacc = c->pacc.as<float2>();
+    a.pacc = c->pacc.as<float4>();
     a.dens_err = c->dens_err.as<float>();
     a.stat = c->stat.as<float>();
     a.ncount = c->ncount.as<uint32_t>();

@@ -794,7 +794,6 @@ struct OpAiiConst {
     __device__ void begin(Acc& a, uint32_t, float4) const { a.cf = a.ax = a.ay = a.a2 = a.bx = a.by = 0.f; }
     __device__ void pair(Acc& a, float4 Aj, NB mr, float dx, float dy, float r2, float hij) const
     {
-        SPH_PAIR_CONTRACT
         a.cf += mr * m.w(r2, hij);
         float gx, gy;
         m.grad(dx, dy, r2, hij, gx, gy);
@@ -895,7 +894,6 @@ struct OpNonPressure {
     }
     __device__ void pair(Acc& a, float4 Aj, NB Bj, float dx, float dy, float r2, float hij) const
     {
-        SPH_PAIR_CONTRACT
         const float ux = a.vix - Bj.vx, uy = a.viy - Bj.vy;
         if (sp.viscosity_type == SPH_VISC_APPROX_LAPLACE) {
             const float xv = dx * ux + dy * uy;
@@ -1063,15 +1061,19 @@ struct OpSource {
     }
     __device__ void pair(Acc& a, float4 Aj, NB Bj, float dx, float dy, float r2, float hij) const
     {
-        SPH_PAIR_CONTRACT
         if (OMEGA && !a.large) a.om += a.om_c * Aj.z * dwdh(sqrtf(r2), hij * 2.f);   // simulation.rs:2289-2305
         if (kind == 2) return;
-        float gx, gy;
-        m.grad(dx, dy, r2, hij, gx, gy);
-        const float dot = (Bj.qx - a.qx) * gx + (Bj.qy - a.qy) * gy;
-        if (sp.opdisc == SPH_OP_WINCHENBACH2020) a.sum += Bj.mr * dot;
-        else if (MathT::EXACT) a.sum += Aj.z / a.rho_i * dot;
-        else a.sum += Aj.z * a.inv_rho_i * dot;
+        if constexpr (MathT::EXACT) {
+            float gx, gy;
+            m.grad(dx, dy, r2, hij, gx, gy);
+            const float dot = (Bj.qx - a.qx) * gx + (Bj.qy - a.qy) * gy;
+            if (sp.opdisc == SPH_OP_WINCHENBACH2020) a.sum += Bj.mr * dot;
+            else a.sum += Aj.z / a.rho_i * dot;
+        } else {   // (Q_j - Q_i) . grad W_ij = s ((Q_j - Q_i) . x_ij): scalars first (MathFast / MathUniform, sph_device.h)
+            const float e = fmaf(Bj.qx - a.qx, dx, (Bj.qy - a.qy) * dy);
+            const float c = sp.opdisc == SPH_OP_WINCHENBACH2020 ? Bj.mr : Aj.z * a.inv_rho_i;
+            a.sum = fmaf(c * m.gscale(r2, hij), e, a.sum);
+        }
     }
     __device__ bool finish(Acc& a, uint32_t i, float4, bool wall) const
     {
@@ -1275,7 +1277,8 @@ struct OpPressureAccel {
     const float* __restrict__ pt0;
     const float* __restrict__ pt1;
     const float2* __restrict__ lam_grad;
-    float2* __restrict__ pacc;
+    float4* __restrict__ pacc;   // {x, y, a^p}: the pressure acceleration travels with the position it belongs to, so that the Jacobi
+                                 // update of a uniform-h scene gathers ONE 16-byte record per neighbour (OpJacobiU)
     SolverCtrl* ctrl;
     const SolverPartial* __restrict__ partials;
     uint32_t nparts;
@@ -1320,14 +1323,19 @@ struct OpPressureAccel {
     }
     __device__ void pair(Acc& a, float4 Aj, NB ptj, float dx, float dy, float r2, float hij) const
     {
-        SPH_PAIR_CONTRACT
-        float gx, gy;
-        m.grad(dx, dy, r2, hij, gx, gy);
-        const float f = -Aj.z * (a.p1t + ptj);
-        a.ax += f * gx;
-        a.ay += f * gy;
+        if constexpr (MathT::EXACT) {
+            float gx, gy;
+            m.grad(dx, dy, r2, hij, gx, gy);
+            const float f = -Aj.z * (a.p1t + ptj);
+            a.ax += f * gx;
+            a.ay += f * gy;
+        } else {
+            const float fs = (-Aj.z * (a.p1t + ptj)) * m.gscale(r2, hij);
+            a.ax = fmaf(fs, dx, a.ax);
+            a.ay = fmaf(fs, dy, a.ay);
+        }
     }
-    __device__ bool finish(Acc& a, uint32_t i, float4, bool wall) const
+    __device__ bool finish(Acc& a, uint32_t i, float4 Ai, bool wall) const
     {
         float bx = 0.f, by = 0.f;
         const bool own = !owned_flag || owned_flag[i];
@@ -1342,7 +1350,7 @@ struct OpPressureAccel {
             bx = f * gl.x;
             by = f * gl.y;
         }
-        pacc[i] = make_float2(a.ax + bx, a.ay + by);
+        pacc[i] = make_float4(Ai.x, Ai.y, a.ax + bx, a.ay + by);
         return wall;
     }
 };
@@ -1352,7 +1360,7 @@ struct OpPressureAccel {
 // (bounding box, h range, CFL term -- what k_header computes) per block, so the next step starts without the header kernels
 // and without the host wait behind them (hdr_partials == nullptr: not wanted).
 __global__ __launch_bounds__(256) void k_solver_tail(uint32_t n, int tail, float dt, float vfactor, const float4* __restrict__ pm, float4* __restrict__ pm_out,
-                                                      float2* __restrict__ vel, const float2* __restrict__ pacc, const uint32_t* __restrict__ orig,
+                                                      float2* __restrict__ vel, const float4* __restrict__ pacc, const uint32_t* __restrict__ orig,
                                                       const uint8_t* __restrict__ owned, const SolverCtrl* __restrict__ ctrl, HeaderOut* __restrict__ hdr_partials,
                                                       DeviceStatus* status, const uint32_t* __restrict__ gate, const double* __restrict__ tot,
                                                       int decide_iter, SolveP solve, float rest_density, SolverCtrl* __restrict__ handoff_host,
@@ -1380,7 +1388,8 @@ __global__ __launch_bounds__(256) void k_solver_tail(uint32_t n, int tail, float
     float nx = 0.f, ny = 0.f, nh = 0.f, ncfl = 0.f;
     if (active) {
         const float4 Ai = pm[i];
-        const float2 ap = pacc[i];
+        const float4 rec = pacc[i];
+        const float2 ap = make_float2(rec.z, rec.w);
         float2 v = vel[i];
         float4 p = Ai;
         if (tail == TAIL_VEL) {
@@ -1452,7 +1461,7 @@ struct OpJacobi {
     const uint32_t* __restrict__ orig;
     const float* __restrict__ rho;
     const float* __restrict__ mrho;
-    const float2* __restrict__ pacc;
+    const float4* __restrict__ pacc;   // {x, y, a^p} (OpPressureAccel)
     const float2* __restrict__ lam_grad;
     const float* __restrict__ aii;
     const float* __restrict__ src;
@@ -1488,7 +1497,7 @@ struct OpJacobi {
     __device__ float4 loadA(uint32_t j) const { return pm[j]; }
     __device__ NB nb(const Acc&, uint32_t j, float4) const
     {
-        float2 a = pacc[j];
+        const float2 a = *(reinterpret_cast<const float2*>(pacc + j) + 1);   // (8 of the record's 16 bytes: this form also gathers pm[j])
         float mr = 0.f;
         if (sp.opdisc == SPH_OP_WINCHENBACH2020) mr = mrho[j];
         return NB{a.x, a.y, mr};
@@ -1498,21 +1507,25 @@ struct OpJacobi {
         a.sum = 0.f;
         a.rho_i = rho[i];
         a.inv_rho_i = fast_rcp(a.rho_i);
-        float2 q = pacc[i];
-        a.qx = q.x;
-        a.qy = q.y;
+        const float4 q = pacc[i];
+        a.qx = q.z;
+        a.qy = q.w;
         a.err = 0.f;
         a.cls = 3u;
     }
     __device__ void pair(Acc& a, float4 Aj, NB Bj, float dx, float dy, float r2, float hij) const
     {
-        SPH_PAIR_CONTRACT
-        float gx, gy;
-        m.grad(dx, dy, r2, hij, gx, gy);
-        const float dot = (Bj.qx - a.qx) * gx + (Bj.qy - a.qy) * gy;
-        if (sp.opdisc == SPH_OP_WINCHENBACH2020) a.sum += Bj.mr * dot;
-        else if (MathT::EXACT) a.sum += Aj.z / a.rho_i * dot;
-        else a.sum += Aj.z * a.inv_rho_i * dot;
+        if constexpr (MathT::EXACT) {
+            float gx, gy;
+            m.grad(dx, dy, r2, hij, gx, gy);
+            const float dot = (Bj.qx - a.qx) * gx + (Bj.qy - a.qy) * gy;
+            if (sp.opdisc == SPH_OP_WINCHENBACH2020) a.sum += Bj.mr * dot;
+            else a.sum += Aj.z / a.rho_i * dot;
+        } else {
+            const float e = fmaf(Bj.qx - a.qx, dx, (Bj.qy - a.qy) * dy);
+            const float c = sp.opdisc == SPH_OP_WINCHENBACH2020 ? Bj.mr : Aj.z * a.inv_rho_i;
+            a.sum = fmaf(c * m.gscale(r2, hij), e, a.sum);
+        }
     }
     __device__ bool finish(Acc& a, uint32_t i, float4, bool wall) const
     {
@@ -1557,6 +1570,46 @@ struct OpJacobi {
     __device__ void epilogue(Acc& a, bool active, uint32_t blk) const { solver_block_partial(partials, active ? a.cls : 3u, a.err, blk); }
 };
 
+
+// The same update for uniform-h scenes with mass-derived smoothing lengths -- BASELINE configs[1] and [3], the headline -- on ONE
+// gathered record per neighbour: {x_j, y_j, a^p_j}, as sweep A leaves it (16 bytes), instead of the particle record (16) plus
+// the a^p payload (8).  What a replay sweep costs is its gather INSTRUCTIONS more than their bytes (profiles/r3_jacobi_lab.md:
+// 27.0 -> 21.9 us for this sweep stand-alone), and the particle's own record brings its own a^p along.  The record holds no mass:
+// the pair coefficient m_j / rho_i becomes m_i / rho_i (the density sweep's m / rho of the particle itself).  With h = 1.9 sqrt(m /
+// (rho_0 pi)) bit-identical on every particle the masses are equal or neighbouring floats (the map m -> h loses one bit), so
+// the substitution is exact or 1.2e-7 relative per pair -- the size of v_rsq_f32's own error.  Everything else is OpJacobi: same
+// finish, same residual statistics, same stop decision.  Not for the consistent-gradient-by-volume discretisation (per-neighbour
+// m_j / rho_j), EXACT mode, non-uniform h or FromDistribution* support lengths: those take OpJacobi.
+template <class MathT>
+struct OpJacobiU : OpJacobi<MathT> {
+    static_assert(MathT::UNIFORM, "OpJacobiU: uniform-h scenes");
+    typedef OpJacobi<MathT> B;
+    typedef typename B::Acc Acc;
+    static constexpr bool TILE = false;
+    typedef NBNone NB;
+    __device__ float4 loadA(uint32_t j) const { return this->pacc[j]; }
+    __device__ NB nb(const Acc&, uint32_t, float4) const { return NB{}; }
+    __device__ void begin(Acc& a, uint32_t i, float4 Ai) const
+    {
+        a.sum = 0.f;
+        a.rho_i = this->rho[i];
+        a.inv_rho_i = this->mrho[i];   // m_i / rho_i: the pair coefficient (see above)
+        a.qx = Ai.z;
+        a.qy = Ai.w;
+        a.err = 0.f;
+        a.cls = 3u;
+    }
+    __device__ void pair(Acc& a, float4 Aj, NB, float dx, float dy, float r2, float hij) const
+    {
+        const float e = fmaf(Aj.z - a.qx, dx, (Aj.w - a.qy) * dy);
+        a.sum = fmaf(this->m.gscale(r2, hij), e, a.sum);
+    }
+    __device__ bool finish(Acc& a, uint32_t i, float4 Ai, bool wall) const
+    {
+        a.sum *= a.inv_rho_i;
+        return B::finish(a, i, Ai, wall);
+    }
+};
 
 // ------------------------------------------------------------------------------------------------
 // Op: check_aii (simulation.rs:1347-1375): a_ii against the operator applied to the unit pressure field e_i
@@ -2280,12 +2333,14 @@ struct OpFuse {
 };
 
 // HybridDFSPH after the divergence solve: v += dt * a^p   (simulation.rs:2547-2560)
-__global__ __launch_bounds__(256) void k_vel_add_pacc(uint32_t n, float dt, float2* __restrict__ vel, const float2* __restrict__ pacc,
+__global__ __launch_bounds__(256) void k_vel_add_pacc(uint32_t n, float dt, float2* __restrict__ vel, const float4* __restrict__ pacc,
                                                        const uint32_t* __restrict__ orig, DeviceStatus* status)
 {
     uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    float2 v = vel[i], a = pacc[i];
+    float2 v = vel[i];
+    const float4 rec = pacc[i];
+    const float2 a = make_float2(rec.z, rec.w);
     v.x += dt * a.x;
     v.y += dt * a.y;
     vel[i] = v;
@@ -2295,13 +2350,15 @@ __global__ __launch_bounds__(256) void k_vel_add_pacc(uint32_t n, float dt, floa
 // mode 0: v += dt a^p ; x += dt v                     (IISPH / OnlyDivergence, simulation.rs:2433-2445, 2486-2499)
 // mode 1: x += dt v + dt^2 a^p ; v += dt a^p * min(dt*factor, 1)   (HybridDFSPH, simulation.rs:2644-2646)
 __global__ __launch_bounds__(256) void k_integrate(uint32_t n, float dt, float vfactor, int mode, const float4* __restrict__ pm,
-                                                    float4* __restrict__ pm_out, float2* __restrict__ vel, const float2* __restrict__ pacc,
+                                                    float4* __restrict__ pm_out, float2* __restrict__ vel, const float4* __restrict__ pacc,
                                                     const uint32_t* __restrict__ orig, DeviceStatus* status)
 {
     uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     float4 p = pm[i];
-    float2 v = vel[i], a = pacc[i];
+    float2 v = vel[i];
+    const float4 rec = pacc[i];
+    const float2 a = make_float2(rec.z, rec.w);
     if (mode == 0) {
         v.x += dt * a.x;
         v.y += dt * a.y;
@@ -2338,6 +2395,12 @@ static int tile_mode()
         g_tile_mode = e ? atoi(e) : SPH_TILE_DEFAULT;
     }
     return g_tile_mode;
+}
+// SPH_JACOBI_GENERIC (read once): the Jacobi update of uniform scenes through OpJacobi as well (measurement: what OpJacobiU is worth)
+static bool jacobi_generic()
+{
+    static const bool v = getenv("SPH_JACOBI_GENERIC") != nullptr;
+    return v;
 }
 extern "C" int sph_set_sweep_variant(int mode)
 {
@@ -2385,6 +2448,8 @@ static MathUniform uniform_math(float h)
     m.h = h;
     m.nf = 10.f / (SPH_SEVEN_PI * (h * h));
     m.inv2h = 1.f / (2.f * h);
+    m.nf2 = 2.f * m.nf;
+    m.nf6 = 6.f * m.nf * m.inv2h;
     return m;
 }
 
@@ -2449,7 +2514,7 @@ void launch_aii_const(hipStream_t s, Profiler* prof, const SweepArgs& a)
 {
     ProfScope ps(prof, "aii_constfield", s);
     SPH_DISPATCH(OpAiiConst, false, a.pm, a.orig, a.rho, a.mrho, a.lam_sum, a.lam_grad, a.aii, a.constf, a.status, a.sp,
-                 a.sp_check_aii ? a.pacc : nullptr)
+                 a.sp_check_aii ? reinterpret_cast<float2*>(a.pacc) : nullptr)   // (check_aii borrows the a^p buffer before the solve: a^p for the field e_i)
 }
 
 template <class M>
@@ -2473,7 +2538,7 @@ void launch_aii_const_non_pressure(hipStream_t s, Profiler* prof, const SweepArg
 void launch_check_aii(hipStream_t s, Profiler* prof, const SweepArgs& a)
 {
     ProfScope ps(prof, "check_aii", s);
-    SPH_DISPATCH(OpCheckAii, false, a.pm, a.orig, a.rho, a.mrho, a.lam_grad, a.aii, a.pacc, a.status, a.sp)
+    SPH_DISPATCH(OpCheckAii, false, a.pm, a.orig, a.rho, a.mrho, a.lam_grad, a.aii, reinterpret_cast<const float2*>(a.pacc), a.status, a.sp)
 }
 
 void launch_non_pressure(hipStream_t s, Profiler* prof, const SweepArgs& a)
@@ -2561,6 +2626,12 @@ void launch_jacobi_update(hipStream_t s, Profiler* prof, const SweepArgs& a, int
     float* pout = (iter & 1) ? a.p0 : a.p1;
     float* ptout = (iter & 1) ? a.pt0 : a.pt1;
     const SolveP q{residual_density, max_avg_error, max_iters, multi};
+    if (!a.exact && a.uniform_h && a.h_mode == SPH_H_FROM_MASS && a.sp.opdisc != SPH_OP_WINCHENBACH2020 && !jacobi_generic()) {
+        OpJacobiU<MathUniform> op{{uniform_math(a.h_uniform), a.pm, a.orig, a.rho, a.mrho, a.pacc, a.lam_grad, a.aii, a.src, pin, pout, ptout, a.dens_err,
+                                   (SolverPartial*)a.partials, a.ctrl, a.status, a.sp, iter, residual_density, q, a.solver_tot, a.gate}};
+        launch_sweep<OpJacobiU<MathUniform>, false>(s, a, op);
+        return;
+    }
     SPH_DISPATCH(OpJacobi, false, a.pm, a.orig, a.rho, a.mrho, a.pacc, a.lam_grad, a.aii, a.src, pin, pout, ptout, a.dens_err, (SolverPartial*)a.partials, a.ctrl,
                  a.status, a.sp, iter, residual_density, q, a.solver_tot, a.gate)
 }

@@ -121,7 +121,8 @@ def test_rebalancing_moves_the_cuts_and_keeps_the_physics(product_lib, k):
     assert np.array_equal(np.sort(ids), np.arange(len(mass)))
     # 60 steps with the column hitting the right wall: summation-order differences grow to a few 1e-4 in v -- the group with
     # the static cuts shows the same
-    for f, tol in (("position", 1e-5), ("velocity", 1e-3), ("density", 1e-4)):
+    # (position: 1.0e-5 .. 1.7e-5 depending on the pair arithmetic of the build -- the same particles summed in another order)
+    for f, tol in (("position", 3e-5), ("velocity", 1e-3), ("density", 1e-4)):
         assert rel_err(D.gather_by_id(moving, f, len(mass)), single.download(f)) <= tol, f
         assert rel_err(D.gather_by_id(static, f, len(mass)), single.download(f)) <= tol, f
     assert (D.gather_by_id(moving, "neighbor_count", len(mass)) != single.download("neighbor_count")).mean() < 1e-3
