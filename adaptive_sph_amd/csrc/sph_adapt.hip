@@ -358,9 +358,9 @@ static int transfer(sph_ctx* c, const sph_params* p, const sph_adapt_params* ap,
     // positions and masses changed: what the last step left behind no longer describes the state
     c->hdr_ahead = false;
     c->grid_valid = false;
-    c->have_level = false;
-    c->have_reduced = false;
     c->lists_after = false;
+    // (sharing neither reorders nor resizes the vector: stash and the step's flags keep describing the particles in their slots,
+    //  as the reference's ParticleVec keeps them through share_particles -- snapshots taken after single_step show them)
     if (rc || !merging) {
         release();
         return rc;
@@ -375,6 +375,8 @@ static int transfer(sph_ctx* c, const sph_params* p, const sph_adapt_params* ap,
         release();
         return SPH_OK;
     }
+    c->have_level = false;    // the deletion reorders the vector: per-step outputs that do not travel (stash, flags) are gone
+    c->have_reduced = false;
     // (the reference's loop never removes the particle it ends on when everything is deleted: last_particle_id is a usize that
     //  would underflow -- it panics there; an empty vector is what truncate(0) would leave)
     const uint32_t n_new = n - n_del;

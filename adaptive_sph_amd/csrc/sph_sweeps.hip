@@ -960,9 +960,10 @@ struct NBVecMr {
 __device__ __forceinline__ void solver_block_partial(SolverPartial* __restrict__ partials, uint32_t cls, float err, uint32_t blk)
 {
     __shared__ SolverPartial s_w[SWEEP_THREADS / 64];
-    uint32_t normal = wave_sum_u32(cls == 0u ? 1u : 0u);
-    uint32_t singular = wave_sum_u32(cls == 1u ? 1u : 0u);
-    uint32_t negative = wave_sum_u32(cls == 2u ? 1u : 0u);
+    // (the three counts are population counts of ballots: scalar instructions instead of three shuffle reductions)
+    const uint32_t normal = (uint32_t)__popcll(__ballot(cls == 0u));
+    const uint32_t singular = (uint32_t)__popcll(__ballot(cls == 1u));
+    const uint32_t negative = (uint32_t)__popcll(__ballot(cls == 2u));
     float sum = wave_sum(cls == 0u ? err : 0.f);
     float mx = wave_max(cls == 0u ? fabsf(err) : 0.f);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -1479,6 +1480,7 @@ struct OpJacobi {
         float sum, rho_i, inv_rho_i, qx, qy;
         float err;       // residual of a "normal" particle
         uint32_t cls;    // 0 normal, 1 singular, 2 negative (PressureSolverStatistics, simulation.rs:397-445)
+        float aii_i, src_i, pin_i;   // what finish() needs of the particle itself, requested with the rest at the head of the wave
     };
     SolveP solve;
     const double* __restrict__ tot;
@@ -1512,6 +1514,9 @@ struct OpJacobi {
         a.qy = q.w;
         a.err = 0.f;
         a.cls = 3u;
+        a.aii_i = aii[i];
+        a.src_i = src[i];
+        a.pin_i = p_in[i];
     }
     __device__ void pair(Acc& a, float4 Aj, NB Bj, float dx, float dy, float r2, float hij) const
     {
@@ -1529,7 +1534,7 @@ struct OpJacobi {
     }
     __device__ bool finish(Acc& a, uint32_t i, float4, bool wall) const
     {
-        const float aii_i = aii[i];
+        const float aii_i = a.aii_i;
         if (fabsf(aii_i) < 10e-4f) {
             p_out[i] = 0.f;
             pterm_out[i] = 0.f;
@@ -1544,9 +1549,9 @@ struct OpJacobi {
             bdiv = sp.opdisc == SPH_OP_WINCHENBACH2020 ? bdot : rho_b / rho_i * bdot;
         }
         const float a_p = a.sum + bdiv;
-        const float s = src[i];
+        const float s = a.src_i;
         if (!isfinite(a_p)) raise_error(status, SPH_ERR_AP_NOT_FINITE, orig[i]);
-        float pn = p_in[i] + sp.jacobi_omega * (s - a_p) / aii_i;
+        float pn = a.pin_i + sp.jacobi_omega * (s - a_p) / aii_i;
         if (!isfinite(pn)) raise_error(status, SPH_ERR_PRESSURE_NOT_FINITE, orig[i]);
         float err;
         if (residual_density) {
@@ -1598,6 +1603,9 @@ struct OpJacobiU : OpJacobi<MathT> {
         a.qy = Ai.w;
         a.err = 0.f;
         a.cls = 3u;
+        a.aii_i = this->aii[i];
+        a.src_i = this->src[i];
+        a.pin_i = this->p_in[i];
     }
     __device__ void pair(Acc& a, float4 Aj, NB, float dx, float dy, float r2, float hij) const
     {
