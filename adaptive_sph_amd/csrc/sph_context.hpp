@@ -92,6 +92,7 @@ struct sph_ctx {
         uint32_t pre_n = 0;          // slots in the arrays before the cell sort (live + gone)
         uint32_t pre_cls_n = 0;      // slots cls describes (the previous step's arrays)
         uint32_t pre_own = 0;        // pre-sort slots below this index are owned (if live), the ghosts follow
+        DevBuf tot_table;            // the ranks' solver totals side by side (RCCL transport: all-gather by send / receive), 2 slots
         DevBuf ring1, ring1_src;     // u8 per slot / per ghost ordinal: ghost within one support radius of the cut
         DevBuf halo_idx, halo_pos, halo_src, ghost_dst;      // index lists / maps (u32)
         DevBuf send[2], recv[2];     // staging, [left, right]

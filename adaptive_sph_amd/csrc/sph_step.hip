@@ -704,6 +704,13 @@ struct Comm {
     virtual int exchange(Group& G, std::vector<Xfer>& x) = 0;
     // element-wise sum of the members' 6 device doubles (solver totals + error flag), result in every member's buffer
     virtual int allreduce_solver(Group& G, int slot) = 0;   // slot 1: the second solve of a chained pair keeps totals of its own
+    // a Jacobi iteration's two collectives -- the ghosts' p / rho^2 and the totals of the iteration before -- as ONE call: a
+    // transport that pays per launch (RCCL) sends both in one group
+    virtual int exchange_and_allreduce_solver(Group& G, std::vector<Xfer>& x, int slot)
+    {
+        const int rc = exchange(G, x);
+        return rc ? rc : allreduce_solver(G, slot);
+    }
     virtual bool host_collectives_wait() const = 0;
     // ONE round trip for a decomposition phase: the class counts the phase's classify kernel left in dist.counts[base ..
     // base + 3] (1 = to the left neighbour, 2 = to the right, 3 = dropped / too narrow; class 0 is derived by the caller) reach
@@ -763,6 +770,15 @@ __global__ void k_tot_sum(double* __restrict__ tot, const double* __restrict__ t
     if (threadIdx.x >= 6) return;
     double s = 0.0;
     for (int j = 0; j < n; j++) s += ((const volatile double*)table)[8 * j + threadIdx.x];   // rank order
+    tot[threadIdx.x] = s;
+}
+// the same sum with this rank's own row still in `tot` (the RCCL transport's all-gather by send / receive)
+__global__ void k_tot_sum_self(double* __restrict__ tot, const double* __restrict__ table, int n, int self)
+{
+    if (threadIdx.x >= 6) return;
+    const double mine = tot[threadIdx.x];
+    double s = 0.0;
+    for (int j = 0; j < n; j++) s += j == self ? mine : table[8 * j + threadIdx.x];   // rank order: the same sum on every rank
     tot[threadIdx.x] = s;
 }
 static void debug_comm_delay(sph_ctx* c)
@@ -1178,6 +1194,43 @@ struct RcclComm : Comm {
         NCCLCHK(c, ncclAllReduce(t, t, 6, ncclFloat64, ncclSum, (ncclComm_t)c->dist.nccl, c->stream));
         return SPH_OK;
     }
+    // ONE grouped launch per Jacobi iteration: the x-neighbours' ghost values, and this rank's six totals to every rank / every
+    // rank's totals into a table (an all-gather by point-to-point messages); a one-block kernel then adds the rows in rank order --
+    // the same sum on every rank, as the all-reduce gave, without its launch.  Messages of 48 bytes: what is saved is a launch
+    // latency per iteration, which at 8 ranks and ~1M particles per rank is what the iteration's time is made of (DESIGN.md multi-GPU).
+    int exchange_and_allreduce_solver(Group& G, std::vector<Xfer>& x, int slot) override
+    {
+        sph_ctx* c = G.m[0];
+        ncclComm_t nc = (ncclComm_t)c->dist.nccl;
+        const int r = c->dist.rank, nr = c->dist.nranks;
+        HIPCHK(c, c->dist.tot_table.ensure((size_t)nr * 8 * 2 * sizeof(double)));
+        double* tot = c->dist.solver_tot.as<double>() + 8 * slot;
+        double* table = c->dist.tot_table.as<double>() + (size_t)slot * nr * 8;
+        c->dist.stat_exchanges++;
+        c->dist.stat_bytes_sent += (r > 0 ? x[0].send_bytes[0] : 0) + (r + 1 < nr ? x[0].send_bytes[1] : 0) + (size_t)(nr - 1) * 48;
+        c->dist.stat_bytes_recv += (r > 0 ? x[0].recv_bytes[0] : 0) + (r + 1 < nr ? x[0].recv_bytes[1] : 0) + (size_t)(nr - 1) * 48;
+        {
+            ProfScope ps(&c->prof, "rccl_sendrecv", c->stream);
+            NCCLCHK(c, ncclGroupStart());
+            if (r > 0) {
+                if (x[0].send_bytes[0]) NCCLCHK(c, ncclSend(x[0].send[0], x[0].send_bytes[0], ncclChar, r - 1, nc, c->stream));
+                if (x[0].recv_bytes[0]) NCCLCHK(c, ncclRecv(x[0].recv[0], x[0].recv_bytes[0], ncclChar, r - 1, nc, c->stream));
+            }
+            if (r + 1 < nr) {
+                if (x[0].send_bytes[1]) NCCLCHK(c, ncclSend(x[0].send[1], x[0].send_bytes[1], ncclChar, r + 1, nc, c->stream));
+                if (x[0].recv_bytes[1]) NCCLCHK(c, ncclRecv(x[0].recv[1], x[0].recv_bytes[1], ncclChar, r + 1, nc, c->stream));
+            }
+            for (int p = 0; p < nr; p++) {
+                if (p == r) continue;
+                NCCLCHK(c, ncclSend(tot, 6, ncclFloat64, p, nc, c->stream));
+                NCCLCHK(c, ncclRecv(table + 8 * p, 6, ncclFloat64, p, nc, c->stream));
+            }
+            NCCLCHK(c, ncclGroupEnd());
+        }
+        ProfScope ps(&c->prof, "solver_totals", c->stream);
+        hipLaunchKernelGGL(k_tot_sum_self, dim3(1), dim3(64), 0, c->stream, tot, table, nr, r);
+        return SPH_OK;
+    }
 };
 
 // ---- threads: one HOST THREAD per rank, all ranks in this process (and on whatever devices their contexts name) -----------------
@@ -1538,7 +1591,8 @@ static int sync_ctrl(Group& G, int mode = SYNC_AGREE)
 }
 
 // refresh `field` (words floats per particle) of every member's ghosts from their owners
-static int refresh_ghosts(Group& G, std::vector<Member>& M, float* (*sel)(Member&), int words, const char* what)
+// `tot_slot` >= 0: the all-reduce of the solver totals of that slot rides in the same call (Comm::exchange_and_allreduce_solver)
+static int refresh_ghosts(Group& G, std::vector<Member>& M, float* (*sel)(Member&), int words, const char* what, int tot_slot = -1)
 {
     if (!G.multi()) return SPH_OK;
     std::vector<Xfer> x(M.size());
@@ -1559,7 +1613,7 @@ static int refresh_ghosts(Group& G, std::vector<Member>& M, float* (*sel)(Member
             x[i].recv_bytes[side] = (size_t)c->dist.n_ghost[side] * words * 4;
         }
     }
-    int rc = G.comm->exchange(G, x);
+    int rc = tot_slot >= 0 ? G.comm->exchange_and_allreduce_solver(G, x, tot_slot) : G.comm->exchange(G, x);
     if (rc) return rc;
     for (size_t i = 0; i < M.size(); i++) {
         sph_ctx* c = M[i].c;
@@ -2161,8 +2215,22 @@ static int exchange_and_sweep_a(Group& G, std::vector<Member>& M, const SolveQ& 
     int rc;
     float* (*sel)(Member&) = (ka & 1u) ? sel_pt1 : sel_pt0;
     if (!split_sweep_a(G, M)) {
-        if ((rc = refresh_ghosts(G, M, sel, 1, "pt"))) return rc;
-        return solve_sweep_a(G, M, q, ka);
+        if (!G.multi()) return solve_sweep_a(G, M, q, ka);
+        // slab decomposition, one launch per sweep: this rank's totals of iteration ka - 1 first (k_solver_totals: what block 0 of
+        // the single-rank sweep does), so that their all-reduce can travel WITH the ghosts' p / rho^2 -- one collective call per
+        // iteration (one grouped RCCL launch) -- then the sweep with the reduced totals already in place
+        for (auto& m : M) {
+            sph_ctx* c = m.c;
+            (void)hipSetDevice(c->device);
+            if (m.n) launch_solver_totals(c->stream, &c->prof, m.a, (int)ka - 1, q.residual_density, q.max_avg_error, q.max_iters);
+            else HIPCHK(c, hipMemsetAsync(c->dist.solver_tot.as<double>() + 8 * q.tot_slot, 0, 48, c->stream));   // an empty slab contributes zeros
+        }
+        if ((rc = refresh_ghosts(G, M, sel, 1, "pt", q.tot_slot))) return rc;
+        for (auto& m : M) {
+            (void)hipSetDevice(m.c->device);
+            if (m.n) launch_pressure_accel(m.c->stream, &m.c->prof, m.a, (int)ka, q.residual_density, q.max_avg_error, q.max_iters, 2);
+        }
+        return SPH_OK;
     }
     for (auto& m : M) {   // the interior, beside everything below
         sph_ctx* c = m.c;
@@ -3429,7 +3497,7 @@ void dist_release(sph_ctx* c)
     auto& d = c->dist;
     if (d.nccl) ncclCommDestroy((ncclComm_t)d.nccl);
     d.nccl = nullptr;
-    DevBuf* all[] = {&d.owned, &d.ring1, &d.ring1_src, &d.halo_idx, &d.halo_pos, &d.halo_src, &d.ghost_dst, &d.send[0], &d.send[1], &d.recv[0], &d.recv[1], &d.counts, &d.solver_tot, &d.hist, &d.cls, &d.blk, &d.edge};
+    DevBuf* all[] = {&d.owned, &d.ring1, &d.ring1_src, &d.halo_idx, &d.halo_pos, &d.halo_src, &d.ghost_dst, &d.send[0], &d.send[1], &d.recv[0], &d.recv[1], &d.counts, &d.solver_tot, &d.tot_table, &d.hist, &d.cls, &d.blk, &d.edge};
     for (auto b : all) b->release();
     if (d.xstream) {
         (void)hipStreamSynchronize(d.xstream);
