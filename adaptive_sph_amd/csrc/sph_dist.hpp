@@ -1,0 +1,81 @@
+// What the step driver (sph_step.hip) and the transports between ranks (sph_transport.hip) share: the transport interface, the
+// group of contexts a step is driven for, and the few wait / staging helpers both sides use.
+#pragma once
+
+#include <cstdint>
+#include <vector>
+
+#include "sph_context.hpp"
+
+enum { RC_BAD = 12, RC_FAR = 13 };   // words of dist.counts: the fused refresh's "take the general path" flag being collected; "a migrant may need more than one hand-over"
+
+// (sph_step.hip) a few device words -> mapped host memory, then wait for them: counts_host[16 ..), sequence number in counts_host[63]
+int publish_and_wait(sph_ctx* c, const void* dev_words, uint32_t n_words);
+
+struct Group;
+struct Xfer {
+    const void* send[2];  // to left, to right
+    size_t send_bytes[2];
+    void* recv[2];        // from left, from right
+    size_t recv_bytes[2];
+};
+
+struct RefreshCounts {
+    uint32_t mig[2], halo[2];         // this rank: migrants to / halo members (that stay) towards [left, right]
+    uint32_t in_mig[2], in_halo[2];   // the neighbours': migrants for me / their halo members towards me, from [left, right]
+};
+
+struct Comm {
+    virtual ~Comm() {}
+    // reduce k host values per member element-wise over ALL ranks; every member's row receives the result
+    virtual int allreduce_min_f32(Group& G, std::vector<std::vector<float>>& rows) = 0;
+    virtual int allreduce_max_i32(Group& G, std::vector<int>& vals) = 0;
+    virtual int allreduce_sum_u32(Group& G, std::vector<std::vector<uint32_t>>& rows) = 0;   // element-wise, REBALANCE_BINS words
+    // every member learns the (to-left, to-right) counts its x-neighbours are about to send it; `status` (optional): this
+    // process's status of the phase, replaced by the maximum over ALL ranks in the same round trip
+    virtual int neighbour_counts(Group& G, const std::vector<uint32_t>& to_left, const std::vector<uint32_t>& to_right,
+                                 std::vector<uint32_t>& from_left, std::vector<uint32_t>& from_right, int* status = nullptr) = 0;
+    // device buffers; ordered after everything queued on the members' streams
+    virtual int exchange(Group& G, std::vector<Xfer>& x) = 0;
+    // element-wise sum of the members' 6 device doubles (solver totals + error flag), result in every member's buffer
+    virtual int allreduce_solver(Group& G, int slot) = 0;   // slot 1: the second solve of a chained pair keeps totals of its own
+    // a Jacobi iteration's two collectives -- the ghosts' p / rho^2 and the totals of the iteration before -- as ONE call: a
+    // transport that pays per launch (RCCL) sends both in one group
+    virtual int exchange_and_allreduce_solver(Group& G, std::vector<Xfer>& x, int slot)
+    {
+        const int rc = exchange(G, x);
+        return rc ? rc : allreduce_solver(G, slot);
+    }
+    virtual bool host_collectives_wait() const = 0;
+    // ONE round trip for a decomposition phase: the class counts the phase's classify kernel left in dist.counts[base ..
+    // base + 3] (1 = to the left neighbour, 2 = to the right, 3 = dropped / too narrow; class 0 is derived by the caller) reach
+    // the host (counts_host[base ..)), the x-neighbours' counts arrive as from_left / from_right, `red` (optional) is
+    // min-reduced element-wise over ALL ranks and `status` (optional) max-reduced -- on the device the status also becomes
+    // SPH_ERR_UNSUPPORTED if this rank's class-3 count of the halo phase (base 4) is non-zero (slab narrower than two ghost layers).
+    virtual int counts_round(Group& G, int base, std::vector<std::vector<float>>* red, int* status, std::vector<uint32_t>& to_left,
+                             std::vector<uint32_t>& to_right, std::vector<uint32_t>& from_left, std::vector<uint32_t>& from_right) = 0;
+    // ONE round trip of the fused refresh: the class totals k_slab_scan left in dist.counts[0 .. 4] reach the host, the x-neighbours'
+    // (migrants, halo members) arrive, `red` is min-reduced and `status` / `fallback` are max-reduced over ALL ranks
+    virtual int refresh_round(Group& G, std::vector<std::vector<float>>* red, int* status, int* fallback, std::vector<RefreshCounts>& rc) = 0;
+    // queued, no wait: the maximum over all ranks of the device-side guard word lands in every rank's ctrl->peer_error, which the
+    // next publish brings to the host (the step's one agreement on the guards, without a round trip of its own)
+    virtual int agree_guards_queued(Group& G) = 0;
+};
+
+struct Group {
+    std::vector<sph_ctx*> m;
+    Comm* comm = nullptr;  // nullptr: one rank, nothing to exchange
+    bool multi() const { return comm != nullptr; }
+    bool comm_waits() const { return comm && comm->host_collectives_wait(); }   // its host-value collectives end with a wait on the members' streams
+};
+
+
+// (sph_step.hip) wait for everything queued on every member's stream
+int wait_all_hinted(Group& G);
+int wait_all(Group& G);
+
+// (sph_transport.hip) the transport a step of `c` uses -- RCCL, the thread group or the shared-memory segment its context was
+// given -- or an error if a slab context has none; the loopback transport of sph_group_step; what a failing rank tells the others
+int comm_for_rank(sph_ctx* c, Comm** out);
+Comm* comm_loopback();
+void comm_abandon(sph_ctx* c);

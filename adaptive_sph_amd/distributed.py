@@ -47,16 +47,49 @@ def _slab_capacity(n_total: int, n_ranks: int) -> int:
     return int(n_total / n_ranks * 2.5) + 65536
 
 
-def make_slab_context(lib: ffi.SphLibrary, pos, mass, vel, planes, rank: int, world: int, local_rank: int) -> ffi.Context:
+def pick_transport(world: int) -> str:
+    """"rccl" -- one rank per GPU over xGMI, the fast path -- unless the launch puts several ranks on one device (RCCL refuses that:
+    "Duplicate GPU detected") or SPH_TRANSPORT=shm asks for the host-staged shared-memory transport (sph_comm_init_shm)."""
+    import os
+    import torch
+    want = os.environ.get("SPH_TRANSPORT", "")
+    if want in ("shm", "rccl"):
+        return want
+    return "shm" if (torch.cuda.is_available() and world > torch.cuda.device_count()) else "rccl"
+
+
+_SHM_SERIAL = [0]
+
+
+def make_slab_context(lib: ffi.SphLibrary, pos, mass, vel, planes, rank: int, world: int, local_rank: int, transport: str = None) -> ffi.Context:
+    """This rank's slab context of a `torch.distributed` launch (one process per rank): configured, communicator attached, particles
+    uploaded.  torch.distributed only carries the RCCL unique id (or the shared-memory segment's name) and a barrier."""
+    import os
     import torch.distributed as dist
     import torch
+    transport = transport or pick_transport(world)
     cuts = slab_cuts(pos[:, 0], world)
     mine = partition(pos[:, 0], cuts)[rank]
-    ctx = ffi.Context(lib, _slab_capacity(len(mass), world), planes, device_id=local_rank)
+    cap = _slab_capacity(len(mass), world)
+    ctx = ffi.Context(lib, cap, planes, device_id=local_rank)
     ctx.dist_configure(rank, world, cuts[rank], cuts[rank + 1])
     ctx.upload(mass[mine], pos[mine], vel[mine])
     if world > 1:
         ctx.upload_field("particle_id", mine.astype(np.uint32))
+    if transport == "shm":
+        # rank 0 names and creates the segment, the others map it after the launcher's barrier; an outbox holds one message to one
+        # x-neighbour: at most every particle of the slab as a 48-byte migrant record
+        _SHM_SERIAL[0] += 1
+        name = [f"/sph_shm_{os.getpid()}_{_SHM_SERIAL[0]}" if rank == 0 else None]
+        dist.broadcast_object_list(name, src=0)
+        per_side = max(1 << 22, cap * 48)
+        if rank == 0:
+            ctx.comm_init_shm(name[0], rank, world, per_side, True)
+        dist.barrier()
+        if rank != 0:
+            ctx.comm_init_shm(name[0], rank, world, per_side, False)
+        dist.barrier()
+        return ctx
     # RCCL unique id: created on rank 0, broadcast through the launcher's process group
     buf = torch.zeros(128, dtype=torch.uint8)
     if rank == 0:

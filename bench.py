@@ -170,10 +170,23 @@ def main():
     if rank == 0:
         build.build_hip()
     distributed = world > 1 or bool(os.environ.get('BENCH_FORCE_DIST'))   # the env knob exercises the launcher glue with one rank
+    transport = None
     if distributed:
+        from adaptive_sph_amd.distributed import pick_transport
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:   # (the forced one-rank distributed flow, started without a launcher)
+            import socket
+            with socket.socket() as so:
+                so.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(so.getsockname()[1])
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        # more ranks than devices (a functional run on a small box): RCCL refuses two ranks on one GPU -- the launcher's own process
+        # group then runs over gloo and the library over its shared-memory transport; the line says so in config.parallelism
+        transport = pick_transport(world)
+        if transport == "rccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
         dist.barrier()
     plib = ffi.load_product()
 
@@ -195,7 +208,7 @@ def main():
         planes = sc.boundary_planes(scn.boundary, P.init_boundary_handler)
         if distributed:
             from adaptive_sph_amd.distributed import make_slab_context
-            c = make_slab_context(plib, pos, mass, vel, planes, rank, world, local_rank)
+            c = make_slab_context(plib, pos, mass, vel, planes, rank, world, local_rank, transport)
         else:
             c = ffi.Context(plib, len(mass), planes, device_id=local_rank)
             c.upload(mass, pos, vel)
@@ -220,7 +233,7 @@ def main():
         barrier()
         el = time.perf_counter() - t0
         if distributed:
-            tt = torch.tensor([el], device="cuda", dtype=torch.float64)
+            tt = torch.tensor([el], device="cuda" if transport == "rccl" else "cpu", dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             el = float(tt.item())
         return el, warm, div_it, dens_it, c.dist_get_stats()
@@ -347,7 +360,7 @@ def main():
         "data": "synthetic",
         "config": {"workload": f"{wl}: {desc}", "particles": n_total, "solver": params.pressure_solver_method,
                    "mean_div_iterations": float(np.mean(div_iters)), "mean_density_iterations": float(np.mean(dens_iters)),
-                   "parallelism": f"x-slabs x{world}" if distributed else "single GPU"},
+                   "parallelism": (f"x-slabs x{world}" + ("" if transport == "rccl" else f", {transport} transport (more ranks than GPUs: functional run)")) if distributed else "single GPU"},
         "roofline": roofline,
         "roofline_density": roofline_density,
         "kernels": kernels,

@@ -438,6 +438,12 @@ int  sph_group_step(sph_ctx** ctxs, int n, const sph_params* params, sph_step_st
  * transport runs -- with the collectives as rendezvous in host memory.  What would hang RCCL is an error here: a collective
  * that not every rank enters (60 s), ranks in different collectives, a send without a receive of the same size on the other
  * side.  sph_thread_group_create(n) once, sph_comm_init_threads on every rank's context instead of sph_comm_init. */
+/* Transport for the ranks of ONE NODE as separate processes without RCCL: rendezvous and staging through a POSIX shared-memory
+ * segment `name` ("/..."), `bytes_per_side` of room for one message to one x-neighbour (ghost records: 28 B, migrants: 48 B each).
+ * Rank 0 creates it (create = 1) before the others map it -- the launcher orders that.  Host-synchronous and PCIe-bound: for boxes
+ * where RCCL cannot serve the launch (several ranks on one GPU: "Duplicate GPU detected") and for checking the launcher glue with
+ * real processes; sph_comm_init is the fast path.  At most 16 ranks. */
+int  sph_comm_init_shm(sph_ctx* ctx, const char* name, int rank, int n_ranks, uint64_t bytes_per_side, int create);
 int  sph_thread_group_create(int n_ranks, void** group_out);
 void sph_thread_group_destroy(void* group);
 int  sph_comm_init_threads(sph_ctx* ctx, void* group, int rank, int n_ranks);

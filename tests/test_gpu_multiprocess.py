@@ -1,0 +1,49 @@
+"""The distributed flow with REAL processes: one rank per process under torch.distributed.run, each calling sph_step by itself.
+On a box with fewer GPUs than ranks the ranks share a device, which RCCL refuses; the launcher glue (distributed.pick_transport)
+then takes the library's shared-memory transport (sph_comm_init_shm) -- the same per-rank driver code, the same collectives,
+staged through the host.  On a multi-GPU box the same tests run over RCCL."""
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+REPO = Path(__file__).resolve().parent.parent
+
+
+def _env():
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["MASTER_ADDR"] = "127.0.0.1"
+    return env
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_ranks_as_processes_reproduce_the_single_context(world):
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+                        "--master-port", str(29650 + world), str(REPO / "tests" / "mp_slab_check.py")],
+                       capture_output=True, text=True, timeout=600, env=_env(), cwd=str(REPO))
+    assert r.returncode == 0 and f"MP_CHECK OK world={world}" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_bench_starts_its_own_ranks_and_prints_the_schema():
+    """`python bench.py --gpus 2` without a launcher: bench.py re-executes itself under torch.distributed.run, the ranks share the box's
+    GPU(s), rank 0 prints the one JSON line with the driver's schema; the forced one-rank distributed flow prints it too."""
+    for cmd, extra_env in ((["--gpus", "2"], {}), (["--gpus", "1"], {"BENCH_FORCE_DIST": "1", "SPH_FORCE_SLAB_MODE": "1"})):
+        env = _env()
+        env.update(extra_env)
+        r = subprocess.run([sys.executable, str(REPO / "bench.py")] + cmd + ["--steps", "4", "--warmup", "2", "--workload", "dam_break_64k", "--no-8m",
+                                                                           "--profile-steps", "2", "--no-cpu-baseline"],
+                           capture_output=True, text=True, timeout=900, env=env, cwd=str(REPO))
+        assert r.returncode == 0, r.stderr[-4000:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, r.stdout[-2000:]
+        d = json.loads(lines[0])
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+            assert k in d, k
+        assert d["n_gpus"] == int(cmd[1]) and d["value"] > 0 and d["steps"] == 4 and d["comm_rank0"]["exchanges_per_step"] >= 0
+        if cmd[1] == "2":
+            assert d["comm_rank0"]["exchanges_per_step"] > 0 and d["comm_rank0"]["halo_bytes_sent_per_step"] > 0
