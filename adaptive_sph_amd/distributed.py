@@ -6,6 +6,7 @@ unique id and the launcher's barrier; the halo exchange itself is RCCL inside li
   make_slab_context  context of this rank, configured, communicator initialised, particles uploaded
   make_loopback_group  k contexts in this process (ranks 0..k-1) for single-GPU verification
   group_single_step_adaptivity  single_step_adaptivity for a slab group, through a gather to one context and back
+  rank_single_step_adaptivity   the same with one process per rank: gather / scatter through the launcher's process group
   ThreadedGroup      k ranks of this process, one host thread each, every rank calling sph_step by itself (verification of the per-rank code)
 """
 from __future__ import annotations
@@ -150,19 +151,70 @@ def assemble_lists(ids: Sequence[np.ndarray], lists: Sequence, n: int):
     return off_g, idx_g
 
 
+class GatherContext:
+    """The ONE plain context an adaptive step of a slab decomposition runs on (the reference decides sequentially over ALL particles
+    in index order, and a transfer's two partners may sit on different ranks: exactness goes through one place).  Kept between
+    adaptive steps -- allocating and freeing every per-particle buffer each time costs more than the step -- on the device the
+    caller names.  MEMORY: the whole particle set of the decomposition must fit that ONE device next to the rank's own slab
+    (~290 B per particle of capacity): scenes that need slabs to fit at all cannot take this path."""
+
+    def __init__(self, lib: ffi.SphLibrary, planes, device_id: int = 0, split_patterns=None, log=None):
+        self.lib, self.planes, self.device_id, self.split_patterns, self.log = lib, planes, device_id, split_patterns, log
+        self.ctx = None
+        self.driver = None
+
+    def ensure(self, n: int, capacity: int = 0):
+        from .adaptivity import AdaptivityDriver
+        want = capacity or max(2 * n, n + 65536)
+        if self.ctx is None or self.ctx.capacity < want:
+            self.close()
+            self.ctx = ffi.Context(self.lib, want, self.planes, device_id=self.device_id)
+            self.driver = AdaptivityDriver(self.ctx, self.split_patterns, self.log)
+        return self.ctx
+
+    def close(self):
+        if self.ctx is not None:
+            self.ctx.close()
+        self.ctx, self.driver = None, None
+
+
+def _adapt_gathered(gc: GatherContext, P, dt: float, step_number: int, g: dict, ids: Sequence[np.ndarray], lists: Sequence, capacity: int = 0):
+    """`g`: the fields of ALL particles in global index order; `ids` / `lists`: the ranks' ids and exported neighbour lists.
+    -> (fields of the new vector in its index order, info)."""
+    n = len(g["mass"])
+    off_g, idx_g = assemble_lists(ids, lists, n)   # neighbour lists in index order
+    if off_g[-1] >= 2 ** 32:
+        raise ValueError(f"adaptive step of a slab decomposition: {int(off_g[-1])} neighbour-list entries do not fit the 32-bit CSR offsets of the partner search")
+    T = gc.ensure(n, capacity)
+    T.upload(g["mass"], g["position"], g["velocity"])
+    for f in _ADAPT_FIELDS:
+        T.upload_field(f, g[f])
+    info = gc.driver.single_step_adaptivity(P, dt, step_number, lists=(off_g.astype(np.uint32), idx_g))
+    new = {f: T.download(f) for f in ("mass", "position", "velocity") + _ADAPT_FIELDS}
+    info["n_after"] = len(new["mass"])
+    return new, info
+
+
+def _reupload(c: ffi.Context, new: dict, mine: np.ndarray):
+    c.upload(new["mass"][mine], new["position"][mine], new["velocity"][mine])
+    for f in _ADAPT_FIELDS:
+        c.upload_field(f, new[f][mine])
+    c.upload_field("particle_id", mine.astype(np.uint32))
+
+
 def group_single_step_adaptivity(lib: ffi.SphLibrary, contexts: Sequence[ffi.Context], planes, P, dt: float, step_number: int,
-                                 split_patterns=None, capacity: int = 0, log=None) -> dict:
+                                 split_patterns=None, capacity: int = 0, log=None, gather: GatherContext = None) -> dict:
     """single_step_adaptivity (simulation.rs:2732-2796) for the ranks of a slab decomposition that have just stepped.
 
     The reference decides sequentially over ALL particles in index order and a transfer's two partners may sit on different
     ranks, so the exact form goes through one place: the owned particles of every rank (mass, position, velocity, h2, h2_next,
     level values, size class) and their neighbour lists (global ids, ghosts included) are assembled in global index order -- the
-    particle ids ARE the reference's Vec indices --, uploaded to ONE plain context, the same decisions (adaptivity.py) and the
-    same device-side share / merge / split run there, and the result goes back: every rank is re-uploaded with the particles of
-    its slab, their new index as id.  Same arithmetic as on a single context; the price is a gather and a scatter over PCIe per
-    adaptive step (support lengths FromMass: the previous step's lambda sums do not travel).  In-process form (loopback group,
-    or one process driving several GPUs); with one process per GPU the same gather / scatter goes through the launcher."""
-    from .adaptivity import AdaptivityDriver
+    particle ids ARE the reference's Vec indices --, uploaded to ONE plain context (GatherContext: pass one to keep it between
+    steps), the same decisions (adaptivity.py) and the same device-side share / merge / split run there, and the result goes
+    back: every rank is re-uploaded with the particles of its slab, their new index as id.  Same arithmetic as on a single
+    context; the price is a gather and a scatter over PCIe per adaptive step (support lengths FromMass: the previous step's lambda
+    sums do not travel).  In-process form (loopback group, or one process driving several GPUs); rank_single_step_adaptivity is
+    the same for one process per GPU."""
     if P.support_length_estimation != "FromMass":
         raise ValueError("group_single_step_adaptivity: support_length_estimation must be FromMass")
     ids = [c.download("particle_id") for c in contexts]
@@ -171,26 +223,59 @@ def group_single_step_adaptivity(lib: ffi.SphLibrary, contexts: Sequence[ffi.Con
     if not np.array_equal(np.sort(allid), np.arange(n, dtype=allid.dtype)):
         raise ValueError("group_single_step_adaptivity: the particle ids of the ranks are not the indices 0 .. n-1")
     g = {f: gather_by_id(contexts, f, n) for f in ("mass", "position", "velocity") + _ADAPT_FIELDS}
-    off_g, idx_g = assemble_lists(ids, [c.download_neighbors() for c in contexts], n)   # neighbour lists in index order
-    T = ffi.Context(lib, capacity or max(2 * n, n + 65536), planes, device_id=0)
+    own = gather is None
+    gc = gather or GatherContext(lib, planes, 0, split_patterns, log)
     try:
-        T.upload(g["mass"], g["position"], g["velocity"])
-        for f in _ADAPT_FIELDS:
-            T.upload_field(f, g[f])
-        info = AdaptivityDriver(T, split_patterns, log).single_step_adaptivity(P, dt, step_number, lists=(off_g.astype(np.uint32), idx_g))
-        new = {f: T.download(f) for f in ("mass", "position", "velocity") + _ADAPT_FIELDS}
+        new, info = _adapt_gathered(gc, P, dt, step_number, g, ids, [c.download_neighbors() for c in contexts], capacity)
     finally:
-        T.close()
-    n_new = len(new["mass"])
+        if own:
+            gc.close()
     cuts = [contexts[0].dist_get_cuts()[0]] + [c.dist_get_cuts()[1] for c in contexts]
     parts = partition(new["position"][:, 0], [-INF] + [float(v) for v in cuts[1:-1]] + [INF])
     for c, mine in zip(contexts, parts):
-        c.upload(new["mass"][mine], new["position"][mine], new["velocity"][mine])
-        for f in _ADAPT_FIELDS:
-            c.upload_field(f, new[f][mine])
-        c.upload_field("particle_id", mine.astype(np.uint32))
-    info["n_after"] = n_new
+        _reupload(c, new, mine)
     return info
+
+
+def rank_single_step_adaptivity(ctx: ffi.Context, gather: GatherContext, P, dt: float, step_number: int, capacity: int = 0, root: int = 0) -> dict:
+    """The same adaptive step with ONE PROCESS PER RANK (the launch bench.py --gpus N and the RCCL / shared-memory transports use):
+    every rank hands the fields adaptivity reads and its exported neighbour lists to `root` through the launcher's process group
+    (torch.distributed gather_object: pickled numpy arrays -- host memory either way, the decisions are host code), `root`
+    assembles them in global index order, runs the decisions and the device-side apply on its GatherContext (`gather`; None on
+    the other ranks) and scatters every rank the particles of its slab, which it uploads with their new indices as ids.  Every
+    rank calls this after the same sph_step; returns the step's counts (shares / merges / splits, n_after) on every rank."""
+    import torch.distributed as dist
+    if P.support_length_estimation != "FromMass":
+        raise ValueError("rank_single_step_adaptivity: support_length_estimation must be FromMass")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    mine = {f: ctx.download(f) for f in ("particle_id", "mass", "position", "velocity") + _ADAPT_FIELDS}
+    mine["lists"] = ctx.download_neighbors()
+    mine["cuts"] = ctx.dist_get_cuts()[:2]
+    parts = [None] * world if rank == root else None
+    dist.gather_object(mine, parts, dst=root)
+    out = [None] * world
+    if rank == root:
+        ids = [q["particle_id"] for q in parts]
+        n = int(sum(len(i) for i in ids))
+        allid = np.concatenate(ids)
+        if not np.array_equal(np.sort(allid), np.arange(n, dtype=allid.dtype)):
+            raise ValueError("rank_single_step_adaptivity: the particle ids of the ranks are not the indices 0 .. n-1")
+        g = {}
+        for f in ("mass", "position", "velocity") + _ADAPT_FIELDS:
+            a = np.zeros((n,) + parts[0][f].shape[1:], parts[0][f].dtype)
+            for q in parts:
+                a[q["particle_id"]] = q[f]
+            g[f] = a
+        new, info = _adapt_gathered(gather, P, dt, step_number, g, ids, [q["lists"] for q in parts], capacity)
+        cuts = [-INF] + [float(q["cuts"][1]) for q in parts[:-1]] + [INF]
+        for r, sel in enumerate(partition(new["position"][:, 0], cuts)):
+            out[r] = ({f: new[f][sel] for f in new}, sel, info)
+    got = [None]
+    dist.scatter_object_list(got, out if rank == root else None, src=root)
+    new, sel, info = got[0]
+    _reupload(ctx, {f: v for f, v in new.items()}, np.arange(len(sel)))
+    ctx.upload_field("particle_id", sel.astype(np.uint32))
+    return dict(info)
 
 
 class ThreadedGroup:

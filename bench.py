@@ -302,6 +302,51 @@ def main():
             strong_8m["sweep_a_one_launch"] = {k: v for k, v in run_8m("0").items() if k in ("value", "ms_per_step", "comm_rank0")}
             strong_8m["sweep_a_split"] = {k: v for k, v in run_8m("1").items() if k in ("value", "ms_per_step", "comm_rank0")}
 
+    # ---- BASELINE configs[4] on the same ranks: the ratio-stress scene (4 004 343 particles at 50:1 radii, IISPH, Sdf2D box, EmptyAngle
+    # level estimation) -- its step path, and a few calls of single_step WITH sharing / merging / splitting, the adaptive half through
+    # the launcher (distributed.rank_single_step_adaptivity: gather to rank 0, decisions + device-side apply there, scatter back).
+    # The ghost layer is a multiple of the LARGEST smoothing length, so this scene's 0.55-wide blocks stand at most TWO slabs: beyond
+    # that every rank returns the library's refusal (all-reduced values: the same branch everywhere), which the line then carries.
+    config4 = None
+    if distributed and not args.no_8m and wl == "dam_break_1m":
+        from adaptive_sph_amd.distributed import GatherContext, rank_single_step_adaptivity
+        s4, p4f, d4 = WORKLOADS["ratio_stress_4m"]
+        r_fine = float(np.sqrt(np.float32(0.0004385) ** 2 * 0.93 / np.pi))
+        P4 = p4f(level_estimation_method="EmptyAngle", merging=True, sharing=True, splitting=True, particle_radius_fine=r_fine,
+                 particle_radius_base=50 * r_fine, maximum_surface_distance=0.3)
+        config4 = {"workload": f"ratio_stress_4m: {d4}, EmptyAngle level estimation", "n_gpus": world}
+        c4 = None
+        try:
+            scn4 = s4()
+            c4, n4 = make_context(scn4, P4)
+            k4 = max(2, min(args.steps, 10))
+            el4, _, _, de4, st4 = timed_run(c4, P4.to_ffi(), 2, k4)
+            config4.update({"particles": n4, "steps": k4, "ms_per_step": el4 * 1e3 / k4, "particle_steps_per_s": n4 * k4 / el4,
+                            "mean_density_iterations": float(np.mean(de4)), "comm_rank0": comm_record(st4, k4)})
+            from adaptive_sph_amd.adaptivity import SplitPatterns
+            pat = REPO / "tests" / "golden" / "split-patterns.yaml"
+            sp4 = SplitPatterns.load_from_file(pat) if pat.exists() else None
+            if sp4 is not None:
+                gc = GatherContext(plib, sc.boundary_planes(scn4.boundary, P4.init_boundary_handler), local_rank, sp4) if rank == 0 else None
+                barrier()
+                t0 = time.perf_counter()
+                ev = {"shares": 0, "merges": 0, "splits": 0}
+                for _ in range(2):
+                    st = c4.step(P4.to_ffi())
+                    info = rank_single_step_adaptivity(c4, gc, P4, float(st.dt), int(st.step_number), capacity=6000000)
+                    for k in ev:
+                        ev[k] += info[k]
+                barrier()
+                config4["single_step_with_adaptivity"] = {"steps": 2, "ms_per_step": (time.perf_counter() - t0) * 1e3 / 2, "events": ev,
+                                                          "particles_after": info["n_after"], "note": "rank 0's clock; gather / scatter through the launcher's process group"}
+                if gc is not None:
+                    gc.close()
+        except ffi.SphError as e:   # (a refusal taken on all-reduced values: every rank is here)
+            config4["refused"] = str(e)[:300]
+        finally:
+            if c4 is not None:
+                c4.close()
+
     if rank != 0:
         if distributed:
             dist.barrier()
@@ -365,6 +410,7 @@ def main():
         "roofline_density": roofline_density,
         "kernels": kernels,
         "strong_8m": strong_8m,
+        "config4_ratio_stress_4m": config4,
         "comm_rank0": comm_record(comm_stats, args.steps) if distributed else {"host_waits_per_step": comm_stats["host_waits"] / max(args.steps, 1)},
     }
     if distributed:   # time inside RCCL per step, from the instrumented pass (HIP events around the grouped send/recv and the all-reduces)

@@ -29,6 +29,15 @@ def test_ranks_as_processes_reproduce_the_single_context(world):
     assert r.returncode == 0 and f"MP_CHECK OK world={world}" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
+def test_adaptive_steps_with_one_process_per_rank():
+    """single_step = sph_step + single_step_adaptivity on a slab decomposition whose ranks are PROCESSES: the gather / decide / apply /
+    scatter of distributed.rank_single_step_adaptivity through the launcher's process group, against the single context."""
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29661", str(REPO / "tests" / "mp_adaptive_check.py")],
+                       capture_output=True, text=True, timeout=600, env=_env(), cwd=str(REPO))
+    assert r.returncode == 0 and "MP_ADAPTIVE OK world=2" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
 def test_bench_starts_its_own_ranks_and_prints_the_schema():
     """`python bench.py --gpus 2` without a launcher: bench.py re-executes itself under torch.distributed.run, the ranks share the box's
     GPU(s), rank 0 prints the one JSON line with the driver's schema; the forced one-rank distributed flow prints it too."""
