@@ -324,11 +324,15 @@ static int transfer(sph_ctx* c, const sph_params* p, const sph_adapt_params* ap,
     const uint32_t n = (uint32_t)c->n;
     if (n == 0) return SPH_OK;
     if (!partner || !counter) return SPH_ERR_INVALID_ARGUMENT;
+    // (before anything is launched: a bad index must not leave some receivers and donors already modified)
+    for (uint32_t i = 0; i < n; i++)
+        if (partner[i] >= n && partner[i] != SPH_MERGE_PARTNER_AVAILABLE && partner[i] != SPH_MERGE_PARTNER_DELETE)
+            return c->fail(SPH_ERR_INVALID_ARGUMENT, "merge_partner holds an index outside the particle vector (particle i=%u: %u)", i, partner[i]);
     hipStream_t s = c->stream;
     const int k = c->cur;
-    DevBuf d_partner, d_counter, d_slot, d_del, d_before, d_scratch, d_holes, d_src, d_sets;
+    TmpBuf d_partner, d_counter, d_slot, d_del, d_before, d_scratch, d_holes, d_src, d_sets;
     auto release = [&] {
-        for (DevBuf* b : {&d_partner, &d_counter, &d_slot, &d_del, &d_before, &d_scratch, &d_holes, &d_src, &d_sets}) b->release();
+        for (TmpBuf* b : {&d_partner, &d_counter, &d_slot, &d_del, &d_before, &d_scratch, &d_holes, &d_src, &d_sets}) b->release();
     };
     auto guard = [&](hipError_t e) { return e == hipSuccess; };
     if (!guard(d_partner.ensure((size_t)n * 4)) || !guard(d_counter.ensure((size_t)n * 2)) || !guard(d_slot.ensure((size_t)n * 4))) {
@@ -429,9 +433,9 @@ extern "C" int sph_split_particles(sph_ctx* c, const sph_params* p, const sph_ad
     hipStream_t s = c->stream;
     const int k = c->cur;
     const uint32_t max_children = c->n_split_patterns + 1u;   // SplitPatterns::get_max_num_children (splitting.rs:115-117)
-    DevBuf d_extra, d_base, d_scratch, d_slot, d_src, d_sets;
+    TmpBuf d_extra, d_base, d_scratch, d_slot, d_src, d_sets;
     auto release = [&] {
-        for (DevBuf* b : {&d_extra, &d_base, &d_scratch, &d_slot, &d_src, &d_sets}) b->release();
+        for (TmpBuf* b : {&d_extra, &d_base, &d_scratch, &d_slot, &d_src, &d_sets}) b->release();
     };
     if (d_extra.ensure((size_t)n * 4) != hipSuccess || d_base.ensure((size_t)n * 4 + 4) != hipSuccess ||
         d_scratch.ensure(((size_t)n / SCAN_TILE + 4) * 4) != hipSuccess || d_slot.ensure((size_t)n * 4) != hipSuccess) {

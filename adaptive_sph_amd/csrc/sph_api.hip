@@ -827,7 +827,7 @@ extern "C" int sph_apply_edits(sph_ctx* c, const sph_edit_op* ops, uint64_t n_op
 
     // ---- one gather on the device into final-index order (slot f = host index f, like a fresh upload)
     hipStream_t s = c->stream;
-    DevBuf d_src, d_sets;
+    TmpBuf d_src, d_sets;
     HIPCHK(c, d_src.ensure(src.size() * sizeof(EditSrc)));
     HIPCHK(c, d_sets.ensure(sets.size() * sizeof(EditSet)));
     HIPCHK(c, hipMemcpyAsync(d_src.p, src.data(), src.size() * sizeof(EditSrc), hipMemcpyHostToDevice, s));
@@ -843,7 +843,7 @@ int regather_host_order(sph_ctx* c, uint32_t n_new, const EditSrc* d_src, const 
     hipStream_t s = c->stream;
     const uint32_t n_old = (uint32_t)c->n;
     if (n_new > c->cap) return c->fail(SPH_ERR_CAPACITY, "%u particles exceed the capacity %llu", n_new, (unsigned long long)c->cap);
-    DevBuf d_slot, d_lam;
+    TmpBuf d_slot, d_lam;
     HIPCHK(c, d_slot.ensure(((size_t)n_old + 1) * 4));
     HIPCHK(c, d_lam.ensure(((size_t)n_new + 1) * 4));
     const int k = c->cur;
@@ -1007,7 +1007,7 @@ extern "C" int sph_profile_copy_bandwidth(sph_ctx* c, uint64_t bytes, double* gb
 {
     if (!c || !gb_per_s || bytes < 1024) return SPH_ERR_INVALID_ARGUMENT;
     HIPCHK(c, hipSetDevice(c->device));
-    DevBuf a, b;
+    TmpBuf a, b;
     HIPCHK(c, a.ensure(bytes));
     HIPCHK(c, b.ensure(bytes));
     HIPCHK(c, hipMemsetAsync(a.p, 0, bytes, c->stream));
@@ -1059,7 +1059,7 @@ extern "C" int sph_profile_list_forms(sph_ctx* c, sph_list_forms* out)
     HIPCHK(c, hipSetDevice(c->device));
     if (!c->grid_valid) return c->fail(SPH_ERR_INVALID_ARGUMENT, "no neighbour lists yet: run a step first");
     const uint32_t n = c->dist.on && c->dist.have_flags ? c->dist.n_tot : (uint32_t)c->n;
-    DevBuf acc;
+    TmpBuf acc;
     HIPCHK(c, acc.ensure(5 * sizeof(unsigned long long)));
     HIPCHK(c, hipMemsetAsync(acc.p, 0, 5 * sizeof(unsigned long long), c->stream));
     const bool flags = c->dist.on && c->dist.have_flags;
@@ -1119,7 +1119,7 @@ extern "C" int sph_download_neighbors(sph_ctx* c, uint32_t* offsets, uint32_t* i
         if (!indices) return SPH_OK;
         if (cap < tot) return c->fail(SPH_ERR_INVALID_ARGUMENT, "indices buffer too small");
         if (tot == 0) return SPH_OK;
-        DevBuf d_off, d_idx, d_row;
+        TmpBuf d_off, d_idx, d_row;
         HIPCHK(c, d_off.ensure(((size_t)n + 1) * 4));
         HIPCHK(c, d_idx.ensure((size_t)tot * 4));
         HIPCHK(c, d_row.ensure((size_t)nt * 4));
@@ -1167,7 +1167,7 @@ extern "C" int sph_download_neighbors(sph_ctx* c, uint32_t* offsets, uint32_t* i
     if (tot == 0) return SPH_OK;
     // The lists are those of the positions the last step STARTED from (NeighborhoodCache after a
     // step): pm[pcur ^ 1] still holds that sorted pre-step snapshot.
-    DevBuf d_off, d_idx;
+    TmpBuf d_off, d_idx;
     HIPCHK(c, d_off.ensure(((size_t)n + 1) * 4));
     HIPCHK(c, d_idx.ensure((size_t)tot * 4));
     HIPCHK(c, hipMemcpyAsync(d_off.p, off.data(), ((size_t)n + 1) * 4, hipMemcpyHostToDevice, s));

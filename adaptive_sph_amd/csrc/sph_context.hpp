@@ -35,6 +35,14 @@ struct DevBuf {
     T* as() const { return (T*)p; }
 };
 
+// a DevBuf of function scope: released on every path out of the function (early error returns included)
+struct TmpBuf : DevBuf {
+    TmpBuf() = default;
+    TmpBuf(const TmpBuf&) = delete;
+    TmpBuf& operator=(const TmpBuf&) = delete;
+    ~TmpBuf() { release(); }
+};
+
 struct sph_ctx {
     int device = 0;
     uint64_t cap = 0, n = 0;

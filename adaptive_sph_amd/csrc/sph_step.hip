@@ -426,6 +426,15 @@ __global__ __launch_bounds__(256) void k_halo_pos(const uint32_t* __restrict__ h
 // after the cell sort: where did my halo particles and my ghosts end up?  perm[s] = pre-sort index of slot s
 // `cls` (fused refresh, else nullptr): halo_pos is only defined for the halo members then -- slots whose class byte says so and the
 // arrivals behind the n_cls previous slots -- and nothing had to clear the rest of it
+// pacc[slot] = {x, y, 0, 0} for every ghost slot (see setup_member)
+__global__ __launch_bounds__(256) void k_seed_ghost_records(const uint32_t* __restrict__ ghost_dst, uint32_t ng, const float4* __restrict__ pm, float4* __restrict__ pacc)
+{
+    const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= ng) return;
+    const uint32_t i = ghost_dst[k];
+    const float4 p = pm[i];
+    pacc[i] = make_float4(p.x, p.y, 0.f, 0.f);
+}
 __global__ void k_edge_mark(const uint32_t* __restrict__ halo_src, uint32_t nh, const uint32_t* __restrict__ ghost_dst, uint32_t ng, uint8_t* __restrict__ edge)
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1792,6 +1801,14 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
                     hipLaunchKernelGGL(k_edge_mark, dim3((nh + ng + 255) / 256), dim3(256), 0, s, d.halo_src.as<uint32_t>(), nh, d.ghost_dst.as<uint32_t>(), ng,
                                        d.edge.as<uint8_t>());
             }
+            // the {x, y, a^p} records of the ghosts: sweep A writes a record for every owned particle and every ghost of the first
+            // ring, sweep B gathers neighbours' records (all of them written) -- but a particle WITHOUT a recorded list walks the
+            // candidates of its 3 x 3 cells through those records (OpJacobiU), and a second-ring ghost among them must carry its
+            // position, not whatever the buffer held: seeded here, once per step, on the ghosts' own slots
+            const uint32_t ng_seed = d.ghosts_ok ? d.n_ghost[0] + d.n_ghost[1] : 0u;
+            if (n && ng_seed)
+                hipLaunchKernelGGL(k_seed_ghost_records, dim3((ng_seed + 255) / 256), dim3(256), 0, s, d.ghost_dst.as<uint32_t>(), ng_seed,
+                                   c->pm[c->pcur].as<float4>(), c->pacc.as<float4>());
             d.have_flags = true;
         }
         if (tev) (void)hipEventRecord(c->ev[1], s);
