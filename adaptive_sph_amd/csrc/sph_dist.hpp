@@ -79,3 +79,39 @@ int wait_all(Group& G);
 int comm_for_rank(sph_ctx* c, Comm** out);
 Comm* comm_loopback();
 void comm_abandon(sph_ctx* c);
+
+// ---- the members of a group step and what the step driver and the slab maintenance (sph_slabs.hip) share ----
+#include <chrono>
+#include "sph_internal.hpp"
+struct Member {
+    sph_ctx* c;
+    uint32_t n;  // particles in the arrays (owned + ghosts)
+    uint32_t n_sort = 0;   // slots the cell sort looks at (fused slab refresh: n + the slots that left, which it drops); 0: n
+    StepP sp;
+    SweepArgs a;
+    sph_step_stats st;
+    std::chrono::steady_clock::time_point wall0;
+    float *lv_level = nullptr, *lv_when = nullptr, *lv_pmnew = nullptr;   // level estimation fields whose ghosts are refreshed
+};
+
+// (sph_step.hip) collective error check at a wait point; publish ctrl + status of every member and wait (SYNC_*: see the definition)
+int agree(Group& G, int local_rc);
+enum { SYNC_AGREE = 0, SYNC_DEFER = 1, SYNC_FINAL = 2 };
+int sync_ctrl(Group& G, int mode = SYNC_AGREE);
+void dbg_sync(sph_ctx* c, const char* what, int id = 0);   // SPH_DEBUG_SYNC: synchronise and name the phase just queued
+
+// (sph_slabs.hip) slab maintenance of a group step, multi-rank only
+enum { SC_STAY = 0, SC_HALO_L = 1, SC_HALO_R = 2, SC_MIG_L = 3, SC_MIG_R = 4, SC_GHOST = 5, SC_GONE_FROM = 3 };   // classes of the fused refresh
+int ensure_dist_buffers(sph_ctx* c, uint32_t n);
+int partition_and_migrate(Group& G, std::vector<Member>& M, std::vector<int>* moved = nullptr, std::vector<std::vector<float>>* red = nullptr);
+int rebalance_cuts(Group& G, std::vector<Member>& M, bool* applied);
+int build_ghost_layer(Group& G, std::vector<Member>& M, float halo_width, float ring1_width, int status_in);
+int slab_refresh_fused(Group& G, std::vector<Member>& M, std::vector<std::vector<float>>& red, float halo_k, bool* fused);
+// refresh `field` (words floats per particle) of every member's ghosts from their owners; tot_slot >= 0: the all-reduce of that slot's
+// solver totals rides in the same call
+int refresh_ghosts(Group& G, std::vector<Member>& M, float* (*sel)(Member&), int words, const char* what, int tot_slot = -1);
+// after the cell sort: slot maps of halo members and ghosts, ownership flags, the split sweep's edge bytes, the ghosts' {x, y, a^p} records
+int slab_maps_after_sort(sph_ctx* c, uint32_t n, bool pre, hipStream_t s);
+// m / rho of the ghosts from their refreshed densities
+void slab_ghost_mrho(sph_ctx* c, const SweepArgs& a);
+
