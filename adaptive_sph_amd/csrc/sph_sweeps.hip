@@ -182,6 +182,55 @@ __device__ __forceinline__ void replay_masks(const Op& op, typename Op::Acc& acc
     }
 }
 
+// ---- list replay, row masks, FLAT form (SPH_FLAT16): the three masks are decoded first, into up to 16 neighbour indices held in
+// registers (row-major, ascending: the order of replay_masks, so the sums are bit-identical), then trips of 4 run over that flat
+// sequence: 16 pair slots for up to 16 neighbours where the per-row trips spend 20-24 (every row pads its last trip).  What is
+// left in the masks after 16 (compressed regions) is replayed one neighbour at a time.
+// MEASURED NEGATIVE for the headline, kept as a switch (profiles/r3_variants.md): in the laboratory the rest lattice is 20.3 vs 20.1 us and
+// a jittered scene 23.4 vs 26.1 us; in the product the driver window of configs[1] (a compressed near-lattice column) LOSES 5 %
+// (OpJacobiU 25.2 vs 23.2 us, 1.265 vs 1.204 ms/step: the 16-slot select chain costs what the padding slots cost), the settled
+// scene 100 steps later gains 3 % of GPU time (0.522 vs 0.533 ms), configs[3] loses 2 %.
+#ifndef SPH_FLAT16
+#define SPH_FLAT16 0
+#endif
+template <class Op>
+__device__ __forceinline__ void replay_masks_flat(const Op& op, typename Op::Acc& acc, const float4 Ai, const uint32_t rb0, const uint32_t rb1,
+                                                  const uint32_t rb2, const uint4 lw, const uint32_t i)
+{
+    typedef typename Op::Math Math;
+    uint32_t m0 = lw.x, m1 = lw.y, m2 = lw.z;
+    const uint32_t cnt = (uint32_t)(__popc(m0) + __popc(m1) + __popc(m2));
+    uint32_t j[16];
+#pragma unroll
+    for (int s = 0; s < 16; s++) {
+        const bool u0 = m0 != 0u, u1 = m1 != 0u;
+        const uint32_t m = u0 ? m0 : (u1 ? m1 : m2);
+        const uint32_t bs = u0 ? rb0 : (u1 ? rb1 : rb2);
+        j[s] = m ? bs + (uint32_t)__ffs(m) - 1u : i;   // (an unused slot fetches the particle's own record: a line the wave holds)
+        const uint32_t mm = m & (m - 1u);
+        m0 = u0 ? mm : m0;
+        m1 = (!u0 && u1) ? mm : m1;
+        m2 = (!u0 && !u1) ? mm : m2;
+    }
+#pragma unroll
+    for (uint32_t s0 = 0; s0 < 16u; s0 += 4u) {
+        if (!__any(s0 < cnt)) break;   // (wave-uniform: the longest list of the wave decides the number of trips)
+        SPH_FETCH(j[s0], A0, N0)
+        SPH_FETCH(j[s0 + 1], A1, N1)
+        SPH_FETCH(j[s0 + 2], A2, N2)
+        SPH_FETCH(j[s0 + 3], A3, N3)
+        SPH_PAIR(A0, N0, s0 < cnt)
+        SPH_PAIR(A1, N1, s0 + 1u < cnt)
+        SPH_PAIR(A2, N2, s0 + 2u < cnt)
+        SPH_PAIR(A3, N3, s0 + 3u < cnt)
+    }
+    // more than 16 neighbours (compressed regions): what is left in the masks goes through the per-row trips
+    if (__any((m0 | m1 | m2) != 0u)) {
+        const uint32_t rbs[3] = {rb0, rb1, rb2};
+        replay_masks(op, acc, Ai, rbs, make_uint4(m0, m1, m2, 0u));
+    }
+}
+
 // ---- list replay, explicit indices: one coalesced uint4 (4 neighbours) per trip ---------------------------
 template <class Op>
 __device__ __forceinline__ void replay_indices(const Op& op, typename Op::Acc& acc, const float4 Ai, const uint32_t i, const uint32_t cnt,
@@ -377,7 +426,8 @@ __device__ __forceinline__ void sweep_particle(const Op& op, const SweepCommon& 
                     const uint32_t sb = i - rb[1];
                     if (sb < 32u) lw.y &= ~(1u << sb);
                 }
-                replay_masks(op, acc, Ai, rb, lw);
+                if (SPH_FLAT16 && Math::UNIFORM && !Op::EXTENDED) replay_masks_flat(op, acc, Ai, rb[0], rb[1], rb[2], lw, i);
+                else replay_masks(op, acc, Ai, rb, lw);
             } else {
                 uint32_t mk[3] = {0u, 0u, 0u}, nacc = 0;
                 IdxRecorder rec;

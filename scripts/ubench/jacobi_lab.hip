@@ -84,6 +84,11 @@ __device__ __forceinline__ uint32_t ix(uint32_t j, uint32_t lim, uint32_t tag)
 #endif
     return j;
 }
+__device__ __forceinline__ uint32_t __reduce_max_sync_lab(uint32_t v)
+{
+    for (int o = 32; o > 0; o >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, o, 64));
+    return v;
+}
 struct Acc {
     float sum, qx, qy, inv_rho;
 };
@@ -255,6 +260,197 @@ __global__ __launch_bounds__(256) void k_gather4_slim(Args A)
     } else {
         finish(A, a, i, rho_i);
     }
+}
+
+// ---- variant: the three row masks decoded FIRST into up to 16 neighbour indices in registers (row-major, ascending: the same
+// order), then trips of 4 over that flat sequence: no padding slot per row, 16 slots for up to 16 neighbours (more: a scalar tail) ----
+__global__ __launch_bounds__(256) void k_flat16_slim(Args A)
+{
+    const uint32_t blk = remap_block(A.nblocks);
+    if (blk >= A.nblocks) return;
+    const uint32_t i = blk * 256 + threadIdx.x;
+    if (i >= A.n) return;
+    const float4 Ai = A.comb[i];
+    const uint4 lw = A.nl[i];
+    const float rho_i = A.rho[i];
+    const float aii_i = A.aii[i], src_i = A.src[i], pin_i = A.p_in[i];
+    uint32_t rb[3];
+    int cx, cy;
+    row_bases(A, Ai.x, Ai.y, rb, cx, cy);
+    Acc a;
+    a.sum = 0.f;
+    a.inv_rho = __builtin_amdgcn_rcpf(rho_i);
+    a.qx = Ai.z;
+    a.qy = Ai.w;
+    const float nf6 = 6.f * A.m.nf * A.m.inv2h;
+    uint32_t m0 = lw.x, m1 = lw.y, m2 = lw.z;
+    const uint32_t cnt = (uint32_t)(__popc(m0) + __popc(m1) + __popc(m2));
+    uint32_t j[16];
+#pragma unroll
+    for (int s = 0; s < 16; s++) {
+        const bool u0 = m0 != 0u, u1 = m1 != 0u;
+        const uint32_t m = u0 ? m0 : (u1 ? m1 : m2);
+        const uint32_t bs = u0 ? rb[0] : (u1 ? rb[1] : rb[2]);
+        j[s] = m ? bs + (uint32_t)__ffs(m) - 1u : i;
+        const uint32_t mm = m & (m - 1u);
+        m0 = u0 ? mm : m0;
+        m1 = (!u0 && u1) ? mm : m1;
+        m2 = (!u0 && !u1) ? mm : m2;
+    }
+    const uint32_t wmax = min(16u, (uint32_t)__reduce_max_sync_lab(cnt));
+#pragma unroll
+    for (uint32_t s0 = 0; s0 < 16; s0 += 4) {   // (wave-uniform trip count: the largest list of the wave; unrolled, registers are not indexable)
+        if (s0 >= wmax) break;
+        const float4 R0 = A.comb[ix(j[s0], A.n, 7u)], R1 = A.comb[ix(j[s0 + 1], A.n, 7u)], R2 = A.comb[ix(j[s0 + 2], A.n, 7u)],
+                     R3 = A.comb[ix(j[s0 + 3], A.n, 7u)];
+        pair_slim(A, a, Ai.x, Ai.y, R0.x, R0.y, R0.z, R0.w, s0 < cnt, nf6);
+        pair_slim(A, a, Ai.x, Ai.y, R1.x, R1.y, R1.z, R1.w, s0 + 1 < cnt, nf6);
+        pair_slim(A, a, Ai.x, Ai.y, R2.x, R2.y, R2.z, R2.w, s0 + 2 < cnt, nf6);
+        pair_slim(A, a, Ai.x, Ai.y, R3.x, R3.y, R3.z, R3.w, s0 + 3 < cnt, nf6);
+    }
+    // more than 16 neighbours: what is left in the masks, one at a time
+    while (m0 | m1 | m2) {
+        const bool u0 = m0 != 0u, u1 = m1 != 0u;
+        const uint32_t m = u0 ? m0 : (u1 ? m1 : m2);
+        const uint32_t bs = u0 ? rb[0] : (u1 ? rb[1] : rb[2]);
+        const float4 R = A.comb[ix(bs + (uint32_t)__ffs(m) - 1u, A.n, 8u)];
+        pair_slim(A, a, Ai.x, Ai.y, R.x, R.y, R.z, R.w, true, nf6);
+        const uint32_t mm = m & (m - 1u);
+        m0 = u0 ? mm : m0;
+        m1 = (!u0 && u1) ? mm : m1;
+        m2 = (!u0 && !u1) ? mm : m2;
+    }
+    a.sum *= A.mass * a.inv_rho;
+    const float pn = pin_i + A.omega * (src_i - a.sum) / aii_i;
+    const bool pos = pn > 0.f;
+    A.p_out[i] = pos ? pn : 0.f;
+    A.pt_out[i] = pos ? pn / (rho_i * rho_i) : 0.f;
+}
+
+// ---- variant: the masks decoded by three short per-row loops that append the neighbour's index to a per-lane column of LDS
+// ([slot][lane]: bank = lane, no conflicts whatever the slot), then flat trips of 4 read back from that column ----
+__global__ __launch_bounds__(256) void k_flat_lds_slim(Args A)
+{
+    __shared__ uint32_t jl[16][256];
+    const uint32_t blk = remap_block(A.nblocks);
+    if (blk >= A.nblocks) return;
+    const uint32_t i = blk * 256 + threadIdx.x;
+    if (i >= A.n) return;
+    const float4 Ai = A.comb[i];
+    const uint4 lw = A.nl[i];
+    const float rho_i = A.rho[i];
+    const float aii_i = A.aii[i], src_i = A.src[i], pin_i = A.p_in[i];
+    uint32_t rb[3];
+    int cx, cy;
+    row_bases(A, Ai.x, Ai.y, rb, cx, cy);
+    Acc a;
+    a.sum = 0.f;
+    a.inv_rho = __builtin_amdgcn_rcpf(rho_i);
+    a.qx = Ai.z;
+    a.qy = Ai.w;
+    const float nf6 = 6.f * A.m.nf * A.m.inv2h;
+    uint32_t k = 0;
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        uint32_t m = r == 0 ? lw.x : (r == 1 ? lw.y : lw.z);
+        const uint32_t bs = rb[r];
+        while (m) {
+            const uint32_t j = bs + (uint32_t)__ffs(m) - 1u;
+            if (k < 16u) jl[k][threadIdx.x] = j;
+            else {
+                const float4 R = A.comb[ix(j, A.n, 10u)];
+                pair_slim(A, a, Ai.x, Ai.y, R.x, R.y, R.z, R.w, true, nf6);
+            }
+            k++;
+            m &= m - 1u;
+        }
+    }
+    const uint32_t cnt = min(k, 16u);
+    const uint32_t wmax = __reduce_max_sync_lab(cnt);
+#pragma unroll
+    for (uint32_t s0 = 0; s0 < 16; s0 += 4) {
+        if (s0 >= wmax) break;
+        const uint32_t q0 = s0 < cnt ? jl[s0][threadIdx.x] : i, q1 = s0 + 1 < cnt ? jl[s0 + 1][threadIdx.x] : i,
+                       q2 = s0 + 2 < cnt ? jl[s0 + 2][threadIdx.x] : i, q3 = s0 + 3 < cnt ? jl[s0 + 3][threadIdx.x] : i;
+        const float4 R0 = A.comb[ix(q0, A.n, 11u)], R1 = A.comb[ix(q1, A.n, 11u)], R2 = A.comb[ix(q2, A.n, 11u)], R3 = A.comb[ix(q3, A.n, 11u)];
+        pair_slim(A, a, Ai.x, Ai.y, R0.x, R0.y, R0.z, R0.w, s0 < cnt, nf6);
+        pair_slim(A, a, Ai.x, Ai.y, R1.x, R1.y, R1.z, R1.w, s0 + 1 < cnt, nf6);
+        pair_slim(A, a, Ai.x, Ai.y, R2.x, R2.y, R2.z, R2.w, s0 + 2 < cnt, nf6);
+        pair_slim(A, a, Ai.x, Ai.y, R3.x, R3.y, R3.z, R3.w, s0 + 3 < cnt, nf6);
+    }
+    a.sum *= A.mass * a.inv_rho;
+    const float pn = pin_i + A.omega * (src_i - a.sum) / aii_i;
+    const bool pos = pn > 0.f;
+    A.p_out[i] = pos ? pn : 0.f;
+    A.pt_out[i] = pos ? pn / (rho_i * rho_i) : 0.f;
+}
+
+// ---- variant: trips of 4 per row (as the product), the gathers of trip k + 1 requested BEFORE the pairs of trip k are evaluated ----
+__global__ __launch_bounds__(256) void k_gather4_slim_pipe(Args A)
+{
+    const uint32_t blk = remap_block(A.nblocks);
+    if (blk >= A.nblocks) return;
+    const uint32_t i = blk * 256 + threadIdx.x;
+    if (i >= A.n) return;
+    const float4 Ai = A.comb[i];
+    const uint4 lw = A.nl[i];
+    const float rho_i = A.rho[i];
+    const float aii_i = A.aii[i], src_i = A.src[i], pin_i = A.p_in[i];
+    uint32_t rb[3];
+    int cx, cy;
+    row_bases(A, Ai.x, Ai.y, rb, cx, cy);
+    Acc a;
+    a.sum = 0.f;
+    a.inv_rho = __builtin_amdgcn_rcpf(rho_i);
+    a.qx = Ai.z;
+    a.qy = Ai.w;
+    const float nf6 = 6.f * A.m.nf * A.m.inv2h;
+    uint32_t m0 = lw.x, m1 = lw.y, m2 = lw.z;
+    // one trip = the next (up to) 4 set bits of the first non-empty row; returns false when nothing is left
+    float4 R0, R1, R2, R3;
+    bool v0, v1, v2, v3;
+    auto fetch = [&](float4& S0, float4& S1, float4& S2, float4& S3, bool& w0, bool& w1, bool& w2, bool& w3) {
+        const bool u0 = m0 != 0u, u1 = m1 != 0u;
+        uint32_t m = u0 ? m0 : (u1 ? m1 : m2);
+        const uint32_t bs = u0 ? rb[0] : (u1 ? rb[1] : rb[2]);
+        w0 = m != 0u;
+        const uint32_t b0 = w0 ? (uint32_t)__ffs(m) - 1u : 0u;
+        m &= m - 1u;
+        w1 = m != 0u;
+        const uint32_t b1 = w1 ? (uint32_t)__ffs(m) - 1u : b0;
+        m &= m - 1u;
+        w2 = m != 0u;
+        const uint32_t b2 = w2 ? (uint32_t)__ffs(m) - 1u : b0;
+        m &= m - 1u;
+        w3 = m != 0u;
+        const uint32_t b3 = w3 ? (uint32_t)__ffs(m) - 1u : b0;
+        m &= m - 1u;
+        m0 = u0 ? m : m0;
+        m1 = (!u0 && u1) ? m : m1;
+        m2 = (!u0 && !u1) ? m : m2;
+        const uint32_t safe = w0 ? bs : i;
+        S0 = A.comb[ix(safe + (w0 ? b0 : 0u), A.n, 9u)];
+        S1 = A.comb[ix(safe + (w0 ? b1 : 0u), A.n, 9u)];
+        S2 = A.comb[ix(safe + (w0 ? b2 : 0u), A.n, 9u)];
+        S3 = A.comb[ix(safe + (w0 ? b3 : 0u), A.n, 9u)];
+    };
+    fetch(R0, R1, R2, R3, v0, v1, v2, v3);
+    while (__any(v0)) {
+        float4 N0, N1, N2, N3;
+        bool n0, n1, n2, n3;
+        fetch(N0, N1, N2, N3, n0, n1, n2, n3);
+        pair_slim(A, a, Ai.x, Ai.y, R0.x, R0.y, R0.z, R0.w, v0, nf6);
+        pair_slim(A, a, Ai.x, Ai.y, R1.x, R1.y, R1.z, R1.w, v1, nf6);
+        pair_slim(A, a, Ai.x, Ai.y, R2.x, R2.y, R2.z, R2.w, v2, nf6);
+        pair_slim(A, a, Ai.x, Ai.y, R3.x, R3.y, R3.z, R3.w, v3, nf6);
+        R0 = N0; R1 = N1; R2 = N2; R3 = N3;
+        v0 = n0; v1 = n1; v2 = n2; v3 = n3;
+    }
+    a.sum *= A.mass * a.inv_rho;
+    const float pn = pin_i + A.omega * (src_i - a.sum) / aii_i;
+    const bool pos = pn > 0.f;
+    A.p_out[i] = pos ? pn : 0.f;
+    A.pt_out[i] = pos ? pn / (rho_i * rho_i) : 0.f;
 }
 
 // ---- variant: no neighbour work at all (own loads, finish, stores): the floor of the launch ----
@@ -631,6 +827,9 @@ int main(int argc, char** argv)
         {"gather4, one combined 16-B record {x, y, a^p}", k_gather4<1>, true},
         {"gather4, combined record, slim pair arithmetic (v_max spline, clamped r2, folded constants, fma)", k_gather4_slim<0>, true},
         {"gather4, combined record, slim pair arithmetic, finish's loads requested at the top", k_gather4_slim<1>, true},
+        {"combined record, slim, masks decoded into 16 indices first, then flat trips of 4 (no per-row padding)", k_flat16_slim, true},
+        {"combined record, slim, masks decoded by per-row loops into an LDS column per lane, then flat trips of 4", k_flat_lds_slim, true},
+        {"gather4, combined record, slim, next trip's gathers requested before this trip's pairs (rows merged into one trip sequence)", k_gather4_slim_pipe, true},
         {"gather, combined record, 2 bits per iteration (no padding beyond pairs)", k_gather_loop<2>, true},
         {"gather, combined record, 1 bit per iteration (no padding slots)", k_gather_loop<1>, true},
         {"LDS windows per wave, trips of 4", k_lds<0>, true},
