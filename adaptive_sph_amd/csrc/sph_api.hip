@@ -446,7 +446,7 @@ extern "C" int sph_create(uint64_t n_capacity, int device_id, const sph_plane* p
               c->status.ensure(sizeof(DeviceStatus)) == hipSuccess && c->n_tiles.ensure(16) == hipSuccess;
     if (!ok) return bail(SPH_ERR_DEVICE);
     if (hipHostMalloc((void**)&c->hdr_host, sizeof(HeaderOut), hipHostMallocMapped) != hipSuccess) return bail(SPH_ERR_DEVICE);
-    if (hipHostMalloc((void**)&c->ctrl_host, 2 * sizeof(SolverCtrl), hipHostMallocMapped) != hipSuccess) return bail(SPH_ERR_DEVICE);
+    if (hipHostMalloc((void**)&c->ctrl_host, 3 * sizeof(SolverCtrl), hipHostMallocMapped) != hipSuccess) return bail(SPH_ERR_DEVICE);
     if (hipHostMalloc((void**)&c->status_host, sizeof(DeviceStatus), hipHostMallocMapped) != hipSuccess) return bail(SPH_ERR_DEVICE);
     if (hipHostMalloc((void**)&c->lvl_changed, 64 * sizeof(uint32_t), hipHostMallocMapped) != hipSuccess) return bail(SPH_ERR_DEVICE);
     if (hipHostGetDevicePointer((void**)&c->lvl_changed_dev, c->lvl_changed, 0) != hipSuccess) return bail(SPH_ERR_DEVICE);
@@ -456,7 +456,9 @@ extern "C" int sph_create(uint64_t n_capacity, int device_id, const sph_plane* p
     if (hipHostGetDevicePointer((void**)&c->status_host_dev, c->status_host, 0) != hipSuccess) return bail(SPH_ERR_DEVICE);
     if (hipEventCreateWithFlags(&c->ev_sync, hipEventDisableTiming) != hipSuccess) return bail(SPH_ERR_DEVICE);
     memset(c->status_host, 0, sizeof(DeviceStatus));
-    memset((void*)c->ctrl_host, 0, 2 * sizeof(SolverCtrl));
+    memset((void*)c->ctrl_host, 0, 3 * sizeof(SolverCtrl));
+    c->prog_host = (volatile uint32_t*)(c->ctrl_host + 2);   // (the third block: only its first word is used)
+    c->prog_host_dev = (uint32_t*)(c->ctrl_host_dev + 2);
     // BoundaryWinchenbach2020::new (boundary_winchenbach2020.rs:33-36)
     std::vector<float> lam, dlam;
     sph_lambda::build_luts(lam, dlam);

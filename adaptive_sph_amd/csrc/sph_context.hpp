@@ -82,6 +82,9 @@ struct sph_ctx {
     HeaderOut* hdr_host_dev = nullptr;
     SolverCtrl* ctrl_host_dev = nullptr;
     DeviceStatus* status_host_dev = nullptr;
+    volatile uint32_t* prog_host = nullptr;   // paced solves: the device's last stop decision (behind ctrl_host[1]; SweepArgs::prog_host)
+    uint32_t* prog_host_dev = nullptr;
+    uint32_t solve_epoch = 0;
     hipEvent_t ev_sync = nullptr;
 
     // ---- slab decomposition (multi-GPU): this context owns x in [cut_lo, cut_hi) -------------------
@@ -160,6 +163,7 @@ struct sph_ctx {
     uint32_t* lvl_changed_dev = nullptr;
     uint32_t pressure_cur = 0;
     uint32_t last_div_iters = 2, last_dens_iters = 2;
+    uint32_t prev_dens_iters = 0;
     uint32_t prev_div_iters = 0;   // the step before: the solves are chained only while the divergence solve's count repeats
     hipEvent_t ev[8];
 

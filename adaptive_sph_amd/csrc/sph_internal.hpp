@@ -168,6 +168,10 @@ struct SweepArgs {
     SolverCtrl* ctrl;
     const uint32_t* gate = nullptr;   // chained solves: the launches of the second solve leave at once while this word is 0 (k_solver_handoff)
     DeviceStatus* status;
+    // paced solves (one context): the stop decision of every iteration is also stored in mapped host memory as
+    // (epoch << 16) | (stop << 15) | iteration, so that the host queues iterations against the device's progress (sph_step.hip)
+    uint32_t* prog_host = nullptr;
+    uint32_t prog_epoch = 0;
 };
 
 size_t sweep_list_bytes(uint32_t n);

@@ -502,6 +502,90 @@ static void solve_stats(Member& m, const SolveQ& q, const SolverCtrl& h)
     st->max_error = h.max_err;
 }
 
+// ---- paced solve (one context) ---------------------------------------------------------------------------------------------
+// The iteration counts of a violent scene jump by factors from step to step (configs[1], steps 5-24: 7 3 6 11 17 22 21 18 6 4 15 ...):
+// queueing "the previous step's count" either falls short (a host wait, then a quarter more) or overshoots (two empty launches of
+// ~3.8 us per iteration not needed): together ~0.14 of the driver window's 1.2 ms per step.  Paced, the host needs no prediction to be
+// right: block 0 of sweep A(k + 1) stores its decision on iteration k in mapped host memory when that sweep STARTS (SolveP::prog),
+// and the host -- which runs far ahead of the device anyway -- queues iteration k + 1 only once fewer than `lead` undecided
+// iterations are in the queue.  The sweep that took the decision still runs for its ~23 us per 1M particles while the next two
+// launches travel, so the device never idles, and a solve ends with at most `lead` - 1 iterations queued in vain.  The first
+// iterations (the smaller of the last two counts) are queued without looking: a cushion against a host thread that is late once.
+// The tail is queued when the host has SEEN "stop": no gate, no re-queueing, and between the two solves of HybridDFSPH no wait.
+static uint32_t pace_setting(const char* name, uint32_t dflt)
+{
+    const char* e = getenv(name);
+    return e ? (uint32_t)atoi(e) : dflt;
+}
+static bool paced_enabled()
+{
+    return pace_setting("SPH_PACED", 1u) != 0u;   // 0: predicted queue + waits (the multi-rank form) on one context too (read per solve: the tests switch it)
+}
+// Small scenes: an iteration of n particles takes ~46 us x n / 2^20 on the device, the host's answer to a decision ~10-20 us: the
+// lead grows as the sweeps shrink (1 from ~0.45M particles up), and the unpaced head is the smaller of the last two counts; large
+// scenes queue nothing unpaced (measured on configs[1]'s driver window: 1.148 ms/step, against 1.164 with the head and 1.201-1.207
+// with the predicted queue; profiles/r3_variants.md section 5).  SPH_PACE_LEAD / SPH_PACE_PRED override both.
+static uint32_t pace_lead(uint32_t n)
+{
+    static const uint32_t forced = pace_setting("SPH_PACE_LEAD", 0u);
+    if (forced) return forced;
+    return std::min(8u, std::max(1u, (450000u + n - 1u) / std::max(n, 1u)));
+}
+static uint32_t pace_prediction(uint32_t n, uint32_t last, uint32_t prev)
+{
+    static const int mode = (int)pace_setting("SPH_PACE_PRED", 0xffffu);   // 0: nothing unpaced; 1: min of the last two counts; 2: the last count
+    const int md = mode == 0xffff ? (n >= 450000u ? 0 : 1) : mode;
+    if (md == 0) return 2u;
+    if (md == 2 || prev == 0u) return last;
+    return std::min(last, prev);
+}
+static int solve_paced(Group& G, std::vector<Member>& M, SolveQ& q, uint32_t predicted_iters)
+{
+    Member& m = M[0];
+    const uint32_t lead = pace_lead(m.n);
+    sph_ctx* c = m.c;
+    int rc;
+    (void)hipSetDevice(c->device);
+    c->solve_epoch = c->solve_epoch >= 0xffffu ? 1u : c->solve_epoch + 1u;
+    const uint32_t epoch = c->solve_epoch;
+    m.a.prog_host = c->prog_host_dev;
+    m.a.prog_epoch = epoch;
+    if ((rc = solve_begin(G, M, q, predicted_iters))) return rc;
+    auto iteration = [&](uint32_t k) -> int {
+        launch_jacobi_update(c->stream, &c->prof, m.a, (int)k, q.residual_density, q.max_avg_error, q.max_iters, 0);
+        return solve_sweep_a(G, M, q, k + 1);
+    };
+    for (; q.k <= q.upto && q.k <= q.max_iters; q.k++)
+        if ((rc = iteration(q.k))) return rc;
+    auto t0 = std::chrono::steady_clock::now();
+    int last_seen = -2;
+    for (uint64_t spins = 0;; spins++) {
+        const uint32_t w = *c->prog_host;
+        const bool seen = (w >> 16) == epoch;
+        if (seen && (w & 0x8000u)) break;
+        const int decided = seen ? (int)(w & 0x7fffu) : -1;   // iterations 0 .. decided are decided; A(q.k) is queued and decides q.k - 1
+        if (q.k <= q.max_iters && (int)q.k - 1 - decided < (int)lead) {
+            if ((rc = iteration(q.k))) return rc;
+            q.k++;
+            continue;
+        }
+        if (decided != last_seen) {
+            last_seen = decided;
+            t0 = std::chrono::steady_clock::now();
+        } else if ((spins & 0xffffu) == 0xffffu && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 2.0) {
+            // no decision for 2 s: a faulted kernel (the event path reports it) -- or a decision that never comes
+            if ((rc = wait_stream(c))) return rc;
+            const uint32_t w2 = *c->prog_host;
+            if ((w2 >> 16) == epoch && (w2 & 0x8000u)) break;
+            if ((w2 >> 16) == epoch && (int)(w2 & 0x7fffu) != decided) continue;
+            return c->fail(SPH_ERR_DEVICE, "pressure solve: the device finished its queue without a stop decision (iteration %u queued)", q.k - 1);
+        }
+    }
+    q.upto = q.k - 1;   // solve_queue() has only the tail left to queue
+    m.a.prog_host = nullptr;
+    return SPH_OK;
+}
+
 // iisph_pressure_iterations (simulation.rs:1377-1516) with a host wait of its own
 static int pressure_iterations(Group& G, std::vector<Member>& M, float max_avg_error, int residual_density, uint32_t max_iters,
                                uint32_t predicted_iters, int tail, bool density_solver, bool final_solve)
@@ -509,6 +593,15 @@ static int pressure_iterations(Group& G, std::vector<Member>& M, float max_avg_e
     int rc;
     const int multi = G.multi() ? 1 : 0;
     SolveQ q{max_avg_error, residual_density, max_iters, tail, density_solver};
+    if (!multi && M[0].n > 0 && paced_enabled()) {
+        sph_ctx* c0 = M[0].c;
+        const uint32_t head = density_solver ? pace_prediction(M[0].n, c0->last_dens_iters, c0->prev_dens_iters) : pace_prediction(M[0].n, c0->last_div_iters, c0->prev_div_iters);
+        if ((rc = solve_paced(G, M, q, head))) return rc;
+        if ((rc = solve_queue(G, M, q, false, true))) return rc;   // (the tail)
+        if ((rc = sync_ctrl(G, SYNC_AGREE))) return rc;
+        solve_stats(M[0], q, *M[0].c->ctrl_host);
+        return SPH_OK;
+    }
     if ((rc = solve_begin(G, M, q, predicted_iters))) return rc;
     for (;;) {
         if ((rc = solve_queue(G, M, q, false, true))) return rc;
@@ -1336,6 +1429,27 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
         // in the first steps of a dam break it jumps by factors (4, 15, 17, 7, ...), and a short-fall there throws away a
         // density solve's worth of gated launches (measured: 1.38 vs 1.27 ms/step over steps 5-24 when always chained).
         // (parameters and all-reduced iteration counts only: every rank decides the same)
+        if (!G.multi() && M[0].n > 0 && paced_enabled()) {
+            // one context: both solves paced against the device's progress, ONE host wait at the end of the step
+            SolveQ qd{p->hybrid_dfsph_max_avg_divergence_error, 0, p->max_iters, T_VEL, false};
+            SolveQ qs{p->hybrid_dfsph_max_avg_density_error, 1, p->max_iters, T_HYBRID, true};
+            if ((rc = solve_paced(G, M, qd, pace_prediction(M[0].n, c0->last_div_iters, c0->prev_div_iters)))) return rc;
+            if ((rc = solve_queue(G, M, qd, true))) return rc;   // the tail (v += dt a^p): it also leaves the solve's control block in ctrl_host[1]
+            g_trace.mark(4);
+            rec(3);
+            if (!p->hybrid_dfsph_non_pressure_accel_before_divergence_free)
+                if ((rc = non_pressure())) return rc;
+            rec(4);
+            begin_solve(p->hybrid_dfsph_density_source_term == SPH_ONLY_DENSITY ? 2 : 1, 1);
+            if ((rc = solve_paced(G, M, qs, pace_prediction(M[0].n, c0->last_dens_iters, c0->prev_dens_iters)))) return rc;
+            if ((rc = solve_queue(G, M, qs, false, true))) return rc;
+            if ((rc = sync_ctrl(G, SYNC_AGREE))) return rc;
+            solve_stats(M[0], qd, M[0].c->ctrl_host[1]);
+            solve_stats(M[0], qs, *M[0].c->ctrl_host);
+            g_trace.mark(5);
+            rec(5);
+            break;
+        }
         const char* chain_env = getenv("SPH_CHAIN");
         const bool chain_wanted = chain_env ? chain_env[0] == '1' : c0->last_div_iters == c0->prev_div_iters;
         const bool chain = (G.multi() || M[0].n > 0) && p->hybrid_dfsph_non_pressure_accel_before_divergence_free && chain_wanted;
@@ -1462,6 +1576,7 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
         c->hdr_ahead = h_from_mass_mode && m.n > 0 && m.a.hdr_partials != nullptr && !p->constrain_neighborhood_count;
         c->hdr_ahead_rest_density = p->rest_density;
         c->prev_div_iters = c->last_div_iters;
+        c->prev_dens_iters = c->last_dens_iters;
         c->last_div_iters = m.st.div_solver.iters;
         c->last_dens_iters = m.st.density_solver.iters;
         c->time += dt_step;  // simulation.rs:2724-2725

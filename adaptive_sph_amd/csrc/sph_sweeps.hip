@@ -1208,6 +1208,8 @@ struct SolveP {
     uint32_t max_iters;
     int multi;   // slab decomposition: block 0 only adds up this rank's totals; the decision follows the all-reduce (k_solver_decide)
                  // 2: ... and not even that -- k_solver_totals did, on the stream of the collectives (split sweep A)
+    uint32_t* prog = nullptr;   // paced solve: mapped host word that receives every decision (SweepArgs::prog_host), else nullptr
+    uint32_t epoch = 0;
 };
 
 // stopping rule of iisph_pressure_iterations (simulation.rs:1453-1479) for iteration `iter`
@@ -1303,6 +1305,8 @@ __device__ __forceinline__ void solver_reduce_decide(const SolverPartial* __rest
     ctrl->cur = (uint32_t)((iter + 1) & 1);  // mem::swap(pressure, pressure_next_iter)
     ctrl->slot_done[(iter + 1) & 1] = stop ? 1u : 0u;
     if (stop) ctrl->done = 1u;
+    // paced solve: the host learns of the decision while this launch still sweeps (it queues the next iteration, or the tail)
+    if (q.prog) *(volatile uint32_t*)q.prog = (q.epoch << 16) | (stop ? 0x8000u : 0u) | ((uint32_t)iter & 0x7fffu);
 }
 
 // Sweep A of iteration `iter` >= 1 reads pressure buffer iter & 1 -- and its block 0 first takes the stop decision of iteration
@@ -2628,7 +2632,7 @@ void launch_pressure_accel(hipStream_t s, Profiler* prof, const SweepArgs& a0, i
     ProfScope ps(prof, part == 2 ? "pressure_accel_edge" : "pressure_accel", s);
     SweepArgs a = a0;
     a.part = part;
-    const SolveP q{residual_density, max_avg_error, max_iters, part ? 2 : multi};
+    const SolveP q{residual_density, max_avg_error, max_iters, part ? 2 : multi, a.prog_host, a.prog_epoch};
     SPH_DISPATCH(OpPressureAccel, false, a.pm, a.orig, a.rho, a.p0, a.p1, a.pt0, a.pt1, a.lam_grad, a.pacc, a.ctrl, (const SolverPartial*)a.partials,
                  solver_reduce_blocks(a.n), a.solver_tot, a.status, a.sp, q, iter, a.owned, a.gate)
 }

@@ -1,7 +1,10 @@
-"""HybridDFSPH on one context: the density solve is queued behind the divergence solve without a host wait in between (chained
-solves, sph_step.hip), its launches gated on the device.  Whatever the gate does -- open at once, or closed because the divergence
-solve needed more iterations than were queued, so that both solves are queued again -- the step must be the step: every field
-and every iteration count bit for bit what the two-wait form gives."""
+"""HybridDFSPH on one context, three ways of queueing the same launches (sph_step.hip):
+  paced     (default) the host queues every iteration against the device's published stop decisions: no prediction, no gate, one
+            host wait per step;
+  chained   (SPH_PACED=0, SPH_CHAIN=1) predicted counts, the density solve queued behind the divergence solve with its launches
+            gated on the device -- the form slab decompositions use; a divergence solve that falls short re-queues both;
+  two-wait  (SPH_PACED=0, SPH_CHAIN=0) predicted counts, a host wait behind each solve.
+Whatever the queue does, the step must be the step: every field and every iteration count bit for bit the same."""
 import numpy as np
 import pytest
 
@@ -10,9 +13,12 @@ from adaptive_sph_amd.workloads import dam_break_params
 
 pytestmark = pytest.mark.gpu
 
+FORMS = {"paced": dict(SPH_PACED="1"), "chained": dict(SPH_PACED="0", SPH_CHAIN="1"), "two-wait": dict(SPH_PACED="0", SPH_CHAIN="0")}
 
-def run(product_lib, monkeypatch, chain, steps, **overrides):
-    monkeypatch.setenv("SPH_CHAIN", chain)
+
+def run(product_lib, monkeypatch, form, steps, **overrides):
+    for k, v in FORMS[form].items():
+        monkeypatch.setenv(k, v)
     scn = sc.dam_break_small(128, 96, 1 / 64)
     pos, mass, vel = sc.init_particles(scn)
     P = dam_break_params(**overrides)
@@ -25,25 +31,44 @@ def run(product_lib, monkeypatch, chain, steps, **overrides):
         its.append((int(st.div_solver.iters), int(st.density_solver.iters), int(st.div_solver.normal_count), int(st.density_solver.normal_count),
                     np.float32(st.div_solver.avg_error).view(np.uint32).item(), np.float32(st.density_solver.avg_error).view(np.uint32).item()))
     waits = g.dist_get_stats()["host_waits"]
-    monkeypatch.delenv("SPH_CHAIN")
+    for k in FORMS[form]:
+        monkeypatch.delenv(k)
     return g, its, waits
 
 
 @pytest.mark.parametrize("overrides", [dict(), dict(hybrid_dfsph_density_source_term="OnlyDensity")])
-def test_chained_solves_are_bit_identical_to_the_two_wait_form(product_lib, monkeypatch, overrides):
+def test_paced_chained_and_two_wait_solves_are_bit_identical(product_lib, monkeypatch, overrides):
     steps = 40
-    a, ia, wa = run(product_lib, monkeypatch, "1", steps, **overrides)
-    b, ib, wb = run(product_lib, monkeypatch, "0", steps, **overrides)
-    assert ia == ib
+    a, ia, wa = run(product_lib, monkeypatch, "chained", steps, **overrides)
+    b, ib, wb = run(product_lib, monkeypatch, "two-wait", steps, **overrides)
+    c, ic, wc = run(product_lib, monkeypatch, "paced", steps, **overrides)
+    assert ia == ib == ic
     div = [t[0] for t in ia]
     assert max(div) > min(div) and any(div[k + 1] > div[k] for k in range(len(div) - 1))   # a chained divergence solve fell short at least once
     assert wa < wb                                                                        # fewer host waits when chained
+    assert wc <= steps + 1 and wc <= wa                                                   # paced: the step's one wait (+ the first step's header)
     for f in ("position", "velocity", "density", "pressure", "aii", "ppe_source_term", "neighbor_count"):
         assert np.array_equal(a.download(f), b.download(f)), f
+        assert np.array_equal(a.download(f), c.download(f)), f
 
 
-def test_default_policy_chains_once_the_iteration_count_repeats(product_lib, monkeypatch):
+@pytest.mark.parametrize("solver", ["IISPH", "IISPH2", "OnlyDivergence"])
+def test_paced_single_solve_modes_match_the_predicted_queue(product_lib, monkeypatch, solver):
+    """pressure_iterations() of the one-solve modes, paced and with the predicted queue"""
+    out = {}
+    for form in ("paced", "two-wait"):
+        g, its, waits = run(product_lib, monkeypatch, form, 25, pressure_solver_method=solver)
+        out[form] = (g, its, waits)
+    assert out["paced"][1] == out["two-wait"][1]
+    assert out["paced"][2] <= out["two-wait"][2]
+    for f in ("position", "velocity", "density", "pressure"):
+        assert np.array_equal(out["paced"][0].download(f), out["two-wait"][0].download(f)), f
+
+
+@pytest.mark.parametrize("paced", ["1", "0"])
+def test_default_policy_waits_once_per_step_when_the_iteration_count_repeats(product_lib, monkeypatch, paced):
     monkeypatch.delenv("SPH_CHAIN", raising=False)
+    monkeypatch.setenv("SPH_PACED", paced)
     scn = sc.dam_break_small(128, 96, 1 / 64)
     pos, mass, vel = sc.init_particles(scn)
     P = dam_break_params(hybrid_dfsph_max_avg_density_error=0.0, hybrid_dfsph_max_avg_divergence_error=0.0, max_iters=3)   # the divergence solve's count pinned
@@ -56,7 +81,7 @@ def test_default_policy_chains_once_the_iteration_count_repeats(product_lib, mon
     for _ in range(10):
         st = g.step(p)
         assert st.div_solver.iters == 3
-    assert g.dist_get_stats()["host_waits"] == 10      # one wait per step: header from the previous step's tail, solves chained
+    assert g.dist_get_stats()["host_waits"] == 10      # one wait per step: header from the previous step's tail, solves paced (or chained)
 
 
 def test_chained_solves_on_slabs_are_bit_identical_to_the_two_wait_form(product_lib, monkeypatch):
