@@ -66,7 +66,7 @@ struct sph_ctx {
     int pcur = 0;  // which pm buffer is live; the other one holds the sorted PRE-step positions after a step
     DevBuf vel_tmp;
     // per-step
-    DevBuf key[2], val[2], sort_scratch, cxy, cell_start, cs_scratch, nl, nl_ok, mrho, pt0, pt1;
+    DevBuf key[2], val[2], sort_scratch, cxy, cell_start, cs_scratch, nl, nl_ok, mrho, pt0, pt1, prec0, prec1;
     bool uniform_h = false;
     float h_uniform = 0.f;
     DevBuf rho, lam_sum, lam_grad, constf, aii, src, p0, p1, pacc, dens_err, stat, ncount;

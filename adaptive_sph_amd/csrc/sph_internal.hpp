@@ -160,6 +160,8 @@ struct SweepArgs {
     float* mrho;        // m / rho
     float* pt0;         // p / rho^2 for pressure buffer 0 / 1
     float* pt1;
+    float4* rec0 = nullptr;   // {x, y, p / rho^2, p} for pressure buffer 0 / 1: written INSTEAD of pt0 / pt1 by the solves of uniform-h scenes
+    float4* rec1 = nullptr;   // on one context (OpPressureAccelU gathers one record per neighbour); nullptr: slabs, IISPH2
     // boundary
     const BoundaryP* planes;
     const float* lam_lut;

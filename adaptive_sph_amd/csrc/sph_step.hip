@@ -74,6 +74,10 @@ SweepArgs make_args(sph_ctx* c, const StepP& sp)
     a.mrho = c->mrho.as<float>();
     a.pt0 = c->pt0.as<float>();
     a.pt1 = c->pt1.as<float>();
+    if (!c->dist.on) {   // (slab decompositions exchange p / rho^2 as a field of its own)
+        a.rec0 = c->prec0.as<float4>();
+        a.rec1 = c->prec1.as<float4>();
+    }
     a.uniform_h = c->uniform_h ? 1 : 0;
     a.h_uniform = c->h_uniform;
     a.planes = c->planes_d.as<BoundaryP>();
@@ -913,6 +917,7 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
         }
         if (tev) (void)hipEventRecord(c->ev[1], s);
         m.a = make_args(c, sp);
+        if (p->pressure_solver_method == SPH_SOLVER_IISPH2) m.a.rec0 = m.a.rec1 = nullptr;   // (its rescaling works on p and p / rho^2)
         m.a.h_mode = p->support_length_estimation;
         m.a.sp_check_aii = p->check_aii;
         m.st.n_particles = c->n;

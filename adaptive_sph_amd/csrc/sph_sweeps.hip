@@ -88,6 +88,16 @@ __device__ __forceinline__ void raise_error(DeviceStatus* st, uint32_t code, uin
     if (atomicCAS(&st->error, 0u, code) == 0u) st->info = info;
 }
 
+// a solve's new pressure of particle i: p, and p / rho^2 for the neighbours' sweep A -- as a field of its own, or (uniform-h scenes
+// on one context, OpPressureAccelU) inside the 16-byte record {x, y, p / rho^2, p} that sweep gathers whole
+__device__ __forceinline__ void store_pressure(float* __restrict__ p_out, float* __restrict__ pterm_out, float4* __restrict__ rec_out, uint32_t i,
+                                               const float4& Ai, float p, float pt)
+{
+    p_out[i] = p;
+    if (rec_out) rec_out[i] = make_float4(Ai.x, Ai.y, pt, p);
+    else pterm_out[i] = pt;
+}
+
 // ------------------------------------------------------------------------------------------------
 // generic sweep.  BUILD = true: candidate walk + list recording (density sweep).
 //
@@ -1053,6 +1063,7 @@ struct OpSource {
     float* __restrict__ src;
     float* __restrict__ p_out;       // pressure after iteration 0 (buffer 1)
     float* __restrict__ pterm_out;
+    float4* __restrict__ rec_out;    // see store_pressure (else nullptr)
     float* __restrict__ dens_err;
     SolverPartial* __restrict__ partials;
     SolverCtrl* __restrict__ ctrl_reset;   // the solve's control block starts from zero (first kernel of a solve)
@@ -1126,7 +1137,7 @@ struct OpSource {
             a.sum = fmaf(c * m.gscale(r2, hij), e, a.sum);
         }
     }
-    __device__ bool finish(Acc& a, uint32_t i, float4, bool wall) const
+    __device__ bool finish(Acc& a, uint32_t i, float4 Ai, bool wall) const
     {
         const float rho_i = a.rho_i, rho_b = sp.rest_density, dt = sp.dt;
         float s;
@@ -1154,8 +1165,7 @@ struct OpSource {
         const float aii_i = aii[i];
         if (aii_i < 0.f) raise_error(status, SPH_ERR_AII_NEGATIVE, orig[i]);  // simulation.rs:1390-1403
         if (fabsf(aii_i) < 10e-4f) {
-            p_out[i] = 0.f;
-            pterm_out[i] = 0.f;
+            store_pressure(p_out, pterm_out, rec_out, i, Ai, 0.f, 0.f);
             a.cls = 1u;
             return wall;
         }
@@ -1170,12 +1180,10 @@ struct OpSource {
             err = dt * (s - a_p);
         }
         if (pn <= 0.f) {
-            p_out[i] = 0.f;
-            pterm_out[i] = 0.f;
+            store_pressure(p_out, pterm_out, rec_out, i, Ai, 0.f, 0.f);
             a.cls = 2u;
         } else {
-            p_out[i] = pn;
-            pterm_out[i] = pn / (rho_i * rho_i);
+            store_pressure(p_out, pterm_out, rec_out, i, Ai, pn, pn / (rho_i * rho_i));
             a.cls = 0u;
             a.err = err;
         }
@@ -1410,6 +1418,53 @@ struct OpPressureAccel {
     }
 };
 
+// Sweep A for uniform-h scenes with mass-derived smoothing lengths on one context -- the headline again -- on ONE gathered record per
+// neighbour: {x_j, y_j, p_j / rho_j^2, p_j}, as OpSource / OpJacobiU leave it (store_pressure), instead of the particle record (16
+// bytes) plus the 4-byte p / rho^2.  Same reasoning and the same measurement as OpJacobiU (profiles/r3_jacobi_lab.md: 23.6 -> 20.3
+// us stand-alone on the rest lattice, 31.3 -> 26.6 jittered; sweep B pays 1-2 us for storing 12 more bytes).  The record holds no
+// mass: m_j becomes the mass of particle 0 (one scalar load) -- equal, or a neighbouring float, on every particle of such a scene
+// (see OpJacobiU).  The particle's own record brings its own p / rho^2 and p along.  Decision, prologue and output are the base's.
+template <class MathT>
+struct OpPressureAccelU : OpPressureAccel<MathT> {
+    static_assert(MathT::UNIFORM, "OpPressureAccelU: uniform-h scenes");
+    typedef OpPressureAccel<MathT> B;
+    static constexpr bool TILE = false, RING1 = false;
+    typedef NBNone NB;
+    const float4* __restrict__ rec;   // of the pressure buffer this iteration reads
+    struct Acc {
+        float ax, ay, p1t, mass;
+    };
+    __device__ float4 loadA(uint32_t j) const { return rec[j]; }
+    __device__ NB nb(const Acc&, uint32_t, float4) const { return NB{}; }
+    __device__ void init(Acc& a) const { a.mass = this->pm[0].z; }
+    __device__ void begin(Acc& a, uint32_t, float4 Ai) const
+    {
+        a.ax = a.ay = 0.f;
+        a.p1t = Ai.z;
+    }
+    __device__ void pair(Acc& a, float4 Aj, NB, float dx, float dy, float r2, float hij) const
+    {
+        const float fs = (-a.mass * (a.p1t + Aj.z)) * this->m.gscale(r2, hij);
+        a.ax = fmaf(fs, dx, a.ax);
+        a.ay = fmaf(fs, dy, a.ay);
+    }
+    __device__ bool finish(Acc& a, uint32_t i, float4 Ai, bool wall) const
+    {
+        float bx = 0.f, by = 0.f;
+        if (this->sp.n_planes && wall) {
+            const float rho_b = this->sp.rest_density;
+            const float p_ib = this->sp.opdisc == SPH_OP_SYMMETRIC_GRADIENT ? Ai.w : 0.f;
+            const float f = -rho_b * (Ai.z + p_ib / (rho_b * rho_b));
+            const float2 gl = this->lam_grad[i];
+            bx = f * gl.x;
+            by = f * gl.y;
+        }
+        this->pacc[i] = make_float4(Ai.x, Ai.y, a.ax + bx, a.ay + by);
+        return wall;
+    }
+    __device__ void epilogue(Acc&, bool, uint32_t) const {}
+};
+
 // The solve's tail: the integrate map of the solver mode (TAIL_*) on the owned particles, run once the stop decision is taken.
 // The integrating tails know the positions and velocities the NEXT step starts from: they also reduce that step's header
 // (bounding box, h range, CFL term -- what k_header computes) per block, so the next step starts without the header kernels
@@ -1523,6 +1578,7 @@ struct OpJacobi {
     const float* __restrict__ p_in;
     float* __restrict__ p_out;
     float* __restrict__ pterm_out;
+    float4* __restrict__ rec_out;   // see store_pressure (OpJacobiU on one context, else nullptr)
     float* __restrict__ dens_err;
     SolverPartial* __restrict__ partials;
     SolverCtrl* ctrl;
@@ -1586,12 +1642,11 @@ struct OpJacobi {
             a.sum = fmaf(c * m.gscale(r2, hij), e, a.sum);
         }
     }
-    __device__ bool finish(Acc& a, uint32_t i, float4, bool wall) const
+    __device__ bool finish(Acc& a, uint32_t i, float4 Ai, bool wall) const
     {
         const float aii_i = a.aii_i;
         if (fabsf(aii_i) < 10e-4f) {
-            p_out[i] = 0.f;
-            pterm_out[i] = 0.f;
+            store_pressure(p_out, pterm_out, rec_out, i, Ai, 0.f, 0.f);
             a.cls = 1u;
             return wall;
         }
@@ -1615,12 +1670,10 @@ struct OpJacobi {
             err = dt * (s - a_p);
         }
         if (pn <= 0.f) {  // clamp_negative_pressures is true at every call site
-            p_out[i] = 0.f;
-            pterm_out[i] = 0.f;
+            store_pressure(p_out, pterm_out, rec_out, i, Ai, 0.f, 0.f);
             a.cls = 2u;
         } else {
-            p_out[i] = pn;
-            pterm_out[i] = pn / (rho_i * rho_i);  // p_j / (rho_j * rho_j) of calculate_fluid_fluid_pressure_accel
+            store_pressure(p_out, pterm_out, rec_out, i, Ai, pn, pn / (rho_i * rho_i));   // p_j / (rho_j * rho_j) of calculate_fluid_fluid_pressure_accel
             a.cls = 0u;
             a.err = err;
         }
@@ -2464,6 +2517,16 @@ static bool jacobi_generic()
     static const bool v = getenv("SPH_JACOBI_GENERIC") != nullptr;
     return v;
 }
+// SPH_ACCEL_GENERIC (read per launch: the tests compare both forms in one process): sweep A of such scenes through OpPressureAccel,
+// the solves' p / rho^2 as a field of its own
+static bool jacobi_on_records(const SweepArgs& a)   // sweep B gathers {x, y, a^p} whole (OpJacobiU)
+{
+    return !a.exact && a.uniform_h && a.h_mode == SPH_H_FROM_MASS && a.sp.opdisc != SPH_OP_WINCHENBACH2020 && !jacobi_generic();
+}
+static bool solve_on_records(const SweepArgs& a)    // ... and sweep A {x, y, p / rho^2, p} (OpPressureAccelU): one context, not IISPH2
+{
+    return jacobi_on_records(a) && a.rec0 != nullptr && a.owned == nullptr && a.part == 0 && getenv("SPH_ACCEL_GENERIC") == nullptr;
+}
 extern "C" int sph_set_sweep_variant(int mode)
 {
     if (mode < 0 || mode > 3) return SPH_ERR_INVALID_ARGUMENT;
@@ -2617,12 +2680,13 @@ using OpSourceOmega = OpSource<M, true>;
 void launch_source_term(hipStream_t s, Profiler* prof, const SweepArgs& a, int kind, int residual_density)
 {
     ProfScope ps(prof, "source_term", s);
+    float4* rec1 = solve_on_records(a) ? a.rec1 : nullptr;
     if (kind == 3) {
-        SPH_DISPATCH(OpSourceOmega, false, a.pm, a.orig, a.rho, a.mrho, a.vel, a.lam_grad, a.aii, a.src, a.p1, a.pt1, a.dens_err,
+        SPH_DISPATCH(OpSourceOmega, false, a.pm, a.orig, a.rho, a.mrho, a.vel, a.lam_grad, a.aii, a.src, a.p1, a.pt1, rec1, a.dens_err,
                      (SolverPartial*)a.partials, a.ctrl, a.status, a.sp, kind, residual_density, a.omega, a.size_class, a.gate)
         return;
     }
-    SPH_DISPATCH(OpSourcePlain, false, a.pm, a.orig, a.rho, a.mrho, a.vel, a.lam_grad, a.aii, a.src, a.p1, a.pt1, a.dens_err,
+    SPH_DISPATCH(OpSourcePlain, false, a.pm, a.orig, a.rho, a.mrho, a.vel, a.lam_grad, a.aii, a.src, a.p1, a.pt1, rec1, a.dens_err,
                  (SolverPartial*)a.partials, a.ctrl, a.status, a.sp, kind, residual_density, nullptr, nullptr, a.gate)
 }
 
@@ -2633,6 +2697,13 @@ void launch_pressure_accel(hipStream_t s, Profiler* prof, const SweepArgs& a0, i
     SweepArgs a = a0;
     a.part = part;
     const SolveP q{residual_density, max_avg_error, max_iters, part ? 2 : multi, a.prog_host, a.prog_epoch};
+    if (solve_on_records(a) && iter >= 1) {   // (iter < 0: IISPH2's extra sweep -- never on records)
+        OpPressureAccelU<MathUniform> op{{uniform_math(a.h_uniform), a.pm, a.orig, a.rho, a.p0, a.p1, a.pt0, a.pt1, a.lam_grad, a.pacc, a.ctrl,
+                                          (const SolverPartial*)a.partials, solver_reduce_blocks(a.n), a.solver_tot, a.status, a.sp, q, iter, a.owned, a.gate},
+                                         (iter & 1) ? a.rec1 : a.rec0};
+        launch_sweep<OpPressureAccelU<MathUniform>, false>(s, a, op);
+        return;
+    }
     SPH_DISPATCH(OpPressureAccel, false, a.pm, a.orig, a.rho, a.p0, a.p1, a.pt0, a.pt1, a.lam_grad, a.pacc, a.ctrl, (const SolverPartial*)a.partials,
                  solver_reduce_blocks(a.n), a.solver_tot, a.status, a.sp, q, iter, a.owned, a.gate)
 }
@@ -2688,13 +2759,14 @@ void launch_jacobi_update(hipStream_t s, Profiler* prof, const SweepArgs& a, int
     float* pout = (iter & 1) ? a.p0 : a.p1;
     float* ptout = (iter & 1) ? a.pt0 : a.pt1;
     const SolveP q{residual_density, max_avg_error, max_iters, multi};
-    if (!a.exact && a.uniform_h && a.h_mode == SPH_H_FROM_MASS && a.sp.opdisc != SPH_OP_WINCHENBACH2020 && !jacobi_generic()) {
-        OpJacobiU<MathUniform> op{{uniform_math(a.h_uniform), a.pm, a.orig, a.rho, a.mrho, a.pacc, a.lam_grad, a.aii, a.src, pin, pout, ptout, a.dens_err,
+    if (jacobi_on_records(a)) {
+        float4* recout = solve_on_records(a) ? ((iter & 1) ? a.rec0 : a.rec1) : nullptr;
+        OpJacobiU<MathUniform> op{{uniform_math(a.h_uniform), a.pm, a.orig, a.rho, a.mrho, a.pacc, a.lam_grad, a.aii, a.src, pin, pout, ptout, recout, a.dens_err,
                                    (SolverPartial*)a.partials, a.ctrl, a.status, a.sp, iter, residual_density, q, a.solver_tot, a.gate}};
         launch_sweep<OpJacobiU<MathUniform>, false>(s, a, op);
         return;
     }
-    SPH_DISPATCH(OpJacobi, false, a.pm, a.orig, a.rho, a.mrho, a.pacc, a.lam_grad, a.aii, a.src, pin, pout, ptout, a.dens_err, (SolverPartial*)a.partials, a.ctrl,
+    SPH_DISPATCH(OpJacobi, false, a.pm, a.orig, a.rho, a.mrho, a.pacc, a.lam_grad, a.aii, a.src, pin, pout, ptout, (float4*)nullptr, a.dens_err, (SolverPartial*)a.partials, a.ctrl,
                  a.status, a.sp, iter, residual_density, q, a.solver_tot, a.gate)
 }
 

@@ -49,6 +49,10 @@ struct Args {
     float* __restrict__ p_out;
     float* __restrict__ pt_out;
     float omega, mass;
+    // sweep A (pressure acceleration): p / rho^2 per particle, the same inside a combined record {x, y, p / rho^2, p}, the output
+    const float* __restrict__ pt;
+    const float4* __restrict__ rec;
+    float4* __restrict__ pacc_out;
 };
 
 __device__ __forceinline__ void grad_uniform(const Math& m, float dx, float dy, float r2, float& gx, float& gy)
@@ -704,6 +708,120 @@ __global__ __launch_bounds__(256) void k_math_only_slim(Args A)
     finish(A, a, i, rho_i);
 }
 
+// ---- sweep A (OpPressureAccel, uniform h): a^p_i = - sum_j m (p_i / rho_i^2 + p_j / rho_j^2) grad W_ij, written as {x, y, a^p} ----
+// COMB = 0: the product's form -- the neighbour's 16-B record {x, y, m, h} and its 4-B p / rho^2, two gathers per neighbour slot;
+// COMB = 1: ONE 16-B gather of a combined record {x, y, p / rho^2, p} (what sweep B would have to store instead of p / rho^2 alone)
+template <int COMB>
+__global__ __launch_bounds__(256) void k_accel(Args A)
+{
+    const uint32_t blk = remap_block(A.nblocks);
+    if (blk >= A.nblocks) return;
+    const uint32_t i = blk * 256 + threadIdx.x;
+    if (i >= A.n) return;
+    const float4 Ai = COMB ? A.rec[i] : A.pm[i];
+    const uint4 lw = A.nl[i];
+    const float pti = COMB ? Ai.z : A.pt[i];
+    uint32_t rb[3];
+    int cx, cy;
+    row_bases(A, Ai.x, Ai.y, rb, cx, cy);
+    const float nf6 = 6.f * A.m.nf * A.m.inv2h;
+    float ax = 0.f, ay = 0.f;
+    const uint32_t masks[3] = {lw.x, lw.y, lw.z};
+#pragma unroll
+    for (int dr = 0; dr < 3; dr++) {
+        uint32_t mk = masks[dr];
+        const uint32_t base = rb[dr];
+        while (mk) {
+            uint32_t b[4];
+            bool v[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                v[k] = mk != 0u;
+                b[k] = v[k] ? (uint32_t)__ffs(mk) - 1u : b[0];
+                mk &= mk - 1u;
+            }
+            float4 R[4];
+            float T[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t j = ix(base + b[k], A.n, 20u);
+                if (COMB) {
+                    R[k] = A.rec[j];
+                    T[k] = R[k].z;
+                } else {
+                    R[k] = A.pm[j];
+                    T[k] = A.pt[j];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const float dx = Ai.x - R[k].x, dy = Ai.y - R[k].y;
+                const float r2 = fmaxf(dx * dx + dy * dy, 1.0e-30f);
+                if (v[k]) {
+                    const float rinv = __builtin_amdgcn_rsqf(r2);
+                    const float q = (r2 * rinv) * A.m.inv2h;
+                    const float u = fmaxf(1.f - q, 0.f), t = fmaxf(0.5f - q, 0.f);
+                    const float d = fmaf(4.f * t, t, -(u * u));
+                    const float fs = (-A.mass * (pti + T[k])) * (nf6 * d * rinv);
+                    ax = fmaf(fs, dx, ax);
+                    ay = fmaf(fs, dy, ay);
+                }
+            }
+        }
+    }
+    A.pacc_out[i] = make_float4(Ai.x, Ai.y, ax, ay);
+}
+
+// sweep B's stores with the combined record: p (4 B) and {x, y, p / rho^2, p} (16 B) instead of p and p / rho^2 (4 B + 4 B):
+// variant `gather4_slim<1>` with that store, to price the 12 extra bytes per particle
+__global__ __launch_bounds__(256) void k_gather4_slim_recstore(Args A)
+{
+    const uint32_t blk = remap_block(A.nblocks);
+    if (blk >= A.nblocks) return;
+    const uint32_t i = blk * 256 + threadIdx.x;
+    if (i >= A.n) return;
+    const float4 Ai = A.comb[i];
+    const uint4 lw = A.nl[i];
+    const float rho_i = A.rho[i];
+    const float aii_i = A.aii[i], src_i = A.src[i], pin_i = A.p_in[i];
+    uint32_t rb[3];
+    int cx, cy;
+    row_bases(A, Ai.x, Ai.y, rb, cx, cy);
+    Acc a;
+    a.sum = 0.f;
+    a.inv_rho = __builtin_amdgcn_rcpf(rho_i);
+    a.qx = Ai.z;
+    a.qy = Ai.w;
+    const float nf6 = 6.f * A.m.nf * A.m.inv2h;
+    const uint32_t masks[3] = {lw.x, lw.y, lw.z};
+#pragma unroll
+    for (int dr = 0; dr < 3; dr++) {
+        uint32_t mk = masks[dr];
+        const uint32_t base = rb[dr];
+        while (mk) {
+            uint32_t b[4];
+            bool v[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                v[k] = mk != 0u;
+                b[k] = v[k] ? (uint32_t)__ffs(mk) - 1u : b[0];
+                mk &= mk - 1u;
+            }
+            float4 R[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) R[k] = A.comb[ix(base + b[k], A.n, 21u)];
+#pragma unroll
+            for (int k = 0; k < 4; k++) pair_slim(A, a, Ai.x, Ai.y, R[k].x, R[k].y, R[k].z, R[k].w, v[k], nf6);
+        }
+    }
+    a.sum *= A.mass * a.inv_rho;
+    const float pn = pin_i + A.omega * (src_i - a.sum) / aii_i;
+    const bool pos = pn > 0.f;
+    const float po = pos ? pn : 0.f;
+    A.p_out[i] = po;
+    const_cast<float4*>(A.rec)[i] = make_float4(Ai.x, Ai.y, pos ? pn / (rho_i * rho_i) : 0.f, po);
+}
+
 int main(int argc, char** argv)
 {
     const int side = argc > 1 ? atoi(argv[1]) : 1024;
@@ -816,6 +934,19 @@ int main(int argc, char** argv)
         A.p_out = (float*)po;
         A.pt_out = (float*)pt;
     }
+    {
+        std::vector<float> pt(n);
+        std::vector<float4> rec(n);
+        for (uint32_t s = 0; s < n; s++) {
+            pt[s] = pin[s] / (rho[s] * rho[s]);
+            rec[s] = make_float4(pm[s].x, pm[s].y, pt[s], pin[s]);
+        }
+        A.pt = (const float*)up(pt.data(), (size_t)n * 4);
+        A.rec = (const float4*)up(rec.data(), (size_t)n * 16);
+        void* po;
+        CHECK(hipMalloc(&po, (size_t)n * 16));
+        A.pacc_out = (float4*)po;
+    }
     const uint32_t grid = ((A.nblocks + 7) / 8) * 8;
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0));
@@ -877,6 +1008,44 @@ int main(int argc, char** argv)
         if (v.check) printf("| %s | %.2f | %.2e |\n", v.name, ms * 1e3 / reps, mx > 0 ? err / mx : 0.0);
         else printf("| %s | %.2f | - |\n", v.name, ms * 1e3 / reps);
         fflush(stdout);
+    }
+    // ---- sweep A ----
+    {
+        struct VA { const char* name; void (*k)(Args); };
+        const VA va[] = {
+            {"sweep A, product form: 16-B record {x, y, m, h} + 4-B p / rho^2, two gathers per slot", k_accel<0>},
+            {"sweep A, ONE 16-B gather of a combined record {x, y, p / rho^2, p}", k_accel<1>},
+            {"sweep B (slim, own loads first) storing p and the 16-B combined record instead of p and p / rho^2", k_gather4_slim_recstore},
+        };
+        printf("| sweep A variant | us per launch | max rel diff of a^p vs the first |\n|---|---|---|\n");
+        std::vector<float4> ref_a(n), out_a(n);
+        bool have = false;
+        for (auto& v : va) {
+            CHECK(hipMemset(A.pacc_out, 0, (size_t)n * 16));
+            hipLaunchKernelGGL(v.k, dim3(grid), dim3(256), 0, 0, A);
+            CHECK(hipDeviceSynchronize());
+            CHECK(hipMemcpy(out_a.data(), A.pacc_out, (size_t)n * 16, hipMemcpyDeviceToHost));
+            double err = 0, mx = 0;
+            if (!have) {
+                ref_a = out_a;
+                have = true;
+            }
+            const bool is_a = v.k != k_gather4_slim_recstore;
+            if (is_a)
+                for (uint32_t s2 = 0; s2 < n; s2++) {
+                    err = std::max(err, (double)std::max(fabsf(out_a[s2].z - ref_a[s2].z), fabsf(out_a[s2].w - ref_a[s2].w)));
+                    mx = std::max(mx, (double)std::max(fabsf(ref_a[s2].z), fabsf(ref_a[s2].w)));
+                }
+            CHECK(hipEventRecord(e0, 0));
+            for (int r = 0; r < reps; r++) hipLaunchKernelGGL(v.k, dim3(grid), dim3(256), 0, 0, A);
+            CHECK(hipEventRecord(e1, 0));
+            CHECK(hipDeviceSynchronize());
+            float ms = 0;
+            CHECK(hipEventElapsedTime(&ms, e0, e1));
+            if (is_a) printf("| %s | %.2f | %.2e |\n", v.name, ms * 1e3 / reps, mx > 0 ? err / mx : 0.0);
+            else printf("| %s | %.2f | - |\n", v.name, ms * 1e3 / reps);
+            fflush(stdout);
+        }
     }
     return 0;
 }

@@ -65,6 +65,24 @@ def test_paced_single_solve_modes_match_the_predicted_queue(product_lib, monkeyp
         assert np.array_equal(out["paced"][0].download(f), out["two-wait"][0].download(f)), f
 
 
+@pytest.mark.parametrize("solver", ["HybridDFSPH", "IISPH", "OnlyDivergence"])
+def test_sweep_a_on_combined_records_is_bit_identical_to_the_generic_sweep(product_lib, monkeypatch, solver):
+    """Uniform-h scenes on one context: the solves store {x, y, p / rho^2, p} records and sweep A gathers one record per neighbour
+    (OpPressureAccelU); SPH_ACCEL_GENERIC=1 keeps p / rho^2 as a field and gathers the particle record beside it.  Equal masses:
+    the same arithmetic on the same values, so every field and every iteration count agree bit for bit."""
+    def go(generic):
+        if generic:
+            monkeypatch.setenv("SPH_ACCEL_GENERIC", "1")
+        out = run(product_lib, monkeypatch, "paced", 25, pressure_solver_method=solver)
+        if generic:
+            monkeypatch.delenv("SPH_ACCEL_GENERIC")
+        return out
+    (a, ia, _), (b, ib, _) = go(False), go(True)
+    assert ia == ib
+    for f in ("position", "velocity", "density", "pressure", "aii", "ppe_source_term"):
+        assert np.array_equal(a.download(f), b.download(f)), f
+
+
 @pytest.mark.parametrize("paced", ["1", "0"])
 def test_default_policy_waits_once_per_step_when_the_iteration_count_repeats(product_lib, monkeypatch, paced):
     monkeypatch.delenv("SPH_CHAIN", raising=False)
