@@ -47,7 +47,7 @@ ALGO_BYTES = {
 
 # rocprofv3 kernel names of the sweeps (profiles/*_kernel_summary.json keys)
 PMC_NAMES = {"density": "OpDensity[build]", "aii_constfield": "OpAiiConst", "non_pressure_accel": "OpNonPressure",
-             "source_term": "OpSource", "pressure_accel": "OpPressureAccel", "jacobi_update": "OpJacobiU"}
+             "source_term": "OpSource", "pressure_accel": "OpPressureAccelU", "jacobi_update": "OpJacobiU"}
 
 
 def committed_pmc_traffic(kernel):
