@@ -35,6 +35,7 @@ struct BArgs {
     float h, nf, inv2h, s2, mass;
     const uint32_t* __restrict__ cell_start;
     const float4* __restrict__ pm;   // x, y, m, h
+    const float2* __restrict__ xy;   // x, y only (uniform scenes need nothing else of a candidate): two candidates per 16-byte load
     uint4* __restrict__ nl_a;        // masks 0..2 (R = 1) or 0..3 (R = 2) [+ count for R = 1]
     uint2* __restrict__ nl_b;        // R = 2: mask 4, count
     float* __restrict__ rho;
@@ -44,9 +45,9 @@ struct BArgs {
 // cubic spline in truncated-power form: W(q) = nf [2 (1 - q)+^3 - 8 (1/2 - q)+^3], q = r / (2 h)
 __device__ __forceinline__ float w_spline(const BArgs& A, float r2)
 {
-    const float q = sqrtf(r2) * A.inv2h;
+    const float q = __builtin_amdgcn_sqrtf(r2) * A.inv2h;   // (v_sqrt_f32, as MathUniform::w of the library)
     const float u = fmaxf(1.f - q, 0.f), t = fmaxf(0.5f - q, 0.f);
-    return A.nf * (2.f * u * u * u - 8.f * t * t * t);
+    return 2.f * A.nf * fmaf(-4.f * t, t * t, u * (u * u));
 }
 
 template <int R, int TRIP>
@@ -99,6 +100,155 @@ __global__ __launch_bounds__(256) void k_build(BArgs A)
         A.nl_a[i] = make_uint4(mk[0], mk[1], mk[2], mk[ROWS > 3 ? 3 : 0]);
         A.nl_b[i] = make_uint2(mk[ROWS > 4 ? 4 : 0], cnt);
     }
+    A.rho[i] = rho;
+}
+
+// ---- branch-free forms (R = 1 only).  Every candidate slot of a trip is evaluated by every lane: the truncated-power spline is
+// zero beyond the support by itself, the predicate (the reference's operations, strict <) only selects the mask bit and zeroes W for
+// a rejected candidate (so that the sum sees exactly the accepted terms); slots behind the row's end are masked by a validity mask
+// computed once per row.  PAIRED: the candidates come from the float2 array, two per 16-byte load (rows are contiguous index ranges).
+template <int PAIRED>
+__global__ __launch_bounds__(256) void k_build_flat(BArgs A)
+{
+    const uint32_t per_xcd = (A.nblocks + 7) >> 3;
+    const uint32_t blk = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    if (blk >= A.nblocks) return;
+    const uint32_t i = blk * 256 + threadIdx.x;
+    if (i >= A.n) return;
+    const float4 Ai = A.pm[i];
+    const int cx = (int)floorf(Ai.x / A.g.cs) - A.g.minx, cy = (int)floorf(Ai.y / A.g.cs) - A.g.miny;
+    uint32_t rb[3], re[3], mk[3];
+#pragma unroll
+    for (int dr = 0; dr < 3; dr++) {
+        const int yy = cy + dr - 1;
+        const bool ok = yy >= 0 && yy < A.g.sy;
+        const uint32_t base = (uint32_t)(ok ? yy : 0) * (uint32_t)A.g.sx;
+        rb[dr] = ok ? A.cell_start[base + (uint32_t)max(cx - 1, 0)] : 0u;
+        re[dr] = ok ? A.cell_start[base + (uint32_t)min(cx + 2, A.g.sx)] : 0u;
+    }
+    float rho = 0.f;
+#pragma unroll
+    for (int dr = 0; dr < 3; dr++) {
+        const uint32_t b = rb[dr], e = re[dr];
+        const uint32_t len = e - b;
+        if (len > 32u) atomicAdd(A.over, 1u);
+        uint32_t m = 0;
+        constexpr uint32_t PER = PAIRED ? 8u : 4u;
+        for (uint32_t k0 = 0; __any(k0 < len); k0 += PER) {   // (wave-uniform trip count)
+            float cxs[PER], cys[PER];
+            if (PAIRED) {
+#pragma unroll
+                for (uint32_t g = 0; g < 4; g++) {
+                    float4 v;
+                    __builtin_memcpy(&v, A.xy + b + k0 + 2 * g, 16);
+                    cxs[2 * g] = v.x; cys[2 * g] = v.y; cxs[2 * g + 1] = v.z; cys[2 * g + 1] = v.w;
+                }
+            } else {
+#pragma unroll
+                for (uint32_t g = 0; g < 4; g++) {
+                    const float4 v = A.pm[b + k0 + g];
+                    cxs[g] = v.x; cys[g] = v.y;
+                }
+            }
+#pragma unroll
+            for (uint32_t g = 0; g < PER; g++) {
+                const float dx = Ai.x - cxs[g], dy = Ai.y - cys[g];
+                const float r2 = dx * dx + dy * dy;
+                const bool in = r2 < A.s2;
+                const float w = w_spline(A, r2);
+                const bool take = in && (k0 + g < len);
+                rho += A.mass * (take ? w : 0.f);
+                m |= (take ? 1u : 0u) << ((k0 + g) & 31u);
+            }
+        }
+        mk[dr] = m;
+    }
+    A.nl_a[i] = make_uint4(mk[0], mk[1], mk[2], (uint32_t)(__popc(mk[0]) + __popc(mk[1]) + __popc(mk[2])));
+    A.rho[i] = rho;
+}
+
+// ---- two phases: (1) the predicate alone over the candidate rows, branch-free, two candidates per 16-byte load of the float2
+// array, into the three row masks; (2) the density sum over the accepted bits only, by the mask replay every later sweep uses
+// (trips of 4 set bits per row, float2 gathers).  Same visiting order as the walk: the sums are bit-identical. ----
+template <int PAIRED>
+__global__ __launch_bounds__(256) void k_build_2phase(BArgs A)
+{
+    const uint32_t per_xcd = (A.nblocks + 7) >> 3;
+    const uint32_t blk = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    if (blk >= A.nblocks) return;
+    const uint32_t i = blk * 256 + threadIdx.x;
+    if (i >= A.n) return;
+    const float2 Ai = A.xy[i];
+    const int cx = (int)floorf(Ai.x / A.g.cs) - A.g.minx, cy = (int)floorf(Ai.y / A.g.cs) - A.g.miny;
+    uint32_t rb[3], re[3], mk[3];
+#pragma unroll
+    for (int dr = 0; dr < 3; dr++) {
+        const int yy = cy + dr - 1;
+        const bool ok = yy >= 0 && yy < A.g.sy;
+        const uint32_t base = (uint32_t)(ok ? yy : 0) * (uint32_t)A.g.sx;
+        rb[dr] = ok ? A.cell_start[base + (uint32_t)max(cx - 1, 0)] : 0u;
+        re[dr] = ok ? A.cell_start[base + (uint32_t)min(cx + 2, A.g.sx)] : 0u;
+    }
+#pragma unroll
+    for (int dr = 0; dr < 3; dr++) {
+        const uint32_t b = rb[dr];
+        const uint32_t len = re[dr] - b;
+        if (len > 32u) atomicAdd(A.over, 1u);
+        uint32_t m = 0;
+        constexpr uint32_t PER = PAIRED ? 8u : 4u;
+        for (uint32_t k0 = 0; __any(k0 < len); k0 += PER) {
+            float cxs[PER], cys[PER];
+            if (PAIRED) {
+#pragma unroll
+                for (uint32_t g = 0; g < 4; g++) {
+                    float4 v;
+                    __builtin_memcpy(&v, A.xy + b + k0 + 2 * g, 16);
+                    cxs[2 * g] = v.x; cys[2 * g] = v.y; cxs[2 * g + 1] = v.z; cys[2 * g + 1] = v.w;
+                }
+            } else {
+#pragma unroll
+                for (uint32_t g = 0; g < 4; g++) {
+                    const float2 v = A.xy[b + k0 + g];
+                    cxs[g] = v.x; cys[g] = v.y;
+                }
+            }
+            uint32_t bits = 0;
+#pragma unroll
+            for (uint32_t g = 0; g < PER; g++) {
+                const float dx = Ai.x - cxs[g], dy = Ai.y - cys[g];
+                const float r2 = dx * dx + dy * dy;
+                bits |= (r2 < A.s2 ? 1u : 0u) << g;
+            }
+            m |= bits << (k0 & 31u);
+        }
+        mk[dr] = m & (len >= 32u ? 0xffffffffu : ((1u << len) - 1u));
+    }
+    float rho = 0.f;
+#pragma unroll
+    for (int dr = 0; dr < 3; dr++) {
+        uint32_t m = mk[dr];
+        const uint32_t b = rb[dr];
+        while (m) {
+            uint32_t bb[4];
+            bool v[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                v[k] = m != 0u;
+                bb[k] = v[k] ? (uint32_t)__ffs(m) - 1u : bb[0];
+                m &= m - 1u;
+            }
+            float2 R[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) R[k] = A.xy[b + bb[k]];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const float dx = Ai.x - R[k].x, dy = Ai.y - R[k].y;
+                const float r2 = dx * dx + dy * dy;
+                if (v[k]) rho += A.mass * w_spline(A, r2);
+            }
+        }
+    }
+    A.nl_a[i] = make_uint4(mk[0], mk[1], mk[2], (uint32_t)(__popc(mk[0]) + __popc(mk[1]) + __popc(mk[2])));
     A.rho[i] = rho;
 }
 
@@ -196,8 +346,13 @@ int main(int argc, char** argv)
         A.mass = mass;
         uint32_t* cs_d = dev_alloc<uint32_t>(S.cell_start.size());
         CHECK(hipMemcpy(cs_d, S.cell_start.data(), S.cell_start.size() * 4, hipMemcpyHostToDevice));
-        float4* pm_d = dev_alloc<float4>(n + 8);
+        float4* pm_d = dev_alloc<float4>(n + 16);
         CHECK(hipMemcpy(pm_d, S.pm.data(), (size_t)n * 16, hipMemcpyHostToDevice));
+        std::vector<float2> xyh(n + 16, make_float2(1e9f, 1e9f));
+        for (uint32_t q = 0; q < n; q++) xyh[q] = make_float2(S.pm[q].x, S.pm[q].y);
+        float2* xy_d = dev_alloc<float2>(n + 16);
+        CHECK(hipMemcpy(xy_d, xyh.data(), (size_t)(n + 16) * 8, hipMemcpyHostToDevice));
+        A.xy = xy_d;
         A.cell_start = cs_d;
         A.pm = pm_d;
         A.nl_a = dev_alloc<uint4>(n);
@@ -205,9 +360,14 @@ int main(int argc, char** argv)
         A.rho = dev_alloc<float>(n);
         A.over = dev_alloc<uint32_t>(1);
         const uint32_t grid = ((A.nblocks + 7) / 8) * 8;
-        for (int trip : {4, 2}) {
+        for (int trip : {4, 2, 104, 108, 204, 208}) {
+            if (R != 1 && trip > 100) continue;
             auto launch = [&]() {
-                if (R == 1 && trip == 4) hipLaunchKernelGGL((k_build<1, 4>), dim3(grid), dim3(256), 0, 0, A);
+                if (trip == 104) hipLaunchKernelGGL((k_build_flat<0>), dim3(grid), dim3(256), 0, 0, A);
+                else if (trip == 108) hipLaunchKernelGGL((k_build_flat<1>), dim3(grid), dim3(256), 0, 0, A);
+                else if (trip == 204) hipLaunchKernelGGL((k_build_2phase<0>), dim3(grid), dim3(256), 0, 0, A);
+                else if (trip == 208) hipLaunchKernelGGL((k_build_2phase<1>), dim3(grid), dim3(256), 0, 0, A);
+                else if (R == 1 && trip == 4) hipLaunchKernelGGL((k_build<1, 4>), dim3(grid), dim3(256), 0, 0, A);
                 else if (R == 1) hipLaunchKernelGGL((k_build<1, 2>), dim3(grid), dim3(256), 0, 0, A);
                 else if (trip == 4) hipLaunchKernelGGL((k_build<2, 4>), dim3(grid), dim3(256), 0, 0, A);
                 else hipLaunchKernelGGL((k_build<2, 2>), dim3(grid), dim3(256), 0, 0, A);
