@@ -180,7 +180,9 @@ __global__ __launch_bounds__(256) void k_header_final(const HeaderOut* __restric
 // sweep and, like it, only once the stop decision has been taken
 // `h_ctrl` != nullptr: the launch is the last one before a host wait and does k_publish's job as well (control block + guard
 // word to mapped host memory, the sequence number last) -- one launch less on the step's critical path
-__global__ __launch_bounds__(256) void k_header_ahead(const HeaderOut* __restrict__ partials, uint32_t nparts, const SolverCtrl* __restrict__ ctrl,
+// (1024 threads, four partials per thread requested together: the launch sits on the step's critical path -- the host waits for its
+//  last store -- and 16 dependent load round trips per thread were most of its 8 us)
+__global__ __launch_bounds__(1024) void k_header_ahead(const HeaderOut* __restrict__ partials, uint32_t nparts, const SolverCtrl* __restrict__ ctrl,
                                                        HeaderOut* __restrict__ out, const DeviceStatus* __restrict__ status, SolverCtrl* __restrict__ h_ctrl,
                                                        DeviceStatus* __restrict__ h_status, uint32_t seq)
 {
@@ -197,22 +199,27 @@ __global__ __launch_bounds__(256) void k_header_ahead(const HeaderOut* __restric
     }
     const float INF = __uint_as_float(0x7f800000u);
     HeaderOut o{INF, INF, -INF, -INF, 0.f, INF, INF, 0};
-    for (uint32_t k = threadIdx.x; k < nparts; k += 256) {
-        const HeaderOut q = partials[k];
-        o.min_x = fminf(o.min_x, q.min_x); o.min_y = fminf(o.min_y, q.min_y);
-        o.max_x = fmaxf(o.max_x, q.max_x); o.max_y = fmaxf(o.max_y, q.max_y);
-        o.h_max = fmaxf(o.h_max, q.h_max); o.h_min = fminf(o.h_min, q.h_min);
-        o.min_cfl = fminf(o.min_cfl, q.min_cfl);
+    for (uint32_t k0 = threadIdx.x; k0 < nparts; k0 += 4096u) {
+        HeaderOut q[4];
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; u++) q[u] = partials[min(k0 + 1024u * u, nparts - 1u)];   // (a repeated partial changes no min / max)
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; u++) {
+            o.min_x = fminf(o.min_x, q[u].min_x); o.min_y = fminf(o.min_y, q[u].min_y);
+            o.max_x = fmaxf(o.max_x, q[u].max_x); o.max_y = fmaxf(o.max_y, q[u].max_y);
+            o.h_max = fmaxf(o.h_max, q[u].h_max); o.h_min = fminf(o.h_min, q[u].h_min);
+            o.min_cfl = fminf(o.min_cfl, q[u].min_cfl);
+        }
     }
     o.min_x = wave_min(o.min_x); o.min_y = wave_min(o.min_y); o.max_x = wave_max(o.max_x); o.max_y = wave_max(o.max_y);
     o.h_max = wave_max(o.h_max); o.h_min = wave_min(o.h_min); o.min_cfl = wave_min(o.min_cfl);
-    __shared__ HeaderOut s[4];
+    __shared__ HeaderOut s[16];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     if (lane == 0) s[w] = o;
     __syncthreads();
     if (threadIdx.x == 0) {
         HeaderOut r = s[0];
-        for (int k = 1; k < 4; k++) {
+        for (int k = 1; k < 16; k++) {
             r.min_x = fminf(r.min_x, s[k].min_x); r.min_y = fminf(r.min_y, s[k].min_y);
             r.max_x = fmaxf(r.max_x, s[k].max_x); r.max_y = fmaxf(r.max_y, s[k].max_y);
             r.h_max = fmaxf(r.h_max, s[k].h_max); r.h_min = fminf(r.h_min, s[k].h_min);
@@ -1225,7 +1232,7 @@ void launch_header_ahead(sph_ctx* c, uint32_t nblocks, HeaderOut* out_dev, bool 
         seq = c->publish_seq;
         c->publish_folded = true;
     }
-    hipLaunchKernelGGL(k_header_ahead, dim3(1), dim3(256), 0, c->stream, c->hdr_ahead_partials.as<HeaderOut>(), nblocks, c->ctrl.as<SolverCtrl>(), out_dev,
+    hipLaunchKernelGGL(k_header_ahead, dim3(1), dim3(1024), 0, c->stream, c->hdr_ahead_partials.as<HeaderOut>(), nblocks, c->ctrl.as<SolverCtrl>(), out_dev,
                        c->status.as<DeviceStatus>(), publish ? c->ctrl_host_dev : (SolverCtrl*)nullptr, publish ? c->status_host_dev : (DeviceStatus*)nullptr, seq);
 }
 

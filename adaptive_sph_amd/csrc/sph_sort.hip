@@ -79,6 +79,7 @@ __global__ __launch_bounds__(256) void k_rs_hist(uint32_t* __restrict__ key, uin
 }
 
 // one workgroup per digit: exclusive scan of that digit's per-block counts, total -> totals[d]
+// (four consecutive counts per thread: 1024 tiles -- 1M keys -- are one trip of loads and one block scan instead of four of each)
 __global__ __launch_bounds__(256) void k_rs_rowscan(uint32_t* __restrict__ hist, uint32_t nblocks, uint32_t* __restrict__ totals)
 {
     __shared__ uint32_t wsum[4];
@@ -87,10 +88,13 @@ __global__ __launch_bounds__(256) void k_rs_rowscan(uint32_t* __restrict__ hist,
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     if (tid == 0) carry_s = 0;
     __syncthreads();
-    for (uint32_t b = 0; b < nblocks; b += 256) {
-        uint32_t i = b + tid;
-        uint32_t v = i < nblocks ? row[i] : 0u;
-        uint32_t x = v;
+    for (uint32_t b = 0; b < nblocks; b += 1024) {
+        const uint32_t i = b + 4u * (uint32_t)tid;
+        uint32_t v[4];
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; u++) v[u] = i + u < nblocks ? row[i + u] : 0u;
+        const uint32_t own = v[0] + v[1] + v[2] + v[3];
+        uint32_t x = own;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             uint32_t y = __shfl_up(x, o, 64);
@@ -100,8 +104,13 @@ __global__ __launch_bounds__(256) void k_rs_rowscan(uint32_t* __restrict__ hist,
         __syncthreads();
         uint32_t woff = 0;
         for (int k = 0; k < w; k++) woff += wsum[k];
-        uint32_t carry = carry_s;
-        if (i < nblocks) row[i] = carry + woff + x - v;
+        const uint32_t carry = carry_s;
+        uint32_t run = carry + woff + x - own;
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; u++) {
+            if (i + u < nblocks) row[i + u] = run;
+            run += v[u];
+        }
         __syncthreads();
         if (tid == 255) carry_s = carry + woff + x;
         __syncthreads();

@@ -1270,13 +1270,23 @@ __device__ __forceinline__ void solver_reduce_decide(const SolverPartial* __rest
     __shared__ SolverPartial s_r[SWEEP_THREADS / 64];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     SolverPartial t{0, 0, 0, 0.f, 0.f};
-    for (uint32_t k = tid; k < nparts; k += SWEEP_THREADS) {
-        const SolverPartial v = partials[k];
-        t.normal += v.normal;
-        t.singular += v.singular;
-        t.negative += v.negative;
-        t.sum_err += v.sum_err;
-        t.max_err = fmaxf(t.max_err, v.max_err);
+    // (four partials requested together, added in the order a one-at-a-time loop adds them: the decision is on the host's critical
+    //  path -- a paced solve queues the next iteration when it arrives -- and sixteen dependent round trips were most of its 8 us)
+    for (uint32_t k0 = tid; k0 < nparts; k0 += 4u * SWEEP_THREADS) {
+        SolverPartial v[4];
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; u++) {
+            const uint32_t k = k0 + u * SWEEP_THREADS;
+            v[u] = k < nparts ? partials[k] : SolverPartial{0, 0, 0, 0.f, 0.f};
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; u++) {
+            t.normal += v[u].normal;
+            t.singular += v[u].singular;
+            t.negative += v[u].negative;
+            t.sum_err += v[u].sum_err;
+            t.max_err = fmaxf(t.max_err, v[u].max_err);
+        }
     }
     t.normal = wave_sum_u32(t.normal);
     t.singular = wave_sum_u32(t.singular);
