@@ -266,6 +266,62 @@ __global__ __launch_bounds__(256) void k_gather4_slim(Args A)
     }
 }
 
+// ---- variant: sweep B, combined record, slim arithmetic, own loads first -- and NO branch around a pair: every slot of a trip is
+// evaluated, an invalid slot's scale factor is selected to zero (the compiler otherwise sinks a slot's gather into the branch that
+// uses it: one of a trip's four loads is then requested only after the first pair is done, a second latency per trip) ----
+__global__ __launch_bounds__(256) void k_gather4_slim_nobranch(Args A)
+{
+    const uint32_t blk = remap_block(A.nblocks);
+    if (blk >= A.nblocks) return;
+    const uint32_t i = blk * 256 + threadIdx.x;
+    if (i >= A.n) return;
+    const float4 Ai = A.comb[i];
+    const uint4 lw = A.nl[i];
+    const float rho_i = A.rho[i];
+    const float aii_i = A.aii[i], src_i = A.src[i], pin_i = A.p_in[i];
+    uint32_t rb[3];
+    int cx, cy;
+    row_bases(A, Ai.x, Ai.y, rb, cx, cy);
+    float sum = 0.f;
+    const float inv_rho = __builtin_amdgcn_rcpf(rho_i);
+    const float nf6 = 6.f * A.m.nf * A.m.inv2h;
+    const uint32_t masks[3] = {lw.x, lw.y, lw.z};
+#pragma unroll
+    for (int dr = 0; dr < 3; dr++) {
+        uint32_t mk = masks[dr];
+        const uint32_t base = rb[dr];
+        while (mk) {
+            uint32_t b[4];
+            bool v[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                v[k] = mk != 0u;
+                b[k] = v[k] ? (uint32_t)__ffs(mk) - 1u : b[0];
+                mk &= mk - 1u;
+            }
+            float4 R[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) R[k] = A.comb[ix(base + b[k], A.n, 30u)];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const float dx = Ai.x - R[k].x, dy = Ai.y - R[k].y;
+                const float r2 = fmaxf(dx * dx + dy * dy, 1.0e-30f);
+                const float rinv = __builtin_amdgcn_rsqf(r2);
+                const float q = (r2 * rinv) * A.m.inv2h;
+                const float u = fmaxf(1.f - q, 0.f), t = fmaxf(0.5f - q, 0.f);
+                const float d = fmaf(4.f * t, t, -(u * u));
+                const float sc = v[k] ? nf6 * d * rinv : 0.f;
+                sum = fmaf((R[k].z - Ai.z) * sc, dx, fmaf((R[k].w - Ai.w) * sc, dy, sum));
+            }
+        }
+    }
+    sum *= A.mass * inv_rho;
+    const float pn = pin_i + A.omega * (src_i - sum) / aii_i;
+    const bool pos = pn > 0.f;
+    A.p_out[i] = pos ? pn : 0.f;
+    A.pt_out[i] = pos ? pn / (rho_i * rho_i) : 0.f;
+}
+
 // ---- variant: the three row masks decoded FIRST into up to 16 neighbour indices in registers (row-major, ascending: the same
 // order), then trips of 4 over that flat sequence: no padding slot per row, 16 slots for up to 16 neighbours (more: a scalar tail) ----
 __global__ __launch_bounds__(256) void k_flat16_slim(Args A)
@@ -772,6 +828,55 @@ __global__ __launch_bounds__(256) void k_accel(Args A)
     A.pacc_out[i] = make_float4(Ai.x, Ai.y, ax, ay);
 }
 
+// sweep A on the combined record without a branch around the pairs
+__global__ __launch_bounds__(256) void k_accel_nobranch(Args A)
+{
+    const uint32_t blk = remap_block(A.nblocks);
+    if (blk >= A.nblocks) return;
+    const uint32_t i = blk * 256 + threadIdx.x;
+    if (i >= A.n) return;
+    const float4 Ai = A.rec[i];
+    const uint4 lw = A.nl[i];
+    const float pti = Ai.z;
+    uint32_t rb[3];
+    int cx, cy;
+    row_bases(A, Ai.x, Ai.y, rb, cx, cy);
+    const float nf6 = 6.f * A.m.nf * A.m.inv2h;
+    float ax = 0.f, ay = 0.f;
+    const uint32_t masks[3] = {lw.x, lw.y, lw.z};
+#pragma unroll
+    for (int dr = 0; dr < 3; dr++) {
+        uint32_t mk = masks[dr];
+        const uint32_t base = rb[dr];
+        while (mk) {
+            uint32_t b[4];
+            bool v[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                v[k] = mk != 0u;
+                b[k] = v[k] ? (uint32_t)__ffs(mk) - 1u : b[0];
+                mk &= mk - 1u;
+            }
+            float4 R[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) R[k] = A.rec[ix(base + b[k], A.n, 31u)];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const float dx = Ai.x - R[k].x, dy = Ai.y - R[k].y;
+                const float r2 = fmaxf(dx * dx + dy * dy, 1.0e-30f);
+                const float rinv = __builtin_amdgcn_rsqf(r2);
+                const float q = (r2 * rinv) * A.m.inv2h;
+                const float u = fmaxf(1.f - q, 0.f), t = fmaxf(0.5f - q, 0.f);
+                const float d = fmaf(4.f * t, t, -(u * u));
+                const float fs = v[k] ? (-A.mass * (pti + R[k].z)) * (nf6 * d * rinv) : 0.f;
+                ax = fmaf(fs, dx, ax);
+                ay = fmaf(fs, dy, ay);
+            }
+        }
+    }
+    A.pacc_out[i] = make_float4(Ai.x, Ai.y, ax, ay);
+}
+
 // sweep B's stores with the combined record: p (4 B) and {x, y, p / rho^2, p} (16 B) instead of p and p / rho^2 (4 B + 4 B):
 // variant `gather4_slim<1>` with that store, to price the 12 extra bytes per particle
 __global__ __launch_bounds__(256) void k_gather4_slim_recstore(Args A)
@@ -958,6 +1063,7 @@ int main(int argc, char** argv)
         {"gather4, one combined 16-B record {x, y, a^p}", k_gather4<1>, true},
         {"gather4, combined record, slim pair arithmetic (v_max spline, clamped r2, folded constants, fma)", k_gather4_slim<0>, true},
         {"gather4, combined record, slim pair arithmetic, finish's loads requested at the top", k_gather4_slim<1>, true},
+        {"gather4, combined record, slim, own loads first, NO branch around the pairs (invalid slots scaled by zero)", k_gather4_slim_nobranch, true},
         {"combined record, slim, masks decoded into 16 indices first, then flat trips of 4 (no per-row padding)", k_flat16_slim, true},
         {"combined record, slim, masks decoded by per-row loops into an LDS column per lane, then flat trips of 4", k_flat_lds_slim, true},
         {"gather4, combined record, slim, next trip's gathers requested before this trip's pairs (rows merged into one trip sequence)", k_gather4_slim_pipe, true},
@@ -1015,6 +1121,7 @@ int main(int argc, char** argv)
         const VA va[] = {
             {"sweep A, product form: 16-B record {x, y, m, h} + 4-B p / rho^2, two gathers per slot", k_accel<0>},
             {"sweep A, ONE 16-B gather of a combined record {x, y, p / rho^2, p}", k_accel<1>},
+            {"sweep A, combined record, NO branch around the pairs", k_accel_nobranch},
             {"sweep B (slim, own loads first) storing p and the 16-B combined record instead of p and p / rho^2", k_gather4_slim_recstore},
         };
         printf("| sweep A variant | us per launch | max rel diff of a^p vs the first |\n|---|---|---|\n");
