@@ -322,6 +322,118 @@ __global__ __launch_bounds__(256) void k_gather4_slim_nobranch(Args A)
     A.pt_out[i] = pos ? pn / (rho_i * rho_i) : 0.f;
 }
 
+// ---- variants of sweep B / sweep A on their combined records with a leaner slot (LEAN bits: 1 = r2 + 1e-30 instead of max(r2,
+// 1e-30) (an add is full rate, a max half rate; same value for every r2 > 1e-23), 2 = no clamp of 1 - q (a listed neighbour is
+// inside the support: q < 1 up to the rsq's rounding, where u^2 ~ 1e-14 is below the sum's resolution), 4 = no select on an empty
+// slot's bit index (ffbl of 0 is -1: the slot gathers record base - 1, which exists -- the arrays carry one element in front) ----
+template <int LEAN>
+__global__ __launch_bounds__(256) void k_gather4_lean(Args A)
+{
+    const uint32_t blk = remap_block(A.nblocks);
+    if (blk >= A.nblocks) return;
+    const uint32_t i = blk * 256 + threadIdx.x;
+    if (i >= A.n) return;
+    const float4 Ai = A.comb[i];
+    const uint4 lw = A.nl[i];
+    const float rho_i = A.rho[i];
+    const float aii_i = A.aii[i], src_i = A.src[i], pin_i = A.p_in[i];
+    uint32_t rb[3];
+    int cx, cy;
+    row_bases(A, Ai.x, Ai.y, rb, cx, cy);
+    float sum = 0.f;
+    const float inv_rho = __builtin_amdgcn_rcpf(rho_i);
+    const float nf6 = 6.f * A.m.nf * A.m.inv2h;
+    const uint32_t masks[3] = {lw.x, lw.y, lw.z};
+#pragma unroll
+    for (int dr = 0; dr < 3; dr++) {
+        uint32_t mk = masks[dr];
+        const uint32_t base = rb[dr];
+        while (mk) {
+            uint32_t b[4];
+            bool v[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                v[k] = mk != 0u;
+                if (LEAN & 4) b[k] = (uint32_t)__ffs(mk) - 1u;
+                else b[k] = v[k] ? (uint32_t)__ffs(mk) - 1u : b[0];
+                mk &= mk - 1u;
+            }
+            float4 R[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) R[k] = A.comb[(int)(base + b[k])];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const float dx = Ai.x - R[k].x, dy = Ai.y - R[k].y;
+                const float r2 = (LEAN & 1) ? (dx * dx + dy * dy) + 1.0e-30f : fmaxf(dx * dx + dy * dy, 1.0e-30f);
+                if (v[k]) {
+                    const float rinv = __builtin_amdgcn_rsqf(r2);
+                    const float q = (r2 * rinv) * A.m.inv2h;
+                    const float u = (LEAN & 2) ? 1.f - q : fmaxf(1.f - q, 0.f), t = fmaxf(0.5f - q, 0.f);
+                    const float d = fmaf(4.f * t, t, -(u * u));
+                    const float sc = nf6 * d * rinv;
+                    sum = fmaf((R[k].z - Ai.z) * sc, dx, fmaf((R[k].w - Ai.w) * sc, dy, sum));
+                }
+            }
+        }
+    }
+    sum *= A.mass * inv_rho;
+    const float pn = pin_i + A.omega * (src_i - sum) / aii_i;
+    const bool pos = pn > 0.f;
+    A.p_out[i] = pos ? pn : 0.f;
+    A.pt_out[i] = pos ? pn / (rho_i * rho_i) : 0.f;
+}
+template <int LEAN>
+__global__ __launch_bounds__(256) void k_accel_lean(Args A)
+{
+    const uint32_t blk = remap_block(A.nblocks);
+    if (blk >= A.nblocks) return;
+    const uint32_t i = blk * 256 + threadIdx.x;
+    if (i >= A.n) return;
+    const float4 Ai = A.rec[i];
+    const uint4 lw = A.nl[i];
+    const float pti = Ai.z;
+    uint32_t rb[3];
+    int cx, cy;
+    row_bases(A, Ai.x, Ai.y, rb, cx, cy);
+    const float nf6 = 6.f * A.m.nf * A.m.inv2h;
+    float ax = 0.f, ay = 0.f;
+    const uint32_t masks[3] = {lw.x, lw.y, lw.z};
+#pragma unroll
+    for (int dr = 0; dr < 3; dr++) {
+        uint32_t mk = masks[dr];
+        const uint32_t base = rb[dr];
+        while (mk) {
+            uint32_t b[4];
+            bool v[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                v[k] = mk != 0u;
+                if (LEAN & 4) b[k] = (uint32_t)__ffs(mk) - 1u;
+                else b[k] = v[k] ? (uint32_t)__ffs(mk) - 1u : b[0];
+                mk &= mk - 1u;
+            }
+            float4 R[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) R[k] = A.rec[(int)(base + b[k])];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const float dx = Ai.x - R[k].x, dy = Ai.y - R[k].y;
+                const float r2 = (LEAN & 1) ? (dx * dx + dy * dy) + 1.0e-30f : fmaxf(dx * dx + dy * dy, 1.0e-30f);
+                if (v[k]) {
+                    const float rinv = __builtin_amdgcn_rsqf(r2);
+                    const float q = (r2 * rinv) * A.m.inv2h;
+                    const float u = (LEAN & 2) ? 1.f - q : fmaxf(1.f - q, 0.f), t = fmaxf(0.5f - q, 0.f);
+                    const float d = fmaf(4.f * t, t, -(u * u));
+                    const float fs = (-A.mass * (pti + R[k].z)) * (nf6 * d * rinv);
+                    ax = fmaf(fs, dx, ax);
+                    ay = fmaf(fs, dy, ay);
+                }
+            }
+        }
+    }
+    A.pacc_out[i] = make_float4(Ai.x, Ai.y, ax, ay);
+}
+
 // ---- variant: the three row masks decoded FIRST into up to 16 neighbour indices in registers (row-major, ascending: the same
 // order), then trips of 4 over that flat sequence: no padding slot per row, 16 slots for up to 16 neighbours (more: a scalar tail) ----
 __global__ __launch_bounds__(256) void k_flat16_slim(Args A)
@@ -1027,7 +1139,12 @@ int main(int argc, char** argv)
     A.nl = (const uint4*)up(nl.data(), (size_t)n * 16);
     A.pm = (const float4*)up(pm.data(), (size_t)n * 16);
     A.pacc = (const float2*)up(pacc.data(), (size_t)n * 8);
-    A.comb = (const float4*)up(comb.data(), (size_t)n * 16);
+    {   // (one element in front: the lean variants gather index base - 1 in an empty slot)
+        std::vector<float4> padded(n + 1);
+        padded[0] = comb[0];
+        std::copy(comb.begin(), comb.end(), padded.begin() + 1);
+        A.comb = (const float4*)up(padded.data(), (size_t)(n + 1) * 16) + 1;
+    }
     A.rho = (const float*)up(rho.data(), (size_t)n * 4);
     A.aii = (const float*)up(aii.data(), (size_t)n * 4);
     A.src = (const float*)up(src.data(), (size_t)n * 4);
@@ -1047,7 +1164,12 @@ int main(int argc, char** argv)
             rec[s] = make_float4(pm[s].x, pm[s].y, pt[s], pin[s]);
         }
         A.pt = (const float*)up(pt.data(), (size_t)n * 4);
-        A.rec = (const float4*)up(rec.data(), (size_t)n * 16);
+        {
+            std::vector<float4> padded(n + 1);
+            padded[0] = rec[0];
+            std::copy(rec.begin(), rec.end(), padded.begin() + 1);
+            A.rec = (const float4*)up(padded.data(), (size_t)(n + 1) * 16) + 1;
+        }
         void* po;
         CHECK(hipMalloc(&po, (size_t)n * 16));
         A.pacc_out = (float4*)po;
@@ -1064,6 +1186,9 @@ int main(int argc, char** argv)
         {"gather4, combined record, slim pair arithmetic (v_max spline, clamped r2, folded constants, fma)", k_gather4_slim<0>, true},
         {"gather4, combined record, slim pair arithmetic, finish's loads requested at the top", k_gather4_slim<1>, true},
         {"gather4, combined record, slim, own loads first, NO branch around the pairs (invalid slots scaled by zero)", k_gather4_slim_nobranch, true},
+        {"sweep B lean: r2 + floor", k_gather4_lean<1>, true},
+        {"sweep B lean: + no clamp of 1 - q", k_gather4_lean<3>, true},
+        {"sweep B lean: + no select on an empty slot's index", k_gather4_lean<7>, true},
         {"combined record, slim, masks decoded into 16 indices first, then flat trips of 4 (no per-row padding)", k_flat16_slim, true},
         {"combined record, slim, masks decoded by per-row loops into an LDS column per lane, then flat trips of 4", k_flat_lds_slim, true},
         {"gather4, combined record, slim, next trip's gathers requested before this trip's pairs (rows merged into one trip sequence)", k_gather4_slim_pipe, true},
@@ -1122,6 +1247,9 @@ int main(int argc, char** argv)
             {"sweep A, product form: 16-B record {x, y, m, h} + 4-B p / rho^2, two gathers per slot", k_accel<0>},
             {"sweep A, ONE 16-B gather of a combined record {x, y, p / rho^2, p}", k_accel<1>},
             {"sweep A, combined record, NO branch around the pairs", k_accel_nobranch},
+            {"sweep A lean: r2 + floor", k_accel_lean<1>},
+            {"sweep A lean: + no clamp of 1 - q", k_accel_lean<3>},
+            {"sweep A lean: + no select on an empty slot's index", k_accel_lean<7>},
             {"sweep B (slim, own loads first) storing p and the 16-B combined record instead of p and p / rho^2", k_gather4_slim_recstore},
         };
         printf("| sweep A variant | us per launch | max rel diff of a^p vs the first |\n|---|---|---|\n");
