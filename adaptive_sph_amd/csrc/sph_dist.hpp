@@ -109,7 +109,8 @@ int build_ghost_layer(Group& G, std::vector<Member>& M, float halo_width, float 
 int slab_refresh_fused(Group& G, std::vector<Member>& M, std::vector<std::vector<float>>& red, float halo_k, bool* fused);
 // refresh `field` (words floats per particle) of every member's ghosts from their owners; tot_slot >= 0: the all-reduce of that slot's
 // solver totals rides in the same call
-int refresh_ghosts(Group& G, std::vector<Member>& M, float* (*sel)(Member&), int words, const char* what, int tot_slot = -1);
+// `sel2` (one word per particle, like `sel` then): a second field in the SAME exchange -- the level estimation's (level, when) pair
+int refresh_ghosts(Group& G, std::vector<Member>& M, float* (*sel)(Member&), int words, const char* what, int tot_slot = -1, float* (*sel2)(Member&) = nullptr);
 // after the cell sort: slot maps of halo members and ghosts, ownership flags, the split sweep's edge bytes, the ghosts' {x, y, a^p} records
 int slab_maps_after_sort(sph_ctx* c, uint32_t n, bool pre, hipStream_t s);
 // m / rho of the ghosts from their refreshed densities

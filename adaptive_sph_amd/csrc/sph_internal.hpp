@@ -221,7 +221,8 @@ struct LevelArgs {
     float* level_old;
     float* stash_first;            // stash filled right after the detection (SurfaceDistanceFirst) or nullptr
     int center_diff;               // surface_detection_by_center_diff instead of the empty-angle detector
-    int plain_propagate;           // slab decomposition: propagation without frontier marks
+    int plain_propagate;           // slab decomposition: 1 = propagation without frontier marks, 2 = frontier form with probing halo members (OpLevelPropagate)
+    const uint8_t* edge;           // mode 2: the slab's halo-member / ghost flags (sph_slabs.hip)
     int replay_step_lists;         // after advection without the extended range: the step's k = 2 lists at the advected positions
     const float4* pm_cell;         // level estimation after advection: the pre-step positions (cells); a.pm = advected. Else nullptr
 };

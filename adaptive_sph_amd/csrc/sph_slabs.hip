@@ -433,25 +433,26 @@ __global__ void k_fill_u8(uint8_t* p, uint32_t n, uint8_t v)
 
 // refresh `field` (words floats per particle) of every member's ghosts from their owners
 // `tot_slot` >= 0: the all-reduce of the solver totals of that slot rides in the same call (Comm::exchange_and_allreduce_solver)
-int refresh_ghosts(Group& G, std::vector<Member>& M, float* (*sel)(Member&), int words, const char* what, int tot_slot)
+int refresh_ghosts(Group& G, std::vector<Member>& M, float* (*sel)(Member&), int words, const char* what, int tot_slot, float* (*sel2)(Member&))
 {
     if (!G.multi()) return SPH_OK;
+    const int nf = sel2 ? 2 : 1;   // fields per exchange: the second one is packed behind the first in every buffer
     std::vector<Xfer> x(M.size());
     for (size_t i = 0; i < M.size(); i++) {
         sph_ctx* c = M[i].c;
         (void)hipSetDevice(c->device);
         ProfScope ps(&c->prof, "ghost_pack", c->stream);
-        float* field = sel(M[i]);
         const uint32_t nh = c->dist.n_halo[0] + c->dist.n_halo[1];
-        if (nh)
+        for (int f = 0; f < nf && nh; f++)
             hipLaunchKernelGGL(k_pack_field, dim3((nh + 255) / 256), dim3(256), 0, c->stream, c->dist.halo_src.as<uint32_t>(), c->dist.n_halo[0],
-                               c->dist.n_halo[1], words, field, c->dist.send[0].as<float>(), c->dist.send[1].as<float>());
+                               c->dist.n_halo[1], words, f ? sel2(M[i]) : sel(M[i]), c->dist.send[0].as<float>() + (size_t)f * c->dist.n_halo[0] * words,
+                               c->dist.send[1].as<float>() + (size_t)f * c->dist.n_halo[1] * words);
         for (int side = 0; side < 2; side++) {
             const uint32_t cnt = c->dist.n_halo[side];
             x[i].send[side] = c->dist.send[side].p;
-            x[i].send_bytes[side] = (size_t)cnt * words * 4;
+            x[i].send_bytes[side] = (size_t)cnt * words * 4 * nf;
             x[i].recv[side] = c->dist.recv[side].p;
-            x[i].recv_bytes[side] = (size_t)c->dist.n_ghost[side] * words * 4;
+            x[i].recv_bytes[side] = (size_t)c->dist.n_ghost[side] * words * 4 * nf;
         }
     }
     int rc = tot_slot >= 0 ? G.comm->exchange_and_allreduce_solver(G, x, tot_slot) : G.comm->exchange(G, x);
@@ -460,11 +461,11 @@ int refresh_ghosts(Group& G, std::vector<Member>& M, float* (*sel)(Member&), int
         sph_ctx* c = M[i].c;
         (void)hipSetDevice(c->device);
         ProfScope ps(&c->prof, "ghost_unpack", c->stream);
-        float* field = sel(M[i]);
         const uint32_t ng = c->dist.ghosts_ok ? c->dist.n_ghost[0] + c->dist.n_ghost[1] : 0u;   // (no ghost slots: received, dropped)
-        if (ng)
+        for (int f = 0; f < nf && ng; f++)
             hipLaunchKernelGGL(k_unpack_field, dim3((ng + 255) / 256), dim3(256), 0, c->stream, c->dist.ghost_dst.as<uint32_t>(), c->dist.n_ghost[0],
-                               c->dist.n_ghost[1], words, c->dist.recv[0].as<float>(), c->dist.recv[1].as<float>(), field);
+                               c->dist.n_ghost[1], words, c->dist.recv[0].as<float>() + (size_t)f * c->dist.n_ghost[0] * words,
+                               c->dist.recv[1].as<float>() + (size_t)f * c->dist.n_ghost[1] * words, f ? sel2(M[i]) : sel(M[i]));
     }
     (void)what;
     return SPH_OK;

@@ -1173,7 +1173,10 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
             l.mark = c->lvl_mark.as<uint32_t>();
             l.level_old = c->lvlold[c->cur].as<float>();
             l.stash_first = p->fill_stash_with == SPH_STASH_SURFACE_DISTANCE_FIRST ? c->stash.as<float>() : nullptr;
-            l.plain_propagate = 1;
+            // frontier form with probing halo members (OpLevelPropagate, mode 2); SPH_SLAB_LEVEL_PLAIN=1: every unassigned particle in
+            // every sweep (measurement / tests; parameters only: the same on every rank)
+            l.plain_propagate = getenv("SPH_SLAB_LEVEL_PLAIN") ? 1 : 2;
+            l.edge = c->dist.edge.as<uint8_t>();
             l.pm_cell = after ? c->pm[c->pcur].as<float4>() : nullptr;
             l.center_diff = p->level_estimation_method == SPH_LEVEL_CENTER_DIFF;
             l.replay_step_lists = replay_step_lists;
@@ -1202,8 +1205,13 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
                 launch_level_detect(c->stream, &c->prof, al, l);
             }
         }
-        if ((rc = refresh_ghosts(G, M, sel_lv_level, 1, "level"))) return rc;
-        if ((rc = refresh_ghosts(G, M, sel_lv_when, 1, "when"))) return rc;
+        if ((rc = refresh_ghosts(G, M, sel_lv_level, 1, "level + when", -1, sel_lv_when))) return rc;   // (both fields in one exchange)
+        const bool frontier = LV[0].plain_propagate == 2;
+        if (frontier)   // sweep 0: the surface particles mark their unassigned neighbours (the candidates of sweep 1)
+            for (size_t i = 0; i < M.size(); i++) {
+                (void)hipSetDevice(M[i].c->device);
+                if (M[i].n) launch_level_propagate(M[i].c->stream, &M[i].c->prof, AL[i], LV[i], 0u, M[i].c->lvl_changed_d.as<uint32_t>() + 1023);
+            }
         const int B = 8;
         uint32_t t = 1;
         for (bool done = false; !done;) {
@@ -1221,8 +1229,7 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
                     if (t == 1u && p->fill_stash_with == SPH_STASH_SURFACE_DISTANCE_MIDDLE)
                         launch_fill_stash(c->stream, &c->prof, AL[i], LV[i], c->stash.as<float>());
                 }
-                if ((rc = refresh_ghosts(G, M, sel_lv_level, 1, "level"))) return rc;
-                if ((rc = refresh_ghosts(G, M, sel_lv_when, 1, "when"))) return rc;
+                if ((rc = refresh_ghosts(G, M, sel_lv_level, 1, "level + when", -1, sel_lv_when))) return rc;
             }
             for (auto& m : M) {
                 (void)hipSetDevice(m.c->device);

@@ -351,6 +351,13 @@ struct OpTile : std::false_type {};
 template <class Op>
 struct OpTile<Op, std::void_t<decltype(Op::TILE)>> : std::bool_constant<Op::TILE> {};
 
+// Ops with `static constexpr bool SECOND_PASS = true`: a lane for which second_wanted(acc) holds after its sweep runs the list again
+// with the op `second()` returns (type Op::Second) -- see OpLevelPropagate.
+template <class Op, class = void>
+struct OpSecondPass : std::false_type {};
+template <class Op>
+struct OpSecondPass<Op, std::void_t<decltype(Op::SECOND_PASS)>> : std::bool_constant<Op::SECOND_PASS> {};
+
 // optional Op hook `bool prologue(raw_block)`: block-uniform work at the start of the launch (the Jacobi stop decision, taken by
 // block 0 of the NEXT pressure-acceleration sweep while the other blocks already sweep); returns true to leave.  Default: skip().
 template <class Op, class = void>
@@ -518,6 +525,15 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_sweep(Op op, SweepCommon c)
             if (!BUILD) lw = c.nl[i];
         }
         sweep_particle<Op, BUILD>(op, c, acc, i, Ai, lw);
+        // optional second pass of a lane over the same list with another op (level-set propagation on slabs: OpLevelPropagate)
+        if constexpr (OpSecondPass<Op>::value) {
+            if (op.second_wanted(acc)) {
+                const typename Op::Second op2 = op.second();
+                typename Op::Second::Acc acc2;
+                op2.init(acc2);
+                sweep_particle<typename Op::Second, false>(op2, c, acc2, i, Ai, lw);
+            }
+        }
     }
     if (Op::HAS_EPILOGUE) op.epilogue(acc, active, blk);
 }
@@ -2060,8 +2076,8 @@ struct NBLevel {
     float lv;
     uint32_t j;
 };
-template <class MathT>
-struct OpLevelPropagate {
+template <class MathT, bool SLAB>   // SLAB: the frontier form of a slab decomposition (mode 2 below) with its second pass
+struct OpLevelPropagateT {
     typedef MathT Math;
     static constexpr bool HAS_EPILOGUE = false, SKIP_SELF = false, EXTENDED = true;
     typedef NBLevel NB;
@@ -2081,18 +2097,29 @@ struct OpLevelPropagate {
     // particle still unassigned has no neighbour from an earlier sweep (it would have been assigned then), so everything
     // later derives from this sweep's values and lies deeper still.  `changed` therefore means "assigned something above the bound".
     float useful_above;
-    int plain;   // slab decomposition: no frontier marks (a ghost cannot mark for its owner's rank) -- every unassigned particle
-                 // looks at its list in every sweep, like the reference does
+    int plain;   // 1: no frontier marks -- every unassigned particle looks at its list in every sweep, like the reference does.
+                 // 2: the frontier form on a slab decomposition.  A ghost cannot mark for its owner's rank, so an owned particle
+                 //    whose candidacy would come from a ghost (assigned on another rank one sweep earlier) is never marked: every
+                 //    unassigned HALO MEMBER (edge[i]: an owned particle the neighbour rank holds as a ghost -- the owned particles
+                 //    with a ghost on their extended list are among them) therefore PROBES its list in every sweep.  A probing lane
+                 //    marks nothing while it looks (it may find no assigned neighbour, and a mark from a particle that is not
+                 //    assigned would start a cascade of idle candidates); if it is assigned, its unassigned neighbours are marked
+                 //    by a second pass over its list (OpLevelMark, SECOND_PASS of k_sweep) -- they are the candidates of sweep t + 1,
+                 //    exactly those the one-context form marks.
+    const uint8_t* __restrict__ edge;   // mode 2
     struct Acc {
         float best, r2max;
-        bool have;
+        bool have, marker, late;
     };
+    static constexpr bool SECOND_PASS = SLAB;
     __device__ float krange() const { return k; }
     __device__ bool skip() const { return false; }
     __device__ bool lane_skip(uint32_t i) const
     {
-        if (plain) return t == 0u || when[i] != LVL_UNASSIGNED;
-        return t == 0u ? when[i] != 0u : !(when[i] == LVL_UNASSIGNED && mark_cur[i] == t);
+        if (plain == 1) return t == 0u || when[i] != LVL_UNASSIGNED;
+        if (t == 0u) return when[i] != 0u;
+        if (when[i] != LVL_UNASSIGNED) return true;
+        return !(mark_cur[i] == t || (plain == 2 && edge[i] != 0));
     }
     __device__ void init(Acc&) const {}
     __device__ void epilogue(Acc&, bool, uint32_t) const {}
@@ -2110,17 +2137,19 @@ struct OpLevelPropagate {
         // four dependent round trips -- the sweep is nothing but such chains on a few frontier lanes
         return NB{when[j], level[j], j};
     }
-    __device__ void begin(Acc& a, uint32_t, float4 Ai) const
+    __device__ void begin(Acc& a, uint32_t i, float4 Ai) const
     {
         a.best = 0.f;
         a.have = false;
+        a.late = false;
+        a.marker = plain == 0 || t == 0u || (plain == 2 && mark_cur[i] == t);   // (a marked lane has an assigned neighbour: it WILL be assigned)
         a.r2max = level_range_sq(Ai.z, range_factor, sp_rest_density);
     }
     __device__ void pair(Acc& a, float4, NB Bj, float, float, float r2, float) const
     {
         // a candidate of sweep t is assigned in sweep t; its unassigned neighbours are the candidates of sweep t+1.  (In the
         // candidate-walk fallback only accepted pairs arrive here, so only real neighbours are marked.)
-        if (!plain && Bj.w == LVL_UNASSIGNED) mark_next[Bj.j] = t + 1u;
+        if (a.marker && Bj.w == LVL_UNASSIGNED) mark_next[Bj.j] = t + 1u;
         if (!(Bj.w < t)) return;
         if (r2 > a.r2max) return;
         const float est = Bj.lv - sqrtf(r2);
@@ -2133,9 +2162,46 @@ struct OpLevelPropagate {
             level[i] = a.best;
             when[i] = t;
             if (a.best > useful_above) *changed = 1u;   // same value from every lane
+            a.late = !a.marker;   // a probing halo member (mode 2) that found its neighbour: OpLevelMark marks for it
         }
         return false;
     }
+    // ---- the second pass of a lane (k_sweep, SECOND_PASS): mark the unassigned neighbours of a probing lane that was assigned ----
+    struct Second {
+        typedef MathT Math;
+        static constexpr bool HAS_EPILOGUE = false, SKIP_SELF = false, EXTENDED = true;
+        typedef NBLevel NB;
+        MathT m;
+        const float4* __restrict__ pm;
+        const float4* __restrict__ pm_cell;
+        const uint32_t* __restrict__ when;
+        uint32_t* __restrict__ mark_next;
+        float k;
+        uint32_t t;
+        struct Acc {};
+        __device__ float krange() const { return k; }
+        __device__ bool skip() const { return false; }
+        __device__ bool lane_skip(uint32_t) const { return false; }
+        __device__ void init(Acc&) const {}
+        __device__ void epilogue(Acc&, bool, uint32_t) const {}
+        __device__ float2 cell_pos(uint32_t i, const float4& Ai) const
+        {
+            if (!pm_cell) return make_float2(Ai.x, Ai.y);
+            const float4 q = pm_cell[i];
+            return make_float2(q.x, q.y);
+        }
+        __device__ float4 loadA(uint32_t j) const { return pm[j]; }
+        __device__ NB nb(const Acc&, uint32_t j, float4) const { return NB{when[j], 0.f, j}; }
+        __device__ void begin(Acc&, uint32_t, float4) const {}
+        __device__ void pair(Acc&, float4, NB Bj, float, float, float, float) const
+        {
+            // (the lane itself was assigned a moment ago: when[i] = t, so its own entry is not "unassigned" any more)
+            if (Bj.w == LVL_UNASSIGNED) mark_next[Bj.j] = t + 1u;
+        }
+        __device__ bool finish(Acc&, uint32_t, float4, bool) const { return false; }
+    };
+    __device__ bool second_wanted(const Acc& a) const { return a.late; }
+    __device__ Second second() const { return Second{m, pm, pm_cell, when, mark_next, k, t}; }
 };
 
 // (Measured negatives, round 3 -- profiles/r3_variants.md: (1) the whole propagation as ONE persistent launch, 256 resident
@@ -2852,13 +2918,22 @@ void launch_level_detect(hipStream_t s, Profiler* prof, const SweepArgs& a, cons
     }
 }
 
+template <class M>
+using OpLevelPropagate = OpLevelPropagateT<M, false>;
+template <class M>
+using OpLevelPropagateSlab = OpLevelPropagateT<M, true>;
 void launch_level_propagate(hipStream_t s, Profiler* prof, const SweepArgs& a, const LevelArgs& l, uint32_t t, uint32_t* changed)
 {
     ProfScope ps(prof, "level_propagate", s);
     const uint32_t* mark_cur = l.mark + ((t & 1u) ? a.n : 0u);
     uint32_t* mark_next = l.mark + ((t & 1u) ? 0u : a.n);
+    if (l.plain_propagate == 2) {
+        SPH_DISPATCH(OpLevelPropagateSlab, false, a.pm, l.pm_cell, l.level, l.when, mark_cur, mark_next, changed, l.k, t, l.maximum_range, a.sp.rest_density,
+                     -l.max_surface_distance, l.plain_propagate, l.edge)
+        return;
+    }
     SPH_DISPATCH(OpLevelPropagate, false, a.pm, l.pm_cell, l.level, l.when, mark_cur, mark_next, changed, l.k, t, l.maximum_range, a.sp.rest_density,
-                 -l.max_surface_distance, l.plain_propagate)
+                 -l.max_surface_distance, l.plain_propagate, l.edge)
 }
 
 void launch_fill_stash(hipStream_t s, Profiler* prof, const SweepArgs& a, const LevelArgs& l, float* stash)

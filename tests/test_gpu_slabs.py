@@ -165,6 +165,38 @@ def test_level_estimation_on_slabs(product_lib, k):
         assert rel_err(D.gather_by_id(grp, f, n), single.download(f)) <= tol, f
 
 
+@pytest.mark.parametrize("k", [2, 3])
+def test_slab_level_propagation_in_frontier_form_equals_the_plain_form(product_lib, monkeypatch, k):
+    """The propagation on slabs runs in the frontier form -- marked candidates plus every unassigned halo member probing its list,
+    a probing lane that is assigned marks its neighbours in a second pass (OpLevelPropagate, mode 2) -- and moves (level, when) of
+    the ghosts in ONE exchange per sweep.  SPH_SLAB_LEVEL_PLAIN=1 is the reference's form, every unassigned particle in every
+    sweep: the same field, bit for bit, and the same number of sweeps (the exchanges of the two runs are equal)."""
+    scn = sc.dam_break_small(96, 48, 1 / 48)
+    pos, mass, vel = sc.init_particles(scn)
+    vel = vel.copy()
+    vel[:, 0] = 0.8
+    planes = sc.boundary_planes(scn.boundary)
+    P = forced(max_iters=4, level_estimation_method="EmptyAngle", maximum_surface_distance=0.2, particle_radius_fine=0.004,
+               particle_radius_base=0.02)
+    p = P.to_ffi()
+    out = {}
+    for form in ("frontier", "plain"):
+        if form == "plain":
+            monkeypatch.setenv("SPH_SLAB_LEVEL_PLAIN", "1")
+        grp = D.make_loopback_group(product_lib, pos, mass, vel, planes, k)
+        for s in range(10):
+            ffi.group_step(grp, p)
+        out[form] = ({f: D.gather_by_id(grp, f, len(mass)) for f in ("level_estimation", "level_old", "flag_is_fluid_surface", "position")},
+                     sum(c.dist_get_stats()["exchanges"] for c in grp))
+        if form == "plain":
+            monkeypatch.delenv("SPH_SLAB_LEVEL_PLAIN")
+    (fa, xa), (fb, xb) = out["frontier"], out["plain"]
+    assert xa == xb
+    for f in fa:
+        assert np.array_equal(fa[f], fb[f], equal_nan=True), f
+    assert np.isfinite(fa["level_estimation"]).sum() > 0.9 * len(mass)
+
+
 @pytest.mark.parametrize("method,extended", [("EmptyAngle", True), ("EmptyAngle", False), ("CenterDiff", True)])
 def test_level_estimation_after_advection_on_slabs(product_lib, method, extended):
     """level_estimation_after_advection (simulation.rs:2678-2722) across the cuts: the ghosts' advected records come from their
