@@ -247,8 +247,13 @@ __device__ __forceinline__ void replay_indices(const Op& op, typename Op::Acc& a
                                                const uint4* __restrict__ nlx, const uint32_t n)
 {
     typedef typename Op::Math Math;
+    // (the index quad of trip k + 1 is requested before trip k's gathers: two dependent round trips per trip -- indices, then
+    //  records -- were the time of a latency-bound sweep: configs[1] + EmptyAngle 2.07 -> 2.00 ms/step.  Requesting the RECORDS of
+    //  trip k + 1 ahead as well measured 2.03-2.05: recorded in profiles/r3_variants.md, not kept)
+    uint4 qn = cnt ? nlx[i] : make_uint4(0, 0, 0, 0);
     for (uint32_t k = 0; k < cnt; k += 4) {
-        const uint4 q = nlx[(size_t)(k >> 2) * n + i];
+        const uint4 q = qn;
+        if (k + 4 < cnt) qn = nlx[(size_t)((k >> 2) + 1) * n + i];
         const bool v1 = k + 1 < cnt, v2 = k + 2 < cnt, v3 = k + 3 < cnt;
         const uint32_t j0 = q.x, j1 = v1 ? q.y : q.x, j2 = v2 ? q.z : q.x, j3 = v3 ? q.w : q.x;
         SPH_FETCH(j0, A0, N0)
