@@ -1,0 +1,213 @@
+"""A second, independent restatement of the step's arithmetic, against which the ORACLE is checked.
+
+`oracle/step.c` follows the reference routine by routine (lists, f32, the reference's loop order).  This file states the same
+physics once more from the reference's equations as DENSE f64 linear algebra in numpy -- n x n kernel matrices, the divergence and the
+pressure acceleration as matrices, a_ii as the DIAGONAL of their product instead of the reference's closed form -- for a free block of
+fluid far from every wall (no boundary terms), one IISPH or HybridDFSPH step with a fixed number of Jacobi iterations.  A slip in the oracle's
+indexing, signs, operator discretisation, iteration count or update order shows here; a slip in the closed form of a_ii shows
+against the operator it is supposed to be the diagonal of.  (What neither restatement can catch is a misreading of the physics
+shared by both -- they have the same reader.)
+
+Equations (reference file:line):
+  h_i = 1.9 sqrt(m_i / (rho_0 pi))                                   simulation.rs:371-380, sph_kernels.rs:203-206
+  j in N(i)  <=>  |x_ij| < 2 h_ij,  h_ij = (h_i + h_j) / 2           neighborhood_search.rs:143-146 (i itself included)
+  W(r, h) = 10 / (7 pi h^2) w(r / 2h), grad W = 10 / (7 pi h^2) w'(q) / (2h) x / r, zero for q <= 1e-5     sph_kernels.rs:23-71
+  rho_i = sum_j m_j W_ij                                             simulation.rs:1007-1028
+  v* = v + dt (g + nu sum_j 8 m_j / rho_ij (x_ij . v_ij) / (|x_ij|^2 + 0.01 h_ij^2) grad W_ij over the pairs with x_ij . v_ij < 0)
+                                                                     simulation.rs:931-1005, 1051-1077 (ApproxLaplace)
+  div(Q)_i = sum_j m_j / rho_i (Q_j - Q_i) . grad W_ij               simulation.rs:1552-1593 (ConsistentSimpleGradient)
+  s_i = -(rho_0 - rho_i) / (rho_i dt^2) - div(v*)_i / dt             simulation.rs:1712-1749
+  a^p_i = -sum_j m_j (p_i / rho_i^2 + p_j / rho_j^2) grad W_ij       simulation.rs:1780-1808
+  p <- max(0, p + omega (s - div(a^p[p])) / a_ii), |a_ii| < 1e-3 -> 0, max_iters + 1 times from p = 0       simulation.rs:1207-1322, 1378-1480
+  a^p from the final p;  v <- v* + dt a^p;  x <- x + dt v           simulation.rs:1499-1509, 2427-2445
+  HybridDFSPH: divergence solve (s = -div(v) / dt), v += dt a^p, forces before or after it, density solve (full source term or
+  its density part), x += dt v + dt^2 a^p, v += dt a^p min(dt factor, 1)                                  simulation.rs:2502-2670
+"""
+import numpy as np
+import pytest
+
+from adaptive_sph_amd import ffi, scene as sc
+from adaptive_sph_amd.workloads import dam_break_params
+from tests.oracle_harness import load_oracle
+
+
+def boundary_terms(pos, h, planes, penalty_term, lam, dlam):
+    """sum of lambda and of grad lambda per particle over the planes it touches (boundary_winchenbach2020.rs:58-152): d = sdf / (2 h_i),
+    lambda(d) and its derivative from the closed forms (plane_numerics.rs; the oracle's f64 functions, pinned to the reference's
+    Maxima values in test_oracle_golden.py), the Quadratic1 penalty, gradient along the plane's normal"""
+    assert penalty_term == "Quadratic1"
+    n = len(h)
+    ls, gl = np.zeros(n), np.zeros((n, 2))
+    for (nx, ny, delta) in planes:
+        sr = 2.0 * h
+        dd = (nx * pos[:, 0] + ny * pos[:, 1] + delta) / sr
+        for i in np.nonzero(dd < 1.0)[0]:
+            d = dd[i]
+            pen = 1.0 if d > 0 else (0.5 * d * d + 1.0 if d > -1.0 else 0.5 - d)
+            dpen = 0.0 if d > 0 else (d if d > -1.0 else -1.0)
+            la, dla = (1.0, 0.0) if d <= -1.0 else (lam(d), dlam(d))
+            ls[i] += la * pen
+            gl[i] += np.array([nx, ny]) / sr[i] * (dpen * la + pen * dla)
+    return ls, gl
+
+
+def dense_step(pos, mass, vel, P, dt, n_iterations, planes=(), lam=None, dlam=None):
+    """one step (IISPH or HybridDFSPH, viscosity ApproxLaplace, plane boundaries in the ConsistentSimpleGradient discretisation) as
+    dense f64 linear algebra; every solve runs `n_iterations` Jacobi iterations from p = 0"""
+    pos, mass, vel = pos.astype(np.float64), mass.astype(np.float64), vel.astype(np.float64)
+    n = len(mass)
+    rest_density, omega = P.rest_density, P.jacobi_omega
+    h = 1.9 * np.sqrt(mass / rest_density / np.pi)
+    d = pos[:, None, :] - pos[None, :, :]                     # x_ij
+    r = np.sqrt((d ** 2).sum(2))
+    hij = 0.5 * (h[:, None] + h[None, :])
+    nb = r < 2.0 * hij
+    q = r / (2.0 * hij)
+    nf = 10.0 / (7.0 * np.pi * hij ** 2)
+    w = np.where(q < 0.5, 6.0 * (q ** 3 - q ** 2) + 1.0, np.where(q < 1.0, 2.0 * (1.0 - q) ** 3, 0.0))
+    dw = np.where(q < 0.5, 18.0 * q ** 2 - 12.0 * q, np.where(q < 1.0, -6.0 * (1.0 - q) ** 2, 0.0))
+    W = nf * w * nb
+    with np.errstate(invalid="ignore", divide="ignore"):
+        unit = np.where((q > 1.0e-5)[:, :, None], d / r[:, :, None], 0.0)
+    G = (nf * dw / (2.0 * hij) * nb)[:, :, None] * unit       # grad W_ij, n x n x 2
+    lam_sum, lam_grad = boundary_terms(pos, h, planes, P.boundary_penalty_term, lam, dlam) if len(planes) else (np.zeros(n), np.zeros((n, 2)))
+    rho = (mass[None, :] * W).sum(1) + lam_sum                # density_boundary_term = sum lambda (boundary_winchenbach2020.rs:154-163)
+    counts = nb.sum(1)
+
+    def non_pressure(v):    # simulation.rs:931-1005: ApproxLaplace viscosity over the approaching pairs, gravity
+        xv = (d * (v[:, None, :] - v[None, :, :])).sum(2)
+        rho_ij = 0.5 * (rho[:, None] + rho[None, :])
+        coeff = 2.0 * 4.0 * (mass[None, :] / rho_ij) * xv / (r ** 2 + 0.01 * hij ** 2)
+        visc = P.viscosity * ((coeff * (xv < 0.0) * nb)[:, :, None] * G).sum(1)
+        return visc + np.array([0.0, P.gravity])
+
+    # the two operators as matrices per component c: div(Q) = sum_c D_c Q_c ;  a^p_c = A_c p
+    D, A = [], []
+    for c in range(2):
+        Dc = mass[None, :] / rho[:, None] * G[:, :, c]
+        Dc[np.arange(n), np.arange(n)] -= Dc.sum(1)           # -Q_i sum_j m_j / rho_i grad W_ij  (the j = i entry of G is zero)
+        Ac = -mass[None, :] / rho[None, :] ** 2 * G[:, :, c]
+        Ac[np.arange(n), np.arange(n)] += -(mass[None, :] * G[:, :, c]).sum(1) / rho ** 2
+        # the walls: div += rho_0 / rho_i (0 - Q_i) . sum grad lambda ;  a^p += -rho_0 (p_i / rho_i^2 + 0) sum grad lambda
+        # (boundary_winchenbach2020.rs:165-223, p_ib = 0 and rho_b = rho_0 in this discretisation)
+        Dc[np.arange(n), np.arange(n)] += -rest_density / rho * lam_grad[:, c]
+        Ac[np.arange(n), np.arange(n)] += -rest_density / rho ** 2 * lam_grad[:, c]
+        D.append(Dc)
+        A.append(Ac)
+    div = lambda Q: D[0] @ Q[:, 0] + D[1] @ Q[:, 1]          # noqa: E731
+    accel = lambda p: np.stack([A[0] @ p, A[1] @ p], 1)       # noqa: E731
+    aii = np.einsum("ij,ji->i", D[0], A[0]) + np.einsum("ij,ji->i", D[1], A[1])   # diag(D A)
+
+    def solve(s):
+        p = np.zeros(n)
+        for _ in range(n_iterations):
+            pn = p + omega * (s - div(accel(p))) / aii
+            pn = np.where(np.abs(aii) < 10e-4, 0.0, pn)
+            p = np.where(pn <= 0.0, 0.0, pn)
+        return p, accel(p)
+
+    out = dict(density=rho, neighbor_count=counts, aii=aii, lambda_sum=lam_sum, lambda_grad_sum=lam_grad)
+    dens_part = -(rest_density - rho) / (rho * dt * dt)
+    if P.pressure_solver_method == "IISPH":                                  # simulation.rs:2389-2446
+        vstar = vel + dt * non_pressure(vel)
+        s = dens_part - div(vstar) / dt
+        p, ap = solve(s)
+        v = vstar + dt * ap
+        x = pos + dt * v
+    else:                                                                    # HybridDFSPH, simulation.rs:2502-2670
+        before = P.hybrid_dfsph_non_pressure_accel_before_divergence_free
+        v1 = vel + dt * non_pressure(vel) if before else vel
+        p_div, ap_div = solve(-div(v1) / dt)
+        out["pressure_div"] = p_div
+        v2 = v1 + dt * ap_div
+        if not before:
+            v2 = v2 + dt * non_pressure(v2)
+        s = dens_part if P.hybrid_dfsph_density_source_term == "OnlyDensity" else dens_part - div(v2) / dt
+        p, ap = solve(s)
+        x = pos + dt * v2 + dt * dt * ap
+        v = v2 + dt * ap * min(dt * P.hybrid_dfsph_factor, 1.0)
+    out.update(ppe_source_term=s, pressure=p, pressure_accel=ap, velocity=v, position=x)
+    return out
+
+
+def rel(a, b):
+    s = np.abs(b).max()
+    return np.abs(np.asarray(a, np.float64) - b).max() / (s if s > 0 else 1.0)
+
+
+def _case(max_iters, solver="IISPH", wall=False, **kw):
+    spacing = 0.03
+    # (a block 12 % denser than rest: positive pressures inside, clamped ones along its rim -- both branches of the update;
+    #  `wall`: the block sits in the lower left corner of the box, one spacing off two walls)
+    origin = [-2.0 + 1.024 * spacing, -1.0 + 1.024 * spacing] if wall else [-0.3, -0.3]
+    scn = sc.SceneConfig(sc.SceneBoundary("box", 4.0, 2.0), [sc.SceneFluidBlock(origin, [0.6001, 0.6001], spacing, 1.12, [0.0, 0.0])])
+    pos, mass, vel = sc.init_particles(scn)
+    assert len(mass) == 20 * 20
+    rng = np.random.default_rng(5)
+    pos = (pos + rng.uniform(-0.12, 0.12, pos.shape).astype(np.float32) * spacing).astype(np.float32)   # off the lattice: no symmetric cancellation
+    vel = np.stack([0.3 * pos[:, 0] + 0.1 * pos[:, 1], -0.2 * pos[:, 1] + 0.05 * np.sin(9.0 * pos[:, 0])], 1).astype(np.float32)
+    P = dam_break_params(pressure_solver_method=solver, max_dt=1.0e-4, max_iters=max_iters, iisph_max_avg_density_error=0.0,
+                         hybrid_dfsph_max_avg_density_error=0.0, hybrid_dfsph_max_avg_divergence_error=0.0, level_estimation_method="None", **kw)
+    assert P.operator_discretization == "ConsistentSimpleGradient" and P.support_length_estimation == "FromMass"
+    assert P.viscosity_type == "ApproxLaplace"
+    return scn, pos, mass, vel, P
+
+
+def _compare(ctx, pos, mass, vel, P, max_iters, tol, planes=()):
+    """one step of `ctx` (oracle or product) against the dense restatement; `tol` scales the bars (1 = the oracle's f32 rounding)"""
+    n = len(mass)
+    L = load_oracle().lib
+    ctx.upload(mass, pos, vel)
+    st = ctx.step(P.to_ffi())
+    assert st.dt == pytest.approx(1.0e-4, rel=1e-6)
+    assert st.density_solver.iters == max_iters           # num_pressure_iters at the break: max_iters + 1 iterations ran
+    ref = dense_step(pos, mass, vel, P, float(st.dt), max_iters + 1, planes, lambda d: float(L.oracle_lambda2(d)), lambda d: float(L.oracle_dlambda2(d)))
+    if P.pressure_solver_method == "HybridDFSPH":
+        assert st.div_solver.iters == max_iters
+        assert (ref["pressure_div"] > 0).sum() > 0
+    if len(planes):
+        assert (ref["lambda_sum"] > 0).sum() > 30
+        assert rel(ctx.download("lambda_sum"), ref["lambda_sum"]) <= 2e-6 * tol       # (the 10001-entry LUT against the closed form)
+        assert rel(ctx.download("lambda_grad_sum"), ref["lambda_grad_sum"]) <= 2e-5 * tol
+    else:
+        assert np.abs(ctx.download("lambda_sum")).max() == 0.0     # far from every wall: no boundary terms in this scene
+    assert np.array_equal(ctx.download("neighbor_count"), ref["neighbor_count"])
+    assert ref["neighbor_count"].min() >= 4 and ref["neighbor_count"].max() <= 24
+    assert np.abs(ref["aii"]).min() > 10e-4                                   # (nobody takes the singular branch)
+    assert (ref["pressure"] > 0).sum() > n // 2 and (ref["pressure"] == 0).sum() > n // 10     # both branches of the clamp
+    # measured with the oracle: 2e-7 (density), 6e-7 (a_ii: the closed form vs the diagonal of div . a^p), 3e-7 (source term),
+    # 1.6e-6 (pressure after 1 and after 4 iterations), 1e-6 (a^p), 1e-6 / 4e-6 of the velocity / position CHANGE of the step
+    assert rel(ctx.download("density"), ref["density"]) <= 2e-6 * tol
+    assert rel(ctx.download("aii"), ref["aii"]) <= 5e-6 * tol
+    assert rel(ctx.download("ppe_source_term"), ref["ppe_source_term"]) <= 5e-6 * tol
+    assert rel(ctx.download("pressure"), ref["pressure"]) <= 1e-5 * tol
+    assert rel(ctx.download("pressure_accel"), ref["pressure_accel"]) <= 1e-5 * tol
+    dv_o, dv_r = ctx.download("velocity").astype(np.float64) - vel, ref["velocity"] - vel
+    assert np.abs(dv_o - dv_r).max() <= 1e-5 * tol * np.abs(dv_r).max()
+    dx_o, dx_r = ctx.download("position").astype(np.float64) - pos, ref["position"] - pos
+    assert np.abs(dx_o - dx_r).max() <= 2e-5 * tol * np.abs(dx_r).max() + 1.2e-7
+
+
+CASES = [("IISPH", dict(viscosity=0.0)), ("IISPH", dict()), ("HybridDFSPH", dict()), ("IISPH", dict(wall=True)), ("HybridDFSPH", dict(wall=True)),
+         ("HybridDFSPH", dict(hybrid_dfsph_density_source_term="OnlyDensity", hybrid_dfsph_non_pressure_accel_before_divergence_free=False))]
+
+
+@pytest.mark.parametrize("solver,kw", CASES)
+@pytest.mark.parametrize("max_iters", [0, 3])
+def test_oracle_against_dense_f64_operators(max_iters, solver, kw):
+    scn, pos, mass, vel, P = _case(max_iters, solver, **kw)
+    planes = sc.boundary_planes(scn.boundary, P.init_boundary_handler)
+    o = ffi.Context(load_oracle(), len(mass), planes)
+    _compare(o, pos, mass, vel, P, max_iters, 1.0, planes if kw.get("wall") else ())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("solver,kw", CASES)
+@pytest.mark.parametrize("max_iters", [0, 3])
+def test_product_against_dense_f64_operators(product_lib, max_iters, solver, kw):
+    """The HIP path against the same independent statement, without the oracle in between (FAST pair arithmetic: v_rsq / v_rcp
+    approximations, the bars ten times the oracle's)."""
+    scn, pos, mass, vel, P = _case(max_iters, solver, **kw)
+    planes = sc.boundary_planes(scn.boundary, P.init_boundary_handler)
+    g = ffi.Context(product_lib, len(mass), planes)
+    _compare(g, pos, mass, vel, P, max_iters, 10.0, planes if kw.get("wall") else ())
