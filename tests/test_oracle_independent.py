@@ -126,7 +126,7 @@ def dense_step(pos, mass, vel, P, dt, n_iterations, planes=(), lam=None, dlam=No
         p, ap = solve(s)
         x = pos + dt * v2 + dt * dt * ap
         v = v2 + dt * ap * min(dt * P.hybrid_dfsph_factor, 1.0)
-    out.update(ppe_source_term=s, pressure=p, pressure_accel=ap, velocity=v, position=x)
+    out.update(ppe_source_term=s, pressure=p, pressure_accel=ap, velocity=v, position=x, _nb=nb, _hij=hij)
     return out
 
 
@@ -149,8 +149,9 @@ def _case(max_iters, solver="IISPH", wall=False, two_sizes=False, **kw):
     rng = np.random.default_rng(5)
     pos = (pos + rng.uniform(-0.12, 0.12, pos.shape).astype(np.float32) * spacing).astype(np.float32)   # off the lattice: no symmetric cancellation
     vel = np.stack([0.3 * pos[:, 0] + 0.1 * pos[:, 1], -0.2 * pos[:, 1] + 0.05 * np.sin(9.0 * pos[:, 0])], 1).astype(np.float32)
+    kw.setdefault("level_estimation_method", "None")
     P = dam_break_params(pressure_solver_method=solver, max_dt=1.0e-4, max_iters=max_iters, iisph_max_avg_density_error=0.0,
-                         hybrid_dfsph_max_avg_density_error=0.0, hybrid_dfsph_max_avg_divergence_error=0.0, level_estimation_method="None", **kw)
+                         hybrid_dfsph_max_avg_density_error=0.0, hybrid_dfsph_max_avg_divergence_error=0.0, **kw)
     assert P.operator_discretization == "ConsistentSimpleGradient" and P.support_length_estimation == "FromMass"
     assert P.viscosity_type == "ApproxLaplace"
     return scn, pos, mass, vel, P
@@ -215,3 +216,118 @@ def test_product_against_dense_f64_operators(product_lib, max_iters, solver, kw)
     planes = sc.boundary_planes(scn.boundary, P.init_boundary_handler)
     g = ffi.Context(product_lib, len(mass), planes)
     _compare(g, pos, mass, vel, P, max_iters, 10.0, planes if kw.get("wall") else ())
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# level estimation (before advection): detection by the empty 50-degree cone, Jacobi propagation, smoothing at the advected positions
+#   lists of range k = level_estimation_range / 1.9 smoothing lengths               simulation.rs:2018-2046
+#   n_i = -sum_j m_i / rho_0 grad W_ij; fewer than 3 list entries: surface (+ flag); |n|^2 < 1e-5: interior; closer than 1.5 h_i to a
+#   wall (unless boundary_is_fluid_surface): interior; else interior iff some j has (x_j - x_i) / (|x_j - x_i| + 1e-6) . n / |n| > cos 50
+#                                                                                      simulation.rs:540-612
+#   sweeps: an interior particle with surface neighbours (state of the PREVIOUS sweep) takes max_j (level_j - |x_j - x_i|), until a
+#   sweep assigns nothing; the stash after the detection / after the first sweep      simulation.rs:725-801, 886-893
+#   smoothing: Shepard average of max(level, -maximum_surface_distance) (interior: the bound) with m_j / rho_j W(x'_ij, h_ij) over the
+#   k = 2 lists of the step's start, at the advected positions x'                      simulation.rs:803-857, 2710-2721
+# ------------------------------------------------------------------------------------------------------------------------------
+def dense_level(pos, mass, P, planes=()):
+    pos, mass = pos.astype(np.float64), mass.astype(np.float64)
+    n = len(mass)
+    h = 1.9 * np.sqrt(mass / P.rest_density / np.pi)
+    d = pos[:, None, :] - pos[None, :, :]
+    r = np.sqrt((d ** 2).sum(2))
+    hij = 0.5 * (h[:, None] + h[None, :])
+    ext = r < hij * (P.level_estimation_range / 1.9)
+    q = r / (2.0 * hij)
+    nf = 10.0 / (7.0 * np.pi * hij ** 2)
+    dw = np.where(q < 0.5, 18.0 * q ** 2 - 12.0 * q, np.where(q < 1.0, -6.0 * (1.0 - q) ** 2, 0.0))
+    with np.errstate(invalid="ignore", divide="ignore"):
+        unit = np.where((q > 1.0e-5)[:, :, None], d / r[:, :, None], 0.0)
+    G = (nf * dw / (2.0 * hij) * ext)[:, :, None] * unit
+    normal = -(mass / P.rest_density)[:, None] * G.sum(1)
+    wall_dist = np.full(n, np.inf)
+    for (nx, ny, delta) in planes:
+        wall_dist = np.minimum(wall_dist, nx * pos[:, 0] + ny * pos[:, 1] + delta)
+    thr = np.cos(50.0 * np.pi / 180.0)
+    surface, insufficient = np.zeros(n, bool), np.zeros(n, bool)
+    for i in range(n):
+        js = np.nonzero(ext[i])[0]
+        if len(js) < 3:
+            surface[i] = insufficient[i] = True
+        elif (normal[i] ** 2).sum() < 0.00001:
+            pass
+        elif not P.boundary_is_fluid_surface and wall_dist[i] < h[i] * 1.5:
+            pass
+        else:
+            nn = normal[i] / np.sqrt((normal[i] ** 2).sum())
+            xji = -d[i, js] / (r[i, js] + 0.000001)[:, None]
+            surface[i] = not ((xji @ nn) > thr).any()
+    level = np.where(surface, 0.0, np.nan)
+    first = level.copy()
+    middle, sweeps = None, 0
+    while True:
+        have = ~np.isnan(level)
+        est = np.where((ext & have[None, :]), level[None, :] - r, -np.inf).max(1)
+        new = np.where(have, level, np.where(np.isfinite(est), est, np.nan))
+        changed = (~have & ~np.isnan(new)).any()
+        level = new
+        sweeps += 1
+        if sweeps == 1:
+            middle = level.copy()
+        if not changed:
+            break
+    return dict(surface=surface, insufficient=insufficient, first=first, middle=middle, level=level, sweeps=sweeps)
+
+
+def dense_smooth(level, step, mass, P):
+    x = step["position"]
+    d = x[:, None, :] - x[None, :, :]
+    r = np.sqrt((d ** 2).sum(2))
+    hij, nb = step["_hij"], step["_nb"]
+    q = r / (2.0 * hij)
+    w = np.where(q < 0.5, 6.0 * (q ** 3 - q ** 2) + 1.0, np.where(q < 1.0, 2.0 * (1.0 - q) ** 3, 0.0))
+    W = 10.0 / (7.0 * np.pi * hij ** 2) * w * nb
+    msd = P.maximum_surface_distance
+    dist = np.where(np.isnan(level), -msd, np.maximum(level, -msd))
+    vol = (mass.astype(np.float64) / step["density"])[None, :] * W
+    return (vol * dist[None, :]).sum(1) / vol.sum(1)
+
+
+def _compare_level(ctx, stash_mode, tol, wall):
+    scn, pos, mass, vel, P = _case(2, "HybridDFSPH", wall=wall, level_estimation_method="EmptyAngle", maximum_surface_distance=0.2)
+    assert P.level_estimation_method == "EmptyAngle" and not P.level_estimation_after_advection and not P.boundary_is_fluid_surface
+    P.fill_stash_with = stash_mode
+    planes = sc.boundary_planes(scn.boundary, P.init_boundary_handler)
+    L = load_oracle().lib
+    ctx.upload(mass, pos, vel)
+    st = ctx.step(P.to_ffi())
+    lv = dense_level(pos, mass, P, planes)
+    step = dense_step(pos, mass, vel, P, float(st.dt), 3, planes if wall else (), lambda d: float(L.oracle_lambda2(d)), lambda d: float(L.oracle_dlambda2(d)))
+    n = len(mass)
+    assert 30 < lv["surface"].sum() < n // 2 and lv["sweeps"] >= 4
+    assert np.isnan(lv["level"]).sum() == 0                                            # the field reaches every particle of this block
+    assert (lv["level"] < -P.maximum_surface_distance).sum() > 10                      # ... and some lie below the bound the smoothing clamps to
+    assert np.array_equal(ctx.download("flag_is_fluid_surface").astype(bool), lv["surface"])
+    assert np.array_equal(ctx.download("flag_insufficient_neighs").astype(bool), lv["insufficient"])
+    ref_stash = lv["first"] if stash_mode == "SurfaceDistanceFirstIteration" else lv["middle"]
+    ref_stash = np.where(np.isnan(ref_stash), -P.maximum_surface_distance, ref_stash)
+    assert np.abs(ctx.download("stash") - ref_stash).max() <= 2e-6 * tol * max(np.abs(ref_stash).max(), 1e-30)
+    sm = dense_smooth(lv["level"], step, mass, P)
+    for f in ("level_estimation", "level_old"):
+        assert np.abs(ctx.download(f) - sm).max() <= 5e-6 * tol * np.abs(sm).max(), f
+
+
+@pytest.mark.parametrize("wall", [False, True])
+@pytest.mark.parametrize("stash_mode", ["SurfaceDistanceFirstIteration", "SurfaceDistanceMiddle"])
+def test_oracle_level_estimation_against_dense_restatement(stash_mode, wall):
+    scn, pos, mass, vel, P = _case(2, "HybridDFSPH", wall=wall)
+    o = ffi.Context(load_oracle(), len(mass), sc.boundary_planes(scn.boundary, P.init_boundary_handler))
+    _compare_level(o, stash_mode, 1.0, wall)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("wall", [False, True])
+@pytest.mark.parametrize("stash_mode", ["SurfaceDistanceFirstIteration", "SurfaceDistanceMiddle"])
+def test_product_level_estimation_against_dense_restatement(product_lib, stash_mode, wall):
+    scn, pos, mass, vel, P = _case(2, "HybridDFSPH", wall=wall)
+    g = ffi.Context(product_lib, len(mass), sc.boundary_planes(scn.boundary, P.init_boundary_handler))
+    _compare_level(g, stash_mode, 10.0, wall)
