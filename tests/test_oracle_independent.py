@@ -52,11 +52,11 @@ def boundary_terms(pos, h, planes, penalty_term, lam, dlam):
 
 
 def dense_step(pos, mass, vel, P, dt, n_iterations, planes=(), lam=None, dlam=None):
-    """one step (IISPH or HybridDFSPH, viscosity ApproxLaplace, plane boundaries in the ConsistentSimpleGradient discretisation) as
+    """one step (IISPH or HybridDFSPH, viscosity ApproxLaplace, plane boundaries, the three operator discretisations) as
     dense f64 linear algebra; every solve runs `n_iterations` Jacobi iterations from p = 0"""
     pos, mass, vel = pos.astype(np.float64), mass.astype(np.float64), vel.astype(np.float64)
     n = len(mass)
-    rest_density, omega = P.rest_density, P.jacobi_omega
+    rest_density, omega, disc = P.rest_density, P.jacobi_omega, P.operator_discretization
     h = 1.9 * np.sqrt(mass / rest_density / np.pi)
     d = pos[:, None, :] - pos[None, :, :]                     # x_ij
     r = np.sqrt((d ** 2).sum(2))
@@ -84,14 +84,16 @@ def dense_step(pos, mass, vel, P, dt, n_iterations, planes=(), lam=None, dlam=No
     # the two operators as matrices per component c: div(Q) = sum_c D_c Q_c ;  a^p_c = A_c p
     D, A = [], []
     for c in range(2):
-        Dc = mass[None, :] / rho[:, None] * G[:, :, c]
-        Dc[np.arange(n), np.arange(n)] -= Dc.sum(1)           # -Q_i sum_j m_j / rho_i grad W_ij  (the j = i entry of G is zero)
+        # (Winchenbach2020 weighs the divergence's pairs with m_j / rho_j instead of m_j / rho_i, simulation.rs:1571-1580)
+        Dc = (mass[None, :] / rho[None, :] if disc == "Winchenbach2020" else mass[None, :] / rho[:, None]) * G[:, :, c]
+        Dc[np.arange(n), np.arange(n)] -= Dc.sum(1)           # -Q_i sum_j ... grad W_ij  (the j = i entry of G is zero)
         Ac = -mass[None, :] / rho[None, :] ** 2 * G[:, :, c]
         Ac[np.arange(n), np.arange(n)] += -(mass[None, :] * G[:, :, c]).sum(1) / rho ** 2
         # the walls: div += rho_0 / rho_i (0 - Q_i) . sum grad lambda ;  a^p += -rho_0 (p_i / rho_i^2 + 0) sum grad lambda
         # (boundary_winchenbach2020.rs:165-223, p_ib = 0 and rho_b = rho_0 in this discretisation)
-        Dc[np.arange(n), np.arange(n)] += -rest_density / rho * lam_grad[:, c]
-        Ac[np.arange(n), np.arange(n)] += -rest_density / rho ** 2 * lam_grad[:, c]
+        # (Winchenbach2020: the wall's divergence term without rho_0 / rho_i; ConsistentSymmetricGradient: p_ib = p_i)
+        Dc[np.arange(n), np.arange(n)] += -(1.0 if disc == "Winchenbach2020" else rest_density / rho) * lam_grad[:, c]
+        Ac[np.arange(n), np.arange(n)] += -rest_density * (1.0 / rho ** 2 + (1.0 / rest_density ** 2 if disc == "ConsistentSymmetricGradient" else 0.0)) * lam_grad[:, c]
         D.append(Dc)
         A.append(Ac)
     div = lambda Q: D[0] @ Q[:, 0] + D[1] @ Q[:, 1]          # noqa: E731
@@ -107,7 +109,7 @@ def dense_step(pos, mass, vel, P, dt, n_iterations, planes=(), lam=None, dlam=No
         return p, accel(p)
 
     out = dict(density=rho, neighbor_count=counts, aii=aii, lambda_sum=lam_sum, lambda_grad_sum=lam_grad)
-    dens_part = -(rest_density - rho) / (rho * dt * dt)
+    dens_part = -(rest_density - rho) / ((rest_density if disc == "Winchenbach2020" else rho) * dt * dt)   # simulation.rs:1661-1676, 1733-1745
     if P.pressure_solver_method == "IISPH":                                  # simulation.rs:2389-2446
         vstar = vel + dt * non_pressure(vel)
         s = dens_part - div(vstar) / dt
@@ -152,7 +154,7 @@ def _case(max_iters, solver="IISPH", wall=False, two_sizes=False, **kw):
     kw.setdefault("level_estimation_method", "None")
     P = dam_break_params(pressure_solver_method=solver, max_dt=1.0e-4, max_iters=max_iters, iisph_max_avg_density_error=0.0,
                          hybrid_dfsph_max_avg_density_error=0.0, hybrid_dfsph_max_avg_divergence_error=0.0, **kw)
-    assert P.operator_discretization == "ConsistentSimpleGradient" and P.support_length_estimation == "FromMass"
+    assert P.support_length_estimation == "FromMass"
     assert P.viscosity_type == "ApproxLaplace"
     return scn, pos, mass, vel, P
 
@@ -194,6 +196,9 @@ def _compare(ctx, pos, mass, vel, P, max_iters, tol, planes=()):
 
 CASES = [("IISPH", dict(viscosity=0.0)), ("IISPH", dict()), ("HybridDFSPH", dict()), ("IISPH", dict(wall=True)), ("HybridDFSPH", dict(wall=True)),
          ("HybridDFSPH", dict(wall=True, two_sizes=True)),
+         ("HybridDFSPH", dict(wall=True, operator_discretization="ConsistentSymmetricGradient")),
+         ("HybridDFSPH", dict(wall=True, two_sizes=True, operator_discretization="Winchenbach2020")),
+         ("IISPH", dict(wall=True, operator_discretization="Winchenbach2020")),
          ("HybridDFSPH", dict(hybrid_dfsph_density_source_term="OnlyDensity", hybrid_dfsph_non_pressure_accel_before_divergence_free=False))]
 
 
