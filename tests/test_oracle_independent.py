@@ -74,11 +74,15 @@ def dense_step(pos, mass, vel, P, dt, n_iterations, planes=(), lam=None, dlam=No
     rho = (mass[None, :] * W).sum(1) + lam_sum                # density_boundary_term = sum lambda (boundary_winchenbach2020.rs:154-163)
     counts = nb.sum(1)
 
-    def non_pressure(v):    # simulation.rs:931-1005: ApproxLaplace viscosity over the approaching pairs, gravity
+    def non_pressure(v):    # simulation.rs:931-1005: viscosity over the approaching pairs (ApproxLaplace or WCSPH), gravity
         xv = (d * (v[:, None, :] - v[None, :, :])).sum(2)
-        rho_ij = 0.5 * (rho[:, None] + rho[None, :])
-        coeff = 2.0 * 4.0 * (mass[None, :] / rho_ij) * xv / (r ** 2 + 0.01 * hij ** 2)
-        visc = P.viscosity * ((coeff * (xv < 0.0) * nb)[:, :, None] * G).sum(1)
+        if P.viscosity_type == "WCSPH":   # -m_j Pi_ij grad W_ij, Pi_ij = -2 nu h_ij c / (rho_i + rho_j) (x . v) / (|x|^2 + 0.001 h_ij^2), c = 88
+            pi_ab = -(2.0 * P.viscosity * hij * 88.0 / (rho[:, None] + rho[None, :])) * xv / (r ** 2 + 0.001 * hij ** 2)
+            visc = ((-mass[None, :] * pi_ab * (xv < 0.0) * nb)[:, :, None] * G).sum(1)
+        else:
+            rho_ij = 0.5 * (rho[:, None] + rho[None, :])
+            coeff = 2.0 * 4.0 * (mass[None, :] / rho_ij) * xv / (r ** 2 + 0.01 * hij ** 2)
+            visc = P.viscosity * ((coeff * (xv < 0.0) * nb)[:, :, None] * G).sum(1)
         return visc + np.array([0.0, P.gravity])
 
     # the two operators as matrices per component c: div(Q) = sum_c D_c Q_c ;  a^p_c = A_c p
@@ -155,7 +159,6 @@ def _case(max_iters, solver="IISPH", wall=False, two_sizes=False, **kw):
     P = dam_break_params(pressure_solver_method=solver, max_dt=1.0e-4, max_iters=max_iters, iisph_max_avg_density_error=0.0,
                          hybrid_dfsph_max_avg_density_error=0.0, hybrid_dfsph_max_avg_divergence_error=0.0, **kw)
     assert P.support_length_estimation == "FromMass"
-    assert P.viscosity_type == "ApproxLaplace"
     return scn, pos, mass, vel, P
 
 
@@ -199,6 +202,7 @@ CASES = [("IISPH", dict(viscosity=0.0)), ("IISPH", dict()), ("HybridDFSPH", dict
          ("HybridDFSPH", dict(wall=True, operator_discretization="ConsistentSymmetricGradient")),
          ("HybridDFSPH", dict(wall=True, two_sizes=True, operator_discretization="Winchenbach2020")),
          ("IISPH", dict(wall=True, operator_discretization="Winchenbach2020")),
+         ("IISPH", dict(viscosity_type="WCSPH", viscosity=0.05)),
          ("HybridDFSPH", dict(hybrid_dfsph_density_source_term="OnlyDensity", hybrid_dfsph_non_pressure_accel_before_divergence_free=False))]
 
 
@@ -336,3 +340,19 @@ def test_product_level_estimation_against_dense_restatement(product_lib, stash_m
     scn, pos, mass, vel, P = _case(2, "HybridDFSPH", wall=wall)
     g = ffi.Context(product_lib, len(mass), sc.boundary_planes(scn.boundary, P.init_boundary_handler))
     _compare_level(g, stash_mode, 10.0, wall)
+
+
+@pytest.mark.parametrize("which", ["oracle", pytest.param("product", marks=pytest.mark.gpu)])
+def test_cfl_time_step_against_its_formula(which, request):
+    """dt = min(max_dt, cfl_factor sqrt(min_i (2 h_i)^2 / (|v_i|^2 + 0.01)))   (simulation.rs:2182-2191), the CFL branch active"""
+    scn, pos, mass, vel, P = _case(1, "IISPH")
+    P = P.replace(max_dt=1.0)
+    vel = (vel * 40.0).astype(np.float32)
+    lib = load_oracle() if which == "oracle" else request.getfixturevalue("product_lib")
+    ctx = ffi.Context(lib, len(mass), sc.boundary_planes(scn.boundary, P.init_boundary_handler))
+    ctx.upload(mass, pos, vel)
+    st = ctx.step(P.to_ffi())
+    h = 1.9 * np.sqrt(mass.astype(np.float64) / P.rest_density / np.pi)
+    dt = P.cfl_factor * np.sqrt(((2.0 * h) ** 2 / ((vel.astype(np.float64) ** 2).sum(1) + 0.01)).min())
+    assert dt < 0.5 * P.max_dt
+    assert st.dt == pytest.approx(dt, rel=2e-6)
