@@ -120,6 +120,22 @@ def dense_step(pos, mass, vel, P, dt, n_iterations, planes=(), lam=None, dlam=No
         p, ap = solve(s)
         v = vstar + dt * ap
         x = pos + dt * v
+    elif P.pressure_solver_method == "IISPH2":                               # simulation.rs:2262-2387 (every particle's size class Optimal)
+        Hi, Hij = 2.0 * h, 2.0 * hij
+        qq = r / Hij
+        wq = np.where(qq < 0.5, 6.0 * (qq ** 3 - qq ** 2) + 1.0, np.where(qq < 1.0, 2.0 * (1.0 - qq) ** 3, 0.0))
+        dwq = np.where(qq < 0.5, 18.0 * qq ** 2 - 12.0 * qq, np.where(qq < 1.0, -6.0 * (1.0 - qq) ** 2, 0.0))
+        cd = 40.0 / (7.0 * np.pi)
+        dwdh = cd * -2.0 / Hij ** 3 * wq + cd / Hij ** 2 * dwq * (-r / Hij ** 2)
+        om = np.minimum(2.5, np.maximum(1.0 + ((Hi / (3.0 * rho))[:, None] * (mass[None, :] * dwdh * nb)).sum(1), 0.125))
+        out["omega"] = om
+        vstar = vel + dt * non_pressure(vel)
+        s = -(rest_density - rho) / (rest_density * dt * dt) - div(vstar) / (dt * om)
+        p, _ = solve(s)
+        p = p / np.sqrt(om)
+        ap = accel(p)
+        v = vstar + dt * ap
+        x = pos + dt * v
     else:                                                                    # HybridDFSPH, simulation.rs:2502-2670
         before = P.hybrid_dfsph_non_pressure_accel_before_divergence_free
         v1 = vel + dt * non_pressure(vel) if before else vel
@@ -203,6 +219,7 @@ CASES = [("IISPH", dict(viscosity=0.0)), ("IISPH", dict()), ("HybridDFSPH", dict
          ("HybridDFSPH", dict(wall=True, two_sizes=True, operator_discretization="Winchenbach2020")),
          ("IISPH", dict(wall=True, operator_discretization="Winchenbach2020")),
          ("IISPH", dict(viscosity_type="WCSPH", viscosity=0.05)),
+         ("IISPH2", dict()), ("IISPH2", dict(wall=True)),
          ("HybridDFSPH", dict(hybrid_dfsph_density_source_term="OnlyDensity", hybrid_dfsph_non_pressure_accel_before_divergence_free=False))]
 
 
