@@ -340,6 +340,23 @@ def _compare_level(ctx, stash_mode, tol, wall):
     sm = dense_smooth(lv["level"], step, mass, P)
     for f in ("level_estimation", "level_old"):
         assert np.abs(ctx.download(f) - sm).max() <= 5e-6 * tol * np.abs(sm).max(), f
+    # classify_particles (adaptivity/mod.rs:24-59) from LevelEstimationState::target_mass (simulation.rs:213-237), three sizing functions
+    for sizing in ("Mass", "Radius", "Radius2"):
+        Pc = P.replace(sizing_function=sizing, particle_radius_fine=0.012, particle_radius_base=0.03)
+        ctx.classify(Pc.to_ffi())
+        t = np.maximum(sm, -Pc.maximum_surface_distance) / -Pc.maximum_surface_distance
+        vol = lambda rad: np.pi * rad * rad                                            # noqa: E731
+        if sizing == "Mass":
+            target = (vol(0.012) * (1.0 - t) + vol(0.03) * t) * Pc.rest_density
+        else:
+            tt = t if sizing == "Radius" else np.sqrt(t)
+            target = vol(0.012 * (1.0 - tt) + 0.03 * tt) * Pc.rest_density
+        mrel = mass.astype(np.float64) / target
+        cls = np.where(mrel <= 0.5, 0, np.where(mrel <= 1.0 / 1.1, 1, np.where(mrel < 1.1, 2, np.where(mrel < 2.0, 3, 4))))
+        near = np.min(np.abs(mrel[:, None] - np.array([0.5, 1.0 / 1.1, 1.1, 2.0])[None, :]), 1) < 1e-4 * tol
+        got = ctx.download("particle_size_class")
+        assert len(np.unique(cls)) >= 4, sizing
+        assert np.array_equal(got[~near], cls[~near]), sizing
 
 
 @pytest.mark.parametrize("wall", [False, True])
