@@ -156,6 +156,19 @@ struct MathFast {
         gx = s * dx;
         gy = s * dy;
     }
+    // W and the gradient's scale of one pair from ONE reciprocal square root and one set of truncated powers (a sweep that needs
+    // both -- a_ii + constant field -- otherwise pays a v_sqrt, a v_rsq and the two v_max twice): q from the rsq path for both
+    __device__ __forceinline__ void wg(float r2, float hij, float& wv, float& s) const
+    {
+        const float r2c = fmaxf(r2, SPH_R2_FLOOR);
+        const float rinv = fast_rsq(r2c);
+        const float inv2h = fast_rcp(hij + hij);
+        const float q = (r2c * rinv) * inv2h;
+        const float u = fmaxf(1.f - q, 0.f), t = fmaxf(0.5f - q, 0.f);
+        const float i2 = inv2h * inv2h;
+        wv = ((80.f / SPH_SEVEN_PI) * i2) * fmaf(-4.f * t, t * t, u * (u * u));
+        s = (((240.f / SPH_SEVEN_PI) * inv2h) * i2) * (fmaf(4.f * t, t, -(u * u)) * rinv);
+    }
 };
 struct MathUniform {
     static constexpr bool EXACT = false, UNIFORM = true;
@@ -181,6 +194,15 @@ struct MathUniform {
         const float s = gscale(r2, 0.f);
         gx = s * dx;
         gy = s * dy;
+    }
+    __device__ __forceinline__ void wg(float r2, float, float& wv, float& s) const   // see MathFast::wg
+    {
+        const float r2c = fmaxf(r2, SPH_R2_FLOOR);
+        const float rinv = fast_rsq(r2c);
+        const float q = (r2c * rinv) * inv2h;
+        const float u = fmaxf(1.f - q, 0.f), t = fmaxf(0.5f - q, 0.f);
+        wv = nf2 * fmaf(-4.f * t, t * t, u * (u * u));
+        s = nf6 * (fmaf(4.f * t, t, -(u * u)) * rinv);
     }
 };
 

@@ -875,9 +875,17 @@ struct OpAiiConst {
     __device__ void begin(Acc& a, uint32_t, float4) const { a.cf = a.ax = a.ay = a.a2 = a.bx = a.by = 0.f; }
     __device__ void pair(Acc& a, float4 Aj, NB mr, float dx, float dy, float r2, float hij) const
     {
-        a.cf += mr * m.w(r2, hij);
         float gx, gy;
-        m.grad(dx, dy, r2, hij, gx, gy);
+        if constexpr (MathT::EXACT) {
+            a.cf += mr * m.w(r2, hij);
+            m.grad(dx, dy, r2, hij, gx, gy);
+        } else {   // W and grad W from one rsq (MathFast::wg)
+            float wv, sc;
+            m.wg(r2, hij, wv, sc);
+            a.cf += mr * wv;
+            gx = sc * dx;
+            gy = sc * dy;
+        }
         a.ax += Aj.z * gx;
         a.ay += Aj.z * gy;
         if (sp.opdisc == SPH_OP_WINCHENBACH2020) {
