@@ -993,7 +993,7 @@ struct OpNonPressure {
             const float den = r2 + 0.01f * hij * hij;
             float coeff;
             if (MathT::EXACT) coeff = 2.f * 4.f * (Aj.z / rho_ij) * xv / den;
-            else coeff = 8.f * (Aj.z * fast_rcp(rho_ij)) * xv * fast_rcp(den);
+            else coeff = 8.f * (Aj.z * xv) * fast_rcp(rho_ij * den);   // (one reciprocal for both divisors)
             const float f = sp.viscosity * coeff;
             a.vx += f * gx;
             a.vy += f * gy;
