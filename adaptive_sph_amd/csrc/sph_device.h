@@ -300,6 +300,32 @@ __device__ __forceinline__ float wave_max(float v)
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_down(v, o, 64));
     return v;
 }
+// wave64 reductions on the DPP network (row_shr 1, 2, 4, 8 inside the rows of 16, then row_bcast:15 and row_bcast:31): seven 4-clock
+// VALU instructions and no LDS round trip, against six ds_bpermute_b32 (what __shfl_down compiles to on gfx9: ~24 clocks of issue
+// and an LDS latency each, as a dependent chain).  The total arrives in lane 63 and is broadcast from there.  A lane without a
+// source in a step receives `old` = 0: the sum's neutral element, and the maximum's as long as the values are not negative.
+#define SPH_DPP(V, CTRL, ROWMASK) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(V), CTRL, ROWMASK, 0xf, false))
+__device__ __forceinline__ float wave_sum_dpp(float v)
+{
+    v += SPH_DPP(v, 0x111, 0xf);   // row_shr:1
+    v += SPH_DPP(v, 0x112, 0xf);   // row_shr:2
+    v += SPH_DPP(v, 0x114, 0xf);   // row_shr:4
+    v += SPH_DPP(v, 0x118, 0xf);   // row_shr:8   -> lane 15 of every row: the row's sum
+    v += SPH_DPP(v, 0x142, 0xa);   // row_bcast:15 into rows 1 and 3
+    v += SPH_DPP(v, 0x143, 0xc);   // row_bcast:31 into rows 2 and 3
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ float wave_max_nonneg_dpp(float v)   // v >= 0 on every lane
+{
+    v = fmaxf(v, SPH_DPP(v, 0x111, 0xf));
+    v = fmaxf(v, SPH_DPP(v, 0x112, 0xf));
+    v = fmaxf(v, SPH_DPP(v, 0x114, 0xf));
+    v = fmaxf(v, SPH_DPP(v, 0x118, 0xf));
+    v = fmaxf(v, SPH_DPP(v, 0x142, 0xa));
+    v = fmaxf(v, SPH_DPP(v, 0x143, 0xc));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+#undef SPH_DPP
 __device__ __forceinline__ float wave_min(float v)
 {
     for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_down(v, o, 64));

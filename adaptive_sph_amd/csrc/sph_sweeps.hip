@@ -1053,8 +1053,10 @@ __device__ __forceinline__ void solver_block_partial(SolverPartial* __restrict__
     const uint32_t normal = (uint32_t)__popcll(__ballot(cls == 0u));
     const uint32_t singular = (uint32_t)__popcll(__ballot(cls == 1u));
     const uint32_t negative = (uint32_t)__popcll(__ballot(cls == 2u));
-    float sum = wave_sum(cls == 0u ? err : 0.f);
-    float mx = wave_max(cls == 0u ? fabsf(err) : 0.f);
+    // (a wave of the sweep may hold idle lanes -- the array's tail, ghosts: the caller passes cls = 3 for them, and every lane of
+    //  the block reaches this point, so the DPP network sees all 64)
+    float sum = wave_sum_dpp(cls == 0u ? err : 0.f);
+    float mx = wave_max_nonneg_dpp(cls == 0u ? fabsf(err) : 0.f);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     if (lane == 0) s_w[w] = SolverPartial{normal, singular, negative, sum, mx};
     __syncthreads();
