@@ -326,6 +326,29 @@ __device__ __forceinline__ float wave_max_nonneg_dpp(float v)   // v >= 0 on eve
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 #undef SPH_DPP
+// minimum / maximum of any floats the same way (a lane without a source receives +inf / -inf); exact, so bit-identical to any other order
+#define SPH_DPPO(V, OLD, CTRL, ROWMASK) __int_as_float(__builtin_amdgcn_update_dpp((int)(OLD), __float_as_int(V), CTRL, ROWMASK, 0xf, false))
+__device__ __forceinline__ float wave_min_dpp(float v)
+{
+    v = fminf(v, SPH_DPPO(v, 0x7f800000u, 0x111, 0xf));
+    v = fminf(v, SPH_DPPO(v, 0x7f800000u, 0x112, 0xf));
+    v = fminf(v, SPH_DPPO(v, 0x7f800000u, 0x114, 0xf));
+    v = fminf(v, SPH_DPPO(v, 0x7f800000u, 0x118, 0xf));
+    v = fminf(v, SPH_DPPO(v, 0x7f800000u, 0x142, 0xa));
+    v = fminf(v, SPH_DPPO(v, 0x7f800000u, 0x143, 0xc));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ float wave_max_dpp(float v)
+{
+    v = fmaxf(v, SPH_DPPO(v, 0xff800000u, 0x111, 0xf));
+    v = fmaxf(v, SPH_DPPO(v, 0xff800000u, 0x112, 0xf));
+    v = fmaxf(v, SPH_DPPO(v, 0xff800000u, 0x114, 0xf));
+    v = fmaxf(v, SPH_DPPO(v, 0xff800000u, 0x118, 0xf));
+    v = fmaxf(v, SPH_DPPO(v, 0xff800000u, 0x142, 0xa));
+    v = fmaxf(v, SPH_DPPO(v, 0xff800000u, 0x143, 0xc));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+#undef SPH_DPPO
 __device__ __forceinline__ float wave_min(float v)
 {
     for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_down(v, o, 64));

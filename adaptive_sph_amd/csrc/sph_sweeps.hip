@@ -1574,8 +1574,9 @@ __global__ __launch_bounds__(256) void k_solver_tail(uint32_t n, int tail, float
     float mnx = active ? nx : INF, mxx = active ? nx : -INF, mny = active ? ny : INF, mxy = active ? ny : -INF;
     float hmx = active ? nh : 0.f, hmn = active ? nh : INF;
     float cfl = active ? ncfl : INF;
-    mnx = wave_min(mnx); mny = wave_min(mny); mxx = wave_max(mxx); mxy = wave_max(mxy);
-    hmx = wave_max(hmx); hmn = wave_min(hmn); cfl = wave_min(cfl);
+    // (every thread of the block is here -- the exits above are launch- or block-uniform: the DPP network sees full waves)
+    mnx = wave_min_dpp(mnx); mny = wave_min_dpp(mny); mxx = wave_max_dpp(mxx); mxy = wave_max_dpp(mxy);
+    hmx = wave_max_dpp(hmx); hmn = wave_min_dpp(hmn); cfl = wave_min_dpp(cfl);
     __shared__ HeaderOut s_h[4];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     if (lane == 0) s_h[w] = HeaderOut{mnx, mny, mxx, mxy, hmx, hmn, cfl, 0};
