@@ -85,6 +85,7 @@ struct sph_ctx {
     volatile uint32_t* prog_host = nullptr;   // paced solves: the device's last stop decision (behind ctrl_host[1]; SweepArgs::prog_host)
     uint32_t* prog_host_dev = nullptr;
     uint32_t solve_epoch = 0;
+    bool paced_step = false;   // this step's solves are paced (SPH_PACED, read once per step)
     hipEvent_t ev_sync = nullptr;
 
     // ---- slab decomposition (multi-GPU): this context owns x in [cut_lo, cut_hi) -------------------

@@ -521,10 +521,7 @@ static uint32_t pace_setting(const char* name, uint32_t dflt)
     const char* e = getenv(name);
     return e ? (uint32_t)atoi(e) : dflt;
 }
-static bool paced_enabled()
-{
-    return pace_setting("SPH_PACED", 1u) != 0u;   // 0: predicted queue + waits (the multi-rank form) on one context too (read per solve: the tests switch it)
-}
+
 // Small scenes: an iteration of n particles takes ~46 us x n / 2^20 on the device, the host's answer to a decision ~10-20 us: the
 // lead grows as the sweeps shrink (1 from ~0.45M particles up), and the unpaced head is the smaller of the last two counts; large
 // scenes queue nothing unpaced (measured on configs[1]'s driver window: 1.148 ms/step, against 1.164 with the head and 1.201-1.207
@@ -597,7 +594,7 @@ static int pressure_iterations(Group& G, std::vector<Member>& M, float max_avg_e
     int rc;
     const int multi = G.multi() ? 1 : 0;
     SolveQ q{max_avg_error, residual_density, max_iters, tail, density_solver};
-    if (!multi && M[0].n > 0 && paced_enabled()) {
+    if (!multi && M[0].n > 0 && M[0].c->paced_step) {
         sph_ctx* c0 = M[0].c;
         const uint32_t head = density_solver ? pace_prediction(M[0].n, c0->last_dens_iters, c0->prev_dens_iters) : pace_prediction(M[0].n, c0->last_div_iters, c0->prev_div_iters);
         if ((rc = solve_paced(G, M, q, head))) return rc;
@@ -650,6 +647,10 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
     for (auto c : G.m)
         if (c->poisoned) return c->fail(SPH_ERR_POISONED, "an earlier step failed inside the step: the particle state is undefined until sph_upload");
     *started = true;   // from here on a failure leaves the state half-stepped
+    // measurement / test switches of the solves, read ONCE per step (never inside the iteration path)
+    const bool no_records = getenv("SPH_ACCEL_GENERIC") != nullptr;   // sweep A through the generic form
+    const bool paced = !G.multi() && pace_setting("SPH_PACED", 1u) != 0u;   // 0: predicted queue + waits on one context too
+    for (auto c : G.m) c->paced_step = paced;
     for (auto c : G.m) c->publish_folded = false;
 
     // ---- slab maintenance part 1 needs no global scalar: partition + migrate (multi-rank) -----------------
@@ -917,7 +918,7 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
         }
         if (tev) (void)hipEventRecord(c->ev[1], s);
         m.a = make_args(c, sp);
-        if (p->pressure_solver_method == SPH_SOLVER_IISPH2) m.a.rec0 = m.a.rec1 = nullptr;   // (its rescaling works on p and p / rho^2)
+        if (p->pressure_solver_method == SPH_SOLVER_IISPH2 || no_records) m.a.rec0 = m.a.rec1 = nullptr;   // (IISPH2's rescaling works on p and p / rho^2)
         m.a.h_mode = p->support_length_estimation;
         m.a.sp_check_aii = p->check_aii;
         m.st.n_particles = c->n;
@@ -1441,7 +1442,7 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
         // in the first steps of a dam break it jumps by factors (4, 15, 17, 7, ...), and a short-fall there throws away a
         // density solve's worth of gated launches (measured: 1.38 vs 1.27 ms/step over steps 5-24 when always chained).
         // (parameters and all-reduced iteration counts only: every rank decides the same)
-        if (!G.multi() && M[0].n > 0 && paced_enabled()) {
+        if (paced && M[0].n > 0) {
             // one context: both solves paced against the device's progress, ONE host wait at the end of the step
             SolveQ qd{p->hybrid_dfsph_max_avg_divergence_error, 0, p->max_iters, T_VEL, false};
             SolveQ qs{p->hybrid_dfsph_max_avg_density_error, 1, p->max_iters, T_HYBRID, true};

@@ -2609,15 +2609,15 @@ static bool jacobi_generic()
     static const bool v = getenv("SPH_JACOBI_GENERIC") != nullptr;
     return v;
 }
-// SPH_ACCEL_GENERIC (read per launch: the tests compare both forms in one process): sweep A of such scenes through OpPressureAccel,
-// the solves' p / rho^2 as a field of its own
+// SPH_ACCEL_GENERIC (read once per step by the step driver, which then passes no record buffers: the tests compare both forms in one
+// process): sweep A of such scenes through OpPressureAccel, the solves' p / rho^2 as a field of its own
 static bool jacobi_on_records(const SweepArgs& a)   // sweep B gathers {x, y, a^p} whole (OpJacobiU)
 {
     return !a.exact && a.uniform_h && a.h_mode == SPH_H_FROM_MASS && a.sp.opdisc != SPH_OP_WINCHENBACH2020 && !jacobi_generic();
 }
 static bool solve_on_records(const SweepArgs& a)    // ... and sweep A {x, y, p / rho^2, p} (OpPressureAccelU): one context, not IISPH2
 {
-    return jacobi_on_records(a) && a.rec0 != nullptr && a.owned == nullptr && a.part == 0 && getenv("SPH_ACCEL_GENERIC") == nullptr;
+    return jacobi_on_records(a) && a.rec0 != nullptr && a.owned == nullptr && a.part == 0;   // (SPH_ACCEL_GENERIC: the step driver leaves rec0 null)
 }
 extern "C" int sph_set_sweep_variant(int mode)
 {
