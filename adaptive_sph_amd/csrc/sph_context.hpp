@@ -100,6 +100,7 @@ struct sph_ctx {
         // fused refresh (sph_step.hip, slab_refresh_fused): class byte per slot of the previous step's arrays, per-block class
         // counts / offsets; `pre_*` describe the arrays between the refresh and the cell sort, which drops the slots that left
         DevBuf cls, blk;
+        int overlap_env = -1;        // SPH_OVERLAP as read at the start of the step (-1: unset)
         bool pre = false;            // the arrays still hold slots that left this rank (class >= SC_GONE_FROM in cls[0 .. pre_cls_n))
         uint32_t pre_n = 0;          // slots in the arrays before the cell sort (live + gone)
         uint32_t pre_cls_n = 0;      // slots cls describes (the previous step's arrays)

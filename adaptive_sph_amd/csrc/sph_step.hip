@@ -393,8 +393,7 @@ static int solve_sweep_a(Group& G, std::vector<Member>& M, const SolveQ& q, uint
 #endif
 static bool split_sweep_a(const Group& G, const std::vector<Member>& M)
 {
-    const char* e = getenv("SPH_OVERLAP");   // (read per call: the tests switch it between two runs of one process)
-    const int env = e ? atoi(e) : -1;
+    const int env = G.m[0]->dist.overlap_env;   // SPH_OVERLAP, read once per step (the tests switch it between two runs of one process)
     if (env == 0 || G.comm == nullptr || G.m[0]->dist.nranks <= 1 || G.m[0]->dist.xstream == nullptr) return false;
     if (env > 0) return true;
     uint32_t n_max = 0;
@@ -651,6 +650,10 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
     const bool no_records = getenv("SPH_ACCEL_GENERIC") != nullptr;   // sweep A through the generic form
     const bool paced = !G.multi() && pace_setting("SPH_PACED", 1u) != 0u;   // 0: predicted queue + waits on one context too
     for (auto c : G.m) c->paced_step = paced;
+    {
+        const char* e = getenv("SPH_OVERLAP");
+        for (auto c : G.m) c->dist.overlap_env = e ? atoi(e) : -1;
+    }
     for (auto c : G.m) c->publish_folded = false;
 
     // ---- slab maintenance part 1 needs no global scalar: partition + migrate (multi-rank) -----------------
