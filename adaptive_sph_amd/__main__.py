@@ -36,7 +36,7 @@ def build_parser() -> argparse.ArgumentParser:
     run.add_argument("--without-adaptivity", action="store_true",
                      help="step with single_step_without_adaptivity even if the config enables merging/sharing/splitting")
     run.add_argument("--split-patterns", default=None,
-                     help="SplitPatterns file (load_split_patterns_from_file); default ./split-patterns.yaml like the reference, else the copy under tests/golden/")
+                     help="SplitPatterns file (load_split_patterns_from_file); default ./split-patterns.yaml, the path the reference reads (main_loop.rs:200-203)")
     run.add_argument("--capacity-factor", type=float, default=4.0, help="device capacity = this x the initial particle count (splitting adds particles)")
     run.add_argument("--device", type=int, default=0)
     # the reference's VtkExporter is compiled in but switched off (main_loop.rs:253 `export_vtk_data = false`); same writer here
@@ -61,12 +61,9 @@ def run(args, lib: Optional[ffi.SphLibrary] = None, out=sys.stdout) -> int:
         from .adaptivity import SplitPatterns
         from .scene import init_particles
         if params.splitting:
-            # main_loop.rs:200-203 reads ./split-patterns.yaml; a checkout of THIS repository has the table under tests/golden/
+            # main_loop.rs:200-203 reads ./split-patterns.yaml and panics without it; so does this
             from pathlib import Path
-            path = args.split_patterns
-            if path is None:
-                here = Path("./split-patterns.yaml")
-                path = here if here.exists() else Path(__file__).resolve().parent.parent / "tests" / "golden" / "split-patterns.yaml"
+            path = Path(args.split_patterns if args.split_patterns is not None else "./split-patterns.yaml")
             split_patterns = SplitPatterns.load_from_file(path)
         capacity = int(len(init_particles(scene)[1]) * args.capacity_factor) + 1024
     sim = init_fluid_sim(params, scene, counters_enabled=counters, lib=lib, device_id=args.device, split_patterns=split_patterns,

@@ -418,6 +418,42 @@ static int alloc_particle_buffers(sph_ctx* c)
     return SPH_OK;
 }
 
+// every switch the library reads from the environment, in one place (sph_context.hpp: Options)
+Options options_from_env()
+{
+    Options o;
+    auto num = [](const char* name, int dflt) {
+        const char* e = getenv(name);
+        return e && e[0] ? atoi(e) : dflt;
+    };
+    auto flag = [](const char* name) { return getenv(name) != nullptr ? 1 : 0; };
+    o.exact = num("SPH_HIP_EXACT", 0) == 1 ? 1 : 0;
+    o.paced = num("SPH_PACED", 1) != 0 ? 1 : 0;
+    o.pace_lead = num("SPH_PACE_LEAD", 0);
+    o.pace_pred = num("SPH_PACE_PRED", 0xffff);
+    o.chain = num("SPH_CHAIN", -1);
+    o.overlap = num("SPH_OVERLAP", -1);
+    o.accel_generic = flag("SPH_ACCEL_GENERIC");
+    o.jacobi_generic = flag("SPH_JACOBI_GENERIC");
+    o.slab_general = flag("SPH_SLAB_GENERAL");
+    o.slab_level_plain = flag("SPH_SLAB_LEVEL_PLAIN");
+    o.level_serial = flag("SPH_LEVEL_SERIAL");
+    o.level_batch8 = flag("SPH_LEVEL_BATCH8");
+    o.no_fuse = flag("SPH_NO_FUSE");
+    o.event_wait = flag("SPH_EVENT_WAIT");
+    o.loopback_sync = num("SPH_LOOPBACK_SYNC", 0) != 0 ? 1 : 0;
+    o.side_stream_normal = flag("SPH_SIDE_STREAM_NORMAL");
+    o.force_slab_mode = flag("SPH_FORCE_SLAB_MODE");
+    o.tile = num("SPH_TILE", 0);
+    o.slab_paced = num("SPH_SLAB_PACED", 1) != 0 ? 1 : 0;
+    o.slab_records = num("SPH_SLAB_RECORDS", 1) != 0 ? 1 : 0;
+    o.debug_sync = num("SPH_DEBUG_SYNC", 0);
+    o.debug_counts = flag("SPH_DEBUG_COUNTS");
+    o.comm_delay_us = num("SPH_DEBUG_COMM_DELAY_US", 0);
+    o.hip_trace = num("SPH_HIP_TRACE", 0) == 1 ? 1 : 0;
+    return o;
+}
+
 extern "C" int sph_create(uint64_t n_capacity, int device_id, const sph_plane* planes, int n_planes, sph_ctx** out)
 {
     if (!out || n_planes < 0 || n_planes > SPH_MAX_PLANES || (n_planes > 0 && !planes)) return SPH_ERR_INVALID_ARGUMENT;
@@ -430,8 +466,8 @@ extern "C" int sph_create(uint64_t n_capacity, int device_id, const sph_plane* p
     c->cap = n_capacity;
     c->n_planes = n_planes;
     for (int k = 0; k < n_planes; k++) c->bnd_h.planes[k] = PlaneP{planes[k].dir_x, planes[k].dir_y, planes[k].delta};
-    const char* ex = getenv("SPH_HIP_EXACT");
-    c->exact = (ex && ex[0] == '1') ? 1 : 0;
+    c->opt = options_from_env();
+    c->exact = c->opt.exact;
     auto bail = [&](int code) {
         sph_destroy(c);
         return code;
@@ -442,7 +478,7 @@ extern "C" int sph_create(uint64_t n_capacity, int device_id, const sph_plane* p
         // the main stream's sweeps -- highest priority, so that the dispatcher serves it first whenever a CU has room
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-        if (getenv("SPH_SIDE_STREAM_NORMAL") || hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, hi) != hipSuccess)
+        if (c->opt.side_stream_normal || hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, hi) != hipSuccess)
             if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess) return bail(SPH_ERR_DEVICE);
     }
     if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess) return bail(SPH_ERR_DEVICE);

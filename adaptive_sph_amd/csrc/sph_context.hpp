@@ -43,8 +43,40 @@ struct TmpBuf : DevBuf {
     ~TmpBuf() { release(); }
 };
 
+// Measurement / test switches.  Read ONCE per context, at sph_create, from the environment (options_from_env, sph_api.hip: the
+// variable names are listed there and in README.md) -- nothing in the step path calls getenv, and two contexts of one process may
+// run different forms side by side (the bit-identity tests do).  Defaults = the product's behaviour.
+struct Options {
+    int exact = 0;              // SPH_HIP_EXACT=1          EXACT math policy (the reference's operations; diagnostics)
+    int paced = 1;              // SPH_PACED=0              predicted queue + waits instead of pacing against the device's decisions
+    int pace_lead = 0;          // SPH_PACE_LEAD=<k>        undecided iterations allowed in the queue (0: by particle count)
+    int pace_pred = 0xffff;     // SPH_PACE_PRED=0|1|2      unpaced head of a solve (0xffff: by particle count)
+    int chain = -1;             // SPH_CHAIN=0|1            predicted queue: never / always chain the two solves of HybridDFSPH (-1: while the count repeats)
+    int overlap = -1;           // SPH_OVERLAP=0|1          slabs: never / always split sweep A around the exchange (-1: by slab size)
+    int accel_generic = 0;      // SPH_ACCEL_GENERIC        sweep A through OpPressureAccel (no pressure records)
+    int jacobi_generic = 0;     // SPH_JACOBI_GENERIC       sweep B through OpJacobi
+    int slab_general = 0;       // SPH_SLAB_GENERAL         slabs: always the general maintenance path (no fused refresh)
+    int slab_level_plain = 0;   // SPH_SLAB_LEVEL_PLAIN     slabs: level propagation without frontier marks
+    int level_serial = 0;       // SPH_LEVEL_SERIAL         level estimation on the main stream
+    int level_batch8 = 0;       // SPH_LEVEL_BATCH8         propagation sweeps in fixed batches of 8
+    int no_fuse = 0;            // SPH_NO_FUSE              a_ii / constant field and the non-pressure forces in two sweeps
+    int event_wait = 0;         // SPH_EVENT_WAIT           wait on events instead of spinning on mapped words
+    int loopback_sync = 0;      // SPH_LOOPBACK_SYNC=1      loopback transport with host waits
+    int side_stream_normal = 0; // SPH_SIDE_STREAM_NORMAL   side stream at normal priority
+    int force_slab_mode = 0;    // SPH_FORCE_SLAB_MODE      sph_dist_configure(0, 1, ..) turns the slab driver on (one-rank check of that path)
+    int tile = 0;               // SPH_TILE=<bits>          LDS-staged sweeps (sph_set_sweep_variant overrides, process-wide)
+    int slab_paced = 1;         // SPH_SLAB_PACED=0         slabs: predicted queue instead of pacing
+    int slab_records = 1;       // SPH_SLAB_RECORDS=0       slabs: sweep A through the generic form (p / rho^2 as a field of its own)
+    int debug_sync = 0;         // SPH_DEBUG_SYNC=<mask>    synchronise and name the phases (fault hunting)
+    int debug_counts = 0;       // SPH_DEBUG_COUNTS         print the fused refresh's counts
+    int comm_delay_us = 0;      // SPH_DEBUG_COMM_DELAY_US  loopback transport: every exchange / all-reduce occupies its stream that long
+    int hip_trace = 0;          // SPH_HIP_TRACE=1          host-side timeline of the step
+};
+Options options_from_env();   // sph_api.hip
+
 struct sph_ctx {
     int device = 0;
+    Options opt;
     uint64_t cap = 0, n = 0;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;   // side stream: the level estimation before advection runs under the step's own sweeps

@@ -174,6 +174,7 @@ struct SweepArgs {
     // (epoch << 16) | (stop << 15) | iteration, so that the host queues iterations against the device's progress (sph_step.hip)
     uint32_t* prog_host = nullptr;
     uint32_t prog_epoch = 0;
+    int opt_tile = 0, opt_jacobi_generic = 0;   // Options::tile / ::jacobi_generic of the context (sph_context.hpp)
 };
 
 size_t sweep_list_bytes(uint32_t n);

@@ -840,7 +840,7 @@ int slab_refresh_fused(Group& G, std::vector<Member>& M, std::vector<std::vector
     for (auto& m : M) dbg_sync(m.c, "fused: classify + scan", 0);
     std::vector<RefreshCounts> rcs(nm);
     if ((rc = G.comm->refresh_round(G, &red, &status, &fallback, rcs))) return rc;
-    if (getenv("SPH_DEBUG_COUNTS"))
+    if (M[0].c->opt.debug_counts)
         for (size_t i = 0; i < nm; i++)
             fprintf(stderr, "[sph debug] rank %zu: n_prev %u owned %llu mig %u %u halo %u %u in_mig %u %u in_halo %u %u fallback %d cap %llu\n", i, n_prev_of[i],
                     (unsigned long long)M[i].c->n, rcs[i].mig[0], rcs[i].mig[1], rcs[i].halo[0], rcs[i].halo[1], rcs[i].in_mig[0], rcs[i].in_mig[1],

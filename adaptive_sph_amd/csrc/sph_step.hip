@@ -95,6 +95,8 @@ SweepArgs make_args(sph_ctx* c, const StepP& sp)
         a.n_eb = c->dist.ghosts_ok ? c->dist.n_ghost[0] + c->dist.n_ghost[1] : 0u;
     }
     a.solver_tot = c->dist.solver_tot.as<double>();
+    a.opt_tile = c->opt.tile;
+    a.opt_jacobi_generic = c->opt.jacobi_generic;
     return a;
 }
 
@@ -157,8 +159,7 @@ int wait_stream(sph_ctx* c)
 // everything queued before it.  Falls back to the event wait if it does not show up (or SPH_EVENT_WAIT is set).
 static int wait_word(sph_ctx* c, volatile uint32_t* word, uint32_t want)
 {
-    static const bool event_wait = getenv("SPH_EVENT_WAIT") != nullptr;
-    if (event_wait) return wait_stream(c);
+    if (c->opt.event_wait) return wait_stream(c);
     c->n_waits++;
     auto t0 = std::chrono::steady_clock::now();
     for (uint64_t spins = 0; *word != want; spins++) {
@@ -216,17 +217,13 @@ static int ilog2_ceil(uint32_t v)
 
 // host-side timeline of one step (SPH_HIP_TRACE=1): where the CPU thread spends its time
 struct HostTrace {
-    bool on;
+    bool on = false;
     std::chrono::steady_clock::time_point t0;
     double acc[8] = {0};
     int steps = 0;
-    HostTrace()
+    void start(bool enabled)
     {
-        const char* e = getenv("SPH_HIP_TRACE");
-        on = e && e[0] == '1';
-    }
-    void start()
-    {
+        on = enabled;
         if (on) t0 = std::chrono::steady_clock::now();
     }
     void mark(int k)
@@ -249,8 +246,7 @@ static thread_local HostTrace g_trace;   // (diagnostic, SPH_HIP_TRACE=1; per ho
 // SPH_DEBUG_SYNC=1 (fault hunting): synchronise and name the phase just queued
 void dbg_sync(sph_ctx* c, const char* what, int id)
 {
-    static const int mask = getenv("SPH_DEBUG_SYNC") ? atoi(getenv("SPH_DEBUG_SYNC")) : 0;   // bit per sync point
-    if (!(mask & (1 << id))) return;
+    if (!(c->opt.debug_sync & (1 << id))) return;   // bit per sync point
     (void)hipSetDevice(c->device);
     const hipError_t e = hipStreamSynchronize(c->stream);
     fprintf(stderr, "[sph debug] rank %d step %llu: %s -> %s\n", c->dist.rank, (unsigned long long)c->step_number, what, hipGetErrorString(e));
@@ -423,6 +419,9 @@ static int exchange_and_sweep_a(Group& G, std::vector<Member>& M, const SolveQ& 
         }
         return SPH_OK;
     }
+    // The COLLECTIVES of the two forms are the same call in the same place -- the totals first, then ONE exchange-and-all-reduce --
+    // because the split decision below is rank-local under a per-rank transport (each rank sees its own particle count): slab counts
+    // that straddle SPLIT_MIN_PARTICLES must not leave one rank in a grouped send/receive and its neighbour in an all-reduce.
     for (auto& m : M) {   // the interior, beside everything below
         sph_ctx* c = m.c;
         auto& d = c->dist;
@@ -431,15 +430,10 @@ static int exchange_and_sweep_a(Group& G, std::vector<Member>& M, const SolveQ& 
         HIPCHK(c, hipStreamWaitEvent(d.xstream, d.ev_x[0], 0));
         if (m.n) launch_pressure_accel(d.xstream, &c->prof, m.a, (int)ka, q.residual_density, q.max_avg_error, q.max_iters, 1, 1);
         HIPCHK(c, hipEventRecord(d.ev_x[1], d.xstream));
-    }
-    if ((rc = refresh_ghosts(G, M, sel, 1, "pt"))) return rc;
-    for (auto& m : M) {
-        sph_ctx* c = m.c;
-        (void)hipSetDevice(c->device);
         if (m.n) launch_solver_totals(c->stream, &c->prof, m.a, (int)ka - 1, q.residual_density, q.max_avg_error, q.max_iters);
         else HIPCHK(c, hipMemsetAsync(c->dist.solver_tot.as<double>() + 8 * q.tot_slot, 0, 48, c->stream));   // an empty slab contributes zeros
     }
-    if ((rc = G.comm->allreduce_solver(G, q.tot_slot))) return rc;
+    if ((rc = refresh_ghosts(G, M, sel, 1, "pt", q.tot_slot))) return rc;
     for (auto& m : M) {
         sph_ctx* c = m.c;
         (void)hipSetDevice(c->device);
@@ -515,25 +509,19 @@ static void solve_stats(Member& m, const SolveQ& q, const SolverCtrl& h)
 // launches travel, so the device never idles, and a solve ends with at most `lead` - 1 iterations queued in vain.  The first
 // iterations (the smaller of the last two counts) are queued without looking: a cushion against a host thread that is late once.
 // The tail is queued when the host has SEEN "stop": no gate, no re-queueing, and between the two solves of HybridDFSPH no wait.
-static uint32_t pace_setting(const char* name, uint32_t dflt)
-{
-    const char* e = getenv(name);
-    return e ? (uint32_t)atoi(e) : dflt;
-}
 
 // Small scenes: an iteration of n particles takes ~46 us x n / 2^20 on the device, the host's answer to a decision ~10-20 us: the
 // lead grows as the sweeps shrink (1 from ~0.45M particles up), and the unpaced head is the smaller of the last two counts; large
 // scenes queue nothing unpaced (measured on configs[1]'s driver window: 1.148 ms/step, against 1.164 with the head and 1.201-1.207
 // with the predicted queue; profiles/r3_variants.md section 5).  SPH_PACE_LEAD / SPH_PACE_PRED override both.
-static uint32_t pace_lead(uint32_t n)
+static uint32_t pace_lead(const sph_ctx* c, uint32_t n)
 {
-    static const uint32_t forced = pace_setting("SPH_PACE_LEAD", 0u);
-    if (forced) return forced;
+    if (c->opt.pace_lead > 0) return (uint32_t)c->opt.pace_lead;
     return std::min(8u, std::max(1u, (450000u + n - 1u) / std::max(n, 1u)));
 }
-static uint32_t pace_prediction(uint32_t n, uint32_t last, uint32_t prev)
+static uint32_t pace_prediction(const sph_ctx* c, uint32_t n, uint32_t last, uint32_t prev)
 {
-    static const int mode = (int)pace_setting("SPH_PACE_PRED", 0xffffu);   // 0: nothing unpaced; 1: min of the last two counts; 2: the last count
+    const int mode = c->opt.pace_pred;   // 0: nothing unpaced; 1: min of the last two counts; 2: the last count
     const int md = mode == 0xffff ? (n >= 450000u ? 0 : 1) : mode;
     if (md == 0) return 2u;
     if (md == 2 || prev == 0u) return last;
@@ -542,8 +530,8 @@ static uint32_t pace_prediction(uint32_t n, uint32_t last, uint32_t prev)
 static int solve_paced(Group& G, std::vector<Member>& M, SolveQ& q, uint32_t predicted_iters)
 {
     Member& m = M[0];
-    const uint32_t lead = pace_lead(m.n);
     sph_ctx* c = m.c;
+    const uint32_t lead = pace_lead(c, m.n);
     int rc;
     (void)hipSetDevice(c->device);
     c->solve_epoch = c->solve_epoch >= 0xffffu ? 1u : c->solve_epoch + 1u;
@@ -595,7 +583,7 @@ static int pressure_iterations(Group& G, std::vector<Member>& M, float max_avg_e
     SolveQ q{max_avg_error, residual_density, max_iters, tail, density_solver};
     if (!multi && M[0].n > 0 && M[0].c->paced_step) {
         sph_ctx* c0 = M[0].c;
-        const uint32_t head = density_solver ? pace_prediction(M[0].n, c0->last_dens_iters, c0->prev_dens_iters) : pace_prediction(M[0].n, c0->last_div_iters, c0->prev_div_iters);
+        const uint32_t head = density_solver ? pace_prediction(c0, M[0].n, c0->last_dens_iters, c0->prev_dens_iters) : pace_prediction(c0, M[0].n, c0->last_div_iters, c0->prev_div_iters);
         if ((rc = solve_paced(G, M, q, head))) return rc;
         if ((rc = solve_queue(G, M, q, false, true))) return rc;   // (the tail)
         if ((rc = sync_ctrl(G, SYNC_AGREE))) return rc;
@@ -618,7 +606,7 @@ static int pressure_iterations(Group& G, std::vector<Member>& M, float max_avg_e
 static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs, bool* started)
 {
     int rc = SPH_OK;
-    g_trace.start();
+    g_trace.start(G.m[0]->opt.hip_trace != 0);
     std::vector<Member> M(G.m.size());
     for (size_t i = 0; i < G.m.size(); i++) {
         M[i].c = G.m[i];
@@ -647,13 +635,11 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
         if (c->poisoned) return c->fail(SPH_ERR_POISONED, "an earlier step failed inside the step: the particle state is undefined until sph_upload");
     *started = true;   // from here on a failure leaves the state half-stepped
     // measurement / test switches of the solves, read ONCE per step (never inside the iteration path)
-    const bool no_records = getenv("SPH_ACCEL_GENERIC") != nullptr;   // sweep A through the generic form
-    const bool paced = !G.multi() && pace_setting("SPH_PACED", 1u) != 0u;   // 0: predicted queue + waits on one context too
+    const bool no_records = c0->opt.accel_generic != 0;   // sweep A through the generic form
+    // (the progress word carries the iteration in 15 bits: a solve that may run longer keeps the predicted queue)
+    const bool paced = !G.multi() && c0->opt.paced != 0 && p->max_iters <= 0x7fffu;   // 0: predicted queue + waits on one context too
     for (auto c : G.m) c->paced_step = paced;
-    {
-        const char* e = getenv("SPH_OVERLAP");
-        for (auto c : G.m) c->dist.overlap_env = e ? atoi(e) : -1;
-    }
+    for (auto c : G.m) c->dist.overlap_env = c0->opt.overlap;
     for (auto c : G.m) c->publish_folded = false;
 
     // ---- slab maintenance part 1 needs no global scalar: partition + migrate (multi-rank) -----------------
@@ -719,7 +705,7 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
         // trip of the first partition's counts.
         // ordinary steps: the fused refresh (one round trip, no partition sort); it reduces `red` whether or not it applies
         const float halo_k_f = halo_factor();
-        const bool no_fused = getenv("SPH_SLAB_GENERAL") != nullptr;   // measurement / test aid: always the general path (read per step)
+        const bool no_fused = c0->opt.slab_general != 0;   // measurement / test aid: always the general path
         const bool attempt = h_from_mass_mode && !rebalanced && !no_fused;     // (parameters and all-reduced values: the same on every rank)
         if (attempt) {
             if ((rc = slab_refresh_fused(G, M, red, halo_k_f, &slab_fused))) return rc;
@@ -1031,8 +1017,7 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
             launch_level_propagate(ls, &c->prof, al, lv, 0u, chg + 1023);   // surface particles mark their neighbours
             uint32_t t = 1, effective = 0;
             int B = (int)std::min<uint32_t>(std::max<uint32_t>(c->last_level_sweeps + 1u, 8u), 1000u);
-            static const bool batch8 = getenv("SPH_LEVEL_BATCH8") != nullptr;   // measurement aid: the fixed batches of 8
-            if (batch8) B = 8;
+            if (c->opt.level_batch8) B = 8;   // measurement aid: the fixed batches of 8
             for (bool done = false; !done; B = 8) {
                 // the flags live in device memory (a store to mapped host memory from every assigning lane made each sweep
                 // wait for PCIe at its end); their sum goes to the host once per batch
@@ -1179,7 +1164,7 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
             l.stash_first = p->fill_stash_with == SPH_STASH_SURFACE_DISTANCE_FIRST ? c->stash.as<float>() : nullptr;
             // frontier form with probing halo members (OpLevelPropagate, mode 2); SPH_SLAB_LEVEL_PLAIN=1: every unassigned particle in
             // every sweep (measurement / tests; parameters only: the same on every rank)
-            l.plain_propagate = getenv("SPH_SLAB_LEVEL_PLAIN") ? 1 : 2;
+            l.plain_propagate = c0->opt.slab_level_plain ? 1 : 2;
             l.edge = c->dist.edge.as<uint8_t>();
             l.pm_cell = after ? c->pm[c->pcur].as<float4>() : nullptr;
             l.center_diff = p->level_estimation_method == SPH_LEVEL_CENTER_DIFF;
@@ -1258,8 +1243,7 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
         if ((rc = level_estimation_slabs(false))) return rc;
         for (auto& m : M) dbg_sync(m.c, "level estimation (slabs)", 4);
     } else if (level_on && !level_after) {
-        static const bool no_side = getenv("SPH_LEVEL_SERIAL") != nullptr;   // measurement aid: everything on one stream
-        if ((rc = level_estimation(nullptr, nullptr, !no_side))) return rc;
+        if ((rc = level_estimation(nullptr, nullptr, !c0->opt.level_serial))) return rc;   // (level_serial: measurement aid, everything on one stream)
     } else if (!level_on) {
         for (auto& m : M) m.c->have_level = false;
     }
@@ -1354,8 +1338,7 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
     // the non-pressure acceleration directly follows in every mode but HybridDFSPH-with-forces-behind-the-divergence-solve:
     // then it shares the sweep (one replay of the lists, one gradient per pair)
     const bool np_first = p->pressure_solver_method != SPH_SOLVER_HYBRID_DFSPH || p->hybrid_dfsph_non_pressure_accel_before_divergence_free;
-    static const bool no_fuse = getenv("SPH_NO_FUSE") != nullptr;   // measurement aid: the two sweeps apart
-    const bool np_fused = np_first && !p->check_aii && !no_fuse;
+    const bool np_fused = np_first && !p->check_aii && !c0->opt.no_fuse;   // (no_fuse: measurement aid, the two sweeps apart)
     for (auto& m : M) {
         (void)hipSetDevice(m.c->device);
         if (m.n && np_fused) {
@@ -1449,7 +1432,7 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
             // one context: both solves paced against the device's progress, ONE host wait at the end of the step
             SolveQ qd{p->hybrid_dfsph_max_avg_divergence_error, 0, p->max_iters, T_VEL, false};
             SolveQ qs{p->hybrid_dfsph_max_avg_density_error, 1, p->max_iters, T_HYBRID, true};
-            if ((rc = solve_paced(G, M, qd, pace_prediction(M[0].n, c0->last_div_iters, c0->prev_div_iters)))) return rc;
+            if ((rc = solve_paced(G, M, qd, pace_prediction(c0, M[0].n, c0->last_div_iters, c0->prev_div_iters)))) return rc;
             if ((rc = solve_queue(G, M, qd, true))) return rc;   // the tail (v += dt a^p): it also leaves the solve's control block in ctrl_host[1]
             g_trace.mark(4);
             rec(3);
@@ -1457,7 +1440,7 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
                 if ((rc = non_pressure())) return rc;
             rec(4);
             begin_solve(p->hybrid_dfsph_density_source_term == SPH_ONLY_DENSITY ? 2 : 1, 1);
-            if ((rc = solve_paced(G, M, qs, pace_prediction(M[0].n, c0->last_dens_iters, c0->prev_dens_iters)))) return rc;
+            if ((rc = solve_paced(G, M, qs, pace_prediction(c0, M[0].n, c0->last_dens_iters, c0->prev_dens_iters)))) return rc;
             if ((rc = solve_queue(G, M, qs, false, true))) return rc;
             if ((rc = sync_ctrl(G, SYNC_AGREE))) return rc;
             solve_stats(M[0], qd, M[0].c->ctrl_host[1]);
@@ -1466,8 +1449,7 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
             rec(5);
             break;
         }
-        const char* chain_env = getenv("SPH_CHAIN");
-        const bool chain_wanted = chain_env ? chain_env[0] == '1' : c0->last_div_iters == c0->prev_div_iters;
+        const bool chain_wanted = c0->opt.chain >= 0 ? c0->opt.chain == 1 : c0->last_div_iters == c0->prev_div_iters;
         const bool chain = (G.multi() || M[0].n > 0) && p->hybrid_dfsph_non_pressure_accel_before_divergence_free && chain_wanted;
         if (chain) {
             const int multi = G.multi() ? 1 : 0;
@@ -1685,7 +1667,7 @@ extern "C" int sph_dist_configure(sph_ctx* c, int rank, int n_ranks, float cut_l
 {
     if (!c || rank < 0 || n_ranks < 1 || rank >= n_ranks) return SPH_ERR_INVALID_ARGUMENT;
     // SPH_FORCE_SLAB_MODE=1: run the slab driver and the RCCL collectives with ONE rank (a single-GPU check of that code path)
-    c->dist.on = n_ranks > 1 || (getenv("SPH_FORCE_SLAB_MODE") != nullptr);
+    c->dist.on = n_ranks > 1 || c->opt.force_slab_mode != 0;
     c->dist.rank = rank;
     c->dist.nranks = n_ranks;
     c->dist.cut_lo = cut_lo;

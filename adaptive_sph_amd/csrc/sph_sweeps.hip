@@ -2594,26 +2594,14 @@ static SweepCommon common_of(const SweepArgs& a, bool ext)
 
 // SPH_TILE: bit 0 = the BUILD sweep (density), bit 1 = the replay sweeps through the LDS-staged form (k_sweep_tile) in
 // uniform-h scenes.  Measured on MI355X: profiles/r2_variants.md.
-static int g_tile_mode = -1;
-static int tile_mode()
-{
-    if (g_tile_mode < 0) {
-        const char* e = getenv("SPH_TILE");
-        g_tile_mode = e ? atoi(e) : SPH_TILE_DEFAULT;
-    }
-    return g_tile_mode;
-}
-// SPH_JACOBI_GENERIC (read once): the Jacobi update of uniform scenes through OpJacobi as well (measurement: what OpJacobiU is worth)
-static bool jacobi_generic()
-{
-    static const bool v = getenv("SPH_JACOBI_GENERIC") != nullptr;
-    return v;
-}
+static int g_tile_mode = -1;   // sph_set_sweep_variant (process-wide override of the contexts' SPH_TILE option)
+static int tile_mode(const SweepArgs& a) { return g_tile_mode >= 0 ? g_tile_mode : (a.opt_tile ? a.opt_tile : SPH_TILE_DEFAULT); }
+// Options::jacobi_generic: the Jacobi update of uniform scenes through OpJacobi as well (measurement: what OpJacobiU is worth)
 // SPH_ACCEL_GENERIC (read once per step by the step driver, which then passes no record buffers: the tests compare both forms in one
 // process): sweep A of such scenes through OpPressureAccel, the solves' p / rho^2 as a field of its own
 static bool jacobi_on_records(const SweepArgs& a)   // sweep B gathers {x, y, a^p} whole (OpJacobiU)
 {
-    return !a.exact && a.uniform_h && a.h_mode == SPH_H_FROM_MASS && a.sp.opdisc != SPH_OP_WINCHENBACH2020 && !jacobi_generic();
+    return !a.exact && a.uniform_h && a.h_mode == SPH_H_FROM_MASS && a.sp.opdisc != SPH_OP_WINCHENBACH2020 && !a.opt_jacobi_generic;
 }
 static bool solve_on_records(const SweepArgs& a)    // ... and sweep A {x, y, p / rho^2, p} (OpPressureAccelU): one context, not IISPH2
 {
@@ -2646,7 +2634,7 @@ static void launch_sweep(hipStream_t s, const SweepArgs& a, const Op& op)
     const uint32_t nblocks = (a.n + SWEEP_THREADS - 1) / SWEEP_THREADS;
     const uint32_t grid = ((nblocks + 7) / 8) * 8;  // XCD remap needs a multiple of 8
     if constexpr (Op::Math::UNIFORM && !Op::EXTENDED && OpTile<Op>::value) {
-        if (tile_mode() & (BUILD ? 1 : 2)) {
+        if (tile_mode(a) & (BUILD ? 1 : 2)) {
             hipLaunchKernelGGL((k_sweep_tile<Op, BUILD>), dim3(grid), dim3(SWEEP_THREADS), 0, s, op, common_of(a, Op::EXTENDED));
             return;
         }

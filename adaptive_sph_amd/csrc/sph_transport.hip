@@ -80,8 +80,7 @@ __global__ void k_tot_sum_self(double* __restrict__ tot, const double* __restric
 }
 static void debug_comm_delay(sph_ctx* c)
 {
-    const char* e = getenv("SPH_DEBUG_COMM_DELAY_US");
-    const int us = e ? atoi(e) : 0;
+    const int us = c->opt.comm_delay_us;
     if (us > 0) hipLaunchKernelGGL(k_spin_us, dim3(1), dim3(1), 0, c->stream, (uint32_t)us);
 }
 
@@ -127,11 +126,7 @@ struct LocalComm : Comm {
     // SPH_LOOPBACK_SYNC=1: the exchanges and the solver all-reduce wait on the host (the first form of this transport, kept as the
     // reference the event-ordered form is tested against).  Default: no host wait -- the copies are ordered by events between the
     // members' streams, the totals meet in mapped host memory: what a host that drives k GPUs from one process runs.
-    static bool host_synchronous()
-    {
-        const char* e = getenv("SPH_LOOPBACK_SYNC");
-        return e && atoi(e) != 0;
-    }
+    static bool host_synchronous(const Group& G) { return G.m[0]->opt.loopback_sync != 0; }
     int exchange(Group& G, std::vector<Xfer>& x) override
     {
         const size_t n = G.m.size();
@@ -144,7 +139,7 @@ struct LocalComm : Comm {
         }
         if (n && (x[0].send_bytes[0] || x[0].recv_bytes[0] || x[n - 1].send_bytes[1] || x[n - 1].recv_bytes[1]))
             return G.m[0]->fail(SPH_ERR_DEVICE, "halo exchange across the outer edge of the slab row");
-        const bool sync = host_synchronous();
+        const bool sync = host_synchronous(G);
         int rc;
         if (sync) {
             for (auto c : G.m) debug_comm_delay(c);
@@ -228,7 +223,7 @@ struct LocalComm : Comm {
     int allreduce_solver(Group& G, int slot) override
     {
         const size_t n = G.m.size();
-        if (host_synchronous()) {
+        if (host_synchronous(G)) {
             for (auto c : G.m) debug_comm_delay(c);
             int rc = wait_all(G);
             if (rc) return rc;

@@ -255,23 +255,34 @@ def rank_single_step_adaptivity(ctx: ffi.Context, gather: GatherContext, P, dt: 
     dist.gather_object(mine, parts, dst=root)
     out = [None] * world
     if rank == root:
-        ids = [q["particle_id"] for q in parts]
-        n = int(sum(len(i) for i in ids))
-        allid = np.concatenate(ids)
-        if not np.array_equal(np.sort(allid), np.arange(n, dtype=allid.dtype)):
-            raise ValueError("rank_single_step_adaptivity: the particle ids of the ranks are not the indices 0 .. n-1")
-        g = {}
-        for f in ("mass", "position", "velocity") + _ADAPT_FIELDS:
-            a = np.zeros((n,) + parts[0][f].shape[1:], parts[0][f].dtype)
-            for q in parts:
-                a[q["particle_id"]] = q[f]
-            g[f] = a
-        new, info = _adapt_gathered(gather, P, dt, step_number, g, ids, [q["lists"] for q in parts], capacity)
-        cuts = [-INF] + [float(q["cuts"][1]) for q in parts[:-1]] + [INF]
-        for r, sel in enumerate(partition(new["position"][:, 0], cuts)):
-            out[r] = ({f: new[f][sel] for f in new}, sel, info)
+        # whatever goes wrong on the root between the gather and the scatter (the ids check, the 2^32-entries check, the mass-sum
+        # assertion, an SphError of the gather context) must reach EVERY rank: the others sit in scatter_object_list meanwhile
+        try:
+            ids = [q["particle_id"] for q in parts]
+            n = int(sum(len(i) for i in ids))
+            allid = np.concatenate(ids)
+            if not np.array_equal(np.sort(allid), np.arange(n, dtype=allid.dtype)):
+                raise ValueError("rank_single_step_adaptivity: the particle ids of the ranks are not the indices 0 .. n-1")
+            g = {}
+            for f in ("mass", "position", "velocity") + _ADAPT_FIELDS:
+                a = np.zeros((n,) + parts[0][f].shape[1:], parts[0][f].dtype)
+                for q in parts:
+                    a[q["particle_id"]] = q[f]
+                g[f] = a
+            new, info = _adapt_gathered(gather, P, dt, step_number, g, ids, [q["lists"] for q in parts], capacity)
+            cuts = [-INF] + [float(q["cuts"][1]) for q in parts[:-1]] + [INF]
+            for r, sel in enumerate(partition(new["position"][:, 0], cuts)):
+                out[r] = ({f: new[f][sel] for f in new}, sel, info)
+        except Exception as e:  # noqa: BLE001 -- re-raised on every rank below
+            code = e.status if isinstance(e, ffi.SphError) else None
+            out = [(None, None, (type(e).__name__, code, str(e)))] * world
     got = [None]
     dist.scatter_object_list(got, out if rank == root else None, src=root)
+    if got[0][0] is None:
+        kind, code, msg = got[0][2]
+        if code is not None:
+            raise ffi.SphError(code, f"adaptive step failed on rank {root}: {msg}")
+        raise RuntimeError(f"adaptive step failed on rank {root} ({kind}): {msg}")
     new, sel, info = got[0]
     _reupload(ctx, {f: v for f, v in new.items()}, np.arange(len(sel)))
     ctx.upload_field("particle_id", sel.astype(np.uint32))

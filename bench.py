@@ -353,8 +353,8 @@ def main():
                                                           "particles_after": info["n_after"], "note": "rank 0's clock; gather / scatter through the launcher's process group"}
                 if gc is not None:
                     gc.close()
-        except ffi.SphError as e:   # (a refusal taken on all-reduced values: every rank is here)
-            config4["refused"] = str(e)[:300]
+        except (ffi.SphError, RuntimeError) as e:   # a refusal taken on all-reduced values, or a failure of the adaptive step's root that
+            config4["refused"] = str(e)[:300]         # rank_single_step_adaptivity re-raises on every rank: every rank is here
         finally:
             if c4 is not None:
                 c4.close()
