@@ -36,7 +36,7 @@ bool Profiler::wants(const char* name) const
 {
     // mode 2: the density kernel only, on every 8th step (a timing-enabled event record forces a command
     // flush; sampling keeps the perturbation of the timed region below 1 %)
-    return mode == 1 || (mode == 2 && (step_index & 7u) == 0u && strncmp(name, "density", 7) == 0);
+    return mode == 1 || mode == 3 || (mode == 2 && (step_index & 7u) == 0u && strncmp(name, "density", 7) == 0);
 }
 hipEvent_t Profiler::get_event()
 {
@@ -51,24 +51,65 @@ hipEvent_t Profiler::get_event()
 }
 // Scopes nest in slab mode (the partition / halo selection run the radix sort and the reorder, which open their own): only the
 // outermost scope is timed, the inner launches are part of it.
-void Profiler::begin(const char* name, hipStream_t s)
+void Profiler::begin(const char* name, hipStream_t s, bool single_launch)
 {
     if (depth++ > 0) return;
     cur = find(name);
+    ext_open = mode == 3 && single_launch && ts_next < (uint32_t)TS_RING;
+    ext_slot = -1;
+    if (ext_open) return;   // timed by the kernel itself (take_slot), or not at all
     cur_a = get_event();
     (void)hipEventRecord(cur_a, s);
+}
+unsigned long long* Profiler::take_slot()
+{
+    if (!ext_open || ext_slot >= 0 || depth != 1) return nullptr;
+    if (!ts_dev) {
+        if (hipMalloc((void**)&ts_dev, 2 * (size_t)TS_RING * sizeof(unsigned long long)) != hipSuccess) return nullptr;
+        (void)hipMemset(ts_dev, 0xff, (size_t)TS_RING * sizeof(unsigned long long));
+        (void)hipMemset(ts_dev + TS_RING, 0, (size_t)TS_RING * sizeof(unsigned long long));
+    }
+    ext_slot = (int)ts_next++;
+    return ts_dev + ext_slot;
 }
 void Profiler::end(hipStream_t s)
 {
     if (--depth > 0) return;
+    if (ext_open) {
+        if (ext_slot >= 0) pending.push_back(Pending{cur, nullptr, nullptr, ext_slot});   // (else: the scope launched nothing, no sample)
+        ext_open = false;
+        cur = -1;
+        return;
+    }
     hipEvent_t b = get_event();
     (void)hipEventRecord(b, s);
-    pending.push_back(Pending{cur, cur_a, b});
+    pending.push_back(Pending{cur, cur_a, b, -1});
     cur = -1;
 }
 void Profiler::collect()
 {
+    // (called behind a wait for the stream: every stamped launch has finished)
+    std::vector<unsigned long long> ts;
+    if (ts_next) {
+        ts.resize(2 * (size_t)ts_next);
+        (void)hipMemcpy(ts.data(), ts_dev, (size_t)ts_next * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        (void)hipMemcpy(ts.data() + ts_next, ts_dev + TS_RING, (size_t)ts_next * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+        (void)hipMemset(ts_dev, 0xff, (size_t)ts_next * sizeof(unsigned long long));
+        (void)hipMemset(ts_dev + TS_RING, 0, (size_t)ts_next * sizeof(unsigned long long));
+    }
+    static FILE* dump = getenv("SPH_TS_DUMP") ? fopen(getenv("SPH_TS_DUMP"), "w") : nullptr;   // (diagnostic: raw stamps, one line per launch)
     for (auto& p : pending) {
+        if (p.slot >= 0) {
+            const unsigned long long t0 = ts[(size_t)p.slot], t1 = ts[(size_t)ts_next + (size_t)p.slot];
+            if (dump) fprintf(dump, "%s %llu %llu\n", recs[p.rec].name.c_str(), t0, t1);
+            if (t1 >= t0 && t0 != ~0ull) {
+                const float ms = (float)((double)(t1 - t0) * 1e-5);   // 100 MHz ticks
+                recs[p.rec].launches++;
+                recs[p.rec].total_ms += ms;
+                recs[p.rec].samples.push_back(ms);
+            }
+            continue;
+        }
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
             recs[p.rec].launches++;
@@ -79,6 +120,8 @@ void Profiler::collect()
         pool.push_back(p.b);
     }
     pending.clear();
+    ts_next = 0;
+    if (dump) fflush(dump);
 }
 void Profiler::reset()
 {
@@ -88,10 +131,11 @@ void Profiler::reset()
 Profiler::~Profiler()
 {
     for (auto& p : pending) {
-        (void)hipEventDestroy(p.a);
-        (void)hipEventDestroy(p.b);
+        if (p.a) (void)hipEventDestroy(p.a);
+        if (p.b) (void)hipEventDestroy(p.b);
     }
     for (auto e : pool) (void)hipEventDestroy(e);
+    if (ts_dev) (void)hipFree(ts_dev);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1042,6 +1086,47 @@ extern "C" int sph_profile_event_overhead(sph_ctx* c, double* microseconds)
     for (auto& e : ev) (void)hipEventDestroy(e);
     const double o = (2.0 * t[0] - t[1]) / reps * 1e3;
     *microseconds = o > 0 ? o : 0;
+    return SPH_OK;
+}
+
+// Calibration of the profiler's marker events: a one-wave kernel that spins for `us` microseconds of the device's constant 100 MHz
+// clock.  rocprofv3 reports its duration as us + 0.44 (the launch / exit of a one-wave dispatch: profiles/r4_event_calibration.md);
+// what a marker-event pair around it reads beyond that is what the pair adds to ANY kernel it brackets in the same place of the
+// queue.  Profiler mode 1 launches one such kernel per step right behind the density sweep -- in the middle of the step's busy queue,
+// bracketed like every other kernel -- under the name "calibration_spin10"; bench.py subtracts (its bracket - 10.44 us) from the
+// sweeps' brackets.  (Alone on an idle queue the same bracket reads 3.9 us more, in the step ~2.4: the calibration must sit where
+// the kernels it corrects sit.)
+__global__ void k_spin_calib(uint32_t us)
+{
+    const uint64_t t0 = wall_clock64();   // 100 MHz
+    while (wall_clock64() - t0 < (uint64_t)us * 100ull) __builtin_amdgcn_s_sleep(4);
+}
+void launch_profile_calibration(sph_ctx* c)
+{
+    if (c->prof.mode != 1) return;
+    ProfScope ps(&c->prof, "calibration_spin10", c->stream);
+    hipLaunchKernelGGL(k_spin_calib, dim3(1), dim3(64), 0, c->stream, 10u);
+}
+extern "C" int sph_profile_dispatch_bracket(sph_ctx* c, uint32_t spin_us, int reps, double* mean_bracket_us)
+{
+    if (!c || !mean_bracket_us || reps < 1 || reps > 10000) return SPH_ERR_INVALID_ARGUMENT;
+    HIPCHK(c, hipSetDevice(c->device));
+    std::vector<hipEvent_t> ev(2 * (size_t)reps);
+    for (auto& e : ev) HIPCHK(c, hipEventCreate(&e));
+    for (int k = 0; k < reps; k++) {
+        HIPCHK(c, hipEventRecord(ev[2 * k], c->stream));
+        hipLaunchKernelGGL(k_spin_calib, dim3(1), dim3(64), 0, c->stream, spin_us);
+        HIPCHK(c, hipEventRecord(ev[2 * k + 1], c->stream));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    double t = 0;
+    for (int k = 0; k < reps; k++) {
+        float ms = 0.f;
+        HIPCHK(c, hipEventElapsedTime(&ms, ev[2 * k], ev[2 * k + 1]));
+        t += ms;
+    }
+    for (auto& e : ev) (void)hipEventDestroy(e);
+    *mean_bracket_us = t / reps * 1e3;
     return SPH_OK;
 }
 

@@ -228,5 +228,6 @@ SweepArgs make_args(sph_ctx* c, const StepP& sp);
 // ---- small launch wrappers owned by sph_api.hip -----------------------------------------------
 void launch_header(sph_ctx* c, uint32_t n, float rest_density, int from_mass, HeaderOut* out_dev, const uint8_t* owned = nullptr);
 void launch_publish(sph_ctx* c);
+void launch_profile_calibration(sph_ctx* c);   // Profiler mode 1: one spin kernel of known duration per step (sph_api.hip)
 void launch_check_neighborhood(sph_ctx* c, const SweepArgs& a);
 void dist_release(sph_ctx* c);  // sph_step.hip

@@ -2,6 +2,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include <string>
@@ -12,7 +13,11 @@
 
 // ---- HIP-event profiler (measurement hook; sph_profile_* in the C ABI) ------------------------
 struct Profiler {
-    int mode = 0;  // 0 off, 1 every kernel, 2 only names starting with "density" (sampled: every 8th step)
+    int mode = 0;  // 0 off, 1 every kernel, 2 only names starting with "density" (sampled: every 8th step),
+                   // 3 (diagnostic) the SWEEPS only, stamped on the device's own clock: the first blocks stamp the constant 100 MHz
+                   //   counter at their start, every block at its end, into the launch's slot of a ring (atomic min / max).  The stamps'
+                   //   same-address atomics make a sweep ~30 us longer, so this mode does not TIME a sweep; it places the dispatch: first
+                   //   wave 3 us behind rocprofv3's start, last wave 0.8 us before its end (profiles/r4_event_calibration.md)
     uint64_t step_index = 0;
     struct Rec {
         std::string name;
@@ -23,6 +28,7 @@ struct Profiler {
     struct Pending {
         int rec;
         hipEvent_t a, b;
+        int slot;   // >= 0: device timestamps in ts_dev[slot] / ts_dev[TS_RING + slot] instead of events
     };
     std::vector<Rec> recs;
     std::vector<Pending> pending;
@@ -31,23 +37,33 @@ struct Profiler {
     int find(const char* name);
     bool wants(const char* name) const;
     hipEvent_t get_event();
-    void begin(const char* name, hipStream_t s);
+    void begin(const char* name, hipStream_t s, bool single_launch = false);
     void end(hipStream_t s);
+    // mode 3, inside a single-launch scope: the launch's slot for its device timestamps (nullptr: not wanted)
+    unsigned long long* take_slot();
+    enum { TS_RING = 1 << 16 };
+    unsigned long long* ts_dev = nullptr;   // [0, TS_RING): first start (min), [TS_RING, 2 TS_RING): last end (max)
+    uint32_t ts_next = 0;
     void collect();  // after a stream sync: fold pending event pairs into recs
     void reset();
     ~Profiler();
     int cur = -1;
     int depth = 0;   // open scopes (only the outermost is timed)
-    hipEvent_t cur_a = nullptr;
+    hipEvent_t cur_a = nullptr, cur_b = nullptr;
+    bool ext_open = false;
+    int ext_slot = -1;
 };
 
 struct ProfScope {
     Profiler* p;
     hipStream_t s;
     bool on;
-    ProfScope(Profiler* p_, const char* name, hipStream_t s_) : p(p_), s(s_), on(p_ && p_->mode && p_->wants(name))
+    // (mode 3 times the stamped sweeps ONLY: one timing-enabled event anywhere in the process switches the queue to per-dispatch
+    //  profiling, and the sweeps themselves then run ~2 us longer -- bench.py takes the other kernels from a mode-1 pass)
+    ProfScope(Profiler* p_, const char* name, hipStream_t s_, bool single_launch = false)
+        : p(p_), s(s_), on(p_ && p_->mode && p_->wants(name) && (p_->mode != 3 || single_launch))
     {
-        if (on) p->begin(name, s);
+        if (on) p->begin(name, s, single_launch);
     }
     ~ProfScope()
     {
@@ -175,6 +191,7 @@ struct SweepArgs {
     uint32_t* prog_host = nullptr;
     uint32_t prog_epoch = 0;
     int opt_tile = 0, opt_jacobi_generic = 0;   // Options::tile / ::jacobi_generic of the context (sph_context.hpp)
+    Profiler* prof = nullptr;                   // host side only: the context's profiler (launch_sweep asks it for a timestamp slot)
 };
 
 size_t sweep_list_bytes(uint32_t n);

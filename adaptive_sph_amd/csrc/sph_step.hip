@@ -97,6 +97,7 @@ SweepArgs make_args(sph_ctx* c, const StepP& sp)
     a.solver_tot = c->dist.solver_tot.as<double>();
     a.opt_tile = c->opt.tile;
     a.opt_jacobi_generic = c->opt.jacobi_generic;
+    a.prof = &c->prof;
     return a;
 }
 
@@ -1252,6 +1253,7 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
     for (auto& m : M) {
         (void)hipSetDevice(m.c->device);
         if (m.n) launch_density(m.c->stream, &m.c->prof, m.a);
+        if (m.n) launch_profile_calibration(m.c);   // (profiler mode 1 only)
         if (p->check_neighborhood && m.n) launch_check_neighborhood(m.c, m.a);
     }
     // ---- constrain_neighborhood_count (simulation.rs:2145-2177): h2 of over-populated particles shrinks AFTER the lists are

@@ -81,7 +81,26 @@ struct SweepCommon {
     const uint32_t* __restrict__ elist_a;
     const uint32_t* __restrict__ elist_b;
     uint32_t n_ea, n_eb;
+    // Profiler mode 3 (else nullptr): this launch's timestamp slot -- ts[0] receives the earliest block start, ts[TS_RING] the latest
+    // block end, on the device's constant 100 MHz clock (sph_internal.hpp)
+    unsigned long long* ts;
 };
+#define SPH_TS_RING 65536   // == Profiler::TS_RING
+
+// first block start / last block end of a launch on the device clock (launch-uniform branch: one scalar compare when off)
+__device__ __forceinline__ void sweep_stamp(unsigned long long* ts, bool end)
+{
+    // start: the first block of every XCD (blocks are dispatched in index order, block b to XCD b % 8); end: every block, once
+    // its last wave is through -- stamped by thread 0 behind a block barrier.  (A stamp per wave -- 32 k same-address atomics per
+    // launch -- made the sweeps 2.5 us longer.)
+    if (!ts) return;
+    if (!end) {
+        if (blockIdx.x < 8u && threadIdx.x == 0) atomicMin(ts, (unsigned long long)wall_clock64());
+        return;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(ts + SPH_TS_RING, (unsigned long long)wall_clock64());
+}
 
 __device__ __forceinline__ void raise_error(DeviceStatus* st, uint32_t code, uint32_t info)
 {
@@ -499,7 +518,18 @@ __device__ __forceinline__ void sweep_particle(const Op& op, const SweepCommon& 
 }
 
 template <class Op, bool BUILD>
+__device__ __forceinline__ void sweep_block(const Op& op, const SweepCommon& c);
+
+template <class Op, bool BUILD>
 __global__ __launch_bounds__(SWEEP_THREADS) void k_sweep(Op op, SweepCommon c)
+{
+    sweep_stamp(c.ts, false);
+    sweep_block<Op, BUILD>(op, c);
+    sweep_stamp(c.ts, true);
+}
+
+template <class Op, bool BUILD>
+__device__ __forceinline__ void sweep_block(const Op& op, const SweepCommon& c)
 {
     if (OpPrologue<Op>::run(op, blockIdx.x)) return;
     // XCD-aware block order: the dispatcher places block b on XCD b % 8; give every XCD a contiguous
@@ -572,7 +602,18 @@ struct TileNB<NB, true> {
 };
 
 template <class Op, bool BUILD>
+__device__ __forceinline__ void sweep_tile_block(const Op& op, const SweepCommon& c);
+
+template <class Op, bool BUILD>
 __global__ __launch_bounds__(SWEEP_THREADS) void k_sweep_tile(Op op, SweepCommon c)
+{
+    sweep_stamp(c.ts, false);
+    sweep_tile_block<Op, BUILD>(op, c);
+    sweep_stamp(c.ts, true);
+}
+
+template <class Op, bool BUILD>
+__device__ __forceinline__ void sweep_tile_block(const Op& op, const SweepCommon& c)
 {
     typedef typename Op::Math Math;
     typedef typename Op::NB NB;
@@ -2589,7 +2630,7 @@ __global__ __launch_bounds__(256) void k_integrate(uint32_t n, float dt, float v
 static SweepCommon common_of(const SweepArgs& a, bool ext)
 {
     return SweepCommon{a.g, ext ? a.t_ext : a.t, a.n, (a.n + SWEEP_THREADS - 1) / SWEEP_THREADS, a.cell_start, ext ? a.nl_ext : a.nl, ext ? a.nlx_ext : a.nlx, a.owned, a.ring1,
-                       0, nullptr, nullptr, nullptr, 0u, 0u};
+                       0, nullptr, nullptr, nullptr, 0u, 0u, nullptr};
 }
 
 // SPH_TILE: bit 0 = the BUILD sweep (density), bit 1 = the replay sweeps through the LDS-staged form (k_sweep_tile) in
@@ -2614,6 +2655,14 @@ extern "C" int sph_set_sweep_variant(int mode)
     return SPH_OK;
 }
 
+// one sweep kernel; under Profiler mode 3 it stamps the device clock into the launch's slot (sweep_stamp)
+template <class K, class Op>
+static void launch_sweep_kernel(K kernel, dim3 grid, hipStream_t s, const SweepArgs& a, const Op& op, SweepCommon c)
+{
+    c.ts = a.prof ? a.prof->take_slot() : nullptr;
+    hipLaunchKernelGGL(kernel, grid, dim3(SWEEP_THREADS), 0, s, op, c);
+}
+
 template <class Op, bool BUILD>
 static void launch_sweep(hipStream_t s, const SweepArgs& a, const Op& op)
 {
@@ -2628,18 +2677,18 @@ static void launch_sweep(hipStream_t s, const SweepArgs& a, const Op& op)
         c.n_eb = a.n_eb;
         if (a.part == 2) c.nblocks = (a.n_ea + a.n_eb + SWEEP_THREADS - 1) / SWEEP_THREADS;
         if (c.nblocks == 0) c.nblocks = 1;   // (the launch's prologue still runs)
-        hipLaunchKernelGGL((k_sweep<Op, BUILD>), dim3(((c.nblocks + 7) / 8) * 8), dim3(SWEEP_THREADS), 0, s, op, c);
+        launch_sweep_kernel(k_sweep<Op, BUILD>, dim3(((c.nblocks + 7) / 8) * 8), s, a, op, c);
         return;
     }
     const uint32_t nblocks = (a.n + SWEEP_THREADS - 1) / SWEEP_THREADS;
     const uint32_t grid = ((nblocks + 7) / 8) * 8;  // XCD remap needs a multiple of 8
     if constexpr (Op::Math::UNIFORM && !Op::EXTENDED && OpTile<Op>::value) {
         if (tile_mode(a) & (BUILD ? 1 : 2)) {
-            hipLaunchKernelGGL((k_sweep_tile<Op, BUILD>), dim3(grid), dim3(SWEEP_THREADS), 0, s, op, common_of(a, Op::EXTENDED));
+            launch_sweep_kernel(k_sweep_tile<Op, BUILD>, dim3(grid), s, a, op, common_of(a, Op::EXTENDED));
             return;
         }
     }
-    hipLaunchKernelGGL((k_sweep<Op, BUILD>), dim3(grid), dim3(SWEEP_THREADS), 0, s, op, common_of(a, Op::EXTENDED));
+    launch_sweep_kernel(k_sweep<Op, BUILD>, dim3(grid), s, a, op, common_of(a, Op::EXTENDED));
 }
 
 size_t sweep_list_bytes(uint32_t n) { return (size_t)n * sizeof(uint4); }
@@ -2678,7 +2727,7 @@ using OpDensityDist = OpDensity<M, true>;
 
 void launch_density(hipStream_t s, Profiler* prof, const SweepArgs& a)
 {
-    ProfScope ps(prof, "density", s);
+    ProfScope ps(prof, "density", s, true);
     if (a.h_mode != SPH_H_FROM_MASS) {
         SPH_DISPATCH(OpDensityDist, true, a.pm, a.orig, a.rho, a.mrho, a.lam_sum, a.lam_grad, a.ncount, a.planes, a.lam_lut, a.dlam_lut, a.status, a.sp,
                      a.h_mode, a.h2_next, a.lam_prev, a.owned)
@@ -2691,7 +2740,7 @@ void launch_density(hipStream_t s, Profiler* prof, const SweepArgs& a)
 // the density sweep again, over the recorded lists (after constrain_neighborhood_count changed the smoothing lengths)
 void launch_density_replay(hipStream_t s, Profiler* prof, const SweepArgs& a)
 {
-    ProfScope ps(prof, "density_replay", s);
+    ProfScope ps(prof, "density_replay", s, true);
     SPH_DISPATCH(OpDensityMass, false, a.pm, a.orig, a.rho, a.mrho, a.lam_sum, a.lam_grad, a.ncount, a.planes, a.lam_lut, a.dlam_lut, a.status, a.sp,
                  a.h_mode, a.h2_next, a.lam_prev, a.owned)
 }
@@ -2705,7 +2754,7 @@ void launch_constrain_init(hipStream_t s, Profiler* prof, const SweepArgs& a, ui
 void launch_constrain_pass(hipStream_t s, Profiler* prof, const SweepArgs& a, uint32_t target, float* thr, uint32_t* consumed, float* h_new,
                            uint32_t* pending)
 {
-    ProfScope ps(prof, "constrain_pass", s);
+    ProfScope ps(prof, "constrain_pass", s, true);
     SPH_DISPATCH(OpConstrain, false, a.pm, a.orig, a.ncount, thr, consumed, h_new, pending, a.status, target)
 }
 
@@ -2717,7 +2766,7 @@ void launch_constrain_apply(hipStream_t s, Profiler* prof, const SweepArgs& a, f
 
 void launch_aii_const(hipStream_t s, Profiler* prof, const SweepArgs& a)
 {
-    ProfScope ps(prof, "aii_constfield", s);
+    ProfScope ps(prof, "aii_constfield", s, true);
     SPH_DISPATCH(OpAiiConst, false, a.pm, a.orig, a.rho, a.mrho, a.lam_sum, a.lam_grad, a.aii, a.constf, a.status, a.sp,
                  a.sp_check_aii ? reinterpret_cast<float2*>(a.pacc) : nullptr)   // (check_aii borrows the a^p buffer before the solve: a^p for the field e_i)
 }
@@ -2734,7 +2783,7 @@ static void launch_fused_aii_np(hipStream_t s, const SweepArgs& a, const M& math
 // constant_field + a_ii and the non-pressure acceleration in one sweep (see OpFuse)
 void launch_aii_const_non_pressure(hipStream_t s, Profiler* prof, const SweepArgs& a)
 {
-    ProfScope ps(prof, "aii_nonpressure", s);
+    ProfScope ps(prof, "aii_nonpressure", s, true);
     if (a.exact) launch_fused_aii_np(s, a, MathExact{0.f});
     else if (a.uniform_h) launch_fused_aii_np(s, a, uniform_math(a.h_uniform));
     else launch_fused_aii_np(s, a, MathFast{0.f});
@@ -2742,13 +2791,13 @@ void launch_aii_const_non_pressure(hipStream_t s, Profiler* prof, const SweepArg
 
 void launch_check_aii(hipStream_t s, Profiler* prof, const SweepArgs& a)
 {
-    ProfScope ps(prof, "check_aii", s);
+    ProfScope ps(prof, "check_aii", s, true);
     SPH_DISPATCH(OpCheckAii, false, a.pm, a.orig, a.rho, a.mrho, a.lam_grad, a.aii, reinterpret_cast<const float2*>(a.pacc), a.status, a.sp)
 }
 
 void launch_non_pressure(hipStream_t s, Profiler* prof, const SweepArgs& a)
 {
-    ProfScope ps(prof, "non_pressure_accel", s);
+    ProfScope ps(prof, "non_pressure_accel", s, true);
     SPH_DISPATCH(OpNonPressure, false, a.pm, a.orig, a.rho, a.vel, a.vel_tmp, a.status, a.sp)
 }
 
@@ -2759,7 +2808,7 @@ using OpSourceOmega = OpSource<M, true>;
 
 void launch_source_term(hipStream_t s, Profiler* prof, const SweepArgs& a, int kind, int residual_density)
 {
-    ProfScope ps(prof, "source_term", s);
+    ProfScope ps(prof, "source_term", s, true);
     float4* rec1 = solve_on_records(a) ? a.rec1 : nullptr;
     if (kind == 3) {
         SPH_DISPATCH(OpSourceOmega, false, a.pm, a.orig, a.rho, a.mrho, a.vel, a.lam_grad, a.aii, a.src, a.p1, a.pt1, rec1, a.dens_err,
@@ -2773,7 +2822,7 @@ void launch_source_term(hipStream_t s, Profiler* prof, const SweepArgs& a, int k
 void launch_pressure_accel(hipStream_t s, Profiler* prof, const SweepArgs& a0, int iter, int residual_density, float max_avg_error, uint32_t max_iters, int multi,
                            int part)
 {
-    ProfScope ps(prof, part == 2 ? "pressure_accel_edge" : "pressure_accel", s);
+    ProfScope ps(prof, part == 2 ? "pressure_accel_edge" : "pressure_accel", s, true);
     SweepArgs a = a0;
     a.part = part;
     const SolveP q{residual_density, max_avg_error, max_iters, part ? 2 : multi, a.prog_host, a.prog_epoch};
@@ -2834,7 +2883,7 @@ void launch_solver_handoff(hipStream_t s, Profiler* prof, SolverCtrl* ctrl, Solv
 
 void launch_jacobi_update(hipStream_t s, Profiler* prof, const SweepArgs& a, int iter, int residual_density, float max_avg_error, uint32_t max_iters, int multi)
 {
-    ProfScope ps(prof, "jacobi_update", s);
+    ProfScope ps(prof, "jacobi_update", s, true);
     const float* pin = (iter & 1) ? a.p1 : a.p0;
     float* pout = (iter & 1) ? a.p0 : a.p1;
     float* ptout = (iter & 1) ? a.pt0 : a.pt1;
@@ -2889,34 +2938,34 @@ void launch_level_detect(hipStream_t s, Profiler* prof, const SweepArgs& a, cons
         // geometry of the advected positions
         if (a.n) hipLaunchKernelGGL(k_require_recorded_lists, dim3((a.n + 255) / 256), dim3(256), 0, s, a.n, a.nl_ext, a.orig, a.owned, a.status);
         if (l.center_diff) {
-            ProfScope ps(prof, "level_center_diff", s);
+            ProfScope ps(prof, "level_center_diff", s, true);
             SPH_DISPATCH(OpLevelCenterDiff, false, a.pm, l.pm_cell, l.level, l.when, l.mark, a.n, l.flag_surface, l.stash_first, l.k, l.max_surface_distance,
                          a.sp.rest_density)
             return;
         }
         {
-            ProfScope ps(prof, "level_normal", s);
+            ProfScope ps(prof, "level_normal", s, true);
             SPH_DISPATCH(OpLevelNormal, false, a.pm, l.pm_cell, l.nrm, l.state, l.flag_insufficient, a.planes, a.sp, l.k, l.boundary_is_fluid_surface)
         }
         {
-            ProfScope ps(prof, "level_cone", s);
+            ProfScope ps(prof, "level_cone", s, true);
             SPH_DISPATCH(OpLevelCone, false, a.pm, l.pm_cell, l.nrm, l.state, l.level, l.when, l.mark, a.n, l.flag_surface, l.stash_first, l.k, l.threshold, l.max_surface_distance,
                          l.maximum_range, a.sp.rest_density)
         }
         return;
     }
     if (l.center_diff) {
-        ProfScope ps(prof, "level_center_diff", s);
+        ProfScope ps(prof, "level_center_diff", s, true);
         SPH_DISPATCH(OpLevelCenterDiff, true, a.pm, l.pm_cell, l.level, l.when, l.mark, a.n, l.flag_surface, l.stash_first, l.k, l.max_surface_distance,
                      a.sp.rest_density)
         return;
     }
     {
-        ProfScope ps(prof, "level_normal", s);
+        ProfScope ps(prof, "level_normal", s, true);
         SPH_DISPATCH(OpLevelNormal, true, a.pm, l.pm_cell, l.nrm, l.state, l.flag_insufficient, a.planes, a.sp, l.k, l.boundary_is_fluid_surface)
     }
     {
-        ProfScope ps(prof, "level_cone", s);
+        ProfScope ps(prof, "level_cone", s, true);
         SPH_DISPATCH(OpLevelCone, false, a.pm, l.pm_cell, l.nrm, l.state, l.level, l.when, l.mark, a.n, l.flag_surface, l.stash_first, l.k, l.threshold, l.max_surface_distance,
                      l.maximum_range, a.sp.rest_density)
     }
@@ -2928,7 +2977,7 @@ template <class M>
 using OpLevelPropagateSlab = OpLevelPropagateT<M, true>;
 void launch_level_propagate(hipStream_t s, Profiler* prof, const SweepArgs& a, const LevelArgs& l, uint32_t t, uint32_t* changed)
 {
-    ProfScope ps(prof, "level_propagate", s);
+    ProfScope ps(prof, "level_propagate", s, true);
     const uint32_t* mark_cur = l.mark + ((t & 1u) ? a.n : 0u);
     uint32_t* mark_next = l.mark + ((t & 1u) ? 0u : a.n);
     if (l.plain_propagate == 2) {
@@ -2974,7 +3023,7 @@ void launch_max_disp(hipStream_t s, Profiler* prof, uint32_t n, const float4* pm
 
 void launch_level_smooth(hipStream_t s, Profiler* prof, const SweepArgs& a, const LevelArgs& l, const float4* pm_new, const float* in, float* out)
 {
-    ProfScope ps(prof, "level_smooth", s);
+    ProfScope ps(prof, "level_smooth", s, true);
     if (l.pm_cell && !l.replay_step_lists) {   // after advection, extended lists of the advected positions
         SPH_DISPATCH(OpLevelSmoothExt, false, pm_new, l.pm_cell, l.k, pm_new, a.orig, a.mrho, in, out, l.level_old, a.status, l.max_surface_distance)
         return;

@@ -149,7 +149,7 @@ class SphError(RuntimeError):
 # every symbol include/sph_ffi.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
     "create", "destroy", "upload", "upload_field", "download", "download_neighbors", "num_particles", "time",
-    "set_time", "step", "classify", "share_particles", "merge_particles", "set_split_patterns", "split_particles", "host_find_partners", "last_error", "grid", "set_boundary_polygon", "apply_edits", "profile_enable", "profile_reset", "profile_get", "profile_event_overhead", "profile_copy_bandwidth", "profile_list_forms", "set_sweep_variant",
+    "set_time", "step", "classify", "share_particles", "merge_particles", "set_split_patterns", "split_particles", "host_find_partners", "last_error", "grid", "set_boundary_polygon", "apply_edits", "profile_enable", "profile_reset", "profile_get", "profile_event_overhead", "profile_dispatch_bracket", "profile_copy_bandwidth", "profile_list_forms", "set_sweep_variant",
     "dist_configure", "dist_set_rebalance", "dist_get_cuts", "dist_get_stats", "comm_unique_id", "comm_init", "comm_init_shm", "group_step", "thread_group_create", "thread_group_destroy", "comm_init_threads",
 ]
 
@@ -206,6 +206,7 @@ class SphLibrary:
         self.profile_reset = sig("profile_reset", i32, [vp], required=False)
         self.profile_get = sig("profile_get", i32, [vp, C.POINTER(SphKernelTime), i32, C.POINTER(i32)], required=False)
         self.profile_event_overhead = sig("profile_event_overhead", i32, [vp, C.POINTER(C.c_double)], required=False)
+        self.profile_dispatch_bracket = sig("profile_dispatch_bracket", i32, [vp, C.c_uint32, i32, C.POINTER(C.c_double)], required=False)
         self.profile_copy_bandwidth = sig("profile_copy_bandwidth", i32, [vp, u64, C.POINTER(C.c_double)], required=False)
         self.profile_list_forms = sig("profile_list_forms", i32, [vp, C.POINTER(SphListForms)], required=False)
         self.set_sweep_variant = sig("set_sweep_variant", i32, [i32], required=False)
@@ -393,8 +394,9 @@ class Context:
         return g
 
     # ---- measurement hooks (product only) ----
-    def profile_enable(self, on: bool = True):
-        self._check(self.lib.profile_enable(self.handle, 1 if on else 0))
+    def profile_enable(self, mode=True):
+        """0 / False off; 1 / True marker events around every kernel; 3 the sweeps only, on the device's own clock (sph_ffi.h)"""
+        self._check(self.lib.profile_enable(self.handle, int(mode)))
 
     def profile_reset(self):
         self._check(self.lib.profile_reset(self.handle))
@@ -428,6 +430,12 @@ class Context:
     def profile_event_overhead_us(self) -> float:
         v = C.c_double(0.0)
         self._check(self.lib.profile_event_overhead(self.handle, C.byref(v)))
+        return float(v.value)
+
+    def profile_dispatch_bracket_us(self, spin_us: int = 20, reps: int = 50) -> float:
+        """mean dispatch-event bracket (microseconds) around a one-wave kernel that spins `spin_us` of the device clock"""
+        v = C.c_double(0.0)
+        self._check(self.lib.profile_dispatch_bracket(self.handle, int(spin_us), int(reps), C.byref(v)))
         return float(v.value)
 
     def dist_configure(self, rank: int, n_ranks: int, cut_lo: float, cut_hi: float):

@@ -45,6 +45,15 @@ ALGO_BYTES = {
 }
 
 
+# VALU instructions per wave of the sweeps (rocprofv3 --pmc SQ_INSTS_VALU / SQ_WAVES, profiles/r3_sq_counters.txt) and the shader clock
+# those launches ran at (SQ_BUSY_CYCLES / 32 / duration, same file): what the `valu_issue` object of a roofline entry is priced with
+VALU_ISSUE = {"density": 1278, "aii_nonpressure": 1298, "source_term": 804, "pressure_accel": 511, "jacobi_update": 674}
+SHADER_CLOCK_HZ = 2.06e9
+# rocprofv3's duration of the profiler's calibration kernel (one wave spinning 10 us of the device clock): 10 us + the launch / exit
+# of a one-wave dispatch, measured once against a kernel trace (profiles/r4_event_calibration.md: 5.33 / 20.44 / 40.43 / 100.47 for
+# 5 / 20 / 40 / 100 us)
+SPIN10_ROCPROF_US = 10.44
+
 # rocprofv3 kernel names of the sweeps (profiles/*_kernel_summary.json keys)
 PMC_NAMES = {"density": "OpDensity[build]", "aii_constfield": "OpAiiConst", "non_pressure_accel": "OpNonPressure",
              "source_term": "OpSource", "pressure_accel": "OpPressureAccelU", "jacobi_update": "OpJacobiU"}
@@ -65,14 +74,16 @@ def committed_pmc_traffic(kernel):
         return None, None
 
 
-def committed_pmc_median(kernel):
-    """rocprofv3's median duration (us) of `kernel` in the newest committed summary of configs[1]: what `avg_us` should be compared with."""
+def committed_pmc_avg(kernel):
+    """rocprofv3's average duration (us) of `kernel`'s working launches in the newest committed summary of configs[1] (the same
+    command under rocprofv3 --kernel-trace --stats): what `avg_us` must agree with."""
     import re
     files = sorted(f for f in (REPO / "profiles").glob("*_kernel_summary.json") if re.fullmatch(r"r\d+[a-z]?_kernel_summary\.json", f.name))
     if not files or kernel not in PMC_NAMES:
         return None
     try:
-        return json.load(open(files[-1])).get(PMC_NAMES[kernel], {}).get("median_us_working")
+        e = json.load(open(files[-1])).get(PMC_NAMES[kernel], {})
+        return e.get("avg_us_working", e.get("median_us_working"))
     except Exception:  # noqa: BLE001
         return None
 
@@ -85,7 +96,7 @@ def parse_args():
     ap.add_argument("--workload", default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
-    ap.add_argument("--profile-steps", type=int, default=20)
+    ap.add_argument("--profile-steps", type=int, default=-1, help="0: skip the instrumented pass (it repeats the timed window: warm-up + steps)")
     ap.add_argument("--no-extra", action="store_true", help="skip the short runs of the other single-GPU BASELINE configs")
     ap.add_argument("--no-8m", action="store_true", help="skip the strong-scaling leg on configs[3] (8.4M particles)")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
@@ -270,19 +281,40 @@ def main():
 
     n_local = ctx.n
 
-    # ---- instrumented pass: HIP events around every kernel on the library's own stream
-    prof_all, prof_work, ev_overhead_us = {}, {}, 0.0
-    if distributed:
-        args.profile_steps = min(args.profile_steps, 5)   # the per-kernel numbers that are judged come from the N = 1 run
-    if args.profile_steps > 0:
+    # ---- instrumented pass: THE SAME WINDOW again -- a fresh context, the same upload, the same W warm-up steps unprofiled, then the
+    # same K steps with HIP events (timing-enabled markers on the library's own stream) around every kernel.  The step is
+    # deterministic, so these are the launches of the timed region (same kernels, same iteration counts: recorded below), and a
+    # rocprofv3 --kernel-trace --stats of `bench.py --profile-steps 0` with the same flags (profiles/r4*_kernel_summary.*) sees exactly
+    # them.  A marker pair reads MORE than the duration rocprofv3 reports for the kernel it brackets (the two marker packets are
+    # processed inside the bracket): that excess is measured live, in the same pass -- the profiler launches one kernel of KNOWN
+    # duration per step behind the density sweep ("calibration_spin10": one wave spinning 10 us of the device's 100 MHz clock, which
+    # rocprofv3 reports as 10.44 us, profiles/r4_event_calibration.md), bracketed like every other kernel -- and subtracted.
+    prof_all, prof_work, ev_overhead_us, marker_excess_us = {}, {}, 0.0, 0.0
+    prof_window = None
+    if args.profile_steps != 0:
+        ctx.close()
+        ctx, _ = make_context(scene, params)
+        k_prof = args.steps if not distributed else min(args.steps, 5)   # (the per-kernel numbers that are judged come from the N = 1 run)
+        for _ in range(args.warmup):
+            ctx.step(p)
         ctx.profile_reset()
         ctx.profile_enable(1)
-        for _ in range(args.profile_steps):
-            ctx.step(p)
+        di2, de2 = [], []
+        for _ in range(k_prof):
+            st = ctx.step(p)
+            di2.append(int(st.div_solver.iters) + 1)
+            de2.append(int(st.density_solver.iters) + 1)
         prof_all = ctx.profile_get()
-        prof_work = ctx.profile_get_working()     # without the speculative launches that return at once
+        prof_work = ctx.profile_get_working()     # without the launches that return at once behind a stop decision
         ev_overhead_us = ctx.profile_event_overhead_us()
         ctx.profile_enable(0)
+        cal = prof_all.pop("calibration_spin10", None)
+        prof_work.pop("calibration_spin10", None)
+        if cal and cal[0]:
+            marker_excess_us = max(0.0, cal[1] * 1e3 / cal[0] - SPIN10_ROCPROF_US)
+        prof_window = {"steps": k_prof, "first_step": args.warmup, "same_iteration_counts_as_timed_region": (di2 == div_iters[:k_prof] and de2 == dens_iters[:k_prof]),
+                       "marker_excess_us": marker_excess_us, "calibration_launches": cal[0] if cal else 0}
+        args.profile_steps = k_prof
     copy_gbs = ctx.profile_copy_bandwidth_gbs(1 << 30) if rank == 0 else 0.0   # achievable HBM rate of this device, same run
     ctx.close()
 
@@ -366,28 +398,38 @@ def main():
         return
 
     def roof(name, launches, total_ms):
-        """Launch duration = HIP-event time of the launches that did work, minus what the event pair itself adds
-        (measured live with empty kernels): the quantity rocprofv3 reports as the kernel's duration."""
+        """Average duration of the kernel's launches that did work: HIP-event brackets over the instrumented repeat of the timed
+        window, minus the marker excess calibrated in the same pass (see above) -- the quantity rocprofv3 --kernel-trace --stats
+        reports as that kernel's average duration for the same command (profiles/r4*_kernel_summary.*: `avg_us_working`)."""
         if not launches or name not in ALGO_BYTES:
             return None
         raw_us = total_ms * 1e3 / launches
-        # the HIP-event bracket as it is.  It also holds what the event pair adds (~2 us against rocprofv3's duration of the same kernel,
-        # profiles/), so `frac` errs LOW by ~8 %.  The pair's cost as measured with empty kernels (`event_overhead_us`, ~5 us) is
-        # reported but NOT subtracted: it overestimates the excess on a working kernel, and the corrected figure would err high.
-        avg_s = raw_us * 1e-6
+        avg_s = (raw_us - marker_excess_us) * 1e-6
         achieved = ALGO_BYTES[name] * n_local / avg_s / 1e9
         traffic, src = committed_pmc_traffic(name) if wl == "dam_break_1m" and not distributed else (None, None)
-        return {"kernel": name, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src, "avg_us": avg_s * 1e6,
-                "event_overhead_us": ev_overhead_us, "rocprofv3_median_us_committed": committed_pmc_median(name) if wl == "dam_break_1m" and not distributed else None, "launches_timed": launches,
-                "copy_kernel_GBs": copy_gbs, "frac_of_copy_kernel": (achieved / copy_gbs) if copy_gbs else None,
-                "algorithmic_bytes_per_particle": ALGO_BYTES[name], "algorithmic_bytes_per_launch": ALGO_BYTES[name] * n_local}
+        issue = VALU_ISSUE.get(name)
+        r = {"kernel": name, "bound": "valu-issue" if issue else "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src, "avg_us": avg_s * 1e6,
+             "avg_us_event_bracket": raw_us, "marker_excess_us": marker_excess_us,
+             "rocprofv3_avg_us_committed": committed_pmc_avg(name) if wl == "dam_break_1m" and not distributed else None,
+             "launches_timed": launches, "window": prof_window,
+             "copy_kernel_GBs": copy_gbs, "frac_of_copy_kernel": (achieved / copy_gbs) if copy_gbs else None,
+             "algorithmic_bytes_per_particle": ALGO_BYTES[name], "algorithmic_bytes_per_launch": ALGO_BYTES[name] * n_local}
+        if issue:
+            # what bounds the sweep by the SQ counters (profiles/r3_sq_counters.txt): VALU instruction issue, priced with the measured
+            # instruction classes (2 / 4 / 8 clocks per wave64 instruction, ~3 on the sweeps' mix; profiles/r3_valu_issue.md).
+            # 16384 waves of 64 lanes per 2^20 particles on 1024 SIMDs; the launch's clocks = avg_us x the shader clock under load.
+            waves_per_simd = (n_local / 64.0) / 1024.0
+            clocks = avg_s * SHADER_CLOCK_HZ
+            r["valu_issue"] = {"valu_instructions_per_wave": issue, "clocks_per_instruction": 3.0, "shader_clock_GHz": SHADER_CLOCK_HZ / 1e9,
+                               "frac": issue * waves_per_simd * 3.0 / clocks, "source": "profiles/r3_sq_counters.txt (SQ_INSTS_VALU / SQ_WAVES), profiles/r3_valu_issue.md"}
+        return r
 
     total_prof_ms = sum(v[1] for v in prof_all.values()) or 1.0
     kernels = []
     for name, (launches, total_ms) in sorted(prof_all.items(), key=lambda kv: -kv[1][1]):
-        k = {"name": name, "launches_per_step": launches / max(args.profile_steps, 1), "avg_us_hip_events": total_ms * 1e3 / max(launches, 1),
-             "time_share": total_ms / total_prof_ms}
+        k = {"name": name, "launches_per_step": launches / max(args.profile_steps, 1), "avg_us_event_bracket": total_ms * 1e3 / max(launches, 1),
+             "avg_us": total_ms * 1e3 / max(launches, 1) - marker_excess_us, "time_share": total_ms / total_prof_ms}
         r = roof(name, *prof_work.get(name, (launches, total_ms)))
         if r:
             k["achieved_GBs"] = r["achieved"]
@@ -398,10 +440,12 @@ def main():
     dominant = max((n for n in prof_work if n in ALGO_BYTES), key=lambda n: prof_work[n][1], default=None)
     roofline = roof(dominant, *prof_work[dominant]) if dominant else None
     roofline_density = roof("density", *prof_work["density"]) if "density" in prof_work else None
-    timing_note = (f"HIP events on the library's stream, instrumented pass of {args.profile_steps} steps continuing the same "
-                   f"workload right after the timed region (events perturb dispatch, so the timed region is uninstrumented); "
-                   f"avg_us = event time of the launches that did work, nothing subtracted; `traffic` is not measured in this run: "
-                   f"it is the FETCH_SIZE x2 + WRITE_SIZE figure of the rocprofv3 --pmc passes summarised in `traffic_source`")
+    timing_note = (f"HIP events on the library's stream around every kernel, over an instrumented REPEAT of the "
+                   f"timed window (fresh context, same {args.warmup} warm-up steps, same {args.profile_steps} steps; events perturb dispatch, so "
+                   f"the timed region itself is uninstrumented); avg_us = mean bracket of the launches that did work minus the marker excess "
+                   f"({marker_excess_us:.2f} us, calibrated in the same pass with a kernel of known duration in the step's queue); dominant kernel = "
+                   f"largest total over that window; `traffic` is not measured in this run: it is the FETCH_SIZE x2 + WRITE_SIZE figure of the rocprofv3 "
+                   f"--pmc passes summarised in `traffic_source`")
     for r in (roofline, roofline_density):
         if r:
             r["timing"] = timing_note

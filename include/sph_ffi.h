@@ -372,6 +372,10 @@ int  sph_profile_get(sph_ctx* ctx, sph_kernel_time* out, int capacity, int* n_ou
 /* what a HIP-event pair adds to the duration of the kernel it brackets (microseconds), measured with empty kernels:
  * 2 x (pair around one) - (pair around two).  bench.py subtracts it to compare with rocprofv3's kernel durations. */
 int  sph_profile_event_overhead(sph_ctx* ctx, double* microseconds);
+/* a marker-event pair (what sph_profile_enable(ctx, 1) brackets every kernel with) around a one-wave kernel that spins `spin_us`
+ * microseconds of the device clock, alone on the queue, mean over `reps` launches (diagnostic: the in-step calibration of bench.py is the
+ * profiler's own "calibration_spin10" record) */
+int sph_profile_dispatch_bracket(sph_ctx* ctx, uint32_t spin_us, int reps, double* mean_bracket_us);
 /* bandwidth of a plain float4 copy kernel over `bytes` of device memory (read + write, GB/s, best of 5): the achievable
  * HBM rate on this device, reported next to the 8 TB/s spec peak */
 int  sph_profile_copy_bandwidth(sph_ctx* ctx, uint64_t bytes, double* gb_per_s);

@@ -1,6 +1,11 @@
 #!/usr/bin/env python3
 """Condense a gpurun_out/<run>/ directory (bench.json, rocprofv3 kernel-trace stats, PMC passes) into the
-files committed under profiles/:   python scripts/summarize_profile.py gpurun_out/r1 profiles/r1"""
+files committed under profiles/:   python scripts/summarize_profile.py gpurun_out/r1 profiles/r1 [warmup_steps]
+
+The kernel trace is of `bench.py --steps K --warmup W --profile-steps 0`: W + K steps, one density BUILD launch each.  Besides the
+figures over the whole trace, every kernel gets the figures of the TIMED WINDOW alone (the launches from the (W+1)-th step's first
+kernel on): `avg_us_working` / `total_ms_window` -- what bench.py's roofline object (dispatch timestamps over an instrumented repeat
+of the same window) must agree with."""
 import collections
 import csv
 import json
@@ -10,6 +15,7 @@ import sys
 from pathlib import Path
 
 src, dst = Path(sys.argv[1]), sys.argv[2]
+WARMUP = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 Path(dst).parent.mkdir(parents=True, exist_ok=True)
 if (src / "bench.json").exists():
     shutil.copy(src / "bench.json", dst + "_bench.json")
@@ -25,8 +31,20 @@ def short(name):
 # exit in ~1-2 us and would drag the plain average down)
 trace = list(csv.DictReader(open(next((src / "kt").rglob("*kernel_trace.csv")))))
 dur = collections.defaultdict(list)
+start_of = collections.defaultdict(list)
 for r in trace:
     dur[short(r["Kernel_Name"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    start_of[short(r["Kernel_Name"])].append(int(r["Start_Timestamp"]))
+# the timed window: from the first kernel of step WARMUP on.  A step begins with the cell sort's first pass (k_rs_hist..[build]: it
+# makes the keys), once per step like the density BUILD sweep
+build = next((k for k in dur if k.startswith("OpDensity") and "[build]" in k), None)
+first = next((k for k in dur if k.startswith("k_rs_hist") and "[build]" in k and build and len(dur[k]) == len(dur[build])), build)
+t_window = sorted(start_of[first])[WARMUP] if first and len(start_of[first]) > WARMUP else None
+dur_w = collections.defaultdict(list)
+if t_window is not None:
+    for r in trace:
+        if int(r["Start_Timestamp"]) >= t_window:
+            dur_w[short(r["Kernel_Name"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 
 
 def pmc(dirname, counter):
@@ -45,6 +63,10 @@ for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
     ref = sorted(v)[int(0.9 * (len(v) - 1))]   # 90th percentile: one slow outlier must not define what "working" means
     real = [x for x in v if x > 0.25 * ref]
     e = {"launches": len(v), "working_launches": len(real), "median_us_working": statistics.median(real), "total_ms": sum(v) / 1e3}
+    if dur_w.get(k):
+        rw = [x for x in dur_w[k] if x > 0.25 * ref]
+        e.update({"window_first_step": WARMUP, "window_launches": len(dur_w[k]), "window_working_launches": len(rw),
+                  "avg_us_working": (sum(rw) / len(rw)) if rw else None, "total_ms_window": sum(dur_w[k]) / 1e3})
     # FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 64 B per 128-B request -> x2 (MI355X_MICROARCH.md,
     # confirmed in round 1 on the then separate key kernel: 16 B/particle read -> 8203 KiB reported for 2^20 particles) ; WRITE_SIZE is exact
     # (that kernel wrote 8 B/particle -> 8192 KiB)
@@ -60,8 +82,10 @@ for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
     summary[k] = e
 json.dump(summary, open(dst + "_kernel_summary.json", "w"), indent=1)
 with open(dst + "_kernel_summary.md", "w") as fh:
-    fh.write("| kernel | launches | working | median us (working) | total ms | HBM read MB | HBM write MB |\n|---|---|---|---|---|---|---|\n")
+    fh.write(f"| kernel | launches | working | median us (working) | total ms | window (steps >= {WARMUP}): launches | avg us (working) | total ms | HBM read MB | HBM write MB |\n|---|---|---|---|---|---|---|---|---|---|\n")
     for k, e in summary.items():
+        aw = e.get("avg_us_working")
         fh.write(f"| {k} | {e['launches']} | {e['working_launches']} | {e['median_us_working']:.1f} | {e['total_ms']:.2f} | "
+                 f"{e.get('window_launches', 0)} | {(f'{aw:.1f}' if aw else '-')} | {e.get('total_ms_window', 0):.2f} | "
                  f"{e.get('hbm_read_bytes_per_launch', 0) / 1e6:.1f} | {e.get('hbm_write_bytes_per_launch', 0) / 1e6:.1f} |\n")
 print(open(dst + "_kernel_summary.md").read())

@@ -13,7 +13,7 @@ import pytest
 
 from adaptive_sph_amd import distributed as D, ffi, scene as sc
 from adaptive_sph_amd.workloads import WORKLOADS
-from tests.oracle_harness import displacement_bars
+from tests.oracle_harness import displacement_bars, same_sets
 
 pytestmark = pytest.mark.gpu
 
@@ -26,28 +26,6 @@ def rel_err(a, b):
     b = np.asarray(b, np.float64)
     s = np.abs(b).max()
     return np.abs(a - b).max() / (s if s > 0 else 1.0)
-
-
-def same_sets(g, o):
-    """Equal CSR offsets, per particle equal sums and sums of squares of the neighbour indices (a cheap first look), then the SETS
-    entry by entry: the order inside a list is unspecified (cell-sorted here, ascending in the oracle)."""
-    go, gi = g.download_neighbors()
-    oo, oi = o.download_neighbors()
-    assert np.array_equal(go, oo)
-    starts = go[:-1].astype(np.int64)
-    assert (np.diff(go.astype(np.int64)) > 0).all()          # every particle is on its own list
-    for power in (1, 2):
-        a = np.add.reduceat(gi.astype(np.uint64) ** power, starts)
-        b = np.add.reduceat(oi.astype(np.uint64) ** power, starts)
-        assert np.array_equal(a, b), power
-    # ... and the sets themselves: (row, index) packed into one 64-bit key per entry, the device's entries sorted (the oracle's lists
-    # are ascending already), compared whole -- 13 M entries at configs[1], 110 M at configs[3]
-    rows = np.repeat(np.arange(len(go) - 1, dtype=np.uint64), np.diff(go.astype(np.int64))) << np.uint64(32)
-    key_o = rows | oi.astype(np.uint64)
-    assert (np.diff(key_o.astype(np.int64)) > 0).all()
-    key_g = rows | gi.astype(np.uint64)
-    key_g.sort()
-    assert np.array_equal(key_g, key_o)
 
 
 def make_pair(product_lib, oracle_lib, name, **overrides):
