@@ -110,7 +110,15 @@ int slab_refresh_fused(Group& G, std::vector<Member>& M, std::vector<std::vector
 // refresh `field` (words floats per particle) of every member's ghosts from their owners; tot_slot >= 0: the all-reduce of that slot's
 // solver totals rides in the same call
 // `sel2` (one word per particle, like `sel` then): a second field in the SAME exchange -- the level estimation's (level, when) pair
-int refresh_ghosts(Group& G, std::vector<Member>& M, float* (*sel)(Member&), int words, const char* what, int tot_slot = -1, float* (*sel2)(Member&) = nullptr);
+// `stride` / `off` (floats): where the field's words sit inside a wider per-particle record (default: a plain array of `words` floats)
+// `totals` (with tot_slot >= 0): this rank's solver totals of that iteration are added up by block 0 of the packing launch itself
+struct TotalsJob {
+    int iter, residual_density;
+    float max_avg_error;
+    uint32_t max_iters;
+};
+int refresh_ghosts(Group& G, std::vector<Member>& M, float* (*sel)(Member&), int words, const char* what, int tot_slot = -1, float* (*sel2)(Member&) = nullptr,
+                   int stride = 0, int off = 0, const TotalsJob* totals = nullptr);
 // after the cell sort: slot maps of halo members and ghosts, ownership flags, the split sweep's edge bytes, the ghosts' {x, y, a^p} records
 int slab_maps_after_sort(sph_ctx* c, uint32_t n, bool pre, hipStream_t s);
 // m / rho of the ghosts from their refreshed densities

@@ -172,7 +172,9 @@ struct SweepArgs {
     const uint32_t* elist_b = nullptr;
     uint32_t n_ea = 0, n_eb = 0;
     int part = 0;
-    double* solver_tot; // multi-rank: all-reduced solver totals
+    double* solver_tot; // multi-rank: all-reduced solver totals (RCCL: this rank's own row; the others' rows in tot_table)
+    const double* tot_table = nullptr;   // RCCL transport: every rank's totals side by side, summed by the readers (SolveP, sph_sweeps.hip)
+    int tot_nr = 0, tot_self = 0;
     float* mrho;        // m / rho
     float* pt0;         // p / rho^2 for pressure buffer 0 / 1
     float* pt1;
@@ -194,6 +196,9 @@ struct SweepArgs {
     Profiler* prof = nullptr;                   // host side only: the context's profiler (launch_sweep asks it for a timestamp slot)
 };
 
+// the solves of this step keep p / rho^2 inside the 16-byte records {x, y, p / rho^2, p} (rec0 / rec1) that sweep A gathers whole, not
+// in pt0 / pt1: what a slab decomposition exchanges for its ghosts per iteration is then word 2 of those records
+bool sweep_a_on_records(const SweepArgs& a);
 size_t sweep_list_bytes(uint32_t n);
 size_t sweep_index_list_bytes(uint32_t n);   // explicit index lists (multi-resolution scenes)
 bool sweep_forces_index_lists();             // build variant SPH_FORCE_IDX
@@ -213,7 +218,11 @@ void launch_source_term(hipStream_t s, Profiler* prof, const SweepArgs& a, int k
 void launch_pressure_accel(hipStream_t s, Profiler* prof, const SweepArgs& a, int iter, int residual_density, float max_avg_error, uint32_t max_iters, int multi,
                            int part = 0);
 void launch_solver_totals(hipStream_t s, Profiler* prof, const SweepArgs& a, int iter, int residual_density, float max_avg_error, uint32_t max_iters);
+// ... as block 0 of the launch that packs the halo members' values for the iteration's ghost exchange (sph_slabs.hip: refresh_ghosts)
+void launch_pack_and_totals(hipStream_t s, Profiler* prof, const SweepArgs& a, int iter, int residual_density, float max_avg_error, uint32_t max_iters,
+                            const uint32_t* src_idx, uint32_t cnt0, uint32_t cnt1, int words, int stride, int off, const float* field, float* out0, float* out1);
 void launch_ctrl_reset(hipStream_t s, SolverCtrl* ctrl, const uint32_t* gate);
+void launch_solver_progress(hipStream_t s, Profiler* prof, const SweepArgs& a, int iter, int residual_density, float max_avg_error, uint32_t max_iters);   // paced slabs (no-op unless a.prog_host)
 void launch_solver_handoff(hipStream_t s, Profiler* prof, SolverCtrl* ctrl, SolverCtrl* saved_host, uint32_t* gate);
 void launch_solver_tail(hipStream_t s, Profiler* prof, const SweepArgs& a, int tail, float4* pm_out, int decide_iter = -1, int residual_density = 0,
                         float max_avg_error = 0.f, uint32_t max_iters = 0, SolverCtrl* handoff_host = nullptr, uint32_t* gate_out = nullptr);

@@ -193,13 +193,19 @@ __global__ __launch_bounds__(256) void k_halo_pos(const uint32_t* __restrict__ h
 // `cls` (fused refresh, else nullptr): halo_pos is only defined for the halo members then -- slots whose class byte says so and the
 // arrivals behind the n_cls previous slots -- and nothing had to clear the rest of it
 // pacc[slot] = {x, y, 0, 0} for every ghost slot (see setup_member)
-__global__ __launch_bounds__(256) void k_seed_ghost_records(const uint32_t* __restrict__ ghost_dst, uint32_t ng, const float4* __restrict__ pm, float4* __restrict__ pacc)
+// ... and the same for the two pressure records {x, y, p / rho^2, p} sweep A gathers (OpPressureAccelU): the ghosts' p / rho^2 arrives
+// with every iteration's exchange, their positions are seeded here
+__global__ __launch_bounds__(256) void k_seed_ghost_records(const uint32_t* __restrict__ ghost_dst, uint32_t ng, const float4* __restrict__ pm, float4* __restrict__ pacc,
+                                                             float4* __restrict__ rec0, float4* __restrict__ rec1)
 {
     const uint32_t k = blockIdx.x * 256 + threadIdx.x;
     if (k >= ng) return;
     const uint32_t i = ghost_dst[k];
     const float4 p = pm[i];
-    pacc[i] = make_float4(p.x, p.y, 0.f, 0.f);
+    const float4 r = make_float4(p.x, p.y, 0.f, 0.f);
+    pacc[i] = r;
+    rec0[i] = r;
+    rec1[i] = r;
 }
 __global__ void k_edge_mark(const uint32_t* __restrict__ halo_src, uint32_t nh, const uint32_t* __restrict__ ghost_dst, uint32_t ng, uint8_t* __restrict__ edge)
 {
@@ -230,23 +236,25 @@ __global__ __launch_bounds__(256) void k_build_maps(uint32_t n_tot, uint32_t n_o
 
 // refresh one field of the ghosts: gather my halo particles' values / scatter the received ones
 // both sides in one launch: entries [0, cnt0) belong to the left neighbour's staging buffer, [cnt0, cnt0 + cnt1) to the right one's
-__global__ __launch_bounds__(256) void k_pack_field(const uint32_t* __restrict__ src_idx, uint32_t cnt0, uint32_t cnt1, int words,
+// (`stride`, `off`: the field's `words` floats sit at field[i * stride + off ..) -- a plain array has stride == words, off == 0; p / rho^2
+//  inside the 16-byte pressure records {x, y, p / rho^2, p} has words 1, stride 4, off 2)
+__global__ __launch_bounds__(256) void k_pack_field(const uint32_t* __restrict__ src_idx, uint32_t cnt0, uint32_t cnt1, int words, int stride, int off,
                                                      const float* __restrict__ field, float* __restrict__ out0, float* __restrict__ out1)
 {
     uint32_t k = blockIdx.x * 256 + threadIdx.x;
     if (k >= cnt0 + cnt1) return;
     const uint32_t i = src_idx[k];
     float* out = k < cnt0 ? out0 + (size_t)k * words : out1 + (size_t)(k - cnt0) * words;
-    for (int w = 0; w < words; w++) out[w] = field[(size_t)i * words + w];
+    for (int w = 0; w < words; w++) out[w] = field[(size_t)i * stride + off + w];
 }
-__global__ __launch_bounds__(256) void k_unpack_field(const uint32_t* __restrict__ dst_idx, uint32_t cnt0, uint32_t cnt1, int words,
+__global__ __launch_bounds__(256) void k_unpack_field(const uint32_t* __restrict__ dst_idx, uint32_t cnt0, uint32_t cnt1, int words, int stride, int off,
                                                        const float* __restrict__ in0, const float* __restrict__ in1, float* __restrict__ field)
 {
     uint32_t k = blockIdx.x * 256 + threadIdx.x;
     if (k >= cnt0 + cnt1) return;
     const uint32_t i = dst_idx[k];
     const float* in = k < cnt0 ? in0 + (size_t)k * words : in1 + (size_t)(k - cnt0) * words;
-    for (int w = 0; w < words; w++) field[(size_t)i * words + w] = in[w];
+    for (int w = 0; w < words; w++) field[(size_t)i * stride + off + w] = in[w];
 }
 
 // m / rho of the ghosts from the refreshed rho (the same expression the owner evaluated: bit-identical, no second exchange)
@@ -324,8 +332,11 @@ __global__ __launch_bounds__(1024) void k_slab_scan(uint32_t nb, const uint32_t*
     const uint32_t per = (nb + 1023u) / 1024u;
     const uint32_t b0 = min(nb, t * per), b1 = min(nb, b0 + per);
     uint32_t sum[4] = {0u, 0u, 0u, 0u};
-    for (uint32_t b = b0; b < b1; b++)
-        for (int k = 0; k < 4; k++) sum[k] += blk_cnt[b * 4 + k];
+    const uint4* __restrict__ cnt4 = reinterpret_cast<const uint4*>(blk_cnt);   // (one 16-byte load per block: 32768 blocks at 8M particles, one thread block)
+    for (uint32_t b = b0; b < b1; b++) {
+        const uint4 v = cnt4[b];
+        sum[0] += v.x; sum[1] += v.y; sum[2] += v.z; sum[3] += v.w;
+    }
     uint32_t inc[4];
     for (int k = 0; k < 4; k++) {
         uint32_t v = sum[k];
@@ -343,11 +354,12 @@ __global__ __launch_bounds__(1024) void k_slab_scan(uint32_t nb, const uint32_t*
         for (uint32_t w = 0; w < wave; w++) base += s_wave[w][k];
         run[k] = base + inc[k] - sum[k];
     }
-    for (uint32_t b = b0; b < b1; b++)
-        for (int k = 0; k < 4; k++) {
-            blk_off[b * 4 + k] = run[k];
-            run[k] += blk_cnt[b * 4 + k];
-        }
+    uint4* __restrict__ off4 = reinterpret_cast<uint4*>(blk_off);
+    for (uint32_t b = b0; b < b1; b++) {
+        const uint4 v = cnt4[b];
+        off4[b] = make_uint4(run[0], run[1], run[2], run[3]);
+        run[0] += v.x; run[1] += v.y; run[2] += v.z; run[3] += v.w;
+    }
     if (t == 1023u) {
         const uint32_t is_bad = counts[RC_BAD];
         counts[RC_BAD] = 0u;
@@ -433,9 +445,11 @@ __global__ void k_fill_u8(uint8_t* p, uint32_t n, uint8_t v)
 
 // refresh `field` (words floats per particle) of every member's ghosts from their owners
 // `tot_slot` >= 0: the all-reduce of the solver totals of that slot rides in the same call (Comm::exchange_and_allreduce_solver)
-int refresh_ghosts(Group& G, std::vector<Member>& M, float* (*sel)(Member&), int words, const char* what, int tot_slot, float* (*sel2)(Member&))
+int refresh_ghosts(Group& G, std::vector<Member>& M, float* (*sel)(Member&), int words, const char* what, int tot_slot, float* (*sel2)(Member&), int stride, int off,
+                   const TotalsJob* totals)
 {
     if (!G.multi()) return SPH_OK;
+    if (stride <= 0) stride = words;
     const int nf = sel2 ? 2 : 1;   // fields per exchange: the second one is packed behind the first in every buffer
     std::vector<Xfer> x(M.size());
     for (size_t i = 0; i < M.size(); i++) {
@@ -443,9 +457,14 @@ int refresh_ghosts(Group& G, std::vector<Member>& M, float* (*sel)(Member&), int
         (void)hipSetDevice(c->device);
         ProfScope ps(&c->prof, "ghost_pack", c->stream);
         const uint32_t nh = c->dist.n_halo[0] + c->dist.n_halo[1];
+        if (totals && M[i].n && nf == 1) {   // the pack launch also adds up the rank's solver totals (its block 0): one launch, neighbours or not
+            launch_pack_and_totals(c->stream, nullptr, M[i].a, totals->iter, totals->residual_density, totals->max_avg_error, totals->max_iters,
+                                   c->dist.halo_src.as<uint32_t>(), c->dist.n_halo[0], c->dist.n_halo[1], words, stride, off, sel(M[i]), c->dist.send[0].as<float>(),
+                                   c->dist.send[1].as<float>());
+        } else
         for (int f = 0; f < nf && nh; f++)
             hipLaunchKernelGGL(k_pack_field, dim3((nh + 255) / 256), dim3(256), 0, c->stream, c->dist.halo_src.as<uint32_t>(), c->dist.n_halo[0],
-                               c->dist.n_halo[1], words, f ? sel2(M[i]) : sel(M[i]), c->dist.send[0].as<float>() + (size_t)f * c->dist.n_halo[0] * words,
+                               c->dist.n_halo[1], words, stride, off, f ? sel2(M[i]) : sel(M[i]), c->dist.send[0].as<float>() + (size_t)f * c->dist.n_halo[0] * words,
                                c->dist.send[1].as<float>() + (size_t)f * c->dist.n_halo[1] * words);
         for (int side = 0; side < 2; side++) {
             const uint32_t cnt = c->dist.n_halo[side];
@@ -464,7 +483,7 @@ int refresh_ghosts(Group& G, std::vector<Member>& M, float* (*sel)(Member&), int
         const uint32_t ng = c->dist.ghosts_ok ? c->dist.n_ghost[0] + c->dist.n_ghost[1] : 0u;   // (no ghost slots: received, dropped)
         for (int f = 0; f < nf && ng; f++)
             hipLaunchKernelGGL(k_unpack_field, dim3((ng + 255) / 256), dim3(256), 0, c->stream, c->dist.ghost_dst.as<uint32_t>(), c->dist.n_ghost[0],
-                               c->dist.n_ghost[1], words, c->dist.recv[0].as<float>() + (size_t)f * c->dist.n_ghost[0] * words,
+                               c->dist.n_ghost[1], words, stride, off, c->dist.recv[0].as<float>() + (size_t)f * c->dist.n_ghost[0] * words,
                                c->dist.recv[1].as<float>() + (size_t)f * c->dist.n_ghost[1] * words, f ? sel2(M[i]) : sel(M[i]));
     }
     (void)what;
@@ -1004,7 +1023,7 @@ int slab_maps_after_sort(sph_ctx* c, uint32_t n, bool pre, hipStream_t s)
     const uint32_t ng_seed = d.ghosts_ok ? d.n_ghost[0] + d.n_ghost[1] : 0u;
     if (n && ng_seed)
         hipLaunchKernelGGL(k_seed_ghost_records, dim3((ng_seed + 255) / 256), dim3(256), 0, s, d.ghost_dst.as<uint32_t>(), ng_seed,
-                           c->pm[c->pcur].as<float4>(), c->pacc.as<float4>());
+                           c->pm[c->pcur].as<float4>(), c->pacc.as<float4>(), c->prec0.as<float4>(), c->prec1.as<float4>());
     d.have_flags = true;
     return SPH_OK;
 }

@@ -74,7 +74,7 @@ SweepArgs make_args(sph_ctx* c, const StepP& sp)
     a.mrho = c->mrho.as<float>();
     a.pt0 = c->pt0.as<float>();
     a.pt1 = c->pt1.as<float>();
-    if (!c->dist.on) {   // (slab decompositions exchange p / rho^2 as a field of its own)
+    if (!c->dist.on || c->opt.slab_records) {   // (Options::slab_records = 0: slab decompositions keep p / rho^2 as a field of its own)
         a.rec0 = c->prec0.as<float4>();
         a.rec1 = c->prec1.as<float4>();
     }
@@ -95,6 +95,11 @@ SweepArgs make_args(sph_ctx* c, const StepP& sp)
         a.n_eb = c->dist.ghosts_ok ? c->dist.n_ghost[0] + c->dist.n_ghost[1] : 0u;
     }
     a.solver_tot = c->dist.solver_tot.as<double>();
+    if (c->dist.on && c->dist.nccl) {   // RCCL transport: the totals are an all-gather, summed by their readers (sph_transport.hip)
+        a.tot_table = c->dist.tot_table.as<double>();
+        a.tot_nr = c->dist.nranks;
+        a.tot_self = c->dist.rank;
+    }
     a.opt_tile = c->opt.tile;
     a.opt_jacobi_generic = c->opt.jacobi_generic;
     a.prof = &c->prof;
@@ -330,6 +335,8 @@ static float* sel_rho(Member& m) { return m.a.rho; }
 static float* sel_vel(Member& m) { return (float*)m.a.vel; }
 static float* sel_pt0(Member& m) { return m.a.pt0; }
 static float* sel_pt1(Member& m) { return m.a.pt1; }
+static float* sel_rec0(Member& m) { return (float*)m.a.rec0; }
+static float* sel_rec1(Member& m) { return (float*)m.a.rec1; }
 static float* sel_lv_level(Member& m) { return m.lv_level; }
 static float* sel_lv_when(Member& m) { return m.lv_when; }
 static float* sel_lv_pmnew(Member& m) { return m.lv_pmnew; }
@@ -401,7 +408,12 @@ static bool split_sweep_a(const Group& G, const std::vector<Member>& M)
 static int exchange_and_sweep_a(Group& G, std::vector<Member>& M, const SolveQ& q, uint32_t ka)
 {
     int rc;
-    float* (*sel)(Member&) = (ka & 1u) ? sel_pt1 : sel_pt0;
+    // the ghosts' p / rho^2 of this iteration's pressure buffer: a field of its own, or word 2 of the 16-byte pressure records the
+    // solves of a uniform scene keep (sweep_a_on_records: parameters and all-reduced values, the same on every rank)
+    const bool recs = sweep_a_on_records(M[0].a);
+    float* (*sel)(Member&) = recs ? ((ka & 1u) ? sel_rec1 : sel_rec0) : ((ka & 1u) ? sel_pt1 : sel_pt0);
+    const int stride = recs ? 4 : 1, off = recs ? 2 : 0;
+    const TotalsJob job{(int)ka - 1, q.residual_density, q.max_avg_error, q.max_iters};   // this rank's totals of iteration ka - 1 (what block 0 of the single-rank sweep adds up)
     if (!split_sweep_a(G, M)) {
         if (!G.multi()) return solve_sweep_a(G, M, q, ka);
         // slab decomposition, one launch per sweep: this rank's totals of iteration ka - 1 first (k_solver_totals: what block 0 of
@@ -410,13 +422,13 @@ static int exchange_and_sweep_a(Group& G, std::vector<Member>& M, const SolveQ& 
         for (auto& m : M) {
             sph_ctx* c = m.c;
             (void)hipSetDevice(c->device);
-            if (m.n) launch_solver_totals(c->stream, &c->prof, m.a, (int)ka - 1, q.residual_density, q.max_avg_error, q.max_iters);
-            else HIPCHK(c, hipMemsetAsync(c->dist.solver_tot.as<double>() + 8 * q.tot_slot, 0, 48, c->stream));   // an empty slab contributes zeros
+            if (!m.n) HIPCHK(c, hipMemsetAsync(c->dist.solver_tot.as<double>() + 8 * q.tot_slot, 0, 48, c->stream));   // an empty slab contributes zeros
         }
-        if ((rc = refresh_ghosts(G, M, sel, 1, "pt", q.tot_slot))) return rc;
+        if ((rc = refresh_ghosts(G, M, sel, 1, "pt", q.tot_slot, nullptr, stride, off, &job))) return rc;   // (block 0 of the pack launch adds up the totals)
         for (auto& m : M) {
             (void)hipSetDevice(m.c->device);
-            if (m.n) launch_pressure_accel(m.c->stream, &m.c->prof, m.a, (int)ka, q.residual_density, q.max_avg_error, q.max_iters, 2);
+            if (m.n) launch_pressure_accel(m.c->stream, &m.c->prof, m.a, (int)ka, q.residual_density, q.max_avg_error, q.max_iters, 2);   // (block 0 takes the decision on iteration ka - 1 from the all-reduced totals)
+            else launch_solver_progress(m.c->stream, &m.c->prof, m.a, (int)ka - 1, q.residual_density, q.max_avg_error, q.max_iters);   // an empty slab has no sweep to take it
         }
         return SPH_OK;
     }
@@ -431,13 +443,13 @@ static int exchange_and_sweep_a(Group& G, std::vector<Member>& M, const SolveQ& 
         HIPCHK(c, hipStreamWaitEvent(d.xstream, d.ev_x[0], 0));
         if (m.n) launch_pressure_accel(d.xstream, &c->prof, m.a, (int)ka, q.residual_density, q.max_avg_error, q.max_iters, 1, 1);
         HIPCHK(c, hipEventRecord(d.ev_x[1], d.xstream));
-        if (m.n) launch_solver_totals(c->stream, &c->prof, m.a, (int)ka - 1, q.residual_density, q.max_avg_error, q.max_iters);
-        else HIPCHK(c, hipMemsetAsync(c->dist.solver_tot.as<double>() + 8 * q.tot_slot, 0, 48, c->stream));   // an empty slab contributes zeros
+        if (!m.n) HIPCHK(c, hipMemsetAsync(c->dist.solver_tot.as<double>() + 8 * q.tot_slot, 0, 48, c->stream));   // an empty slab contributes zeros
     }
-    if ((rc = refresh_ghosts(G, M, sel, 1, "pt", q.tot_slot))) return rc;
+    if ((rc = refresh_ghosts(G, M, sel, 1, "pt", q.tot_slot, nullptr, stride, off, &job))) return rc;
     for (auto& m : M) {
         sph_ctx* c = m.c;
         (void)hipSetDevice(c->device);
+        launch_solver_progress(c->stream, &c->prof, m.a, (int)ka - 1, q.residual_density, q.max_avg_error, q.max_iters);   // the decision on iteration ka - 1 (paced: the host learns of it while the interior still sweeps)
         HIPCHK(c, hipStreamWaitEvent(c->stream, c->dist.ev_x[1], 0));
         if (m.n) launch_pressure_accel(c->stream, &c->prof, m.a, (int)ka, q.residual_density, q.max_avg_error, q.max_iters, 1, 2);
     }
@@ -465,23 +477,21 @@ static int solve_queue(Group& G, std::vector<Member>& M, SolveQ& q, bool handoff
         for (auto& m : M) {
             (void)hipSetDevice(m.c->device);
             if (m.n) launch_jacobi_update(m.c->stream, &m.c->prof, m.a, (int)k, q.residual_density, q.max_avg_error, q.max_iters, multi);
-            else if (multi) launch_solver_decide(m.c->stream, &m.c->prof, m.a, (int)k - 1, q.residual_density, q.max_avg_error, q.max_iters);   // an empty slab has no sweep B to take it
         }
         // (no exchange of a^p: the first ghost ring computes its own in sweep A)
         if ((rc = exchange_and_sweep_a(G, M, q, k + 1))) return rc;
     }
-    // slab decomposition: the last queued sweep A(k) left the totals of iteration k - 1 behind; the decision on them is taken by
-    // the tail itself (every block, from the all-reduced totals), or by a launch of its own where no tail follows
+    // (slab decomposition: the decision on the last queued iteration was taken behind its all-reduce, like every other -- by the last
+    //  sweep A's block 0, or the launch that stands in for it: exchange_and_sweep_a)
     for (auto& m : M) {
         (void)hipSetDevice(m.c->device);
-        if (multi && (!m.n || q.tail == 0)) launch_solver_decide(m.c->stream, &m.c->prof, m.a, (int)q.k - 1, q.residual_density, q.max_avg_error, q.max_iters);
         SolverCtrl* hand_host = handoff ? m.c->ctrl_host_dev + 1 : nullptr;
         uint32_t* gate_out = handoff ? (uint32_t*)(m.c->ctrl.as<SolverCtrl>() + 2) : nullptr;
         if (!m.n || q.tail == 0 /* TAIL_NONE */) {
             if (handoff) launch_solver_handoff(m.c->stream, &m.c->prof, m.c->ctrl.as<SolverCtrl>(), hand_host, gate_out);
             continue;
         }
-        launch_solver_tail(m.c->stream, &m.c->prof, m.a, q.tail, m.c->pm[m.c->pcur ^ 1].as<float4>(), multi ? (int)q.k - 1 : -1, q.residual_density,
+        launch_solver_tail(m.c->stream, &m.c->prof, m.a, q.tail, m.c->pm[m.c->pcur ^ 1].as<float4>(), -1, q.residual_density,
                            q.max_avg_error, q.max_iters, hand_host, gate_out);
         if (q.tail >= 2 /* TAIL_VX, TAIL_HYBRID */ && m.a.hdr_partials) launch_header_ahead(m.c, (m.n + 255u) / 256u, m.c->hdr_host_dev, publish_next && !multi);
     }
@@ -528,21 +538,36 @@ static uint32_t pace_prediction(const sph_ctx* c, uint32_t n, uint32_t last, uin
     if (md == 2 || prev == 0u) return last;
     return std::min(last, prev);
 }
+// Slab decompositions pace the same way with lead 1 and no unpaced head beyond the two iterations every solve runs: block 0 of the
+// sweep A behind the iteration's exchange-and-all-reduce publishes what the stop rule makes of the ALL-REDUCED totals
+// (solver_publish_progress_multi) -- the same word on every rank -- and iteration k + 1 is queued only once iteration k is known to
+// continue: every rank queues exactly the same launches and collectives, none in vain (the predicted queue this replaces re-sent the
+// ghosts and all-reduced the totals of every over-predicted iteration, and waited for the host on every shortfall).
 static int solve_paced(Group& G, std::vector<Member>& M, SolveQ& q, uint32_t predicted_iters)
 {
-    Member& m = M[0];
+    const bool multi = G.multi();
+    size_t lead_member = 0;   // whose progress word the host watches: the first member with particles (all members publish the same decisions)
+    while (lead_member + 1 < M.size() && M[lead_member].n == 0) lead_member++;
+    Member& m = M[lead_member];
     sph_ctx* c = m.c;
-    const uint32_t lead = pace_lead(c, m.n);
+    const uint32_t lead = multi ? 1u : pace_lead(c, m.n);
     int rc;
-    (void)hipSetDevice(c->device);
-    c->solve_epoch = c->solve_epoch >= 0xffffu ? 1u : c->solve_epoch + 1u;
-    const uint32_t epoch = c->solve_epoch;
-    m.a.prog_host = c->prog_host_dev;
-    m.a.prog_epoch = epoch;
-    if ((rc = solve_begin(G, M, q, predicted_iters))) return rc;
+    // one epoch for the whole group (a member's word is only compared with the epoch its own launches carry)
+    sph_ctx* c0 = M[0].c;
+    c0->solve_epoch = c0->solve_epoch >= 0xffffu ? 1u : c0->solve_epoch + 1u;
+    const uint32_t epoch = c0->solve_epoch;
+    for (auto& mm : M) {
+        mm.c->solve_epoch = epoch;
+        mm.a.prog_host = mm.c->prog_host_dev;
+        mm.a.prog_epoch = epoch;
+    }
+    if ((rc = solve_begin(G, M, q, multi ? 2u : predicted_iters))) return rc;
     auto iteration = [&](uint32_t k) -> int {
-        launch_jacobi_update(c->stream, &c->prof, m.a, (int)k, q.residual_density, q.max_avg_error, q.max_iters, 0);
-        return solve_sweep_a(G, M, q, k + 1);
+        for (auto& mm : M) {
+            (void)hipSetDevice(mm.c->device);
+            if (mm.n) launch_jacobi_update(mm.c->stream, &mm.c->prof, mm.a, (int)k, q.residual_density, q.max_avg_error, q.max_iters, multi ? 1 : 0);
+        }
+        return exchange_and_sweep_a(G, M, q, k + 1);
     };
     for (; q.k <= q.upto && q.k <= q.max_iters; q.k++)
         if ((rc = iteration(q.k))) return rc;
@@ -571,7 +596,7 @@ static int solve_paced(Group& G, std::vector<Member>& M, SolveQ& q, uint32_t pre
         }
     }
     q.upto = q.k - 1;   // solve_queue() has only the tail left to queue
-    m.a.prog_host = nullptr;
+    for (auto& mm : M) mm.a.prog_host = nullptr;
     return SPH_OK;
 }
 
@@ -582,13 +607,16 @@ static int pressure_iterations(Group& G, std::vector<Member>& M, float max_avg_e
     int rc;
     const int multi = G.multi() ? 1 : 0;
     SolveQ q{max_avg_error, residual_density, max_iters, tail, density_solver};
-    if (!multi && M[0].n > 0 && M[0].c->paced_step) {
+    // (a slab decomposition paces whether or not THIS rank has particles: every rank must queue the same collectives -- an empty
+    //  slab's progress word is published by a launch of its own, launch_solver_progress)
+    if ((multi || M[0].n > 0) && M[0].c->paced_step) {
         sph_ctx* c0 = M[0].c;
         const uint32_t head = density_solver ? pace_prediction(c0, M[0].n, c0->last_dens_iters, c0->prev_dens_iters) : pace_prediction(c0, M[0].n, c0->last_div_iters, c0->prev_div_iters);
         if ((rc = solve_paced(G, M, q, head))) return rc;
         if ((rc = solve_queue(G, M, q, false, true))) return rc;   // (the tail)
-        if ((rc = sync_ctrl(G, SYNC_AGREE))) return rc;
-        solve_stats(M[0], q, *M[0].c->ctrl_host);
+        if (multi && final_solve && (rc = G.comm->agree_guards_queued(G))) return rc;
+        if ((rc = sync_ctrl(G, multi ? (final_solve ? SYNC_FINAL : SYNC_DEFER) : SYNC_AGREE))) return rc;
+        for (auto& m : M) solve_stats(m, q, *m.c->ctrl_host);
         return SPH_OK;
     }
     if ((rc = solve_begin(G, M, q, predicted_iters))) return rc;
@@ -638,7 +666,9 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
     // measurement / test switches of the solves, read ONCE per step (never inside the iteration path)
     const bool no_records = c0->opt.accel_generic != 0;   // sweep A through the generic form
     // (the progress word carries the iteration in 15 bits: a solve that may run longer keeps the predicted queue)
-    const bool paced = !G.multi() && c0->opt.paced != 0 && p->max_iters <= 0x7fffu;   // 0: predicted queue + waits on one context too
+    // Slab decompositions pace too (Options::slab_paced; lead 1: nothing is ever queued in vain, so every rank queues the same
+    // collectives) -- parameters only: the same on every rank
+    const bool paced = c0->opt.paced != 0 && p->max_iters <= 0x7fffu && (!G.multi() || c0->opt.slab_paced != 0);   // 0: predicted queue + waits
     for (auto c : G.m) c->paced_step = paced;
     for (auto c : G.m) c->dist.overlap_env = c0->opt.overlap;
     for (auto c : G.m) c->publish_folded = false;
@@ -1430,23 +1460,30 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
         // in the first steps of a dam break it jumps by factors (4, 15, 17, 7, ...), and a short-fall there throws away a
         // density solve's worth of gated launches (measured: 1.38 vs 1.27 ms/step over steps 5-24 when always chained).
         // (parameters and all-reduced iteration counts only: every rank decides the same)
-        if (paced && M[0].n > 0) {
-            // one context: both solves paced against the device's progress, ONE host wait at the end of the step
+        if (paced && (G.multi() || M[0].n > 0)) {
+            // both solves paced against the device's progress, ONE host wait at the end of the step (a slab decomposition: the
+            // ghosts' velocities follow the first solve's tail, the guards are agreed in front of the wait)
+            const bool multi = G.multi();
             SolveQ qd{p->hybrid_dfsph_max_avg_divergence_error, 0, p->max_iters, T_VEL, false};
             SolveQ qs{p->hybrid_dfsph_max_avg_density_error, 1, p->max_iters, T_HYBRID, true};
             if ((rc = solve_paced(G, M, qd, pace_prediction(c0, M[0].n, c0->last_div_iters, c0->prev_div_iters)))) return rc;
             if ((rc = solve_queue(G, M, qd, true))) return rc;   // the tail (v += dt a^p): it also leaves the solve's control block in ctrl_host[1]
             g_trace.mark(4);
             rec(3);
+            if (multi && (rc = refresh_ghosts(G, M, sel_vel, 2, "vel"))) return rc;   // v += dt a^p happened in the tail: the forces / the source term read the neighbours' velocities
             if (!p->hybrid_dfsph_non_pressure_accel_before_divergence_free)
                 if ((rc = non_pressure())) return rc;
             rec(4);
             begin_solve(p->hybrid_dfsph_density_source_term == SPH_ONLY_DENSITY ? 2 : 1, 1);
             if ((rc = solve_paced(G, M, qs, pace_prediction(c0, M[0].n, c0->last_dens_iters, c0->prev_dens_iters)))) return rc;
             if ((rc = solve_queue(G, M, qs, false, true))) return rc;
-            if ((rc = sync_ctrl(G, SYNC_AGREE))) return rc;
-            solve_stats(M[0], qd, M[0].c->ctrl_host[1]);
-            solve_stats(M[0], qs, *M[0].c->ctrl_host);
+            const bool final_solve = !level_on;
+            if (multi && final_solve && (rc = G.comm->agree_guards_queued(G))) return rc;
+            if ((rc = sync_ctrl(G, multi ? (final_solve ? SYNC_FINAL : SYNC_DEFER) : SYNC_AGREE))) return rc;
+            for (auto& m : M) {
+                solve_stats(m, qd, m.c->ctrl_host[1]);
+                solve_stats(m, qs, *m.c->ctrl_host);
+            }
             g_trace.mark(5);
             rec(5);
             break;
@@ -1464,6 +1501,7 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
                 for (auto& m : M) {
                     m.a.gate = on ? (const uint32_t*)(m.c->ctrl.as<SolverCtrl>() + 2) : nullptr;
                     m.a.solver_tot = m.c->dist.solver_tot.as<double>() + (on && m.c->dist.solver_tot.p ? 8 : 0);
+                    if (m.a.tot_table) m.a.tot_table = m.c->dist.tot_table.as<double>() + (on ? (size_t)m.c->dist.nranks * 8 : 0);
                 }
             };
             if ((rc = solve_begin(G, M, qd, c0->last_div_iters))) return rc;

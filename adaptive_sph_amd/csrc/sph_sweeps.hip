@@ -1286,11 +1286,36 @@ struct SolveP {
     int residual_density;
     float max_avg_error;
     uint32_t max_iters;
-    int multi;   // slab decomposition: block 0 only adds up this rank's totals; the decision follows the all-reduce (k_solver_decide)
-                 // 2: ... and not even that -- k_solver_totals did, on the stream of the collectives (split sweep A)
+    int multi;   // slab decomposition (0: one context -- block 0 of sweep A reduces the partials and decides):
+                 // 1: block 0 only adds up this rank's totals (k_solver_totals, block 0 of k_pack_totals);
+                 // 2: the launch runs BEHIND the all-reduce of the totals that travelled with the ghost exchange: its block 0 takes the
+                 //    decision from them (solver_decide_multi) -- the place and the protocol of the one-context form, so sweep B and the
+                 //    tail read one flag whatever the transport;
+                 // 3: neither (the two launches of a split sweep A: k_solver_progress decides between them)
     uint32_t* prog = nullptr;   // paced solve: mapped host word that receives every decision (SweepArgs::prog_host), else nullptr
     uint32_t epoch = 0;
+    // slab decomposition over RCCL: the ranks' totals arrive as an all-gather (one row per rank, tot_table[8 j ..]) in the iteration's
+    // ONE grouped send / receive; whoever reads the "all-reduced" totals adds the rows up in rank order -- the same sum on every rank,
+    // without a launch of its own for it.  nullptr: the transport reduced in place (tot[] holds the sums).
+    const double* tot_table = nullptr;
+    int tot_nr = 0, tot_self = 0;
 };
+// element k of the ranks' summed totals (solver_reduce_decide's layout)
+__device__ __forceinline__ double solver_total(const double* __restrict__ tot, const SolveP& q, int k)
+{
+    if (!q.tot_table) return tot[k];
+    double s = 0.0;
+    for (int j = 0; j < q.tot_nr; j++) s += j == q.tot_self ? tot[k] : q.tot_table[8 * j + k];
+    return s;
+}
+static SolveP solve_params(const SweepArgs& a, int residual_density, float max_avg_error, uint32_t max_iters, int multi, bool progress)
+{
+    SolveP q{residual_density, max_avg_error, max_iters, multi, progress ? a.prog_host : nullptr, a.prog_epoch};
+    q.tot_table = a.tot_table;
+    q.tot_nr = a.tot_nr;
+    q.tot_self = a.tot_self;
+    return q;
+}
 
 // stopping rule of iisph_pressure_iterations (simulation.rs:1453-1479) for iteration `iter`
 __device__ __forceinline__ bool solver_stop_rule(uint32_t normal, float sum_err, int iter, const SolveP& q, float rest_density, float dt)
@@ -1312,24 +1337,29 @@ __device__ __forceinline__ bool solver_decide_multi(const double* __restrict__ t
 {
     const uint32_t slot = (uint32_t)(iter + 1) & 1u;
     if (ctrl->slot_done[iter & 1] != 0u) {   // decided earlier: hand the flag on (the totals are stale)
-        if (publish) ctrl->slot_done[slot] = 1u;
+        if (publish) {
+            ctrl->slot_done[slot] = 1u;
+            if (q.prog) *(volatile uint32_t*)q.prog = (q.epoch << 16) | 0x8000u | ((uint32_t)iter & 0x7fffu);
+        }
         return true;
     }
-    const uint32_t normal = (uint32_t)tot[0];
-    const float sum_err = (float)tot[3];
-    const bool failed = tot[5] > 0.0;
+    const uint32_t normal = (uint32_t)solver_total(tot, q, 0);
+    const float sum_err = (float)solver_total(tot, q, 3);
+    const bool failed = solver_total(tot, q, 5) > 0.0;
     const bool stop = failed || solver_stop_rule(normal, sum_err, iter, q, rest_density, dt);
     if (publish) {
         ctrl->normal = normal;
-        ctrl->singular = (uint32_t)tot[1];
-        ctrl->negative = (uint32_t)tot[2];
+        ctrl->singular = (uint32_t)solver_total(tot, q, 1);
+        ctrl->negative = (uint32_t)solver_total(tot, q, 2);
         ctrl->sum_err = sum_err;
-        ctrl->max_err = (float)tot[4];
+        ctrl->max_err = (float)solver_total(tot, q, 4);
         ctrl->iters = (uint32_t)iter;
         ctrl->cur = (uint32_t)((iter + 1) & 1);
         ctrl->slot_done[slot] = stop ? 1u : 0u;
         if (failed) ctrl->peer_error = 1u;
         if (stop) ctrl->done = 1u;
+        // paced solve: the host learns of the decision while the launch that took it still sweeps
+        if (q.prog) *(volatile uint32_t*)q.prog = (q.epoch << 16) | (stop ? 0x8000u : 0u) | ((uint32_t)iter & 0x7fffu);
     }
     return stop;
 }
@@ -1445,10 +1475,15 @@ struct OpPressureAccel {
         if (gate && *gate == 0u) return true;
         if (iter < 0) return ctrl->done == 0u;
         if (ctrl->slot_done[(iter - 1) & 1] != 0u) {   // the solve ended before this launch: hand the flag on, leave
-            if (raw_block == 0u && threadIdx.x == 0 && !solve.multi) ctrl->slot_done[iter & 1] = 1u;
+            if (raw_block == 0u && threadIdx.x == 0 && (solve.multi == 0 || solve.multi == 2)) {
+                ctrl->slot_done[iter & 1] = 1u;
+                if (solve.multi == 2 && solve.prog)   // (paced slabs: an unpaced head launch behind the end of the solve)
+                    *(volatile uint32_t*)solve.prog = (solve.epoch << 16) | 0x8000u | ((uint32_t)(iter - 1) & 0x7fffu);
+            }
             return true;
         }
-        if (raw_block == 0u && solve.multi != 2) solver_reduce_decide(partials, nparts, ctrl, tot, iter - 1, solve, sp.rest_density, sp.dt, status);
+        if (raw_block == 0u && solve.multi <= 1) solver_reduce_decide(partials, nparts, ctrl, tot, iter - 1, solve, sp.rest_density, sp.dt, status);
+        if (raw_block == 0u && solve.multi == 2 && threadIdx.x == 0) solver_decide_multi(tot, ctrl, iter - 1, solve, sp.rest_density, sp.dt, true);
         return false;
     }
     __device__ bool lane_skip(uint32_t) const { return false; }
@@ -1510,9 +1545,9 @@ template <class MathT>
 struct OpPressureAccelU : OpPressureAccel<MathT> {
     static_assert(MathT::UNIFORM, "OpPressureAccelU: uniform-h scenes");
     typedef OpPressureAccel<MathT> B;
-    static constexpr bool TILE = false, RING1 = false;
+    static constexpr bool TILE = false, RING1 = true;   // (slab decomposition: the first ghost ring computes its own a^p, as in the base)
     typedef NBNone NB;
-    const float4* __restrict__ rec;   // of the pressure buffer this iteration reads
+    const float4* __restrict__ rec;   // of the pressure buffer this iteration reads (slabs: the ghosts' records carry their owners' p / rho^2, refreshed every iteration)
     struct Acc {
         float ax, ay, p1t, mass;
     };
@@ -1535,7 +1570,14 @@ struct OpPressureAccelU : OpPressureAccel<MathT> {
         float bx = 0.f, by = 0.f;
         if (this->sp.n_planes && wall) {
             const float rho_b = this->sp.rest_density;
-            const float p_ib = this->sp.opdisc == SPH_OP_SYMMETRIC_GRADIENT ? Ai.w : 0.f;
+            // (a ghost's record holds p / rho^2 only: p from it and the ghost's refreshed density, like the base does)
+            const bool own = !this->owned_flag || this->owned_flag[i];
+            float p_i = Ai.w;
+            if (!own) {
+                const float rho_i = this->rho[i];
+                p_i = Ai.z * (rho_i * rho_i);
+            }
+            const float p_ib = this->sp.opdisc == SPH_OP_SYMMETRIC_GRADIENT ? p_i : 0.f;
             const float f = -rho_b * (Ai.z + p_ib / (rho_b * rho_b));
             const float2 gl = this->lam_grad[i];
             bx = f * gl.x;
@@ -1559,13 +1601,10 @@ __global__ __launch_bounds__(256) void k_solver_tail(uint32_t n, int tail, float
                                                       uint32_t* __restrict__ gate_out)
 {
     if (gate && *gate == 0u) return;
-    // slab decomposition: the decision on the solve's last queued iteration has no sweep B behind it to take it -- every block
-    // evaluates it here from the all-reduced totals (the same values, the same decision), block 0 publishes it
-    // (what k_solver_decide did in a launch of its own)
     const bool b0t0 = blockIdx.x == 0 && threadIdx.x == 0;
-    bool done;
-    if (decide_iter >= 0) done = solver_decide_multi(tot, const_cast<SolverCtrl*>(ctrl), decide_iter, solve, rest_density, dt, b0t0);
-    else done = ctrl->done != 0u;
+    (void)decide_iter;
+    (void)tot;
+    const bool done = ctrl->done != 0u;   // (the decision was taken by the last sweep A's block 0, or the launch that stood in for it)
     // chained solves: this is the FIRST solve's tail -- hand its control block to the host and open (or keep shut) the gate of
     // the second solve's launches (k_solver_handoff's job; the next kernel starts after every block of this one has finished)
     if (gate_out && b0t0) {
@@ -1679,13 +1718,12 @@ struct OpJacobi {
     const double* __restrict__ tot;
     const uint32_t* __restrict__ gate;   // chained solves (else nullptr), see OpSource
     __device__ bool skip() const { return false; }
-    // the decision on iteration iter - 1: taken by block 0 of A(iter) (single rank), or -- slab decomposition -- evaluated here by
-    // every block from the all-reduced totals, published by block 0 for the launches behind this one
+    // the decision on iteration iter - 1 was taken by block 0 of A(iter) -- from the partials (one context), or from the ranks'
+    // all-reduced totals (slab decomposition; a split sweep A: by k_solver_progress between its two launches)
     __device__ bool prologue(uint32_t raw_block) const
     {
         if (gate && *gate == 0u) return true;
-        if (!solve.multi) return ctrl->slot_done[iter & 1] != 0u;
-        return solver_decide_multi(tot, ctrl, iter - 1, solve, sp.rest_density, sp.dt, raw_block == 0u && threadIdx.x == 0);
+        return ctrl->slot_done[iter & 1] != 0u;
     }
     __device__ bool lane_skip(uint32_t) const { return false; }
     __device__ void init(Acc&) const {}
@@ -2408,6 +2446,20 @@ __global__ void k_ctrl_reset(SolverCtrl* ctrl, const uint32_t* __restrict__ gate
     if (gate && *gate == 0u) return;
     if (threadIdx.x == 0 && blockIdx.x == 0) *ctrl = SolverCtrl{};
 }
+// slab decomposition: the decision on iteration `iter` (and a paced solve's progress word) by a launch of its own, right behind the
+// all-reduce of its totals -- where no sweep A's block 0 can take it: a split sweep A (its interior runs BESIDE the all-reduce, its
+// edge launch only after the interior), an empty slab (no sweep at all)
+__global__ void k_solver_progress(const double* __restrict__ tot, SolverCtrl* ctrl, int iter, SolveP q, float rest_density, float dt, const uint32_t* __restrict__ gate)
+{
+    if (gate && *gate == 0u) return;
+    if (threadIdx.x == 0) solver_decide_multi(tot, ctrl, iter, q, rest_density, dt, true);
+}
+void launch_solver_progress(hipStream_t s, Profiler* prof, const SweepArgs& a, int iter, int residual_density, float max_avg_error, uint32_t max_iters)
+{
+    ProfScope ps(prof, "solver_progress", s);
+    hipLaunchKernelGGL(k_solver_progress, dim3(1), dim3(64), 0, s, a.solver_tot, a.ctrl, iter, solve_params(a, residual_density, max_avg_error, max_iters, 2, true),
+                       a.sp.rest_density, a.sp.dt, a.gate);
+}
 void launch_ctrl_reset(hipStream_t s, SolverCtrl* ctrl, const uint32_t* gate) { hipLaunchKernelGGL(k_ctrl_reset, dim3(1), dim3(64), 0, s, ctrl, gate); }
 
 // ------------------------------------------------------------------------------------------------
@@ -2644,10 +2696,11 @@ static bool jacobi_on_records(const SweepArgs& a)   // sweep B gathers {x, y, a^
 {
     return !a.exact && a.uniform_h && a.h_mode == SPH_H_FROM_MASS && a.sp.opdisc != SPH_OP_WINCHENBACH2020 && !a.opt_jacobi_generic;
 }
-static bool solve_on_records(const SweepArgs& a)    // ... and sweep A {x, y, p / rho^2, p} (OpPressureAccelU): one context, not IISPH2
+static bool solve_on_records(const SweepArgs& a)    // ... and sweep A {x, y, p / rho^2, p} (OpPressureAccelU): not IISPH2
 {
-    return jacobi_on_records(a) && a.rec0 != nullptr && a.owned == nullptr && a.part == 0;   // (SPH_ACCEL_GENERIC: the step driver leaves rec0 null)
+    return jacobi_on_records(a) && a.rec0 != nullptr;   // (Options::accel_generic / ::slab_records: the step driver leaves rec0 null)
 }
+bool sweep_a_on_records(const SweepArgs& a) { return solve_on_records(a); }
 extern "C" int sph_set_sweep_variant(int mode)
 {
     if (mode < 0 || mode > 3) return SPH_ERR_INVALID_ARGUMENT;
@@ -2825,7 +2878,9 @@ void launch_pressure_accel(hipStream_t s, Profiler* prof, const SweepArgs& a0, i
     ProfScope ps(prof, part == 2 ? "pressure_accel_edge" : "pressure_accel", s, true);
     SweepArgs a = a0;
     a.part = part;
-    const SolveP q{residual_density, max_avg_error, max_iters, part ? 2 : multi, a.prog_host, a.prog_epoch};
+    // (split sweep: neither launch publishes the paced solve's progress -- the interior runs BESIDE the all-reduce of the totals, the
+    //  edge launch only after the interior: the step driver queues launch_solver_progress right behind the all-reduce instead)
+    const SolveP q = solve_params(a, residual_density, max_avg_error, max_iters, part ? 3 : multi, part == 0);   // (part != 0: launch_solver_progress decides)
     if (solve_on_records(a) && iter >= 1) {   // (iter < 0: IISPH2's extra sweep -- never on records)
         OpPressureAccelU<MathUniform> op{{uniform_math(a.h_uniform), a.pm, a.orig, a.rho, a.p0, a.p1, a.pt0, a.pt1, a.lam_grad, a.pacc, a.ctrl,
                                           (const SolverPartial*)a.partials, solver_reduce_blocks(a.n), a.solver_tot, a.status, a.sp, q, iter, a.owned, a.gate},
@@ -2851,7 +2906,83 @@ void launch_solver_totals(hipStream_t s, Profiler* prof, const SweepArgs& a, int
 {
     ProfScope ps(prof, "solver_totals", s);
     hipLaunchKernelGGL(k_solver_totals, dim3(1), dim3(SWEEP_THREADS), 0, s, (const SolverPartial*)a.partials, solver_reduce_blocks(a.n), a.ctrl, a.solver_tot, iter,
-                       SolveP{residual_density, max_avg_error, max_iters, 2}, a.sp.rest_density, a.sp.dt, a.status, a.gate);
+                       solve_params(a, residual_density, max_avg_error, max_iters, 1, false), a.sp.rest_density, a.sp.dt, a.status, a.gate);
+}
+
+// The same totals as block 0 of the launch that packs the halo members' values for the iteration's ghost exchange (slab
+// decomposition): both wait for sweep B, both precede the exchange -- one launch instead of two (a kernel boundary is ~4 us, and an
+// iteration of 1M particles per rank is ~45 us of sweeps).  Blocks 1.. pack: entries [0, cnt0) go to the left neighbour's staging
+// buffer, [cnt0, cnt0 + cnt1) to the right one's (k_pack_field of sph_slabs.hip).
+#define PACK_THREADS 1024   // block 0 adds up one partial per 256 particles: 32768 of them at 8M particles per rank -- on the iteration's critical path
+__global__ __launch_bounds__(PACK_THREADS) void k_pack_totals(const SolverPartial* __restrict__ partials, uint32_t nparts, SolverCtrl* ctrl, double* __restrict__ tot,
+                                                              int iter, float rest_density, float dt, const DeviceStatus* status,
+                                                              const uint32_t* __restrict__ gate, const uint32_t* __restrict__ src_idx, uint32_t cnt0, uint32_t cnt1,
+                                                              int words, int stride, int off, const float* __restrict__ field, float* __restrict__ out0,
+                                                              float* __restrict__ out1)
+{
+    if (blockIdx.x == 0) {
+        if (gate && *gate == 0u) return;
+        if (ctrl->slot_done[iter & 1] != 0u) return;   // (see k_solver_totals)
+        // the rank's totals in a fixed order (thread t takes partials t, t + 1024, ...; lanes, then waves in index order): deterministic
+        __shared__ SolverPartial s_r[PACK_THREADS / 64];
+        const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+        SolverPartial t{0, 0, 0, 0.f, 0.f};
+        for (uint32_t k0 = tid; k0 < nparts; k0 += 8u * PACK_THREADS) {
+            SolverPartial v[8];
+#pragma unroll
+            for (uint32_t u = 0; u < 8u; u++) {
+                const uint32_t k = k0 + u * PACK_THREADS;
+                v[u] = k < nparts ? partials[k] : SolverPartial{0, 0, 0, 0.f, 0.f};
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < 8u; u++) {
+                t.normal += v[u].normal;
+                t.singular += v[u].singular;
+                t.negative += v[u].negative;
+                t.sum_err += v[u].sum_err;
+                t.max_err = fmaxf(t.max_err, v[u].max_err);
+            }
+        }
+        t.normal = wave_sum_u32(t.normal);
+        t.singular = wave_sum_u32(t.singular);
+        t.negative = wave_sum_u32(t.negative);
+        t.sum_err = wave_sum(t.sum_err);
+        t.max_err = wave_max(t.max_err);
+        if (lane == 0) s_r[w] = t;
+        __syncthreads();
+        if (tid != 0) return;
+        t = s_r[0];
+        for (int k = 1; k < PACK_THREADS / 64; k++) {
+            t.normal += s_r[k].normal;
+            t.singular += s_r[k].singular;
+            t.negative += s_r[k].negative;
+            t.sum_err += s_r[k].sum_err;
+            t.max_err = fmaxf(t.max_err, s_r[k].max_err);
+        }
+        tot[0] = (double)t.normal;
+        tot[1] = (double)t.singular;
+        tot[2] = (double)t.negative;
+        tot[3] = (double)t.sum_err;
+        tot[4] = (double)t.max_err;   // summed over the ranks: informational
+        tot[5] = status->error != 0u ? 1.0 : 0.0;   // a guard fired on this rank: every rank ends the solve (solver_decide_multi)
+        return;
+    }
+    const uint32_t k = (blockIdx.x - 1u) * PACK_THREADS + threadIdx.x;
+    if (k >= cnt0 + cnt1) return;
+    const uint32_t i = src_idx[k];
+    float* out = k < cnt0 ? out0 + (size_t)k * words : out1 + (size_t)(k - cnt0) * words;
+    for (int w = 0; w < words; w++) out[w] = field[(size_t)i * stride + off + w];
+}
+void launch_pack_and_totals(hipStream_t s, Profiler* prof, const SweepArgs& a, int iter, int residual_density, float max_avg_error, uint32_t max_iters,
+                            const uint32_t* src_idx, uint32_t cnt0, uint32_t cnt1, int words, int stride, int off, const float* field, float* out0, float* out1)
+{
+    (void)residual_density;
+    (void)max_avg_error;
+    (void)max_iters;
+    ProfScope ps(prof, "ghost_pack_totals", s);
+    const uint32_t nb = 1u + (cnt0 + cnt1 + PACK_THREADS - 1u) / PACK_THREADS;
+    hipLaunchKernelGGL(k_pack_totals, dim3(nb), dim3(PACK_THREADS), 0, s, (const SolverPartial*)a.partials, solver_reduce_blocks(a.n), a.ctrl, a.solver_tot, iter,
+                       a.sp.rest_density, a.sp.dt, a.status, a.gate, src_idx, cnt0, cnt1, words, stride, off, field, out0, out1);
 }
 
 void launch_solver_tail(hipStream_t s, Profiler* prof, const SweepArgs& a, int tail, float4* pm_out, int decide_iter, int residual_density,
@@ -2861,7 +2992,7 @@ void launch_solver_tail(hipStream_t s, Profiler* prof, const SweepArgs& a, int t
     if (a.n && tail != TAIL_NONE)
         hipLaunchKernelGGL(k_solver_tail, dim3((a.n + 255) / 256), dim3(256), 0, s, a.n, tail, a.sp.dt, a.sp.hyb_vfactor, a.pm, pm_out, a.vel, a.pacc, a.orig,
                            a.owned, a.ctrl, tail >= TAIL_VX ? a.hdr_partials : nullptr, a.status, a.gate, a.solver_tot, decide_iter,
-                           SolveP{residual_density, max_avg_error, max_iters, 1}, a.sp.rest_density, handoff_host, gate_out);
+                           solve_params(a, residual_density, max_avg_error, max_iters, 1, false), a.sp.rest_density, handoff_host, gate_out);
 }
 
 // Chained solves (HybridDFSPH, one context): the host does not wait between the divergence solve and the density solve.  Behind
@@ -2887,7 +3018,7 @@ void launch_jacobi_update(hipStream_t s, Profiler* prof, const SweepArgs& a, int
     const float* pin = (iter & 1) ? a.p1 : a.p0;
     float* pout = (iter & 1) ? a.p0 : a.p1;
     float* ptout = (iter & 1) ? a.pt0 : a.pt1;
-    const SolveP q{residual_density, max_avg_error, max_iters, multi};
+    const SolveP q = solve_params(a, residual_density, max_avg_error, max_iters, multi, false);
     if (jacobi_on_records(a)) {
         float4* recout = solve_on_records(a) ? ((iter & 1) ? a.rec0 : a.rec1) : nullptr;
         OpJacobiU<MathUniform> op{{uniform_math(a.h_uniform), a.pm, a.orig, a.rho, a.mrho, a.pacc, a.lam_grad, a.aii, a.src, pin, pout, ptout, recout, a.dens_err,
@@ -2903,7 +3034,7 @@ void launch_solver_decide(hipStream_t s, Profiler* prof, const SweepArgs& a, int
                           uint32_t max_iters)
 {
     ProfScope ps(prof, "solver_decide", s);
-    hipLaunchKernelGGL(k_solver_decide, dim3(1), dim3(64), 0, s, a.solver_tot, a.ctrl, iter, SolveP{residual_density, max_avg_error, max_iters, 1},
+    hipLaunchKernelGGL(k_solver_decide, dim3(1), dim3(64), 0, s, a.solver_tot, a.ctrl, iter, solve_params(a, residual_density, max_avg_error, max_iters, 1, false),
                        a.sp.rest_density, a.sp.dt, a.gate);
 }
 

@@ -69,15 +69,6 @@ __global__ void k_tot_sum(double* __restrict__ tot, const double* __restrict__ t
     for (int j = 0; j < n; j++) s += ((const volatile double*)table)[8 * j + threadIdx.x];   // rank order
     tot[threadIdx.x] = s;
 }
-// the same sum with this rank's own row still in `tot` (the RCCL transport's all-gather by send / receive)
-__global__ void k_tot_sum_self(double* __restrict__ tot, const double* __restrict__ table, int n, int self)
-{
-    if (threadIdx.x >= 6) return;
-    const double mine = tot[threadIdx.x];
-    double s = 0.0;
-    for (int j = 0; j < n; j++) s += j == self ? mine : table[8 * j + threadIdx.x];   // rank order: the same sum on every rank
-    tot[threadIdx.x] = s;
-}
 static void debug_comm_delay(sph_ctx* c)
 {
     const int us = c->opt.comm_delay_us;
@@ -477,14 +468,13 @@ struct RcclComm : Comm {
         NCCLCHK(c, ncclGroupEnd());
         return SPH_OK;
     }
+    // The solver totals over RCCL are an ALL-GATHER into the rank's table (row p = rank p's six doubles; this rank's own row stays in
+    // solver_tot), summed in rank order by whoever reads them (SolveP::tot_table, sph_sweeps.hip) -- never reduced in place.
     int allreduce_solver(Group& G, int slot) override
     {
-        sph_ctx* c = G.m[0];
-        c->dist.stat_allreduces++;
-        ProfScope ps(&c->prof, "rccl_allreduce", c->stream);
-        double* t = c->dist.solver_tot.as<double>() + 8 * slot;
-        NCCLCHK(c, ncclAllReduce(t, t, 6, ncclFloat64, ncclSum, (ncclComm_t)c->dist.nccl, c->stream));
-        return SPH_OK;
+        std::vector<Xfer> none(1);
+        memset(&none[0], 0, sizeof(Xfer));
+        return exchange_and_allreduce_solver(G, none, slot);
     }
     // ONE grouped launch per Jacobi iteration: the x-neighbours' ghost values, and this rank's six totals to every rank / every
     // rank's totals into a table (an all-gather by point-to-point messages); a one-block kernel then adds the rows in rank order --
@@ -495,13 +485,12 @@ struct RcclComm : Comm {
         sph_ctx* c = G.m[0];
         ncclComm_t nc = (ncclComm_t)c->dist.nccl;
         const int r = c->dist.rank, nr = c->dist.nranks;
-        HIPCHK(c, c->dist.tot_table.ensure((size_t)nr * 8 * 2 * sizeof(double)));
         double* tot = c->dist.solver_tot.as<double>() + 8 * slot;
         double* table = c->dist.tot_table.as<double>() + (size_t)slot * nr * 8;
         c->dist.stat_exchanges++;
         c->dist.stat_bytes_sent += (r > 0 ? x[0].send_bytes[0] : 0) + (r + 1 < nr ? x[0].send_bytes[1] : 0) + (size_t)(nr - 1) * 48;
         c->dist.stat_bytes_recv += (r > 0 ? x[0].recv_bytes[0] : 0) + (r + 1 < nr ? x[0].recv_bytes[1] : 0) + (size_t)(nr - 1) * 48;
-        {
+        if (nr > 1) {
             ProfScope ps(&c->prof, "rccl_sendrecv", c->stream);
             NCCLCHK(c, ncclGroupStart());
             if (r > 0) {
@@ -519,9 +508,7 @@ struct RcclComm : Comm {
             }
             NCCLCHK(c, ncclGroupEnd());
         }
-        ProfScope ps(&c->prof, "solver_totals", c->stream);
-        hipLaunchKernelGGL(k_tot_sum_self, dim3(1), dim3(64), 0, c->stream, tot, table, nr, r);
-        return SPH_OK;
+        return SPH_OK;   // (no kernel adds the rows up: the readers do)
     }
 };
 
@@ -1157,6 +1144,8 @@ extern "C" int sph_comm_init(sph_ctx* c, const uint8_t id[128], int rank, int n_
     ncclComm_t nc;
     NCCLCHK(c, ncclCommInitRank(&nc, n_ranks, uid, rank));
     c->dist.nccl = nc;
+    HIPCHK(c, c->dist.tot_table.ensure((size_t)n_ranks * 8 * 2 * sizeof(double)));   // two slots (chained solves) of one row per rank
+    HIPCHK(c, hipMemset(c->dist.tot_table.p, 0, (size_t)n_ranks * 8 * 2 * sizeof(double)));
     return SPH_OK;
 }
 

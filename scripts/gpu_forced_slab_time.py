@@ -7,7 +7,8 @@ import torch  # noqa: F401
 from adaptive_sph_amd import distributed as D, ffi, scene as sc
 from adaptive_sph_amd.workloads import WORKLOADS
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 60
-scene_f, params_f, _ = WORKLOADS["dam_break_1m"]
+wl = sys.argv[2] if len(sys.argv) > 2 else "dam_break_1m"
+scene_f, params_f, _ = WORKLOADS[wl]
 scn, P = scene_f(), params_f()
 pos, mass, vel = sc.init_particles(scn)
 lib = ffi.load_product()
@@ -24,5 +25,5 @@ t0 = time.perf_counter()
 for _ in range(steps):
     c.step(p)
 w = c.dist_get_stats()
-print(f"forced slab mode, 1 rank, dam_break_1m: {(time.perf_counter() - t0) / steps * 1e3:.3f} ms/step; per step over the whole run: host waits {w['host_waits'] / (steps + 20):.2f}, "
+print(f"forced slab mode, 1 rank, {wl}: {(time.perf_counter() - t0) / steps * 1e3:.3f} ms/step; per step over the whole run: host waits {w['host_waits'] / (steps + 20):.2f}, "
       f"all-reduces {w['allreduces'] / (steps + 20):.2f}, exchanges {w['exchanges'] / (steps + 20):.2f}")

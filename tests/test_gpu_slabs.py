@@ -828,9 +828,9 @@ def test_split_sweep_a_is_bit_identical_to_the_unsplit_form(product_lib, monkeyp
             grp[1].profile_enable(1)
             stats = [step() for _ in range(12)]
             prof = grp[1].profile_get()
-            # (either form adds up the rank's totals in a kernel of its own BEFORE the ghost exchange, so that the all-reduce travels
+            # (either form adds up the rank's totals in block 0 of the launch that packs the ghost values, so that the all-reduce travels
             #  with it: one collective call per iteration)
-            assert ("pressure_accel_edge" in prof) == (name == "split") and "solver_totals" in prof
+            assert ("pressure_accel_edge" in prof) == (name == "split") and ("solver_progress" in prof) == (name == "split") and "ghost_pack" in prof
             runs[name] = ([(x.dt, x.div_solver.iters, x.density_solver.iters) for st in stats for x in st],
                           [{f: c.download(f) for f in ("particle_id", "position", "velocity", "density", "pressure")} for c in grp])
         finally:
