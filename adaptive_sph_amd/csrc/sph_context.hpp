@@ -128,6 +128,11 @@ struct sph_ctx {
         uint32_t n_tot = 0;          // particles in the arrays incl. ghosts (== n when not distributed)
         bool have_flags = false;     // `owned` describes the current arrays (after a step)
         uint32_t n_halo[2] = {0, 0}, n_ghost[2] = {0, 0};   // [left, right]
+        // Ghost width PER CUT: H = the largest smoothing length among the particles of both ranks within the region a global-width
+        // layer would span around the cut ([left, right]; agreed with the x-neighbour), layer width = base_k * H + slack.  A fine
+        // region of a strongly multi-resolution scene then pays for its own support, not for the coarsest particle anywhere.
+        float hcut[2] = {0.f, 0.f};     // of the current ghost layer (the next fused refresh predicts with it)
+        float halo_w[2] = {0.f, 0.f};   // the widths the current layer was selected with
         DevBuf owned;                // u8 per slot: 1 owned, 0 ghost
         // fused refresh (sph_step.hip, slab_refresh_fused): class byte per slot of the previous step's arrays, per-block class
         // counts / offsets; `pre_*` describe the arrays between the refresh and the cell sort, which drops the slots that left

@@ -7,7 +7,7 @@
 
 #include "sph_context.hpp"
 
-enum { RC_BAD = 12, RC_FAR = 13 };   // words of dist.counts: the fused refresh's "take the general path" flag being collected; "a migrant may need more than one hand-over"
+enum { RC_BAD = 12, RC_FAR = 13, RC_HL = 14, RC_HR = 15 };   // RC_HL / RC_HR: float bits of the largest h in the region of the left / right cut   // words of dist.counts: the fused refresh's "take the general path" flag being collected; "a migrant may need more than one hand-over"
 
 // (sph_step.hip) a few device words -> mapped host memory, then wait for them: counts_host[16 ..), sequence number in counts_host[63]
 int publish_and_wait(sph_ctx* c, const void* dev_words, uint32_t n_words);
@@ -23,6 +23,7 @@ struct Xfer {
 struct RefreshCounts {
     uint32_t mig[2], halo[2];         // this rank: migrants to / halo members (that stay) towards [left, right]
     uint32_t in_mig[2], in_halo[2];   // the neighbours': migrants for me / their halo members towards me, from [left, right]
+    float hreg[2], in_hreg[2];        // largest h among this rank's particles in the region of its [left, right] cut; the neighbours' figure for the same cut
 };
 
 struct Comm {
@@ -105,8 +106,9 @@ enum { SC_STAY = 0, SC_HALO_L = 1, SC_HALO_R = 2, SC_MIG_L = 3, SC_MIG_R = 4, SC
 int ensure_dist_buffers(sph_ctx* c, uint32_t n);
 int partition_and_migrate(Group& G, std::vector<Member>& M, std::vector<int>* moved = nullptr, std::vector<std::vector<float>>* red = nullptr);
 int rebalance_cuts(Group& G, std::vector<Member>& M, bool* applied);
-int build_ghost_layer(Group& G, std::vector<Member>& M, float halo_width, float ring1_width, int status_in);
-int slab_refresh_fused(Group& G, std::vector<Member>& M, std::vector<std::vector<float>>& red, float halo_k, bool* fused);
+// ghost width per cut = base_k * H_cut + slack_w, H_cut = largest h within base_k * h_max + slack_w of the cut (both ranks); first ring: 2 H_cut
+int build_ghost_layer(Group& G, std::vector<Member>& M, float base_k, float slack_w, float h_max, int status_in);
+int slab_refresh_fused(Group& G, std::vector<Member>& M, std::vector<std::vector<float>>& red, float base_k, float slack_k, bool* fused);
 // refresh `field` (words floats per particle) of every member's ghosts from their owners; tot_slot >= 0: the all-reduce of that slot's
 // solver totals rides in the same call
 // `sel2` (one word per particle, like `sel` then): a second field in the SAME exchange -- the level estimation's (level, when) pair

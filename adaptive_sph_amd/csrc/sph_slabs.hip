@@ -40,7 +40,7 @@ __device__ __forceinline__ void block_class_counts(uint32_t cls, uint32_t* __res
 // class of every slot of the previous step's arrays: 0 stay, 1 migrate left, 2 migrate right, 3 drop (ghost)
 __global__ __launch_bounds__(256) void k_classify_migrate(uint32_t n, const float4* __restrict__ pm, const uint8_t* __restrict__ owned,
                                                            float cut_lo, float cut_hi, int has_left, int has_right, uint32_t* __restrict__ key,
-                                                           uint32_t* __restrict__ val, uint32_t* __restrict__ counts, float far_w)
+                                                           uint32_t* __restrict__ val, uint32_t* __restrict__ counts, float far_l, float far_r)
 {
     uint32_t i = blockIdx.x * 256 + threadIdx.x;
     uint32_t cls = 4;
@@ -50,10 +50,10 @@ __global__ __launch_bounds__(256) void k_classify_migrate(uint32_t n, const floa
         if (owned && !owned[i]) cls = 3;
         else if (has_left && x < cut_lo) {
             cls = 1;
-            far = x < cut_lo - far_w;
+            far = x < cut_lo - far_l;
         } else if (has_right && !(x < cut_hi)) {
             cls = 2;
-            far = !(x < cut_hi + far_w);
+            far = !(x < cut_hi + far_r);
         } else cls = 0;
         key[i] = cls;
         val[i] = i;
@@ -94,7 +94,26 @@ __global__ __launch_bounds__(256) void k_hist_x(uint32_t n, const float4* __rest
     atomicAdd(&hist[b], 1u);
 }
 
-// owned particles within `w` of a cut are ghosts of that neighbour: 1 left halo, 2 right halo, 0 none
+// largest smoothing length among the owned particles within `region` of the left / right cut (float bits: h >= 0, so unsigned order)
+__global__ __launch_bounds__(256) void k_region_hmax(uint32_t n, const float4* __restrict__ pm, float lo_edge, float hi_edge, int has_left, int has_right,
+                                                      uint32_t* __restrict__ out /* [2] */)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    float hl = 0.f, hr = 0.f;
+    if (i < n) {
+        const float4 p = pm[i];
+        if (has_left && p.x < lo_edge) hl = p.w;
+        if (has_right && !(p.x < hi_edge)) hr = p.w;
+    }
+    hl = wave_max(hl);
+    hr = wave_max(hr);
+    if ((threadIdx.x & 63u) == 0u) {
+        if (hl > 0.f) atomicMax(&out[0], __float_as_uint(hl));
+        if (hr > 0.f) atomicMax(&out[1], __float_as_uint(hr));
+    }
+}
+
+// owned particles within the layer width of a cut are ghosts of that neighbour: 1 left halo, 2 right halo, 0 none
 __global__ __launch_bounds__(256) void k_classify_halo(uint32_t n, const float4* __restrict__ pm, float lo_edge, float hi_edge, int has_left,
                                                         int has_right, uint32_t* __restrict__ key, uint32_t* __restrict__ val,
                                                         uint32_t* __restrict__ counts)
@@ -281,32 +300,47 @@ __global__ __launch_bounds__(256) void k_ghost_mrho(const uint32_t* __restrict__
 struct RefreshStage {
     float red[8];
     uint32_t status, fallback;
+    float hpred[2];   // the H per cut the classification's layer widths were predicted from: a larger one in this step's regions -> the general path
 };
 // launch 1: class byte per slot + per-block class counts
 // (a last-block-done ticket that would fold launch 2 into this one costs 230 us at N = 1M: 4096 device-scope fences + 4096 adds
 //  on one word -- measured, forced one-rank slab step 0.72 -> 0.95 ms)
+// (w_l / w_r: the layer widths of the left / right cut as PREDICTED from the previous step's H_cut; `region`: the distance from a cut
+//  within which a particle's h counts towards this step's H_cut -- reduced here, compared with the prediction after the round)
 __global__ __launch_bounds__(256) void k_slab_classify(uint32_t n, const float4* __restrict__ pm, const uint8_t* __restrict__ owned, float cut_lo,
-                                                        float cut_hi, float halo_w, int has_left, int has_right, uint8_t* __restrict__ cls,
+                                                        float cut_hi, float w_l, float w_r, float region, int has_left, int has_right, uint8_t* __restrict__ cls,
                                                         uint32_t* __restrict__ blk_cnt, uint32_t* __restrict__ counts)
 {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     uint32_t c = 7u;
     bool bad = false;
+    float hl = 0.f, hr = 0.f;
     if (i < n) {
-        const float x = pm[i].x;
+        const float4 P = pm[i];
+        const float x = P.x;
         if (owned && !owned[i]) c = SC_GHOST;
         else if (has_left && x < cut_lo) {
             c = SC_MIG_L;
-            bad = x < cut_lo - halo_w;          // the left rank's halo test is !(x < its cut_hi - halo_w), its cut_hi == my cut_lo
+            bad = x < cut_lo - w_l;             // the left rank's halo test is !(x < its cut_hi - w), its cut_hi == my cut_lo, the same w
         } else if (has_right && !(x < cut_hi)) {
             c = SC_MIG_R;
-            bad = !(x < cut_hi + halo_w);       // the right rank's: x < its cut_lo + halo_w
+            bad = !(x < cut_hi + w_r);          // the right rank's: x < its cut_lo + w
         } else {
-            const bool l = has_left && x < cut_lo + halo_w, r = has_right && !(x < cut_hi - halo_w);
+            const bool l = has_left && x < cut_lo + w_l, r = has_right && !(x < cut_hi - w_r);
             bad = l && r;
             c = l ? SC_HALO_L : (r ? SC_HALO_R : SC_STAY);
         }
         cls[i] = (uint8_t)c;
+        if (c != SC_GHOST) {
+            if (has_left && x < cut_lo + region) hl = P.w;
+            if (has_right && !(x < cut_hi - region)) hr = P.w;
+        }
+    }
+    hl = wave_max(hl);
+    hr = wave_max(hr);
+    if ((threadIdx.x & 63u) == 0u) {
+        if (hl > 0.f) atomicMax(&counts[RC_HL], __float_as_uint(hl));
+        if (hr > 0.f) atomicMax(&counts[RC_HR], __float_as_uint(hr));
     }
     __shared__ uint32_t s_cnt[4][4];   // [wave][class - 1]
     const uint32_t t = threadIdx.x, wave = t >> 6, lane = t & 63u;
@@ -323,7 +357,8 @@ __global__ __launch_bounds__(256) void k_slab_classify(uint32_t n, const float4*
 // launch 2, one 1024-thread block: exclusive scan of the block counts over the blocks (thread t owns a contiguous run of blocks),
 // the totals (counts[0 .. 3] = classes 1 .. 4, counts[4] = bad) and the words of the collective round, staged behind the counters:
 //   stage[0 .. 7] header values, stage[8] = -status, stage[9] = -"general path" (floats: ONE min all-reduce takes all ten),
-//   stage[10 .. 11] = (migrants, halo members) for the left neighbour, stage[12 .. 13] for the right one, stage[14 .. 17] = 0 (received)
+//   stage[10 .. 12] = (migrants, halo members, largest h in the cut's region) for the left neighbour, stage[13 .. 15] for the right
+//   one, stage[16 .. 21] = 0 (received)
 __global__ __launch_bounds__(1024) void k_slab_scan(uint32_t nb, const uint32_t* __restrict__ blk_cnt, uint32_t* __restrict__ blk_off,
                                                      uint32_t* __restrict__ counts, uint32_t* __restrict__ stage, RefreshStage rs)
 {
@@ -361,8 +396,11 @@ __global__ __launch_bounds__(1024) void k_slab_scan(uint32_t nb, const uint32_t*
         run[0] += v.x; run[1] += v.y; run[2] += v.z; run[3] += v.w;
     }
     if (t == 1023u) {
-        const uint32_t is_bad = counts[RC_BAD];
+        uint32_t is_bad = counts[RC_BAD];
         counts[RC_BAD] = 0u;
+        // (h >= 0: the float bits order like the values.  The neighbour holds the same prediction for the shared cut and tests its own
+        //  particles; the verdicts meet in the round's max-reduced fallback flag)
+        if (counts[RC_HL] > __float_as_uint(rs.hpred[0]) || counts[RC_HR] > __float_as_uint(rs.hpred[1])) is_bad = 1u;
         for (int k = 0; k < 4; k++) counts[k] = run[k];
         counts[4] = is_bad;
         for (int k = 0; k < 8; k++) stage[k] = __float_as_uint(rs.red[k]);
@@ -370,9 +408,14 @@ __global__ __launch_bounds__(1024) void k_slab_scan(uint32_t nb, const uint32_t*
         stage[9] = __float_as_uint((rs.fallback || is_bad) ? -1.f : 0.f);
         stage[10] = run[2];   // SC_MIG_L
         stage[11] = run[0];   // SC_HALO_L
-        stage[12] = run[3];   // SC_MIG_R
-        stage[13] = run[1];   // SC_HALO_R
-        stage[14] = stage[15] = stage[16] = stage[17] = 0u;
+        stage[12] = counts[RC_HL];   // largest h in the left cut's region (float bits)
+        stage[13] = run[3];   // SC_MIG_R
+        stage[14] = run[1];   // SC_HALO_R
+        stage[15] = counts[RC_HR];
+        counts[5] = counts[RC_HL];   // (beside the class totals: what the transports without device staging read)
+        counts[6] = counts[RC_HR];
+        counts[RC_HL] = counts[RC_HR] = 0u;
+        for (int k = 16; k < 22; k++) stage[k] = 0u;
     }
 }
 
@@ -554,7 +597,7 @@ int partition_and_migrate(Group& G, std::vector<Member>& M, std::vector<int>* mo
             hipLaunchKernelGGL(k_classify_migrate, dim3((n_prev + 255) / 256), dim3(256), 0, c->stream, n_prev, c->pm[c->pcur].as<float4>(),
                                d.have_flags ? d.owned.as<uint8_t>() : (const uint8_t*)nullptr, d.cut_lo, d.cut_hi, d.rank > 0 ? 1 : 0,
                                d.rank + 1 < d.nranks ? 1 : 0, c->key[0].as<uint32_t>(), c->val[0].as<uint32_t>(), d.counts.as<uint32_t>(),
-                               4.f * fmaxf(c->h_max_step, 0.f));   // every slab is at least two ghost layers (>= 8 h_max) wide
+                               d.halo_w[0], d.halo_w[1]);   // the x-neighbour's slab is at least as wide as its ghost layer at the shared cut -- the previous layer's width (0: unknown, every migrant may need another hand-over)
             int res = radix_sort_pairs(c->stream, &c->prof, c->key[0].as<uint32_t>(), c->val[0].as<uint32_t>(), c->key[1].as<uint32_t>(),
                                        c->val[1].as<uint32_t>(), n_prev, 2, c->sort_scratch.as<uint32_t>());
             if (res == 1) {
@@ -718,12 +761,42 @@ int rebalance_cuts(Group& G, std::vector<Member>& M, bool* applied)
 
 // part 2: ghost layer -- owned particles within halo_width of a cut are copied to that neighbour, in array
 // order (stable partition again)
-int build_ghost_layer(Group& G, std::vector<Member>& M, float halo_width, float ring1_width, int status_in)
+int build_ghost_layer(Group& G, std::vector<Member>& M, float base_k, float slack_w, float h_max, int status_in)
 {
     const size_t nm = M.size();
     int rc = SPH_OK;
     std::vector<uint32_t> tl(nm), tr(nm), fl(nm), fr(nm);
     std::vector<Xfer> x(nm);
+    // ---- H per cut: the largest h of either rank's particles within a global-width layer of the cut (one neighbour round)
+    const float region = base_k * h_max + slack_w;
+    for (auto& m : M) {
+        sph_ctx* c = m.c;
+        auto& d = c->dist;
+        (void)hipSetDevice(c->device);
+        const uint32_t n = (uint32_t)c->n;
+        (void)hipMemsetAsync(d.counts.p, 0, 64, c->stream);
+        if (n)
+            hipLaunchKernelGGL(k_region_hmax, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, c->pm[c->pcur].as<float4>(), d.cut_lo + region, d.cut_hi - region,
+                               d.rank > 0 ? 1 : 0, d.rank + 1 < d.nranks ? 1 : 0, d.counts.as<uint32_t>() + RC_HL);
+        HIPCHK(c, hipMemcpyAsync(d.counts_host + RC_HL, d.counts.as<uint32_t>() + RC_HL, 8, hipMemcpyDeviceToHost, c->stream));
+    }
+    if ((rc = agree(G, wait_all(G)))) return rc;
+    {
+        std::vector<uint32_t> hl(nm), hr(nm), nl(nm), nr(nm);
+        for (size_t i = 0; i < nm; i++) {
+            hl[i] = M[i].c->dist.counts_host[RC_HL];
+            hr[i] = M[i].c->dist.counts_host[RC_HR];
+        }
+        if ((rc = G.comm->neighbour_counts(G, hl, hr, nl, nr, nullptr))) return rc;   // (float bits of non-negative values: the exchange is word-wise)
+        for (size_t i = 0; i < nm; i++) {
+            auto& d = M[i].c->dist;
+            float a, b, na, nb;
+            memcpy(&a, &hl[i], 4); memcpy(&b, &hr[i], 4); memcpy(&na, &nl[i], 4); memcpy(&nb, &nr[i], 4);
+            d.hcut[0] = d.rank > 0 ? fmaxf(a, na) : 0.f;
+            d.hcut[1] = d.rank + 1 < d.nranks ? fmaxf(b, nb) : 0.f;
+            for (int s = 0; s < 2; s++) d.halo_w[s] = d.hcut[s] > 0.f ? base_k * d.hcut[s] + slack_w : 0.f;
+        }
+    }
     for (auto& m : M) {
         sph_ctx* c = m.c;
         auto& d = c->dist;
@@ -732,8 +805,8 @@ int build_ghost_layer(Group& G, std::vector<Member>& M, float halo_width, float 
         (void)hipMemsetAsync(d.counts.p, 0, 64, c->stream);
         if (n) {
             ProfScope ps(&c->prof, "slab_halo_select", c->stream);
-            hipLaunchKernelGGL(k_classify_halo, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, c->pm[c->pcur].as<float4>(), d.cut_lo + halo_width,
-                               d.cut_hi - halo_width, d.rank > 0 ? 1 : 0, d.rank + 1 < d.nranks ? 1 : 0, c->key[0].as<uint32_t>(),
+            hipLaunchKernelGGL(k_classify_halo, dim3((n + 255) / 256), dim3(256), 0, c->stream, n, c->pm[c->pcur].as<float4>(), d.cut_lo + d.halo_w[0],
+                               d.cut_hi - d.halo_w[1], d.rank > 0 ? 1 : 0, d.rank + 1 < d.nranks ? 1 : 0, c->key[0].as<uint32_t>(),
                                c->val[0].as<uint32_t>(), d.counts.as<uint32_t>());
             int res = radix_sort_pairs(c->stream, &c->prof, c->key[0].as<uint32_t>(), c->val[0].as<uint32_t>(), c->key[1].as<uint32_t>(),
                                        c->val[1].as<uint32_t>(), n, 2, c->sort_scratch.as<uint32_t>());
@@ -801,7 +874,7 @@ int build_ghost_layer(Group& G, std::vector<Member>& M, float halo_width, float 
                 hipLaunchKernelGGL(k_unpack_ghosts, dim3((d.n_ghost[side] + 255) / 256), dim3(256), 0, c->stream, base[side], d.n_ghost[side],
                                    d.recv[side].as<float>(), c->pm[c->pcur].as<float4>(), c->vel[k].as<float2>(), c->orig[k].as<uint32_t>(),
                                    c->lvl[k].as<float>(), c->lvlold[k].as<float>(), d.ring1_src.as<uint8_t>(), side == 0 ? 0u : d.n_ghost[0],
-                                   side == 0 ? d.cut_lo - ring1_width : d.cut_hi + ring1_width, side);
+                                   side == 0 ? d.cut_lo - 2.f * d.hcut[0] : d.cut_hi + 2.f * d.hcut[1], side);
         d.n_tot = d.ghosts_ok ? n + d.n_ghost[0] + d.n_ghost[1] : n;
         M[i].n = d.n_tot;
         // pre-sort index -> position in my halo list
@@ -822,7 +895,7 @@ int build_ghost_layer(Group& G, std::vector<Member>& M, float halo_width, float 
 // value stands in (masses do not change inside a step) and is compared afterwards.  *fused = false: nothing was applied
 // (a rank without a prediction, a different h_max, a deep migrant, a narrow slab) and the caller takes the general path;
 // `red` is reduced either way.
-int slab_refresh_fused(Group& G, std::vector<Member>& M, std::vector<std::vector<float>>& red, float halo_k, bool* fused)
+int slab_refresh_fused(Group& G, std::vector<Member>& M, std::vector<std::vector<float>>& red, float base_k, float slack_k, bool* fused)
 {
     const size_t nm = M.size();
     int rc = SPH_OK;
@@ -838,19 +911,24 @@ int slab_refresh_fused(Group& G, std::vector<Member>& M, std::vector<std::vector
         const uint32_t n_prev = d.have_flags ? d.n_tot : (uint32_t)c->n;
         n_prev_of[i] = n_prev;
         if (!(c->h_max_step > 0.f) || c->h_max_step != h_pred) fallback = 1;
-        const float halo_w = h_pred * halo_k;
+        // the layer widths as the previous step's H per cut predicts them (agreed with the neighbours then; compared with this step's
+        // after the round: a larger particle that came near a cut sends the step to the general path, which measures first)
+        const float slack_w = slack_k * h_pred, region = base_k * h_pred + slack_w;
+        const float w_l = d.hcut[0] > 0.f ? base_k * d.hcut[0] + slack_w : 0.f, w_r = d.hcut[1] > 0.f ? base_k * d.hcut[1] + slack_w : 0.f;
         const bool has_l = d.rank > 0, has_r = d.rank + 1 < d.nranks;
-        if (has_l && has_r && !(d.cut_hi - halo_w >= d.cut_lo + halo_w)) fallback = 1;   // narrower than two ghost layers: the general path reports it
+        if (has_l && has_r && !(d.cut_hi - w_r >= d.cut_lo + w_l)) fallback = 1;   // narrower than two ghost layers: the general path reports it
         // two launches: classify + per-block counts; scan, totals and the staging of the round (no memset, no copy, no stage kernel)
         const uint32_t nb = (n_prev + 255u) / 256u;
         RefreshStage rs{};
         for (int k = 0; k < 8; k++) rs.red[k] = red[i][(size_t)k];
         rs.status = 0u;
+        rs.hpred[0] = d.hcut[0];
+        rs.hpred[1] = d.hcut[1];
         rs.fallback = (uint32_t)fallback;   // what this process knows so far (a later member's verdict reaches the round through the host)
         ProfScope ps(&c->prof, "slab_refresh", c->stream);
         if (n_prev)
             hipLaunchKernelGGL(k_slab_classify, dim3(nb), dim3(256), 0, c->stream, n_prev, c->pm[c->pcur].as<float4>(),
-                               d.have_flags ? d.owned.as<uint8_t>() : (const uint8_t*)nullptr, d.cut_lo, d.cut_hi, halo_w, has_l ? 1 : 0, has_r ? 1 : 0,
+                               d.have_flags ? d.owned.as<uint8_t>() : (const uint8_t*)nullptr, d.cut_lo, d.cut_hi, w_l, w_r, region, has_l ? 1 : 0, has_r ? 1 : 0,
                                d.cls.as<uint8_t>(), d.blk.as<uint32_t>(), d.counts.as<uint32_t>());
         hipLaunchKernelGGL(k_slab_scan, dim3(1), dim3(1024), 0, c->stream, nb, d.blk.as<uint32_t>(), d.blk.as<uint32_t>() + (size_t)nb * 4,
                            d.counts.as<uint32_t>(), d.counts.as<uint32_t>() + 16, rs);
@@ -867,7 +945,11 @@ int slab_refresh_fused(Group& G, std::vector<Member>& M, std::vector<std::vector
     if (status) return M[0].c->fail(status, "another rank of the slab decomposition reported status %d", status);
     if (red[0][3] < 0.f) return SPH_OK;                       // a rank's header wait failed: the caller reports it (same value everywhere)
     if (fallback || !(-red[0][0] == h_pred)) return SPH_OK;   // identical on every rank: all-reduced values only
-    const float halo_w = h_pred * halo_k, ring1_w = h_pred * 2.f;
+    for (size_t i = 0; i < nm; i++) {   // the layer is selected with the predicted widths (>= this step's: a region whose H grew raised `fallback`)
+        auto& d = M[i].c->dist;
+        const float slack_w = slack_k * h_pred;
+        for (int s = 0; s < 2; s++) d.halo_w[s] = d.hcut[s] > 0.f ? base_k * d.hcut[s] + slack_w : 0.f;
+    }
 
     std::vector<Xfer> x(nm);
     std::vector<char> over(nm, 0);
@@ -976,7 +1058,7 @@ int slab_refresh_fused(Group& G, std::vector<Member>& M, std::vector<std::vector
                 hipLaunchKernelGGL(k_unpack_ghosts, dim3((d.n_ghost[side] + 255) / 256), dim3(256), 0, c->stream, base[side], d.n_ghost[side],
                                    d.recv[side].as<float>(), c->pm[c->pcur].as<float4>(), c->vel[k].as<float2>(), c->orig[k].as<uint32_t>(),
                                    c->lvl[k].as<float>(), c->lvlold[k].as<float>(), d.ring1_src.as<uint8_t>(), side == 0 ? 0u : d.n_ghost[0],
-                                   side == 0 ? d.cut_lo - ring1_w : d.cut_hi + ring1_w, side);
+                                   side == 0 ? d.cut_lo - 2.f * d.hcut[0] : d.cut_hi + 2.f * d.hcut[1], side);
         dbg_sync(c, "fused: ghosts unpacked (this rank)", 1);
         d.pre = true;
         d.pre_cls_n = n_prev;
@@ -993,8 +1075,12 @@ int slab_refresh_fused(Group& G, std::vector<Member>& M, std::vector<std::vector
         if (nh) hipLaunchKernelGGL(k_halo_pos, dim3((nh + 255) / 256), dim3(256), 0, c->stream, d.halo_idx.as<uint32_t>(), nh, d.halo_pos.as<uint32_t>());
         dbg_sync(c, "fused: halo_pos set", 1);
     }
-    (void)halo_w;
     for (auto& m : M) dbg_sync(m.c, "fused: ghosts unpacked", 2);
+    for (size_t i = 0; i < nm; i++) {   // the next step predicts with THIS step's H per cut (both ranks of a cut hold the same two figures)
+        auto& d = M[i].c->dist;
+        d.hcut[0] = d.rank > 0 ? fmaxf(rcs[i].hreg[0], rcs[i].in_hreg[0]) : 0.f;
+        d.hcut[1] = d.rank + 1 < d.nranks ? fmaxf(rcs[i].hreg[1], rcs[i].in_hreg[1]) : 0.f;
+    }
     *fused = true;
     return SPH_OK;
 }

@@ -693,7 +693,7 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
     // previous step's (all-reduced) largest displacement, at least 2 h_max -- and the step checks afterwards that it sufficed.
     const float slab_slack_k = (level_on && p->level_estimation_after_advection && G.multi())
                                    ? fmaxf(2.f, c0->h_max_step > 0.f ? 4.f * c0->last_dmax / c0->h_max_step : 0.f) : 0.f;
-    auto halo_factor = [&]() { return fmaxf(4.f, level_on ? p->level_estimation_range / SPH_ETA : 0.f) + slab_slack_k; };
+    const float halo_base_k = fmaxf(4.f, level_on ? p->level_estimation_range / SPH_ETA : 0.f);
     // The tail of the previous step's last solve already reduced this step's header into hdr_host (k_solver_tail,
     // k_header_ahead): nothing to launch, nothing to wait for -- unless the host touched the state or the smoothing lengths are
     // not the mass-derived ones.  On a slab the header describes the particles the rank owned at the END of that step; the ones
@@ -735,11 +735,10 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
         // repeat until nobody moved (the all-reduced count), at most once per rank.  The header all-reduce rides in the round
         // trip of the first partition's counts.
         // ordinary steps: the fused refresh (one round trip, no partition sort); it reduces `red` whether or not it applies
-        const float halo_k_f = halo_factor();
         const bool no_fused = c0->opt.slab_general != 0;   // measurement / test aid: always the general path
         const bool attempt = h_from_mass_mode && !rebalanced && !no_fused;     // (parameters and all-reduced values: the same on every rank)
         if (attempt) {
-            if ((rc = slab_refresh_fused(G, M, red, halo_k_f, &slab_fused))) return rc;
+            if ((rc = slab_refresh_fused(G, M, red, halo_base_k, slab_slack_k, &slab_fused))) return rc;
             if (!slab_fused && (hdr_rc || red[0][3] < 0.f)) {
                 if (hdr_rc) return hdr_rc;
                 return c0->fail((int)-red[0][3], "another rank of the slab decomposition reported status %d", (int)-red[0][3]);
@@ -791,15 +790,13 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
         // (the extended lists of the level estimation reach level_estimation_range / ETA smoothing lengths)
         // Two rings of one support radius (2 h_max) each: ghosts of the first ring compute their pressure acceleration here
         // (their neighbours are all inside the second), so a Jacobi iteration exchanges p / rho^2 only.
-        const float halo_k = halo_factor();
         for (auto& m : M) m.c->slab_slack_w = slab_slack_k * h_max_g;
-        const float halo_w = h_max_g * halo_k;
-        if (!slab_fused && (rc = build_ghost_layer(G, M, halo_w, h_max_g * 2.f, status_in))) return rc;
-        // bounding box of owned + ghosts from the cuts: an owned particle lies between them, a ghost within halo_w beyond one
+        if (!slab_fused && (rc = build_ghost_layer(G, M, halo_base_k, slab_slack_k * h_max_g, h_max_g, status_in))) return rc;
+        // bounding box of owned + ghosts from the cuts: an owned particle lies between them, a ghost within the cut's layer width beyond one
         for (size_t i = 0; i < M.size(); i++) {
             const auto& d = M[i].c->dist;
-            if (d.rank > 0) boxes[i].min_x = fmaxf(gbox.min_x, d.cut_lo - halo_w);
-            if (d.rank + 1 < d.nranks) boxes[i].max_x = fminf(gbox.max_x, d.cut_hi + halo_w);
+            if (d.rank > 0) boxes[i].min_x = fmaxf(gbox.min_x, d.cut_lo - d.halo_w[0]);
+            if (d.rank + 1 < d.nranks) boxes[i].max_x = fminf(gbox.max_x, d.cut_hi + d.halo_w[1]);
             if (!(boxes[i].max_x >= boxes[i].min_x)) boxes[i].max_x = boxes[i].min_x;   // an empty slab beyond the fluid
         }
     }

@@ -193,19 +193,22 @@ struct LocalComm : Comm {
         for (size_t i = 0; i < n; i++) {
             sph_ctx* c = G.m[i];
             HIPCHK(c, hipSetDevice(c->device));
-            uint32_t w[5];
-            HIPCHK(c, hipMemcpy(w, c->dist.counts.p, 20, hipMemcpyDeviceToHost));
+            uint32_t w[7];
+            HIPCHK(c, hipMemcpy(w, c->dist.counts.p, 28, hipMemcpyDeviceToHost));
             rcs[i].halo[0] = w[0];
             rcs[i].halo[1] = w[1];
             rcs[i].mig[0] = w[2];
             rcs[i].mig[1] = w[3];
             if (w[4]) *fallback = 1;
+            memcpy(rcs[i].hreg, w + 5, 8);
         }
         for (size_t i = 0; i < n; i++) {
             rcs[i].in_mig[0] = i > 0 ? rcs[i - 1].mig[1] : 0;
             rcs[i].in_halo[0] = i > 0 ? rcs[i - 1].halo[1] : 0;
+            rcs[i].in_hreg[0] = i > 0 ? rcs[i - 1].hreg[1] : 0.f;
             rcs[i].in_mig[1] = i + 1 < n ? rcs[i + 1].mig[0] : 0;
             rcs[i].in_halo[1] = i + 1 < n ? rcs[i + 1].halo[0] : 0;
+            rcs[i].in_hreg[1] = i + 1 < n ? rcs[i + 1].hreg[0] : 0.f;
         }
         if (red) allreduce_min_f32(G, *red);
         return SPH_OK;
@@ -393,7 +396,8 @@ struct RcclComm : Comm {
         ncclComm_t nc = (ncclComm_t)c->dist.nccl;
         const int r = c->dist.rank, nr = c->dist.nranks;
         // k_slab_classify's last block staged the round behind the counters: d[0 .. 7] header values, d[8] = -status,
-        // d[9] = -"general path" (ten floats, ONE min all-reduce), d[10 .. 13] my counts for the left / right neighbour, d[14 .. 17] theirs
+        // d[9] = -"general path" (ten floats, ONE min all-reduce), d[10 .. 12] / d[13 .. 15] my (migrants, halo members, largest h in the
+        // cut's region) for the left / right neighbour, d[16 .. 18] / d[19 .. 21] theirs
         uint32_t* d = c->dist.counts.as<uint32_t>() + 16;
         const uint32_t* h = (const uint32_t*)((const uint8_t*)c->dist.counts_host + 64);   // publish destination
         const size_t nred = red ? (*red)[0].size() : 0;
@@ -407,16 +411,16 @@ struct RcclComm : Comm {
             ProfScope ps(&c->prof, "rccl_sendrecv", c->stream);
             NCCLCHK(c, ncclGroupStart());
             if (r > 0) {
-                NCCLCHK(c, ncclSend(d + 10, 2, ncclUint32, r - 1, nc, c->stream));
-                NCCLCHK(c, ncclRecv(d + 14, 2, ncclUint32, r - 1, nc, c->stream));
+                NCCLCHK(c, ncclSend(d + 10, 3, ncclUint32, r - 1, nc, c->stream));
+                NCCLCHK(c, ncclRecv(d + 16, 3, ncclUint32, r - 1, nc, c->stream));
             }
             if (r + 1 < nr) {
-                NCCLCHK(c, ncclSend(d + 12, 2, ncclUint32, r + 1, nc, c->stream));
-                NCCLCHK(c, ncclRecv(d + 16, 2, ncclUint32, r + 1, nc, c->stream));
+                NCCLCHK(c, ncclSend(d + 13, 3, ncclUint32, r + 1, nc, c->stream));
+                NCCLCHK(c, ncclRecv(d + 19, 3, ncclUint32, r + 1, nc, c->stream));
             }
             NCCLCHK(c, ncclGroupEnd());
         }
-        int rc = publish_and_wait(c, d, 18);
+        int rc = publish_and_wait(c, d, 22);
         if (rc) return rc;
         float f[10];
         memcpy(f, h, sizeof f);
@@ -426,12 +430,17 @@ struct RcclComm : Comm {
         RefreshCounts& o = rcs[0];
         o.mig[0] = h[10];
         o.halo[0] = h[11];
-        o.mig[1] = h[12];
-        o.halo[1] = h[13];
-        o.in_mig[0] = r > 0 ? h[14] : 0;
-        o.in_halo[0] = r > 0 ? h[15] : 0;
-        o.in_mig[1] = r + 1 < nr ? h[16] : 0;
-        o.in_halo[1] = r + 1 < nr ? h[17] : 0;
+        memcpy(&o.hreg[0], &h[12], 4);
+        o.mig[1] = h[13];
+        o.halo[1] = h[14];
+        memcpy(&o.hreg[1], &h[15], 4);
+        o.in_mig[0] = r > 0 ? h[16] : 0;
+        o.in_halo[0] = r > 0 ? h[17] : 0;
+        o.in_mig[1] = r + 1 < nr ? h[19] : 0;
+        o.in_halo[1] = r + 1 < nr ? h[20] : 0;
+        o.in_hreg[0] = o.in_hreg[1] = 0.f;
+        if (r > 0) memcpy(&o.in_hreg[0], &h[18], 4);
+        if (r + 1 < nr) memcpy(&o.in_hreg[1], &h[21], 4);
         return SPH_OK;
     }
     int agree_guards_queued(Group& G) override
@@ -689,20 +698,24 @@ struct ThreadComm : Comm {
             grp(G)->abandon();
             return rc;
         }
-        uint32_t w[5];
-        HIPCHK(c, hipMemcpy(w, c->dist.counts.p, 20, hipMemcpyDeviceToHost));
+        uint32_t w[7];
+        HIPCHK(c, hipMemcpy(w, c->dist.counts.p, 28, hipMemcpyDeviceToHost));
         RefreshCounts& o = rcs[0];
         o.halo[0] = w[0];
         o.halo[1] = w[1];
         o.mig[0] = w[2];
         o.mig[1] = w[3];
         if (w[4]) *fallback = 1;
-        rc = meet(G, 5, [&](ThreadGroup* g, int r) { g->words[(size_t)r] = {o.mig[0], o.halo[0], o.mig[1], o.halo[1], (uint32_t)*status, (uint32_t)*fallback, 0, 0}; },
+        memcpy(o.hreg, w + 5, 8);
+        rc = meet(G, 5, [&](ThreadGroup* g, int r) { g->words[(size_t)r] = {o.mig[0], o.halo[0], o.mig[1], o.halo[1], (uint32_t)*status, (uint32_t)*fallback, w[5], w[6]}; },
                   [&](ThreadGroup* g, int r) {
                       o.in_mig[0] = r > 0 ? g->words[(size_t)r - 1][2] : 0;
                       o.in_halo[0] = r > 0 ? g->words[(size_t)r - 1][3] : 0;
                       o.in_mig[1] = r + 1 < g->n ? g->words[(size_t)r + 1][0] : 0;
                       o.in_halo[1] = r + 1 < g->n ? g->words[(size_t)r + 1][1] : 0;
+                      o.in_hreg[0] = o.in_hreg[1] = 0.f;
+                      if (r > 0) memcpy(&o.in_hreg[0], &g->words[(size_t)r - 1][7], 4);        // the left rank's figure for ITS right cut = my left one
+                      if (r + 1 < g->n) memcpy(&o.in_hreg[1], &g->words[(size_t)r + 1][6], 4);
                       for (int q = 0; q < g->n; q++) {
                           *status = std::max(*status, (int)g->words[(size_t)q][4]);
                           if (g->words[(size_t)q][5]) *fallback = 1;
@@ -982,17 +995,18 @@ struct ShmComm : Comm {
             comm_abandon(c);
             return rc;
         }
-        uint32_t w[5];
-        HIPCHK(c, hipMemcpy(w, c->dist.counts.p, 20, hipMemcpyDeviceToHost));
+        uint32_t w[7];
+        HIPCHK(c, hipMemcpy(w, c->dist.counts.p, 28, hipMemcpyDeviceToHost));
         RefreshCounts& o = rcs[0];
         o.halo[0] = w[0];
         o.halo[1] = w[1];
         o.mig[0] = w[2];
         o.mig[1] = w[3];
         if (w[4]) *fallback = 1;
+        memcpy(o.hreg, w + 5, 8);
         rc = meet(G, 5,
                   [&](ShmSegment* g, int r) {
-                      const uint32_t v[8] = {o.mig[0], o.halo[0], o.mig[1], o.halo[1], (uint32_t)*status, (uint32_t)*fallback, 0, 0};
+                      const uint32_t v[8] = {o.mig[0], o.halo[0], o.mig[1], o.halo[1], (uint32_t)*status, (uint32_t)*fallback, w[5], w[6]};
                       memcpy(g->words[r], v, sizeof v);
                   },
                   [&](ShmSegment* g, int r) {
@@ -1000,6 +1014,9 @@ struct ShmComm : Comm {
                       o.in_halo[0] = r > 0 ? g->words[r - 1][3] : 0;
                       o.in_mig[1] = r + 1 < (int)g->n ? g->words[r + 1][0] : 0;
                       o.in_halo[1] = r + 1 < (int)g->n ? g->words[r + 1][1] : 0;
+                      o.in_hreg[0] = o.in_hreg[1] = 0.f;
+                      if (r > 0) memcpy(&o.in_hreg[0], &g->words[r - 1][7], 4);
+                      if (r + 1 < (int)g->n) memcpy(&o.in_hreg[1], &g->words[r + 1][6], 4);
                       for (int q = 0; q < (int)g->n; q++) {
                           *status = std::max(*status, (int)g->words[q][4]);
                           if (g->words[q][5]) *fallback = 1;

@@ -102,6 +102,39 @@ def test_config3_dam_break_8m_eight_slabs_against_the_single_context(product_lib
             assert np.array_equal(np.add.reduceat(idx.astype(np.uint64) ** power, off[:-1].astype(np.int64)), ref[power - 1][pid]), power
 
 
+def test_config4_ratio_stress_4m_step_path_on_eight_slabs(product_lib):
+    """BASELINE configs[4]'s scene (4 002 768 fine + 1 575 coarse particles, 50:1 radii, IISPH, Sdf2D box, EmptyAngle level estimation)
+    on the EIGHT x-slabs BASELINE.json names, against the single context.  The ghost layer of a cut is as wide as the largest
+    smoothing length NEAR THAT CUT demands (sph_context.hpp: Dist::hcut) -- seven of the eight slabs are 0.069-wide slices of the
+    fine block, a fifth of the ghost layer the coarse particles' support would ask for, which round 3 refused beyond two slabs."""
+    scene_f, params_f, _ = WORKLOADS["ratio_stress_4m"]
+    scn, P = scene_f(), params_f(level_estimation_method="EmptyAngle", max_iters=3, **FORCED)
+    pos, mass, vel = sc.init_particles(scn)
+    planes = sc.boundary_planes(scn.boundary, P.init_boundary_handler)
+    p = P.to_ffi()
+    single = ffi.Context(product_lib, len(mass), planes)
+    single.upload(mass, pos, vel)
+    grp = D.make_loopback_group(product_lib, pos, mass, vel, planes, 8)
+    assert sum(c.n for c in grp) == len(mass) and min(c.n for c in grp) > 400000
+    for s in range(3):
+        st1 = single.step(p)
+        sts = ffi.group_step(grp, p)
+        assert all(st.dt == st1.dt for st in sts)
+        assert all(st.density_solver.iters == st1.density_solver.iters for st in sts)
+    n = len(mass)
+    ids = np.concatenate([c.download("particle_id") for c in grp])
+    assert np.array_equal(np.sort(ids), np.arange(n))
+    assert np.array_equal(D.gather_by_id(grp, "neighbor_count", n), single.download("neighbor_count"))
+    for f, tol in (("position", 1e-5), ("velocity", 1e-4), ("density", 1e-5), ("mass", 0.0), ("level_estimation", 1e-4)):
+        assert rel_err(D.gather_by_id(grp, f, n), single.download(f)) <= tol, f
+    # the inner slabs of the fine block carry ghost layers of a few thousand particles, not the 660 k a global-width layer held
+    st = grp[3].dist_get_stats()
+    assert 0 < st["n_ghost"][0] < 100000 and 0 < st["n_ghost"][1] < 100000, st
+    for c in grp:
+        c.close()
+    single.close()
+
+
 def test_config3_dam_break_8m_eight_ranks_on_their_own_threads(product_lib):
     """configs[3] the way 8 processes would run it: 8 slab contexts, one host thread each, every rank calling sph_step by itself
     (thread transport: the per-rank driver code with its rank-local branches; a collective not entered by all or an unmatched
