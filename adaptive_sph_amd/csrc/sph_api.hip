@@ -355,6 +355,24 @@ __global__ __launch_bounds__(256) void k_from_host_order(uint32_t n, int kind, c
     }
 }
 
+// dst[slot[r]] = src[r]: the rows of a slab context's owned particles (download order) into their slots
+__global__ __launch_bounds__(256) void k_rows_to_slots(uint32_t n, int kind, const uint32_t* __restrict__ slot, const void* __restrict__ src, void* __restrict__ dst)
+{
+    const uint32_t r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= n) return;
+    const uint32_t i = slot[r];
+    switch (kind) {
+    case G_F32: ((float*)dst)[i] = ((const float*)src)[r]; break;
+    case G_U32: ((uint32_t*)dst)[i] = ((const uint32_t*)src)[r]; break;
+    case G_F32X2: ((float2*)dst)[i] = ((const float2*)src)[r]; break;
+    case G_U8: ((uint8_t*)dst)[i] = ((const uint8_t*)src)[r]; break;
+    case G_PM_X: { float2 p = ((const float2*)src)[r]; float4 q = ((float4*)dst)[i]; q.x = p.x; q.y = p.y; ((float4*)dst)[i] = q; } break;
+    case G_PM_M: { float4 q = ((float4*)dst)[i]; q.z = ((const float*)src)[r]; ((float4*)dst)[i] = q; } break;
+    case G_PM_H: { float4 q = ((float4*)dst)[i]; q.w = ((const float*)src)[r]; ((float4*)dst)[i] = q; } break;
+    default: break;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_cell_index_host(uint32_t n, GridP g, const uint32_t* __restrict__ orig, const float4* __restrict__ pm,
                                                           uint32_t* __restrict__ dst)
 {
@@ -993,12 +1011,30 @@ extern "C" int sph_upload_field(sph_ctx* c, int field, const void* src, uint64_t
         r = FieldRef{G_U32, c->orig[c->cur].p, 4, true};
     } else if (!field_ref(c, field, &r) || !r.uploadable)
         return c->fail(SPH_ERR_INVALID_ARGUMENT, "field %d cannot be uploaded", field);
-    if (c->dist.on && c->dist.have_flags) return c->fail(SPH_ERR_INVALID_ARGUMENT, "slab contexts accept field uploads only right after sph_upload");
     const uint32_t n = (uint32_t)c->n;
     c->hdr_ahead = false;   // the header computed at the end of the last step no longer describes the state
     if (bytes != (uint64_t)n * r.elem) return c->fail(SPH_ERR_INVALID_ARGUMENT, "field %d: size mismatch", field);
     if (n == 0) return SPH_OK;
     hipStream_t s = c->stream;
+    if (c->dist.on && c->dist.have_flags) {
+        // a slab context behind a step: the rows are the OWNED particles in download order, the arrays also hold the ghosts (whose
+        // values stay: they are refreshed from their owners whenever something reads them)
+        const uint32_t nt = c->dist.n_tot;
+        std::vector<uint8_t> flags(nt ? nt : 1);
+        HIPCHK(c, hipMemcpy(flags.data(), c->dist.owned.p, nt, hipMemcpyDeviceToHost));
+        std::vector<uint32_t> slots;
+        slots.reserve(n);
+        for (uint32_t i = 0; i < nt; i++)
+            if (flags[i]) slots.push_back(i);
+        if (slots.size() != n) return c->fail(SPH_ERR_DEVICE, "owned-particle count mismatch");
+        TmpBuf d_slots;
+        HIPCHK(c, d_slots.ensure((size_t)n * 4));
+        HIPCHK(c, hipMemcpyAsync(d_slots.p, slots.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
+        HIPCHK(c, hipMemcpyAsync(c->scratch.p, src, bytes, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_rows_to_slots, dim3((n + 255) / 256), dim3(256), 0, s, n, r.kind, d_slots.as<uint32_t>(), (const void*)c->scratch.p, (void*)r.src);
+        HIPCHK(c, hipStreamSynchronize(s));
+        return SPH_OK;
+    }
     HIPCHK(c, hipMemcpyAsync(c->scratch.p, src, bytes, hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(k_from_host_order, dim3((n + 255) / 256), dim3(256), 0, s, n, r.kind,
                        c->dist.on ? (const uint32_t*)nullptr : c->orig[c->cur].as<uint32_t>(), (const void*)c->scratch.p, (void*)r.src);

@@ -32,6 +32,9 @@ struct Comm {
     virtual int allreduce_min_f32(Group& G, std::vector<std::vector<float>>& rows) = 0;
     virtual int allreduce_max_i32(Group& G, std::vector<int>& vals) = 0;
     virtual int allreduce_sum_u32(Group& G, std::vector<std::vector<uint32_t>>& rows) = 0;   // element-wise, REBALANCE_BINS words
+    // the same over `n` words of DEVICE memory per member (the adaptivity apply's global child counts, sph_adapt.hip); default: through
+    // the host, in chunks of what allreduce_sum_u32 takes -- a correctness path; RCCL reduces in place
+    virtual int allreduce_sum_u32_dev(Group& G, std::vector<uint32_t*>& bufs, size_t n);
     // every member learns the (to-left, to-right) counts its x-neighbours are about to send it; `status` (optional): this
     // process's status of the phase, replaced by the maximum over ALL ranks in the same round trip
     virtual int neighbour_counts(Group& G, const std::vector<uint32_t>& to_left, const std::vector<uint32_t>& to_right,

@@ -75,6 +75,29 @@ static void debug_comm_delay(sph_ctx* c)
     if (us > 0) hipLaunchKernelGGL(k_spin_us, dim3(1), dim3(1), 0, c->stream, (uint32_t)us);
 }
 
+int Comm::allreduce_sum_u32_dev(Group& G, std::vector<uint32_t*>& bufs, size_t n)
+{
+    const size_t CH = 4096;   // (the shared-memory transport's and the RCCL staging's limit per call)
+    std::vector<std::vector<uint32_t>> rows(G.m.size(), std::vector<uint32_t>(CH));
+    for (size_t o = 0; o < n; o += CH) {
+        const size_t len = std::min(CH, n - o);
+        for (size_t i = 0; i < G.m.size(); i++) {
+            sph_ctx* c = G.m[i];
+            HIPCHK(c, hipSetDevice(c->device));
+            rows[i].assign(CH, 0u);
+            HIPCHK(c, hipMemcpy(rows[i].data(), bufs[i] + o, len * 4, hipMemcpyDeviceToHost));
+        }
+        int rc = allreduce_sum_u32(G, rows);
+        if (rc) return rc;
+        for (size_t i = 0; i < G.m.size(); i++) {
+            sph_ctx* c = G.m[i];
+            HIPCHK(c, hipSetDevice(c->device));
+            HIPCHK(c, hipMemcpy(bufs[i] + o, rows[i].data(), len * 4, hipMemcpyHostToDevice));
+        }
+    }
+    return SPH_OK;
+}
+
 // ---- loopback: all ranks are contexts of this process ---------------------------------------------
 struct LocalComm : Comm {
     bool host_collectives_wait() const override { return false; }   // plain host arithmetic on values the caller already has
@@ -299,10 +322,18 @@ struct RcclComm : Comm {
     {
         sph_ctx* c = G.m[0];
         ncclComm_t nc = (ncclComm_t)c->dist.nccl;
+        HIPCHK(c, c->dist.hist.ensure(rows[0].size() * 4));
         void* d = c->dist.hist.p;   // the histogram's own device buffer is the staging area
         HIPCHK(c, hipMemcpyAsync(d, rows[0].data(), rows[0].size() * 4, hipMemcpyHostToDevice, c->stream));
         NCCLCHK(c, ncclAllReduce(d, d, rows[0].size(), ncclUint32, ncclSum, nc, c->stream));
         HIPCHK(c, hipMemcpyAsync(rows[0].data(), d, rows[0].size() * 4, hipMemcpyDeviceToHost, c->stream));
+        return wait_stream(c);
+    }
+    int allreduce_sum_u32_dev(Group& G, std::vector<uint32_t*>& bufs, size_t n) override
+    {
+        sph_ctx* c = G.m[0];
+        c->dist.stat_allreduces++;
+        NCCLCHK(c, ncclAllReduce(bufs[0], bufs[0], n, ncclUint32, ncclSum, (ncclComm_t)c->dist.nccl, c->stream));
         return wait_stream(c);
     }
     int neighbour_counts(Group& G, const std::vector<uint32_t>& tl, const std::vector<uint32_t>& tr, std::vector<uint32_t>& fl,

@@ -237,6 +237,143 @@ def group_single_step_adaptivity(lib: ffi.SphLibrary, contexts: Sequence[ffi.Con
     return info
 
 
+def _decide_on_gathered(lib, kind: str, g: dict, lists, P, dt: float):
+    """find_share_partner_sequential / find_merge_partner_sequential over the WHOLE vector (fields in global index order)"""
+    from .adaptivity import find_partners_native
+    return find_partners_native(lib, kind, g["particle_size_class"], g["mass"], g["level_estimation"], g["position"], g["h2"], lists[0], lists[1], P, dt)
+
+
+def group_single_step_adaptivity_on_slabs(lib: ffi.SphLibrary, contexts: Sequence[ffi.Context], P, dt: float, step_number: int, log=None) -> dict:
+    """single_step_adaptivity (simulation.rs:2732-2796) for the ranks of a slab group that have just stepped, WITHOUT moving the
+    particles: the DECISIONS are taken where the reference takes them -- sequentially over the whole vector, here on the host over
+    the fields the searches read (size class, mass, level, position, h2: 21 B per particle) and the step's neighbour lists, gathered
+    by global id -- and applied by every rank to its own slab (sph_group_adapt: the slab form of share / merge / split).  Same
+    arithmetic, same indices as on one context; nothing is re-uploaded.  (Every context needs its split patterns:
+    Context.set_split_patterns.)"""
+    from .adaptivity import adapt_params
+    if P.support_length_estimation != "FromMass":
+        raise ValueError("group_single_step_adaptivity_on_slabs: support_length_estimation must be FromMass")
+    p, ap = P.to_ffi(), adapt_params(P, dt)
+    ids = [c.download("particle_id") for c in contexts]
+    n = int(sum(len(i) for i in ids))
+    info = {"n_before": n, "shares": 0, "merges": 0, "splits": 0}
+    off_g, idx_g = assemble_lists(ids, [c.download_neighbors() for c in contexts], n)   # the step's lists, kept across the passes like self.neighs
+    if off_g[-1] >= 2 ** 32:
+        raise ValueError(f"adaptive step of a slab decomposition: {int(off_g[-1])} neighbour-list entries do not fit the 32-bit CSR offsets of the partner search")
+    lists = (off_g.astype(np.uint32), idx_g)
+    total_mass1 = float(sum(c.download("mass").sum(dtype=np.float64) for c in contexts))
+
+    def gathered():
+        for c in contexts:
+            c.classify(p)
+        return {f: gather_by_id(contexts, f, n) for f in ("particle_size_class", "mass", "level_estimation", "position", "h2")}
+
+    if P.sharing:
+        mp, mc = _decide_on_gathered(lib, "share", gathered(), lists, P, dt)
+        info["shares"] = int(mc.sum())
+        if log:
+            log(f"SEQUENTIAL SHARE {info['shares']} shares")
+        ffi.group_adapt(contexts, "share", p, ap, mp, mc)
+    if step_number % 2 == 0:
+        if P.merging:
+            mp, mc = _decide_on_gathered(lib, "merge", gathered(), lists, P, dt)
+            info["merges"] = int(mc.sum())
+            if log:
+                log(f"SEQUENTIAL MERGE {info['merges']} merges")
+            ffi.group_adapt(contexts, "merge", p, ap, mp, mc)
+    elif P.splitting:
+        for c in contexts:
+            c.classify(p)
+        ffi.group_adapt(contexts, "split", p, ap)
+        info["splits"] = int(sum(c.n for c in contexts)) - n
+    total_mass2 = float(sum(c.download("mass").sum(dtype=np.float64) for c in contexts))
+    if not abs(total_mass1 - total_mass2) <= 0.005:             # assert_ft_approx_eq(total_mass1, total_mass2, 0.005, "mass sum"), in f64 (adaptivity.py)
+        raise AssertionError(f"mass sum: {total_mass1} vs {total_mass2}")
+    info["n_after"] = int(sum(c.n for c in contexts))
+    return info
+
+
+def rank_single_step_adaptivity_on_slabs(ctx: ffi.Context, P, dt: float, step_number: int, root: int = 0) -> dict:
+    """The same with ONE PROCESS PER RANK (the RCCL / shared-memory / thread transports): every rank sends `root` the fields the
+    partner searches read and its exported neighbour lists through the launcher's process group, `root` decides over the whole
+    vector and broadcasts merge_partner / merge_counter (6 B per particle), every rank applies them to its own slab (the slab form
+    of sph_share_particles / sph_merge_particles / sph_split_particles: collective calls through the context's own transport).
+    Every rank calls this after the same sph_step; a failure on the root is re-raised on every rank."""
+    import torch.distributed as dist
+    from .adaptivity import adapt_params
+    if P.support_length_estimation != "FromMass":
+        raise ValueError("rank_single_step_adaptivity_on_slabs: support_length_estimation must be FromMass")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    p, ap = P.to_ffi(), adapt_params(P, dt)
+    lists_mine = ctx.download_neighbors()
+    ids_mine = ctx.download("particle_id")
+    state = {"lists": None, "n": 0}
+
+    def decide(kind):
+        """-> (merge_partner, merge_counter) of the whole vector on every rank"""
+        ctx.classify(p)
+        mine = {f: ctx.download(f) for f in ("particle_size_class", "mass", "level_estimation", "position", "h2")}
+        mine["particle_id"] = ids_mine
+        if state["lists"] is None:
+            mine["lists"] = lists_mine
+        parts = [None] * world if rank == root else None
+        dist.gather_object(mine, parts, dst=root)
+        out = [None]
+        if rank == root:
+            try:
+                n = int(sum(len(q["particle_id"]) for q in parts))
+                if state["lists"] is None:
+                    off_g, idx_g = assemble_lists([q["particle_id"] for q in parts], [q["lists"] for q in parts], n)
+                    if off_g[-1] >= 2 ** 32:
+                        raise ValueError(f"{int(off_g[-1])} neighbour-list entries do not fit the 32-bit CSR offsets of the partner search")
+                    state["lists"] = (off_g.astype(np.uint32), idx_g)
+                g = {}
+                for f in ("particle_size_class", "mass", "level_estimation", "position", "h2"):
+                    a = np.zeros((n,) + parts[0][f].shape[1:], parts[0][f].dtype)
+                    for q in parts:
+                        a[q["particle_id"]] = q[f]
+                    g[f] = a
+                out = [_decide_on_gathered(ctx.lib, kind, g, state["lists"], P, dt)]
+            except Exception as e:  # noqa: BLE001 -- re-raised on every rank below
+                out = [(None, (type(e).__name__, e.status if isinstance(e, ffi.SphError) else None, str(e)))]
+        else:
+            state["lists"] = True   # (only the root keeps them)
+        dist.broadcast_object_list(out, src=root)
+        if out[0][0] is None:
+            kind_, code, msg = out[0][1]
+            if code is not None:
+                raise ffi.SphError(code, f"adaptive step failed on rank {root}: {msg}")
+            raise RuntimeError(f"adaptive step failed on rank {root} ({kind_}): {msg}")
+        return out[0]
+
+    def total(v):
+        t = [None] * world
+        dist.all_gather_object(t, v)
+        return sum(t)
+
+    n_before = total(ctx.n)
+    info = {"n_before": n_before, "shares": 0, "merges": 0, "splits": 0}
+    m1 = total(float(ctx.download("mass").sum(dtype=np.float64)))
+    if P.sharing:
+        mp, mc = decide("share")
+        info["shares"] = int(mc.sum())
+        ctx.share_particles(p, ap, mp, mc)
+    if step_number % 2 == 0:
+        if P.merging:
+            mp, mc = decide("merge")
+            info["merges"] = int(mc.sum())
+            ctx.merge_particles(p, ap, mp, mc)
+    elif P.splitting:
+        ctx.classify(p)
+        ctx.split_particles(p, ap)
+    info["n_after"] = total(ctx.n)
+    info["splits"] = max(0, info["n_after"] - n_before) if step_number % 2 == 1 else 0
+    m2 = total(float(ctx.download("mass").sum(dtype=np.float64)))
+    if not abs(m1 - m2) <= 0.005:
+        raise AssertionError(f"mass sum: {m1} vs {m2}")
+    return info
+
+
 def rank_single_step_adaptivity(ctx: ffi.Context, gather: GatherContext, P, dt: float, step_number: int, capacity: int = 0, root: int = 0) -> dict:
     """The same adaptive step with ONE PROCESS PER RANK (the launch bench.py --gpus N and the RCCL / shared-memory transports use):
     every rank hands the fields adaptivity reads and its exported neighbour lists to `root` through the launcher's process group

@@ -150,7 +150,7 @@ class SphError(RuntimeError):
 ABI_SYMBOLS = [
     "create", "destroy", "upload", "upload_field", "download", "download_neighbors", "num_particles", "time",
     "set_time", "step", "classify", "share_particles", "merge_particles", "set_split_patterns", "split_particles", "host_find_partners", "last_error", "grid", "set_boundary_polygon", "apply_edits", "profile_enable", "profile_reset", "profile_get", "profile_event_overhead", "profile_dispatch_bracket", "profile_copy_bandwidth", "profile_list_forms", "set_sweep_variant",
-    "dist_configure", "dist_set_rebalance", "dist_get_cuts", "dist_get_stats", "comm_unique_id", "comm_init", "comm_init_shm", "group_step", "thread_group_create", "thread_group_destroy", "comm_init_threads",
+    "dist_configure", "dist_set_rebalance", "dist_get_cuts", "dist_get_stats", "comm_unique_id", "comm_init", "comm_init_shm", "group_step", "group_adapt", "thread_group_create", "thread_group_destroy", "comm_init_threads",
 ]
 
 
@@ -210,6 +210,7 @@ class SphLibrary:
         self.profile_copy_bandwidth = sig("profile_copy_bandwidth", i32, [vp, u64, C.POINTER(C.c_double)], required=False)
         self.profile_list_forms = sig("profile_list_forms", i32, [vp, C.POINTER(SphListForms)], required=False)
         self.set_sweep_variant = sig("set_sweep_variant", i32, [i32], required=False)
+        self.group_adapt = sig("group_adapt", i32, [vp, i32, i32, C.POINTER(SphParams), ap, vp, vp], required=False)
         self.comm_unique_id = sig("comm_unique_id", i32, [C.POINTER(C.c_uint8)], required=False)
         self.comm_init = sig("comm_init", i32, [vp, C.POINTER(C.c_uint8), i32, i32], required=False)
         self.comm_init_shm = sig("comm_init_shm", i32, [vp, C.c_char_p, i32, i32, u64, i32], required=False)
@@ -255,6 +256,7 @@ class Context:
         """`planes`: the (dir_x, dir_y, delta) planes of an AnalyticOverestimate box, or a scene.BoundaryPolygon (the single
         Sdf2D of AnalyticUnderestimate)."""
         self.lib = lib
+        self.is_slab = False
         polygon = getattr(planes, "points", None)
         planes = [] if polygon is not None else list(planes)
         arr = (SphPlane * max(1, len(planes)))()
@@ -364,7 +366,8 @@ class Context:
     def _partner_arrays(self, merge_partner, merge_counter):
         mp = np.ascontiguousarray(merge_partner, dtype=np.uint32)
         mc = np.ascontiguousarray(merge_counter, dtype=np.uint16)
-        if mp.shape != (self.n,) or mc.shape != (self.n,):
+        # (a slab context takes the arrays of the WHOLE vector, indexed by global particle id: its own count says nothing about their length)
+        if mp.shape != mc.shape or mp.ndim != 1 or (not self.is_slab and mp.shape != (self.n,)):
             raise ValueError("merge_partner / merge_counter must have one entry per particle")
         return mp, mc
 
@@ -440,6 +443,7 @@ class Context:
 
     def dist_configure(self, rank: int, n_ranks: int, cut_lo: float, cut_hi: float):
         self._check(self.lib.dist_configure(self.handle, int(rank), int(n_ranks), float(cut_lo), float(cut_hi)))
+        self.is_slab = n_ranks > 1
 
     def dist_set_rebalance(self, every_n_steps: int):
         self._check(self.lib.dist_set_rebalance(self.handle, int(every_n_steps)))
@@ -482,3 +486,18 @@ def group_step(contexts, params: SphParams):
         msgs = [c.lib.last_error(c.handle) for c in contexts]
         raise SphError(rc, " | ".join(m.decode(errors="replace") for m in msgs if m))
     return list(stats)
+
+
+def group_adapt(contexts, op: str, params: SphParams, ap, merge_partner=None, merge_counter=None):
+    """share / merge / split on the k slab contexts of this process (sph_group_adapt): `merge_partner` / `merge_counter` are the arrays
+    of the WHOLE vector, indexed by global particle id.  The contexts' particle counts change with merge and split."""
+    lib = contexts[0].lib
+    k = len(contexts)
+    handles = (C.c_void_p * k)(*[c.handle for c in contexts])
+    code = {"share": 0, "merge": 1, "split": 2}[op]
+    mp = np.ascontiguousarray(merge_partner, np.uint32) if merge_partner is not None else None
+    mc = np.ascontiguousarray(merge_counter, np.uint16) if merge_counter is not None else None
+    rc = lib.group_adapt(handles, k, code, C.byref(params), C.byref(ap), mp.ctypes.data if mp is not None else None, mc.ctypes.data if mc is not None else None)
+    if rc != 0:
+        msgs = [c.lib.last_error(c.handle) for c in contexts]
+        raise SphError(rc, " | ".join(m.decode(errors="replace") for m in msgs if m))

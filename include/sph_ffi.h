@@ -263,7 +263,15 @@ int  sph_apply_edits(sph_ctx* ctx, const sph_edit_op* ops, uint64_t n_ops);
  * does and hands the two arrays over.  The DATA never leaves the device: the gather-form mass / momentum transfers, the
  * swap-to-end deletion order and the appended split children are computed there, with the Vec semantics of the reference
  * (host indices after the call are the reference's indices).  Afterwards per-step outputs and neighbour lists belong to the old
- * vector, as after sph_apply_edits.  Not available on slab contexts (SPH_ERR_UNSUPPORTED). */
+ * vector, as after sph_apply_edits.
+ * SLAB CONTEXTS (one process per GPU, or the k contexts of sph_group_step through sph_group_adapt): the same three calls, collective --
+ * every rank calls them in the same order, right behind a step.  The particles stay on their ranks.  merge_partner / merge_counter
+ * are then the arrays of the WHOLE vector, indexed by global particle id (SPH_F_PARTICLE_ID = the reference's Vec index), the same on
+ * every rank: the decisions are taken in one place, as the reference takes them.  A receiver reads its donor from the step's ghost
+ * layer (a donor is a neighbour of its receiver; the ghosts' records are refreshed from their owners first), merge_particles' new
+ * indices are derived from the two arrays by every rank alike, split_particles' child counts are all-reduced over the ids; afterwards
+ * a rank holds owned particles only, their ids = the reference's indices after the call (SPH_ERR_INVALID_ARGUMENT if a donor is not
+ * among the receiver's owned particles and ghosts, or if no step came before). */
 typedef struct sph_adapt_params {
     float    dt;                          /* the step's dt (single_step, simulation.rs:1973-1978) */
     float    max_mass_transfer_sharing;   /* dropped_mass_sharing, particle_sharing.rs:242-253 */
@@ -437,6 +445,10 @@ int  sph_dist_get_stats(sph_ctx* ctx, sph_dist_stats* out, int reset);
 int  sph_comm_unique_id(uint8_t id_out[128]);
 int  sph_comm_init(sph_ctx* ctx, const uint8_t id[128], int rank, int n_ranks);
 int  sph_group_step(sph_ctx** ctxs, int n, const sph_params* params, sph_step_stats* outs);
+/* sph_share_particles (op 0) / sph_merge_particles (1) / sph_split_particles (2) for the k contexts sph_group_step steps, in their
+ * slab form (see "adaptivity data path" above): merge_partner / merge_counter by global particle id, NULL for op 2 */
+int  sph_group_adapt(sph_ctx** ctxs, int n, int op, const sph_params* params, const sph_adapt_params* ap, const uint32_t* merge_partner,
+                     const uint16_t* merge_counter);
 /* Verification transport for the PER-RANK driver code: all ranks in this process, one HOST THREAD per rank, each calling sph_step
  * on its own slab context -- a group of one member, its own view of the counts, its own branches, exactly as a rank of the RCCL
  * transport runs -- with the collectives as rendezvous in host memory.  What would hang RCCL is an error here: a collective

@@ -369,3 +369,182 @@ def test_config4_ratio_stress_4m_adaptive_steps_on_two_slabs(product_lib):
     x = D.gather_by_id(grp, "position", n)
     assert np.isfinite(x).all() and np.abs(x).max() < 1.0
     ffi.group_step(grp, p)                                   # and the re-uploaded slabs step
+
+
+def _fields_by_id(grp, n):
+    from adaptive_sph_amd import distributed as D
+    return {f: D.gather_by_id(grp, f, n) for f in ("mass", "position", "velocity", "h2_next", "level_estimation", "level_old", "particle_size_class")}
+
+
+@pytest.mark.parametrize("transport", ["loopback", "threads"])
+def test_slab_form_of_the_apply_equals_the_gather_path(product_lib, transport):
+    """share / merge / split applied ON the slabs (sph_group_adapt; per rank: the slab form of sph_share_particles / sph_merge_particles
+    / sph_split_particles through the context's own transport) against the round-3 path that gathers every particle to ONE context,
+    applies there and re-uploads: BASELINE configs[0]'s adaptive run on two ranks.  Up to adaptive step t - 1 both groups take the
+    gather path (identical states); at step t one of them applies on its slabs: same decisions (the same host code on the same
+    gathered fields), and then the same particle under the same id with the same bits in every field adaptivity writes."""
+    from adaptive_sph_amd import distributed as D
+    from concurrent.futures import ThreadPoolExecutor
+    P = default_params()
+    scn = sc.SceneConfig.from_yaml(str(REPO / "tests" / "golden" / "default-scene.yaml"))
+    sp = A.SplitPatterns.load_from_file(PATTERNS)
+    pos, mass, vel = sc.init_particles(scn)
+    planes = sc.boundary_planes(scn.boundary, P.init_boundary_handler)
+    p = P.to_ffi()
+    k = 2      # (the 1035-particle scene is too narrow for a rank with two ghost layers)
+    seen = {"shares": 0, "merges": 0, "splits": 0}
+    for t in (1, 2, 3, 4, 6):
+        a = D.make_loopback_group(product_lib, pos, mass, vel, planes, k)
+        thr = D.ThreadedGroup(product_lib, pos, mass, vel, planes, k) if transport == "threads" else None
+        b = thr.contexts if thr else D.make_loopback_group(product_lib, pos, mass, vel, planes, k)
+        for c in b:
+            c.set_split_patterns(sp.patterns)
+        step_b = (lambda: thr.step(p)) if thr else (lambda: ffi.group_step(b, p))
+        try:
+            for s in range(1, t + 1):
+                sa, sb = ffi.group_step(a, p), step_b()
+                dt, num = float(sa[0].dt), int(sa[0].step_number)
+                assert float(sb[0].dt) == dt
+                ia = D.group_single_step_adaptivity(product_lib, a, planes, P, dt, num, split_patterns=sp, capacity=120000)
+                if s < t:
+                    # (a ThreadedGroup's contexts are ordinary slab contexts: the gather path re-uploads them all the same)
+                    ib = D.group_single_step_adaptivity(product_lib, b, planes, P, dt, num, split_patterns=sp, capacity=120000)
+                    for c in b:
+                        c.set_split_patterns(sp.patterns)
+                elif thr is None:
+                    ib = D.group_single_step_adaptivity_on_slabs(product_lib, b, P, dt, num)
+                else:
+                    # every rank calls the per-rank entry points from its own thread; the decisions are taken once, here
+                    ap = A.adapt_params(P, dt)
+                    ids = [c.download("particle_id") for c in b]
+                    n = int(sum(len(i) for i in ids))
+                    off, idx = D.assemble_lists(ids, [c.download_neighbors() for c in b], n)
+                    lists = (off.astype(np.uint32), idx)
+                    ib = {"shares": 0, "merges": 0, "splits": 0}
+
+                    def all_ranks(fn):
+                        with ThreadPoolExecutor(k) as pool:
+                            for f in [pool.submit(fn, c) for c in b]:
+                                f.result()
+
+                    def gathered():
+                        all_ranks(lambda c: c.classify(p))
+                        return {f: D.gather_by_id(b, f, n) for f in ("particle_size_class", "mass", "level_estimation", "position", "h2")}
+                    if P.sharing:
+                        mp, mc = D._decide_on_gathered(product_lib, "share", gathered(), lists, P, dt)
+                        ib["shares"] = int(mc.sum())
+                        all_ranks(lambda c: c.share_particles(p, ap, mp, mc))
+                    if num % 2 == 0:
+                        mp, mc = D._decide_on_gathered(product_lib, "merge", gathered(), lists, P, dt)
+                        ib["merges"] = int(mc.sum())
+                        all_ranks(lambda c: c.merge_particles(p, ap, mp, mc))
+                    else:
+                        all_ranks(lambda c: c.classify(p))
+                        all_ranks(lambda c: c.split_particles(p, ap))
+                        ib["splits"] = int(sum(c.n for c in b)) - n
+                assert (ia["shares"], ia["merges"], ia["splits"]) == (ib["shares"], ib["merges"], ib["splits"]), (t, s, ia, ib)
+            for key in seen:
+                seen[key] += ib[key]
+            n = sum(c.n for c in a)
+            assert n == sum(c.n for c in b)
+            ids = np.concatenate([c.download("particle_id") for c in b])
+            assert np.array_equal(np.sort(ids), np.arange(n))              # the ids are the reference's indices 0 .. n-1 again
+            fa, fb = _fields_by_id(a, n), _fields_by_id(b, n)
+            for f in fa:
+                assert np.array_equal(fa[f], fb[f], equal_nan=f == "level_estimation"), (t, f)
+            step_b()                                                       # and the slabs step with what the apply left them
+        finally:
+            for c in a:
+                c.close()
+            if thr:
+                thr.close()
+            else:
+                for c in b:
+                    c.close()
+    assert seen["splits"] > 0 and seen["merges"] + seen["shares"] > 0, seen
+
+
+def test_config4_adaptive_steps_with_the_oracles_decisions_on_eight_slabs(product_lib, oracle_lib):
+    """BASELINE configs[4] as BASELINE.json states it: the 4 004 343-particle 50:1 scene on EIGHT x-slabs (loopback transport: the
+    driver code the RCCL transport runs), adaptive half included -- the test above this file's single-context one, with the device
+    side a slab group that applies share / split / merge on its slabs (sph_group_adapt).  Decisions from the ORACLE's state, applied
+    to both sides; fields compared by global id."""
+    from adaptive_sph_amd import distributed as D
+    scene_f, params_f, _ = WORKLOADS["ratio_stress_4m"]
+    scn = scene_f()
+    r_fine = float(np.sqrt(np.float32(0.0004385) ** 2 * 0.93 / np.pi))
+    P = params_f(level_estimation_method="EmptyAngle", merging=True, sharing=True, splitting=True, particle_radius_fine=r_fine,
+                 particle_radius_base=50 * r_fine, maximum_surface_distance=0.3, max_iters=3, iisph_max_avg_density_error=0.0)
+    sp = A.SplitPatterns.load_from_file(PATTERNS)
+    pos, mass, vel = sc.init_particles(scn)
+    planes = sc.boundary_planes(scn.boundary, P.init_boundary_handler)
+    o = ffi.Context(oracle_lib, 6000000, planes)
+    o.upload(mass, pos, vel)
+    o.set_split_patterns(sp.patterns)
+    grp = D.make_loopback_group(product_lib, pos, mass, vel, planes, 8)
+    for c in grp:
+        c.set_split_patterns(sp.patterns)
+    p = P.to_ffi()
+    m0 = float(mass.sum(dtype=np.float64))
+
+    def to_ranks(field, values):
+        for c in grp:
+            c.upload_field(field, values[c.download("particle_id")])
+
+    def decide(kind, dt, lists):
+        o.classify(p)
+        cls = o.download("particle_size_class")
+        to_ranks("particle_size_class", cls)
+        if kind == "split":
+            to_ranks("level_estimation", o.download("level_estimation"))
+            return None, None
+        return A.find_partners_native(product_lib, kind, cls, o.download("mass"), o.download("level_estimation"), o.download("position"),
+                                      o.download("h2"), *lists, P, dt)
+
+    def same(tol):
+        n = o.n
+        assert sum(c.n for c in grp) == n
+        ids = np.concatenate([c.download("particle_id") for c in grp])
+        assert np.array_equal(np.sort(ids), np.arange(n))
+        for f in ("mass", "position", "velocity", "h2_next"):
+            assert rel_err(D.gather_by_id(grp, f, n), o.download(f)) < tol, f
+        a, b = D.gather_by_id(grp, "level_estimation", n), o.download("level_estimation")
+        assert np.array_equal(np.isnan(a), np.isnan(b))
+        assert np.nanmax(np.abs(a - b)) <= 1e-4 * max(np.nanmax(np.abs(b)), 1e-30)
+
+    # ---- step 1 (odd): share, then split
+    sg, so = ffi.group_step(grp, p), o.step(p)
+    assert abs(sg[0].dt - so.dt) <= 1e-6 * so.dt and int(so.step_number) == 1
+    dt = float(so.dt)
+    ap = A.adapt_params(P, dt)
+    lists = o.download_neighbors()
+    mp, mc = decide("share", dt, lists)
+    o.share_particles(p, ap, mp, mc)
+    ffi.group_adapt(grp, "share", p, ap, mp, mc)
+    same(1e-5)
+    decide("split", dt, lists)
+    n0 = o.n
+    o.split_particles(p, ap)
+    ffi.group_adapt(grp, "split", p, ap)
+    assert o.n > n0
+    same(1e-5)
+    # ---- step 2 (even): share, then merge -- on the vector the first adaptive step left behind
+    sg, so = ffi.group_step(grp, p), o.step(p)
+    assert abs(sg[0].dt - so.dt) <= 1e-5 * so.dt and int(so.step_number) == 2
+    dt = float(so.dt)
+    ap = A.adapt_params(P, dt)
+    lists = o.download_neighbors()
+    mp, mc = decide("share", dt, lists)
+    o.share_particles(p, ap, mp, mc)
+    ffi.group_adapt(grp, "share", p, ap, mp, mc)
+    same(1e-4)
+    mp, mc = decide("merge", dt, lists)
+    n1, n_merge = o.n, int(mc.sum())
+    o.merge_particles(p, ap, mp, mc)
+    ffi.group_adapt(grp, "merge", p, ap, mp, mc)
+    assert o.n < n1 and n_merge > 1000
+    same(1e-4)
+    assert abs(float(sum(c.download("mass").sum(dtype=np.float64) for c in grp)) - m0) < 1e-4 * m0
+    sg, so = ffi.group_step(grp, p), o.step(p)                # and both edited vectors step
+    assert abs(sg[0].dt - so.dt) <= 1e-4 * so.dt
+    assert rel_err(D.gather_by_id(grp, "density", o.n), o.download("density")) < 2e-3
