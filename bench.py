@@ -347,13 +347,13 @@ def main():
             strong_8m["sweep_a_split"] = {k: v for k, v in run_8m("1").items() if k in ("value", "ms_per_step", "comm_rank0")}
 
     # ---- BASELINE configs[4] on the same ranks: the ratio-stress scene (4 004 343 particles at 50:1 radii, IISPH, Sdf2D box, EmptyAngle
-    # level estimation) -- its step path, and a few calls of single_step WITH sharing / merging / splitting, the adaptive half through
-    # the launcher (distributed.rank_single_step_adaptivity: gather to rank 0, decisions + device-side apply there, scatter back).
-    # The ghost layer is a multiple of the LARGEST smoothing length, so this scene's 0.55-wide blocks stand at most TWO slabs: beyond
-    # that every rank returns the library's refusal (all-reduced values: the same branch everywhere), which the line then carries.
+    # level estimation) -- its step path, and a few calls of single_step WITH sharing / merging / splitting, the adaptive half in its
+    # slab form (distributed.rank_single_step_adaptivity_on_slabs: the decisions on rank 0's host over the gathered 21 B per particle
+    # and the lists, merge_partner / merge_counter broadcast, every rank applies to its own slab; the particles never leave their GPU).
+    # The ghost layer of a cut is as wide as the largest smoothing length NEAR it asks for, so the fine block's slices stand on 8 ranks.
     config4 = None
     if distributed and not args.no_8m and wl == "dam_break_1m":
-        from adaptive_sph_amd.distributed import GatherContext, rank_single_step_adaptivity
+        from adaptive_sph_amd.distributed import rank_single_step_adaptivity_on_slabs
         s4, p4f, d4 = WORKLOADS["ratio_stress_4m"]
         r_fine = float(np.sqrt(np.float32(0.0004385) ** 2 * 0.93 / np.pi))
         P4 = p4f(level_estimation_method="EmptyAngle", merging=True, sharing=True, splitting=True, particle_radius_fine=r_fine,
@@ -371,20 +371,18 @@ def main():
             pat = REPO / "tests" / "golden" / "split-patterns.yaml"
             sp4 = SplitPatterns.load_from_file(pat) if pat.exists() else None
             if sp4 is not None:
-                gc = GatherContext(plib, sc.boundary_planes(scn4.boundary, P4.init_boundary_handler), local_rank, sp4) if rank == 0 else None
+                c4.set_split_patterns(sp4.patterns)
                 barrier()
                 t0 = time.perf_counter()
                 ev = {"shares": 0, "merges": 0, "splits": 0}
                 for _ in range(2):
                     st = c4.step(P4.to_ffi())
-                    info = rank_single_step_adaptivity(c4, gc, P4, float(st.dt), int(st.step_number), capacity=6000000)
+                    info = rank_single_step_adaptivity_on_slabs(c4, P4, float(st.dt), int(st.step_number))
                     for k in ev:
                         ev[k] += info[k]
                 barrier()
                 config4["single_step_with_adaptivity"] = {"steps": 2, "ms_per_step": (time.perf_counter() - t0) * 1e3 / 2, "events": ev,
-                                                          "particles_after": info["n_after"], "note": "rank 0's clock; gather / scatter through the launcher's process group"}
-                if gc is not None:
-                    gc.close()
+                                                          "particles_after": info["n_after"], "note": "rank 0's clock; decisions on rank 0's host, apply on the slabs"}
         except (ffi.SphError, RuntimeError) as e:   # a refusal taken on all-reduced values, or a failure of the adaptive step's root that
             config4["refused"] = str(e)[:300]         # rank_single_step_adaptivity re-raises on every rank: every rank is here
         finally:

@@ -32,14 +32,20 @@ def main():
     pos, mass, vel = sc.init_particles(scn)
     planes = sc.boundary_planes(scn.boundary, P.init_boundary_handler)
     ctx = D.make_slab_context(lib, pos, mass, vel, planes, rank, world, local, transport)
-    gather = D.GatherContext(lib, planes, local, sp) if rank == 0 else None
+    on_slabs = os.environ.get("MP_ADAPTIVE_ON_SLABS") == "1"   # the slab form of the apply (the particles stay on their ranks) instead of the gather to rank 0
+    ctx.set_split_patterns(sp.patterns)
+    gather = D.GatherContext(lib, planes, local, sp) if rank == 0 and not on_slabs else None
     single = init_fluid_sim(P, scn, lib=lib, split_patterns=sp, n_capacity=120000, device_id=local) if rank == 0 else None
     p = P.to_ffi()
     m0 = float(mass.sum(dtype=np.float64))
     counts, events = [[], []], {"shares": 0, "merges": 0, "splits": 0}
     for s in range(12):
         st = ctx.step(p)
-        info = D.rank_single_step_adaptivity(ctx, gather, P, float(st.dt), int(st.step_number), capacity=120000)
+        if on_slabs:
+            info = D.rank_single_step_adaptivity_on_slabs(ctx, P, float(st.dt), int(st.step_number))
+        else:
+            info = D.rank_single_step_adaptivity(ctx, gather, P, float(st.dt), int(st.step_number), capacity=120000)
+            ctx.set_split_patterns(sp.patterns)
         n_mine = torch.tensor([ctx.n], dtype=torch.int64)
         dist.all_reduce(n_mine.cuda() if transport == "rccl" else n_mine)
         assert info["n_after"] > 0
@@ -63,8 +69,9 @@ def main():
         assert abs(m1 - m0) < 0.005 * 12
         x = np.concatenate([q["position"] for q in parts])
         assert np.isfinite(x).all() and np.abs(x).max() < 1.05
-        print(f"MP_ADAPTIVE OK world={world} transport={transport} counts={counts[1]}", flush=True)
-        gather.close()
+        print(f"MP_ADAPTIVE OK world={world} transport={transport} on_slabs={int(on_slabs)} counts={counts[1]}", flush=True)
+        if gather is not None:
+            gather.close()
         single.close()
     dist.barrier()
     ctx.close()

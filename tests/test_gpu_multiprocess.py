@@ -29,13 +29,18 @@ def test_ranks_as_processes_reproduce_the_single_context(world):
     assert r.returncode == 0 and f"MP_CHECK OK world={world}" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
-def test_adaptive_steps_with_one_process_per_rank():
-    """single_step = sph_step + single_step_adaptivity on a slab decomposition whose ranks are PROCESSES: the gather / decide / apply /
-    scatter of distributed.rank_single_step_adaptivity through the launcher's process group, against the single context."""
+@pytest.mark.parametrize("on_slabs", [0, 1])
+def test_adaptive_steps_with_one_process_per_rank(on_slabs):
+    """single_step = sph_step + single_step_adaptivity on a slab decomposition whose ranks are PROCESSES, against the single context:
+    on_slabs = 1 the slab form of the apply (distributed.rank_single_step_adaptivity_on_slabs: decisions on the root, merge_partner /
+    merge_counter broadcast, every rank's sph_share / merge / split_particles collective through its own transport); 0 the gather /
+    decide / apply / scatter of round 3 (rank_single_step_adaptivity)."""
+    env = _env()
+    env["MP_ADAPTIVE_ON_SLABS"] = str(on_slabs)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29661", str(REPO / "tests" / "mp_adaptive_check.py")],
-                       capture_output=True, text=True, timeout=600, env=_env(), cwd=str(REPO))
-    assert r.returncode == 0 and "MP_ADAPTIVE OK world=2" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+                        "--master-port", str(29661 + on_slabs), str(REPO / "tests" / "mp_adaptive_check.py")],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=str(REPO))
+    assert r.returncode == 0 and f"MP_ADAPTIVE OK world=2" in r.stdout and f"on_slabs={on_slabs}" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
 def test_bench_starts_its_own_ranks_and_prints_the_schema():
