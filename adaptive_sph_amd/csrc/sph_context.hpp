@@ -163,6 +163,7 @@ struct sph_ctx {
         uint32_t gtot_seq = 0;
         bool ghosts_ok = true;       // false: this rank ran out of room for its ghost layer (the step goes on without it and ends in SPH_ERR_CAPACITY on every rank)
         void* tgroup = nullptr;      // ThreadGroup*: in-process transport with one host thread per rank (sph_comm_init_threads)
+        void* ipc = nullptr;         // IpcState*: peer-mapped push transport on top of the shared-memory one (sph_comm_init_ipc)
         void* shm = nullptr;         // ShmSegment*: processes of one node without RCCL (sph_comm_init_shm)
         size_t shm_bytes = 0;
         std::string shm_name;        // non-empty on the rank that created the segment (it unlinks the name)

@@ -16,7 +16,8 @@ struct Group;
 struct Xfer {
     const void* send[2];  // to left, to right
     size_t send_bytes[2];
-    void* recv[2];        // from left, from right
+    void* recv[2];        // from left, from right.  IN: where the caller has room; OUT: where the data IS once the exchange is through
+                          // (a transport may hand back its own buffer -- the peer-mapped inbox the neighbour wrote into -- instead of copying)
     size_t recv_bytes[2];
 };
 

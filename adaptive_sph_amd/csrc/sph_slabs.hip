@@ -526,8 +526,8 @@ int refresh_ghosts(Group& G, std::vector<Member>& M, float* (*sel)(Member&), int
         const uint32_t ng = c->dist.ghosts_ok ? c->dist.n_ghost[0] + c->dist.n_ghost[1] : 0u;   // (no ghost slots: received, dropped)
         for (int f = 0; f < nf && ng; f++)
             hipLaunchKernelGGL(k_unpack_field, dim3((ng + 255) / 256), dim3(256), 0, c->stream, c->dist.ghost_dst.as<uint32_t>(), c->dist.n_ghost[0],
-                               c->dist.n_ghost[1], words, stride, off, c->dist.recv[0].as<float>() + (size_t)f * c->dist.n_ghost[0] * words,
-                               c->dist.recv[1].as<float>() + (size_t)f * c->dist.n_ghost[1] * words, f ? sel2(M[i]) : sel(M[i]));
+                               c->dist.n_ghost[1], words, stride, off, (const float*)x[i].recv[0] + (size_t)f * c->dist.n_ghost[0] * words,
+                               (const float*)x[i].recv[1] + (size_t)f * c->dist.n_ghost[1] * words, f ? sel2(M[i]) : sel(M[i]));
     }
     (void)what;
     return SPH_OK;
@@ -667,7 +667,7 @@ int partition_and_migrate(Group& G, std::vector<Member>& M, std::vector<int>* mo
         for (int side = 0; side < 2; side++)
             if (cnt[side])
                 hipLaunchKernelGGL(k_unpack_migrants, dim3((cnt[side] + 255) / 256), dim3(256), 0, c->stream, base[side], cnt[side],
-                                   d.recv[side].as<float>(), c->pm[c->pcur].as<float4>(), c->vel[k].as<float2>(), c->orig[k].as<uint32_t>(),
+                                   (const float*)x[i].recv[side], c->pm[c->pcur].as<float4>(), c->vel[k].as<float2>(), c->orig[k].as<uint32_t>(),
                                    c->lvl[k].as<float>(), c->lvlold[k].as<float>(), c->h2n[k].as<float>(), c->lam_sum.as<float>(),
                                    c->szc[k].as<uint8_t>());
         c->n = n_stay + cnt[0] + cnt[1];
@@ -872,7 +872,7 @@ int build_ghost_layer(Group& G, std::vector<Member>& M, float base_k, float slac
         for (int side = 0; side < 2; side++)
             if (d.n_ghost[side] && d.ghosts_ok)
                 hipLaunchKernelGGL(k_unpack_ghosts, dim3((d.n_ghost[side] + 255) / 256), dim3(256), 0, c->stream, base[side], d.n_ghost[side],
-                                   d.recv[side].as<float>(), c->pm[c->pcur].as<float4>(), c->vel[k].as<float2>(), c->orig[k].as<uint32_t>(),
+                                   (const float*)x[i].recv[side], c->pm[c->pcur].as<float4>(), c->vel[k].as<float2>(), c->orig[k].as<uint32_t>(),
                                    c->lvl[k].as<float>(), c->lvlold[k].as<float>(), d.ring1_src.as<uint8_t>(), side == 0 ? 0u : d.n_ghost[0],
                                    side == 0 ? d.cut_lo - 2.f * d.hcut[0] : d.cut_hi + 2.f * d.hcut[1], side);
         d.n_tot = d.ghosts_ok ? n + d.n_ghost[0] + d.n_ghost[1] : n;
@@ -1018,7 +1018,7 @@ int slab_refresh_fused(Group& G, std::vector<Member>& M, std::vector<std::vector
                 hipLaunchKernelGGL(k_fill_u32, dim3((cnt + 255) / 256), dim3(256), 0, c->stream, d.halo_idx.as<uint32_t>() + hoff[side], cnt, 0u);
                 continue;
             }
-            hipLaunchKernelGGL(k_unpack_migrants, dim3((cnt + 255) / 256), dim3(256), 0, c->stream, base[side], cnt, d.recv[side].as<float>(),
+            hipLaunchKernelGGL(k_unpack_migrants, dim3((cnt + 255) / 256), dim3(256), 0, c->stream, base[side], cnt, (const float*)x[i].recv[side],
                                c->pm[c->pcur].as<float4>(), c->vel[k].as<float2>(), c->orig[k].as<uint32_t>(), c->lvl[k].as<float>(),
                                c->lvlold[k].as<float>(), c->h2n[k].as<float>(), c->lam_sum.as<float>(), c->szc[k].as<uint8_t>());
             hipLaunchKernelGGL(k_iota_u32, dim3((cnt + 255) / 256), dim3(256), 0, c->stream, d.halo_idx.as<uint32_t>() + hoff[side], cnt, base[side]);
@@ -1056,7 +1056,7 @@ int slab_refresh_fused(Group& G, std::vector<Member>& M, std::vector<std::vector
         for (int side = 0; side < 2; side++)
             if (d.n_ghost[side] && d.ghosts_ok)
                 hipLaunchKernelGGL(k_unpack_ghosts, dim3((d.n_ghost[side] + 255) / 256), dim3(256), 0, c->stream, base[side], d.n_ghost[side],
-                                   d.recv[side].as<float>(), c->pm[c->pcur].as<float4>(), c->vel[k].as<float2>(), c->orig[k].as<uint32_t>(),
+                                   (const float*)x[i].recv[side], c->pm[c->pcur].as<float4>(), c->vel[k].as<float2>(), c->orig[k].as<uint32_t>(),
                                    c->lvl[k].as<float>(), c->lvlold[k].as<float>(), d.ring1_src.as<uint8_t>(), side == 0 ? 0u : d.n_ghost[0],
                                    side == 0 ? d.cut_lo - 2.f * d.hcut[0] : d.cut_hi + 2.f * d.hcut[1], side);
         dbg_sync(c, "fused: ghosts unpacked (this rank)", 1);

@@ -1146,6 +1146,229 @@ struct ShmComm : Comm {
     }
 };
 
+
+// ---- peer-mapped PUSH transport: the ranks of one node as processes, device to device --------
+// Every rank owns one device allocation -- its BOX: an inbox per x-neighbour side (two parities), a table of the ranks' solver totals
+// (two slots x two parities), and the arrival flags -- exported with hipIpcGetMemHandle and mapped by the others
+// (hipIpcOpenMemHandle: over xGMI between GPUs, plain device memory between two ranks of one GPU).  A message is PUSHED: the sender's
+// kernel copies its staging buffer into the receiver's inbox and then stores the message's sequence number into the receiver's flag
+// (system-scope release); the receiver's next kernel spins on its own flag (system-scope acquire) and the kernels behind it read the
+// inbox in place (Xfer::recv is handed back pointing at it).  No collective library launch, no host wait, no copy on the receiving
+// side; per exchange one push kernel and one wait kernel of one workgroup each (multi-block copies for the per-step record messages).
+// Flow control without acknowledgements: a pair of ranks enters every exchange together (the pairing rule the other transports check),
+// so rank A's push k + 2 into the parity push k used follows A's wait for B's signal k + 1, which B issued behind its kernels that
+// read message k.  The totals all-reduce is the same between all ranks: push six doubles into everybody's table, wait for
+// everybody's, add the rows in rank order.  Host-value collectives (counts, header, agreement) stay the shared-memory transport's.
+struct IpcBox {   // layout of a rank's exported allocation (device memory)
+    uint32_t data_seq[2];                 // [side]: sequence number of the last complete message in my inbox of that side
+    uint32_t tot_seq[2][SHM_MAX_RANKS];   // [slot][rank]: ... of that rank's totals row
+    double tot[2][2][SHM_MAX_RANKS][8];   // [slot][parity][rank][6 used]
+    // followed by the inboxes: side s, parity q at payload() + (2 s + q) * bytes_per_side
+    static size_t header_bytes() { return (sizeof(IpcBox) + 255) & ~(size_t)255; }
+    static size_t size_for(uint64_t per_side) { return header_bytes() + 4 * (size_t)per_side; }
+};
+struct IpcState {
+    uint8_t* mine = nullptr;                  // my box
+    uint8_t* peer[SHM_MAX_RANKS] = {};        // every rank's box as mapped here (peer[rank] == mine for myself)
+    uint64_t bytes_per_side = 0;
+    uint32_t seq[2] = {0, 0};                 // messages exchanged with the [left, right] neighbour
+    uint32_t tot_n[2] = {0, 0};               // all-reduces of the totals of slot 0 / 1
+    static uint8_t* inbox(uint8_t* box, uint64_t per_side, int side, uint32_t parity) { return box + IpcBox::header_bytes() + ((size_t)2 * side + parity) * per_side; }
+};
+
+__device__ __forceinline__ void ipc_store_release(uint32_t* flag, uint32_t v) { __hip_atomic_store(flag, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ void ipc_wait(const uint32_t* flag, uint32_t want)
+{
+    // (sequence numbers only grow; a 32-bit wrap is 4 G exchanges away)
+    while ((int32_t)(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - want) < 0) __builtin_amdgcn_s_sleep(2);
+}
+struct IpcPush {
+    const uint4* src[2];       // staging of the message to the [left, right] neighbour (16-byte granules) or nullptr
+    uint4* dst[2];             // the neighbour's inbox (peer-mapped)
+    uint32_t granules[2];
+    uint32_t* flag[2];         // the neighbour's data_seq word for me
+    uint32_t seq[2];           // 0: this side does not take part
+    // totals (nr == 0: none): my row into every rank's table, then its flag
+    const double* tot;
+    double* tot_dst[SHM_MAX_RANKS];
+    uint32_t* tot_flag[SHM_MAX_RANKS];
+    uint32_t tot_seq;
+    int nr, self;
+};
+// one workgroup: small messages (a Jacobi iteration's ghost values: a few thousand floats) -- copy, fence, signal
+__global__ __launch_bounds__(1024) void k_ipc_push(IpcPush j)
+{
+    for (int s = 0; s < 2; s++)
+        for (uint32_t k = threadIdx.x; k < j.granules[s]; k += 1024u) j.dst[s][k] = j.src[s][k];
+    if (j.nr && threadIdx.x < 6u * (uint32_t)j.nr) {
+        const int r = (int)(threadIdx.x / 6u), k = (int)(threadIdx.x % 6u);
+        if (r != j.self) j.tot_dst[r][k] = j.tot[k];
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x < 2 && j.seq[threadIdx.x]) ipc_store_release(j.flag[threadIdx.x], j.seq[threadIdx.x]);
+    if (j.nr && threadIdx.x >= 64 && threadIdx.x < 64u + (uint32_t)j.nr && (int)(threadIdx.x - 64u) != j.self) ipc_store_release(j.tot_flag[threadIdx.x - 64u], j.tot_seq);
+}
+// the copy of a large message (per-step migrant / ghost records) by many workgroups; k_ipc_push with granules = 0 signals behind it
+__global__ __launch_bounds__(256) void k_ipc_copy(const uint4* __restrict__ src, uint4* __restrict__ dst, uint32_t granules)
+{
+    for (uint32_t k = blockIdx.x * 256u + threadIdx.x; k < granules; k += gridDim.x * 256u) dst[k] = src[k];
+    __threadfence_system();
+}
+struct IpcWait {
+    const uint32_t* flag[2];
+    uint32_t seq[2];           // 0: nothing expected from that side
+    const uint32_t* tot_flag;  // my tot_seq[slot] row (nr words), nullptr: no totals
+    uint32_t tot_seq;
+    const double* table;       // my table of this slot and parity
+    double* tot;               // in: my row; out: the sum over the ranks in rank order
+    int nr, self;
+};
+__global__ __launch_bounds__(64) void k_ipc_wait(IpcWait j)
+{
+    const uint32_t t = threadIdx.x;
+    if (t < 2 && j.seq[t]) ipc_wait(j.flag[t], j.seq[t]);
+    if (j.tot_flag && t >= 2 && t < 2u + (uint32_t)j.nr && (int)(t - 2u) != j.self) ipc_wait(j.tot_flag + (t - 2u), j.tot_seq);
+    __syncthreads();
+    if (j.tot_flag && t < 6) {
+        double s = 0.0;
+        for (int r = 0; r < j.nr; r++) s += r == j.self ? j.tot[t] : __hip_atomic_load(j.table + 8 * r + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        j.tot[t] = s;
+    }
+}
+
+struct IpcComm : ShmComm {
+    static IpcState* st(sph_ctx* c) { return (IpcState*)c->dist.ipc; }
+    // queue the push and the wait of one round: the ghost / record messages of `x` (nullptr: none) and, with slot >= 0, the totals
+    int round(Group& G, std::vector<Xfer>* x, int slot)
+    {
+        sph_ctx* c = G.m[0];
+        IpcState* I = st(c);
+        const int r = c->dist.rank, nr = c->dist.nranks;
+        IpcPush ps{};
+        IpcWait w{};
+        bool any = false;
+        for (int side = 0; side < 2 && x; side++) {
+            Xfer& xf = (*x)[0];
+            const int nb = side == 0 ? r - 1 : r + 1;
+            if (nb < 0 || nb >= nr) {
+                if (xf.send_bytes[side] || xf.recv_bytes[side]) return c->fail(SPH_ERR_DEVICE, "halo exchange across the outer edge of the slab row (rank %d)", r);
+                continue;
+            }
+            if (!xf.send_bytes[side] && !xf.recv_bytes[side]) continue;
+            if (xf.send_bytes[side] > I->bytes_per_side || xf.recv_bytes[side] > I->bytes_per_side) {
+                comm_abandon(c);
+                return c->fail(SPH_ERR_CAPACITY, "peer-mapped transport: a message of %zu bytes does not fit the %llu-byte inbox (sph_comm_ipc_export bytes_per_side)",
+                               std::max(xf.send_bytes[side], xf.recv_bytes[side]), (unsigned long long)I->bytes_per_side);
+            }
+            any = true;
+            const uint32_t seq = ++I->seq[side], parity = seq & 1u;
+            const int oside = side ^ 1;   // I am my left neighbour's right side
+            const uint32_t gran = (uint32_t)((xf.send_bytes[side] + 15) / 16);
+            uint4* dst = (uint4*)IpcState::inbox(I->peer[nb], I->bytes_per_side, oside, parity);
+            if (gran > 16384u) {   // > 256 KB: many workgroups copy, the push kernel only signals
+                hipLaunchKernelGGL(k_ipc_copy, dim3(std::min(1024u, (gran + 255u) / 256u)), dim3(256), 0, c->stream, (const uint4*)xf.send[side], dst, gran);
+                ps.granules[side] = 0;
+            } else {
+                ps.src[side] = (const uint4*)xf.send[side];
+                ps.dst[side] = dst;
+                ps.granules[side] = gran;
+            }
+            ps.flag[side] = &((IpcBox*)I->peer[nb])->data_seq[oside];
+            ps.seq[side] = seq;
+            w.flag[side] = &((IpcBox*)I->mine)->data_seq[side];
+            w.seq[side] = seq;
+            c->dist.stat_bytes_sent += xf.send_bytes[side];
+            c->dist.stat_bytes_recv += xf.recv_bytes[side];
+            xf.recv[side] = IpcState::inbox(I->mine, I->bytes_per_side, side, parity);   // the kernels behind the wait read the inbox in place
+        }
+        if (slot >= 0) {
+            any = true;
+            const uint32_t seq = ++I->tot_n[slot], parity = seq & 1u;
+            ps.tot = c->dist.solver_tot.as<double>() + 8 * slot;
+            ps.tot_seq = seq;
+            ps.nr = nr;
+            ps.self = r;
+            for (int q = 0; q < nr; q++) {
+                IpcBox* b = (IpcBox*)I->peer[q];
+                ps.tot_dst[q] = b->tot[slot][parity][r];
+                ps.tot_flag[q] = &b->tot_seq[slot][r];
+            }
+            IpcBox* me = (IpcBox*)I->mine;
+            w.tot_flag = me->tot_seq[slot];
+            w.tot_seq = seq;
+            w.table = &me->tot[slot][parity][0][0];
+            w.tot = c->dist.solver_tot.as<double>() + 8 * slot;
+            w.nr = nr;
+            w.self = r;
+            c->dist.stat_allreduces++;
+        }
+        if (!any) return SPH_OK;
+        if (x) c->dist.stat_exchanges++;
+        {
+            ProfScope p1(&c->prof, "ipc_push", c->stream);
+            hipLaunchKernelGGL(k_ipc_push, dim3(1), dim3(1024), 0, c->stream, ps);
+        }
+        ProfScope p2(&c->prof, "ipc_wait", c->stream);
+        hipLaunchKernelGGL(k_ipc_wait, dim3(1), dim3(64), 0, c->stream, w);
+        return SPH_OK;
+    }
+    int exchange(Group& G, std::vector<Xfer>& x) override { return round(G, &x, -1); }
+    int allreduce_solver(Group& G, int slot) override { return round(G, nullptr, slot); }
+    int exchange_and_allreduce_solver(Group& G, std::vector<Xfer>& x, int slot) override { return round(G, &x, slot); }
+};
+static IpcComm g_ipc;
+
+// this rank's box: allocated here, its IPC handle for the other ranks (the launcher all-gathers the n_ranks handles)
+extern "C" int sph_comm_ipc_export(sph_ctx* c, uint64_t bytes_per_side, uint8_t handle_out[64])
+{
+    if (!c || !handle_out || bytes_per_side < 4096) return SPH_ERR_INVALID_ARGUMENT;
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is 64 bytes");
+    if (!c->dist.on || !c->dist.shm) return c->fail(SPH_ERR_INVALID_ARGUMENT, "call sph_comm_init_shm before sph_comm_ipc_export (the host-value collectives stay the shared-memory transport's)");
+    if (c->dist.nranks > SHM_MAX_RANKS) return c->fail(SPH_ERR_INVALID_ARGUMENT, "peer-mapped transport: at most %d ranks", SHM_MAX_RANKS);
+    HIPCHK(c, hipSetDevice(c->device));
+    IpcState* I = new IpcState();
+    I->bytes_per_side = (bytes_per_side + 255) & ~(uint64_t)255;
+    const size_t total = IpcBox::size_for(I->bytes_per_side);
+    if (hipMalloc((void**)&I->mine, total) != hipSuccess) {
+        delete I;
+        return c->fail(SPH_ERR_DEVICE, "peer-mapped transport: out of device memory (%zu bytes)", total);
+    }
+    HIPCHK(c, hipMemset(I->mine, 0, IpcBox::header_bytes()));
+    HIPCHK(c, hipDeviceSynchronize());
+    hipIpcMemHandle_t h;
+    const hipError_t e = hipIpcGetMemHandle(&h, I->mine);
+    if (e != hipSuccess) {
+        (void)hipFree(I->mine);
+        delete I;
+        return c->fail(SPH_ERR_DEVICE, "hipIpcGetMemHandle failed: %s", hipGetErrorString(e));
+    }
+    memcpy(handle_out, &h, 64);
+    c->dist.ipc = I;
+    return SPH_OK;
+}
+// map the other ranks' boxes: `handles` = the n_ranks handles of sph_comm_ipc_export in rank order.  From here on the ghost / record
+// exchanges and the totals all-reduce of this context are pushed device to device.
+extern "C" int sph_comm_init_ipc(sph_ctx* c, const uint8_t* handles, int n_ranks)
+{
+    if (!c || !handles || !c->dist.ipc || n_ranks != c->dist.nranks) return SPH_ERR_INVALID_ARGUMENT;
+    HIPCHK(c, hipSetDevice(c->device));
+    IpcState* I = (IpcState*)c->dist.ipc;
+    for (int r = 0; r < n_ranks; r++) {
+        if (r == c->dist.rank) {
+            I->peer[r] = I->mine;
+            continue;
+        }
+        hipIpcMemHandle_t h;
+        memcpy(&h, handles + (size_t)64 * r, 64);
+        void* p = nullptr;
+        const hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) return c->fail(SPH_ERR_DEVICE, "hipIpcOpenMemHandle (rank %d's box) failed: %s", r, hipGetErrorString(e));
+        I->peer[r] = (uint8_t*)p;
+    }
+    return SPH_OK;
+}
+
 // the transports carry no state of their own (everything lives in the contexts / the thread group): one object each serves every group
 static RcclComm g_rccl;
 static LocalComm g_local;
@@ -1158,6 +1381,7 @@ int comm_for_rank(sph_ctx* c, Comm** out)
     *out = nullptr;
     if (!c->dist.on) return SPH_OK;
     if (c->dist.tgroup) *out = &g_threads;
+    else if (c->dist.ipc && ((IpcState*)c->dist.ipc)->peer[c->dist.rank]) *out = &g_ipc;   // (exported AND mapped)
     else if (c->dist.shm) *out = &g_shm;
     else if (c->dist.nccl) *out = &g_rccl;
     else return c->fail(SPH_ERR_INVALID_ARGUMENT, "slab context without a communicator: call sph_comm_init or use sph_group_step");
@@ -1260,6 +1484,15 @@ extern "C" int sph_comm_init_shm(sph_ctx* c, const char* name, int rank, int n_r
 void dist_release(sph_ctx* c)
 {
     auto& d = c->dist;
+    if (d.ipc) {
+        IpcState* I = (IpcState*)d.ipc;
+        (void)hipSetDevice(c->device);
+        for (int r = 0; r < SHM_MAX_RANKS; r++)
+            if (I->peer[r] && I->peer[r] != I->mine) (void)hipIpcCloseMemHandle(I->peer[r]);
+        if (I->mine) (void)hipFree(I->mine);
+        delete I;
+        d.ipc = nullptr;
+    }
     if (d.shm) {
         munmap(d.shm, d.shm_bytes);
         if (!d.shm_name.empty()) (void)shm_unlink(d.shm_name.c_str());   // (the creating rank; the others' mappings stay valid)

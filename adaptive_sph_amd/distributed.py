@@ -54,7 +54,7 @@ def pick_transport(world: int) -> str:
     import os
     import torch
     want = os.environ.get("SPH_TRANSPORT", "")
-    if want in ("shm", "rccl"):
+    if want in ("shm", "rccl", "ipc"):   # ipc: the peer-mapped push transport (device to device, no RCCL launch per exchange) on top of shm
         return want
     return "shm" if (torch.cuda.is_available() and world > torch.cuda.device_count()) else "rccl"
 
@@ -77,7 +77,7 @@ def make_slab_context(lib: ffi.SphLibrary, pos, mass, vel, planes, rank: int, wo
     ctx.upload(mass[mine], pos[mine], vel[mine])
     if world > 1:
         ctx.upload_field("particle_id", mine.astype(np.uint32))
-    if transport == "shm":
+    if transport in ("shm", "ipc"):
         # rank 0 names and creates the segment, the others map it after the launcher's barrier; an outbox holds one message to one
         # x-neighbour: at most every particle of the slab as a 48-byte migrant record
         _SHM_SERIAL[0] += 1
@@ -90,6 +90,13 @@ def make_slab_context(lib: ffi.SphLibrary, pos, mass, vel, planes, rank: int, wo
         if rank != 0:
             ctx.comm_init_shm(name[0], rank, world, per_side, False)
         dist.barrier()
+        if transport == "ipc":
+            # every rank exports its device inbox, the launcher all-gathers the 64-byte handles, every rank maps the others'
+            mine = ctx.comm_ipc_export(per_side)
+            handles = [None] * world
+            dist.all_gather_object(handles, mine)
+            ctx.comm_init_ipc(b"".join(handles), world)
+            dist.barrier()
         return ctx
     # RCCL unique id: created on rank 0, broadcast through the launcher's process group
     buf = torch.zeros(128, dtype=torch.uint8)

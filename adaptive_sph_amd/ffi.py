@@ -150,7 +150,7 @@ class SphError(RuntimeError):
 ABI_SYMBOLS = [
     "create", "destroy", "upload", "upload_field", "download", "download_neighbors", "num_particles", "time",
     "set_time", "step", "classify", "share_particles", "merge_particles", "set_split_patterns", "split_particles", "host_find_partners", "last_error", "grid", "set_boundary_polygon", "apply_edits", "profile_enable", "profile_reset", "profile_get", "profile_event_overhead", "profile_dispatch_bracket", "profile_copy_bandwidth", "profile_list_forms", "set_sweep_variant",
-    "dist_configure", "dist_set_rebalance", "dist_get_cuts", "dist_get_stats", "comm_unique_id", "comm_init", "comm_init_shm", "group_step", "group_adapt", "thread_group_create", "thread_group_destroy", "comm_init_threads",
+    "dist_configure", "dist_set_rebalance", "dist_get_cuts", "dist_get_stats", "comm_unique_id", "comm_init", "comm_init_shm", "comm_ipc_export", "comm_init_ipc", "group_step", "group_adapt", "thread_group_create", "thread_group_destroy", "comm_init_threads",
 ]
 
 
@@ -214,6 +214,8 @@ class SphLibrary:
         self.comm_unique_id = sig("comm_unique_id", i32, [C.POINTER(C.c_uint8)], required=False)
         self.comm_init = sig("comm_init", i32, [vp, C.POINTER(C.c_uint8), i32, i32], required=False)
         self.comm_init_shm = sig("comm_init_shm", i32, [vp, C.c_char_p, i32, i32, u64, i32], required=False)
+        self.comm_ipc_export = sig("comm_ipc_export", i32, [vp, u64, C.POINTER(C.c_uint8)], required=False)
+        self.comm_init_ipc = sig("comm_init_ipc", i32, [vp, C.POINTER(C.c_uint8), i32], required=False)
         self.dist_configure = sig("dist_configure", i32, [vp, i32, i32, C.c_float, C.c_float], required=False)
         self.group_step = sig("group_step", i32, [C.POINTER(vp), i32, C.POINTER(SphParams), C.POINTER(SphStepStats)], required=False)
         self.thread_group_create = sig("thread_group_create", i32, [i32, C.POINTER(vp)], required=False)
@@ -469,6 +471,16 @@ class Context:
     def comm_init_shm(self, name: str, rank: int, n_ranks: int, bytes_per_side: int, create: bool):
         """Shared-memory transport between processes of one node (sph_ffi.h): rank 0 creates, the others map afterwards."""
         self._check(self.lib.comm_init_shm(self.handle, name.encode(), int(rank), int(n_ranks), int(bytes_per_side), 1 if create else 0))
+
+    def comm_ipc_export(self, bytes_per_side: int) -> bytes:
+        """Peer-mapped push transport (sph_ffi.h): allocate this rank's box, return its 64-byte IPC handle."""
+        buf = (C.c_uint8 * 64)()
+        self._check(self.lib.comm_ipc_export(self.handle, int(bytes_per_side), buf))
+        return bytes(buf)
+
+    def comm_init_ipc(self, handles: bytes, n_ranks: int):
+        buf = (C.c_uint8 * len(handles)).from_buffer_copy(handles)
+        self._check(self.lib.comm_init_ipc(self.handle, buf, int(n_ranks)))
 
     def comm_init(self, unique_id: bytes, rank: int, n_ranks: int):
         buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)

@@ -460,6 +460,14 @@ int  sph_group_adapt(sph_ctx** ctxs, int n, int op, const sph_params* params, co
  * where RCCL cannot serve the launch (several ranks on one GPU: "Duplicate GPU detected") and for checking the launcher glue with
  * real processes; sph_comm_init is the fast path.  At most 16 ranks. */
 int  sph_comm_init_shm(sph_ctx* ctx, const char* name, int rank, int n_ranks, uint64_t bytes_per_side, int create);
+/* Peer-mapped PUSH transport on top of the shared-memory one (ranks as processes of one node, one per GPU or several per GPU): every
+ * rank exports a device buffer (sph_comm_ipc_export: its hipIpcMemHandle, 64 bytes), the launcher all-gathers the handles, every rank
+ * maps the others' (sph_comm_init_ipc).  From then on the ghost / migrant exchanges and the all-reduce of the Jacobi totals are pushed
+ * device to device by small kernels -- the sender writes into the receiver's inbox and raises a flag there, the receiver's next kernel
+ * waits on it -- with no collective-library launch and no host wait per exchange; the host-value collectives (counts, header) stay the
+ * shared-memory transport's.  `bytes_per_side`: room for one message from one x-neighbour (as for sph_comm_init_shm). */
+int  sph_comm_ipc_export(sph_ctx* ctx, uint64_t bytes_per_side, uint8_t handle_out[64]);
+int  sph_comm_init_ipc(sph_ctx* ctx, const uint8_t* handles /* n_ranks x 64 bytes, rank order */, int n_ranks);
 int  sph_thread_group_create(int n_ranks, void** group_out);
 void sph_thread_group_destroy(void* group);
 int  sph_comm_init_threads(sph_ctx* ctx, void* group, int rank, int n_ranks);

@@ -29,6 +29,20 @@ def test_ranks_as_processes_reproduce_the_single_context(world):
     assert r.returncode == 0 and f"MP_CHECK OK world={world}" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_peer_mapped_push_transport_between_processes(world):
+    """The same check with SPH_TRANSPORT=ipc: every rank exports a device inbox (hipIpcGetMemHandle), maps the others'
+    (hipIpcOpenMemHandle) and from then on ghost values, migrant / ghost records and the Jacobi totals are PUSHED device to device by
+    the sender's kernel and awaited by the receiver's (sph_comm_ipc_export / sph_comm_init_ipc) -- between processes that here share
+    one GPU, over xGMI on a multi-GPU node.  Same results as the single context, like the shared-memory transport's run."""
+    env = _env()
+    env["SPH_TRANSPORT"] = "ipc"
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+                        "--master-port", str(29670 + world), str(REPO / "tests" / "mp_slab_check.py")],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=str(REPO))
+    assert r.returncode == 0 and f"MP_CHECK OK world={world}" in r.stdout and "transport=ipc" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
 @pytest.mark.parametrize("on_slabs", [0, 1])
 def test_adaptive_steps_with_one_process_per_rank(on_slabs):
     """single_step = sph_step + single_step_adaptivity on a slab decomposition whose ranks are PROCESSES, against the single context:
