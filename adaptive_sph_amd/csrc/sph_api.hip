@@ -507,6 +507,7 @@ Options options_from_env()
     o.side_stream_normal = flag("SPH_SIDE_STREAM_NORMAL");
     o.force_slab_mode = flag("SPH_FORCE_SLAB_MODE");
     o.tile = num("SPH_TILE", 0);
+    o.ahead_build = num("SPH_AHEAD_BUILD", 1) != 0 ? 1 : 0;
     o.slab_paced = num("SPH_SLAB_PACED", 1) != 0 ? 1 : 0;
     o.slab_records = num("SPH_SLAB_RECORDS", 1) != 0 ? 1 : 0;
     o.debug_sync = num("SPH_DEBUG_SYNC", 0);
@@ -625,7 +626,7 @@ extern "C" void sph_destroy(sph_ctx* c)
                      &c->cs_scratch, &c->hdr_ahead_partials, &c->h2n[0], &c->h2n[1], &c->lam_prev, &c->nl, &c->nlx, &c->tile_raw, &c->tile_h, &c->tile_h_ext, &c->lvl_changed_d, &c->lvl_tmp, &c->lvl_nrm, &c->lvl_state, &c->lvl_when, &c->lvl_mark, &c->flag_surface,
                      &c->flag_insufficient, &c->con_thr, &c->con_consumed, &c->con_h, &c->flag_reduced, &c->szc[0], &c->szc[1], &c->omega, &c->stash, &c->nl_ext, &c->nlx_ext, &c->nl_ok, &c->mrho, &c->pt0, &c->pt1, &c->prec0, &c->prec1, &c->rho, &c->lam_sum, &c->lam_grad, &c->constf, &c->aii, &c->src, &c->p0, &c->p1, &c->pacc, &c->dens_err,
                      &c->stat, &c->ncount, &c->planes_d, &c->lam_lut, &c->dlam_lut, &c->hdr_partials, &c->hdr_out, &c->ctrl, &c->status,
-                     &c->n_tiles, &c->red_partials, &c->scratch, &c->split_patterns};
+                     &c->n_tiles, &c->red_partials, &c->scratch, &c->split_patterns, &c->akey[0], &c->akey[1], &c->aval[0], &c->aval[1], &c->acxy, &c->acell_start, &c->pm2};
     for (auto b : all) b->release();
     if (c->hdr_host) (void)hipHostFree(c->hdr_host);
     if (c->ctrl_host) (void)hipHostFree(c->ctrl_host);
@@ -761,13 +762,14 @@ extern "C" int sph_download(sph_ctx* c, int field, void* dst, uint64_t bytes)
         if (c->dist.on) return download_slab(c, G_U32, c->key[0].p, 4, dst, bytes);
         if (bytes != (uint64_t)n * 4) return c->fail(SPH_ERR_INVALID_ARGUMENT, "field %d: size mismatch", field);
         if (n == 0) return SPH_OK;
-        if (c->uniform_h) {
+        const bool same_grid = c->fgrid.minx == c->grid.minx && c->fgrid.miny == c->grid.miny && c->fgrid.sx == c->grid.sx && c->fgrid.sy == c->grid.sy;
+        if (c->uniform_h && same_grid) {
             // sorted cell keys of the positions the last step started from
             hipLaunchKernelGGL(k_to_host_order, dim3((n + 255) / 256), dim3(256), 0, s, n, (int)G_U32, c->orig[k].as<uint32_t>(),
                                (const void*)c->key[0].p, c->scratch.p);
         } else {
-            // multi-resolution scenes sort by a finer grid: recompute the reference-convention index (cell = largest
-            // support) from the sorted pre-step snapshot pm[pcur ^ 1]
+            // multi-resolution scenes sort by a finer grid, a step that adopted the build queued ahead by a wider one (predicted
+            // bounding box): recompute the reference-convention index (cell = largest support) from the sorted pre-step snapshot pm[pcur ^ 1]
             hipLaunchKernelGGL(k_cell_index_host, dim3((n + 255) / 256), dim3(256), 0, s, n, c->grid, c->orig[k].as<uint32_t>(),
                                c->pm[c->pcur ^ 1].as<float4>(), c->scratch.as<uint32_t>());
         }

@@ -65,6 +65,7 @@ struct Options {
     int side_stream_normal = 0; // SPH_SIDE_STREAM_NORMAL   side stream at normal priority
     int force_slab_mode = 0;    // SPH_FORCE_SLAB_MODE      sph_dist_configure(0, 1, ..) turns the slab driver on (one-rank check of that path)
     int tile = 0;               // SPH_TILE=<bits>          LDS-staged sweeps (sph_set_sweep_variant overrides, process-wide)
+    int ahead_build = 1;        // SPH_AHEAD_BUILD=0        one context: never queue the next step's cell sort behind the integrating tail
     int slab_paced = 1;         // SPH_SLAB_PACED=0         slabs: predicted queue instead of pacing
     int slab_records = 1;       // SPH_SLAB_RECORDS=0       slabs: sweep A through the generic form (p / rho^2 as a field of its own)
     int debug_sync = 0;         // SPH_DEBUG_SYNC=<mask>    synchronise and name the phases (fault hunting)
@@ -178,6 +179,18 @@ struct sph_ctx {
     GridP fgrid{};          // the grid the particles are sorted by (== grid in uniform scenes)
     int tile_ts = 0, tile_tsx = 0, tile_tsy = 0;
     DevBuf tile_raw, tile_h, tile_h_ext, nlx;
+    // Neighbour build AHEAD (one context, uniform scenes; sph_step.hip: queue_ahead_build): the NEXT step's cell sort, reorder and
+    // cell-range table are queued behind this step's integrating tail, on a grid predicted from this step's bounding box plus a
+    // margin -- the device works on them while the host finishes the step, returns, and enters the next one (the step boundary was
+    // ~20-36 us of idle queue).  They write buffers of their own (post-step downloads still see this step's order, keys and ranges);
+    // the next step adopts them by swapping pointers if nothing touched the state and the real bounding box fits the predicted grid.
+    DevBuf akey[2], aval[2], acxy, acell_start, pm2;
+    struct Ahead {
+        bool valid = false;
+        GridP g{};
+        float h_max = 0.f, rest_density = 0.f;
+        uint64_t n = 0;
+    } ahead;
     DevBuf hdr_ahead_partials;   // per sweep block: next step's header terms from the integrating final sweep
     bool hdr_ahead = false;      // hdr_host already holds the header of the state on the device (no k_header needed)
     float hdr_ahead_rest_density = 0.f;

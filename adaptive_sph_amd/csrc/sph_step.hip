@@ -602,7 +602,8 @@ static int solve_paced(Group& G, std::vector<Member>& M, SolveQ& q, uint32_t pre
 
 // iisph_pressure_iterations (simulation.rs:1377-1516) with a host wait of its own
 static int pressure_iterations(Group& G, std::vector<Member>& M, float max_avg_error, int residual_density, uint32_t max_iters,
-                               uint32_t predicted_iters, int tail, bool density_solver, bool final_solve)
+                               uint32_t predicted_iters, int tail, bool density_solver, bool final_solve,
+                               const std::function<int()>* behind_tail = nullptr /* paced: queued behind the solve's tail, in front of the wait */)
 {
     int rc;
     const int multi = G.multi() ? 1 : 0;
@@ -614,6 +615,7 @@ static int pressure_iterations(Group& G, std::vector<Member>& M, float max_avg_e
         const uint32_t head = density_solver ? pace_prediction(c0, M[0].n, c0->last_dens_iters, c0->prev_dens_iters) : pace_prediction(c0, M[0].n, c0->last_div_iters, c0->prev_div_iters);
         if ((rc = solve_paced(G, M, q, head))) return rc;
         if ((rc = solve_queue(G, M, q, false, true))) return rc;   // (the tail)
+        if (behind_tail && (rc = (*behind_tail)())) return rc;
         if (multi && final_solve && (rc = G.comm->agree_guards_queued(G))) return rc;
         if ((rc = sync_ctrl(G, multi ? (final_solve ? SYNC_FINAL : SYNC_DEFER) : SYNC_AGREE))) return rc;
         for (auto& m : M) solve_stats(m, q, *m.c->ctrl_host);
@@ -699,6 +701,7 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
     // not the mass-derived ones.  On a slab the header describes the particles the rank owned at the END of that step; the ones
     // about to migrate are some other rank's soon, but every value below is reduced over ALL ranks (or replaced by the cuts).
     auto header_ready = [&](sph_ctx* c) { return h_from_mass_mode && c->hdr_ahead && c->hdr_ahead_rest_density == p->rest_density; };
+    const bool ahead_usable = !G.multi() && header_ready(c0);   // (every call that touches the state clears hdr_ahead)
     auto fill_red = [&]() {
         for (size_t i = 0; i < M.size(); i++) {
             const HeaderOut h = *M[i].c->hdr_host;
@@ -897,7 +900,26 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
         const bool pre = c->dist.on && c->dist.pre;
         const uint32_t n_sort = pre ? m.n_sort : n;
         c->dist.pre = false;
-        if (n_sort) {
+        // the build the previous step queued ahead (queue_ahead_build): adopted if nothing touched the state since (the header that
+        // step left behind was still the one in force), the scene is what it predicted and the real bounding box fits its grid
+        const GridP ag = c->ahead.g;
+        const bool adopt = ahead_usable && c->ahead.valid && !c->dist.on && c->ahead.n == c->n && n == (uint32_t)c->n && c->ahead.h_max == h_max_g &&
+                           c->ahead.rest_density == p->rest_density && c->uniform_h && c->tile_ts == 0 && !c->exact && ag.cs == g.cs && g.minx >= ag.minx &&
+                           g.miny >= ag.miny && g.minx + g.sx <= ag.minx + ag.sx && g.miny + g.sy <= ag.miny + ag.sy;
+        c->ahead.valid = false;
+        if (adopt) {
+            for (int q = 0; q < 2; q++) {
+                std::swap(c->key[q], c->akey[q]);
+                std::swap(c->val[q], c->aval[q]);
+            }
+            std::swap(c->cxy, c->acxy);
+            std::swap(c->cell_start, c->acell_start);
+            std::swap(c->pm[c->pcur ^ 1], c->pm2);
+            c->cur = k ^ 1;
+            c->pcur ^= 1;
+            c->fgrid = ag;
+            g = ag;
+        } else if (n_sort) {
             // (the keys -- cell index, or one past the last cell for a slot that left -- are made by the sort's first pass)
             const CellKeyGen kg{c->pm[c->pcur].as<float4>(), g, pre ? c->dist.cls.as<uint8_t>() : nullptr, pre ? c->dist.pre_cls_n : 0u, (uint32_t)SC_GONE_FROM};
             int res = radix_sort_pairs(s, prof, c->key[0].as<uint32_t>(), c->val[0].as<uint32_t>(), c->key[1].as<uint32_t>(),
@@ -915,7 +937,7 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
             c->cur = k ^ 1;
             c->pcur ^= 1;
         }
-        launch_cell_start(s, prof, c->key[0].as<uint32_t>(), n, g.ncells, c->cell_start.as<uint32_t>(), c->cs_scratch.p, n > 0);
+        if (!adopt) launch_cell_start(s, prof, c->key[0].as<uint32_t>(), n, g.ncells, c->cell_start.as<uint32_t>(), c->cs_scratch.p, n > 0);
         if (c->tile_ts > 0) {
             const size_t nt = (size_t)c->tile_tsx * (size_t)c->tile_tsy;
             HIPCHK(c, c->tile_raw.ensure(nt * 4));
@@ -1405,13 +1427,64 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
     };
     enum { T_NONE = 0, T_VEL = 1, T_VX = 2, T_HYBRID = 3 };  // TAIL_* of sph_sweeps.hip
     g_trace.mark(3);
+    // The NEXT step's neighbour build, queued behind this step's integrating tail (sph_context.hpp: Ahead): cell keys on a grid
+    // predicted from this step's bounding box + 2 cells (a particle moves at most cfl_factor supports per step), radix sort,
+    // reorder into buffers of their own, cell ranges.  One context, paced solves (the tail is queued once the stop decision was
+    // seen), uniform scenes with mass-derived smoothing lengths, no level estimation behind the solve.
+    const std::function<int()> queue_ahead_build = [&]() -> int {
+        sph_ctx* c = c0;
+        c->ahead.valid = false;
+        if (G.multi() || !paced || !c->opt.ahead_build || level_on || !h_from_mass_mode || p->constrain_neighborhood_count || !c->uniform_h || c->tile_ts != 0 ||
+            c->exact || M[0].n == 0)
+            return SPH_OK;
+        const uint32_t n = M[0].n;
+        const float cs = h_max_g * 2.f;
+        const int margin = 2;
+        GridP g{};
+        g.cs = cs;
+        g.minx = (int)floorf(boxes[0].min_x / cs) - 1 - margin;
+        g.miny = (int)floorf(boxes[0].min_y / cs) - 1 - margin;
+        const long long sx = (long long)((int)floorf(boxes[0].max_x / cs) + 2 + margin) - g.minx, sy = (long long)((int)floorf(boxes[0].max_y / cs) + 2 + margin) - g.miny;
+        if (sx <= 0 || sy <= 0 || sx >= 65536 || sy >= 65536 || sx * sy >= (1ll << 27)) return SPH_OK;
+        g.sx = (int)sx;
+        g.sy = (int)sy;
+        g.ncells = (uint32_t)sx * (uint32_t)sy;
+        for (int q = 0; q < 2; q++) {
+            HIPCHK(c, c->akey[q].ensure((size_t)c->cap * 4));
+            HIPCHK(c, c->aval[q].ensure((size_t)c->cap * 4));
+        }
+        HIPCHK(c, c->acxy.ensure((size_t)c->cap * 4));
+        HIPCHK(c, c->pm2.ensure((size_t)c->cap * sizeof(float4)));
+        HIPCHK(c, c->acell_start.ensure(((size_t)g.ncells + 1) * 4));
+        hipStream_t s = c->stream;
+        const int k = c->cur;
+        const float4* integrated = c->pm[c->pcur ^ 1].as<float4>();   // (the tail's output; the step's end flips pcur)
+        const CellKeyGen kg{integrated, g, nullptr, 0u, (uint32_t)SC_GONE_FROM};
+        const int res = radix_sort_pairs(s, &c->prof, c->akey[0].as<uint32_t>(), c->aval[0].as<uint32_t>(), c->akey[1].as<uint32_t>(), c->aval[1].as<uint32_t>(), n,
+                                         ilog2_ceil(g.ncells), c->sort_scratch.as<uint32_t>(), &kg);
+        if (res == 1) {
+            std::swap(c->akey[0], c->akey[1]);
+            std::swap(c->aval[0], c->aval[1]);
+        }
+        launch_reorder(s, &c->prof, n, g, c->akey[0].as<uint32_t>(), c->aval[0].as<uint32_t>(), integrated, c->vel[k].as<float2>(), c->orig[k].as<uint32_t>(),
+                       c->lvl[k].as<float>(), c->lvlold[k].as<float>(), c->pm2.as<float4>(), c->vel[k ^ 1].as<float2>(), c->orig[k ^ 1].as<uint32_t>(),
+                       c->lvl[k ^ 1].as<float>(), c->lvlold[k ^ 1].as<float>(), c->acxy.as<uint32_t>(), c->h2n[k].as<float>(), c->h2n[k ^ 1].as<float>(),
+                       c->lam_sum.as<float>(), c->lam_prev.as<float>(), c->cs_scratch.p, c->szc[k].as<uint8_t>(), c->szc[k ^ 1].as<uint8_t>());
+        launch_cell_start(s, &c->prof, c->akey[0].as<uint32_t>(), n, g.ncells, c->acell_start.as<uint32_t>(), c->cs_scratch.p, true);
+        c->ahead.valid = true;
+        c->ahead.g = g;
+        c->ahead.h_max = h_max_g;
+        c->ahead.rest_density = p->rest_density;
+        c->ahead.n = c->n;
+        return SPH_OK;
+    };
 
     switch (p->pressure_solver_method) {
     case SPH_SOLVER_IISPH:  // simulation.rs:2389-2446
         if ((rc = non_pressure())) return rc;
         rec(4);
         begin_solve(1, 1);
-        if ((rc = pressure_iterations(G, M, p->iisph_max_avg_density_error, 1, p->max_iters, c0->last_dens_iters, T_VX, true, !level_on))) return rc;
+        if ((rc = pressure_iterations(G, M, p->iisph_max_avg_density_error, 1, p->max_iters, c0->last_dens_iters, T_VX, true, !level_on, &queue_ahead_build))) return rc;
         rec(5);
         break;
     case SPH_SOLVER_IISPH2:  // simulation.rs:2262-2387: omega rides in the source-term sweep; p /= sqrt(omega) before the last a^p
@@ -1439,7 +1512,7 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
         if ((rc = non_pressure())) return rc;
         rec(2);
         begin_solve(0, 0);
-        if ((rc = pressure_iterations(G, M, p->hybrid_dfsph_max_avg_divergence_error, 0, p->max_iters, c0->last_div_iters, T_VX, false, !level_on))) return rc;
+        if ((rc = pressure_iterations(G, M, p->hybrid_dfsph_max_avg_divergence_error, 0, p->max_iters, c0->last_div_iters, T_VX, false, !level_on, &queue_ahead_build))) return rc;
         rec(3);
         break;
     default: {  // HybridDFSPH, simulation.rs:2502-2670
@@ -1474,6 +1547,7 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
             begin_solve(p->hybrid_dfsph_density_source_term == SPH_ONLY_DENSITY ? 2 : 1, 1);
             if ((rc = solve_paced(G, M, qs, pace_prediction(c0, M[0].n, c0->last_dens_iters, c0->prev_dens_iters)))) return rc;
             if ((rc = solve_queue(G, M, qs, false, true))) return rc;
+            if ((rc = queue_ahead_build())) return rc;
             const bool final_solve = !level_on;
             if (multi && final_solve && (rc = G.comm->agree_guards_queued(G))) return rc;
             if ((rc = sync_ctrl(G, multi ? (final_solve ? SYNC_FINAL : SYNC_DEFER) : SYNC_AGREE))) return rc;

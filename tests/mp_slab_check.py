@@ -66,6 +66,17 @@ def main():
         assert (cnt != single.download("neighbor_count")).mean() < 1e-3
         assert all(q[2]["exchanges"] > 0 and q[2]["bytes_sent"] > 0 for q in parts), [q[2] for q in parts]
         assert min(len(q[0]["particle_id"]) for q in parts) > 0 and len({len(q[0]["particle_id"]) for q in parts}) > 1     # particles migrated
+        # ... and BIT FOR BIT the loopback group's result (the same slabs as contexts of one process: the verification form of the
+        # decomposition) -- whatever carried the messages, the ranks did the same arithmetic on the same particles in the same order
+        from adaptive_sph_amd.distributed import make_loopback_group
+        grp = make_loopback_group(lib, pos, mass, vel, planes, world, device_id=local)
+        for _ in range(steps):
+            ffi.group_step(grp, p)
+        for r, (q, c) in enumerate(zip(parts, grp)):
+            for f in ("particle_id", "position", "velocity", "density", "neighbor_count"):
+                assert np.array_equal(q[0][f], c.download(f)), (r, f)
+        for c in grp:
+            c.close()
         print(f"MP_CHECK OK world={world} transport={transport} steps={steps}", flush=True)
     dist.barrier()
     ctx.close()
