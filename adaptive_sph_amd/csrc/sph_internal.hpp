@@ -104,6 +104,10 @@ struct CellKeyGen {
     GridP g;
     const uint8_t* gone;
     uint32_t n_gone, gone_from;
+    // 1: a record outside the grid gets the key of the nearest cell instead of an index beyond the cell table -- the grid of a build
+    // queued AHEAD is a prediction (sph_step.hip: queue_ahead_build); such a build is never adopted (the real bounding box does not
+    // fit its grid), but its kernels have run by then
+    int clamp = 0;
 };
 // keygen != nullptr: the first pass computes the keys (keyA) and the identity values (valA) itself
 int radix_sort_pairs(hipStream_t s, Profiler* prof, uint32_t* keyA, uint32_t* valA, uint32_t* keyB, uint32_t* valB,

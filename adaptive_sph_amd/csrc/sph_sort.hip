@@ -43,8 +43,12 @@ __device__ __forceinline__ uint32_t cell_key_of(const CellKeyGen& kg, uint32_t i
     if (kg.gone && i < kg.n_gone && kg.gone[i] >= kg.gone_from) return kg.g.ncells;
     const float4 p = kg.pm[i];
     // IEEE division, like `(particle_pos / kernel_support_radius).map(|x| x.floor() as i32)`
-    const int cx = (int)floorf(p.x / kg.g.cs) - kg.g.minx;
-    const int cy = (int)floorf(p.y / kg.g.cs) - kg.g.miny;
+    int cx = (int)floorf(p.x / kg.g.cs) - kg.g.minx;
+    int cy = (int)floorf(p.y / kg.g.cs) - kg.g.miny;
+    if (kg.clamp) {   // (launch-uniform)
+        cx = min(max(cx, 0), kg.g.sx - 1);
+        cy = min(max(cy, 0), kg.g.sy - 1);
+    }
     return (uint32_t)cx + (uint32_t)cy * (uint32_t)kg.g.sx;
 }
 template <int NB, bool KEYGEN>

@@ -1459,7 +1459,7 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
         hipStream_t s = c->stream;
         const int k = c->cur;
         const float4* integrated = c->pm[c->pcur ^ 1].as<float4>();   // (the tail's output; the step's end flips pcur)
-        const CellKeyGen kg{integrated, g, nullptr, 0u, (uint32_t)SC_GONE_FROM};
+        const CellKeyGen kg{integrated, g, nullptr, 0u, (uint32_t)SC_GONE_FROM, 1};   // (clamped keys: the grid is a prediction)
         const int res = radix_sort_pairs(s, &c->prof, c->akey[0].as<uint32_t>(), c->aval[0].as<uint32_t>(), c->akey[1].as<uint32_t>(), c->aval[1].as<uint32_t>(), n,
                                          ilog2_ceil(g.ncells), c->sort_scratch.as<uint32_t>(), &kg);
         if (res == 1) {

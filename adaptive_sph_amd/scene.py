@@ -145,9 +145,12 @@ def dam_break_1m_adaptive() -> SceneConfig:
 
 
 def dam_break_8m() -> SceneConfig:
-    """configs[3]: 2896 x 2896 = 8 386 816 particles."""
-    return SceneConfig(SceneBoundary("box", 4.0, 2.0),
-                       [SceneFluidBlock([-1.9995, -0.9995], [1.4143, 1.4143], 0.00048828125, 0.93, [0.0, 0.0])])
+    """configs[3]: 8192 x 1024 = 8 388 608 particles: configs[1]'s column eight times as wide (same spacing, same height, same
+    parameters), in a box 16 x 2.  (Until round 4 this was a 2896 x 2896 column at spacing 1/2048 with max_dt = 0.001: that scene
+    DIVERGES at step 3 -- largest speed 6 -> 74 -> 566 -> 1580 -> 3800 m/s, dt 1e-7, particles below the floor -- in the CPU oracle
+    identically, digit for digit, and for max_dt = 0.0005 and 0.00025 as well: the relaxed Jacobi solves stop on AVERAGE errors long
+    before 2896 layers have seen the floor.  A benchmark of a blown-up state measures nothing, so the scene went.)"""
+    return dam_break_weak(8)
 
 
 def ratio_stress_4m() -> SceneConfig:
@@ -159,21 +162,17 @@ def ratio_stress_4m() -> SceneConfig:
 
 
 def dam_break_weak(n_gpus: int) -> SceneConfig:
-    """Weak-scaling family between configs[1] (1 GPU, 1M) and configs[3] (8 GPUs, 8M): ~1M particles per GPU.
-    2 GPUs: configs[1]'s column twice as wide, 2048 x 1024 = 2 097 152 at spacing 1/1024; 4 GPUs: 2048 x 2048 = 4 194 304
-    at spacing 1/2048.  (A 1448 x 1448 column at spacing 1/1448 was tried first: with the proportionally scaled max_dt it
-    diverges at step 3 -- in the CPU oracle identically -- so it is no benchmark scene.)"""
-    if n_gpus <= 1:
+    """Weak-scaling family between configs[1] (1 GPU, 1M) and configs[3] (8 GPUs, 8M): configs[1]'s column n times as wide --
+    (1024 n) x 1024 particles at spacing 1/1024, one configs[1] per x-slab -- in a box of twice the column's width (4 x 2 up to
+    n = 2).  (Taller columns at finer spacing were tried first -- 1448 x 1448 at 1/1448, 2048 x 2048 and 2896 x 2896 at 1/2048 with
+    proportionally scaled max_dt: they all diverge within four steps, in the CPU oracle identically, so they are no benchmark
+    scenes.)"""
+    n = max(int(n_gpus), 1)
+    if n == 1:
         return dam_break_1m()
-    if n_gpus >= 8:
-        return dam_break_8m()
-    if n_gpus < 4:
-        return SceneConfig(SceneBoundary("box", 4.0, 2.0),
-                           [SceneFluidBlock([-1.999, -0.999], [2.0005, 1.0005], 0.0009765625, 0.93, [0.0, 0.0])])
-    side = 2048
-    s = 1.0 / side
-    return SceneConfig(SceneBoundary("box", 4.0, 2.0),
-                       [SceneFluidBlock([-2.0 + 1.024 * s, -1.0 + 1.024 * s], [side * s + 0.5 * s, side * s + 0.5 * s], s, 0.93, [0.0, 0.0])])
+    width = 4.0 if n <= 2 else 2.0 * n
+    return SceneConfig(SceneBoundary("box", width, 2.0),
+                       [SceneFluidBlock([-0.5 * width + 0.001, -0.999], [n + 0.0005, 1.0005], 0.0009765625, 0.93, [0.0, 0.0])])
 
 
 def dam_break_small(nx: int = 64, ny: int = 64, spacing: float = 1.0 / 64.0) -> SceneConfig:

@@ -8,7 +8,7 @@ particle set, inputs resident in HBM.  Every N runs BASELINE.json configs[1] (2D
 uniform-h particles, HybridDFSPH): for N>1 the driver launches one rank per GPU through
 torch.distributed.run and the SAME particle set is split into x-slabs (one per rank, RCCL halo exchange) --
 STRONG scaling, the experiment north_star names ("N=1M at 1, 2, 4 and 8 GPUs").  north_star's second target,
->= 6x from 1 to 8 GPUs at N=8M, is measured in the same invocation on configs[3] (8 386 816 particles) and
+>= 6x from 1 to 8 GPUs at N=8M, is measured in the same invocation on configs[3] (8 388 608 particles) and
 reported under "strong_8m" at every N (at N=1: the whole scene on one GPU).  --scaling weak keeps last
 round's ~1M-particles-per-GPU series as a side experiment.
 
@@ -170,6 +170,13 @@ def main():
             pass
         os.write(real_stdout, (line + "\n").encode())
 
+    t_start = time.perf_counter()
+
+    def leg(name):
+        """progress marks on stderr: which leg of the run a failure (or the driver's clock) belongs to"""
+        if rank == 0:
+            print(f"[bench +{time.perf_counter() - t_start:6.1f}s] {name}", file=sys.stderr, flush=True)
+
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # started by itself (`python bench.py --gpus N`): become the launcher -- one rank per GPU through torch.distributed.run on
@@ -277,6 +284,7 @@ def main():
     # event switches the ROCm queue into per-dispatch profiling for the rest of the process: +~8 us per launch, +0.38 ms per
     # step here -- measured -- so the per-kernel HIP-event timings below come from an instrumented pass that continues the same
     # workload right after the timed region; `value` is never taken from it.)
+    leg(f"timed region: {wl}, {args.warmup} + {args.steps} steps")
     elapsed, warmup_elapsed, div_iters, dens_iters, comm_stats = timed_run(ctx, p, args.warmup, args.steps)
 
     n_local = ctx.n
@@ -292,6 +300,7 @@ def main():
     prof_all, prof_work, ev_overhead_us, marker_excess_us = {}, {}, 0.0, 0.0
     prof_window = None
     if args.profile_steps != 0:
+        leg("instrumented repeat of the timed window")
         ctx.close()
         ctx, _ = make_context(scene, params)
         k_prof = args.steps if not distributed else min(args.steps, 5)   # (the per-kernel numbers that are judged come from the N = 1 run)
@@ -315,6 +324,7 @@ def main():
         prof_window = {"steps": k_prof, "first_step": args.warmup, "same_iteration_counts_as_timed_region": (di2 == div_iters[:k_prof] and de2 == dens_iters[:k_prof]),
                        "marker_excess_us": marker_excess_us, "calibration_launches": cal[0] if cal else 0}
         args.profile_steps = k_prof
+    leg("copy kernel")
     copy_gbs = ctx.profile_copy_bandwidth_gbs(1 << 30) if rank == 0 else 0.0   # achievable HBM rate of this device, same run
     ctx.close()
 
@@ -340,6 +350,7 @@ def main():
                     "mean_div_iterations": float(np.mean(di8)), "mean_density_iterations": float(np.mean(de8)),
                     "comm_rank0": comm_record(st8, args.steps) if distributed else None}
 
+        leg("configs[3]: dam_break_8m")
         strong_8m = run_8m(None)
         if distributed:   # the same run with sweep A forced into one launch / forced split: what the overlap is worth on this node
             strong_8m["sweep_a"] = "library rule (split on slabs of >= 786432 particles)"
@@ -359,6 +370,7 @@ def main():
         P4 = p4f(level_estimation_method="EmptyAngle", merging=True, sharing=True, splitting=True, particle_radius_fine=r_fine,
                  particle_radius_base=50 * r_fine, maximum_surface_distance=0.3)
         config4 = {"workload": f"ratio_stress_4m: {d4}, EmptyAngle level estimation", "n_gpus": world}
+        leg("configs[4]: ratio_stress_4m on the slabs")
         c4 = None
         try:
             scn4 = s4()
@@ -492,13 +504,16 @@ def main():
                             "note": "steps 0..warmup-1 (rest lattice, first launches included); rank 0's clock, not part of `value`"},
     }
     if not args.no_extra and not distributed and wl == "dam_break_1m":
-        out["other_configs"] = [
-            short_run(plib, "dam_break_1m_adaptive"),                                       # configs[2]: 4:1 radius ratio
-            short_run(plib, "ratio_stress_4m", steps=20, warmup=5),                         # configs[4]'s scene (50:1, 4M), no adaptivity
-            short_run(plib, "dam_break_1m", steps=20, warmup=20, level_estimation_method="EmptyAngle",
-                      maximum_surface_distance=0.2, particle_radius_fine=0.0005, particle_radius_base=0.002),   # + level estimation
-        ]
+        out["other_configs"] = []
+        leg("other configs: dam_break_1m_adaptive")
+        out["other_configs"].append(short_run(plib, "dam_break_1m_adaptive"))                                    # configs[2]: 4:1 radius ratio
+        leg("other configs: ratio_stress_4m")
+        out["other_configs"].append(short_run(plib, "ratio_stress_4m", steps=20, warmup=5))                      # configs[4]'s scene (50:1, 4M), no adaptivity
+        leg("other configs: dam_break_1m + EmptyAngle")
+        out["other_configs"].append(short_run(plib, "dam_break_1m", steps=20, warmup=20, level_estimation_method="EmptyAngle",
+                                              maximum_surface_distance=0.2, particle_radius_fine=0.0005, particle_radius_base=0.002))   # + level estimation
     if not args.no_cpu_baseline and not distributed:
+        leg("cpu baseline (oracle)")
         out["cpu_baseline"] = cpu_baseline(scene, params, args.cpu_seconds)
     emit(json.dumps(out))
     if distributed:

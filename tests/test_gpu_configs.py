@@ -1,4 +1,4 @@
-"""BASELINE.json configs[3] (2D dam-break, 8 386 816 particles, slab decomposition) and configs[4] (ratio-stress scene,
+"""BASELINE.json configs[3] (2D dam-break, 8 388 608 particles = configs[1]'s column eight times as wide, slab decomposition) and configs[4] (ratio-stress scene,
 4 004 343 particles at 50:1 radii, IISPH, Sdf2D box, EmptyAngle level estimation) at FULL size, through the C ABI.
 
 configs[3]: against the CPU oracle (bit-exact cell / neighbour indices, positions and densities within 1e-4 after N steps with
@@ -47,7 +47,7 @@ def assert_displacements(g, o):
 
 def test_config3_dam_break_8m_against_the_oracle(product_lib, oracle_lib):
     g, o, P = make_pair(product_lib, oracle_lib, "dam_break_8m", max_iters=3, **FORCED)
-    assert g.n == 8386816
+    assert g.n == 8388608
     p = P.to_ffi()
     for s in range(3):
         sg, so = g.step(p), o.step(p)

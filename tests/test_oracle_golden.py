@@ -148,7 +148,7 @@ def test_scene_counts_baseline_configs():
     assert sc.block_dims(sc.dam_break_1m().blocks[0]) == (1024, 1024)
     a = sc.dam_break_1m_adaptive()
     assert [sc.block_dims(b) for b in a.blocks] == [(1024, 920), (230, 256)]
-    assert sc.block_dims(sc.dam_break_8m().blocks[0]) == (2896, 2896)
+    assert sc.block_dims(sc.dam_break_8m().blocks[0]) == (8192, 1024)
     # media/motivation-scene2.yaml geometry: 150 x 224 (f32 floor of 1.8/0.008 is 224)
     blk = sc.SceneFluidBlock([-0.95, -0.9], [1.2, 1.8], 0.008, 0.93, [0, 0])
     assert sc.block_dims(blk) == (150, 224)
