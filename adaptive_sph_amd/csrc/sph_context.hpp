@@ -59,6 +59,7 @@ struct Options {
     int slab_level_plain = 0;   // SPH_SLAB_LEVEL_PLAIN     slabs: level propagation without frontier marks
     int level_serial = 0;       // SPH_LEVEL_SERIAL         level estimation on the main stream
     int level_batch8 = 0;       // SPH_LEVEL_BATCH8         propagation sweeps in fixed batches of 8
+    int level_queue = 1;        // SPH_LEVEL_QUEUE=0        one context: propagation sweeps over all particles (frontier marks) instead of the compacted frontier
     int no_fuse = 0;            // SPH_NO_FUSE              a_ii / constant field and the non-pressure forces in two sweeps
     int event_wait = 0;         // SPH_EVENT_WAIT           wait on events instead of spinning on mapped words
     int loopback_sync = 0;      // SPH_LOOPBACK_SYNC=1      loopback transport with host waits
@@ -197,6 +198,7 @@ struct sph_ctx {
     DevBuf h2n[2];     // ParticleVec::h2_next (FromDistribution* support-length estimation), ping-pong across the reorder
     DevBuf lam_prev;   // lambda_sum of the previous step in this step's order (estimate_h_next_from_distribution)
     // level estimation (simulation.rs:539-927), sorted order
+    DevBuf lvl_queue;   // the propagation's compacted frontier: two transposed candidate maps, one byte per particle (sph_sweeps.hip: k_level_frontier)
     DevBuf lvl_tmp, lvl_nrm, lvl_state, lvl_when, lvl_mark, flag_surface, flag_insufficient, stash, nl_ext, nlx_ext;
     DevBuf con_thr, con_consumed, con_h, flag_reduced;   // constrain_neighborhood_count
     bool have_reduced = false;

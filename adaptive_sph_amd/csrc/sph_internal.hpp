@@ -248,7 +248,9 @@ struct LevelArgs {
     uint8_t* size_class;
     float* level;                  // the level field (detection output, propagated in place)
     uint32_t* when;                // propagation sweep that assigned the value (sph_sweeps.hip)
-    uint32_t* mark;                // 2 n words: frontier marks, double-buffered by sweep parity
+    uint32_t* mark;                // 2 n words: frontier marks, double-buffered by sweep parity 
+    uint8_t* fmap = nullptr;       // one context: the propagation on a compacted frontier (sph_sweeps.hip: k_level_frontier) -- two candidate
+    uint32_t fmap_lg_s = 0;        //   maps of 64 S bytes, S = 1 << fmap_lg_s >= n / 64 (transposed: particle j at byte (j mod S) 64 + j / S); nullptr: the sweep forms
     float* level_old;
     float* stash_first;            // stash filled right after the detection (SurfaceDistanceFirst) or nullptr
     int center_diff;               // surface_detection_by_center_diff instead of the empty-angle detector

@@ -1031,6 +1031,16 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
         lv.pm_cell = pm_old;
         lv.center_diff = p->level_estimation_method == SPH_LEVEL_CENTER_DIFF;
         lv.replay_step_lists = pm_old != nullptr && !p->use_extended_range_for_level_estimation;   // simulation.rs:2680: no rebuild
+        // the propagation on a compacted frontier (explicit index lists: the extended-range lists; the step's own lists of a uniform
+        // scene are mask words, which the sweep forms replay)
+        lv.fmap = nullptr;
+        if (c->opt.level_queue && !lv.replay_step_lists) {
+            uint32_t lg = 0;
+            while ((64ull << lg) < n) lg++;
+            HIPCHK(c, c->lvl_queue.ensure((size_t)128 << lg));
+            lv.fmap = c->lvl_queue.as<uint8_t>();
+            lv.fmap_lg_s = lg;
+        }
         if (lv.replay_step_lists) {
             m.a.nl_ext = m.a.nl;
             m.a.nlx_ext = m.a.nlx;

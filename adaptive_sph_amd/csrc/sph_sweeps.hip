@@ -520,6 +520,10 @@ __device__ __forceinline__ void sweep_particle(const Op& op, const SweepCommon& 
 template <class Op, bool BUILD>
 __device__ __forceinline__ void sweep_block(const Op& op, const SweepCommon& c);
 
+// (A form with FEWER workgroups than tiles, each looping over tiles raw, raw + gridDim.x, ..., was measured in round 4 for the steps
+//  that run a level propagation on the side stream -- a dispatch with more workgroups than the device holds keeps the workgroup
+//  dispatcher to itself, scripts/ubench/two_queues.hip -- and removed: the loop around the tile costs the headline 4.7 % (1.075 ->
+//  1.126 ms/step) and the side stream's launches still waited for the main queue to drain: profiles/r4_level_frontier.md.)
 template <class Op, bool BUILD>
 __global__ __launch_bounds__(SWEEP_THREADS) void k_sweep(Op op, SweepCommon c)
 {
@@ -2299,6 +2303,208 @@ struct OpLevelPropagateT {
     __device__ Second second() const { return Second{m, pm, pm_cell, when, mark_next, k, t}; }
 };
 
+// ---- the propagation on a COMPACTED FRONTIER (one context) ---------------------------------------------
+// The frontier form above still launches N / 256 blocks per sweep and reads 8 bytes of (when, mark) per particle to find the few
+// thousand candidates of the sweep, and a candidate then walks its list on ONE lane in dependent trips of four: 104 launches x 13 us
+// at N = 2^20, running alone.  Here the candidates of sweep t are the set bytes of a MAP with one byte per particle: a particle
+// assigned in sweep t stores a 1 into the bytes of its unassigned list neighbours in the map of sweep t + 1 (plain byte stores, no
+// atomics: every writer writes the same value), and sweep t + 1 is a launch of N / 8 lanes, each reading eight bytes of the map.
+// The map is TRANSPOSED -- particle j = q S + r sits at byte ((r + q P) mod S) 64 + q, S = 2^k >= N / 64, P odd -- so that consecutive particles (the
+// frontier is a band: the free surface of a dam break is two or three rows of cells) land eight lanes apart: a wave then holds ~8
+// candidates, one per group of G = 8 lanes, and the group works on its candidate together -- lane l takes the index quads l, l + G,
+// ... of the explicit list, so a list of up to 32 neighbours is ONE round of gathers (when, level, position), the eight partial
+// maxima meet through __shfl_xor.  A lane's chain is three dependent loads (map word; own record + list word + index quad;
+// neighbours) instead of eleven, and no value-returning atomic sits in it (on this device an agent-scope atomic is performed at
+// the memory side, 2-3 us per round trip: a first form with a queue, atomicMax marks and an atomic tail took 16 us per sweep).
+// The values are those of the other forms bit for bit: a particle is assigned once, in the first sweep in which a neighbour inside its
+// range had a value, with the exact maximum over the neighbours that had one when the sweep started (fmaxf is order-independent on
+// finite values; `when < t` is the sweep's snapshot).  Candidates without an explicit index list (more than NLX_CAP neighbours:
+// they walk their candidates) take the generic path through sweep_particle on one lane of their group; sweep 0 (the surface
+// particles mark their neighbours) is the generic sweep over all particles with the same op.
+struct LevelFrontier {
+    uint64_t* __restrict__ cur;    // the map of this sweep (eight particles' bytes per word), cleared by its readers
+    uint8_t* __restrict__ next;    // the map of sweep t + 1
+    uint32_t lg_s, n_words;        // S = 1 << lg_s; words per map = 8 S
+    // particle j = q S + r0 sits at byte r 64 + q with r = (r0 + q P) mod S: the skew by an odd P per q keeps particles that are a
+    // multiple of S / 2^k apart (the ends of the cell rows of a 1024-wide lattice: the vertical part of the band) out of each other's group
+    static constexpr uint32_t SKEW = 0x9E3779B1u;
+    __device__ __forceinline__ uint32_t slot_of(uint32_t j) const
+    {
+        const uint32_t q = j >> lg_s, m = (1u << lg_s) - 1u;
+        return (((j + q * SKEW) & m) << 6) | q;
+    }
+    __device__ __forceinline__ uint32_t particle_of(uint32_t slot) const
+    {
+        const uint32_t q = slot & 63u, m = (1u << lg_s) - 1u;
+        return (q << lg_s) | (((slot >> 6) - q * SKEW) & m);
+    }
+    __device__ __forceinline__ void push(uint32_t j) const { next[slot_of(j)] = 1; }
+};
+template <class MathT>
+struct OpLevelPropagateQ {
+    typedef MathT Math;
+    static constexpr bool HAS_EPILOGUE = false, SKIP_SELF = false, EXTENDED = true;
+    typedef NBLevel NB;
+    MathT m;
+    const float4* __restrict__ pm;
+    const float4* __restrict__ pm_cell;
+    float* __restrict__ level;
+    uint32_t* __restrict__ when;
+    LevelFrontier q;
+    uint32_t* __restrict__ changed;
+    float k;
+    uint32_t t;
+    float range_factor, sp_rest_density, useful_above;   // see OpLevelPropagateT
+    struct Acc {
+        float best, r2max;
+        bool have;
+    };
+    __device__ float krange() const { return k; }
+    __device__ bool skip() const { return false; }
+    __device__ bool lane_skip(uint32_t i) const { return t == 0u ? when[i] != 0u : when[i] != LVL_UNASSIGNED; }
+    __device__ void init(Acc&) const {}
+    __device__ void epilogue(Acc&, bool, uint32_t) const {}
+    __device__ float2 cell_pos(uint32_t i, const float4& Ai) const
+    {
+        if (!pm_cell) return make_float2(Ai.x, Ai.y);
+        const float4 c = pm_cell[i];
+        return make_float2(c.x, c.y);
+    }
+    __device__ float4 loadA(uint32_t j) const { return pm[j]; }
+    __device__ NB nb(const Acc&, uint32_t j, float4) const { return NB{when[j], level[j], j}; }
+    __device__ void begin(Acc& a, uint32_t, float4 Ai) const
+    {
+        a.best = 0.f;
+        a.have = false;
+        a.r2max = level_range_sq(Ai.z, range_factor, sp_rest_density);
+    }
+    __device__ void pair(Acc& a, float4, NB Bj, float, float, float r2, float) const
+    {
+        if (Bj.w == LVL_UNASSIGNED) q.push(Bj.j);
+        if (!(Bj.w < t)) return;
+        if (r2 > a.r2max) return;
+        const float est = Bj.lv - sqrtf(r2);
+        a.best = a.have ? fmaxf(a.best, est) : est;
+        a.have = true;
+    }
+    __device__ bool finish(Acc& a, uint32_t i, float4, bool) const
+    {
+        if (t > 0u && a.have) {
+            level[i] = a.best;
+            when[i] = t;
+            if (a.best > useful_above) *changed = 1u;
+        }
+        return false;
+    }
+};
+
+#ifdef LEVEL_FRONTIER_STATS
+__device__ unsigned long long g_lf_stats[8];   // launches with work, waves with work, rounds, candidates, pushes, second trips
+extern "C" void sph_debug_frontier_stats(unsigned long long* out)
+{
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lf_stats), sizeof(g_lf_stats));
+    unsigned long long z[8] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lf_stats), z, sizeof(z));
+}
+#define LF_STAT(K, V) atomicAdd(&g_lf_stats[K], (unsigned long long)(V))
+#else
+#define LF_STAT(K, V)
+#endif
+template <class Op>
+__device__ __forceinline__ void level_frontier_body(const Op& op, const SweepCommon& c)
+{
+    constexpr int G = 8;   // lanes per candidate == map bytes per lane == the transposition's lane stride
+    const uint32_t tid = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u, gl = lane & (uint32_t)(G - 1), grp = lane & ~(uint32_t)(G - 1);
+    uint64_t w = tid < op.q.n_words ? op.q.cur[tid] : 0ull;
+    if (w) op.q.cur[tid] = 0ull;   // (this map is the "next" of sweep t + 1)
+    const uint32_t t = op.t;
+    const float NEG_INF = __uint_as_float(0xff800000u);
+#ifdef LEVEL_FRONTIER_STATS
+    const bool wave_has_work = __any(w != 0ull);
+    if (lane == 0 && wave_has_work) LF_STAT(1, 1);
+#endif
+    while (__any(w != 0ull)) {
+        if (lane == 0) LF_STAT(2, 1);
+        // every group of G lanes takes ONE candidate per round: the lowest set byte of its lowest lane that has one
+        const uint64_t have = __ballot(w != 0ull);
+        const uint32_t gm = (uint32_t)(have >> grp) & 0xffu;
+        const uint32_t src = grp + (gm ? (uint32_t)__ffs(gm) - 1u : 0u);
+        const uint32_t lb = w ? ((uint32_t)__ffsll((unsigned long long)w) - 1u) >> 3 : 0u;
+        const uint32_t mine = op.q.particle_of(tid * 8u + lb);
+        if (lane == src && w) w &= ~(0xffull << (lb * 8u));
+        const uint32_t i = __shfl(mine, src, 64);
+        const bool in = gm != 0u && i < c.n;
+        // own record, list word and this lane's first index quad in one round (the quad is read before the list's length is known:
+        // the index-list array holds NLX_GROUPS quads for every particle)
+        uint32_t wi = 0u;
+        uint4 lw = make_uint4(0, 0, 0, 0), quad = make_uint4(0, 0, 0, 0);
+        float4 Ai = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (in) {
+            wi = op.when[i];
+            lw = c.nl[i];
+            Ai = op.pm[i];
+            quad = c.nlx[(size_t)gl * c.n + i];
+        }
+        // (a particle may be a candidate of two consecutive sweeps: a neighbour saw it unassigned while its own sweep assigned it)
+        const bool cand = in && wi == LVL_UNASSIGNED;
+        if (gl == 0 && in) LF_STAT(6, 1);
+        if (gl == 0 && cand) LF_STAT(3, 1);
+        const bool fast = cand && (lw.w & NL_IDX) != 0u;
+        const uint32_t ni = fast ? (lw.w & 0xffffu) : 0u;
+        const float r2max = level_range_sq(Ai.z, op.range_factor, op.sp_rest_density);
+        float best = NEG_INF;
+        for (uint32_t g0 = 0; __any(g0 * 4u < ni); g0 += (uint32_t)G) {
+            const uint32_t g = g0 + gl;
+            const bool gv = g * 4u < ni;
+            if (g0 && gv) quad = c.nlx[(size_t)g * c.n + i];
+            if (g0 && gv) LF_STAT(5, 1);
+            const uint32_t nv = gv ? min(ni - g * 4u, 4u) : 0u;   // valid entries of the quad
+            const uint32_t j0 = nv ? quad.x : i;
+            const uint32_t jj[4] = {j0, nv > 1u ? quad.y : j0, nv > 2u ? quad.z : j0, nv > 3u ? quad.w : j0};
+            uint32_t wj[4];
+            float lv[4];
+            float4 A[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                wj[k] = op.when[jj[k]];
+                lv[k] = op.level[jj[k]];
+                A[k] = op.pm[jj[k]];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if ((uint32_t)k >= nv) continue;
+                // the unassigned neighbours are the candidates of sweep t + 1
+                if (wj[k] == LVL_UNASSIGNED) {
+                    op.q.push(jj[k]);
+                    LF_STAT(4, 1);
+                }
+                const float dx = Ai.x - A[k].x, dy = Ai.y - A[k].y;
+                const float r2 = dx * dx + dy * dy;
+                if (wj[k] < t && !(r2 > r2max)) best = fmaxf(best, lv[k] - sqrtf(r2));
+            }
+        }
+#pragma unroll
+        for (int d = G / 2; d >= 1; d >>= 1) best = fmaxf(best, __shfl_xor(best, d, 64));
+        if (fast && gl == 0u && best > NEG_INF) {
+            op.level[i] = best;
+            op.when[i] = t;
+            if (best > op.useful_above) *op.changed = 1u;
+        }
+        if (cand && !fast && gl == 0u) {   // no explicit index list: the generic path on one lane
+            typename Op::Acc acc;
+            op.init(acc);
+            sweep_particle<Op, false>(op, c, acc, i, Ai, lw);
+        }
+    }
+}
+
+template <class Op>
+__global__ __launch_bounds__(256) void k_level_frontier(Op op, SweepCommon c)
+{
+    level_frontier_body(op, c);
+}
+
 // (Measured negatives, round 3 -- profiles/r3_variants.md: (1) the whole propagation as ONE persistent launch, 256 resident
 //  workgroups, a progress word per workgroup as grid barrier, every shared word moved with agent-scope (sc1) loads and stores:
 //  67 us per sweep, 7.8 ms per step against 2.2 -- a frontier lane's chain is five dependent round trips, and an sc1 round trip
@@ -3106,9 +3312,32 @@ template <class M>
 using OpLevelPropagate = OpLevelPropagateT<M, false>;
 template <class M>
 using OpLevelPropagateSlab = OpLevelPropagateT<M, true>;
+template <class M>
+static void launch_level_frontier(hipStream_t s, const SweepArgs& a, const LevelArgs& l, const M& math, uint32_t t, uint32_t* changed)
+{
+    // the map of sweep t at fmap[(t & 1) x 64 S ..]
+    const uint32_t S = 1u << l.fmap_lg_s;
+    const size_t map_bytes = (size_t)S * 64u;
+    LevelFrontier q{(uint64_t*)(l.fmap + ((t & 1u) ? map_bytes : 0u)), l.fmap + ((t & 1u) ? 0u : map_bytes), l.fmap_lg_s, S * 8u};
+    OpLevelPropagateQ<M> op{math, a.pm, l.pm_cell, l.level, l.when, q, changed, l.k, t, l.maximum_range, a.sp.rest_density, -l.max_surface_distance};
+    if (t == 0u) {   // the surface particles mark their neighbours: the generic sweep over all particles
+        (void)hipMemsetAsync(l.fmap, 0, 2 * map_bytes, s);
+        launch_sweep<OpLevelPropagateQ<M>, false>(s, a, op);
+        return;
+    }
+    SweepCommon c = common_of(a, true);
+    hipLaunchKernelGGL((k_level_frontier<OpLevelPropagateQ<M>>), dim3((S * 8u + 255u) / 256u), dim3(256), 0, s, op, c);
+}
+
 void launch_level_propagate(hipStream_t s, Profiler* prof, const SweepArgs& a, const LevelArgs& l, uint32_t t, uint32_t* changed)
 {
     ProfScope ps(prof, "level_propagate", s, true);
+    if (l.fmap && a.n) {   // one context: the compacted frontier
+        if (a.exact) launch_level_frontier(s, a, l, MathExact{0.f}, t, changed);
+        else if (a.uniform_h) launch_level_frontier(s, a, l, uniform_math(a.h_uniform), t, changed);
+        else launch_level_frontier(s, a, l, MathFast{0.f}, t, changed);
+        return;
+    }
     const uint32_t* mark_cur = l.mark + ((t & 1u) ? a.n : 0u);
     uint32_t* mark_next = l.mark + ((t & 1u) ? 0u : a.n);
     if (l.plain_propagate == 2) {

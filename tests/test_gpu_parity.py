@@ -962,6 +962,52 @@ def test_reference_media_recipes(product_lib, oracle_lib, name):
         _level_fields_match(g, o, p)
 
 
+@pytest.mark.parametrize("scene_name", ["uniform", "two_sizes", "ratio12", "default_scene"])
+def test_level_propagation_on_the_compacted_frontier_is_the_sweep_form(product_lib, monkeypatch, scene_name):
+    """The propagation over a queue of candidates (k_level_frontier: G lanes per candidate, pushes deduplicated by atomicMax) against
+    the sweeps over all particles with frontier marks (SPH_LEVEL_QUEUE=0): every level-estimation output bit for bit, the same number
+    of sweeps, over several steps.  "ratio12": coarse particles with more neighbours than an index list holds -- the queue's
+    generic path through sweep_particle."""
+    fine = 0.02
+    scenes = {
+        "uniform": lambda: sc.dam_break_small(96, 80, 1 / 96),
+        "two_sizes": lambda: sc.SceneConfig(sc.SceneBoundary("box", 3.0, 3.0),
+                                            [sc.SceneFluidBlock([-0.95, -0.5], [0.55, 1.4], fine, 0.93, [0.5, 0]),
+                                             sc.SceneFluidBlock([-0.40 + 0.3 * fine * 4, -0.5], [0.7, 1.4], fine * 4, 0.93, [-0.5, 0])]),
+        "ratio12": lambda: sc.SceneConfig(sc.SceneBoundary("box", 3.0, 3.0),
+                                          [sc.SceneFluidBlock([-0.95, -0.5], [0.55, 1.4], fine, 0.93, [0.5, 0]),
+                                           sc.SceneFluidBlock([-0.40 + 0.3 * fine * 12, -0.5], [0.7, 1.4], fine * 12, 0.93, [-0.5, 0])]),
+        "default_scene": lambda: sc.SceneConfig.from_yaml(str(Path(__file__).resolve().parent / "golden" / "default-scene.yaml")),
+    }
+    scn = scenes[scene_name]()
+    pos, mass, vel = sc.init_particles(scn)
+    planes = sc.boundary_planes(scn.boundary)
+    if scene_name == "default_scene":
+        P = default_params(merging=False, sharing=False, splitting=False)
+    else:
+        P = dam_break_params(level_estimation_method="EmptyAngle", maximum_surface_distance=0.2, particle_radius_fine=0.004, particle_radius_base=0.02)
+    P.fill_stash_with = "SurfaceDistanceMiddle"
+    p = P.to_ffi()
+    ctx = {}
+    for form in ("queue", "sweeps"):
+        if form == "sweeps":
+            monkeypatch.setenv("SPH_LEVEL_QUEUE", "0")
+        ctx[form] = ffi.Context(product_lib, len(mass), planes)   # (the switches are read at sph_create)
+        if form == "sweeps":
+            monkeypatch.delenv("SPH_LEVEL_QUEUE")
+        ctx[form].upload(mass, pos, vel)
+    for s in range(5):
+        sa, sb = ctx["queue"].step(p), ctx["sweeps"].step(p)
+        assert sa.dt == sb.dt
+        for f in ("level_estimation", "level_old", "stash", "flag_is_fluid_surface", "flag_insufficient_neighs", "position"):
+            a, b = ctx["queue"].download(f), ctx["sweeps"].download(f)
+            assert np.array_equal(a, b, equal_nan=True), (s, f)
+    lv = ctx["queue"].download("level_estimation")
+    assert np.isfinite(lv).all() and lv.min() < -0.05     # the field reaches into the fluid
+    for c in ctx.values():
+        c.close()
+
+
 def test_run_to_run_determinism(product_lib):
     """No atomics on values, fixed reduction orders, a stable sort: two runs of the same scene agree to the last bit
     (the reference's rayon reductions do not)."""
