@@ -59,6 +59,7 @@ struct Options {
     int slab_level_plain = 0;   // SPH_SLAB_LEVEL_PLAIN     slabs: level propagation without frontier marks
     int level_serial = 0;       // SPH_LEVEL_SERIAL         level estimation on the main stream
     int level_batch8 = 0;       // SPH_LEVEL_BATCH8         propagation sweeps in fixed batches of 8
+    int offset_lists = 1;       // SPH_OFFSET_LISTS=0       the Jacobi sweeps of uniform scenes replay the mask words instead of the 16-bit offset lists
     int level_queue = 1;        // SPH_LEVEL_QUEUE=0        one context: propagation sweeps over all particles (frontier marks) instead of the compacted frontier
     int no_fuse = 0;            // SPH_NO_FUSE              a_ii / constant field and the non-pressure forces in two sweeps
     int event_wait = 0;         // SPH_EVENT_WAIT           wait on events instead of spinning on mapped words
@@ -180,6 +181,7 @@ struct sph_ctx {
     GridP fgrid{};          // the grid the particles are sorted by (== grid in uniform scenes)
     int tile_ts = 0, tile_tsx = 0, tile_tsy = 0;
     DevBuf tile_raw, tile_h, tile_h_ext, nlx;
+    DevBuf nloff, nlh;   // relative-offset lists + header words (uniform scenes whose solves run on records; sph_sweeps.hip: k_sweep_off)
     // Neighbour build AHEAD (one context, uniform scenes; sph_step.hip: queue_ahead_build): the NEXT step's cell sort, reorder and
     // cell-range table are queued behind this step's integrating tail, on a grid predicted from this step's bounding box plus a
     // margin -- the device works on them while the host finishes the step, returns, and enters the next one (the step boundary was

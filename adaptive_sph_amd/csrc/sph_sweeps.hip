@@ -81,6 +81,9 @@ struct SweepCommon {
     const uint32_t* __restrict__ elist_a;
     const uint32_t* __restrict__ elist_b;
     uint32_t n_ea, n_eb;
+    // relative-offset lists (k_sweep_off; nullptr: not built this step)
+    const uint4* __restrict__ nloff;
+    const uint32_t* __restrict__ nlh;
     // Profiler mode 3 (else nullptr): this launch's timestamp slot -- ts[0] receives the earliest block start, ts[TS_RING] the latest
     // block end, on the device's constant 100 MHz clock (sph_internal.hpp)
     unsigned long long* ts;
@@ -575,6 +578,156 @@ __device__ __forceinline__ void sweep_block(const Op& op, const SweepCommon& c)
         }
     }
     if (Op::HAS_EPILOGUE) op.epilogue(acc, active, blk);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Replay on RELATIVE-OFFSET LISTS (round 4; VERDICT round 3 item 7, profiles/r4_jacobi_lab.md: sweep B 19.7 -> 16.5 us and sweep A
+// 19.9 -> 16.0 us stand-alone on the rest lattice, 25.8 -> 20.1 and 27.4 -> 20.0 jittered).  The neighbours of a particle of a
+// cell-sorted array sit within two cell rows of it -- a few thousand slots -- so j - i fits 16 bits.  k_offsets_from_masks turns the
+// mask word of every particle into up to NLOFF_SLOTS such offsets once per step, in the masks' visiting order (rows bottom to top,
+// index ascending: the sums are those of the mask replay bit for bit), the particle itself left out and the slots behind the count
+// holding 0 = the particle itself, whose pair term in a gradient sweep is exactly zero (dx = dy = 0, W'(q) / r finite: MathUniform::
+// gscale).  A slot then costs one v_bfe_i32 / v_ashrrev_i32 and one add where the mask replay spends ffs / and / compare / select / add,
+// no slot carries a predicate, and the head of the sweep needs neither the two IEEE divisions of the cell index nor the three
+// dependent cell_start loads -- the neighbours' gathers go out one round trip after the wave starts instead of two.
+// Header word nlh[i]: bits 0..7 count, NLH_OK list valid (mask list, <= NLOFF_SLOTS neighbours, every offset within 16 bits),
+// NLH_WALL = NL_WALL.  A lane without NLH_OK takes the mask path (sweep_particle) inside the same launch.
+// Ops: `static constexpr bool OFF16 = true` -- uniform-h gradient sweeps whose loadA() returns the whole gathered record and whose
+// pair term of the particle with itself is exactly zero (SKIP_SELF).
+// ------------------------------------------------------------------------------------------------
+#define NLOFF_QUADS 3
+#define NLOFF_SLOTS (8 * NLOFF_QUADS)
+#define NLH_OK 0x200u
+#define NLH_WALL 0x100u
+__global__ __launch_bounds__(256) void k_offsets_from_masks(uint32_t n, GridP g, const float4* __restrict__ pm, const uint32_t* __restrict__ cell_start,
+                                                            const uint4* __restrict__ nl, const uint8_t* __restrict__ owned, const uint8_t* __restrict__ ring1,
+                                                            uint4* __restrict__ nloff, uint32_t* __restrict__ nlh)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    if (owned && !owned[i] && !(ring1 && ring1[i])) {   // (slab decomposition: the outer ghosts carry no list)
+        nlh[i] = 0u;
+        return;
+    }
+    const uint4 lw = nl[i];
+    uint32_t head = (lw.w & NL_WALL) ? NLH_WALL : 0u;
+    if (!(lw.w & NL_OK)) {
+        nlh[i] = head;
+        return;
+    }
+    const float4 Ai = pm[i];
+    const int cx = (int)floorf(Ai.x / g.cs) - g.minx;
+    const int cy = (int)floorf(Ai.y / g.cs) - g.miny;
+    uint32_t out[4 * NLOFF_QUADS];
+#pragma unroll
+    for (int k = 0; k < 4 * NLOFF_QUADS; k++) out[k] = 0u;
+    uint32_t cnt = 0;
+    bool fits = true;
+    const uint32_t masks[3] = {lw.x, lw.y, lw.z};
+#pragma unroll
+    for (int dr = 0; dr < 3; dr++) {
+        const int yy = cy + dr - 1;
+        const bool ok = yy >= 0 && yy < g.sy;
+        const uint32_t rb = ok ? cell_start[(uint32_t)(ok ? yy : 0) * (uint32_t)g.sx + (uint32_t)max(cx - 1, 0)] : 0u;
+        uint32_t mk = masks[dr];
+        if (dr == 1) {   // the particle itself is on the reference's list; its pair term in the gradient sweeps is zero
+            const uint32_t sb = i - rb;
+            if (sb < 32u) mk &= ~(1u << sb);
+        }
+        while (mk) {
+            const uint32_t b = (uint32_t)__ffs(mk) - 1u;
+            mk &= mk - 1u;
+            const int d = (int)(rb + b) - (int)i;
+            fits = fits && d >= -32768 && d <= 32767 && cnt < (uint32_t)NLOFF_SLOTS;
+            if (cnt < (uint32_t)NLOFF_SLOTS) {
+                // (dynamic index into a register array would go through scratch: a select chain over the 12 words instead)
+                const uint32_t half = ((uint32_t)d & 0xffffu) << ((cnt & 1u) * 16u);
+#pragma unroll
+                for (int k = 0; k < 4 * NLOFF_QUADS; k++) out[k] |= (cnt >> 1) == (uint32_t)k ? half : 0u;
+            }
+            cnt++;
+        }
+    }
+    if (fits) head |= NLH_OK | cnt;
+    nlh[i] = head;
+    if (fits) {
+#pragma unroll
+        for (int q = 0; q < NLOFF_QUADS; q++)
+            // (the sweep reads quads 0 and 1 of every list before it knows the count: both are always written -- zeros = the particle
+            //  itself behind the count; quad 2 only when the list is longer than 16, and the sweep does not look at it otherwise)
+            if (q < 2 || cnt > (uint32_t)(8 * q)) nloff[(size_t)q * n + i] = make_uint4(out[4 * q], out[4 * q + 1], out[4 * q + 2], out[4 * q + 3]);
+    }
+}
+
+template <class Op, class = void>
+struct OpOff16 : std::false_type {};
+template <class Op>
+struct OpOff16<Op, std::void_t<decltype(Op::OFF16)>> : std::bool_constant<Op::OFF16> {};
+
+template <class Op>
+__global__ __launch_bounds__(SWEEP_THREADS) void k_sweep_off(Op op, SweepCommon c)
+{
+    typedef typename Op::Math Math;
+    static_assert(Math::UNIFORM && Op::SKIP_SELF && !Op::EXTENDED, "k_sweep_off: uniform-h gradient sweeps");
+    sweep_stamp(c.ts, false);
+    if (!OpPrologue<Op>::run(op, blockIdx.x)) {
+        const uint32_t per_xcd = (c.nblocks + 7) >> 3;
+        const uint32_t blk = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+        if (blk < c.nblocks) {
+            uint32_t i = blk * SWEEP_THREADS + threadIdx.x;
+            if (c.part == 2) i = i < c.n_ea ? c.elist_a[i] : (i < c.n_ea + c.n_eb ? c.elist_b[i - c.n_ea] : c.n);   // (launch-uniform test)
+            const uint32_t ic = i < c.n ? i : 0;
+            // the record, the header and the first two offset quads are requested together (one round trip at the head of the wave)
+            const float4 Ai = op.loadA(ic);
+            const uint32_t head = c.nlh[ic];
+            const uint4 q0 = c.nloff[ic], q1 = c.nloff[(size_t)c.n + ic];
+            const bool slab = c.owned != nullptr;   // launch-uniform
+            const bool mine = !slab || c.owned[ic] || (OpRing1<Op>::value && c.ring1 && c.ring1[ic]);
+            const bool active = i < c.n && mine && !op.lane_skip(i) && !(c.part == 1 && c.edge[ic]);
+            typename Op::Acc acc;
+            op.init(acc);
+            if (active && (head & NLH_OK)) {
+                op.begin(acc, i, Ai);
+                const uint32_t cnt = head & 0xffu;
+#define SPH_OFF_SLOT(D)                                                                                        \
+    {                                                                                                          \
+        const float4 Aj = op.loadA(i + (uint32_t)(D));                                                         \
+        const float dx = Ai.x - Aj.x, dy = Ai.y - Aj.y;                                                        \
+        op.pair(acc, Aj, typename Op::NB{}, dx, dy, dx * dx + dy * dy, op.m.h);                                \
+    }
+#define SPH_OFF_TRIP(WA, WB)                                                                                   \
+    {                                                                                                          \
+        const int d0 = (int)((WA) << 16) >> 16, d1 = (int)(WA) >> 16, d2 = (int)((WB) << 16) >> 16, d3 = (int)(WB) >> 16; \
+        const float4 A0 = op.loadA(i + (uint32_t)d0), A1 = op.loadA(i + (uint32_t)d1), A2 = op.loadA(i + (uint32_t)d2), A3 = op.loadA(i + (uint32_t)d3); \
+        SPH_OFF_PAIR(A0) SPH_OFF_PAIR(A1) SPH_OFF_PAIR(A2) SPH_OFF_PAIR(A3)                                    \
+    }
+#define SPH_OFF_PAIR(AJ)                                                                                       \
+    {                                                                                                          \
+        const float dx = Ai.x - AJ.x, dy = Ai.y - AJ.y;                                                        \
+        op.pair(acc, AJ, typename Op::NB{}, dx, dy, dx * dx + dy * dy, op.m.h);                                \
+    }
+                // (the trips are wave-uniform: the longest list of the wave decides; a shorter one evaluates its own record, for nothing)
+                SPH_OFF_TRIP(q0.x, q0.y)
+                if (__any(cnt > 4u)) SPH_OFF_TRIP(q0.z, q0.w)
+                if (__any(cnt > 8u)) SPH_OFF_TRIP(q1.x, q1.y)
+                if (__any(cnt > 12u)) SPH_OFF_TRIP(q1.z, q1.w)
+                if (__any(cnt > 16u)) {
+                    const uint4 q2 = c.nloff[2 * (size_t)c.n + i];   // (written only for lists longer than 16)
+                    const uint4 q2v = cnt > 16u ? q2 : make_uint4(0, 0, 0, 0);
+                    SPH_OFF_TRIP(q2v.x, q2v.y)
+                    if (__any(cnt > 20u)) SPH_OFF_TRIP(q2v.z, q2v.w)
+                }
+#undef SPH_OFF_TRIP
+#undef SPH_OFF_PAIR
+#undef SPH_OFF_SLOT
+                op.finish(acc, i, Ai, (head & NLH_WALL) != 0u);
+            } else if (active) {
+                sweep_particle<Op, false>(op, c, acc, i, Ai, c.nl[i]);   // no offset list: the mask word (or the candidate walk)
+            }
+            if (Op::HAS_EPILOGUE) op.epilogue(acc, active, blk);
+        }
+    }
+    sweep_stamp(c.ts, true);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1550,6 +1703,7 @@ struct OpPressureAccelU : OpPressureAccel<MathT> {
     static_assert(MathT::UNIFORM, "OpPressureAccelU: uniform-h scenes");
     typedef OpPressureAccel<MathT> B;
     static constexpr bool TILE = false, RING1 = true;   // (slab decomposition: the first ghost ring computes its own a^p, as in the base)
+    static constexpr bool OFF16 = true;                 // (k_sweep_off: relative-offset lists)
     typedef NBNone NB;
     const float4* __restrict__ rec;   // of the pressure buffer this iteration reads (slabs: the ghosts' records carry their owners' p / rho^2, refreshed every iteration)
     struct Acc {
@@ -1823,6 +1977,7 @@ struct OpJacobiU : OpJacobi<MathT> {
     typedef OpJacobi<MathT> B;
     typedef typename B::Acc Acc;
     static constexpr bool TILE = false;
+    static constexpr bool OFF16 = true;   // (k_sweep_off: relative-offset lists)
     typedef NBNone NB;
     __device__ float4 loadA(uint32_t j) const { return this->pacc[j]; }
     __device__ NB nb(const Acc&, uint32_t, float4) const { return NB{}; }
@@ -2888,7 +3043,7 @@ __global__ __launch_bounds__(256) void k_integrate(uint32_t n, float dt, float v
 static SweepCommon common_of(const SweepArgs& a, bool ext)
 {
     return SweepCommon{a.g, ext ? a.t_ext : a.t, a.n, (a.n + SWEEP_THREADS - 1) / SWEEP_THREADS, a.cell_start, ext ? a.nl_ext : a.nl, ext ? a.nlx_ext : a.nlx, a.owned, a.ring1,
-                       0, nullptr, nullptr, nullptr, 0u, 0u, nullptr};
+                       0, nullptr, nullptr, nullptr, 0u, 0u, ext ? nullptr : a.nloff, ext ? nullptr : a.nlh, nullptr};
 }
 
 // SPH_TILE: bit 0 = the BUILD sweep (density), bit 1 = the replay sweeps through the LDS-staged form (k_sweep_tile) in
@@ -2936,11 +3091,23 @@ static void launch_sweep(hipStream_t s, const SweepArgs& a, const Op& op)
         c.n_eb = a.n_eb;
         if (a.part == 2) c.nblocks = (a.n_ea + a.n_eb + SWEEP_THREADS - 1) / SWEEP_THREADS;
         if (c.nblocks == 0) c.nblocks = 1;   // (the launch's prologue still runs)
+        if constexpr (!BUILD && OpOff16<Op>::value) {
+            if (a.nloff) {
+                launch_sweep_kernel(k_sweep_off<Op>, dim3(((c.nblocks + 7) / 8) * 8), s, a, op, c);
+                return;
+            }
+        }
         launch_sweep_kernel(k_sweep<Op, BUILD>, dim3(((c.nblocks + 7) / 8) * 8), s, a, op, c);
         return;
     }
     const uint32_t nblocks = (a.n + SWEEP_THREADS - 1) / SWEEP_THREADS;
     const uint32_t grid = ((nblocks + 7) / 8) * 8;  // XCD remap needs a multiple of 8
+    if constexpr (!BUILD && OpOff16<Op>::value) {
+        if (a.nloff) {
+            launch_sweep_kernel(k_sweep_off<Op>, dim3(grid), s, a, op, common_of(a, false));
+            return;
+        }
+    }
     if constexpr (Op::Math::UNIFORM && !Op::EXTENDED && OpTile<Op>::value) {
         if (tile_mode(a) & (BUILD ? 1 : 2)) {
             launch_sweep_kernel(k_sweep_tile<Op, BUILD>, dim3(grid), s, a, op, common_of(a, Op::EXTENDED));
@@ -2951,6 +3118,13 @@ static void launch_sweep(hipStream_t s, const SweepArgs& a, const Op& op)
 }
 
 size_t sweep_list_bytes(uint32_t n) { return (size_t)n * sizeof(uint4); }
+size_t sweep_offset_list_bytes(uint32_t n) { return (size_t)n * sizeof(uint4) * NLOFF_QUADS; }
+bool sweeps_want_offset_lists(const SweepArgs& a) { return jacobi_on_records(a); }
+void launch_offsets_from_masks(hipStream_t s, Profiler* prof, const SweepArgs& a, uint4* nloff, uint32_t* nlh)
+{
+    ProfScope ps(prof, "offset_lists", s);
+    if (a.n) hipLaunchKernelGGL(k_offsets_from_masks, dim3((a.n + 255) / 256), dim3(256), 0, s, a.n, a.g, a.pm, a.cell_start, a.nl, a.owned, a.ring1, nloff, nlh);
+}
 size_t sweep_index_list_bytes(uint32_t n) { return (size_t)n * sizeof(uint4) * NLX_GROUPS; }
 bool sweep_forces_index_lists() { return SPH_FORCE_IDX != 0; }
 uint32_t solver_reduce_blocks(uint32_t n) { return (n + SWEEP_THREADS - 1) / SWEEP_THREADS; }

@@ -53,6 +53,10 @@ struct Args {
     const float* __restrict__ pt;
     const float4* __restrict__ rec;
     float4* __restrict__ pacc_out;
+    // relative-offset lists (round 4): 24 slots of int16 (j - i) per particle, quad g of particle i at off16[g n + i]; slots behind the
+    // count hold 0 (the particle itself: its pair term is exactly zero in the slim arithmetic); cnt8[i] = number of neighbours
+    const uint4* __restrict__ off16;
+    const uint8_t* __restrict__ cnt8;
 };
 
 __device__ __forceinline__ void grad_uniform(const Math& m, float dx, float dy, float r2, float& gx, float& gy)
@@ -432,6 +436,100 @@ __global__ __launch_bounds__(256) void k_accel_lean(Args A)
         }
     }
     A.pacc_out[i] = make_float4(Ai.x, Ai.y, ax, ay);
+}
+
+// ---- variant (round 4): NO mask decoding, NO row bases.  The list is 16-bit offsets j - i (the neighbours of a
+// particle of a cell-sorted array sit within +-(two cell rows) of it: a few thousand slots), flat and row-major like the masks'
+// visiting order, padded with 0 = the particle itself, whose pair term is exactly zero -- so a slot costs one v_bfe_i32 / v_ashrrev and
+// one add instead of ffs / and / compare / select / add, there is no predicate on a slot, and the sweep's head needs neither the two
+// IEEE divisions of the cell index nor the three dependent cell_start loads.  PRED = 1: a slot behind the count is skipped by a branch.
+template <int PRED>
+__global__ __launch_bounds__(256) void k_off16_slim(Args A)
+{
+    const uint32_t blk = remap_block(A.nblocks);
+    if (blk >= A.nblocks) return;
+    const uint32_t i = blk * 256 + threadIdx.x;
+    if (i >= A.n) return;
+    const float4 Ai = A.comb[i];
+    const uint4 q0 = A.off16[i], q1 = A.off16[(size_t)A.n + i];
+    const uint32_t cnt = A.cnt8[i];
+    const float rho_i = A.rho[i];
+    const float aii_i = A.aii[i], src_i = A.src[i], pin_i = A.p_in[i];
+    Acc a;
+    a.sum = 0.f;
+    a.inv_rho = __builtin_amdgcn_rcpf(rho_i);
+    a.qx = Ai.z;
+    a.qy = Ai.w;
+    const float nf6 = 6.f * A.m.nf * A.m.inv2h;
+#define OFF_TRIP(WA, WB, S0)                                                                                              \
+    {                                                                                                                     \
+        const uint32_t j0 = i + (uint32_t)((int)((WA) << 16) >> 16), j1 = i + (uint32_t)((int)(WA) >> 16);                \
+        const uint32_t j2 = i + (uint32_t)((int)((WB) << 16) >> 16), j3 = i + (uint32_t)((int)(WB) >> 16);                \
+        const float4 R0 = A.comb[ix(j0, A.n, 7u)], R1 = A.comb[ix(j1, A.n, 7u)], R2 = A.comb[ix(j2, A.n, 7u)], R3 = A.comb[ix(j3, A.n, 7u)]; \
+        pair_slim(A, a, Ai.x, Ai.y, R0.x, R0.y, R0.z, R0.w, !PRED || (S0) < cnt, nf6);                                    \
+        pair_slim(A, a, Ai.x, Ai.y, R1.x, R1.y, R1.z, R1.w, !PRED || (S0) + 1u < cnt, nf6);                               \
+        pair_slim(A, a, Ai.x, Ai.y, R2.x, R2.y, R2.z, R2.w, !PRED || (S0) + 2u < cnt, nf6);                               \
+        pair_slim(A, a, Ai.x, Ai.y, R3.x, R3.y, R3.z, R3.w, !PRED || (S0) + 3u < cnt, nf6);                               \
+    }
+    OFF_TRIP(q0.x, q0.y, 0u)
+    if (__any(cnt > 4u)) OFF_TRIP(q0.z, q0.w, 4u)
+    if (__any(cnt > 8u)) OFF_TRIP(q1.x, q1.y, 8u)
+    if (__any(cnt > 12u)) OFF_TRIP(q1.z, q1.w, 12u)
+    if (__any(cnt > 16u)) {
+        const uint4 q2 = A.off16[2 * (size_t)A.n + i];
+        OFF_TRIP(q2.x, q2.y, 16u)
+        if (__any(cnt > 20u)) OFF_TRIP(q2.z, q2.w, 20u)
+    }
+#undef OFF_TRIP
+    a.sum *= A.mass * a.inv_rho;
+    const float pn = pin_i + A.omega * (src_i - a.sum) / aii_i;
+    const bool pos = pn > 0.f;
+    A.p_out[i] = pos ? pn : 0.f;
+    A.pt_out[i] = pos ? pn / (rho_i * rho_i) : 0.f;
+}
+
+// ... the same list for sweep A on its combined record {x, y, p / rho^2, p}
+__global__ __launch_bounds__(256) void k_accel_off16(Args A)
+{
+    const uint32_t blk = remap_block(A.nblocks);
+    if (blk >= A.nblocks) return;
+    const uint32_t i = blk * 256 + threadIdx.x;
+    if (i >= A.n) return;
+    const float4 Ri = A.rec[i];
+    const uint4 q0 = A.off16[i], q1 = A.off16[(size_t)A.n + i];
+    const uint32_t cnt = A.cnt8[i];
+    const float nf6 = 6.f * A.m.nf * A.m.inv2h;
+    float ax = 0.f, ay = 0.f;
+#define OFF_SLOT(J)                                                                                                       \
+    {                                                                                                                     \
+        const float4 R = A.rec[ix(J, A.n, 8u)];                                                                           \
+        const float dx = Ri.x - R.x, dy = Ri.y - R.y;                                                                     \
+        const float r2 = fmaxf(dx * dx + dy * dy, 1.0e-30f);                                                              \
+        const float rinv = __builtin_amdgcn_rsqf(r2);                                                                     \
+        const float q = (r2 * rinv) * A.m.inv2h;                                                                          \
+        const float u = fmaxf(1.f - q, 0.f), t = fmaxf(0.5f - q, 0.f);                                                    \
+        const float s = (-A.mass * (Ri.z + R.z)) * (nf6 * fmaf(4.f * t, t, -(u * u)) * rinv);                             \
+        ax = fmaf(s, dx, ax);                                                                                             \
+        ay = fmaf(s, dy, ay);                                                                                             \
+    }
+#define OFF_TRIP(WA, WB)                                                                                                  \
+    {                                                                                                                     \
+        const uint32_t j0 = i + (uint32_t)((int)((WA) << 16) >> 16), j1 = i + (uint32_t)((int)(WA) >> 16);                \
+        const uint32_t j2 = i + (uint32_t)((int)((WB) << 16) >> 16), j3 = i + (uint32_t)((int)(WB) >> 16);                \
+        OFF_SLOT(j0) OFF_SLOT(j1) OFF_SLOT(j2) OFF_SLOT(j3)                                                               \
+    }
+    OFF_TRIP(q0.x, q0.y)
+    if (__any(cnt > 4u)) OFF_TRIP(q0.z, q0.w)
+    if (__any(cnt > 8u)) OFF_TRIP(q1.x, q1.y)
+    if (__any(cnt > 12u)) OFF_TRIP(q1.z, q1.w)
+    if (__any(cnt > 16u)) {
+        const uint4 q2 = A.off16[2 * (size_t)A.n + i];
+        OFF_TRIP(q2.x, q2.y)
+        if (__any(cnt > 20u)) OFF_TRIP(q2.z, q2.w)
+    }
+#undef OFF_TRIP
+#undef OFF_SLOT
+    A.pacc_out[i] = make_float4(Ri.x, Ri.y, ax, ay);
 }
 
 // ---- variant: the three row masks decoded FIRST into up to 16 neighbour indices in registers (row-major, ascending: the same
@@ -1112,7 +1210,32 @@ int main(int argc, char** argv)
         nl[s] = make_uint4(mk[0], mk[1], mk[2], cnt);
         sum_cnt += cnt;
     }
+    // relative-offset lists: the masks' visiting order (rows bottom to top, index ascending) as 16-bit j - i, 24 slots
+    std::vector<uint16_t> off16((size_t)n * 24, 0);
+    std::vector<uint8_t> cnt8(n);
+    uint32_t off_overflow = 0, max_cnt = 0;
+    for (uint32_t s = 0; s < n; s++) {
+        const int cx = (int)(skey[s] % (uint32_t)g.sx), cy = (int)(skey[s] / (uint32_t)g.sx);
+        uint32_t k = 0;
+        const uint32_t mk[3] = {nl[s].x, nl[s].y, nl[s].z};
+        for (int dr = 0; dr < 3; dr++) {
+            const int yy = cy + dr - 1;
+            if (yy < 0 || yy >= g.sy) continue;
+            const uint32_t b = cell_start[(uint32_t)yy * g.sx + std::max(cx - 1, 0)];
+            for (uint32_t bit = 0; bit < 32; bit++)
+                if (mk[dr] & (1u << bit)) {
+                    const long long d = (long long)(b + bit) - (long long)s;
+                    if (d < -32768 || d > 32767 || k >= 24) { off_overflow++; continue; }
+                    // quad g = k / 8 of particle s: 8 halfwords at off16[(g n + s) 8 ..]
+                    off16[((size_t)(k / 8) * n + s) * 8 + (k % 8)] = (uint16_t)(int16_t)d;
+                    k++;
+                }
+        }
+        cnt8[s] = (uint8_t)k;
+        max_cnt = std::max(max_cnt, k);
+    }
     setvbuf(stdout, nullptr, _IOLBF, 0);
+    printf("offset lists: largest count %u, entries that do not fit (24 slots, 16 bits): %u\n", max_cnt, off_overflow);
     printf("n = %u, cells %d x %d, %.2f neighbours per particle (self excluded), %.2f slots per particle in trips of 4 (per lane), rows > 32 candidates: %u\n", n, g.sx,
            g.sy, sum_cnt / n, sum_slots4 / n, overflow);
     std::vector<float> rho(n), aii(n), src(n), pin(n);
@@ -1145,6 +1268,8 @@ int main(int argc, char** argv)
         std::copy(comb.begin(), comb.end(), padded.begin() + 1);
         A.comb = (const float4*)up(padded.data(), (size_t)(n + 1) * 16) + 1;
     }
+    A.off16 = (const uint4*)up(off16.data(), off16.size() * 2);
+    A.cnt8 = (const uint8_t*)up(cnt8.data(), (size_t)n);
     A.rho = (const float*)up(rho.data(), (size_t)n * 4);
     A.aii = (const float*)up(aii.data(), (size_t)n * 4);
     A.src = (const float*)up(src.data(), (size_t)n * 4);
@@ -1189,6 +1314,8 @@ int main(int argc, char** argv)
         {"sweep B lean: r2 + floor", k_gather4_lean<1>, true},
         {"sweep B lean: + no clamp of 1 - q", k_gather4_lean<3>, true},
         {"sweep B lean: + no select on an empty slot's index", k_gather4_lean<7>, true},
+        {"combined record, slim, 16-bit offset list j - i (no mask decoding, no row bases), padding slots = the particle itself, no predicate", k_off16_slim<0>, true},
+        {"combined record, slim, 16-bit offset list, slots behind the count skipped by a branch", k_off16_slim<1>, true},
         {"combined record, slim, masks decoded into 16 indices first, then flat trips of 4 (no per-row padding)", k_flat16_slim, true},
         {"combined record, slim, masks decoded by per-row loops into an LDS column per lane, then flat trips of 4", k_flat_lds_slim, true},
         {"gather4, combined record, slim, next trip's gathers requested before this trip's pairs (rows merged into one trip sequence)", k_gather4_slim_pipe, true},
@@ -1247,6 +1374,7 @@ int main(int argc, char** argv)
             {"sweep A, product form: 16-B record {x, y, m, h} + 4-B p / rho^2, two gathers per slot", k_accel<0>},
             {"sweep A, ONE 16-B gather of a combined record {x, y, p / rho^2, p}", k_accel<1>},
             {"sweep A, combined record, NO branch around the pairs", k_accel_nobranch},
+            {"sweep A, combined record, 16-bit offset list (no mask decoding, no row bases, no predicate)", k_accel_off16},
             {"sweep A lean: r2 + floor", k_accel_lean<1>},
             {"sweep A lean: + no clamp of 1 - q", k_accel_lean<3>},
             {"sweep A lean: + no select on an empty slot's index", k_accel_lean<7>},

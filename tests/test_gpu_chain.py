@@ -168,3 +168,47 @@ def test_record_sweeps_with_masses_one_ulp_apart_stay_within_rounding_of_the_gen
     for f, tol in (("position", 2e-6), ("velocity", 2e-5), ("density", 2e-6), ("pressure", 2e-4)):
         x, y = a.download(f).astype(np.float64), b.download(f).astype(np.float64)
         assert np.abs(x - y).max() <= tol * max(np.abs(y).max(), 1e-30), (f, np.abs(x - y).max() / np.abs(y).max())
+
+
+@pytest.mark.parametrize("compression", [1.0, 0.85, 0.66])
+@pytest.mark.parametrize("solver", ["HybridDFSPH", "IISPH"])
+def test_offset_lists_are_bit_identical_to_the_mask_words(product_lib, monkeypatch, solver, compression):
+    """The two sweeps of a Jacobi iteration on 16-bit relative offsets (k_sweep_off: no mask decoding, no row bases; padding slots =
+    the particle itself) against the replay of the mask words (SPH_OFFSET_LISTS=0): same visiting order, same arithmetic, so every
+    field and every iteration statistic agree bit for bit over free-running steps.  compression < 1: a lattice squeezed below its
+    rest spacing -- 0.85: lists of 17-24 neighbours (the third quad of offsets), 0.66: more than 24 (no offset list: those lanes
+    replay their mask words inside the same launch)."""
+    nx, ny = 96, 80
+    d0 = 1.0 / 64
+    # (a squeezed lattice pushes itself apart violently: short steps, few of them -- the point is the list forms, not the flow)
+    squeezed = dict(max_dt=0.00002, max_iters=4, hybrid_dfsph_max_avg_density_error=0.0, hybrid_dfsph_max_avg_divergence_error=0.0,
+                    iisph_max_avg_density_error=0.0)
+    P = dam_break_params(pressure_solver_method=solver, **(dict(max_dt=0.0005) if compression == 1.0 else squeezed))
+    scn = sc.dam_break_small(nx, ny, d0)
+    pos, mass, vel = sc.init_particles(scn)
+    if compression != 1.0:   # the same masses (the same h) on a tighter lattice
+        pos = (pos[0] + (pos - pos[0]) * np.float32(compression)).astype(np.float32)
+    planes = sc.boundary_planes(scn.boundary, P.init_boundary_handler)
+    p = P.to_ffi()
+    out = {}
+    for form in ("offsets", "masks"):
+        if form == "masks":
+            monkeypatch.setenv("SPH_OFFSET_LISTS", "0")
+        g = ffi.Context(product_lib, len(mass), planes)   # (the switches are read at sph_create)
+        if form == "masks":
+            monkeypatch.delenv("SPH_OFFSET_LISTS")
+        g.upload(mass, pos, vel)
+        its, fields = [], []
+        for _ in range(4 if compression != 1.0 else 25):
+            st = g.step(p)
+            its.append((int(st.div_solver.iters), int(st.density_solver.iters), int(st.density_solver.normal_count),
+                        np.float32(st.density_solver.avg_error).view(np.uint32).item(), np.float32(st.dt).view(np.uint32).item()))
+            fields.append({f: g.download(f) for f in ("position", "velocity", "pressure", "density", "neighbor_count")})
+        out[form] = (its, fields)
+        g.close()
+    assert out["offsets"][0] == out["masks"][0]
+    for s, (fa, fb) in enumerate(zip(out["offsets"][1], out["masks"][1])):
+        for f in fa:
+            assert np.array_equal(fa[f], fb[f]), (s, f)
+    nc = out["offsets"][1][0]["neighbor_count"].max() - 1   # (the reference counts the particle itself)
+    assert {1.0: nc <= 16, 0.85: 16 < nc <= 24, 0.66: nc > 24}[compression], nc
