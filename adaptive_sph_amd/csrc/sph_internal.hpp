@@ -165,6 +165,8 @@ struct SweepArgs {
     const float* lam_prev;
     const uint4* nloff = nullptr;   // relative-offset lists of this step (sph_sweeps.hip: k_sweep_off) and their header words; nullptr: the
     const uint32_t* nlh = nullptr;  //   gradient sweeps of a uniform scene replay the mask words
+    uint4* nloff_out = nullptr;     // the density BUILD sweep writes them (set for that launch only)
+    uint32_t* nlh_out = nullptr;
     uint4* nl_ext;      // list words / index lists of the extended-range lists (level estimation)
     uint4* nlx_ext;
     TileP t;            // stencil bound per tile (multi-resolution scenes; ts = 0: uniform)
@@ -209,7 +211,6 @@ size_t sweep_list_bytes(uint32_t n);
 size_t sweep_index_list_bytes(uint32_t n);   // explicit index lists (multi-resolution scenes)
 size_t sweep_offset_list_bytes(uint32_t n);  // relative-offset lists (uniform scenes whose solves run on records)
 bool sweeps_want_offset_lists(const SweepArgs& a);
-void launch_offsets_from_masks(hipStream_t s, Profiler* prof, const SweepArgs& a, uint4* nloff, uint32_t* nlh);   // behind the density sweep
 bool sweep_forces_index_lists();             // build variant SPH_FORCE_IDX
 uint32_t solver_reduce_blocks(uint32_t n);
 void launch_density(hipStream_t s, Profiler* prof, const SweepArgs& a);

@@ -1311,20 +1311,26 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
     // ---- density + boundary lambda + neighbour count (simulation.rs:2072-2074, 2179-2180, 2204) -----------
     for (auto& m : M) {
         (void)hipSetDevice(m.c->device);
-        if (m.n) launch_density(m.c->stream, &m.c->prof, m.a);
-        if (m.n) launch_profile_calibration(m.c);   // (profiler mode 1 only)
-        if (p->check_neighborhood && m.n) launch_check_neighborhood(m.c, m.a);
-        // uniform scenes whose solves run on records: the mask words as 16-bit relative offsets, once per step, for the two sweeps of
-        // the Jacobi iterations (sph_sweeps.hip: k_sweep_off)
+        // uniform scenes whose solves run on records: the density BUILD sweep also writes the mask words as 16-bit relative offsets, for
+        // the two sweeps of the Jacobi iterations and the source-term sweeps (sph_sweeps.hip: k_sweep_off)
         m.a.nloff = nullptr;
         m.a.nlh = nullptr;
-        if (m.n && m.c->opt.offset_lists && sweeps_want_offset_lists(m.a)) {
+        const bool offsets = m.n && m.c->opt.offset_lists && sweeps_want_offset_lists(m.a);
+        if (offsets) {
             HIPCHK(m.c, m.c->nloff.ensure(sweep_offset_list_bytes((uint32_t)(m.c->cap ? m.c->cap : 1))));
             HIPCHK(m.c, m.c->nlh.ensure((size_t)(m.c->cap ? m.c->cap : 1) * 4));
-            launch_offsets_from_masks(m.c->stream, &m.c->prof, m.a, m.c->nloff.as<uint4>(), m.c->nlh.as<uint32_t>());
+            m.a.nloff_out = m.c->nloff.as<uint4>();
+            m.a.nlh_out = m.c->nlh.as<uint32_t>();
+        }
+        if (m.n) launch_density(m.c->stream, &m.c->prof, m.a);
+        m.a.nloff_out = nullptr;
+        m.a.nlh_out = nullptr;
+        if (offsets) {
             m.a.nloff = m.c->nloff.as<uint4>();
             m.a.nlh = m.c->nlh.as<uint32_t>();
         }
+        if (m.n) launch_profile_calibration(m.c);   // (profiler mode 1 only)
+        if (p->check_neighborhood && m.n) launch_check_neighborhood(m.c, m.a);
     }
     // ---- constrain_neighborhood_count (simulation.rs:2145-2177): h2 of over-populated particles shrinks AFTER the lists are
     // built; boundary terms (:2179), the CFL step (:2182-2191), the densities (:2204) follow with the new values

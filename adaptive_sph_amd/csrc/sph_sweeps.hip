@@ -84,6 +84,8 @@ struct SweepCommon {
     // relative-offset lists (k_sweep_off; nullptr: not built this step)
     const uint4* __restrict__ nloff;
     const uint32_t* __restrict__ nlh;
+    uint4* __restrict__ nloff_out;      // BUILD sweep of a uniform scene: write them (emit_offset_list), else nullptr
+    uint32_t* __restrict__ nlh_out;
     // Profiler mode 3 (else nullptr): this launch's timestamp slot -- ts[0] receives the earliest block start, ts[TS_RING] the latest
     // block end, on the device's constant 100 MHz clock (sph_internal.hpp)
     unsigned long long* ts;
@@ -424,6 +426,61 @@ __device__ __forceinline__ uint32_t predicate_row(const Op& op, const float4 Ai,
     return m;
 }
 
+// BUILD sweep of a uniform scene whose solves run on records: the particle's mask word as 16-bit relative offsets j - i for k_sweep_off
+// (described there), written at the end of the density sweep -- it holds the row bases and the masks in registers; a kernel of its
+// own re-read 32 B and took 18 us for what costs the BUILD sweep ~2.  The halfwords go through a column of LDS per lane ([slot][lane]:
+// conflict-free; a slot number that is only known at run time is an address there, a select chain over twelve registers otherwise).
+#define NLOFF_QUADS 3
+#define NLOFF_SLOTS (8 * NLOFF_QUADS)
+#define NLH_OK 0x200u
+#define NLH_WALL 0x100u
+__device__ __forceinline__ void emit_offset_list(uint4* __restrict__ nloff, uint32_t* __restrict__ nlh, const uint32_t n, const uint32_t i, const uint4 lw,
+                                                 const uint32_t (&rb)[3])
+{
+    __shared__ uint16_t s_half[NLOFF_SLOTS][SWEEP_THREADS];
+    uint32_t head = (lw.w & NL_WALL) ? NLH_WALL : 0u;
+    if (!(lw.w & NL_OK)) {
+        nlh[i] = head;
+        return;
+    }
+    uint32_t cnt = 0;
+    bool fits = true;
+    const uint32_t masks[3] = {lw.x, lw.y, lw.z};
+#pragma unroll
+    for (int dr = 0; dr < 3; dr++) {
+        uint32_t mk = masks[dr];
+        if (dr == 1) {   // the particle itself is on the reference's list; its pair term in the gradient sweeps is zero
+            const uint32_t sb = i - rb[1];
+            if (sb < 32u) mk &= ~(1u << sb);
+        }
+        while (mk) {
+            const uint32_t b = (uint32_t)__ffs(mk) - 1u;
+            mk &= mk - 1u;
+            const int d = (int)(rb[dr] + b) - (int)i;
+            fits = fits && d >= -32768 && d <= 32767 && cnt < (uint32_t)NLOFF_SLOTS;
+            if (cnt < (uint32_t)NLOFF_SLOTS) s_half[cnt][threadIdx.x] = (uint16_t)d;
+            cnt++;
+        }
+    }
+    if (fits) head |= NLH_OK | cnt;
+    nlh[i] = head;
+    if (!fits) return;
+    // (the sweep reads quads 0 and 1 of every list before it knows the count: both are always written -- zeros = the particle itself
+    //  behind the count; quad 2 only when the list is longer than 16, and the sweep does not look at it otherwise)
+#pragma unroll
+    for (int q = 0; q < NLOFF_QUADS; q++) {
+        if (!(q < 2 || cnt > (uint32_t)(8 * q))) continue;
+        uint32_t w[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t s0 = (uint32_t)(8 * q + 2 * k);
+            const uint32_t lo = s0 < cnt ? (uint32_t)s_half[s0][threadIdx.x] : 0u, hi = s0 + 1u < cnt ? (uint32_t)s_half[s0 + 1u][threadIdx.x] : 0u;
+            w[k] = lo | (hi << 16);
+        }
+        nloff[(size_t)q * n + i] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
 // one particle of a sweep, every list form: mask word, explicit index list, candidate walk (3 x 3 cells or a wide stencil)
 // (Ai, lw: the particle's record and list word, loaded by the caller BEFORE it looks at the slab flags -- one memory round trip
 //  at the head of every wave instead of two)
@@ -432,6 +489,7 @@ __device__ __forceinline__ void sweep_particle(const Op& op, const SweepCommon& 
 {
     typedef typename Op::Math Math;
     const GridP g = c.g;
+    uint32_t rb_build[3] = {0u, 0u, 0u};   // (BUILD: the row bases of a 3 x 3 stencil, for emit_offset_list)
     op.begin(acc, i, Ai);
     // explicit index lists exist in multi-resolution scenes and for the extended-range lists of the level estimation
     // SPH_FORCE_IDX (variant): explicit index lists in uniform scenes too -- no mask decoding per neighbour slot, one more coalesced
@@ -491,9 +549,13 @@ __device__ __forceinline__ void sweep_particle(const Op& op, const SweepCommon& 
 #pragma unroll
                     for (int dr = 0; dr < 3; dr++) walk_row<Op, BUILD, false>(op, acc, Ai, rb[dr], re[dr], mk[dr], nacc, rec, c.nlx, c.n, i);
                 }
-                if (BUILD)
+                if (BUILD) {
                     lw = make_uint4(mk[0], mk[1], mk[2],
                                     (nacc & 0xffffu) | (ok_list ? NL_OK : 0u) | (rec_idx && nacc <= NLX_CAP ? NL_IDX : 0u));
+                    rb_build[0] = rb[0];
+                    rb_build[1] = rb[1];
+                    rb_build[2] = rb[2];
+                }
             }
         } else {
             // wide stencil (a large neighbour may be around): (2R+1) rows, explicit index list
@@ -517,6 +579,9 @@ __device__ __forceinline__ void sweep_particle(const Op& op, const SweepCommon& 
     if (BUILD) {
         if (wall) lw.w |= NL_WALL;
         c.nl[i] = lw;
+        if constexpr (Math::UNIFORM && !Op::EXTENDED) {
+            if (c.nloff_out) emit_offset_list(c.nloff_out, c.nlh_out, c.n, i, lw, rb_build);   // (launch-uniform)
+        }
     }
 }
 
@@ -583,7 +648,7 @@ __device__ __forceinline__ void sweep_block(const Op& op, const SweepCommon& c)
 // ------------------------------------------------------------------------------------------------
 // Replay on RELATIVE-OFFSET LISTS (round 4; VERDICT round 3 item 7, profiles/r4_jacobi_lab.md: sweep B 19.7 -> 16.5 us and sweep A
 // 19.9 -> 16.0 us stand-alone on the rest lattice, 25.8 -> 20.1 and 27.4 -> 20.0 jittered).  The neighbours of a particle of a
-// cell-sorted array sit within two cell rows of it -- a few thousand slots -- so j - i fits 16 bits.  k_offsets_from_masks turns the
+// cell-sorted array sit within two cell rows of it -- a few thousand slots -- so j - i fits 16 bits.  The density BUILD sweep (emit_offset_list) turns the
 // mask word of every particle into up to NLOFF_SLOTS such offsets once per step, in the masks' visiting order (rows bottom to top,
 // index ascending: the sums are those of the mask replay bit for bit), the particle itself left out and the slots behind the count
 // holding 0 = the particle itself, whose pair term in a gradient sweep is exactly zero (dx = dy = 0, W'(q) / r finite: MathUniform::
@@ -592,73 +657,9 @@ __device__ __forceinline__ void sweep_block(const Op& op, const SweepCommon& c)
 // dependent cell_start loads -- the neighbours' gathers go out one round trip after the wave starts instead of two.
 // Header word nlh[i]: bits 0..7 count, NLH_OK list valid (mask list, <= NLOFF_SLOTS neighbours, every offset within 16 bits),
 // NLH_WALL = NL_WALL.  A lane without NLH_OK takes the mask path (sweep_particle) inside the same launch.
-// Ops: `static constexpr bool OFF16 = true` -- uniform-h gradient sweeps whose loadA() returns the whole gathered record and whose
-// pair term of the particle with itself is exactly zero (SKIP_SELF).
+// Ops: `static constexpr bool OFF16 = true` -- uniform-h gradient sweeps whose pair term of the particle with itself is exactly zero
+// (SKIP_SELF): the two sweeps of a Jacobi iteration on their records, the source-term sweep.
 // ------------------------------------------------------------------------------------------------
-#define NLOFF_QUADS 3
-#define NLOFF_SLOTS (8 * NLOFF_QUADS)
-#define NLH_OK 0x200u
-#define NLH_WALL 0x100u
-__global__ __launch_bounds__(256) void k_offsets_from_masks(uint32_t n, GridP g, const float4* __restrict__ pm, const uint32_t* __restrict__ cell_start,
-                                                            const uint4* __restrict__ nl, const uint8_t* __restrict__ owned, const uint8_t* __restrict__ ring1,
-                                                            uint4* __restrict__ nloff, uint32_t* __restrict__ nlh)
-{
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    if (owned && !owned[i] && !(ring1 && ring1[i])) {   // (slab decomposition: the outer ghosts carry no list)
-        nlh[i] = 0u;
-        return;
-    }
-    const uint4 lw = nl[i];
-    uint32_t head = (lw.w & NL_WALL) ? NLH_WALL : 0u;
-    if (!(lw.w & NL_OK)) {
-        nlh[i] = head;
-        return;
-    }
-    const float4 Ai = pm[i];
-    const int cx = (int)floorf(Ai.x / g.cs) - g.minx;
-    const int cy = (int)floorf(Ai.y / g.cs) - g.miny;
-    uint32_t out[4 * NLOFF_QUADS];
-#pragma unroll
-    for (int k = 0; k < 4 * NLOFF_QUADS; k++) out[k] = 0u;
-    uint32_t cnt = 0;
-    bool fits = true;
-    const uint32_t masks[3] = {lw.x, lw.y, lw.z};
-#pragma unroll
-    for (int dr = 0; dr < 3; dr++) {
-        const int yy = cy + dr - 1;
-        const bool ok = yy >= 0 && yy < g.sy;
-        const uint32_t rb = ok ? cell_start[(uint32_t)(ok ? yy : 0) * (uint32_t)g.sx + (uint32_t)max(cx - 1, 0)] : 0u;
-        uint32_t mk = masks[dr];
-        if (dr == 1) {   // the particle itself is on the reference's list; its pair term in the gradient sweeps is zero
-            const uint32_t sb = i - rb;
-            if (sb < 32u) mk &= ~(1u << sb);
-        }
-        while (mk) {
-            const uint32_t b = (uint32_t)__ffs(mk) - 1u;
-            mk &= mk - 1u;
-            const int d = (int)(rb + b) - (int)i;
-            fits = fits && d >= -32768 && d <= 32767 && cnt < (uint32_t)NLOFF_SLOTS;
-            if (cnt < (uint32_t)NLOFF_SLOTS) {
-                // (dynamic index into a register array would go through scratch: a select chain over the 12 words instead)
-                const uint32_t half = ((uint32_t)d & 0xffffu) << ((cnt & 1u) * 16u);
-#pragma unroll
-                for (int k = 0; k < 4 * NLOFF_QUADS; k++) out[k] |= (cnt >> 1) == (uint32_t)k ? half : 0u;
-            }
-            cnt++;
-        }
-    }
-    if (fits) head |= NLH_OK | cnt;
-    nlh[i] = head;
-    if (fits) {
-#pragma unroll
-        for (int q = 0; q < NLOFF_QUADS; q++)
-            // (the sweep reads quads 0 and 1 of every list before it knows the count: both are always written -- zeros = the particle
-            //  itself behind the count; quad 2 only when the list is longer than 16, and the sweep does not look at it otherwise)
-            if (q < 2 || cnt > (uint32_t)(8 * q)) nloff[(size_t)q * n + i] = make_uint4(out[4 * q], out[4 * q + 1], out[4 * q + 2], out[4 * q + 3]);
-    }
-}
-
 template <class Op, class = void>
 struct OpOff16 : std::false_type {};
 template <class Op>
@@ -689,22 +690,18 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_sweep_off(Op op, SweepCommon 
             if (active && (head & NLH_OK)) {
                 op.begin(acc, i, Ai);
                 const uint32_t cnt = head & 0xffu;
-#define SPH_OFF_SLOT(D)                                                                                        \
-    {                                                                                                          \
-        const float4 Aj = op.loadA(i + (uint32_t)(D));                                                         \
-        const float dx = Ai.x - Aj.x, dy = Ai.y - Aj.y;                                                        \
-        op.pair(acc, Aj, typename Op::NB{}, dx, dy, dx * dx + dy * dy, op.m.h);                                \
-    }
 #define SPH_OFF_TRIP(WA, WB)                                                                                   \
     {                                                                                                          \
-        const int d0 = (int)((WA) << 16) >> 16, d1 = (int)(WA) >> 16, d2 = (int)((WB) << 16) >> 16, d3 = (int)(WB) >> 16; \
-        const float4 A0 = op.loadA(i + (uint32_t)d0), A1 = op.loadA(i + (uint32_t)d1), A2 = op.loadA(i + (uint32_t)d2), A3 = op.loadA(i + (uint32_t)d3); \
-        SPH_OFF_PAIR(A0) SPH_OFF_PAIR(A1) SPH_OFF_PAIR(A2) SPH_OFF_PAIR(A3)                                    \
+        const uint32_t j0 = i + (uint32_t)((int)((WA) << 16) >> 16), j1 = i + (uint32_t)((int)(WA) >> 16);     \
+        const uint32_t j2 = i + (uint32_t)((int)((WB) << 16) >> 16), j3 = i + (uint32_t)((int)(WB) >> 16);     \
+        const float4 A0 = op.loadA(j0), A1 = op.loadA(j1), A2 = op.loadA(j2), A3 = op.loadA(j3);               \
+        const typename Op::NB N0 = op.nb(acc, j0, A0), N1 = op.nb(acc, j1, A1), N2 = op.nb(acc, j2, A2), N3 = op.nb(acc, j3, A3); \
+        SPH_OFF_PAIR(A0, N0) SPH_OFF_PAIR(A1, N1) SPH_OFF_PAIR(A2, N2) SPH_OFF_PAIR(A3, N3)                    \
     }
-#define SPH_OFF_PAIR(AJ)                                                                                       \
+#define SPH_OFF_PAIR(AJ, NJ)                                                                                   \
     {                                                                                                          \
         const float dx = Ai.x - AJ.x, dy = Ai.y - AJ.y;                                                        \
-        op.pair(acc, AJ, typename Op::NB{}, dx, dy, dx * dx + dy * dy, op.m.h);                                \
+        op.pair(acc, AJ, NJ, dx, dy, dx * dx + dy * dy, op.m.h);                                               \
     }
                 // (the trips are wave-uniform: the longest list of the wave decides; a shorter one evaluates its own record, for nothing)
                 SPH_OFF_TRIP(q0.x, q0.y)
@@ -719,7 +716,6 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_sweep_off(Op op, SweepCommon 
                 }
 #undef SPH_OFF_TRIP
 #undef SPH_OFF_PAIR
-#undef SPH_OFF_SLOT
                 op.finish(acc, i, Ai, (head & NLH_WALL) != 0u);
             } else if (active) {
                 sweep_particle<Op, false>(op, c, acc, i, Ai, c.nl[i]);   // no offset list: the mask word (or the candidate walk)
@@ -1279,6 +1275,7 @@ struct OpSource {
     typedef MathT Math;
     static constexpr bool HAS_EPILOGUE = true, SKIP_SELF = !OMEGA;
     static constexpr bool EXTENDED = false;
+    static constexpr bool OFF16 = MathT::UNIFORM && !OMEGA;   // (k_sweep_off: relative-offset lists, when the step built them)
     __device__ constexpr float krange() const { return 2.f; }
     typedef NBVecMr NB;
     MathT m;
@@ -3043,7 +3040,7 @@ __global__ __launch_bounds__(256) void k_integrate(uint32_t n, float dt, float v
 static SweepCommon common_of(const SweepArgs& a, bool ext)
 {
     return SweepCommon{a.g, ext ? a.t_ext : a.t, a.n, (a.n + SWEEP_THREADS - 1) / SWEEP_THREADS, a.cell_start, ext ? a.nl_ext : a.nl, ext ? a.nlx_ext : a.nlx, a.owned, a.ring1,
-                       0, nullptr, nullptr, nullptr, 0u, 0u, ext ? nullptr : a.nloff, ext ? nullptr : a.nlh, nullptr};
+                       0, nullptr, nullptr, nullptr, 0u, 0u, ext ? nullptr : a.nloff, ext ? nullptr : a.nlh, ext ? nullptr : a.nloff_out, ext ? nullptr : a.nlh_out, nullptr};
 }
 
 // SPH_TILE: bit 0 = the BUILD sweep (density), bit 1 = the replay sweeps through the LDS-staged form (k_sweep_tile) in
@@ -3118,14 +3115,9 @@ static void launch_sweep(hipStream_t s, const SweepArgs& a, const Op& op)
 }
 
 size_t sweep_list_bytes(uint32_t n) { return (size_t)n * sizeof(uint4); }
-size_t sweep_offset_list_bytes(uint32_t n) { return (size_t)n * sizeof(uint4) * NLOFF_QUADS; }
-bool sweeps_want_offset_lists(const SweepArgs& a) { return jacobi_on_records(a); }
-void launch_offsets_from_masks(hipStream_t s, Profiler* prof, const SweepArgs& a, uint4* nloff, uint32_t* nlh)
-{
-    ProfScope ps(prof, "offset_lists", s);
-    if (a.n) hipLaunchKernelGGL(k_offsets_from_masks, dim3((a.n + 255) / 256), dim3(256), 0, s, a.n, a.g, a.pm, a.cell_start, a.nl, a.owned, a.ring1, nloff, nlh);
-}
 size_t sweep_index_list_bytes(uint32_t n) { return (size_t)n * sizeof(uint4) * NLX_GROUPS; }
+size_t sweep_offset_list_bytes(uint32_t n) { return (size_t)n * sizeof(uint4) * NLOFF_QUADS; }
+bool sweeps_want_offset_lists(const SweepArgs& a) { return jacobi_on_records(a) && !(tile_mode(a) & 1); }   // (the LDS-staged BUILD form does not write them)
 bool sweep_forces_index_lists() { return SPH_FORCE_IDX != 0; }
 uint32_t solver_reduce_blocks(uint32_t n) { return (n + SWEEP_THREADS - 1) / SWEEP_THREADS; }
 

@@ -5,7 +5,10 @@ tab = collections.defaultdict(dict)
 for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        n = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("k_sweep<", "").replace("<MathUniform, false>", "").replace("<MathUniform, true>", "<dist>").replace("<MathUniform>", "").replace(", false>", "").replace(", true>", "[build]")
+        kn = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        if kn.startswith("k_sweep_off<"):
+            kn = kn[len("k_sweep_off<"):-1].strip()
+        n = kn.replace("k_sweep<", "").replace("<MathUniform, false>", "").replace("<MathUniform, true>", "<dist>").replace("<MathUniform>", "").replace(", false>", "").replace(", true>", "[build]")
         acc[(n, r["Counter_Name"])].append(float(r["Counter_Value"]))
     for (n, c), v in acc.items():
         big = [x for x in v if x >= 0.5 * max(v)] or v     # launches that did real work

@@ -24,6 +24,8 @@ shutil.copy(next((src / "kt").rglob("*kernel_stats.csv")), dst + "_rocprofv3_ker
 
 def short(name):
     n = name.split("(")[0].replace("void ", "")
+    if n.startswith("k_sweep_off<"):   # the replay on relative-offset lists (round 4): keyed by its op, like the mask form it replaced
+        return n[len("k_sweep_off<"):-1].replace("<MathUniform, false>", "").replace("<MathUniform>", "").strip()
     return n.replace("k_sweep<", "").replace("<MathUniform, false>", "").replace("<MathUniform, true>", "<dist>").replace("<MathUniform>", "").replace(", false>", "").replace(", true>", "[build]")
 
 
