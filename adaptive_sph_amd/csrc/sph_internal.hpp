@@ -163,10 +163,10 @@ struct SweepArgs {
     float* omega;       // IISPH2
     const uint8_t* size_class;
     const float* lam_prev;
-    const uint4* nloff = nullptr;   // relative-offset lists of this step (sph_sweeps.hip: k_sweep_off) and their header words; nullptr: the
-    const uint32_t* nlh = nullptr;  //   gradient sweeps of a uniform scene replay the mask words
-    uint4* nloff_out = nullptr;     // the density BUILD sweep writes them (set for that launch only)
-    uint32_t* nlh_out = nullptr;
+    const uint2* nloff = nullptr;   // relative-offset lists of this step (sph_sweeps.hip: k_sweep_off) and their header bytes; nullptr: the
+    const uint8_t* nlh = nullptr;   //   gradient sweeps of a uniform scene replay the mask words
+    uint2* nloff_out = nullptr;     // the density BUILD sweep writes them (set for that launch only)
+    uint8_t* nlh_out = nullptr;
     uint4* nl_ext;      // list words / index lists of the extended-range lists (level estimation)
     uint4* nlx_ext;
     TileP t;            // stencil bound per tile (multi-resolution scenes; ts = 0: uniform)

@@ -1318,16 +1318,16 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
         const bool offsets = m.n && m.c->opt.offset_lists && sweeps_want_offset_lists(m.a);
         if (offsets) {
             HIPCHK(m.c, m.c->nloff.ensure(sweep_offset_list_bytes((uint32_t)(m.c->cap ? m.c->cap : 1))));
-            HIPCHK(m.c, m.c->nlh.ensure((size_t)(m.c->cap ? m.c->cap : 1) * 4));
-            m.a.nloff_out = m.c->nloff.as<uint4>();
-            m.a.nlh_out = m.c->nlh.as<uint32_t>();
+            HIPCHK(m.c, m.c->nlh.ensure((size_t)(m.c->cap ? m.c->cap : 1)));
+            m.a.nloff_out = m.c->nloff.as<uint2>();
+            m.a.nlh_out = m.c->nlh.as<uint8_t>();
         }
         if (m.n) launch_density(m.c->stream, &m.c->prof, m.a);
         m.a.nloff_out = nullptr;
         m.a.nlh_out = nullptr;
         if (offsets) {
-            m.a.nloff = m.c->nloff.as<uint4>();
-            m.a.nlh = m.c->nlh.as<uint32_t>();
+            m.a.nloff = m.c->nloff.as<uint2>();
+            m.a.nlh = m.c->nlh.as<uint8_t>();
         }
         if (m.n) launch_profile_calibration(m.c);   // (profiler mode 1 only)
         if (p->check_neighborhood && m.n) launch_check_neighborhood(m.c, m.a);

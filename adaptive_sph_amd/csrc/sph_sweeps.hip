@@ -82,10 +82,10 @@ struct SweepCommon {
     const uint32_t* __restrict__ elist_b;
     uint32_t n_ea, n_eb;
     // relative-offset lists (k_sweep_off; nullptr: not built this step)
-    const uint4* __restrict__ nloff;
-    const uint32_t* __restrict__ nlh;
-    uint4* __restrict__ nloff_out;      // BUILD sweep of a uniform scene: write them (emit_offset_list), else nullptr
-    uint32_t* __restrict__ nlh_out;
+    const uint2* __restrict__ nloff;
+    const uint8_t* __restrict__ nlh;
+    uint2* __restrict__ nloff_out;      // BUILD sweep of a uniform scene: write them (emit_offset_list), else nullptr
+    uint8_t* __restrict__ nlh_out;
     // Profiler mode 3 (else nullptr): this launch's timestamp slot -- ts[0] receives the earliest block start, ts[TS_RING] the latest
     // block end, on the device's constant 100 MHz clock (sph_internal.hpp)
     unsigned long long* ts;
@@ -430,17 +430,17 @@ __device__ __forceinline__ uint32_t predicate_row(const Op& op, const float4 Ai,
 // (described there), written at the end of the density sweep -- it holds the row bases and the masks in registers; a kernel of its
 // own re-read 32 B and took 18 us for what costs the BUILD sweep ~2.  The halfwords go through a column of LDS per lane ([slot][lane]:
 // conflict-free; a slot number that is only known at run time is an address there, a select chain over twelve registers otherwise).
-#define NLOFF_QUADS 3
-#define NLOFF_SLOTS (8 * NLOFF_QUADS)
-#define NLH_OK 0x200u
-#define NLH_WALL 0x100u
-__device__ __forceinline__ void emit_offset_list(uint4* __restrict__ nloff, uint32_t* __restrict__ nlh, const uint32_t n, const uint32_t i, const uint4 lw,
+#define NLOFF_GROUPS 6                  // groups of four offsets = one trip of k_sweep_off = one 8-byte load
+#define NLOFF_SLOTS (4 * NLOFF_GROUPS)
+#define NLH_OK 0x20u                    // header byte: bits 0..4 count, NLH_OK, NLH_WALL
+#define NLH_WALL 0x40u
+__device__ __forceinline__ void emit_offset_list(uint2* __restrict__ nloff, uint8_t* __restrict__ nlh, const uint32_t n, const uint32_t i, const uint4 lw,
                                                  const uint32_t (&rb)[3])
 {
     __shared__ uint16_t s_half[NLOFF_SLOTS][SWEEP_THREADS];
     uint32_t head = (lw.w & NL_WALL) ? NLH_WALL : 0u;
     if (!(lw.w & NL_OK)) {
-        nlh[i] = head;
+        nlh[i] = (uint8_t)head;
         return;
     }
     uint32_t cnt = 0;
@@ -463,21 +463,21 @@ __device__ __forceinline__ void emit_offset_list(uint4* __restrict__ nloff, uint
         }
     }
     if (fits) head |= NLH_OK | cnt;
-    nlh[i] = head;
+    nlh[i] = (uint8_t)head;
     if (!fits) return;
-    // (the sweep reads quads 0 and 1 of every list before it knows the count: both are always written -- zeros = the particle itself
-    //  behind the count; quad 2 only when the list is longer than 16, and the sweep does not look at it otherwise)
+    // (the sweep reads groups 0..2 of every list before it knows the count: they are always written -- zeros = the particle itself
+    //  behind the count; a later group only when the list reaches it, and the sweep does not look at it otherwise)
 #pragma unroll
-    for (int q = 0; q < NLOFF_QUADS; q++) {
-        if (!(q < 2 || cnt > (uint32_t)(8 * q))) continue;
-        uint32_t w[4];
+    for (int g = 0; g < NLOFF_GROUPS; g++) {
+        if (!(g < 3 || cnt > (uint32_t)(4 * g))) continue;
+        uint32_t w[2];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const uint32_t s0 = (uint32_t)(8 * q + 2 * k);
+        for (int k = 0; k < 2; k++) {
+            const uint32_t s0 = (uint32_t)(4 * g + 2 * k);
             const uint32_t lo = s0 < cnt ? (uint32_t)s_half[s0][threadIdx.x] : 0u, hi = s0 + 1u < cnt ? (uint32_t)s_half[s0 + 1u][threadIdx.x] : 0u;
             w[k] = lo | (hi << 16);
         }
-        nloff[(size_t)q * n + i] = make_uint4(w[0], w[1], w[2], w[3]);
+        nloff[(size_t)g * n + i] = make_uint2(w[0], w[1]);
     }
 }
 
@@ -655,8 +655,10 @@ __device__ __forceinline__ void sweep_block(const Op& op, const SweepCommon& c)
 // gscale).  A slot then costs one v_bfe_i32 / v_ashrrev_i32 and one add where the mask replay spends ffs / and / compare / select / add,
 // no slot carries a predicate, and the head of the sweep needs neither the two IEEE divisions of the cell index nor the three
 // dependent cell_start loads -- the neighbours' gathers go out one round trip after the wave starts instead of two.
-// Header word nlh[i]: bits 0..7 count, NLH_OK list valid (mask list, <= NLOFF_SLOTS neighbours, every offset within 16 bits),
-// NLH_WALL = NL_WALL.  A lane without NLH_OK takes the mask path (sweep_particle) inside the same launch.
+// Layout: group g (four offsets, 8 bytes: one trip) of particle i at nloff[g n + i]; header BYTE nlh[i]: bits 0..4 count, NLH_OK list
+// valid (mask list, <= NLOFF_SLOTS neighbours, every offset within 16 bits), NLH_WALL = NL_WALL.  A lane without NLH_OK takes the mask
+// path (sweep_particle) inside the same launch.  (First form: 16-byte quads of eight offsets + a 4-byte header = 36 B read per
+// particle where the rest lattice needs 24 + 1: the sweeps had become bandwidth-bound on exactly those bytes, profiles/r4_sq_counters.txt.)
 // Ops: `static constexpr bool OFF16 = true` -- uniform-h gradient sweeps whose pair term of the particle with itself is exactly zero
 // (SKIP_SELF): the two sweeps of a Jacobi iteration on their records, the source-term sweep.
 // ------------------------------------------------------------------------------------------------
@@ -678,10 +680,10 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_sweep_off(Op op, SweepCommon 
             uint32_t i = blk * SWEEP_THREADS + threadIdx.x;
             if (c.part == 2) i = i < c.n_ea ? c.elist_a[i] : (i < c.n_ea + c.n_eb ? c.elist_b[i - c.n_ea] : c.n);   // (launch-uniform test)
             const uint32_t ic = i < c.n ? i : 0;
-            // the record, the header and the first two offset quads are requested together (one round trip at the head of the wave)
+            // the record, the header byte and the first three offset groups are requested together (one round trip at the head of the wave)
             const float4 Ai = op.loadA(ic);
             const uint32_t head = c.nlh[ic];
-            const uint4 q0 = c.nloff[ic], q1 = c.nloff[(size_t)c.n + ic];
+            const uint2 g0 = c.nloff[ic], g1 = c.nloff[(size_t)c.n + ic], g2 = c.nloff[2 * (size_t)c.n + ic];
             const bool slab = c.owned != nullptr;   // launch-uniform
             const bool mine = !slab || c.owned[ic] || (OpRing1<Op>::value && c.ring1 && c.ring1[ic]);
             const bool active = i < c.n && mine && !op.lane_skip(i) && !(c.part == 1 && c.edge[ic]);
@@ -689,7 +691,7 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_sweep_off(Op op, SweepCommon 
             op.init(acc);
             if (active && (head & NLH_OK)) {
                 op.begin(acc, i, Ai);
-                const uint32_t cnt = head & 0xffu;
+                const uint32_t cnt = head & 0x1fu;
 #define SPH_OFF_TRIP(WA, WB)                                                                                   \
     {                                                                                                          \
         const uint32_t j0 = i + (uint32_t)((int)((WA) << 16) >> 16), j1 = i + (uint32_t)((int)(WA) >> 16);     \
@@ -704,15 +706,15 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_sweep_off(Op op, SweepCommon 
         op.pair(acc, AJ, NJ, dx, dy, dx * dx + dy * dy, op.m.h);                                               \
     }
                 // (the trips are wave-uniform: the longest list of the wave decides; a shorter one evaluates its own record, for nothing)
-                SPH_OFF_TRIP(q0.x, q0.y)
-                if (__any(cnt > 4u)) SPH_OFF_TRIP(q0.z, q0.w)
-                if (__any(cnt > 8u)) SPH_OFF_TRIP(q1.x, q1.y)
-                if (__any(cnt > 12u)) SPH_OFF_TRIP(q1.z, q1.w)
-                if (__any(cnt > 16u)) {
-                    const uint4 q2 = c.nloff[2 * (size_t)c.n + i];   // (written only for lists longer than 16)
-                    const uint4 q2v = cnt > 16u ? q2 : make_uint4(0, 0, 0, 0);
-                    SPH_OFF_TRIP(q2v.x, q2v.y)
-                    if (__any(cnt > 20u)) SPH_OFF_TRIP(q2v.z, q2v.w)
+                SPH_OFF_TRIP(g0.x, g0.y)
+                if (__any(cnt > 4u)) SPH_OFF_TRIP(g1.x, g1.y)
+                if (__any(cnt > 8u)) SPH_OFF_TRIP(g2.x, g2.y)
+#pragma unroll
+                for (uint32_t g = 3; g < (uint32_t)NLOFF_GROUPS; g++) {
+                    if (!__any(cnt > 4u * g)) break;
+                    // (a group behind a list's end was not written: that lane evaluates its own record)
+                    const uint2 gg = cnt > 4u * g ? c.nloff[(size_t)g * c.n + i] : make_uint2(0u, 0u);
+                    SPH_OFF_TRIP(gg.x, gg.y)
                 }
 #undef SPH_OFF_TRIP
 #undef SPH_OFF_PAIR
@@ -3116,7 +3118,7 @@ static void launch_sweep(hipStream_t s, const SweepArgs& a, const Op& op)
 
 size_t sweep_list_bytes(uint32_t n) { return (size_t)n * sizeof(uint4); }
 size_t sweep_index_list_bytes(uint32_t n) { return (size_t)n * sizeof(uint4) * NLX_GROUPS; }
-size_t sweep_offset_list_bytes(uint32_t n) { return (size_t)n * sizeof(uint4) * NLOFF_QUADS; }
+size_t sweep_offset_list_bytes(uint32_t n) { return (size_t)n * sizeof(uint2) * NLOFF_GROUPS; }
 bool sweeps_want_offset_lists(const SweepArgs& a) { return jacobi_on_records(a) && !(tile_mode(a) & 1); }   // (the LDS-staged BUILD form does not write them)
 bool sweep_forces_index_lists() { return SPH_FORCE_IDX != 0; }
 uint32_t solver_reduce_blocks(uint32_t n) { return (n + SWEEP_THREADS - 1) / SWEEP_THREADS; }

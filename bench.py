@@ -45,9 +45,9 @@ ALGO_BYTES = {
 }
 
 
-# VALU instructions per wave of the sweeps (rocprofv3 --pmc SQ_INSTS_VALU / SQ_WAVES, profiles/r3_sq_counters.txt) and the shader clock
+# VALU instructions per wave of the sweeps (rocprofv3 --pmc SQ_INSTS_VALU / SQ_WAVES, profiles/r4_sq_counters.txt) and the shader clock
 # those launches ran at (SQ_BUSY_CYCLES / 32 / duration, same file): what the `valu_issue` object of a roofline entry is priced with
-VALU_ISSUE = {"density": 1278, "aii_nonpressure": 1298, "source_term": 804, "pressure_accel": 511, "jacobi_update": 674}
+VALU_ISSUE = {"density": 1505, "aii_nonpressure": 1183, "source_term": 567, "pressure_accel": 298, "jacobi_update": 459}
 SHADER_CLOCK_HZ = 2.06e9
 # rocprofv3's duration of the profiler's calibration kernel (one wave spinning 10 us of the device clock): 10 us + the launch / exit
 # of a one-wave dispatch, measured once against a kernel trace (profiles/r4_event_calibration.md: 5.33 / 20.44 / 40.43 / 100.47 for
@@ -418,21 +418,26 @@ def main():
         achieved = ALGO_BYTES[name] * n_local / avg_s / 1e9
         traffic, src = committed_pmc_traffic(name) if wl == "dam_break_1m" and not distributed else (None, None)
         issue = VALU_ISSUE.get(name)
-        r = {"kernel": name, "bound": "valu-issue" if issue else "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src, "avg_us": avg_s * 1e6,
+        # what bounds the launch: HBM when the bytes it really moves (the committed --pmc figure) leave at >= 85 % of what this device's
+        # copy kernel reaches in the same run; else VALU issue where the SQ counters say so (profiles/r4_sq_counters.txt)
+        traffic_gbs = (traffic / avg_s / 1e9) if traffic else None
+        hbm_bound = bool(traffic_gbs and copy_gbs and traffic_gbs >= 0.85 * copy_gbs)
+        r = {"kernel": name, "bound": "hbm" if (hbm_bound or not issue) else "valu-issue", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src, "traffic_GBs": traffic_gbs,
+             "traffic_frac_of_copy_kernel": (traffic_gbs / copy_gbs) if (traffic_gbs and copy_gbs) else None, "avg_us": avg_s * 1e6,
              "avg_us_event_bracket": raw_us, "marker_excess_us": marker_excess_us,
              "rocprofv3_avg_us_committed": committed_pmc_avg(name) if wl == "dam_break_1m" and not distributed else None,
              "launches_timed": launches, "window": prof_window,
              "copy_kernel_GBs": copy_gbs, "frac_of_copy_kernel": (achieved / copy_gbs) if copy_gbs else None,
              "algorithmic_bytes_per_particle": ALGO_BYTES[name], "algorithmic_bytes_per_launch": ALGO_BYTES[name] * n_local}
         if issue:
-            # what bounds the sweep by the SQ counters (profiles/r3_sq_counters.txt): VALU instruction issue, priced with the measured
+            # the sweep's VALU instruction issue by the SQ counters (profiles/r4_sq_counters.txt), priced with the measured
             # instruction classes (2 / 4 / 8 clocks per wave64 instruction, ~3 on the sweeps' mix; profiles/r3_valu_issue.md).
             # 16384 waves of 64 lanes per 2^20 particles on 1024 SIMDs; the launch's clocks = avg_us x the shader clock under load.
             waves_per_simd = (n_local / 64.0) / 1024.0
             clocks = avg_s * SHADER_CLOCK_HZ
             r["valu_issue"] = {"valu_instructions_per_wave": issue, "clocks_per_instruction": 3.0, "shader_clock_GHz": SHADER_CLOCK_HZ / 1e9,
-                               "frac": issue * waves_per_simd * 3.0 / clocks, "source": "profiles/r3_sq_counters.txt (SQ_INSTS_VALU / SQ_WAVES), profiles/r3_valu_issue.md"}
+                               "frac": issue * waves_per_simd * 3.0 / clocks, "source": "profiles/r4_sq_counters.txt (SQ_INSTS_VALU / SQ_WAVES), profiles/r3_valu_issue.md"}
         return r
 
     total_prof_ms = sum(v[1] for v in prof_all.values()) or 1.0

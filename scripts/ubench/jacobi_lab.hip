@@ -57,6 +57,9 @@ struct Args {
     // count hold 0 (the particle itself: its pair term is exactly zero in the slim arithmetic); cnt8[i] = number of neighbours
     const uint4* __restrict__ off16;
     const uint8_t* __restrict__ cnt8;
+    // the mask words with STORED row bases (20 B per particle instead of 36): rbd[i] = (rb0 - i) & 0xffff | (rb2 - i) << 16, and the
+    // position of the particle's own bit in row 1 (i - rb1) in bits 8..12 of nl[i].w
+    const uint32_t* __restrict__ rbd;
 };
 
 __device__ __forceinline__ void grad_uniform(const Math& m, float dx, float dy, float r2, float& gx, float& gy)
@@ -436,6 +439,58 @@ __global__ __launch_bounds__(256) void k_accel_lean(Args A)
         }
     }
     A.pacc_out[i] = make_float4(Ai.x, Ai.y, ax, ay);
+}
+
+// ---- variant (round 4): the product's mask replay, but the three row bases come from 4 stored bytes (two 16-bit deltas and the
+// position of the own bit) instead of two IEEE divisions and three dependent cell_start loads: which part of the offset lists' gain
+// is the head of the sweep, which the per-slot decoding?
+__global__ __launch_bounds__(256) void k_gather4_slim_rbd(Args A)
+{
+    const uint32_t blk = remap_block(A.nblocks);
+    if (blk >= A.nblocks) return;
+    const uint32_t i = blk * 256 + threadIdx.x;
+    if (i >= A.n) return;
+    const float4 Ai = A.comb[i];
+    const uint4 lw = A.nl[i];
+    const uint32_t dd = A.rbd[i];
+    const float rho_i = A.rho[i];
+    const float aii_i = A.aii[i], src_i = A.src[i], pin_i = A.p_in[i];
+    const uint32_t rb[3] = {i + (uint32_t)((int)(dd << 16) >> 16), i - ((lw.w >> 8) & 31u), i + (uint32_t)((int)dd >> 16)};
+    Acc a;
+    a.sum = 0.f;
+    a.inv_rho = __builtin_amdgcn_rcpf(rho_i);
+    a.qx = Ai.z;
+    a.qy = Ai.w;
+    const float nf6 = 6.f * A.m.nf * A.m.inv2h;
+    const uint32_t masks[3] = {lw.x, lw.y, lw.z};
+#pragma unroll
+    for (int dr = 0; dr < 3; dr++) {
+        uint32_t mk = masks[dr];
+        const uint32_t base = rb[dr];
+        while (mk) {
+            const uint32_t b0 = __ffs(mk) - 1;
+            mk &= mk - 1;
+            const bool v1 = mk != 0;
+            const uint32_t b1 = v1 ? __ffs(mk) - 1 : b0;
+            mk &= mk - 1;
+            const bool v2 = mk != 0;
+            const uint32_t b2 = v2 ? __ffs(mk) - 1 : b0;
+            mk &= mk - 1;
+            const bool v3 = mk != 0;
+            const uint32_t b3 = v3 ? __ffs(mk) - 1 : b0;
+            mk &= mk - 1;
+            const float4 R0 = A.comb[ix(base + b0, A.n, 9u)], R1 = A.comb[ix(base + b1, A.n, 9u)], R2 = A.comb[ix(base + b2, A.n, 9u)], R3 = A.comb[ix(base + b3, A.n, 9u)];
+            pair_slim(A, a, Ai.x, Ai.y, R0.x, R0.y, R0.z, R0.w, true, nf6);
+            pair_slim(A, a, Ai.x, Ai.y, R1.x, R1.y, R1.z, R1.w, v1, nf6);
+            pair_slim(A, a, Ai.x, Ai.y, R2.x, R2.y, R2.z, R2.w, v2, nf6);
+            pair_slim(A, a, Ai.x, Ai.y, R3.x, R3.y, R3.z, R3.w, v3, nf6);
+        }
+    }
+    a.sum *= A.mass * a.inv_rho;
+    const float pn = pin_i + A.omega * (src_i - a.sum) / aii_i;
+    const bool pos = pn > 0.f;
+    A.p_out[i] = pos ? pn : 0.f;
+    A.pt_out[i] = pos ? pn / (rho_i * rho_i) : 0.f;
 }
 
 // ---- variant (round 4): NO mask decoding, NO row bases.  The list is 16-bit offsets j - i (the neighbours of a
@@ -1213,6 +1268,7 @@ int main(int argc, char** argv)
     // relative-offset lists: the masks' visiting order (rows bottom to top, index ascending) as 16-bit j - i, 24 slots
     std::vector<uint16_t> off16((size_t)n * 24, 0);
     std::vector<uint8_t> cnt8(n);
+    std::vector<uint32_t> rbd(n);
     uint32_t off_overflow = 0, max_cnt = 0;
     for (uint32_t s = 0; s < n; s++) {
         const int cx = (int)(skey[s] % (uint32_t)g.sx), cy = (int)(skey[s] / (uint32_t)g.sx);
@@ -1233,6 +1289,18 @@ int main(int argc, char** argv)
         }
         cnt8[s] = (uint8_t)k;
         max_cnt = std::max(max_cnt, k);
+        {
+            uint32_t rbv[3] = {0, 0, 0};
+            for (int dr = 0; dr < 3; dr++) {
+                const int yy = cy + dr - 1;
+                if (yy >= 0 && yy < g.sy) rbv[dr] = cell_start[(uint32_t)yy * g.sx + std::max(cx - 1, 0)];
+                else rbv[dr] = s;
+            }
+            const long long d0 = (long long)rbv[0] - s, d2 = (long long)rbv[2] - s, sb = (long long)s - rbv[1];
+            if (d0 < -32768 || d0 > 32767 || d2 < -32768 || d2 > 32767 || sb < 0 || sb > 31) off_overflow++;
+            rbd[s] = ((uint32_t)d0 & 0xffffu) | ((uint32_t)d2 << 16);
+            nl[s].w |= ((uint32_t)sb & 31u) << 8;
+        }
     }
     setvbuf(stdout, nullptr, _IOLBF, 0);
     printf("offset lists: largest count %u, entries that do not fit (24 slots, 16 bits): %u\n", max_cnt, off_overflow);
@@ -1270,6 +1338,7 @@ int main(int argc, char** argv)
     }
     A.off16 = (const uint4*)up(off16.data(), off16.size() * 2);
     A.cnt8 = (const uint8_t*)up(cnt8.data(), (size_t)n);
+    A.rbd = (const uint32_t*)up(rbd.data(), (size_t)n * 4);
     A.rho = (const float*)up(rho.data(), (size_t)n * 4);
     A.aii = (const float*)up(aii.data(), (size_t)n * 4);
     A.src = (const float*)up(src.data(), (size_t)n * 4);
@@ -1316,6 +1385,7 @@ int main(int argc, char** argv)
         {"sweep B lean: + no select on an empty slot's index", k_gather4_lean<7>, true},
         {"combined record, slim, 16-bit offset list j - i (no mask decoding, no row bases), padding slots = the particle itself, no predicate", k_off16_slim<0>, true},
         {"combined record, slim, 16-bit offset list, slots behind the count skipped by a branch", k_off16_slim<1>, true},
+        {"combined record, slim, mask replay with STORED row bases (20 B per particle; no cell index, no cell_start loads)", k_gather4_slim_rbd, true},
         {"combined record, slim, masks decoded into 16 indices first, then flat trips of 4 (no per-row padding)", k_flat16_slim, true},
         {"combined record, slim, masks decoded by per-row loops into an LDS column per lane, then flat trips of 4", k_flat_lds_slim, true},
         {"gather4, combined record, slim, next trip's gathers requested before this trip's pairs (rows merged into one trip sequence)", k_gather4_slim_pipe, true},
