@@ -667,6 +667,14 @@ struct OpOff16 : std::false_type {};
 template <class Op>
 struct OpOff16<Op, std::void_t<decltype(Op::OFF16)>> : std::bool_constant<Op::OFF16> {};
 
+#ifndef SPH_OFF_WIDE
+#define SPH_OFF_WIDE 1
+#endif
+// ops with `static constexpr int WIDE_TRIPS = k`: the gathers of the first k trips of k_sweep_off leave together (default 1)
+template <class Op, class = void>
+struct OpWideTrips : std::integral_constant<int, 1> {};
+template <class Op>
+struct OpWideTrips<Op, std::void_t<decltype(Op::WIDE_TRIPS)>> : std::integral_constant<int, Op::WIDE_TRIPS> {};
 template <class Op>
 __global__ __launch_bounds__(SWEEP_THREADS) void k_sweep_off(Op op, SweepCommon c)
 {
@@ -706,9 +714,30 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_sweep_off(Op op, SweepCommon 
         op.pair(acc, AJ, NJ, dx, dy, dx * dx + dy * dy, op.m.h);                                               \
     }
                 // (the trips are wave-uniform: the longest list of the wave decides; a shorter one evaluates its own record, for nothing)
+#if SPH_OFF_WIDE
+                constexpr int WT = OpWideTrips<Op>::value;   // trips whose gathers leave together (3: twelve records in flight, one round trip instead of three)
+                if (WT >= 2 && std::is_empty<typename Op::NB>::value && __any(cnt > 4u * (uint32_t)(WT - 1))) {
+                    // the usual wave (12 neighbours on the rest lattice)
+                    const uint32_t w[6] = {g0.x, g0.y, g1.x, g1.y, g2.x, g2.y};
+                    float4 R[4 * (WT >= 2 ? WT : 2)];
+#pragma unroll
+                    for (int k = 0; k < 2 * WT; k++) {
+                        R[2 * k] = op.loadA(i + (uint32_t)((int)(w[k] << 16) >> 16));
+                        R[2 * k + 1] = op.loadA(i + (uint32_t)((int)w[k] >> 16));
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4 * WT; k++) SPH_OFF_PAIR(R[k], typename Op::NB{})
+                    if (WT == 2 && __any(cnt > 8u)) SPH_OFF_TRIP(g2.x, g2.y)
+                } else {
+                    SPH_OFF_TRIP(g0.x, g0.y)
+                    if (__any(cnt > 4u)) SPH_OFF_TRIP(g1.x, g1.y)
+                    if (__any(cnt > 8u)) SPH_OFF_TRIP(g2.x, g2.y)
+                }
+#else
                 SPH_OFF_TRIP(g0.x, g0.y)
                 if (__any(cnt > 4u)) SPH_OFF_TRIP(g1.x, g1.y)
                 if (__any(cnt > 8u)) SPH_OFF_TRIP(g2.x, g2.y)
+#endif
 #pragma unroll
                 for (uint32_t g = 3; g < (uint32_t)NLOFF_GROUPS; g++) {
                     if (!__any(cnt > 4u * g)) break;
@@ -1703,6 +1732,10 @@ struct OpPressureAccelU : OpPressureAccel<MathT> {
     typedef OpPressureAccel<MathT> B;
     static constexpr bool TILE = false, RING1 = true;   // (slab decomposition: the first ghost ring computes its own a^p, as in the base)
     static constexpr bool OFF16 = true;                 // (k_sweep_off: relative-offset lists)
+#ifndef SPH_WIDE_A
+#define SPH_WIDE_A 3
+#endif
+    static constexpr int WIDE_TRIPS = SPH_WIDE_A;
     typedef NBNone NB;
     const float4* __restrict__ rec;   // of the pressure buffer this iteration reads (slabs: the ghosts' records carry their owners' p / rho^2, refreshed every iteration)
     struct Acc {
@@ -1977,6 +2010,10 @@ struct OpJacobiU : OpJacobi<MathT> {
     typedef typename B::Acc Acc;
     static constexpr bool TILE = false;
     static constexpr bool OFF16 = true;   // (k_sweep_off: relative-offset lists)
+#ifndef SPH_WIDE_B
+#define SPH_WIDE_B 3
+#endif
+    static constexpr int WIDE_TRIPS = SPH_WIDE_B;
     typedef NBNone NB;
     __device__ float4 loadA(uint32_t j) const { return this->pacc[j]; }
     __device__ NB nb(const Acc&, uint32_t, float4) const { return NB{}; }
