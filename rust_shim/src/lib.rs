@@ -235,6 +235,16 @@ pub mod ffi {
         pub fn sph_comm_init(ctx: *mut c_void, id: *const u8 /* [128] */, rank: c_int, n_ranks: c_int) -> c_int;
         /// k contexts of ONE process as ranks 0..k-1 (plain copies as transport): the single-GPU check of the decomposition
         pub fn sph_group_step(ctxs: *mut *mut c_void, n: c_int, params: *const SphParams, outs: *mut SphStepStats) -> c_int;
+        /// share (op 0) / merge (1) / split (2) for those k contexts in their slab form: `merge_partner` / `merge_counter` of the WHOLE
+        /// vector by global particle id, null for op 2.  (One process per rank: the three apply calls themselves, collectively.)
+        pub fn sph_group_adapt(ctxs: *mut *mut c_void, n: c_int, op: c_int, params: *const SphParams, ap: *const SphAdaptParams,
+                               merge_partner: *const u32, merge_counter: *const u16) -> c_int;
+        /// ranks as processes of one node without RCCL: rendezvous and staging through a POSIX shared-memory segment
+        pub fn sph_comm_init_shm(ctx: *mut c_void, name: *const c_char, rank: c_int, n_ranks: c_int, bytes_per_side: u64, create: c_int) -> c_int;
+        /// ... and on top of it the peer-mapped push transport: export this rank's inbox (64-byte hipIpc handle), all-gather the handles
+        /// with the launcher, map the others'
+        pub fn sph_comm_ipc_export(ctx: *mut c_void, bytes_per_side: u64, handle_out: *mut u8 /* [64] */) -> c_int;
+        pub fn sph_comm_init_ipc(ctx: *mut c_void, handles: *const u8 /* n_ranks x 64 */, n_ranks: c_int) -> c_int;
     }
 
     /// `sph_dist_stats`
