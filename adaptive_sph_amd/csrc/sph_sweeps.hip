@@ -579,7 +579,7 @@ __device__ __forceinline__ void sweep_particle(const Op& op, const SweepCommon& 
     if (BUILD) {
         if (wall) lw.w |= NL_WALL;
         c.nl[i] = lw;
-        if constexpr (Math::UNIFORM && !Op::EXTENDED) {
+        if constexpr (!Math::EXACT && !Op::EXTENDED) {
             if (c.nloff_out) emit_offset_list(c.nloff_out, c.nlh_out, c.n, i, lw, rb_build);   // (launch-uniform)
         }
     }
@@ -659,8 +659,10 @@ __device__ __forceinline__ void sweep_block(const Op& op, const SweepCommon& c)
 // valid (mask list, <= NLOFF_SLOTS neighbours, every offset within 16 bits), NLH_WALL = NL_WALL.  A lane without NLH_OK takes the mask
 // path (sweep_particle) inside the same launch.  (First form: 16-byte quads of eight offsets + a 4-byte header = 36 B read per
 // particle where the rest lattice needs 24 + 1: the sweeps had become bandwidth-bound on exactly those bytes, profiles/r4_sq_counters.txt.)
-// Ops: `static constexpr bool OFF16 = true` -- uniform-h gradient sweeps whose pair term of the particle with itself is exactly zero
-// (SKIP_SELF): the two sweeps of a Jacobi iteration on their records, the source-term sweep.
+// Ops: `static constexpr bool OFF16 = true` -- gradient sweeps (FAST / UNIFORM math) whose pair term of the particle with itself is exactly
+// zero (SKIP_SELF): the two sweeps of a Jacobi iteration (on their records in uniform scenes, record + payload otherwise), the source-term
+// sweep, the non-pressure forces when they run alone.  In a multi-resolution scene the lanes with a mask list (3 x 3 stencil: the bulk) take
+// the offsets, the interface particles their index lists, inside the same launch.
 // ------------------------------------------------------------------------------------------------
 template <class Op, class = void>
 struct OpOff16 : std::false_type {};
@@ -679,7 +681,7 @@ template <class Op>
 __global__ __launch_bounds__(SWEEP_THREADS) void k_sweep_off(Op op, SweepCommon c)
 {
     typedef typename Op::Math Math;
-    static_assert(Math::UNIFORM && Op::SKIP_SELF && !Op::EXTENDED, "k_sweep_off: uniform-h gradient sweeps");
+    static_assert(!Math::EXACT && Op::SKIP_SELF && !Op::EXTENDED, "k_sweep_off: gradient sweeps of the FAST / UNIFORM math policies");
     sweep_stamp(c.ts, false);
     if (!OpPrologue<Op>::run(op, blockIdx.x)) {
         const uint32_t per_xcd = (c.nblocks + 7) >> 3;
@@ -711,7 +713,7 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_sweep_off(Op op, SweepCommon 
 #define SPH_OFF_PAIR(AJ, NJ)                                                                                   \
     {                                                                                                          \
         const float dx = Ai.x - AJ.x, dy = Ai.y - AJ.y;                                                        \
-        op.pair(acc, AJ, NJ, dx, dy, dx * dx + dy * dy, op.m.h);                                               \
+        op.pair(acc, AJ, NJ, dx, dy, dx * dx + dy * dy, Math::UNIFORM ? op.m.h : (Ai.w + AJ.w) * 0.5f);        \
     }
                 // (the trips are wave-uniform: the longest list of the wave decides; a shorter one evaluates its own record, for nothing)
 #if SPH_OFF_WIDE
@@ -1175,6 +1177,7 @@ struct OpNonPressure {
     typedef MathT Math;
     static constexpr bool HAS_EPILOGUE = false, SKIP_SELF = true;
     static constexpr bool EXTENDED = false;
+    static constexpr bool OFF16 = !MathT::EXACT;   // (k_sweep_off: relative-offset lists, when the step built them)
     __device__ constexpr float krange() const { return 2.f; }
     typedef NBRhoVel NB;
     MathT m;
@@ -1306,7 +1309,7 @@ struct OpSource {
     typedef MathT Math;
     static constexpr bool HAS_EPILOGUE = true, SKIP_SELF = !OMEGA;
     static constexpr bool EXTENDED = false;
-    static constexpr bool OFF16 = MathT::UNIFORM && !OMEGA;   // (k_sweep_off: relative-offset lists, when the step built them)
+    static constexpr bool OFF16 = !MathT::EXACT && !OMEGA;   // (k_sweep_off: relative-offset lists, when the step built them)
     __device__ constexpr float krange() const { return 2.f; }
     typedef NBVecMr NB;
     MathT m;
@@ -1626,6 +1629,7 @@ struct OpPressureAccel {
     typedef MathT Math;
     static constexpr bool HAS_EPILOGUE = false, SKIP_SELF = true;
     static constexpr bool EXTENDED = false, RING1 = true;
+    static constexpr bool OFF16 = !MathT::EXACT;   // (k_sweep_off: relative-offset lists, when the step built them)
     __device__ constexpr float krange() const { return 2.f; }
     typedef float NB;  // p_j / (rho_j * rho_j)
     MathT m;
@@ -1876,6 +1880,7 @@ struct OpJacobi {
     typedef MathT Math;
     static constexpr bool HAS_EPILOGUE = true, SKIP_SELF = true;
     static constexpr bool EXTENDED = false;
+    static constexpr bool OFF16 = !MathT::EXACT;   // (k_sweep_off: relative-offset lists, when the step built them)
     __device__ constexpr float krange() const { return 2.f; }
     typedef NBVecMr NB;
     MathT m;
@@ -3156,7 +3161,16 @@ static void launch_sweep(hipStream_t s, const SweepArgs& a, const Op& op)
 size_t sweep_list_bytes(uint32_t n) { return (size_t)n * sizeof(uint4); }
 size_t sweep_index_list_bytes(uint32_t n) { return (size_t)n * sizeof(uint4) * NLX_GROUPS; }
 size_t sweep_offset_list_bytes(uint32_t n) { return (size_t)n * sizeof(uint2) * NLOFF_GROUPS; }
-bool sweeps_want_offset_lists(const SweepArgs& a) { return jacobi_on_records(a) && !(tile_mode(a) & 1); }   // (the LDS-staged BUILD form does not write them)
+// every scene but the EXACT policy's: the gradient sweeps of the step replay them where a particle has a mask list (3 x 3 stencil)
+// (not with the LDS-staged BUILD form or forced index lists, which do not write them)
+// Measured (bench.py other_configs, round 4): configs[2] (1M particles, 4:1) 0.634 -> 0.586 ms/step with them, configs[4]'s scene (4M, 50:1)
+// 0.914 -> 0.972 WITHOUT them -- at 4M the step's arrays no longer sit in the 256 MB Infinity Cache, its generic sweeps are bound by HBM bytes
+// and the list is 9 bytes longer than the mask word -- so multi-resolution scenes take them up to 2 M particles; uniform scenes (one
+// gathered record per neighbour) gain at 1M and at 8M alike.
+bool sweeps_want_offset_lists(const SweepArgs& a)
+{
+    return !a.exact && !(tile_mode(a) & 1) && SPH_FORCE_IDX == 0 && (jacobi_on_records(a) || a.n <= (1u << 21));
+}
 bool sweep_forces_index_lists() { return SPH_FORCE_IDX != 0; }
 uint32_t solver_reduce_blocks(uint32_t n) { return (n + SWEEP_THREADS - 1) / SWEEP_THREADS; }
 

@@ -212,3 +212,39 @@ def test_offset_lists_are_bit_identical_to_the_mask_words(product_lib, monkeypat
             assert np.array_equal(fa[f], fb[f]), (s, f)
     nc = out["offsets"][1][0]["neighbor_count"].max() - 1   # (the reference counts the particle itself)
     assert {1.0: nc <= 16, 0.85: 16 < nc <= 24, 0.66: nc > 24}[compression], nc
+
+
+@pytest.mark.parametrize("solver", ["HybridDFSPH", "IISPH"])
+def test_offset_lists_in_a_multi_resolution_scene(product_lib, monkeypatch, solver):
+    """Two particle sizes (4:1): the bulk has mask lists and replays them as offsets (FAST math: h_ij from the gathered records), the
+    interface particles keep their explicit index lists inside the same launches.  Bit for bit the mask replay."""
+    fine = 0.02
+    scn = sc.SceneConfig(sc.SceneBoundary("box", 3.0, 3.0),
+                         [sc.SceneFluidBlock([-0.95, -0.5], [0.55, 1.4], fine, 0.93, [0.5, 0]),
+                          sc.SceneFluidBlock([-0.40 + 0.3 * fine * 4, -0.5], [0.7, 1.4], fine * 4, 0.93, [-0.5, 0])])
+    pos, mass, vel = sc.init_particles(scn)
+    P = dam_break_params(pressure_solver_method=solver)
+    planes = sc.boundary_planes(scn.boundary, P.init_boundary_handler)
+    p = P.to_ffi()
+    out = {}
+    for form in ("offsets", "masks"):
+        if form == "masks":
+            monkeypatch.setenv("SPH_OFFSET_LISTS", "0")
+        g = ffi.Context(product_lib, len(mass), planes)
+        if form == "masks":
+            monkeypatch.delenv("SPH_OFFSET_LISTS")
+        g.upload(mass, pos, vel)
+        its, fields = [], []
+        for _ in range(12):
+            st = g.step(p)
+            its.append((int(st.div_solver.iters), int(st.density_solver.iters), np.float32(st.dt).view(np.uint32).item()))
+            fields.append({f: g.download(f) for f in ("position", "velocity", "pressure", "density")})
+        forms = g.profile_list_forms()
+        out[form] = (its, fields, forms)
+        g.close()
+    assert out["offsets"][0] == out["masks"][0]
+    for s, (fa, fb) in enumerate(zip(out["offsets"][1], out["masks"][1])):
+        for f in fa:
+            assert np.array_equal(fa[f], fb[f]), (s, f)
+    forms = out["offsets"][2]
+    assert forms["n_mask"] > 0 and forms["n_index"] > 0, forms     # both list forms are in the scene
