@@ -60,6 +60,10 @@ struct Args {
     // the mask words with STORED row bases (20 B per particle instead of 36): rbd[i] = (rb0 - i) & 0xffff | (rb2 - i) << 16, and the
     // position of the particle's own bit in row 1 (i - rb1) in bits 8..12 of nl[i].w
     const uint32_t* __restrict__ rbd;
+    // row-delta lists: one 32-bit word per group of up to four ROW-CONSECUTIVE neighbours -- 16-bit offset of the first (j0 - i), three
+    // 5-bit deltas to the next ones (0 = no entry); group g of particle i at dlt[g n + i], dcnt[i] = number of groups (<= 6)
+    const uint32_t* __restrict__ dlt;
+    const uint8_t* __restrict__ dcnt;
 };
 
 __device__ __forceinline__ void grad_uniform(const Math& m, float dx, float dy, float r2, float& gx, float& gy)
@@ -439,6 +443,72 @@ __global__ __launch_bounds__(256) void k_accel_lean(Args A)
         }
     }
     A.pacc_out[i] = make_float4(Ai.x, Ai.y, ax, ay);
+}
+
+// ---- variant (round 4): ROW-DELTA lists, 4 bytes per trip instead of 8: the rest lattice's 12 neighbours are 12 + 1 bytes per particle
+// instead of 24 + 1.  An empty slot (delta 0) evaluates the particle itself.
+__global__ __launch_bounds__(256) void k_delta_slim(Args A)
+{
+    const uint32_t blk = remap_block(A.nblocks);
+    if (blk >= A.nblocks) return;
+    const uint32_t i = blk * 256 + threadIdx.x;
+    if (i >= A.n) return;
+    const float4 Ai = A.comb[i];
+    const uint32_t g0 = A.dlt[i], g1 = A.dlt[(size_t)A.n + i], g2 = A.dlt[2 * (size_t)A.n + i];
+    const uint32_t ng = A.dcnt[i];
+    const float rho_i = A.rho[i];
+    const float aii_i = A.aii[i], src_i = A.src[i], pin_i = A.p_in[i];
+    Acc a;
+    a.sum = 0.f;
+    a.inv_rho = __builtin_amdgcn_rcpf(rho_i);
+    a.qx = Ai.z;
+    a.qy = Ai.w;
+    const float nf6 = 6.f * A.m.nf * A.m.inv2h;
+#define DLT_IDX(G, J0, J1, J2, J3)                                                                  \
+    const uint32_t J0 = i + (uint32_t)((int)((G) << 16) >> 16);                                     \
+    const uint32_t e1 = ((G) >> 16) & 31u, e2 = ((G) >> 21) & 31u, e3 = ((G) >> 26) & 31u;          \
+    const uint32_t J1 = e1 ? J0 + e1 : i, J2 = e2 ? J0 + e1 + e2 : i, J3 = e3 ? J0 + e1 + e2 + e3 : i;
+#define DLT_TRIP(G)                                                                                 \
+    {                                                                                               \
+        DLT_IDX(G, j0, j1, j2, j3)                                                                  \
+        const float4 R0 = A.comb[ix(j0, A.n, 10u)], R1 = A.comb[ix(j1, A.n, 10u)], R2 = A.comb[ix(j2, A.n, 10u)], R3 = A.comb[ix(j3, A.n, 10u)]; \
+        pair_slim(A, a, Ai.x, Ai.y, R0.x, R0.y, R0.z, R0.w, true, nf6);                             \
+        pair_slim(A, a, Ai.x, Ai.y, R1.x, R1.y, R1.z, R1.w, true, nf6);                             \
+        pair_slim(A, a, Ai.x, Ai.y, R2.x, R2.y, R2.z, R2.w, true, nf6);                             \
+        pair_slim(A, a, Ai.x, Ai.y, R3.x, R3.y, R3.z, R3.w, true, nf6);                             \
+    }
+    if (__any(ng > 2u)) {   // the usual wave: the gathers of three groups leave together
+        float4 R[12];
+        {
+            DLT_IDX(g0, a0, a1, a2, a3)
+            R[0] = A.comb[ix(a0, A.n, 10u)]; R[1] = A.comb[ix(a1, A.n, 10u)]; R[2] = A.comb[ix(a2, A.n, 10u)]; R[3] = A.comb[ix(a3, A.n, 10u)];
+        }
+        {
+            DLT_IDX(g1, b0, b1, b2, b3)
+            R[4] = A.comb[ix(b0, A.n, 10u)]; R[5] = A.comb[ix(b1, A.n, 10u)]; R[6] = A.comb[ix(b2, A.n, 10u)]; R[7] = A.comb[ix(b3, A.n, 10u)];
+        }
+        {
+            DLT_IDX(g2, c0, c1, c2, c3)
+            R[8] = A.comb[ix(c0, A.n, 10u)]; R[9] = A.comb[ix(c1, A.n, 10u)]; R[10] = A.comb[ix(c2, A.n, 10u)]; R[11] = A.comb[ix(c3, A.n, 10u)];
+        }
+#pragma unroll
+        for (int k = 0; k < 12; k++) pair_slim(A, a, Ai.x, Ai.y, R[k].x, R[k].y, R[k].z, R[k].w, true, nf6);
+    } else {
+        DLT_TRIP(g0)
+        if (__any(ng > 1u)) DLT_TRIP(g1)
+    }
+    for (uint32_t g = 3; g < 6u; g++) {
+        if (!__any(ng > g)) break;
+        const uint32_t gg = ng > g ? A.dlt[(size_t)g * A.n + i] : 0u;
+        DLT_TRIP(gg)
+    }
+#undef DLT_TRIP
+#undef DLT_IDX
+    a.sum *= A.mass * a.inv_rho;
+    const float pn = pin_i + A.omega * (src_i - a.sum) / aii_i;
+    const bool pos = pn > 0.f;
+    A.p_out[i] = pos ? pn : 0.f;
+    A.pt_out[i] = pos ? pn / (rho_i * rho_i) : 0.f;
 }
 
 // ---- variant (round 4): the product's mask replay, but the three row bases come from 4 stored bytes (two 16-bit deltas and the
@@ -1269,6 +1339,10 @@ int main(int argc, char** argv)
     std::vector<uint16_t> off16((size_t)n * 24, 0);
     std::vector<uint8_t> cnt8(n);
     std::vector<uint32_t> rbd(n);
+    std::vector<uint32_t> dlt((size_t)n * 6, 0);
+    std::vector<uint8_t> dcnt(n);
+    uint32_t dlt_overflow = 0;
+    double sum_groups = 0;
     uint32_t off_overflow = 0, max_cnt = 0;
     for (uint32_t s = 0; s < n; s++) {
         const int cx = (int)(skey[s] % (uint32_t)g.sx), cy = (int)(skey[s] / (uint32_t)g.sx);
@@ -1289,6 +1363,36 @@ int main(int argc, char** argv)
         }
         cnt8[s] = (uint8_t)k;
         max_cnt = std::max(max_cnt, k);
+        {   // row-delta groups
+            uint32_t ng = 0;
+            for (int dr = 0; dr < 3; dr++) {
+                const int yy = cy + dr - 1;
+                if (yy < 0 || yy >= g.sy) continue;
+                const uint32_t b = cell_start[(uint32_t)yy * g.sx + std::max(cx - 1, 0)];
+                uint32_t word = 0, in_group = 0, last = 0;
+                for (uint32_t bit = 0; bit < 32; bit++)
+                    if (mk[dr] & (1u << bit)) {
+                        const uint32_t j = b + bit;
+                        if (in_group == 0) {
+                            word = (uint32_t)((long long)j - (long long)s) & 0xffffu;
+                        } else {
+                            word |= (j - last) << (16 + 5 * (in_group - 1));
+                        }
+                        last = j;
+                        if (++in_group == 4) {
+                            if (ng < 6) dlt[(size_t)ng * n + s] = word; else dlt_overflow++;
+                            ng++;
+                            in_group = 0;
+                        }
+                    }
+                if (in_group) {
+                    if (ng < 6) dlt[(size_t)ng * n + s] = word; else dlt_overflow++;
+                    ng++;
+                }
+            }
+            dcnt[s] = (uint8_t)std::min(ng, 6u);
+            sum_groups += ng;
+        }
         {
             uint32_t rbv[3] = {0, 0, 0};
             for (int dr = 0; dr < 3; dr++) {
@@ -1303,7 +1407,7 @@ int main(int argc, char** argv)
         }
     }
     setvbuf(stdout, nullptr, _IOLBF, 0);
-    printf("offset lists: largest count %u, entries that do not fit (24 slots, 16 bits): %u\n", max_cnt, off_overflow);
+    printf("offset lists: largest count %u, entries that do not fit (24 slots, 16 bits): %u; row-delta lists: %.2f groups per particle, groups beyond 6: %u\n", max_cnt, off_overflow, sum_groups / n, dlt_overflow);
     printf("n = %u, cells %d x %d, %.2f neighbours per particle (self excluded), %.2f slots per particle in trips of 4 (per lane), rows > 32 candidates: %u\n", n, g.sx,
            g.sy, sum_cnt / n, sum_slots4 / n, overflow);
     std::vector<float> rho(n), aii(n), src(n), pin(n);
@@ -1339,6 +1443,8 @@ int main(int argc, char** argv)
     A.off16 = (const uint4*)up(off16.data(), off16.size() * 2);
     A.cnt8 = (const uint8_t*)up(cnt8.data(), (size_t)n);
     A.rbd = (const uint32_t*)up(rbd.data(), (size_t)n * 4);
+    A.dlt = (const uint32_t*)up(dlt.data(), dlt.size() * 4);
+    A.dcnt = (const uint8_t*)up(dcnt.data(), (size_t)n);
     A.rho = (const float*)up(rho.data(), (size_t)n * 4);
     A.aii = (const float*)up(aii.data(), (size_t)n * 4);
     A.src = (const float*)up(src.data(), (size_t)n * 4);
@@ -1385,6 +1491,7 @@ int main(int argc, char** argv)
         {"sweep B lean: + no select on an empty slot's index", k_gather4_lean<7>, true},
         {"combined record, slim, 16-bit offset list j - i (no mask decoding, no row bases), padding slots = the particle itself, no predicate", k_off16_slim<0>, true},
         {"combined record, slim, 16-bit offset list, slots behind the count skipped by a branch", k_off16_slim<1>, true},
+        {"combined record, slim, ROW-DELTA lists (4 B per group of four: 16-bit offset + three 5-bit deltas), three groups' gathers together", k_delta_slim, true},
         {"combined record, slim, mask replay with STORED row bases (20 B per particle; no cell index, no cell_start loads)", k_gather4_slim_rbd, true},
         {"combined record, slim, masks decoded into 16 indices first, then flat trips of 4 (no per-row padding)", k_flat16_slim, true},
         {"combined record, slim, masks decoded by per-row loops into an LDS column per lane, then flat trips of 4", k_flat_lds_slim, true},
