@@ -669,9 +669,6 @@ struct OpOff16 : std::false_type {};
 template <class Op>
 struct OpOff16<Op, std::void_t<decltype(Op::OFF16)>> : std::bool_constant<Op::OFF16> {};
 
-#ifndef SPH_OFF_WIDE
-#define SPH_OFF_WIDE 1
-#endif
 // ops with `static constexpr int WIDE_TRIPS = k`: the gathers of the first k trips of k_sweep_off leave together (default 1)
 template <class Op, class = void>
 struct OpWideTrips : std::integral_constant<int, 1> {};
@@ -716,7 +713,6 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_sweep_off(Op op, SweepCommon 
         op.pair(acc, AJ, NJ, dx, dy, dx * dx + dy * dy, Math::UNIFORM ? op.m.h : (Ai.w + AJ.w) * 0.5f);        \
     }
                 // (the trips are wave-uniform: the longest list of the wave decides; a shorter one evaluates its own record, for nothing)
-#if SPH_OFF_WIDE
                 constexpr int WT = OpWideTrips<Op>::value;   // trips whose gathers leave together (3: twelve records in flight, one round trip instead of three)
                 if (WT >= 2 && std::is_empty<typename Op::NB>::value && __any(cnt > 4u * (uint32_t)(WT - 1))) {
                     // the usual wave (12 neighbours on the rest lattice)
@@ -735,11 +731,6 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_sweep_off(Op op, SweepCommon 
                     if (__any(cnt > 4u)) SPH_OFF_TRIP(g1.x, g1.y)
                     if (__any(cnt > 8u)) SPH_OFF_TRIP(g2.x, g2.y)
                 }
-#else
-                SPH_OFF_TRIP(g0.x, g0.y)
-                if (__any(cnt > 4u)) SPH_OFF_TRIP(g1.x, g1.y)
-                if (__any(cnt > 8u)) SPH_OFF_TRIP(g2.x, g2.y)
-#endif
 #pragma unroll
                 for (uint32_t g = 3; g < (uint32_t)NLOFF_GROUPS; g++) {
                     if (!__any(cnt > 4u * g)) break;
@@ -1736,10 +1727,7 @@ struct OpPressureAccelU : OpPressureAccel<MathT> {
     typedef OpPressureAccel<MathT> B;
     static constexpr bool TILE = false, RING1 = true;   // (slab decomposition: the first ghost ring computes its own a^p, as in the base)
     static constexpr bool OFF16 = true;                 // (k_sweep_off: relative-offset lists)
-#ifndef SPH_WIDE_A
-#define SPH_WIDE_A 3
-#endif
-    static constexpr int WIDE_TRIPS = SPH_WIDE_A;
+    static constexpr int WIDE_TRIPS = 3;                // (measured: 3 and 2 alike, 1 is 1.3 % slower on the driver window)
     typedef NBNone NB;
     const float4* __restrict__ rec;   // of the pressure buffer this iteration reads (slabs: the ghosts' records carry their owners' p / rho^2, refreshed every iteration)
     struct Acc {
@@ -2015,10 +2003,7 @@ struct OpJacobiU : OpJacobi<MathT> {
     typedef typename B::Acc Acc;
     static constexpr bool TILE = false;
     static constexpr bool OFF16 = true;   // (k_sweep_off: relative-offset lists)
-#ifndef SPH_WIDE_B
-#define SPH_WIDE_B 3
-#endif
-    static constexpr int WIDE_TRIPS = SPH_WIDE_B;
+    static constexpr int WIDE_TRIPS = 3;   // (OpJacobiU 18.2 -> 17.1 us)
     typedef NBNone NB;
     __device__ float4 loadA(uint32_t j) const { return this->pacc[j]; }
     __device__ NB nb(const Acc&, uint32_t, float4) const { return NB{}; }
