@@ -17,6 +17,10 @@
 //     that word: per row, up to 4 set bits per trip -> four independent gathers of the neighbour
 //     record and its per-neighbour payload -> four pair evaluations -- 13 instead of ~38
 //     candidate evaluations per particle, 4-way ILP, no barriers, no LDS, 8 waves per SIMD.
+//     Since round 4 the gradient sweeps (both sweeps of a Jacobi iteration, the source terms) replay
+//     the same list in a second form the density sweep writes beside the word: 16-bit offsets j - i,
+//     flat, four per 8-byte group (k_sweep_off below): no decoding per slot, no cell index and no
+//     cell-table loads at the head of the sweep;
 //     Neighbours of neighbouring lanes are adjacent in memory (cell-sorted order), so the gathers
 //     hit the same few cache lines per wave; per-neighbour derived quantities (p_j/rho_j^2,
 //     m_j/rho_j) are produced once per particle by the sweep that owns them, not once per pair;
