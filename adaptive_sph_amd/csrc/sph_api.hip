@@ -510,6 +510,7 @@ Options options_from_env()
     o.force_slab_mode = flag("SPH_FORCE_SLAB_MODE");
     o.tile = num("SPH_TILE", 0);
     o.ahead_build = num("SPH_AHEAD_BUILD", 1) != 0 ? 1 : 0;
+    o.inc_sort = num("SPH_INC_SORT", 1) != 0 ? 1 : 0;
     o.slab_paced = num("SPH_SLAB_PACED", 1) != 0 ? 1 : 0;
     o.slab_records = num("SPH_SLAB_RECORDS", 1) != 0 ? 1 : 0;
     o.debug_sync = num("SPH_DEBUG_SYNC", 0);

@@ -113,6 +113,33 @@ struct CellKeyGen {
 int radix_sort_pairs(hipStream_t s, Profiler* prof, uint32_t* keyA, uint32_t* valA, uint32_t* keyB, uint32_t* valB,
                      uint32_t n, int bits, uint32_t* hist_scratch /* >= 256 * nblocks + 256 */, const CellKeyGen* keygen = nullptr);
 size_t radix_sort_scratch_elems(uint32_t n);
+// The same stable sort as a MERGE, for an array that is sorted by the cells `cxy_cur` (grid g_cur, ranges cell_start_cur) and whose
+// particles mostly stay in their cells -- with the reorder of the per-particle arrays in the same pass: sorted keys of `kg` (a grid of
+// the same cell size), the arrays of `io` in the new order and the new cell-range table [kg.g.ncells + 1], bit for bit what
+// radix_sort_pairs + launch_reorder + launch_cell_start produce (the permutation itself is never stored).  Scratch: nk[n], mv[n] bytes,
+// next[n], head[kg.g.ncells] (zeroed once when allocated, never cleared: `epoch` must differ from call to call and from 0),
+// bsum[incremental_sort_block_sums(ncells)], movers (one zeroed word; the call leaves the number of movers in *movers_host).
+struct ReorderIO {   // what launch_reorder moves (same meaning, same optional members)
+    const float4* pm_in;
+    const float2* vel_in;
+    const uint32_t* orig_in;
+    const float *lvl_in, *lvlold_in;
+    float4* pm_out;
+    float2* vel_out;
+    uint32_t* orig_out;
+    float *lvl_out, *lvlold_out;
+    uint32_t* cxy_out;
+    const float* h2n_in;
+    float* h2n_out;
+    const float* lam_in;
+    float* lam_prev_out;
+    const uint8_t* szc_in;
+    uint8_t* szc_out;
+};
+size_t incremental_sort_block_sums(uint32_t ncells);
+void incremental_cell_sort_reorder(hipStream_t s, Profiler* prof, uint32_t n, const CellKeyGen& kg, const GridP& g_cur, const uint32_t* cxy_cur,
+                                   const uint32_t* cell_start_cur, uint32_t* key_out, uint32_t* cell_start_out, const ReorderIO& io, uint32_t* nk, uint8_t* mv,
+                                   uint32_t* next, unsigned long long* head, uint32_t* bsum, uint32_t epoch, uint32_t* movers, uint32_t* movers_host);
 
 void launch_reorder(hipStream_t s, Profiler* prof, uint32_t n, GridP g, const uint32_t* sorted_key, const uint32_t* perm,
                     const float4* pm_in, const float2* vel_in, const uint32_t* orig_in, const float* lvl_in,

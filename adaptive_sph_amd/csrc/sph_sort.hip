@@ -254,6 +254,219 @@ int radix_sort_pairs(hipStream_t s, Profiler* prof, uint32_t* keyA, uint32_t* va
 }
 
 // ------------------------------------------------------------------------------------------------
+// Incremental cell sort (round 4; VERDICT r3 "do not sort every step"): the array is ALREADY sorted by the cells its particles
+// stood in at the start of the step, and a step moves few of them into another cell (configs[1]: 0.1-1 % per step,
+// scripts/gpu_cell_movers.py).  The stable sort by the new cells is then a MERGE: the particles that stay (their keys are still
+// ascending) with the few movers -- and every particle can compute its own slot:
+//     slot(i) = first slot of its new cell                                    (scan over the cells' new populations)
+//             + stayers of that cell in front of it                           (a look at the cell's old range: ~5 flags)
+//             + movers INTO that cell with a smaller old index                (a per-cell list, empty for 96 % of the cells)
+// which is exactly where the stable LSD sort puts it (ties by old index).  Four launches (classify, count, scan, place + reorder)
+// instead of the six of two radix passes, the reorder and the two of the cell-range table; same sorted keys, same order of the arrays
+// and same cell_start bit for bit, whatever the number of movers -- the per-cell lists are built with atomics but only ever COUNTED, so no
+// result depends on their order.  Cost grows with the movers (one 64-bit atomic exchange each, list walks in the cells they
+// enter): the caller falls back to the radix sort when the previous step's count was large (queue_ahead_build).
+// The grids of the two steps differ by a translation only (same cell size): lexicographic order of the cells is the same in both.
+// ------------------------------------------------------------------------------------------------
+struct IncGrid {
+    GridP cur, nxt;   // the grid the array is sorted by; the grid of the keys to sort by (same cs)
+};
+// key of current-grid cell (cx, cy) in the next grid.  The next grid covers the bounding box the current cells were computed from
+// (queue_ahead_build), so the cell lies inside it; if it ever did not, no key equals the value returned here and the particle counts
+// as a mover -- it is then on exactly one list and in no cell's stayers, like every other mover: the slots still add up to n.
+__device__ __forceinline__ uint32_t inc_key_of_cur_cell(const IncGrid& G, uint32_t cxy)
+{
+    const int cx = (int)(cxy & 0xffffu) + G.cur.minx - G.nxt.minx, cy = (int)(cxy >> 16) + G.cur.miny - G.nxt.miny;
+    if (cx < 0 || cx >= G.nxt.sx || cy < 0 || cy >= G.nxt.sy) return 0xffffffffu;
+    return (uint32_t)cx + (uint32_t)cy * (uint32_t)G.nxt.sx;
+}
+// range of next-grid cell c in the CURRENT order ([0, 0) if the current grid has no such cell)
+__device__ __forceinline__ void inc_cur_range(const IncGrid& G, uint32_t c, const uint32_t* __restrict__ cell_start_cur, uint32_t& b, uint32_t& e)
+{
+    const uint32_t cy = c / (uint32_t)G.nxt.sx, cx = c - cy * (uint32_t)G.nxt.sx;
+    const int ox = (int)cx + G.nxt.minx - G.cur.minx, oy = (int)cy + G.nxt.miny - G.cur.miny;
+    b = e = 0u;
+    if (ox >= 0 && ox < G.cur.sx && oy >= 0 && oy < G.cur.sy) {
+        const uint32_t k = (uint32_t)ox + (uint32_t)oy * (uint32_t)G.cur.sx;
+        b = cell_start_cur[k];
+        e = cell_start_cur[k + 1];
+    }
+}
+#define INC_HEAD(EPOCH, I) (((unsigned long long)(EPOCH) << 32) | (unsigned long long)((I) + 1u))
+
+// 1. new key and mover flag of every particle; a mover hangs itself into the list of the cell it enters (head[c]: epoch-tagged, so
+//    the table is never cleared -- an entry of another step reads as "empty")
+__global__ __launch_bounds__(256) void k_inc_classify(uint32_t n, CellKeyGen kg, IncGrid G, const uint32_t* __restrict__ cxy_cur, uint32_t* __restrict__ nk,
+                                                       uint8_t* __restrict__ mv, uint32_t* __restrict__ next, unsigned long long* __restrict__ head, uint32_t epoch)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t k = cell_key_of(kg, i);
+    const bool mover = k != inc_key_of_cur_cell(G, cxy_cur[i]);
+    nk[i] = k;
+    mv[i] = mover ? 1 : 0;
+    if (mover) {
+        const unsigned long long prev = atomicExch(&head[k], INC_HEAD(epoch, i));
+        next[i] = (uint32_t)(prev >> 32) == epoch ? (uint32_t)prev : 0u;
+    }
+}
+
+// 2. new population of every cell = its stayers + the length of its list; per-block sums (INC_CELLS cells per block, one per thread:
+//    the chain range -> flags -> list is three dependent round trips, so the launch wants many short threads)
+#define INC_CELLS 1024
+__global__ __launch_bounds__(INC_CELLS) void k_inc_count(IncGrid G, const uint32_t* __restrict__ cell_start_cur, const uint8_t* __restrict__ mv,
+                                                          const uint32_t* __restrict__ next, const unsigned long long* __restrict__ head, uint32_t epoch,
+                                                          uint32_t* __restrict__ count /* cell_start of the next grid, used as scratch */, uint32_t* __restrict__ bsum,
+                                                          uint32_t* __restrict__ movers)
+{
+    __shared__ uint32_t ws[INC_CELLS / 64], wm[INC_CELLS / 64];
+    const uint32_t c = blockIdx.x * (uint32_t)INC_CELLS + threadIdx.x;
+    uint32_t cnt = 0, listed = 0;
+    if (c < G.nxt.ncells) {
+        uint32_t b, e;
+        inc_cur_range(G, c, cell_start_cur, b, e);
+        const unsigned long long h = head[c];
+        for (uint32_t j = b; j < e; j++) cnt += mv[j] ? 0u : 1u;
+        if ((uint32_t)(h >> 32) == epoch)
+            for (uint32_t m = (uint32_t)h; m; m = next[m - 1u]) listed++;
+        cnt += listed;
+        count[c] = cnt;
+    }
+    uint32_t x = cnt, y = listed;
+    for (int o = 32; o > 0; o >>= 1) {
+        x += (uint32_t)__shfl_xor((int)x, o, 64);
+        y += (uint32_t)__shfl_xor((int)y, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        ws[threadIdx.x >> 6] = x;
+        wm[threadIdx.x >> 6] = y;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0, m = 0;
+        for (int k = 0; k < INC_CELLS / 64; k++) {
+            t += ws[k];
+            m += wm[k];
+        }
+        bsum[blockIdx.x] = t;
+        if (m) atomicAdd(movers, m);   // (what the caller's next decision is taken on: a few hundred adds at most)
+    }
+}
+
+// 3. exclusive scan of the populations: cell_start of the next grid (in place); block 0 hands the mover count to the host
+__global__ __launch_bounds__(256) void k_inc_scan(uint32_t ncells, uint32_t* __restrict__ cell_start, const uint32_t* __restrict__ bsum, uint32_t* __restrict__ movers,
+                                                   uint32_t* __restrict__ movers_host)
+{
+    __shared__ uint32_t ws[4], base_s;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    uint32_t pre = 0;
+    for (uint32_t k = tid; k < blockIdx.x; k += 256) pre += bsum[k];
+    for (int o = 32; o > 0; o >>= 1) pre += (uint32_t)__shfl_xor((int)pre, o, 64);
+    if (lane == 0) ws[w] = pre;
+    __syncthreads();
+    if (tid == 0) base_s = ws[0] + ws[1] + ws[2] + ws[3];
+    __syncthreads();
+    const uint32_t c0 = blockIdx.x * (uint32_t)INC_CELLS + 4u * (uint32_t)tid;
+    uint32_t v[4];
+#pragma unroll
+    for (uint32_t u = 0; u < 4u; u++) v[u] = c0 + u < ncells ? cell_start[c0 + u] : 0u;
+    const uint32_t own = v[0] + v[1] + v[2] + v[3];
+    uint32_t x = own;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t y = __shfl_up(x, o, 64);
+        if (lane >= o) x += y;
+    }
+    if (lane == 63) ws[w] = x;
+    __syncthreads();
+    uint32_t run = base_s + x - own;
+    for (int k = 0; k < w; k++) run += ws[k];
+#pragma unroll
+    for (uint32_t u = 0; u < 4u; u++) {
+        if (c0 + u < ncells) cell_start[c0 + u] = run;
+        run += v[u];
+        if (c0 + u + 1u == ncells) cell_start[ncells] = run;
+    }
+    if (blockIdx.x == 0 && tid == 0) {
+        *movers_host = *movers;
+        *movers = 0u;
+    }
+}
+
+// 4. every particle to its slot, with everything k_reorder moves (the merge knows where a particle GOES, so the reorder is a scatter of
+//    coalesced reads -- a near-identity one -- and the permutation is never stored); the sorted keys as the radix sort leaves them
+__global__ __launch_bounds__(256) void k_inc_place_reorder(uint32_t n, IncGrid G, const uint32_t* __restrict__ cell_start_cur, const uint32_t* __restrict__ cell_start_nxt,
+                                                            const uint32_t* __restrict__ nk, const uint8_t* __restrict__ mv, const uint32_t* __restrict__ next,
+                                                            const unsigned long long* __restrict__ head, uint32_t epoch, const uint32_t* __restrict__ cxy_cur,
+                                                            uint32_t* __restrict__ key_out, ReorderIO io)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    // (everything that does not depend on the slot is requested first)
+    const uint32_t c = nk[i];
+    const bool mover = mv[i] != 0;
+    const uint32_t own = cxy_cur[i];
+    const float4 pm = io.pm_in[i];
+    const float2 vel = io.vel_in[i];
+    const uint32_t orig = io.orig_in[i];
+    const float lvl = io.lvl_in[i], lvlold = io.lvlold_in[i];
+    const unsigned long long h = head[c];
+    const uint32_t first = cell_start_nxt[c];
+    uint32_t b, e, r = 0;
+    if (!mover) {   // the particle's own cell: no division
+        const uint32_t k = (own & 0xffffu) + (own >> 16) * (uint32_t)G.cur.sx;
+        b = cell_start_cur[k];
+        e = i;
+    } else {        // stayers of the cell it enters: all of them if it comes from behind the cell's old range, none if from before it
+        uint32_t eb;
+        inc_cur_range(G, c, cell_start_cur, b, eb);
+        e = i >= eb ? eb : b;
+    }
+    for (uint32_t j = b; j < e; j++) r += mv[j] ? 0u : 1u;
+    if ((uint32_t)(h >> 32) == epoch)
+        for (uint32_t m = (uint32_t)h; m; m = next[m - 1u]) r += (m - 1u < i) ? 1u : 0u;
+    const uint32_t dst = first + r;
+    key_out[dst] = c;
+    io.pm_out[dst] = pm;
+    io.vel_out[dst] = vel;
+    io.orig_out[dst] = orig;
+    io.lvl_out[dst] = lvl;
+    io.lvlold_out[dst] = lvlold;
+    if (io.h2n_in) io.h2n_out[dst] = io.h2n_in[i];
+    if (io.lam_in) io.lam_prev_out[dst] = io.lam_in[i];
+    if (io.szc_in) io.szc_out[dst] = io.szc_in[i];
+    const uint32_t cy = c / (uint32_t)G.nxt.sx;
+    io.cxy_out[dst] = (c - cy * (uint32_t)G.nxt.sx) | (cy << 16);
+}
+
+size_t incremental_sort_block_sums(uint32_t ncells) { return ((size_t)ncells + INC_CELLS - 1) / INC_CELLS; }
+
+void incremental_cell_sort_reorder(hipStream_t s, Profiler* prof, uint32_t n, const CellKeyGen& kg, const GridP& g_cur, const uint32_t* cxy_cur,
+                                   const uint32_t* cell_start_cur, uint32_t* key_out, uint32_t* cell_start_out, const ReorderIO& io, uint32_t* nk, uint8_t* mv,
+                                   uint32_t* next, unsigned long long* head, uint32_t* bsum, uint32_t epoch, uint32_t* movers, uint32_t* movers_host)
+{
+    const IncGrid G{g_cur, kg.g};
+    const uint32_t ncells = kg.g.ncells, cblocks = (uint32_t)incremental_sort_block_sums(ncells);
+    {
+        ProfScope ps(prof, "inc_classify", s);
+        hipLaunchKernelGGL(k_inc_classify, dim3((n + 255) / 256), dim3(256), 0, s, n, kg, G, cxy_cur, nk, mv, next, head, epoch);
+    }
+    {
+        ProfScope ps(prof, "inc_count", s);
+        hipLaunchKernelGGL(k_inc_count, dim3(cblocks), dim3(INC_CELLS), 0, s, G, cell_start_cur, mv, next, head, epoch, cell_start_out, bsum, movers);
+    }
+    {
+        ProfScope ps(prof, "inc_scan", s);
+        hipLaunchKernelGGL(k_inc_scan, dim3(cblocks), dim3(256), 0, s, ncells, cell_start_out, bsum, movers, movers_host);
+    }
+    {
+        ProfScope ps(prof, "inc_reorder", s);
+        hipLaunchKernelGGL(k_inc_place_reorder, dim3((n + 255) / 256), dim3(256), 0, s, n, G, cell_start_cur, cell_start_out, nk, mv, next, head, epoch, cxy_cur,
+                           key_out, io);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // cell keys / reorder / cell-range table / tiles
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_reorder(uint32_t n, GridP g, const uint32_t* __restrict__ sorted_key,

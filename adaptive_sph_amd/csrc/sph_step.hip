@@ -1487,17 +1487,49 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
         const int k = c->cur;
         const float4* integrated = c->pm[c->pcur ^ 1].as<float4>();   // (the tail's output; the step's end flips pcur)
         const CellKeyGen kg{integrated, g, nullptr, 0u, (uint32_t)SC_GONE_FROM, 1};   // (clamped keys: the grid is a prediction)
-        const int res = radix_sort_pairs(s, &c->prof, c->akey[0].as<uint32_t>(), c->aval[0].as<uint32_t>(), c->akey[1].as<uint32_t>(), c->aval[1].as<uint32_t>(), n,
-                                         ilog2_ceil(g.ncells), c->sort_scratch.as<uint32_t>(), &kg);
-        if (res == 1) {
-            std::swap(c->akey[0], c->akey[1]);
-            std::swap(c->aval[0], c->aval[1]);
+        // The array is sorted by the cells of this step's start and a step moves few particles into another cell: the sort is a
+        // merge of the ones that stay with the ones that do not (sph_sort.hip: incremental_cell_sort) -- same keys, permutation and
+        // cell ranges as the radix sort, whatever the number of movers; its cost grows with them, so a large count (the last one the
+        // device reported: a step or two old) sends the build through the radix sort, and every eighth such build probes again.
+        uint32_t* movers_host = (uint32_t*)(c->ctrl_host + 2) + 1;   // (second word of the mapped block whose first word is the paced solves' progress)
+        bool incremental = c->opt.inc_sort && c->grid_valid && c->fgrid.cs == cs && c->fgrid.ncells > 0 && g.ncells <= 4u * n + 4096u;
+        if (incremental && *movers_host > n / 8u) {
+            incremental = ++c->inc_radix_streak >= 8;
+            if (incremental) c->inc_radix_streak = 0;
         }
-        launch_reorder(s, &c->prof, n, g, c->akey[0].as<uint32_t>(), c->aval[0].as<uint32_t>(), integrated, c->vel[k].as<float2>(), c->orig[k].as<uint32_t>(),
-                       c->lvl[k].as<float>(), c->lvlold[k].as<float>(), c->pm2.as<float4>(), c->vel[k ^ 1].as<float2>(), c->orig[k ^ 1].as<uint32_t>(),
-                       c->lvl[k ^ 1].as<float>(), c->lvlold[k ^ 1].as<float>(), c->acxy.as<uint32_t>(), c->h2n[k].as<float>(), c->h2n[k ^ 1].as<float>(),
-                       c->lam_sum.as<float>(), c->lam_prev.as<float>(), c->cs_scratch.p, c->szc[k].as<uint8_t>(), c->szc[k ^ 1].as<uint8_t>());
-        launch_cell_start(s, &c->prof, c->akey[0].as<uint32_t>(), n, g.ncells, c->acell_start.as<uint32_t>(), c->cs_scratch.p, true);
+        if (incremental) {
+            const size_t head_before = c->inc_head.bytes;
+            HIPCHK(c, c->inc_head.ensure((size_t)g.ncells * 8));
+            if (c->inc_head.bytes != head_before) HIPCHK(c, hipMemsetAsync(c->inc_head.p, 0, c->inc_head.bytes, s));   // (epoch 0: no list)
+            HIPCHK(c, c->inc_next.ensure((size_t)c->cap * 4));
+            HIPCHK(c, c->inc_bsum.ensure(incremental_sort_block_sums(g.ncells) * 4));
+            if (!c->inc_movers.p) {
+                HIPCHK(c, c->inc_movers.ensure(4));
+                HIPCHK(c, hipMemsetAsync(c->inc_movers.p, 0, 4, s));
+            }
+            if (++c->inc_epoch == 0u) c->inc_epoch = 1u;
+            const ReorderIO io{integrated, c->vel[k].as<float2>(), c->orig[k].as<uint32_t>(), c->lvl[k].as<float>(), c->lvlold[k].as<float>(), c->pm2.as<float4>(),
+                               c->vel[k ^ 1].as<float2>(), c->orig[k ^ 1].as<uint32_t>(), c->lvl[k ^ 1].as<float>(), c->lvlold[k ^ 1].as<float>(), c->acxy.as<uint32_t>(),
+                               c->h2n[k].as<float>(), c->h2n[k ^ 1].as<float>(), c->lam_sum.as<float>(), c->lam_prev.as<float>(), c->szc[k].as<uint8_t>(),
+                               c->szc[k ^ 1].as<uint8_t>()};
+            incremental_cell_sort_reorder(s, &c->prof, n, kg, c->fgrid, c->cxy.as<uint32_t>(), c->cell_start.as<uint32_t>(), c->akey[0].as<uint32_t>(),
+                                          c->acell_start.as<uint32_t>(), io, c->akey[1].as<uint32_t>(), c->aval[1].as<uint8_t>(), c->inc_next.as<uint32_t>(),
+                                          c->inc_head.as<unsigned long long>(), c->inc_bsum.as<uint32_t>(), c->inc_epoch, c->inc_movers.as<uint32_t>(),
+                                          (uint32_t*)(c->ctrl_host_dev + 2) + 1);
+        } else {
+            const int res = radix_sort_pairs(s, &c->prof, c->akey[0].as<uint32_t>(), c->aval[0].as<uint32_t>(), c->akey[1].as<uint32_t>(), c->aval[1].as<uint32_t>(), n,
+                                             ilog2_ceil(g.ncells), c->sort_scratch.as<uint32_t>(), &kg);
+            if (res == 1) {
+                std::swap(c->akey[0], c->akey[1]);
+                std::swap(c->aval[0], c->aval[1]);
+            }
+        }
+        if (!incremental)
+            launch_reorder(s, &c->prof, n, g, c->akey[0].as<uint32_t>(), c->aval[0].as<uint32_t>(), integrated, c->vel[k].as<float2>(), c->orig[k].as<uint32_t>(),
+                           c->lvl[k].as<float>(), c->lvlold[k].as<float>(), c->pm2.as<float4>(), c->vel[k ^ 1].as<float2>(), c->orig[k ^ 1].as<uint32_t>(),
+                           c->lvl[k ^ 1].as<float>(), c->lvlold[k ^ 1].as<float>(), c->acxy.as<uint32_t>(), c->h2n[k].as<float>(), c->h2n[k ^ 1].as<float>(),
+                           c->lam_sum.as<float>(), c->lam_prev.as<float>(), c->cs_scratch.p, c->szc[k].as<uint8_t>(), c->szc[k ^ 1].as<uint8_t>());
+        if (!incremental) launch_cell_start(s, &c->prof, c->akey[0].as<uint32_t>(), n, g.ncells, c->acell_start.as<uint32_t>(), c->cs_scratch.p, true);
         c->ahead.valid = true;
         c->ahead.g = g;
         c->ahead.h_max = h_max_g;

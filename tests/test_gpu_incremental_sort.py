@@ -1,0 +1,64 @@
+"""The cell sort a step queues ahead for the next one (sph_step.hip: queue_ahead_build) as a MERGE of the particles that stay in
+their cells with the few that do not (sph_sort.hip: incremental_cell_sort) against the stable radix sort it replaces
+(SPH_INC_SORT=0): the same keys, permutation and cell ranges, so the same order of the arrays -- every field, every iteration
+statistic and every neighbour LIST (order included: it is the order of the sorted array) bit for bit, over free-running steps."""
+import numpy as np
+import pytest
+
+from adaptive_sph_amd import ffi, scene as sc
+from adaptive_sph_amd.workloads import dam_break_params
+
+pytestmark = pytest.mark.gpu
+
+
+def scene_of(kind):
+    if kind == "column":   # the headline's shape: a column at rest that starts to collapse (few movers per step)
+        return sc.dam_break_small(128, 96, 1 / 64), {}
+    if kind == "thrown":   # a block thrown through the box: many movers per step, a bounding box (and a grid origin) that travels
+        d = 1 / 64
+        return sc.SceneConfig(sc.SceneBoundary("box", 4.0, 2.0), [sc.SceneFluidBlock([-1.6, -0.6], [96 * d, 64 * d], d, 0.93, [3.0, 1.0])]), dict(max_dt=0.0005)
+    # two blocks that run into each other: cells that receive several movers in one step, cells that empty
+    d = 1 / 64
+    return sc.SceneConfig(sc.SceneBoundary("box", 4.0, 2.0), [sc.SceneFluidBlock([-1.2, -0.9], [48 * d, 80 * d], d, 0.93, [4.0, 0.0]),
+                                                               sc.SceneFluidBlock([-0.2, -0.9], [48 * d, 80 * d], d, 0.93, [-4.0, 0.5])]), dict(max_dt=0.0005)
+
+
+@pytest.mark.parametrize("kind,solver,steps", [("column", "HybridDFSPH", 40), ("thrown", "HybridDFSPH", 30), ("collide", "IISPH", 30)])
+def test_incremental_cell_sort_is_the_radix_sort(product_lib, monkeypatch, kind, solver, steps):
+    scn, over = scene_of(kind)
+    pos, mass, vel = sc.init_particles(scn)
+    P = dam_break_params(pressure_solver_method=solver, **over)
+    planes = sc.boundary_planes(scn.boundary, P.init_boundary_handler)
+    p = P.to_ffi()
+    out = {}
+    for form in ("merge", "radix"):
+        if form == "radix":
+            monkeypatch.setenv("SPH_INC_SORT", "0")
+        g = ffi.Context(product_lib, len(mass), planes)   # (the switches are read at sph_create)
+        if form == "radix":
+            monkeypatch.delenv("SPH_INC_SORT")
+        g.upload(mass, pos, vel)
+        g.profile_enable(1)
+        its, fields = [], []
+        for s in range(steps):
+            st = g.step(p)
+            its.append((int(st.div_solver.iters), int(st.density_solver.iters), int(st.density_solver.normal_count),
+                        np.float32(st.density_solver.avg_error).view(np.uint32).item(), np.float32(st.dt).view(np.uint32).item()))
+            f = {k: g.download(k) for k in ("position", "velocity", "pressure", "density", "cell_index")}
+            if s % 5 == 4 or s == steps - 1:
+                f["nl_offsets"], f["nl_indices"] = g.download_neighbors()
+            fields.append(f)
+        prof = g.profile_get()
+        out[form] = (its, fields, prof)
+        g.close()
+    # the forms really differ in what they launched: all but the first build were queued ahead
+    assert out["merge"][2].get("inc_reorder", (0, 0))[0] >= steps - 2, out["merge"][2]
+    assert "inc_reorder" not in out["radix"][2] and out["radix"][2]["sort_scatter"][0] >= 2 * (steps - 1)
+    assert out["merge"][2].get("sort_scatter", (0, 0))[0] <= 4   # (the first build of the run, and nothing else)
+    assert out["merge"][0] == out["radix"][0]
+    for s, (fa, fb) in enumerate(zip(out["merge"][1], out["radix"][1])):
+        for k in fa:
+            assert np.array_equal(fa[k], fb[k]), (s, k)
+    if kind != "column":   # these scenes move: the bounding box (hence the grid origin) travelled by more than a cell along the way
+        x0, x1 = out["merge"][1][0]["position"], out["merge"][1][-1]["position"]
+        assert np.abs(x1 - x0).max() > (1 / 64) * 2.2
