@@ -10,6 +10,7 @@
 // sph_step.hip.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -1085,10 +1086,18 @@ extern "C" int sph_profile_get(sph_ctx* c, sph_kernel_time* out, int capacity, i
             strncpy(out[k].name, r.name.c_str(), sizeof(out[k].name) - 1);
             out[k].launches = r.launches;
             out[k].total_ms = r.total_ms;
-            float mx = 0.f;
-            for (float v : r.samples) mx = v > mx ? v : mx;
+            // a launch "did work" if it took more than a quarter of the kernel's 90th-percentile duration (a launch that returns at
+            // once behind a stop decision takes 2-4 us).  Not of the maximum: one hiccup of 100 us among 400 launches of 17 us
+            // made every ordinary launch "idle" and the kernel's working average that of its outliers
+            float ref = 0.f;
+            if (!r.samples.empty()) {
+                std::vector<float> sorted(r.samples);
+                const size_t k = (sorted.size() - 1) * 9 / 10;
+                std::nth_element(sorted.begin(), sorted.begin() + k, sorted.end());
+                ref = sorted[k];
+            }
             for (float v : r.samples)
-                if (v > 0.25f * mx) {
+                if (v > 0.25f * ref) {
                     out[k].working_launches++;
                     out[k].working_ms += v;
                 }

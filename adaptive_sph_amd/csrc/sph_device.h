@@ -32,6 +32,50 @@ struct GridP {
     uint32_t ncells;
 };
 
+// cell key of a position in grid g, clamped into it (the grid of a build queued ahead is a prediction: sph_sort.hip, cell_key_of).
+// IEEE division, like `(particle_pos / kernel_support_radius).map(|x| x.floor() as i32)` (neighborhood_search.rs:253-255)
+__device__ __forceinline__ uint32_t cell_key_clamped(const GridP& g, float x, float y)
+{
+    int cx = (int)floorf(x / g.cs) - g.minx;
+    int cy = (int)floorf(y / g.cs) - g.miny;
+    cx = min(max(cx, 0), g.sx - 1);
+    cy = min(max(cy, 0), g.sy - 1);
+    return (uint32_t)cx + (uint32_t)cy * (uint32_t)g.sx;
+}
+
+// Incremental cell sort (sph_sort.hip): what classifies a particle -- by k_inc_classify, or by the integrating tail of the step's
+// last solve, which holds the new position in registers (sph_sweeps.hip: k_solver_tail).  head == nullptr: not wanted.
+struct IncClassifyP {
+    GridP cur, nxt;                   // the grid the array is sorted by; the grid of the keys to sort by (same cell size)
+    const uint32_t* cxy_cur;          // cell of every particle in the current order (cx | cy << 16, grid `cur`)
+    uint32_t* nk;                     // out: new key
+    uint8_t* mv;                      // out: 1 = the particle changes its cell
+    uint32_t* next;                   // out: list link of a mover
+    unsigned long long* head;         // per-cell list heads of grid `nxt`, tagged with `epoch` (never cleared)
+    uint32_t epoch;
+};
+// key of current-grid cell (cx, cy) in the next grid.  The next grid covers the bounding box the current cells were computed from
+// (queue_ahead_build), so the cell lies inside it; if it ever did not, no key equals the value returned here and the particle counts
+// as a mover -- it is then on exactly one list and in no cell's stayers, like every other mover: the slots still add up to n.
+__device__ __forceinline__ uint32_t inc_key_of_cur_cell(const GridP& cur, const GridP& nxt, uint32_t cxy)
+{
+    const int cx = (int)(cxy & 0xffffu) + cur.minx - nxt.minx, cy = (int)(cxy >> 16) + cur.miny - nxt.miny;
+    if (cx < 0 || cx >= nxt.sx || cy < 0 || cy >= nxt.sy) return 0xffffffffu;
+    return (uint32_t)cx + (uint32_t)cy * (uint32_t)nxt.sx;
+}
+// new key and mover flag of particle i at (x, y); a mover hangs itself into the list of the cell it enters
+__device__ __forceinline__ void inc_classify_particle(const IncClassifyP& q, uint32_t i, float x, float y)
+{
+    const uint32_t k = cell_key_clamped(q.nxt, x, y);
+    const bool mover = k != inc_key_of_cur_cell(q.cur, q.nxt, q.cxy_cur[i]);
+    q.nk[i] = k;
+    q.mv[i] = mover ? 1 : 0;
+    if (mover) {
+        const unsigned long long prev = atomicExch(&q.head[k], ((unsigned long long)q.epoch << 32) | (unsigned long long)(i + 1u));
+        q.next[i] = (uint32_t)(prev >> 32) == q.epoch ? (uint32_t)prev : 0u;
+    }
+}
+
 // Multi-resolution scenes sort by a grid whose cell is the support of the SMALLEST particle.  A tile is
 // ts x ts cells with ts * cs >= the largest support, so every neighbour of a particle lives in the 3 x 3
 // tiles around its own; hmax[tile] is the largest h found in those 3 x 3 tiles, i.e. an upper bound on h_j of

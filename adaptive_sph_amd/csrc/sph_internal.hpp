@@ -113,12 +113,14 @@ struct CellKeyGen {
 int radix_sort_pairs(hipStream_t s, Profiler* prof, uint32_t* keyA, uint32_t* valA, uint32_t* keyB, uint32_t* valB,
                      uint32_t n, int bits, uint32_t* hist_scratch /* >= 256 * nblocks + 256 */, const CellKeyGen* keygen = nullptr);
 size_t radix_sort_scratch_elems(uint32_t n);
-// The same stable sort as a MERGE, for an array that is sorted by the cells `cxy_cur` (grid g_cur, ranges cell_start_cur) and whose
-// particles mostly stay in their cells -- with the reorder of the per-particle arrays in the same pass: sorted keys of `kg` (a grid of
-// the same cell size), the arrays of `io` in the new order and the new cell-range table [kg.g.ncells + 1], bit for bit what
-// radix_sort_pairs + launch_reorder + launch_cell_start produce (the permutation itself is never stored).  Scratch: nk[n], mv[n] bytes,
-// next[n], head[kg.g.ncells] (zeroed once when allocated, never cleared: `epoch` must differ from call to call and from 0),
-// bsum[incremental_sort_block_sums(ncells)], movers (one zeroed word; the call leaves the number of movers in *movers_host).
+// The same stable sort as a MERGE, for an array that is sorted by the cells q.cxy_cur (grid q.cur, ranges cell_start_cur) and whose
+// particles mostly stay in their cells -- with the reorder of the per-particle arrays in the same pass: sorted keys of the positions
+// pm_new in grid q.nxt (same cell size, clamped keys), the arrays of `io` in the new order and the new cell-range table
+// [q.nxt.ncells + 1], bit for bit what radix_sort_pairs + launch_reorder + launch_cell_start produce (the permutation itself is never
+// stored).  `classified`: the kernel that computed pm_new has run inc_classify_particle (sph_device.h) for every particle already.
+// Scratch: q.nk[n], q.mv[n] bytes, q.next[n], q.head[q.nxt.ncells] (zeroed once when allocated, never cleared: q.epoch must differ
+// from call to call and from 0), bsum[incremental_sort_block_sums(ncells)], movers (one zeroed word; the call leaves the number of
+// movers in *movers_host).
 struct ReorderIO {   // what launch_reorder moves (same meaning, same optional members)
     const float4* pm_in;
     const float2* vel_in;
@@ -137,9 +139,9 @@ struct ReorderIO {   // what launch_reorder moves (same meaning, same optional m
     uint8_t* szc_out;
 };
 size_t incremental_sort_block_sums(uint32_t ncells);
-void incremental_cell_sort_reorder(hipStream_t s, Profiler* prof, uint32_t n, const CellKeyGen& kg, const GridP& g_cur, const uint32_t* cxy_cur,
-                                   const uint32_t* cell_start_cur, uint32_t* key_out, uint32_t* cell_start_out, const ReorderIO& io, uint32_t* nk, uint8_t* mv,
-                                   uint32_t* next, unsigned long long* head, uint32_t* bsum, uint32_t epoch, uint32_t* movers, uint32_t* movers_host);
+void incremental_cell_sort_reorder(hipStream_t s, Profiler* prof, uint32_t n, const float4* pm_new, const IncClassifyP& q, bool classified,
+                                   const uint32_t* cell_start_cur, uint32_t* key_out, uint32_t* cell_start_out, const ReorderIO& io, uint32_t* bsum, uint32_t* movers,
+                                   uint32_t* movers_host);
 
 void launch_reorder(hipStream_t s, Profiler* prof, uint32_t n, GridP g, const uint32_t* sorted_key, const uint32_t* perm,
                     const float4* pm_in, const float2* vel_in, const uint32_t* orig_in, const float* lvl_in,
@@ -184,6 +186,7 @@ struct SweepArgs {
     uint4* nl;          // neighbour list words (sph_sweeps.hip)
     uint4* nlx;         // explicit index lists (multi-resolution scenes)
     HeaderOut* hdr_partials;   // per-block partials of the NEXT step's header, written by the integrating final sweep (or nullptr)
+    IncClassifyP inc;          // the integrating tail also classifies its particles for the incremental cell sort queued behind it (head == nullptr: no)
     int h_mode;         // support_length_estimation (SPH_H_*)
     int sp_check_aii;   // SimulationParams::check_aii
     float* h2_next;     // FromDistribution*: the estimate for the next step is written here by the density sweep

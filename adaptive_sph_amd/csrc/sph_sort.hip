@@ -42,13 +42,10 @@ __device__ __forceinline__ uint32_t cell_key_of(const CellKeyGen& kg, uint32_t i
 {
     if (kg.gone && i < kg.n_gone && kg.gone[i] >= kg.gone_from) return kg.g.ncells;
     const float4 p = kg.pm[i];
+    if (kg.clamp) return cell_key_clamped(kg.g, p.x, p.y);   // (launch-uniform)
     // IEEE division, like `(particle_pos / kernel_support_radius).map(|x| x.floor() as i32)`
-    int cx = (int)floorf(p.x / kg.g.cs) - kg.g.minx;
-    int cy = (int)floorf(p.y / kg.g.cs) - kg.g.miny;
-    if (kg.clamp) {   // (launch-uniform)
-        cx = min(max(cx, 0), kg.g.sx - 1);
-        cy = min(max(cy, 0), kg.g.sy - 1);
-    }
+    const int cx = (int)floorf(p.x / kg.g.cs) - kg.g.minx;
+    const int cy = (int)floorf(p.y / kg.g.cs) - kg.g.miny;
     return (uint32_t)cx + (uint32_t)cy * (uint32_t)kg.g.sx;
 }
 template <int NB, bool KEYGEN>
@@ -271,15 +268,6 @@ int radix_sort_pairs(hipStream_t s, Profiler* prof, uint32_t* keyA, uint32_t* va
 struct IncGrid {
     GridP cur, nxt;   // the grid the array is sorted by; the grid of the keys to sort by (same cs)
 };
-// key of current-grid cell (cx, cy) in the next grid.  The next grid covers the bounding box the current cells were computed from
-// (queue_ahead_build), so the cell lies inside it; if it ever did not, no key equals the value returned here and the particle counts
-// as a mover -- it is then on exactly one list and in no cell's stayers, like every other mover: the slots still add up to n.
-__device__ __forceinline__ uint32_t inc_key_of_cur_cell(const IncGrid& G, uint32_t cxy)
-{
-    const int cx = (int)(cxy & 0xffffu) + G.cur.minx - G.nxt.minx, cy = (int)(cxy >> 16) + G.cur.miny - G.nxt.miny;
-    if (cx < 0 || cx >= G.nxt.sx || cy < 0 || cy >= G.nxt.sy) return 0xffffffffu;
-    return (uint32_t)cx + (uint32_t)cy * (uint32_t)G.nxt.sx;
-}
 // range of next-grid cell c in the CURRENT order ([0, 0) if the current grid has no such cell)
 __device__ __forceinline__ void inc_cur_range(const IncGrid& G, uint32_t c, const uint32_t* __restrict__ cell_start_cur, uint32_t& b, uint32_t& e)
 {
@@ -292,23 +280,16 @@ __device__ __forceinline__ void inc_cur_range(const IncGrid& G, uint32_t c, cons
         e = cell_start_cur[k + 1];
     }
 }
-#define INC_HEAD(EPOCH, I) (((unsigned long long)(EPOCH) << 32) | (unsigned long long)((I) + 1u))
 
 // 1. new key and mover flag of every particle; a mover hangs itself into the list of the cell it enters (head[c]: epoch-tagged, so
-//    the table is never cleared -- an entry of another step reads as "empty")
-__global__ __launch_bounds__(256) void k_inc_classify(uint32_t n, CellKeyGen kg, IncGrid G, const uint32_t* __restrict__ cxy_cur, uint32_t* __restrict__ nk,
-                                                       uint8_t* __restrict__ mv, uint32_t* __restrict__ next, unsigned long long* __restrict__ head, uint32_t epoch)
+//    the table is never cleared -- an entry of another step reads as "empty").  inc_classify_particle, sph_device.h; the integrating
+//    tail of the step's last solve does the same for the positions it has just computed, and this launch is then not needed.
+__global__ __launch_bounds__(256) void k_inc_classify(uint32_t n, const float4* __restrict__ pm, IncClassifyP q)
 {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const uint32_t k = cell_key_of(kg, i);
-    const bool mover = k != inc_key_of_cur_cell(G, cxy_cur[i]);
-    nk[i] = k;
-    mv[i] = mover ? 1 : 0;
-    if (mover) {
-        const unsigned long long prev = atomicExch(&head[k], INC_HEAD(epoch, i));
-        next[i] = (uint32_t)(prev >> 32) == epoch ? (uint32_t)prev : 0u;
-    }
+    const float4 p = pm[i];
+    inc_classify_particle(q, i, p.x, p.y);
 }
 
 // 2. new population of every cell = its stayers + the length of its list; per-block sums (INC_CELLS cells per block, one per thread:
@@ -441,19 +422,19 @@ __global__ __launch_bounds__(256) void k_inc_place_reorder(uint32_t n, IncGrid G
 
 size_t incremental_sort_block_sums(uint32_t ncells) { return ((size_t)ncells + INC_CELLS - 1) / INC_CELLS; }
 
-void incremental_cell_sort_reorder(hipStream_t s, Profiler* prof, uint32_t n, const CellKeyGen& kg, const GridP& g_cur, const uint32_t* cxy_cur,
-                                   const uint32_t* cell_start_cur, uint32_t* key_out, uint32_t* cell_start_out, const ReorderIO& io, uint32_t* nk, uint8_t* mv,
-                                   uint32_t* next, unsigned long long* head, uint32_t* bsum, uint32_t epoch, uint32_t* movers, uint32_t* movers_host)
+void incremental_cell_sort_reorder(hipStream_t s, Profiler* prof, uint32_t n, const float4* pm_new, const IncClassifyP& q, bool classified,
+                                   const uint32_t* cell_start_cur, uint32_t* key_out, uint32_t* cell_start_out, const ReorderIO& io, uint32_t* bsum, uint32_t* movers,
+                                   uint32_t* movers_host)
 {
-    const IncGrid G{g_cur, kg.g};
-    const uint32_t ncells = kg.g.ncells, cblocks = (uint32_t)incremental_sort_block_sums(ncells);
-    {
+    const IncGrid G{q.cur, q.nxt};
+    const uint32_t ncells = q.nxt.ncells, cblocks = (uint32_t)incremental_sort_block_sums(ncells);
+    if (!classified) {
         ProfScope ps(prof, "inc_classify", s);
-        hipLaunchKernelGGL(k_inc_classify, dim3((n + 255) / 256), dim3(256), 0, s, n, kg, G, cxy_cur, nk, mv, next, head, epoch);
+        hipLaunchKernelGGL(k_inc_classify, dim3((n + 255) / 256), dim3(256), 0, s, n, pm_new, q);
     }
     {
         ProfScope ps(prof, "inc_count", s);
-        hipLaunchKernelGGL(k_inc_count, dim3(cblocks), dim3(INC_CELLS), 0, s, G, cell_start_cur, mv, next, head, epoch, cell_start_out, bsum, movers);
+        hipLaunchKernelGGL(k_inc_count, dim3(cblocks), dim3(INC_CELLS), 0, s, G, cell_start_cur, q.mv, q.next, q.head, q.epoch, cell_start_out, bsum, movers);
     }
     {
         ProfScope ps(prof, "inc_scan", s);
@@ -461,8 +442,8 @@ void incremental_cell_sort_reorder(hipStream_t s, Profiler* prof, uint32_t n, co
     }
     {
         ProfScope ps(prof, "inc_reorder", s);
-        hipLaunchKernelGGL(k_inc_place_reorder, dim3((n + 255) / 256), dim3(256), 0, s, n, G, cell_start_cur, cell_start_out, nk, mv, next, head, epoch, cxy_cur,
-                           key_out, io);
+        hipLaunchKernelGGL(k_inc_place_reorder, dim3((n + 255) / 256), dim3(256), 0, s, n, G, cell_start_cur, cell_start_out, q.nk, q.mv, q.next, q.head, q.epoch,
+                           q.cxy_cur, key_out, io);
     }
 }
 

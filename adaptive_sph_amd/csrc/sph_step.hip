@@ -1455,12 +1455,20 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
     enum { T_NONE = 0, T_VEL = 1, T_VX = 2, T_HYBRID = 3 };  // TAIL_* of sph_sweeps.hip
     g_trace.mark(3);
     // The NEXT step's neighbour build, queued behind this step's integrating tail (sph_context.hpp: Ahead): cell keys on a grid
-    // predicted from this step's bounding box + 2 cells (a particle moves at most cfl_factor supports per step), radix sort,
+    // predicted from this step's bounding box + 2 cells (a particle moves at most cfl_factor supports per step), cell sort,
     // reorder into buffers of their own, cell ranges.  One context, paced solves (the tail is queued once the stop decision was
     // seen), uniform scenes with mass-derived smoothing lengths, no level estimation behind the solve.
-    const std::function<int()> queue_ahead_build = [&]() -> int {
+    // Two calls: plan_ahead_build() in front of the step's last solve -- everything it decides is known by then, and the integrating
+    // tail of that solve classifies the particles for the incremental sort while it holds their new positions -- and
+    // queue_ahead_build() behind the tail.
+    struct AheadPlan {
+        bool on = false, incremental = false;
+        GridP g{};
+        IncClassifyP q{};
+    } plan;
+    auto plan_ahead_build = [&]() -> int {
         sph_ctx* c = c0;
-        c->ahead.valid = false;
+        plan = AheadPlan{};
         if (G.multi() || !paced || !c->opt.ahead_build || level_on || !h_from_mass_mode || p->constrain_neighborhood_count || !c->uniform_h || c->tile_ts != 0 ||
             c->exact || M[0].n == 0)
             return SPH_OK;
@@ -1483,53 +1491,67 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
         HIPCHK(c, c->acxy.ensure((size_t)c->cap * 4));
         HIPCHK(c, c->pm2.ensure((size_t)c->cap * sizeof(float4)));
         HIPCHK(c, c->acell_start.ensure(((size_t)g.ncells + 1) * 4));
-        hipStream_t s = c->stream;
-        const int k = c->cur;
-        const float4* integrated = c->pm[c->pcur ^ 1].as<float4>();   // (the tail's output; the step's end flips pcur)
-        const CellKeyGen kg{integrated, g, nullptr, 0u, (uint32_t)SC_GONE_FROM, 1};   // (clamped keys: the grid is a prediction)
+        plan.on = true;
+        plan.g = g;
         // The array is sorted by the cells of this step's start and a step moves few particles into another cell: the sort is a
-        // merge of the ones that stay with the ones that do not (sph_sort.hip: incremental_cell_sort) -- same keys, permutation and
-        // cell ranges as the radix sort, whatever the number of movers; its cost grows with them, so a large count (the last one the
-        // device reported: a step or two old) sends the build through the radix sort, and every eighth such build probes again.
-        uint32_t* movers_host = (uint32_t*)(c->ctrl_host + 2) + 1;   // (second word of the mapped block whose first word is the paced solves' progress)
+        // merge of the ones that stay with the ones that do not (sph_sort.hip: incremental_cell_sort_reorder) -- the same keys, order
+        // and cell ranges as the radix sort, whatever the number of movers; its cost grows with them, so a large count (the last one
+        // the device reported: a step or two old) sends the build through the radix sort, and every eighth such build probes again.
+        const uint32_t* movers_host = (const uint32_t*)(c->ctrl_host + 2) + 1;   // (second word of the mapped block whose first word is the paced solves' progress)
         bool incremental = c->opt.inc_sort && c->grid_valid && c->fgrid.cs == cs && c->fgrid.ncells > 0 && g.ncells <= 4u * n + 4096u;
         if (incremental && *movers_host > n / 8u) {
             incremental = ++c->inc_radix_streak >= 8;
             if (incremental) c->inc_radix_streak = 0;
         }
-        if (incremental) {
-            const size_t head_before = c->inc_head.bytes;
-            HIPCHK(c, c->inc_head.ensure((size_t)g.ncells * 8));
-            if (c->inc_head.bytes != head_before) HIPCHK(c, hipMemsetAsync(c->inc_head.p, 0, c->inc_head.bytes, s));   // (epoch 0: no list)
-            HIPCHK(c, c->inc_next.ensure((size_t)c->cap * 4));
-            HIPCHK(c, c->inc_bsum.ensure(incremental_sort_block_sums(g.ncells) * 4));
-            if (!c->inc_movers.p) {
-                HIPCHK(c, c->inc_movers.ensure(4));
-                HIPCHK(c, hipMemsetAsync(c->inc_movers.p, 0, 4, s));
-            }
-            if (++c->inc_epoch == 0u) c->inc_epoch = 1u;
+        if (!incremental) return SPH_OK;
+        hipStream_t s = c->stream;
+        const size_t head_before = c->inc_head.bytes;
+        HIPCHK(c, c->inc_head.ensure((size_t)g.ncells * 8));
+        if (c->inc_head.bytes != head_before) HIPCHK(c, hipMemsetAsync(c->inc_head.p, 0, c->inc_head.bytes, s));   // (epoch 0: no list)
+        HIPCHK(c, c->inc_next.ensure((size_t)c->cap * 4));
+        HIPCHK(c, c->inc_bsum.ensure(incremental_sort_block_sums(g.ncells) * 4));
+        if (!c->inc_movers.p) {
+            HIPCHK(c, c->inc_movers.ensure(4));
+            HIPCHK(c, hipMemsetAsync(c->inc_movers.p, 0, 4, s));
+        }
+        if (++c->inc_epoch == 0u) c->inc_epoch = 1u;
+        plan.incremental = true;
+        plan.q = IncClassifyP{c->fgrid, g, c->cxy.as<uint32_t>(), c->akey[1].as<uint32_t>(), c->aval[1].as<uint8_t>(), c->inc_next.as<uint32_t>(),
+                              c->inc_head.as<unsigned long long>(), c->inc_epoch};
+        M[0].a.inc = plan.q;   // (the integrating tail classifies: launch_solver_tail)
+        return SPH_OK;
+    };
+    const std::function<int()> queue_ahead_build = [&]() -> int {
+        sph_ctx* c = c0;
+        c->ahead.valid = false;
+        if (!plan.on) return SPH_OK;
+        const uint32_t n = M[0].n;
+        const GridP g = plan.g;
+        hipStream_t s = c->stream;
+        const int k = c->cur;
+        const float4* integrated = c->pm[c->pcur ^ 1].as<float4>();   // (the tail's output; the step's end flips pcur)
+        if (plan.incremental) {
             const ReorderIO io{integrated, c->vel[k].as<float2>(), c->orig[k].as<uint32_t>(), c->lvl[k].as<float>(), c->lvlold[k].as<float>(), c->pm2.as<float4>(),
                                c->vel[k ^ 1].as<float2>(), c->orig[k ^ 1].as<uint32_t>(), c->lvl[k ^ 1].as<float>(), c->lvlold[k ^ 1].as<float>(), c->acxy.as<uint32_t>(),
                                c->h2n[k].as<float>(), c->h2n[k ^ 1].as<float>(), c->lam_sum.as<float>(), c->lam_prev.as<float>(), c->szc[k].as<uint8_t>(),
                                c->szc[k ^ 1].as<uint8_t>()};
-            incremental_cell_sort_reorder(s, &c->prof, n, kg, c->fgrid, c->cxy.as<uint32_t>(), c->cell_start.as<uint32_t>(), c->akey[0].as<uint32_t>(),
-                                          c->acell_start.as<uint32_t>(), io, c->akey[1].as<uint32_t>(), c->aval[1].as<uint8_t>(), c->inc_next.as<uint32_t>(),
-                                          c->inc_head.as<unsigned long long>(), c->inc_bsum.as<uint32_t>(), c->inc_epoch, c->inc_movers.as<uint32_t>(),
+            incremental_cell_sort_reorder(s, &c->prof, n, integrated, plan.q, /* classified by the tail */ true, c->cell_start.as<uint32_t>(), c->akey[0].as<uint32_t>(),
+                                          c->acell_start.as<uint32_t>(), io, c->inc_bsum.as<uint32_t>(), c->inc_movers.as<uint32_t>(),
                                           (uint32_t*)(c->ctrl_host_dev + 2) + 1);
         } else {
+            const CellKeyGen kg{integrated, g, nullptr, 0u, (uint32_t)SC_GONE_FROM, 1};   // (clamped keys: the grid is a prediction)
             const int res = radix_sort_pairs(s, &c->prof, c->akey[0].as<uint32_t>(), c->aval[0].as<uint32_t>(), c->akey[1].as<uint32_t>(), c->aval[1].as<uint32_t>(), n,
                                              ilog2_ceil(g.ncells), c->sort_scratch.as<uint32_t>(), &kg);
             if (res == 1) {
                 std::swap(c->akey[0], c->akey[1]);
                 std::swap(c->aval[0], c->aval[1]);
             }
-        }
-        if (!incremental)
             launch_reorder(s, &c->prof, n, g, c->akey[0].as<uint32_t>(), c->aval[0].as<uint32_t>(), integrated, c->vel[k].as<float2>(), c->orig[k].as<uint32_t>(),
                            c->lvl[k].as<float>(), c->lvlold[k].as<float>(), c->pm2.as<float4>(), c->vel[k ^ 1].as<float2>(), c->orig[k ^ 1].as<uint32_t>(),
                            c->lvl[k ^ 1].as<float>(), c->lvlold[k ^ 1].as<float>(), c->acxy.as<uint32_t>(), c->h2n[k].as<float>(), c->h2n[k ^ 1].as<float>(),
                            c->lam_sum.as<float>(), c->lam_prev.as<float>(), c->cs_scratch.p, c->szc[k].as<uint8_t>(), c->szc[k ^ 1].as<uint8_t>());
-        if (!incremental) launch_cell_start(s, &c->prof, c->akey[0].as<uint32_t>(), n, g.ncells, c->acell_start.as<uint32_t>(), c->cs_scratch.p, true);
+            launch_cell_start(s, &c->prof, c->akey[0].as<uint32_t>(), n, g.ncells, c->acell_start.as<uint32_t>(), c->cs_scratch.p, true);
+        }
         c->ahead.valid = true;
         c->ahead.g = g;
         c->ahead.h_max = h_max_g;
@@ -1543,6 +1565,7 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
         if ((rc = non_pressure())) return rc;
         rec(4);
         begin_solve(1, 1);
+        if ((rc = plan_ahead_build())) return rc;
         if ((rc = pressure_iterations(G, M, p->iisph_max_avg_density_error, 1, p->max_iters, c0->last_dens_iters, T_VX, true, !level_on, &queue_ahead_build))) return rc;
         rec(5);
         break;
@@ -1571,6 +1594,7 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
         if ((rc = non_pressure())) return rc;
         rec(2);
         begin_solve(0, 0);
+        if ((rc = plan_ahead_build())) return rc;
         if ((rc = pressure_iterations(G, M, p->hybrid_dfsph_max_avg_divergence_error, 0, p->max_iters, c0->last_div_iters, T_VX, false, !level_on, &queue_ahead_build))) return rc;
         rec(3);
         break;
@@ -1604,6 +1628,7 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
                 if ((rc = non_pressure())) return rc;
             rec(4);
             begin_solve(p->hybrid_dfsph_density_source_term == SPH_ONLY_DENSITY ? 2 : 1, 1);
+            if ((rc = plan_ahead_build())) return rc;
             if ((rc = solve_paced(G, M, qs, pace_prediction(c0, M[0].n, c0->last_dens_iters, c0->prev_dens_iters)))) return rc;
             if ((rc = solve_queue(G, M, qs, false, true))) return rc;
             if ((rc = queue_ahead_build())) return rc;

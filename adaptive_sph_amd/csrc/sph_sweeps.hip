@@ -1784,7 +1784,7 @@ __global__ __launch_bounds__(256) void k_solver_tail(uint32_t n, int tail, float
                                                       const uint8_t* __restrict__ owned, const SolverCtrl* __restrict__ ctrl, HeaderOut* __restrict__ hdr_partials,
                                                       DeviceStatus* status, const uint32_t* __restrict__ gate, const double* __restrict__ tot,
                                                       int decide_iter, SolveP solve, float rest_density, SolverCtrl* __restrict__ handoff_host,
-                                                      uint32_t* __restrict__ gate_out)
+                                                      uint32_t* __restrict__ gate_out, IncClassifyP inc)
 {
     if (gate && *gate == 0u) return;
     const bool b0t0 = blockIdx.x == 0 && threadIdx.x == 0;
@@ -1804,7 +1804,8 @@ __global__ __launch_bounds__(256) void k_solver_tail(uint32_t n, int tail, float
     const bool active = i < n && (!owned || owned[i]);
     float nx = 0.f, ny = 0.f, nh = 0.f, ncfl = 0.f;
     if (active) {
-        const float4 Ai = pm[i];
+        // (TAIL_VEL moves no particle and reduces no header: it does not need the record)
+        const float4 Ai = tail == TAIL_VEL ? make_float4(0.f, 0.f, 0.f, 0.f) : pm[i];
         const float4 rec = pacc[i];
         const float2 ap = make_float2(rec.z, rec.w);
         float2 v = vel[i];
@@ -1829,6 +1830,8 @@ __global__ __launch_bounds__(256) void k_solver_tail(uint32_t n, int tail, float
             pm_out[i] = p;
         }
         vel[i] = v;
+        // the incremental cell sort queued behind this launch (sph_sort.hip) wants every particle's new cell: the position is at hand
+        if (inc.head && tail >= TAIL_VX) inc_classify_particle(inc, i, p.x, p.y);   // (launch-uniform test)
         nx = p.x;
         ny = p.y;
         nh = Ai.w;
@@ -3406,7 +3409,8 @@ void launch_solver_tail(hipStream_t s, Profiler* prof, const SweepArgs& a, int t
     if (a.n && tail != TAIL_NONE)
         hipLaunchKernelGGL(k_solver_tail, dim3((a.n + 255) / 256), dim3(256), 0, s, a.n, tail, a.sp.dt, a.sp.hyb_vfactor, a.pm, pm_out, a.vel, a.pacc, a.orig,
                            a.owned, a.ctrl, tail >= TAIL_VX ? a.hdr_partials : nullptr, a.status, a.gate, a.solver_tot, decide_iter,
-                           solve_params(a, residual_density, max_avg_error, max_iters, 1, false), a.sp.rest_density, handoff_host, gate_out);
+                           solve_params(a, residual_density, max_avg_error, max_iters, 1, false), a.sp.rest_density, handoff_host, gate_out,
+                           tail >= TAIL_VX ? a.inc : IncClassifyP{});
 }
 
 // Chained solves (HybridDFSPH, one context): the host does not wait between the divergence solve and the density solve.  Behind

@@ -370,8 +370,8 @@ typedef struct sph_kernel_time {
     char     name[48];
     uint64_t launches;
     double   total_ms;           /* HIP-event time on the context's stream */
-    uint64_t working_launches;   /* launches longer than a quarter of the longest one: a speculatively queued Jacobi
-                                  * iteration behind the stop decision returns at once and is not a sweep */
+    uint64_t working_launches;   /* launches longer than a quarter of the kernel's 90th-percentile duration: a speculatively
+                                  * queued Jacobi iteration behind the stop decision returns at once and is not a sweep */
     double   working_ms;
 } sph_kernel_time;
 int  sph_profile_enable(sph_ctx* ctx, int enable);

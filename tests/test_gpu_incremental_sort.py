@@ -23,7 +23,7 @@ def scene_of(kind):
                                                                sc.SceneFluidBlock([-0.2, -0.9], [48 * d, 80 * d], d, 0.93, [-4.0, 0.5])]), dict(max_dt=0.0005)
 
 
-@pytest.mark.parametrize("kind,solver,steps", [("column", "HybridDFSPH", 40), ("thrown", "HybridDFSPH", 30), ("collide", "IISPH", 30)])
+@pytest.mark.parametrize("kind,solver,steps", [("column", "HybridDFSPH", 40), ("thrown", "HybridDFSPH", 30), ("collide", "IISPH", 30), ("thrown", "OnlyDivergence", 30)])
 def test_incremental_cell_sort_is_the_radix_sort(product_lib, monkeypatch, kind, solver, steps):
     scn, over = scene_of(kind)
     pos, mass, vel = sc.init_particles(scn)
