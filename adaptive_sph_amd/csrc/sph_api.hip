@@ -511,7 +511,7 @@ Options options_from_env()
     o.force_slab_mode = flag("SPH_FORCE_SLAB_MODE");
     o.tile = num("SPH_TILE", 0);
     o.ahead_build = num("SPH_AHEAD_BUILD", 1) != 0 ? 1 : 0;
-    o.inc_sort = num("SPH_INC_SORT", 1) != 0 ? 1 : 0;
+    o.inc_sort = num("SPH_INC_SORT", 1);
     o.slab_paced = num("SPH_SLAB_PACED", 1) != 0 ? 1 : 0;
     o.slab_records = num("SPH_SLAB_RECORDS", 1) != 0 ? 1 : 0;
     o.debug_sync = num("SPH_DEBUG_SYNC", 0);
@@ -630,7 +630,8 @@ extern "C" void sph_destroy(sph_ctx* c)
                      &c->cs_scratch, &c->hdr_ahead_partials, &c->h2n[0], &c->h2n[1], &c->lam_prev, &c->nl, &c->nlx, &c->tile_raw, &c->tile_h, &c->tile_h_ext, &c->lvl_changed_d, &c->lvl_tmp, &c->lvl_nrm, &c->lvl_state, &c->lvl_when, &c->lvl_mark, &c->lvl_queue, &c->nloff, &c->nlh, &c->flag_surface,
                      &c->flag_insufficient, &c->con_thr, &c->con_consumed, &c->con_h, &c->flag_reduced, &c->szc[0], &c->szc[1], &c->omega, &c->stash, &c->nl_ext, &c->nlx_ext, &c->nl_ok, &c->mrho, &c->pt0, &c->pt1, &c->prec0, &c->prec1, &c->rho, &c->lam_sum, &c->lam_grad, &c->constf, &c->aii, &c->src, &c->p0, &c->p1, &c->pacc, &c->dens_err,
                      &c->stat, &c->ncount, &c->planes_d, &c->lam_lut, &c->dlam_lut, &c->hdr_partials, &c->hdr_out, &c->ctrl, &c->status,
-                     &c->n_tiles, &c->red_partials, &c->scratch, &c->split_patterns, &c->akey[0], &c->akey[1], &c->aval[0], &c->aval[1], &c->acxy, &c->acell_start, &c->pm2};
+                     &c->n_tiles, &c->red_partials, &c->scratch, &c->split_patterns, &c->akey[0], &c->akey[1], &c->aval[0], &c->aval[1], &c->acxy, &c->acell_start, &c->pm2,
+                     &c->atile_raw, &c->atile_h, &c->inc_head, &c->inc_next, &c->inc_bsum, &c->inc_movers};
     for (auto b : all) b->release();
     if (c->hdr_host) (void)hipHostFree(c->hdr_host);
     if (c->ctrl_host) (void)hipHostFree(c->ctrl_host);

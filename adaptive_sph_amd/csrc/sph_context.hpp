@@ -68,7 +68,7 @@ struct Options {
     int force_slab_mode = 0;    // SPH_FORCE_SLAB_MODE      sph_dist_configure(0, 1, ..) turns the slab driver on (one-rank check of that path)
     int tile = 0;               // SPH_TILE=<bits>          LDS-staged sweeps (sph_set_sweep_variant overrides, process-wide)
     int ahead_build = 1;        // SPH_AHEAD_BUILD=0        one context: never queue the next step's cell sort behind the integrating tail
-    int inc_sort = 1;           // SPH_INC_SORT=0           the cell sort queued ahead is always the radix sort (never the incremental merge)
+    int inc_sort = 1;           // SPH_INC_SORT=0 | k       the cell sort queued ahead is always the radix sort (never the incremental merge); k > 1: the merge up to n / k movers (default n / 3: at 4M the merge still beats the radix sort with a third of the particles changing cell)
     int slab_paced = 1;         // SPH_SLAB_PACED=0         slabs: predicted queue instead of pacing
     int slab_records = 1;       // SPH_SLAB_RECORDS=0       slabs: sweep A through the generic form (p / rho^2 as a field of its own)
     int debug_sync = 0;         // SPH_DEBUG_SYNC=<mask>    synchronise and name the phases (fault hunting)
@@ -189,6 +189,7 @@ struct sph_ctx {
     // ~20-36 us of idle queue).  They write buffers of their own (post-step downloads still see this step's order, keys and ranges);
     // the next step adopts them by swapping pointers if nothing touched the state and the real bounding box fits the predicted grid.
     DevBuf akey[2], aval[2], acxy, acell_start, pm2;
+    DevBuf atile_raw, atile_h;   // ... and, in a multi-resolution scene, the tiles' h bounds on the predicted grid
     // the build queued ahead as a merge of the particles that stay in their cells with the few that do not (sph_sort.hip:
     // incremental_cell_sort): per-cell list heads (epoch-tagged, never cleared), list links, block sums, the mover counter
     DevBuf inc_head, inc_next, inc_bsum, inc_movers;
@@ -197,7 +198,8 @@ struct sph_ctx {
     struct Ahead {
         bool valid = false;
         GridP g{};
-        float h_max = 0.f, rest_density = 0.f;
+        float h_max = 0.f, h_min = 0.f, rest_density = 0.f;
+        int tile_ts = 0, tile_tsx = 0, tile_tsy = 0;   // multi-resolution scenes: the tiles of the predicted grid
         uint64_t n = 0;
     } ahead;
     DevBuf hdr_ahead_partials;   // per sweep block: next step's header terms from the integrating final sweep

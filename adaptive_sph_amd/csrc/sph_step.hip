@@ -903,11 +903,21 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
         // the build the previous step queued ahead (queue_ahead_build): adopted if nothing touched the state since (the header that
         // step left behind was still the one in force), the scene is what it predicted and the real bounding box fits its grid
         const GridP ag = c->ahead.g;
+        // (a multi-resolution scene: the same smoothing lengths, hence the same cell size and tile side; its tiles then lie on the
+        //  predicted grid -- another tiling bounds the neighbours' h as well, and the visiting order of a list does not depend on the
+        //  stencil width it was gathered with)
         const bool adopt = ahead_usable && c->ahead.valid && !c->dist.on && c->ahead.n == c->n && n == (uint32_t)c->n && c->ahead.h_max == h_max_g &&
-                           c->ahead.rest_density == p->rest_density && c->uniform_h && c->tile_ts == 0 && !c->exact && ag.cs == g.cs && g.minx >= ag.minx &&
-                           g.miny >= ag.miny && g.minx + g.sx <= ag.minx + ag.sx && g.miny + g.sy <= ag.miny + ag.sy;
+                           c->ahead.h_min == h_min_g && c->ahead.rest_density == p->rest_density && (c->uniform_h ? c->tile_ts == 0 : c->tile_ts > 0) &&
+                           c->ahead.tile_ts == c->tile_ts && !c->exact && ag.cs == g.cs && g.minx >= ag.minx && g.miny >= ag.miny &&
+                           g.minx + g.sx <= ag.minx + ag.sx && g.miny + g.sy <= ag.miny + ag.sy;
         c->ahead.valid = false;
         if (adopt) {
+            if (c->tile_ts > 0) {
+                c->tile_tsx = c->ahead.tile_tsx;
+                c->tile_tsy = c->ahead.tile_tsy;
+                std::swap(c->tile_raw, c->atile_raw);
+                std::swap(c->tile_h, c->atile_h);
+            }
             for (int q = 0; q < 2; q++) {
                 std::swap(c->key[q], c->akey[q]);
                 std::swap(c->val[q], c->aval[q]);
@@ -940,15 +950,19 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
         if (!adopt) launch_cell_start(s, prof, c->key[0].as<uint32_t>(), n, g.ncells, c->cell_start.as<uint32_t>(), c->cs_scratch.p, n > 0);
         if (c->tile_ts > 0) {
             const size_t nt = (size_t)c->tile_tsx * (size_t)c->tile_tsy;
-            HIPCHK(c, c->tile_raw.ensure(nt * 4));
-            HIPCHK(c, c->tile_h.ensure(nt * 4));
             // the extended-range lists reach k * h_max with k = level_estimation_range / ETA > 2: a larger particle may sit
             // ceil(k / 2) tiles away (tile side >= 2 h_max)
             const bool want_ext = p->level_estimation_method != SPH_LEVEL_NONE;
             const int d_ext = want_ext ? (int)ceilf(fmaxf(p->level_estimation_range / SPH_ETA, 2.f) * 0.5f) : 1;
             if (want_ext) HIPCHK(c, c->tile_h_ext.ensure(nt * 4));
-            launch_tile_hmax(s, prof, n, c->pm[c->pcur].as<float4>(), g, c->tile_ts, c->tile_tsx, c->tile_tsy, c->tile_raw.as<uint32_t>(),
-                             c->tile_h.as<uint32_t>(), want_ext ? c->tile_h_ext.as<uint32_t>() : nullptr, d_ext);
+            if (!adopt) {
+                HIPCHK(c, c->tile_raw.ensure(nt * 4));
+                HIPCHK(c, c->tile_h.ensure(nt * 4));
+                launch_tile_hmax(s, prof, n, c->pm[c->pcur].as<float4>(), g, c->tile_ts, c->tile_tsx, c->tile_tsy, c->tile_raw.as<uint32_t>(),
+                                 c->tile_h.as<uint32_t>(), want_ext ? c->tile_h_ext.as<uint32_t>() : nullptr, d_ext);
+            } else if (want_ext) {   // (adopted: the build queued ahead made the tiles' bounds; it never runs with the level estimation on)
+                launch_tile_redilate(s, prof, c->tile_tsx, c->tile_tsy, d_ext, c->tile_raw.as<uint32_t>(), c->tile_h_ext.as<uint32_t>());
+            }
         }
         if (c->exact || !c->uniform_h || sweep_forces_index_lists()) HIPCHK(c, c->nlx.ensure(sweep_index_list_bytes(n ? n : 1)));
         if (c->dist.on) {
@@ -1464,17 +1478,23 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
     struct AheadPlan {
         bool on = false, incremental = false;
         GridP g{};
+        int tile_ts = 0, tile_tsx = 0, tile_tsy = 0;
         IncClassifyP q{};
     } plan;
     auto plan_ahead_build = [&]() -> int {
         sph_ctx* c = c0;
         plan = AheadPlan{};
-        if (G.multi() || !paced || !c->opt.ahead_build || level_on || !h_from_mass_mode || p->constrain_neighborhood_count || !c->uniform_h || c->tile_ts != 0 ||
-            c->exact || M[0].n == 0)
+        // (uniform scenes, and multi-resolution scenes sorted by their fine grid: tile_ts > 0; a narrow h distribution on the coarse
+        //  grid -- FromDistribution* -- is excluded with h_from_mass_mode)
+        if (G.multi() || !paced || !c->opt.ahead_build || level_on || !h_from_mass_mode || p->constrain_neighborhood_count || (!c->uniform_h && c->tile_ts <= 0) ||
+            (c->uniform_h && c->tile_ts != 0) || c->exact || M[0].n == 0)
             return SPH_OK;
         const uint32_t n = M[0].n;
-        const float cs = h_max_g * 2.f;
-        const int margin = 2;
+        // the grid this step sorted by, moved to where the particles may be after it: the same cell size (the smoothing lengths are the
+        // masses'), the bounding box of the step's start + 1 cell + a margin of two SUPPORTS of the largest particle (a particle moves
+        // at most cfl_factor supports per step): two cells of a uniform scene, two tiles of a multi-resolution one
+        const float cs = c->fgrid.cs;
+        const int ts = c->tile_ts, margin = 2 * (ts > 0 ? ts : 1);
         GridP g{};
         g.cs = cs;
         g.minx = (int)floorf(boxes[0].min_x / cs) - 1 - margin;
@@ -1484,6 +1504,14 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
         g.sx = (int)sx;
         g.sy = (int)sy;
         g.ncells = (uint32_t)sx * (uint32_t)sy;
+        if (ts > 0) {
+            plan.tile_ts = ts;
+            plan.tile_tsx = (g.sx + ts - 1) / ts;
+            plan.tile_tsy = (g.sy + ts - 1) / ts;
+            const size_t nt = (size_t)plan.tile_tsx * (size_t)plan.tile_tsy;
+            HIPCHK(c, c->atile_raw.ensure(nt * 4));
+            HIPCHK(c, c->atile_h.ensure(nt * 4));
+        }
         for (int q = 0; q < 2; q++) {
             HIPCHK(c, c->akey[q].ensure((size_t)c->cap * 4));
             HIPCHK(c, c->aval[q].ensure((size_t)c->cap * 4));
@@ -1499,7 +1527,7 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
         // the device reported: a step or two old) sends the build through the radix sort, and every eighth such build probes again.
         const uint32_t* movers_host = (const uint32_t*)(c->ctrl_host + 2) + 1;   // (second word of the mapped block whose first word is the paced solves' progress)
         bool incremental = c->opt.inc_sort && c->grid_valid && c->fgrid.cs == cs && c->fgrid.ncells > 0 && g.ncells <= 4u * n + 4096u;
-        if (incremental && *movers_host > n / 8u) {
+        if (incremental && *movers_host > n / (c->opt.inc_sort > 1 ? (uint32_t)c->opt.inc_sort : 3u)) {
             incremental = ++c->inc_radix_streak >= 8;
             if (incremental) c->inc_radix_streak = 0;
         }
@@ -1552,9 +1580,16 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
                            c->lam_sum.as<float>(), c->lam_prev.as<float>(), c->cs_scratch.p, c->szc[k].as<uint8_t>(), c->szc[k ^ 1].as<uint8_t>());
             launch_cell_start(s, &c->prof, c->akey[0].as<uint32_t>(), n, g.ncells, c->acell_start.as<uint32_t>(), c->cs_scratch.p, true);
         }
+        if (plan.tile_ts > 0)
+            launch_tile_hmax(s, &c->prof, n, c->pm2.as<float4>(), g, plan.tile_ts, plan.tile_tsx, plan.tile_tsy, c->atile_raw.as<uint32_t>(), c->atile_h.as<uint32_t>(),
+                             nullptr, 1);
         c->ahead.valid = true;
         c->ahead.g = g;
         c->ahead.h_max = h_max_g;
+        c->ahead.h_min = h_min_g;
+        c->ahead.tile_ts = plan.tile_ts;
+        c->ahead.tile_tsx = plan.tile_tsx;
+        c->ahead.tile_tsy = plan.tile_tsy;
         c->ahead.rest_density = p->rest_density;
         c->ahead.n = c->n;
         return SPH_OK;

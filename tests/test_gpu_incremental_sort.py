@@ -62,3 +62,52 @@ def test_incremental_cell_sort_is_the_radix_sort(product_lib, monkeypatch, kind,
     if kind != "column":   # these scenes move: the bounding box (hence the grid origin) travelled by more than a cell along the way
         x0, x1 = out["merge"][1][0]["position"], out["merge"][1][-1]["position"]
         assert np.abs(x1 - x0).max() > (1 / 64) * 2.2
+
+
+def two_sizes_scene():
+    fine = 0.02
+    return sc.SceneConfig(sc.SceneBoundary("box", 3.0, 3.0),
+                          [sc.SceneFluidBlock([-0.95, -0.5], [0.55, 1.4], fine, 0.93, [0.5, 0]),
+                           sc.SceneFluidBlock([-0.40 + 0.3 * fine * 4, -0.5], [0.7, 1.4], fine * 4, 0.93, [-0.5, 0])])
+
+
+@pytest.mark.parametrize("kind,solver", [("column", "HybridDFSPH"), ("two_sizes", "HybridDFSPH"), ("two_sizes", "IISPH")])
+def test_build_queued_ahead_is_the_build_at_the_step_start(product_lib, monkeypatch, kind, solver):
+    """The next step's neighbour build queued behind the integrating tail on a PREDICTED grid (another origin, a margin around the
+    bounding box; in a multi-resolution scene other tiles, hence other stencil widths for the same lists) against the build at the
+    start of the step (SPH_AHEAD_BUILD=0): every field, every iteration statistic and every neighbour list bit for bit."""
+    scn = sc.dam_break_small(128, 96, 1 / 64) if kind == "column" else two_sizes_scene()
+    pos, mass, vel = sc.init_particles(scn)
+    P = dam_break_params(pressure_solver_method=solver)
+    planes = sc.boundary_planes(scn.boundary, P.init_boundary_handler)
+    p = P.to_ffi()
+    steps = 25
+    out = {}
+    for form in ("ahead", "at-start"):
+        if form == "at-start":
+            monkeypatch.setenv("SPH_AHEAD_BUILD", "0")
+        g = ffi.Context(product_lib, len(mass), planes)
+        if form == "at-start":
+            monkeypatch.delenv("SPH_AHEAD_BUILD")
+        g.upload(mass, pos, vel)
+        g.profile_enable(1)
+        its, fields = [], []
+        for s in range(steps):
+            st = g.step(p)
+            its.append((int(st.div_solver.iters), int(st.density_solver.iters), int(st.density_solver.normal_count),
+                        np.float32(st.density_solver.avg_error).view(np.uint32).item(), np.float32(st.dt).view(np.uint32).item()))
+            f = {k: g.download(k) for k in ("position", "velocity", "pressure", "density", "cell_index", "neighbor_count")}
+            if s % 6 == 5 or s == steps - 1:
+                f["nl_offsets"], f["nl_indices"] = g.download_neighbors()
+            fields.append(f)
+        out[form] = (its, fields, g.profile_get())
+        g.close()
+    assert out["ahead"][2].get("inc_reorder", (0, 0))[0] >= steps - 2, out["ahead"][2]     # queued ahead, as a merge ...
+    assert out["ahead"][2].get("sort_scatter", (0, 0))[0] <= 4                               # ... and adopted: no sort at a step's start
+    assert "inc_reorder" not in out["at-start"][2]
+    if kind == "two_sizes":
+        assert out["ahead"][2]["tile_hmax"][0] >= steps - 1
+    assert out["ahead"][0] == out["at-start"][0]
+    for s, (fa, fb) in enumerate(zip(out["ahead"][1], out["at-start"][1])):
+        for k in fa:
+            assert np.array_equal(fa[k], fb[k]), (s, k)
