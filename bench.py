@@ -502,9 +502,11 @@ def main():
         "achieved_GBs": step_gbs, "frac_hbm_peak": step_gbs / (HBM_PEAK_GBS * world),
         "without_closed_form_iteration_0": {"algorithmic_bytes_per_particle_step": b_step - 100.0 * n_solves, "achieved_GBs": step_gbs_launched,
                                             "frac_hbm_peak": step_gbs_launched / (HBM_PEAK_GBS * world)},
-        # cell keys 16r + 8w; two radix passes of (4r histogram + 8r + 8w scatter); reorder 40r + 40w (value, record, velocity,
-        # id, level state); cell-range table 4r
-        "neighbour_build_algorithmic_bytes_per_particle": 24 + 2 * 20 + 80 + 4,
+        # the build queued ahead as a merge (sph_sort.hip: incremental_cell_sort_reorder): classification in the integrating tail
+        # (old cell 4r, new key 4w, mover flag 1w), place + reorder (key 4r, flag 1r, old cell 4r; record, velocity, id, level state
+        # 40r + 40w; sorted key 4w, new cell 4w); the per-cell count and scan touch the cell tables, not the particles.
+        # (the radix form it replaces: cell keys 16r + 8w, two passes of 4r + 8r + 8w, reorder 40r + 40w, cell-range table 4r = 148)
+        "neighbour_build_algorithmic_bytes_per_particle": 9 + 9 + 80 + 8,
         "steps_from_rest": {"steps": args.warmup, "ms_per_step": warmup_elapsed * 1e3 / max(args.warmup, 1),
                             "note": "steps 0..warmup-1 (rest lattice, first launches included); rank 0's clock, not part of `value`"},
     }
