@@ -99,6 +99,7 @@ void Profiler::collect()
         (void)hipMemset(ts_dev + TS_RING, 0, (size_t)ts_next * sizeof(unsigned long long));
     }
     static FILE* dump = getenv("SPH_TS_DUMP") ? fopen(getenv("SPH_TS_DUMP"), "w") : nullptr;   // (diagnostic: raw stamps, one line per launch)
+    std::vector<Pending> later;
     for (auto& p : pending) {
         if (p.slot >= 0) {
             const unsigned long long t0 = ts[(size_t)p.slot], t1 = ts[(size_t)ts_next + (size_t)p.slot];
@@ -112,7 +113,12 @@ void Profiler::collect()
             continue;
         }
         float ms = 0.f;
-        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+        const hipError_t e = hipEventElapsedTime(&ms, p.a, p.b);
+        if (e == hipErrorNotReady) {   // (a launch queued behind the step's last wait -- the build queued ahead: the next collection takes it)
+            later.push_back(p);
+            continue;
+        }
+        if (e == hipSuccess) {
             recs[p.rec].launches++;
             recs[p.rec].total_ms += ms;
             recs[p.rec].samples.push_back(ms);
@@ -120,7 +126,7 @@ void Profiler::collect()
         pool.push_back(p.a);
         pool.push_back(p.b);
     }
-    pending.clear();
+    pending.swap(later);
     ts_next = 0;
     if (dump) fflush(dump);
 }

@@ -1471,7 +1471,7 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
     // The NEXT step's neighbour build, queued behind this step's integrating tail (sph_context.hpp: Ahead): cell keys on a grid
     // predicted from this step's bounding box + 2 cells (a particle moves at most cfl_factor supports per step), cell sort,
     // reorder into buffers of their own, cell ranges.  One context, paced solves (the tail is queued once the stop decision was
-    // seen), uniform scenes with mass-derived smoothing lengths, no level estimation behind the solve.
+    // seen), mass-derived smoothing lengths, uniform scenes and multi-resolution scenes on their fine grid.
     // Two calls: plan_ahead_build() in front of the step's last solve -- everything it decides is known by then, and the integrating
     // tail of that solve classifies the particles for the incremental sort while it holds their new positions -- and
     // queue_ahead_build() behind the tail.
@@ -1486,7 +1486,7 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
         plan = AheadPlan{};
         // (uniform scenes, and multi-resolution scenes sorted by their fine grid: tile_ts > 0; a narrow h distribution on the coarse
         //  grid -- FromDistribution* -- is excluded with h_from_mass_mode)
-        if (G.multi() || !paced || !c->opt.ahead_build || level_on || !h_from_mass_mode || p->constrain_neighborhood_count || (!c->uniform_h && c->tile_ts <= 0) ||
+        if (G.multi() || !paced || !c->opt.ahead_build || !h_from_mass_mode || p->constrain_neighborhood_count || (!c->uniform_h && c->tile_ts <= 0) ||
             (c->uniform_h && c->tile_ts != 0) || c->exact || M[0].n == 0)
             return SPH_OK;
         const uint32_t n = M[0].n;
@@ -1549,8 +1549,12 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
         M[0].a.inc = plan.q;   // (the integrating tail classifies: launch_solver_tail)
         return SPH_OK;
     };
+    // (with the level estimation on, the build -- it moves the level arrays -- waits for the smoothing at the end of the step: the
+    //  calls behind the tail return at once, the one behind the step's last wait queues it)
+    bool ahead_deferred = level_on;
     const std::function<int()> queue_ahead_build = [&]() -> int {
         sph_ctx* c = c0;
+        if (ahead_deferred) return SPH_OK;
         c->ahead.valid = false;
         if (!plan.on) return SPH_OK;
         const uint32_t n = M[0].n;
@@ -1790,6 +1794,9 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
         }
         if ((rc = sync_ctrl(G))) return rc;
         m.st.ms_level_estimation += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_lvl0).count();
+        // the next step's neighbour build, behind the smoothed level values (the device works on it while the host leaves the step)
+        ahead_deferred = false;
+        if ((rc = queue_ahead_build())) return rc;
     }
 
     for (size_t i = 0; i < M.size(); i++) {

@@ -71,14 +71,20 @@ def two_sizes_scene():
                            sc.SceneFluidBlock([-0.40 + 0.3 * fine * 4, -0.5], [0.7, 1.4], fine * 4, 0.93, [-0.5, 0])])
 
 
-@pytest.mark.parametrize("kind,solver", [("column", "HybridDFSPH"), ("two_sizes", "HybridDFSPH"), ("two_sizes", "IISPH")])
-def test_build_queued_ahead_is_the_build_at_the_step_start(product_lib, monkeypatch, kind, solver):
+LEVEL = dict(level_estimation_method="EmptyAngle", maximum_surface_distance=0.2, particle_radius_fine=0.004, particle_radius_base=0.02)
+
+
+@pytest.mark.parametrize("kind,solver,level", [("column", "HybridDFSPH", None), ("two_sizes", "HybridDFSPH", None), ("two_sizes", "IISPH", None),
+                                               ("column", "HybridDFSPH", dict(LEVEL)), ("two_sizes", "IISPH", dict(LEVEL)),
+                                               ("column", "IISPH", dict(LEVEL, level_estimation_after_advection=True))])
+def test_build_queued_ahead_is_the_build_at_the_step_start(product_lib, monkeypatch, kind, solver, level):
     """The next step's neighbour build queued behind the integrating tail on a PREDICTED grid (another origin, a margin around the
     bounding box; in a multi-resolution scene other tiles, hence other stencil widths for the same lists) against the build at the
-    start of the step (SPH_AHEAD_BUILD=0): every field, every iteration statistic and every neighbour list bit for bit."""
+    start of the step (SPH_AHEAD_BUILD=0): every field, every iteration statistic and every neighbour list bit for bit.  With the
+    level estimation on (before or after advection) the build moves the smoothed level values: it is queued behind the smoothing."""
     scn = sc.dam_break_small(128, 96, 1 / 64) if kind == "column" else two_sizes_scene()
     pos, mass, vel = sc.init_particles(scn)
-    P = dam_break_params(pressure_solver_method=solver)
+    P = dam_break_params(pressure_solver_method=solver, **(level or {}))
     planes = sc.boundary_planes(scn.boundary, P.init_boundary_handler)
     p = P.to_ffi()
     steps = 25
@@ -97,6 +103,8 @@ def test_build_queued_ahead_is_the_build_at_the_step_start(product_lib, monkeypa
             its.append((int(st.div_solver.iters), int(st.density_solver.iters), int(st.density_solver.normal_count),
                         np.float32(st.density_solver.avg_error).view(np.uint32).item(), np.float32(st.dt).view(np.uint32).item()))
             f = {k: g.download(k) for k in ("position", "velocity", "pressure", "density", "cell_index", "neighbor_count")}
+            if level:
+                f.update({k: g.download(k) for k in ("level_estimation", "level_old", "flag_is_fluid_surface")})
             if s % 6 == 5 or s == steps - 1:
                 f["nl_offsets"], f["nl_indices"] = g.download_neighbors()
             fields.append(f)
