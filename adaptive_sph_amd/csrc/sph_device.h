@@ -63,17 +63,21 @@ __device__ __forceinline__ uint32_t inc_key_of_cur_cell(const GridP& cur, const 
     if (cx < 0 || cx >= nxt.sx || cy < 0 || cy >= nxt.sy) return 0xffffffffu;
     return (uint32_t)cx + (uint32_t)cy * (uint32_t)nxt.sx;
 }
-// new key and mover flag of particle i at (x, y); a mover hangs itself into the list of the cell it enters
-__device__ __forceinline__ void inc_classify_particle(const IncClassifyP& q, uint32_t i, float x, float y)
+// new key and mover flag of particle i; a mover hangs itself into the list of the cell it enters
+__device__ __forceinline__ void inc_register(const IncClassifyP& q, uint32_t i, uint32_t k, bool mover)
 {
-    const uint32_t k = cell_key_clamped(q.nxt, x, y);
-    const bool mover = k != inc_key_of_cur_cell(q.cur, q.nxt, q.cxy_cur[i]);
     q.nk[i] = k;
     q.mv[i] = mover ? 1 : 0;
     if (mover) {
         const unsigned long long prev = atomicExch(&q.head[k], ((unsigned long long)q.epoch << 32) | (unsigned long long)(i + 1u));
         q.next[i] = (uint32_t)(prev >> 32) == q.epoch ? (uint32_t)prev : 0u;
     }
+}
+// ... of particle i at (x, y), an element of the array that is sorted by q.cxy_cur
+__device__ __forceinline__ void inc_classify_particle(const IncClassifyP& q, uint32_t i, float x, float y)
+{
+    const uint32_t k = cell_key_clamped(q.nxt, x, y);
+    inc_register(q, i, k, k != inc_key_of_cur_cell(q.cur, q.nxt, q.cxy_cur[i]));
 }
 
 // Multi-resolution scenes sort by a grid whose cell is the support of the SMALLEST particle.  A tile is

@@ -143,6 +143,13 @@ void incremental_cell_sort_reorder(hipStream_t s, Profiler* prof, uint32_t n, co
                                    const uint32_t* cell_start_cur, uint32_t* key_out, uint32_t* cell_start_out, const ReorderIO& io, uint32_t* bsum, uint32_t* movers,
                                    uint32_t* movers_host);
 
+// ... for a slab rank behind its fused refresh: slots [0, n_prev) are last step's sorted array (those of class >= kg.gone_from in
+// kg.gone[0 .. kg.n_gone) left the rank and are not placed), [n_prev, n) this step's arrivals; sorted keys and the permutation
+// (slot -> current index) of the live slots, and the cell-range table -- what radix_sort_pairs (with the key `ncells` for the slots
+// that left) + launch_cell_start produce for them
+void incremental_cell_sort_perm(hipStream_t s, Profiler* prof, uint32_t n, uint32_t n_prev, const CellKeyGen& kg, const IncClassifyP& q, const uint32_t* cell_start_cur,
+                                uint32_t* key_out, uint32_t* perm_out, uint32_t* cell_start_out, uint32_t* bsum, uint32_t* movers, uint32_t* movers_host);
+
 void launch_reorder(hipStream_t s, Profiler* prof, uint32_t n, GridP g, const uint32_t* sorted_key, const uint32_t* perm,
                     const float4* pm_in, const float2* vel_in, const uint32_t* orig_in, const float* lvl_in,
                     const float* lvlold_in, float4* pm_out, float2* vel_out, uint32_t* orig_out, float* lvl_out,

@@ -292,6 +292,21 @@ __global__ __launch_bounds__(256) void k_inc_classify(uint32_t n, const float4* 
     inc_classify_particle(q, i, p.x, p.y);
 }
 
+// ... of a slab rank (sph_slabs.hip: fused refresh): the array is last step's sorted slots [0, n_prev) -- of which the ones that left
+// this rank (last step's ghosts, particles handed to a neighbour: class byte >= gone_from) take no part: flag 2 -- followed by this
+// step's arrivals [n_prev, n) in the order they were unpacked: movers all, whatever their cell
+__global__ __launch_bounds__(256) void k_inc_classify_slab(uint32_t n, uint32_t n_prev, CellKeyGen kg, IncClassifyP q)
+{
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    if (kg.gone && i < kg.n_gone && kg.gone[i] >= kg.gone_from) {
+        q.mv[i] = 2;
+        return;
+    }
+    const uint32_t k = cell_key_of(kg, i);
+    inc_register(q, i, k, i >= n_prev || k != inc_key_of_cur_cell(q.cur, q.nxt, q.cxy_cur[i]));
+}
+
 // 2. new population of every cell = its stayers + the length of its list; per-block sums (INC_CELLS cells per block, one per thread:
 //    the chain range -> flags -> list is three dependent round trips, so the launch wants many short threads)
 #define INC_CELLS 1024
@@ -376,21 +391,33 @@ __global__ __launch_bounds__(256) void k_inc_scan(uint32_t ncells, uint32_t* __r
 
 // 4. every particle to its slot, with everything k_reorder moves (the merge knows where a particle GOES, so the reorder is a scatter of
 //    coalesced reads -- a near-identity one -- and the permutation is never stored); the sorted keys as the radix sort leaves them
+//    PERM (a slab rank: the maps of its ghost layer are built from the permutation): slot -> current index instead of the reorder;
+//    slots that left the rank (flag 2) are not placed
+template <bool PERM>
 __global__ __launch_bounds__(256) void k_inc_place_reorder(uint32_t n, IncGrid G, const uint32_t* __restrict__ cell_start_cur, const uint32_t* __restrict__ cell_start_nxt,
                                                             const uint32_t* __restrict__ nk, const uint8_t* __restrict__ mv, const uint32_t* __restrict__ next,
                                                             const unsigned long long* __restrict__ head, uint32_t epoch, const uint32_t* __restrict__ cxy_cur,
-                                                            uint32_t* __restrict__ key_out, ReorderIO io)
+                                                            uint32_t* __restrict__ key_out, ReorderIO io, uint32_t* __restrict__ perm_out)
 {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     // (everything that does not depend on the slot is requested first)
+    const uint32_t flag = mv[i];
+    if (PERM && flag == 2u) return;
     const uint32_t c = nk[i];
-    const bool mover = mv[i] != 0;
-    const uint32_t own = cxy_cur[i];
-    const float4 pm = io.pm_in[i];
-    const float2 vel = io.vel_in[i];
-    const uint32_t orig = io.orig_in[i];
-    const float lvl = io.lvl_in[i], lvlold = io.lvlold_in[i];
+    const bool mover = flag != 0u;
+    const uint32_t own = mover ? 0u : cxy_cur[i];   // (an arrival has no current cell)
+    float4 pm;
+    float2 vel;
+    uint32_t orig = 0;
+    float lvl = 0.f, lvlold = 0.f;
+    if (!PERM) {
+        pm = io.pm_in[i];
+        vel = io.vel_in[i];
+        orig = io.orig_in[i];
+        lvl = io.lvl_in[i];
+        lvlold = io.lvlold_in[i];
+    }
     const unsigned long long h = head[c];
     const uint32_t first = cell_start_nxt[c];
     uint32_t b, e, r = 0;
@@ -408,6 +435,10 @@ __global__ __launch_bounds__(256) void k_inc_place_reorder(uint32_t n, IncGrid G
         for (uint32_t m = (uint32_t)h; m; m = next[m - 1u]) r += (m - 1u < i) ? 1u : 0u;
     const uint32_t dst = first + r;
     key_out[dst] = c;
+    if (PERM) {
+        perm_out[dst] = i;
+        return;
+    }
     io.pm_out[dst] = pm;
     io.vel_out[dst] = vel;
     io.orig_out[dst] = orig;
@@ -442,8 +473,32 @@ void incremental_cell_sort_reorder(hipStream_t s, Profiler* prof, uint32_t n, co
     }
     {
         ProfScope ps(prof, "inc_reorder", s);
-        hipLaunchKernelGGL(k_inc_place_reorder, dim3((n + 255) / 256), dim3(256), 0, s, n, G, cell_start_cur, cell_start_out, q.nk, q.mv, q.next, q.head, q.epoch,
-                           q.cxy_cur, key_out, io);
+        hipLaunchKernelGGL(k_inc_place_reorder<false>, dim3((n + 255) / 256), dim3(256), 0, s, n, G, cell_start_cur, cell_start_out, q.nk, q.mv, q.next, q.head,
+                           q.epoch, q.cxy_cur, key_out, io, (uint32_t*)nullptr);
+    }
+}
+
+void incremental_cell_sort_perm(hipStream_t s, Profiler* prof, uint32_t n, uint32_t n_prev, const CellKeyGen& kg, const IncClassifyP& q, const uint32_t* cell_start_cur,
+                                uint32_t* key_out, uint32_t* perm_out, uint32_t* cell_start_out, uint32_t* bsum, uint32_t* movers, uint32_t* movers_host)
+{
+    const IncGrid G{q.cur, q.nxt};
+    const uint32_t ncells = q.nxt.ncells, cblocks = (uint32_t)incremental_sort_block_sums(ncells);
+    {
+        ProfScope ps(prof, "inc_classify", s);
+        hipLaunchKernelGGL(k_inc_classify_slab, dim3((n + 255) / 256), dim3(256), 0, s, n, n_prev, kg, q);
+    }
+    {
+        ProfScope ps(prof, "inc_count", s);
+        hipLaunchKernelGGL(k_inc_count, dim3(cblocks), dim3(INC_CELLS), 0, s, G, cell_start_cur, q.mv, q.next, q.head, q.epoch, cell_start_out, bsum, movers);
+    }
+    {
+        ProfScope ps(prof, "inc_scan", s);
+        hipLaunchKernelGGL(k_inc_scan, dim3(cblocks), dim3(256), 0, s, ncells, cell_start_out, bsum, movers, movers_host);
+    }
+    {
+        ProfScope ps(prof, "inc_place", s);
+        hipLaunchKernelGGL(k_inc_place_reorder<true>, dim3((n + 255) / 256), dim3(256), 0, s, n, G, cell_start_cur, cell_start_out, q.nk, q.mv, q.next, q.head, q.epoch,
+                           q.cxy_cur, key_out, ReorderIO{}, perm_out);
     }
 }
 

@@ -867,11 +867,14 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
         }
         if (!coarse_ok)
             return c->fail(SPH_ERR_UNSUPPORTED, "cell grid of cell size %g is too large for this build", (double)g.cs);
+        // (what the last build left behind -- the grid the arrays are sorted by, their cells, the cell ranges -- if nothing touched the
+        //  state since: a slab rank's sort below is then a merge)
+        const GridP prev_grid = c->fgrid;
+        const bool prev_valid = c->grid_valid;
         c->grid = g;
         c->fgrid = fg;
         c->grid_valid = true;
         g = fg;   // everything below (keys, sort, cell ranges, sweeps) works on the sorting grid
-        HIPCHK(c, c->cell_start.ensure(((size_t)g.ncells + 1) * sizeof(uint32_t)));
 
         StepP sp{};
         sp.rest_density = p->rest_density;
@@ -900,6 +903,22 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
         const bool pre = c->dist.on && c->dist.pre;
         const uint32_t n_sort = pre ? m.n_sort : n;
         c->dist.pre = false;
+        // A slab rank behind its fused refresh: slots [0, n_prev) are last step's sorted array (some of them left the rank), the
+        // arrivals follow unsorted -- the stable sort is the merge of sph_sort.hip (incremental_cell_sort_perm) with the arrivals as
+        // movers, if they and the particles that changed cell last time are few; same keys, permutation and cell ranges as the radix sort.
+        const uint32_t n_prev = pre ? c->dist.pre_cls_n : 0u;
+        uint32_t* movers_host = (uint32_t*)(c->ctrl_host + 2) + 1;
+        bool merge = pre && c->opt.inc_sort && prev_valid && prev_grid.cs == g.cs && prev_grid.ncells > 0 && n_prev > 0 && n_prev <= n_sort && !c->exact &&
+                     g.ncells <= 4u * n_sort + 4096u;
+        if (merge) {
+            const uint32_t limit = n_sort / (c->opt.inc_sort > 1 ? (uint32_t)c->opt.inc_sort : 3u);
+            if (n_sort - n_prev > limit) merge = false;
+            else if (*movers_host > limit) {
+                merge = ++c->inc_radix_streak >= 8;
+                if (merge) c->inc_radix_streak = 0;
+            }
+        }
+        if (!merge) HIPCHK(c, c->cell_start.ensure(((size_t)g.ncells + 1) * sizeof(uint32_t)));
         // the build the previous step queued ahead (queue_ahead_build): adopted if nothing touched the state since (the header that
         // step left behind was still the one in force), the scene is what it predicted and the real bounding box fits its grid
         const GridP ag = c->ahead.g;
@@ -932,11 +951,31 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
         } else if (n_sort) {
             // (the keys -- cell index, or one past the last cell for a slot that left -- are made by the sort's first pass)
             const CellKeyGen kg{c->pm[c->pcur].as<float4>(), g, pre ? c->dist.cls.as<uint8_t>() : nullptr, pre ? c->dist.pre_cls_n : 0u, (uint32_t)SC_GONE_FROM};
-            int res = radix_sort_pairs(s, prof, c->key[0].as<uint32_t>(), c->val[0].as<uint32_t>(), c->key[1].as<uint32_t>(),
-                                       c->val[1].as<uint32_t>(), n_sort, ilog2_ceil(g.ncells + (pre ? 1u : 0u)), c->sort_scratch.as<uint32_t>(), &kg);
-            if (res == 1) {  // keep the sorted keys in key[0] / val[0]
-                std::swap(c->key[0], c->key[1]);
-                std::swap(c->val[0], c->val[1]);
+            if (merge) {
+                const size_t head_before = c->inc_head.bytes;
+                HIPCHK(c, c->inc_head.ensure((size_t)g.ncells * 8));
+                if (c->inc_head.bytes != head_before) HIPCHK(c, hipMemsetAsync(c->inc_head.p, 0, c->inc_head.bytes, s));   // (epoch 0: no list)
+                HIPCHK(c, c->inc_next.ensure((size_t)c->cap * 4));
+                HIPCHK(c, c->inc_bsum.ensure(incremental_sort_block_sums(g.ncells) * 4));
+                if (!c->inc_movers.p) {
+                    HIPCHK(c, c->inc_movers.ensure(4));
+                    HIPCHK(c, hipMemsetAsync(c->inc_movers.p, 0, 4, s));
+                }
+                HIPCHK(c, c->acell_start.ensure(((size_t)g.ncells + 1) * sizeof(uint32_t)));
+                if (++c->inc_epoch == 0u) c->inc_epoch = 1u;
+                const IncClassifyP q{prev_grid, g, c->cxy.as<uint32_t>(), c->key[1].as<uint32_t>(), c->val[1].as<uint8_t>(), c->inc_next.as<uint32_t>(),
+                                     c->inc_head.as<unsigned long long>(), c->inc_epoch};
+                incremental_cell_sort_perm(s, prof, n_sort, n_prev, kg, q, c->cell_start.as<uint32_t>(), c->key[0].as<uint32_t>(), c->val[0].as<uint32_t>(),
+                                           c->acell_start.as<uint32_t>(), c->inc_bsum.as<uint32_t>(), c->inc_movers.as<uint32_t>(),
+                                           (uint32_t*)(c->ctrl_host_dev + 2) + 1);
+                std::swap(c->cell_start, c->acell_start);   // (the old table was read while the new one was written)
+            } else {
+                int res = radix_sort_pairs(s, prof, c->key[0].as<uint32_t>(), c->val[0].as<uint32_t>(), c->key[1].as<uint32_t>(),
+                                           c->val[1].as<uint32_t>(), n_sort, ilog2_ceil(g.ncells + (pre ? 1u : 0u)), c->sort_scratch.as<uint32_t>(), &kg);
+                if (res == 1) {  // keep the sorted keys in key[0] / val[0]
+                    std::swap(c->key[0], c->key[1]);
+                    std::swap(c->val[0], c->val[1]);
+                }
             }
             if (n)
                 launch_reorder(s, prof, n, g, c->key[0].as<uint32_t>(), c->val[0].as<uint32_t>(), c->pm[c->pcur].as<float4>(), c->vel[k].as<float2>(),
@@ -947,7 +986,7 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
             c->cur = k ^ 1;
             c->pcur ^= 1;
         }
-        if (!adopt) launch_cell_start(s, prof, c->key[0].as<uint32_t>(), n, g.ncells, c->cell_start.as<uint32_t>(), c->cs_scratch.p, n > 0);
+        if (!adopt && !(merge && n_sort)) launch_cell_start(s, prof, c->key[0].as<uint32_t>(), n, g.ncells, c->cell_start.as<uint32_t>(), c->cs_scratch.p, n > 0);
         if (c->tile_ts > 0) {
             const size_t nt = (size_t)c->tile_tsx * (size_t)c->tile_tsy;
             // the extended-range lists reach k * h_max with k = level_estimation_range / ETA > 2: a larger particle may sit

@@ -119,3 +119,50 @@ def test_build_queued_ahead_is_the_build_at_the_step_start(product_lib, monkeypa
     for s, (fa, fb) in enumerate(zip(out["ahead"][1], out["at-start"][1])):
         for k in fa:
             assert np.array_equal(fa[k], fb[k]), (s, k)
+
+
+@pytest.mark.parametrize("k,two_sizes", [(2, False), (3, False), (2, True)])
+def test_slab_ranks_sort_by_merging_their_arrivals(product_lib, monkeypatch, k, two_sizes):
+    """A slab rank behind its fused refresh: last step's sorted slots (some of them left: last step's ghosts, migrants), then this
+    step's arrivals (migrants, the new ghost layer) unsorted behind them.  The merge with the arrivals as movers against the radix
+    sort (SPH_INC_SORT=0) on a loopback group whose fluid is pushed across the cuts: every rank's arrays bit for bit."""
+    from adaptive_sph_amd import distributed as D
+    if two_sizes:
+        scn = two_sizes_scene()
+        pos, mass, vel = sc.init_particles(scn)
+    else:
+        scn = sc.dam_break_small(96, 48, 1 / 48)
+        pos, mass, vel = sc.init_particles(scn)
+        vel = vel.copy()
+        vel[:, 0] = 0.8
+    P = dam_break_params(max_iters=6)
+    planes = sc.boundary_planes(scn.boundary, P.init_boundary_handler)
+    p = P.to_ffi()
+    out = {}
+    for form in ("merge", "radix"):
+        if form == "radix":
+            monkeypatch.setenv("SPH_INC_SORT", "0")
+        grp = D.make_loopback_group(product_lib, pos, mass, vel, planes, k)
+        if form == "radix":
+            monkeypatch.delenv("SPH_INC_SORT")
+        for c in grp:
+            c.profile_enable(1)
+        n0 = [c.n for c in grp]
+        its = []
+        for s in range(25):
+            sts = ffi.group_step(grp, p)
+            its.append(tuple((int(st.div_solver.iters), int(st.density_solver.iters), int(st.density_solver.normal_count)) for st in sts))
+        fields = [{f: c.download(f) for f in ("particle_id", "position", "velocity", "pressure", "density", "neighbor_count", "cell_index")} for c in grp]
+        out[form] = (its, fields, [c.profile_get() for c in grp], n0, [c.n for c in grp])
+        for c in grp:
+            c.close()
+    # (two particle sizes in a small box: the ghost layer of a coarse cut is a large part of a rank's array -- above a third of it the
+    #  rank keeps the radix sort)
+    assert all(pr.get("inc_place", (0, 0))[0] >= (3 if two_sizes else 20) for pr in out["merge"][2]), out["merge"][2][0]
+    assert all("inc_place" not in pr for pr in out["radix"][2])
+    if not two_sizes:
+        assert out["merge"][3] != out["merge"][4]   # particles did migrate
+    assert out["merge"][0] == out["radix"][0] and out["merge"][4] == out["radix"][4]
+    for r, (fa, fb) in enumerate(zip(out["merge"][1], out["radix"][1])):
+        for f in fa:
+            assert np.array_equal(fa[f], fb[f]), (r, f)
