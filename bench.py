@@ -506,8 +506,9 @@ def main():
         # (old cell 4r, new key 4w, mover flag 1w), place + reorder (key 4r, flag 1r, old cell 4r; record, velocity, id, level state
         # 40r + 40w; sorted key 4w, new cell 4w); the per-cell count and scan touch the cell tables, not the particles.
         # (the radix form it replaces: cell keys 16r + 8w, two passes of 4r + 8r + 8w, reorder 40r + 40w, cell-range table 4r = 148)
-        # (slab ranks sort at the step's start with the radix form)
-        "neighbour_build_algorithmic_bytes_per_particle": (24 + 2 * 20 + 80 + 4) if distributed else (9 + 9 + 80 + 8),
+        # (slab ranks merge at the step's start, with a classification pass of its own and a stored permutation: record 16r, old cell 4r,
+        #  key 4w, flag 1w; place: key 4r, flag 1r, old cell 4r, sorted key 4w, permutation 4w; gather reorder 4r + 40r + 40w + new cell 4w)
+        "neighbour_build_algorithmic_bytes_per_particle": (25 + 17 + 88) if distributed else (9 + 9 + 80 + 8),
         "steps_from_rest": {"steps": args.warmup, "ms_per_step": warmup_elapsed * 1e3 / max(args.warmup, 1),
                             "note": "steps 0..warmup-1 (rest lattice, first launches included); rank 0's clock, not part of `value`"},
     }
