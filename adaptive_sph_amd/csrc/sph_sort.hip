@@ -258,12 +258,16 @@ int radix_sort_pairs(hipStream_t s, Profiler* prof, uint32_t* keyA, uint32_t* va
 //     slot(i) = first slot of its new cell                                    (scan over the cells' new populations)
 //             + stayers of that cell in front of it                           (a look at the cell's old range: ~5 flags)
 //             + movers INTO that cell with a smaller old index                (a per-cell list, empty for 96 % of the cells)
-// which is exactly where the stable LSD sort puts it (ties by old index).  Four launches (classify, count, scan, place + reorder)
-// instead of the six of two radix passes, the reorder and the two of the cell-range table; same sorted keys, same order of the arrays
-// and same cell_start bit for bit, whatever the number of movers -- the per-cell lists are built with atomics but only ever COUNTED, so no
+// which is exactly where the stable LSD sort puts it (ties by old index).  Classification (by the step's integrating tail, which holds
+// the new positions, or a launch of its own), count, scan, place + reorder in one scatter pass -- three or four launches instead of the
+// six of two radix passes, the gather reorder and the two of the cell-range table; same sorted keys, same order of the arrays and same
+// cell_start bit for bit, whatever the number of movers -- the per-cell lists are built with atomics but only ever COUNTED, so no
 // result depends on their order.  Cost grows with the movers (one 64-bit atomic exchange each, list walks in the cells they
-// enter): the caller falls back to the radix sort when the previous step's count was large (queue_ahead_build).
+// enter): the caller falls back to the radix sort when the previous step's count was large (sph_step.hip: plan_ahead_build).
 // The grids of the two steps differ by a translation only (same cell size): lexicographic order of the cells is the same in both.
+// Two callers: the build a plain context queues AHEAD behind its integrating tail (incremental_cell_sort_reorder), and a slab rank's
+// sort at the start of its step, where last step's ghosts and migrants leave the array and the arrivals behind it are movers whatever
+// their cell (incremental_cell_sort_perm: the rank builds the maps of its ghost layer from the permutation, so that form stores it).
 // ------------------------------------------------------------------------------------------------
 struct IncGrid {
     GridP cur, nxt;   // the grid the array is sorted by; the grid of the keys to sort by (same cs)
