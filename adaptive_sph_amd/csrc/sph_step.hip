@@ -1604,8 +1604,8 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
         if (plan.incremental) {
             const ReorderIO io{integrated, c->vel[k].as<float2>(), c->orig[k].as<uint32_t>(), c->lvl[k].as<float>(), c->lvlold[k].as<float>(), c->pm2.as<float4>(),
                                c->vel[k ^ 1].as<float2>(), c->orig[k ^ 1].as<uint32_t>(), c->lvl[k ^ 1].as<float>(), c->lvlold[k ^ 1].as<float>(), c->acxy.as<uint32_t>(),
-                               c->h2n[k].as<float>(), c->h2n[k ^ 1].as<float>(), c->lam_sum.as<float>(), c->lam_prev.as<float>(), c->szc[k].as<uint8_t>(),
-                               c->szc[k ^ 1].as<uint8_t>()};
+                               c->h2n[k].as<float>(), c->h2n[k ^ 1].as<float>(), /* lambda sums of this step: only FromDistribution* reads them next step,
+                               and a step in that mode does not adopt this build */ nullptr, nullptr, c->szc[k].as<uint8_t>(), c->szc[k ^ 1].as<uint8_t>()};
             incremental_cell_sort_reorder(s, &c->prof, n, integrated, plan.q, /* classified by the tail */ true, c->cell_start.as<uint32_t>(), c->akey[0].as<uint32_t>(),
                                           c->acell_start.as<uint32_t>(), io, c->inc_bsum.as<uint32_t>(), c->inc_movers.as<uint32_t>(),
                                           (uint32_t*)(c->ctrl_host_dev + 2) + 1);
