@@ -678,11 +678,19 @@ template <class Op, class = void>
 struct OpWideTrips : std::integral_constant<int, 1> {};
 template <class Op>
 struct OpWideTrips<Op, std::void_t<decltype(Op::WIDE_TRIPS)>> : std::integral_constant<int, Op::WIDE_TRIPS> {};
+// ops with `static constexpr bool OFF16_SELF = true` need the particle itself (W(0) != 0 in one of their sums): they get every slot's
+// offset -- pair_off(.., off) instead of pair(..) -- and add their own term where the reference's list has it, between the last
+// neighbour in front of the particle and the first behind it (off > 0 for the first time: the list is in ascending order of j); a
+// padding slot has off == 0 (no neighbour has); begin_off() behind begin()
+template <class Op, class = void>
+struct OpOffSelf : std::false_type {};
+template <class Op>
+struct OpOffSelf<Op, std::void_t<decltype(Op::OFF16_SELF)>> : std::bool_constant<Op::OFF16_SELF> {};
 template <class Op>
 __global__ __launch_bounds__(SWEEP_THREADS) void k_sweep_off(Op op, SweepCommon c)
 {
     typedef typename Op::Math Math;
-    static_assert(!Math::EXACT && Op::SKIP_SELF && !Op::EXTENDED, "k_sweep_off: gradient sweeps of the FAST / UNIFORM math policies");
+    static_assert(!Math::EXACT && (Op::SKIP_SELF || OpOffSelf<Op>::value) && !Op::EXTENDED, "k_sweep_off: gradient sweeps of the FAST / UNIFORM math policies");
     sweep_stamp(c.ts, false);
     if (!OpPrologue<Op>::run(op, blockIdx.x)) {
         const uint32_t per_xcd = (c.nblocks + 7) >> 3;
@@ -702,19 +710,22 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_sweep_off(Op op, SweepCommon 
             op.init(acc);
             if (active && (head & NLH_OK)) {
                 op.begin(acc, i, Ai);
+                if constexpr (OpOffSelf<Op>::value) op.begin_off(acc, i, Ai);
                 const uint32_t cnt = head & 0x1fu;
 #define SPH_OFF_TRIP(WA, WB)                                                                                   \
     {                                                                                                          \
-        const uint32_t j0 = i + (uint32_t)((int)((WA) << 16) >> 16), j1 = i + (uint32_t)((int)(WA) >> 16);     \
-        const uint32_t j2 = i + (uint32_t)((int)((WB) << 16) >> 16), j3 = i + (uint32_t)((int)(WB) >> 16);     \
+        const int o0 = (int)((WA) << 16) >> 16, o1 = (int)(WA) >> 16, o2 = (int)((WB) << 16) >> 16, o3 = (int)(WB) >> 16; \
+        const uint32_t j0 = i + (uint32_t)o0, j1 = i + (uint32_t)o1, j2 = i + (uint32_t)o2, j3 = i + (uint32_t)o3; \
         const float4 A0 = op.loadA(j0), A1 = op.loadA(j1), A2 = op.loadA(j2), A3 = op.loadA(j3);               \
         const typename Op::NB N0 = op.nb(acc, j0, A0), N1 = op.nb(acc, j1, A1), N2 = op.nb(acc, j2, A2), N3 = op.nb(acc, j3, A3); \
-        SPH_OFF_PAIR(A0, N0) SPH_OFF_PAIR(A1, N1) SPH_OFF_PAIR(A2, N2) SPH_OFF_PAIR(A3, N3)                    \
+        SPH_OFF_PAIR(A0, N0, o0) SPH_OFF_PAIR(A1, N1, o1) SPH_OFF_PAIR(A2, N2, o2) SPH_OFF_PAIR(A3, N3, o3)    \
     }
-#define SPH_OFF_PAIR(AJ, NJ)                                                                                   \
+#define SPH_OFF_PAIR(AJ, NJ, OFF)                                                                              \
     {                                                                                                          \
         const float dx = Ai.x - AJ.x, dy = Ai.y - AJ.y;                                                        \
-        op.pair(acc, AJ, NJ, dx, dy, dx * dx + dy * dy, Math::UNIFORM ? op.m.h : (Ai.w + AJ.w) * 0.5f);        \
+        const float hij_ = Math::UNIFORM ? op.m.h : (Ai.w + AJ.w) * 0.5f;                                      \
+        if constexpr (OpOffSelf<Op>::value) op.pair_off(acc, AJ, NJ, dx, dy, dx * dx + dy * dy, hij_, OFF);    \
+        else op.pair(acc, AJ, NJ, dx, dy, dx * dx + dy * dy, hij_);                                            \
     }
                 // (the trips are wave-uniform: the longest list of the wave decides; a shorter one evaluates its own record, for nothing)
                 constexpr int WT = OpWideTrips<Op>::value;   // trips whose gathers leave together (3: twelve records in flight, one round trip instead of three)
@@ -728,7 +739,7 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_sweep_off(Op op, SweepCommon 
                         R[2 * k + 1] = op.loadA(i + (uint32_t)((int)w[k] >> 16));
                     }
 #pragma unroll
-                    for (int k = 0; k < 4 * WT; k++) SPH_OFF_PAIR(R[k], typename Op::NB{})
+                    for (int k = 0; k < 4 * WT; k++) SPH_OFF_PAIR(R[k], typename Op::NB{}, ((k & 1) ? (int)w[k >> 1] >> 16 : (int)(w[k >> 1] << 16) >> 16))
                     if (WT == 2 && __any(cnt > 8u)) SPH_OFF_TRIP(g2.x, g2.y)
                 } else {
                     SPH_OFF_TRIP(g0.x, g0.y)
@@ -1087,14 +1098,37 @@ struct OpAiiConst {
     float2* __restrict__ ap_unit;   // check_aii only: a^p_i for the pressure field e_i (input of OpCheckAii), else nullptr
     struct Acc {
         float cf, ax, ay, a2, bx, by;
+        float self_cf;    // offset lists: the particle's own term of the constant field, (m_i / rho_i) W(0) ...
+        bool self_done;   // ... and whether it has been added (a list that names the particle itself: always)
     };
+    // (k_sweep_off: the offset list leaves the particle out; of its pair with itself only the constant field's W(0) term is not zero --
+    //  the gradient is -- and that term goes where the mask replay has it, in front of the first neighbour behind the particle)
+    static constexpr bool OFF16 = !MathT::EXACT, OFF16_SELF = true;
+    __device__ void begin_off(Acc& a, uint32_t i, float4 Ai) const
+    {
+        float wv, sc;
+        m.wg(0.f, Ai.w, wv, sc);
+        a.self_cf = mrho[i] * wv;
+        a.self_done = false;
+    }
+    __device__ void pair_off(Acc& a, float4 Aj, NB mr, float dx, float dy, float r2, float hij, int off) const
+    {
+        a.cf += (off > 0 && !a.self_done) ? a.self_cf : 0.f;
+        a.self_done = a.self_done || off > 0;
+        pair(a, Aj, off != 0 ? mr : 0.f, dx, dy, r2, hij);   // (a padding slot is the particle again: its gradient is zero, its m / rho must not count)
+    }
     __device__ bool skip() const { return false; }
     __device__ bool lane_skip(uint32_t) const { return false; }
     __device__ void init(Acc&) const {}
     __device__ void epilogue(Acc&, bool, uint32_t) const {}
     __device__ float4 loadA(uint32_t j) const { return pm[j]; }
     __device__ NB nb(const Acc&, uint32_t j, float4) const { return mrho[j]; }
-    __device__ void begin(Acc& a, uint32_t, float4) const { a.cf = a.ax = a.ay = a.a2 = a.bx = a.by = 0.f; }
+    __device__ void begin(Acc& a, uint32_t, float4) const
+    {
+        a.cf = a.ax = a.ay = a.a2 = a.bx = a.by = 0.f;
+        a.self_cf = 0.f;
+        a.self_done = true;
+    }
     __device__ void pair(Acc& a, float4 Aj, NB mr, float dx, float dy, float r2, float hij) const
     {
         float gx, gy;
@@ -1126,6 +1160,7 @@ struct OpAiiConst {
             ls = lam_sum[i];
             gl = lam_grad[i];
         }
+        if (!a.self_done) a.cf += a.self_cf;   // (offset list without a neighbour behind the particle)
         constf[i] = a.cf + ls / sp.rest_density;
         const float mi = Ai.z, rho_i = rho[i], rho_b = sp.rest_density;
         const float rho_i_sq = rho_i * rho_i;
@@ -2986,6 +3021,8 @@ struct OpFuse {
     static constexpr bool TILE = true;
     typedef typename A::Math Math;
     static constexpr bool HAS_EPILOGUE = false, SKIP_SELF = A::SKIP_SELF && B::SKIP_SELF, EXTENDED = false;
+    // (k_sweep_off: A knows about its own term -- OpAiiConst --, B's pair of the particle with itself is zero)
+    static constexpr bool OFF16 = OpOff16<A>::value && OpOff16<B>::value && OpOffSelf<A>::value && B::SKIP_SELF, OFF16_SELF = true;
     __device__ constexpr float krange() const { return 2.f; }
     A a;
     B b;
@@ -3016,6 +3053,12 @@ struct OpFuse {
     __device__ void pair(Acc& c, float4 Aj, NB n, float dx, float dy, float r2, float hij) const
     {
         a.pair(c.x, Aj, n.x, dx, dy, r2, hij);
+        b.pair(c.y, Aj, n.y, dx, dy, r2, hij);
+    }
+    __device__ void begin_off(Acc& c, uint32_t i, float4 Ai) const { a.begin_off(c.x, i, Ai); }
+    __device__ void pair_off(Acc& c, float4 Aj, NB n, float dx, float dy, float r2, float hij, int off) const
+    {
+        a.pair_off(c.x, Aj, n.x, dx, dy, r2, hij, off);
         b.pair(c.y, Aj, n.y, dx, dy, r2, hij);
     }
     __device__ bool finish(Acc& c, uint32_t i, float4 Ai, bool wall) const

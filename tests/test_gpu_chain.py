@@ -203,7 +203,9 @@ def test_offset_lists_are_bit_identical_to_the_mask_words(product_lib, monkeypat
             st = g.step(p)
             its.append((int(st.div_solver.iters), int(st.density_solver.iters), int(st.density_solver.normal_count),
                         np.float32(st.density_solver.avg_error).view(np.uint32).item(), np.float32(st.dt).view(np.uint32).item()))
-            fields.append({f: g.download(f) for f in ("position", "velocity", "pressure", "density", "neighbor_count")})
+            # (a_ii and the constant field: the fused force sweep is on the lists too, with the particle's own W(0) term put where the
+            #  mask replay has it)
+            fields.append({f: g.download(f) for f in ("position", "velocity", "pressure", "density", "neighbor_count", "aii", "constant_field")})
         out[form] = (its, fields)
         g.close()
     assert out["offsets"][0] == out["masks"][0]
@@ -238,7 +240,7 @@ def test_offset_lists_in_a_multi_resolution_scene(product_lib, monkeypatch, solv
         for _ in range(12):
             st = g.step(p)
             its.append((int(st.div_solver.iters), int(st.density_solver.iters), np.float32(st.dt).view(np.uint32).item()))
-            fields.append({f: g.download(f) for f in ("position", "velocity", "pressure", "density")})
+            fields.append({f: g.download(f) for f in ("position", "velocity", "pressure", "density", "aii", "constant_field")})
         forms = g.profile_list_forms()
         out[form] = (its, fields, forms)
         g.close()
