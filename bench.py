@@ -47,7 +47,7 @@ ALGO_BYTES = {
 
 # VALU instructions per wave of the sweeps (rocprofv3 --pmc SQ_INSTS_VALU / SQ_WAVES, profiles/r4_sq_counters.txt) and the shader clock
 # those launches ran at (SQ_BUSY_CYCLES / 32 / duration, same file): what the `valu_issue` object of a roofline entry is priced with
-VALU_ISSUE = {"density": 1498, "aii_nonpressure": 1183, "source_term": 563, "pressure_accel": 294, "jacobi_update": 450}
+VALU_ISSUE = {"density": 1497, "aii_nonpressure": 887, "source_term": 563, "pressure_accel": 294, "jacobi_update": 450}
 SHADER_CLOCK_HZ = 2.06e9
 # rocprofv3's duration of the profiler's calibration kernel (one wave spinning 10 us of the device clock): 10 us + the launch / exit
 # of a one-wave dispatch, measured once against a kernel trace (profiles/r4_event_calibration.md: 5.33 / 20.44 / 40.43 / 100.47 for
