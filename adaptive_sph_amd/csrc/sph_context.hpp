@@ -183,7 +183,7 @@ struct sph_ctx {
     int tile_ts = 0, tile_tsx = 0, tile_tsy = 0;
     DevBuf tile_raw, tile_h, tile_h_ext, nlx;
     DevBuf nloff, nlh;   // relative-offset lists + header words (uniform scenes whose solves run on records; sph_sweeps.hip: k_sweep_off)
-    // Neighbour build AHEAD (one context, uniform scenes; sph_step.hip: queue_ahead_build): the NEXT step's cell sort, reorder and
+    // Neighbour build AHEAD (one context; uniform scenes and multi-resolution scenes on their fine grid; sph_step.hip: plan_ahead_build, queue_ahead_build): the NEXT step's cell sort, reorder and
     // cell-range table are queued behind this step's integrating tail, on a grid predicted from this step's bounding box plus a
     // margin -- the device works on them while the host finishes the step, returns, and enters the next one (the step boundary was
     // ~20-36 us of idle queue).  They write buffers of their own (post-step downloads still see this step's order, keys and ranges);
