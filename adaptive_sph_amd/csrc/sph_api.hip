@@ -37,7 +37,7 @@ bool Profiler::wants(const char* name) const
 {
     // mode 2: the density kernel only, on every 8th step (a timing-enabled event record forces a command
     // flush; sampling keeps the perturbation of the timed region below 1 %)
-    return mode == 1 || mode == 3 || (mode == 2 && (step_index & 7u) == 0u && strncmp(name, "density", 7) == 0);
+    return mode == 1 || mode == 3 || mode == 4 || (mode == 2 && (step_index & 7u) == 0u && strncmp(name, "density", 7) == 0);
 }
 hipEvent_t Profiler::get_event()
 {
@@ -59,8 +59,19 @@ void Profiler::begin(const char* name, hipStream_t s, bool single_launch)
     ext_open = mode == 3 && single_launch && ts_next < (uint32_t)TS_RING;
     ext_slot = -1;
     if (ext_open) return;   // timed by the kernel itself (take_slot), or not at all
+    kev_open = mode == 4 && single_launch;
+    kev_taken = false;
     cur_a = get_event();
-    (void)hipEventRecord(cur_a, s);
+    if (!kev_open) (void)hipEventRecord(cur_a, s);   // (mode 4, one launch: the dispatch carries the pair, take_events)
+}
+bool Profiler::take_events(hipEvent_t* a, hipEvent_t* b)
+{
+    if (!kev_open || kev_taken || depth != 1) return false;
+    kev_taken = true;
+    cur_b = get_event();
+    *a = cur_a;
+    *b = cur_b;
+    return true;
 }
 unsigned long long* Profiler::take_slot()
 {
@@ -79,6 +90,13 @@ void Profiler::end(hipStream_t s)
     if (ext_open) {
         if (ext_slot >= 0) pending.push_back(Pending{cur, nullptr, nullptr, ext_slot});   // (else: the scope launched nothing, no sample)
         ext_open = false;
+        cur = -1;
+        return;
+    }
+    if (kev_open) {
+        kev_open = false;
+        if (kev_taken) pending.push_back(Pending{cur, cur_a, cur_b, -1});
+        else pool.push_back(cur_a);   // (the scope launched nothing)
         cur = -1;
         return;
     }
@@ -1160,9 +1178,16 @@ __global__ void k_spin_calib(uint32_t us)
 }
 void launch_profile_calibration(sph_ctx* c)
 {
-    if (c->prof.mode != 1) return;
-    ProfScope ps(&c->prof, "calibration_spin10", c->stream);
-    hipLaunchKernelGGL(k_spin_calib, dim3(1), dim3(64), 0, c->stream, 10u);
+    if (c->prof.mode != 1 && c->prof.mode != 4) return;
+    {
+        ProfScope ps(&c->prof, "calibration_spin10", c->stream);
+        hipLaunchKernelGGL(k_spin_calib, dim3(1), dim3(64), 0, c->stream, 10u);
+    }
+    if (c->prof.mode == 4) {   // ... and timed the way mode 4 times the sweeps: by the dispatch's own timestamps (must read rocprofv3's 10.44 us)
+        ProfScope ps(&c->prof, "calibration_spin10_dispatch", c->stream, true);
+        hipEvent_t e0, e1;
+        if (c->prof.take_events(&e0, &e1)) hipExtLaunchKernelGGL(k_spin_calib, dim3(1), dim3(64), 0, c->stream, e0, e1, 0, 10u);
+    }
 }
 extern "C" int sph_profile_dispatch_bracket(sph_ctx* c, uint32_t spin_us, int reps, double* mean_bracket_us)
 {
@@ -1187,14 +1212,40 @@ extern "C" int sph_profile_dispatch_bracket(sph_ctx* c, uint32_t spin_us, int re
     return SPH_OK;
 }
 
+// The device's achievable streaming rate, measured in the same run as the sweeps it is compared with.  The guide's figure (6.29 TB/s,
+// MI355X_MICROARCH.md) needs several independent 16-byte accesses in flight per lane and a grid that fills every CU several times over:
+// each thread moves U float4 a block-stride apart (loads first, then stores), one tile of 256 U records per workgroup, nontemporal or
+// plain.  (The grid-stride loop of rounds 1-4 -- ONE access in flight per lane, 4096 workgroups -- reached 4.6-4.8 TB/s.)
+typedef float copy_v4f __attribute__((ext_vector_type(4)));
+template <int U, bool NT>
+__global__ __launch_bounds__(256) void k_copy4u(const float4* __restrict__ src4, float4* __restrict__ dst4, size_t n)
+{
+    const copy_v4f* __restrict__ src = reinterpret_cast<const copy_v4f*>(src4);
+    copy_v4f* __restrict__ dst = reinterpret_cast<copy_v4f*>(dst4);
+    const size_t base = (size_t)blockIdx.x * (256u * U) + threadIdx.x;
+    copy_v4f v[U];
+#pragma unroll
+    for (int k = 0; k < U; k++) {
+        const size_t i = base + (size_t)k * 256u;
+        if (i < n) v[k] = NT ? __builtin_nontemporal_load(src + i) : src[i];
+    }
+#pragma unroll
+    for (int k = 0; k < U; k++) {
+        const size_t i = base + (size_t)k * 256u;
+        if (i < n) {
+            if (NT) __builtin_nontemporal_store(v[k], dst + i);
+            else dst[i] = v[k];
+        }
+    }
+}
 __global__ __launch_bounds__(256) void k_copy4(const float4* __restrict__ src, float4* __restrict__ dst, size_t n)
 {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = src[i];
 }
 
-extern "C" int sph_profile_copy_bandwidth(sph_ctx* c, uint64_t bytes, double* gb_per_s)
+// best of the forms (first repetition of each warms up); *form (optional) names the winner: 0 grid-stride, 1 U=4, 2 U=8, 3 U=4 nt, 4 U=8 nt
+static int copy_bandwidth(sph_ctx* c, uint64_t bytes, double* gb_per_s, int* form)
 {
-    if (!c || !gb_per_s || bytes < 1024) return SPH_ERR_INVALID_ARGUMENT;
     HIPCHK(c, hipSetDevice(c->device));
     TmpBuf a, b;
     HIPCHK(c, a.ensure(bytes));
@@ -1205,22 +1256,42 @@ extern "C" int sph_profile_copy_bandwidth(sph_ctx* c, uint64_t bytes, double* gb
     HIPCHK(c, hipEventCreate(&e1));
     const size_t n4 = bytes / 16;
     double best = 0;
-    for (int rep = 0; rep < 6; rep++) {
-        HIPCHK(c, hipEventRecord(e0, c->stream));
-        hipLaunchKernelGGL(k_copy4, dim3(256 * 16), dim3(256), 0, c->stream, a.as<float4>(), b.as<float4>(), n4);
-        HIPCHK(c, hipEventRecord(e1, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        float ms = 0.f;
-        HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
-        const double g = 2.0 * (double)(n4 * 16) / (ms * 1e-3) / 1e9;
-        if (rep > 0 && g > best) best = g;   // first run warms up
+    int best_form = 0;
+    for (int f = 0; f < 5; f++) {
+        for (int rep = 0; rep < 5; rep++) {
+            HIPCHK(c, hipEventRecord(e0, c->stream));
+            const float4 *src = a.as<float4>();
+            float4* dst = b.as<float4>();
+            switch (f) {
+            case 0: hipLaunchKernelGGL(k_copy4, dim3(256 * 16), dim3(256), 0, c->stream, src, dst, n4); break;
+            case 1: hipLaunchKernelGGL((k_copy4u<4, false>), dim3((unsigned)((n4 + 1023) / 1024)), dim3(256), 0, c->stream, src, dst, n4); break;
+            case 2: hipLaunchKernelGGL((k_copy4u<8, false>), dim3((unsigned)((n4 + 2047) / 2048)), dim3(256), 0, c->stream, src, dst, n4); break;
+            case 3: hipLaunchKernelGGL((k_copy4u<4, true>), dim3((unsigned)((n4 + 1023) / 1024)), dim3(256), 0, c->stream, src, dst, n4); break;
+            default: hipLaunchKernelGGL((k_copy4u<8, true>), dim3((unsigned)((n4 + 2047) / 2048)), dim3(256), 0, c->stream, src, dst, n4); break;
+            }
+            HIPCHK(c, hipEventRecord(e1, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            float ms = 0.f;
+            HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
+            const double g = 2.0 * (double)(n4 * 16) / (ms * 1e-3) / 1e9;
+            if (rep > 0 && g > best) {
+                best = g;
+                best_form = f;
+            }
+        }
     }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     a.release();
     b.release();
     *gb_per_s = best;
+    if (form) *form = best_form;
     return SPH_OK;
+}
+extern "C" int sph_profile_copy_bandwidth(sph_ctx* c, uint64_t bytes, double* gb_per_s)
+{
+    if (!c || !gb_per_s || bytes < 1024) return SPH_ERR_INVALID_ARGUMENT;
+    return copy_bandwidth(c, bytes, gb_per_s, nullptr);
 }
 
 // list words of the last step by form (measurement hook): NL_OK 0x80000000, NL_WALL 0x40000000, NL_IDX 0x20000000 (sph_sweeps.hip)

@@ -18,6 +18,9 @@ struct Profiler {
                    //   counter at their start, every block at its end, into the launch's slot of a ring (atomic min / max).  The stamps'
                    //   same-address atomics make a sweep ~30 us longer, so this mode does not TIME a sweep; it places the dispatch: first
                    //   wave 3 us behind rocprofv3's start, last wave 0.8 us before its end (profiles/r4_event_calibration.md)
+                   // 4 every kernel like mode 1, but a scope that holds ONE sweep launch is timed by that dispatch's own start / end
+                   //   timestamps (hipExtLaunchKernelGGL's start / stop events: the completion signal's, what rocprofv3 --kernel-trace
+                   //   reports) instead of a marker bracket around it -- no marker excess to calibrate away (bench.py's roofline figures)
     uint64_t step_index = 0;
     struct Rec {
         std::string name;
@@ -41,6 +44,8 @@ struct Profiler {
     void end(hipStream_t s);
     // mode 3, inside a single-launch scope: the launch's slot for its device timestamps (nullptr: not wanted)
     unsigned long long* take_slot();
+    // mode 4, inside a single-launch scope: the event pair the launch itself carries (false: not wanted, launch plainly)
+    bool take_events(hipEvent_t* a, hipEvent_t* b);
     enum { TS_RING = 1 << 16 };
     unsigned long long* ts_dev = nullptr;   // [0, TS_RING): first start (min), [TS_RING, 2 TS_RING): last end (max)
     uint32_t ts_next = 0;
@@ -52,6 +57,7 @@ struct Profiler {
     hipEvent_t cur_a = nullptr, cur_b = nullptr;
     bool ext_open = false;
     int ext_slot = -1;
+    bool kev_open = false, kev_taken = false;
 };
 
 struct ProfScope {

@@ -1382,7 +1382,7 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
             m.a.nloff = m.c->nloff.as<uint2>();
             m.a.nlh = m.c->nlh.as<uint8_t>();
         }
-        if (m.n) launch_profile_calibration(m.c);   // (profiler mode 1 only)
+        if (m.n) launch_profile_calibration(m.c);   // (profiler modes 1 and 4 only)
         if (p->check_neighborhood && m.n) launch_check_neighborhood(m.c, m.a);
     }
     // ---- constrain_neighborhood_count (simulation.rs:2145-2177): h2 of over-populated particles shrinks AFTER the lists are

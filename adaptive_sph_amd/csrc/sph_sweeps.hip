@@ -3150,6 +3150,11 @@ template <class K, class Op>
 static void launch_sweep_kernel(K kernel, dim3 grid, hipStream_t s, const SweepArgs& a, const Op& op, SweepCommon c)
 {
     c.ts = a.prof ? a.prof->take_slot() : nullptr;
+    hipEvent_t e0, e1;
+    if (a.prof && a.prof->take_events(&e0, &e1)) {   // Profiler mode 4: the dispatch's own start / end timestamps
+        hipExtLaunchKernelGGL(kernel, grid, dim3(SWEEP_THREADS), 0, s, e0, e1, 0, op, c);
+        return;
+    }
     hipLaunchKernelGGL(kernel, grid, dim3(SWEEP_THREADS), 0, s, op, c);
 }
 

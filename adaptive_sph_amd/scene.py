@@ -153,6 +153,15 @@ def dam_break_8m() -> SceneConfig:
     return dam_break_weak(8)
 
 
+def dam_break_8m_spec() -> SceneConfig:
+    """SURVEY.md section 8d config 4 AS WRITTEN: box 4 x 2, one block pos [-1.9995, -0.9995], size [1.4143, 1.4143], spacing 1/2048
+    -> 2896 x 2896 = 8 386 816 particles.  Kept under its own name since configs[3] became `dam_break_8m` (round 4): this column
+    blows up at step 3 on the reference's algorithm -- scripts/gpu_config3_divergence.py steps it on the CPU oracle and on the device
+    for max_dt 0.001 / 0.0005 / 0.00025, output in profiles/r5_config3_divergence.md."""
+    return SceneConfig(SceneBoundary("box", 4.0, 2.0),
+                       [SceneFluidBlock([-1.9995, -0.9995], [1.4143, 1.4143], 0.00048828125, 0.93, [0.0, 0.0])])
+
+
 def ratio_stress_4m() -> SceneConfig:
     """configs[4]: the geometry of media/ratio-stress-test-scene.yaml at 50:1 radius ratio with 4 002 768 fine + 1 575 coarse
     particles."""

@@ -51,8 +51,14 @@ VALU_ISSUE = {"density": 1497, "aii_nonpressure": 887, "source_term": 563, "pres
 SHADER_CLOCK_HZ = 2.06e9
 # rocprofv3's duration of the profiler's calibration kernel (one wave spinning 10 us of the device clock): 10 us + the launch / exit
 # of a one-wave dispatch, measured once against a kernel trace (profiles/r4_event_calibration.md: 5.33 / 20.44 / 40.43 / 100.47 for
-# 5 / 20 / 40 / 100 us)
+# 5 / 20 / 40 / 100 us).  Since round 5 the sweeps are timed by their dispatches' own start / end timestamps (Profiler mode 4:
+# hipExtLaunchKernelGGL's event pair -- the completion signal's timestamps, what rocprofv3 reads), so this constant only checks that
+# mode (the calibration kernel's dispatch must read it) and prices the marker brackets of the kernels that are not sweeps.
 SPIN10_ROCPROF_US = 10.44
+# the guide's measured streaming rate (MI355X_MICROARCH.md: 6.29 TB/s float4 copy): what `bound` compares a sweep's real traffic with,
+# next to this run's own copy kernel
+GUIDE_COPY_GBS = 6290.0
+SWEEP_KERNELS = ("density", "aii_constfield", "non_pressure_accel", "aii_nonpressure", "source_term", "pressure_accel", "jacobi_update")
 
 # rocprofv3 kernel names of the sweeps (profiles/*_kernel_summary.json keys)
 PMC_NAMES = {"density": "OpDensity[build]", "aii_constfield": "OpAiiConst", "non_pressure_accel": "OpNonPressure",
@@ -72,6 +78,20 @@ def committed_pmc_traffic(kernel):
         return e.get("hbm_traffic_bytes_per_launch"), files[-1].name
     except Exception:  # noqa: BLE001
         return None, None
+
+
+def committed_8m(kernel):
+    """(HBM bytes per launch, rocprofv3 average us, file) of `kernel` on configs[3] (8.4 M particles: the step's arrays no longer sit in the
+    256 MB Infinity Cache, so FETCH_SIZE / WRITE_SIZE are HBM traffic there) from the newest committed summary of that config."""
+    import re
+    files = sorted(f for f in (REPO / "profiles").glob("*_dam_break_8m_kernel_summary.json") if re.fullmatch(r"r\d+[a-z]?_dam_break_8m_kernel_summary\.json", f.name))
+    if not files or kernel not in PMC_NAMES:
+        return None, None, None
+    try:
+        e = json.load(open(files[-1])).get(PMC_NAMES[kernel], {})
+        return e.get("hbm_traffic_bytes_per_launch"), e.get("avg_us_working", e.get("median_us_working")), files[-1].name
+    except Exception:  # noqa: BLE001
+        return None, None, None
 
 
 def committed_pmc_avg(kernel):
@@ -307,7 +327,7 @@ def main():
         for _ in range(args.warmup):
             ctx.step(p)
         ctx.profile_reset()
-        ctx.profile_enable(1)
+        ctx.profile_enable(4)   # sweeps: the dispatch's own timestamps; everything else: marker brackets
         di2, de2 = [], []
         for _ in range(k_prof):
             st = ctx.step(p)
@@ -319,10 +339,15 @@ def main():
         ctx.profile_enable(0)
         cal = prof_all.pop("calibration_spin10", None)
         prof_work.pop("calibration_spin10", None)
+        cal_d = prof_all.pop("calibration_spin10_dispatch", None)
+        prof_work.pop("calibration_spin10_dispatch", None)
         if cal and cal[0]:
             marker_excess_us = max(0.0, cal[1] * 1e3 / cal[0] - SPIN10_ROCPROF_US)
         prof_window = {"steps": k_prof, "first_step": args.warmup, "same_iteration_counts_as_timed_region": (di2 == div_iters[:k_prof] and de2 == dens_iters[:k_prof]),
-                       "marker_excess_us": marker_excess_us, "calibration_launches": cal[0] if cal else 0}
+                       "marker_excess_us": marker_excess_us, "calibration_launches": cal[0] if cal else 0,
+                       # the calibration kernel timed like the sweeps are (its dispatch's own timestamps): rocprofv3 reports 10.44 us for it
+                       "calibration_spin10_dispatch_us": (cal_d[1] * 1e3 / cal_d[0]) if cal_d and cal_d[0] else None,
+                       "calibration_spin10_rocprofv3_us": SPIN10_ROCPROF_US}
         args.profile_steps = k_prof
     leg("copy kernel")
     copy_gbs = ctx.profile_copy_bandwidth_gbs(1 << 30) if rank == 0 else 0.0   # achievable HBM rate of this device, same run
@@ -408,28 +433,40 @@ def main():
         return
 
     def roof(name, launches, total_ms):
-        """Average duration of the kernel's launches that did work: HIP-event brackets over the instrumented repeat of the timed
-        window, minus the marker excess calibrated in the same pass (see above) -- the quantity rocprofv3 --kernel-trace --stats
-        reports as that kernel's average duration for the same command (profiles/r4*_kernel_summary.*: `avg_us_working`)."""
+        """Average duration of the kernel's launches that did work over the instrumented repeat of the timed window.  Sweeps: the
+        dispatch's own start / end timestamps (Profiler mode 4) -- the quantity rocprofv3 --kernel-trace --stats reports as that
+        kernel's duration (profiles/r5*_kernel_summary.*: `avg_us_working`), no correction.  Other kernels: marker brackets minus
+        the marker excess calibrated in the same pass."""
         if not launches or name not in ALGO_BYTES:
             return None
         raw_us = total_ms * 1e3 / launches
-        avg_s = (raw_us - marker_excess_us) * 1e-6
+        own_ts = name in SWEEP_KERNELS
+        avg_s = (raw_us if own_ts else raw_us - marker_excess_us) * 1e-6
         achieved = ALGO_BYTES[name] * n_local / avg_s / 1e9
         traffic, src = committed_pmc_traffic(name) if wl == "dam_break_1m" and not distributed else (None, None)
         issue = VALU_ISSUE.get(name)
-        # what bounds the launch: HBM when the bytes it really moves (the committed --pmc figure) leave at >= 85 % of what this device's
-        # copy kernel reaches in the same run; else VALU issue where the SQ counters say so (profiles/r4_sq_counters.txt)
         traffic_gbs = (traffic / avg_s / 1e9) if traffic else None
-        hbm_bound = bool(traffic_gbs and copy_gbs and traffic_gbs >= 0.85 * copy_gbs)
-        r = {"kernel": name, "bound": "hbm" if (hbm_bound or not issue) else "valu-issue", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        # What bounds the launch.  Decided where the counters mean HBM: on configs[3] (8.4 M particles; at 1 M the step's ~240 MB sit
+        # inside the 256 MB Infinity Cache and FETCH_SIZE counts its hits) -- committed traffic per launch / committed rocprofv3
+        # duration of the same kernel there, against the streaming rate of this device (this run's copy kernel, and the guide's
+        # 6.29 TB/s).  "hbm" from 85 % of it; else the sweep waits on its gathers' latency and on VALU issue, and the line says so.
+        t8, us8, src8 = committed_8m(name) if not distributed else (None, None, None)
+        gbs8 = (t8 / (us8 * 1e-6) / 1e9) if (t8 and us8) else None
+        copy_ref = max(copy_gbs, GUIDE_COPY_GBS) if copy_gbs else GUIDE_COPY_GBS
+        hbm_bound = bool(gbs8 and gbs8 >= 0.85 * copy_ref)
+        r = {"kernel": name, "bound": "hbm" if (hbm_bound or not issue) else "latency / valu-issue", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
              "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src, "traffic_GBs": traffic_gbs,
-             "traffic_frac_of_copy_kernel": (traffic_gbs / copy_gbs) if (traffic_gbs and copy_gbs) else None, "avg_us": avg_s * 1e6,
-             "avg_us_event_bracket": raw_us, "marker_excess_us": marker_excess_us,
+             "bound_evidence": {"config": "dam_break_8m (out of the Infinity Cache)", "traffic_bytes_per_launch": t8, "rocprofv3_avg_us": us8,
+                                "traffic_GBs": gbs8, "source": src8, "copy_kernel_GBs": copy_gbs, "guide_copy_GBs": GUIDE_COPY_GBS,
+                                "frac_of_streaming_rate": (gbs8 / copy_ref) if gbs8 else None, "rule": "hbm when >= 0.85"},
+             "avg_us": avg_s * 1e6, "timed_by": "dispatch timestamps (hipExtLaunchKernelGGL event pair)" if own_ts else "marker bracket - marker excess",
+             "marker_excess_us": None if own_ts else marker_excess_us,
              "rocprofv3_avg_us_committed": committed_pmc_avg(name) if wl == "dam_break_1m" and not distributed else None,
              "launches_timed": launches, "window": prof_window,
              "copy_kernel_GBs": copy_gbs, "frac_of_copy_kernel": (achieved / copy_gbs) if copy_gbs else None,
              "algorithmic_bytes_per_particle": ALGO_BYTES[name], "algorithmic_bytes_per_launch": ALGO_BYTES[name] * n_local}
+        if r["rocprofv3_avg_us_committed"]:
+            r["avg_us_vs_rocprofv3_committed"] = r["avg_us"] / r["rocprofv3_avg_us_committed"]
         if issue:
             # the sweep's VALU instruction issue by the SQ counters (profiles/r4_sq_counters.txt), priced with the measured
             # instruction classes (2 / 4 / 8 clocks per wave64 instruction, ~3 on the sweeps' mix; profiles/r3_valu_issue.md).
@@ -443,8 +480,10 @@ def main():
     total_prof_ms = sum(v[1] for v in prof_all.values()) or 1.0
     kernels = []
     for name, (launches, total_ms) in sorted(prof_all.items(), key=lambda kv: -kv[1][1]):
-        k = {"name": name, "launches_per_step": launches / max(args.profile_steps, 1), "avg_us_event_bracket": total_ms * 1e3 / max(launches, 1),
-             "avg_us": total_ms * 1e3 / max(launches, 1) - marker_excess_us, "time_share": total_ms / total_prof_ms}
+        own_ts = name in SWEEP_KERNELS
+        k = {"name": name, "launches_per_step": launches / max(args.profile_steps, 1),
+             "avg_us": total_ms * 1e3 / max(launches, 1) - (0.0 if own_ts else marker_excess_us), "timed_by": "dispatch" if own_ts else "bracket - excess",
+             "time_share": total_ms / total_prof_ms}
         r = roof(name, *prof_work.get(name, (launches, total_ms)))
         if r:
             k["achieved_GBs"] = r["achieved"]
@@ -455,12 +494,14 @@ def main():
     dominant = max((n for n in prof_work if n in ALGO_BYTES), key=lambda n: prof_work[n][1], default=None)
     roofline = roof(dominant, *prof_work[dominant]) if dominant else None
     roofline_density = roof("density", *prof_work["density"]) if "density" in prof_work else None
-    timing_note = (f"HIP events on the library's stream around every kernel, over an instrumented REPEAT of the "
-                   f"timed window (fresh context, same {args.warmup} warm-up steps, same {args.profile_steps} steps; events perturb dispatch, so "
-                   f"the timed region itself is uninstrumented); avg_us = mean bracket of the launches that did work minus the marker excess "
-                   f"({marker_excess_us:.2f} us, calibrated in the same pass with a kernel of known duration in the step's queue); dominant kernel = "
+    timing_note = (f"HIP events on the library's stream, over an instrumented REPEAT of the timed window (fresh context, same {args.warmup} warm-up "
+                   f"steps, same {args.profile_steps} steps; events perturb dispatch, so the timed region itself is uninstrumented); a sweep's avg_us = mean over "
+                   f"its working launches of the dispatch's own start-to-end timestamps (the event pair hipExtLaunchKernelGGL attaches to the launch: "
+                   f"the quantity rocprofv3 reports; the 10 us calibration kernel reads "
+                   f"{(prof_window or {}).get('calibration_spin10_dispatch_us') or float('nan'):.2f} us that way, rocprofv3 {SPIN10_ROCPROF_US}); dominant kernel = "
                    f"largest total over that window; `traffic` is not measured in this run: it is the FETCH_SIZE x2 + WRITE_SIZE figure of the rocprofv3 "
-                   f"--pmc passes summarised in `traffic_source`")
+                   f"--pmc passes summarised in `traffic_source`; `bound` is decided on configs[3]'s committed traffic and duration (out of the Infinity "
+                   f"Cache) against the streaming rate")
     for r in (roofline, roofline_density):
         if r:
             r["timing"] = timing_note
