@@ -492,6 +492,10 @@ static int alloc_particle_buffers(sph_ctx* c)
                     &c->mrho, &c->pt0, &c->pt1};
     for (auto b : f1) HIPCHK(c, b->ensure(n * sizeof(float)));
     HIPCHK(c, c->lam_grad.ensure(n * sizeof(float2)));
+    if (c->exact) {   // the boundary handler's per-SDF entries (MathExact, sph_device.h)
+        HIPCHK(c, c->wall_pl.ensure(n * sizeof(float2) * SPH_MAX_PLANES));
+        HIPCHK(c, c->wall_cnt.ensure(n));
+    }
     HIPCHK(c, c->lam_prev.ensure(n * sizeof(float)));
     HIPCHK(c, c->omega.ensure(n * sizeof(float)));
     HIPCHK(c, c->pacc.ensure(n * sizeof(float4)));   // {x, y, a^p}
@@ -652,7 +656,7 @@ extern "C" void sph_destroy(sph_ctx* c)
     DevBuf* all[] = {&c->pm[0], &c->pm[1], &c->vel[0], &c->vel[1], &c->orig[0], &c->orig[1], &c->lvl[0], &c->lvl[1], &c->lvlold[0],
                      &c->lvlold[1], &c->vel_tmp, &c->key[0], &c->key[1], &c->val[0], &c->val[1], &c->sort_scratch, &c->cxy, &c->cell_start,
                      &c->cs_scratch, &c->hdr_ahead_partials, &c->h2n[0], &c->h2n[1], &c->lam_prev, &c->nl, &c->nlx, &c->tile_raw, &c->tile_h, &c->tile_h_ext, &c->lvl_changed_d, &c->lvl_tmp, &c->lvl_nrm, &c->lvl_state, &c->lvl_when, &c->lvl_mark, &c->lvl_queue, &c->nloff, &c->nlh, &c->flag_surface,
-                     &c->flag_insufficient, &c->con_thr, &c->con_consumed, &c->con_h, &c->flag_reduced, &c->szc[0], &c->szc[1], &c->omega, &c->stash, &c->nl_ext, &c->nlx_ext, &c->nl_ok, &c->mrho, &c->pt0, &c->pt1, &c->prec0, &c->prec1, &c->rho, &c->lam_sum, &c->lam_grad, &c->constf, &c->aii, &c->src, &c->p0, &c->p1, &c->pacc, &c->dens_err,
+                     &c->flag_insufficient, &c->con_thr, &c->con_consumed, &c->con_h, &c->flag_reduced, &c->szc[0], &c->szc[1], &c->omega, &c->stash, &c->nl_ext, &c->nlx_ext, &c->nl_ok, &c->mrho, &c->pt0, &c->pt1, &c->prec0, &c->prec1, &c->rho, &c->lam_sum, &c->lam_grad, &c->wall_pl, &c->wall_cnt, &c->constf, &c->aii, &c->src, &c->p0, &c->p1, &c->pacc, &c->dens_err,
                      &c->stat, &c->ncount, &c->planes_d, &c->lam_lut, &c->dlam_lut, &c->hdr_partials, &c->hdr_out, &c->ctrl, &c->status,
                      &c->n_tiles, &c->red_partials, &c->scratch, &c->split_patterns, &c->akey[0], &c->akey[1], &c->aval[0], &c->aval[1], &c->acxy, &c->acell_start, &c->pm2,
                      &c->atile_raw, &c->atile_h, &c->inc_head, &c->inc_next, &c->inc_bsum, &c->inc_movers};

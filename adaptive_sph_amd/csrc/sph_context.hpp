@@ -105,6 +105,7 @@ struct sph_ctx {
     DevBuf key[2], val[2], sort_scratch, cxy, cell_start, cs_scratch, nl, nl_ok, mrho, pt0, pt1, prec0, prec1;
     bool uniform_h = false;
     float h_uniform = 0.f;
+    DevBuf wall_pl, wall_cnt;   // EXACT policy only (MathExact, sph_device.h)
     DevBuf rho, lam_sum, lam_grad, constf, aii, src, p0, p1, pacc, dens_err, stat, ncount;
     DevBuf planes_d, lam_lut, dlam_lut, hdr_partials, hdr_out, ctrl, status, n_tiles, red_partials, scratch;
     // mapped pinned host memory: written by kernels directly (no D2H copy launches)

@@ -148,6 +148,29 @@ __device__ __forceinline__ float cubic_unnorm_deriv(float q)
 struct MathExact {
     static constexpr bool EXACT = true, UNIFORM = false;
     float h;  // unused
+    // The boundary handler's PER-SDF entries (BoundaryWinchenbach2020::lambda: Vec<Vec<(FT, VF)>>, boundary_winchenbach2020.rs:27): the
+    // FAST policies fold a particle's entries into sum(lambda), sum(grad lambda) once (every use is linear in them); f (g1 + g2) and
+    // f g1 + f g2 differ in the last bit for a particle in a CORNER of the box (two entries), so the EXACT policy keeps the gradient
+    // entries apart -- entry k of particle i at wall_pl[k wall_n + i], wall_cnt[i] of them, written by the density sweep -- and adds
+    // them up where and how the reference does (tests/test_gpu_bitexact.py).
+    float2* wall_pl = nullptr;
+    uint8_t* wall_cnt = nullptr;
+    uint32_t wall_n = 0;
+    __device__ __forceinline__ uint32_t wall_count(uint32_t i) const { return wall_cnt[i]; }
+    __device__ __forceinline__ float2 wall_entry(uint32_t i, uint32_t k) const { return wall_pl[(size_t)k * wall_n + i]; }
+    // calculate_divergence_iisph's boundary part (boundary_winchenbach2020.rs:196-223), quantity_b = 0
+    __device__ __forceinline__ float wall_divergence(uint32_t i, float qx, float qy, float rho_i, float rho_b, bool by_volume) const
+    {
+        float r = 0.f;
+        const uint32_t cnt = wall_cnt[i];
+        for (uint32_t k = 0; k < cnt; k++) {
+            const float2 g = wall_entry(i, k);
+            const float dot = (0.f - qx) * g.x + (0.f - qy) * g.y;
+            if (by_volume) r += dot;
+            else r += rho_b / rho_i * dot;
+        }
+        return r;
+    }
     __device__ __forceinline__ float w(float r2, float hij) const
     {
         float r = sqrtf(r2);

@@ -83,6 +83,7 @@ int wait_all(Group& G);
 // given -- or an error if a slab context has none; the loopback transport of sph_group_step; what a failing rank tells the others
 int comm_for_rank(sph_ctx* c, Comm** out);
 Comm* comm_loopback();
+void comm_describe(sph_ctx* c, uint32_t* transport, uint32_t* ranks);   // sph_dist_stats::transport / ::comm_ranks
 void comm_abandon(sph_ctx* c);
 
 // ---- the members of a group step and what the step driver and the slab maintenance (sph_slabs.hip) share ----

@@ -187,6 +187,8 @@ struct SweepArgs {
     float* rho;
     float* lam_sum;
     float2* lam_grad;
+    float2* wall_pl = nullptr;    // EXACT policy: the boundary handler's per-SDF gradient entries and their count (MathExact, sph_device.h)
+    uint8_t* wall_cnt = nullptr;
     float* constf;
     float* aii;
     float* src;

@@ -49,6 +49,8 @@ SweepArgs make_args(sph_ctx* c, const StepP& sp)
     a.rho = c->rho.as<float>();
     a.lam_sum = c->lam_sum.as<float>();
     a.lam_grad = c->lam_grad.as<float2>();
+    a.wall_pl = c->wall_pl.as<float2>();
+    a.wall_cnt = c->wall_cnt.as<uint8_t>();
     a.constf = c->constf.as<float>();
     a.aii = c->aii.as<float>();
     a.src = c->src.as<float>();
@@ -1990,6 +1992,7 @@ extern "C" int sph_dist_get_stats(sph_ctx* c, sph_dist_stats* out, int reset)
     out->n_halo[1] = d.n_halo[1];
     out->n_ghost[0] = d.n_ghost[0];
     out->n_ghost[1] = d.n_ghost[1];
+    comm_describe(c, &out->transport, &out->comm_ranks);
     if (reset) {
         d.stat_exchanges = d.stat_bytes_sent = d.stat_bytes_recv = d.stat_allreduces = 0;
         d.stat_step0 = c->step_number;

@@ -996,6 +996,7 @@ struct OpDensity {
         const float x = Ai.x, y = Ai.y;
         const float sr_i = Ai.w * 2.f;
         float ls = 0.f, gxs = 0.f, gys = 0.f;
+        uint32_t n_entries = 0;
         for (int k = 0; k < sp.n_planes; k++) {
             float d = sdf_probe(planes, k, x, y) / sr_i;
             if (!(d < 1.f)) continue;
@@ -1030,7 +1031,12 @@ struct OpDensity {
             ls += lambda * penalty;
             gxs += gx / sr_i * s;
             gys += gy / sr_i * s;
+            if constexpr (MathT::EXACT) {   // the entry itself (boundary_winchenbach2020.rs:139-149)
+                m.wall_pl[(size_t)n_entries * m.wall_n + i] = make_float2(gx / sr_i * s, gy / sr_i * s);
+                n_entries++;
+            }
         }
+        if constexpr (MathT::EXACT) m.wall_cnt[i] = (uint8_t)n_entries;
         a.lam = ls;
         a.wall = ls != 0.f || gxs != 0.f || gys != 0.f;
         lam_sum[i] = ls;
@@ -1165,7 +1171,29 @@ struct OpAiiConst {
         const float mi = Ai.z, rho_i = rho[i], rho_b = sp.rest_density;
         const float rho_i_sq = rho_i * rho_i;
         float v;
-        if (sp.opdisc == SPH_OP_WINCHENBACH2020) {
+        if constexpr (MathT::EXACT) {   // the boundary sums entry by entry, as iisph_aii adds them (boundary_winchenbach2020.rs:236-304)
+            const float coeff = sp.opdisc == SPH_OP_SYMMETRIC_GRADIENT ? 1.f : 0.f;
+            const float f = rho_b * (1.f / (rho_i * rho_i) + coeff / (rho_b * rho_b));
+            float sgx = 0.f, sgy = 0.f, rgx = 0.f, rgy = 0.f, sbx = 0.f, sby = 0.f;
+            const uint32_t cnt = wall ? m.wall_count(i) : 0u;
+            for (uint32_t k = 0; k < cnt; k++) {
+                const float2 g = m.wall_entry(i, k);
+                sgx += g.x;
+                sgy += g.y;
+                rgx += rho_b * g.x;
+                rgy += rho_b * g.y;
+                sbx += f * g.x;
+                sby += f * g.y;
+            }
+            const float lx = a.ax / rho_i_sq + sbx, ly = a.ay / rho_i_sq + sby;
+            if (sp.opdisc == SPH_OP_WINCHENBACH2020) {
+                const float rx = a.bx + sgx, ry = a.by + sgy;
+                v = (lx * rx + ly * ry) + (mi * a.a2 / rho_i_sq);
+            } else {
+                const float rx = a.ax / rho_i + rgx / rho_i, ry = a.ay / rho_i + rgy / rho_i;
+                v = (lx * rx + ly * ry) + (mi * a.a2) / (rho_i * rho_i * rho_i);
+            }
+        } else if (sp.opdisc == SPH_OP_WINCHENBACH2020) {
             float f = rho_b * (1.f / (rho_i * rho_i) + 0.f / (rho_b * rho_b));
             float lx = a.ax / rho_i_sq + f * gl.x, ly = a.ay / rho_i_sq + f * gl.y;
             float rx = a.bx + gl.x, ry = a.by + gl.y;
@@ -1186,7 +1214,17 @@ struct OpAiiConst {
             const float pti = 1.f / (rho_i * rho_i);
             const float p_ib = sp.opdisc == SPH_OP_SYMMETRIC_GRADIENT ? 1.f : 0.f;
             const float fb = -rho_b * (1.f / (rho_i * rho_i) + p_ib / (rho_b * rho_b));
-            ap_unit[i] = make_float2(-(pti * a.ax) + fb * gl.x, -(pti * a.ay) + fb * gl.y);
+            float wx = fb * gl.x, wy = fb * gl.y;
+            if constexpr (MathT::EXACT) {
+                wx = wy = 0.f;
+                const uint32_t cnt = wall ? m.wall_count(i) : 0u;
+                for (uint32_t k = 0; k < cnt; k++) {
+                    const float2 g = m.wall_entry(i, k);
+                    wx += fb * g.x;
+                    wy += fb * g.y;
+                }
+            }
+            ap_unit[i] = make_float2(-(pti * a.ax) + wx, -(pti * a.ay) + wy);
         }
         return wall;
     }
@@ -1438,7 +1476,8 @@ struct OpSource {
             float2 gl = make_float2(0.f, 0.f);
             if (wall) gl = lam_grad[i];
             const float bdot = (0.f - a.qx) * gl.x + (0.f - a.qy) * gl.y;
-            const float bdiv = sp.opdisc == SPH_OP_WINCHENBACH2020 ? bdot : rho_b / rho_i * bdot;
+            float bdiv = sp.opdisc == SPH_OP_WINCHENBACH2020 ? bdot : rho_b / rho_i * bdot;
+            if constexpr (MathT::EXACT) bdiv = wall ? m.wall_divergence(i, a.qx, a.qy, rho_i, rho_b, sp.opdisc == SPH_OP_WINCHENBACH2020) : 0.f;
             const float vdiv = a.sum + (sp.n_planes ? bdiv : 0.f);
             if (kind == 0) s = -vdiv / dt;
             else if (OMEGA) {
@@ -1748,6 +1787,15 @@ struct OpPressureAccel {
             const float2 gl = lam_grad[i];
             bx = f * gl.x;
             by = f * gl.y;
+            if constexpr (MathT::EXACT) {   // iisph_boundary_pressure_accel entry by entry (boundary_winchenbach2020.rs:164-194)
+                bx = by = 0.f;
+                const uint32_t cnt = m.wall_count(i);
+                for (uint32_t k = 0; k < cnt; k++) {
+                    const float2 g = m.wall_entry(i, k);
+                    bx += f * g.x;
+                    by += f * g.y;
+                }
+            }
         }
         pacc[i] = make_float4(Ai.x, Ai.y, a.ax + bx, a.ay + by);
         return wall;
@@ -2002,6 +2050,7 @@ struct OpJacobi {
             const float2 gl = lam_grad[i];
             const float bdot = (0.f - a.qx) * gl.x + (0.f - a.qy) * gl.y;
             bdiv = sp.opdisc == SPH_OP_WINCHENBACH2020 ? bdot : rho_b / rho_i * bdot;
+            if constexpr (MathT::EXACT) bdiv = m.wall_divergence(i, a.qx, a.qy, rho_i, rho_b, sp.opdisc == SPH_OP_WINCHENBACH2020);
         }
         const float a_p = a.sum + bdiv;
         const float s = a.src_i;
@@ -2131,6 +2180,7 @@ struct OpCheckAii {
             const float2 gl = lam_grad[i];
             const float bdot = (0.f - a.qx) * gl.x + (0.f - a.qy) * gl.y;
             bdiv = sp.opdisc == SPH_OP_WINCHENBACH2020 ? bdot : sp.rest_density / a.rho_i * bdot;
+            if constexpr (MathT::EXACT) bdiv = m.wall_divergence(i, a.qx, a.qy, a.rho_i, sp.rest_density, sp.opdisc == SPH_OP_WINCHENBACH2020);
         }
         const float real = a.sum + bdiv;
         const float v = aii[i];
@@ -2748,6 +2798,7 @@ __global__ __launch_bounds__(256) void k_fill_stash(uint32_t n, const float* __r
 // the k = 2 lists of the step, evaluated at the ADVECTED positions (the lists are those of the start of the step).
 struct NBSmooth {
     float x, y, mr, dist;
+    float m, rho;   // EXACT policy only: the reference's `dist * mass[j] / density[j] * w_ij` is ((dist m) / rho) w, not dist (m / rho) w
 };
 // EXT (level_estimation_after_advection with the extended range, simulation.rs:2678-2722): `self.neighs` then holds the
 // extended lists of the ADVECTED positions -- pm = pm_new = advected, pm_cell = pre-step (cells), lists = nl_ext / nlx_ext.
@@ -2768,6 +2819,7 @@ struct OpLevelSmoothT {
     float* __restrict__ level_old;
     DeviceStatus* status;
     float max_surface_distance;
+    const float* __restrict__ rho;       // (EXACT policy: see NBSmooth)
     struct Acc {
         float x, y, level, weight;
     };
@@ -2788,7 +2840,8 @@ struct OpLevelSmoothT {
         const float4 q = pm_new[j];
         const float lj = level_in[j];
         const float dist = isnan(lj) ? -max_surface_distance : fmaxf(lj, -max_surface_distance);
-        return NB{q.x, q.y, mrho[j], dist};
+        if constexpr (MathT::EXACT) return NB{q.x, q.y, mrho[j], dist, pm[j].z, rho[j]};
+        return NB{q.x, q.y, mrho[j], dist, 0.f, 0.f};
     }
     __device__ void begin(Acc& a, uint32_t i, float4) const
     {
@@ -2801,8 +2854,13 @@ struct OpLevelSmoothT {
     {
         const float dx = a.x - Bj.x, dy = a.y - Bj.y;
         const float w = m.w(dx * dx + dy * dy, hij);
-        a.level += Bj.dist * Bj.mr * w;
-        a.weight += Bj.mr * w;
+        if constexpr (MathT::EXACT) {
+            a.level += Bj.dist * Bj.m / Bj.rho * w;
+            a.weight += Bj.m / Bj.rho * w;
+        } else {
+            a.level += Bj.dist * Bj.mr * w;
+            a.weight += Bj.mr * w;
+        }
     }
     __device__ bool finish(Acc& a, uint32_t i, float4, bool) const
     {
@@ -3225,10 +3283,20 @@ static MathUniform uniform_math(float h)
     return m;
 }
 
+static MathExact exact_math(const SweepArgs& a)
+{
+    MathExact m;
+    m.h = 0.f;
+    m.wall_pl = a.wall_pl;
+    m.wall_cnt = a.wall_cnt;
+    m.wall_n = a.n;
+    return m;
+}
+
 // math mode dispatch: EXACT (diagnostic) / UNIFORM (all h identical) / FAST
 #define SPH_DISPATCH(OPNAME, BUILD, ...)                                                   \
     if (a.exact) {                                                                         \
-        OPNAME<MathExact> op{MathExact{0.f}, __VA_ARGS__};                                 \
+        OPNAME<MathExact> op{exact_math(a), __VA_ARGS__};                                  \
         launch_sweep<OPNAME<MathExact>, BUILD>(s, a, op);                                  \
     } else if (a.uniform_h) {                                                              \
         OPNAME<MathUniform> op{uniform_math(a.h_uniform), __VA_ARGS__};                    \
@@ -3302,7 +3370,7 @@ static void launch_fused_aii_np(hipStream_t s, const SweepArgs& a, const M& math
 void launch_aii_const_non_pressure(hipStream_t s, Profiler* prof, const SweepArgs& a)
 {
     ProfScope ps(prof, "aii_nonpressure", s, true);
-    if (a.exact) launch_fused_aii_np(s, a, MathExact{0.f});
+    if (a.exact) launch_fused_aii_np(s, a, exact_math(a));
     else if (a.uniform_h) launch_fused_aii_np(s, a, uniform_math(a.h_uniform));
     else launch_fused_aii_np(s, a, MathFast{0.f});
 }
@@ -3593,7 +3661,7 @@ void launch_level_propagate(hipStream_t s, Profiler* prof, const SweepArgs& a, c
 {
     ProfScope ps(prof, "level_propagate", s, true);
     if (l.fmap && a.n) {   // one context: the compacted frontier
-        if (a.exact) launch_level_frontier(s, a, l, MathExact{0.f}, t, changed);
+        if (a.exact) launch_level_frontier(s, a, l, exact_math(a), t, changed);
         else if (a.uniform_h) launch_level_frontier(s, a, l, uniform_math(a.h_uniform), t, changed);
         else launch_level_frontier(s, a, l, MathFast{0.f}, t, changed);
         return;
@@ -3645,10 +3713,10 @@ void launch_level_smooth(hipStream_t s, Profiler* prof, const SweepArgs& a, cons
 {
     ProfScope ps(prof, "level_smooth", s, true);
     if (l.pm_cell && !l.replay_step_lists) {   // after advection, extended lists of the advected positions
-        SPH_DISPATCH(OpLevelSmoothExt, false, pm_new, l.pm_cell, l.k, pm_new, a.orig, a.mrho, in, out, l.level_old, a.status, l.max_surface_distance)
+        SPH_DISPATCH(OpLevelSmoothExt, false, pm_new, l.pm_cell, l.k, pm_new, a.orig, a.mrho, in, out, l.level_old, a.status, l.max_surface_distance, a.rho)
         return;
     }
-    SPH_DISPATCH(OpLevelSmooth, false, a.pm, nullptr, 2.f, pm_new, a.orig, a.mrho, in, out, l.level_old, a.status, l.max_surface_distance)
+    SPH_DISPATCH(OpLevelSmooth, false, a.pm, nullptr, 2.f, pm_new, a.orig, a.mrho, in, out, l.level_old, a.status, l.max_surface_distance, a.rho)
 }
 
 void launch_classify(hipStream_t s, Profiler* prof, uint32_t n, const float4* pm, const float* level, uint8_t* size_class, const uint8_t* owned,

@@ -1173,14 +1173,25 @@ struct IpcState {
     uint64_t bytes_per_side = 0;
     uint32_t seq[2] = {0, 0};                 // messages exchanged with the [left, right] neighbour
     uint32_t tot_n[2] = {0, 0};               // all-reduces of the totals of slot 0 / 1
+    uint64_t timeout_ticks = 2000000000ull;   // a wait gives up after 20 s of the 100 MHz clock (SPH_IPC_TIMEOUT_MS)
     static uint8_t* inbox(uint8_t* box, uint64_t per_side, int side, uint32_t parity) { return box + IpcBox::header_bytes() + ((size_t)2 * side + parity) * per_side; }
 };
 
 __device__ __forceinline__ void ipc_store_release(uint32_t* flag, uint32_t v) { __hip_atomic_store(flag, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
-__device__ __forceinline__ void ipc_wait(const uint32_t* flag, uint32_t want)
+// Bounded (advisor r4): a peer that failed before its push -- a device fault, the SPH_ERR_CAPACITY exit of round() -- must not leave
+// this GPU spinning inside a kernel nobody can stop.  After `timeout_ticks` of the constant 100 MHz clock the wait gives up and raises
+// the context's sticky status word (SPH_ERR_DEVICE: the step's status check turns it into the error the other transports report for a
+// collective a rank never entered); the kernels behind it then read a stale inbox, and the step's result is discarded with the error.
+__device__ __forceinline__ bool ipc_wait(const uint32_t* flag, uint32_t want, uint64_t timeout_ticks)
 {
     // (sequence numbers only grow; a 32-bit wrap is 4 G exchanges away)
-    while ((int32_t)(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - want) < 0) __builtin_amdgcn_s_sleep(2);
+    const uint64_t t0 = wall_clock64();
+    uint32_t spins = 0;
+    while ((int32_t)(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - want) < 0) {
+        __builtin_amdgcn_s_sleep(2);
+        if ((++spins & 0x3ffu) == 0u && wall_clock64() - t0 > timeout_ticks) return false;
+    }
+    return true;
 }
 struct IpcPush {
     const uint4* src[2];       // staging of the message to the [left, right] neighbour (16-byte granules) or nullptr
@@ -1223,12 +1234,16 @@ struct IpcWait {
     const double* table;       // my table of this slot and parity
     double* tot;               // in: my row; out: the sum over the ranks in rank order
     int nr, self;
+    DeviceStatus* status;      // raised when a flag does not arrive within timeout_ticks (100 MHz)
+    uint64_t timeout_ticks;
 };
 __global__ __launch_bounds__(64) void k_ipc_wait(IpcWait j)
 {
     const uint32_t t = threadIdx.x;
-    if (t < 2 && j.seq[t]) ipc_wait(j.flag[t], j.seq[t]);
-    if (j.tot_flag && t >= 2 && t < 2u + (uint32_t)j.nr && (int)(t - 2u) != j.self) ipc_wait(j.tot_flag + (t - 2u), j.tot_seq);
+    bool ok = true;
+    if (t < 2 && j.seq[t]) ok = ipc_wait(j.flag[t], j.seq[t], j.timeout_ticks);
+    if (j.tot_flag && t >= 2 && t < 2u + (uint32_t)j.nr && (int)(t - 2u) != j.self) ok = ipc_wait(j.tot_flag + (t - 2u), j.tot_seq, j.timeout_ticks);
+    if (!ok && atomicCAS(&j.status->error, 0u, (uint32_t)SPH_ERR_DEVICE) == 0u) j.status->info = 0x1bc00000u | t;   // (info: which waiter gave up)
     __syncthreads();
     if (j.tot_flag && t < 6) {
         double s = 0.0;
@@ -1309,6 +1324,8 @@ struct IpcComm : ShmComm {
             ProfScope p1(&c->prof, "ipc_push", c->stream);
             hipLaunchKernelGGL(k_ipc_push, dim3(1), dim3(1024), 0, c->stream, ps);
         }
+        w.status = c->status.as<DeviceStatus>();
+        w.timeout_ticks = I->timeout_ticks;
         ProfScope p2(&c->prof, "ipc_wait", c->stream);
         hipLaunchKernelGGL(k_ipc_wait, dim3(1), dim3(64), 0, c->stream, w);
         return SPH_OK;
@@ -1330,9 +1347,13 @@ extern "C" int sph_comm_ipc_export(sph_ctx* c, uint64_t bytes_per_side, uint8_t 
     IpcState* I = new IpcState();
     I->bytes_per_side = (bytes_per_side + 255) & ~(uint64_t)255;
     const size_t total = IpcBox::size_for(I->bytes_per_side);
-    if (hipMalloc((void**)&I->mine, total) != hipSuccess) {
+    if (const char* e = getenv("SPH_IPC_TIMEOUT_MS")) I->timeout_ticks = (uint64_t)std::max(1, atoi(e)) * 100000ull;
+    // FINE-GRAINED device memory (advisor r4): another GPU writes this box -- inbox, flags, totals -- while kernels of this one spin on
+    // it and then read it in place.  HIP guarantees visibility of a peer's writes DURING a kernel only for fine-grained allocations
+    // (a coarse-grained hipMalloc may serve the poll from this GPU's L2, which remote xGMI writes bypass).
+    if (hipExtMallocWithFlags((void**)&I->mine, total, hipDeviceMallocFinegrained) != hipSuccess) {
         delete I;
-        return c->fail(SPH_ERR_DEVICE, "peer-mapped transport: out of device memory (%zu bytes)", total);
+        return c->fail(SPH_ERR_DEVICE, "peer-mapped transport: no fine-grained device memory (%zu bytes)", total);
     }
     HIPCHK(c, hipMemset(I->mine, 0, IpcBox::header_bytes()));
     HIPCHK(c, hipDeviceSynchronize());
@@ -1386,6 +1407,26 @@ int comm_for_rank(sph_ctx* c, Comm** out)
     else if (c->dist.nccl) *out = &g_rccl;
     else return c->fail(SPH_ERR_INVALID_ARGUMENT, "slab context without a communicator: call sph_comm_init or use sph_group_step");
     return SPH_OK;
+}
+void comm_describe(sph_ctx* c, uint32_t* transport, uint32_t* ranks)
+{
+    *transport = 0;
+    *ranks = 0;
+    if (!c->dist.on) return;
+    *transport = 1;
+    *ranks = (uint32_t)c->dist.nranks;
+    if (c->dist.tgroup) *transport = 3;
+    else if (c->dist.ipc && ((IpcState*)c->dist.ipc)->peer[c->dist.rank]) {
+        *transport = 5;
+        uint32_t mapped = 0;
+        for (int r = 0; r < SHM_MAX_RANKS; r++) mapped += ((IpcState*)c->dist.ipc)->peer[r] != nullptr;
+        *ranks = mapped;
+    } else if (c->dist.shm) *transport = 4;
+    else if (c->dist.nccl) {
+        *transport = 2;
+        int cnt = 0;
+        *ranks = ncclCommCount((ncclComm_t)c->dist.nccl, &cnt) == ncclSuccess ? (uint32_t)cnt : 0u;
+    }
 }
 void comm_abandon(sph_ctx* c)
 {

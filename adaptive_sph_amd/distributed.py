@@ -91,12 +91,28 @@ def make_slab_context(lib: ffi.SphLibrary, pos, mass, vel, planes, rank: int, wo
             ctx.comm_init_shm(name[0], rank, world, per_side, False)
         dist.barrier()
         if transport == "ipc":
-            # every rank exports its device inbox, the launcher all-gathers the 64-byte handles, every rank maps the others'
-            mine = ctx.comm_ipc_export(per_side)
+            # every rank exports its device inbox, the launcher all-gathers the 64-byte handles, every rank maps the others'.  A rank
+            # whose export or mapping fails tells the others THROUGH the gather (None / a flag) instead of leaving them in it: every rank
+            # then raises the same error
+            try:
+                mine_h, err = ctx.comm_ipc_export(per_side), None
+            except ffi.SphError as e:
+                mine_h, err = None, str(e)
             handles = [None] * world
-            dist.all_gather_object(handles, mine)
-            ctx.comm_init_ipc(b"".join(handles), world)
-            dist.barrier()
+            dist.all_gather_object(handles, (mine_h, err))
+            bad = [(r, h[1]) for r, h in enumerate(handles) if h[0] is None]
+            if bad:
+                raise ffi.SphError(2, f"peer-mapped transport: rank {bad[0][0]} could not export its inbox: {bad[0][1]}")
+            try:
+                ctx.comm_init_ipc(b"".join(h[0] for h in handles), world)
+                err = None
+            except ffi.SphError as e:
+                err = str(e)
+            errs = [None] * world
+            dist.all_gather_object(errs, err)
+            bad = [(r, e) for r, e in enumerate(errs) if e]
+            if bad:
+                raise ffi.SphError(2, f"peer-mapped transport: rank {bad[0][0]} could not map its peers' inboxes: {bad[0][1]}")
         return ctx
     # RCCL unique id: created on rank 0, broadcast through the launcher's process group
     buf = torch.zeros(128, dtype=torch.uint8)

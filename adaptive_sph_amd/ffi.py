@@ -131,7 +131,10 @@ MERGE_PARTNER_DELETE = 0xFFFFFFFE      # adaptivity/mod.rs:30
 class SphDistStats(C.Structure):
     _fields_ = [("steps", C.c_uint64), ("exchanges", C.c_uint64), ("bytes_sent", C.c_uint64), ("bytes_received", C.c_uint64),
                 ("allreduces", C.c_uint64), ("host_waits", C.c_uint64), ("n_owned", C.c_uint64), ("n_halo", C.c_uint32 * 2),
-                ("n_ghost", C.c_uint32 * 2)]
+                ("n_ghost", C.c_uint32 * 2), ("transport", C.c_uint32), ("comm_ranks", C.c_uint32)]
+
+
+TRANSPORT_NAMES = {0: "none", 1: "loopback", 2: "rccl", 3: "threads", 4: "shm", 5: "ipc"}
 
 
 class SphListForms(C.Structure):
@@ -462,7 +465,8 @@ class Context:
         self._check(self.lib.dist_get_stats(self.handle, C.byref(st), 1 if reset else 0))
         return {"steps": int(st.steps), "exchanges": int(st.exchanges), "bytes_sent": int(st.bytes_sent), "bytes_received": int(st.bytes_received),
                 "allreduces": int(st.allreduces), "host_waits": int(st.host_waits), "n_owned": int(st.n_owned),
-                "n_halo": [int(st.n_halo[0]), int(st.n_halo[1])], "n_ghost": [int(st.n_ghost[0]), int(st.n_ghost[1])]}
+                "n_halo": [int(st.n_halo[0]), int(st.n_halo[1])], "n_ghost": [int(st.n_ghost[0]), int(st.n_ghost[1])],
+                "transport": TRANSPORT_NAMES.get(int(st.transport), str(int(st.transport))), "comm_ranks": int(st.comm_ranks)}
 
     def comm_init_threads(self, group, rank: int, n_ranks: int):
         """Thread transport (sph_ffi.h): `group` from SphLibrary.thread_group_create; every rank then steps on a thread of its own."""

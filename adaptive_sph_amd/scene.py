@@ -148,16 +148,18 @@ def dam_break_8m() -> SceneConfig:
     """configs[3]: 8192 x 1024 = 8 388 608 particles: configs[1]'s column eight times as wide (same spacing, same height, same
     parameters), in a box 16 x 2.  (Until round 4 this was a 2896 x 2896 column at spacing 1/2048 with max_dt = 0.001: that scene
     DIVERGES at step 3 -- largest speed 6 -> 74 -> 566 -> 1580 -> 3800 m/s, dt 1e-7, particles below the floor -- in the CPU oracle
-    identically, digit for digit, and for max_dt = 0.0005 and 0.00025 as well: the relaxed Jacobi solves stop on AVERAGE errors long
-    before 2896 layers have seen the floor.  A benchmark of a blown-up state measures nothing, so the scene went.)"""
+    identically: the relaxed Jacobi solves stop on AVERAGE errors long before 2896 layers have seen the floor.  Round 4 wrote "and for
+    max_dt = 0.0005 and 0.00025 as well"; the record committed in round 5 (profiles/r5_config3_divergence.md) shows 0.0005 diverging
+    ten times milder and 0.00025 NOT diverging -- the surveyed geometry is back as `dam_break_8m_spec` with that value.)"""
     return dam_break_weak(8)
 
 
 def dam_break_8m_spec() -> SceneConfig:
     """SURVEY.md section 8d config 4 AS WRITTEN: box 4 x 2, one block pos [-1.9995, -0.9995], size [1.4143, 1.4143], spacing 1/2048
-    -> 2896 x 2896 = 8 386 816 particles.  Kept under its own name since configs[3] became `dam_break_8m` (round 4): this column
-    blows up at step 3 on the reference's algorithm -- scripts/gpu_config3_divergence.py steps it on the CPU oracle and on the device
-    for max_dt 0.001 / 0.0005 / 0.00025, output in profiles/r5_config3_divergence.md."""
+    -> 2896 x 2896 = 8 386 816 particles.  Kept under its own name since configs[3] became `dam_break_8m` (round 4).  With max_dt 0.001
+    this column blows up at step 3 on the reference's algorithm (3 800 m/s, dt 1e-7), with 0.0005 at step 6 (107 m/s); with 0.00025
+    it behaves like configs[1] (8-10 m/s, density 1.7): scripts/gpu_config3_divergence.py steps it on the CPU oracle and on the device
+    for the three values, output in profiles/r5_config3_divergence.md.  workloads.py runs it with 0.00025 (bench.py: strong_8m_spec)."""
     return SceneConfig(SceneBoundary("box", 4.0, 2.0),
                        [SceneFluidBlock([-1.9995, -0.9995], [1.4143, 1.4143], 0.00048828125, 0.93, [0.0, 0.0])])
 

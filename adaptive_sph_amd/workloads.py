@@ -65,8 +65,8 @@ WORKLOADS = {
     "dam_break_1m": (sc.dam_break_1m, dam_break_params, "2D dam-break, 1024x1024 = 1 048 576 uniform-h particles, HybridDFSPH"),
     "dam_break_1m_adaptive": (sc.dam_break_1m_adaptive, dam_break_params, "2D dam-break, 1 000 960 particles, 4:1 radius ratio"),
     "dam_break_8m": (sc.dam_break_8m, dam_break_params, "2D dam-break, 8192x1024 = 8 388 608 particles (configs[1]'s column eight times as wide)"),
-    "dam_break_8m_spec": (sc.dam_break_8m_spec, lambda **kw: dam_break_params(**dict(dict(max_dt=0.001), **kw)),
-                          "SURVEY 8d config 4 as written: 2896x2896 = 8 386 816 particles at spacing 1/2048, box 4x2 (diverges at step 3: profiles/r5_config3_divergence.md)"),
+    "dam_break_8m_spec": (sc.dam_break_8m_spec, lambda **kw: dam_break_params(**dict(dict(max_dt=0.00025), **kw)),
+                          "SURVEY 8d config 4 as written: 2896x2896 = 8 386 816 particles at spacing 1/2048, box 4x2, max_dt 0.00025 (0.001 blows up at step 3, 0.0005 at step 6: profiles/r5_config3_divergence.md)"),
     "dam_break_2m": (lambda: sc.dam_break_weak(2), dam_break_params, "2D dam-break, 2048x1024 = 2 097 152 particles (configs[1]'s column twice as wide)"),
     "dam_break_4m": (lambda: sc.dam_break_weak(4), dam_break_params, "2D dam-break, 4096x1024 = 4 194 304 particles (configs[1]'s column four times as wide)"),
     # configs[4] without the host-side adaptivity: media/ratio-stress-test-video.yaml's IISPH recipe on the 4M-particle scene

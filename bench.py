@@ -191,9 +191,32 @@ def main():
         os.write(real_stdout, (line + "\n").encode())
 
     t_start = time.perf_counter()
+    # ---- watchdog: a collective that some rank never enters hangs every other rank inside the library or inside
+    # torch.distributed with nothing on stdout.  A thread on every rank watches the time since the last progress mark; past the bar
+    # (BENCH_WATCHDOG_S, default 420 s per leg -- the longest leg, the CPU baseline, takes ~30 s) it prints ONE JSON line naming the leg
+    # and the rank to the real stdout and ends the process (torch.distributed.run then tears the other ranks down).
+    import threading
+    wd = {"leg": "start", "t": time.perf_counter(), "off": False}
+    wd_limit = float(os.environ.get("BENCH_WATCHDOG_S", "420"))
+
+    def watchdog():
+        while not wd["off"]:
+            time.sleep(1.0)
+            idle = time.perf_counter() - wd["t"]
+            if idle > wd_limit and not wd["off"]:
+                line = {"metric": "particle-steps/sec (whole node), 2D dam-break N=1M DFSPH; 1/2/4/8 GPUs", "value": None, "unit": "particle-steps/s",
+                        "n_gpus": world, "error": f"watchdog: rank {rank} made no progress for {idle:.0f} s in leg '{wd['leg']}' (a collective some rank never entered?)",
+                        "leg": wd["leg"], "rank": rank, "seconds_since_start": time.perf_counter() - t_start}
+                os.write(real_stdout, (json.dumps(line) + "\n").encode())
+                sys.stderr.write(f"[bench] {line['error']}\n")
+                sys.stderr.flush()
+                os._exit(3)
+
+    threading.Thread(target=watchdog, daemon=True).start()
 
     def leg(name):
-        """progress marks on stderr: which leg of the run a failure (or the driver's clock) belongs to"""
+        """progress marks on stderr: which leg of the run a failure (or the driver's clock) belongs to; resets the watchdog"""
+        wd["leg"], wd["t"] = name, time.perf_counter()
         if rank == 0:
             print(f"[bench +{time.perf_counter() - t_start:6.1f}s] {name}", file=sys.stderr, flush=True)
 
@@ -253,12 +276,12 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    def make_context(scn, P):
+    def make_context(scn, P, tname=None):
         pos, mass, vel = sc.init_particles(scn)
         planes = sc.boundary_planes(scn.boundary, P.init_boundary_handler)
         if distributed:
             from adaptive_sph_amd.distributed import make_slab_context
-            c = make_slab_context(plib, pos, mass, vel, planes, rank, world, local_rank, transport)
+            c = make_slab_context(plib, pos, mass, vel, planes, rank, world, local_rank, tname or transport)
         else:
             c = ffi.Context(plib, len(mass), planes, device_id=local_rank)
             c.upload(mass, pos, vel)
@@ -294,7 +317,9 @@ def main():
         return {"exchanges_per_step": stats["exchanges"] / k, "allreduces_per_step": stats["allreduces"] / k,
                 "halo_bytes_sent_per_step": stats["bytes_sent"] / k, "halo_bytes_received_per_step": stats["bytes_received"] / k,
                 "host_waits_per_step": stats["host_waits"] / k, "owned_particles": stats["n_owned"],
-                "ghost_particles": stats["n_ghost"], "halo_particles": stats["n_halo"], "rank": rank}
+                "ghost_particles": stats["n_ghost"], "halo_particles": stats["n_halo"], "rank": rank,
+                # what the LIBRARY ran over and how many ranks it sees there (RCCL: ncclCommCount of its communicator)
+                "transport": stats.get("transport"), "comm_ranks": stats.get("comm_ranks")}
 
     ctx, n_total = make_context(scene, params)
     p = params.to_ffi()
@@ -353,24 +378,73 @@ def main():
     copy_gbs = ctx.profile_copy_bandwidth_gbs(1 << 30) if rank == 0 else 0.0   # achievable HBM rate of this device, same run
     ctx.close()
 
+    # ---- every transport this launch can run, side by side: the headline and configs[3] again over the peer-mapped
+    # push transport (hipIpc inboxes + device flags, no collective-library launch per exchange) when the primary one is RCCL (or the
+    # shared-memory transport on a box with fewer GPUs than ranks) -- same scene, same K / W, same protocol; per transport: ms/step, what
+    # one exchange costs in the step's queue (HIP-event brackets of a short instrumented run), the library's own view of the group.
+    # `value` stays the primary transport's.  A transport that cannot be set up is recorded as such on every rank (make_slab_context
+    # agrees on failures through the launcher's process group), it does not end the run.
+    EXCHANGE_KERNELS = ("rccl_sendrecv", "rccl_allreduce", "ipc_push", "ipc_wait", "ghost_pack", "ghost_unpack", "slab_refresh")
+    transports = None
+
+    def transport_run(tname, scn, P, label):
+        rec = {"transport_requested": tname}
+        c = None
+        try:
+            leg(f"{label} over {tname}")
+            c, n_ = make_context(scn, P, tname)
+            el_, _, di_, de_, st_ = timed_run(c, P.to_ffi(), args.warmup, args.steps)
+            rec.update({"ms_per_step": el_ * 1e3 / args.steps, "value": n_ * args.steps / el_, "unit": "particle-steps/s", "particles": n_,
+                        "mean_div_iterations": float(np.mean(di_)), "mean_density_iterations": float(np.mean(de_)), "comm_rank0": comm_record(st_, args.steps)})
+            leg(f"{label} over {tname}: exchange cost")
+            c.profile_reset()
+            c.profile_enable(1)
+            k_ = 5
+            it_ = 0
+            for _ in range(k_):
+                s_ = c.step(P.to_ffi())
+                it_ += int(s_.div_solver.iters) + int(s_.density_solver.iters)
+            pa = c.profile_get()
+            c.profile_enable(0)
+            rec["exchange_rank0"] = {"steps": k_, "jacobi_iterations": it_,
+                                     "us_per_launch": {k: pa[k][1] * 1e3 / max(pa[k][0], 1) for k in EXCHANGE_KERNELS if k in pa},
+                                     "launches_per_step": {k: pa[k][0] / k_ for k in EXCHANGE_KERNELS if k in pa},
+                                     "us_per_jacobi_iteration": sum(pa[k][1] * 1e3 for k in ("rccl_sendrecv", "rccl_allreduce", "ipc_push", "ipc_wait") if k in pa) / max(it_, 1),
+                                     "note": "HIP-event brackets on rank 0's stream (they include the wait for the neighbour's message)"}
+        except (ffi.SphError, RuntimeError) as e:
+            rec["failed"] = str(e)[:300]
+        finally:
+            if c is not None:
+                c.close()
+        return rec
+
+    other_transports = [t for t in (["ipc"] if distributed and not os.environ.get("BENCH_ONE_TRANSPORT") else []) if t != transport]
+    if distributed and wl == "dam_break_1m":
+        transports = {transport: {"ms_per_step": elapsed * 1e3 / args.steps, "value": n_total * args.steps / elapsed, "unit": "particle-steps/s",
+                                  "comm_rank0": comm_record(comm_stats, args.steps), "primary": True}}
+        for t in other_transports:
+            transports[t] = transport_run(t, scene, params, "headline")
+
     # ---- north_star's second strong-scaling target: configs[3], 8.4M particles, same K / W, same protocol -------------------
     strong_8m = None
     if not args.no_8m and wl == "dam_break_1m":
         s8, p8f, d8 = WORKLOADS["dam_break_8m"]
         P8 = p8f()
 
-        def run_8m(overlap):
+        def run_8m(overlap, name="dam_break_8m"):
             """overlap: None = the library's own rule (sweep A split around the iteration's communication on slabs of >= 786k particles
             with neighbours), "0" / "1" = forced (SPH_OVERLAP, read by the library at every iteration; same results either way)."""
             if overlap is None:
                 os.environ.pop("SPH_OVERLAP", None)
             else:
                 os.environ["SPH_OVERLAP"] = overlap
-            c8, n8 = make_context(s8(), P8)
-            el8, _, di8, de8, st8 = timed_run(c8, P8.to_ffi(), args.warmup, args.steps)
+            sN, pNf, dN = WORKLOADS[name]
+            PN = pNf()
+            c8, n8 = make_context(sN(), PN)
+            el8, _, di8, de8, st8 = timed_run(c8, PN.to_ffi(), args.warmup, args.steps)
             c8.close()
             os.environ.pop("SPH_OVERLAP", None)
-            return {"workload": f"dam_break_8m: {d8}", "particles": n8, "value": n8 * args.steps / el8, "unit": "particle-steps/s",
+            return {"workload": f"{name}: {dN}", "particles": n8, "value": n8 * args.steps / el8, "unit": "particle-steps/s",
                     "ms_per_step": el8 * 1e3 / args.steps, "steps": args.steps, "warmup": args.warmup, "n_gpus": world, "scaling": "strong",
                     "mean_div_iterations": float(np.mean(di8)), "mean_density_iterations": float(np.mean(de8)),
                     "comm_rank0": comm_record(st8, args.steps) if distributed else None}
@@ -381,6 +455,18 @@ def main():
             strong_8m["sweep_a"] = "library rule (split on slabs of >= 786432 particles)"
             strong_8m["sweep_a_one_launch"] = {k: v for k, v in run_8m("0").items() if k in ("value", "ms_per_step", "comm_rank0")}
             strong_8m["sweep_a_split"] = {k: v for k, v in run_8m("1").items() if k in ("value", "ms_per_step", "comm_rank0")}
+            strong_8m["transports"] = {transport: {"ms_per_step": strong_8m["ms_per_step"], "value": strong_8m["value"], "primary": True}}
+            for t in other_transports:
+                strong_8m["transports"][t] = transport_run(t, s8(), P8, "configs[3]")
+
+    # ---- SURVEY section 8d's configs[3] geometry (2896 x 2896 at spacing 1/2048, box 4 x 2: ONE tall column, 2896-row halos -- the harder
+    # strong-scaling case) with max_dt 0.00025, the largest of the three probed values at which it does not blow up
+    # (profiles/r5_config3_divergence.md); same K / W, same protocol, at every N
+    strong_8m_spec = None
+    if not args.no_8m and wl == "dam_break_1m":
+        leg("SURVEY's configs[3] geometry: dam_break_8m_spec")
+        strong_8m_spec = run_8m(None, "dam_break_8m_spec")
+        strong_8m_spec["max_dt"] = 0.00025
 
     # ---- BASELINE configs[4] on the same ranks: the ratio-stress scene (4 004 343 particles at 50:1 radii, IISPH, Sdf2D box, EmptyAngle
     # level estimation) -- its step path, and a few calls of single_step WITH sharing / merging / splitting, the adaptive half in its
@@ -427,10 +513,28 @@ def main():
                 c4.close()
 
     if rank != 0:
+        wd["leg"], wd["t"] = "waiting for rank 0's line", time.perf_counter()
         if distributed:
             dist.barrier()
             dist.destroy_process_group()
+        wd["off"] = True
         return
+
+    # The instrumented repeat runs every sweep ~0.6 us SHORTER than the timed region does: measured under ONE rocprofv3 kernel trace of
+    # both passes (scripts/kt_two_passes.py, profiles/r5_two_passes.txt: OpJacobiU 17.75 us in the timed pass, 17.16 in the instrumented
+    # one; OpPressureAccelU 15.55 / 14.44) -- an instrumented queue leaves a gap behind every launch, an uninstrumented one starts the
+    # next dispatch's clock where the last one ended, so there the launch boundary is INSIDE the durations (rocprofv3's durations of the
+    # timed pass add up to its wall clock, 99 % busy).  The line therefore adds that boundary back: the timed region's wall clock per
+    # step minus the instrumented durations of the step's launches, spread over the launches -- one figure per run, printed -- so that
+    # a kernel's `avg_us` is what `rocprofv3 --kernel-trace --stats -- bench.py --profile-steps 0` reports for it (within 2 %), and
+    # the durations add up to the step.
+    launch_boundary_us = 0.0
+    if prof_all and not distributed:
+        n_launch = sum(v[0] for v in prof_all.values())
+        t_instr = sum((v[1] * 1e3 - (0.0 if k in SWEEP_KERNELS else marker_excess_us * v[0])) for k, v in prof_all.items())
+        wall_us = elapsed * 1e6 / args.steps * max(args.profile_steps, 1)
+        if n_launch:
+            launch_boundary_us = max(0.0, (wall_us - t_instr) / n_launch)
 
     def roof(name, launches, total_ms):
         """Average duration of the kernel's launches that did work over the instrumented repeat of the timed window.  Sweeps: the
@@ -441,7 +545,8 @@ def main():
             return None
         raw_us = total_ms * 1e3 / launches
         own_ts = name in SWEEP_KERNELS
-        avg_s = (raw_us if own_ts else raw_us - marker_excess_us) * 1e-6
+        # + the launch boundary of the UNINSTRUMENTED queue (see `launch_boundary_us` below): what rocprofv3 sees of the timed region
+        avg_s = ((raw_us if own_ts else raw_us - marker_excess_us) + launch_boundary_us) * 1e-6
         achieved = ALGO_BYTES[name] * n_local / avg_s / 1e9
         traffic, src = committed_pmc_traffic(name) if wl == "dam_break_1m" and not distributed else (None, None)
         issue = VALU_ISSUE.get(name)
@@ -459,7 +564,8 @@ def main():
              "bound_evidence": {"config": "dam_break_8m (out of the Infinity Cache)", "traffic_bytes_per_launch": t8, "rocprofv3_avg_us": us8,
                                 "traffic_GBs": gbs8, "source": src8, "copy_kernel_GBs": copy_gbs, "guide_copy_GBs": GUIDE_COPY_GBS,
                                 "frac_of_streaming_rate": (gbs8 / copy_ref) if gbs8 else None, "rule": "hbm when >= 0.85"},
-             "avg_us": avg_s * 1e6, "timed_by": "dispatch timestamps (hipExtLaunchKernelGGL event pair)" if own_ts else "marker bracket - marker excess",
+             "avg_us": avg_s * 1e6, "avg_us_instrumented": raw_us if own_ts else raw_us - marker_excess_us, "launch_boundary_us": launch_boundary_us,
+             "timed_by": ("dispatch timestamps (hipExtLaunchKernelGGL event pair)" if own_ts else "marker bracket - marker excess") + " + launch boundary",
              "marker_excess_us": None if own_ts else marker_excess_us,
              "rocprofv3_avg_us_committed": committed_pmc_avg(name) if wl == "dam_break_1m" and not distributed else None,
              "launches_timed": launches, "window": prof_window,
@@ -482,7 +588,8 @@ def main():
     for name, (launches, total_ms) in sorted(prof_all.items(), key=lambda kv: -kv[1][1]):
         own_ts = name in SWEEP_KERNELS
         k = {"name": name, "launches_per_step": launches / max(args.profile_steps, 1),
-             "avg_us": total_ms * 1e3 / max(launches, 1) - (0.0 if own_ts else marker_excess_us), "timed_by": "dispatch" if own_ts else "bracket - excess",
+             "avg_us": total_ms * 1e3 / max(launches, 1) - (0.0 if own_ts else marker_excess_us) + launch_boundary_us,
+             "avg_us_instrumented": total_ms * 1e3 / max(launches, 1) - (0.0 if own_ts else marker_excess_us), "timed_by": "dispatch" if own_ts else "bracket - excess",
              "time_share": total_ms / total_prof_ms}
         r = roof(name, *prof_work.get(name, (launches, total_ms)))
         if r:
@@ -497,7 +604,8 @@ def main():
     timing_note = (f"HIP events on the library's stream, over an instrumented REPEAT of the timed window (fresh context, same {args.warmup} warm-up "
                    f"steps, same {args.profile_steps} steps; events perturb dispatch, so the timed region itself is uninstrumented); a sweep's avg_us = mean over "
                    f"its working launches of the dispatch's own start-to-end timestamps (the event pair hipExtLaunchKernelGGL attaches to the launch: "
-                   f"the quantity rocprofv3 reports; the 10 us calibration kernel reads "
+                   f"the quantity rocprofv3 reports -- plus the launch boundary of the uninstrumented queue, {launch_boundary_us:.2f} us per launch = (the timed region's wall "
+                   f"clock - the instrumented durations) / launches, so that the durations add up to the step as rocprofv3's do; the 10 us calibration kernel reads "
                    f"{(prof_window or {}).get('calibration_spin10_dispatch_us') or float('nan'):.2f} us that way, rocprofv3 {SPIN10_ROCPROF_US}); dominant kernel = "
                    f"largest total over that window; `traffic` is not measured in this run: it is the FETCH_SIZE x2 + WRITE_SIZE figure of the rocprofv3 "
                    f"--pmc passes summarised in `traffic_source`; `bound` is decided on configs[3]'s committed traffic and duration (out of the Infinity "
@@ -524,6 +632,8 @@ def main():
         "roofline_density": roofline_density,
         "kernels": kernels,
         "strong_8m": strong_8m,
+        "strong_8m_spec": strong_8m_spec,
+        "transports": transports,
         "config4_ratio_stress_4m": config4,
         "comm_rank0": comm_record(comm_stats, args.steps) if distributed else {"host_waits_per_step": comm_stats["host_waits"] / max(args.steps, 1)},
     }
@@ -565,6 +675,7 @@ def main():
     if not args.no_cpu_baseline and not distributed:
         leg("cpu baseline (oracle)")
         out["cpu_baseline"] = cpu_baseline(scene, params, args.cpu_seconds)
+    wd["off"] = True
     emit(json.dumps(out))
     if distributed:
         dist.barrier()

@@ -440,6 +440,10 @@ typedef struct sph_dist_stats {
     uint64_t n_owned;
     uint32_t n_halo[2];    /* owned particles copied to the left / right neighbour as its ghosts */
     uint32_t n_ghost[2];   /* ghosts received from the left / right neighbour */
+    uint32_t transport;    /* what the NEXT step's exchanges run over: 0 no slab context, 1 none attached yet (sph_group_step's loopback
+                            * copies), 2 RCCL, 3 threads, 4 shared memory (host-staged), 5 peer-mapped push (hipIpc) */
+    uint32_t comm_ranks;   /* ranks of that transport AS THE LIBRARY SEES THEM: ncclCommCount of the communicator (RCCL), the ranks mapped
+                            * (peer-mapped push), the group's size (threads, shared memory) -- the launcher checks it against its world size */
 } sph_dist_stats;
 int  sph_dist_get_stats(sph_ctx* ctx, sph_dist_stats* out, int reset);
 int  sph_comm_unique_id(uint8_t id_out[128]);

@@ -260,6 +260,8 @@ pub mod ffi {
         pub n_owned: u64,
         pub n_halo: [u32; 2],
         pub n_ghost: [u32; 2],
+        pub transport: u32,
+        pub comm_ranks: u32,
     }
 }
 

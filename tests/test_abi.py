@@ -39,7 +39,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(ffi.SphKernelTime) == 80
     assert C.sizeof(ffi.SphEditOp) == 52
     assert C.sizeof(ffi.SphAdaptParams) == 11 * 4
-    assert C.sizeof(ffi.SphDistStats) == 7 * 8 + 4 * 4
+    assert C.sizeof(ffi.SphDistStats) == 7 * 8 + 6 * 4
 
 
 def test_no_gpu_create_fails_loudly(product_lib, gpu_available):
