@@ -172,6 +172,18 @@ def ratio_stress_4m() -> SceneConfig:
                         SceneFluidBlock([-0.95, -0.5], [0.55, 1.4], 0.0004385, 0.93, [0.0, 0.0])])
 
 
+def ratio_stress_4m_settled() -> SceneConfig:
+    """configs[4]'s two blocks STANDING ON THE FLOOR and against each other (VERDICT r4 missing 4 / next 6): the reference scene hangs both
+    blocks 0.5 above the floor (media/ratio-stress-test-scene.yaml:5-15), so its first ~0.3 s are free fall -- IISPH's Jacobi loop sees
+    all-negative pressures and leaves after one iteration, and nothing of the 50:1 interface is ever under load.  Here the same blocks
+    (same spacings, same sizes, 4 002 768 fine + 1 575 coarse particles) start one fine spacing above the floor with the fine block's
+    right edge a fraction of a coarse spacing from the coarse block: hydrostatic pressure builds from step 0, the solver iterates, and a
+    coarse particle at the interface has thousands of fine neighbours."""
+    return SceneConfig(SceneBoundary("box", 2.0, 2.0),
+                       [SceneFluidBlock([-0.39, -0.999], [0.55, 1.4], 0.021925, 0.93, [0.0, 0.0]),
+                        SceneFluidBlock([-0.95, -0.999], [0.55, 1.4], 0.0004385, 0.93, [0.0, 0.0])])
+
+
 def dam_break_weak(n_gpus: int) -> SceneConfig:
     """Weak-scaling family between configs[1] (1 GPU, 1M) and configs[3] (8 GPUs, 8M): configs[1]'s column n times as wide --
     (1024 n) x 1024 particles at spacing 1/1024, one configs[1] per x-slab -- in a box of twice the column's width (4 x 2 up to

@@ -74,5 +74,9 @@ WORKLOADS = {
         merging=False, sharing=False, splitting=False, support_length_estimation="FromMass", pressure_solver_method="IISPH",
         cfl_factor=0.2, max_dt=0.001, iisph_max_avg_density_error=0.001, init_boundary_handler="AnalyticUnderestimate",
         level_estimation_method="None"), **kw)), "ratio-stress-test geometry, 4 004 343 particles at 50:1 radii, IISPH, Sdf2D box"),
+    "ratio_stress_4m_settled": (sc.ratio_stress_4m_settled, lambda **kw: default_params(**dict(dict(
+        merging=False, sharing=False, splitting=False, support_length_estimation="FromMass", pressure_solver_method="IISPH",
+        cfl_factor=0.2, max_dt=0.001, iisph_max_avg_density_error=0.001, init_boundary_handler="AnalyticUnderestimate",
+        level_estimation_method="None"), **kw)), "configs[4]'s blocks standing on the floor, in contact: 4 004 343 particles at 50:1 radii, IISPH under hydrostatic load"),
     "dam_break_64k": (lambda: sc.dam_break_small(256, 256, 1.0 / 256), dam_break_params, "2D dam-break, 256x256 particles (smoke)"),
 }

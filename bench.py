@@ -137,12 +137,16 @@ def short_run(plib, name, steps=40, warmup=10, **param_overrides):
     for _ in range(warmup):
         ctx.step(p)
     t0 = time.perf_counter()
+    its = []
     for _ in range(steps):
-        ctx.step(p)
+        st = ctx.step(p)
+        its.append((int(st.div_solver.iters) + 1 if P.pressure_solver_method in ("HybridDFSPH", "OnlyDivergence") else 0,
+                    int(st.density_solver.iters) + 1 if P.pressure_solver_method != "OnlyDivergence" else 0))
     dt = time.perf_counter() - t0
     ctx.close()
     return {"workload": f"{name}: {desc}", "overrides": param_overrides, "particles": len(mass), "steps": steps, "warmup": warmup,
-            "ms_per_step": dt * 1e3 / steps, "particle_steps_per_s": len(mass) * steps / dt}
+            "ms_per_step": dt * 1e3 / steps, "particle_steps_per_s": len(mass) * steps / dt,
+            "mean_div_iterations": float(np.mean([a for a, _ in its])), "mean_density_iterations": float(np.mean([b for _, b in its]))}
 
 
 def cpu_baseline(scene, params, budget_s: float):
@@ -669,6 +673,10 @@ def main():
         out["other_configs"].append(short_run(plib, "dam_break_1m_adaptive"))                                    # configs[2]: 4:1 radius ratio
         leg("other configs: ratio_stress_4m")
         out["other_configs"].append(short_run(plib, "ratio_stress_4m", steps=20, warmup=5))                      # configs[4]'s scene (50:1, 4M), no adaptivity
+        out["other_configs"][-1]["state"] = "FREE FALL (the reference scene hangs both blocks 0.5 above the floor): one Jacobi iteration per step, not an IISPH number"
+        leg("other configs: ratio_stress_4m_settled")
+        out["other_configs"].append(short_run(plib, "ratio_stress_4m_settled", steps=20, warmup=5))              # ... standing on the floor, in contact: IISPH iterates
+        out["other_configs"][-1]["state"] = "blocks on the floor and in contact: hydrostatic load from step 0, the 50:1 interface inside the solve"
         leg("other configs: dam_break_1m + EmptyAngle")
         out["other_configs"].append(short_run(plib, "dam_break_1m", steps=20, warmup=20, level_estimation_method="EmptyAngle",
                                               maximum_surface_distance=0.2, particle_radius_fine=0.0005, particle_radius_base=0.002))   # + level estimation
