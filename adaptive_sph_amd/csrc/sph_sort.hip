@@ -626,7 +626,12 @@ __global__ __launch_bounds__(256) void k_tile_hmax(uint32_t n, const float4* __r
     uint32_t tile = 0xffffffffu, hb = 0u;
     if (i < n) {
         const float4 p = pm[i];
-        const int cx = (int)floorf(p.x / g.cs) - g.minx, cy = (int)floorf(p.y / g.cs) - g.miny;
+        // clamped into the grid like the cell keys (cell_key_clamped): the grid of a build queued AHEAD is a prediction, and a particle an
+        // exploding solve threw out of it indexed a tile beyond the table -- a memory fault BEHIND the step that had already returned its
+        // error (round 5, configs[4]'s blocks too close to the floor: scripts/gpu_fault_bisect.sh); such a build is never adopted
+        int cx = (int)floorf(p.x / g.cs) - g.minx, cy = (int)floorf(p.y / g.cs) - g.miny;
+        cx = min(max(cx, 0), g.sx - 1);
+        cy = min(max(cy, 0), g.sy - 1);
         tile = (uint32_t)(cy / ts) * (uint32_t)tsx + (uint32_t)(cx / ts);
         hb = __float_as_uint(p.w);
     }

@@ -173,15 +173,17 @@ def ratio_stress_4m() -> SceneConfig:
 
 
 def ratio_stress_4m_settled() -> SceneConfig:
-    """configs[4]'s two blocks STANDING ON THE FLOOR and against each other (VERDICT r4 missing 4 / next 6): the reference scene hangs both
-    blocks 0.5 above the floor (media/ratio-stress-test-scene.yaml:5-15), so its first ~0.3 s are free fall -- IISPH's Jacobi loop sees
-    all-negative pressures and leaves after one iteration, and nothing of the 50:1 interface is ever under load.  Here the same blocks
-    (same spacings, same sizes, 4 002 768 fine + 1 575 coarse particles) start one fine spacing above the floor with the fine block's
-    right edge a fraction of a coarse spacing from the coarse block: hydrostatic pressure builds from step 0, the solver iterates, and a
-    coarse particle at the interface has thousands of fine neighbours."""
+    """configs[4]'s two blocks STANDING ON THE FLOOR (VERDICT r4 missing 4 / next 6): the reference scene hangs both blocks 0.5 above the
+    floor (media/ratio-stress-test-scene.yaml:5-15), so its first ~0.3 s are free fall -- IISPH's Jacobi loop sees all-negative pressures
+    and leaves after one iteration.  Here the same blocks (same x positions, spacings and sizes: 4 002 768 fine + 1 575 coarse particles)
+    start one fine spacing above the floor: hydrostatic pressure builds from step 0 and the solver iterates.  (Moving the blocks AGAINST
+    each other as well was tried and is no benchmark scene: with h_ij = (h_i + h_j) / 2 a coarse particle adds m_c W(r, h_c / 2) ~ 1.5 rho_0 to
+    every fine particle within half its smoothing length, IISPH answers the density error with velocities ~ 1 / dt -- 64, 159, 319 m/s
+    at step 0 for max_dt 2.5e-4, 1e-4, 5e-5 -- and the state is NaN by step 10, on the oracle alike; the interface at 50:1 is covered by
+    the forced-count parity test test_config4_ratio_stress_4m_blocks_in_contact.)"""
     return SceneConfig(SceneBoundary("box", 2.0, 2.0),
-                       [SceneFluidBlock([-0.39, -0.999], [0.55, 1.4], 0.021925, 0.93, [0.0, 0.0]),
-                        SceneFluidBlock([-0.95, -0.999], [0.55, 1.4], 0.0004385, 0.93, [0.0, 0.0])])
+                       [SceneFluidBlock([0.4, -0.97755], [0.55, 1.4], 0.021925, 0.93, [0.0, 0.0]),
+                        SceneFluidBlock([-0.95, -0.99955], [0.55, 1.4], 0.0004385, 0.93, [0.0, 0.0])])
 
 
 def dam_break_weak(n_gpus: int) -> SceneConfig:

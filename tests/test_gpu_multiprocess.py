@@ -75,3 +75,58 @@ def test_bench_starts_its_own_ranks_and_prints_the_schema():
         assert d["n_gpus"] == int(cmd[1]) and d["value"] > 0 and d["steps"] == 4 and d["comm_rank0"]["exchanges_per_step"] >= 0
         if cmd[1] == "2":
             assert d["comm_rank0"]["exchanges_per_step"] > 0 and d["comm_rank0"]["halo_bytes_sent_per_step"] > 0
+
+
+def test_a_particle_thrown_out_of_the_predicted_grid_does_not_fault_the_build_queued_ahead():
+    """Round 5 (found on configs[4]'s blocks set 50 x too close to the floor, scripts/gpu_fault_bisect.sh): an exploding IISPH solve threw
+    coarse particles far out; the step that saw it returned its error -- but the NEXT step's cell sort had already been queued behind
+    the tail on a PREDICTED grid (this step's bounding box + 3 cells), and in a multi-resolution scene its tile bounds (k_tile_hmax)
+    indexed a tile beyond the table: a memory fault AFTER the error had been reported.  Deterministic trigger, in a process of its own
+    (a fault kills the process): two particle sizes, cfl_factor so large that dt = max_dt, and one particle with 2e5 m/s -- it lands
+    200 m outside the box in ONE step.  The build queued ahead must run harmlessly (clamped) and must not be adopted: the following steps
+    are bit for bit those of SPH_AHEAD_BUILD=0 (or refused alike), and a fresh context steps normally afterwards.  (The library before
+    the fix dies here with "Memory access fault by GPU node".)"""
+    code = r'''
+import os, sys
+sys.path.insert(0, %r)
+import numpy as np
+from adaptive_sph_amd import ffi, scene as sc
+from adaptive_sph_amd.workloads import dam_break_params
+lib = ffi.load_product()
+scn = sc.SceneConfig(sc.SceneBoundary("box", 4.0, 2.0),
+                     [sc.SceneFluidBlock([-1.99, -0.99], [0.5, 0.4], 1.0 / 64, 0.93, [0.0, 0.0]),
+                      sc.SceneFluidBlock([-1.48, -0.985], [0.5, 0.5], 1.0 / 16, 0.93, [0.0, 0.0])])
+pos, mass, vel = sc.init_particles(scn)
+top = int(np.argmax(pos[:, 1] + 1e-3 * pos[:, 0]))
+vel2 = vel.copy()
+vel2[top] = (3.0e4, 2.0e5)
+P = dam_break_params(cfl_factor=1.0e9, max_dt=0.001, hybrid_dfsph_max_avg_density_error=0.0, hybrid_dfsph_max_avg_divergence_error=0.0, max_iters=3)
+planes = sc.boundary_planes(scn.boundary)
+out = {}
+for ahead in ("1", "0"):
+    os.environ["SPH_AHEAD_BUILD"] = ahead
+    g = ffi.Context(lib, len(mass), planes)
+    g.upload(mass, pos, vel2)
+    st = g.step(P.to_ffi())
+    assert st.dt == np.float32(0.001), st.dt
+    assert g.download("position")[top, 1] > 100.0
+    status = 0
+    try:                                           # (a scene this wide may be refused -- "cell grid too large" -- or stepped: the same either way)
+        for s in range(3):
+            g.step(P.to_ffi())
+    except ffi.SphError as e:
+        status = e.status
+    out[ahead] = (status, None if status else {f: g.download(f) for f in ("position", "velocity", "density", "neighbor_count")})
+    g.close()
+    h = ffi.Context(lib, len(mass), planes)     # (drains whatever the last step left queued)
+    h.upload(mass, pos, vel)
+    h.step(dam_break_params().to_ffi())
+    h.close()
+assert out["1"][0] == out["0"][0], (out["1"][0], out["0"][0])
+if out["1"][1] is not None:
+    for f in out["1"][1]:
+        assert np.array_equal(out["1"][1][f], out["0"][1][f]), f
+print("CLEAN", flush=True)
+''' % str(REPO)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "CLEAN" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-2500:])
