@@ -25,7 +25,14 @@ def _stale(target: Path, sources) -> bool:
     return any(Path(s).stat().st_mtime > t for s in sources)
 
 
-def build_hip(force: bool = False, verbose: bool = False, out_name: str = "libsph_hip.so") -> Path:
+def build_lab(force: bool = False, verbose: bool = False) -> Path:
+    """The LABORATORY build of the same sources: -DSPH_LAB compiles in the ablation switches (sph_context.hpp: Options) that put older or
+    alternative forms of a kernel / a queueing policy beside the product's.  The bit-identity tests load it (tests/conftest.py: lab_lib),
+    scripts/variants and scripts/gpu_*.py select it with SPH_HIP_LIBRARY=libsph_lab.so.  Never the measured or shipped path."""
+    return build_hip(force=force, verbose=verbose, out_name="libsph_lab.so", extra_flags=["-DSPH_LAB=1"])
+
+
+def build_hip(force: bool = False, verbose: bool = False, out_name: str = "libsph_hip.so", extra_flags=()) -> Path:
     """hipcc --offload-arch=gfx950 -> adaptive_sph_amd/csrc/libsph_hip.so
 
     Each translation unit is compiled to an object of its own (in parallel; only the stale ones), then linked: a change to
@@ -36,7 +43,7 @@ def build_hip(force: bool = False, verbose: bool = False, out_name: str = "libsp
     out = CSRC / out_name   # (variants are built HERE, next to the product library, and selected with SPH_HIP_LIBRARY: ffi.py)
     srcs = sorted(CSRC.glob("*.hip"))
     headers = sorted(CSRC.glob("*.h")) + sorted(CSRC.glob("*.hpp")) + [REPO / "include" / "sph_ffi.h"]
-    extra = os.environ.get("SPH_EXTRA_HIPCC_FLAGS", "").split()
+    extra = os.environ.get("SPH_EXTRA_HIPCC_FLAGS", "").split() + list(extra_flags)
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall",
              "-I", str(REPO / "include")] + extra
     tag = hashlib.sha1(" ".join(flags).encode()).hexdigest()[:10]
@@ -59,7 +66,9 @@ def build_hip(force: bool = False, verbose: bool = False, out_name: str = "libsp
 
     with ThreadPoolExecutor(max_workers=min(len(todo), os.cpu_count() or 4) or 1) as ex:
         list(ex.map(compile_one, todo))
-    cmd = [hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(out)] + [str(o) for o in objs] + ["-L/opt/rocm/lib", "-lrccl"]
+    # -Bsymbolic: the library's references to its own global symbols bind to ITS definitions -- two builds of these sources in one process
+    # (the product and the laboratory build, tests/conftest.py) must not interpose each other's functions
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-Bsymbolic", "-o", str(out)] + [str(o) for o in objs] + ["-L/opt/rocm/lib", "-lrccl"]
     if verbose:
         print(" ".join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)

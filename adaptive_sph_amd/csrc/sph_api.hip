@@ -518,12 +518,24 @@ Options options_from_env()
         return e && e[0] ? atoi(e) : dflt;
     };
     auto flag = [](const char* name) { return getenv(name) != nullptr ? 1 : 0; };
+    // the product library reads the math policy, the transport's behaviour and the debug aids -- nothing that selects between kernels
     o.exact = num("SPH_HIP_EXACT", 0) == 1 ? 1 : 0;
+    o.overlap = num("SPH_OVERLAP", -1);
+    o.loopback_sync = num("SPH_LOOPBACK_SYNC", 0) != 0 ? 1 : 0;
+    o.force_slab_mode = flag("SPH_FORCE_SLAB_MODE");
+    o.event_wait = flag("SPH_EVENT_WAIT");
+    o.debug_sync = num("SPH_DEBUG_SYNC", 0);
+    o.debug_counts = flag("SPH_DEBUG_COUNTS");
+    o.comm_delay_us = num("SPH_DEBUG_COMM_DELAY_US", 0);
+    o.hip_trace = num("SPH_HIP_TRACE", 0) == 1 ? 1 : 0;
+#ifdef SPH_LAB
+    // the LABORATORY build (-DSPH_LAB: adaptive_sph_amd/build.py build_lab -> libsph_lab.so, same sources): the ablation switches that put
+    // an older or alternative form of a kernel / a queueing policy beside the product's -- what the bit-identity tests compare against
+    // (tests/conftest.py: lab_lib) and what scripts/variants and scripts/gpu_*.py time.  Defaults = the product's behaviour.
     o.paced = num("SPH_PACED", 1) != 0 ? 1 : 0;
     o.pace_lead = num("SPH_PACE_LEAD", 0);
     o.pace_pred = num("SPH_PACE_PRED", 0xffff);
     o.chain = num("SPH_CHAIN", -1);
-    o.overlap = num("SPH_OVERLAP", -1);
     o.accel_generic = flag("SPH_ACCEL_GENERIC");
     o.jacobi_generic = flag("SPH_JACOBI_GENERIC");
     o.slab_general = flag("SPH_SLAB_GENERAL");
@@ -533,19 +545,13 @@ Options options_from_env()
     o.level_queue = num("SPH_LEVEL_QUEUE", 1) != 0 ? 1 : 0;
     o.offset_lists = num("SPH_OFFSET_LISTS", 1) != 0 ? 1 : 0;
     o.no_fuse = flag("SPH_NO_FUSE");
-    o.event_wait = flag("SPH_EVENT_WAIT");
-    o.loopback_sync = num("SPH_LOOPBACK_SYNC", 0) != 0 ? 1 : 0;
     o.side_stream_normal = flag("SPH_SIDE_STREAM_NORMAL");
-    o.force_slab_mode = flag("SPH_FORCE_SLAB_MODE");
     o.tile = num("SPH_TILE", 0);
     o.ahead_build = num("SPH_AHEAD_BUILD", 1) != 0 ? 1 : 0;
     o.inc_sort = num("SPH_INC_SORT", 1);
     o.slab_paced = num("SPH_SLAB_PACED", 1) != 0 ? 1 : 0;
     o.slab_records = num("SPH_SLAB_RECORDS", 1) != 0 ? 1 : 0;
-    o.debug_sync = num("SPH_DEBUG_SYNC", 0);
-    o.debug_counts = flag("SPH_DEBUG_COUNTS");
-    o.comm_delay_us = num("SPH_DEBUG_COMM_DELAY_US", 0);
-    o.hip_trace = num("SPH_HIP_TRACE", 0) == 1 ? 1 : 0;
+#endif
     return o;
 }
 

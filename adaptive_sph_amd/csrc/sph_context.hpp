@@ -46,8 +46,11 @@ struct TmpBuf : DevBuf {
 // Measurement / test switches.  Read ONCE per context, at sph_create, from the environment (options_from_env, sph_api.hip: the
 // variable names are listed there and in README.md) -- nothing in the step path calls getenv, and two contexts of one process may
 // run different forms side by side (the bit-identity tests do).  Defaults = the product's behaviour.
+// Read from the environment once, at sph_create.  The PRODUCT library (libsph_hip.so) reads the math policy, the transport's behaviour and
+// the debug aids (marked P); everything else is a laboratory switch and exists only in the -DSPH_LAB build of the same sources
+// (libsph_lab.so, adaptive_sph_amd/build.py: build_lab; options_from_env in sph_api.hip) -- the product runs the defaults below.
 struct Options {
-    int exact = 0;              // SPH_HIP_EXACT=1          EXACT math policy (the reference's operations; diagnostics)
+    int exact = 0;              // SPH_HIP_EXACT=1        P EXACT math policy (the reference's operations; diagnostics)
     int paced = 1;              // SPH_PACED=0              predicted queue + waits instead of pacing against the device's decisions
     int pace_lead = 0;          // SPH_PACE_LEAD=<k>        undecided iterations allowed in the queue (0: by particle count)
     int pace_pred = 0xffff;     // SPH_PACE_PRED=0|1|2      unpaced head of a solve (0xffff: by particle count)

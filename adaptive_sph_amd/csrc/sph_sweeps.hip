@@ -3199,6 +3199,9 @@ bool sweep_a_on_records(const SweepArgs& a) { return solve_on_records(a); }
 extern "C" int sph_set_sweep_variant(int mode)
 {
     if (mode < 0 || mode > 3) return SPH_ERR_INVALID_ARGUMENT;
+#ifndef SPH_LAB
+    if (mode != 0) return SPH_ERR_UNSUPPORTED;   // the LDS-staged forms are laboratory forms (libsph_lab.so, -DSPH_LAB)
+#endif
     g_tile_mode = mode;
     return SPH_OK;
 }

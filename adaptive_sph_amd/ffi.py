@@ -160,7 +160,7 @@ ABI_SYMBOLS = [
 class SphLibrary:
     """A loaded implementation of include/sph_ffi.h."""
 
-    def __init__(self, path: os.PathLike, prefix: str = "sph_"):
+    def __init__(self, path: os.PathLike, prefix: str = "sph_", global_symbols: bool = None):
         path = Path(path)
         if not path.exists():
             raise FileNotFoundError(
@@ -168,7 +168,9 @@ class SphLibrary:
                 f"(python -c 'import __graft_entry__ as g; g.build()' or adaptive_sph_amd.build.build_hip())")
         self.path = path
         self.prefix = prefix
-        self.lib = C.CDLL(str(path), mode=C.RTLD_GLOBAL if prefix == "sph_" else C.RTLD_LOCAL)
+        if global_symbols is None:
+            global_symbols = prefix == "sph_"
+        self.lib = C.CDLL(str(path), mode=C.RTLD_GLOBAL if global_symbols else C.RTLD_LOCAL)
         L, P = self.lib, prefix
         vp, u64, i32 = C.c_void_p, C.c_uint64, C.c_int
 

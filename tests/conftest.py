@@ -31,6 +31,16 @@ def product_lib():
 
 
 @pytest.fixture(scope="session")
+def lab_lib():
+    """The LABORATORY build of the product's sources (-DSPH_LAB: the ablation switches compiled in, adaptive_sph_amd/build.py) -- for the
+    tests that put an alternative form of a kernel or a queueing policy beside the product's default.  Its defaults are the product's
+    code paths (tests/test_gpu_chain.py::test_the_laboratory_build_runs_the_products_defaults)."""
+    import torch  # noqa: F401
+    from adaptive_sph_amd import build, ffi
+    return ffi.SphLibrary(build.build_lab(), "sph_", global_symbols=False)
+
+
+@pytest.fixture(scope="session")
 def gpu_available():
     import torch
     return torch.cuda.is_available()

@@ -16,13 +16,13 @@ pytestmark = pytest.mark.gpu
 FORMS = {"paced": dict(SPH_PACED="1"), "chained": dict(SPH_PACED="0", SPH_CHAIN="1"), "two-wait": dict(SPH_PACED="0", SPH_CHAIN="0")}
 
 
-def run(product_lib, monkeypatch, form, steps, **overrides):
+def run(lab_lib, monkeypatch, form, steps, **overrides):
     for k, v in FORMS[form].items():
         monkeypatch.setenv(k, v)
     scn = sc.dam_break_small(128, 96, 1 / 64)
     pos, mass, vel = sc.init_particles(scn)
     P = dam_break_params(**overrides)
-    g = ffi.Context(product_lib, len(mass), sc.boundary_planes(scn.boundary, P.init_boundary_handler))
+    g = ffi.Context(lab_lib, len(mass), sc.boundary_planes(scn.boundary, P.init_boundary_handler))
     g.upload(mass, pos, vel)
     p = P.to_ffi()
     its = []
@@ -37,11 +37,11 @@ def run(product_lib, monkeypatch, form, steps, **overrides):
 
 
 @pytest.mark.parametrize("overrides", [dict(), dict(hybrid_dfsph_density_source_term="OnlyDensity")])
-def test_paced_chained_and_two_wait_solves_are_bit_identical(product_lib, monkeypatch, overrides):
+def test_paced_chained_and_two_wait_solves_are_bit_identical(lab_lib, monkeypatch, overrides):
     steps = 40
-    a, ia, wa = run(product_lib, monkeypatch, "chained", steps, **overrides)
-    b, ib, wb = run(product_lib, monkeypatch, "two-wait", steps, **overrides)
-    c, ic, wc = run(product_lib, monkeypatch, "paced", steps, **overrides)
+    a, ia, wa = run(lab_lib, monkeypatch, "chained", steps, **overrides)
+    b, ib, wb = run(lab_lib, monkeypatch, "two-wait", steps, **overrides)
+    c, ic, wc = run(lab_lib, monkeypatch, "paced", steps, **overrides)
     assert ia == ib == ic
     div = [t[0] for t in ia]
     assert max(div) > min(div) and any(div[k + 1] > div[k] for k in range(len(div) - 1))   # a chained divergence solve fell short at least once
@@ -53,11 +53,11 @@ def test_paced_chained_and_two_wait_solves_are_bit_identical(product_lib, monkey
 
 
 @pytest.mark.parametrize("solver", ["IISPH", "IISPH2", "OnlyDivergence"])
-def test_paced_single_solve_modes_match_the_predicted_queue(product_lib, monkeypatch, solver):
+def test_paced_single_solve_modes_match_the_predicted_queue(lab_lib, monkeypatch, solver):
     """pressure_iterations() of the one-solve modes, paced and with the predicted queue"""
     out = {}
     for form in ("paced", "two-wait"):
-        g, its, waits = run(product_lib, monkeypatch, form, 25, pressure_solver_method=solver)
+        g, its, waits = run(lab_lib, monkeypatch, form, 25, pressure_solver_method=solver)
         out[form] = (g, its, waits)
     assert out["paced"][1] == out["two-wait"][1]
     assert out["paced"][2] <= out["two-wait"][2]
@@ -66,14 +66,14 @@ def test_paced_single_solve_modes_match_the_predicted_queue(product_lib, monkeyp
 
 
 @pytest.mark.parametrize("solver", ["HybridDFSPH", "IISPH", "OnlyDivergence"])
-def test_sweep_a_on_combined_records_is_bit_identical_to_the_generic_sweep(product_lib, monkeypatch, solver):
+def test_sweep_a_on_combined_records_is_bit_identical_to_the_generic_sweep(lab_lib, monkeypatch, solver):
     """Uniform-h scenes on one context: the solves store {x, y, p / rho^2, p} records and sweep A gathers one record per neighbour
     (OpPressureAccelU); SPH_ACCEL_GENERIC=1 keeps p / rho^2 as a field and gathers the particle record beside it.  Equal masses:
     the same arithmetic on the same values, so every field and every iteration count agree bit for bit."""
     def go(generic):
         if generic:
             monkeypatch.setenv("SPH_ACCEL_GENERIC", "1")
-        out = run(product_lib, monkeypatch, "paced", 25, pressure_solver_method=solver)
+        out = run(lab_lib, monkeypatch, "paced", 25, pressure_solver_method=solver)
         if generic:
             monkeypatch.delenv("SPH_ACCEL_GENERIC")
         return out
@@ -84,13 +84,13 @@ def test_sweep_a_on_combined_records_is_bit_identical_to_the_generic_sweep(produ
 
 
 @pytest.mark.parametrize("paced", ["1", "0"])
-def test_default_policy_waits_once_per_step_when_the_iteration_count_repeats(product_lib, monkeypatch, paced):
+def test_default_policy_waits_once_per_step_when_the_iteration_count_repeats(lab_lib, monkeypatch, paced):
     monkeypatch.delenv("SPH_CHAIN", raising=False)
     monkeypatch.setenv("SPH_PACED", paced)
     scn = sc.dam_break_small(128, 96, 1 / 64)
     pos, mass, vel = sc.init_particles(scn)
     P = dam_break_params(hybrid_dfsph_max_avg_density_error=0.0, hybrid_dfsph_max_avg_divergence_error=0.0, max_iters=3)   # the divergence solve's count pinned
-    g = ffi.Context(product_lib, len(mass), sc.boundary_planes(scn.boundary, P.init_boundary_handler))
+    g = ffi.Context(lab_lib, len(mass), sc.boundary_planes(scn.boundary, P.init_boundary_handler))
     g.upload(mass, pos, vel)
     p = P.to_ffi()
     for _ in range(4):
@@ -102,7 +102,7 @@ def test_default_policy_waits_once_per_step_when_the_iteration_count_repeats(pro
     assert g.dist_get_stats()["host_waits"] == 10      # one wait per step: header from the previous step's tail, solves paced (or chained)
 
 
-def test_chained_solves_on_slabs_are_bit_identical_to_the_two_wait_form(product_lib, monkeypatch):
+def test_chained_solves_on_slabs_are_bit_identical_to_the_two_wait_form(lab_lib, monkeypatch):
     """The same on a slab decomposition (loopback transport, 3 ranks): the gated solve all-reduces into totals of its own, the
     exchanges behind a closed gate re-send what the ghosts already hold."""
     from adaptive_sph_amd import distributed as D
@@ -113,7 +113,7 @@ def test_chained_solves_on_slabs_are_bit_identical_to_the_two_wait_form(product_
     out = {}
     for chain in ("1", "0"):
         monkeypatch.setenv("SPH_CHAIN", chain)
-        grp = D.make_loopback_group(product_lib, pos, mass, vel, planes, 3)
+        grp = D.make_loopback_group(lab_lib, pos, mass, vel, planes, 3)
         its = []
         for _ in range(40):
             sts = ffi.group_step(grp, p)
@@ -132,7 +132,7 @@ def test_chained_solves_on_slabs_are_bit_identical_to_the_two_wait_form(product_
             assert np.array_equal(a.download(f), b.download(f)), f
 
 
-def test_record_sweeps_with_masses_one_ulp_apart_stay_within_rounding_of_the_generic_sweeps(product_lib, monkeypatch):
+def test_record_sweeps_with_masses_one_ulp_apart_stay_within_rounding_of_the_generic_sweeps(lab_lib, monkeypatch):
     """OpPressureAccelU / OpJacobiU take ONE mass for every neighbour (slot 0's, respectively the particle's own): exact when the masses
     are equal.  h = 1.9 sqrt(m / (rho0 pi)) loses a bit, so masses that are neighbouring floats still give bit-identical smoothing
     lengths -- the record path stays on -- and the substitution is then a relative error of one ulp per pair.  Bound it: the same
@@ -153,7 +153,7 @@ def test_record_sweeps_with_masses_one_ulp_apart_stay_within_rounding_of_the_gen
         if generic:
             monkeypatch.setenv("SPH_ACCEL_GENERIC", "1")
             monkeypatch.setenv("SPH_JACOBI_GENERIC", "1")
-        g = ffi.Context(product_lib, len(mass2), sc.boundary_planes(scn.boundary, P.init_boundary_handler))
+        g = ffi.Context(lab_lib, len(mass2), sc.boundary_planes(scn.boundary, P.init_boundary_handler))
         g.upload(mass2, pos, vel)
         its = []
         for _ in range(10):
@@ -172,7 +172,7 @@ def test_record_sweeps_with_masses_one_ulp_apart_stay_within_rounding_of_the_gen
 
 @pytest.mark.parametrize("compression", [1.0, 0.85, 0.66])
 @pytest.mark.parametrize("solver", ["HybridDFSPH", "IISPH"])
-def test_offset_lists_are_bit_identical_to_the_mask_words(product_lib, monkeypatch, solver, compression):
+def test_offset_lists_are_bit_identical_to_the_mask_words(lab_lib, monkeypatch, solver, compression):
     """The two sweeps of a Jacobi iteration on 16-bit relative offsets (k_sweep_off: no mask decoding, no row bases; padding slots =
     the particle itself) against the replay of the mask words (SPH_OFFSET_LISTS=0): same visiting order, same arithmetic, so every
     field and every iteration statistic agree bit for bit over free-running steps.  compression < 1: a lattice squeezed below its
@@ -194,7 +194,7 @@ def test_offset_lists_are_bit_identical_to_the_mask_words(product_lib, monkeypat
     for form in ("offsets", "masks"):
         if form == "masks":
             monkeypatch.setenv("SPH_OFFSET_LISTS", "0")
-        g = ffi.Context(product_lib, len(mass), planes)   # (the switches are read at sph_create)
+        g = ffi.Context(lab_lib, len(mass), planes)   # (the switches are read at sph_create)
         if form == "masks":
             monkeypatch.delenv("SPH_OFFSET_LISTS")
         g.upload(mass, pos, vel)
@@ -217,7 +217,7 @@ def test_offset_lists_are_bit_identical_to_the_mask_words(product_lib, monkeypat
 
 
 @pytest.mark.parametrize("solver", ["HybridDFSPH", "IISPH"])
-def test_offset_lists_in_a_multi_resolution_scene(product_lib, monkeypatch, solver):
+def test_offset_lists_in_a_multi_resolution_scene(lab_lib, monkeypatch, solver):
     """Two particle sizes (4:1): the bulk has mask lists and replays them as offsets (FAST math: h_ij from the gathered records), the
     interface particles keep their explicit index lists inside the same launches.  Bit for bit the mask replay."""
     fine = 0.02
@@ -232,7 +232,7 @@ def test_offset_lists_in_a_multi_resolution_scene(product_lib, monkeypatch, solv
     for form in ("offsets", "masks"):
         if form == "masks":
             monkeypatch.setenv("SPH_OFFSET_LISTS", "0")
-        g = ffi.Context(product_lib, len(mass), planes)
+        g = ffi.Context(lab_lib, len(mass), planes)
         if form == "masks":
             monkeypatch.delenv("SPH_OFFSET_LISTS")
         g.upload(mass, pos, vel)
@@ -250,3 +250,24 @@ def test_offset_lists_in_a_multi_resolution_scene(product_lib, monkeypatch, solv
             assert np.array_equal(fa[f], fb[f]), (s, f)
     forms = out["offsets"][2]
     assert forms["n_mask"] > 0 and forms["n_index"] > 0, forms     # both list forms are in the scene
+
+
+def test_the_laboratory_build_runs_the_products_defaults(product_lib, lab_lib):
+    """libsph_lab.so is libsph_hip.so's sources with the ablation switches compiled in (-DSPH_LAB); with no switch set it must BE the
+    product: the same exported symbols, and 25 free-running steps of a dam break bit for bit -- so that what the tests above establish
+    about the laboratory build's default forms holds for the library that ships."""
+    assert [n for n in ffi.ABI_SYMBOLS if not hasattr(lab_lib.lib, "sph_" + n)] == []
+    scn = sc.dam_break_small(128, 96, 1 / 64)
+    pos, mass, vel = sc.init_particles(scn)
+    planes = sc.boundary_planes(scn.boundary)
+    p = dam_break_params().to_ffi()
+    a, b = ffi.Context(product_lib, len(mass), planes), ffi.Context(lab_lib, len(mass), planes)
+    a.upload(mass, pos, vel)
+    b.upload(mass, pos, vel)
+    for s in range(25):
+        sa, sb = a.step(p), b.step(p)
+        assert (sa.dt, int(sa.div_solver.iters), int(sa.density_solver.iters)) == (sb.dt, int(sb.div_solver.iters), int(sb.density_solver.iters)), s
+    for f in ("position", "velocity", "density", "pressure", "aii", "neighbor_count"):
+        assert np.array_equal(a.download(f), b.download(f)), f
+    # ... and the product IGNORES the laboratory's switches: sph_set_sweep_variant refuses the LDS-staged forms there
+    assert product_lib.set_sweep_variant(3) == 30 and lab_lib.set_sweep_variant(0) == 0

@@ -24,7 +24,7 @@ def scene_of(kind):
 
 
 @pytest.mark.parametrize("kind,solver,steps", [("column", "HybridDFSPH", 40), ("thrown", "HybridDFSPH", 30), ("collide", "IISPH", 30), ("thrown", "OnlyDivergence", 30)])
-def test_incremental_cell_sort_is_the_radix_sort(product_lib, monkeypatch, kind, solver, steps):
+def test_incremental_cell_sort_is_the_radix_sort(lab_lib, monkeypatch, kind, solver, steps):
     scn, over = scene_of(kind)
     pos, mass, vel = sc.init_particles(scn)
     P = dam_break_params(pressure_solver_method=solver, **over)
@@ -34,7 +34,7 @@ def test_incremental_cell_sort_is_the_radix_sort(product_lib, monkeypatch, kind,
     for form in ("merge", "radix"):
         if form == "radix":
             monkeypatch.setenv("SPH_INC_SORT", "0")
-        g = ffi.Context(product_lib, len(mass), planes)   # (the switches are read at sph_create)
+        g = ffi.Context(lab_lib, len(mass), planes)   # (the switches are read at sph_create)
         if form == "radix":
             monkeypatch.delenv("SPH_INC_SORT")
         g.upload(mass, pos, vel)
@@ -77,7 +77,7 @@ LEVEL = dict(level_estimation_method="EmptyAngle", maximum_surface_distance=0.2,
 @pytest.mark.parametrize("kind,solver,level", [("column", "HybridDFSPH", None), ("two_sizes", "HybridDFSPH", None), ("two_sizes", "IISPH", None),
                                                ("column", "HybridDFSPH", dict(LEVEL)), ("two_sizes", "IISPH", dict(LEVEL)),
                                                ("column", "IISPH", dict(LEVEL, level_estimation_after_advection=True))])
-def test_build_queued_ahead_is_the_build_at_the_step_start(product_lib, monkeypatch, kind, solver, level):
+def test_build_queued_ahead_is_the_build_at_the_step_start(lab_lib, monkeypatch, kind, solver, level):
     """The next step's neighbour build queued behind the integrating tail on a PREDICTED grid (another origin, a margin around the
     bounding box; in a multi-resolution scene other tiles, hence other stencil widths for the same lists) against the build at the
     start of the step (SPH_AHEAD_BUILD=0): every field, every iteration statistic and every neighbour list bit for bit.  With the
@@ -92,7 +92,7 @@ def test_build_queued_ahead_is_the_build_at_the_step_start(product_lib, monkeypa
     for form in ("ahead", "at-start"):
         if form == "at-start":
             monkeypatch.setenv("SPH_AHEAD_BUILD", "0")
-        g = ffi.Context(product_lib, len(mass), planes)
+        g = ffi.Context(lab_lib, len(mass), planes)
         if form == "at-start":
             monkeypatch.delenv("SPH_AHEAD_BUILD")
         g.upload(mass, pos, vel)
@@ -122,7 +122,7 @@ def test_build_queued_ahead_is_the_build_at_the_step_start(product_lib, monkeypa
 
 
 @pytest.mark.parametrize("k,two_sizes", [(2, False), (3, False), (2, True)])
-def test_slab_ranks_sort_by_merging_their_arrivals(product_lib, monkeypatch, k, two_sizes):
+def test_slab_ranks_sort_by_merging_their_arrivals(lab_lib, monkeypatch, k, two_sizes):
     """A slab rank behind its fused refresh: last step's sorted slots (some of them left: last step's ghosts, migrants), then this
     step's arrivals (migrants, the new ghost layer) unsorted behind them.  The merge with the arrivals as movers against the radix
     sort (SPH_INC_SORT=0) on a loopback group whose fluid is pushed across the cuts: every rank's arrays bit for bit."""
@@ -142,7 +142,7 @@ def test_slab_ranks_sort_by_merging_their_arrivals(product_lib, monkeypatch, k, 
     for form in ("merge", "radix"):
         if form == "radix":
             monkeypatch.setenv("SPH_INC_SORT", "0")
-        grp = D.make_loopback_group(product_lib, pos, mass, vel, planes, k)
+        grp = D.make_loopback_group(lab_lib, pos, mass, vel, planes, k)
         if form == "radix":
             monkeypatch.delenv("SPH_INC_SORT")
         for c in grp:

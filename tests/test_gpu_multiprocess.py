@@ -128,5 +128,7 @@ if out["1"][1] is not None:
         assert np.array_equal(out["1"][1][f], out["0"][1][f]), f
 print("CLEAN", flush=True)
 ''' % str(REPO)
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    from adaptive_sph_amd import build
+    build.build_lab()   # (SPH_AHEAD_BUILD is a laboratory switch: both runs on libsph_lab.so, whose default IS the product's path)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, SPH_HIP_LIBRARY="libsph_lab.so"))
     assert r.returncode == 0 and "CLEAN" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-2500:])

@@ -963,7 +963,7 @@ def test_reference_media_recipes(product_lib, oracle_lib, name):
 
 
 @pytest.mark.parametrize("scene_name", ["uniform", "two_sizes", "ratio12", "default_scene"])
-def test_level_propagation_on_the_compacted_frontier_is_the_sweep_form(product_lib, monkeypatch, scene_name):
+def test_level_propagation_on_the_compacted_frontier_is_the_sweep_form(lab_lib, monkeypatch, scene_name):
     """The propagation over a queue of candidates (k_level_frontier: G lanes per candidate, pushes deduplicated by atomicMax) against
     the sweeps over all particles with frontier marks (SPH_LEVEL_QUEUE=0): every level-estimation output bit for bit, the same number
     of sweeps, over several steps.  "ratio12": coarse particles with more neighbours than an index list holds -- the queue's
@@ -992,7 +992,7 @@ def test_level_propagation_on_the_compacted_frontier_is_the_sweep_form(product_l
     for form in ("queue", "sweeps"):
         if form == "sweeps":
             monkeypatch.setenv("SPH_LEVEL_QUEUE", "0")
-        ctx[form] = ffi.Context(product_lib, len(mass), planes)   # (the switches are read at sph_create)
+        ctx[form] = ffi.Context(lab_lib, len(mass), planes)   # (the switches are read at sph_create)
         if form == "sweeps":
             monkeypatch.delenv("SPH_LEVEL_QUEUE")
         ctx[form].upload(mass, pos, vel)
@@ -1155,18 +1155,18 @@ def test_exact_math_policy(product_lib, oracle_lib, monkeypatch, case):
 
 
 @pytest.mark.parametrize("solver", ["HybridDFSPH", "IISPH"])
-def test_lds_staged_sweeps_are_bit_identical_to_the_gather_form(product_lib, solver):
+def test_lds_staged_sweeps_are_bit_identical_to_the_gather_form(lab_lib, solver):
     """sph_set_sweep_variant: the LDS-staged form of the sweeps (the wave's three candidate rows loaded once into LDS) visits the
     same pairs in the same order with the same arithmetic as the per-lane gather form: every field agrees to the last bit, also
     where waves fall back (row ends, crowded cells after the column has collapsed against the wall)."""
     out = {}
     for mode in (0, 3):
-        assert product_lib.set_sweep_variant(mode) == 0
+        assert lab_lib.set_sweep_variant(mode) == 0
         scn = sc.dam_break_small(96, 80, 1 / 96)
         pos, mass, vel = sc.init_particles(scn)
         vel = vel.copy()
         vel[:, 0] = -3.0                                   # into the wall: compressed, crowded cells
-        g = ffi.Context(product_lib, len(mass), sc.boundary_planes(scn.boundary))
+        g = ffi.Context(lab_lib, len(mass), sc.boundary_planes(scn.boundary))
         g.upload(mass, pos, vel)
         p = dam_break_params(pressure_solver_method=solver, check_neighborhood=True).to_ffi()
         iters = []
@@ -1176,7 +1176,7 @@ def test_lds_staged_sweeps_are_bit_identical_to_the_gather_form(product_lib, sol
         off, idx = g.download_neighbors()
         out[mode] = (iters, off, idx) + tuple(g.download(f) for f in ALL_FIELDS + ["neighbor_count", "lambda_sum", "constant_field"])
         g.close()
-    product_lib.set_sweep_variant(0)
+    lab_lib.set_sweep_variant(0)
     assert out[0][0] == out[3][0]
     for a, b in zip(out[0][1:], out[3][1:]):
         assert np.array_equal(a, b)

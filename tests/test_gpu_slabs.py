@@ -166,7 +166,7 @@ def test_level_estimation_on_slabs(product_lib, k):
 
 
 @pytest.mark.parametrize("k", [2, 3])
-def test_slab_level_propagation_in_frontier_form_equals_the_plain_form(product_lib, monkeypatch, k):
+def test_slab_level_propagation_in_frontier_form_equals_the_plain_form(lab_lib, monkeypatch, k):
     """The propagation on slabs runs in the frontier form -- marked candidates plus every unassigned halo member probing its list,
     a probing lane that is assigned marks its neighbours in a second pass (OpLevelPropagate, mode 2) -- and moves (level, when) of
     the ghosts in ONE exchange per sweep.  SPH_SLAB_LEVEL_PLAIN=1 is the reference's form, every unassigned particle in every
@@ -183,7 +183,7 @@ def test_slab_level_propagation_in_frontier_form_equals_the_plain_form(product_l
     for form in ("frontier", "plain"):
         if form == "plain":
             monkeypatch.setenv("SPH_SLAB_LEVEL_PLAIN", "1")
-        grp = D.make_loopback_group(product_lib, pos, mass, vel, planes, k)
+        grp = D.make_loopback_group(lab_lib, pos, mass, vel, planes, k)
         for s in range(10):
             ffi.group_step(grp, p)
         out[form] = ({f: D.gather_by_id(grp, f, len(mass)) for f in ("level_estimation", "level_old", "flag_is_fluid_surface", "position")},
@@ -322,7 +322,7 @@ def test_profiling_a_slab_group(product_lib):
     ffi.group_step(grp, p)
 
 
-def test_fused_refresh_is_bit_identical_to_the_general_path(product_lib, monkeypatch):
+def test_fused_refresh_is_bit_identical_to_the_general_path(lab_lib, monkeypatch):
     """Ordinary steps maintain the slabs in one round trip (classify once, arrivals appended, the cell sort drops what left);
     the general path (SPH_SLAB_GENERAL: partition sort + reorder, then the halo selection -- also what the first step, re-balancing
     steps and FromDistribution* support lengths take) must leave the same particles in the same order: every field bit for bit."""
@@ -336,7 +336,7 @@ def test_fused_refresh_is_bit_identical_to_the_general_path(product_lib, monkeyp
     for name in ("fused", "general"):
         if name == "general":
             monkeypatch.setenv("SPH_SLAB_GENERAL", "1")
-        grp = D.make_loopback_group(product_lib, pos, mass, vel, planes, 3)
+        grp = D.make_loopback_group(lab_lib, pos, mass, vel, planes, 3)
         for c in grp:
             c.profile_enable(1)
         moved = 0
@@ -669,7 +669,7 @@ def test_ranks_on_threads_exchange_point_to_point(product_lib):
 
 
 @pytest.mark.parametrize("mode", ["rebalance", "after_advection", "from_distribution", "general_path"])
-def test_ranks_on_threads_other_step_variants(product_lib, monkeypatch, mode):
+def test_ranks_on_threads_other_step_variants(lab_lib, monkeypatch, mode):
     """The same per-rank execution for the steps that take other collectives: re-balancing (x range, histogram, migration
     rounds), level estimation after advection (all-reduced displacement, widened ghost layer), FromDistribution support lengths
     (header launch + two-round slab maintenance every step), and the general slab maintenance forced on every step."""
@@ -687,8 +687,8 @@ def test_ranks_on_threads_other_step_variants(product_lib, monkeypatch, mode):
     if mode == "general_path":
         monkeypatch.setenv("SPH_SLAB_GENERAL", "1")
     p = forced(max_iters=4, **kw).to_ffi()
-    loop = D.make_loopback_group(product_lib, pos, mass, vel, planes, 3)
-    thr = D.ThreadedGroup(product_lib, pos, mass, vel, planes, 3)
+    loop = D.make_loopback_group(lab_lib, pos, mass, vel, planes, 3)
+    thr = D.ThreadedGroup(lab_lib, pos, mass, vel, planes, 3)
     try:
         if mode == "rebalance":
             for c in loop + thr.contexts:
@@ -710,7 +710,7 @@ def test_ranks_on_threads_other_step_variants(product_lib, monkeypatch, mode):
 @pytest.mark.parametrize("solver,extra", [("IISPH", {}), ("IISPH2", dict(max_dt=0.0005)), ("OnlyDivergence", {}),
                                           ("HybridDFSPH", dict(hybrid_dfsph_non_pressure_accel_before_divergence_free=False)),
                                           ("HybridDFSPH", dict(check_neighborhood=True, check_aii=True))])
-def test_ranks_on_threads_every_solver_mode(product_lib, monkeypatch, solver, extra):
+def test_ranks_on_threads_every_solver_mode(lab_lib, monkeypatch, solver, extra):
     """Every sequencing of the step, per rank on its own thread, chained solves forced on (SPH_CHAIN=1: the gated second solve and
     its short-fall path run on every rank together or not at all) -- bit for bit the loopback group."""
     monkeypatch.setenv("SPH_CHAIN", "1")
@@ -720,8 +720,8 @@ def test_ranks_on_threads_every_solver_mode(product_lib, monkeypatch, solver, ex
     vel[:, 0] = 0.8
     planes = sc.boundary_planes(scn.boundary)
     p = dam_break_params(pressure_solver_method=solver, **extra).to_ffi()
-    loop = D.make_loopback_group(product_lib, pos, mass, vel, planes, 3)
-    thr = D.ThreadedGroup(product_lib, pos, mass, vel, planes, 3)
+    loop = D.make_loopback_group(lab_lib, pos, mass, vel, planes, 3)
+    thr = D.ThreadedGroup(lab_lib, pos, mass, vel, planes, 3)
     try:
         for s in range(15):
             a = ffi.group_step(loop, p)
