@@ -703,7 +703,8 @@ extern "C" int sph_upload(sph_ctx* c, uint64_t n, const float* mass, const float
     c->poisoned = false;
     c->dist.have_flags = false;
     c->dist.n_tot = (uint32_t)n;
-    c->grid_valid = false;
+    c->grid_valid = false;   // lists, cell indices and per-step outputs belong to the vector before this call
+    if (c->ctrl_host) ((uint32_t*)(c->ctrl_host + 2))[1] = 0u;   // ... and so does the incremental sort's last mover count (advisor r4)
     c->have_level = false;
     c->have_reduced = false;
     c->lists_after = false;
@@ -1034,7 +1035,8 @@ int regather_host_order(sph_ctx* c, uint32_t n_new, const EditSrc* d_src, const 
     c->dist.n_tot = n_new;
     c->dist.have_flags = false;   // (slab context: owned particles only, in row order; the next step selects new ghosts)
     c->dist.n_ghost[0] = c->dist.n_ghost[1] = c->dist.n_halo[0] = c->dist.n_halo[1] = 0;
-    c->grid_valid = false;   // lists, cell indices and per-step outputs belong to the vector before the edit
+    c->grid_valid = false;   // lists, cell indices and per-step outputs belong to the vector before this call
+    if (c->ctrl_host) ((uint32_t*)(c->ctrl_host + 2))[1] = 0u;   // ... and so does the incremental sort's last mover count (advisor r4)
     c->have_level = false;
     c->have_reduced = false;
     c->lists_after = false;

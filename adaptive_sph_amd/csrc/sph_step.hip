@@ -911,7 +911,7 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
         const uint32_t n_prev = pre ? c->dist.pre_cls_n : 0u;
         uint32_t* movers_host = (uint32_t*)(c->ctrl_host + 2) + 1;
         bool merge = pre && c->opt.inc_sort && prev_valid && prev_grid.cs == g.cs && prev_grid.ncells > 0 && n_prev > 0 && n_prev <= n_sort && !c->exact &&
-                     g.ncells <= 4u * n_sort + 4096u;
+                     g.ncells <= n_sort + 4096u;   // (k_inc_scan adds up the preceding block sums per block: quadratic in ncells / 1024 -- a sparse grid takes the radix sort; advisor r4)
         if (merge) {
             const uint32_t limit = n_sort / (c->opt.inc_sort > 1 ? (uint32_t)c->opt.inc_sort : 3u);
             if (n_sort - n_prev > limit) merge = false;
@@ -1567,7 +1567,7 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
         // and cell ranges as the radix sort, whatever the number of movers; its cost grows with them, so a large count (the last one
         // the device reported: a step or two old) sends the build through the radix sort, and every eighth such build probes again.
         const uint32_t* movers_host = (const uint32_t*)(c->ctrl_host + 2) + 1;   // (second word of the mapped block whose first word is the paced solves' progress)
-        bool incremental = c->opt.inc_sort && c->grid_valid && c->fgrid.cs == cs && c->fgrid.ncells > 0 && g.ncells <= 4u * n + 4096u;
+        bool incremental = c->opt.inc_sort && c->grid_valid && c->fgrid.cs == cs && c->fgrid.ncells > 0 && g.ncells <= n + 4096u;   // (see k_inc_scan: quadratic in ncells / 1024; a grid much sparser than one cell per particle takes the radix sort)
         if (incremental && *movers_host > n / (c->opt.inc_sort > 1 ? (uint32_t)c->opt.inc_sort : 3u)) {
             incremental = ++c->inc_radix_streak >= 8;
             if (incremental) c->inc_radix_streak = 0;

@@ -326,22 +326,33 @@ def rank_single_step_adaptivity_on_slabs(ctx: ffi.Context, P, dt: float, step_nu
     from .adaptivity import adapt_params
     if P.support_length_estimation != "FromMass":
         raise ValueError("rank_single_step_adaptivity_on_slabs: support_length_estimation must be FromMass")
+    import time
     rank, world = dist.get_rank(), dist.get_world_size()
     p, ap = P.to_ffi(), adapt_params(P, dt)
+    # where the adaptive step's time goes (this rank's clock): device -> host (lists, fields), the launcher's
+    # gather / broadcast (pickled numpy arrays), the host's partner search on the root, the apply calls on the slabs
+    tm = {"download_s": 0.0, "gather_broadcast_s": 0.0, "host_decide_s": 0.0, "apply_s": 0.0}
+    t0 = time.perf_counter()
     lists_mine = ctx.download_neighbors()
     ids_mine = ctx.download("particle_id")
+    tm["download_s"] += time.perf_counter() - t0
     state = {"lists": None, "n": 0}
 
     def decide(kind):
         """-> (merge_partner, merge_counter) of the whole vector on every rank"""
+        t0 = time.perf_counter()
         ctx.classify(p)
         mine = {f: ctx.download(f) for f in ("particle_size_class", "mass", "level_estimation", "position", "h2")}
+        tm["download_s"] += time.perf_counter() - t0
         mine["particle_id"] = ids_mine
         if state["lists"] is None:
             mine["lists"] = lists_mine
         parts = [None] * world if rank == root else None
+        t0 = time.perf_counter()
         dist.gather_object(mine, parts, dst=root)
+        tm["gather_broadcast_s"] += time.perf_counter() - t0
         out = [None]
+        t0 = time.perf_counter()
         if rank == root:
             try:
                 n = int(sum(len(q["particle_id"]) for q in parts))
@@ -361,7 +372,10 @@ def rank_single_step_adaptivity_on_slabs(ctx: ffi.Context, P, dt: float, step_nu
                 out = [(None, (type(e).__name__, e.status if isinstance(e, ffi.SphError) else None, str(e)))]
         else:
             state["lists"] = True   # (only the root keeps them)
+        tm["host_decide_s"] += time.perf_counter() - t0
+        t0 = time.perf_counter()
         dist.broadcast_object_list(out, src=root)
+        tm["gather_broadcast_s"] += time.perf_counter() - t0
         if out[0][0] is None:
             kind_, code, msg = out[0][1]
             if code is not None:
@@ -377,19 +391,25 @@ def rank_single_step_adaptivity_on_slabs(ctx: ffi.Context, P, dt: float, step_nu
     n_before = total(ctx.n)
     info = {"n_before": n_before, "shares": 0, "merges": 0, "splits": 0}
     m1 = total(float(ctx.download("mass").sum(dtype=np.float64)))
+    def apply(f, *a):
+        t0 = time.perf_counter()
+        f(*a)
+        tm["apply_s"] += time.perf_counter() - t0
+
     if P.sharing:
         mp, mc = decide("share")
         info["shares"] = int(mc.sum())
-        ctx.share_particles(p, ap, mp, mc)
+        apply(ctx.share_particles, p, ap, mp, mc)
     if step_number % 2 == 0:
         if P.merging:
             mp, mc = decide("merge")
             info["merges"] = int(mc.sum())
-            ctx.merge_particles(p, ap, mp, mc)
+            apply(ctx.merge_particles, p, ap, mp, mc)
     elif P.splitting:
-        ctx.classify(p)
-        ctx.split_particles(p, ap)
+        apply(ctx.classify, p)
+        apply(ctx.split_particles, p, ap)
     info["n_after"] = total(ctx.n)
+    info["seconds"] = tm
     info["splits"] = max(0, info["n_after"] - n_before) if step_number % 2 == 1 else 0
     m2 = total(float(ctx.download("mass").sum(dtype=np.float64)))
     if not abs(m1 - m2) <= 0.005:

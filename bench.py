@@ -502,14 +502,18 @@ def main():
                 barrier()
                 t0 = time.perf_counter()
                 ev = {"shares": 0, "merges": 0, "splits": 0}
+                brk = {}
                 for _ in range(2):
                     st = c4.step(P4.to_ffi())
                     info = rank_single_step_adaptivity_on_slabs(c4, P4, float(st.dt), int(st.step_number))
                     for k in ev:
                         ev[k] += info[k]
+                    for k, v in info["seconds"].items():
+                        brk[k] = brk.get(k, 0.0) + v / 2
                 barrier()
                 config4["single_step_with_adaptivity"] = {"steps": 2, "ms_per_step": (time.perf_counter() - t0) * 1e3 / 2, "events": ev,
-                                                          "particles_after": info["n_after"], "note": "rank 0's clock; decisions on rank 0's host, apply on the slabs"}
+                                                          "particles_after": info["n_after"], "breakdown_s_per_step_rank0": brk,
+                                                          "note": "rank 0's clock; decisions on rank 0's host (download = device -> host of lists and fields, gather_broadcast = the launcher's pickled gather / broadcast, host_decide = the sequential partner searches), apply on the slabs"}
         except (ffi.SphError, RuntimeError) as e:   # a refusal taken on all-reduced values, or a failure of the adaptive step's root that
             config4["refused"] = str(e)[:300]         # rank_single_step_adaptivity re-raises on every rank: every rank is here
         finally:
