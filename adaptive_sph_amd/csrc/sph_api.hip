@@ -551,6 +551,8 @@ Options options_from_env()
     o.inc_sort = num("SPH_INC_SORT", 1);
     o.slab_paced = num("SPH_SLAB_PACED", 1) != 0 ? 1 : 0;
     o.slab_records = num("SPH_SLAB_RECORDS", 1) != 0 ? 1 : 0;
+    o.side_cus = num("SPH_SIDE_CUS", 0);
+    o.main_exclude = num("SPH_MAIN_EXCLUDE", 0) != 0 ? 1 : 0;
 #endif
     return o;
 }
@@ -573,7 +575,17 @@ extern "C" int sph_create(uint64_t n_capacity, int device_id, const sph_plane* p
         sph_destroy(c);
         return code;
     };
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return bail(SPH_ERR_DEVICE);
+    // (lab) CU masks: bit i of the mask = CU i / 8 of XCD i % 8 (the dispatcher's round-robin over the 8 XCDs); the side stream gets the
+    // first `side_cus` CUs of every XCD, the main stream -- if asked -- everything else
+    uint32_t side_mask[8] = {0, 0, 0, 0, 0, 0, 0, 0}, main_mask[8];
+    for (int b = 0; b < 8 * c->opt.side_cus && b < 256; b++) side_mask[b >> 5] |= 1u << (b & 31);
+    for (int w = 0; w < 8; w++) main_mask[w] = ~side_mask[w];
+    if (c->opt.side_cus > 0 && c->opt.main_exclude) {
+        if (hipExtStreamCreateWithCUMask(&c->stream, 8, main_mask) != hipSuccess) return bail(SPH_ERR_DEVICE);
+    } else if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return bail(SPH_ERR_DEVICE);
+    if (c->opt.side_cus > 0) {
+        if (hipExtStreamCreateWithCUMask(&c->stream2, 8, side_mask) != hipSuccess) return bail(SPH_ERR_DEVICE);
+    } else
     {
         // the side stream carries the level-set propagation: ~100 tiny dependent launches that must slot in between the waves of
         // the main stream's sweeps -- highest priority, so that the dispatcher serves it first whenever a CU has room

@@ -78,6 +78,8 @@ struct Options {
     int debug_counts = 0;       // SPH_DEBUG_COUNTS         print the fused refresh's counts
     int comm_delay_us = 0;      // SPH_DEBUG_COMM_DELAY_US  loopback transport: every exchange / all-reduce occupies its stream that long
     int hip_trace = 0;          // SPH_HIP_TRACE=1          host-side timeline of the step
+    int side_cus = 0;           // SPH_SIDE_CUS=<k>         (lab) the side stream (level-set propagation) owns k CUs of every XCD through a CU mask (0: no mask)
+    int main_exclude = 0;       // SPH_MAIN_EXCLUDE=1       (lab) ... and the main stream is masked OFF those CUs
 };
 Options options_from_env();   // sph_api.hip
 

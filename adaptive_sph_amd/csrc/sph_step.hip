@@ -1121,10 +1121,18 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
             }
         }
         if (m.n) {
-            if (p->fill_stash_with == SPH_STASH_NONE) (void)hipMemsetAsync(c->stash.p, 0, n * 4, ls);
+            // (lab, SPH_SIDE_CUS: the side stream owns a few CUs -- the heavy detection sweeps then run on the MAIN stream, and only the
+            //  propagation's ~100 small dependent launches go to the side stream, behind an event)
+            const bool masked_side = side && c->opt.side_cus > 0;
+            hipStream_t ds = masked_side ? c->stream : ls;
+            if (p->fill_stash_with == SPH_STASH_NONE) (void)hipMemsetAsync(c->stash.p, 0, n * 4, ds);
             // (the CenterDiff detector leaves flag_insufficient_neighs alone: its default, false)
-            if (lv.center_diff) (void)hipMemsetAsync(c->flag_insufficient.p, 0, n, ls);
-            launch_level_detect(ls, &c->prof, al, lv);
+            if (lv.center_diff) (void)hipMemsetAsync(c->flag_insufficient.p, 0, n, ds);
+            launch_level_detect(ds, &c->prof, al, lv);
+            if (masked_side) {
+                HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+                HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+            }
             // propagate until a sweep assigns nothing (`while changed`, simulation.rs:740-800).  Sweeps are queued in batches and the
             // host learns once per batch how many of them assigned something (a sweep behind the last effective one has no
             // candidates and costs a scan).  The first batch is as long as the previous step's propagation + 1 -- the fluid's

@@ -88,18 +88,25 @@ def test_config3_dam_break_8m_eight_slabs_against_the_single_context(product_lib
         assert rel_err(D.gather_by_id(grp, f, n), single.download(f)) <= tol, f
     st = grp[3].dist_get_stats()
     assert st["n_ghost"][0] > 0 and st["n_ghost"][1] > 0 and st["exchanges"] > 0    # an inner slab has two neighbours
-    # the slabs' neighbour lists (global ids, ghosts included) are the single context's: per particle equal counts, equal sums
-    # and sums of squares of the neighbour ids (exact integer arithmetic)
+    # the slabs' neighbour lists (global ids, ghosts included) are the single context's ENTRY BY ENTRY (this test
+    # compared counts, sums and sums of squares until round 5): (row = global particle id, neighbour id) packed into one 64-bit key per
+    # entry, sorted, compared whole -- 109 M entries over the eight slabs
     so, si = single.download_neighbors()
-    starts = so[:-1].astype(np.int64)
-    ref = [np.add.reduceat(si.astype(np.uint64) ** power, starts) for power in (1, 2)]
+    cnt_ref = np.diff(so.astype(np.int64))
+    key_ref = (np.repeat(np.arange(n, dtype=np.uint64), cnt_ref) << np.uint64(32)) | si.astype(np.uint64)
     del si
+    key_ref.sort()
+    keys = []
     for c in grp:
         pid = c.download("particle_id")
         off, idx = c.download_neighbors()
-        assert np.array_equal(np.diff(off.astype(np.int64)), np.diff(so.astype(np.int64))[pid])
-        for power in (1, 2):
-            assert np.array_equal(np.add.reduceat(idx.astype(np.uint64) ** power, off[:-1].astype(np.int64)), ref[power - 1][pid]), power
+        assert np.array_equal(np.diff(off.astype(np.int64)), cnt_ref[pid])
+        keys.append((np.repeat(pid.astype(np.uint64), np.diff(off.astype(np.int64))) << np.uint64(32)) | idx.astype(np.uint64))
+        del off, idx
+    key_grp = np.concatenate(keys)
+    del keys
+    key_grp.sort()
+    assert np.array_equal(key_grp, key_ref)
 
 
 def test_config4_ratio_stress_4m_step_path_on_eight_slabs(product_lib):

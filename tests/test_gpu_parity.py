@@ -699,9 +699,16 @@ def test_bench_window_of_config1_against_the_oracle(product_lib, oracle_lib, mon
     the product's default arithmetic (v_rsq / v_rcp, truncated-power spline, the single-mass record sweeps) is NOT what separates
     device and oracle.  A third run, the ORDER twin (the same particles uploaded in a random order: the stable cell sort then orders
     every cell -- and every neighbour sum -- differently), stays ~30 x closer to the device than the oracle does (counts 0.04 apart,
-    p99 density 9e-5): reordering inside cells is not it either.  What is left is the one event the report shows: at step 4 the
-    divergence solve's stop rule sees a near-tie (asserted below: both sides' average residual within 1 % of the threshold and of
-    each other), the oracle iterates once more, and the violent steps amplify that like they amplify the one-ulp twin's flips."""
+    p99 density 9e-5): reordering INSIDE cells is not it either.
+
+    ROUND 5 settled what is (scripts/gpu_normal_count.py, profiles/r5_normal_count.md): the ORIENTATION of the neighbour sums.  At step 4
+    the divergence solve's stop rule divides a stable residual sum (137 893 on both sides) by the number of "normal" particles, and that
+    number is decided by rounding for tens of thousands of particles whose new pressure is zero up to the last bit: the ORACLE AGAINST
+    ITSELF counts 51 753 ... 78 944 of them for the same state uploaded in four orders; with the reference's arithmetic (EXACT) and the
+    oracle summing in the device's visiting order the device IS the oracle -- counts, pressures, accelerations, densities of all
+    1 048 576 particles bit for bit -- which tests/test_gpu_bitexact.py asserts for the whole window, step by step.  THIS test keeps
+    the comparison in HOST order with the product's default arithmetic as what it is: two correct evaluations of the reference's
+    algorithm that a chaotic window drives apart like a one-ulp twin."""
     if policy == "exact":
         monkeypatch.setenv("SPH_HIP_EXACT", "1")   # (read by sph_create: both device contexts below)
     scn = sc.dam_break_1m()
