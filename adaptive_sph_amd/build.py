@@ -44,7 +44,9 @@ def build_hip(force: bool = False, verbose: bool = False, out_name: str = "libsp
     srcs = sorted(CSRC.glob("*.hip"))
     headers = sorted(CSRC.glob("*.h")) + sorted(CSRC.glob("*.hpp")) + [REPO / "include" / "sph_ffi.h"]
     extra = os.environ.get("SPH_EXTRA_HIPCC_FLAGS", "").split() + list(extra_flags)
-    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall",
+    # -fno-slp-vectorize: the SLP vectoriser turns pairs of scalar f32 operations into v_pk_* instructions and pays for each with register
+    # moves (73 v_mov in sweep B's hot path); without it the same arithmetic is 1-5 % faster per sweep (profiles/r5_variants.md section 3)
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize", "-Wall",
              "-I", str(REPO / "include")] + extra
     tag = hashlib.sha1(" ".join(flags).encode()).hexdigest()[:10]
     objdir = CSRC / "build" / tag

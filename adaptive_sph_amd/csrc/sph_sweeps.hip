@@ -48,6 +48,21 @@
 #ifndef SPH_FORCE_IDX
 #define SPH_FORCE_IDX 0
 #endif
+// SPH_OFF32 (round 5): the record gathers of the uniform-h Jacobi sweeps address their 16-byte records through a 32-bit BYTE offset from
+// the (uniform) base pointer -- `global_load_dwordx4 v, v_off, s[base]` -- instead of a 64-bit index: the zero-extension (one v_mov per
+// gather) and the 64-bit shift-add go, and sweep A's register count drops from 80 to 68.  Valid up to 2^28 particles (4 GB per record
+// array): larger contexts do not build offset lists (sweeps_want_offset_lists) and replay their mask words through the 64-bit form.
+#ifndef SPH_OFF32
+#define SPH_OFF32 1
+#endif
+__device__ __forceinline__ float4 load_record(const float4* __restrict__ base, uint32_t j)
+{
+#if SPH_OFF32
+    return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + (uint32_t)(j << 4));
+#else
+    return base[j];
+#endif
+}
 
 // Neighbour list word (one uint4 = 16 B per particle, coalesced 1 KB per wave):
 //   x, y, z : accepted-candidate bit masks of the three cell rows cy-1, cy, cy+1.  Bit b of row r
@@ -686,8 +701,16 @@ template <class Op, class = void>
 struct OpOffSelf : std::false_type {};
 template <class Op>
 struct OpOffSelf<Op, std::void_t<decltype(Op::OFF16_SELF)>> : std::bool_constant<Op::OFF16_SELF> {};
+// ops with `static constexpr int OFF_WAVES = 8` (the two record sweeps of a Jacobi iteration): the offset-list replay is compiled for that
+// many waves per SIMD.  Sweep A's twelve records in flight made it 80 VGPRs = 6 waves; with the 32-bit record addressing (load_record)
+// it fits 64 with one spilled register and runs 8 (round 5, A/B on one box: sweep B 17.15 -> 16.5 us, sweep A 14.5 -> 14.25; the same
+// bound on EVERY offset-list op spills the fused a_ii / force sweep to twice its time: profiles/r5_variants.md section 3)
+template <class Op, class = void>
+struct OpOffWaves : std::integral_constant<int, 1> {};
 template <class Op>
-__global__ __launch_bounds__(SWEEP_THREADS) void k_sweep_off(Op op, SweepCommon c)
+struct OpOffWaves<Op, std::void_t<decltype(Op::OFF_WAVES)>> : std::integral_constant<int, Op::OFF_WAVES> {};
+template <class Op>
+__global__ __launch_bounds__(SWEEP_THREADS, OpOffWaves<Op>::value) void k_sweep_off(Op op, SweepCommon c)
 {
     typedef typename Op::Math Math;
     static_assert(!Math::EXACT && (Op::SKIP_SELF || OpOffSelf<Op>::value) && !Op::EXTENDED, "k_sweep_off: gradient sweeps of the FAST / UNIFORM math policies");
@@ -1815,12 +1838,13 @@ struct OpPressureAccelU : OpPressureAccel<MathT> {
     static constexpr bool TILE = false, RING1 = true;   // (slab decomposition: the first ghost ring computes its own a^p, as in the base)
     static constexpr bool OFF16 = true;                 // (k_sweep_off: relative-offset lists)
     static constexpr int WIDE_TRIPS = 3;                // (measured: 3 and 2 alike, 1 is 1.3 % slower on the driver window)
+    static constexpr int OFF_WAVES = 8;                 // (see OpOffWaves)
     typedef NBNone NB;
     const float4* __restrict__ rec;   // of the pressure buffer this iteration reads (slabs: the ghosts' records carry their owners' p / rho^2, refreshed every iteration)
     struct Acc {
         float ax, ay, p1t, mass;
     };
-    __device__ float4 loadA(uint32_t j) const { return rec[j]; }
+    __device__ float4 loadA(uint32_t j) const { return load_record(rec, j); }
     __device__ NB nb(const Acc&, uint32_t, float4) const { return NB{}; }
     __device__ void init(Acc& a) const { a.mass = this->pm[0].z; }
     __device__ void begin(Acc& a, uint32_t, float4 Ai) const
@@ -2095,8 +2119,9 @@ struct OpJacobiU : OpJacobi<MathT> {
     static constexpr bool TILE = false;
     static constexpr bool OFF16 = true;   // (k_sweep_off: relative-offset lists)
     static constexpr int WIDE_TRIPS = 3;   // (OpJacobiU 18.2 -> 17.1 us)
+    static constexpr int OFF_WAVES = 8;    // (see OpOffWaves)
     typedef NBNone NB;
-    __device__ float4 loadA(uint32_t j) const { return this->pacc[j]; }
+    __device__ float4 loadA(uint32_t j) const { return load_record(this->pacc, j); }
     __device__ NB nb(const Acc&, uint32_t, float4) const { return NB{}; }
     __device__ void begin(Acc& a, uint32_t i, float4 Ai) const
     {
@@ -3189,7 +3214,8 @@ static int tile_mode(const SweepArgs& a) { return g_tile_mode >= 0 ? g_tile_mode
 // process): sweep A of such scenes through OpPressureAccel, the solves' p / rho^2 as a field of its own
 static bool jacobi_on_records(const SweepArgs& a)   // sweep B gathers {x, y, a^p} whole (OpJacobiU)
 {
-    return !a.exact && a.uniform_h && a.h_mode == SPH_H_FROM_MASS && a.sp.opdisc != SPH_OP_WINCHENBACH2020 && !a.opt_jacobi_generic;
+    return !a.exact && a.uniform_h && a.h_mode == SPH_H_FROM_MASS && a.sp.opdisc != SPH_OP_WINCHENBACH2020 && !a.opt_jacobi_generic &&
+           a.n <= (1u << 28);   // (the record sweeps address their records with 32-bit byte offsets: load_record)
 }
 static bool solve_on_records(const SweepArgs& a)    // ... and sweep A {x, y, p / rho^2, p} (OpPressureAccelU): not IISPH2
 {
@@ -3270,7 +3296,7 @@ size_t sweep_offset_list_bytes(uint32_t n) { return (size_t)n * sizeof(uint2) * 
 // gathered record per neighbour) gain at 1M and at 8M alike.
 bool sweeps_want_offset_lists(const SweepArgs& a)
 {
-    return !a.exact && !(tile_mode(a) & 1) && SPH_FORCE_IDX == 0 && (jacobi_on_records(a) || a.n <= (1u << 21));
+    return !a.exact && !(tile_mode(a) & 1) && SPH_FORCE_IDX == 0 && (jacobi_on_records(a) || a.n <= (1u << 21)) && a.n <= (1u << 28);   // (2^28: load_record's 32-bit byte offsets)
 }
 bool sweep_forces_index_lists() { return SPH_FORCE_IDX != 0; }
 uint32_t solver_reduce_blocks(uint32_t n) { return (n + SWEEP_THREADS - 1) / SWEEP_THREADS; }
