@@ -200,6 +200,10 @@ struct MathExact {
 //     (scalar) x grad W multiplies scalars first and needs two fma for the vector.
 // Stand-alone effect on the Jacobi sweep: 21.9 -> 20.0 us (profiles/r3_jacobi_lab.md).  EXACT mode keeps the reference's operations.
 #define SPH_R2_FLOOR 1.0e-30f
+// max(x, 0) for an x that is never above 1 -- (1 - q) and (1/2 - q) with q >= 0 -- as med3(x, 0, 1): the backend folds that into the CLAMP
+// modifier of the subtraction that produced x, one instruction instead of two, the same value bit for bit (round 5: two of the ~23
+// instructions a pair costs in every FAST / UNIFORM sweep)
+__device__ __forceinline__ float pos_part(float x) { return __builtin_amdgcn_fmed3f(x, 0.f, 1.f); }
 struct MathFast {
     static constexpr bool EXACT = false, UNIFORM = false;
     float h;  // unused
@@ -208,7 +212,7 @@ struct MathFast {
     {
         const float inv2h = fast_rcp(hij + hij);
         const float q = fast_sqrt(r2) * inv2h;
-        const float u = fmaxf(1.f - q, 0.f), t = fmaxf(0.5f - q, 0.f);
+        const float u = pos_part(1.f - q), t = pos_part(0.5f - q);
         return ((80.f / SPH_SEVEN_PI) * (inv2h * inv2h)) * fmaf(-4.f * t, t * t, u * (u * u));
     }
     __device__ __forceinline__ float gscale(float r2, float hij) const
@@ -217,7 +221,7 @@ struct MathFast {
         const float rinv = fast_rsq(r2c);
         const float inv2h = fast_rcp(hij + hij);
         const float q = (r2c * rinv) * inv2h;
-        const float u = fmaxf(1.f - q, 0.f), t = fmaxf(0.5f - q, 0.f);
+        const float u = pos_part(1.f - q), t = pos_part(0.5f - q);
         const float d = fmaf(4.f * t, t, -(u * u));
         return (((240.f / SPH_SEVEN_PI) * inv2h) * (inv2h * inv2h)) * (d * rinv);
     }
@@ -235,7 +239,7 @@ struct MathFast {
         const float rinv = fast_rsq(r2c);
         const float inv2h = fast_rcp(hij + hij);
         const float q = (r2c * rinv) * inv2h;
-        const float u = fmaxf(1.f - q, 0.f), t = fmaxf(0.5f - q, 0.f);
+        const float u = pos_part(1.f - q), t = pos_part(0.5f - q);
         const float i2 = inv2h * inv2h;
         wv = ((80.f / SPH_SEVEN_PI) * i2) * fmaf(-4.f * t, t * t, u * (u * u));
         s = (((240.f / SPH_SEVEN_PI) * inv2h) * i2) * (fmaf(4.f * t, t, -(u * u)) * rinv);
@@ -248,7 +252,7 @@ struct MathUniform {
     __device__ __forceinline__ float w(float r2, float) const
     {
         const float q = fast_sqrt(r2) * inv2h;
-        const float u = fmaxf(1.f - q, 0.f), t = fmaxf(0.5f - q, 0.f);
+        const float u = pos_part(1.f - q), t = pos_part(0.5f - q);
         return nf2 * fmaf(-4.f * t, t * t, u * (u * u));
     }
     __device__ __forceinline__ float gscale(float r2, float) const
@@ -256,7 +260,7 @@ struct MathUniform {
         const float r2c = fmaxf(r2, SPH_R2_FLOOR);
         const float rinv = fast_rsq(r2c);
         const float q = (r2c * rinv) * inv2h;
-        const float u = fmaxf(1.f - q, 0.f), t = fmaxf(0.5f - q, 0.f);
+        const float u = pos_part(1.f - q), t = pos_part(0.5f - q);
         const float d = fmaf(4.f * t, t, -(u * u));
         return nf6 * (d * rinv);
     }
@@ -271,7 +275,7 @@ struct MathUniform {
         const float r2c = fmaxf(r2, SPH_R2_FLOOR);
         const float rinv = fast_rsq(r2c);
         const float q = (r2c * rinv) * inv2h;
-        const float u = fmaxf(1.f - q, 0.f), t = fmaxf(0.5f - q, 0.f);
+        const float u = pos_part(1.f - q), t = pos_part(0.5f - q);
         wv = nf2 * fmaf(-4.f * t, t * t, u * (u * u));
         s = nf6 * (fmaf(4.f * t, t, -(u * u)) * rinv);
     }
