@@ -713,6 +713,17 @@ static void slab_after_regather(sph_ctx* c, uint32_t n_new)
 }
 
 // op: 0 share, 1 merge, 2 split -- for every member of the group (collective over ALL ranks of the decomposition)
+// A HIP failure INSIDE one of slab_adapt's per-member loops must not return before the collective that follows (agree, an all-reduce): under
+// a per-rank transport the other ranks would wait in it for ever (advisor r4).  It becomes this rank's local_rc and leaves the loop;
+// agree() then ends the call on every rank together.
+#define HIPLOC(ctx, call)                                                                                            \
+    {                                                                                                                \
+        hipError_t e_ = (call);                                                                                      \
+        if (e_ != hipSuccess) {                                                                                      \
+            local_rc = (ctx)->fail(SPH_ERR_DEVICE, "%s failed: %s", #call, hipGetErrorString(e_));                   \
+            break;                                                                                                   \
+        }                                                                                                            \
+    }
 static int slab_adapt(Group& G, int op, const sph_params* p, const sph_adapt_params* ap, const uint32_t* partner, const uint16_t* counter)
 {
     const size_t nm = G.m.size();
@@ -759,22 +770,22 @@ static int slab_adapt(Group& G, int op, const sph_params* p, const sph_adapt_par
         uint32_t n_del = 0, n_new_global = n_global;
         for (size_t i = 0; i < nm && !local_rc; i++) {
             sph_ctx* c = G.m[i];
-            HIPCHK(c, hipSetDevice(c->device));
+            HIPLOC(c, hipSetDevice(c->device));
             hipStream_t s = c->stream;
             const uint32_t nt = c->dist.n_tot;
             const int k = c->cur;
             if ((local_rc = need(c, buf(i, B_PARTNER), (size_t)n_global * 4)) || (local_rc = need(c, buf(i, B_COUNTER), (size_t)n_global * 2)) ||
                 (local_rc = need(c, buf(i, B_SLOT), (size_t)n_global * 4)))
                 break;
-            HIPCHK(c, hipMemcpyAsync(buf(i, B_PARTNER).p, partner, (size_t)n_global * 4, hipMemcpyHostToDevice, s));
-            HIPCHK(c, hipMemcpyAsync(buf(i, B_COUNTER).p, counter, (size_t)n_global * 2, hipMemcpyHostToDevice, s));
-            HIPCHK(c, hipMemsetAsync(buf(i, B_SLOT).p, 0xff, (size_t)n_global * 4, s));
+            HIPLOC(c, hipMemcpyAsync(buf(i, B_PARTNER).p, partner, (size_t)n_global * 4, hipMemcpyHostToDevice, s));
+            HIPLOC(c, hipMemcpyAsync(buf(i, B_COUNTER).p, counter, (size_t)n_global * 2, hipMemcpyHostToDevice, s));
+            HIPLOC(c, hipMemsetAsync(buf(i, B_SLOT).p, 0xff, (size_t)n_global * 4, s));
             if (!nt) continue;
             const dim3 grid((nt + 255) / 256);
             hipLaunchKernelGGL(k_slab_slot_of, grid, blk, 0, s, nt, c->orig[k].as<uint32_t>(), n_global, buf(i, B_SLOT).as<uint32_t>(), c->status.as<DeviceStatus>());
             // receivers write the other record / velocity buffers, which first take a copy of the current ones (donors, bystanders)
-            HIPCHK(c, hipMemcpyAsync(c->pm[c->pcur ^ 1].p, c->pm[c->pcur].p, (size_t)nt * sizeof(float4), hipMemcpyDeviceToDevice, s));
-            HIPCHK(c, hipMemcpyAsync(c->vel[k ^ 1].p, c->vel[k].p, (size_t)nt * sizeof(float2), hipMemcpyDeviceToDevice, s));
+            HIPLOC(c, hipMemcpyAsync(c->pm[c->pcur ^ 1].p, c->pm[c->pcur].p, (size_t)nt * sizeof(float4), hipMemcpyDeviceToDevice, s));
+            HIPLOC(c, hipMemcpyAsync(c->vel[k ^ 1].p, c->vel[k].p, (size_t)nt * sizeof(float2), hipMemcpyDeviceToDevice, s));
             hipLaunchKernelGGL(k_slab_receive, grid, blk, 0, s, nt, merging, c->dist.owned.as<uint8_t>(), c->orig[k].as<uint32_t>(), buf(i, B_SLOT).as<uint32_t>(), n_global,
                                buf(i, B_PARTNER).as<uint32_t>(), buf(i, B_COUNTER).as<uint16_t>(), min_partners, ap->dt, ap->max_mass_transfer_sharing, tp,
                                c->pm[c->pcur].as<float4>(), c->vel[k].as<float2>(), c->pm[c->pcur ^ 1].as<float4>(), c->vel[k ^ 1].as<float2>(), c->lvl[k].as<float>(),
@@ -783,8 +794,8 @@ static int slab_adapt(Group& G, int op, const sph_params* p, const sph_adapt_par
                                buf(i, B_COUNTER).as<uint16_t>(), min_partners, ap->dt, ap->max_mass_transfer_sharing, tp, c->pm[c->pcur ^ 1].as<float4>(), c->lvl[k].as<float>(),
                                c->h2n[k].as<float>());
             // the updated records become the current ones (velocities likewise); the slots stay where they are
-            HIPCHK(c, hipMemcpyAsync(c->pm[c->pcur].p, c->pm[c->pcur ^ 1].p, (size_t)nt * sizeof(float4), hipMemcpyDeviceToDevice, s));
-            HIPCHK(c, hipMemcpyAsync(c->vel[k].p, c->vel[k ^ 1].p, (size_t)nt * sizeof(float2), hipMemcpyDeviceToDevice, s));
+            HIPLOC(c, hipMemcpyAsync(c->pm[c->pcur].p, c->pm[c->pcur ^ 1].p, (size_t)nt * sizeof(float4), hipMemcpyDeviceToDevice, s));
+            HIPLOC(c, hipMemcpyAsync(c->vel[k].p, c->vel[k ^ 1].p, (size_t)nt * sizeof(float2), hipMemcpyDeviceToDevice, s));
             int r2 = check_status(c, "merge_partner holds an index outside the particle vector, or a donor that is not a neighbour of its receiver");
             if (r2) local_rc = r2;
             c->hdr_ahead = false;
@@ -797,7 +808,7 @@ static int slab_adapt(Group& G, int op, const sph_params* p, const sph_adapt_par
         // ---- delete: every rank derives the new index of every id from the two global arrays
         for (size_t i = 0; i < nm && !local_rc; i++) {
             sph_ctx* c = G.m[i];
-            HIPCHK(c, hipSetDevice(c->device));
+            HIPLOC(c, hipSetDevice(c->device));
             hipStream_t s = c->stream;
             if ((local_rc = need(c, buf(i, B_DEL), (size_t)n_global * 4)) || (local_rc = need(c, buf(i, B_BEFORE), (size_t)n_global * 4 + 4)) ||
                 (local_rc = need(c, buf(i, B_SCRATCH), ((size_t)n_global / SCAN_TILE + 4) * 4)) || (local_rc = need(c, buf(i, B_HOLES), (size_t)n_global * 4)))
@@ -807,8 +818,8 @@ static int slab_adapt(Group& G, int op, const sph_params* p, const sph_adapt_par
             uint32_t* d_total = buf(i, B_BEFORE).as<uint32_t>() + n_global;
             device_exclusive_scan_u32(s, buf(i, B_DEL).as<uint32_t>(), buf(i, B_BEFORE).as<uint32_t>(), n_global, buf(i, B_SCRATCH).as<uint32_t>(), d_total);
             uint32_t nd = 0;
-            HIPCHK(c, hipMemcpyAsync(&nd, d_total, 4, hipMemcpyDeviceToHost, s));
-            HIPCHK(c, hipStreamSynchronize(s));
+            HIPLOC(c, hipMemcpyAsync(&nd, d_total, 4, hipMemcpyDeviceToHost, s));
+            HIPLOC(c, hipStreamSynchronize(s));
             n_del = nd;   // (the same on every member: the same arrays)
         }
         if ((rc = agree(G, local_rc))) return rc;
@@ -816,7 +827,7 @@ static int slab_adapt(Group& G, int op, const sph_params* p, const sph_adapt_par
         n_new_global = n_global - n_del;
         for (size_t i = 0; i < nm && !local_rc; i++) {
             sph_ctx* c = G.m[i];
-            HIPCHK(c, hipSetDevice(c->device));
+            HIPLOC(c, hipSetDevice(c->device));
             hipStream_t s = c->stream;
             const uint32_t nt = c->dist.n_tot;
             if ((local_rc = need(c, buf(i, B_SRC), ((size_t)n_new_global + 1) * sizeof(EditSrc))) || (local_rc = need(c, buf(i, B_NEWID), (size_t)n_global * 4)) ||
@@ -836,9 +847,9 @@ static int slab_adapt(Group& G, int op, const sph_params* p, const sph_adapt_par
                 uint32_t* d_tot = buf(i, B_POS).as<uint32_t>() + nt;
                 device_exclusive_scan_u32(s, buf(i, B_KEEP).as<uint32_t>(), buf(i, B_POS).as<uint32_t>(), nt, buf(i, B_SCRATCH).as<uint32_t>(), d_tot);
                 hipLaunchKernelGGL(k_slab_compact, grid, blk, 0, s, nt, buf(i, B_KEEP).as<uint32_t>(), buf(i, B_POS).as<uint32_t>(), buf(i, B_NEWID).as<uint32_t>(), slab_gather_of(c));
-                HIPCHK(c, hipMemcpyAsync(&n_keep, d_tot, 4, hipMemcpyDeviceToHost, s));
+                HIPLOC(c, hipMemcpyAsync(&n_keep, d_tot, 4, hipMemcpyDeviceToHost, s));
             }
-            HIPCHK(c, hipStreamSynchronize(s));
+            HIPLOC(c, hipStreamSynchronize(s));
             slab_after_regather(c, n_keep);
         }
         return agree(G, local_rc);
@@ -847,13 +858,13 @@ static int slab_adapt(Group& G, int op, const sph_params* p, const sph_adapt_par
     uint32_t n_extra_global = 0;
     for (size_t i = 0; i < nm && !local_rc; i++) {
         sph_ctx* c = G.m[i];
-        HIPCHK(c, hipSetDevice(c->device));
+        HIPLOC(c, hipSetDevice(c->device));
         hipStream_t s = c->stream;
         const uint32_t nt = c->dist.n_tot;
         if ((local_rc = need(c, buf(i, B_EXTRA), (size_t)nt * 4 + 4)) || (local_rc = need(c, buf(i, B_DEL), (size_t)n_global * 4)) ||
             (local_rc = need(c, buf(i, B_BEFORE), (size_t)n_global * 4 + 4)) || (local_rc = need(c, buf(i, B_SCRATCH), ((size_t)std::max(n_global, nt) / SCAN_TILE + 4) * 4)))
             break;
-        HIPCHK(c, hipMemsetAsync(buf(i, B_DEL).p, 0, (size_t)n_global * 4, s));   // (B_DEL: the child counts - 1 of the whole vector, by id)
+        HIPLOC(c, hipMemsetAsync(buf(i, B_DEL).p, 0, (size_t)n_global * 4, s));   // (B_DEL: the child counts - 1 of the whole vector, by id)
         if (nt)
             hipLaunchKernelGGL(k_slab_split_count, dim3((nt + 255) / 256), blk, 0, s, nt, c->dist.owned.as<uint8_t>(), c->orig[c->cur].as<uint32_t>(), c->pm[c->pcur].as<float4>(),
                                c->lvl[c->cur].as<float>(), c->szc[c->cur].as<uint8_t>(), tp, c->n_split_patterns + 1u, ap->fail_on_missing_split_pattern,
@@ -869,20 +880,21 @@ static int slab_adapt(Group& G, int op, const sph_params* p, const sph_adapt_par
     }
     for (size_t i = 0; i < nm && !local_rc; i++) {
         sph_ctx* c = G.m[i];
-        HIPCHK(c, hipSetDevice(c->device));
+        HIPLOC(c, hipSetDevice(c->device));
         hipStream_t s = c->stream;
         uint32_t* d_total = buf(i, B_BEFORE).as<uint32_t>() + n_global;
         device_exclusive_scan_u32(s, buf(i, B_DEL).as<uint32_t>(), buf(i, B_BEFORE).as<uint32_t>(), n_global, buf(i, B_SCRATCH).as<uint32_t>(), d_total);
         uint32_t ne = 0;
-        HIPCHK(c, hipMemcpyAsync(&ne, d_total, 4, hipMemcpyDeviceToHost, s));
-        HIPCHK(c, hipStreamSynchronize(s));
+        HIPLOC(c, hipMemcpyAsync(&ne, d_total, 4, hipMemcpyDeviceToHost, s));
+        HIPLOC(c, hipStreamSynchronize(s));
         n_extra_global = ne;
     }
+    if ((rc = agree(G, local_rc))) return rc;
     if (n_extra_global == 0) return SPH_OK;
     if ((uint64_t)n_global + n_extra_global >= 0xfffffff0ull) return G.m[0]->fail(SPH_ERR_CAPACITY, "splitting needs %llu particle ids", (unsigned long long)n_global + n_extra_global);
     for (size_t i = 0; i < nm && !local_rc; i++) {
         sph_ctx* c = G.m[i];
-        HIPCHK(c, hipSetDevice(c->device));
+        HIPLOC(c, hipSetDevice(c->device));
         hipStream_t s = c->stream;
         const uint32_t nt = c->dist.n_tot, n_own = (uint32_t)c->n;
         if ((local_rc = need(c, buf(i, B_KEEP), (size_t)nt * 4 + 4)) || (local_rc = need(c, buf(i, B_POS), (size_t)nt * 4 + 8)) || (local_rc = need(c, buf(i, B_HOLES), (size_t)nt * 4 + 8)))
@@ -895,9 +907,9 @@ static int slab_adapt(Group& G, int op, const sph_params* p, const sph_adapt_par
             device_exclusive_scan_u32(s, buf(i, B_KEEP).as<uint32_t>(), buf(i, B_POS).as<uint32_t>(), nt, buf(i, B_SCRATCH).as<uint32_t>(), d_tot);
             uint32_t* d_tot2 = buf(i, B_HOLES).as<uint32_t>() + nt;   // (B_HOLES: exclusive prefix of the children over the slots)
             device_exclusive_scan_u32(s, buf(i, B_EXTRA).as<uint32_t>(), buf(i, B_HOLES).as<uint32_t>(), nt, buf(i, B_SCRATCH).as<uint32_t>(), d_tot2);
-            HIPCHK(c, hipMemcpyAsync(&n_keep, d_tot, 4, hipMemcpyDeviceToHost, s));
-            HIPCHK(c, hipMemcpyAsync(&n_children, d_tot2, 4, hipMemcpyDeviceToHost, s));
-            HIPCHK(c, hipStreamSynchronize(s));
+            HIPLOC(c, hipMemcpyAsync(&n_keep, d_tot, 4, hipMemcpyDeviceToHost, s));
+            HIPLOC(c, hipMemcpyAsync(&n_children, d_tot2, 4, hipMemcpyDeviceToHost, s));
+            HIPLOC(c, hipStreamSynchronize(s));
             if (n_keep != n_own) local_rc = c->fail(SPH_ERR_DEVICE, "owned-particle count mismatch");
             else if ((uint64_t)n_own + n_children > c->cap)
                 local_rc = c->fail(SPH_ERR_CAPACITY, "splitting needs %llu particles on rank %d, capacity %llu", (unsigned long long)n_own + n_children, c->dist.rank, (unsigned long long)c->cap);
@@ -905,7 +917,7 @@ static int slab_adapt(Group& G, int op, const sph_params* p, const sph_adapt_par
                 hipLaunchKernelGGL(k_slab_split_apply, grid, blk, 0, s, nt, n_own, n_global, buf(i, B_KEEP).as<uint32_t>(), buf(i, B_POS).as<uint32_t>(), buf(i, B_EXTRA).as<uint32_t>(),
                                    buf(i, B_HOLES).as<uint32_t>(), buf(i, B_BEFORE).as<uint32_t>(), c->split_patterns.as<float2>(), p->rest_density, slab_gather_of(c));
         }
-        HIPCHK(c, hipStreamSynchronize(s));
+        HIPLOC(c, hipStreamSynchronize(s));
         if (!local_rc) slab_after_regather(c, n_own + n_children);
     }
     return agree(G, local_rc);
