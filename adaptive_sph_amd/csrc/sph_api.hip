@@ -501,6 +501,7 @@ static int alloc_particle_buffers(sph_ctx* c)
     HIPCHK(c, c->pacc.ensure(n * sizeof(float4)));   // {x, y, a^p}
     HIPCHK(c, c->prec0.ensure(n * sizeof(float4)));  // {x, y, p / rho^2, p} of pressure buffer 0 / 1 (OpPressureAccelU)
     HIPCHK(c, c->prec1.ensure(n * sizeof(float4)));
+    HIPCHK(c, c->xv.ensure(n * sizeof(float4)));     // {x, y, v} for the source-term sweeps (OpSourceU)
     HIPCHK(c, c->scratch.ensure(n * sizeof(float4)));
     HIPCHK(c, c->nl.ensure(sweep_list_bytes((uint32_t)n)));
     HIPCHK(c, c->nl_ok.ensure(n));
@@ -538,6 +539,7 @@ Options options_from_env()
     o.chain = num("SPH_CHAIN", -1);
     o.accel_generic = flag("SPH_ACCEL_GENERIC");
     o.jacobi_generic = flag("SPH_JACOBI_GENERIC");
+    o.source_generic = flag("SPH_SOURCE_GENERIC");
     o.slab_general = flag("SPH_SLAB_GENERAL");
     o.slab_level_plain = flag("SPH_SLAB_LEVEL_PLAIN");
     o.level_serial = flag("SPH_LEVEL_SERIAL");
@@ -674,7 +676,7 @@ extern "C" void sph_destroy(sph_ctx* c)
     DevBuf* all[] = {&c->pm[0], &c->pm[1], &c->vel[0], &c->vel[1], &c->orig[0], &c->orig[1], &c->lvl[0], &c->lvl[1], &c->lvlold[0],
                      &c->lvlold[1], &c->vel_tmp, &c->key[0], &c->key[1], &c->val[0], &c->val[1], &c->sort_scratch, &c->cxy, &c->cell_start,
                      &c->cs_scratch, &c->hdr_ahead_partials, &c->h2n[0], &c->h2n[1], &c->lam_prev, &c->nl, &c->nlx, &c->tile_raw, &c->tile_h, &c->tile_h_ext, &c->lvl_changed_d, &c->lvl_tmp, &c->lvl_nrm, &c->lvl_state, &c->lvl_when, &c->lvl_mark, &c->lvl_queue, &c->nloff, &c->nlh, &c->flag_surface,
-                     &c->flag_insufficient, &c->con_thr, &c->con_consumed, &c->con_h, &c->flag_reduced, &c->szc[0], &c->szc[1], &c->omega, &c->stash, &c->nl_ext, &c->nlx_ext, &c->nl_ok, &c->mrho, &c->pt0, &c->pt1, &c->prec0, &c->prec1, &c->rho, &c->lam_sum, &c->lam_grad, &c->wall_pl, &c->wall_cnt, &c->constf, &c->aii, &c->src, &c->p0, &c->p1, &c->pacc, &c->dens_err,
+                     &c->flag_insufficient, &c->con_thr, &c->con_consumed, &c->con_h, &c->flag_reduced, &c->szc[0], &c->szc[1], &c->omega, &c->stash, &c->nl_ext, &c->nlx_ext, &c->nl_ok, &c->mrho, &c->pt0, &c->pt1, &c->prec0, &c->prec1, &c->xv, &c->rho, &c->lam_sum, &c->lam_grad, &c->wall_pl, &c->wall_cnt, &c->constf, &c->aii, &c->src, &c->p0, &c->p1, &c->pacc, &c->dens_err,
                      &c->stat, &c->ncount, &c->planes_d, &c->lam_lut, &c->dlam_lut, &c->hdr_partials, &c->hdr_out, &c->ctrl, &c->status,
                      &c->n_tiles, &c->red_partials, &c->scratch, &c->split_patterns, &c->akey[0], &c->akey[1], &c->aval[0], &c->aval[1], &c->acxy, &c->acell_start, &c->pm2,
                      &c->atile_raw, &c->atile_h, &c->inc_head, &c->inc_next, &c->inc_bsum, &c->inc_movers};

@@ -58,6 +58,7 @@ struct Options {
     int overlap = -1;           // SPH_OVERLAP=0|1          slabs: never / always split sweep A around the exchange (-1: by slab size)
     int accel_generic = 0;      // SPH_ACCEL_GENERIC        sweep A through OpPressureAccel (no pressure records)
     int jacobi_generic = 0;     // SPH_JACOBI_GENERIC       sweep B through OpJacobi
+    int source_generic = 0;     // SPH_SOURCE_GENERIC       the source-term sweep through OpSource (no {x, y, v} records)
     int slab_general = 0;       // SPH_SLAB_GENERAL         slabs: always the general maintenance path (no fused refresh)
     int slab_level_plain = 0;   // SPH_SLAB_LEVEL_PLAIN     slabs: level propagation without frontier marks
     int level_serial = 0;       // SPH_LEVEL_SERIAL         level estimation on the main stream
@@ -107,7 +108,7 @@ struct sph_ctx {
     int pcur = 0;  // which pm buffer is live; the other one holds the sorted PRE-step positions after a step
     DevBuf vel_tmp;
     // per-step
-    DevBuf key[2], val[2], sort_scratch, cxy, cell_start, cs_scratch, nl, nl_ok, mrho, pt0, pt1, prec0, prec1;
+    DevBuf key[2], val[2], sort_scratch, cxy, cell_start, cs_scratch, nl, nl_ok, mrho, pt0, pt1, prec0, prec1, xv;
     bool uniform_h = false;
     float h_uniform = 0.f;
     DevBuf wall_pl, wall_cnt;   // EXACT policy only (MathExact, sph_device.h)

@@ -233,6 +233,9 @@ struct SweepArgs {
     float* pt1;
     float4* rec0 = nullptr;   // {x, y, p / rho^2, p} for pressure buffer 0 / 1: written INSTEAD of pt0 / pt1 by the solves of uniform-h scenes
     float4* rec1 = nullptr;   // on one context (OpPressureAccelU gathers one record per neighbour); nullptr: slabs, IISPH2
+    float4* xv = nullptr;     // {x, y, vx, vy}: what the source-term sweep of such a scene gathers per neighbour (OpSourceU) -- written by whoever
+    bool xv_ok = false;       // writes the velocities behind the step's sort (the non-pressure forces, the divergence solve's tail); xv_ok: it
+                              // holds the current positions and velocities (set by the step driver behind those launches); nullptr: slabs, IISPH2
     // boundary
     const BoundaryP* planes;
     const float* lam_lut;
@@ -252,6 +255,7 @@ struct SweepArgs {
 // the solves of this step keep p / rho^2 inside the 16-byte records {x, y, p / rho^2, p} (rec0 / rec1) that sweep A gathers whole, not
 // in pt0 / pt1: what a slab decomposition exchanges for its ghosts per iteration is then word 2 of those records
 bool sweep_a_on_records(const SweepArgs& a);
+bool source_term_on_records(const SweepArgs& a);   // the step driver sets SweepArgs::xv_ok behind the launches that write the record
 size_t sweep_list_bytes(uint32_t n);
 size_t sweep_index_list_bytes(uint32_t n);   // explicit index lists (multi-resolution scenes)
 size_t sweep_offset_list_bytes(uint32_t n);  // relative-offset lists (uniform scenes whose solves run on records)

@@ -80,6 +80,7 @@ SweepArgs make_args(sph_ctx* c, const StepP& sp)
         a.rec0 = c->prec0.as<float4>();
         a.rec1 = c->prec1.as<float4>();
     }
+    if (!c->dist.on && !c->opt.source_generic) a.xv = c->xv.as<float4>();   // (a slab's ghosts get velocities, not records)
     a.uniform_h = c->uniform_h ? 1 : 0;
     a.h_uniform = c->h_uniform;
     a.planes = c->planes_d.as<BoundaryP>();
@@ -495,6 +496,7 @@ static int solve_queue(Group& G, std::vector<Member>& M, SolveQ& q, bool handoff
         }
         launch_solver_tail(m.c->stream, &m.c->prof, m.a, q.tail, m.c->pm[m.c->pcur ^ 1].as<float4>(), -1, q.residual_density,
                            q.max_avg_error, q.max_iters, hand_host, gate_out);
+        if (q.tail == 1 /* TAIL_VEL */ && source_term_on_records(m.a)) m.a.xv_ok = true;   // (the tail rewrote the {x, y, v} record with the velocities it left)
         if (q.tail >= 2 /* TAIL_VX, TAIL_HYBRID */ && m.a.hdr_partials) launch_header_ahead(m.c, (m.n + 255u) / 256u, m.c->hdr_host_dev, publish_next && !multi);
     }
     return SPH_OK;
@@ -1012,7 +1014,7 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
         }
         if (tev) (void)hipEventRecord(c->ev[1], s);
         m.a = make_args(c, sp);
-        if (p->pressure_solver_method == SPH_SOLVER_IISPH2 || no_records) m.a.rec0 = m.a.rec1 = nullptr;   // (IISPH2's rescaling works on p and p / rho^2)
+        if (p->pressure_solver_method == SPH_SOLVER_IISPH2 || no_records) m.a.rec0 = m.a.rec1 = m.a.xv = nullptr;   // (IISPH2's rescaling works on p and p / rho^2)
         m.a.h_mode = p->support_length_estimation;
         m.a.sp_check_aii = p->check_aii;
         m.st.n_particles = c->n;
@@ -1498,6 +1500,7 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
             std::swap(c->vel[c->cur], c->vel_tmp);
             m.a.vel = c->vel[c->cur].as<float2>();
             m.a.vel_tmp = c->vel_tmp.as<float2>();
+            m.a.xv_ok = m.n && source_term_on_records(m.a);   // (the sweep wrote the {x, y, v'} record beside v')
         }
         return refresh_ghosts(G, M, sel_vel, 2, "vel");
     };

@@ -1279,6 +1279,7 @@ struct OpNonPressure {
     float2* __restrict__ vel_out;
     DeviceStatus* status;
     StepP sp;
+    float4* __restrict__ xv_out;   // {x, y, v'}: the record the source-term sweep gathers (OpSourceU; else nullptr)
     struct Acc {
         float vx, vy, rho_i, vix, viy;
     };
@@ -1348,7 +1349,9 @@ struct OpNonPressure {
         const float ax = (a.vx + 0.f) + px;
         const float ay = (a.vy + sp.gravity) + py;
         if (!isfinite(a.vx) || !isfinite(a.vy)) raise_error(status, SPH_ERR_VISCOSITY_NOT_FINITE, orig[i]);
-        vel_out[i] = make_float2(a.vix + sp.dt * ax, a.viy + sp.dt * ay);
+        const float2 vn = make_float2(a.vix + sp.dt * ax, a.viy + sp.dt * ay);
+        vel_out[i] = vn;
+        if (xv_out) xv_out[i] = make_float4(Ai.x, Ai.y, vn.x, vn.y);   // (launch-uniform)
         return wall;
     }
 };
@@ -1545,6 +1548,46 @@ struct OpSource {
     {
         solver_block_partial(partials, active ? a.cls : 3u, a.err, blk);
         if (blk == 0u && threadIdx.x == 0) *ctrl_reset = SolverCtrl{};
+    }
+};
+
+// The same source term for uniform-h scenes with mass-derived smoothing lengths on one context -- the headline -- on ONE gathered record
+// per neighbour: {x_j, y_j, v_j}, as the sweep of the non-pressure forces (OpNonPressure::finish) or the divergence solve's tail
+// (k_solver_tail, TAIL_VEL) left it, instead of the particle record (16 bytes) plus the velocity (8).  Round 5; the
+// reasoning of OpJacobiU / OpPressureAccelU: a replay sweep costs its gather instructions.  The record holds no mass: m_j becomes the
+// mass of particle 0 (see OpPressureAccelU) -- with equal masses the pair coefficient m_j / rho_i is the generic sweep's bit for bit,
+// and so is everything behind it (same finish, same closed-form iteration 0, same residual statistics).  Divergence and full source
+// terms (kind 0 / 1); the step driver says when the record is current (SweepArgs::xv_ok), else the sweep is OpSource.
+template <class MathT>
+struct OpSourceU : OpSource<MathT, false> {
+    static_assert(MathT::UNIFORM, "OpSourceU: uniform-h scenes");
+    typedef OpSource<MathT, false> B;
+    typedef typename B::Acc Acc;
+    static constexpr bool TILE = false;
+    static constexpr bool OFF16 = true;    // (k_sweep_off: relative-offset lists)
+    static constexpr int WIDE_TRIPS = 3;
+    static constexpr int OFF_WAVES = 8;    // (see OpOffWaves)
+    typedef NBNone NB;
+    const float4* __restrict__ xv;
+    __device__ float4 loadA(uint32_t j) const { return load_record(xv, j); }
+    __device__ NB nb(const Acc&, uint32_t, float4) const { return NB{}; }
+    __device__ void begin(Acc& a, uint32_t i, float4 Ai) const
+    {
+        a.sum = 0.f;
+        a.rho_i = this->rho[i];
+        a.inv_rho_i = fast_rcp(a.rho_i);
+        a.qx = Ai.z;
+        a.qy = Ai.w;
+        a.err = 0.f;
+        a.cls = 3u;
+        a.om = 1.f;
+        a.om_c = this->pm[0].z * a.inv_rho_i;   // the pair coefficient m / rho_i (om_c is IISPH2's otherwise)
+        a.large = false;
+    }
+    __device__ void pair(Acc& a, float4 Aj, NB, float dx, float dy, float r2, float hij) const
+    {
+        const float e = fmaf(Aj.z - a.qx, dx, (Aj.w - a.qy) * dy);
+        a.sum = fmaf(a.om_c * this->m.gscale(r2, hij), e, a.sum);
     }
 };
 
@@ -1891,7 +1934,7 @@ __global__ __launch_bounds__(256) void k_solver_tail(uint32_t n, int tail, float
                                                       const uint8_t* __restrict__ owned, const SolverCtrl* __restrict__ ctrl, HeaderOut* __restrict__ hdr_partials,
                                                       DeviceStatus* status, const uint32_t* __restrict__ gate, const double* __restrict__ tot,
                                                       int decide_iter, SolveP solve, float rest_density, SolverCtrl* __restrict__ handoff_host,
-                                                      uint32_t* __restrict__ gate_out, IncClassifyP inc)
+                                                      uint32_t* __restrict__ gate_out, IncClassifyP inc, float4* __restrict__ xv)
 {
     if (gate && *gate == 0u) return;
     const bool b0t0 = blockIdx.x == 0 && threadIdx.x == 0;
@@ -1921,6 +1964,7 @@ __global__ __launch_bounds__(256) void k_solver_tail(uint32_t n, int tail, float
             v.x += dt * ap.x;
             v.y += dt * ap.y;
             if (!isfinite(v.x) || !isfinite(v.y)) raise_error(status, SPH_ERR_VELOCITY_NOT_FINITE, orig[i]);
+            if (xv) xv[i] = make_float4(rec.x, rec.y, v.x, v.y);   // (the a^p record carries the position: sweep A's finish; OpSourceU gathers this)
         } else if (tail == TAIL_VX) {
             v.x += dt * ap.x;
             v.y += dt * ap.y;
@@ -3223,6 +3267,8 @@ static bool solve_on_records(const SweepArgs& a)    // ... and sweep A {x, y, p 
     return jacobi_on_records(a) && a.rec0 != nullptr;   // (Options::accel_generic / ::slab_records: the step driver leaves rec0 null)
 }
 bool sweep_a_on_records(const SweepArgs& a) { return solve_on_records(a); }
+// ... and the source-term sweep {x, y, v} (OpSourceU): one context, the record kept current by the writers of the velocities
+bool source_term_on_records(const SweepArgs& a) { return solve_on_records(a) && a.xv != nullptr; }
 extern "C" int sph_set_sweep_variant(int mode)
 {
     if (mode < 0 || mode > 3) return SPH_ERR_INVALID_ARGUMENT;
@@ -3392,7 +3438,7 @@ static void launch_fused_aii_np(hipStream_t s, const SweepArgs& a, const M& math
 {
     typedef OpFuse<OpAiiConst<M>, OpNonPressure<M>> Op;
     Op op{OpAiiConst<M>{math, a.pm, a.orig, a.rho, a.mrho, a.lam_sum, a.lam_grad, a.aii, a.constf, a.status, a.sp, nullptr},
-          OpNonPressure<M>{math, a.pm, a.orig, a.rho, a.vel, a.vel_tmp, a.status, a.sp}, math};
+          OpNonPressure<M>{math, a.pm, a.orig, a.rho, a.vel, a.vel_tmp, a.status, a.sp, source_term_on_records(a) ? a.xv : nullptr}, math};
     launch_sweep<Op, false>(s, a, op);
 }
 
@@ -3414,7 +3460,7 @@ void launch_check_aii(hipStream_t s, Profiler* prof, const SweepArgs& a)
 void launch_non_pressure(hipStream_t s, Profiler* prof, const SweepArgs& a)
 {
     ProfScope ps(prof, "non_pressure_accel", s, true);
-    SPH_DISPATCH(OpNonPressure, false, a.pm, a.orig, a.rho, a.vel, a.vel_tmp, a.status, a.sp)
+    SPH_DISPATCH(OpNonPressure, false, a.pm, a.orig, a.rho, a.vel, a.vel_tmp, a.status, a.sp, source_term_on_records(a) ? a.xv : nullptr)
 }
 
 template <class M>
@@ -3426,6 +3472,13 @@ void launch_source_term(hipStream_t s, Profiler* prof, const SweepArgs& a, int k
 {
     ProfScope ps(prof, "source_term", s, true);
     float4* rec1 = solve_on_records(a) ? a.rec1 : nullptr;
+    if (source_term_on_records(a) && a.xv_ok && (kind == 0 || kind == 1)) {
+        OpSourceU<MathUniform> op{{uniform_math(a.h_uniform), a.pm, a.orig, a.rho, a.mrho, a.vel, a.lam_grad, a.aii, a.src, a.p1, a.pt1, rec1, a.dens_err,
+                                   (SolverPartial*)a.partials, a.ctrl, a.status, a.sp, kind, residual_density, nullptr, nullptr, a.gate},
+                                  a.xv};
+        launch_sweep<OpSourceU<MathUniform>, false>(s, a, op);
+        return;
+    }
     if (kind == 3) {
         SPH_DISPATCH(OpSourceOmega, false, a.pm, a.orig, a.rho, a.mrho, a.vel, a.lam_grad, a.aii, a.src, a.p1, a.pt1, rec1, a.dens_err,
                      (SolverPartial*)a.partials, a.ctrl, a.status, a.sp, kind, residual_density, a.omega, a.size_class, a.gate)
@@ -3556,7 +3609,7 @@ void launch_solver_tail(hipStream_t s, Profiler* prof, const SweepArgs& a, int t
         hipLaunchKernelGGL(k_solver_tail, dim3((a.n + 255) / 256), dim3(256), 0, s, a.n, tail, a.sp.dt, a.sp.hyb_vfactor, a.pm, pm_out, a.vel, a.pacc, a.orig,
                            a.owned, a.ctrl, tail >= TAIL_VX ? a.hdr_partials : nullptr, a.status, a.gate, a.solver_tot, decide_iter,
                            solve_params(a, residual_density, max_avg_error, max_iters, 1, false), a.sp.rest_density, handoff_host, gate_out,
-                           tail >= TAIL_VX ? a.inc : IncClassifyP{});
+                           tail >= TAIL_VX ? a.inc : IncClassifyP{}, tail == TAIL_VEL && source_term_on_records(a) ? a.xv : nullptr);
 }
 
 // Chained solves (HybridDFSPH, one context): the host does not wait between the divergence solve and the density solve.  Behind

@@ -83,6 +83,27 @@ def test_sweep_a_on_combined_records_is_bit_identical_to_the_generic_sweep(lab_l
         assert np.array_equal(a.download(f), b.download(f)), f
 
 
+@pytest.mark.parametrize("np_before", [True, False])
+@pytest.mark.parametrize("solver", ["HybridDFSPH", "IISPH", "OnlyDivergence"])
+def test_source_term_on_position_velocity_records_is_bit_identical_to_the_generic_sweep(lab_lib, monkeypatch, solver, np_before):
+    """Uniform-h scenes on one context: the sweep of the non-pressure forces and the divergence solve's tail leave {x, y, v} records and
+    the source-term sweep gathers one record per neighbour (OpSourceU); SPH_SOURCE_GENERIC=1 gathers the particle record and the
+    velocity (OpSource).  Equal masses: the same arithmetic on the same values -- every field, every iteration count and the
+    residual statistics agree bit for bit.  np_before = False (HybridDFSPH): the forces behind the divergence solve -- its source
+    term has no current record (the generic sweep runs), the density solve's has the tail's, then the forces'."""
+    def go(generic):
+        if generic:
+            monkeypatch.setenv("SPH_SOURCE_GENERIC", "1")
+        out = run(lab_lib, monkeypatch, "paced", 25, pressure_solver_method=solver, hybrid_dfsph_non_pressure_accel_before_divergence_free=np_before)
+        if generic:
+            monkeypatch.delenv("SPH_SOURCE_GENERIC")
+        return out
+    (a, ia, _), (b, ib, _) = go(False), go(True)
+    assert ia == ib
+    for f in ("position", "velocity", "density", "pressure", "aii", "ppe_source_term", "density_error"):
+        assert np.array_equal(a.download(f), b.download(f)), f
+
+
 @pytest.mark.parametrize("paced", ["1", "0"])
 def test_default_policy_waits_once_per_step_when_the_iteration_count_repeats(lab_lib, monkeypatch, paced):
     monkeypatch.delenv("SPH_CHAIN", raising=False)
