@@ -45,20 +45,20 @@ ALGO_BYTES = {
 }
 
 
-# VALU instructions per wave of the sweeps (rocprofv3 --pmc SQ_INSTS_VALU / SQ_WAVES, profiles/r5_sq_counters.txt: unchanged since round 4)
+# VALU instructions per wave of the sweeps (rocprofv3 --pmc SQ_INSTS_VALU / SQ_WAVES, profiles/r5q_sq_counters.txt: the round's last tree)
 # and the shader clock those launches ran at (SQ_BUSY_CYCLES / 32 / duration, profiles/r4_sq_counters.txt): what the `valu_issue` object
 # of a roofline entry is priced with
-VALU_ISSUE = {"density": 1497, "aii_nonpressure": 887, "source_term": 563, "pressure_accel": 294, "jacobi_update": 450}
-# Where a wave of the sweep spends its life (profiles/r5_sq_counters.txt, separate --pmc passes over the driver window):
+VALU_ISSUE = {"density": 1527, "aii_nonpressure": 985, "source_term": 440, "pressure_accel": 306, "jacobi_update": 394}
+# Where a wave of the sweep spends its life (profiles/r5q_sq_counters.txt, separate --pmc passes over the driver window):
 # SQ_WAIT_ANY (parked on s_waitcnt: its gathers), SQ_WAIT_INST_ANY (ready, waiting for an issue slot), SQ_ACTIVE_INST_ANY (issuing) as
 # shares of SQ_WAVE_CYCLES; the mean life of a wave = SQ_WAVE_CYCLES x 4 / waves (16 384 waves on 1 024 SIMDs at <= 8 per SIMD: a sweep is two
 # such lives end to end); L1 -> L2 read latency = TCP_TCC_READ_REQ_LATENCY / TCP_TCC_READ_REQ; L2 hit rate = TCC_HIT / TCC_REQ.
 WAVE_STATE = {
-    "density":         {"parked_on_memory": 0.52, "waiting_to_issue": 0.21, "issuing": 0.27, "wave_life_clocks": 37300, "l1_to_l2_read_latency_clocks": 227, "l2_hit_rate": 0.60},
-    "aii_nonpressure": {"parked_on_memory": 0.33, "waiting_to_issue": 0.46, "issuing": 0.20, "wave_life_clocks": 25100, "l1_to_l2_read_latency_clocks": 249, "l2_hit_rate": 0.73},
-    "source_term":     {"parked_on_memory": 0.40, "waiting_to_issue": 0.42, "issuing": 0.18, "wave_life_clocks": 18000, "l1_to_l2_read_latency_clocks": 330, "l2_hit_rate": 0.64},
-    "pressure_accel":  {"parked_on_memory": 0.48, "waiting_to_issue": 0.35, "issuing": 0.17, "wave_life_clocks": 10300, "l1_to_l2_read_latency_clocks": 395, "l2_hit_rate": 0.54},
-    "jacobi_update":   {"parked_on_memory": 0.41, "waiting_to_issue": 0.42, "issuing": 0.17, "wave_life_clocks": 15000, "l1_to_l2_read_latency_clocks": 441, "l2_hit_rate": 0.50},
+    "density":         {"parked_on_memory": 0.55, "waiting_to_issue": 0.17, "issuing": 0.28, "wave_life_clocks": 36700, "l1_to_l2_read_latency_clocks": 230, "l2_hit_rate": 0.60},
+    "aii_nonpressure": {"parked_on_memory": 0.26, "waiting_to_issue": 0.51, "issuing": 0.23, "wave_life_clocks": 24000, "l1_to_l2_read_latency_clocks": 252, "l2_hit_rate": 0.71},
+    "source_term":     {"parked_on_memory": 0.44, "waiting_to_issue": 0.39, "issuing": 0.17, "wave_life_clocks": 14700, "l1_to_l2_read_latency_clocks": 481, "l2_hit_rate": 0.52},
+    "pressure_accel":  {"parked_on_memory": 0.43, "waiting_to_issue": 0.44, "issuing": 0.13, "wave_life_clocks": 13700, "l1_to_l2_read_latency_clocks": 426, "l2_hit_rate": 0.56},
+    "jacobi_update":   {"parked_on_memory": 0.45, "waiting_to_issue": 0.40, "issuing": 0.15, "wave_life_clocks": 14700, "l1_to_l2_read_latency_clocks": 468, "l2_hit_rate": 0.49},
 }
 SHADER_CLOCK_HZ = 2.06e9
 # rocprofv3's duration of the profiler's calibration kernel (one wave spinning 10 us of the device clock): 10 us + the launch / exit
@@ -600,9 +600,9 @@ def main():
             waves_per_simd = (n_local / 64.0) / 1024.0
             clocks = avg_s * SHADER_CLOCK_HZ
             r["valu_issue"] = {"valu_instructions_per_wave": issue, "clocks_per_instruction": 3.0, "shader_clock_GHz": SHADER_CLOCK_HZ / 1e9,
-                               "frac": issue * waves_per_simd * 3.0 / clocks, "source": "profiles/r5_sq_counters.txt (SQ_INSTS_VALU / SQ_WAVES), profiles/r3_valu_issue.md"}
+                               "frac": issue * waves_per_simd * 3.0 / clocks, "source": "profiles/r5q_sq_counters.txt (SQ_INSTS_VALU / SQ_WAVES), profiles/r3_valu_issue.md"}
         if name in WAVE_STATE:
-            r["wave_state"] = dict(WAVE_STATE[name], source="profiles/r5_sq_counters.txt (SQ_WAIT_ANY, SQ_WAIT_INST_ANY, SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES; TCP_TCC_READ_REQ_LATENCY / TCP_TCC_READ_REQ; TCC_HIT / TCC_REQ)")
+            r["wave_state"] = dict(WAVE_STATE[name], source="profiles/r5q_sq_counters.txt (SQ_WAIT_ANY, SQ_WAIT_INST_ANY, SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES; TCP_TCC_READ_REQ_LATENCY / TCP_TCC_READ_REQ; TCC_HIT / TCC_REQ)")
         return r
 
     total_prof_ms = sum(v[1] for v in prof_all.values()) or 1.0
