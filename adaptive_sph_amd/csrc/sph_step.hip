@@ -1382,8 +1382,10 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
         m.a.nlh = nullptr;
         const bool offsets = m.n && m.c->opt.offset_lists && sweeps_want_offset_lists(m.a);
         if (offsets) {
-            HIPCHK(m.c, m.c->nloff.ensure(sweep_offset_list_bytes((uint32_t)(m.c->cap ? m.c->cap : 1))));
-            HIPCHK(m.c, m.c->nlh.ensure((size_t)(m.c->cap ? m.c->cap : 1)));
+            // (sized by the particles the sweep visits, not by the context's capacity -- group g of particle i sits at [g n + i], the lists are
+            //  rebuilt by every BUILD sweep, and DevBuf::ensure keeps a quarter of slack: a growing scene reallocates now and then)
+            HIPCHK(m.c, m.c->nloff.ensure(sweep_offset_list_bytes(m.a.n ? m.a.n : 1u)));
+            HIPCHK(m.c, m.c->nlh.ensure((size_t)(m.a.n ? m.a.n : 1u)));
             m.a.nloff_out = m.c->nloff.as<uint2>();
             m.a.nlh_out = m.c->nlh.as<uint8_t>();
         }
