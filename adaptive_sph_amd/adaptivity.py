@@ -216,45 +216,61 @@ class AdaptivityDriver:
     def single_step_adaptivity(self, P: SimulationParams, dt: float, step_number: int, lists=None) -> dict:
         """`lists` = (offsets, indices): the step's neighbour lists when they do not live in `ctx` (slab decomposition: the ranks'
         exports assembled in global index order, distributed.group_single_step_adaptivity)."""
+        import time as _t
         ctx, log = self.ctx, self.log
         p, ap = P.to_ffi(), adapt_params(P, dt)
         info = {"n_before": ctx.n, "shares": 0, "merges": 0, "splits": 0}
+        # what the adaptive half of a step costs, by phase (bench.py reports it): device -> host of the lists and the five fields a
+        # decision reads, the sequential partner searches on the host, the apply calls on the device
+        tm = info["seconds"] = {"download": 0.0, "host_decide": 0.0, "apply": 0.0}
         # particles.mass.iter().cloned().sum() (:2745, 2791) is a SEQUENTIAL f32 sum.  At the reference's own scene sizes (1e3..1e5
         # particles) that is accurate to ~1e-5 and the 0.005 bar means "mass is conserved".  At millions of particles it is not a
         # measurement any more: adding 1.8e-7 to a running total of 1.4 rounds to 1 or 2 ulp of the total every time (4M particles of
         # configs[4]: the sequential sums before and after a merge pass differ by > 0.005 although the mass is conserved to 1e-7, and
         # the reference would panic there).  The mirror keeps the assertion's MEANING: the sums are taken in f64.
         seq_sum = lambda a: float(np.sum(a, dtype=np.float64))   # noqa: E731
+        t0 = _t.perf_counter()
         total_mass1 = seq_sum(ctx.download("mass"))
         off, idx = lists if lists is not None else ctx.download_neighbors()   # the lists single_step_without_adaptivity left behind (self.neighs)
+        tm["download"] += _t.perf_counter() - t0
 
         def decide(kind):
+            t0 = _t.perf_counter()
             ctx.classify(p)
             cls = ctx.download("particle_size_class")
             fields = (cls, ctx.download("mass"), ctx.download("level_estimation"), ctx.download("position"), ctx.download("h2"))
-            if getattr(ctx.lib, "host_find_partners", None) is not None:
-                return find_partners_native(ctx.lib, kind, *fields, off, idx, P, dt)     # (validates like the reference does)
-            mp, mc = _find_partners(kind, *fields, off, idx, P, dt)
-            validate_partners(kind, cls, mp, mc, off, idx)
-            return mp, mc
+            t1 = _t.perf_counter()
+            tm["download"] += t1 - t0
+            try:
+                if getattr(ctx.lib, "host_find_partners", None) is not None:
+                    return find_partners_native(ctx.lib, kind, *fields, off, idx, P, dt)     # (validates like the reference does)
+                mp, mc = _find_partners(kind, *fields, off, idx, P, dt)
+                validate_partners(kind, cls, mp, mc, off, idx)
+                return mp, mc
+            finally:
+                tm["host_decide"] += _t.perf_counter() - t1
+
+        def apply(f, *a):
+            t0 = _t.perf_counter()
+            f(*a)
+            tm["apply"] += _t.perf_counter() - t0
 
         if P.sharing:
             mp, mc = decide("share")
             info["shares"] = int(mc.sum())
             if log:
                 log(f"SEQUENTIAL SHARE {info['shares']} shares")
-            ctx.share_particles(p, ap, mp, mc)
+            apply(ctx.share_particles, p, ap, mp, mc)
         if step_number % 2 == 0:
             if P.merging:
                 mp, mc = decide("merge")
                 info["merges"] = int(mc.sum())
                 if log:
                     log(f"SEQUENTIAL MERGE {info['merges']} merges")
-                ctx.merge_particles(p, ap, mp, mc)
+                apply(ctx.merge_particles, p, ap, mp, mc)
         elif P.splitting:
-            ctx.classify(p)
             n0 = ctx.n
-            ctx.split_particles(p, ap)
+            apply(lambda: (ctx.classify(p), ctx.split_particles(p, ap)))
             info["splits"] = ctx.n - n0
         total_mass2 = seq_sum(ctx.download("mass"))
         if not abs(total_mass1 - total_mass2) <= 0.005:             # assert_ft_approx_eq(total_mass1, total_mass2, 0.005, "mass sum")
