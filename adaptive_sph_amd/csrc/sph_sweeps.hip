@@ -3150,7 +3150,8 @@ struct OpFuse {
     static constexpr bool HAS_EPILOGUE = false, SKIP_SELF = A::SKIP_SELF && B::SKIP_SELF, EXTENDED = false;
     // (k_sweep_off: A knows about its own term -- OpAiiConst --, B's pair of the particle with itself is zero)
     static constexpr bool OFF16 = OpOff16<A>::value && OpOff16<B>::value && OpOffSelf<A>::value && B::SKIP_SELF, OFF16_SELF = true;
-    // (OFF_WAVES: not here -- 79 VGPRs = 6 waves; bounded to 7 it spills 10 registers, to 8 it spills 165 and runs twice as long)
+    // (OFF_WAVES: not here -- 79 VGPRs = 6 waves; bounded to 7 it spills 10 registers and runs 35.3 instead of 35.7 us (A/B on one box, four
+    //  runs each: inside the noise), to 8 it spills 165 and runs twice as long)
     __device__ constexpr float krange() const { return 2.f; }
     A a;
     B b;
