@@ -705,6 +705,32 @@ extern "C" int sph_set_time(sph_ctx* c, float t, uint64_t step)
     return SPH_OK;
 }
 
+// include/sph_ffi.h: the arithmetic of the sweeps, chosen by the host through the ABI (SPH_HIP_EXACT only sets the initial value).
+// The particle state is policy-free; what a step derives from it (lists, cell table, the build queued ahead, the header computed ahead)
+// is dropped, so the next step starts like the first one after an upload -- and the EXACT policy's per-SDF boundary entries get their
+// buffers here if the context was created without them.
+extern "C" int sph_set_math_policy(sph_ctx* c, int policy)
+{
+    if (!c || (policy != SPH_MATH_FAST && policy != SPH_MATH_EXACT)) return SPH_ERR_INVALID_ARGUMENT;
+    if (c->poisoned) return c->fail(SPH_ERR_POISONED, "sph_set_math_policy: the context is poisoned until sph_upload");
+    if (policy == c->exact) return SPH_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (int rc = wait_stream(c)) return rc;   // a build queued ahead may still be running on the old policy's buffers
+    c->exact = policy;
+    if (c->exact) {
+        size_t n = c->cap ? c->cap : 1;
+        HIPCHK(c, c->wall_pl.ensure(n * sizeof(float2) * SPH_MAX_PLANES));
+        HIPCHK(c, c->wall_cnt.ensure(n));
+    }
+    c->grid_valid = false;
+    c->ahead.valid = false;
+    c->hdr_ahead = false;
+    c->lists_after = false;
+    if (c->ctrl_host) ((uint32_t*)(c->ctrl_host + 2))[1] = 0u;
+    return SPH_OK;
+}
+extern "C" int sph_get_math_policy(const sph_ctx* c) { return c ? c->exact : -1; }
+
 extern "C" int sph_upload(sph_ctx* c, uint64_t n, const float* mass, const float* pos, const float* vel)
 {
     if (!c || (n && (!mass || !pos || !vel))) return SPH_ERR_INVALID_ARGUMENT;

@@ -150,9 +150,11 @@ class SphError(RuntimeError):
 
 
 # every symbol include/sph_ffi.h declares (checked by tests/test_abi.py)
+MATH_POLICIES = {"fast": 0, "exact": 1}   # enum sph_math_policy
+
 ABI_SYMBOLS = [
     "create", "destroy", "upload", "upload_field", "download", "download_neighbors", "num_particles", "time",
-    "set_time", "step", "classify", "share_particles", "merge_particles", "set_split_patterns", "split_particles", "host_find_partners", "last_error", "grid", "set_boundary_polygon", "apply_edits", "profile_enable", "profile_reset", "profile_get", "profile_event_overhead", "profile_dispatch_bracket", "profile_copy_bandwidth", "profile_list_forms", "set_sweep_variant",
+    "set_time", "step", "classify", "share_particles", "merge_particles", "set_split_patterns", "split_particles", "host_find_partners", "last_error", "grid", "set_boundary_polygon", "set_math_policy", "get_math_policy", "apply_edits", "profile_enable", "profile_reset", "profile_get", "profile_event_overhead", "profile_dispatch_bracket", "profile_copy_bandwidth", "profile_list_forms", "set_sweep_variant",
     "dist_configure", "dist_set_rebalance", "dist_get_cuts", "dist_get_stats", "comm_unique_id", "comm_init", "comm_init_shm", "comm_ipc_export", "comm_init_ipc", "group_step", "group_adapt", "thread_group_create", "thread_group_destroy", "comm_init_threads",
 ]
 
@@ -187,6 +189,8 @@ class SphLibrary:
         self.create = sig("create", i32, [u64, i32, C.POINTER(SphPlane), i32, C.POINTER(vp)])
         self.destroy = sig("destroy", None, [vp])
         self.set_boundary_polygon = sig("set_boundary_polygon", i32, [vp, C.POINTER(C.c_float), i32])
+        self.set_math_policy = sig("set_math_policy", i32, [vp, i32])
+        self.get_math_policy = sig("get_math_policy", i32, [vp])
         self.upload = sig("upload", i32, [vp, u64, vp, vp, vp])
         self.upload_field = sig("upload_field", i32, [vp, i32, vp, u64])
         self.apply_edits = sig("apply_edits", i32, [vp, C.POINTER(SphEditOp), u64])
@@ -302,6 +306,13 @@ class Context:
     @property
     def time(self) -> float:
         return float(self.lib.time(self.handle))
+
+    def set_math_policy(self, policy):
+        """sph_set_math_policy: "fast" (default) or "exact" (the reference's IEEE operations in its order; include/sph_ffi.h)."""
+        self._check(self.lib.set_math_policy(self.handle, MATH_POLICIES[policy] if isinstance(policy, str) else int(policy)))
+
+    def math_policy(self) -> str:
+        return {v: k for k, v in MATH_POLICIES.items()}[int(self.lib.get_math_policy(self.handle))]
 
     def set_time(self, t: float, step_number: int = 0):
         self._check(self.lib.set_time(self.handle, float(t), int(step_number)))

@@ -135,15 +135,17 @@ def parse_args():
     return ap.parse_args()
 
 
-def short_run(plib, name, steps=40, warmup=10, **param_overrides):
+def short_run(plib, name, steps=40, warmup=10, math_policy=None, **param_overrides):
     """A short untimed-warm-up + timed run of another BASELINE config on the same GPU (reported under "other_configs";
-    never part of `value`)."""
+    never part of `value`).  `math_policy` = "exact": the same run under sph_set_math_policy(SPH_MATH_EXACT)."""
     from adaptive_sph_amd import ffi, scene as sc
     from adaptive_sph_amd.workloads import WORKLOADS
     scene_f, params_f, desc = WORKLOADS[name]
     scn, P = scene_f(), params_f(**param_overrides)
     pos, mass, vel = sc.init_particles(scn)
     ctx = ffi.Context(plib, len(mass), sc.boundary_planes(scn.boundary, P.init_boundary_handler))
+    if math_policy is not None:
+        ctx.set_math_policy(math_policy)
     ctx.upload(mass, pos, vel)
     p = P.to_ffi()
     for _ in range(warmup):
@@ -156,9 +158,12 @@ def short_run(plib, name, steps=40, warmup=10, **param_overrides):
                     int(st.density_solver.iters) + 1 if P.pressure_solver_method != "OnlyDivergence" else 0))
     dt = time.perf_counter() - t0
     ctx.close()
-    return {"workload": f"{name}: {desc}", "overrides": param_overrides, "particles": len(mass), "steps": steps, "warmup": warmup,
-            "ms_per_step": dt * 1e3 / steps, "particle_steps_per_s": len(mass) * steps / dt,
-            "mean_div_iterations": float(np.mean([a for a, _ in its])), "mean_density_iterations": float(np.mean([b for _, b in its]))}
+    out = {"workload": f"{name}: {desc}", "overrides": param_overrides, "particles": len(mass), "steps": steps, "warmup": warmup,
+           "ms_per_step": dt * 1e3 / steps, "particle_steps_per_s": len(mass) * steps / dt,
+           "mean_div_iterations": float(np.mean([a for a, _ in its])), "mean_density_iterations": float(np.mean([b for _, b in its]))}
+    if math_policy is not None:
+        out["math_policy"] = math_policy
+    return out
 
 
 def adaptive_steps(plib, name, steps=2, warmup=2, **param_overrides):
@@ -732,6 +737,17 @@ def main():
         out["other_configs"] = []
         leg("other configs: dam_break_1m_adaptive")
         out["other_configs"].append(short_run(plib, "dam_break_1m_adaptive"))                                    # configs[2]: 4:1 radius ratio
+        leg("other configs: dam_break_1m_adaptive_contact")
+        out["other_configs"].append(short_run(plib, "dam_break_1m_adaptive_contact"))                            # ... with the two resolutions in contact (mixed-h pairs from step 0)
+        out["other_configs"][-1]["state"] = ("configs[2]'s blocks one coarse spacing apart: the symmetric (h_i + h_j) / 2 rule at work from step 0 "
+                                             "(tests/test_gpu_configs.py::test_config2_columns_in_contact_at_full_size); the leg above is BASELINE's placement, "
+                                             "2.0 apart: two uniform columns on the fine sorting grid")
+        leg("other configs: headline under the EXACT math policy")
+        ex = short_run(plib, "dam_break_1m", steps=args.steps, warmup=args.warmup, math_policy="exact")          # what "identical results" costs: the headline window, same K / W
+        ex["state"] = ("the headline's window under sph_set_math_policy(SPH_MATH_EXACT): IEEE division / sqrt, no fma, the reference's operation order, "
+                       "mask-word replays (no record sweeps, no offset lists, no build queued ahead) -- bit for bit the oracle in the device's visiting "
+                       "order (tests/test_gpu_bitexact.py); the free-running iteration counts are those of its own arithmetic")
+        out["other_configs"].append(ex)
         leg("other configs: ratio_stress_4m")
         out["other_configs"].append(short_run(plib, "ratio_stress_4m", steps=20, warmup=5))                      # configs[4]'s scene (50:1, 4M), no adaptivity
         out["other_configs"][-1]["state"] = "FREE FALL (the reference scene hangs both blocks 0.5 above the floor): one Jacobi iteration per step, not an IISPH number"

@@ -208,6 +208,19 @@ int  sph_create(uint64_t n_capacity, int device_id, const sph_plane* planes, int
  * SPH_ERR_INVALID_ARGUMENT on the conditions Sdf2DConnectedComponents::from_points asserts (sdf2d.rs:43, 59). */
 #define SPH_MAX_POLYGON_POINTS 16
 int  sph_set_boundary_polygon(sph_ctx* ctx, const float* points_xy, int n_points);
+
+/* Which arithmetic the sweeps evaluate the reference's formulas in (no counterpart in the reference: it has ONE arithmetic, f32 IEEE
+ * operations in the order of the Rust source -- sph_kernels.rs:23-71, simulation.rs:1007-1322):
+ *   SPH_MATH_FAST   (default) v_rsq / v_rcp, fma, the truncated-power form of the cubic spline, m_j -> m_i in uniform scenes, boundary
+ *                   entries folded per particle: within 1e-4 relative of the reference after N steps (tests/test_gpu_parity.py);
+ *   SPH_MATH_EXACT  IEEE division / sqrt, no fma, every operation in the reference's order, per-SDF boundary entries kept apart: the
+ *                   reference's results BIT FOR BIT when the particles are uploaded in the device's visiting order
+ *                   (tests/test_gpu_bitexact.py), at the price bench.py prints under other_configs ("EXACT policy").
+ * Allowed between steps at any time: the particle state stays, the lists and per-step outputs of the previous step are dropped
+ * (the next step rebuilds them).  The environment variable SPH_HIP_EXACT=1 only sets the initial value at sph_create. */
+enum sph_math_policy { SPH_MATH_FAST = 0, SPH_MATH_EXACT = 1 };
+int  sph_set_math_policy(sph_ctx* ctx, int policy);
+int  sph_get_math_policy(const sph_ctx* ctx);
 void sph_destroy(sph_ctx* ctx);
 
 /* Replace the whole particle set (FluidSimulation::new arguments, and what the host must do

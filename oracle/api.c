@@ -261,6 +261,15 @@ int oracle_download_neighbors(oracle_ctx* c, uint32_t* offsets, uint32_t* indice
     return SPH_OK;
 }
 
+/* include/sph_ffi.h sph_set_math_policy: the oracle has ONE arithmetic -- the reference's IEEE operations in the reference's order
+ * (what the device calls SPH_MATH_EXACT); the call is accepted so that the same host code drives both libraries. */
+int oracle_set_math_policy(oracle_ctx* c, int policy)
+{
+    if (!c || (policy != SPH_MATH_FAST && policy != SPH_MATH_EXACT)) return SPH_ERR_INVALID_ARGUMENT;
+    return SPH_OK;
+}
+int oracle_get_math_policy(const oracle_ctx* c) { return c ? SPH_MATH_EXACT : -1; }
+
 uint64_t oracle_num_particles(const oracle_ctx* c) { return c ? c->n : 0; }
 float oracle_time(const oracle_ctx* c) { return c ? c->time : 0.f; }
 int oracle_set_time(oracle_ctx* c, float t, uint64_t step)

@@ -12,6 +12,8 @@ pub mod ffi {
     use std::os::raw::{c_char, c_int, c_void};
 
     // ---- enums of simulation_parameters.rs as the header numbers them -------------------------------------
+    pub const SPH_MATH_FAST: i32 = 0;
+    pub const SPH_MATH_EXACT: i32 = 1;
     pub const SPH_VISC_WCSPH: i32 = 0;
     pub const SPH_VISC_APPROX_LAPLACE: i32 = 1;
     pub const SPH_VISC_XSPH: i32 = 2;
@@ -203,6 +205,8 @@ pub mod ffi {
     extern "C" {
         pub fn sph_create(n_capacity: u64, device_id: c_int, planes: *const SphPlane, n_planes: c_int, out: *mut *mut c_void) -> c_int;
         pub fn sph_set_boundary_polygon(ctx: *mut c_void, points_xy: *const f32, n_points: c_int) -> c_int;
+        pub fn sph_set_math_policy(ctx: *mut c_void, policy: c_int) -> c_int;
+        pub fn sph_get_math_policy(ctx: *const c_void) -> c_int;
         pub fn sph_destroy(ctx: *mut c_void);
         pub fn sph_upload(ctx: *mut c_void, n: u64, mass: *const f32, position_xy: *const f32, velocity_xy: *const f32) -> c_int;
         pub fn sph_upload_field(ctx: *mut c_void, field: c_int, src: *const c_void, src_bytes: u64) -> c_int;
@@ -384,6 +388,12 @@ impl HipStep {
 
     pub fn time(&self) -> f32 {
         unsafe { ffi::sph_time(self.ctx) }
+    }
+
+    /// `SPH_MATH_EXACT`: the reference's IEEE operations in the reference's order (bit for bit the Rust sweeps when the particles
+    /// are in the device's visiting order); `SPH_MATH_FAST` (default): hardware rsq / rcp, fma -- within 1e-4 relative.
+    pub fn set_math_policy(&mut self, policy: c_int) {
+        self.check(unsafe { ffi::sph_set_math_policy(self.ctx, policy) });
     }
 
     pub fn set_time(&mut self, time: f32, step_number: u64) {
