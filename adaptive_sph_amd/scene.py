@@ -144,14 +144,14 @@ def dam_break_1m_adaptive() -> SceneConfig:
                         SceneFluidBlock([1.0, -0.996], [0.9, 1.0005], 0.00390625, 0.93, [0.0, 0.0])])
 
 
-def dam_break_1m_adaptive_contact() -> SceneConfig:
+def dam_break_1m_adaptive_contact(gap: float = 0.00390625) -> SceneConfig:
     """configs[2]'s two blocks -- the same sizes, spacings and counts (942 080 fine + 58 880 coarse, 4:1 radii) -- with the coarse block
     moved against the fine one: its first column stands one coarse spacing (1/256) right of the fine block's last column (x = -1.999 +
     1023/1024), so the symmetric (h_i + h_j) / 2 rule of sph_kernels.rs:273-278 is at work from step 0 (BASELINE's placement leaves 2.0
     between the blocks: they meet after thousands of steps).  Same floor offsets as configs[2]."""
     return SceneConfig(SceneBoundary("box", 4.0, 2.0),
                        [SceneFluidBlock([-1.999, -0.999], [1.0005, 0.8989], 0.0009765625, 0.93, [0.0, 0.0]),
-                        SceneFluidBlock([-1.999 + 1023.0 / 1024.0 + 0.00390625, -0.996], [0.9, 1.0005], 0.00390625, 0.93, [0.0, 0.0])])
+                        SceneFluidBlock([-1.999 + 1023.0 / 1024.0 + gap, -0.996], [0.9, 1.0005], 0.00390625, 0.93, [0.0, 0.0])])
 
 
 def dam_break_8m() -> SceneConfig:

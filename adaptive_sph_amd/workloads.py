@@ -66,6 +66,8 @@ WORKLOADS = {
     "dam_break_1m_adaptive": (sc.dam_break_1m_adaptive, dam_break_params, "2D dam-break, 1 000 960 particles, 4:1 radius ratio"),
     "dam_break_1m_adaptive_contact": (sc.dam_break_1m_adaptive_contact, dam_break_params,
                                       "configs[2]'s two blocks (1 000 960 particles, 4:1 radius ratio) one coarse spacing apart: the mixed-h interface from step 0"),
+    "dam_break_1m_adaptive_colliding": (lambda: sc.dam_break_1m_adaptive_contact(1.5 * 0.00390625), dam_break_params,
+                                        "configs[2]'s two blocks 1.5 coarse spacings apart: no mixed-h pair at rest, the collapsing fine column reaches the coarse block within ~13 steps"),
     "dam_break_8m": (sc.dam_break_8m, dam_break_params, "2D dam-break, 8192x1024 = 8 388 608 particles (configs[1]'s column eight times as wide)"),
     "dam_break_8m_spec": (sc.dam_break_8m_spec, lambda **kw: dam_break_params(**dict(dict(max_dt=0.00025), **kw)),
                           "SURVEY 8d config 4 as written: 2896x2896 = 8 386 816 particles at spacing 1/2048, box 4x2, max_dt 0.00025 (0.001 blows up at step 3, 0.0005 at step 6: profiles/r5_config3_divergence.md)"),

@@ -135,7 +135,7 @@ def parse_args():
     return ap.parse_args()
 
 
-def short_run(plib, name, steps=40, warmup=10, math_policy=None, **param_overrides):
+def short_run(plib, name, steps=40, warmup=10, math_policy=None, list_forms=False, **param_overrides):
     """A short untimed-warm-up + timed run of another BASELINE config on the same GPU (reported under "other_configs";
     never part of `value`).  `math_policy` = "exact": the same run under sph_set_math_policy(SPH_MATH_EXACT)."""
     from adaptive_sph_amd import ffi, scene as sc
@@ -157,12 +157,15 @@ def short_run(plib, name, steps=40, warmup=10, math_policy=None, **param_overrid
         its.append((int(st.div_solver.iters) + 1 if P.pressure_solver_method in ("HybridDFSPH", "OnlyDivergence") else 0,
                     int(st.density_solver.iters) + 1 if P.pressure_solver_method != "OnlyDivergence" else 0))
     dt = time.perf_counter() - t0
+    forms = ctx.profile_list_forms() if list_forms else None
     ctx.close()
     out = {"workload": f"{name}: {desc}", "overrides": param_overrides, "particles": len(mass), "steps": steps, "warmup": warmup,
            "ms_per_step": dt * 1e3 / steps, "particle_steps_per_s": len(mass) * steps / dt,
            "mean_div_iterations": float(np.mean([a for a, _ in its])), "mean_density_iterations": float(np.mean([b for _, b in its]))}
     if math_policy is not None:
         out["math_policy"] = math_policy
+    if forms is not None:
+        out["list_forms"] = {k: int(v) for k, v in forms.items()}
     return out
 
 
@@ -738,10 +741,13 @@ def main():
         leg("other configs: dam_break_1m_adaptive")
         out["other_configs"].append(short_run(plib, "dam_break_1m_adaptive"))                                    # configs[2]: 4:1 radius ratio
         leg("other configs: dam_break_1m_adaptive_contact")
-        out["other_configs"].append(short_run(plib, "dam_break_1m_adaptive_contact"))                            # ... with the two resolutions in contact (mixed-h pairs from step 0)
-        out["other_configs"][-1]["state"] = ("configs[2]'s blocks one coarse spacing apart: the symmetric (h_i + h_j) / 2 rule at work from step 0 "
-                                             "(tests/test_gpu_configs.py::test_config2_columns_in_contact_at_full_size); the leg above is BASELINE's placement, "
-                                             "2.0 apart: two uniform columns on the fine sorting grid")
+        out["other_configs"].append(short_run(plib, "dam_break_1m_adaptive_colliding", steps=40, warmup=20, list_forms=True))   # ... with the two resolutions in contact
+        out["other_configs"][-1]["state"] = ("configs[2]'s blocks 1.5 coarse spacings apart: the fine column's collapse drives it into the coarse block from step ~13 on, "
+                                             "steps 20-59 run the symmetric (h_i + h_j) / 2 rule on the interface (`list_forms`: particles on explicit index lists / "
+                                             "candidate walks; profiles/r6_config2_contact.md).  One coarse spacing apart -- mixed-h pairs from step 0, the parity test "
+                                             "tests/test_gpu_configs.py::test_config2_columns_in_contact_at_full_size -- the recipe blows up at step 5 (density solve at "
+                                             "max_iters, 1e26 m/s) on device and oracle alike, so it is no bench window; the leg above is BASELINE's placement, 2.0 apart: "
+                                             "two uniform columns on the fine sorting grid")
         leg("other configs: headline under the EXACT math policy")
         ex = short_run(plib, "dam_break_1m", steps=args.steps, warmup=args.warmup, math_policy="exact")          # what "identical results" costs: the headline window, same K / W
         ex["state"] = ("the headline's window under sph_set_math_policy(SPH_MATH_EXACT): IEEE division / sqrt, no fma, the reference's operation order, "

@@ -45,19 +45,20 @@ def assert_displacements(g, o):
     assert ok, rep
 
 
-CONFIG3 = [("dam_break_8m", 8388608), ("dam_break_8m_spec", 8386816)]
+CONFIG3 = [("dam_break_8m", 8388608, 3), ("dam_break_8m_spec", 8386816, 8)]
 """configs[3] twice: round 4's eight-configs[1]-columns scene (8192 x 1024 at spacing 1/1024, 1 024-row halos) and SURVEY.md section 8d's
 geometry AS WRITTEN (simulation.rs:2915-2983 add_fluid_block: pos [-1.9995, -0.9995], size [1.4143, 1.4143], spacing 1/2048 ->
 2896 x 2896, box 4 x 2; max_dt 0.00025, profiles/r5_config3_divergence.md) -- the scene bench.py quotes as `strong_8m_spec`, with
-2 896-row halos on eight slabs (VERDICT r5 missing 3 / next 1a)."""
+2 896-row halos on eight slabs (VERDICT r5 missing 3 / next 1a).  Third entry: steps against the oracle -- at max_dt 0.00025 three steps
+move a particle 19 ulp of its coordinate, which the displacement bars refuse as "not meaningful"; eight steps move it > 100."""
 
 
-@pytest.mark.parametrize("name,n_expected", CONFIG3)
-def test_config3_dam_break_8m_against_the_oracle(product_lib, oracle_lib, name, n_expected):
+@pytest.mark.parametrize("name,n_expected,steps", CONFIG3)
+def test_config3_dam_break_8m_against_the_oracle(product_lib, oracle_lib, name, n_expected, steps):
     g, o, P = make_pair(product_lib, oracle_lib, name, max_iters=3, **FORCED)
     assert g.n == n_expected
     p = P.to_ffi()
-    for s in range(3):
+    for s in range(steps):
         sg, so = g.step(p), o.step(p)
         assert abs(sg.dt - so.dt) <= 1e-6 * so.dt, s
         assert sg.div_solver.iters == so.div_solver.iters and sg.density_solver.iters == so.density_solver.iters
@@ -73,8 +74,8 @@ def test_config3_dam_break_8m_against_the_oracle(product_lib, oracle_lib, name, 
     assert_displacements(g, o)
 
 
-@pytest.mark.parametrize("name,n_expected", CONFIG3)
-def test_config3_dam_break_8m_eight_slabs_against_the_single_context(product_lib, name, n_expected):
+@pytest.mark.parametrize("name,n_expected,steps", CONFIG3)
+def test_config3_dam_break_8m_eight_slabs_against_the_single_context(product_lib, name, n_expected, steps):
     scene_f, params_f, _ = WORKLOADS[name]
     scn, P = scene_f(), params_f(max_iters=3, **FORCED)
     pos, mass, vel = sc.init_particles(scn)
@@ -271,8 +272,10 @@ def test_config2_columns_in_contact_at_full_size(product_lib, oracle_lib):
     apart -- they meet after thousands of steps, so neither test_full_size_parity_adaptive_4to1_against_the_oracle (3 steps) nor the
     free-standing bench leg ever evaluates a mixed-h pair.  Here the same two blocks -- 942 080 fine + 58 880 coarse particles, 4:1 radii
     -- stand one COARSE spacing apart (`scene.dam_break_1m_adaptive_contact`): every fine particle within a coarse support of the
-    interface (some 10^4) has a stencil wider than 3 x 3 cells of the fine sorting grid and records an explicit index list, a coarse
-    interface particle ~200 fine neighbours.  3 steps, iteration counts forced; sets entry by entry, fields within north_star's 1e-4."""
+    interface has a stencil wider than 3 x 3 cells of the fine sorting grid and records an explicit index list, a coarse interface
+    particle dozens of fine neighbours.  (Free-running this placement blows up at step 5 -- density solve at max_iters, 1e26 m/s -- on the
+    recipe's own parameters: profiles/r6_config2_contact.md; with forced counts it is a parity scene, the bench leg takes the blocks 1.5
+    coarse spacings apart, which collide dynamically.)  3 steps, iteration counts forced; sets entry by entry, fields within north_star's 1e-4."""
     g, o, P = make_pair(product_lib, oracle_lib, "dam_break_1m_adaptive_contact", max_iters=3, **FORCED)
     assert g.n == 942080 + 58880
     p = P.to_ffi()
@@ -297,11 +300,14 @@ def test_config2_columns_in_contact_at_full_size(product_lib, oracle_lib):
     mixed = row_fine != fine[idx]
     n_mixed_rows_fine = len(np.unique(np.repeat(np.arange(g.n), cnt)[mixed & row_fine]))
     n_mixed_rows_coarse = len(np.unique(np.repeat(np.arange(g.n), cnt)[mixed & ~row_fine]))
-    assert n_mixed_rows_fine > 10000 and n_mixed_rows_coarse >= 200, (n_mixed_rows_fine, n_mixed_rows_coarse)
+    # (measured: 1 609 fine particles -- the last two fine columns, 920 rows -- and 230 coarse ones -- the first coarse column -- carry mixed-h pairs)
+    assert n_mixed_rows_fine > 1500 and n_mixed_rows_coarse >= 200, (n_mixed_rows_fine, n_mixed_rows_coarse)
     del off, idx, row_fine, mixed
-    # ... and the device walks it on explicit index lists (or candidate walks), the bulk on row masks
+    # ... and the device works it on explicit index lists (or candidate walks) -- every particle with a mixed-h pair and, the stencil width
+    # being decided per tile of the sorting grid, the fine particles around them --, the bulk on row masks
     forms = g.profile_list_forms()
-    assert forms["n_lists"] == g.n and forms["n_index"] + forms["n_walk"] > 10000 and forms["n_mask"] > 0.9 * g.n, forms
+    assert forms["n_lists"] == g.n and forms["n_index"] + forms["n_walk"] >= n_mixed_rows_fine + n_mixed_rows_coarse and forms["n_mask"] > 0.9 * g.n, forms
+    print("config2 in contact: list forms", forms, "mixed rows", n_mixed_rows_fine, n_mixed_rows_coarse)
     for f in ("position", "density", "aii", "ppe_source_term"):
         assert rel_err(g.download(f), o.download(f)) < REL_TOL_FIELDS, f
     assert rel_err(g.download("velocity"), o.download("velocity")) < 1e-3     # carries the unconverged (3 iterations) pressure field
