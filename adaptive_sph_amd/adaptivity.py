@@ -119,7 +119,7 @@ def _find_partners(kind: str, size_class, mass, level, position, h2, offsets, in
                     can = True
             if not can:
                 continue
-            # XXX: VERY IMPORTANT long distance shares lead to popping/unstable behavior
+            # the partner must lie within max_{share,merge}_distance mean smoothing lengths (particle_sharing.rs:60-67, particle_merging.rs:71-78)
             dx, dy = position[i, 0] - position[j, 0], position[i, 1] - position[j, 1]
             max_dist = ((h2[i] + h2[j]) * f32(0.5)) * max_dist_factor
             if dx * dx + dy * dy > max_dist * max_dist:

@@ -1000,7 +1000,7 @@ extern "C" int sph_host_find_partners(int kind, uint64_t n, const uint8_t* cls, 
                 if (ap->allow_merge_on_size_difference && mass[j] > 5.f * mass[i]) can = true;
             }
             if (!can) continue;
-            // XXX: VERY IMPORTANT long distance shares lead to popping/unstable behavior
+            // the partner must lie within max_{share,merge}_distance mean smoothing lengths (particle_sharing.rs:60-67, particle_merging.rs:71-78)
             const float dx = pos[2 * i] - pos[2 * j], dy = pos[2 * i + 1] - pos[2 * j + 1];
             const float max_dist = ((h2[i] + h2[j]) * 0.5f) * max_dist_factor;
             if (dx * dx + dy * dy > max_dist * max_dist) continue;

@@ -246,6 +246,7 @@ __device__ __forceinline__ void replay_masks(const Op& op, typename Op::Acc& acc
 #ifndef SPH_FLAT16
 #define SPH_FLAT16 0
 #endif
+#if SPH_FLAT16   // (laboratory form: compiled only when a variant build asks for it, scripts/variants)
 template <class Op>
 __device__ __forceinline__ void replay_masks_flat(const Op& op, typename Op::Acc& acc, const float4 Ai, const uint32_t rb0, const uint32_t rb1,
                                                   const uint32_t rb2, const uint4 lw, const uint32_t i)
@@ -283,6 +284,8 @@ __device__ __forceinline__ void replay_masks_flat(const Op& op, typename Op::Acc
         replay_masks(op, acc, Ai, rbs, make_uint4(m0, m1, m2, 0u));
     }
 }
+
+#endif   // SPH_FLAT16
 
 // ---- list replay, explicit indices: one coalesced uint4 (4 neighbours) per trip ---------------------------
 template <class Op>
@@ -424,6 +427,7 @@ struct OpPrologue<Op, std::void_t<decltype(&Op::prologue)>> {
 #ifndef SPH_BUILD_2PHASE
 #define SPH_BUILD_2PHASE 0
 #endif
+#if SPH_BUILD_2PHASE   // (laboratory form: compiled only when a variant build asks for it, scripts/variants)
 template <class Op>
 __device__ __forceinline__ uint32_t predicate_row(const Op& op, const float4 Ai, const uint32_t b, const uint32_t e, const float s2)
 {
@@ -444,6 +448,8 @@ __device__ __forceinline__ uint32_t predicate_row(const Op& op, const float4 Ai,
     }
     return m;
 }
+
+#endif   // SPH_BUILD_2PHASE
 
 // BUILD sweep of a uniform scene whose solves run on records: the particle's mask word as 16-bit relative offsets j - i for k_sweep_off
 // (described there), written at the end of the density sweep -- it holds the row bases and the masks in registers; a kernel of its
@@ -547,20 +553,26 @@ __device__ __forceinline__ void sweep_particle(const Op& op, const SweepCommon& 
                     const uint32_t sb = i - rb[1];
                     if (sb < 32u) lw.y &= ~(1u << sb);
                 }
-                if (SPH_FLAT16 && Math::UNIFORM && !Op::EXTENDED) replay_masks_flat(op, acc, Ai, rb[0], rb[1], rb[2], lw, i);
-                else replay_masks(op, acc, Ai, rb, lw);
+#if SPH_FLAT16
+                if (Math::UNIFORM && !Op::EXTENDED) replay_masks_flat(op, acc, Ai, rb[0], rb[1], rb[2], lw, i);
+                else
+#endif
+                    replay_masks(op, acc, Ai, rb, lw);
             } else {
                 uint32_t mk[3] = {0u, 0u, 0u}, nacc = 0;
                 IdxRecorder rec;
                 rec.cur = make_uint4(0, 0, 0, 0);
                 const bool rec_idx = BUILD && IDX && (!ok_list || (SPH_FORCE_IDX && !Op::EXTENDED));
-                if (SPH_BUILD_2PHASE && BUILD && Math::UNIFORM && !Op::EXTENDED && !SPH_FORCE_IDX && ok_list) {
+#if SPH_BUILD_2PHASE
+                if (BUILD && Math::UNIFORM && !Op::EXTENDED && !SPH_FORCE_IDX && ok_list) {
                     const float s = op.m.h * op.krange();
 #pragma unroll
                     for (int dr = 0; dr < 3; dr++) mk[dr] = predicate_row(op, Ai, rb[dr], re[dr], s * s);
                     replay_masks(op, acc, Ai, rb, make_uint4(mk[0], mk[1], mk[2], 0u));
                     nacc = (uint32_t)(__popc(mk[0]) + __popc(mk[1]) + __popc(mk[2]));
-                } else if (rec_idx) {
+                } else
+#endif
+                if (rec_idx) {
 #pragma unroll
                     for (int dr = 0; dr < 3; dr++) walk_row<Op, false, true>(op, acc, Ai, rb[dr], re[dr], mk[dr], nacc, rec, c.nlx, c.n, i);
                     rec.flush(nacc, c.nlx, c.n, i);
@@ -788,6 +800,7 @@ __global__ __launch_bounds__(SWEEP_THREADS, OpOffWaves<Op>::value) void k_sweep_
     sweep_stamp(c.ts, true);
 }
 
+#ifdef SPH_LAB   // the LDS-staged form of the sweeps: a laboratory form (libsph_lab.so), measured slower every round (profiles/r2..r6_variants.md); not in the product TU
 // ------------------------------------------------------------------------------------------------
 // The same sweep with the wave's candidate rows staged in LDS (uniform-h scenes, mask lists).
 // The 64 particles of a wave are consecutive in the cell-sorted order; when they sit in ONE row of cells, their three
@@ -966,6 +979,8 @@ __device__ __forceinline__ void sweep_tile_block(const Op& op, const SweepCommon
 //   BoundaryWinchenbach2020::update_after_advect   boundary_winchenbach2020.rs:58-152
 //   neighbor_count                           simulation.rs:2072-2074
 // ------------------------------------------------------------------------------------------------
+#endif   // SPH_LAB (k_sweep_tile)
+
 struct NBNone {};
 
 // HDIST: support_length_estimation FromDistribution* -- compiled apart, the density sweep is VALU-bound and the two
@@ -3254,7 +3269,11 @@ static SweepCommon common_of(const SweepArgs& a, bool ext)
 // SPH_TILE: bit 0 = the BUILD sweep (density), bit 1 = the replay sweeps through the LDS-staged form (k_sweep_tile) in
 // uniform-h scenes.  Measured on MI355X: profiles/r2_variants.md.
 static int g_tile_mode = -1;   // sph_set_sweep_variant (process-wide override of the contexts' SPH_TILE option)
+#ifdef SPH_LAB
 static int tile_mode(const SweepArgs& a) { return g_tile_mode >= 0 ? g_tile_mode : (a.opt_tile ? a.opt_tile : SPH_TILE_DEFAULT); }
+#else
+static int tile_mode(const SweepArgs&) { return 0; }   // (the product ships the gather forms only)
+#endif
 // Options::jacobi_generic: the Jacobi update of uniform scenes through OpJacobi as well (measurement: what OpJacobiU is worth)
 // SPH_ACCEL_GENERIC (read once per step by the step driver, which then passes no record buffers: the tests compare both forms in one
 // process): sweep A of such scenes through OpPressureAccel, the solves' p / rho^2 as a field of its own
@@ -3324,12 +3343,14 @@ static void launch_sweep(hipStream_t s, const SweepArgs& a, const Op& op)
             return;
         }
     }
+#ifdef SPH_LAB
     if constexpr (Op::Math::UNIFORM && !Op::EXTENDED && OpTile<Op>::value) {
         if (tile_mode(a) & (BUILD ? 1 : 2)) {
             launch_sweep_kernel(k_sweep_tile<Op, BUILD>, dim3(grid), s, a, op, common_of(a, Op::EXTENDED));
             return;
         }
     }
+#endif
     launch_sweep_kernel(k_sweep<Op, BUILD>, dim3(grid), s, a, op, common_of(a, Op::EXTENDED));
 }
 

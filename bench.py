@@ -77,17 +77,30 @@ PMC_NAMES = {"density": "OpDensity[build]", "aii_constfield": "OpAiiConst", "non
              "source_term": "OpSource", "pressure_accel": "OpPressureAccelU", "jacobi_update": "OpJacobiU"}
 
 
+def newest_summary(pattern, regex):
+    """The newest committed profiles/ summary of a family: by PARSED round number, then suffix ('r10' after 'r9', 'r5q' after 'r5p';
+    a lexicographic sort puts r10 in front of r5q -- advisor r5)."""
+    import re
+    best = None
+    for f in (REPO / "profiles").glob(pattern):
+        m = re.fullmatch(regex, f.name)
+        if m:
+            key = (int(m.group(1)), m.group(2) or "")
+            if best is None or key > best[0]:
+                best = (key, f)
+    return best[1] if best else None
+
+
 def committed_pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the newest committed rocprofv3 --pmc summary (FETCH_SIZE and
     WRITE_SIZE are collected in their own passes, outside bench.py: scripts/summarize_profile.py)."""
-    import re
     # profiles/<round>_kernel_summary.json = configs[1] (the other configs carry their name: r2a_dam_break_8m_kernel_summary.json)
-    files = sorted(f for f in (REPO / "profiles").glob("*_kernel_summary.json") if re.fullmatch(r"r\d+[a-z]?_kernel_summary\.json", f.name))
-    if not files or kernel not in PMC_NAMES:
+    f = newest_summary("*_kernel_summary.json", r"r(\d+)([a-z]?)_kernel_summary\.json")
+    if f is None or kernel not in PMC_NAMES:
         return None, None
     try:
-        e = json.load(open(files[-1])).get(PMC_NAMES[kernel], {})
-        return e.get("hbm_traffic_bytes_per_launch"), files[-1].name
+        e = json.load(open(f)).get(PMC_NAMES[kernel], {})
+        return e.get("hbm_traffic_bytes_per_launch"), f.name
     except Exception:  # noqa: BLE001
         return None, None
 
@@ -95,13 +108,12 @@ def committed_pmc_traffic(kernel):
 def committed_8m(kernel):
     """(HBM bytes per launch, rocprofv3 average us, file) of `kernel` on configs[3] (8.4 M particles: the step's arrays no longer sit in the
     256 MB Infinity Cache, so FETCH_SIZE / WRITE_SIZE are HBM traffic there) from the newest committed summary of that config."""
-    import re
-    files = sorted(f for f in (REPO / "profiles").glob("*_dam_break_8m_kernel_summary.json") if re.fullmatch(r"r\d+[a-z]?_dam_break_8m_kernel_summary\.json", f.name))
-    if not files or kernel not in PMC_NAMES:
+    f = newest_summary("*_dam_break_8m_kernel_summary.json", r"r(\d+)([a-z]?)_dam_break_8m_kernel_summary\.json")
+    if f is None or kernel not in PMC_NAMES:
         return None, None, None
     try:
-        e = json.load(open(files[-1])).get(PMC_NAMES[kernel], {})
-        return e.get("hbm_traffic_bytes_per_launch"), e.get("avg_us_working", e.get("median_us_working")), files[-1].name
+        e = json.load(open(f)).get(PMC_NAMES[kernel], {})
+        return e.get("hbm_traffic_bytes_per_launch"), e.get("avg_us_working", e.get("median_us_working")), f.name
     except Exception:  # noqa: BLE001
         return None, None, None
 
@@ -109,12 +121,11 @@ def committed_8m(kernel):
 def committed_pmc_avg(kernel):
     """rocprofv3's average duration (us) of `kernel`'s working launches in the newest committed summary of configs[1] (the same
     command under rocprofv3 --kernel-trace --stats): what `avg_us` must agree with."""
-    import re
-    files = sorted(f for f in (REPO / "profiles").glob("*_kernel_summary.json") if re.fullmatch(r"r\d+[a-z]?_kernel_summary\.json", f.name))
-    if not files or kernel not in PMC_NAMES:
+    f = newest_summary("*_kernel_summary.json", r"r(\d+)([a-z]?)_kernel_summary\.json")
+    if f is None or kernel not in PMC_NAMES:
         return None
     try:
-        e = json.load(open(files[-1])).get(PMC_NAMES[kernel], {})
+        e = json.load(open(f)).get(PMC_NAMES[kernel], {})
         return e.get("avg_us_working", e.get("median_us_working"))
     except Exception:  # noqa: BLE001
         return None
@@ -535,6 +546,45 @@ def main():
         strong_8m_spec = run_8m(None, "dam_break_8m_spec")
         strong_8m_spec["max_dt"] = 0.00025
 
+    # ---- forced-count legs: the headline's window is chaotic -- its iteration counts change with any rounding
+    # and with the rank count -- so a ratio of two `value`s mixes communication with the counts.  Here the counts are FORCED (tolerances
+    # 0, max_iters = K: every solve runs exactly K iterations) at two values of K on the same steps from rest; the difference divided by
+    # the iterations is what ONE Jacobi iteration costs end to end (both sweeps, and on slabs: pack, exchange, unpack, totals) -- per
+    # transport, comparable across N.  Never part of `value`.
+    forced_count = None
+    if wl == "dam_break_1m":
+        FORCED = dict(hybrid_dfsph_max_avg_density_error=0.0, hybrid_dfsph_max_avg_divergence_error=0.0)
+        K_LO, K_HI, W_F, S_F = 6, 18, 2, 6
+
+        def forced_leg(name, tname):
+            sF, pFf, dF = WORKLOADS[name]
+            rec = {}
+            for K in (K_LO, K_HI):
+                c = None
+                try:
+                    PF = pFf(max_iters=K, **FORCED)
+                    c, nF = make_context(sF(), PF, tname)
+                    elF, _, diF, deF, _ = timed_run(c, PF.to_ffi(), W_F, S_F)
+                    rec[K] = (elF * 1e3 / S_F, float(np.mean(diF)) - 1 + float(np.mean(deF)) - 1, nF)
+                except (ffi.SphError, RuntimeError) as e:
+                    return {"failed": str(e)[:300]}
+                finally:
+                    if c is not None:
+                        c.close()
+            (t_lo, it_lo, nF), (t_hi, it_hi, _) = rec[K_LO], rec[K_HI]
+            return {"particles": nF, "steps": S_F, "warmup": W_F, "ms_per_step": {f"max_iters={K_LO}": t_lo, f"max_iters={K_HI}": t_hi},
+                    "jacobi_iterations_per_step": {f"max_iters={K_LO}": it_lo, f"max_iters={K_HI}": it_hi},
+                    "us_per_jacobi_iteration": (t_hi - t_lo) * 1e3 / max(it_hi - it_lo, 1e-9),
+                    "ms_per_step_without_iterations": t_lo - (t_hi - t_lo) / max(it_hi - it_lo, 1e-9) * it_lo}
+
+        forced_count = {"note": f"tolerances 0, max_iters = {K_LO} / {K_HI}: exact iteration counts; us_per_jacobi_iteration = the difference / the iterations "
+                                "(sweeps A + B and, on slabs, one exchange + totals); steps 2..7 from rest; n_gpus as the line's"}
+        for name in ["dam_break_1m"] + ([] if args.no_8m else ["dam_break_8m_spec"]):
+            forced_count[name] = {}
+            for t in ([transport] + other_transports) if distributed else ["single context"]:
+                leg(f"forced counts: {name} over {t}")
+                forced_count[name][t] = forced_leg(name, t if distributed else None)
+
     # ---- BASELINE configs[4] on the same ranks: the ratio-stress scene (4 004 343 particles at 50:1 radii, IISPH, Sdf2D box, EmptyAngle
     # level estimation) -- its step path, and a few calls of single_step WITH sharing / merging / splitting, the adaptive half in its
     # slab form (distributed.rank_single_step_adaptivity_on_slabs: the decisions on rank 0's host over the gathered 21 B per particle
@@ -634,8 +684,12 @@ def main():
              "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src, "traffic_GBs": traffic_gbs,
              "bound_evidence": {"config": "dam_break_8m (out of the Infinity Cache)", "traffic_bytes_per_launch": t8, "rocprofv3_avg_us": us8,
                                 "traffic_GBs": gbs8, "source": src8, "copy_kernel_GBs": copy_gbs, "guide_copy_GBs": GUIDE_COPY_GBS,
-                                "frac_of_streaming_rate": (gbs8 / copy_ref) if gbs8 else None, "rule": "hbm when >= 0.85"},
+                                "frac_of_streaming_rate": (gbs8 / copy_ref) if gbs8 else None, "rule": "hbm when >= 0.85",
+                                "measured_in_this_run": False},   # committed profiles of the shipped tree (dropped for another build, below)
              "avg_us": avg_s * 1e6, "avg_us_instrumented": raw_us if own_ts else raw_us - marker_excess_us, "launch_boundary_us": launch_boundary_us,
+             # (advisor r5) the same fraction on the dispatch's own timestamps alone -- MEASURED in this run; `launch_boundary_us` is DERIVED
+             # ((wall clock of the timed region - instrumented durations) / launches: host gaps of the timed region would land in it too)
+             "frac_dispatch_only": ALGO_BYTES[name] * n_local / ((raw_us if own_ts else raw_us - marker_excess_us) * 1e-6) / 1e9 / HBM_PEAK_GBS,
              "timed_by": ("dispatch timestamps (hipExtLaunchKernelGGL event pair)" if own_ts else "marker bracket - marker excess") + " + launch boundary",
              "marker_excess_us": None if own_ts else marker_excess_us,
              "rocprofv3_avg_us_committed": committed_pmc_avg(name) if wl == "dam_break_1m" and not distributed else None,
@@ -652,8 +706,13 @@ def main():
             clocks = avg_s * SHADER_CLOCK_HZ
             r["valu_issue"] = {"valu_instructions_per_wave": issue, "clocks_per_instruction": 3.0, "shader_clock_GHz": SHADER_CLOCK_HZ / 1e9,
                                "frac": issue * waves_per_simd * 3.0 / clocks, "source": "profiles/r5q_sq_counters.txt (SQ_INSTS_VALU / SQ_WAVES), profiles/r3_valu_issue.md"}
+            r["valu_issue"]["measured_in_this_run"] = False
         if name in WAVE_STATE:
-            r["wave_state"] = dict(WAVE_STATE[name], source="profiles/r5q_sq_counters.txt (SQ_WAIT_ANY, SQ_WAIT_INST_ANY, SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES; TCP_TCC_READ_REQ_LATENCY / TCP_TCC_READ_REQ; TCC_HIT / TCC_REQ)")
+            r["wave_state"] = dict(WAVE_STATE[name], measured_in_this_run=False, source="profiles/r5q_sq_counters.txt (SQ_WAIT_ANY, SQ_WAIT_INST_ANY, SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES; TCP_TCC_READ_REQ_LATENCY / TCP_TCC_READ_REQ; TCC_HIT / TCC_REQ)")
+        if os.environ.get("SPH_HIP_LIBRARY"):   # another build than the shipped one: the committed counters are not its counters
+            for key in ("bound_evidence", "valu_issue", "wave_state", "traffic", "traffic_source", "traffic_GBs", "rocprofv3_avg_us_committed", "avg_us_vs_rocprofv3_committed"):
+                r.pop(key, None)
+            r["bound"] = "not decided (SPH_HIP_LIBRARY: the committed counters belong to the shipped build)"
         return r
 
     total_prof_ms = sum(v[1] for v in prof_all.values()) or 1.0
@@ -707,6 +766,7 @@ def main():
         "strong_8m": strong_8m,
         "strong_8m_spec": strong_8m_spec,
         "transports": transports,
+        "forced_count": forced_count,
         "config4_ratio_stress_4m": config4,
         "comm_rank0": comm_record(comm_stats, args.steps) if distributed else {"host_waits_per_step": comm_stats["host_waits"] / max(args.steps, 1)},
     }
