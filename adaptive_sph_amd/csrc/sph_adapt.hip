@@ -364,7 +364,8 @@ static int transfer(sph_ctx* c, const sph_params* p, const sph_adapt_params* ap,
     // positions and masses changed: what the last step left behind no longer describes the state
     c->hdr_ahead = false;
     c->grid_valid = false;
-    if (c->ctrl_host) ((uint32_t*)(c->ctrl_host + 2))[1] = 0u;   // (the incremental sort's last mover count belongs to the vector before this call)
+    if (c->ctrl_host) ((uint32_t*)(c->ctrl_host + 2))[1] = 0u;
+    c->inc_count_valid = false;   // (the incremental sort's last mover count belongs to the vector before this call)
     c->lists_after = false;
     // (sharing neither reorders nor resizes the vector: stash and the step's flags keep describing the particles in their slots,
     //  as the reference's ParticleVec keeps them through share_particles -- snapshots taken after single_step show them)
@@ -705,7 +706,8 @@ static void slab_after_regather(sph_ctx* c, uint32_t n_new)
     c->dist.have_flags = false;
     c->dist.n_ghost[0] = c->dist.n_ghost[1] = c->dist.n_halo[0] = c->dist.n_halo[1] = 0;
     c->grid_valid = false;
-    if (c->ctrl_host) ((uint32_t*)(c->ctrl_host + 2))[1] = 0u;   // (the incremental sort's last mover count belongs to the vector before this call)
+    if (c->ctrl_host) ((uint32_t*)(c->ctrl_host + 2))[1] = 0u;
+    c->inc_count_valid = false;   // (the incremental sort's last mover count belongs to the vector before this call)
     c->have_level = false;
     c->have_reduced = false;
     c->lists_after = false;
@@ -800,7 +802,8 @@ static int slab_adapt(Group& G, int op, const sph_params* p, const sph_adapt_par
             if (r2) local_rc = r2;
             c->hdr_ahead = false;
             c->grid_valid = false;
-            if (c->ctrl_host) ((uint32_t*)(c->ctrl_host + 2))[1] = 0u;   // (the incremental sort's last mover count belongs to the vector before this call)
+            if (c->ctrl_host) ((uint32_t*)(c->ctrl_host + 2))[1] = 0u;
+    c->inc_count_valid = false;   // (the incremental sort's last mover count belongs to the vector before this call)
             c->lists_after = false;
         }
         if ((rc = agree(G, local_rc))) return rc;

@@ -555,6 +555,20 @@ Options options_from_env()
     o.slab_records = num("SPH_SLAB_RECORDS", 1) != 0 ? 1 : 0;
     o.side_cus = num("SPH_SIDE_CUS", 0);
     o.main_exclude = num("SPH_MAIN_EXCLUDE", 0) != 0 ? 1 : 0;
+#else
+    // the product ignores the laboratory's switches -- and says so, once per process (advisor r5: a bisect script that sets them against
+    // libsph_hip.so would otherwise run the defaults in every row and report nothing)
+    static const char* const lab_only[] = {"SPH_PACED", "SPH_PACE_LEAD", "SPH_PACE_PRED", "SPH_CHAIN", "SPH_ACCEL_GENERIC", "SPH_JACOBI_GENERIC", "SPH_SOURCE_GENERIC",
+                                           "SPH_SLAB_GENERAL", "SPH_SLAB_LEVEL_PLAIN", "SPH_LEVEL_SERIAL", "SPH_LEVEL_BATCH8", "SPH_LEVEL_QUEUE", "SPH_OFFSET_LISTS",
+                                           "SPH_NO_FUSE", "SPH_SIDE_STREAM_NORMAL", "SPH_TILE", "SPH_AHEAD_BUILD", "SPH_INC_SORT", "SPH_SLAB_PACED", "SPH_SLAB_RECORDS",
+                                           "SPH_SIDE_CUS", "SPH_MAIN_EXCLUDE"};
+    static bool warned = false;
+    if (!warned)
+        for (const char* name : lab_only)
+            if (getenv(name)) {
+                fprintf(stderr, "libsph_hip: %s is a laboratory switch and is IGNORED by the product library (use SPH_HIP_LIBRARY=libsph_lab.so, scripts/README.md)\n", name);
+                warned = true;
+            }
 #endif
     return o;
 }
@@ -727,6 +741,7 @@ extern "C" int sph_set_math_policy(sph_ctx* c, int policy)
     c->hdr_ahead = false;
     c->lists_after = false;
     if (c->ctrl_host) ((uint32_t*)(c->ctrl_host + 2))[1] = 0u;
+    c->inc_count_valid = false;
     return SPH_OK;
 }
 extern "C" int sph_get_math_policy(const sph_ctx* c) { return c ? c->exact : -1; }
@@ -744,7 +759,8 @@ extern "C" int sph_upload(sph_ctx* c, uint64_t n, const float* mass, const float
     c->dist.have_flags = false;
     c->dist.n_tot = (uint32_t)n;
     c->grid_valid = false;   // lists, cell indices and per-step outputs belong to the vector before this call
-    if (c->ctrl_host) ((uint32_t*)(c->ctrl_host + 2))[1] = 0u;   // ... and so does the incremental sort's last mover count (advisor r4)
+    if (c->ctrl_host) ((uint32_t*)(c->ctrl_host + 2))[1] = 0u;
+    c->inc_count_valid = false;   // ... and so does the incremental sort's last mover count (advisor r4)
     c->have_level = false;
     c->have_reduced = false;
     c->lists_after = false;
@@ -1076,7 +1092,8 @@ int regather_host_order(sph_ctx* c, uint32_t n_new, const EditSrc* d_src, const 
     c->dist.have_flags = false;   // (slab context: owned particles only, in row order; the next step selects new ghosts)
     c->dist.n_ghost[0] = c->dist.n_ghost[1] = c->dist.n_halo[0] = c->dist.n_halo[1] = 0;
     c->grid_valid = false;   // lists, cell indices and per-step outputs belong to the vector before this call
-    if (c->ctrl_host) ((uint32_t*)(c->ctrl_host + 2))[1] = 0u;   // ... and so does the incremental sort's last mover count (advisor r4)
+    if (c->ctrl_host) ((uint32_t*)(c->ctrl_host + 2))[1] = 0u;
+    c->inc_count_valid = false;   // ... and so does the incremental sort's last mover count (advisor r4)
     c->have_level = false;
     c->have_reduced = false;
     c->lists_after = false;

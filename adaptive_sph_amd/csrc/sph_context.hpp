@@ -202,6 +202,8 @@ struct sph_ctx {
     DevBuf inc_head, inc_next, inc_bsum, inc_movers;
     uint32_t inc_epoch = 0;     // tag of the current call's list heads
     int inc_radix_streak = 0;   // ahead builds in a row that took the radix sort because the last known mover count was large
+    bool inc_count_valid = false;   // the mapped mover-count word was written by a merge queued SINCE the state was last replaced (upload, edits,
+                                    // adaptivity, math policy): a build still in flight at such a call may write its stale count after the host's reset (advisor r5)
     struct Ahead {
         bool valid = false;
         GridP g{};

@@ -917,7 +917,7 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
         if (merge) {
             const uint32_t limit = n_sort / (c->opt.inc_sort > 1 ? (uint32_t)c->opt.inc_sort : 3u);
             if (n_sort - n_prev > limit) merge = false;
-            else if (*movers_host > limit) {
+            else if (c->inc_count_valid && *movers_host > limit) {
                 merge = ++c->inc_radix_streak >= 8;
                 if (merge) c->inc_radix_streak = 0;
             }
@@ -972,6 +972,7 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
                 incremental_cell_sort_perm(s, prof, n_sort, n_prev, kg, q, c->cell_start.as<uint32_t>(), c->key[0].as<uint32_t>(), c->val[0].as<uint32_t>(),
                                            c->acell_start.as<uint32_t>(), c->inc_bsum.as<uint32_t>(), c->inc_movers.as<uint32_t>(),
                                            (uint32_t*)(c->ctrl_host_dev + 2) + 1);
+                c->inc_count_valid = true;   // (a count of the current state is on its way, behind any stale one on the same stream)
                 std::swap(c->cell_start, c->acell_start);   // (the old table was read while the new one was written)
             } else {
                 int res = radix_sort_pairs(s, prof, c->key[0].as<uint32_t>(), c->val[0].as<uint32_t>(), c->key[1].as<uint32_t>(),
@@ -1581,7 +1582,7 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
         // the device reported: a step or two old) sends the build through the radix sort, and every eighth such build probes again.
         const uint32_t* movers_host = (const uint32_t*)(c->ctrl_host + 2) + 1;   // (second word of the mapped block whose first word is the paced solves' progress)
         bool incremental = c->opt.inc_sort && c->grid_valid && c->fgrid.cs == cs && c->fgrid.ncells > 0 && g.ncells <= n + 4096u;   // (see k_inc_scan: quadratic in ncells / 1024; a grid much sparser than one cell per particle takes the radix sort)
-        if (incremental && *movers_host > n / (c->opt.inc_sort > 1 ? (uint32_t)c->opt.inc_sort : 3u)) {
+        if (incremental && c->inc_count_valid && *movers_host > n / (c->opt.inc_sort > 1 ? (uint32_t)c->opt.inc_sort : 3u)) {
             incremental = ++c->inc_radix_streak >= 8;
             if (incremental) c->inc_radix_streak = 0;
         }
@@ -1624,6 +1625,7 @@ static int group_step_inner(Group& G, const sph_params* p, sph_step_stats* outs,
             incremental_cell_sort_reorder(s, &c->prof, n, integrated, plan.q, /* classified by the tail */ true, c->cell_start.as<uint32_t>(), c->akey[0].as<uint32_t>(),
                                           c->acell_start.as<uint32_t>(), io, c->inc_bsum.as<uint32_t>(), c->inc_movers.as<uint32_t>(),
                                           (uint32_t*)(c->ctrl_host_dev + 2) + 1);
+            c->inc_count_valid = true;   // (a count of the current state is on its way, behind any stale one on the same stream)
         } else {
             const CellKeyGen kg{integrated, g, nullptr, 0u, (uint32_t)SC_GONE_FROM, 1};   // (clamped keys: the grid is a prediction)
             const int res = radix_sort_pairs(s, &c->prof, c->akey[0].as<uint32_t>(), c->aval[0].as<uint32_t>(), c->akey[1].as<uint32_t>(), c->aval[1].as<uint32_t>(), n,

@@ -1243,6 +1243,10 @@ __global__ __launch_bounds__(64) void k_ipc_wait(IpcWait j)
     bool ok = true;
     if (t < 2 && j.seq[t]) ok = ipc_wait(j.flag[t], j.seq[t], j.timeout_ticks);
     if (j.tot_flag && t >= 2 && t < 2u + (uint32_t)j.nr && (int)(t - 2u) != j.self) ok = ipc_wait(j.tot_flag + (t - 2u), j.tot_seq, j.timeout_ticks);
+    // a wait that gave up: the sticky status word ends the step with SPH_ERR_DEVICE at its next status check; sph_step then poisons the
+    // context AND abandons the group (comm_abandon: the shared-memory segment under this transport is marked broken), so every rank's
+    // later steps fail at once instead of pairing mismatched sequence numbers -- the segment is recreated, as a failed RCCL communicator
+    // would be (advisor r5).  Under rocprofv3 or a debugger a rank may stall for longer than the default: raise SPH_IPC_TIMEOUT_MS there.
     if (!ok && atomicCAS(&j.status->error, 0u, (uint32_t)SPH_ERR_DEVICE) == 0u) j.status->info = 0x1bc00000u | t;   // (info: which waiter gave up)
     __syncthreads();
     if (j.tot_flag && t < 6) {

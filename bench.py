@@ -311,8 +311,12 @@ def main():
                                   "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:])
     if args.gpus != world:
         raise SystemExit(f"bench.py --gpus {args.gpus} was launched with WORLD_SIZE={world}: one rank per GPU")
+    # where the time in front of the timed region goes (21 s there): on a fresh box `import torch` pages in ~2 GB of
+    # libraries (10-60 s the first time, 1.5 s later); the library load, the scene (1M particles in numpy) and the upload are < 1 s together
+    leg("start-up: import torch (first import on a fresh box pages the libraries in)")
     import torch
     import torch.distributed as dist
+    leg("start-up: build check, library load, scene")
     if torch.cuda.is_available():
         local_rank %= max(torch.cuda.device_count(), 1)   # more ranks than devices: only for functional checks on a small box
     from adaptive_sph_amd import build, ffi, scene as sc

@@ -154,7 +154,7 @@ def test_chained_solves_on_slabs_are_bit_identical_to_the_two_wait_form(lab_lib,
 
 
 def test_record_sweeps_with_masses_one_ulp_apart_stay_within_rounding_of_the_generic_sweeps(lab_lib, monkeypatch):
-    """OpPressureAccelU / OpJacobiU take ONE mass for every neighbour (slot 0's, respectively the particle's own): exact when the masses
+    """OpPressureAccelU / OpJacobiU / OpSourceU take ONE mass for every neighbour (slot 0's, respectively the particle's own): exact when the masses
     are equal.  h = 1.9 sqrt(m / (rho0 pi)) loses a bit, so masses that are neighbouring floats still give bit-identical smoothing
     lengths -- the record path stays on -- and the substitution is then a relative error of one ulp per pair.  Bound it: the same
     steps through the generic sweeps (per-neighbour m_j) agree to a few 1e-6 of the field's scale, counts equal."""
@@ -174,6 +174,7 @@ def test_record_sweeps_with_masses_one_ulp_apart_stay_within_rounding_of_the_gen
         if generic:
             monkeypatch.setenv("SPH_ACCEL_GENERIC", "1")
             monkeypatch.setenv("SPH_JACOBI_GENERIC", "1")
+            monkeypatch.setenv("SPH_SOURCE_GENERIC", "1")   # (advisor r5: OpSourceU's single mass -- particle 0's -- is bounded by the same bars)
         g = ffi.Context(lab_lib, len(mass2), sc.boundary_planes(scn.boundary, P.init_boundary_handler))
         g.upload(mass2, pos, vel)
         its = []
@@ -184,6 +185,7 @@ def test_record_sweeps_with_masses_one_ulp_apart_stay_within_rounding_of_the_gen
         if generic:
             monkeypatch.delenv("SPH_ACCEL_GENERIC")
             monkeypatch.delenv("SPH_JACOBI_GENERIC")
+            monkeypatch.delenv("SPH_SOURCE_GENERIC")
     (a, ia), (b, ib) = out[False], out[True]
     assert ia == ib
     for f, tol in (("position", 2e-6), ("velocity", 2e-5), ("density", 2e-6), ("pressure", 2e-4)):
