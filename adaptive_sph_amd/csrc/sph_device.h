@@ -434,3 +434,55 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
     return v;
 }
+
+// A rank's solver totals of one Jacobi iteration from sweep B's per-block partials, by ONE workgroup of 1024 lanes in a fixed order
+// (lane t takes partials t, t + 1024, ...; lanes, then waves in index order): deterministic.  Thread 0 stores the six doubles the ranks
+// all-reduce (solver_decide_multi): normal, singular, negative, sum of errors, largest error (informational when summed), "a guard
+// fired on this rank".  Shared by the slab decomposition's packing launch (sph_sweeps.hip: k_pack_totals) and the push transport's fused
+// pack + push (sph_transport.hip: k_ipc_pack_push); every lane of the workgroup must call it, a __syncthreads() sits inside.
+#define RANK_TOTALS_THREADS 1024
+struct DeviceStatus;
+__device__ __forceinline__ void rank_totals_block(const SolverPartial* __restrict__ partials, uint32_t nparts, double* __restrict__ tot, const uint32_t* __restrict__ status_error)
+{
+    __shared__ SolverPartial s_r[RANK_TOTALS_THREADS / 64];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+    SolverPartial t{0, 0, 0, 0.f, 0.f};
+    for (uint32_t k0 = tid; k0 < nparts; k0 += 8u * RANK_TOTALS_THREADS) {
+        SolverPartial v[8];
+#pragma unroll
+        for (uint32_t u = 0; u < 8u; u++) {
+            const uint32_t k = k0 + u * RANK_TOTALS_THREADS;
+            v[u] = k < nparts ? partials[k] : SolverPartial{0, 0, 0, 0.f, 0.f};
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < 8u; u++) {
+            t.normal += v[u].normal;
+            t.singular += v[u].singular;
+            t.negative += v[u].negative;
+            t.sum_err += v[u].sum_err;
+            t.max_err = fmaxf(t.max_err, v[u].max_err);
+        }
+    }
+    t.normal = wave_sum_u32(t.normal);
+    t.singular = wave_sum_u32(t.singular);
+    t.negative = wave_sum_u32(t.negative);
+    t.sum_err = wave_sum(t.sum_err);
+    t.max_err = wave_max(t.max_err);
+    if (lane == 0) s_r[w] = t;
+    __syncthreads();
+    if (tid != 0) return;
+    t = s_r[0];
+    for (int k = 1; k < RANK_TOTALS_THREADS / 64; k++) {
+        t.normal += s_r[k].normal;
+        t.singular += s_r[k].singular;
+        t.negative += s_r[k].negative;
+        t.sum_err += s_r[k].sum_err;
+        t.max_err = fmaxf(t.max_err, s_r[k].max_err);
+    }
+    tot[0] = (double)t.normal;
+    tot[1] = (double)t.singular;
+    tot[2] = (double)t.negative;
+    tot[3] = (double)t.sum_err;
+    tot[4] = (double)t.max_err;   // summed over the ranks: informational
+    tot[5] = *status_error != 0u ? 1.0 : 0.0;   // a guard fired on this rank: every rank ends the solve (solver_decide_multi)
+}

@@ -21,6 +21,26 @@ struct Xfer {
     size_t recv_bytes[2];
 };
 
+// A Jacobi iteration's ghost exchange with the packing and the unpacking INSIDE the transport's own launches (round 6; the push transport:
+// pack + totals + push in ONE launch, wait + totals' sum + unpack in ONE -- four launches per iteration with sweeps B and A instead of six).
+// One float per particle at field[slot * stride + off]; the halo members' slots in halo_src = [to the left | to the right neighbour], the
+// ghosts' in ghost_dst = [from the left | from the right]; the rank's totals of iteration `iter` are added up in front of the push (what
+// block 0 of k_pack_totals does: same reduction, same early exits).
+struct FusedField {
+    const uint32_t* halo_src;
+    uint32_t n_halo[2];
+    const uint32_t* ghost_dst;
+    uint32_t n_ghost[2];
+    bool scatter;   // false: this rank has no ghost slots (ghosts_ok == false): the messages are received and dropped
+    float* field;
+    int stride, off;
+    const void* partials;   // SolverPartial[nparts]
+    uint32_t nparts;
+    SolverCtrl* ctrl;
+    const uint32_t* gate;
+    int iter;
+};
+
 struct RefreshCounts {
     uint32_t mig[2], halo[2];         // this rank: migrants to / halo members (that stay) towards [left, right]
     uint32_t in_mig[2], in_halo[2];   // the neighbours': migrants for me / their halo members towards me, from [left, right]
@@ -51,6 +71,10 @@ struct Comm {
         const int rc = exchange(G, x);
         return rc ? rc : allreduce_solver(G, slot);
     }
+    // ... and the same with the packing / unpacking of ONE float field inside the transport's launches, where the transport has launches of
+    // its own to put them in (the push transport); `bytes` = the largest message of the exchange
+    virtual bool can_fuse_iteration(Group&, size_t /*bytes*/) { return false; }
+    virtual int exchange_fused(Group&, const FusedField&, int /*slot*/) { return SPH_ERR_UNSUPPORTED; }
     virtual bool host_collectives_wait() const = 0;
     // ONE round trip for a decomposition phase: the class counts the phase's classify kernel left in dist.counts[base ..
     // base + 3] (1 = to the left neighbour, 2 = to the right, 3 = dropped / too narrow; class 0 is derived by the caller) reach

@@ -494,6 +494,18 @@ int refresh_ghosts(Group& G, std::vector<Member>& M, float* (*sel)(Member&), int
     if (!G.multi()) return SPH_OK;
     if (stride <= 0) stride = words;
     const int nf = sel2 ? 2 : 1;   // fields per exchange: the second one is packed behind the first in every buffer
+    if (totals && nf == 1 && words == 1 && tot_slot >= 0 && M.size() == 1 && M[0].n) {
+        // a Jacobi iteration's exchange on a transport with launches of its own (the push transport): pack + totals + push in one launch,
+        // wait + unpack in one (Comm::exchange_fused) -- no k_pack_totals, no k_unpack_field
+        sph_ctx* c = M[0].c;
+        auto& d = c->dist;
+        const size_t bytes = 4 * (size_t)std::max(std::max(d.n_halo[0], d.n_halo[1]), std::max(d.n_ghost[0], d.n_ghost[1]));
+        if (G.comm->can_fuse_iteration(G, bytes)) {
+            const FusedField f{d.halo_src.as<uint32_t>(), {d.n_halo[0], d.n_halo[1]}, d.ghost_dst.as<uint32_t>(), {d.n_ghost[0], d.n_ghost[1]}, d.ghosts_ok,
+                               sel(M[0]), stride, off, M[0].a.partials, solver_reduce_blocks(M[0].a.n), M[0].a.ctrl, M[0].a.gate, totals->iter};
+            return G.comm->exchange_fused(G, f, tot_slot);
+        }
+    }
     std::vector<Xfer> x(M.size());
     for (size_t i = 0; i < M.size(); i++) {
         sph_ctx* c = M[i].c;

@@ -3551,6 +3551,7 @@ void launch_solver_totals(hipStream_t s, Profiler* prof, const SweepArgs& a, int
 // decomposition): both wait for sweep B, both precede the exchange -- one launch instead of two (a kernel boundary is ~4 us, and an
 // iteration of 1M particles per rank is ~45 us of sweeps).  Blocks 1.. pack: entries [0, cnt0) go to the left neighbour's staging
 // buffer, [cnt0, cnt0 + cnt1) to the right one's (k_pack_field of sph_slabs.hip).
+static_assert(RANK_TOTALS_THREADS == 1024, "k_pack_totals' block 0 is rank_totals_block's workgroup");
 #define PACK_THREADS 1024   // block 0 adds up one partial per 256 particles: 32768 of them at 8M particles per rank -- on the iteration's critical path
 __global__ __launch_bounds__(PACK_THREADS) void k_pack_totals(const SolverPartial* __restrict__ partials, uint32_t nparts, SolverCtrl* ctrl, double* __restrict__ tot,
                                                               int iter, float rest_density, float dt, const DeviceStatus* status,
@@ -3561,48 +3562,7 @@ __global__ __launch_bounds__(PACK_THREADS) void k_pack_totals(const SolverPartia
     if (blockIdx.x == 0) {
         if (gate && *gate == 0u) return;
         if (ctrl->slot_done[iter & 1] != 0u) return;   // (see k_solver_totals)
-        // the rank's totals in a fixed order (thread t takes partials t, t + 1024, ...; lanes, then waves in index order): deterministic
-        __shared__ SolverPartial s_r[PACK_THREADS / 64];
-        const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
-        SolverPartial t{0, 0, 0, 0.f, 0.f};
-        for (uint32_t k0 = tid; k0 < nparts; k0 += 8u * PACK_THREADS) {
-            SolverPartial v[8];
-#pragma unroll
-            for (uint32_t u = 0; u < 8u; u++) {
-                const uint32_t k = k0 + u * PACK_THREADS;
-                v[u] = k < nparts ? partials[k] : SolverPartial{0, 0, 0, 0.f, 0.f};
-            }
-#pragma unroll
-            for (uint32_t u = 0; u < 8u; u++) {
-                t.normal += v[u].normal;
-                t.singular += v[u].singular;
-                t.negative += v[u].negative;
-                t.sum_err += v[u].sum_err;
-                t.max_err = fmaxf(t.max_err, v[u].max_err);
-            }
-        }
-        t.normal = wave_sum_u32(t.normal);
-        t.singular = wave_sum_u32(t.singular);
-        t.negative = wave_sum_u32(t.negative);
-        t.sum_err = wave_sum(t.sum_err);
-        t.max_err = wave_max(t.max_err);
-        if (lane == 0) s_r[w] = t;
-        __syncthreads();
-        if (tid != 0) return;
-        t = s_r[0];
-        for (int k = 1; k < PACK_THREADS / 64; k++) {
-            t.normal += s_r[k].normal;
-            t.singular += s_r[k].singular;
-            t.negative += s_r[k].negative;
-            t.sum_err += s_r[k].sum_err;
-            t.max_err = fmaxf(t.max_err, s_r[k].max_err);
-        }
-        tot[0] = (double)t.normal;
-        tot[1] = (double)t.singular;
-        tot[2] = (double)t.negative;
-        tot[3] = (double)t.sum_err;
-        tot[4] = (double)t.max_err;   // summed over the ranks: informational
-        tot[5] = status->error != 0u ? 1.0 : 0.0;   // a guard fired on this rank: every rank ends the solve (solver_decide_multi)
+        rank_totals_block(partials, nparts, tot, &status->error);   // (sph_device.h: the same reduction the push transport's fused launch runs)
         return;
     }
     const uint32_t k = (blockIdx.x - 1u) * PACK_THREADS + threadIdx.x;

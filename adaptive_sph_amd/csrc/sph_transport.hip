@@ -1256,8 +1256,160 @@ __global__ __launch_bounds__(64) void k_ipc_wait(IpcWait j)
     }
 }
 
+// ---- the fused round of a Jacobi iteration (round 6; VERDICT r5 next 4: launches that are deterministic cost) ----------------------------
+// k_ipc_pack_push: ONE workgroup adds up the rank's totals of the iteration (rank_totals_block: what block 0 of k_pack_totals does, with its
+// early exits), gathers the halo members' values from the field straight into the x-neighbours' inboxes (no staging buffer, no packing
+// launch), writes the totals row into every rank's table, fences, signals.  k_ipc_wait_unpack: ONE workgroup waits for the neighbours' and
+// the ranks' flags (bounded, like k_ipc_wait), sums the totals in rank order and scatters the inboxes into the ghosts' slots (no unpacking
+// launch).  The inboxes live in fine-grained memory a peer GPU writes: they are read with system-scope loads behind the acquiring wait.
+struct IpcFusedPush {
+    const SolverPartial* partials;
+    uint32_t nparts;
+    const SolverCtrl* ctrl;
+    const uint32_t* gate;
+    const uint32_t* status_error;
+    int iter;
+    const uint32_t* halo_src;
+    uint32_t cnt[2];
+    const float* field;
+    int stride, off;
+    float* dst[2];             // the neighbour's inbox (peer-mapped), nullptr: no neighbour on that side
+    uint32_t* flag[2];
+    uint32_t seq[2];
+    double* tot;               // my row (local): written here, read by my own k_ipc_wait_unpack
+    double* tot_dst[SHM_MAX_RANKS];
+    uint32_t* tot_flag[SHM_MAX_RANKS];
+    uint32_t tot_seq;
+    int nr, self;
+};
+__global__ __launch_bounds__(RANK_TOTALS_THREADS) void k_ipc_pack_push(IpcFusedPush j)
+{
+    // (block-uniform conditions: every lane takes the same branch around the reduction's barrier)
+    const bool stale = (j.gate && *j.gate == 0u) || j.ctrl->slot_done[j.iter & 1] != 0u;   // k_pack_totals' early exits: nobody reads the totals then
+    if (!stale) rank_totals_block(j.partials, j.nparts, j.tot, j.status_error);
+    __syncthreads();   // thread 0's totals are visible to the lanes that push them
+    uint32_t base = 0;
+    for (int s = 0; s < 2; s++) {
+        if (j.dst[s])
+            for (uint32_t k = threadIdx.x; k < j.cnt[s]; k += RANK_TOTALS_THREADS) j.dst[s][k] = j.field[(size_t)j.halo_src[base + k] * j.stride + j.off];
+        base += j.cnt[s];
+    }
+    if (threadIdx.x < 6u * (uint32_t)j.nr) {
+        const int r = (int)(threadIdx.x / 6u), k = (int)(threadIdx.x % 6u);
+        if (r != j.self) j.tot_dst[r][k] = j.tot[k];
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x < 2 && j.seq[threadIdx.x]) ipc_store_release(j.flag[threadIdx.x], j.seq[threadIdx.x]);
+    if (threadIdx.x >= 64 && threadIdx.x < 64u + (uint32_t)j.nr && (int)(threadIdx.x - 64u) != j.self) ipc_store_release(j.tot_flag[threadIdx.x - 64u], j.tot_seq);
+}
+struct IpcFusedWait {
+    IpcWait w;
+    const uint32_t* inbox[2];   // my inboxes of this round ([from left, from right]); nullptr: nothing to scatter from that side
+    const uint32_t* ghost_dst;
+    uint32_t cnt[2];
+    uint32_t* field;            // (the float field, moved as words)
+    int stride, off;
+};
+__global__ __launch_bounds__(1024) void k_ipc_wait_unpack(IpcFusedWait f)
+{
+    const IpcWait& j = f.w;
+    const uint32_t t = threadIdx.x;
+    bool ok = true;
+    if (t < 2 && j.seq[t]) ok = ipc_wait(j.flag[t], j.seq[t], j.timeout_ticks);
+    if (j.tot_flag && t >= 2 && t < 2u + (uint32_t)j.nr && (int)(t - 2u) != j.self) ok = ipc_wait(j.tot_flag + (t - 2u), j.tot_seq, j.timeout_ticks);
+    if (!ok && atomicCAS(&j.status->error, 0u, (uint32_t)SPH_ERR_DEVICE) == 0u) j.status->info = 0x1bc00000u | t;   // (see k_ipc_wait)
+    __syncthreads();
+    if (j.tot_flag && t < 6) {
+        double s = 0.0;
+        for (int r = 0; r < j.nr; r++) s += r == j.self ? j.tot[t] : __hip_atomic_load(j.table + 8 * r + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        j.tot[t] = s;
+    }
+    uint32_t base = 0;
+    for (int s = 0; s < 2; s++) {
+        if (f.inbox[s])
+            for (uint32_t k = t; k < f.cnt[s]; k += 1024u)
+                f.field[(size_t)f.ghost_dst[base + k] * f.stride + f.off] = __hip_atomic_load(f.inbox[s] + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        base += f.cnt[s];
+    }
+}
+
 struct IpcComm : ShmComm {
     static IpcState* st(sph_ctx* c) { return (IpcState*)c->dist.ipc; }
+    bool can_fuse_iteration(Group& G, size_t bytes) override { return G.m.size() == 1 && st(G.m[0]) && bytes <= st(G.m[0])->bytes_per_side && bytes <= (64u << 10); }
+    int exchange_fused(Group& G, const FusedField& f, int slot) override
+    {
+        sph_ctx* c = G.m[0];
+        IpcState* I = st(c);
+        const int r = c->dist.rank, nr = c->dist.nranks;
+        IpcFusedPush ps{};
+        IpcFusedWait fw{};
+        IpcWait& w = fw.w;
+        ps.partials = (const SolverPartial*)f.partials;
+        ps.nparts = f.nparts;
+        ps.ctrl = f.ctrl;
+        ps.gate = f.gate;
+        ps.status_error = &c->status.as<DeviceStatus>()->error;
+        ps.iter = f.iter;
+        ps.halo_src = f.halo_src;
+        ps.field = f.field;
+        ps.stride = f.stride;
+        ps.off = f.off;
+        fw.ghost_dst = f.ghost_dst;
+        fw.field = (uint32_t*)f.field;
+        fw.stride = f.stride;
+        fw.off = f.off;
+        for (int side = 0; side < 2; side++) {
+            ps.cnt[side] = f.n_halo[side];
+            fw.cnt[side] = f.n_ghost[side];
+            const int nb = side == 0 ? r - 1 : r + 1;
+            if (nb < 0 || nb >= nr) {
+                if (f.n_halo[side] || f.n_ghost[side]) return c->fail(SPH_ERR_DEVICE, "halo exchange across the outer edge of the slab row (rank %d)", r);
+                continue;
+            }
+            if (!f.n_halo[side] && !f.n_ghost[side]) continue;
+            const uint32_t seq = ++I->seq[side], parity = seq & 1u;
+            const int oside = side ^ 1;   // I am my left neighbour's right side
+            ps.dst[side] = (float*)IpcState::inbox(I->peer[nb], I->bytes_per_side, oside, parity);
+            ps.flag[side] = &((IpcBox*)I->peer[nb])->data_seq[oside];
+            ps.seq[side] = seq;
+            w.flag[side] = &((IpcBox*)I->mine)->data_seq[side];
+            w.seq[side] = seq;
+            if (f.scatter) fw.inbox[side] = (const uint32_t*)IpcState::inbox(I->mine, I->bytes_per_side, side, parity);
+            c->dist.stat_bytes_sent += (size_t)f.n_halo[side] * 4;
+            c->dist.stat_bytes_recv += (size_t)f.n_ghost[side] * 4;
+        }
+        {
+            const uint32_t seq = ++I->tot_n[slot], parity = seq & 1u;
+            ps.tot = c->dist.solver_tot.as<double>() + 8 * slot;
+            ps.tot_seq = seq;
+            ps.nr = nr;
+            ps.self = r;
+            for (int q = 0; q < nr; q++) {
+                IpcBox* b = (IpcBox*)I->peer[q];
+                ps.tot_dst[q] = b->tot[slot][parity][r];
+                ps.tot_flag[q] = &b->tot_seq[slot][r];
+            }
+            IpcBox* me = (IpcBox*)I->mine;
+            w.tot_flag = me->tot_seq[slot];
+            w.tot_seq = seq;
+            w.table = &me->tot[slot][parity][0][0];
+            w.tot = c->dist.solver_tot.as<double>() + 8 * slot;
+            w.nr = nr;
+            w.self = r;
+            c->dist.stat_allreduces++;
+        }
+        c->dist.stat_exchanges++;
+        {
+            ProfScope p1(&c->prof, "ipc_pack_push", c->stream);
+            hipLaunchKernelGGL(k_ipc_pack_push, dim3(1), dim3(RANK_TOTALS_THREADS), 0, c->stream, ps);
+        }
+        w.status = c->status.as<DeviceStatus>();
+        w.timeout_ticks = I->timeout_ticks;
+        ProfScope p2(&c->prof, "ipc_wait_unpack", c->stream);
+        hipLaunchKernelGGL(k_ipc_wait_unpack, dim3(1), dim3(1024), 0, c->stream, fw);
+        return SPH_OK;
+    }
     // queue the push and the wait of one round: the ghost / record messages of `x` (nullptr: none) and, with slot >= 0, the totals
     int round(Group& G, std::vector<Xfer>* x, int slot)
     {

@@ -466,7 +466,7 @@ def main():
     # one exchange costs in the step's queue (HIP-event brackets of a short instrumented run), the library's own view of the group.
     # `value` stays the primary transport's.  A transport that cannot be set up is recorded as such on every rank (make_slab_context
     # agrees on failures through the launcher's process group), it does not end the run.
-    EXCHANGE_KERNELS = ("rccl_sendrecv", "rccl_allreduce", "ipc_push", "ipc_wait", "ghost_pack", "ghost_unpack", "slab_refresh")
+    EXCHANGE_KERNELS = ("rccl_sendrecv", "rccl_allreduce", "ipc_push", "ipc_wait", "ipc_pack_push", "ipc_wait_unpack", "ghost_pack", "ghost_pack_totals", "ghost_unpack", "slab_refresh")
     transports = None
 
     def transport_run(tname, scn, P, label):
@@ -491,7 +491,7 @@ def main():
             rec["exchange_rank0"] = {"steps": k_, "jacobi_iterations": it_,
                                      "us_per_launch": {k: pa[k][1] * 1e3 / max(pa[k][0], 1) for k in EXCHANGE_KERNELS if k in pa},
                                      "launches_per_step": {k: pa[k][0] / k_ for k in EXCHANGE_KERNELS if k in pa},
-                                     "us_per_jacobi_iteration": sum(pa[k][1] * 1e3 for k in ("rccl_sendrecv", "rccl_allreduce", "ipc_push", "ipc_wait") if k in pa) / max(it_, 1),
+                                     "us_per_jacobi_iteration": sum(pa[k][1] * 1e3 for k in ("rccl_sendrecv", "rccl_allreduce", "ipc_push", "ipc_wait", "ipc_pack_push", "ipc_wait_unpack") if k in pa) / max(it_, 1),
                                      "note": "HIP-event brackets on rank 0's stream (they include the wait for the neighbour's message)"}
         except (ffi.SphError, RuntimeError) as e:
             rec["failed"] = str(e)[:300]
