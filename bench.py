@@ -749,6 +749,17 @@ def main():
     for r in (roofline, roofline_density):
         if r:
             r["timing"] = timing_note
+    if roofline_density:
+        # the 20 B charge is the harshest reading of a launch that fuses a3's predicate, a5's boundary lambda and a7's
+        # density (SURVEY 8d's whole-step ledger: density 20 + boundary-lambda 24 B); both figures, and the roof the sweep actually runs
+        # against -- VALU issue (0.40 of the HBM peak on 20 B is beyond it for any form that evaluates the predicate)
+        fused_b = 44
+        roofline_density["fused_ledger"] = {"algorithmic_bytes_per_particle": fused_b, "what": "a3 neighbour predicate + a5 boundary lambda (24 B) + a7 density (20 B): what this ONE launch does",
+                                            "achieved": roofline_density["achieved"] * fused_b / 20.0, "frac": roofline_density["frac"] * fused_b / 20.0}
+        vi = roofline_density.get("valu_issue") or {}
+        roofline_density["operative_roof"] = {"roof": "valu-issue", "frac": vi.get("frac"),
+                                              "note": "VALU instructions per wave x 3 clocks / the launch's shader clocks (committed SQ counters); the north_star target "
+                                                      "(0.40 of 8 TB/s on 20 B = 6.6 us) allows ~280 VALU instructions per wave, the exact predicate over 42 candidates alone is ~340"}
 
     out = {
         "metric": "particle-steps/sec (whole node), 2D dam-break N=1M DFSPH; 1/2/4/8 GPUs",
