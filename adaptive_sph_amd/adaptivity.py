@@ -184,14 +184,15 @@ def adapt_params(P: SimulationParams, dt: float) -> ffi.SphAdaptParams:
     return ap
 
 
-def find_partners_native(lib: ffi.SphLibrary, kind: str, size_class, mass, level, position, h2, offsets, indices, P: SimulationParams, dt: float):
-    """The same sequential loops as `_find_partners`, compiled (sph_host_find_partners): for million-particle scenes."""
+def find_partners_native(lib: ffi.SphLibrary, kind: str, size_class, mass, level, position, h2, offsets, indices, P: SimulationParams, dt: float, host=None):
+    """The same sequential loops as `_find_partners`, compiled (sph_host_find_partners): for million-particle scenes.  `host`
+    (ffi.HostBuffers): merge_partner / merge_counter land in persistent memory (views, overwritten by the next search)."""
     import ctypes as C
     n = len(mass)
     arrs = [np.ascontiguousarray(size_class, np.uint8), np.ascontiguousarray(mass, np.float32), np.ascontiguousarray(level, np.float32),
             np.ascontiguousarray(position, np.float32), np.ascontiguousarray(h2, np.float32), np.ascontiguousarray(offsets, np.uint32),
             np.ascontiguousarray(indices, np.uint32)]
-    mp, mc = np.empty(n, np.uint32), np.empty(n, np.uint16)
+    mp, mc = (np.empty(n, np.uint32), np.empty(n, np.uint16)) if host is None else (host.view("merge_partner", np.uint32, n), host.view("merge_counter", np.uint16, n))
     p, ap, tot = P.to_ffi(), adapt_params(P, dt), C.c_uint64(0)
     rc = lib.host_find_partners(0 if kind == "share" else 1, n, *[a.ctypes.data for a in arrs], C.byref(p), C.byref(ap), mp.ctypes.data, mc.ctypes.data,
                                 C.byref(tot))
@@ -210,6 +211,9 @@ class AdaptivityDriver:
     def __init__(self, ctx: ffi.Context, split_patterns: SplitPatterns = None, log=None):
         self.ctx = ctx
         self.log = log
+        self.host = ffi.HostBuffers()   # the exports land in the same host memory every step (round 6: the 26 ms "download" of configs[4]'s adaptive step were mostly page faults of fresh arrays)
+        if ctx.n:
+            self.host.reserve(ctx.n)
         if split_patterns is not None:
             ctx.set_split_patterns(split_patterns.patterns)
 
@@ -230,20 +234,21 @@ class AdaptivityDriver:
         # the reference would panic there).  The mirror keeps the assertion's MEANING: the sums are taken in f64.
         seq_sum = lambda a: float(np.sum(a, dtype=np.float64))   # noqa: E731
         t0 = _t.perf_counter()
-        total_mass1 = seq_sum(ctx.download("mass"))
-        off, idx = lists if lists is not None else ctx.download_neighbors()   # the lists single_step_without_adaptivity left behind (self.neighs)
+        host = self.host
+        total_mass1 = seq_sum(ctx.download("mass", host))
+        off, idx = lists if lists is not None else ctx.download_neighbors(host)   # the lists single_step_without_adaptivity left behind (self.neighs)
         tm["download"] += _t.perf_counter() - t0
 
         def decide(kind):
             t0 = _t.perf_counter()
             ctx.classify(p)
-            cls = ctx.download("particle_size_class")
-            fields = (cls, ctx.download("mass"), ctx.download("level_estimation"), ctx.download("position"), ctx.download("h2"))
+            cls = ctx.download("particle_size_class", host)
+            fields = (cls, ctx.download("mass", host), ctx.download("level_estimation", host), ctx.download("position", host), ctx.download("h2", host))
             t1 = _t.perf_counter()
             tm["download"] += t1 - t0
             try:
                 if getattr(ctx.lib, "host_find_partners", None) is not None:
-                    return find_partners_native(ctx.lib, kind, *fields, off, idx, P, dt)     # (validates like the reference does)
+                    return find_partners_native(ctx.lib, kind, *fields, off, idx, P, dt, host)     # (validates like the reference does)
                 mp, mc = _find_partners(kind, *fields, off, idx, P, dt)
                 validate_partners(kind, cls, mp, mc, off, idx)
                 return mp, mc
@@ -272,7 +277,7 @@ class AdaptivityDriver:
             n0 = ctx.n
             apply(lambda: (ctx.classify(p), ctx.split_particles(p, ap)))
             info["splits"] = ctx.n - n0
-        total_mass2 = seq_sum(ctx.download("mass"))
+        total_mass2 = seq_sum(ctx.download("mass", host))
         if not abs(total_mass1 - total_mass2) <= 0.005:             # assert_ft_approx_eq(total_mass1, total_mass2, 0.005, "mass sum")
             raise AssertionError(f"mass sum: {total_mass1} vs {total_mass2}")
         info["n_after"] = ctx.n

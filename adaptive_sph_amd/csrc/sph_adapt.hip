@@ -992,10 +992,21 @@ extern "C" int sph_host_find_partners(int kind, uint64_t n, const uint8_t* cls, 
             const float target = host_target_mass(level[i], p);     // dropped_mass_sharing (particle_sharing.rs:242-253)
             dropped = fminf(mass[i] - target, target * ap->max_mass_transfer_sharing * ap->dt);
         } else dropped = mass[i];                                   // dropped_mass_merging (particle_merging.rs:372-385)
+        // Two reorderings of the reference's filters that cannot change a decision (every filter is a pure test; nothing is written
+        // before all of them passed): (i) a donor that is already somebody's partner accepts nobody -- with counter[i] == 0 every
+        // candidate ends at the "this particle is itself somebody's partner" test below -- so its row is only bounds-checked; (ii) "the
+        // neighbour is somebody's partner already" is tested first: it reads one word where the others read five arrays at a random j.
+        // In configs[4]'s merging pass (3 M donors of 4 M particles) most rows and most candidates leave there.
+        if (partner[i] != SPH_MERGE_PARTNER_AVAILABLE) {
+            for (uint32_t q = off[i]; q < off[i + 1]; q++)
+                if (idx[q] >= n) return SPH_ERR_INVALID_ARGUMENT;
+            continue;
+        }
         for (uint32_t q = off[i]; q < off[i + 1]; q++) {
             const uint64_t j = idx[q];
             if (j == i) continue;
             if (j >= n) return SPH_ERR_INVALID_ARGUMENT;
+            if (partner[j] != SPH_MERGE_PARTNER_AVAILABLE) continue;   // the neighbour is somebody's partner already
             bool can;
             if (share) can = cls[j] == 1 || (cls[j] == 0 && ap->allow_share_with_too_small_particle) || (cls[j] == 2 && ap->allow_share_with_optimal_particle);
             else {
@@ -1011,11 +1022,7 @@ extern "C" int sph_host_find_partners(int kind, uint64_t n, const uint8_t* cls, 
             const float target_j = host_target_mass(level[j], p);
             if (new_mass_j >= target_j * 1.1f /* PARTICLE_SIZE_FACTOR_LARGE */) continue;
             if (new_mass_j > mass_base) continue;
-            if (partner[j] != SPH_MERGE_PARTNER_AVAILABLE) continue;   // the neighbour is somebody's partner already
-            if (counter[i] == 0) {
-                if (partner[i] != SPH_MERGE_PARTNER_AVAILABLE) continue;   // this particle is itself somebody's partner
-                partner[i] = SPH_MERGE_PARTNER_DELETE;
-            }
+            if (counter[i] == 0) partner[i] = SPH_MERGE_PARTNER_DELETE;   // (available: tested at the head of the row)
             partner[j] = (uint32_t)i;
             counter[i] += 1;
             total += 1;

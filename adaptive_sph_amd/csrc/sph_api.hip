@@ -693,7 +693,7 @@ extern "C" void sph_destroy(sph_ctx* c)
                      &c->flag_insufficient, &c->con_thr, &c->con_consumed, &c->con_h, &c->flag_reduced, &c->szc[0], &c->szc[1], &c->omega, &c->stash, &c->nl_ext, &c->nlx_ext, &c->nl_ok, &c->mrho, &c->pt0, &c->pt1, &c->prec0, &c->prec1, &c->xv, &c->rho, &c->lam_sum, &c->lam_grad, &c->wall_pl, &c->wall_cnt, &c->constf, &c->aii, &c->src, &c->p0, &c->p1, &c->pacc, &c->dens_err,
                      &c->stat, &c->ncount, &c->planes_d, &c->lam_lut, &c->dlam_lut, &c->hdr_partials, &c->hdr_out, &c->ctrl, &c->status,
                      &c->n_tiles, &c->red_partials, &c->scratch, &c->split_patterns, &c->akey[0], &c->akey[1], &c->aval[0], &c->aval[1], &c->acxy, &c->acell_start, &c->pm2,
-                     &c->atile_raw, &c->atile_h, &c->inc_head, &c->inc_next, &c->inc_bsum, &c->inc_movers};
+                     &c->atile_raw, &c->atile_h, &c->inc_head, &c->inc_next, &c->inc_bsum, &c->inc_movers, &c->export_d_off, &c->export_d_idx};
     for (auto b : all) b->release();
     if (c->hdr_host) (void)hipHostFree(c->hdr_host);
     if (c->ctrl_host) (void)hipHostFree(c->ctrl_host);
@@ -761,6 +761,8 @@ extern "C" int sph_upload(sph_ctx* c, uint64_t n, const float* mass, const float
     c->grid_valid = false;   // lists, cell indices and per-step outputs belong to the vector before this call
     if (c->ctrl_host) ((uint32_t*)(c->ctrl_host + 2))[1] = 0u;
     c->inc_count_valid = false;   // ... and so does the incremental sort's last mover count (advisor r4)
+    c->export_d_off.release();   // (the CSR export's device buffers: a host that re-uploads is not exporting every step)
+    c->export_d_idx.release();
     c->have_level = false;
     c->have_reduced = false;
     c->lists_after = false;
@@ -1413,7 +1415,10 @@ extern "C" int sph_download_neighbors(sph_ctx* c, uint32_t* offsets, uint32_t* i
     HIPCHK(c, hipSetDevice(c->device));
     const uint32_t n = (uint32_t)c->n;
     if (!c->grid_valid) return c->fail(SPH_ERR_INVALID_ARGUMENT, "no neighbour lists yet: run a step first");
-    std::vector<uint32_t> cnt(n), off((size_t)n + 1);
+    // (persistent host staging: two fresh 4 n-byte vectors per call were ~3 ms of page faults and zero-filling at 4 M particles)
+    std::vector<uint32_t>&cnt = c->export_cnt, &off = c->export_off;
+    if (cnt.size() < n) cnt.resize(n);
+    if (off.size() < (size_t)n + 1) off.resize((size_t)n + 1);
     int rc = SPH_OK;
     hipStream_t s = c->stream;
     if (c->dist.on) {
@@ -1496,7 +1501,7 @@ extern "C" int sph_download_neighbors(sph_ctx* c, uint32_t* offsets, uint32_t* i
     if (tot == 0) return SPH_OK;
     // The lists are those of the positions the last step STARTED from (NeighborhoodCache after a
     // step): pm[pcur ^ 1] still holds that sorted pre-step snapshot.
-    TmpBuf d_off, d_idx;
+    DevBuf &d_off = c->export_d_off, &d_idx = c->export_d_idx;   // (kept across calls: an adaptive host exports every step)
     HIPCHK(c, d_off.ensure(((size_t)n + 1) * 4));
     HIPCHK(c, d_idx.ensure((size_t)tot * 4));
     HIPCHK(c, hipMemcpyAsync(d_off.p, off.data(), ((size_t)n + 1) * 4, hipMemcpyHostToDevice, s));
@@ -1511,8 +1516,6 @@ extern "C" int sph_download_neighbors(sph_ctx* c, uint32_t* offsets, uint32_t* i
                            c->lists_after_k, (const uint32_t*)nullptr);
     HIPCHK(c, hipMemcpyAsync(indices, d_idx.p, (size_t)tot * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
-    d_off.release();
-    d_idx.release();
     return SPH_OK;
 }
 

@@ -101,6 +101,8 @@ struct sph_ctx {
     std::string err;
     Profiler prof;
     int exact = 0;
+    std::vector<uint32_t> export_cnt, export_off;   // sph_download_neighbors: host staging of the counts / offsets, kept across calls
+    DevBuf export_d_off, export_d_idx;              // ... and its device-side CSR (a 200 MB hipMalloc + hipFree per call otherwise); freed by sph_destroy and by sph_upload
 
     // persistent SoA (ping-pong across the per-step reorder)
     DevBuf pm[2], vel[2], orig[2], lvl[2], lvlold[2];

@@ -141,6 +141,80 @@ __global__ __launch_bounds__(256, 8) void k_sweep_a(Args A)
     A.pacc[i] = make_float4(Ri.x, Ri.y, ax, ay);
 }
 
+template <int THREADS, int WAVES>
+__global__ __launch_bounds__(THREADS, WAVES) void k_sweep_a_var(Args A)
+{
+    const uint32_t nblocks = (A.n + THREADS - 1) / THREADS;
+    const uint32_t blk = remap(nblocks);
+    if (blk >= nblocks) return;
+    const uint32_t i = blk * THREADS + threadIdx.x;
+    if (i >= A.n) return;
+    const float4 Ri = rec32(A.rec, i);
+    const uint2 g0 = A.nloff[i], g1 = A.nloff[(size_t)A.n + i], g2 = A.nloff[2 * (size_t)A.n + i];
+    const uint32_t cnt = A.nlh[i];
+    float ax = 0.f, ay = 0.f;
+    const uint32_t w[6] = {g0.x, g0.y, g1.x, g1.y, g2.x, g2.y};
+    float4 R[12];
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        R[2 * k] = rec32(A.rec, i + LO16(w[k]));
+        R[2 * k + 1] = rec32(A.rec, i + HI16(w[k]));
+    }
+#pragma unroll
+    for (int k = 0; k < 12; k++) A_SLOT(Ri, R[k], ax, ay)
+    for (uint32_t g = 3; g < 6; g++) {
+        if (!__any(cnt > 4u * g)) break;
+        const uint2 gg = cnt > 4u * g ? A.nloff[(size_t)g * A.n + i] : make_uint2(0u, 0u);
+        const float4 Ra = rec32(A.rec, i + LO16(gg.x)), Rb = rec32(A.rec, i + HI16(gg.x)), Rc = rec32(A.rec, i + LO16(gg.y)), Rd = rec32(A.rec, i + HI16(gg.y));
+        A_SLOT(Ri, Ra, ax, ay) A_SLOT(Ri, Rb, ax, ay) A_SLOT(Ri, Rc, ax, ay) A_SLOT(Ri, Rd, ax, ay)
+    }
+    A.pacc[i] = make_float4(Ri.x, Ri.y, ax, ay);
+}
+
+// VAR (round 6, section 2 of profiles/r6_variants.md: scheduling experiments on the product's form, same arithmetic and order):
+//   1 = odd waves of a SIMD sleep ~1000 clocks before their first load (break the lock-step of a batch's memory and compute phases)
+//   2 = s_setprio 3 while the head's loads and the twelve gathers are issued, 0 for the arithmetic
+//   3 = both;  THREADS = workgroup size (the XCD band remap works on workgroups), WAVES = waves per SIMD the kernel is compiled for
+template <int VAR, int THREADS, int WAVES>
+__global__ __launch_bounds__(THREADS, WAVES) void k_sweep_b_var(Args A)
+{
+    const uint32_t nblocks = (A.n + THREADS - 1) / THREADS;
+    const uint32_t blk = remap(nblocks);
+    if (blk >= nblocks) return;
+    const uint32_t i = blk * THREADS + threadIdx.x;
+    float err = 0.f;
+    if (VAR & 1) {
+        if ((threadIdx.x >> 6) & 1) __builtin_amdgcn_s_sleep(16);
+    }
+    if (i < A.n) {
+        if (VAR & 2) __builtin_amdgcn_s_setprio(3);
+        const float4 Ri = rec32(A.pacc, i);
+        const uint2 g0 = A.nloff[i], g1 = A.nloff[(size_t)A.n + i], g2 = A.nloff[2 * (size_t)A.n + i];
+        const uint32_t cnt = A.nlh[i];
+        const float rho_i = A.rho[i], mrho_i = A.mrho[i], aii_i = A.aii[i], src_i = A.src[i], pin_i = A.p_in[i];
+        float sum = 0.f;
+        const uint32_t w[6] = {g0.x, g0.y, g1.x, g1.y, g2.x, g2.y};
+        float4 R[12];
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            R[2 * k] = rec32(A.pacc, i + LO16(w[k]));
+            R[2 * k + 1] = rec32(A.pacc, i + HI16(w[k]));
+        }
+        if (VAR & 2) __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+        for (int k = 0; k < 12; k++) B_SLOT(Ri, R[k], sum)
+        for (uint32_t g = 3; g < 6; g++) {
+            if (!__any(cnt > 4u * g)) break;
+            const uint2 gg = cnt > 4u * g ? A.nloff[(size_t)g * A.n + i] : make_uint2(0u, 0u);
+            const float4 Ra = rec32(A.pacc, i + LO16(gg.x)), Rb = rec32(A.pacc, i + HI16(gg.x)), Rc = rec32(A.pacc, i + LO16(gg.y)), Rd = rec32(A.pacc, i + HI16(gg.y));
+            B_SLOT(Ri, Ra, sum) B_SLOT(Ri, Rb, sum) B_SLOT(Ri, Rc, sum) B_SLOT(Ri, Rd, sum)
+        }
+        err = finish_b(A, i, Ri, sum, rho_i, mrho_i, aii_i, src_i, pin_i);
+    }
+    err = wave_sum(err);
+    if ((threadIdx.x & 63) == 0) A.partials[blk * (THREADS / 64) + (threadIdx.x >> 6)] = err;
+}
+
 __global__ __launch_bounds__(256, 8) void k_sweep_b(Args A)
 {
     const uint32_t blk = remap(A.nblocks);
@@ -528,6 +602,60 @@ int main(int argc, char** argv)
         double ua = time_it([&]() { hipLaunchKernelGGL(k_sweep_a, dim3(grid2), dim3(256), 0, 0, A); });
         double ub = time_it([&]() { hipLaunchKernelGGL(k_sweep_b, dim3(grid2), dim3(256), 0, 0, A); });
         printf("| two launches (the product's form): sweep A %.2f + sweep B %.2f alone | %.2f | reference | - |\n", ua, ub, us);
+    }
+    {   // scheduling experiments on the product's two sweeps (pacc holds sweep A's output of the reference run): every form timed in
+        // THREE rounds, round-robin over the forms (no form always runs behind the same predecessor); min and median of the rounds
+        struct Form { const char* name; void (*k)(Args); int threads; bool is_b; std::vector<double> us; uint32_t diff; int regs; };
+        std::vector<Form> forms = {
+            {"sweep B, the product's form: 256 lanes, compiled for 8 waves per SIMD", k_sweep_b_var<0, 256, 8>, 256, true},
+            {"sweep B, odd waves sleep ~1000 clocks before their first load", k_sweep_b_var<1, 256, 8>, 256, true},
+            {"sweep B, s_setprio 3 while the loads are issued", k_sweep_b_var<2, 256, 8>, 256, true},
+            {"sweep B, 256 lanes, compiled for 6 waves", k_sweep_b_var<0, 256, 6>, 256, true},
+            {"sweep B, 256 lanes, compiled for 4 waves", k_sweep_b_var<0, 256, 4>, 256, true},
+            {"sweep B, 128 lanes, 8 waves", k_sweep_b_var<0, 128, 8>, 128, true},
+            {"sweep B, 128 lanes, 6 waves", k_sweep_b_var<0, 128, 6>, 128, true},
+            {"sweep B, 64 lanes, 8 waves", k_sweep_b_var<0, 64, 8>, 64, true},
+            {"sweep B, 64 lanes, 6 waves", k_sweep_b_var<0, 64, 6>, 64, true},
+            {"sweep B, 512 lanes, 8 waves", k_sweep_b_var<0, 512, 8>, 512, true},
+            {"sweep A, the product's form: 256 lanes, compiled for 8 waves per SIMD", k_sweep_a_var<256, 8>, 256, false},
+            {"sweep A, 256 lanes, compiled for 6 waves", k_sweep_a_var<256, 6>, 256, false},
+            {"sweep A, 256 lanes, compiled for 4 waves", k_sweep_a_var<256, 4>, 256, false},
+            {"sweep A, 128 lanes, 8 waves", k_sweep_a_var<128, 8>, 128, false},
+            {"sweep A, 128 lanes, 6 waves", k_sweep_a_var<128, 6>, 128, false},
+            {"sweep A, 64 lanes, 8 waves", k_sweep_a_var<64, 8>, 64, false},
+            {"sweep A, 64 lanes, 6 waves", k_sweep_a_var<64, 6>, 64, false},
+        };
+        std::vector<float4> ref_pa(n), out_pa(n);
+        hipLaunchKernelGGL(k_sweep_a, dim3(grid2), dim3(256), 0, 0, A);
+        CHECK(hipDeviceSynchronize());
+        CHECK(hipMemcpy(ref_pa.data(), A.pacc, (size_t)n * 16, hipMemcpyDeviceToHost));
+        for (int round = 0; round < 3; round++)
+            for (auto& f : forms) {
+                const uint32_t nb = (n + f.threads - 1) / f.threads, grid = ((nb + 7) / 8) * 8;
+                if (round == 0) {
+                    if (f.is_b) CHECK(hipMemset(A.p_out, 0, (size_t)n * 4));
+                    else CHECK(hipMemset(A.pacc, 0, (size_t)n * 16));
+                }
+                f.us.push_back(time_it([&]() { hipLaunchKernelGGL(f.k, dim3(grid), dim3(f.threads), 0, 0, A); }));
+                if (round == 0) {
+                    f.diff = 0;
+                    if (f.is_b) {
+                        CHECK(hipMemcpy(out.data(), A.p_out, (size_t)n * 4, hipMemcpyDeviceToHost));
+                        for (uint32_t s = 0; s < n; s++) f.diff += out[s] != ref[s];
+                    } else {
+                        CHECK(hipMemcpy(out_pa.data(), A.pacc, (size_t)n * 16, hipMemcpyDeviceToHost));
+                        for (uint32_t s = 0; s < n; s++) f.diff += out_pa[s].z != ref_pa[s].z || out_pa[s].w != ref_pa[s].w;
+                    }
+                    hipFuncAttributes fa{};
+                    (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(f.k));
+                    f.regs = fa.numRegs;
+                }
+            }
+        printf("| form (alone, %d launches back to back, three rounds round-robin) | VGPRs | us: min / median of the rounds | result |\n|---|---|---|---|\n", reps);
+        for (auto& f : forms) {
+            std::sort(f.us.begin(), f.us.end());
+            printf("| %s | %d | %.2f / %.2f | %s |\n", f.name, f.regs, f.us[0], f.us[1], f.diff == 0 ? "bit-identical" : "DIFFERENT");
+        }
     }
     auto run_fused = [&](const char* name, auto kernel, int TX, int TY, int threads) {
         A.tiles_x = (sx + TX - 1) / TX;
