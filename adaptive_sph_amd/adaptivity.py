@@ -226,7 +226,7 @@ class AdaptivityDriver:
         info = {"n_before": ctx.n, "shares": 0, "merges": 0, "splits": 0}
         # what the adaptive half of a step costs, by phase (bench.py reports it): device -> host of the lists and the five fields a
         # decision reads, the sequential partner searches on the host, the apply calls on the device
-        tm = info["seconds"] = {"download": 0.0, "host_decide": 0.0, "apply": 0.0}
+        tm = info["seconds"] = {"download": 0.0, "host_decide": 0.0, "apply": 0.0, "mass_check": 0.0}
         # particles.mass.iter().cloned().sum() (:2745, 2791) is a SEQUENTIAL f32 sum.  At the reference's own scene sizes (1e3..1e5
         # particles) that is accurate to ~1e-5 and the 0.005 bar means "mass is conserved".  At millions of particles it is not a
         # measurement any more: adding 1.8e-7 to a running total of 1.4 rounds to 1 or 2 ulp of the total every time (4M particles of
@@ -235,13 +235,18 @@ class AdaptivityDriver:
         seq_sum = lambda a: float(np.sum(a, dtype=np.float64))   # noqa: E731
         t0 = _t.perf_counter()
         host = self.host
-        total_mass1 = seq_sum(ctx.download("mass", host))
+        m1 = ctx.download("mass", host)
         off, idx = lists if lists is not None else ctx.download_neighbors(host)   # the lists single_step_without_adaptivity left behind (self.neighs)
-        tm["download"] += _t.perf_counter() - t0
+        t1 = _t.perf_counter()
+        tm["download"] += t1 - t0
+        total_mass1 = seq_sum(m1)   # (before the next download of the masses overwrites the persistent buffer)
+        tm["mass_check"] += _t.perf_counter() - t1
 
         def decide(kind):
-            t0 = _t.perf_counter()
+            ta = _t.perf_counter()
             ctx.classify(p)
+            t0 = _t.perf_counter()
+            tm["apply"] += t0 - ta   # (classify_particles on the device: the apply side's device work)
             cls = ctx.download("particle_size_class", host)
             fields = (cls, ctx.download("mass", host), ctx.download("level_estimation", host), ctx.download("position", host), ctx.download("h2", host))
             t1 = _t.perf_counter()
@@ -277,7 +282,12 @@ class AdaptivityDriver:
             n0 = ctx.n
             apply(lambda: (ctx.classify(p), ctx.split_particles(p, ap)))
             info["splits"] = ctx.n - n0
-        total_mass2 = seq_sum(ctx.download("mass", host))
+        t0 = _t.perf_counter()
+        m2 = ctx.download("mass", host)
+        t1 = _t.perf_counter()
+        tm["download"] += t1 - t0
+        total_mass2 = seq_sum(m2)
+        tm["mass_check"] += _t.perf_counter() - t1
         if not abs(total_mass1 - total_mass2) <= 0.005:             # assert_ft_approx_eq(total_mass1, total_mass2, 0.005, "mass sum")
             raise AssertionError(f"mass sum: {total_mass1} vs {total_mass2}")
         info["n_after"] = ctx.n

@@ -217,8 +217,9 @@ def adaptive_steps(plib, name, steps=2, warmup=2, **param_overrides):
         return {"workload": f"{name} WITH adaptivity: {desc}", "overrides": param_overrides, "particles": len(mass), "particles_after": int(ctx.n),
                 "steps": steps, "warmup": warmup, "ms_per_step": dt * 1e3 / steps, "step_path_ms_per_step": t_step * 1e3 / steps, "events": ev,
                 "adaptivity_breakdown_s_per_step": brk,
-                "note": "download = device -> host of the neighbour lists (CSR) and of the five fields a decision reads; host_decide = the "
-                        "reference's sequential partner searches, compiled, on ONE host core; apply = classify + share / merge / split on the device"}
+                "note": "download = device -> host of the neighbour lists (CSR), of the five fields a decision reads and of the masses the conservation check sums "
+                        "(into persistent host buffers since round 6: profiles/r6_export_time.txt); host_decide = the reference's sequential partner searches, compiled, "
+                        "on ONE host core; apply = classify + share / merge / split on the device; mass_check = the f64 sums of single_step_adaptivity's assertion (numpy)"}
     finally:
         ctx.close()
 
