@@ -45,7 +45,8 @@ ALGO_BYTES = {
 }
 
 
-# VALU instructions per wave of the sweeps (rocprofv3 --pmc SQ_INSTS_VALU / SQ_WAVES, profiles/r5q_sq_counters.txt: the round's last tree)
+# VALU instructions per wave of the sweeps (rocprofv3 --pmc SQ_INSTS_VALU / SQ_WAVES, profiles/r5q_sq_counters.txt; re-collected on round 6's
+# tree, profiles/r6p_sq_counters.txt: the same figures -- no sweep of the headline changed)
 # and the shader clock those launches ran at (SQ_BUSY_CYCLES / 32 / duration, profiles/r4_sq_counters.txt): what the `valu_issue` object
 # of a roofline entry is priced with
 VALU_ISSUE = {"density": 1527, "aii_nonpressure": 985, "source_term": 440, "pressure_accel": 306, "jacobi_update": 394}
@@ -201,6 +202,7 @@ def adaptive_steps(plib, name, steps=2, warmup=2, **param_overrides):
         p = P.to_ffi()
         for _ in range(warmup):
             ctx.step(p)
+        ctx.download_neighbors(drv.host)   # one untimed export: the library's device-side CSR buffers exist from here on, as a host's vectors do (steady state of an adaptive run)
         ev = {"shares": 0, "merges": 0, "splits": 0}
         brk, t_step = {}, 0.0
         t0 = time.perf_counter()
@@ -710,10 +712,10 @@ def main():
             waves_per_simd = (n_local / 64.0) / 1024.0
             clocks = avg_s * SHADER_CLOCK_HZ
             r["valu_issue"] = {"valu_instructions_per_wave": issue, "clocks_per_instruction": 3.0, "shader_clock_GHz": SHADER_CLOCK_HZ / 1e9,
-                               "frac": issue * waves_per_simd * 3.0 / clocks, "source": "profiles/r5q_sq_counters.txt (SQ_INSTS_VALU / SQ_WAVES), profiles/r3_valu_issue.md"}
+                               "frac": issue * waves_per_simd * 3.0 / clocks, "source": "profiles/r6p_sq_counters.txt = r5q_sq_counters.txt (SQ_INSTS_VALU / SQ_WAVES), profiles/r3_valu_issue.md"}
             r["valu_issue"]["measured_in_this_run"] = False
         if name in WAVE_STATE:
-            r["wave_state"] = dict(WAVE_STATE[name], measured_in_this_run=False, source="profiles/r5q_sq_counters.txt (SQ_WAIT_ANY, SQ_WAIT_INST_ANY, SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES; TCP_TCC_READ_REQ_LATENCY / TCP_TCC_READ_REQ; TCC_HIT / TCC_REQ)")
+            r["wave_state"] = dict(WAVE_STATE[name], measured_in_this_run=False, source="profiles/r5q_sq_counters.txt, re-collected as r6p_sq_counters.txt (SQ_WAIT_ANY, SQ_WAIT_INST_ANY, SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES; TCP_TCC_READ_REQ_LATENCY / TCP_TCC_READ_REQ; TCC_HIT / TCC_REQ)")
         if os.environ.get("SPH_HIP_LIBRARY"):   # another build than the shipped one: the committed counters are not its counters
             for key in ("bound_evidence", "valu_issue", "wave_state", "traffic", "traffic_source", "traffic_GBs", "rocprofv3_avg_us_committed", "avg_us_vs_rocprofv3_committed"):
                 r.pop(key, None)
