@@ -304,3 +304,42 @@ def test_assemble_lists_of_the_ranks_in_global_index_order():
     assert off_g[0] == 0 and off_g[-1] == sum(len(t) for t in truth)
     for i in range(n):
         assert np.array_equal(idx_g[off_g[i]:off_g[i + 1]], truth[i]), i
+
+
+def test_host_buffers_are_reused_and_grow():
+    """ffi.HostBuffers (round 6): an export lands in the same, already touched host memory every step; a request that does not fit gets a
+    larger buffer; views of different keys never alias."""
+    from adaptive_sph_amd import ffi
+    hb = ffi.HostBuffers()
+    a = hb.view("field:mass", np.float32, 1000)
+    a[:] = 7.0
+    b = hb.view("field:mass", np.float32, 900)
+    assert b.ctypes.data == a.ctypes.data and b.shape == (900,) and (b == 7.0).all()          # the same memory, nothing reallocated
+    c = hb.view("csr:indices", np.uint32, 1000)
+    assert c.ctypes.data != a.ctypes.data and (c == 0).all()                                 # another key, zero-filled (= touched)
+    assert hb.capacity("field:mass", np.float32) >= 1000
+    big = hb.view("field:mass", np.float32, 100000)                                          # does not fit: a new, larger buffer
+    assert big.shape == (100000,) and hb.capacity("field:mass", np.float32) >= 100000
+    hb2 = ffi.HostBuffers()
+    hb2.reserve(1234)
+    assert hb2.capacity("csr:indices", np.uint32) >= 16 * 1234 and hb2.capacity("field:position", np.float32) >= 2 * 1234
+    assert hb2.capacity("merge_counter", np.uint16) >= 1234
+
+
+def test_bench_picks_the_newest_committed_summary_by_parsed_round(tmp_path, monkeypatch):
+    """bench.py's `bound` / `traffic` come from the newest committed profiles/ summary: 'r10' is newer than 'r5q' although it sorts in
+    front of it (advisor r5), 'r6p' newer than 'r6', a suffix newer than none."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_for_test", REPO / "bench.py")
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    (tmp_path / "profiles").mkdir()
+    for name in ("r5q_kernel_summary.json", "r10_kernel_summary.json", "r6_kernel_summary.json", "r6p_kernel_summary.json", "r9z_dam_break_8m_kernel_summary.json",
+                 "r2a_level_1m_kernel_summary.json"):
+        (tmp_path / "profiles" / name).write_text("{}")
+    monkeypatch.setattr(bench, "REPO", tmp_path)
+    assert bench.newest_summary("*_kernel_summary.json", r"r(\d+)([a-z]?)_kernel_summary\.json").name == "r10_kernel_summary.json"
+    (tmp_path / "profiles" / "r10_kernel_summary.json").unlink()
+    assert bench.newest_summary("*_kernel_summary.json", r"r(\d+)([a-z]?)_kernel_summary\.json").name == "r6p_kernel_summary.json"
+    assert bench.newest_summary("*_dam_break_8m_kernel_summary.json", r"r(\d+)([a-z]?)_dam_break_8m_kernel_summary\.json").name == "r9z_dam_break_8m_kernel_summary.json"
+    assert bench.newest_summary("*_nothing.json", r"r(\d+)([a-z]?)_nothing\.json") is None
