@@ -52,8 +52,11 @@ def main():
         assert np.array_equal(np.sort(ids), np.arange(n)), "particles lost or duplicated"
         for q in parts:
             assert q[1] == parts[0][1], "ranks disagree on dt / iteration counts"
-        assert all(abs(a[0] - b[0]) <= 1e-5 * b[0] and abs(a[1] - b[1]) <= 1 and abs(a[2] - b[2]) <= 1 for a, b in zip(parts[0][1], ref_its)), (parts[0][1], ref_its)
-        for f, tol in (("position", 1e-5), ("velocity", 1e-3), ("density", 1e-4)):
+        # MP_SOAK (scripts/mp_ipc_soak.sh: hundreds of free-running steps): slabs and single context are two correct evaluations of a chaotic
+        # scene and part ways after ~75 steps -- the soak keeps the exact checks (nothing lost, the ranks agree, BIT FOR BIT the loopback group)
+        soak = bool(os.environ.get("MP_SOAK"))
+        assert soak or all(abs(a[0] - b[0]) <= 1e-5 * b[0] and abs(a[1] - b[1]) <= 1 and abs(a[2] - b[2]) <= 1 for a, b in zip(parts[0][1], ref_its)), (parts[0][1][:20], ref_its[:20])
+        for f, tol in (() if soak else (("position", 1e-5), ("velocity", 1e-3), ("density", 1e-4))):
             got = np.zeros_like(single.download(f))
             for q in parts:
                 got[q[0]["particle_id"]] = q[0][f]
@@ -63,7 +66,7 @@ def main():
         cnt = np.zeros(n, np.uint32)
         for q in parts:
             cnt[q[0]["particle_id"]] = q[0]["neighbor_count"]
-        assert (cnt != single.download("neighbor_count")).mean() < 1e-3
+        assert soak or (cnt != single.download("neighbor_count")).mean() < 1e-3
         assert all(q[2]["exchanges"] > 0 and q[2]["bytes_sent"] > 0 for q in parts), [q[2] for q in parts]
         assert min(len(q[0]["particle_id"]) for q in parts) > 0 and len({len(q[0]["particle_id"]) for q in parts}) > 1     # particles migrated
         # ... and BIT FOR BIT the loopback group's result (the same slabs as contexts of one process: the verification form of the
