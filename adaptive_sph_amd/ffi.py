@@ -414,7 +414,7 @@ class Context:
         cap = max(host.capacity("csr:indices", np.uint32), 16 * n)
         indices = host.view("csr:indices", np.uint32, cap)
         rc = self.lib.download_neighbors(self.handle, offsets.ctypes.data, indices.ctypes.data, indices.size, C.byref(total))
-        if rc != 0 and int(total.value) > cap:   # the lists outgrew the buffer: the total is known now
+        if rc != 0 and int(total.value) > indices.size:   # the lists outgrew the buffer: the total is known now
             indices = host.view("csr:indices", np.uint32, int(total.value) + int(total.value) // 8)
             rc = self.lib.download_neighbors(self.handle, offsets.ctypes.data, indices.ctypes.data, indices.size, C.byref(total))
         self._check(rc)

@@ -548,3 +548,37 @@ def test_config4_adaptive_steps_with_the_oracles_decisions_on_eight_slabs(produc
     sg, so = ffi.group_step(grp, p), o.step(p)                # and both edited vectors step
     assert abs(sg[0].dt - so.dt) <= 1e-4 * so.dt
     assert rel_err(D.gather_by_id(grp, "density", o.n), o.download("density")) < 2e-3
+
+
+def test_exports_into_persistent_host_buffers_are_the_fresh_exports(product_lib):
+    """Round 6 (profiles/r6_export_time.txt): the adaptive driver exports into persistent host buffers (ffi.HostBuffers) with ONE library
+    call for the lists -- same offsets, indices and fields as the two-call export into fresh arrays, before and after the particle count
+    changed, and a list that outgrew its buffer is fetched with a second call."""
+    from adaptive_sph_amd.workloads import default_params
+    scn = sc.dam_break_small(96, 64, 1.0 / 64)
+    pos, mass, vel = sc.init_particles(scn)
+    P = default_params(merging=False, sharing=False, splitting=False, level_estimation_method="None")
+    g = ffi.Context(product_lib, 2 * len(mass), sc.boundary_planes(scn.boundary))
+    g.upload(mass, pos, vel)
+    p = P.to_ffi()
+    host = ffi.HostBuffers()
+    for n_now in (len(mass), len(mass) // 2):
+        if n_now != len(mass):
+            g.upload(mass[:n_now], pos[:n_now], vel[:n_now])     # the vector shrank: the same buffers, shorter views
+        g.step(p)
+        off0, idx0 = g.download_neighbors()
+        off1, idx1 = g.download_neighbors(host)
+        assert np.array_equal(off0, off1) and np.array_equal(idx0, idx1) and len(idx1) == int(off1[-1])
+        off2, idx2 = g.download_neighbors(host)                  # again: the library's own staging is kept across calls
+        assert off2.ctypes.data == off1.ctypes.data and np.array_equal(idx0, idx2)
+        for f in ("mass", "position", "h2", "density", "neighbor_count"):
+            a, b = g.download(f), g.download(f, host)
+            assert a.dtype == b.dtype and a.shape == b.shape and np.array_equal(a, b), f
+    # a buffer that is too small: the call reports the total, the wrapper grows the buffer and asks again
+    tiny = ffi.HostBuffers()
+    tiny._bufs["csr:indices"] = np.zeros(64, np.uint8)
+    real_view = tiny.view
+    tiny.view = lambda key, dt, count: real_view(key, dt, 16 if key == "csr:indices" and count >= 16 * g.n else count)   # (defeat the 16 n default once)
+    off3, idx3 = g.download_neighbors(tiny)
+    assert np.array_equal(off3, off0) and np.array_equal(idx3, idx0)
+    g.close()
